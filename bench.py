@@ -1,0 +1,242 @@
+#!/usr/bin/env python3
+"""Headline benchmark: training snapshots/sec of gatres_small on C-Town-shaped batches (BASELINE.json).
+
+One "step" = one full reference training iteration (train.py:159-190) on one batch of `--batch-size` snapshots per
+GPU: device mask sampling -> x[mask]=0 -> forward -> MSE on masked nodes -> backward -> [RCCL all-reduce] -> Adam,
+replayed from a hipGraph.  Inputs (several batches, rotated) are resident in HBM before the timed region.
+
+  python bench.py --gpus 1 --steps 200 --warmup 20
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+         bench.py --gpus N --steps K --warmup W
+
+Rank 0 prints ONE JSON line.  Data: synthetic (seeded WDN topology with C-Town's size, N(0,1) pressures,
+PyG-style random-init weights); the reference's C-Town files are not shipped.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
+
+MODELS = {"gatres_small": (15, 32), "gatres_large": (25, 128)}     # ConfigModels.py:22-42
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--model", default="gatres_small", choices=sorted(MODELS))
+    ap.add_argument("--batch-size", type=int, default=32, help="snapshots per GPU per step")
+    ap.add_argument("--nodes", type=int, default=388)
+    ap.add_argument("--pipes", type=int, default=430)
+    ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--no-roofline", action="store_true")
+    return ap.parse_args()
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# per-kernel timing (HIP events on the launch stream) and algorithmic bytes -- DESIGN.md section 4
+# ------------------------------------------------------------------------------------------------------------------
+def kernel_table(G, model, plan, nc):
+    """[(name, calls_per_step, algorithmic_bytes_per_launch, launcher)] for the kernels of one training step."""
+    import ctypes as C
+    lib = G._native.load()
+    N, Eg, E = plan.num_nodes, plan.num_edges_gat, plan.num_edges_mean
+    nb = model.num_blocks
+    dev = plan.device
+    f = lambda *s: torch.randn(*s, dtype=torch.float32, device=dev)
+    st = lambda: G._native.current_stream(dev)
+    S = int(lib.gatres_num_slabs(model._cmodel_ref(), N))
+    rows = []
+
+    def conv(tag, K, H):
+        HC = H * nc
+        x, W, Wt = f(N, K), f(HC, K), f(K, HC)
+        att_s, att_d, bias = f(HC), f(HC), f(HC)
+        h, a_s, a_d = f(N, HC), f(N, H), f(N, H)
+        out, alpha = f(N, HC), torch.rand(Eg, H, device=dev)
+        g_out, g_e, g_ad, g_as, g_h, g_x = f(N, HC), f(Eg, H), f(N, H), f(N, H), f(N, HC), f(N, K)
+        slab = torch.empty(S * (HC * K + 3 * HC), device=dev)
+        gp = plan.ref()
+        idx = 4 * (N + 1) + 4 * Eg
+        rows.append((f"proj_attn_fwd[{tag}]", nb, 4 * (N * K + HC * K + 2 * HC + N * HC + 2 * N * H),
+                     lambda: lib.gatres_proj_attn_fwd(x.data_ptr(), W.data_ptr(), att_s.data_ptr(), att_d.data_ptr(),
+                                                      h.data_ptr(), a_s.data_ptr(), a_d.data_ptr(), N, K, H, nc, st())))
+        rows.append((f"gat_aggregate_fwd[{tag}]", nb,
+                     idx + 4 * (Eg * H + N * H + Eg * HC + HC + N * HC + Eg * H),
+                     lambda: lib.gatres_gat_aggregate_fwd(gp, h.data_ptr(), a_s.data_ptr(), a_d.data_ptr(),
+                                                          bias.data_ptr(), out.data_ptr(), alpha.data_ptr(), H, nc, 1,
+                                                          st())))
+        rows.append((f"gat_aggregate_bwd_dst[{tag}]", nb,
+                     idx + 4 * (N * HC + Eg * HC + Eg * H + Eg * H + N * H + Eg * H + N * H),
+                     lambda: lib.gatres_gat_aggregate_bwd_dst(gp, g_out.data_ptr(), h.data_ptr(), alpha.data_ptr(),
+                                                              a_s.data_ptr(), a_d.data_ptr(), g_e.data_ptr(),
+                                                              g_ad.data_ptr(), H, nc, st())))
+        rows.append((f"gat_aggregate_bwd_src[{tag}]", nb,
+                     4 * (N + 1) + 8 * Eg + 4 * (Eg * HC + 2 * Eg * H + N * H + 2 * HC + N * HC + N * H),
+                     lambda: lib.gatres_gat_aggregate_bwd_src(gp, g_out.data_ptr(), alpha.data_ptr(), g_e.data_ptr(),
+                                                              g_ad.data_ptr(), att_s.data_ptr(), att_d.data_ptr(),
+                                                              g_h.data_ptr(), g_as.data_ptr(), H, nc, st())))
+        rows.append((f"proj_bwd_dx[{tag}]", nb, 4 * (N * HC + HC * K + 3 * N * K),
+                     lambda: lib.gatres_proj_bwd_dx(g_h.data_ptr(), Wt.data_ptr(), g_x.data_ptr(), x.data_ptr(),
+                                                    g_x.data_ptr(), N, K, HC, st())))
+        rows.append((f"proj_bwd_dw[{tag}]", nb, 4 * (N * HC + N * K + S * HC * K),
+                     lambda: lib.gatres_proj_bwd_dw(g_h.data_ptr(), x.data_ptr(), slab.data_ptr(), S, HC * K + 3 * HC,
+                                                    N, K, HC, st())))
+        rows.append((f"conv_param_grads[{tag}]", nb, 4 * (2 * N * HC + 2 * N * H + 3 * S * HC),
+                     lambda: lib.gatres_conv_param_grads(h.data_ptr(), g_as.data_ptr(), g_ad.data_ptr(),
+                                                         g_out.data_ptr(), slab.data_ptr(), slab.data_ptr() + 4 * HC,
+                                                         slab.data_ptr() + 8 * HC, S, HC * K + 3 * HC, N, H, nc, st())))
+
+    conv("conv1", nc, 2)
+    conv("conv2", 2 * nc, 1)
+    y, x0, o = f(N, nc), f(N, nc), f(N, nc)
+    gp = plan.ref()
+    rows.append(("mean_residual_relu_fwd", nb, 4 * (N + 1) + 4 * E + 4 * (E * nc + 2 * N * nc),
+                 lambda: lib.gatres_mean_residual_relu_fwd(gp, y.data_ptr(), x0.data_ptr(), o.data_ptr(), nc, st())))
+    rows.append(("mean_bwd", nb, 8 * (N + 1) + 4 * E + 4 * (E * nc + N * nc),
+                 lambda: lib.gatres_mean_bwd(gp, y.data_ptr(), o.data_ptr(), nc, st())))
+    return rows
+
+
+def time_kernels(rows, device, reps=200):
+    out = []
+    for name, calls, nbytes, fn in rows:
+        for _ in range(10):
+            rc = fn()
+            assert rc == 0, (name, rc)
+        torch.cuda.synchronize(device)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(torch.cuda.current_stream(device))
+        for _ in range(reps):
+            fn()
+        e1.record(torch.cuda.current_stream(device))
+        e1.synchronize()
+        us = e0.elapsed_time(e1) * 1e3 / reps
+        out.append(dict(kernel=name, calls_per_step=calls, avg_us=us, algorithmic_bytes=nbytes,
+                        gbs=nbytes / us * 1e-3))
+    return out
+
+
+def cpu_baseline(args, nb, nc):
+    """The oracle (a torch-CPU restatement of the PyG path; PyG itself is not installable here) timed on the host
+    cores for the same step on the same batch shape."""
+    from oracle import gatres_oracle as O
+    import gnn_pressure_estimation_amd as G
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    x, y, ei, mask = G.wdn_synth.make_batch(args.batch_size, args.nodes, args.pipes)
+    tr = O.OracleTrainer(O.init_params(nb, nc, seed=3))
+    tr.step(x, y, ei, mask)                           # warm-up (thread pool, autograd graph)
+    t0, n = time.perf_counter(), 0
+    while n < 3 or (time.perf_counter() - t0 < args.cpu_seconds and n < 50):
+        tr.step(x, y, ei, mask)
+        n += 1
+    dt = time.perf_counter() - t0
+    return dict(value=args.batch_size * n / dt, unit="snapshots/s", cores=cores, kind="port",
+                sample=f"{n} full training steps (mask->fwd->MSE->bwd->Adam) of {args.model} on one "
+                       f"bs={args.batch_size} batch after 1 warm-up, torch {torch.__version__} CPU ops, "
+                       f"{cores} threads")
+
+
+def main():
+    args = parse()
+    nb, nc = MODELS[args.model]
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if args.gpus != world and rank == 0 and world > 1:
+        print(f"warning: --gpus {args.gpus} but WORLD_SIZE {world}", file=sys.stderr)
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the HIP engine has no CPU path")
+    device = torch.device("cuda", local_rank)
+    torch.cuda.set_device(device)
+    if world > 1:
+        torch.distributed.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+
+    import gnn_pressure_estimation_amd as G
+    torch.manual_seed(3)                                   # identical replicas on every rank
+    model = G.GATResMeanConv(name=args.model, num_blocks=nb, nc=nc).to(device)
+    N = args.nodes * args.batch_size
+    topo = G.wdn_synth.make_wdn_topology(args.nodes, args.pipes, seed=0)
+    ei = G.wdn_synth.collate_edge_index(topo, args.nodes, args.batch_size).to(device)
+    trainer = G.GATResTrainer(model, ei, N, nodes_per_graph=[args.nodes] * args.batch_size, seed=1000 + rank,
+                              use_graph=not args.no_graph)
+    nbatches = 8
+    snaps = G.wdn_synth.make_snapshots(nbatches * args.batch_size, args.nodes, seed=100 + rank).to(device)
+    batches = [snaps[i * args.batch_size:(i + 1) * args.batch_size].reshape(-1).contiguous() for i in range(nbatches)]
+
+    def one_step(i):
+        b = batches[i % nbatches]
+        trainer.load_batch(b, b)
+        trainer.run_step(device_mask=True)
+
+    for i in range(args.warmup):
+        one_step(i)
+    torch.cuda.synchronize(device)
+    if world > 1:
+        torch.distributed.barrier()
+    torch.cuda.synchronize(device)
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        one_step(i)
+    torch.cuda.synchronize(device)
+    if world > 1:
+        torch.distributed.barrier()
+    torch.cuda.synchronize(device)
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=device)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = float(t.item())
+    loss = float(trainer.loss.item())
+    if not (loss == loss) or loss > 1e6:
+        raise SystemExit(f"training diverged (loss={loss})")
+
+    result = {
+        "metric": "train snapshots/sec", "value": world * args.batch_size * args.steps / dt, "unit": "snapshots/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"{args.model} ({nb} blocks, nc={nc}), C-Town-sized WDN ({args.nodes} nodes, "
+                               f"{2 * args.pipes} directed edges), batch_size={args.batch_size} per GPU, fp32, "
+                               f"full training step (device mask 0.95 -> fwd -> masked MSE -> bwd -> Adam), "
+                               f"{'eager launches' if args.no_graph else 'hipGraph replay'}",
+                   "global_batch": world * args.batch_size, "parallelism": f"dp{world}",
+                   "final_loss": loss},
+    }
+
+    if rank == 0 and not args.no_roofline:
+        rows = time_kernels(kernel_table(G, model, trainer.plan, nc), device)
+        for r in rows:
+            r["step_share_us"] = r["avg_us"] * r["calls_per_step"]
+        dom = max(rows, key=lambda r: r["step_share_us"])
+        result["roofline"] = {"bound": "hbm", "kernel": dom["kernel"], "achieved": dom["gbs"], "peak": HBM_PEAK_GBS,
+                              "unit": "GB/s", "frac": dom["gbs"] / HBM_PEAK_GBS, "traffic": None,
+                              "avg_launch_us": dom["avg_us"], "algorithmic_bytes_per_launch": dom["algorithmic_bytes"]}
+        result["kernels"] = [{k: (round(v, 3) if isinstance(v, float) else v) for k, v in r.items()} for r in rows]
+        result["kernel_time_sum_us_per_step"] = round(sum(r["step_share_us"] for r in rows), 1)
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        result["cpu_baseline"] = cpu_baseline(args, nb, nc)
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(result))
+
+
+if __name__ == "__main__":
+    main()

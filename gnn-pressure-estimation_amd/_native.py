@@ -1,0 +1,122 @@
+"""ctypes binding of include/gatres.h (lib/libgatres_hip.so).
+
+There is NO CPU fallback: if the library is missing it is built with hipcc, and if that fails or a kernel
+launch fails the caller gets a RuntimeError.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+import torch
+
+from . import _build
+
+_LIB: Optional[C.CDLL] = None
+
+ERRORS = {-1: "GATRES_E_BADARG (null/misaligned pointer or bad size)",
+          -2: "GATRES_E_UNSUPPORTED (width not supported: nc must be a power of two in [4, 128])",
+          -3: "GATRES_E_GRAPH (edge endpoint out of range)"}
+
+
+class GatresGraph(C.Structure):
+    """gatres_graph_t"""
+    _fields_ = [("num_nodes", C.c_int32), ("num_edges_gat", C.c_int32), ("num_edges_mean", C.c_int32),
+                ("reserved", C.c_int32),
+                ("rowptr", C.c_void_p), ("col", C.c_void_p), ("t_rowptr", C.c_void_p), ("t_eid", C.c_void_p),
+                ("t_dst", C.c_void_p), ("m_rowptr", C.c_void_p), ("m_col", C.c_void_p), ("mt_rowptr", C.c_void_p),
+                ("mt_dst", C.c_void_p)]
+
+
+class GatresModel(C.Structure):
+    """gatres_model_t"""
+    _fields_ = [("num_blocks", C.c_int32), ("nc", C.c_int32)]
+
+
+_P = C.c_void_p
+_I32, _I64, _U64, _F32, _F64 = C.c_int32, C.c_int64, C.c_uint64, C.c_float, C.c_double
+_GP, _MP = C.POINTER(GatresGraph), C.POINTER(GatresModel)
+
+# name -> (restype, argtypes): must list every symbol include/gatres.h declares
+SIGNATURES = {
+    "gatres_graph_count_host": (C.c_int, [_P, _I64, _I64, C.POINTER(_I64)]),
+    "gatres_graph_build_host": (C.c_int, [_P, _I64, _I64] + [_P] * 9),
+    "gatres_edge_index_hash": (C.c_int, [_P, _I64, _P, _P]),
+    "gatres_lin0_fwd": (C.c_int, [_P, _P, _P, _P, _P, _I32, _I32, _P]),
+    "gatres_proj_attn_fwd": (C.c_int, [_P] * 7 + [_I32] * 4 + [_P]),
+    "gatres_gat_aggregate_fwd": (C.c_int, [_GP] + [_P] * 6 + [_I32] * 3 + [_P]),
+    "gatres_mean_residual_relu_fwd": (C.c_int, [_GP, _P, _P, _P, _I32, _P]),
+    "gatres_lin1_fwd": (C.c_int, [_P, _P, _P, _P, _I32, _I32, _P]),
+    "gatres_reduce_slabs": (C.c_int, [_P, _I32, _I64, _I64, _P, _P]),
+    "gatres_lin1_bwd": (C.c_int, [_P] * 6 + [_I32, _I64, _I32, _I32, _I32, _P]),
+    "gatres_mean_bwd": (C.c_int, [_GP, _P, _P, _I32, _P]),
+    "gatres_gat_aggregate_bwd_dst": (C.c_int, [_GP] + [_P] * 7 + [_I32, _I32, _P]),
+    "gatres_gat_aggregate_bwd_src": (C.c_int, [_GP] + [_P] * 8 + [_I32, _I32, _P]),
+    "gatres_proj_bwd_dx": (C.c_int, [_P] * 5 + [_I32] * 3 + [_P]),
+    "gatres_proj_bwd_dw": (C.c_int, [_P] * 3 + [_I32, _I64, _I32, _I32, _I32, _P]),
+    "gatres_conv_param_grads": (C.c_int, [_P] * 7 + [_I32, _I64, _I32, _I32, _I32, _P]),
+    "gatres_lin0_bwd": (C.c_int, [_P] * 5 + [_I32, _I64, _I32, _I32, _P]),
+    "gatres_transpose_conv_weights": (C.c_int, [_P, _P, _I32, _I32, _P]),
+    "gatres_mask_generate": (C.c_int, [_P, _I32, _F64, _U64, _P, _P, _P]),
+    "gatres_masked_mse": (C.c_int, [_P] * 5 + [_I32, _P]),
+    "gatres_adam_step": (C.c_int, [_P] * 5 + [_I64] + [_F64] * 5 + [_F32, _P]),
+    "gatres_param_count": (_I64, [_I32, _I32]),
+    "gatres_saved_floats": (_I64, [_MP, _I32, _I32]),
+    "gatres_scratch_floats": (_I64, [_MP, _I32, _I32]),
+    "gatres_num_slabs": (_I32, [_MP, _I32]),
+    "gatres_model_forward": (C.c_int, [_MP, _GP] + [_P] * 6 + [_P]),
+    "gatres_model_backward": (C.c_int, [_MP, _GP] + [_P] * 8 + [_P]),
+    "gatres_train_step": (C.c_int, [_P, _P]),
+    "gatres_version": (C.c_char_p, []),
+}
+
+
+def lib_path() -> str:
+    return _build.LIB_PATH
+
+
+def load(build_if_missing: bool = True) -> C.CDLL:
+    """dlopen the library (building it first when absent) and attach the C signatures."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    path = lib_path()
+    if not os.path.exists(path):
+        if not build_if_missing:
+            raise RuntimeError(f"{path} is missing; run `python __graft_entry__.py` (build()) first")
+        _build.build_native()
+    lib = C.CDLL(path)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)     # AttributeError here == the library does not export the header's symbol
+        fn.restype = res
+        fn.argtypes = args
+    _LIB = lib
+    return lib
+
+
+def check(rc: int, what: str) -> None:
+    if rc == 0:
+        return
+    if rc < 0:
+        raise RuntimeError(f"{what}: {ERRORS.get(rc, rc)}")
+    raise RuntimeError(f"{what}: HIP error {rc}")
+
+
+def ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def current_stream(device) -> int:
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+def require_gpu_tensor(t: torch.Tensor, name: str, dtype=torch.float32) -> None:
+    if not isinstance(t, torch.Tensor):
+        raise ValueError(f"{name} must be a torch.Tensor")
+    if not t.is_cuda:
+        raise ValueError(f"{name} must live on a ROCm device (got {t.device}); this engine has no CPU path")
+    if t.dtype != dtype:
+        raise ValueError(f"{name} must be {dtype} (got {t.dtype})")
+    if not t.is_contiguous():
+        raise ValueError(f"{name} must be contiguous")

@@ -1,0 +1,29 @@
+// Shared device/host helpers for the gfx950 GATRes kernels.  Compiled with -ffp-contract=off: every
+// multiply-add below rounds twice unless written as fmaf(), which keeps the sparse sums in the same
+// association as the reference's index_add_/scatter path.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "gatres.h"
+
+#define GATRES_NEG_SLOPE 0.2f        // GATConv default negative_slope
+#define GATRES_SOFTMAX_EPS 1e-16f    // torch_geometric.utils.softmax: out_sum + 1e-16
+#define GATRES_WAVE 64
+
+static inline int gatres_launch_status() { return (int)hipGetLastError(); }
+static inline hipStream_t gatres_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
+static inline bool gatres_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+static inline bool gatres_is_pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
+
+// lanes that cooperate on one feature row: one float4 per lane, rounded up to a power of two
+static inline int gatres_row_lanes(int width) {
+  int need = (width + 3) / 4, g = 1;
+  while (g < need) g <<= 1;
+  return g;
+}
+
+__device__ __forceinline__ float gatres_leaky(float v) { return v > 0.f ? v : v * GATRES_NEG_SLOPE; }
+
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+__device__ __forceinline__ float4 f4zero() { return make_float4(0.f, 0.f, 0.f, 0.f); }

@@ -1,0 +1,344 @@
+// Sparse message-passing kernels for gfx950 (wave64): GATConv edge scoring + per-destination softmax +
+// weighted neighbour sum (K2) and SimpleConv mean + residual + ReLU (K3), forward and backward.
+//
+// Layout: feature rows are row-major fp32; a row of width HC is owned by G = HC/4 adjacent lanes, one float4
+// per lane, so a neighbour-row gather is one 16-B load per lane and G*16 contiguous bytes per row.  A wave holds
+// 64/G destination rows.  WDN graphs have in-degree ~2-5, so the reduction over a row's edges is sequential per
+// lane in CSR order (= the order PyG's scatter visits them: original edges first, self loop last); there are no
+// atomics anywhere and results are bitwise reproducible.
+//
+// Reference semantics restated (torch_geometric >= 2.3, call sites GraphModels.py:464-466):
+//   s_e   = LeakyReLU_0.2(a_src[j] + a_dst[i])                 GATConv.edge_update
+//   m_i   = max_e s_e;  p_e = exp(s_e - m_i);  Z_i = sum p_e + 1e-16;  alpha_e = p_e / Z_i     utils.softmax
+//   out_i = sum_e alpha_e * h[j] + bias                        GATConv.message / aggregate(sum) / bias
+//   mean  : out_i = (sum_{j->i} y[j]) / max(indeg(i), 1)       SimpleConv(aggr="mean")
+#include "gatres_common.h"
+
+namespace {
+
+struct RowGeom {
+  int HC, C, lgC, H, G, lgG;
+};
+
+static inline int ilog2(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
+
+static inline bool make_geom(int H, int C, RowGeom* g) {
+  if (H < 1 || C < 4 || !gatres_is_pow2(C) || !gatres_is_pow2(H)) return false;
+  int HC = H * C;
+  if (HC > 256) return false;
+  g->HC = HC; g->C = C; g->lgC = ilog2(C); g->H = H;
+  g->G = HC / 4; g->lgG = ilog2(g->G);
+  return true;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// K2 forward
+// ------------------------------------------------------------------------------------------------------
+template <bool RELU>
+__global__ __launch_bounds__(256) void gat_aggregate_fwd_kernel(
+    const int* __restrict__ rowptr, const int* __restrict__ col, const float* __restrict__ h,
+    const float* __restrict__ a_src, const float* __restrict__ a_dst, const float* __restrict__ bias,
+    float* __restrict__ out, float* __restrict__ alpha, int N, RowGeom gm) {
+  const int tid = blockIdx.x * 256 + threadIdx.x;
+  const int row = tid >> gm.lgG;
+  if (row >= N) return;
+  const int c0 = (tid & (gm.G - 1)) * 4;
+  const int hd = c0 >> gm.lgC;
+  const bool leader = (c0 & (gm.C - 1)) == 0;
+  const int H = gm.H, HC = gm.HC;
+  const int beg = rowptr[row], end = rowptr[row + 1];
+  const float adst = a_dst[row * H + hd];
+
+  float m = -INFINITY;
+  for (int e = beg; e < end; ++e) {
+    const float s = gatres_leaky(a_src[col[e] * H + hd] + adst);
+    m = fmaxf(m, s);
+  }
+  float Z = 0.f;
+  for (int e = beg; e < end; ++e) {
+    const float s = gatres_leaky(a_src[col[e] * H + hd] + adst);
+    Z = Z + expf(s - m);
+  }
+  Z = Z + GATRES_SOFTMAX_EPS;
+
+  float4 acc = f4zero();
+  int e = beg;
+  // two edges per trip so both neighbour rows are in flight together
+  for (; e + 1 < end; e += 2) {
+    const int j0 = col[e], j1 = col[e + 1];
+    const float4 v0 = ld4(h + (size_t)j0 * HC + c0);
+    const float4 v1 = ld4(h + (size_t)j1 * HC + c0);
+    const float al0 = expf(gatres_leaky(a_src[j0 * H + hd] + adst) - m) / Z;
+    const float al1 = expf(gatres_leaky(a_src[j1 * H + hd] + adst) - m) / Z;
+    if (leader) { alpha[(size_t)e * H + hd] = al0; alpha[(size_t)(e + 1) * H + hd] = al1; }
+    acc.x = acc.x + al0 * v0.x; acc.y = acc.y + al0 * v0.y; acc.z = acc.z + al0 * v0.z; acc.w = acc.w + al0 * v0.w;
+    acc.x = acc.x + al1 * v1.x; acc.y = acc.y + al1 * v1.y; acc.z = acc.z + al1 * v1.z; acc.w = acc.w + al1 * v1.w;
+  }
+  if (e < end) {
+    const int j0 = col[e];
+    const float4 v0 = ld4(h + (size_t)j0 * HC + c0);
+    const float al0 = expf(gatres_leaky(a_src[j0 * H + hd] + adst) - m) / Z;
+    if (leader) alpha[(size_t)e * H + hd] = al0;
+    acc.x = acc.x + al0 * v0.x; acc.y = acc.y + al0 * v0.y; acc.z = acc.z + al0 * v0.z; acc.w = acc.w + al0 * v0.w;
+  }
+  const float4 b = ld4(bias + c0);
+  acc.x = acc.x + b.x; acc.y = acc.y + b.y; acc.z = acc.z + b.z; acc.w = acc.w + b.w;
+  if (RELU) {
+    acc.x = fmaxf(acc.x, 0.f); acc.y = fmaxf(acc.y, 0.f); acc.z = fmaxf(acc.z, 0.f); acc.w = fmaxf(acc.w, 0.f);
+  }
+  st4(out + (size_t)row * HC + c0, acc);
+}
+
+// ------------------------------------------------------------------------------------------------------
+// K2 backward, destination-major: per in-edge e = (j -> i)
+//   ga_e  = <g_out[i,h,:], h[j,h,:]>            (reduced over the C/4 lanes of the head)
+//   S_i   = sum_e alpha_e * ga_e
+//   gs_e  = alpha_e * (ga_e - S_i)              softmax backward (max is detached, eps is a constant)
+//   g_e   = gs_e * (raw_e > 0 ? 1 : 0.2)        LeakyReLU backward,  raw_e = a_src[j] + a_dst[i]
+//   g_a_dst[i] = sum_e g_e
+// ------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float head_dot(const float4 a, const float4 b, int lanes_per_head) {
+  float d = a.x * b.x;
+  d = fmaf(a.y, b.y, d);
+  d = fmaf(a.z, b.z, d);
+  d = fmaf(a.w, b.w, d);
+  for (int off = lanes_per_head >> 1; off > 0; off >>= 1) d += __shfl_xor(d, off);
+  return d;
+}
+
+__global__ __launch_bounds__(256) void gat_aggregate_bwd_dst_kernel(
+    const int* __restrict__ rowptr, const int* __restrict__ col, const float* __restrict__ g_out,
+    const float* __restrict__ h, const float* __restrict__ alpha, const float* __restrict__ a_src,
+    const float* __restrict__ a_dst, float* __restrict__ g_e, float* __restrict__ g_a_dst, int N, RowGeom gm) {
+  const int tid = blockIdx.x * 256 + threadIdx.x;
+  int row = tid >> gm.lgG;
+  const bool valid = row < N;
+  if (!valid) row = N - 1;              // keep every lane alive for the shuffles; stores are predicated
+  const int c0 = (tid & (gm.G - 1)) * 4;
+  const int hd = c0 >> gm.lgC;
+  const bool leader = valid && (c0 & (gm.C - 1)) == 0;
+  const int H = gm.H, HC = gm.HC, LH = gm.C >> 2;
+  const int beg = rowptr[row], end = rowptr[row + 1];
+  const float4 go = ld4(g_out + (size_t)row * HC + c0);
+  const float adst = a_dst[row * H + hd];
+
+  float S = 0.f, gad = 0.f;
+  if (end - beg <= 8) {                 // the common case: cache the per-edge dots in registers
+    float ga[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      ga[k] = 0.f;
+      if (beg + k < end) {
+        const int j = col[beg + k];
+        ga[k] = head_dot(go, ld4(h + (size_t)j * HC + c0), LH);
+        S = S + alpha[(size_t)(beg + k) * H + hd] * ga[k];
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      if (beg + k < end) {
+        const int e = beg + k;
+        const float gs = alpha[(size_t)e * H + hd] * (ga[k] - S);
+        const float raw = a_src[col[e] * H + hd] + adst;
+        const float ge = raw > 0.f ? gs : gs * GATRES_NEG_SLOPE;
+        if (leader) g_e[(size_t)e * H + hd] = ge;
+        gad = gad + ge;
+      }
+    }
+  } else {                              // hub rows: recompute the dots in the second pass
+    for (int e = beg; e < end; ++e) {
+      const float ga = head_dot(go, ld4(h + (size_t)col[e] * HC + c0), LH);
+      S = S + alpha[(size_t)e * H + hd] * ga;
+    }
+    for (int e = beg; e < end; ++e) {
+      const int j = col[e];
+      const float ga = head_dot(go, ld4(h + (size_t)j * HC + c0), LH);
+      const float gs = alpha[(size_t)e * H + hd] * (ga - S);
+      const float raw = a_src[j * H + hd] + adst;
+      const float ge = raw > 0.f ? gs : gs * GATRES_NEG_SLOPE;
+      if (leader) g_e[(size_t)e * H + hd] = ge;
+      gad = gad + ge;
+    }
+  }
+  if (leader) g_a_dst[row * H + hd] = gad;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// K2 backward, source-major over CSR^T:
+//   g_a_src[j] = sum_{e out of j} g_e
+//   g_h[j]     = sum_{e=(j->i)} alpha_e * g_out[i]  +  g_a_src[j] (x) att_src  +  g_a_dst[j] (x) att_dst
+// ------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gat_aggregate_bwd_src_kernel(
+    const int* __restrict__ t_rowptr, const int* __restrict__ t_eid, const int* __restrict__ t_dst,
+    const float* __restrict__ g_out, const float* __restrict__ alpha, const float* __restrict__ g_e,
+    const float* __restrict__ g_a_dst, const float* __restrict__ att_src, const float* __restrict__ att_dst,
+    float* __restrict__ g_h, float* __restrict__ g_a_src, int N, RowGeom gm) {
+  const int tid = blockIdx.x * 256 + threadIdx.x;
+  const int row = tid >> gm.lgG;
+  if (row >= N) return;
+  const int c0 = (tid & (gm.G - 1)) * 4;
+  const int hd = c0 >> gm.lgC;
+  const bool leader = (c0 & (gm.C - 1)) == 0;
+  const int H = gm.H, HC = gm.HC;
+  const int beg = t_rowptr[row], end = t_rowptr[row + 1];
+  float4 acc = f4zero();
+  float gas = 0.f;
+  int t = beg;
+  for (; t + 1 < end; t += 2) {
+    const int e0 = t_eid[t], e1 = t_eid[t + 1];
+    const int i0 = t_dst[t], i1 = t_dst[t + 1];
+    const float4 v0 = ld4(g_out + (size_t)i0 * HC + c0);
+    const float4 v1 = ld4(g_out + (size_t)i1 * HC + c0);
+    const float al0 = alpha[(size_t)e0 * H + hd], al1 = alpha[(size_t)e1 * H + hd];
+    gas = gas + g_e[(size_t)e0 * H + hd];
+    gas = gas + g_e[(size_t)e1 * H + hd];
+    acc.x = acc.x + al0 * v0.x; acc.y = acc.y + al0 * v0.y; acc.z = acc.z + al0 * v0.z; acc.w = acc.w + al0 * v0.w;
+    acc.x = acc.x + al1 * v1.x; acc.y = acc.y + al1 * v1.y; acc.z = acc.z + al1 * v1.z; acc.w = acc.w + al1 * v1.w;
+  }
+  if (t < end) {
+    const int e0 = t_eid[t], i0 = t_dst[t];
+    const float4 v0 = ld4(g_out + (size_t)i0 * HC + c0);
+    const float al0 = alpha[(size_t)e0 * H + hd];
+    gas = gas + g_e[(size_t)e0 * H + hd];
+    acc.x = acc.x + al0 * v0.x; acc.y = acc.y + al0 * v0.y; acc.z = acc.z + al0 * v0.z; acc.w = acc.w + al0 * v0.w;
+  }
+  if (leader) g_a_src[row * H + hd] = gas;
+  const float gad = g_a_dst[row * H + hd];
+  const float4 as = ld4(att_src + c0), ad = ld4(att_dst + c0);
+  acc.x = acc.x + gas * as.x; acc.y = acc.y + gas * as.y; acc.z = acc.z + gas * as.z; acc.w = acc.w + gas * as.w;
+  acc.x = acc.x + gad * ad.x; acc.y = acc.y + gad * ad.y; acc.z = acc.z + gad * ad.z; acc.w = acc.w + gad * ad.w;
+  st4(g_h + (size_t)row * HC + c0, acc);
+}
+
+// ------------------------------------------------------------------------------------------------------
+// K3: out_i = relu( (sum_{j->i} y[j]) / max(indeg(i),1) + x0_i )       and its backward
+// ------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void mean_residual_relu_fwd_kernel(
+    const int* __restrict__ rowptr, const int* __restrict__ col, const float* __restrict__ y,
+    const float* __restrict__ x0, float* __restrict__ out, int N, int C, int G, int lgG) {
+  const int tid = blockIdx.x * 256 + threadIdx.x;
+  const int row = tid >> lgG;
+  if (row >= N) return;
+  const int c0 = (tid & (G - 1)) * 4;
+  const int beg = rowptr[row], end = rowptr[row + 1];
+  float4 acc = f4zero();
+  int e = beg;
+  for (; e + 1 < end; e += 2) {
+    const float4 v0 = ld4(y + (size_t)col[e] * C + c0);
+    const float4 v1 = ld4(y + (size_t)col[e + 1] * C + c0);
+    acc.x = acc.x + v0.x; acc.y = acc.y + v0.y; acc.z = acc.z + v0.z; acc.w = acc.w + v0.w;
+    acc.x = acc.x + v1.x; acc.y = acc.y + v1.y; acc.z = acc.z + v1.z; acc.w = acc.w + v1.w;
+  }
+  if (e < end) {
+    const float4 v0 = ld4(y + (size_t)col[e] * C + c0);
+    acc.x = acc.x + v0.x; acc.y = acc.y + v0.y; acc.z = acc.z + v0.z; acc.w = acc.w + v0.w;
+  }
+  const float cnt = (float)max(end - beg, 1);
+  const float4 r = ld4(x0 + (size_t)row * C + c0);
+  float4 o;
+  o.x = fmaxf(acc.x / cnt + r.x, 0.f);
+  o.y = fmaxf(acc.y / cnt + r.y, 0.f);
+  o.z = fmaxf(acc.z / cnt + r.z, 0.f);
+  o.w = fmaxf(acc.w / cnt + r.w, 0.f);
+  st4(out + (size_t)row * C + c0, o);
+}
+
+__global__ __launch_bounds__(256) void mean_bwd_kernel(
+    const int* __restrict__ m_rowptr, const int* __restrict__ mt_rowptr, const int* __restrict__ mt_dst,
+    const float* __restrict__ g_pre, float* __restrict__ g_y, int N, int C, int G, int lgG) {
+  const int tid = blockIdx.x * 256 + threadIdx.x;
+  const int row = tid >> lgG;
+  if (row >= N) return;
+  const int c0 = (tid & (G - 1)) * 4;
+  const int beg = mt_rowptr[row], end = mt_rowptr[row + 1];
+  float4 acc = f4zero();
+  for (int t = beg; t < end; ++t) {
+    const int i = mt_dst[t];
+    const float cnt = (float)max(m_rowptr[i + 1] - m_rowptr[i], 1);
+    const float4 v = ld4(g_pre + (size_t)i * C + c0);
+    acc.x = acc.x + v.x / cnt; acc.y = acc.y + v.y / cnt; acc.z = acc.z + v.z / cnt; acc.w = acc.w + v.w / cnt;
+  }
+  st4(g_y + (size_t)row * C + c0, acc);
+}
+
+static inline bool graph_ok(const gatres_graph_t* g) {
+  return g && g->num_nodes > 0 && g->rowptr && g->col && g->t_rowptr && g->t_eid && g->t_dst && g->m_rowptr &&
+         g->m_col && g->mt_rowptr && g->mt_dst;
+}
+
+static inline int grid_rows(int N, int G) {
+  const long long threads = (long long)N * G;
+  return (int)((threads + 255) / 256);
+}
+
+}  // namespace
+
+extern "C" int gatres_gat_aggregate_fwd(const gatres_graph_t* g, const float* h, const float* a_src,
+                                        const float* a_dst, const float* bias, float* out, float* alpha,
+                                        int32_t H, int32_t C, int32_t apply_relu, void* stream) {
+  if (!graph_ok(g) || !h || !a_src || !a_dst || !bias || !out || !alpha) return GATRES_E_BADARG;
+  if (!gatres_aligned16(h) || !gatres_aligned16(out) || !gatres_aligned16(bias)) return GATRES_E_BADARG;
+  RowGeom gm;
+  if (!make_geom(H, C, &gm)) return GATRES_E_UNSUPPORTED;
+  const int N = g->num_nodes;
+  dim3 grid(grid_rows(N, gm.G)), block(256);
+  if (apply_relu)
+    hipLaunchKernelGGL(gat_aggregate_fwd_kernel<true>, grid, block, 0, gatres_stream(stream), g->rowptr, g->col, h,
+                       a_src, a_dst, bias, out, alpha, N, gm);
+  else
+    hipLaunchKernelGGL(gat_aggregate_fwd_kernel<false>, grid, block, 0, gatres_stream(stream), g->rowptr, g->col, h,
+                       a_src, a_dst, bias, out, alpha, N, gm);
+  return gatres_launch_status();
+}
+
+extern "C" int gatres_gat_aggregate_bwd_dst(const gatres_graph_t* g, const float* g_out, const float* h,
+                                            const float* alpha, const float* a_src, const float* a_dst,
+                                            float* g_e, float* g_a_dst, int32_t H, int32_t C, void* stream) {
+  if (!graph_ok(g) || !g_out || !h || !alpha || !a_src || !a_dst || !g_e || !g_a_dst) return GATRES_E_BADARG;
+  if (!gatres_aligned16(h) || !gatres_aligned16(g_out)) return GATRES_E_BADARG;
+  RowGeom gm;
+  if (!make_geom(H, C, &gm)) return GATRES_E_UNSUPPORTED;
+  const int N = g->num_nodes;
+  hipLaunchKernelGGL(gat_aggregate_bwd_dst_kernel, dim3(grid_rows(N, gm.G)), dim3(256), 0, gatres_stream(stream),
+                     g->rowptr, g->col, g_out, h, alpha, a_src, a_dst, g_e, g_a_dst, N, gm);
+  return gatres_launch_status();
+}
+
+extern "C" int gatres_gat_aggregate_bwd_src(const gatres_graph_t* g, const float* g_out, const float* alpha,
+                                            const float* g_e, const float* g_a_dst, const float* att_src,
+                                            const float* att_dst, float* g_h, float* g_a_src, int32_t H,
+                                            int32_t C, void* stream) {
+  if (!graph_ok(g) || !g_out || !alpha || !g_e || !g_a_dst || !att_src || !att_dst || !g_h || !g_a_src)
+    return GATRES_E_BADARG;
+  if (!gatres_aligned16(g_out) || !gatres_aligned16(g_h) || !gatres_aligned16(att_src) ||
+      !gatres_aligned16(att_dst))
+    return GATRES_E_BADARG;
+  RowGeom gm;
+  if (!make_geom(H, C, &gm)) return GATRES_E_UNSUPPORTED;
+  const int N = g->num_nodes;
+  hipLaunchKernelGGL(gat_aggregate_bwd_src_kernel, dim3(grid_rows(N, gm.G)), dim3(256), 0, gatres_stream(stream),
+                     g->t_rowptr, g->t_eid, g->t_dst, g_out, alpha, g_e, g_a_dst, att_src, att_dst, g_h, g_a_src,
+                     N, gm);
+  return gatres_launch_status();
+}
+
+extern "C" int gatres_mean_residual_relu_fwd(const gatres_graph_t* g, const float* y, const float* x0,
+                                             float* out, int32_t C, void* stream) {
+  if (!graph_ok(g) || !y || !x0 || !out) return GATRES_E_BADARG;
+  if (!gatres_aligned16(y) || !gatres_aligned16(x0) || !gatres_aligned16(out)) return GATRES_E_BADARG;
+  if (C < 4 || !gatres_is_pow2(C) || C > 256) return GATRES_E_UNSUPPORTED;
+  const int G = C / 4, N = g->num_nodes;
+  hipLaunchKernelGGL(mean_residual_relu_fwd_kernel, dim3(grid_rows(N, G)), dim3(256), 0, gatres_stream(stream),
+                     g->m_rowptr, g->m_col, y, x0, out, N, C, G, ilog2(G));
+  return gatres_launch_status();
+}
+
+extern "C" int gatres_mean_bwd(const gatres_graph_t* g, const float* g_pre, float* g_y, int32_t C, void* stream) {
+  if (!graph_ok(g) || !g_pre || !g_y) return GATRES_E_BADARG;
+  if (!gatres_aligned16(g_pre) || !gatres_aligned16(g_y)) return GATRES_E_BADARG;
+  if (C < 4 || !gatres_is_pow2(C) || C > 256) return GATRES_E_UNSUPPORTED;
+  const int G = C / 4, N = g->num_nodes;
+  hipLaunchKernelGGL(mean_bwd_kernel, dim3(grid_rows(N, G)), dim3(256), 0, gatres_stream(stream), g->m_rowptr,
+                     g->mt_rowptr, g->mt_dst, g_pre, g_y, N, C, G, ilog2(G));
+  return gatres_launch_status();
+}

@@ -1,0 +1,417 @@
+// Small dense / reduction kernels around the message-passing stack: lin0 / lin1 (PyG Linear(1,nc), Linear(nc,1);
+// GraphModels.py:477,484,487,492), parameter-gradient column reductions, the slab reducer, weight transposes,
+// and the caller-side pieces of the training step (device mask sampler, masked MSE, Adam; train.py:174-188).
+//
+// Reductions over nodes: `num_slabs` waves each own a contiguous node range and write their partial sums to
+// their own slab at the parameter's flat offset; gatres_reduce_slabs adds the slabs in index order.  No atomics,
+// bitwise reproducible.
+#include "gatres_common.h"
+
+namespace {
+
+static inline int nodes_per_slab(int N, int num_slabs) {
+  int nps = (N + num_slabs - 1) / num_slabs;
+  return (nps + 3) & ~3;     // same rounding as the dW kernel so every reduction shares slab boundaries
+}
+
+// ---------------------------------------------------------------------------------------------------- lin0
+__global__ __launch_bounds__(256) void lin0_fwd_kernel(const float* __restrict__ x, const uint8_t* __restrict__ mask,
+                                                       const float* __restrict__ w, const float* __restrict__ b,
+                                                       float* __restrict__ out, int N, int nc4) {
+  const long long tid = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (tid >= (long long)N * nc4) return;
+  const int n = (int)(tid / nc4), c0 = (int)(tid % nc4) * 4;
+  const float xv = (mask && mask[n]) ? 0.f : x[n];
+  const float4 wv = ld4(w + c0), bv = ld4(b + c0);
+  float4 o;
+  o.x = xv * wv.x + bv.x; o.y = xv * wv.y + bv.y; o.z = xv * wv.z + bv.z; o.w = xv * wv.w + bv.w;
+  st4(out + (size_t)n * nc4 * 4 + c0, o);
+}
+
+// g_w[c] = sum_n g[n,c]*xm[n] ; g_b[c] = sum_n g[n,c]        (one wave per slab, lane = column)
+__global__ __launch_bounds__(64) void lin0_bwd_kernel(const float* __restrict__ g, const float* __restrict__ x,
+                                                      const uint8_t* __restrict__ mask, float* __restrict__ slab_w,
+                                                      float* __restrict__ slab_b, long long stride, int N, int nc,
+                                                      int nps) {
+  const int s = blockIdx.x, lane = threadIdx.x;
+  const int nbeg = s * nps, nend = min(N, nbeg + nps);
+  float aw[4] = {0.f, 0.f, 0.f, 0.f}, ab[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int n = nbeg; n < nend; ++n) {
+    const float xv = (mask && mask[n]) ? 0.f : x[n];
+#pragma unroll
+    for (int cc = 0; cc < 4; ++cc) {
+      const int c = lane + 64 * cc;
+      if (c < nc) {
+        const float gv = g[(size_t)n * nc + c];
+        aw[cc] = fmaf(gv, xv, aw[cc]);
+        ab[cc] += gv;
+      }
+    }
+  }
+#pragma unroll
+  for (int cc = 0; cc < 4; ++cc) {
+    const int c = lane + 64 * cc;
+    if (c < nc) {
+      slab_w[(size_t)s * stride + c] = aw[cc];
+      slab_b[(size_t)s * stride + c] = ab[cc];
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------- lin1
+// out[n] = sum_c x[n,c]*w[c] + b   (G = nc/4 lanes per row)
+__global__ __launch_bounds__(256) void lin1_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                       const float* __restrict__ b, float* __restrict__ out, int N,
+                                                       int nc, int G, int lgG) {
+  const int tid = blockIdx.x * 256 + threadIdx.x;
+  int row = tid >> lgG;
+  const bool valid = row < N;
+  if (!valid) row = N - 1;
+  const int c0 = (tid & (G - 1)) * 4;
+  const float4 xv = ld4(x + (size_t)row * nc + c0), wv = ld4(w + c0);
+  float d = xv.x * wv.x;
+  d = fmaf(xv.y, wv.y, d); d = fmaf(xv.z, wv.z, d); d = fmaf(xv.w, wv.w, d);
+  for (int off = G >> 1; off > 0; off >>= 1) d += __shfl_xor(d, off);
+  if (valid && c0 == 0) out[row] = d + (b ? b[0] : 0.f);
+}
+
+// g_x[n,c] = g_out[n]*w[c] (ReLU-masked by x>0);  slabs: g_w[c] = sum_n g_out[n]*x[n,c], g_b = sum_n g_out[n]
+__global__ __launch_bounds__(64) void lin1_bwd_kernel(const float* __restrict__ g_out, const float* __restrict__ x,
+                                                      const float* __restrict__ w, float* __restrict__ g_x,
+                                                      float* __restrict__ slab_w, float* __restrict__ slab_b,
+                                                      long long stride, int N, int nc, int nps, int relu_mask) {
+  const int s = blockIdx.x, lane = threadIdx.x;
+  const int nbeg = s * nps, nend = min(N, nbeg + nps);
+  float aw[4] = {0.f, 0.f, 0.f, 0.f}, wv[4];
+  float ab = 0.f;
+#pragma unroll
+  for (int cc = 0; cc < 4; ++cc) wv[cc] = (lane + 64 * cc < nc) ? w[lane + 64 * cc] : 0.f;
+  for (int n = nbeg; n < nend; ++n) {
+    const float go = g_out[n];
+    ab += go;
+#pragma unroll
+    for (int cc = 0; cc < 4; ++cc) {
+      const int c = lane + 64 * cc;
+      if (c < nc) {
+        const float xv = x[(size_t)n * nc + c];
+        aw[cc] = fmaf(go, xv, aw[cc]);
+        g_x[(size_t)n * nc + c] = (relu_mask && !(xv > 0.f)) ? 0.f : go * wv[cc];
+      }
+    }
+  }
+#pragma unroll
+  for (int cc = 0; cc < 4; ++cc) {
+    const int c = lane + 64 * cc;
+    if (c < nc) slab_w[(size_t)s * stride + c] = aw[cc];
+  }
+  if (lane == 0) slab_b[(size_t)s * stride] = ab;
+}
+
+// -------------------------------------------------------------------------------- GATConv parameter grads
+// g_att_src[hc] = sum_n g_a_src[n,h]*h[n,hc];  g_att_dst likewise;  g_bias[hc] = sum_n g_out[n,hc]
+__global__ __launch_bounds__(64) void conv_param_grads_kernel(
+    const float* __restrict__ h, const float* __restrict__ g_a_src, const float* __restrict__ g_a_dst,
+    const float* __restrict__ g_out, float* __restrict__ slab_as, float* __restrict__ slab_ad,
+    float* __restrict__ slab_b, long long stride, int N, int H, int C, int nps) {
+  const int s = blockIdx.x, lane = threadIdx.x;
+  const int HC = H * C;
+  const int nbeg = s * nps, nend = min(N, nbeg + nps);
+  float as[4] = {0.f, 0.f, 0.f, 0.f}, ad[4] = {0.f, 0.f, 0.f, 0.f}, ab[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int n = nbeg; n < nend; ++n) {
+#pragma unroll
+    for (int cc = 0; cc < 4; ++cc) {
+      const int c = lane + 64 * cc;
+      if (c < HC) {
+        const int hd = c / C;
+        const float hv = h[(size_t)n * HC + c];
+        as[cc] = fmaf(g_a_src[n * H + hd], hv, as[cc]);
+        ad[cc] = fmaf(g_a_dst[n * H + hd], hv, ad[cc]);
+        ab[cc] += g_out[(size_t)n * HC + c];
+      }
+    }
+  }
+#pragma unroll
+  for (int cc = 0; cc < 4; ++cc) {
+    const int c = lane + 64 * cc;
+    if (c < HC) {
+      slab_as[(size_t)s * stride + c] = as[cc];
+      slab_ad[(size_t)s * stride + c] = ad[cc];
+      slab_b[(size_t)s * stride + c] = ab[cc];
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void reduce_slabs_kernel(const float* __restrict__ slabs, int num_slabs,
+                                                           long long stride, long long count,
+                                                           float* __restrict__ out) {
+  const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= count) return;
+  float acc = 0.f;
+  for (int s = 0; s < num_slabs; ++s) acc += slabs[(size_t)s * stride + idx];
+  out[idx] = acc;
+}
+
+// wt block layout: [W1^T : nc x 2nc][W2^T : 2nc x nc]
+__global__ __launch_bounds__(256) void transpose_conv_weights_kernel(const float* __restrict__ params,
+                                                                     float* __restrict__ wt, int num_blocks,
+                                                                     int nc) {
+  const int per = 2 * nc * nc;                       // elements of one conv weight
+  const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (long long)num_blocks * 2 * per) return;
+  const int b = (int)(idx / (2 * per));
+  const int r = (int)(idx % (2 * per));
+  const int conv = r / per, e = r % per;
+  const long long blk = 2LL * nc + (long long)b * (9LL * nc + 4LL * nc * nc);   // lin0.w + lin0.b, then blocks
+  // conv1: att_src[2nc] att_dst[2nc] bias[2nc] W[2nc, nc];  conv2: att_src[nc] att_dst[nc] bias[nc] W[nc, 2nc]
+  const float* W = params + blk + (conv == 0 ? 6LL * nc : 6LL * nc + per + 3LL * nc);
+  const int rows = conv == 0 ? 2 * nc : nc, cols = conv == 0 ? nc : 2 * nc;
+  const int orow = e / rows, ocol = e % rows;        // output is [cols, rows]
+  wt[(size_t)b * 2 * per + (size_t)conv * per + e] = W[(size_t)ocol * cols + orow];
+}
+
+// ------------------------------------------------------------------------------------------ edge_index hash
+__device__ __forceinline__ uint64_t mix64(uint64_t z) {
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+  return z ^ (z >> 31);
+}
+
+__global__ __launch_bounds__(256) void edge_hash_kernel(const int64_t* __restrict__ ei, long long E,
+                                                        unsigned long long* __restrict__ out) {
+  const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
+  unsigned long long v = 0;
+  if (e < E) {
+    const uint64_t a = mix64((uint64_t)ei[e] + 0x9E3779B97F4A7C15ULL * (uint64_t)(e + 1));
+    v = mix64(a ^ ((uint64_t)ei[E + e] + 0xD1B54A32D192ED03ULL));
+  }
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+  if ((threadIdx.x & 63) == 0 && v) atomicAdd(out, v);      // integer add: order-independent
+}
+
+// ---------------------------------------------------------------------------------- device mask sampler
+// One workgroup per graph.  Every node gets a unique 64-bit key (hash32(seed, step, node) << 32 | local id);
+// the k = int(n*rate) smallest keys are masked: an exactly-k uniform subset without replacement, the same
+// distribution as np.random.choice(n, k, replace=False) in utils/auxil.py:154-157.  The k-th key is found by an
+// 8-pass byte-wise radix select in LDS.
+__device__ __forceinline__ uint64_t mask_key(uint64_t seed, uint64_t step, int gnode, int local) {
+  const uint64_t z = mix64(seed + 0x9E3779B97F4A7C15ULL * (step + 1) + 0xBF58476D1CE4E5B9ULL * (uint64_t)(gnode + 1));
+  return ((z >> 32) << 32) | (uint32_t)local;
+}
+
+__global__ __launch_bounds__(256) void mask_generate_kernel(const int* __restrict__ node_ptr, double rate,
+                                                            uint64_t seed, const uint64_t* __restrict__ step_counter,
+                                                            uint8_t* __restrict__ mask) {
+  __shared__ int hist[256];
+  __shared__ uint64_t s_prefix;
+  __shared__ int s_k;
+  const int g = blockIdx.x, tid = threadIdx.x;
+  const int n0 = node_ptr[g], n = node_ptr[g + 1] - n0;
+  const uint64_t step = step_counter ? step_counter[0] : 0;
+  const int k = (int)((double)n * rate);          // Python: int(num_nodes * masking_rate)
+  if (k <= 0) {
+    for (int v = tid; v < n; v += 256) mask[n0 + v] = 0;
+    return;
+  }
+  if (tid == 0) { s_prefix = 0; s_k = k; }
+  for (int pass = 7; pass >= 0; --pass) {
+    hist[tid] = 0;
+    __syncthreads();
+    const uint64_t prefix = s_prefix;
+    for (int v = tid; v < n; v += 256) {
+      const uint64_t key = mask_key(seed, step, n0 + v, v);
+      const bool match = (pass == 7) || ((key >> (8 * (pass + 1))) == prefix);
+      if (match) atomicAdd(&hist[(int)((key >> (8 * pass)) & 255)], 1);
+    }
+    __syncthreads();
+    if (tid == 0) {
+      int kk = s_k, b = 0;
+      while (b < 255 && kk > hist[b]) { kk -= hist[b]; ++b; }
+      s_k = kk;
+      s_prefix = (prefix << 8) | (uint64_t)b;
+    }
+    __syncthreads();
+  }
+  const uint64_t kth = s_prefix;
+  for (int v = tid; v < n; v += 256) mask[n0 + v] = mask_key(seed, step, n0 + v, v) <= kth ? 1 : 0;
+}
+
+// ------------------------------------------------------------------------------------------- masked MSE
+__global__ __launch_bounds__(1024) void masked_mse_kernel(const float* __restrict__ out, const float* __restrict__ y,
+                                                          const uint8_t* __restrict__ mask, float* __restrict__ loss,
+                                                          float* __restrict__ g_out, int N) {
+  __shared__ float s_sum[1024];
+  __shared__ int s_cnt[1024];
+  const int tid = threadIdx.x;
+  float acc = 0.f;
+  int cnt = 0;
+  for (int n = tid; n < N; n += 1024) {
+    if (mask[n]) {
+      const float d = out[n] - y[n];
+      acc = fmaf(d, d, acc);
+      ++cnt;
+    }
+  }
+  s_sum[tid] = acc; s_cnt[tid] = cnt;
+  __syncthreads();
+  for (int off = 512; off > 0; off >>= 1) {
+    if (tid < off) { s_sum[tid] += s_sum[tid + off]; s_cnt[tid] += s_cnt[tid + off]; }
+    __syncthreads();
+  }
+  const int M = s_cnt[0];
+  if (tid == 0) loss[0] = s_sum[0] / (float)M;            // M == 0 -> NaN, like torch's mean of an empty tensor
+  const float scale = M > 0 ? 2.f / (float)M : 0.f;
+  for (int n = tid; n < N; n += 1024) g_out[n] = mask[n] ? (out[n] - y[n]) * scale : 0.f;
+}
+
+// ------------------------------------------------------------------------------------------------- Adam
+// torch.optim.Adam (single-tensor path): g += wd*p; m.lerp_(g, 1-b1); v = b2*v + (1-b2) g*g;
+// p += (-(lr/bc1) * m) / (sqrt(v)/sqrt(bc2) + eps).   step_counter[0] = step, [1] = block ticket.
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                   float* __restrict__ m, float* __restrict__ v,
+                                                   unsigned long long* __restrict__ step_counter, long long count,
+                                                   double lr, double b1, double b2, double eps, double wd,
+                                                   float grad_scale) {
+  __shared__ float s_step_size, s_bc2_sqrt;
+  if (threadIdx.x == 0) {
+    const double t = (double)(step_counter[0] + 1ULL);
+    const double bc1 = 1.0 - pow(b1, t), bc2 = 1.0 - pow(b2, t);
+    s_step_size = (float)(lr / bc1);
+    s_bc2_sqrt = (float)sqrt(bc2);
+  }
+  __syncthreads();
+  const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (idx < count) {
+    const float pv = p[idx];
+    float gv = g[idx] * grad_scale;
+    gv = gv + (float)wd * pv;
+    float mv = m[idx];
+    mv = mv + (float)(1.0 - b1) * (gv - mv);
+    const float vv = (float)b2 * v[idx] + (float)(1.0 - b2) * gv * gv;
+    const float denom = sqrtf(vv) / s_bc2_sqrt + (float)eps;
+    p[idx] = pv + (-s_step_size * mv) / denom;
+    m[idx] = mv;
+    v[idx] = vv;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {                       // the last block to finish bumps the step; all blocks have read it
+    __threadfence();
+    const unsigned long long done = atomicAdd(&step_counter[1], 1ULL);
+    if (done == (unsigned long long)gridDim.x - 1ULL) {
+      step_counter[1] = 0ULL;
+      atomicAdd(&step_counter[0], 1ULL);
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int gatres_lin0_fwd(const float* x, const uint8_t* mask, const float* w, const float* b, float* out,
+                               int32_t num_nodes, int32_t nc, void* stream) {
+  if (!x || !w || !b || !out || num_nodes <= 0) return GATRES_E_BADARG;
+  if (nc < 4 || nc % 4) return GATRES_E_UNSUPPORTED;
+  if (!gatres_aligned16(w) || !gatres_aligned16(b) || !gatres_aligned16(out)) return GATRES_E_BADARG;
+  const long long total = (long long)num_nodes * (nc / 4);
+  hipLaunchKernelGGL(lin0_fwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, gatres_stream(stream), x,
+                     mask, w, b, out, num_nodes, nc / 4);
+  return gatres_launch_status();
+}
+
+extern "C" int gatres_lin0_bwd(const float* g, const float* x, const uint8_t* mask, float* slab_w, float* slab_b,
+                               int32_t num_slabs, int64_t slab_stride, int32_t num_nodes, int32_t nc, void* stream) {
+  if (!g || !x || !slab_w || !slab_b || num_nodes <= 0 || num_slabs <= 0) return GATRES_E_BADARG;
+  if (nc < 1 || nc > 256) return GATRES_E_UNSUPPORTED;
+  hipLaunchKernelGGL(lin0_bwd_kernel, dim3(num_slabs), dim3(64), 0, gatres_stream(stream), g, x, mask, slab_w, slab_b,
+                     (long long)slab_stride, num_nodes, nc, nodes_per_slab(num_nodes, num_slabs));
+  return gatres_launch_status();
+}
+
+extern "C" int gatres_lin1_fwd(const float* x, const float* w, const float* b, float* out, int32_t num_nodes,
+                               int32_t nc, void* stream) {
+  if (!x || !w || !out || num_nodes <= 0) return GATRES_E_BADARG;
+  if (nc < 4 || !gatres_is_pow2(nc) || nc > 256) return GATRES_E_UNSUPPORTED;
+  if (!gatres_aligned16(x) || !gatres_aligned16(w)) return GATRES_E_BADARG;
+  const int G = nc / 4;
+  int lgG = 0;
+  while ((1 << lgG) < G) ++lgG;
+  const long long threads = (long long)num_nodes * G;
+  hipLaunchKernelGGL(lin1_fwd_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, gatres_stream(stream), x,
+                     w, b, out, num_nodes, nc, G, lgG);
+  return gatres_launch_status();
+}
+
+extern "C" int gatres_lin1_bwd(const float* g_out, const float* x, const float* w, float* g_x, float* slab_w,
+                               float* slab_b, int32_t num_slabs, int64_t slab_stride, int32_t num_nodes, int32_t nc,
+                               int32_t relu_mask, void* stream) {
+  if (!g_out || !x || !w || !g_x || !slab_w || !slab_b || num_nodes <= 0 || num_slabs <= 0) return GATRES_E_BADARG;
+  if (nc < 1 || nc > 256) return GATRES_E_UNSUPPORTED;
+  hipLaunchKernelGGL(lin1_bwd_kernel, dim3(num_slabs), dim3(64), 0, gatres_stream(stream), g_out, x, w, g_x, slab_w,
+                     slab_b, (long long)slab_stride, num_nodes, nc, nodes_per_slab(num_nodes, num_slabs), relu_mask);
+  return gatres_launch_status();
+}
+
+extern "C" int gatres_conv_param_grads(const float* h, const float* g_a_src, const float* g_a_dst,
+                                       const float* g_out, float* slab_att_src, float* slab_att_dst,
+                                       float* slab_bias, int32_t num_slabs, int64_t slab_stride, int32_t num_nodes,
+                                       int32_t H, int32_t C, void* stream) {
+  if (!h || !g_a_src || !g_a_dst || !g_out || !slab_att_src || !slab_att_dst || !slab_bias || num_nodes <= 0 ||
+      num_slabs <= 0)
+    return GATRES_E_BADARG;
+  if (H < 1 || C < 1 || H * C > 256) return GATRES_E_UNSUPPORTED;
+  hipLaunchKernelGGL(conv_param_grads_kernel, dim3(num_slabs), dim3(64), 0, gatres_stream(stream), h, g_a_src, g_a_dst,
+                     g_out, slab_att_src, slab_att_dst, slab_bias, (long long)slab_stride, num_nodes, H, C,
+                     nodes_per_slab(num_nodes, num_slabs));
+  return gatres_launch_status();
+}
+
+extern "C" int gatres_reduce_slabs(const float* slabs, int32_t num_slabs, int64_t slab_stride, int64_t count,
+                                   float* out, void* stream) {
+  if (!slabs || !out || num_slabs <= 0 || count <= 0 || slab_stride < count) return GATRES_E_BADARG;
+  hipLaunchKernelGGL(reduce_slabs_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, gatres_stream(stream),
+                     slabs, num_slabs, (long long)slab_stride, (long long)count, out);
+  return gatres_launch_status();
+}
+
+extern "C" int gatres_transpose_conv_weights(const float* params, float* wt, int32_t num_blocks, int32_t nc,
+                                             void* stream) {
+  if (!params || !wt || num_blocks < 0 || nc < 1) return GATRES_E_BADARG;
+  if (num_blocks == 0) return 0;
+  const long long total = (long long)num_blocks * 4 * nc * nc;
+  hipLaunchKernelGGL(transpose_conv_weights_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
+                     gatres_stream(stream), params, wt, num_blocks, nc);
+  return gatres_launch_status();
+}
+
+extern "C" int gatres_edge_index_hash(const int64_t* edge_index, int64_t num_edges, uint64_t* hash_out,
+                                      void* stream) {
+  if (!hash_out || num_edges < 0 || (!edge_index && num_edges > 0)) return GATRES_E_BADARG;
+  if (num_edges == 0) return 0;
+  hipLaunchKernelGGL(edge_hash_kernel, dim3((unsigned)((num_edges + 255) / 256)), dim3(256), 0, gatres_stream(stream),
+                     edge_index, (long long)num_edges, reinterpret_cast<unsigned long long*>(hash_out));
+  return gatres_launch_status();
+}
+
+extern "C" int gatres_mask_generate(const int32_t* node_ptr, int32_t num_graphs, double mask_rate, uint64_t seed,
+                                    const uint64_t* step_counter, uint8_t* mask, void* stream) {
+  if (!node_ptr || !mask || num_graphs <= 0 || !(mask_rate >= 0.0 && mask_rate <= 1.0)) return GATRES_E_BADARG;
+  hipLaunchKernelGGL(mask_generate_kernel, dim3(num_graphs), dim3(256), 0, gatres_stream(stream), node_ptr, mask_rate,
+                     seed, step_counter, mask);
+  return gatres_launch_status();
+}
+
+extern "C" int gatres_masked_mse(const float* out, const float* y, const uint8_t* mask, float* loss, float* g_out,
+                                 int32_t num_nodes, void* stream) {
+  if (!out || !y || !mask || !loss || !g_out || num_nodes <= 0) return GATRES_E_BADARG;
+  hipLaunchKernelGGL(masked_mse_kernel, dim3(1), dim3(1024), 0, gatres_stream(stream), out, y, mask, loss, g_out,
+                     num_nodes);
+  return gatres_launch_status();
+}
+
+extern "C" int gatres_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq,
+                                uint64_t* step_counter, int64_t count, double lr, double beta1, double beta2,
+                                double eps, double weight_decay, float grad_scale, void* stream) {
+  if (!params || !grads || !exp_avg || !exp_avg_sq || !step_counter || count <= 0) return GATRES_E_BADARG;
+  hipLaunchKernelGGL(adam_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, gatres_stream(stream), params,
+                     grads, exp_avg, exp_avg_sq, reinterpret_cast<unsigned long long*>(step_counter),
+                     (long long)count, lr, beta1, beta2, eps, weight_decay, grad_scale);
+  return gatres_launch_status();
+}

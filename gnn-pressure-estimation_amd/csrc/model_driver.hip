@@ -1,0 +1,207 @@
+// Whole-network drivers: enqueue GATResMeanConv.forward (GraphModels.py:486-494) and its backward as a fixed
+// sequence of kernel launches on one stream, natively, so a training step costs two host calls (or one hipGraph
+// replay) instead of ~2400 framework dispatches.  No allocation, no synchronisation: graph-capture safe.
+//
+// Block b (GResBlockMeanConv.forward, GraphModels.py:462-468):
+//   xin -> K1(conv1) h1,a1 -> K2(conv1)+bias+ReLU out1 -> K1(conv2) h2,a2 -> K2(conv2)+bias y2
+//       -> K3 mean(y2)+xin, ReLU -> xin of block b+1
+#include "gatres_common.h"
+
+namespace {
+
+static inline int64_t r4(int64_t v) { return (v + 3) & ~(int64_t)3; }
+
+struct Layout {
+  int nb, nc;
+  int64_t N, Eg;
+  // flat parameters
+  int64_t p_lin0_w, p_lin0_b, p_block0, p_block_stride, p_lin1_w, p_lin1_b, P;
+  int64_t c1_as, c1_ad, c1_b, c1_W, c2_as, c2_ad, c2_b, c2_W;   // inside a block
+  // saved activations of one block (s_xin == 0 so that "xin of block nb" is the final activation)
+  int64_t s_xin, s_h1, s_as1, s_ad1, s_al1, s_o1, s_h2, s_as2, s_ad2, s_al2, s_stride, saved_total;
+  // scratch
+  int64_t sc_y2, sc_ev, sc_xa, sc_xb, sc_gpa, sc_gpb, sc_gy2, sc_ge, sc_gad, sc_gas, sc_gh, sc_go1, sc_wt,
+      sc_slabs, scratch_total;
+  int num_slabs;
+  int64_t slab_stride;
+};
+
+static int num_slabs_for(int64_t P, int64_t N) {
+  int64_t cap = (64LL << 20) / (4 * (P > 0 ? P : 1));
+  if (cap > 256) cap = 256;
+  if (cap < 16) cap = 16;
+  int64_t s = (N + 63) / 64;
+  if (s > cap) s = cap;
+  if (s < 1) s = 1;
+  return (int)s;
+}
+
+static bool make_layout(const gatres_model_t* m, int64_t N, int64_t Eg, Layout* L) {
+  if (!m || m->num_blocks < 0 || N <= 0 || Eg < 0) return false;
+  const int nc = m->nc, nb = m->num_blocks;
+  if (nc < 4 || nc > 128 || !gatres_is_pow2(nc)) return false;
+  L->nb = nb; L->nc = nc; L->N = N; L->Eg = Eg;
+  const int64_t w = 2LL * nc * nc;
+  L->p_lin0_w = 0; L->p_lin0_b = nc; L->p_block0 = 2LL * nc;
+  L->c1_as = 0; L->c1_ad = 2LL * nc; L->c1_b = 4LL * nc; L->c1_W = 6LL * nc;
+  L->c2_as = 6LL * nc + w; L->c2_ad = L->c2_as + nc; L->c2_b = L->c2_ad + nc; L->c2_W = L->c2_b + nc;
+  L->p_block_stride = 9LL * nc + 2 * w;
+  L->p_lin1_w = L->p_block0 + nb * L->p_block_stride;
+  L->p_lin1_b = L->p_lin1_w + nc;
+  L->P = L->p_lin1_b + 1;
+
+  int64_t o = 0;
+  L->s_xin = o; o += r4(N * nc);
+  L->s_h1 = o;  o += r4(N * 2 * nc);
+  L->s_as1 = o; o += r4(N * 2);
+  L->s_ad1 = o; o += r4(N * 2);
+  L->s_al1 = o; o += r4(Eg * 2);
+  L->s_o1 = o;  o += r4(N * 2 * nc);
+  L->s_h2 = o;  o += r4(N * nc);
+  L->s_as2 = o; o += r4(N);
+  L->s_ad2 = o; o += r4(N);
+  L->s_al2 = o; o += r4(Eg);
+  L->s_stride = o;
+  L->saved_total = nb * L->s_stride + r4(N * nc);
+
+  L->num_slabs = num_slabs_for(L->P, N);
+  L->slab_stride = r4(L->P);
+  o = 0;
+  L->sc_y2 = o;  o += r4(N * nc);
+  L->sc_ev = o;  o += L->s_stride;
+  L->sc_xa = o;  o += r4(N * nc);
+  L->sc_xb = o;  o += r4(N * nc);
+  L->sc_gpa = o; o += r4(N * nc);
+  L->sc_gpb = o; o += r4(N * nc);
+  L->sc_gy2 = o; o += r4(N * nc);
+  L->sc_ge = o;  o += r4(Eg * 2);
+  L->sc_gad = o; o += r4(N * 2);
+  L->sc_gas = o; o += r4(N * 2);
+  L->sc_gh = o;  o += r4(N * 2 * nc);
+  L->sc_go1 = o; o += r4(N * 2 * nc);
+  L->sc_wt = o;  o += r4((int64_t)nb * 2 * w);
+  L->sc_slabs = o; o += (int64_t)L->num_slabs * L->slab_stride;
+  L->scratch_total = o;
+  return true;
+}
+
+#define RC(call)            \
+  do {                      \
+    const int rc_ = (call); \
+    if (rc_) return rc_;    \
+  } while (0)
+
+}  // namespace
+
+extern "C" int64_t gatres_param_count(int32_t num_blocks, int32_t nc) {
+  return 2LL * nc + (int64_t)num_blocks * (9LL * nc + 4LL * nc * nc) + nc + 1;
+}
+
+extern "C" int64_t gatres_saved_floats(const gatres_model_t* m, int32_t num_nodes, int32_t num_edges_gat) {
+  Layout L;
+  return make_layout(m, num_nodes, num_edges_gat, &L) ? L.saved_total : (int64_t)GATRES_E_UNSUPPORTED;
+}
+
+extern "C" int64_t gatres_scratch_floats(const gatres_model_t* m, int32_t num_nodes, int32_t num_edges_gat) {
+  Layout L;
+  return make_layout(m, num_nodes, num_edges_gat, &L) ? L.scratch_total : (int64_t)GATRES_E_UNSUPPORTED;
+}
+
+extern "C" int32_t gatres_num_slabs(const gatres_model_t* m, int32_t num_nodes) {
+  Layout L;
+  return make_layout(m, num_nodes, 0, &L) ? L.num_slabs : GATRES_E_UNSUPPORTED;
+}
+
+extern "C" const char* gatres_version(void) { return "gatres-gfx950 abi1"; }
+
+extern "C" int gatres_model_forward(const gatres_model_t* m, const gatres_graph_t* g, const float* params,
+                                    const float* x, const uint8_t* mask, float* out, float* saved, float* scratch,
+                                    void* stream) {
+  if (!m || !g || !params || !x || !out || !scratch) return GATRES_E_BADARG;
+  if (!gatres_aligned16(params) || !gatres_aligned16(saved) || !gatres_aligned16(scratch)) return GATRES_E_BADARG;
+  Layout L;
+  if (!make_layout(m, g->num_nodes, g->num_edges_gat, &L)) return GATRES_E_UNSUPPORTED;
+  const int N = g->num_nodes, nc = L.nc;
+  float* y2 = scratch + L.sc_y2;
+  float* xa = scratch + L.sc_xa;
+  float* xb = scratch + L.sc_xb;
+  float* xcur = saved ? saved + L.s_xin : xa;
+  RC(gatres_lin0_fwd(x, mask, params + L.p_lin0_w, params + L.p_lin0_b, xcur, N, nc, stream));
+  for (int b = 0; b < L.nb; ++b) {
+    float* base = saved ? saved + (int64_t)b * L.s_stride : scratch + L.sc_ev;
+    float* xnext = saved ? saved + (int64_t)(b + 1) * L.s_stride + L.s_xin : (xcur == xa ? xb : xa);
+    const float* pb = params + L.p_block0 + (int64_t)b * L.p_block_stride;
+    RC(gatres_proj_attn_fwd(xcur, pb + L.c1_W, pb + L.c1_as, pb + L.c1_ad, base + L.s_h1, base + L.s_as1,
+                            base + L.s_ad1, N, nc, 2, nc, stream));
+    RC(gatres_gat_aggregate_fwd(g, base + L.s_h1, base + L.s_as1, base + L.s_ad1, pb + L.c1_b, base + L.s_o1,
+                                base + L.s_al1, 2, nc, 1, stream));
+    RC(gatres_proj_attn_fwd(base + L.s_o1, pb + L.c2_W, pb + L.c2_as, pb + L.c2_ad, base + L.s_h2, base + L.s_as2,
+                            base + L.s_ad2, N, 2 * nc, 1, nc, stream));
+    RC(gatres_gat_aggregate_fwd(g, base + L.s_h2, base + L.s_as2, base + L.s_ad2, pb + L.c2_b, y2, base + L.s_al2, 1,
+                                nc, 0, stream));
+    RC(gatres_mean_residual_relu_fwd(g, y2, xcur, xnext, nc, stream));
+    xcur = xnext;
+  }
+  RC(gatres_lin1_fwd(xcur, params + L.p_lin1_w, params + L.p_lin1_b, out, N, nc, stream));
+  return 0;
+}
+
+extern "C" int gatres_model_backward(const gatres_model_t* m, const gatres_graph_t* g, const float* params,
+                                     const float* x, const uint8_t* mask, const float* g_out, const float* saved,
+                                     float* scratch, float* grads, float* g_x, void* stream) {
+  if (!m || !g || !params || !x || !g_out || !saved || !scratch || !grads) return GATRES_E_BADARG;
+  if (!gatres_aligned16(params) || !gatres_aligned16(saved) || !gatres_aligned16(scratch)) return GATRES_E_BADARG;
+  Layout L;
+  if (!make_layout(m, g->num_nodes, g->num_edges_gat, &L)) return GATRES_E_UNSUPPORTED;
+  const int N = g->num_nodes, nc = L.nc, S = L.num_slabs;
+  const int64_t st = L.slab_stride, w = 2LL * nc * nc;
+  float* gp_cur = scratch + L.sc_gpa;
+  float* gp_nxt = scratch + L.sc_gpb;
+  float* gy2 = scratch + L.sc_gy2;
+  float* ge = scratch + L.sc_ge;
+  float* gad = scratch + L.sc_gad;
+  float* gas = scratch + L.sc_gas;
+  float* gh = scratch + L.sc_gh;
+  float* go1 = scratch + L.sc_go1;
+  float* wt = scratch + L.sc_wt;
+  float* slabs = scratch + L.sc_slabs;
+
+  RC(gatres_transpose_conv_weights(params, wt, L.nb, nc, stream));
+  const float* xfinal = saved + (int64_t)L.nb * L.s_stride + L.s_xin;
+  RC(gatres_lin1_bwd(g_out, xfinal, params + L.p_lin1_w, gp_cur, slabs + L.p_lin1_w, slabs + L.p_lin1_b, S, st, N, nc,
+                     L.nb > 0 ? 1 : 0, stream));
+  for (int b = L.nb - 1; b >= 0; --b) {
+    const float* base = saved + (int64_t)b * L.s_stride;
+    const int64_t po = L.p_block0 + (int64_t)b * L.p_block_stride;
+    const float* pb = params + po;
+    float* sb = slabs + po;
+    const float* wt1 = wt + (int64_t)b * 2 * w;        // W1^T [nc, 2nc]
+    const float* wt2 = wt1 + w;                        // W2^T [2nc, nc]
+    // K3 backward: gradient w.r.t. conv2's output
+    RC(gatres_mean_bwd(g, gp_cur, gy2, nc, stream));
+    // conv2 (H = 1, C = nc, K = 2nc); its output has no ReLU
+    RC(gatres_gat_aggregate_bwd_dst(g, gy2, base + L.s_h2, base + L.s_al2, base + L.s_as2, base + L.s_ad2, ge, gad, 1,
+                                    nc, stream));
+    RC(gatres_gat_aggregate_bwd_src(g, gy2, base + L.s_al2, ge, gad, pb + L.c2_as, pb + L.c2_ad, gh, gas, 1, nc,
+                                    stream));
+    RC(gatres_conv_param_grads(base + L.s_h2, gas, gad, gy2, sb + L.c2_as, sb + L.c2_ad, sb + L.c2_b, S, st, N, 1, nc,
+                               stream));
+    RC(gatres_proj_bwd_dw(gh, base + L.s_o1, sb + L.c2_W, S, st, N, 2 * nc, nc, stream));
+    RC(gatres_proj_bwd_dx(gh, wt2, nullptr, base + L.s_o1, go1, N, 2 * nc, nc, stream));   // ReLU mask of conv1
+    // conv1 (H = 2, C = nc, K = nc)
+    RC(gatres_gat_aggregate_bwd_dst(g, go1, base + L.s_h1, base + L.s_al1, base + L.s_as1, base + L.s_ad1, ge, gad, 2,
+                                    nc, stream));
+    RC(gatres_gat_aggregate_bwd_src(g, go1, base + L.s_al1, ge, gad, pb + L.c1_as, pb + L.c1_ad, gh, gas, 2, nc,
+                                    stream));
+    RC(gatres_conv_param_grads(base + L.s_h1, gas, gad, go1, sb + L.c1_as, sb + L.c1_ad, sb + L.c1_b, S, st, N, 2, nc,
+                               stream));
+    RC(gatres_proj_bwd_dw(gh, base + L.s_xin, sb + L.c1_W, S, st, N, nc, 2 * nc, stream));
+    // d/d xin = conv1 path + residual; masked by the previous block's ReLU (block 0's input is lin0, no ReLU)
+    RC(gatres_proj_bwd_dx(gh, wt1, gp_cur, b > 0 ? base + L.s_xin : nullptr, gp_nxt, N, nc, 2 * nc, stream));
+    float* t = gp_cur; gp_cur = gp_nxt; gp_nxt = t;
+  }
+  RC(gatres_lin0_bwd(gp_cur, x, mask, slabs + L.p_lin0_w, slabs + L.p_lin0_b, S, st, N, nc, stream));
+  if (g_x) RC(gatres_lin1_fwd(gp_cur, params + L.p_lin0_w, nullptr, g_x, N, nc, stream));
+  RC(gatres_reduce_slabs(slabs, S, st, L.P, grads, stream));
+  return 0;
+}

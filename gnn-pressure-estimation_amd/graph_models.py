@@ -1,0 +1,276 @@
+"""GATRes on MI355X: the reference's ``nn.Module`` surface over the gfx950 HIP engine.
+
+Mirrors gnn_pressure_estimation/GraphModels.py:454-494 (``GResBlockMeanConv``, ``GATResMeanConv``): same class
+names, constructor arguments, ``forward(x, edge_index, batch=None, edge_attr=None)`` signature, ``.name`` attribute
+and the ``state_dict`` keys torch_geometric's ``GATConv`` / ``Linear`` produce, so ``train.py`` / ``evaluation.py``
+call it unchanged and reference checkpoints load.  Underneath there is no torch_geometric, torch_scatter or
+Triton: one autograd node runs the whole network through ``gatres_model_forward`` / ``gatres_model_backward``
+(include/gatres.h).  There is no CPU path; tensors must live on the ROCm device.
+"""
+from __future__ import annotations
+
+import math
+from typing import List, Optional
+
+import torch
+from torch import Tensor, nn
+
+from . import _native
+from .graph_plan import GraphPlan, PlanCache
+
+
+# ----------------------------------------------------------------------------------------------
+# parameter containers with PyG's names / shapes / initialisers
+# ----------------------------------------------------------------------------------------------
+def _glorot_(t: Tensor) -> None:
+    stdv = math.sqrt(6.0 / (t.size(-2) + t.size(-1)))
+    with torch.no_grad():
+        t.uniform_(-stdv, stdv)
+
+
+class Linear(nn.Module):
+    """Parameter holder for ``torch_geometric.nn.dense.linear.Linear`` (GraphModels.py:11,477,484)."""
+
+    def __init__(self, in_channels: int, out_channels: int, bias: bool = True, weight_initializer: Optional[str] = None):
+        super().__init__()
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.weight_initializer = weight_initializer
+        self.weight = nn.Parameter(torch.empty(out_channels, in_channels))
+        self.bias = nn.Parameter(torch.empty(out_channels)) if bias else None
+        self.reset_parameters()
+
+    def reset_parameters(self) -> None:
+        if self.weight_initializer == "glorot":
+            _glorot_(self.weight)
+        else:  # PyG default: kaiming_uniform(a=sqrt(5)) == U(+-1/sqrt(fan_in))
+            bound = 1.0 / math.sqrt(self.in_channels)
+            with torch.no_grad():
+                self.weight.uniform_(-bound, bound)
+        if self.bias is not None:
+            bound = 1.0 / math.sqrt(self.in_channels)
+            with torch.no_grad():
+                self.bias.uniform_(-bound, bound)
+
+    def extra_repr(self) -> str:
+        return f"{self.in_channels}, {self.out_channels}, bias={self.bias is not None}"
+
+
+class GATConv(nn.Module):
+    """Parameter holder for ``torch_geometric.nn.GATConv(in, out, heads, concat)`` as the reference builds it
+    (GraphModels.py:458-459: edge_dim=None, add_self_loops=True, negative_slope=0.2, dropout=0, bias=True).
+    ``lin_dst`` aliases ``lin_src`` exactly as PyG 2.3 does, so both keys appear in the state_dict."""
+
+    def __init__(self, in_channels: int, out_channels: int, heads: int = 1, concat: bool = True):
+        super().__init__()
+        if not concat and heads != 1:
+            raise ValueError("the gfx950 engine implements concat=False only for heads=1 (GATRes' conv2)")
+        self.in_channels, self.out_channels, self.heads, self.concat = in_channels, out_channels, heads, concat
+        self.lin_src = Linear(in_channels, heads * out_channels, bias=False, weight_initializer="glorot")
+        self.lin_dst = self.lin_src
+        self.att_src = nn.Parameter(torch.empty(1, heads, out_channels))
+        self.att_dst = nn.Parameter(torch.empty(1, heads, out_channels))
+        self.bias = nn.Parameter(torch.empty(heads * out_channels if concat else out_channels))
+        self.reset_parameters()
+
+    def reset_parameters(self) -> None:
+        self.lin_src.reset_parameters()
+        _glorot_(self.att_src)
+        _glorot_(self.att_dst)
+        with torch.no_grad():
+            self.bias.zero_()
+
+    def _load_from_state_dict(self, state_dict, prefix, *args, **kwargs):
+        # PyG >= 2.5 stores the shared projection once as `lin.weight`
+        k = prefix + "lin.weight"
+        if k in state_dict:
+            w = state_dict.pop(k)
+            state_dict.setdefault(prefix + "lin_src.weight", w)
+            state_dict.setdefault(prefix + "lin_dst.weight", w)
+        super()._load_from_state_dict(state_dict, prefix, *args, **kwargs)
+
+    def extra_repr(self) -> str:
+        return f"{self.in_channels}, {self.out_channels}, heads={self.heads}"
+
+
+class SimpleConv(nn.Module):
+    """Marker for ``torch_geometric.nn.conv.SimpleConv(aggr='mean')`` (no parameters; GraphModels.py:460)."""
+
+    def __init__(self, aggr: str = "mean"):
+        super().__init__()
+        if aggr != "mean":
+            raise ValueError("only aggr='mean' is used by GATRes")
+        self.aggr = aggr
+
+
+class GResBlockMeanConv(nn.Module):
+    """GraphModels.py:454-468.  The block's arithmetic runs inside ``GATResMeanConv``'s fused launch sequence."""
+
+    def __init__(self, in_dim: int, out_dim: int, hc: int):
+        super().__init__()
+        self.conv1 = GATConv(in_dim, hc, 2, concat=True)
+        self.conv2 = GATConv(hc * 2, out_dim, 1, concat=False)
+        self.mean_conv = SimpleConv(aggr="mean")
+
+
+# ----------------------------------------------------------------------------------------------
+# the autograd node
+# ----------------------------------------------------------------------------------------------
+class _GATResFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, module: "GATResMeanConv", plan: GraphPlan, x: Tensor, *params: Tensor) -> Tensor:
+        lib = _native.load()
+        N = plan.num_nodes
+        needs_grad = torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in params))
+        out = torch.empty((N, 1), dtype=torch.float32, device=x.device)
+        scratch = module._scratch_for(plan)
+        saved = None
+        if needs_grad:
+            saved = torch.empty(module._saved_floats(plan), dtype=torch.float32, device=x.device)
+        stream = _native.current_stream(x.device)
+        _native.check(lib.gatres_model_forward(module._cmodel_ref(), plan.ref(), module._flat.data_ptr(), x.data_ptr(),
+                                               None, out.data_ptr(), _native.ptr(saved), scratch.data_ptr(), stream),
+                      "gatres_model_forward")
+        ctx.module, ctx.plan, ctx.saved_acts = module, plan, saved
+        ctx.save_for_backward(x)
+        ctx.param_shapes = [p.shape for p in params]
+        return out
+
+    @staticmethod
+    def backward(ctx, g_out: Tensor):
+        module, plan, saved = ctx.module, ctx.plan, ctx.saved_acts
+        (x,) = ctx.saved_tensors
+        if saved is None:
+            raise RuntimeError("backward through a forward that ran without grad")
+        lib = _native.load()
+        g_out = g_out.contiguous()
+        if g_out.dtype != torch.float32:
+            raise ValueError("grad_output must be float32")
+        grads = torch.empty(module._flat.numel(), dtype=torch.float32, device=x.device)
+        g_x = torch.empty_like(x) if ctx.needs_input_grad[2] else None
+        scratch = module._scratch_for(plan)
+        stream = _native.current_stream(x.device)
+        _native.check(lib.gatres_model_backward(module._cmodel_ref(), plan.ref(), module._flat.data_ptr(), x.data_ptr(),
+                                                None, g_out.data_ptr(), saved.data_ptr(), scratch.data_ptr(),
+                                                grads.data_ptr(), _native.ptr(g_x), stream), "gatres_model_backward")
+        outs: List[Optional[Tensor]] = [None, None, g_x]
+        off = 0
+        for shape in ctx.param_shapes:
+            n = int(math.prod(shape))
+            outs.append(grads[off:off + n].view(shape))
+            off += n
+        return tuple(outs)
+
+
+# ----------------------------------------------------------------------------------------------
+# the model
+# ----------------------------------------------------------------------------------------------
+class GATResMeanConv(nn.Module):
+    """GraphModels.py:471-494.  ``gatres_small`` = (num_blocks=15, nc=32), ``gatres_large`` = (25, 128)
+    (ConfigModels.py:22-42)."""
+
+    def __init__(self, name: str = "GATResMeanConv", num_blocks: int = 5, nc: int = 32):
+        super().__init__()
+        if nc < 4 or nc > 128 or (nc & (nc - 1)):
+            raise ValueError(f"nc={nc}: the gfx950 kernels support powers of two in [4, 128]")
+        self.num_blocks = num_blocks
+        self.nc = nc
+        self.lin0 = Linear(1, nc)
+        self.blocks = nn.ModuleList()
+        self.name = name
+        for _ in range(self.num_blocks):
+            self.blocks.append(GResBlockMeanConv(nc, nc, nc))
+        self.lin1 = Linear(nc, 1)
+        self._flat: Optional[Tensor] = None
+        self._plans = PlanCache()
+        self._scratch = {}
+        self._cmodel = _native.GatresModel(num_blocks, nc)
+        self._flatten_parameters()
+
+    # ---- flat parameter storage (state_dict order == include/gatres.h layout) ------------------
+    def _flatten_parameters(self) -> None:
+        params = list(self.parameters())
+        total = sum(p.numel() for p in params)
+        expect = 2 * self.nc + self.num_blocks * (9 * self.nc + 4 * self.nc * self.nc) + self.nc + 1
+        if total != expect:
+            raise RuntimeError(f"parameter count {total} != layout {expect}")
+        for p in params:
+            if p.dtype != torch.float32:
+                raise ValueError("the gfx950 engine computes in float32; do not cast the module")
+        flat = torch.empty(total, dtype=torch.float32, device=params[0].device)
+        off = 0
+        with torch.no_grad():
+            for p in params:
+                n = p.numel()
+                flat[off:off + n].copy_(p.detach().reshape(-1))
+                p.data = flat[off:off + n].view(p.shape)
+                off += n
+        self._flat = flat
+        self._scratch = {}
+
+    def _flat_is_current(self) -> bool:
+        flat = self._flat
+        if flat is None:
+            return False
+        off = 0
+        base = flat.data_ptr()
+        for p in self.parameters():
+            if p.data_ptr() != base + 4 * off:
+                return False
+            off += p.numel()
+        return True
+
+    def _apply(self, fn, *args, **kwargs):
+        out = super()._apply(fn, *args, **kwargs)
+        self._flatten_parameters()
+        self._plans.clear()
+        return out
+
+    @property
+    def flat_parameters(self) -> Tensor:
+        """The [P] fp32 buffer every parameter is a view of (state_dict order)."""
+        if not self._flat_is_current():
+            self._flatten_parameters()
+        return self._flat
+
+    # ---- engine plumbing -------------------------------------------------------------------
+    def _cmodel_ref(self):
+        import ctypes
+        return ctypes.byref(self._cmodel)
+
+    def _saved_floats(self, plan: GraphPlan) -> int:
+        lib = _native.load()
+        n = lib.gatres_saved_floats(self._cmodel_ref(), plan.num_nodes, plan.num_edges_gat)
+        if n < 0:
+            _native.check(int(n), "gatres_saved_floats")
+        return int(n)
+
+    def _scratch_for(self, plan: GraphPlan) -> Tensor:
+        key = (plan.num_nodes, plan.num_edges_gat, str(plan.device))
+        buf = self._scratch.get(key)
+        if buf is None:
+            lib = _native.load()
+            n = lib.gatres_scratch_floats(self._cmodel_ref(), plan.num_nodes, plan.num_edges_gat)
+            if n < 0:
+                _native.check(int(n), "gatres_scratch_floats")
+            self._scratch = {key: torch.empty(int(n), dtype=torch.float32, device=plan.device)}
+            buf = self._scratch[key]
+        return buf
+
+    def plan_for(self, edge_index: Tensor, num_nodes: int) -> GraphPlan:
+        return self._plans.get(edge_index, num_nodes)
+
+    # ---- reference surface -----------------------------------------------------------------
+    def forward(self, x: Tensor, edge_index: Tensor, batch: Optional[Tensor] = None,
+                edge_attr: Optional[Tensor] = None) -> Tensor:
+        if edge_attr is not None:
+            raise ValueError("GATRes is configured with use_data_edge_attrs=None (ConfigModels.py:38); "
+                             "edge_attr must be None")
+        if x.dim() != 2 or x.shape[1] != 1:
+            raise ValueError(f"x must be [N, 1], got {tuple(x.shape)}")
+        _native.require_gpu_tensor(x, "x")
+        if not self._flat_is_current():
+            self._flatten_parameters()
+        if self._flat.device != x.device:
+            raise ValueError(f"model is on {self._flat.device}, x on {x.device}")
+        plan = self._plans.get(edge_index, x.shape[0])
+        return _GATResFunction.apply(self, plan, x, *self.parameters())

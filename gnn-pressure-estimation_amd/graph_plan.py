@@ -1,0 +1,97 @@
+"""Graph plan (K0): the per-topology CSR structures the HIP kernels walk.
+
+PyG re-derives the self-loop-augmented edge list inside every ``GATConv.forward`` call
+(remove_self_loops -> boolean indexing -> device-to-host sync; 30 times per forward of gatres_small,
+reference GraphModels.py:464-465).  A WDN batch has the same topology every iteration, so the plan is built
+once (``gatres_graph_build_host``) and cached on the content of ``edge_index``.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, Tuple
+
+import torch
+
+from . import _native
+
+
+class GraphPlan:
+    """Device-resident destination-/source-sorted CSR of one (batched) topology."""
+
+    def __init__(self, edge_index: torch.Tensor, num_nodes: int, device=None):
+        if edge_index.dim() != 2 or edge_index.shape[0] != 2:
+            raise ValueError(f"edge_index must be [2, E], got {tuple(edge_index.shape)}")
+        if edge_index.dtype != torch.int64:
+            raise ValueError(f"edge_index must be int64 (PyG convention), got {edge_index.dtype}")
+        if num_nodes <= 0:
+            raise ValueError("num_nodes must be positive")
+        device = torch.device(device if device is not None else edge_index.device)
+        lib = _native.load()
+        ei_host = edge_index.detach().to("cpu").contiguous()
+        E = int(ei_host.shape[1])
+        N = int(num_nodes)
+        e_gat = C.c_int64(0)
+        _native.check(lib.gatres_graph_count_host(ei_host.data_ptr(), E, N, C.byref(e_gat)), "gatres_graph_count_host")
+        Eg = int(e_gat.value)
+        i32 = dict(dtype=torch.int32)
+        host = {
+            "rowptr": torch.empty(N + 1, **i32), "col": torch.empty(Eg, **i32),
+            "t_rowptr": torch.empty(N + 1, **i32), "t_eid": torch.empty(Eg, **i32), "t_dst": torch.empty(Eg, **i32),
+            "m_rowptr": torch.empty(N + 1, **i32), "m_col": torch.empty(max(E, 1), **i32),
+            "mt_rowptr": torch.empty(N + 1, **i32), "mt_dst": torch.empty(max(E, 1), **i32),
+        }
+        _native.check(lib.gatres_graph_build_host(ei_host.data_ptr(), E, N, *[t.data_ptr() for t in host.values()]),
+                      "gatres_graph_build_host")
+        self.num_nodes, self.num_edges_gat, self.num_edges_mean = N, Eg, E
+        self.device = device
+        self.arrays: Dict[str, torch.Tensor] = {k: v.to(device) for k, v in host.items()}
+        self.c = _native.GatresGraph(N, Eg, E, 0, *[self.arrays[k].data_ptr() for k in host.keys()])
+
+    def ref(self):
+        return C.byref(self.c)
+
+    def node_ptr_for(self, nodes_per_graph) -> torch.Tensor:
+        """int32 [B+1] node offsets for the device mask sampler."""
+        off = [0]
+        for n in nodes_per_graph:
+            off.append(off[-1] + int(n))
+        if off[-1] != self.num_nodes:
+            raise ValueError("nodes_per_graph does not add up to num_nodes")
+        return torch.tensor(off, dtype=torch.int32, device=self.device)
+
+
+class PlanCache:
+    """edge_index -> GraphPlan.  Key = (device content hash, E, N); the hash is one small kernel plus an 8-byte
+    read-back, against PyG's ~30 boolean-index syncs per forward.  A tensor object already seen (same storage,
+    same version counter) skips the hash."""
+
+    def __init__(self, max_entries: int = 16):
+        self.max_entries = max_entries
+        self._by_hash: Dict[Tuple[int, int, int, str], GraphPlan] = {}
+        self._by_identity: Dict[Tuple[int, int, int, int, str], GraphPlan] = {}
+
+    def clear(self) -> None:
+        self._by_hash.clear()
+        self._by_identity.clear()
+
+    def get(self, edge_index: torch.Tensor, num_nodes: int) -> GraphPlan:
+        _native.require_gpu_tensor(edge_index, "edge_index", torch.int64)
+        ident = (edge_index.data_ptr(), edge_index._version, int(edge_index.shape[1]), int(num_nodes),
+                 str(edge_index.device))
+        plan = self._by_identity.get(ident)
+        if plan is not None and getattr(plan, "_src_ref", None) is edge_index:
+            return plan
+        lib = _native.load()
+        h = torch.zeros(1, dtype=torch.int64, device=edge_index.device)
+        _native.check(lib.gatres_edge_index_hash(edge_index.data_ptr(), int(edge_index.shape[1]), h.data_ptr(),
+                                                 _native.current_stream(edge_index.device)), "gatres_edge_index_hash")
+        key = (int(h.item()), int(edge_index.shape[1]), int(num_nodes), str(edge_index.device))
+        plan = self._by_hash.get(key)
+        if plan is None:
+            if len(self._by_hash) >= self.max_entries:
+                self.clear()
+            plan = GraphPlan(edge_index, num_nodes)
+            self._by_hash[key] = plan
+        plan._src_ref = edge_index        # identity fast path is valid only while this exact tensor is alive
+        self._by_identity = {ident: plan}
+        return plan

@@ -1,0 +1,160 @@
+"""Native training step for GATRes: the reference's inner loop body (train.py:159-190) as one stream-ordered
+launch sequence -- device mask sampling (auxil.py:143-182), ``x[mask] = 0``, forward, MSE on the masked nodes,
+backward, [RCCL gradient all-reduce], Adam(lr, weight_decay) -- captured once into a hipGraph and replayed.
+
+Data-parallel: one process per GPU, snapshots sharded by graph across ranks, every rank holds the same topology
+plan and an identical replica of the flat parameter vector; the only exchange is ONE all-reduce of the flat fp32
+gradient per step (RCCL over xGMI; `torch.distributed` backend "nccl"), after which each rank applies the same Adam
+update with the gradient scaled by 1/world_size.  Equal masked-node counts per graph make the average of per-rank
+mean-losses equal the global-batch mean loss, so the result matches single-process training on the global batch.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Sequence
+
+import torch
+
+from . import _native
+from .graph_models import GATResMeanConv
+from .graph_plan import GraphPlan
+
+PHASE_MASK, PHASE_FORWARD, PHASE_BACKWARD, PHASE_ADAM = 1, 2, 4, 8
+
+
+class _TrainStepC(C.Structure):
+    """gatres_train_step_t"""
+    _fields_ = [("model", _native.GatresModel), ("graph", C.POINTER(_native.GatresGraph)),
+                ("params", C.c_void_p), ("grads", C.c_void_p), ("exp_avg", C.c_void_p), ("exp_avg_sq", C.c_void_p),
+                ("step_counter", C.c_void_p), ("x", C.c_void_p), ("y", C.c_void_p), ("mask", C.c_void_p),
+                ("node_ptr", C.c_void_p), ("num_graphs", C.c_int32), ("phases", C.c_int32),
+                ("mask_rate", C.c_double), ("seed", C.c_uint64),
+                ("out", C.c_void_p), ("g_out", C.c_void_p), ("loss", C.c_void_p), ("saved", C.c_void_p),
+                ("scratch", C.c_void_p),
+                ("lr", C.c_double), ("beta1", C.c_double), ("beta2", C.c_double), ("eps", C.c_double),
+                ("weight_decay", C.c_double), ("grad_scale", C.c_float), ("reserved", C.c_int32)]
+
+
+class GATResTrainer:
+    """Owns the static buffers of one (model, topology, batch size) and runs training steps on them.
+
+    ``step(x, y)`` draws a fresh device-side mask; ``step(x, y, mask=...)`` uses the caller's mask (bool/uint8 [N]),
+    e.g. one produced by the reference's host sampler, for bit-for-bit comparable runs."""
+
+    def __init__(self, model: GATResMeanConv, edge_index: torch.Tensor, num_nodes: int,
+                 nodes_per_graph: Optional[Sequence[int]] = None, lr: float = 5e-4, weight_decay: float = 6e-6,
+                 betas=(0.9, 0.999), eps: float = 1e-8, mask_rate: float = 0.95, seed: int = 0,
+                 process_group=None, use_graph: bool = True):
+        self.lib = _native.load()
+        self.model = model
+        params = model.flat_parameters
+        if not params.is_cuda:
+            raise ValueError("move the model to the ROCm device first; this engine has no CPU path")
+        dev = params.device
+        self.device = dev
+        self.plan: GraphPlan = GraphPlan(edge_index, num_nodes, device=dev)
+        N = num_nodes
+        self.N = N
+        self.P = params.numel()
+        f32 = dict(dtype=torch.float32, device=dev)
+        self.grads = torch.zeros(self.P, **f32)
+        self.exp_avg = torch.zeros(self.P, **f32)
+        self.exp_avg_sq = torch.zeros(self.P, **f32)
+        self.step_counter = torch.zeros(2, dtype=torch.int64, device=dev)
+        self.x = torch.zeros(N, **f32)
+        self.y = torch.zeros(N, **f32)
+        self.mask = torch.zeros(N, dtype=torch.uint8, device=dev)
+        self.out = torch.zeros(N, **f32)
+        self.g_out = torch.zeros(N, **f32)
+        self.loss = torch.zeros(1, **f32)
+        self.saved = torch.empty(model._saved_floats(self.plan), **f32)
+        self.scratch = model._scratch_for(self.plan)
+        self.node_ptr = self.plan.node_ptr_for(nodes_per_graph) if nodes_per_graph is not None else None
+        self.num_graphs = len(nodes_per_graph) if nodes_per_graph is not None else 0
+        self.hparams = dict(lr=lr, weight_decay=weight_decay, beta1=betas[0], beta2=betas[1], eps=eps)
+        self.mask_rate, self.seed = mask_rate, seed
+        self.pg = process_group
+        self.world = 1
+        if process_group is not None or (torch.distributed.is_available() and torch.distributed.is_initialized()):
+            self.world = torch.distributed.get_world_size(process_group)
+        self.use_graph = use_graph
+        self._graphs = {}
+        self._params_ptr = params.data_ptr()
+
+    # ------------------------------------------------------------------------------------------
+    def _desc(self, phases: int, device_mask: bool) -> _TrainStepC:
+        m = self.model
+        params = m.flat_parameters
+        if params.data_ptr() != self._params_ptr:
+            raise RuntimeError("the model's parameter storage moved (e.g. .to()/deepcopy); build a new GATResTrainer")
+        h = self.hparams
+        return _TrainStepC(
+            _native.GatresModel(m.num_blocks, m.nc), C.pointer(self.plan.c), params.data_ptr(), self.grads.data_ptr(),
+            self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr(), self.step_counter.data_ptr(), self.x.data_ptr(),
+            self.y.data_ptr(), self.mask.data_ptr(),
+            self.node_ptr.data_ptr() if (device_mask and self.node_ptr is not None) else None,
+            self.num_graphs, phases, self.mask_rate, self.seed, self.out.data_ptr(), self.g_out.data_ptr(),
+            self.loss.data_ptr(), self.saved.data_ptr(), self.scratch.data_ptr(), h["lr"], h["beta1"], h["beta2"],
+            h["eps"], h["weight_decay"], 1.0 / self.world, 0)
+
+    def _enqueue(self, phases: int, device_mask: bool) -> None:
+        ts = self._desc(phases, device_mask)
+        _native.check(self.lib.gatres_train_step(C.byref(ts), _native.current_stream(self.device)),
+                      "gatres_train_step")
+
+    def _run(self, phases: int, device_mask: bool) -> None:
+        if not self.use_graph:
+            self._enqueue(phases, device_mask)
+            return
+        key = (phases, device_mask)
+        g = self._graphs.get(key)
+        if g is None:
+            # warm-up launch outside capture (module load, lazy init), then capture the same sequence once
+            state = (self.step_counter.clone(), self.model.flat_parameters.clone(), self.exp_avg.clone(),
+                     self.exp_avg_sq.clone())
+            self._enqueue(phases, device_mask)
+            torch.cuda.synchronize(self.device)
+            self.step_counter.copy_(state[0]); self.model.flat_parameters.copy_(state[1])
+            self.exp_avg.copy_(state[2]); self.exp_avg_sq.copy_(state[3])
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                self._enqueue(phases, device_mask)
+            self.step_counter.copy_(state[0]); self.model.flat_parameters.copy_(state[1])
+            self.exp_avg.copy_(state[2]); self.exp_avg_sq.copy_(state[3])
+            self._graphs[key] = g
+        g.replay()
+
+    # ------------------------------------------------------------------------------------------
+    def load_batch(self, x: torch.Tensor, y: torch.Tensor, mask: Optional[torch.Tensor] = None) -> None:
+        """Stage a batch into the static buffers (async copies on the current stream)."""
+        self.x.copy_(x.reshape(-1), non_blocking=True)
+        self.y.copy_(y.reshape(-1), non_blocking=True)
+        if mask is not None:
+            self.mask.copy_(mask.reshape(-1).to(torch.uint8), non_blocking=True)
+
+    def run_step(self, device_mask: bool = True) -> None:
+        """One optimisation step on the staged batch.  Nothing is synchronised; read ``self.loss`` afterwards."""
+        if device_mask and self.node_ptr is None:
+            raise ValueError("device mask sampling needs nodes_per_graph at construction")
+        if self.world == 1:
+            self._run(PHASE_MASK | PHASE_FORWARD | PHASE_BACKWARD | PHASE_ADAM, device_mask)
+        else:
+            self._run(PHASE_MASK | PHASE_FORWARD | PHASE_BACKWARD, device_mask)
+            torch.distributed.all_reduce(self.grads, op=torch.distributed.ReduceOp.SUM, group=self.pg)
+            self._run(PHASE_ADAM, device_mask)
+
+    def step(self, x: torch.Tensor, y: torch.Tensor, mask: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """Reference-shaped call: one iteration of train.py:159-190.  Returns the (device) loss tensor."""
+        self.load_batch(x, y, mask)
+        self.run_step(device_mask=mask is None)
+        return self.loss
+
+    def forward_backward(self, x: torch.Tensor, y: torch.Tensor, mask: torch.Tensor) -> torch.Tensor:
+        """Forward + loss + gradients only (no optimiser update); gradients land in ``self.grads``."""
+        self.load_batch(x, y, mask)
+        self._enqueue(PHASE_FORWARD | PHASE_BACKWARD, False)
+        return self.loss
+
+    @property
+    def optimizer_step(self) -> int:
+        return int(self.step_counter[0].item())

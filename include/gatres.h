@@ -1,0 +1,256 @@
+/*
+ * gatres.h -- C-ABI of the MI355X (gfx950) GATRes message-passing engine.
+ *
+ * Drop-in boundary for ONE hot path of DiTEC-project/gnn-pressure-estimation: the
+ * GATConv-with-residual stack `GATResMeanConv` (reference gnn_pressure_estimation/GraphModels.py:454-494),
+ * forward + backward, and the training step around it (train.py:159-190).  The reference has no FFI of its
+ * own for this path (it is pure Python over torch_geometric); these entry points are what a ctypes binding
+ * on the reference side would call (INTEGRATION.md shows that binding).
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless the name ends in _host;
+ *   - feature matrices are row-major fp32, [rows, cols] with cols contiguous;
+ *   - graph index arrays are int32;
+ *   - `stream` is a hipStream_t passed as void*; every call only enqueues work on it (no allocation, no
+ *     synchronisation) so a caller may capture any sequence of calls into a hipGraph;
+ *   - return value: 0 = ok; < 0 = argument error (GATRES_E_*); > 0 = hipError_t from the launch.
+ *
+ * Supported widths: nc (hidden channels) a power of two, 4 <= nc <= 128  (gatres_small: 32, gatres_large: 128).
+ */
+#ifndef GATRES_H
+#define GATRES_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GATRES_ABI_VERSION 1
+
+#define GATRES_E_BADARG      (-1)  /* null pointer, negative size, misaligned pointer            */
+#define GATRES_E_UNSUPPORTED (-2)  /* width not supported by the gfx950 kernels                  */
+#define GATRES_E_GRAPH       (-3)  /* edge endpoint out of range while building the graph plan   */
+
+/* --------------------------------------------------------------------------------------------------------
+ * Graph plan (K0).  Replaces what PyG re-derives inside every GATConv.forward call --
+ * remove_self_loops + add_self_loops (torch_geometric.utils.loop; reference call sites
+ * GraphModels.py:464-465) -- and the scatter indices of GATConv / SimpleConv (GraphModels.py:464-466).
+ * Built once per topology.
+ *   gat CSR   : edges of edge_index with src != dst, then one self loop per node appended (PyG order),
+ *               stably sorted by destination.              rowptr[N+1], col[E'] = source node.
+ *   gat CSR^T : the same edge list stably sorted by source. t_rowptr[N+1], t_eid[E'] = position of the
+ *               edge in the destination-sorted list, t_dst[E'] = destination node.
+ *   mean CSR  : the ORIGINAL edge_index (self loops kept, none added) sorted by destination (SimpleConv).
+ *   mean CSR^T: sorted by source.  mt_dst[E] = destination node.
+ * ------------------------------------------------------------------------------------------------------ */
+typedef struct gatres_graph {
+  int32_t num_nodes;        /* N                                         */
+  int32_t num_edges_gat;    /* E' = #(src != dst) + N                    */
+  int32_t num_edges_mean;   /* E  = edge_index.shape[1]                  */
+  int32_t reserved;
+  const int32_t* rowptr;
+  const int32_t* col;
+  const int32_t* t_rowptr;
+  const int32_t* t_eid;
+  const int32_t* t_dst;
+  const int32_t* m_rowptr;
+  const int32_t* m_col;
+  const int32_t* mt_rowptr;
+  const int32_t* mt_dst;
+} gatres_graph_t;
+
+/* Host-side plan builder (runs on the CPU, once per topology).  edge_index_host: int64 [2, E] row-major as
+ * torch stores it.  Step 1: count -> E'.  Step 2: fill caller-allocated HOST arrays sized from that count. */
+int gatres_graph_count_host(const int64_t* edge_index_host, int64_t num_edges, int64_t num_nodes,
+                            int64_t* num_edges_gat_out);
+int gatres_graph_build_host(const int64_t* edge_index_host, int64_t num_edges, int64_t num_nodes,
+                            int32_t* rowptr, int32_t* col, int32_t* t_rowptr, int32_t* t_eid, int32_t* t_dst,
+                            int32_t* m_rowptr, int32_t* m_col, int32_t* mt_rowptr, int32_t* mt_dst);
+
+/* 64-bit content hash of an int64 [2,E] DEVICE edge_index (for plan caching); hash_out: device uint64[1],
+ * must be zeroed by the caller on the same stream before the call. */
+int gatres_edge_index_hash(const int64_t* edge_index, int64_t num_edges, uint64_t* hash_out, void* stream);
+
+/* --------------------------------------------------------------------------------------------------------
+ * Per-op kernels.  Each replaces the PyG op sequence named in its comment.
+ * ------------------------------------------------------------------------------------------------------ */
+
+/* lin0: PyG Linear(1, nc) (GraphModels.py:477,487).  out[n,c] = xm[n]*w[c] + b[c], where xm[n] = 0 if
+ * mask != NULL and mask[n] != 0 (the caller-side `data.x[batch_mask] = 0`, train.py:174). */
+int gatres_lin0_fwd(const float* x, const uint8_t* mask, const float* w, const float* b, float* out,
+                    int32_t num_nodes, int32_t nc, void* stream);
+
+/* K1: GATConv's lin_src projection + attention logits (GATConv.forward:
+ *   h = lin(x).view(N,H,C); a_src = (h*att_src).sum(-1); a_dst = (h*att_dst).sum(-1)).
+ * fp32 MFMA (v_mfma_f32_16x16x4_f32).  W is [H*C, K] row-major (PyG Linear.weight). */
+int gatres_proj_attn_fwd(const float* x, const float* W, const float* att_src, const float* att_dst,
+                         float* h, float* a_src, float* a_dst,
+                         int32_t num_nodes, int32_t K, int32_t H, int32_t C, void* stream);
+
+/* K2: GATConv edge scoring + per-destination softmax + weighted neighbour sum + bias (+ReLU)
+ * (GATConv.edge_update / torch_geometric.utils.softmax / message / aggregate; heads concatenated;
+ * heads=1, concat=False is the H=1 case).  alpha[E',H] is written for the backward pass. */
+int gatres_gat_aggregate_fwd(const gatres_graph_t* g, const float* h, const float* a_src, const float* a_dst,
+                             const float* bias, float* out, float* alpha,
+                             int32_t H, int32_t C, int32_t apply_relu, void* stream);
+
+/* K3: SimpleConv(aggr="mean")(y) + x0, then ReLU (GraphModels.py:466-467). */
+int gatres_mean_residual_relu_fwd(const gatres_graph_t* g, const float* y, const float* x0, float* out,
+                                  int32_t C, void* stream);
+
+/* lin1: PyG Linear(nc, 1) (GraphModels.py:484,492).  out[n] = sum_c x[n,c]*w[c] + b[0]. */
+int gatres_lin1_fwd(const float* x, const float* w, const float* b, float* out,
+                    int32_t num_nodes, int32_t nc, void* stream);
+
+/* ---- backward -------------------------------------------------------------------------------------- */
+
+/* Gradient partial sums.  Every reduction over nodes is done by `num_slabs` waves, each writing its partial
+ * into its own slab of a [num_slabs, slab_stride] fp32 buffer at the parameter's flat offset; a final
+ * gatres_reduce_slabs sums the slabs in a fixed order (bitwise reproducible, no atomics). */
+int gatres_reduce_slabs(const float* slabs, int32_t num_slabs, int64_t slab_stride, int64_t count,
+                        float* out, void* stream);
+
+/* lin1 backward.  g_x[n,c] = g_out[n]*w[c], masked by (x[n,c] > 0) when relu_mask != 0 (x is the last block's
+ * post-ReLU output).  slab_w / slab_b: this parameter's position inside slab 0. */
+int gatres_lin1_bwd(const float* g_out, const float* x, const float* w, float* g_x,
+                    float* slab_w, float* slab_b, int32_t num_slabs, int64_t slab_stride,
+                    int32_t num_nodes, int32_t nc, int32_t relu_mask, void* stream);
+
+/* K3 backward.  g_pre is the gradient w.r.t. the block's pre-ReLU sum (already ReLU-masked by its producer);
+ * g_y[j] = sum over out-edges (j->i) of g_pre[i] / max(indeg(i), 1). */
+int gatres_mean_bwd(const gatres_graph_t* g, const float* g_pre, float* g_y, int32_t C, void* stream);
+
+/* K2 backward, destination-major pass: softmax / LeakyReLU backward per in-edge.
+ * g_e[E',H] (grad w.r.t. the raw score a_src[j]+a_dst[i]) and g_a_dst[N,H]. */
+int gatres_gat_aggregate_bwd_dst(const gatres_graph_t* g, const float* g_out, const float* h,
+                                 const float* alpha, const float* a_src, const float* a_dst,
+                                 float* g_e, float* g_a_dst, int32_t H, int32_t C, void* stream);
+
+/* K2 backward, source-major pass over CSR^T (atomics-free):
+ * g_a_src[j,h] = sum_out-edges g_e;  g_h[j] = sum alpha_e*g_out[i] + g_a_src (x) att_src + g_a_dst (x) att_dst. */
+int gatres_gat_aggregate_bwd_src(const gatres_graph_t* g, const float* g_out, const float* alpha,
+                                 const float* g_e, const float* g_a_dst, const float* att_src,
+                                 const float* att_dst, float* g_h, float* g_a_src,
+                                 int32_t H, int32_t C, void* stream);
+
+/* K1 backward, data gradient: g_x = g_h @ W (fp32 MFMA), W given TRANSPOSED as Wt[K, HC] row-major.
+ * Optional fused epilogue: g_x = (g_x + resid) masked by (relu_ref > 0)  (resid / relu_ref may be NULL). */
+int gatres_proj_bwd_dx(const float* g_h, const float* Wt, const float* resid, const float* relu_ref,
+                       float* g_x, int32_t num_nodes, int32_t K, int32_t HC, void* stream);
+
+/* K1 backward, weight gradient partials: slab[s][c*K+k] = sum over slab s's nodes of g_h[n,c]*x[n,k]. */
+int gatres_proj_bwd_dw(const float* g_h, const float* x, float* slab_W, int32_t num_slabs,
+                       int64_t slab_stride, int32_t num_nodes, int32_t K, int32_t HC, void* stream);
+
+/* Column reductions of one GATConv: partials of g_att_src[h,c] = sum_n g_a_src[n,h]*h[n,h,c], g_att_dst likewise,
+ * g_bias[hc] = sum_n g_out[n,hc]. */
+int gatres_conv_param_grads(const float* h, const float* g_a_src, const float* g_a_dst, const float* g_out,
+                            float* slab_att_src, float* slab_att_dst, float* slab_bias, int32_t num_slabs,
+                            int64_t slab_stride, int32_t num_nodes, int32_t H, int32_t C, void* stream);
+
+/* lin0 backward partials: g_w[c] = sum_n g[n,c]*xm[n], g_b[c] = sum_n g[n,c]. */
+int gatres_lin0_bwd(const float* g, const float* x, const uint8_t* mask, float* slab_w, float* slab_b,
+                    int32_t num_slabs, int64_t slab_stride, int32_t num_nodes, int32_t nc, void* stream);
+
+/* out[c*rows + r] = in[r*cols + c] for every GATConv weight of the flat parameter vector (see layout below). */
+int gatres_transpose_conv_weights(const float* params, float* wt, int32_t num_blocks, int32_t nc, void* stream);
+
+/* ---- caller side of the step (train.py:174-188) ---------------------------------------------------- */
+
+/* Per-graph random node mask with EXACTLY int(n_g*rate) ones per graph (utils/auxil.py:143-182), generated
+ * on the device.  node_ptr[B+1]: node offsets of the graphs; step_counter: device uint64[1] (read; combined
+ * with seed so a replayed hipGraph draws a fresh mask each step when the caller bumps the counter). */
+int gatres_mask_generate(const int32_t* node_ptr, int32_t num_graphs, double mask_rate, uint64_t seed,
+                         const uint64_t* step_counter, uint8_t* mask, void* stream);
+
+/* MSELoss(mean) over masked nodes + its gradient: loss[0] = mean_{mask}(out-y)^2, g_out[n] = mask ? 2(out-y)/M : 0. */
+int gatres_masked_mse(const float* out, const float* y, const uint8_t* mask, float* loss, float* g_out,
+                      int32_t num_nodes, void* stream);
+
+/* torch.optim.Adam step (weight_decay folded into the gradient), step counter on the device:
+ * step_counter is device uint64[2] = {step, internal ticket (must start at 0)}; the kernel uses step+1 for the
+ * bias corrections and then increments step.  grad_scale multiplies the gradient first (1/world_size). */
+int gatres_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq,
+                     uint64_t* step_counter, int64_t count, double lr, double beta1, double beta2, double eps,
+                     double weight_decay, float grad_scale, void* stream);
+
+/* --------------------------------------------------------------------------------------------------------
+ * Whole-network drivers: enqueue every kernel of GATResMeanConv.forward / its backward natively.
+ *
+ * Flat parameter layout (fp32, state_dict order; GraphModels.py:472-484, :455-460):
+ *   lin0.weight[nc]  lin0.bias[nc]
+ *   per block: conv1.att_src[2nc] conv1.att_dst[2nc] conv1.bias[2nc] conv1.lin.weight[2nc, nc]
+ *              conv2.att_src[nc]  conv2.att_dst[nc]  conv2.bias[nc]  conv2.lin.weight[nc, 2nc]
+ *   lin1.weight[nc]  lin1.bias[1]
+ * ------------------------------------------------------------------------------------------------------ */
+typedef struct gatres_model {
+  int32_t num_blocks;
+  int32_t nc;
+} gatres_model_t;
+
+int64_t gatres_param_count(int32_t num_blocks, int32_t nc);
+/* floats of forward state kept for backward / of scratch needed by forward+backward / slabs used. */
+int64_t gatres_saved_floats(const gatres_model_t* m, int32_t num_nodes, int32_t num_edges_gat);
+int64_t gatres_scratch_floats(const gatres_model_t* m, int32_t num_nodes, int32_t num_edges_gat);
+int32_t gatres_num_slabs(const gatres_model_t* m, int32_t num_nodes);
+
+/* out[N] = GATResMeanConv(x).  saved == NULL: inference (activations are not kept; scratch is reused per block). */
+int gatres_model_forward(const gatres_model_t* m, const gatres_graph_t* g, const float* params,
+                         const float* x, const uint8_t* mask, float* out, float* saved, float* scratch,
+                         void* stream);
+
+/* grads[P] = d loss / d params given g_out[N] = d loss / d out; g_x (may be NULL) = d loss / d x. */
+int gatres_model_backward(const gatres_model_t* m, const gatres_graph_t* g, const float* params,
+                          const float* x, const uint8_t* mask, const float* g_out, const float* saved,
+                          float* scratch, float* grads, float* g_x, void* stream);
+
+/* --------------------------------------------------------------------------------------------------------
+ * One reference training iteration (train.py:159-190) enqueued natively:
+ *   PHASE_MASK     device mask sampler (utils/auxil.py:166-182) -- skipped when node_ptr == NULL (caller's mask)
+ *   PHASE_FORWARD  x[mask] = 0 ; out = model(x) ; loss = MSE(out[mask], y[mask]) and d loss / d out
+ *   PHASE_BACKWARD grads = d loss / d params
+ *   PHASE_ADAM     torch.optim.Adam(lr, weight_decay) update, step counter on the device
+ * `phases` selects which of them a call enqueues, so a data-parallel caller can run its gradient all-reduce
+ * between BACKWARD and ADAM.  Everything is stream-ordered and allocation-free (hipGraph capturable).
+ * ------------------------------------------------------------------------------------------------------ */
+#define GATRES_PHASE_MASK     1
+#define GATRES_PHASE_FORWARD  2
+#define GATRES_PHASE_BACKWARD 4
+#define GATRES_PHASE_ADAM     8
+#define GATRES_PHASE_ALL      15
+
+typedef struct gatres_train_step {
+  gatres_model_t model;
+  const gatres_graph_t* graph;     /* HOST pointer to the plan struct (its members are device pointers) */
+  float* params;                   /* [P] flat parameters (layout above)                 */
+  float* grads;                    /* [P]                                                */
+  float* exp_avg;                  /* [P] Adam first moment                              */
+  float* exp_avg_sq;               /* [P] Adam second moment                             */
+  uint64_t* step_counter;          /* device uint64[2]: {optimizer step, ticket}         */
+  const float* x;                  /* [N] node inputs (z-normed pressures)               */
+  const float* y;                  /* [N] targets (== x before masking, train.py:162-163)*/
+  uint8_t* mask;                   /* [N] 1 = masked node                                */
+  const int32_t* node_ptr;         /* [B+1] graph node offsets, or NULL                  */
+  int32_t num_graphs;
+  int32_t phases;
+  double mask_rate;
+  uint64_t seed;
+  float* out;                      /* [N] predictions                                    */
+  float* g_out;                    /* [N] d loss / d out                                 */
+  float* loss;                     /* [1]                                                */
+  float* saved;                    /* gatres_saved_floats()                              */
+  float* scratch;                  /* gatres_scratch_floats()                            */
+  double lr, beta1, beta2, eps, weight_decay;
+  float grad_scale;                /* multiplies grads inside Adam (1/world_size)        */
+  int32_t reserved;
+} gatres_train_step_t;
+
+int gatres_train_step(const gatres_train_step_t* ts, void* stream);
+
+const char* gatres_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GATRES_H */

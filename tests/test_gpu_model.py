@@ -1,0 +1,225 @@
+"""Whole-path parity on the GPU: GATResMeanConv forward/backward and the training step against the CPU oracle,
+through the nn.Module surface the reference's train.py uses and through the native step driver.
+
+Tolerances (fp32): predictions within 1e-5 relative (north-star), gradients / updated weights within 1e-4
+relative (max-abs error over max-abs value of each tensor)."""
+import copy
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+REPORT = {}
+
+
+def relerr(a, b):
+    a, b = a.detach().double().cpu().reshape(-1), b.detach().double().cpu().reshape(-1)
+    return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
+
+
+def note(name, val):
+    REPORT[name] = val
+    d = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    try:
+        os.makedirs(d, exist_ok=True)
+        with open(os.path.join(d, "parity_report.json"), "w") as f:
+            json.dump(REPORT, f, indent=1, sort_keys=True)
+    except OSError:
+        pass
+
+
+def load_params(model, p):
+    sd = {}
+    for k, v in p.items():
+        sd[k] = v
+        if k.endswith("lin_src.weight"):
+            sd[k.replace("lin_src", "lin_dst")] = v
+    model.load_state_dict(sd)
+
+
+def build(pkg, oracle, nb, nc, seed):
+    p = oracle.init_params(nb, nc, seed=seed)
+    m = pkg.GATResMeanConv(num_blocks=nb, nc=nc)
+    load_params(m, p)
+    return m.cuda(), p
+
+
+def ctown_batch(pkg, bs, nodes=388, pipes=430):
+    return pkg.wdn_synth.make_batch(bs, nodes, pipes)
+
+
+@pytest.mark.parametrize("nb,nc,bs,nodes,pipes", [(2, 8, 3, 40, 47), (15, 32, 2, 388, 430), (3, 128, 2, 60, 70),
+                                                   (1, 4, 1, 9, 10), (0, 16, 2, 12, 14)])
+def test_forward_backward_parity(pkg, oracle, nb, nc, bs, nodes, pipes):
+    x, y, ei, mask = ctown_batch(pkg, bs, nodes, pipes)
+    model, p = build(pkg, oracle, nb, nc, seed=3)
+    # oracle fp32 + fp64
+    leaves = {k: v.clone().requires_grad_(True) for k, v in p.items()}
+    xin = x.clone(); xin[mask] = 0
+    out_ref = oracle.gatres_forward(leaves, xin, ei, num_blocks=nb)
+    loss_ref = torch.nn.functional.mse_loss(out_ref[mask], y[mask])
+    loss_ref.backward()
+    p64 = {k: v.double() for k, v in p.items()}
+    out64 = oracle.gatres_forward(p64, xin.double(), ei, num_blocks=nb)
+    # HIP through the reference call signature: model(x, edge_index, batch, edge_attr)
+    xd = xin.cuda()
+    out = model(xd, ei.cuda(), None, None)
+    assert out.shape == (x.shape[0], 1) and out.requires_grad
+    e_out, e_out64, e_ref64 = relerr(out, out_ref), relerr(out, out64), relerr(out_ref, out64)
+    note(f"fwd nb{nb} nc{nc}: hip-vs-oracle32 / hip-vs-oracle64 / oracle32-vs-oracle64", [e_out, e_out64, e_ref64])
+    assert e_out < 1e-5, (e_out, e_out64, e_ref64)
+    m = mask.cuda()
+    loss = torch.nn.functional.mse_loss(out[m], y.cuda()[m])
+    loss.backward()
+    assert relerr(loss, loss_ref) < 1e-5
+    worst = 0.0
+    for (k, ref), prm in zip(leaves.items(), model.parameters()):
+        assert prm.grad is not None and prm.grad.shape == ref.shape, k
+        e = relerr(prm.grad, ref.grad)
+        worst = max(worst, e)
+        assert e < 1e-4, (k, e)
+    note(f"bwd nb{nb} nc{nc}: worst param-grad rel err", worst)
+
+
+def test_module_surface_matches_reference(pkg, oracle):
+    m = pkg.GATResMeanConv(name="x", num_blocks=2, nc=8)
+    assert m.name == "x" and m.num_blocks == 2
+    assert [type(b).__name__ for b in m.blocks] == ["GResBlockMeanConv"] * 2
+    keys = set(m.state_dict().keys())
+    exp = set()
+    for k in oracle.param_shapes(2, 8):
+        exp.add(k)
+        if "lin_src" in k:
+            exp.add(k.replace("lin_src", "lin_dst"))
+    assert keys == exp
+    for k, s in oracle.param_shapes(2, 8).items():
+        assert tuple(m.state_dict()[k].shape) == s
+    # PyG >= 2.5 spelling of the shared projection
+    sd = {k.replace("lin_src.weight", "lin.weight"): v for k, v in m.state_dict().items() if "lin_dst" not in k}
+    m2 = pkg.GATResMeanConv(num_blocks=2, nc=8)
+    m2.load_state_dict(sd)
+    assert torch.equal(m2.flat_parameters, m.flat_parameters)
+    x, _, ei, _ = ctown_batch(pkg, 1, 20, 24)
+    m = m.cuda()
+    with pytest.raises(ValueError):
+        m(x, ei.cuda())                                   # CPU tensor: there is no CPU path
+    with pytest.raises(ValueError):
+        m(x.cuda(), ei.cuda(), None, torch.zeros(ei.shape[1], 1).cuda())
+    with pytest.raises(ValueError):
+        pkg.GATResMeanConv(num_blocks=1, nc=24)
+    with torch.no_grad():
+        o = m(x.cuda(), ei.cuda())
+    assert not o.requires_grad
+    m3 = copy.deepcopy(m)
+    assert relerr(m3(x.cuda(), ei.cuda()), o) == 0.0
+
+
+def test_drop_in_training_loop_with_torch_adam(pkg, oracle):
+    """The reference's loop body verbatim (train.py:160-188) on the HIP module vs the oracle, 4 iterations."""
+    nb, nc, bs = 4, 32, 4
+    model, p = build(pkg, oracle, nb, nc, seed=11)
+    ref = oracle.OracleTrainer(p)
+    opt = torch.optim.Adam(model.parameters(), lr=5e-4, weight_decay=6e-6)
+    snaps = pkg.wdn_synth.make_snapshots(16, 388, seed=5)
+    ei1 = pkg.wdn_synth.make_wdn_topology()
+    rng = np.random.RandomState(0)
+    for it in range(4):
+        y = pkg.wdn_synth.collate_snapshots(snaps, range(it * bs, (it + 1) * bs))
+        edge_index = pkg.wdn_synth.collate_edge_index(ei1, 388, bs)          # a fresh tensor per batch, like PyG
+        batch_mask = pkg.wdn_synth.generate_batch_mask([388] * bs, 0.95, rng)
+        l_ref, _ = ref.step(y.clone(), y, edge_index, batch_mask)
+        opt.zero_grad()
+        dx, dy, dei = y.clone().cuda(), y.cuda(), edge_index.cuda()
+        dx[batch_mask] = 0
+        out = model(dx, dei, None, None)
+        loss = torch.nn.functional.mse_loss(out[batch_mask], dy[batch_mask])
+        loss.backward()
+        opt.step()
+        assert relerr(loss, l_ref) < 1e-5, it
+    e = relerr(model.flat_parameters, ref.flat("params"))
+    note("drop-in 4 Adam steps: flat param rel err", e)
+    assert e < 1e-4
+
+
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_native_train_step_matches_oracle(pkg, oracle, use_graph):
+    nb, nc, bs = 15, 32, 2
+    model, p = build(pkg, oracle, nb, nc, seed=4)
+    ref = oracle.OracleTrainer(p)
+    ei = pkg.wdn_synth.collate_edge_index(pkg.wdn_synth.make_wdn_topology(), 388, bs)
+    tr = pkg.GATResTrainer(model, ei.cuda(), 388 * bs, nodes_per_graph=[388] * bs, use_graph=use_graph)
+    snaps = pkg.wdn_synth.make_snapshots(8, 388, seed=6)
+    rng = np.random.RandomState(1)
+    for it in range(3):
+        y = pkg.wdn_synth.collate_snapshots(snaps, range(it * bs, (it + 1) * bs))
+        mask = torch.from_numpy(pkg.wdn_synth.generate_batch_mask([388] * bs, 0.95, rng))
+        l_ref, o_ref = ref.step(y.clone(), y, ei, mask)
+        loss = tr.step(y.cuda(), y.cuda(), mask.cuda())
+        assert relerr(loss, l_ref) < 2e-5, it
+        assert relerr(tr.out, o_ref) < 2e-5, it
+        if it == 0:
+            g = relerr(tr.grads, ref.flat("grads"))
+            note(f"native step (graph={use_graph}) flat grad rel err", g)
+            assert g < 1e-4
+    assert tr.optimizer_step == 3
+    e = relerr(model.flat_parameters, ref.flat("params"))
+    note(f"native step (graph={use_graph}) 3 steps: flat param rel err", e)
+    assert e < 1e-4
+    assert relerr(model.state_dict()["lin0.weight"], ref.flat("params")[:nc]) < 1e-4   # the module sees the update
+    # device-side mask path: exact count per graph, loss finite, fresh mask per step
+    tr.step(y.cuda(), y.cuda())
+    m1 = tr.mask.clone()
+    tr.step(y.cuda(), y.cuda())
+    assert int(m1.sum()) == 2 * 368 and int(tr.mask.sum()) == 2 * 368 and not torch.equal(m1, tr.mask)
+    assert torch.isfinite(tr.loss).all()
+
+
+def test_edge_cases_and_determinism(pkg, oracle):
+    model, p = build(pkg, oracle, 2, 8, seed=9)
+    n = 30
+    cases = {
+        "no_edges": torch.zeros((2, 0), dtype=torch.int64),
+        "self_loops_dups_isolated": torch.tensor([[0, 1, 1, 2, 2, 5, 5, 7, 3, 3], [1, 0, 0, 2, 2, 6, 6, 7, 4, 4]]),
+        "hub": torch.stack([torch.arange(1, 29), torch.zeros(28, dtype=torch.int64)]),
+    }
+    x = torch.randn(n, 1)
+    for name, ei in cases.items():
+        ref = oracle.gatres_forward(p, x, ei)
+        out = model(x.cuda(), ei.cuda())
+        assert relerr(out, ref) < 1e-5, name
+        assert torch.equal(out, model(x.cuda(), ei.clone().cuda())), name      # bitwise reproducible
+    # K6 on the device: a batch equals the concatenation of its graphs
+    x2, _, ei2, _ = ctown_batch(pkg, 3, 50, 58)
+    one = pkg.wdn_synth.make_wdn_topology(50, 58)
+    whole = model(x2.cuda(), ei2.cuda())
+    parts = torch.cat([model(x2[i * 50:(i + 1) * 50].cuda(), one.cuda()) for i in range(3)])
+    assert torch.equal(whole, parts)
+
+
+def test_full_size_properties_bs32(pkg, oracle):
+    """BASELINE config 2 size (gatres_small, C-Town, bs=32): size-independent properties instead of the slow oracle."""
+    model, p = build(pkg, oracle, 15, 32, seed=3)
+    x, y, ei, mask = ctown_batch(pkg, 32)
+    dx, dei = x.cuda(), ei.cuda()
+    out = model(dx, dei)
+    assert torch.isfinite(out).all()
+    one = pkg.wdn_synth.make_wdn_topology()
+    first = model(dx[:388], one.cuda())
+    assert torch.equal(out[:388], first)                                        # block-diagonal independence
+    perm = torch.randperm(ei.shape[1], generator=torch.Generator().manual_seed(0))
+    assert relerr(model(dx, ei[:, perm].cuda()), out) < 1e-5                    # edge-order invariance
+    # gradient of a linear functional is linear in the upstream gradient
+    g1, g2 = torch.randn_like(out), torch.randn_like(out)
+    def grad_for(g):
+        model.zero_grad()
+        model(dx, dei).backward(g)
+        return torch.cat([q.grad.reshape(-1) for q in model.parameters()]).clone()
+    ga, gb, gab = grad_for(g1), grad_for(g2), grad_for(g1 + 2 * g2)
+    assert relerr(gab, ga + 2 * gb) < 1e-4
+    # the oracle on one graph of the batch pins the values
+    ref = oracle.gatres_forward(p, x[:388], one)
+    assert relerr(first, ref) < 1e-5

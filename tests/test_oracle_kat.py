@@ -1,0 +1,198 @@
+"""Known-answer tests that pin the CPU oracle to the published PyG semantics.
+The reference ships no tests or vectors for this path, so these hand-derivable identities are the pin."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import gatres_oracle as O
+
+
+def rand_graph(n, e, seed, self_loops=0, dup=0):
+    g = torch.Generator().manual_seed(seed)
+    src = torch.randint(0, n, (e,), generator=g)
+    dst = torch.randint(0, n, (e,), generator=g)
+    keep = src != dst
+    ei = torch.stack([src[keep], dst[keep]])
+    if self_loops:
+        l = torch.randint(0, n, (self_loops,), generator=g)
+        ei = torch.cat([ei, torch.stack([l, l])], 1)
+    if dup:
+        ei = torch.cat([ei, ei[:, :dup]], 1)
+    return ei
+
+
+def conv_params(k, h, c, seed, dtype=torch.float64):
+    g = torch.Generator().manual_seed(seed)
+    r = lambda *s: (torch.rand(*s, generator=g, dtype=torch.float64) - 0.5).to(dtype)
+    return r(h * c, k), r(1, h, c), r(1, h, c), r(h * c)
+
+
+def test_k1_zero_attention_is_uniform_mean_over_neighbours_and_self():
+    n, k, h, c = 9, 5, 2, 4
+    ei = rand_graph(n, 20, 0)
+    W, _, _, b = conv_params(k, h, c, 1)
+    z = torch.zeros(1, h, c, dtype=torch.float64)
+    x = torch.randn(n, k, dtype=torch.float64)
+    out = O.gat_conv(x, ei, W, z, z, b, h, True)
+    hh = x @ W.t()
+    exp = torch.zeros_like(hh)
+    for i in range(n):
+        nb = [int(s) for s, d in zip(ei[0], ei[1]) if int(d) == i] + [i]
+        exp[i] = hh[nb].mean(0)
+    assert torch.allclose(out, exp + b, atol=1e-12)
+
+
+def test_k2_isolated_node_sees_only_its_self_loop():
+    k, h, c = 3, 2, 4
+    W, a_s, a_d, b = conv_params(k, h, c, 2)
+    x = torch.randn(1, k, dtype=torch.float64)
+    ei = torch.zeros((2, 0), dtype=torch.int64)
+    out = O.gat_conv(x, ei, W, a_s, a_d, b, h, True)
+    assert torch.allclose(out, x @ W.t() + b, atol=1e-12)
+    assert torch.equal(O.simple_conv_mean(x, ei), torch.zeros_like(x))
+    p = O.init_params(1, 4, seed=0, dtype=torch.float64)
+    xin = torch.randn(1, 4, dtype=torch.float64)
+    blk = O.gres_block(xin, ei, p, "blocks.0.")
+    assert torch.allclose(blk, xin.relu())          # mean over no neighbours is 0 -> block = relu(x0)
+
+
+def test_k3_alpha_rows_sum_to_one_and_shift_invariance():
+    n, k, h, c = 12, 6, 2, 4
+    ei = rand_graph(n, 40, 3)
+    W, a_s, a_d, b = conv_params(k, h, c, 4)
+    x = torch.randn(n, k, dtype=torch.float64)
+    out, alpha, ei2 = O.gat_conv(x, ei, W, a_s, a_d, b, h, True, return_alpha=True)
+    sums = torch.zeros(n, h, dtype=torch.float64).index_add_(0, ei2[1], alpha)
+    assert torch.allclose(sums, torch.ones_like(sums), atol=1e-12)
+    # softmax is invariant to a per-destination constant: shifting every score of a row must not matter
+    s = torch.randn(ei2.shape[1], h, dtype=torch.float64)
+    shift = torch.randn(n, h, dtype=torch.float64).index_select(0, ei2[1])
+    assert torch.allclose(O.segment_softmax(s, ei2[1], n), O.segment_softmax(s + shift, ei2[1], n), atol=1e-12)
+
+
+def test_k4_self_loops_removed_then_one_added_by_gat_but_kept_by_mean():
+    n, k, h, c = 7, 4, 1, 4
+    ei = rand_graph(n, 15, 5)
+    loops = torch.tensor([[2, 2, 5], [2, 2, 5]])
+    ei_l = torch.cat([ei[:, :4], loops, ei[:, 4:]], 1)
+    W, a_s, a_d, b = conv_params(k, h, c, 6)
+    x = torch.randn(n, k, dtype=torch.float64)
+    assert torch.allclose(O.gat_conv(x, ei, W, a_s, a_d, b, h, True), O.gat_conv(x, ei_l, W, a_s, a_d, b, h, True),
+                          atol=1e-13)
+    m0, m1 = O.simple_conv_mean(x, ei), O.simple_conv_mean(x, ei_l)
+    assert not torch.allclose(m0[2], m1[2])         # node 2 now also averages itself twice
+    untouched = [i for i in range(n) if i not in (2, 5)]
+    assert torch.allclose(m0[untouched], m1[untouched])
+    e_gat = O.add_self_loops(O.remove_self_loops(ei_l), n)
+    assert e_gat.shape[1] == ei.shape[1] + n
+    assert torch.equal(e_gat[:, -n:], torch.arange(n).repeat(2, 1))   # appended at the END, in node order
+
+
+def test_k5_edge_permutation_invariance():
+    n = 20
+    ei = rand_graph(n, 60, 7)
+    p = O.init_params(2, 8, seed=1, dtype=torch.float64)
+    x = torch.randn(n, 1, dtype=torch.float64)
+    perm = torch.randperm(ei.shape[1], generator=torch.Generator().manual_seed(0))
+    assert torch.allclose(O.gatres_forward(p, x, ei), O.gatres_forward(p, x, ei[:, perm]), atol=1e-12)
+
+
+def test_k6_block_diagonal_batching_equals_per_graph():
+    n1, n2 = 11, 17
+    e1, e2 = rand_graph(n1, 30, 8), rand_graph(n2, 40, 9)
+    p = O.init_params(3, 8, seed=2, dtype=torch.float64)
+    x1, x2 = torch.randn(n1, 1, dtype=torch.float64), torch.randn(n2, 1, dtype=torch.float64)
+    batched = O.gatres_forward(p, torch.cat([x1, x2]), torch.cat([e1, e2 + n1], 1))
+    assert torch.allclose(batched, torch.cat([O.gatres_forward(p, x1, e1), O.gatres_forward(p, x2, e2)]), atol=1e-12)
+
+
+def test_k7_single_head_mean_is_identity():
+    n, k, c = 8, 6, 4
+    ei = rand_graph(n, 20, 10)
+    W, a_s, a_d, b = conv_params(k, 1, c, 11)
+    x = torch.randn(n, k, dtype=torch.float64)
+    assert torch.equal(O.gat_conv(x, ei, W, a_s, a_d, b, 1, True), O.gat_conv(x, ei, W, a_s, a_d, b, 1, False))
+
+
+def test_k8_two_node_path_by_hand():
+    # nodes 0 <-> 1, scalar features, H = 1, C = 1
+    x = torch.tensor([[1.0], [2.0]], dtype=torch.float64)
+    ei = torch.tensor([[0, 1], [1, 0]])
+    W = torch.tensor([[0.5]], dtype=torch.float64)
+    a_s = torch.tensor([[[2.0]]], dtype=torch.float64)
+    a_d = torch.tensor([[[-3.0]]], dtype=torch.float64)
+    b = torch.tensor([0.25], dtype=torch.float64)
+    h = [0.5, 1.0]
+    asrc = [1.0, 2.0]
+    adst = [-1.5, -3.0]
+    lrelu = lambda v: v if v > 0 else 0.2 * v
+    # destination 0: edges (1->0), (0->0) ; destination 1: (0->1), (1->1)
+    s0 = [lrelu(asrc[1] + adst[0]), lrelu(asrc[0] + adst[0])]
+    s1 = [lrelu(asrc[0] + adst[1]), lrelu(asrc[1] + adst[1])]
+    sm = lambda s: [math.exp(v - max(s)) / (sum(math.exp(u - max(s)) for u in s) + 1e-16) for v in s]
+    a0, a1 = sm(s0), sm(s1)
+    exp = torch.tensor([[a0[0] * h[1] + a0[1] * h[0] + 0.25], [a1[0] * h[0] + a1[1] * h[1] + 0.25]], dtype=torch.float64)
+    out = O.gat_conv(x, ei, W, a_s, a_d, b, 1, True)
+    assert torch.allclose(out, exp, atol=1e-14)
+    # gradient of sum(out) w.r.t. the bias is N, w.r.t. h through alpha-weighted transpose
+    bb = b.clone().requires_grad_(True)
+    O.gat_conv(x, ei, W, a_s, a_d, bb, 1, True).sum().backward()
+    assert bb.grad.item() == 2.0
+
+
+def test_k9_gradcheck_and_dense_cross_check_and_fp32_vs_fp64():
+    n = 10
+    ei = rand_graph(n, 24, 12, self_loops=2, dup=3)
+    W, a_s, a_d, b = conv_params(3, 2, 4, 13)
+    x = torch.randn(n, 3, dtype=torch.float64)
+    args = [t.clone().requires_grad_(True) for t in (x, W, a_s, a_d, b)]
+    assert torch.autograd.gradcheck(lambda x_, W_, s_, d_, b_: O.gat_conv(x_, ei, W_, s_, d_, b_, 2, True), args,
+                                    eps=1e-6, atol=1e-6)
+    assert torch.allclose(O.gat_conv(x, ei, W, a_s, a_d, b, 2, True), O.gat_conv_dense(x, ei, W, a_s, a_d, b, 2, True),
+                          atol=1e-12)
+    p64 = O.init_params(4, 8, seed=3, dtype=torch.float64)
+    p32 = {k: v.float() for k, v in p64.items()}
+    xx = torch.randn(n, 1, dtype=torch.float64)
+    o64 = O.gatres_forward(p64, xx, ei)
+    o64d = O.gatres_forward(p64, xx, ei, conv=O.gat_conv_dense)
+    o32 = O.gatres_forward(p32, xx.float(), ei)
+    assert torch.allclose(o64, o64d, atol=1e-11)
+    rel = (o32.double() - o64).abs().max() / o64.abs().max()
+    assert rel < 1e-5, rel
+
+
+def test_k10_parameter_counts_and_keys():
+    assert O.num_params(15, 32) == 65857
+    assert O.num_params(25, 128) == 1667585
+    keys = list(O.param_shapes(1, 32).keys())
+    assert keys == ["lin0.weight", "lin0.bias", "blocks.0.conv1.att_src", "blocks.0.conv1.att_dst",
+                    "blocks.0.conv1.bias", "blocks.0.conv1.lin_src.weight", "blocks.0.conv2.att_src",
+                    "blocks.0.conv2.att_dst", "blocks.0.conv2.bias", "blocks.0.conv2.lin_src.weight", "lin1.weight",
+                    "lin1.bias"]
+
+
+def test_mask_sampler_matches_reference_contract():
+    rng = np.random.RandomState(0)
+    m = O.generate_batch_mask([388] * 4, 0.95, rng)
+    assert m.shape == (388 * 4,) and m.dtype == bool
+    assert all(int(m[i * 388:(i + 1) * 388].sum()) == int(388 * 0.95) == 368 for i in range(4))
+
+
+def test_train_step_matches_torch_adam():
+    n = 30
+    ei = rand_graph(n, 70, 20)
+    p = O.init_params(2, 8, seed=5)
+    x = torch.randn(n, 1)
+    mask = torch.from_numpy(O.mask_nodes(n, 0.8, np.random.RandomState(1)))
+    loss, out, grads, new_p, st = O.train_step(p, None, x, x.clone(), ei, mask)
+    params = [v.clone().requires_grad_(True) for v in p.values()]
+    opt = torch.optim.Adam(params, lr=5e-4, weight_decay=6e-6)
+    xin = x.clone(); xin[mask] = 0
+    o = O.gatres_forward(dict(zip(p.keys(), params)), xin, ei)
+    l = torch.nn.functional.mse_loss(o[mask], x[mask])
+    l.backward(); opt.step()
+    assert torch.allclose(l.detach(), loss)
+    for a, b_ in zip(params, new_p.values()):
+        assert torch.allclose(a.detach(), b_, rtol=1e-5, atol=1e-7)
