@@ -29,6 +29,11 @@ HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
 MODELS = {"gatres_small": (15, 32), "gatres_large": (25, 128)}     # ConfigModels.py:22-42
 
 
+def log(msg):
+    if int(os.environ.get("RANK", "0")) == 0:
+        print(f"[bench] {msg}", file=sys.stderr, flush=True)
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -134,8 +139,12 @@ def cpu_baseline(args, nb, nc):
     cores for the same step on the same batch shape."""
     from oracle import gatres_oracle as O
     import gnn_pressure_estimation_amd as G
-    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
     torch.set_num_threads(cores)
+    log(f"cpu baseline on {cores} host threads ...")
     x, y, ei, mask = G.wdn_synth.make_batch(args.batch_size, args.nodes, args.pipes)
     tr = O.OracleTrainer(O.init_params(nb, nc, seed=3))
     tr.step(x, y, ei, mask)                           # warm-up (thread pool, autograd graph)
@@ -185,6 +194,7 @@ def main():
         trainer.load_batch(b, b)
         trainer.run_step(device_mask=True)
 
+    log(f"model/trainer ready on {device}; warm-up {args.warmup} steps")
     for i in range(args.warmup):
         one_step(i)
     torch.cuda.synchronize(device)
@@ -204,6 +214,7 @@ def main():
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t.item())
     loss = float(trainer.loss.item())
+    log(f"timed {args.steps} steps in {dt:.4f}s, loss {loss:.5f}")
     if not (loss == loss) or loss > 1e6:
         raise SystemExit(f"training diverged (loss={loss})")
 
@@ -220,6 +231,7 @@ def main():
     }
 
     if rank == 0 and not args.no_roofline:
+        log("per-kernel timing ...")
         rows = time_kernels(kernel_table(G, model, trainer.plan, nc), device)
         for r in rows:
             r["step_share_us"] = r["avg_us"] * r["calls_per_step"]

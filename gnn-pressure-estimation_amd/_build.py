@@ -18,7 +18,7 @@ OBJ_DIR = os.path.join(PKG_DIR, "build")
 LIB_PATH = os.path.join(LIB_DIR, "libgatres_hip.so")
 ARCH = "gfx950"
 
-SOURCES = ["k_aggregate.hip", "k_proj.hip", "k_misc.hip", "graph_plan.hip", "model_driver.hip", "train_driver.hip"]
+SOURCES = ["k_aggregate.hip", "k_proj.hip", "k_misc.hip", "graph_plan.hip", "model_driver.hip", "train_driver.hip", "k_fused.hip"]
 
 
 def _hipcc() -> str:

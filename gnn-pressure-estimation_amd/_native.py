@@ -23,10 +23,11 @@ ERRORS = {-1: "GATRES_E_BADARG (null/misaligned pointer or bad size)",
 class GatresGraph(C.Structure):
     """gatres_graph_t"""
     _fields_ = [("num_nodes", C.c_int32), ("num_edges_gat", C.c_int32), ("num_edges_mean", C.c_int32),
-                ("reserved", C.c_int32),
+                ("num_segments", C.c_int32),
                 ("rowptr", C.c_void_p), ("col", C.c_void_p), ("t_rowptr", C.c_void_p), ("t_eid", C.c_void_p),
                 ("t_dst", C.c_void_p), ("m_rowptr", C.c_void_p), ("m_col", C.c_void_p), ("mt_rowptr", C.c_void_p),
-                ("mt_dst", C.c_void_p)]
+                ("mt_dst", C.c_void_p), ("seg_ptr", C.c_void_p), ("max_segment_nodes", C.c_int32),
+                ("reserved", C.c_int32)]
 
 
 class GatresModel(C.Structure):
@@ -42,6 +43,7 @@ _GP, _MP = C.POINTER(GatresGraph), C.POINTER(GatresModel)
 SIGNATURES = {
     "gatres_graph_count_host": (C.c_int, [_P, _I64, _I64, C.POINTER(_I64)]),
     "gatres_graph_build_host": (C.c_int, [_P, _I64, _I64] + [_P] * 9),
+    "gatres_graph_segments_host": (C.c_int, [_P, _I64, _I64, _I32, _P, C.POINTER(_I32), C.POINTER(_I32)]),
     "gatres_edge_index_hash": (C.c_int, [_P, _I64, _P, _P]),
     "gatres_lin0_fwd": (C.c_int, [_P, _P, _P, _P, _P, _I32, _I32, _P]),
     "gatres_proj_attn_fwd": (C.c_int, [_P] * 7 + [_I32] * 4 + [_P]),
@@ -62,11 +64,17 @@ SIGNATURES = {
     "gatres_masked_mse": (C.c_int, [_P] * 5 + [_I32, _P]),
     "gatres_adam_step": (C.c_int, [_P] * 5 + [_I64] + [_F64] * 5 + [_F32, _P]),
     "gatres_param_count": (_I64, [_I32, _I32]),
-    "gatres_saved_floats": (_I64, [_MP, _I32, _I32]),
-    "gatres_scratch_floats": (_I64, [_MP, _I32, _I32]),
+    "gatres_saved_floats": (_I64, [_MP, _GP]),
+    "gatres_scratch_floats": (_I64, [_MP, _GP]),
     "gatres_num_slabs": (_I32, [_MP, _I32]),
     "gatres_model_forward": (C.c_int, [_MP, _GP] + [_P] * 6 + [_P]),
     "gatres_model_backward": (C.c_int, [_MP, _GP] + [_P] * 8 + [_P]),
+    "gatres_model_forward_per_op": (C.c_int, [_MP, _GP] + [_P] * 6 + [_P]),
+    "gatres_model_backward_per_op": (C.c_int, [_MP, _GP] + [_P] * 8 + [_P]),
+    "gatres_fused_supported": (C.c_int, [_MP, _GP]),
+    "gatres_fused_prepare_backward": (C.c_int, [_MP, _GP, _P, _P, _P]),
+    "gatres_fused_run": (C.c_int, [_MP, _GP] + [_P] * 10 + [_I32, _P]),
+    "gatres_fused_finish": (C.c_int, [_MP, _GP] + [_P] * 4 + [_I32] + [_P] * 4 + [_F64] * 5 + [_F32, _P]),
     "gatres_train_step": (C.c_int, [_P, _P]),
     "gatres_version": (C.c_char_p, []),
 }

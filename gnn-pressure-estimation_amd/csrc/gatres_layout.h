@@ -1,0 +1,83 @@
+// Flat parameter / saved-activation / scratch layouts shared by the per-op driver and the fused per-snapshot kernels.
+#pragma once
+#include "gatres_common.h"
+
+static inline __host__ __device__ int64_t r4(int64_t v) { return (v + 3) & ~(int64_t)3; }
+
+struct Layout {
+  int nb, nc;
+  int64_t N, Eg;
+  // flat parameters
+  int64_t p_lin0_w, p_lin0_b, p_block0, p_block_stride, p_lin1_w, p_lin1_b, P;
+  int64_t c1_as, c1_ad, c1_b, c1_W, c2_as, c2_ad, c2_b, c2_W;   // inside a block
+  // saved activations of one block (s_xin == 0 so that "xin of block nb" is the final activation)
+  int64_t s_xin, s_h1, s_as1, s_ad1, s_al1, s_o1, s_h2, s_as2, s_ad2, s_al2, s_stride, saved_total;
+  // scratch
+  int64_t sc_y2, sc_ev, sc_xa, sc_xb, sc_gpa, sc_gpb, sc_gy2, sc_ge, sc_gad, sc_gas, sc_gh, sc_go1, sc_wt,
+      sc_slabs, sc_loss_part, scratch_total;
+  int num_slabs;      // node-range slabs of the per-op path
+  int slab_rows;      // slabs allocated = max(num_slabs, segments)
+  int64_t slab_stride;
+};
+
+static inline int num_slabs_for(int64_t P, int64_t N) {
+  int64_t cap = (64LL << 20) / (4 * (P > 0 ? P : 1));
+  if (cap > 256) cap = 256;
+  if (cap < 16) cap = 16;
+  int64_t s = (N + 63) / 64;
+  if (s > cap) s = cap;
+  if (s < 1) s = 1;
+  return (int)s;
+}
+
+static inline bool make_layout(const gatres_model_t* m, int64_t N, int64_t Eg, int num_segments, Layout* L) {
+  if (!m || m->num_blocks < 0 || N <= 0 || Eg < 0) return false;
+  const int nc = m->nc, nb = m->num_blocks;
+  if (nc < 4 || nc > 128 || !gatres_is_pow2(nc)) return false;
+  L->nb = nb; L->nc = nc; L->N = N; L->Eg = Eg;
+  const int64_t w = 2LL * nc * nc;
+  L->p_lin0_w = 0; L->p_lin0_b = nc; L->p_block0 = 2LL * nc;
+  L->c1_as = 0; L->c1_ad = 2LL * nc; L->c1_b = 4LL * nc; L->c1_W = 6LL * nc;
+  L->c2_as = 6LL * nc + w; L->c2_ad = L->c2_as + nc; L->c2_b = L->c2_ad + nc; L->c2_W = L->c2_b + nc;
+  L->p_block_stride = 9LL * nc + 2 * w;
+  L->p_lin1_w = L->p_block0 + nb * L->p_block_stride;
+  L->p_lin1_b = L->p_lin1_w + nc;
+  L->P = L->p_lin1_b + 1;
+
+  int64_t o = 0;
+  L->s_xin = o; o += r4(N * nc);
+  L->s_h1 = o;  o += r4(N * 2 * nc);
+  L->s_as1 = o; o += r4(N * 2);
+  L->s_ad1 = o; o += r4(N * 2);
+  L->s_al1 = o; o += r4(Eg * 2);
+  L->s_o1 = o;  o += r4(N * 2 * nc);
+  L->s_h2 = o;  o += r4(N * nc);
+  L->s_as2 = o; o += r4(N);
+  L->s_ad2 = o; o += r4(N);
+  L->s_al2 = o; o += r4(Eg);
+  L->s_stride = o;
+  L->saved_total = nb * L->s_stride + r4(N * nc);
+
+  L->num_slabs = num_slabs_for(L->P, N);
+  L->slab_stride = r4(L->P);
+  o = 0;
+  L->sc_y2 = o;  o += r4(N * nc);
+  L->sc_ev = o;  o += L->s_stride;
+  L->sc_xa = o;  o += r4(N * nc);
+  L->sc_xb = o;  o += r4(N * nc);
+  L->sc_gpa = o; o += r4(N * nc);
+  L->sc_gpb = o; o += r4(N * nc);
+  L->sc_gy2 = o; o += r4(N * nc);
+  L->sc_ge = o;  o += r4(Eg * 2);
+  L->sc_gad = o; o += r4(N * 2);
+  L->sc_gas = o; o += r4(N * 2);
+  L->sc_gh = o;  o += r4(N * 2 * nc);
+  L->sc_go1 = o; o += r4(N * 2 * nc);
+  L->sc_wt = o;  o += r4((int64_t)nb * 2 * w);
+  L->slab_rows = L->num_slabs > num_segments ? L->num_slabs : num_segments;
+  L->sc_slabs = o; o += (int64_t)L->slab_rows * L->slab_stride;
+  L->sc_loss_part = o; o += r4((int64_t)L->slab_rows + 1);
+  L->scratch_total = o;
+  return true;
+}
+

@@ -68,3 +68,42 @@ extern "C" int gatres_graph_build_host(const int64_t* ei, int64_t E, int64_t N, 
   for (int64_t p = 0; p < E; ++p) mt_dst[p] = md[perm[p]];
   return 0;
 }
+
+// Segments: cut after node i iff no edge joins a node <= i with a node > i.  A PyG Batch yields one segment per
+// snapshot (or finer, if a snapshot is disconnected); neighbours smaller than `merge_upto` are then coalesced so a
+// workgroup never gets a degenerate handful of nodes.
+extern "C" int gatres_graph_segments_host(const int64_t* ei, int64_t E, int64_t N, int32_t merge_upto,
+                                          int32_t* seg_ptr, int32_t* num_segments_out, int32_t* max_nodes_out) {
+  if ((!ei && E > 0) || !seg_ptr || !num_segments_out || !max_nodes_out || E < 0 || N <= 0) return GATRES_E_BADARG;
+  if (N > INT32_MAX) return GATRES_E_UNSUPPORTED;
+  std::vector<int32_t> reach(N);
+  for (int64_t i = 0; i < N; ++i) reach[i] = (int32_t)i;
+  for (int64_t e = 0; e < E; ++e) {
+    const int64_t s = ei[e], d = ei[E + e];
+    if (s < 0 || s >= N || d < 0 || d >= N) return GATRES_E_GRAPH;
+    const int64_t lo = s < d ? s : d, hi = s < d ? d : s;
+    if (reach[lo] < hi) reach[lo] = (int32_t)hi;
+  }
+  std::vector<int32_t> cuts;                       // fine segment ends (exclusive)
+  int32_t far = 0;
+  for (int64_t i = 0; i < N; ++i) {
+    if (reach[i] > far) far = reach[i];
+    if (far <= i) cuts.push_back((int32_t)(i + 1));
+  }
+  int32_t ns = 0, start = 0, cur_end = 0, mx = 0;
+  seg_ptr[0] = 0;
+  for (size_t c = 0; c < cuts.size(); ++c) {
+    const int32_t end = cuts[c];
+    if (cur_end > start && end - start > merge_upto) {      // close the running segment before this piece
+      seg_ptr[++ns] = cur_end;
+      if (cur_end - start > mx) mx = cur_end - start;
+      start = cur_end;
+    }
+    cur_end = end;
+  }
+  seg_ptr[++ns] = cur_end;
+  if (cur_end - start > mx) mx = cur_end - start;
+  *num_segments_out = ns;
+  *max_nodes_out = mx;
+  return 0;
+}

@@ -6,84 +6,9 @@
 //   xin -> K1(conv1) h1,a1 -> K2(conv1)+bias+ReLU out1 -> K1(conv2) h2,a2 -> K2(conv2)+bias y2
 //       -> K3 mean(y2)+xin, ReLU -> xin of block b+1
 #include "gatres_common.h"
+#include "gatres_layout.h"
 
 namespace {
-
-static inline int64_t r4(int64_t v) { return (v + 3) & ~(int64_t)3; }
-
-struct Layout {
-  int nb, nc;
-  int64_t N, Eg;
-  // flat parameters
-  int64_t p_lin0_w, p_lin0_b, p_block0, p_block_stride, p_lin1_w, p_lin1_b, P;
-  int64_t c1_as, c1_ad, c1_b, c1_W, c2_as, c2_ad, c2_b, c2_W;   // inside a block
-  // saved activations of one block (s_xin == 0 so that "xin of block nb" is the final activation)
-  int64_t s_xin, s_h1, s_as1, s_ad1, s_al1, s_o1, s_h2, s_as2, s_ad2, s_al2, s_stride, saved_total;
-  // scratch
-  int64_t sc_y2, sc_ev, sc_xa, sc_xb, sc_gpa, sc_gpb, sc_gy2, sc_ge, sc_gad, sc_gas, sc_gh, sc_go1, sc_wt,
-      sc_slabs, scratch_total;
-  int num_slabs;
-  int64_t slab_stride;
-};
-
-static int num_slabs_for(int64_t P, int64_t N) {
-  int64_t cap = (64LL << 20) / (4 * (P > 0 ? P : 1));
-  if (cap > 256) cap = 256;
-  if (cap < 16) cap = 16;
-  int64_t s = (N + 63) / 64;
-  if (s > cap) s = cap;
-  if (s < 1) s = 1;
-  return (int)s;
-}
-
-static bool make_layout(const gatres_model_t* m, int64_t N, int64_t Eg, Layout* L) {
-  if (!m || m->num_blocks < 0 || N <= 0 || Eg < 0) return false;
-  const int nc = m->nc, nb = m->num_blocks;
-  if (nc < 4 || nc > 128 || !gatres_is_pow2(nc)) return false;
-  L->nb = nb; L->nc = nc; L->N = N; L->Eg = Eg;
-  const int64_t w = 2LL * nc * nc;
-  L->p_lin0_w = 0; L->p_lin0_b = nc; L->p_block0 = 2LL * nc;
-  L->c1_as = 0; L->c1_ad = 2LL * nc; L->c1_b = 4LL * nc; L->c1_W = 6LL * nc;
-  L->c2_as = 6LL * nc + w; L->c2_ad = L->c2_as + nc; L->c2_b = L->c2_ad + nc; L->c2_W = L->c2_b + nc;
-  L->p_block_stride = 9LL * nc + 2 * w;
-  L->p_lin1_w = L->p_block0 + nb * L->p_block_stride;
-  L->p_lin1_b = L->p_lin1_w + nc;
-  L->P = L->p_lin1_b + 1;
-
-  int64_t o = 0;
-  L->s_xin = o; o += r4(N * nc);
-  L->s_h1 = o;  o += r4(N * 2 * nc);
-  L->s_as1 = o; o += r4(N * 2);
-  L->s_ad1 = o; o += r4(N * 2);
-  L->s_al1 = o; o += r4(Eg * 2);
-  L->s_o1 = o;  o += r4(N * 2 * nc);
-  L->s_h2 = o;  o += r4(N * nc);
-  L->s_as2 = o; o += r4(N);
-  L->s_ad2 = o; o += r4(N);
-  L->s_al2 = o; o += r4(Eg);
-  L->s_stride = o;
-  L->saved_total = nb * L->s_stride + r4(N * nc);
-
-  L->num_slabs = num_slabs_for(L->P, N);
-  L->slab_stride = r4(L->P);
-  o = 0;
-  L->sc_y2 = o;  o += r4(N * nc);
-  L->sc_ev = o;  o += L->s_stride;
-  L->sc_xa = o;  o += r4(N * nc);
-  L->sc_xb = o;  o += r4(N * nc);
-  L->sc_gpa = o; o += r4(N * nc);
-  L->sc_gpb = o; o += r4(N * nc);
-  L->sc_gy2 = o; o += r4(N * nc);
-  L->sc_ge = o;  o += r4(Eg * 2);
-  L->sc_gad = o; o += r4(N * 2);
-  L->sc_gas = o; o += r4(N * 2);
-  L->sc_gh = o;  o += r4(N * 2 * nc);
-  L->sc_go1 = o; o += r4(N * 2 * nc);
-  L->sc_wt = o;  o += r4((int64_t)nb * 2 * w);
-  L->sc_slabs = o; o += (int64_t)L->num_slabs * L->slab_stride;
-  L->scratch_total = o;
-  return true;
-}
 
 #define RC(call)            \
   do {                      \
@@ -97,19 +22,23 @@ extern "C" int64_t gatres_param_count(int32_t num_blocks, int32_t nc) {
   return 2LL * nc + (int64_t)num_blocks * (9LL * nc + 4LL * nc * nc) + nc + 1;
 }
 
-extern "C" int64_t gatres_saved_floats(const gatres_model_t* m, int32_t num_nodes, int32_t num_edges_gat) {
+extern "C" int64_t gatres_saved_floats(const gatres_model_t* m, const gatres_graph_t* g) {
   Layout L;
-  return make_layout(m, num_nodes, num_edges_gat, &L) ? L.saved_total : (int64_t)GATRES_E_UNSUPPORTED;
+  if (!g) return GATRES_E_BADARG;
+  return make_layout(m, g->num_nodes, g->num_edges_gat, g->num_segments, &L) ? L.saved_total
+                                                                             : (int64_t)GATRES_E_UNSUPPORTED;
 }
 
-extern "C" int64_t gatres_scratch_floats(const gatres_model_t* m, int32_t num_nodes, int32_t num_edges_gat) {
+extern "C" int64_t gatres_scratch_floats(const gatres_model_t* m, const gatres_graph_t* g) {
   Layout L;
-  return make_layout(m, num_nodes, num_edges_gat, &L) ? L.scratch_total : (int64_t)GATRES_E_UNSUPPORTED;
+  if (!g) return GATRES_E_BADARG;
+  return make_layout(m, g->num_nodes, g->num_edges_gat, g->num_segments, &L) ? L.scratch_total
+                                                                             : (int64_t)GATRES_E_UNSUPPORTED;
 }
 
 extern "C" int32_t gatres_num_slabs(const gatres_model_t* m, int32_t num_nodes) {
   Layout L;
-  return make_layout(m, num_nodes, 0, &L) ? L.num_slabs : GATRES_E_UNSUPPORTED;
+  return make_layout(m, num_nodes, 0, 0, &L) ? L.num_slabs : GATRES_E_UNSUPPORTED;
 }
 
 extern "C" const char* gatres_version(void) { return "gatres-gfx950 abi1"; }
@@ -119,8 +48,19 @@ extern "C" int gatres_model_forward(const gatres_model_t* m, const gatres_graph_
                                     void* stream) {
   if (!m || !g || !params || !x || !out || !scratch) return GATRES_E_BADARG;
   if (!gatres_aligned16(params) || !gatres_aligned16(saved) || !gatres_aligned16(scratch)) return GATRES_E_BADARG;
+  if (gatres_fused_supported(m, g))
+    return gatres_fused_run(m, g, params, x, mask, nullptr, out, nullptr, nullptr, nullptr, saved, scratch,
+                            GATRES_PHASE_FORWARD, stream);
+  return gatres_model_forward_per_op(m, g, params, x, mask, out, saved, scratch, stream);
+}
+
+extern "C" int gatres_model_forward_per_op(const gatres_model_t* m, const gatres_graph_t* g, const float* params,
+                                           const float* x, const uint8_t* mask, float* out, float* saved,
+                                           float* scratch, void* stream) {
+  if (!m || !g || !params || !x || !out || !scratch) return GATRES_E_BADARG;
+  if (!gatres_aligned16(params) || !gatres_aligned16(saved) || !gatres_aligned16(scratch)) return GATRES_E_BADARG;
   Layout L;
-  if (!make_layout(m, g->num_nodes, g->num_edges_gat, &L)) return GATRES_E_UNSUPPORTED;
+  if (!make_layout(m, g->num_nodes, g->num_edges_gat, g->num_segments, &L)) return GATRES_E_UNSUPPORTED;
   const int N = g->num_nodes, nc = L.nc;
   float* y2 = scratch + L.sc_y2;
   float* xa = scratch + L.sc_xa;
@@ -151,8 +91,24 @@ extern "C" int gatres_model_backward(const gatres_model_t* m, const gatres_graph
                                      float* scratch, float* grads, float* g_x, void* stream) {
   if (!m || !g || !params || !x || !g_out || !saved || !scratch || !grads) return GATRES_E_BADARG;
   if (!gatres_aligned16(params) || !gatres_aligned16(saved) || !gatres_aligned16(scratch)) return GATRES_E_BADARG;
+  if (gatres_fused_supported(m, g)) {
+    RC(gatres_fused_prepare_backward(m, g, params, scratch, stream));
+    RC(gatres_fused_run(m, g, params, x, mask, nullptr, nullptr, const_cast<float*>(g_out), nullptr, g_x,
+                        const_cast<float*>(saved), scratch, GATRES_PHASE_BACKWARD, stream));
+    return gatres_fused_finish(m, g, scratch, grads, nullptr, nullptr, 0, nullptr, nullptr, nullptr, nullptr, 0, 0, 0,
+                               0, 0, 1.f, stream);
+  }
+  return gatres_model_backward_per_op(m, g, params, x, mask, g_out, saved, scratch, grads, g_x, stream);
+}
+
+extern "C" int gatres_model_backward_per_op(const gatres_model_t* m, const gatres_graph_t* g, const float* params,
+                                            const float* x, const uint8_t* mask, const float* g_out,
+                                            const float* saved, float* scratch, float* grads, float* g_x,
+                                            void* stream) {
+  if (!m || !g || !params || !x || !g_out || !saved || !scratch || !grads) return GATRES_E_BADARG;
+  if (!gatres_aligned16(params) || !gatres_aligned16(saved) || !gatres_aligned16(scratch)) return GATRES_E_BADARG;
   Layout L;
-  if (!make_layout(m, g->num_nodes, g->num_edges_gat, &L)) return GATRES_E_UNSUPPORTED;
+  if (!make_layout(m, g->num_nodes, g->num_edges_gat, g->num_segments, &L)) return GATRES_E_UNSUPPORTED;
   const int N = g->num_nodes, nc = L.nc, S = L.num_slabs;
   const int64_t st = L.slab_stride, w = 2LL * nc * nc;
   float* gp_cur = scratch + L.sc_gpa;

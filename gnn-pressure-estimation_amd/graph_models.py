@@ -117,10 +117,9 @@ class GResBlockMeanConv(nn.Module):
 # ----------------------------------------------------------------------------------------------
 class _GATResFunction(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, module: "GATResMeanConv", plan: GraphPlan, x: Tensor, *params: Tensor) -> Tensor:
+    def forward(ctx, module: "GATResMeanConv", plan: GraphPlan, needs_grad: bool, x: Tensor, *params: Tensor) -> Tensor:
         lib = _native.load()
         N = plan.num_nodes
-        needs_grad = torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in params))
         out = torch.empty((N, 1), dtype=torch.float32, device=x.device)
         scratch = module._scratch_for(plan)
         saved = None
@@ -146,13 +145,13 @@ class _GATResFunction(torch.autograd.Function):
         if g_out.dtype != torch.float32:
             raise ValueError("grad_output must be float32")
         grads = torch.empty(module._flat.numel(), dtype=torch.float32, device=x.device)
-        g_x = torch.empty_like(x) if ctx.needs_input_grad[2] else None
+        g_x = torch.empty_like(x) if ctx.needs_input_grad[3] else None
         scratch = module._scratch_for(plan)
         stream = _native.current_stream(x.device)
         _native.check(lib.gatres_model_backward(module._cmodel_ref(), plan.ref(), module._flat.data_ptr(), x.data_ptr(),
                                                 None, g_out.data_ptr(), saved.data_ptr(), scratch.data_ptr(),
                                                 grads.data_ptr(), _native.ptr(g_x), stream), "gatres_model_backward")
-        outs: List[Optional[Tensor]] = [None, None, g_x]
+        outs: List[Optional[Tensor]] = [None, None, None, g_x]
         off = 0
         for shape in ctx.param_shapes:
             n = int(math.prod(shape))
@@ -168,8 +167,9 @@ class GATResMeanConv(nn.Module):
     """GraphModels.py:471-494.  ``gatres_small`` = (num_blocks=15, nc=32), ``gatres_large`` = (25, 128)
     (ConfigModels.py:22-42)."""
 
-    def __init__(self, name: str = "GATResMeanConv", num_blocks: int = 5, nc: int = 32):
+    def __init__(self, name: str = "GATResMeanConv", num_blocks: int = 5, nc: int = 32, fused: bool = True):
         super().__init__()
+        self.fused = fused          # False: always run the per-op kernels (one launch per stage)
         if nc < 4 or nc > 128 or (nc & (nc - 1)):
             raise ValueError(f"nc={nc}: the gfx950 kernels support powers of two in [4, 128]")
         self.num_blocks = num_blocks
@@ -181,9 +181,24 @@ class GATResMeanConv(nn.Module):
             self.blocks.append(GResBlockMeanConv(nc, nc, nc))
         self.lin1 = Linear(nc, 1)
         self._flat: Optional[Tensor] = None
-        self._plans = PlanCache()
+        self._plans = PlanCache(segments=fused)
         self._scratch = {}
         self._cmodel = _native.GatresModel(num_blocks, nc)
+        self._flatten_parameters()
+
+    # ---- copy / pickle: engine handles (ctypes structs, device plans, scratch) are rebuilt, not copied ---------
+    def __getstate__(self):
+        state = self.__dict__.copy()
+        for k in ("_plans", "_scratch", "_cmodel", "_flat"):
+            state.pop(k, None)
+        return state
+
+    def __setstate__(self, state):
+        super().__setstate__(state)
+        self._flat = None
+        self._plans = PlanCache(segments=getattr(self, 'fused', True))
+        self._scratch = {}
+        self._cmodel = _native.GatresModel(self.num_blocks, self.nc)
         self._flatten_parameters()
 
     # ---- flat parameter storage (state_dict order == include/gatres.h layout) ------------------
@@ -239,17 +254,17 @@ class GATResMeanConv(nn.Module):
 
     def _saved_floats(self, plan: GraphPlan) -> int:
         lib = _native.load()
-        n = lib.gatres_saved_floats(self._cmodel_ref(), plan.num_nodes, plan.num_edges_gat)
+        n = lib.gatres_saved_floats(self._cmodel_ref(), plan.ref())
         if n < 0:
             _native.check(int(n), "gatres_saved_floats")
         return int(n)
 
     def _scratch_for(self, plan: GraphPlan) -> Tensor:
-        key = (plan.num_nodes, plan.num_edges_gat, str(plan.device))
+        key = (plan.num_nodes, plan.num_edges_gat, plan.num_segments, str(plan.device))
         buf = self._scratch.get(key)
         if buf is None:
             lib = _native.load()
-            n = lib.gatres_scratch_floats(self._cmodel_ref(), plan.num_nodes, plan.num_edges_gat)
+            n = lib.gatres_scratch_floats(self._cmodel_ref(), plan.ref())
             if n < 0:
                 _native.check(int(n), "gatres_scratch_floats")
             self._scratch = {key: torch.empty(int(n), dtype=torch.float32, device=plan.device)}
@@ -273,4 +288,7 @@ class GATResMeanConv(nn.Module):
         if self._flat.device != x.device:
             raise ValueError(f"model is on {self._flat.device}, x on {x.device}")
         plan = self._plans.get(edge_index, x.shape[0])
-        return _GATResFunction.apply(self, plan, x, *self.parameters())
+        params = list(self.parameters())
+        # grad mode is switched off inside Function.forward, so decide here whether activations must be kept
+        needs_grad = torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in params))
+        return _GATResFunction.apply(self, plan, needs_grad, x, *params)

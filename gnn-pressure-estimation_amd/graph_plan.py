@@ -18,7 +18,8 @@ from . import _native
 class GraphPlan:
     """Device-resident destination-/source-sorted CSR of one (batched) topology."""
 
-    def __init__(self, edge_index: torch.Tensor, num_nodes: int, device=None):
+    def __init__(self, edge_index: torch.Tensor, num_nodes: int, device=None, segments: bool = True,
+                 merge_upto: int = 64):
         if edge_index.dim() != 2 or edge_index.shape[0] != 2:
             raise ValueError(f"edge_index must be [2, E], got {tuple(edge_index.shape)}")
         if edge_index.dtype != torch.int64:
@@ -45,7 +46,20 @@ class GraphPlan:
         self.num_nodes, self.num_edges_gat, self.num_edges_mean = N, Eg, E
         self.device = device
         self.arrays: Dict[str, torch.Tensor] = {k: v.to(device) for k, v in host.items()}
-        self.c = _native.GatresGraph(N, Eg, E, 0, *[self.arrays[k].data_ptr() for k in host.keys()])
+        # segment table: the snapshots of the batch (one workgroup each in the fused kernels)
+        self.num_segments, self.max_segment_nodes = 0, 0
+        seg_dev_ptr = None
+        if segments:
+            seg = torch.empty(N + 1, **i32)
+            ns, mx = C.c_int32(0), C.c_int32(0)
+            _native.check(lib.gatres_graph_segments_host(ei_host.data_ptr(), E, N, int(merge_upto), seg.data_ptr(),
+                                                         C.byref(ns), C.byref(mx)), "gatres_graph_segments_host")
+            self.num_segments, self.max_segment_nodes = int(ns.value), int(mx.value)
+            self.segment_ptr_host = seg[: self.num_segments + 1].clone()
+            self.arrays["seg_ptr"] = self.segment_ptr_host.to(device)
+            seg_dev_ptr = self.arrays["seg_ptr"].data_ptr()
+        self.c = _native.GatresGraph(N, Eg, E, self.num_segments, *[self.arrays[k].data_ptr() for k in host.keys()],
+                                     seg_dev_ptr, self.max_segment_nodes, 0)
 
     def ref(self):
         return C.byref(self.c)
@@ -65,8 +79,9 @@ class PlanCache:
     read-back, against PyG's ~30 boolean-index syncs per forward.  A tensor object already seen (same storage,
     same version counter) skips the hash."""
 
-    def __init__(self, max_entries: int = 16):
+    def __init__(self, max_entries: int = 16, segments: bool = True):
         self.max_entries = max_entries
+        self.segments = segments
         self._by_hash: Dict[Tuple[int, int, int, str], GraphPlan] = {}
         self._by_identity: Dict[Tuple[int, int, int, int, str], GraphPlan] = {}
 
@@ -90,7 +105,7 @@ class PlanCache:
         if plan is None:
             if len(self._by_hash) >= self.max_entries:
                 self.clear()
-            plan = GraphPlan(edge_index, num_nodes)
+            plan = GraphPlan(edge_index, num_nodes, segments=self.segments)
             self._by_hash[key] = plan
         plan._src_ref = edge_index        # identity fast path is valid only while this exact tensor is alive
         self._by_identity = {ident: plan}

@@ -32,7 +32,7 @@ class _TrainStepC(C.Structure):
                 ("out", C.c_void_p), ("g_out", C.c_void_p), ("loss", C.c_void_p), ("saved", C.c_void_p),
                 ("scratch", C.c_void_p),
                 ("lr", C.c_double), ("beta1", C.c_double), ("beta2", C.c_double), ("eps", C.c_double),
-                ("weight_decay", C.c_double), ("grad_scale", C.c_float), ("reserved", C.c_int32)]
+                ("weight_decay", C.c_double), ("grad_scale", C.c_float), ("flags", C.c_int32)]
 
 
 class GATResTrainer:
@@ -44,7 +44,7 @@ class GATResTrainer:
     def __init__(self, model: GATResMeanConv, edge_index: torch.Tensor, num_nodes: int,
                  nodes_per_graph: Optional[Sequence[int]] = None, lr: float = 5e-4, weight_decay: float = 6e-6,
                  betas=(0.9, 0.999), eps: float = 1e-8, mask_rate: float = 0.95, seed: int = 0,
-                 process_group=None, use_graph: bool = True):
+                 process_group=None, use_graph: bool = True, fused: bool = True):
         self.lib = _native.load()
         self.model = model
         params = model.flat_parameters
@@ -52,7 +52,8 @@ class GATResTrainer:
             raise ValueError("move the model to the ROCm device first; this engine has no CPU path")
         dev = params.device
         self.device = dev
-        self.plan: GraphPlan = GraphPlan(edge_index, num_nodes, device=dev)
+        self.plan: GraphPlan = GraphPlan(edge_index, num_nodes, device=dev, segments=fused)
+        self.fused = bool(fused and self.lib.gatres_fused_supported(model._cmodel_ref(), self.plan.ref()))
         N = num_nodes
         self.N = N
         self.P = params.numel()
@@ -95,7 +96,7 @@ class GATResTrainer:
             self.node_ptr.data_ptr() if (device_mask and self.node_ptr is not None) else None,
             self.num_graphs, phases, self.mask_rate, self.seed, self.out.data_ptr(), self.g_out.data_ptr(),
             self.loss.data_ptr(), self.saved.data_ptr(), self.scratch.data_ptr(), h["lr"], h["beta1"], h["beta2"],
-            h["eps"], h["weight_decay"], 1.0 / self.world, 0)
+            h["eps"], h["weight_decay"], 1.0 / self.world, 0 if self.fused else 1)
 
     def _enqueue(self, phases: int, device_mask: bool) -> None:
         ts = self._desc(phases, device_mask)

@@ -48,7 +48,7 @@ typedef struct gatres_graph {
   int32_t num_nodes;        /* N                                         */
   int32_t num_edges_gat;    /* E' = #(src != dst) + N                    */
   int32_t num_edges_mean;   /* E  = edge_index.shape[1]                  */
-  int32_t reserved;
+  int32_t num_segments;     /* 0 = no segment table (per-op kernels only) */
   const int32_t* rowptr;
   const int32_t* col;
   const int32_t* t_rowptr;
@@ -58,6 +58,11 @@ typedef struct gatres_graph {
   const int32_t* m_col;
   const int32_t* mt_rowptr;
   const int32_t* mt_dst;
+  /* Segments: contiguous node ranges [seg_ptr[s], seg_ptr[s+1]) that no edge leaves -- the snapshots of a PyG
+   * Batch (train.py:302-303).  The fused kernels give each segment to one workgroup. */
+  const int32_t* seg_ptr;   /* [num_segments + 1]                         */
+  int32_t max_segment_nodes;
+  int32_t reserved;
 } gatres_graph_t;
 
 /* Host-side plan builder (runs on the CPU, once per topology).  edge_index_host: int64 [2, E] row-major as
@@ -67,6 +72,12 @@ int gatres_graph_count_host(const int64_t* edge_index_host, int64_t num_edges, i
 int gatres_graph_build_host(const int64_t* edge_index_host, int64_t num_edges, int64_t num_nodes,
                             int32_t* rowptr, int32_t* col, int32_t* t_rowptr, int32_t* t_eid, int32_t* t_dst,
                             int32_t* m_rowptr, int32_t* m_col, int32_t* mt_rowptr, int32_t* mt_dst);
+
+/* Segment table (host): the finest partition of [0, N) into contiguous ranges closed under the edges, adjacent
+ * ranges merged while the result stays <= merge_upto nodes.  seg_ptr_host must hold N + 1 entries. */
+int gatres_graph_segments_host(const int64_t* edge_index_host, int64_t num_edges, int64_t num_nodes,
+                               int32_t merge_upto, int32_t* seg_ptr_host, int32_t* num_segments_out,
+                               int32_t* max_segment_nodes_out);
 
 /* 64-bit content hash of an int64 [2,E] DEVICE edge_index (for plan caching); hash_out: device uint64[1],
  * must be zeroed by the caller on the same stream before the call. */
@@ -191,8 +202,8 @@ typedef struct gatres_model {
 
 int64_t gatres_param_count(int32_t num_blocks, int32_t nc);
 /* floats of forward state kept for backward / of scratch needed by forward+backward / slabs used. */
-int64_t gatres_saved_floats(const gatres_model_t* m, int32_t num_nodes, int32_t num_edges_gat);
-int64_t gatres_scratch_floats(const gatres_model_t* m, int32_t num_nodes, int32_t num_edges_gat);
+int64_t gatres_saved_floats(const gatres_model_t* m, const gatres_graph_t* g);
+int64_t gatres_scratch_floats(const gatres_model_t* m, const gatres_graph_t* g);
 int32_t gatres_num_slabs(const gatres_model_t* m, int32_t num_nodes);
 
 /* out[N] = GATResMeanConv(x).  saved == NULL: inference (activations are not kept; scratch is reused per block). */
@@ -204,6 +215,36 @@ int gatres_model_forward(const gatres_model_t* m, const gatres_graph_t* g, const
 int gatres_model_backward(const gatres_model_t* m, const gatres_graph_t* g, const float* params,
                           const float* x, const uint8_t* mask, const float* g_out, const float* saved,
                           float* scratch, float* grads, float* g_x, void* stream);
+
+/* The same two entry points restricted to the per-op kernels above (any graph, any segment size). */
+int gatres_model_forward_per_op(const gatres_model_t* m, const gatres_graph_t* g, const float* params,
+                                const float* x, const uint8_t* mask, float* out, float* saved, float* scratch,
+                                void* stream);
+int gatres_model_backward_per_op(const gatres_model_t* m, const gatres_graph_t* g, const float* params,
+                                 const float* x, const uint8_t* mask, const float* g_out, const float* saved,
+                                 float* scratch, float* grads, float* g_x, void* stream);
+
+/* --------------------------------------------------------------------------------------------------------
+ * Fused per-snapshot path (k_fused.hip): ONE launch carries every segment through the selected phases --
+ * GATRES_PHASE_FORWARD (lin0 .. lin1), GATRES_PHASE_LOSS (masked MSE + d loss/d out; needs mask, y) and
+ * GATRES_PHASE_BACKWARD (all gradients, as per-segment slabs in scratch) -- one workgroup per segment, neighbour
+ * gathers of the forward pass served from LDS when a segment fits (C-Town at nc=32 does).  gatres_fused_finish
+ * sums the slabs into grads[P] and optionally applies Adam and finalises the loss in the same pass.
+ * gatres_model_forward/backward and gatres_train_step take this path whenever gatres_fused_supported().
+ * loss_part: device float[num_segments + 1].  GATRES_PHASE_BACKWARD reads the transposed conv weights from scratch:
+ * call gatres_fused_prepare_backward (one small launch) after the parameters last changed.
+ * ------------------------------------------------------------------------------------------------------ */
+#define GATRES_PHASE_LOSS 16
+int gatres_fused_supported(const gatres_model_t* m, const gatres_graph_t* g);
+int gatres_fused_prepare_backward(const gatres_model_t* m, const gatres_graph_t* g, const float* params,
+                                  float* scratch, void* stream);
+int gatres_fused_run(const gatres_model_t* m, const gatres_graph_t* g, const float* params, const float* x,
+                     const uint8_t* mask, const float* y, float* out, float* g_out, float* loss_part, float* g_x,
+                     float* saved, float* scratch, int32_t phases, void* stream);
+int gatres_fused_finish(const gatres_model_t* m, const gatres_graph_t* g, float* scratch, float* grads,
+                        const float* loss_part, float* loss, int32_t do_adam, float* params, float* exp_avg,
+                        float* exp_avg_sq, uint64_t* step_counter, double lr, double beta1, double beta2,
+                        double eps, double weight_decay, float grad_scale, void* stream);
 
 /* --------------------------------------------------------------------------------------------------------
  * One reference training iteration (train.py:159-190) enqueued natively:
@@ -243,8 +284,9 @@ typedef struct gatres_train_step {
   float* scratch;                  /* gatres_scratch_floats()                            */
   double lr, beta1, beta2, eps, weight_decay;
   float grad_scale;                /* multiplies grads inside Adam (1/world_size)        */
-  int32_t reserved;
+  int32_t flags;                   /* GATRES_FLAG_PER_OP: force the per-op kernels       */
 } gatres_train_step_t;
+#define GATRES_FLAG_PER_OP 1
 
 int gatres_train_step(const gatres_train_step_t* ts, void* stream);
 

@@ -41,9 +41,9 @@ def load_params(model, p):
     model.load_state_dict(sd)
 
 
-def build(pkg, oracle, nb, nc, seed):
+def build(pkg, oracle, nb, nc, seed, fused=True):
     p = oracle.init_params(nb, nc, seed=seed)
-    m = pkg.GATResMeanConv(num_blocks=nb, nc=nc)
+    m = pkg.GATResMeanConv(num_blocks=nb, nc=nc, fused=fused)
     load_params(m, p)
     return m.cuda(), p
 
@@ -52,11 +52,13 @@ def ctown_batch(pkg, bs, nodes=388, pipes=430):
     return pkg.wdn_synth.make_batch(bs, nodes, pipes)
 
 
+@pytest.mark.parametrize("fused", [True, False], ids=["fused", "per_op"])
 @pytest.mark.parametrize("nb,nc,bs,nodes,pipes", [(2, 8, 3, 40, 47), (15, 32, 2, 388, 430), (3, 128, 2, 60, 70),
-                                                   (1, 4, 1, 9, 10), (0, 16, 2, 12, 14)])
-def test_forward_backward_parity(pkg, oracle, nb, nc, bs, nodes, pipes):
+                                                   (1, 4, 1, 9, 10), (0, 16, 2, 12, 14), (2, 64, 2, 130, 150),
+                                                   (2, 32, 1, 450, 500)])
+def test_forward_backward_parity(pkg, oracle, nb, nc, bs, nodes, pipes, fused):
     x, y, ei, mask = ctown_batch(pkg, bs, nodes, pipes)
-    model, p = build(pkg, oracle, nb, nc, seed=3)
+    model, p = build(pkg, oracle, nb, nc, seed=3, fused=fused)
     # oracle fp32 + fp64
     leaves = {k: v.clone().requires_grad_(True) for k, v in p.items()}
     xin = x.clone(); xin[mask] = 0
@@ -70,19 +72,36 @@ def test_forward_backward_parity(pkg, oracle, nb, nc, bs, nodes, pipes):
     out = model(xd, ei.cuda(), None, None)
     assert out.shape == (x.shape[0], 1) and out.requires_grad
     e_out, e_out64, e_ref64 = relerr(out, out_ref), relerr(out, out64), relerr(out_ref, out64)
-    note(f"fwd nb{nb} nc{nc}: hip-vs-oracle32 / hip-vs-oracle64 / oracle32-vs-oracle64", [e_out, e_out64, e_ref64])
+    note(f"fwd nb{nb} nc{nc} {'fused' if fused else 'per-op'}: hip-vs-oracle32 / hip-vs-oracle64 / oracle32-vs-oracle64", [e_out, e_out64, e_ref64])
     assert e_out < 1e-5, (e_out, e_out64, e_ref64)
     m = mask.cuda()
     loss = torch.nn.functional.mse_loss(out[m], y.cuda()[m])
     loss.backward()
     assert relerr(loss, loss_ref) < 1e-5
-    worst = 0.0
+    # gradients: the fp64 oracle arbitrates.  Some tensors (att_dst: sum_e g_e is ~0 by softmax symmetry) are pure
+    # cancellation noise in fp32, so each tensor's error is judged against the fp32 oracle's own error vs fp64
+    # and against the scale of the whole gradient.
+    l64 = {k: v.clone().requires_grad_(True) for k, v in p64.items()}
+    o64 = oracle.gatres_forward(l64, xin.double(), ei, num_blocks=nb)
+    torch.nn.functional.mse_loss(o64[mask], y.double()[mask]).backward()
+    gscale = max(float(v.grad.abs().max()) for v in l64.values())
+    worst_ratio, worst_rel = 0.0, 0.0
     for (k, ref), prm in zip(leaves.items(), model.parameters()):
         assert prm.grad is not None and prm.grad.shape == ref.shape, k
-        e = relerr(prm.grad, ref.grad)
-        worst = max(worst, e)
-        assert e < 1e-4, (k, e)
-    note(f"bwd nb{nb} nc{nc}: worst param-grad rel err", worst)
+        g64 = l64[k].grad
+        e_hip = float((prm.grad.double().cpu() - g64).abs().max())
+        e_ref = float((ref.grad.double() - g64).abs().max())
+        tscale = float(g64.abs().max())
+        tol = max(8 * e_ref, 1e-5 * tscale, 2e-6 * gscale)
+        assert e_hip <= tol, (k, e_hip, e_ref, tscale, gscale)
+        worst_ratio = max(worst_ratio, e_hip / max(e_ref, 1e-30))
+        worst_rel = max(worst_rel, e_hip / gscale)
+    flat_hip = torch.cat([q.grad.reshape(-1) for q in model.parameters()])
+    flat_ref = torch.cat([v.grad.reshape(-1) for v in leaves.values()])
+    e_flat = relerr(flat_hip, flat_ref)
+    note(f"bwd nb{nb} nc{nc} {'fused' if fused else 'per-op'}: flat grad rel err vs oracle32 / worst err over |g|max / worst (hip err)/(oracle32 err)",
+         [e_flat, worst_rel, worst_ratio])
+    assert e_flat < 1e-5
 
 
 def test_module_surface_matches_reference(pkg, oracle):
@@ -145,13 +164,15 @@ def test_drop_in_training_loop_with_torch_adam(pkg, oracle):
     assert e < 1e-4
 
 
+@pytest.mark.parametrize("fused", [True, False], ids=["fused", "per_op"])
 @pytest.mark.parametrize("use_graph", [False, True])
-def test_native_train_step_matches_oracle(pkg, oracle, use_graph):
+def test_native_train_step_matches_oracle(pkg, oracle, use_graph, fused):
     nb, nc, bs = 15, 32, 2
-    model, p = build(pkg, oracle, nb, nc, seed=4)
+    model, p = build(pkg, oracle, nb, nc, seed=4, fused=fused)
     ref = oracle.OracleTrainer(p)
     ei = pkg.wdn_synth.collate_edge_index(pkg.wdn_synth.make_wdn_topology(), 388, bs)
-    tr = pkg.GATResTrainer(model, ei.cuda(), 388 * bs, nodes_per_graph=[388] * bs, use_graph=use_graph)
+    tr = pkg.GATResTrainer(model, ei.cuda(), 388 * bs, nodes_per_graph=[388] * bs, use_graph=use_graph, fused=fused)
+    assert tr.fused == fused
     snaps = pkg.wdn_synth.make_snapshots(8, 388, seed=6)
     rng = np.random.RandomState(1)
     for it in range(3):
@@ -163,12 +184,17 @@ def test_native_train_step_matches_oracle(pkg, oracle, use_graph):
         assert relerr(tr.out, o_ref) < 2e-5, it
         if it == 0:
             g = relerr(tr.grads, ref.flat("grads"))
-            note(f"native step (graph={use_graph}) flat grad rel err", g)
+            note(f"native step (graph={use_graph}, fused={fused}) flat grad rel err", g)
             assert g < 1e-4
     assert tr.optimizer_step == 3
-    e = relerr(model.flat_parameters, ref.flat("params"))
-    note(f"native step (graph={use_graph}) 3 steps: flat param rel err", e)
-    assert e < 1e-4
+    # Adam divides by sqrt(v): parameters whose gradient is fp32 cancellation noise move by ~lr per step in a
+    # noise-determined direction, in the fp32 oracle just as here.  So: the bulk must agree tightly, nothing may
+    # differ by more than the 3 steps could move it, and the loss/prediction trajectory above pins the rest.
+    diff = (model.flat_parameters.detach().cpu().double() - ref.flat("params").double()).abs()
+    frac_off = float((diff > 1e-5).double().mean())
+    note(f"native step (graph={use_graph}, fused={fused}) 3 steps: max |dp| / fraction of params off by > 1e-5",
+         [float(diff.max()), frac_off])
+    assert float(diff.max()) <= 3 * 5e-4 * 1.01 and frac_off < 0.01
     assert relerr(model.state_dict()["lin0.weight"], ref.flat("params")[:nc]) < 1e-4   # the module sees the update
     # device-side mask path: exact count per graph, loss finite, fresh mask per step
     tr.step(y.cuda(), y.cuda())
@@ -223,3 +249,24 @@ def test_full_size_properties_bs32(pkg, oracle):
     # the oracle on one graph of the batch pins the values
     ref = oracle.gatres_forward(p, x[:388], one)
     assert relerr(first, ref) < 1e-5
+
+
+def test_fused_equals_per_op_bitwise_forward(pkg, oracle):
+    """Same arithmetic, statement for statement: the fused per-snapshot kernel and the per-op kernels must give
+    bit-identical predictions (LDS-cached and uncached variants), and gradients equal up to the slab partition."""
+    for nb, nc, nodes, pipes, bs in [(15, 32, 388, 430, 3), (3, 32, 450, 500, 2), (2, 128, 90, 100, 2), (3, 8, 25, 28, 7)]:
+        x, y, ei, mask = ctown_batch(pkg, bs, nodes, pipes)
+        mf, p = build(pkg, oracle, nb, nc, seed=5, fused=True)
+        mp, _ = build(pkg, oracle, nb, nc, seed=5, fused=False)
+        dx, dei = x.cuda(), ei.cuda()
+        of, op = mf(dx, dei), mp(dx, dei)
+        assert mf._plans.get(dei, dx.shape[0]).num_segments >= bs and mp._plans.get(dei, dx.shape[0]).num_segments == 0
+        assert torch.equal(of, op), (nb, nc, nodes)
+        with torch.no_grad():
+            assert torch.equal(mf(dx, dei), of)          # inference path (no saved activations) == training path
+        g = torch.randn_like(of)
+        of.backward(g)
+        op.backward(g)
+        gf = torch.cat([q.grad.reshape(-1) for q in mf.parameters()])
+        gp = torch.cat([q.grad.reshape(-1) for q in mp.parameters()])
+        assert relerr(gf, gp) < 2e-6, (nb, nc, nodes, relerr(gf, gp))
