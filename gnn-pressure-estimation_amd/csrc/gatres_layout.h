@@ -12,9 +12,10 @@ struct Layout {
   int64_t c1_as, c1_ad, c1_b, c1_W, c2_as, c2_ad, c2_b, c2_W;   // inside a block
   // saved activations of one block (s_xin == 0 so that "xin of block nb" is the final activation)
   int64_t s_xin, s_h1, s_as1, s_ad1, s_al1, s_o1, s_h2, s_as2, s_ad2, s_al2, s_stride, saved_total;
-  // scratch
+  // scratch.  The *2 arrays are conv2's private copies for the fused kernels: there, workgroups are at different
+  // stages at the same time, so conv1 ([row*2], [row*2nc]) and conv2 ([row], [row*nc]) must not share an array.
   int64_t sc_y2, sc_ev, sc_xa, sc_xb, sc_gpa, sc_gpb, sc_gy2, sc_ge, sc_gad, sc_gas, sc_gh, sc_go1, sc_wt,
-      sc_slabs, sc_loss_part, scratch_total;
+      sc_ge2, sc_gad2, sc_gas2, sc_gh2, sc_slabs, sc_loss_part, scratch_total;
   int num_slabs;      // node-range slabs of the per-op path
   int slab_rows;      // slabs allocated = max(num_slabs, segments)
   int64_t slab_stride;
@@ -74,6 +75,10 @@ static inline bool make_layout(const gatres_model_t* m, int64_t N, int64_t Eg, i
   L->sc_gh = o;  o += r4(N * 2 * nc);
   L->sc_go1 = o; o += r4(N * 2 * nc);
   L->sc_wt = o;  o += r4((int64_t)nb * 2 * w);
+  L->sc_ge2 = o;  o += r4(Eg);
+  L->sc_gad2 = o; o += r4(N);
+  L->sc_gas2 = o; o += r4(N);
+  L->sc_gh2 = o;  o += r4(N * nc);
   L->slab_rows = L->num_slabs > num_segments ? L->num_slabs : num_segments;
   L->sc_slabs = o; o += (int64_t)L->slab_rows * L->slab_stride;
   L->sc_loss_part = o; o += r4((int64_t)L->slab_rows + 1);

@@ -19,6 +19,7 @@
 // and per-op forward/backward agree bitwise except for the parameter-gradient slabs, which are per-segment here.
 #include "gatres_common.h"
 #include "gatres_layout.h"
+#include <cstdlib>
 
 namespace {
 
@@ -47,9 +48,20 @@ struct FusedArgs {
   float* slabs;
   Layout L;
   int phases;               // GATRES_PHASE_FORWARD | _BACKWARD, bit 16: loss
+  unsigned long long* stamps;   // diagnostic: segment 0 stamps the wall clock at every stage boundary
+  int stamp_cap;
 };
 
 enum { PH_LOSS = 16 };
+
+static unsigned long long* g_stamps = nullptr;
+static int g_stamp_cap = 0;
+
+#define STAMP()                                                                                  \
+  do {                                                                                           \
+    if (a.stamps && blockIdx.x == 0 && threadIdx.x == 0 && stamp_i < a.stamp_cap)                \
+      a.stamps[stamp_i++] = wall_clock64();                                                      \
+  } while (0)
 
 // ------------------------------------------------------------------------------------------ small helpers
 template <int THREADS>
@@ -525,6 +537,8 @@ __global__ __launch_bounds__(THREADS) void gatres_fused_kernel(const FusedArgs a
   float* sd = sa + (size_t)n * 2;
   const float* P = a.params;
   float* sc = a.scratch;
+  int stamp_i = 0;
+  STAMP();
 
   if (a.phases & GATRES_PHASE_FORWARD) {
     float* xa = sc + L.sc_xa;
@@ -544,6 +558,7 @@ __global__ __launch_bounds__(THREADS) void gatres_fused_kernel(const FusedArgs a
       }
     }
     __syncthreads();
+    STAMP();
     for (int b = 0; b < L.nb; ++b) {
       float* base = a.saved ? a.saved + (int64_t)b * L.s_stride : sc + L.sc_ev;
       float* xnext = a.saved ? a.saved + (int64_t)(b + 1) * L.s_stride + L.s_xin : (xcur == xa ? xb : xa);
@@ -554,6 +569,7 @@ __global__ __launch_bounds__(THREADS) void gatres_fused_kernel(const FusedArgs a
                                                  pb + L.c1_as, pb + L.c1_ad, base + L.s_as1, base + L.s_ad1,
                                                  CACHE ? sa : nullptr, CACHE ? sd : nullptr, nullptr, nullptr);
       __syncthreads();
+      STAMP();
       if (CACHE)
         seg_agg_fwd<true, 2, NC, THREADS>(n0, n, a.rowptr, a.col, hA, n0, sa, sd, n0, pb + L.c1_b, base + L.s_o1, 0,
                                           base + L.s_al1);
@@ -561,11 +577,13 @@ __global__ __launch_bounds__(THREADS) void gatres_fused_kernel(const FusedArgs a
         seg_agg_fwd<true, 2, NC, THREADS>(n0, n, a.rowptr, a.col, base + L.s_h1, 0, base + L.s_as1, base + L.s_ad1, 0,
                                           pb + L.c1_b, base + L.s_o1, 0, base + L.s_al1);
       __syncthreads();
+      STAMP();
       // conv2
       seg_proj<2 * NC, NC, 1, EPI_ATT, THREADS>(n0, n, base + L.s_o1, pb + L.c2_W, base + L.s_h2, CACHE ? hB : nullptr,
                                                  pb + L.c2_as, pb + L.c2_ad, base + L.s_as2, base + L.s_ad2,
                                                  CACHE ? sa : nullptr, CACHE ? sd : nullptr, nullptr, nullptr);
       __syncthreads();
+      STAMP();
       if (CACHE)
         seg_agg_fwd<false, 1, NC, THREADS>(n0, n, a.rowptr, a.col, hB, n0, sa, sd, n0, pb + L.c2_b, hA, n0,
                                            base + L.s_al2);
@@ -573,12 +591,14 @@ __global__ __launch_bounds__(THREADS) void gatres_fused_kernel(const FusedArgs a
         seg_agg_fwd<false, 1, NC, THREADS>(n0, n, a.rowptr, a.col, base + L.s_h2, 0, base + L.s_as2, base + L.s_ad2, 0,
                                            pb + L.c2_b, y2g, 0, base + L.s_al2);
       __syncthreads();
+      STAMP();
       // K3
       if (CACHE)
         seg_mean_fwd<NC, THREADS>(n0, n, a.m_rowptr, a.m_col, hA, n0, xcur, xnext);
       else
         seg_mean_fwd<NC, THREADS>(n0, n, a.m_rowptr, a.m_col, y2g, 0, xcur, xnext);
       __syncthreads();
+      STAMP();
       xcur = xnext;
     }
     {  // lin1
@@ -598,6 +618,7 @@ __global__ __launch_bounds__(THREADS) void gatres_fused_kernel(const FusedArgs a
       }
     }
     __syncthreads();
+    STAMP();
   }
 
   if (a.phases & PH_LOSS) {
@@ -624,6 +645,7 @@ __global__ __launch_bounds__(THREADS) void gatres_fused_kernel(const FusedArgs a
       a.g_out[node] = a.mask[node] ? (a.out[node] - a.y[node]) * scale : 0.f;
     }
     __syncthreads();
+    STAMP();
   }
 
   if (a.phases & GATRES_PHASE_BACKWARD) {
@@ -636,12 +658,17 @@ __global__ __launch_bounds__(THREADS) void gatres_fused_kernel(const FusedArgs a
     float* gas = sc + L.sc_gas;
     float* gh = sc + L.sc_gh;
     float* go1 = sc + L.sc_go1;
+    float* ge2 = sc + L.sc_ge2;
+    float* gad2 = sc + L.sc_gad2;
+    float* gas2 = sc + L.sc_gas2;
+    float* gh2 = sc + L.sc_gh2;
     float* slab = a.slabs + (int64_t)seg * L.slab_stride;
     const int64_t w = 2LL * NC * NC;
     const float* xfinal = saved + (int64_t)L.nb * L.s_stride + L.s_xin;
     seg_lin1_bwd<NC, THREADS>(n0, n, a.g_out, xfinal, P + L.p_lin1_w, gp_cur, slab + L.p_lin1_w, slab + L.p_lin1_b,
                               L.nb > 0 ? 1 : 0, lds);
     __syncthreads();
+    STAMP();
     for (int b = L.nb - 1; b >= 0; --b) {
       const float* base = saved + (int64_t)b * L.s_stride;
       const int64_t po = L.p_block0 + (int64_t)b * L.p_block_stride;
@@ -651,33 +678,44 @@ __global__ __launch_bounds__(THREADS) void gatres_fused_kernel(const FusedArgs a
       const float* wt2 = wt1 + w;
       seg_mean_bwd<NC, THREADS>(n0, n, a.m_rowptr, a.mt_rowptr, a.mt_dst, gp_cur, gy2);
       __syncthreads();
+      STAMP();
       // conv2
       seg_agg_bwd_dst<1, NC, THREADS>(n0, n, a.rowptr, a.col, gy2, base + L.s_h2, base + L.s_al2, base + L.s_as2,
-                                      base + L.s_ad2, ge, gad);
+                                      base + L.s_ad2, ge2, gad2);
       __syncthreads();
-      seg_agg_bwd_src<1, NC, THREADS>(n0, n, a.t_rowptr, a.t_eid, a.t_dst, gy2, base + L.s_al2, ge, gad, pb + L.c2_as,
-                                      pb + L.c2_ad, gh, gas);
+      STAMP();
+      seg_agg_bwd_src<1, NC, THREADS>(n0, n, a.t_rowptr, a.t_eid, a.t_dst, gy2, base + L.s_al2, ge2, gad2, pb + L.c2_as,
+                                      pb + L.c2_ad, gh2, gas2);
       __syncthreads();
-      seg_conv_param_grads<1, NC, THREADS>(n0, n, base + L.s_h2, gas, gad, gy2, sb + L.c2_as, sb + L.c2_ad,
+      STAMP();
+      seg_conv_param_grads<1, NC, THREADS>(n0, n, base + L.s_h2, gas2, gad2, gy2, sb + L.c2_as, sb + L.c2_ad,
                                            sb + L.c2_b, lds);
-      seg_dw<NC, 2 * NC, THREADS>(n0, n, gh, base + L.s_o1, sb + L.c2_W);
-      seg_proj<NC, 2 * NC, 1, EPI_RESID_MASK, THREADS>(n0, n, gh, wt2, go1, nullptr, nullptr, nullptr, nullptr,
+      STAMP();
+      seg_dw<NC, 2 * NC, THREADS>(n0, n, gh2, base + L.s_o1, sb + L.c2_W);
+      STAMP();
+      seg_proj<NC, 2 * NC, 1, EPI_RESID_MASK, THREADS>(n0, n, gh2, wt2, go1, nullptr, nullptr, nullptr, nullptr,
                                                         nullptr, nullptr, nullptr, nullptr, base + L.s_o1);
       __syncthreads();
+      STAMP();
       // conv1
       seg_agg_bwd_dst<2, NC, THREADS>(n0, n, a.rowptr, a.col, go1, base + L.s_h1, base + L.s_al1, base + L.s_as1,
                                       base + L.s_ad1, ge, gad);
       __syncthreads();
+      STAMP();
       seg_agg_bwd_src<2, NC, THREADS>(n0, n, a.t_rowptr, a.t_eid, a.t_dst, go1, base + L.s_al1, ge, gad, pb + L.c1_as,
                                       pb + L.c1_ad, gh, gas);
       __syncthreads();
+      STAMP();
       seg_conv_param_grads<2, NC, THREADS>(n0, n, base + L.s_h1, gas, gad, go1, sb + L.c1_as, sb + L.c1_ad,
                                            sb + L.c1_b, lds);
+      STAMP();
       seg_dw<2 * NC, NC, THREADS>(n0, n, gh, base + L.s_xin, sb + L.c1_W);
+      STAMP();
       seg_proj<2 * NC, NC, 1, EPI_RESID_MASK, THREADS>(n0, n, gh, wt1, gp_nxt, nullptr, nullptr, nullptr, nullptr,
                                                         nullptr, nullptr, nullptr, gp_cur,
                                                         b > 0 ? base + L.s_xin : nullptr);
       __syncthreads();
+      STAMP();
       float* t = gp_cur; gp_cur = gp_nxt; gp_nxt = t;
     }
     seg_lin0_bwd<NC, THREADS>(n0, n, gp_cur, a.x, a.mask, slab + L.p_lin0_w, slab + L.p_lin0_b, lds);
@@ -753,7 +791,8 @@ __global__ __launch_bounds__(256) void reduce_adam_kernel(const float* __restric
 
 template <int NC, int THREADS>
 static int launch_fused(const FusedArgs& a, int num_segments, int max_seg, hipStream_t st) {
-  const bool cache = (long long)max_seg * (3 * NC + 4) <= LDS_FLOATS_MAX && 3 * THREADS <= LDS_FLOATS_MAX;
+  const bool cache = (long long)max_seg * (3 * NC + 4) <= LDS_FLOATS_MAX && 3 * THREADS <= LDS_FLOATS_MAX &&
+                     !getenv("GATRES_FUSED_NOCACHE");
   if (cache)
     hipLaunchKernelGGL((gatres_fused_kernel<NC, THREADS, true>), dim3(num_segments), dim3(THREADS), 0, st, a);
   else
@@ -769,6 +808,14 @@ extern "C" int gatres_fused_supported(const gatres_model_t* m, const gatres_grap
   if (!m || !g || g->num_segments <= 0 || !g->seg_ptr) return 0;
   if (g->max_segment_nodes > 4096) return 0;      // beyond this a snapshot should be spread over many CUs
   return (m->nc >= 4 && m->nc <= 128 && gatres_is_pow2(m->nc)) ? 1 : 0;
+}
+
+// Diagnostic: segment 0 of the next fused launches writes a 100 MHz wall-clock stamp at every stage boundary into
+// stamps[0..capacity) (device memory).  Pass nullptr to switch it off.
+extern "C" int gatres_fused_set_stamps(uint64_t* stamps, int32_t capacity) {
+  g_stamps = reinterpret_cast<unsigned long long*>(stamps);
+  g_stamp_cap = stamps ? capacity : 0;
+  return 0;
 }
 
 extern "C" int gatres_fused_prepare_backward(const gatres_model_t* m, const gatres_graph_t* g, const float* params,
@@ -797,6 +844,7 @@ extern "C" int gatres_fused_run(const gatres_model_t* m, const gatres_graph_t* g
   a.params = params; a.wt = scratch + a.L.sc_wt;
   a.x = x; a.mask = mask; a.y = y; a.out = out; a.g_out = g_out; a.loss_part = loss_part; a.g_x = g_x;
   a.saved = saved; a.scratch = scratch; a.slabs = scratch + a.L.sc_slabs;
+  a.stamps = g_stamps; a.stamp_cap = g_stamp_cap;
   a.phases = (phases & (GATRES_PHASE_FORWARD | GATRES_PHASE_BACKWARD)) | ((phases & GATRES_PHASE_LOSS) ? PH_LOSS : 0);
   hipStream_t st = gatres_stream(stream);
   const int S = g->num_segments, mx = g->max_segment_nodes;
