@@ -44,6 +44,7 @@ def parse():
     ap.add_argument("--nodes", type=int, default=388)
     ap.add_argument("--pipes", type=int, default=430)
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
+    ap.add_argument("--per-op", action="store_true", help="one launch per stage instead of the fused per-snapshot kernel")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--no-roofline", action="store_true")
@@ -115,6 +116,41 @@ def kernel_table(G, model, plan, nc):
     return rows
 
 
+def algorithmic_bytes_per_step(rows, N, nc, P):
+    """Compulsory-traffic model of one training step: every stage's inputs read once and
+    outputs written once at full row width, no cache credit; = sum over the per-op stages + lin0/lin1/loss/Adam."""
+    stages = sum(r[1] * r[2] for r in rows)
+    small = 4 * (N + 2 * N * nc) * 2 + 4 * (2 * N * nc + 2 * N) + 4 * 4 * N + 4 * 7 * P
+    return stages + small
+
+
+def time_fused(G, trainer, device, reps=50):
+    """Average duration of the fused per-snapshot kernel (forward + loss + backward in ONE launch), HIP events on
+    the launch stream."""
+    import ctypes as C
+    lib = G._native.load()
+    m, plan = trainer.model, trainer.plan
+    L = trainer
+    PH = 2 | 16 | 4
+    lp = torch.zeros(plan.num_segments + 1, dtype=torch.float32, device=device)
+    args = (m._cmodel_ref(), plan.ref(), m.flat_parameters.data_ptr(), L.x.data_ptr(), L.mask.data_ptr(),
+            L.y.data_ptr(), L.out.data_ptr(), L.g_out.data_ptr(), lp.data_ptr(), None, L.saved.data_ptr(),
+            L.scratch.data_ptr(), PH)
+    st = lambda: G._native.current_stream(device)
+    G._native.check(lib.gatres_fused_prepare_backward(m._cmodel_ref(), plan.ref(), m.flat_parameters.data_ptr(),
+                                                      L.scratch.data_ptr(), st()), "prepare")
+    for _ in range(5):
+        G._native.check(lib.gatres_fused_run(*args, st()), "fused_run")
+    torch.cuda.synchronize(device)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(torch.cuda.current_stream(device))
+    for _ in range(reps):
+        lib.gatres_fused_run(*args, st())
+    e1.record(torch.cuda.current_stream(device))
+    e1.synchronize()
+    return e0.elapsed_time(e1) * 1e3 / reps
+
+
 def time_kernels(rows, device, reps=200):
     out = []
     for name, calls, nbytes, fn in rows:
@@ -140,14 +176,26 @@ def cpu_baseline(args, nb, nc):
     from oracle import gatres_oracle as O
     import gnn_pressure_estimation_amd as G
     try:
-        cores = len(os.sched_getaffinity(0))
+        avail = len(os.sched_getaffinity(0))
     except AttributeError:
-        cores = os.cpu_count() or 1
-    torch.set_num_threads(cores)
-    log(f"cpu baseline on {cores} host threads ...")
+        avail = os.cpu_count() or 1
     x, y, ei, mask = G.wdn_synth.make_batch(args.batch_size, args.nodes, args.pipes)
     tr = O.OracleTrainer(O.init_params(nb, nc, seed=3))
+    # These are ~2400 tiny ops per step: an OpenMP team as wide as a 256-thread host makes every one of them
+    # slower, so the thread count is chosen by a short calibration (one step each) and reported as `cores`.
+    cands = sorted({c for c in (8, 16, 32) if c <= avail} or {avail})
+    torch.set_num_threads(cands[0])
     tr.step(x, y, ei, mask)                           # warm-up (thread pool, autograd graph)
+    best, cores = None, cands[0]
+    for c in cands:
+        torch.set_num_threads(c)
+        t0 = time.perf_counter()
+        tr.step(x, y, ei, mask)
+        dt1 = time.perf_counter() - t0
+        log(f"cpu baseline calibration: {c} threads -> {dt1:.3f} s/step")
+        if best is None or dt1 < best:
+            best, cores = dt1, c
+    torch.set_num_threads(cores)
     t0, n = time.perf_counter(), 0
     while n < 3 or (time.perf_counter() - t0 < args.cpu_seconds and n < 50):
         tr.step(x, y, ei, mask)
@@ -155,8 +203,8 @@ def cpu_baseline(args, nb, nc):
     dt = time.perf_counter() - t0
     return dict(value=args.batch_size * n / dt, unit="snapshots/s", cores=cores, kind="port",
                 sample=f"{n} full training steps (mask->fwd->MSE->bwd->Adam) of {args.model} on one "
-                       f"bs={args.batch_size} batch after 1 warm-up, torch {torch.__version__} CPU ops, "
-                       f"{cores} threads")
+                       f"bs={args.batch_size} batch after warm-up, torch {torch.__version__} CPU ops, {cores} threads "
+                       f"(best of {cands} on a host with {avail} hardware threads)")
 
 
 def main():
@@ -184,7 +232,7 @@ def main():
     topo = G.wdn_synth.make_wdn_topology(args.nodes, args.pipes, seed=0)
     ei = G.wdn_synth.collate_edge_index(topo, args.nodes, args.batch_size).to(device)
     trainer = G.GATResTrainer(model, ei, N, nodes_per_graph=[args.nodes] * args.batch_size, seed=1000 + rank,
-                              use_graph=not args.no_graph)
+                              use_graph=not args.no_graph, fused=not args.per_op)
     nbatches = 8
     snaps = G.wdn_synth.make_snapshots(nbatches * args.batch_size, args.nodes, seed=100 + rank).to(device)
     batches = [snaps[i * args.batch_size:(i + 1) * args.batch_size].reshape(-1).contiguous() for i in range(nbatches)]
@@ -225,22 +273,34 @@ def main():
         "config": {"workload": f"{args.model} ({nb} blocks, nc={nc}), C-Town-sized WDN ({args.nodes} nodes, "
                                f"{2 * args.pipes} directed edges), batch_size={args.batch_size} per GPU, fp32, "
                                f"full training step (device mask 0.95 -> fwd -> masked MSE -> bwd -> Adam), "
+                               f"{'per-op kernels' if not trainer.fused else 'fused per-snapshot kernel'}, "
                                f"{'eager launches' if args.no_graph else 'hipGraph replay'}",
                    "global_batch": world * args.batch_size, "parallelism": f"dp{world}",
                    "final_loss": loss},
     }
 
     if rank == 0 and not args.no_roofline:
-        log("per-kernel timing ...")
-        rows = time_kernels(kernel_table(G, model, trainer.plan, nc), device)
-        for r in rows:
-            r["step_share_us"] = r["avg_us"] * r["calls_per_step"]
-        dom = max(rows, key=lambda r: r["step_share_us"])
-        result["roofline"] = {"bound": "hbm", "kernel": dom["kernel"], "achieved": dom["gbs"], "peak": HBM_PEAK_GBS,
-                              "unit": "GB/s", "frac": dom["gbs"] / HBM_PEAK_GBS, "traffic": None,
-                              "avg_launch_us": dom["avg_us"], "algorithmic_bytes_per_launch": dom["algorithmic_bytes"]}
-        result["kernels"] = [{k: (round(v, 3) if isinstance(v, float) else v) for k, v in r.items()} for r in rows]
-        result["kernel_time_sum_us_per_step"] = round(sum(r["step_share_us"] for r in rows), 1)
+        table = kernel_table(G, model, trainer.plan, nc)
+        if trainer.fused:
+            log("timing the fused per-snapshot kernel ...")
+            nbytes = algorithmic_bytes_per_step(table, N, nc, trainer.P)
+            us = time_fused(G, trainer, device)
+            result["roofline"] = {"bound": "hbm", "kernel": "gatres_fused_kernel (forward+loss+backward, one launch)",
+                                  "achieved": nbytes / us * 1e-3, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                  "frac": nbytes / us * 1e-3 / HBM_PEAK_GBS, "traffic": None,
+                                  "avg_launch_us": us, "algorithmic_bytes_per_launch": nbytes,
+                                  "algorithmic_bytes_per_snapshot": nbytes / args.batch_size}
+        else:
+            log("per-kernel timing ...")
+            rows = time_kernels(table, device)
+            for r in rows:
+                r["step_share_us"] = r["avg_us"] * r["calls_per_step"]
+            dom = max(rows, key=lambda r: r["step_share_us"])
+            result["roofline"] = {"bound": "hbm", "kernel": dom["kernel"], "achieved": dom["gbs"],
+                                  "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": dom["gbs"] / HBM_PEAK_GBS,
+                                  "traffic": None, "avg_launch_us": dom["avg_us"],
+                                  "algorithmic_bytes_per_launch": dom["algorithmic_bytes"]}
+            result["kernels"] = [{k: (round(v, 3) if isinstance(v, float) else v) for k, v in r.items()} for r in rows]
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(args, nb, nc)
     if world > 1:

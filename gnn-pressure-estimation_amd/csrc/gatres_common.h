@@ -27,3 +27,8 @@ __device__ __forceinline__ float gatres_leaky(float v) { return v > 0.f ? v : v 
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 __device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
 __device__ __forceinline__ float4 f4zero() { return make_float4(0.f, 0.f, 0.f, 0.f); }
+// acc += a * v with ONE rounding per element (fma); used by every neighbour accumulation, fused and per-op alike,
+// so both paths produce bit-identical sums.
+__device__ __forceinline__ void gatres_axpy4(float4& acc, float a, const float4 v) {
+  acc.x = fmaf(a, v.x, acc.x); acc.y = fmaf(a, v.y, acc.y); acc.z = fmaf(a, v.z, acc.z); acc.w = fmaf(a, v.w, acc.w);
+}

@@ -73,8 +73,11 @@ extern "C" int gatres_graph_build_host(const int64_t* ei, int64_t E, int64_t N, 
 // snapshot (or finer, if a snapshot is disconnected); neighbours smaller than `merge_upto` are then coalesced so a
 // workgroup never gets a degenerate handful of nodes.
 extern "C" int gatres_graph_segments_host(const int64_t* ei, int64_t E, int64_t N, int32_t merge_upto,
-                                          int32_t* seg_ptr, int32_t* num_segments_out, int32_t* max_nodes_out) {
-  if ((!ei && E > 0) || !seg_ptr || !num_segments_out || !max_nodes_out || E < 0 || N <= 0) return GATRES_E_BADARG;
+                                          int32_t* seg_ptr, int32_t* num_segments_out, int32_t* max_nodes_out,
+                                          int32_t* max_edges_gat_out, int32_t* max_edges_mean_out) {
+  if ((!ei && E > 0) || !seg_ptr || !num_segments_out || !max_nodes_out || !max_edges_gat_out || !max_edges_mean_out ||
+      E < 0 || N <= 0)
+    return GATRES_E_BADARG;
   if (N > INT32_MAX) return GATRES_E_UNSUPPORTED;
   std::vector<int32_t> reach(N);
   for (int64_t i = 0; i < N; ++i) reach[i] = (int32_t)i;
@@ -103,7 +106,22 @@ extern "C" int gatres_graph_segments_host(const int64_t* ei, int64_t E, int64_t 
   }
   seg_ptr[++ns] = cur_end;
   if (cur_end - start > mx) mx = cur_end - start;
+  // per-segment edge counts (every edge lies inside one segment, so count by destination)
+  std::vector<int64_t> in_all(N + 1, 0), in_gat(N + 1, 0);
+  for (int64_t e = 0; e < E; ++e) {
+    in_all[ei[E + e] + 1]++;
+    in_gat[ei[E + e] + 1] += (ei[e] != ei[E + e]);
+  }
+  for (int64_t i = 0; i < N; ++i) { in_all[i + 1] += in_all[i]; in_gat[i + 1] += in_gat[i] + 1; }   // +1: self loop
+  int64_t mg = 0, mm = 0;
+  for (int32_t sgi = 0; sgi < ns; ++sgi) {
+    const int64_t a = seg_ptr[sgi], b = seg_ptr[sgi + 1];
+    if (in_gat[b] - in_gat[a] > mg) mg = in_gat[b] - in_gat[a];
+    if (in_all[b] - in_all[a] > mm) mm = in_all[b] - in_all[a];
+  }
   *num_segments_out = ns;
   *max_nodes_out = mx;
+  *max_edges_gat_out = (int32_t)(mg > INT32_MAX ? INT32_MAX : mg);
+  *max_edges_mean_out = (int32_t)(mm > INT32_MAX ? INT32_MAX : mm);
   return 0;
 }

@@ -71,15 +71,15 @@ __global__ __launch_bounds__(256) void gat_aggregate_fwd_kernel(
     const float al0 = expf(gatres_leaky(a_src[j0 * H + hd] + adst) - m) / Z;
     const float al1 = expf(gatres_leaky(a_src[j1 * H + hd] + adst) - m) / Z;
     if (leader) { alpha[(size_t)e * H + hd] = al0; alpha[(size_t)(e + 1) * H + hd] = al1; }
-    acc.x = acc.x + al0 * v0.x; acc.y = acc.y + al0 * v0.y; acc.z = acc.z + al0 * v0.z; acc.w = acc.w + al0 * v0.w;
-    acc.x = acc.x + al1 * v1.x; acc.y = acc.y + al1 * v1.y; acc.z = acc.z + al1 * v1.z; acc.w = acc.w + al1 * v1.w;
+    gatres_axpy4(acc, al0, v0);
+    gatres_axpy4(acc, al1, v1);
   }
   if (e < end) {
     const int j0 = col[e];
     const float4 v0 = ld4(h + (size_t)j0 * HC + c0);
     const float al0 = expf(gatres_leaky(a_src[j0 * H + hd] + adst) - m) / Z;
     if (leader) alpha[(size_t)e * H + hd] = al0;
-    acc.x = acc.x + al0 * v0.x; acc.y = acc.y + al0 * v0.y; acc.z = acc.z + al0 * v0.z; acc.w = acc.w + al0 * v0.w;
+    gatres_axpy4(acc, al0, v0);
   }
   const float4 b = ld4(bias + c0);
   acc.x = acc.x + b.x; acc.y = acc.y + b.y; acc.z = acc.z + b.z; acc.w = acc.w + b.w;
@@ -131,7 +131,7 @@ __global__ __launch_bounds__(256) void gat_aggregate_bwd_dst_kernel(
       if (beg + k < end) {
         const int j = col[beg + k];
         ga[k] = head_dot(go, ld4(h + (size_t)j * HC + c0), LH);
-        S = S + alpha[(size_t)(beg + k) * H + hd] * ga[k];
+        S = fmaf(alpha[(size_t)(beg + k) * H + hd], ga[k], S);
       }
     }
 #pragma unroll
@@ -148,7 +148,7 @@ __global__ __launch_bounds__(256) void gat_aggregate_bwd_dst_kernel(
   } else {                              // hub rows: recompute the dots in the second pass
     for (int e = beg; e < end; ++e) {
       const float ga = head_dot(go, ld4(h + (size_t)col[e] * HC + c0), LH);
-      S = S + alpha[(size_t)e * H + hd] * ga;
+      S = fmaf(alpha[(size_t)e * H + hd], ga, S);
     }
     for (int e = beg; e < end; ++e) {
       const int j = col[e];
@@ -192,21 +192,21 @@ __global__ __launch_bounds__(256) void gat_aggregate_bwd_src_kernel(
     const float al0 = alpha[(size_t)e0 * H + hd], al1 = alpha[(size_t)e1 * H + hd];
     gas = gas + g_e[(size_t)e0 * H + hd];
     gas = gas + g_e[(size_t)e1 * H + hd];
-    acc.x = acc.x + al0 * v0.x; acc.y = acc.y + al0 * v0.y; acc.z = acc.z + al0 * v0.z; acc.w = acc.w + al0 * v0.w;
-    acc.x = acc.x + al1 * v1.x; acc.y = acc.y + al1 * v1.y; acc.z = acc.z + al1 * v1.z; acc.w = acc.w + al1 * v1.w;
+    gatres_axpy4(acc, al0, v0);
+    gatres_axpy4(acc, al1, v1);
   }
   if (t < end) {
     const int e0 = t_eid[t], i0 = t_dst[t];
     const float4 v0 = ld4(g_out + (size_t)i0 * HC + c0);
     const float al0 = alpha[(size_t)e0 * H + hd];
     gas = gas + g_e[(size_t)e0 * H + hd];
-    acc.x = acc.x + al0 * v0.x; acc.y = acc.y + al0 * v0.y; acc.z = acc.z + al0 * v0.z; acc.w = acc.w + al0 * v0.w;
+    gatres_axpy4(acc, al0, v0);
   }
   if (leader) g_a_src[row * H + hd] = gas;
   const float gad = g_a_dst[row * H + hd];
   const float4 as = ld4(att_src + c0), ad = ld4(att_dst + c0);
-  acc.x = acc.x + gas * as.x; acc.y = acc.y + gas * as.y; acc.z = acc.z + gas * as.z; acc.w = acc.w + gas * as.w;
-  acc.x = acc.x + gad * ad.x; acc.y = acc.y + gad * ad.y; acc.z = acc.z + gad * ad.z; acc.w = acc.w + gad * ad.w;
+  gatres_axpy4(acc, gas, as);
+  gatres_axpy4(acc, gad, ad);
   st4(g_h + (size_t)row * HC + c0, acc);
 }
 

@@ -2,42 +2,45 @@
 // and carries it through lin0 -> num_blocks x [K1 conv1, K2 conv1, K1 conv2, K2 conv2, K3] -> lin1 -> masked-MSE ->
 // the whole backward, inside a single launch.
 //
-// Why (measured on MI355X, profiles/r01_unfused_*): as ~230 separate launches every stage is a dependent kernel
-// whose inputs were just written by other XCDs, so each costs ~5 us of launch + Infinity-Cache latency however
-// little it moves; the step was 2.35 ms for 1.6 GB of algorithmic traffic.  A PyG batch is block-diagonal
-// (train.py:302-303; `batch` is not even passed to the model, train.py:167), so a snapshot never needs another
-// workgroup's data: the only synchronisation left is __syncthreads().
+// Why (measured on MI355X, profiles/r01_perop_kernel_stats.csv): as ~230 separate launches every stage is a
+// dependent kernel whose inputs were just written by other XCDs, so each costs ~5 us of launch + Infinity-Cache
+// latency however little it moves; the step was 2.35 ms for 1.6 GB of algorithmic traffic.  A PyG batch is
+// block-diagonal (train.py:302-303; `batch` is not even passed to the model, train.py:167), so a snapshot never
+// needs another workgroup's data: the only synchronisation left is __syncthreads().
 //
-// Data placement: a 388-node C-Town snapshot at nc=32 needs 388 x (64 + 32) x 4 B = 149 KB for the two tables that
-// are gathered by neighbour index (h of conv1 / y2, h of conv2) plus the attention logits -- it fits the CU's
-// 160 KB LDS, so every neighbour gather of the forward pass is an LDS read (16-B per lane, conflict-free for
-// 256-B rows under the ds_read_b128 lane groups).  Activations that the backward pass needs are written once to
-// HBM (coalesced float4 rows); backward gathers are L2/Infinity-Cache hits.  Dense projections run on the matrix
-// cores (v_mfma_f32_16x16x4_f32, exact fp32), 16 waves per workgroup, one 16-node tile per wave per trip.
-//
-// Arithmetic is statement-for-statement the same as the per-op kernels (k_aggregate.hip, k_proj.hip), so fused
-// and per-op forward/backward agree bitwise except for the parameter-gradient slabs, which are per-segment here.
+// A single workgroup cannot hide latency with parallelism, so the kernel is organised around dependent-load depth
+// (profiles/r01_fused_v0_stage_times.txt: a naive port of the per-op stages ran 3.4 ms because every col[e] ->
+// gather hop was a serial ~0.3 us trip):
+//   * the segment's topology lives in LDS as 16-bit LOCAL indices (rowptr / col / transposed / mean CSR);
+//   * per destination row all (<= 8) neighbour loads are issued together, then reduced in CSR order, so the sums
+//     are bit-identical to the per-op kernels' edge-at-a-time loops;
+//   * forward: the tables gathered by neighbour index (h of conv1 / y2, h of conv2, attention logits) stay in LDS
+//     (C-Town at nc=32: 388 x (64+32+4) x 4 B = 155 KB of the CU's 160 KB); backward: g_pre | g_y2, g_out1, g_e,
+//     g_a_src, g_a_dst stay in LDS;  only what the backward pass needs later is written to HBM (coalesced float4);
+//   * dense projections on the matrix cores (v_mfma_f32_16x16x4_f32, exact fp32), two 16-node tiles per wave
+//     sharing each W fragment; dW partials with 8 operand pairs in flight per wave.
+#include <cstdlib>
+#include <type_traits>
+
 #include "gatres_common.h"
 #include "gatres_layout.h"
-#include <cstdlib>
 
 namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned short u16;
 
-constexpr int LDS_FLOATS_MAX = 40000;   // 160,000 B of the CU's 163,840 B
+constexpr int LDS_BYTES = 163840;   // the whole CU LDS; one workgroup per CU
+constexpr int MAXD = 8;             // neighbour loads issued together per row (rows with more edges take a loop)
 
 struct FusedArgs {
-  // graph plan
   const int* seg_ptr;
   const int *rowptr, *col, *t_rowptr, *t_eid, *t_dst, *m_rowptr, *m_col, *mt_rowptr, *mt_dst;
   int N;
-  // model
   const float* params;
   const float* wt;          // transposed conv weights (backward)
-  // io
   const float* x;
-  const uint8_t* mask;      // may be null (no masking of x; loss phase needs it)
+  const uint8_t* mask;      // may be null (no masking of x; the loss phase needs it)
   const float* y;
   float* out;
   float* g_out;             // written by the loss phase, read by the backward phase
@@ -63,6 +66,23 @@ static int g_stamp_cap = 0;
       a.stamps[stamp_i++] = wall_clock64();                                                      \
   } while (0)
 
+// ------------------------------------------------------------------------------------------ LDS budget (host+device)
+__host__ __device__ inline int even(int v) { return (v + 1) & ~1; }
+__host__ __device__ inline int topo_fwd_bytes(int n, int eg, int em) {
+  return 2 * (2 * even(n + 1) + even(eg) + even(em));
+}
+__host__ __device__ inline int topo_bwd_bytes(int n, int eg, int em) {
+  return 2 * (4 * even(n + 1) + 3 * even(eg) + 2 * even(em));
+}
+static bool cache_fits(int nc, int threads, int n, int eg, int em) {
+  const long long fwd = 4LL * n * (3 * nc + 4) + topo_fwd_bytes(n, eg, em);
+  const long long bwd = 12LL * threads + 4LL * n * 2 * nc + 8LL * even(eg) + 16LL * n + topo_bwd_bytes(n, eg, em);
+  return fwd <= LDS_BYTES && bwd <= LDS_BYTES && n <= 65535 && eg <= 65535 && em <= 65535;
+}
+static bool nocache_fits(int threads, int n, int eg, int em) {
+  return 12LL * threads + topo_bwd_bytes(n, eg, em) <= LDS_BYTES && n <= 65535 && eg <= 65535 && em <= 65535;
+}
+
 // ------------------------------------------------------------------------------------------ small helpers
 template <int THREADS>
 __device__ __forceinline__ float block_sum(float v, float* red) {
@@ -77,7 +97,7 @@ __device__ __forceinline__ float block_sum(float v, float* red) {
 }
 
 template <int KQ>
-__device__ __forceinline__ void load_frag(const float* __restrict__ p, float (&f)[KQ]) {
+__device__ __forceinline__ void load_frag(const float* p, float (&f)[KQ]) {
   if constexpr (KQ % 4 == 0) {
 #pragma unroll
     for (int s = 0; s < KQ; s += 4) {
@@ -96,44 +116,37 @@ __device__ __forceinline__ void load_frag(const float* __restrict__ p, float (&f
   }
 }
 
+__device__ __forceinline__ void add4(float4& acc, const float4 v) {
+  acc.x = acc.x + v.x; acc.y = acc.y + v.y; acc.z = acc.z + v.z; acc.w = acc.w + v.w;
+}
+
+template <int THREADS>
+__device__ __forceinline__ void copy_rowptr16(u16* dst, const int* __restrict__ src, int n0, int n, int e0) {
+  for (int r = threadIdx.x; r <= n; r += THREADS) dst[r] = (u16)(src[n0 + r] - e0);
+}
+template <int THREADS>
+__device__ __forceinline__ void copy_idx16(u16* dst, const int* __restrict__ src, int e0, int cnt, int sub) {
+  for (int k = threadIdx.x; k < cnt; k += THREADS) dst[k] = (u16)(src[e0 + k] - sub);
+}
+
 enum { EPI_NONE = 0, EPI_ATT = 1, EPI_RESID_MASK = 2 };
 
 // ------------------------------------------------------------------------------------------ K1 (MFMA)
-// OUT[n0+r, :] = X[n0+r, :] @ Wm^T for r in [0, n).  Optional copies into LDS (local row index) for the gathers
-// that follow.  Same tile / lane map / k order as proj_kernel in k_proj.hip.
+// OUT[ob + r, :] = X[xb + r, :] @ Wm^T for r in [0, n).  Same lane map / k order as proj_kernel (k_proj.hip), so
+// results are bit-identical; each wave takes TWO 16-node tiles per trip and feeds both from one W fragment load.
 template <int K, int M, int H, int EPI, int THREADS>
-__device__ __forceinline__ void seg_proj(int n0, int n, const float* __restrict__ X, const float* __restrict__ Wm,
-                                         float* __restrict__ OUT, float* OUT_L, const float* __restrict__ att_src,
-                                         const float* __restrict__ att_dst, float* __restrict__ a_src_g,
-                                         float* __restrict__ a_dst_g, float* a_src_l, float* a_dst_l,
-                                         const float* __restrict__ resid, const float* __restrict__ relu_ref) {
-  constexpr int KQ = K / 4, NT = (M + 15) / 16;
+__device__ __forceinline__ void seg_proj(int n, const float* X, int xb, const float* __restrict__ Wm, float* OUT,
+                                         int ob, float* OUT2, int o2b, const float* __restrict__ att_src,
+                                         const float* __restrict__ att_dst, float* as_g, float* ad_g, int ag_b,
+                                         float* as_l, float* ad_l, const float* resid, int rb,
+                                         const float* relu_ref, int mb_) {
+  constexpr int KQ = K / 4, NT = (M + 15) / 16, NW = THREADS / 64;
   constexpr int SC = (KQ % 4 == 0) ? 4 : ((KQ % 2 == 0) ? 2 : 1);
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int i = lane & 15, q = lane >> 4;
   const int ntiles = (n + 15) >> 4;
-  for (int t = wave; t < ntiles; t += THREADS / 64) {
-    const int r = t * 16 + i;
-    const bool rok = r < n;
-    const size_t node = (size_t)n0 + (rok ? r : n - 1);
-    float xf[KQ];
-    load_frag<KQ>(X + node * K + q * KQ, xf);
-    f32x4 acc[NT];
-#pragma unroll
-    for (int tt = 0; tt < NT; ++tt) acc[tt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int s = 0; s < KQ; s += SC) {
-#pragma unroll
-      for (int tt = 0; tt < NT; ++tt) {
-        const int m = tt * 16 + i;
-        const bool mok = (M % 16 == 0) || (m < M);
-        float wf[SC];
-        load_frag<SC>(Wm + (size_t)(mok ? m : 0) * K + q * KQ + s, wf);
-#pragma unroll
-        for (int u = 0; u < SC; ++u)
-          acc[tt] = __builtin_amdgcn_mfma_f32_16x16x4f32(mok ? wf[u] : 0.f, xf[s + u], acc[tt], 0, 0, 0);
-      }
-    }
+
+  auto epilogue = [&](f32x4(&acc)[NT], int r, bool rok) {
     if constexpr (EPI == EPI_ATT) {
       constexpr int C = M / H;
       float ps[H], pd[H];
@@ -160,9 +173,9 @@ __device__ __forceinline__ void seg_proj(int n0, int n, const float* __restrict_
       if (q == 0 && rok) {
 #pragma unroll
         for (int hh = 0; hh < H; ++hh) {
-          a_src_g[node * H + hh] = ps[hh];
-          a_dst_g[node * H + hh] = pd[hh];
-          if (a_src_l) { a_src_l[r * H + hh] = ps[hh]; a_dst_l[r * H + hh] = pd[hh]; }
+          as_g[(size_t)(ag_b + r) * H + hh] = ps[hh];
+          ad_g[(size_t)(ag_b + r) * H + hh] = pd[hh];
+          if (as_l) { as_l[r * H + hh] = ps[hh]; ad_l[r * H + hh] = pd[hh]; }
         }
       }
     }
@@ -173,151 +186,312 @@ __device__ __forceinline__ void seg_proj(int n0, int n, const float* __restrict_
         if ((M % 16 == 0) || (mb < M)) {
           float4 o = make_float4(acc[tt][0], acc[tt][1], acc[tt][2], acc[tt][3]);
           if constexpr (EPI == EPI_RESID_MASK) {
-            if (resid) {
-              const float4 rr = ld4(resid + node * M + mb);
-              o.x = o.x + rr.x; o.y = o.y + rr.y; o.z = o.z + rr.z; o.w = o.w + rr.w;
-            }
+            if (resid) add4(o, ld4(resid + (size_t)(rb + r) * M + mb));
             if (relu_ref) {
-              const float4 rr = ld4(relu_ref + node * M + mb);
+              const float4 rr = ld4(relu_ref + (size_t)(mb_ + r) * M + mb);
               o.x = rr.x > 0.f ? o.x : 0.f; o.y = rr.y > 0.f ? o.y : 0.f;
               o.z = rr.z > 0.f ? o.z : 0.f; o.w = rr.w > 0.f ? o.w : 0.f;
             }
           }
-          st4(OUT + node * M + mb, o);
-          if (OUT_L) st4(OUT_L + (size_t)r * M + mb, o);
+          st4(OUT + (size_t)(ob + r) * M + mb, o);
+          if (OUT2) st4(OUT2 + (size_t)(o2b + r) * M + mb, o);
         }
+      }
+    }
+  };
+
+  // W fragments: loaded ONCE per stage into registers when they fit (one load latency instead of NT*KQ/SC
+  // dependent ones); lane (i, q) needs Wm[16*tt + i][q*KQ .. q*KQ+KQ) for every tile row tt.
+  constexpr bool HOIST = (NT * KQ <= 64);
+  float wreg[HOIST ? NT : 1][HOIST ? KQ : 1];
+  if constexpr (HOIST) {
+#pragma unroll
+    for (int tt = 0; tt < NT; ++tt) {
+      const int m = tt * 16 + i;
+      const bool mok = (M % 16 == 0) || (m < M);
+      load_frag<KQ>(Wm + (size_t)(mok ? m : 0) * K + q * KQ, wreg[tt]);
+      if (!mok) {
+#pragma unroll
+        for (int s = 0; s < KQ; ++s) wreg[tt][s] = 0.f;
+      }
+    }
+  }
+  // one 16-node tile (DUAL = false) or two (DUAL = true) per trip; straight-line MFMA chains, no per-MFMA branches
+  auto run_tiles = [&](auto dual_tag, int t0, int t1) {
+    constexpr bool DUAL = decltype(dual_tag)::value;
+    const int rA = t0 * 16 + i, rB = t1 * 16 + i;
+    const bool okA = rA < n, okB = DUAL && rB < n;
+    float xA[KQ], xB[DUAL ? KQ : 1];
+    load_frag<KQ>(X + (size_t)(xb + (okA ? rA : n - 1)) * K + q * KQ, xA);
+    if constexpr (DUAL) load_frag<KQ>(X + (size_t)(xb + (okB ? rB : n - 1)) * K + q * KQ, xB);
+    f32x4 accA[NT], accB[DUAL ? NT : 1];
+#pragma unroll
+    for (int tt = 0; tt < NT; ++tt) {
+      accA[tt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      if constexpr (DUAL) accB[tt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int s = 0; s < KQ; s += SC) {
+#pragma unroll
+      for (int tt = 0; tt < NT; ++tt) {
+        float wf[SC];
+        if constexpr (HOIST) {
+#pragma unroll
+          for (int u = 0; u < SC; ++u) wf[u] = wreg[tt][s + u];
+        } else {
+          const int m = tt * 16 + i;
+          const bool mok = (M % 16 == 0) || (m < M);
+          load_frag<SC>(Wm + (size_t)(mok ? m : 0) * K + q * KQ + s, wf);
+          if (!mok) {
+#pragma unroll
+            for (int u = 0; u < SC; ++u) wf[u] = 0.f;
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < SC; ++u) {
+          accA[tt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[u], xA[s + u], accA[tt], 0, 0, 0);
+          if constexpr (DUAL) accB[tt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[u], xB[s + u], accB[tt], 0, 0, 0);
+        }
+      }
+    }
+    epilogue(accA, rA, okA);
+    if constexpr (DUAL) epilogue(accB, rB, okB);
+  };
+  for (int t0 = wave; t0 < ntiles; t0 += 2 * NW) {
+    const int t1 = t0 + NW;
+    if (t1 < ntiles) run_tiles(std::true_type{}, t0, t1);       // wave-uniform branch
+    else             run_tiles(std::false_type{}, t0, t0);
+  }
+}
+
+// dW partial of this segment: slab[c*K + k] = sum_r G[gb + r, c] * X[xb + r, k].  One 16x16 output tile per wave
+// (x 2 node halves when there are waves to spare), 8 operand pairs in flight, halves combined through LDS.
+template <int HC, int K, int THREADS>
+__device__ __forceinline__ void seg_dw(int n, const float* G, int gb, const float* X, int xb,
+                                       float* __restrict__ slab, float* red) {
+  constexpr int NCT = (HC + 15) / 16, NKT = (K + 15) / 16, NTILE = NCT * NKT, NW = THREADS / 64;
+  constexpr int HALVES = (NW >= 2 * NTILE) ? 2 : 1;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int i = lane & 15, q = lane >> 4;
+  const int nhalf = HALVES == 2 ? (((n + 1) / 2 + 3) & ~3) : n;
+  for (int u0 = 0; u0 < NTILE * HALVES; u0 += NW) {
+    const int u = u0 + wave;
+    const bool active = u < NTILE * HALVES;              // wave-uniform
+    const int tile = active ? u % NTILE : 0, half = active ? u / NTILE : 0;
+    const int c = (tile / NKT) * 16 + i, k = (tile % NKT) * 16 + i;
+    const bool cok = c < HC, kok = k < K;
+    const int rbeg = half * nhalf, rend = min(n, rbeg + nhalf);
+    f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (active) {
+      for (int nb = rbeg; nb < rend; nb += 32) {
+        float av[8], bv[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int r = nb + 4 * j + q;
+          const bool rok = r < rend;
+          av[j] = (rok && cok) ? G[(size_t)(gb + (rok ? r : 0)) * HC + c] : 0.f;
+          bv[j] = (rok && kok) ? X[(size_t)(xb + (rok ? r : 0)) * K + k] : 0.f;
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j], bv[j], acc, 0, 0, 0);
+      }
+    }
+    if constexpr (HALVES == 2) {
+      __syncthreads();
+      if (active && half == 1) {
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) red[(tile * 64 + lane) * 4 + rr] = acc[rr];
+      }
+      __syncthreads();
+      if (active && half == 0) {
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) acc[rr] += red[(tile * 64 + lane) * 4 + rr];
+      }
+    }
+    if (active && half == 0) {
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) {
+        const int cr = (tile / NKT) * 16 + 4 * q + rr;
+        if (cr < HC && kok) slab[(size_t)cr * K + k] = acc[rr];
       }
     }
   }
 }
 
-// dW partial of this segment: slab[c*K + k] = sum_r G[n0+r, c] * X[n0+r, k].  One 16x16 output tile per wave-trip.
-template <int HC, int K, int THREADS>
-__device__ __forceinline__ void seg_dw(int n0, int n, const float* __restrict__ G, const float* __restrict__ X,
-                                       float* __restrict__ slab) {
-  constexpr int NCT = (HC + 15) / 16, NKT = (K + 15) / 16;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int i = lane & 15, q = lane >> 4;
-  for (int u = wave; u < NCT * NKT; u += THREADS / 64) {
-    const int c = (u / NKT) * 16 + i, k = (u % NKT) * 16 + i;
-    const bool cok = c < HC, kok = k < K;
-    f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll 4
-    for (int nb = 0; nb < n; nb += 4) {
-      const int r = nb + q;
-      const bool rok = r < n;
-      const size_t node = (size_t)n0 + (rok ? r : 0);
-      const float a = (rok && cok) ? G[node * HC + c] : 0.f;
-      const float b = (rok && kok) ? X[node * K + k] : 0.f;
-      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc, 0, 0, 0);
-    }
+// ------------------------------------------------------------------------------------------ sparse stages
+// Conventions.  Row r of the segment; tables are addressed as  base + (tb + local_index) * width  with tb = 0 for an
+// LDS copy and tb = n0 for the global array; rp/col/...: LDS, 16-bit local indices.
+// Rows with <= MAXD edges (every WDN row) take the slot path: all neighbour loads are issued together and the
+// reductions run in CSR order, so results are bit-identical to the per-op kernels' edge-at-a-time loops.  Slots
+// beyond a row's degree are made HARMLESS instead of predicated (weight 0, a valid address), and slots beyond the
+// wave's maximum degree are skipped with wave-uniform branches: no per-lane exec-mask juggling in the hot loop.
+
+__device__ __forceinline__ int wave_max_deg(int deg) {
+  int d = 0;
 #pragma unroll
-    for (int rr = 0; rr < 4; ++rr) {
-      const int cr = (u / NKT) * 16 + 4 * q + rr;
-      if (cr < HC && kok) slab[(size_t)cr * K + k] = acc[rr];
-    }
-  }
+  for (int k = 0; k < MAXD; ++k)
+    if (__ballot(deg > k)) d = k + 1;            // scalar condition
+  return d;
 }
 
-// ------------------------------------------------------------------------------------------ K2 forward
-// Row r of the segment is node n0 + r.  Gathered tables are addressed as base + (j - joff) * width so the same
-// code reads either an LDS copy (joff = n0) or the global array (joff = 0).
+// K2 forward
 template <bool RELU, int H, int C, int THREADS>
-__device__ __forceinline__ void seg_agg_fwd(int n0, int n, const int* __restrict__ rowptr,
-                                            const int* __restrict__ col, const float* hsrc, int hoff,
-                                            const float* asrc, const float* adst_t, int aoff,
-                                            const float* __restrict__ bias, float* out, int ooff,
-                                            float* __restrict__ alpha) {
-  constexpr int HC = H * C, G = HC / 4;
+__device__ __forceinline__ void seg_agg_fwd(int n, const u16* rp, const u16* col, const float* hsrc, int hb,
+                                            const float* asrc, const float* adst_t, int ab,
+                                            const float* __restrict__ bias, float* out, int ob,
+                                            float* __restrict__ alpha, int eb) {
+  constexpr int HC = H * C, G = HC / 4, LH = C / 4, SLOTS = (MAXD + LH - 1) / LH, RPP = THREADS / G;
   const int c0 = (threadIdx.x % G) * 4;
   const int hd = c0 / C;
   const bool leader = (c0 % C) == 0;
-  for (int r = threadIdx.x / G; r < n; r += THREADS / G) {
-    const int row = n0 + r;
-    const int beg = rowptr[row], end = rowptr[row + 1];
-    const float adst = adst_t[(row - aoff) * H + hd];
-    float m = -INFINITY;
-    for (int e = beg; e < end; ++e) m = fmaxf(m, gatres_leaky(asrc[(col[e] - aoff) * H + hd] + adst));
-    float Z = 0.f;
-    for (int e = beg; e < end; ++e) Z = Z + expf(gatres_leaky(asrc[(col[e] - aoff) * H + hd] + adst) - m);
-    Z = Z + GATRES_SOFTMAX_EPS;
+  const int lih = (threadIdx.x % G) % LH;                 // lane inside its head
+  const int hbase = (threadIdx.x & 63) - lih;             // wave lane of the head's first lane
+  const float4 b = ld4(bias + c0);
+  const int rounds = (n + RPP - 1) / RPP;
+  for (int it = 0; it < rounds; ++it) {
+    int r = it * RPP + threadIdx.x / G;
+    const bool valid = r < n;                             // all lanes stay in the loop for the shuffles
+    if (!valid) r = n - 1;
+    const int beg = rp[r], deg = (int)rp[r + 1] - beg;    // deg >= 1: GATConv adds a self loop to every node
+    const int dmax = wave_max_deg(deg);
+    const float adst = adst_t[(unsigned)((ab + r) * H + hd)];
     float4 acc = f4zero();
-    int e = beg;
-    for (; e + 1 < end; e += 2) {
-      const int j0 = col[e], j1 = col[e + 1];
-      const float4 v0 = ld4(hsrc + (size_t)(j0 - hoff) * HC + c0);
-      const float4 v1 = ld4(hsrc + (size_t)(j1 - hoff) * HC + c0);
-      const float al0 = expf(gatres_leaky(asrc[(j0 - aoff) * H + hd] + adst) - m) / Z;
-      const float al1 = expf(gatres_leaky(asrc[(j1 - aoff) * H + hd] + adst) - m) / Z;
-      if (leader) { alpha[(size_t)e * H + hd] = al0; alpha[(size_t)(e + 1) * H + hd] = al1; }
-      acc.x = acc.x + al0 * v0.x; acc.y = acc.y + al0 * v0.y; acc.z = acc.z + al0 * v0.z; acc.w = acc.w + al0 * v0.w;
-      acc.x = acc.x + al1 * v1.x; acc.y = acc.y + al1 * v1.y; acc.z = acc.z + al1 * v1.z; acc.w = acc.w + al1 * v1.w;
+    if (deg <= MAXD) {
+      // the head's LH lanes split the row's edges: lane l scores slots l, l+LH, ... (ONE exp and ONE divide per
+      // slot instead of one per lane); values are broadcast with __shfl.
+      float so[SLOTS];
+      float m = -INFINITY;
+#pragma unroll
+      for (int t = 0; t < SLOTS; ++t) {
+        const int k = lih + LH * t;
+        const int jj = col[beg + min(k, deg - 1)];
+        const float sv = gatres_leaky(asrc[(unsigned)((ab + jj) * H + hd)] + adst);
+        so[t] = k < deg ? sv : -INFINITY;
+        m = fmaxf(m, so[t]);
+      }
+#pragma unroll
+      for (int off = LH >> 1; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
+#pragma unroll
+      for (int t = 0; t < SLOTS; ++t) so[t] = expf(so[t] - m);          // exp(-inf) = 0 for padding slots
+      float4 v[MAXD];
+#pragma unroll
+      for (int k = 0; k < MAXD; ++k)
+        if (k < dmax) v[k] = ld4(hsrc + (unsigned)((hb + (int)col[beg + min(k, deg - 1)]) * HC + c0));
+      float Z = 0.f;
+#pragma unroll
+      for (int k = 0; k < MAXD; ++k)
+        if (k < dmax) Z = Z + __shfl(so[k / LH], hbase + (k % LH));     // + 0 for padding slots: exact
+      Z = Z + GATRES_SOFTMAX_EPS;
+#pragma unroll
+      for (int t = 0; t < SLOTS; ++t) {
+        const int k = lih + LH * t;
+        so[t] = so[t] / Z;
+        if (valid && k < deg) alpha[(unsigned)((eb + beg + k) * H + hd)] = so[t];
+      }
+#pragma unroll
+      for (int k = 0; k < MAXD; ++k)
+        if (k < dmax) gatres_axpy4(acc, __shfl(so[k / LH], hbase + (k % LH)), v[k]);   // weight 0 on padding
+    } else {
+      const int end = beg + deg;
+      float m = -INFINITY;
+      for (int e = beg; e < end; ++e) m = fmaxf(m, gatres_leaky(asrc[(unsigned)((ab + col[e]) * H + hd)] + adst));
+      float Z = 0.f;
+      for (int e = beg; e < end; ++e) Z = Z + expf(gatres_leaky(asrc[(unsigned)((ab + col[e]) * H + hd)] + adst) - m);
+      Z = Z + GATRES_SOFTMAX_EPS;
+      for (int e = beg; e < end; ++e) {
+        const int jj = col[e];
+        const float al = expf(gatres_leaky(asrc[(unsigned)((ab + jj) * H + hd)] + adst) - m) / Z;
+        if (valid && leader) alpha[(unsigned)((eb + e) * H + hd)] = al;
+        gatres_axpy4(acc, al, ld4(hsrc + (unsigned)((hb + jj) * HC + c0)));
+      }
     }
-    if (e < end) {
-      const int j0 = col[e];
-      const float4 v0 = ld4(hsrc + (size_t)(j0 - hoff) * HC + c0);
-      const float al0 = expf(gatres_leaky(asrc[(j0 - aoff) * H + hd] + adst) - m) / Z;
-      if (leader) alpha[(size_t)e * H + hd] = al0;
-      acc.x = acc.x + al0 * v0.x; acc.y = acc.y + al0 * v0.y; acc.z = acc.z + al0 * v0.z; acc.w = acc.w + al0 * v0.w;
-    }
-    const float4 b = ld4(bias + c0);
-    acc.x = acc.x + b.x; acc.y = acc.y + b.y; acc.z = acc.z + b.z; acc.w = acc.w + b.w;
+    add4(acc, b);
     if (RELU) {
       acc.x = fmaxf(acc.x, 0.f); acc.y = fmaxf(acc.y, 0.f); acc.z = fmaxf(acc.z, 0.f); acc.w = fmaxf(acc.w, 0.f);
     }
-    st4(out + (size_t)(row - ooff) * HC + c0, acc);
+    if (valid) st4(out + (unsigned)((ob + r) * HC + c0), acc);
   }
 }
 
-// K3 forward
+// K3 forward: out = relu(mean_{j->r} y[j] + x0[r])
 template <int C, int THREADS>
-__device__ __forceinline__ void seg_mean_fwd(int n0, int n, const int* __restrict__ rowptr,
-                                             const int* __restrict__ col, const float* y, int yoff,
-                                             const float* __restrict__ x0, float* __restrict__ out) {
-  constexpr int G = C / 4;
+__device__ __forceinline__ void seg_mean_fwd(int n, int em, const u16* mrp, const u16* mcol, const float* y, int yb,
+                                             const float* x0, int xb, float* out, int ob) {
+  constexpr int G = C / 4, RPP = THREADS / G;
   const int c0 = (threadIdx.x % G) * 4;
-  for (int r = threadIdx.x / G; r < n; r += THREADS / G) {
-    const int row = n0 + r;
-    const int beg = rowptr[row], end = rowptr[row + 1];
+  const int rounds = (n + RPP - 1) / RPP;
+  const int elast = max(em - 1, 0);
+  for (int it = 0; it < rounds; ++it) {
+    int r = it * RPP + threadIdx.x / G;
+    const bool valid = r < n;
+    if (!valid) r = n - 1;
+    const int beg = mrp[r], deg = (int)mrp[r + 1] - beg;
+    const int dmax = wave_max_deg(deg);
+    const float4 rr = ld4(x0 + (unsigned)((xb + r) * C + c0));
     float4 acc = f4zero();
-    int e = beg;
-    for (; e + 1 < end; e += 2) {
-      const float4 v0 = ld4(y + (size_t)(col[e] - yoff) * C + c0);
-      const float4 v1 = ld4(y + (size_t)(col[e + 1] - yoff) * C + c0);
-      acc.x = acc.x + v0.x; acc.y = acc.y + v0.y; acc.z = acc.z + v0.z; acc.w = acc.w + v0.w;
-      acc.x = acc.x + v1.x; acc.y = acc.y + v1.y; acc.z = acc.z + v1.z; acc.w = acc.w + v1.w;
+    if (deg <= MAXD) {
+      float4 v[MAXD];
+#pragma unroll
+      for (int k = 0; k < MAXD; ++k)
+        if (k < dmax) {
+          const int jj = k < deg ? (int)mcol[min(beg + k, elast)] : r;
+          v[k] = ld4(y + (unsigned)((yb + jj) * C + c0));
+        }
+#pragma unroll
+      for (int k = 0; k < MAXD; ++k)
+        if (k < dmax) gatres_axpy4(acc, k < deg ? 1.f : 0.f, v[k]);      // fma(1, v, acc) == acc + v exactly
+    } else {
+      for (int e = beg; e < beg + deg; ++e) add4(acc, ld4(y + (unsigned)((yb + mcol[e]) * C + c0)));
     }
-    if (e < end) {
-      const float4 v0 = ld4(y + (size_t)(col[e] - yoff) * C + c0);
-      acc.x = acc.x + v0.x; acc.y = acc.y + v0.y; acc.z = acc.z + v0.z; acc.w = acc.w + v0.w;
-    }
-    const float cnt = (float)max(end - beg, 1);
-    const float4 rr = ld4(x0 + (size_t)row * C + c0);
+    const float cnt = (float)max(deg, 1);
     float4 o;
     o.x = fmaxf(acc.x / cnt + rr.x, 0.f); o.y = fmaxf(acc.y / cnt + rr.y, 0.f);
     o.z = fmaxf(acc.z / cnt + rr.z, 0.f); o.w = fmaxf(acc.w / cnt + rr.w, 0.f);
-    st4(out + (size_t)row * C + c0, o);
+    if (valid) st4(out + (unsigned)((ob + r) * C + c0), o);
   }
 }
 
-// ------------------------------------------------------------------------------------------ backward stages
+// K3 backward: g_y[r] = sum over out-edges (r -> i) of g_pre[i] / max(indeg(i), 1)
 template <int C, int THREADS>
-__device__ __forceinline__ void seg_mean_bwd(int n0, int n, const int* __restrict__ m_rowptr,
-                                             const int* __restrict__ mt_rowptr, const int* __restrict__ mt_dst,
-                                             const float* __restrict__ g_pre, float* __restrict__ g_y) {
-  constexpr int G = C / 4;
+__device__ __forceinline__ void seg_mean_bwd(int n, int em, const u16* mrp, const u16* mtrp, const u16* mtdst,
+                                             const float* g_pre, int pb, float* g_y, int yb) {
+  constexpr int G = C / 4, RPP = THREADS / G;
   const int c0 = (threadIdx.x % G) * 4;
-  for (int r = threadIdx.x / G; r < n; r += THREADS / G) {
-    const int row = n0 + r;
-    const int beg = mt_rowptr[row], end = mt_rowptr[row + 1];
+  const int rounds = (n + RPP - 1) / RPP;
+  const int elast = max(em - 1, 0);
+  for (int it = 0; it < rounds; ++it) {
+    int r = it * RPP + threadIdx.x / G;
+    const bool valid = r < n;
+    if (!valid) r = n - 1;
+    const int beg = mtrp[r], deg = (int)mtrp[r + 1] - beg;
+    const int dmax = wave_max_deg(deg);
     float4 acc = f4zero();
-    for (int t = beg; t < end; ++t) {
-      const int i = mt_dst[t];
-      const float cnt = (float)max(m_rowptr[i + 1] - m_rowptr[i], 1);
-      const float4 v = ld4(g_pre + (size_t)i * C + c0);
-      acc.x = acc.x + v.x / cnt; acc.y = acc.y + v.y / cnt; acc.z = acc.z + v.z / cnt; acc.w = acc.w + v.w / cnt;
+    if (deg <= MAXD) {
+      float4 v[MAXD];
+      float cnt[MAXD];
+#pragma unroll
+      for (int k = 0; k < MAXD; ++k)
+        if (k < dmax) {
+          const int ii = k < deg ? (int)mtdst[min(beg + k, elast)] : r;
+          cnt[k] = (float)max((int)mrp[ii + 1] - (int)mrp[ii], 1);
+          v[k] = ld4(g_pre + (unsigned)((pb + ii) * C + c0));
+        }
+#pragma unroll
+      for (int k = 0; k < MAXD; ++k)
+        if (k < dmax) {
+          const float w = k < deg ? 1.f : 0.f;                           // x + 0 * q == x exactly
+          acc.x = fmaf(w, v[k].x / cnt[k], acc.x); acc.y = fmaf(w, v[k].y / cnt[k], acc.y);
+          acc.z = fmaf(w, v[k].z / cnt[k], acc.z); acc.w = fmaf(w, v[k].w / cnt[k], acc.w);
+        }
+    } else {
+      for (int t = beg; t < beg + deg; ++t) {
+        const int ii = mtdst[t];
+        const float cnt = (float)max((int)mrp[ii + 1] - (int)mrp[ii], 1);
+        const float4 v = ld4(g_pre + (unsigned)((pb + ii) * C + c0));
+        acc.x = acc.x + v.x / cnt; acc.y = acc.y + v.y / cnt; acc.z = acc.z + v.z / cnt; acc.w = acc.w + v.w / cnt;
+      }
     }
-    st4(g_y + (size_t)row * C + c0, acc);
+    if (valid) st4(g_y + (unsigned)((yb + r) * C + c0), acc);
   }
 }
 
@@ -330,12 +504,14 @@ __device__ __forceinline__ float head_dot(const float4 a, const float4 b, int la
   return d;
 }
 
+// K2 backward, destination-major.  g_out: [gb + r]; h / a_src / a_dst: global saved arrays (base n0);
+// alpha: global (base e0); g_e / g_a_dst: [eb2 + e], [db + r] (LDS or global scratch).
 template <int H, int C, int THREADS>
-__device__ __forceinline__ void seg_agg_bwd_dst(int n0, int n, const int* __restrict__ rowptr,
-                                                const int* __restrict__ col, const float* __restrict__ g_out,
-                                                const float* __restrict__ h, const float* __restrict__ alpha,
-                                                const float* __restrict__ a_src, const float* __restrict__ a_dst,
-                                                float* __restrict__ g_e, float* __restrict__ g_a_dst) {
+__device__ __forceinline__ void seg_agg_bwd_dst(int n, int n0, int e0, const u16* rp, const u16* col,
+                                                const float* g_out, int gb, const float* __restrict__ h,
+                                                const float* __restrict__ alpha, const float* __restrict__ a_src,
+                                                const float* __restrict__ a_dst, float* g_e, int eb2,
+                                                float* g_a_dst, int db) {
   constexpr int HC = H * C, G = HC / 4, LH = C / 4, RPP = THREADS / G;
   const int c0 = (threadIdx.x % G) * 4;
   const int hd = c0 / C;
@@ -345,115 +521,143 @@ __device__ __forceinline__ void seg_agg_bwd_dst(int n0, int n, const int* __rest
     const bool valid = r < n;              // every lane stays in the loop: head_dot shuffles across the head's lanes
     if (!valid) r = n - 1;
     const bool leader = valid && (c0 % C) == 0;
-    const int row = n0 + r;
-    const int beg = rowptr[row], end = rowptr[row + 1];
-    const float4 go = ld4(g_out + (size_t)row * HC + c0);
-    const float adst = a_dst[row * H + hd];
+    const int beg = rp[r], deg = (int)rp[r + 1] - beg;
+    const int dmax = wave_max_deg(deg);
+    const float4 go = ld4(g_out + (unsigned)((gb + r) * HC + c0));
+    const float adst = a_dst[(unsigned)((n0 + r) * H + hd)];
     float S = 0.f, gad = 0.f;
-    if (end - beg <= 8) {
-      float ga[8];
+    if (deg <= MAXD) {
+      float al[MAXD], raw[MAXD], ga[MAXD];
+      float4 hv[MAXD];
 #pragma unroll
-      for (int k = 0; k < 8; ++k) {
-        ga[k] = 0.f;
-        if (beg + k < end) {
-          ga[k] = head_dot(go, ld4(h + (size_t)col[beg + k] * HC + c0), LH);
-          S = S + alpha[(size_t)(beg + k) * H + hd] * ga[k];
+      for (int k = 0; k < MAXD; ++k)
+        if (k < dmax) {
+          const int kk = min(k, deg - 1);
+          const int jj = col[beg + kk];
+          hv[k] = ld4(h + (unsigned)((n0 + jj) * HC + c0));
+          al[k] = alpha[(unsigned)((e0 + beg + kk) * H + hd)];
+          raw[k] = a_src[(unsigned)((n0 + jj) * H + hd)] + adst;
         }
-      }
 #pragma unroll
-      for (int k = 0; k < 8; ++k) {
-        if (beg + k < end) {
-          const int e = beg + k;
-          const float gs = alpha[(size_t)e * H + hd] * (ga[k] - S);
-          const float raw = a_src[col[e] * H + hd] + adst;
-          const float ge = raw > 0.f ? gs : gs * GATRES_NEG_SLOPE;
-          if (leader) g_e[(size_t)e * H + hd] = ge;
-          gad = gad + ge;
+      for (int k = 0; k < MAXD; ++k)
+        if (k < dmax) {
+          al[k] = k < deg ? al[k] : 0.f;                                 // padding slots weigh nothing
+          ga[k] = head_dot(go, hv[k], LH);
+          S = fmaf(al[k], ga[k], S);
         }
-      }
+#pragma unroll
+      for (int k = 0; k < MAXD; ++k)
+        if (k < dmax) {
+          const float gs = al[k] * (ga[k] - S);
+          const float ge = raw[k] > 0.f ? gs : gs * GATRES_NEG_SLOPE;
+          if (leader && k < deg) g_e[(unsigned)((eb2 + beg + k) * H + hd)] = ge;
+          gad = gad + ge;                                                // ge == 0 on padding slots
+        }
     } else {
+      const int end = beg + deg;
       for (int e = beg; e < end; ++e) {
-        const float ga = head_dot(go, ld4(h + (size_t)col[e] * HC + c0), LH);
-        S = S + alpha[(size_t)e * H + hd] * ga;
+        const float ga = head_dot(go, ld4(h + (unsigned)((n0 + col[e]) * HC + c0)), LH);
+        S = fmaf(alpha[(unsigned)((e0 + e) * H + hd)], ga, S);
       }
       for (int e = beg; e < end; ++e) {
-        const int j = col[e];
-        const float ga = head_dot(go, ld4(h + (size_t)j * HC + c0), LH);
-        const float gs = alpha[(size_t)e * H + hd] * (ga - S);
-        const float raw = a_src[j * H + hd] + adst;
-        const float ge = raw > 0.f ? gs : gs * GATRES_NEG_SLOPE;
-        if (leader) g_e[(size_t)e * H + hd] = ge;
+        const int jj = col[e];
+        const float ga = head_dot(go, ld4(h + (unsigned)((n0 + jj) * HC + c0)), LH);
+        const float gs = alpha[(unsigned)((e0 + e) * H + hd)] * (ga - S);
+        const float rw = a_src[(unsigned)((n0 + jj) * H + hd)] + adst;
+        const float ge = rw > 0.f ? gs : gs * GATRES_NEG_SLOPE;
+        if (leader) g_e[(unsigned)((eb2 + e) * H + hd)] = ge;
         gad = gad + ge;
       }
     }
-    if (leader) g_a_dst[row * H + hd] = gad;
+    if (leader) g_a_dst[(unsigned)((db + r) * H + hd)] = gad;
   }
 }
 
+// K2 backward, source-major over CSR^T.
 template <int H, int C, int THREADS>
-__device__ __forceinline__ void seg_agg_bwd_src(int n0, int n, const int* __restrict__ t_rowptr,
-                                                const int* __restrict__ t_eid, const int* __restrict__ t_dst,
-                                                const float* __restrict__ g_out, const float* __restrict__ alpha,
-                                                const float* __restrict__ g_e, const float* __restrict__ g_a_dst,
+__device__ __forceinline__ void seg_agg_bwd_src(int n, int e0, const u16* trp, const u16* teid, const u16* tdst,
+                                                const float* g_out, int gb, const float* __restrict__ alpha,
+                                                const float* g_e, int eb2, const float* g_a_dst, int db,
                                                 const float* __restrict__ att_src,
-                                                const float* __restrict__ att_dst, float* __restrict__ g_h,
-                                                float* __restrict__ g_a_src) {
-  constexpr int HC = H * C, G = HC / 4;
+                                                const float* __restrict__ att_dst, float* g_h, int hb,
+                                                float* g_a_src) {
+  constexpr int HC = H * C, G = HC / 4, RPP = THREADS / G;
   const int c0 = (threadIdx.x % G) * 4;
   const int hd = c0 / C;
-  const bool leader = (c0 % C) == 0;
   const float4 as = ld4(att_src + c0), ad = ld4(att_dst + c0);
-  for (int r = threadIdx.x / G; r < n; r += THREADS / G) {
-    const int row = n0 + r;
-    const int beg = t_rowptr[row], end = t_rowptr[row + 1];
+  const int rounds = (n + RPP - 1) / RPP;
+  for (int it = 0; it < rounds; ++it) {
+    int r = it * RPP + threadIdx.x / G;
+    const bool valid = r < n;
+    if (!valid) r = n - 1;
+    const bool leader = valid && (c0 % C) == 0;
+    const int beg = trp[r], deg = (int)trp[r + 1] - beg;   // deg >= 1 (self loop)
+    const int dmax = wave_max_deg(deg);
     float4 acc = f4zero();
     float gas = 0.f;
-    int t = beg;
-    for (; t + 1 < end; t += 2) {
-      const int e0 = t_eid[t], e1 = t_eid[t + 1];
-      const int i0 = t_dst[t], i1 = t_dst[t + 1];
-      const float4 v0 = ld4(g_out + (size_t)i0 * HC + c0);
-      const float4 v1 = ld4(g_out + (size_t)i1 * HC + c0);
-      const float al0 = alpha[(size_t)e0 * H + hd], al1 = alpha[(size_t)e1 * H + hd];
-      gas = gas + g_e[(size_t)e0 * H + hd];
-      gas = gas + g_e[(size_t)e1 * H + hd];
-      acc.x = acc.x + al0 * v0.x; acc.y = acc.y + al0 * v0.y; acc.z = acc.z + al0 * v0.z; acc.w = acc.w + al0 * v0.w;
-      acc.x = acc.x + al1 * v1.x; acc.y = acc.y + al1 * v1.y; acc.z = acc.z + al1 * v1.z; acc.w = acc.w + al1 * v1.w;
+    if (deg <= MAXD) {
+      float al[MAXD], ge[MAXD];
+      float4 v[MAXD];
+#pragma unroll
+      for (int k = 0; k < MAXD; ++k)
+        if (k < dmax) {
+          const int kk = beg + min(k, deg - 1);
+          const int e = teid[kk], ii = tdst[kk];
+          v[k] = ld4(g_out + (unsigned)((gb + ii) * HC + c0));
+          al[k] = alpha[(unsigned)((e0 + e) * H + hd)];
+          ge[k] = g_e[(unsigned)((eb2 + e) * H + hd)];
+        }
+#pragma unroll
+      for (int k = 0; k < MAXD; ++k)
+        if (k < dmax) {
+          const bool ok = k < deg;
+          gas = gas + (ok ? ge[k] : 0.f);
+          gatres_axpy4(acc, ok ? al[k] : 0.f, v[k]);
+        }
+    } else {
+      for (int t = beg; t < beg + deg; ++t) {
+        const int e = teid[t], ii = tdst[t];
+        gas = gas + g_e[(unsigned)((eb2 + e) * H + hd)];
+        gatres_axpy4(acc, alpha[(unsigned)((e0 + e) * H + hd)], ld4(g_out + (unsigned)((gb + ii) * HC + c0)));
+      }
     }
-    if (t < end) {
-      const int e0 = t_eid[t], i0 = t_dst[t];
-      const float4 v0 = ld4(g_out + (size_t)i0 * HC + c0);
-      const float al0 = alpha[(size_t)e0 * H + hd];
-      gas = gas + g_e[(size_t)e0 * H + hd];
-      acc.x = acc.x + al0 * v0.x; acc.y = acc.y + al0 * v0.y; acc.z = acc.z + al0 * v0.z; acc.w = acc.w + al0 * v0.w;
-    }
-    if (leader) g_a_src[row * H + hd] = gas;
-    const float gad = g_a_dst[row * H + hd];
-    acc.x = acc.x + gas * as.x; acc.y = acc.y + gas * as.y; acc.z = acc.z + gas * as.z; acc.w = acc.w + gas * as.w;
-    acc.x = acc.x + gad * ad.x; acc.y = acc.y + gad * ad.y; acc.z = acc.z + gad * ad.z; acc.w = acc.w + gad * ad.w;
-    st4(g_h + (size_t)row * HC + c0, acc);
+    if (leader) g_a_src[(unsigned)((db + r) * H + hd)] = gas;
+    const float gad = g_a_dst[(unsigned)((db + r) * H + hd)];
+    gatres_axpy4(acc, gas, as);
+    gatres_axpy4(acc, gad, ad);
+    if (valid) st4(g_h + (unsigned)((hb + r) * HC + c0), acc);
   }
 }
 
 // column sums of one GATConv for this segment (att_src / att_dst / bias gradients) -> the segment's slab.
-// thread = (column c, row group rg); partials are combined across row groups through LDS in a fixed order.
+// thread = (column c, row group rg); 4 rows in flight; partials combined across row groups through LDS.
 template <int H, int C, int THREADS>
-__device__ __forceinline__ void seg_conv_param_grads(int n0, int n, const float* __restrict__ h,
-                                                     const float* __restrict__ g_a_src,
-                                                     const float* __restrict__ g_a_dst,
-                                                     const float* __restrict__ g_out, float* __restrict__ slab_as,
-                                                     float* __restrict__ slab_ad, float* __restrict__ slab_b,
-                                                     float* red) {
+__device__ __forceinline__ void seg_conv_param_grads(int n, int n0, const float* __restrict__ h, const float* g_a_src,
+                                                     const float* g_a_dst, int db, const float* g_out, int gb,
+                                                     float* __restrict__ slab_as, float* __restrict__ slab_ad,
+                                                     float* __restrict__ slab_b, float* red) {
   constexpr int HC = H * C, R = THREADS / HC;
   const int c = threadIdx.x % HC, rg = threadIdx.x / HC;
   const int hd = c / C;
   float as = 0.f, ad = 0.f, ab = 0.f;
-  for (int r = rg; r < n; r += R) {
-    const size_t node = (size_t)n0 + r;
-    const float hv = h[node * HC + c];
-    as = fmaf(g_a_src[node * H + hd], hv, as);
-    ad = fmaf(g_a_dst[node * H + hd], hv, ad);
-    ab += g_out[node * HC + c];
+  for (int r0 = rg; r0 < n; r0 += 4 * R) {
+    float hv[4], gs[4], gd[4], go[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int r = r0 + k * R;
+      const bool ok = r < n;
+      const int rr = ok ? r : 0;
+      hv[k] = ok ? h[(size_t)(n0 + rr) * HC + c] : 0.f;
+      gs[k] = ok ? g_a_src[(size_t)(db + rr) * H + hd] : 0.f;
+      gd[k] = ok ? g_a_dst[(size_t)(db + rr) * H + hd] : 0.f;
+      go[k] = ok ? g_out[(size_t)(gb + rr) * HC + c] : 0.f;
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      as = fmaf(gs[k], hv[k], as);
+      ad = fmaf(gd[k], hv[k], ad);
+      ab += go[k];
+    }
   }
   __syncthreads();
   red[threadIdx.x] = as; red[THREADS + threadIdx.x] = ad; red[2 * THREADS + threadIdx.x] = ab;
@@ -469,10 +673,10 @@ __device__ __forceinline__ void seg_conv_param_grads(int n0, int n, const float*
 
 // lin1 backward for this segment: g_x = g_out (x) w (ReLU-masked), slab partials of g_w, g_b.
 template <int NC, int THREADS>
-__device__ __forceinline__ void seg_lin1_bwd(int n0, int n, const float* __restrict__ g_out,
-                                             const float* __restrict__ x, const float* __restrict__ w,
-                                             float* __restrict__ g_x, float* __restrict__ slab_w,
-                                             float* __restrict__ slab_b, int relu_mask, float* red) {
+__device__ __forceinline__ void seg_lin1_bwd(int n, int n0, const float* __restrict__ g_out,
+                                             const float* __restrict__ x, const float* __restrict__ w, float* g_x,
+                                             float* g_x2, float* __restrict__ slab_w, float* __restrict__ slab_b,
+                                             int relu_mask, float* red) {
   constexpr int R = THREADS / NC;
   const int c = threadIdx.x % NC, rg = threadIdx.x / NC;
   const float wv = w[c];
@@ -483,7 +687,9 @@ __device__ __forceinline__ void seg_lin1_bwd(int n0, int n, const float* __restr
     const float xv = x[node * NC + c];
     aw = fmaf(go, xv, aw);
     ab += go;
-    g_x[node * NC + c] = (relu_mask && !(xv > 0.f)) ? 0.f : go * wv;
+    const float gv = (relu_mask && !(xv > 0.f)) ? 0.f : go * wv;
+    g_x[node * NC + c] = gv;
+    if (g_x2) g_x2[(size_t)r * NC + c] = gv;
   }
   __syncthreads();
   red[threadIdx.x] = aw; red[THREADS + threadIdx.x] = ab;
@@ -497,7 +703,7 @@ __device__ __forceinline__ void seg_lin1_bwd(int n0, int n, const float* __restr
 }
 
 template <int NC, int THREADS>
-__device__ __forceinline__ void seg_lin0_bwd(int n0, int n, const float* __restrict__ g, const float* __restrict__ x,
+__device__ __forceinline__ void seg_lin0_bwd(int n, int n0, const float* __restrict__ g, const float* __restrict__ x,
                                              const uint8_t* __restrict__ mask, float* __restrict__ slab_w,
                                              float* __restrict__ slab_b, float* red) {
   constexpr int R = THREADS / NC;
@@ -523,24 +729,36 @@ __device__ __forceinline__ void seg_lin0_bwd(int n0, int n, const float* __restr
 // ------------------------------------------------------------------------------------------ the kernel
 template <int NC, int THREADS, bool CACHE>
 __global__ __launch_bounds__(THREADS) void gatres_fused_kernel(const FusedArgs a) {
-  // forward LDS map (CACHE): hA [n, 2NC] (h of conv1, then y2 [n, NC]) | hB [n, NC] (h of conv2) | sa, sd [n, 2]
-  // backward / loss: the first 3*THREADS floats are reduction scratch
-  constexpr int LDSF = CACHE ? LDS_FLOATS_MAX : 3 * THREADS;
-  __shared__ __attribute__((aligned(16))) float lds[LDSF];
+  __shared__ __attribute__((aligned(16))) unsigned char lds_raw[LDS_BYTES];
+  float* ldsf = reinterpret_cast<float*>(lds_raw);
   const Layout& L = a.L;
   const int seg = blockIdx.x;
   const int n0 = a.seg_ptr[seg], n = a.seg_ptr[seg + 1] - n0;
+  const int e0 = a.rowptr[n0], eg = a.rowptr[n0 + n] - e0;            // GATConv edges of this segment
+  const int em0 = a.m_rowptr[n0], em = a.m_rowptr[n0 + n] - em0;      // SimpleConv edges
   const int tid = threadIdx.x;
-  float* hA = lds;
-  float* hB = hA + (size_t)n * 2 * NC;
-  float* sa = hB + (size_t)n * NC;
-  float* sd = sa + (size_t)n * 2;
   const float* P = a.params;
   float* sc = a.scratch;
   int stamp_i = 0;
   STAMP();
+  if (a.stamps && blockIdx.x == 0 && threadIdx.x == 0) a.stamps[a.stamp_cap] = clock64();   // shader-clock probe
 
   if (a.phases & GATRES_PHASE_FORWARD) {
+    // LDS map: [hA n x 2NC | hB n x NC | sa 2n | sd 2n] (CACHE) then the 16-bit topology
+    float* hA = ldsf;
+    float* hB = hA + (size_t)n * 2 * NC;
+    float* sa = hB + (size_t)n * NC;
+    float* sd = sa + (size_t)n * 2;
+    u16* tp = reinterpret_cast<u16*>(CACHE ? (sd + (size_t)n * 2) : ldsf);
+    u16* rp = tp;              tp += even(n + 1);
+    u16* col = tp;             tp += even(eg);
+    u16* mrp = tp;             tp += even(n + 1);
+    u16* mcol = tp;
+    copy_rowptr16<THREADS>(rp, a.rowptr, n0, n, e0);
+    copy_idx16<THREADS>(col, a.col, e0, eg, n0);
+    copy_rowptr16<THREADS>(mrp, a.m_rowptr, n0, n, em0);
+    copy_idx16<THREADS>(mcol, a.m_col, em0, em, n0);
+
     float* xa = sc + L.sc_xa;
     float* xb = sc + L.sc_xb;
     float* xcur = a.saved ? a.saved + L.s_xin : xa;
@@ -564,39 +782,39 @@ __global__ __launch_bounds__(THREADS) void gatres_fused_kernel(const FusedArgs a
       float* xnext = a.saved ? a.saved + (int64_t)(b + 1) * L.s_stride + L.s_xin : (xcur == xa ? xb : xa);
       const float* pb = P + L.p_block0 + (int64_t)b * L.p_block_stride;
       float* y2g = sc + L.sc_y2;
-      // conv1: K1 then K2(+bias+ReLU)
-      seg_proj<NC, 2 * NC, 2, EPI_ATT, THREADS>(n0, n, xcur, pb + L.c1_W, base + L.s_h1, CACHE ? hA : nullptr,
-                                                 pb + L.c1_as, pb + L.c1_ad, base + L.s_as1, base + L.s_ad1,
-                                                 CACHE ? sa : nullptr, CACHE ? sd : nullptr, nullptr, nullptr);
+      // conv1: K1, then K2 (+bias+ReLU)
+      seg_proj<NC, 2 * NC, 2, EPI_ATT, THREADS>(n, xcur, n0, pb + L.c1_W, base + L.s_h1, n0, CACHE ? hA : nullptr, 0,
+                                                 pb + L.c1_as, pb + L.c1_ad, base + L.s_as1, base + L.s_ad1, n0,
+                                                 CACHE ? sa : nullptr, CACHE ? sd : nullptr, nullptr, 0, nullptr, 0);
       __syncthreads();
       STAMP();
       if (CACHE)
-        seg_agg_fwd<true, 2, NC, THREADS>(n0, n, a.rowptr, a.col, hA, n0, sa, sd, n0, pb + L.c1_b, base + L.s_o1, 0,
-                                          base + L.s_al1);
+        seg_agg_fwd<true, 2, NC, THREADS>(n, rp, col, hA, 0, sa, sd, 0, pb + L.c1_b, base + L.s_o1, n0,
+                                          base + L.s_al1, e0);
       else
-        seg_agg_fwd<true, 2, NC, THREADS>(n0, n, a.rowptr, a.col, base + L.s_h1, 0, base + L.s_as1, base + L.s_ad1, 0,
-                                          pb + L.c1_b, base + L.s_o1, 0, base + L.s_al1);
+        seg_agg_fwd<true, 2, NC, THREADS>(n, rp, col, base + L.s_h1, n0, base + L.s_as1, base + L.s_ad1, n0,
+                                          pb + L.c1_b, base + L.s_o1, n0, base + L.s_al1, e0);
       __syncthreads();
       STAMP();
       // conv2
-      seg_proj<2 * NC, NC, 1, EPI_ATT, THREADS>(n0, n, base + L.s_o1, pb + L.c2_W, base + L.s_h2, CACHE ? hB : nullptr,
-                                                 pb + L.c2_as, pb + L.c2_ad, base + L.s_as2, base + L.s_ad2,
-                                                 CACHE ? sa : nullptr, CACHE ? sd : nullptr, nullptr, nullptr);
+      seg_proj<2 * NC, NC, 1, EPI_ATT, THREADS>(n, base + L.s_o1, n0, pb + L.c2_W, base + L.s_h2, n0,
+                                                 CACHE ? hB : nullptr, 0, pb + L.c2_as, pb + L.c2_ad, base + L.s_as2,
+                                                 base + L.s_ad2, n0, CACHE ? sa : nullptr, CACHE ? sd : nullptr,
+                                                 nullptr, 0, nullptr, 0);
       __syncthreads();
       STAMP();
       if (CACHE)
-        seg_agg_fwd<false, 1, NC, THREADS>(n0, n, a.rowptr, a.col, hB, n0, sa, sd, n0, pb + L.c2_b, hA, n0,
-                                           base + L.s_al2);
+        seg_agg_fwd<false, 1, NC, THREADS>(n, rp, col, hB, 0, sa, sd, 0, pb + L.c2_b, hA, 0, base + L.s_al2, e0);
       else
-        seg_agg_fwd<false, 1, NC, THREADS>(n0, n, a.rowptr, a.col, base + L.s_h2, 0, base + L.s_as2, base + L.s_ad2, 0,
-                                           pb + L.c2_b, y2g, 0, base + L.s_al2);
+        seg_agg_fwd<false, 1, NC, THREADS>(n, rp, col, base + L.s_h2, n0, base + L.s_as2, base + L.s_ad2, n0,
+                                           pb + L.c2_b, y2g, n0, base + L.s_al2, e0);
       __syncthreads();
       STAMP();
       // K3
       if (CACHE)
-        seg_mean_fwd<NC, THREADS>(n0, n, a.m_rowptr, a.m_col, hA, n0, xcur, xnext);
+        seg_mean_fwd<NC, THREADS>(n, em, mrp, mcol, hA, 0, xcur, n0, xnext, n0);
       else
-        seg_mean_fwd<NC, THREADS>(n0, n, a.m_rowptr, a.m_col, y2g, 0, xcur, xnext);
+        seg_mean_fwd<NC, THREADS>(n, em, mrp, mcol, y2g, n0, xcur, n0, xnext, n0);
       __syncthreads();
       STAMP();
       xcur = xnext;
@@ -625,7 +843,7 @@ __global__ __launch_bounds__(THREADS) void gatres_fused_kernel(const FusedArgs a
     // M = number of masked nodes in the WHOLE batch (every workgroup counts them itself: N bytes from L2)
     float cnt = 0.f;
     for (int i = tid; i < a.N; i += THREADS) cnt += a.mask[i] ? 1.f : 0.f;
-    const float M = block_sum<THREADS>(cnt, lds);
+    const float M = block_sum<THREADS>(cnt, ldsf);
     float part = 0.f;
     for (int r = tid; r < n; r += THREADS) {
       const int node = n0 + r;
@@ -634,7 +852,7 @@ __global__ __launch_bounds__(THREADS) void gatres_fused_kernel(const FusedArgs a
         part = fmaf(d, d, part);
       }
     }
-    part = block_sum<THREADS>(part, lds);
+    part = block_sum<THREADS>(part, ldsf);
     if (tid == 0) {
       a.loss_part[seg] = part;
       if (seg == 0) a.loss_part[gridDim.x] = M;
@@ -649,24 +867,51 @@ __global__ __launch_bounds__(THREADS) void gatres_fused_kernel(const FusedArgs a
   }
 
   if (a.phases & GATRES_PHASE_BACKWARD) {
+    // LDS map: [red 3*THREADS] ( [RA n x 2NC : g_pre | g_y2, later g_out1] [ge 2*eg] [gad 2n] [gas 2n] ) topology
+    float* red = ldsf;
+    float* RA = red + 3 * THREADS;
+    float* geL = RA + (size_t)n * 2 * NC;
+    float* gadL = geL + 2 * (size_t)even(eg);
+    float* gasL = gadL + 2 * (size_t)n;
+    u16* tp = reinterpret_cast<u16*>(CACHE ? (gasL + 2 * (size_t)n) : RA);
+    u16* rp = tp;              tp += even(n + 1);
+    u16* col = tp;             tp += even(eg);
+    u16* trp = tp;             tp += even(n + 1);
+    u16* teid = tp;            tp += even(eg);
+    u16* tdst = tp;            tp += even(eg);
+    u16* mrp = tp;             tp += even(n + 1);
+    u16* mtrp = tp;            tp += even(n + 1);
+    u16* mtdst = tp;
+    __syncthreads();           // forward's LDS contents are dead from here
+    copy_rowptr16<THREADS>(rp, a.rowptr, n0, n, e0);
+    copy_idx16<THREADS>(col, a.col, e0, eg, n0);
+    copy_rowptr16<THREADS>(trp, a.t_rowptr, n0, n, e0);
+    copy_idx16<THREADS>(teid, a.t_eid, e0, eg, e0);
+    copy_idx16<THREADS>(tdst, a.t_dst, e0, eg, n0);
+    copy_rowptr16<THREADS>(mrp, a.m_rowptr, n0, n, em0);
+    copy_rowptr16<THREADS>(mtrp, a.mt_rowptr, n0, n, em0);
+    copy_idx16<THREADS>(mtdst, a.mt_dst, em0, em, n0);
+
     const float* saved = a.saved;
-    float* gp_cur = sc + L.sc_gpa;
+    float* gp_cur = sc + L.sc_gpa;       // global copies of g_pre (row-wise residual reads)
     float* gp_nxt = sc + L.sc_gpb;
-    float* gy2 = sc + L.sc_gy2;
-    float* ge = sc + L.sc_ge;
-    float* gad = sc + L.sc_gad;
-    float* gas = sc + L.sc_gas;
     float* gh = sc + L.sc_gh;
-    float* go1 = sc + L.sc_go1;
-    float* ge2 = sc + L.sc_ge2;
-    float* gad2 = sc + L.sc_gad2;
-    float* gas2 = sc + L.sc_gas2;
     float* gh2 = sc + L.sc_gh2;
+    // gathered / small backward tables: LDS when CACHE, else global scratch (conv2 has private arrays: see Layout)
+    float* gpT = CACHE ? RA : nullptr;                                   // g_pre, LDS copy for the K3 gather
+    float* gy2T = CACHE ? RA + (size_t)n * NC : sc + L.sc_gy2;  const int gy2b = CACHE ? 0 : n0;
+    float* go1T = CACHE ? RA : sc + L.sc_go1;                   const int go1b = CACHE ? 0 : n0;
+    float* ge1T = CACHE ? geL : sc + L.sc_ge;                   const int ge_b = CACHE ? 0 : e0;
+    float* ge2T = CACHE ? geL : sc + L.sc_ge2;
+    float* gad1T = CACHE ? gadL : sc + L.sc_gad;                const int gd_b = CACHE ? 0 : n0;
+    float* gad2T = CACHE ? gadL : sc + L.sc_gad2;
+    float* gas1T = CACHE ? gasL : sc + L.sc_gas;
+    float* gas2T = CACHE ? gasL : sc + L.sc_gas2;
     float* slab = a.slabs + (int64_t)seg * L.slab_stride;
     const int64_t w = 2LL * NC * NC;
     const float* xfinal = saved + (int64_t)L.nb * L.s_stride + L.s_xin;
-    seg_lin1_bwd<NC, THREADS>(n0, n, a.g_out, xfinal, P + L.p_lin1_w, gp_cur, slab + L.p_lin1_w, slab + L.p_lin1_b,
-                              L.nb > 0 ? 1 : 0, lds);
+    seg_lin1_bwd<NC, THREADS>(n, n0, a.g_out, xfinal, P + L.p_lin1_w, gp_cur, gpT, slab + L.p_lin1_w,
+                              slab + L.p_lin1_b, L.nb > 0 ? 1 : 0, red);
     __syncthreads();
     STAMP();
     for (int b = L.nb - 1; b >= 0; --b) {
@@ -676,49 +921,55 @@ __global__ __launch_bounds__(THREADS) void gatres_fused_kernel(const FusedArgs a
       float* sb = slab + po;
       const float* wt1 = a.wt + (int64_t)b * 2 * w;
       const float* wt2 = wt1 + w;
-      seg_mean_bwd<NC, THREADS>(n0, n, a.m_rowptr, a.mt_rowptr, a.mt_dst, gp_cur, gy2);
+      // K3 backward
+      if (CACHE) seg_mean_bwd<NC, THREADS>(n, em, mrp, mtrp, mtdst, gpT, 0, gy2T, gy2b);
+      else       seg_mean_bwd<NC, THREADS>(n, em, mrp, mtrp, mtdst, gp_cur, n0, gy2T, gy2b);
       __syncthreads();
       STAMP();
       // conv2
-      seg_agg_bwd_dst<1, NC, THREADS>(n0, n, a.rowptr, a.col, gy2, base + L.s_h2, base + L.s_al2, base + L.s_as2,
-                                      base + L.s_ad2, ge2, gad2);
+      seg_agg_bwd_dst<1, NC, THREADS>(n, n0, e0, rp, col, gy2T, gy2b, base + L.s_h2, base + L.s_al2, base + L.s_as2,
+                                      base + L.s_ad2, ge2T, ge_b, gad2T, gd_b);
       __syncthreads();
       STAMP();
-      seg_agg_bwd_src<1, NC, THREADS>(n0, n, a.t_rowptr, a.t_eid, a.t_dst, gy2, base + L.s_al2, ge2, gad2, pb + L.c2_as,
-                                      pb + L.c2_ad, gh2, gas2);
+      seg_agg_bwd_src<1, NC, THREADS>(n, e0, trp, teid, tdst, gy2T, gy2b, base + L.s_al2, ge2T, ge_b, gad2T, gd_b,
+                                      pb + L.c2_as, pb + L.c2_ad, gh2, n0, gas2T);
       __syncthreads();
       STAMP();
-      seg_conv_param_grads<1, NC, THREADS>(n0, n, base + L.s_h2, gas2, gad2, gy2, sb + L.c2_as, sb + L.c2_ad,
-                                           sb + L.c2_b, lds);
+      seg_conv_param_grads<1, NC, THREADS>(n, n0, base + L.s_h2, gas2T, gad2T, gd_b, gy2T, gy2b, sb + L.c2_as,
+                                           sb + L.c2_ad, sb + L.c2_b, red);
       STAMP();
-      seg_dw<NC, 2 * NC, THREADS>(n0, n, gh2, base + L.s_o1, sb + L.c2_W);
+      seg_dw<NC, 2 * NC, THREADS>(n, gh2, n0, base + L.s_o1, n0, sb + L.c2_W, red);
+      __syncthreads();         // g_y2 (RA) is dead: dx2 overwrites RA with g_out1
       STAMP();
-      seg_proj<NC, 2 * NC, 1, EPI_RESID_MASK, THREADS>(n0, n, gh2, wt2, go1, nullptr, nullptr, nullptr, nullptr,
-                                                        nullptr, nullptr, nullptr, nullptr, base + L.s_o1);
+      seg_proj<NC, 2 * NC, 1, EPI_RESID_MASK, THREADS>(n, gh2, n0, wt2, go1T, go1b, nullptr, 0, nullptr, nullptr,
+                                                        nullptr, nullptr, 0, nullptr, nullptr, nullptr, 0,
+                                                        base + L.s_o1, n0);
       __syncthreads();
       STAMP();
       // conv1
-      seg_agg_bwd_dst<2, NC, THREADS>(n0, n, a.rowptr, a.col, go1, base + L.s_h1, base + L.s_al1, base + L.s_as1,
-                                      base + L.s_ad1, ge, gad);
+      seg_agg_bwd_dst<2, NC, THREADS>(n, n0, e0, rp, col, go1T, go1b, base + L.s_h1, base + L.s_al1, base + L.s_as1,
+                                      base + L.s_ad1, ge1T, ge_b, gad1T, gd_b);
       __syncthreads();
       STAMP();
-      seg_agg_bwd_src<2, NC, THREADS>(n0, n, a.t_rowptr, a.t_eid, a.t_dst, go1, base + L.s_al1, ge, gad, pb + L.c1_as,
-                                      pb + L.c1_ad, gh, gas);
+      seg_agg_bwd_src<2, NC, THREADS>(n, e0, trp, teid, tdst, go1T, go1b, base + L.s_al1, ge1T, ge_b, gad1T, gd_b,
+                                      pb + L.c1_as, pb + L.c1_ad, gh, n0, gas1T);
       __syncthreads();
       STAMP();
-      seg_conv_param_grads<2, NC, THREADS>(n0, n, base + L.s_h1, gas, gad, go1, sb + L.c1_as, sb + L.c1_ad,
-                                           sb + L.c1_b, lds);
+      seg_conv_param_grads<2, NC, THREADS>(n, n0, base + L.s_h1, gas1T, gad1T, gd_b, go1T, go1b, sb + L.c1_as,
+                                           sb + L.c1_ad, sb + L.c1_b, red);
       STAMP();
-      seg_dw<2 * NC, NC, THREADS>(n0, n, gh, base + L.s_xin, sb + L.c1_W);
+      seg_dw<2 * NC, NC, THREADS>(n, gh, n0, base + L.s_xin, n0, sb + L.c1_W, red);
+      __syncthreads();         // g_out1 (RA) is dead: dx1 writes the next g_pre into RA's low half
       STAMP();
-      seg_proj<2 * NC, NC, 1, EPI_RESID_MASK, THREADS>(n0, n, gh, wt1, gp_nxt, nullptr, nullptr, nullptr, nullptr,
-                                                        nullptr, nullptr, nullptr, gp_cur,
-                                                        b > 0 ? base + L.s_xin : nullptr);
+      // d/d xin = conv1 path + residual, masked by the previous block's ReLU (block 0's input is lin0: no ReLU)
+      seg_proj<2 * NC, NC, 1, EPI_RESID_MASK, THREADS>(n, gh, n0, wt1, gp_nxt, n0, gpT, 0, nullptr, nullptr, nullptr,
+                                                        nullptr, 0, nullptr, nullptr, gp_cur, n0,
+                                                        b > 0 ? base + L.s_xin : nullptr, n0);
       __syncthreads();
       STAMP();
       float* t = gp_cur; gp_cur = gp_nxt; gp_nxt = t;
     }
-    seg_lin0_bwd<NC, THREADS>(n0, n, gp_cur, a.x, a.mask, slab + L.p_lin0_w, slab + L.p_lin0_b, lds);
+    seg_lin0_bwd<NC, THREADS>(n, n0, gp_cur, a.x, a.mask, slab + L.p_lin0_w, slab + L.p_lin0_b, red);
     if (a.g_x) {
       constexpr int G = NC / 4;
       const float4 wv = ld4(P + L.p_lin0_w + (tid % G) * 4);
@@ -734,6 +985,10 @@ __global__ __launch_bounds__(THREADS) void gatres_fused_kernel(const FusedArgs a
         if (valid && (tid % G) == 0) a.g_x[n0 + r] = d;
       }
     }
+  }
+  if (a.stamps && blockIdx.x == 0 && threadIdx.x == 0) {
+    a.stamps[a.stamp_cap + 1] = clock64();
+    a.stamps[a.stamp_cap + 2] = wall_clock64();
   }
 }
 
@@ -789,14 +1044,20 @@ __global__ __launch_bounds__(256) void reduce_adam_kernel(const float* __restric
   }
 }
 
+static int fused_threads_small() {
+  const char* e = getenv("GATRES_FUSED_THREADS");
+  return (e && atoi(e) == 512) ? 512 : 1024;
+}
+static int threads_for(int nc) { return nc <= 32 ? fused_threads_small() : (nc == 64 ? 512 : 256); }
+
 template <int NC, int THREADS>
-static int launch_fused(const FusedArgs& a, int num_segments, int max_seg, hipStream_t st) {
-  const bool cache = (long long)max_seg * (3 * NC + 4) <= LDS_FLOATS_MAX && 3 * THREADS <= LDS_FLOATS_MAX &&
-                     !getenv("GATRES_FUSED_NOCACHE");
+static int launch_fused(const FusedArgs& a, const gatres_graph_t* g, hipStream_t st) {
+  const bool cache = !getenv("GATRES_FUSED_NOCACHE") &&
+                     cache_fits(NC, THREADS, g->max_segment_nodes, g->max_segment_edges_gat, g->max_segment_edges_mean);
   if (cache)
-    hipLaunchKernelGGL((gatres_fused_kernel<NC, THREADS, true>), dim3(num_segments), dim3(THREADS), 0, st, a);
+    hipLaunchKernelGGL((gatres_fused_kernel<NC, THREADS, true>), dim3(g->num_segments), dim3(THREADS), 0, st, a);
   else
-    hipLaunchKernelGGL((gatres_fused_kernel<NC, THREADS, false>), dim3(num_segments), dim3(THREADS), 0, st, a);
+    hipLaunchKernelGGL((gatres_fused_kernel<NC, THREADS, false>), dim3(g->num_segments), dim3(THREADS), 0, st, a);
   return gatres_launch_status();
 }
 
@@ -806,8 +1067,10 @@ static int launch_fused(const FusedArgs& a, int num_segments, int max_seg, hipSt
 
 extern "C" int gatres_fused_supported(const gatres_model_t* m, const gatres_graph_t* g) {
   if (!m || !g || g->num_segments <= 0 || !g->seg_ptr) return 0;
+  if (!(m->nc >= 4 && m->nc <= 128 && gatres_is_pow2(m->nc))) return 0;
   if (g->max_segment_nodes > 4096) return 0;      // beyond this a snapshot should be spread over many CUs
-  return (m->nc >= 4 && m->nc <= 128 && gatres_is_pow2(m->nc)) ? 1 : 0;
+  return nocache_fits(threads_for(m->nc), g->max_segment_nodes, g->max_segment_edges_gat, g->max_segment_edges_mean)
+             ? 1 : 0;
 }
 
 // Diagnostic: segment 0 of the next fused launches writes a 100 MHz wall-clock stamp at every stage boundary into
@@ -847,14 +1110,13 @@ extern "C" int gatres_fused_run(const gatres_model_t* m, const gatres_graph_t* g
   a.stamps = g_stamps; a.stamp_cap = g_stamp_cap;
   a.phases = (phases & (GATRES_PHASE_FORWARD | GATRES_PHASE_BACKWARD)) | ((phases & GATRES_PHASE_LOSS) ? PH_LOSS : 0);
   hipStream_t st = gatres_stream(stream);
-  const int S = g->num_segments, mx = g->max_segment_nodes;
   switch (m->nc) {
-    case 4: return launch_fused<4, 1024>(a, S, mx, st);
-    case 8: return launch_fused<8, 1024>(a, S, mx, st);
-    case 16: return launch_fused<16, 1024>(a, S, mx, st);
-    case 32: return launch_fused<32, 1024>(a, S, mx, st);
-    case 64: return launch_fused<64, 512>(a, S, mx, st);
-    case 128: return launch_fused<128, 256>(a, S, mx, st);
+    case 4: return launch_fused<4, 1024>(a, g, st);
+    case 8: return launch_fused<8, 1024>(a, g, st);
+    case 16: return launch_fused<16, 1024>(a, g, st);
+    case 32: return fused_threads_small() == 512 ? launch_fused<32, 512>(a, g, st) : launch_fused<32, 1024>(a, g, st);
+    case 64: return launch_fused<64, 512>(a, g, st);
+    case 128: return launch_fused<128, 256>(a, g, st);
   }
   return GATRES_E_UNSUPPORTED;
 }

@@ -48,18 +48,22 @@ class GraphPlan:
         self.arrays: Dict[str, torch.Tensor] = {k: v.to(device) for k, v in host.items()}
         # segment table: the snapshots of the batch (one workgroup each in the fused kernels)
         self.num_segments, self.max_segment_nodes = 0, 0
+        self.max_segment_edges_gat, self.max_segment_edges_mean = 0, 0
         seg_dev_ptr = None
         if segments:
             seg = torch.empty(N + 1, **i32)
-            ns, mx = C.c_int32(0), C.c_int32(0)
+            ns, mx, mg, mm = C.c_int32(0), C.c_int32(0), C.c_int32(0), C.c_int32(0)
             _native.check(lib.gatres_graph_segments_host(ei_host.data_ptr(), E, N, int(merge_upto), seg.data_ptr(),
-                                                         C.byref(ns), C.byref(mx)), "gatres_graph_segments_host")
+                                                         C.byref(ns), C.byref(mx), C.byref(mg), C.byref(mm)),
+                          "gatres_graph_segments_host")
             self.num_segments, self.max_segment_nodes = int(ns.value), int(mx.value)
+            self.max_segment_edges_gat, self.max_segment_edges_mean = int(mg.value), int(mm.value)
             self.segment_ptr_host = seg[: self.num_segments + 1].clone()
             self.arrays["seg_ptr"] = self.segment_ptr_host.to(device)
             seg_dev_ptr = self.arrays["seg_ptr"].data_ptr()
         self.c = _native.GatresGraph(N, Eg, E, self.num_segments, *[self.arrays[k].data_ptr() for k in host.keys()],
-                                     seg_dev_ptr, self.max_segment_nodes, 0)
+                                     seg_dev_ptr, self.max_segment_nodes, self.max_segment_edges_gat,
+                                     self.max_segment_edges_mean, 0)
 
     def ref(self):
         return C.byref(self.c)

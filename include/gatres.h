@@ -62,6 +62,8 @@ typedef struct gatres_graph {
    * Batch (train.py:302-303).  The fused kernels give each segment to one workgroup. */
   const int32_t* seg_ptr;   /* [num_segments + 1]                         */
   int32_t max_segment_nodes;
+  int32_t max_segment_edges_gat;   /* most GATConv edges (self loops included) inside one segment */
+  int32_t max_segment_edges_mean;  /* most SimpleConv edges inside one segment                    */
   int32_t reserved;
 } gatres_graph_t;
 
@@ -77,7 +79,8 @@ int gatres_graph_build_host(const int64_t* edge_index_host, int64_t num_edges, i
  * ranges merged while the result stays <= merge_upto nodes.  seg_ptr_host must hold N + 1 entries. */
 int gatres_graph_segments_host(const int64_t* edge_index_host, int64_t num_edges, int64_t num_nodes,
                                int32_t merge_upto, int32_t* seg_ptr_host, int32_t* num_segments_out,
-                               int32_t* max_segment_nodes_out);
+                               int32_t* max_segment_nodes_out, int32_t* max_segment_edges_gat_out,
+                               int32_t* max_segment_edges_mean_out);
 
 /* 64-bit content hash of an int64 [2,E] DEVICE edge_index (for plan caching); hash_out: device uint64[1],
  * must be zeroed by the caller on the same stream before the call. */

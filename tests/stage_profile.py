@@ -12,15 +12,18 @@ tr = G.GATResTrainer(model, ei, 388 * bs, nodes_per_graph=[388] * bs, use_graph=
 y = torch.randn(388 * bs, device="cuda")
 lib = G._native.load()
 cap = 4096
-stamps = torch.zeros(cap, dtype=torch.int64, device="cuda")
+stamps = torch.zeros(cap + 3, dtype=torch.int64, device="cuda")
 for _ in range(3):
     tr.step(y, y)
 lib.gatres_fused_set_stamps(stamps.data_ptr(), cap)
 tr.step(y, y)
 torch.cuda.synchronize()
 lib.gatres_fused_set_stamps(None, 0)
-s = stamps.cpu().numpy()
+raw = stamps.cpu().numpy()
+clk = raw[cap:cap + 3]
+s = raw[:cap]
 s = s[s > 0]
+print('shader clock MHz ~', (clk[1] - clk[0]) / ((clk[2] - s[0]) / 100.0))
 d = (s[1:] - s[:-1]) / 100.0   # us
 print("stamps", len(s), "total us", (s[-1] - s[0]) / 100.0)
 names_f = ["proj1", "agg1", "proj2", "agg2", "mean"]

@@ -293,3 +293,26 @@ def test_fused_equals_per_op_bitwise_forward(pkg, oracle):
         gf = torch.cat([q.grad.reshape(-1) for q in mf.parameters()])
         gp = torch.cat([q.grad.reshape(-1) for q in mp.parameters()])
         assert relerr(gf, gp) < 2e-6, (nb, nc, nodes, relerr(gf, gp))
+
+
+@pytest.mark.parametrize("fused", [True, False], ids=["fused", "per_op"])
+@pytest.mark.parametrize("name", ["tiny_nb2_nc8", "ctown_small_bs2"])
+def test_golden_vectors(pkg, name, fused):
+    """Committed fixtures (tests/golden/*.npz, made by tests/golden/make_golden.py from the oracle): one reference
+    training iteration -> predictions, loss, gradients, weights after one Adam step."""
+    d = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", name + ".npz"))
+    nb, nc, npg = int(d["num_blocks"]), int(d["nc"]), int(d["nodes_per_graph"])
+    model = pkg.GATResMeanConv(num_blocks=nb, nc=nc, fused=fused).cuda()
+    with torch.no_grad():
+        model.flat_parameters.copy_(torch.from_numpy(d["params"]))
+    x = torch.from_numpy(d["x"]).cuda()
+    ei = torch.from_numpy(d["edge_index"]).cuda()
+    bs = x.shape[0] // npg
+    tr = pkg.GATResTrainer(model, ei, x.shape[0], nodes_per_graph=[npg] * bs, use_graph=False, fused=fused)
+    loss = tr.step(x, x, torch.from_numpy(d["mask"]).cuda())
+    assert relerr(tr.out, torch.from_numpy(d["out"])) < 1e-5
+    assert relerr(loss, torch.tensor(float(d["loss"]))) < 1e-5
+    assert relerr(tr.grads, torch.from_numpy(d["grads"])) < 1e-5
+    assert float((model.flat_parameters.cpu() - torch.from_numpy(d["params_after"])).abs().max()) <= 2 * 5e-4
+    frac = float(((model.flat_parameters.cpu() - torch.from_numpy(d["params_after"])).abs() > 1e-5).double().mean())
+    assert frac < 0.01

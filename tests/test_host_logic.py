@@ -1,0 +1,133 @@
+"""CPU-side tests: the oracle against the committed golden vectors, the host plan builder, the C-ABI export list
+against include/gatres.h, and the nn.Module surface.  No GPU, no kernel launches."""
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def unflatten(oracle, flat, nb, nc):
+    out, off = {}, 0
+    for k, shp in oracle.param_shapes(nb, nc).items():
+        n = int(np.prod(shp))
+        out[k] = torch.from_numpy(flat[off:off + n].copy()).reshape(shp)
+        off += n
+    assert off == flat.size
+    return out
+
+
+@pytest.mark.parametrize("name", ["tiny_nb2_nc8", "ctown_small_bs2"])
+def test_oracle_reproduces_golden_vectors(oracle, name):
+    d = np.load(os.path.join(GOLDEN, name + ".npz"))
+    nb, nc = int(d["num_blocks"]), int(d["nc"])
+    p = unflatten(oracle, d["params"], nb, nc)
+    tr = oracle.OracleTrainer(p)
+    x = torch.from_numpy(d["x"])
+    loss, out = tr.step(x.clone(), x, torch.from_numpy(d["edge_index"]), torch.from_numpy(d["mask"]))
+    rel = lambda a, b: float(np.abs(a - b).max() / np.abs(b).max())
+    assert rel(out.numpy(), d["out"]) < 2e-6          # thread-count dependent reduction order only
+    assert abs(float(loss) - float(d["loss"])) < 1e-5 * abs(float(d["loss"]))
+    assert rel(tr.flat("grads").numpy(), d["grads"]) < 1e-5
+    assert np.abs(tr.flat("params").numpy() - d["params_after"]).max() <= 2 * 5e-4      # Adam: |dp| <= ~lr per step
+
+
+def test_c_abi_exports_every_declared_symbol(pkg, lib):
+    """include/gatres.h is the contract: every function it declares must be exported by the built library and bound
+    by the ctypes table (and vice versa)."""
+    hdr = open(os.path.join(ROOT, "include", "gatres.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(gatres_[a-z0-9_]+)\s*\(", hdr))
+    assert len(declared) >= 35
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in gatres.h but not exported"
+    assert declared == set(pkg._native.SIGNATURES), declared ^ set(pkg._native.SIGNATURES)
+    assert lib.gatres_param_count(15, 32) == 65857 and lib.gatres_param_count(25, 128) == 1667585
+
+
+def ref_plan(ei, n):
+    """numpy restatement of the plan: PyG edge order, stable sorts."""
+    src, dst = ei[0].numpy(), ei[1].numpy()
+    keep = src != dst
+    gs = np.concatenate([src[keep], np.arange(n)])
+    gd = np.concatenate([dst[keep], np.arange(n)])
+    order = np.argsort(gd, kind="stable")
+    rowptr = np.concatenate([[0], np.cumsum(np.bincount(gd, minlength=n))])
+    col = gs[order]
+    pos = np.empty_like(order); pos[order] = np.arange(order.size)
+    torder = np.argsort(gs, kind="stable")
+    t_rowptr = np.concatenate([[0], np.cumsum(np.bincount(gs, minlength=n))])
+    morder = np.argsort(dst, kind="stable")
+    m_rowptr = np.concatenate([[0], np.cumsum(np.bincount(dst, minlength=n))])
+    mtorder = np.argsort(src, kind="stable")
+    return dict(rowptr=rowptr, col=col, t_rowptr=t_rowptr, t_eid=pos[torder], t_dst=gd[torder], m_rowptr=m_rowptr,
+                m_col=src[morder], mt_rowptr=np.concatenate([[0], np.cumsum(np.bincount(src, minlength=n))]),
+                mt_dst=dst[mtorder])
+
+
+def test_graph_plan_matches_numpy_restatement(pkg):
+    g = torch.Generator().manual_seed(0)
+    n = 57
+    ei = torch.randint(0, n, (2, 300), generator=g)          # self loops and duplicates included
+    plan = pkg.GraphPlan(ei, n, device="cpu")
+    ref = ref_plan(ei, n)
+    assert plan.num_edges_gat == int((ei[0] != ei[1]).sum()) + n and plan.num_edges_mean == 300
+    for k, v in ref.items():
+        got = plan.arrays[k].numpy()[: v.size]
+        assert np.array_equal(got, v), k
+    with pytest.raises(RuntimeError):
+        pkg.GraphPlan(torch.tensor([[0, 99], [1, 2]]), 5, device="cpu")       # endpoint out of range
+    with pytest.raises(ValueError):
+        pkg.GraphPlan(torch.zeros((2, 3), dtype=torch.int32), 5, device="cpu")
+
+
+def test_segments_are_the_snapshots_of_a_batch(pkg):
+    one = pkg.wdn_synth.make_wdn_topology()
+    plan = pkg.GraphPlan(pkg.wdn_synth.collate_edge_index(one, 388, 5), 388 * 5, device="cpu")
+    assert plan.num_segments == 5 and plan.max_segment_nodes == 388
+    assert plan.segment_ptr_host.tolist() == [0, 388, 776, 1164, 1552, 1940]
+    assert plan.max_segment_edges_mean == 860 and plan.max_segment_edges_gat == 860 + 388
+    # an edge across two snapshots fuses them into one segment; isolated nodes are merged up to merge_upto
+    ei = torch.cat([pkg.wdn_synth.collate_edge_index(one, 388, 3), torch.tensor([[10], [400]])], 1)
+    p2 = pkg.GraphPlan(ei, 388 * 3, device="cpu")
+    assert p2.segment_ptr_host.tolist() == [0, 776, 1164]
+    p3 = pkg.GraphPlan(torch.zeros((2, 0), dtype=torch.int64), 10, device="cpu", merge_upto=4)
+    assert p3.segment_ptr_host.tolist() == [0, 4, 8, 10]
+    assert pkg.GraphPlan(one, 388, device="cpu", segments=False).num_segments == 0
+
+
+def test_module_surface_on_cpu(pkg, oracle):
+    m = pkg.GATResMeanConv(name="GATResMeanConv_small_znorm_15b_32c", num_blocks=15, nc=32)
+    assert sum(p.numel() for p in m.parameters()) == 65857
+    assert m.flat_parameters.numel() == 65857 and m._flat_is_current()
+    keys = [k for k in m.state_dict() if "lin_dst" not in k]
+    assert keys == list(oracle.param_shapes(15, 32).keys())
+    # parameters are views of the flat vector in state_dict order
+    m.lin1.bias.data.fill_(3.5)
+    assert float(m.flat_parameters[-1]) == 3.5
+    with pytest.raises(ValueError):
+        m(torch.zeros(4, 1), torch.zeros((2, 0), dtype=torch.int64))       # CPU tensors: no CPU path
+    import argparse
+    args, model = pkg.select_model(argparse.Namespace(model="gatres_large"))
+    assert (model.num_blocks, model.nc, args.criterion, args.norm_type) == (25, 128, "mse", "znorm")
+    assert args.use_data_edge_attrs is None and model.name == "GATRes_Large_znorm_25b_128c"
+    with pytest.raises(NotImplementedError):
+        pkg.select_model(argparse.Namespace(model="gin"))
+
+
+def test_synthetic_wdn_has_ctown_shape(pkg):
+    ei = pkg.wdn_synth.make_wdn_topology()
+    assert ei.shape == (2, 860) and ei.dtype == torch.int64
+    assert torch.equal(ei, pkg.wdn_synth.make_wdn_topology())                # seeded
+    und = {(min(a, b), max(a, b)) for a, b in ei.t().tolist()}
+    assert len(und) == 430 and all(a != b for a, b in und)
+    assert torch.equal(ei[0], torch.sort(ei[0], stable=True).values)         # grouped by source (from_networkx order)
+    deg = torch.bincount(ei[1], minlength=388)
+    assert int(deg.min()) >= 1 and int(deg.max()) <= 5
+    x, y, bei, mask = pkg.wdn_synth.make_batch(4)
+    assert x.shape == (1552, 1) and torch.equal(x, y) and bei.shape == (2, 3440) and int(bei.max()) == 1551
+    assert mask.dtype == torch.bool and all(int(mask[i * 388:(i + 1) * 388].sum()) == 368 for i in range(4))
