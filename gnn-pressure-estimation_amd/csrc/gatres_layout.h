@@ -86,3 +86,32 @@ static inline bool make_layout(const gatres_model_t* m, int64_t N, int64_t Eg, i
   return true;
 }
 
+
+
+// Saved activations of the FUSED path: segment-major.  Every segment (snapshot) owns one contiguous slot of
+// `total` floats laid out [block 0 | block 1 | ... | final x], each block holding the same ten tables as the
+// per-op layout but indexed by LOCAL node / edge ids.  A workgroup then walks ~5 MB of contiguous memory instead of
+// ten arrays per block spread over 150 MB (which cost a TLB miss on almost every access).  Slots are sized for the
+// largest segment of the plan.
+struct SegLayout {
+  int64_t xin, h1, as1, ad1, al1, o1, h2, as2, ad2, al2, bstride, total;
+};
+
+static inline __host__ __device__ SegLayout make_seg_layout(int nb, int nc, int64_t mn, int64_t me) {
+  SegLayout S;
+  int64_t o = 0;
+  S.xin = o; o += r4(mn * nc);
+  S.h1 = o;  o += r4(mn * 2 * nc);
+  S.as1 = o; o += r4(mn * 2);
+  S.ad1 = o; o += r4(mn * 2);
+  S.al1 = o; o += r4(me * 2);
+  S.o1 = o;  o += r4(mn * 2 * nc);
+  S.h2 = o;  o += r4(mn * nc);
+  S.as2 = o; o += r4(mn);
+  S.ad2 = o; o += r4(mn);
+  S.al2 = o; o += r4(me);
+  S.bstride = o;
+  S.total = (int64_t)nb * o + r4(mn * nc);
+  S.total = (S.total + 63) & ~(int64_t)63;          // 256-B aligned slots
+  return S;
+}

@@ -50,6 +50,7 @@ struct FusedArgs {
   float* scratch;
   float* slabs;
   Layout L;
+  SegLayout SL;             // segment-major saved activations (training)
   int phases;               // GATRES_PHASE_FORWARD | _BACKWARD, bit 16: loss
   unsigned long long* stamps;   // diagnostic: segment 0 stamps the wall clock at every stage boundary
   int stamp_cap;
@@ -74,13 +75,19 @@ __host__ __device__ inline int topo_fwd_bytes(int n, int eg, int em) {
 __host__ __device__ inline int topo_bwd_bytes(int n, int eg, int em) {
   return 2 * (4 * even(n + 1) + 3 * even(eg) + 2 * even(em));
 }
+static long long wl_bytes(int nc) {
+  const long long f = 4LL * (2LL * nc * (2 * nc + 4) + 4 * nc);
+  return f <= 40960 ? f + 16 : 0;          // W staging slot of seg_proj (not used for nc = 128: W does not fit)
+}
 static bool cache_fits(int nc, int threads, int n, int eg, int em) {
   const long long fwd = 4LL * n * (3 * nc + 4) + topo_fwd_bytes(n, eg, em);
-  const long long bwd = 12LL * threads + 4LL * n * 2 * nc + 8LL * even(eg) + 16LL * n + topo_bwd_bytes(n, eg, em);
+  const long long bwd = 12LL * threads + 4LL * n * 2 * nc + 8LL * even(eg) + 16LL * n + topo_bwd_bytes(n, eg, em) +
+                        wl_bytes(nc);
   return fwd <= LDS_BYTES && bwd <= LDS_BYTES && n <= 65535 && eg <= 65535 && em <= 65535;
 }
-static bool nocache_fits(int threads, int n, int eg, int em) {
-  return 12LL * threads + topo_bwd_bytes(n, eg, em) <= LDS_BYTES && n <= 65535 && eg <= 65535 && em <= 65535;
+static bool nocache_fits(int nc, int threads, int n, int eg, int em) {
+  return 12LL * threads + topo_bwd_bytes(n, eg, em) + wl_bytes(nc) <= LDS_BYTES && n <= 65535 && eg <= 65535 &&
+         em <= 65535;
 }
 
 // ------------------------------------------------------------------------------------------ small helpers
@@ -134,17 +141,42 @@ enum { EPI_NONE = 0, EPI_ATT = 1, EPI_RESID_MASK = 2 };
 // ------------------------------------------------------------------------------------------ K1 (MFMA)
 // OUT[ob + r, :] = X[xb + r, :] @ Wm^T for r in [0, n).  Same lane map / k order as proj_kernel (k_proj.hip), so
 // results are bit-identical; each wave takes TWO 16-node tiles per trip and feeds both from one W fragment load.
-template <int K, int M, int H, int EPI, int THREADS>
+template <int K, int M, int H, int EPI, int THREADS, bool WLDS>
 __device__ __forceinline__ void seg_proj(int n, const float* X, int xb, const float* __restrict__ Wm, float* OUT,
                                          int ob, float* OUT2, int o2b, const float* __restrict__ att_src,
                                          const float* __restrict__ att_dst, float* as_g, float* ad_g, int ag_b,
                                          float* as_l, float* ad_l, const float* resid, int rb,
-                                         const float* relu_ref, int mb_) {
+                                         const float* relu_ref, int mb_, float* wl,
+                                         unsigned long long* dbg = nullptr) {
   constexpr int KQ = K / 4, NT = (M + 15) / 16, NW = THREADS / 64;
+  constexpr int KP = K + 4;                  // padded LDS row: 16 lanes x float4 at stride KP hit distinct banks
+  int di = 0;
+#define PSTAMP() do { if (dbg && threadIdx.x == 0 && di < 24) dbg[di++] = wall_clock64(); } while (0)
+  PSTAMP();
   constexpr int SC = (KQ % 4 == 0) ? 4 : ((KQ % 2 == 0) ? 2 : 1);
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int i = lane & 15, q = lane >> 4;
   const int ntiles = (n + 15) >> 4;
+
+  // Stage W (rows padded to KP) and the attention vectors into LDS once per stage: every wave then feeds its MFMA
+  // chain from 28-ns LDS reads instead of ~0.3-us L2 trips that the in-order wave exposes one after another.
+  const float* attS = att_src;
+  const float* attD = att_dst;
+  if constexpr (WLDS) {
+    for (int idx = threadIdx.x; idx < M * (K / 4); idx += THREADS) {
+      const int m = idx / (K / 4), k4 = (idx % (K / 4)) * 4;
+      st4(wl + m * KP + k4, ld4(Wm + (unsigned)(m * K + k4)));
+    }
+    if constexpr (EPI == EPI_ATT) {
+      float* al = wl + M * KP;
+      for (int idx = threadIdx.x; idx < 2 * (M / 4); idx += THREADS) {
+        const int which = idx / (M / 4), c4 = (idx % (M / 4)) * 4;
+        st4(al + which * M + c4, ld4((which ? att_dst : att_src) + c4));
+      }
+      attS = al; attD = al + M;
+    }
+    __syncthreads();
+  }
 
   auto epilogue = [&](f32x4(&acc)[NT], int r, bool rok) {
     if constexpr (EPI == EPI_ATT) {
@@ -156,7 +188,7 @@ __device__ __forceinline__ void seg_proj(int n, const float* X, int xb, const fl
       for (int tt = 0; tt < NT; ++tt) {
         const int mb = tt * 16 + q * 4;
         if ((M % 16 == 0) || (mb < M)) {
-          const float4 as = ld4(att_src + mb), ad = ld4(att_dst + mb);
+          const float4 as = ld4(attS + mb), ad = ld4(attD + mb);
           const float ds = fmaf(acc[tt][3], as.w, fmaf(acc[tt][2], as.z, fmaf(acc[tt][1], as.y, acc[tt][0] * as.x)));
           const float dd = fmaf(acc[tt][3], ad.w, fmaf(acc[tt][2], ad.z, fmaf(acc[tt][1], ad.y, acc[tt][0] * ad.x)));
           const int hd = mb / C;
@@ -173,8 +205,8 @@ __device__ __forceinline__ void seg_proj(int n, const float* X, int xb, const fl
       if (q == 0 && rok) {
 #pragma unroll
         for (int hh = 0; hh < H; ++hh) {
-          as_g[(size_t)(ag_b + r) * H + hh] = ps[hh];
-          ad_g[(size_t)(ag_b + r) * H + hh] = pd[hh];
+          as_g[(unsigned)((ag_b + r) * H + hh)] = ps[hh];
+          ad_g[(unsigned)((ag_b + r) * H + hh)] = pd[hh];
           if (as_l) { as_l[r * H + hh] = ps[hh]; ad_l[r * H + hh] = pd[hh]; }
         }
       }
@@ -186,15 +218,15 @@ __device__ __forceinline__ void seg_proj(int n, const float* X, int xb, const fl
         if ((M % 16 == 0) || (mb < M)) {
           float4 o = make_float4(acc[tt][0], acc[tt][1], acc[tt][2], acc[tt][3]);
           if constexpr (EPI == EPI_RESID_MASK) {
-            if (resid) add4(o, ld4(resid + (size_t)(rb + r) * M + mb));
+            if (resid) add4(o, ld4(resid + (unsigned)((rb + r) * M + mb)));
             if (relu_ref) {
-              const float4 rr = ld4(relu_ref + (size_t)(mb_ + r) * M + mb);
+              const float4 rr = ld4(relu_ref + (unsigned)((mb_ + r) * M + mb));
               o.x = rr.x > 0.f ? o.x : 0.f; o.y = rr.y > 0.f ? o.y : 0.f;
               o.z = rr.z > 0.f ? o.z : 0.f; o.w = rr.w > 0.f ? o.w : 0.f;
             }
           }
-          st4(OUT + (size_t)(ob + r) * M + mb, o);
-          if (OUT2) st4(OUT2 + (size_t)(o2b + r) * M + mb, o);
+          st4(OUT + (unsigned)((ob + r) * M + mb), o);
+          if (OUT2) st4(OUT2 + (unsigned)((o2b + r) * M + mb), o);
         }
       }
     }
@@ -202,7 +234,7 @@ __device__ __forceinline__ void seg_proj(int n, const float* X, int xb, const fl
 
   // W fragments: loaded ONCE per stage into registers when they fit (one load latency instead of NT*KQ/SC
   // dependent ones); lane (i, q) needs Wm[16*tt + i][q*KQ .. q*KQ+KQ) for every tile row tt.
-  constexpr bool HOIST = (NT * KQ <= 64);
+  constexpr bool HOIST = false;   // holding W in 32+ registers spills at the 128-VGPR budget; W re-reads hit L1
   float wreg[HOIST ? NT : 1][HOIST ? KQ : 1];
   if constexpr (HOIST) {
 #pragma unroll
@@ -216,20 +248,24 @@ __device__ __forceinline__ void seg_proj(int n, const float* X, int xb, const fl
       }
     }
   }
-  // one 16-node tile (DUAL = false) or two (DUAL = true) per trip; straight-line MFMA chains, no per-MFMA branches
-  auto run_tiles = [&](auto dual_tag, int t0, int t1) {
-    constexpr bool DUAL = decltype(dual_tag)::value;
-    const int rA = t0 * 16 + i, rB = t1 * 16 + i;
-    const bool okA = rA < n, okB = DUAL && rB < n;
-    float xA[KQ], xB[DUAL ? KQ : 1];
-    load_frag<KQ>(X + (size_t)(xb + (okA ? rA : n - 1)) * K + q * KQ, xA);
-    if constexpr (DUAL) load_frag<KQ>(X + (size_t)(xb + (okB ? rB : n - 1)) * K + q * KQ, xB);
-    f32x4 accA[NT], accB[DUAL ? NT : 1];
+  // one 16-node tile per trip; the NEXT trip's x fragment is loaded before this trip's MFMA chain so its latency
+  // hides behind the matrix work (a two-tiles-per-trip variant spilled at the 128-VGPR budget of a 16-wave workgroup)
+  float xcur[KQ], xnxt[KQ];
+  {
+    const int r0 = wave * 16 + i;
+    load_frag<KQ>(X + (unsigned)((xb + min(r0, n - 1)) * K + q * KQ), xcur);
+  }
+  PSTAMP();
+  for (int t0 = wave; t0 < ntiles; t0 += NW) {
+    const int rA = t0 * 16 + i;
+    const bool okA = rA < n;
+    if (dbg) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+    PSTAMP();
+    const int rN = (t0 + NW) * 16 + i;
+    if (t0 + NW < ntiles) load_frag<KQ>(X + (unsigned)((xb + min(rN, n - 1)) * K + q * KQ), xnxt);   // uniform branch
+    f32x4 acc[NT];
 #pragma unroll
-    for (int tt = 0; tt < NT; ++tt) {
-      accA[tt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-      if constexpr (DUAL) accB[tt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    }
+    for (int tt = 0; tt < NT; ++tt) acc[tt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int s = 0; s < KQ; s += SC) {
 #pragma unroll
@@ -241,27 +277,27 @@ __device__ __forceinline__ void seg_proj(int n, const float* X, int xb, const fl
         } else {
           const int m = tt * 16 + i;
           const bool mok = (M % 16 == 0) || (m < M);
-          load_frag<SC>(Wm + (size_t)(mok ? m : 0) * K + q * KQ + s, wf);
+          if constexpr (WLDS) load_frag<SC>(wl + (mok ? m : 0) * KP + q * KQ + s, wf);
+          else                load_frag<SC>(Wm + (unsigned)((mok ? m : 0) * K + q * KQ + s), wf);
           if (!mok) {
 #pragma unroll
             for (int u = 0; u < SC; ++u) wf[u] = 0.f;
           }
         }
 #pragma unroll
-        for (int u = 0; u < SC; ++u) {
-          accA[tt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[u], xA[s + u], accA[tt], 0, 0, 0);
-          if constexpr (DUAL) accB[tt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[u], xB[s + u], accB[tt], 0, 0, 0);
-        }
+        for (int u = 0; u < SC; ++u)
+          acc[tt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[u], xcur[s + u], acc[tt], 0, 0, 0);
       }
     }
-    epilogue(accA, rA, okA);
-    if constexpr (DUAL) epilogue(accB, rB, okB);
-  };
-  for (int t0 = wave; t0 < ntiles; t0 += 2 * NW) {
-    const int t1 = t0 + NW;
-    if (t1 < ntiles) run_tiles(std::true_type{}, t0, t1);       // wave-uniform branch
-    else             run_tiles(std::false_type{}, t0, t0);
+    if (dbg) { asm volatile("" :: "v"(acc[0][0]), "v"(acc[NT - 1][3])); }
+    PSTAMP();
+    epilogue(acc, rA, okA);
+    PSTAMP();
+#pragma unroll
+    for (int s = 0; s < KQ; ++s) xcur[s] = xnxt[s];
   }
+  PSTAMP();
+#undef PSTAMP
 }
 
 // dW partial of this segment: slab[c*K + k] = sum_r G[gb + r, c] * X[xb + r, k].  One 16x16 output tile per wave
@@ -334,63 +370,40 @@ __device__ __forceinline__ int wave_max_deg(int deg) {
   return d;
 }
 
-// K2 forward
-template <bool RELU, int H, int C, int THREADS>
-__device__ __forceinline__ void seg_agg_fwd(int n, const u16* rp, const u16* col, const float* hsrc, int hb,
-                                            const float* asrc, const float* adst_t, int ab,
-                                            const float* __restrict__ bias, float* out, int ob,
-                                            float* __restrict__ alpha, int eb) {
-  constexpr int HC = H * C, G = HC / 4, LH = C / 4, SLOTS = (MAXD + LH - 1) / LH, RPP = THREADS / G;
-  const int c0 = (threadIdx.x % G) * 4;
-  const int hd = c0 / C;
-  const bool leader = (c0 % C) == 0;
-  const int lih = (threadIdx.x % G) % LH;                 // lane inside its head
-  const int hbase = (threadIdx.x & 63) - lih;             // wave lane of the head's first lane
-  const float4 b = ld4(bias + c0);
-  const int rounds = (n + RPP - 1) / RPP;
-  for (int it = 0; it < rounds; ++it) {
-    int r = it * RPP + threadIdx.x / G;
-    const bool valid = r < n;                             // all lanes stay in the loop for the shuffles
-    if (!valid) r = n - 1;
-    const int beg = rp[r], deg = (int)rp[r + 1] - beg;    // deg >= 1: GATConv adds a self loop to every node
-    const int dmax = wave_max_deg(deg);
+// K2 forward, sub-stage A: attention coefficients.  ONE thread per (row, head): no cross-lane traffic, one exp and
+// one divide per edge.  alpha goes to HBM (saved for the backward pass) and, when ALDS, to an LDS table for sub-stage B.
+template <int H, bool ALDS, int THREADS>
+__device__ __forceinline__ void seg_softmax(int n, const u16* rp, const u16* col, const float* asrc,
+                                            const float* adst_t, int ab, float* __restrict__ alpha_g, int eb,
+                                            float* alpha_l) {
+  for (int idx = threadIdx.x; idx < n * H; idx += THREADS) {
+    const int r = idx / H, hd = idx % H;
+    const int beg = rp[r], deg = (int)rp[r + 1] - beg;            // deg >= 1 (self loop)
     const float adst = adst_t[(unsigned)((ab + r) * H + hd)];
-    float4 acc = f4zero();
     if (deg <= MAXD) {
-      // the head's LH lanes split the row's edges: lane l scores slots l, l+LH, ... (ONE exp and ONE divide per
-      // slot instead of one per lane); values are broadcast with __shfl.
-      float so[SLOTS];
+      float so[MAXD];
       float m = -INFINITY;
 #pragma unroll
-      for (int t = 0; t < SLOTS; ++t) {
-        const int k = lih + LH * t;
+      for (int k = 0; k < MAXD; ++k) {
         const int jj = col[beg + min(k, deg - 1)];
         const float sv = gatres_leaky(asrc[(unsigned)((ab + jj) * H + hd)] + adst);
-        so[t] = k < deg ? sv : -INFINITY;
-        m = fmaxf(m, so[t]);
+        so[k] = k < deg ? sv : -INFINITY;
+        m = fmaxf(m, so[k]);
       }
-#pragma unroll
-      for (int off = LH >> 1; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
-#pragma unroll
-      for (int t = 0; t < SLOTS; ++t) so[t] = expf(so[t] - m);          // exp(-inf) = 0 for padding slots
-      float4 v[MAXD];
-#pragma unroll
-      for (int k = 0; k < MAXD; ++k)
-        if (k < dmax) v[k] = ld4(hsrc + (unsigned)((hb + (int)col[beg + min(k, deg - 1)]) * HC + c0));
       float Z = 0.f;
 #pragma unroll
-      for (int k = 0; k < MAXD; ++k)
-        if (k < dmax) Z = Z + __shfl(so[k / LH], hbase + (k % LH));     // + 0 for padding slots: exact
+      for (int k = 0; k < MAXD; ++k) {
+        so[k] = expf(so[k] - m);                                   // exp(-inf) = 0 on padding slots
+        Z = Z + so[k];
+      }
       Z = Z + GATRES_SOFTMAX_EPS;
 #pragma unroll
-      for (int t = 0; t < SLOTS; ++t) {
-        const int k = lih + LH * t;
-        so[t] = so[t] / Z;
-        if (valid && k < deg) alpha[(unsigned)((eb + beg + k) * H + hd)] = so[t];
-      }
-#pragma unroll
       for (int k = 0; k < MAXD; ++k)
-        if (k < dmax) gatres_axpy4(acc, __shfl(so[k / LH], hbase + (k % LH)), v[k]);   // weight 0 on padding
+        if (k < deg) {
+          const float al = so[k] / Z;
+          alpha_g[(unsigned)((eb + beg + k) * H + hd)] = al;
+          if constexpr (ALDS) alpha_l[(beg + k) * H + hd] = al;
+        }
     } else {
       const int end = beg + deg;
       float m = -INFINITY;
@@ -399,11 +412,48 @@ __device__ __forceinline__ void seg_agg_fwd(int n, const u16* rp, const u16* col
       for (int e = beg; e < end; ++e) Z = Z + expf(gatres_leaky(asrc[(unsigned)((ab + col[e]) * H + hd)] + adst) - m);
       Z = Z + GATRES_SOFTMAX_EPS;
       for (int e = beg; e < end; ++e) {
-        const int jj = col[e];
-        const float al = expf(gatres_leaky(asrc[(unsigned)((ab + jj) * H + hd)] + adst) - m) / Z;
-        if (valid && leader) alpha[(unsigned)((eb + e) * H + hd)] = al;
-        gatres_axpy4(acc, al, ld4(hsrc + (unsigned)((hb + jj) * HC + c0)));
+        const float al = expf(gatres_leaky(asrc[(unsigned)((ab + col[e]) * H + hd)] + adst) - m) / Z;
+        alpha_g[(unsigned)((eb + e) * H + hd)] = al;
+        if constexpr (ALDS) alpha_l[e * H + hd] = al;
       }
+    }
+  }
+}
+
+// K2 forward, sub-stage B: out[r] = sum_e alpha_e * h[src(e)] + bias (+ReLU).  HC/4 lanes per row; the per-row chain is
+// rowptr -> col -> {alpha, h rows} -> fma.  alpha: [ab2 + e] (LDS table with ab2 = 0, or the global array with ab2 = eb).
+template <bool RELU, int H, int C, int THREADS>
+__device__ __forceinline__ void seg_gather(int n, const u16* rp, const u16* col, const float* hsrc, int hb,
+                                           const float* alpha, int ab2, const float* __restrict__ bias, float* out,
+                                           int ob) {
+  constexpr int HC = H * C, G = HC / 4, RPP = THREADS / G;
+  const int c0 = (threadIdx.x % G) * 4;
+  const int hd = c0 / C;
+  const float4 b = ld4(bias + c0);
+  const int rounds = (n + RPP - 1) / RPP;
+  for (int it = 0; it < rounds; ++it) {
+    int r = it * RPP + threadIdx.x / G;
+    const bool valid = r < n;
+    if (!valid) r = n - 1;
+    const int beg = rp[r], deg = (int)rp[r + 1] - beg;
+    const int dmax = wave_max_deg(deg);
+    float4 acc = f4zero();
+    if (deg <= MAXD) {
+      float4 v[MAXD];
+      float al[MAXD];
+#pragma unroll
+      for (int k = 0; k < MAXD; ++k)
+        if (k < dmax) {
+          const int e = beg + min(k, deg - 1);
+          v[k] = ld4(hsrc + (unsigned)((hb + (int)col[e]) * HC + c0));
+          al[k] = alpha[(unsigned)((ab2 + e) * H + hd)];
+        }
+#pragma unroll
+      for (int k = 0; k < MAXD; ++k)
+        if (k < dmax) gatres_axpy4(acc, k < deg ? al[k] : 0.f, v[k]);     // weight 0 on padding slots
+    } else {
+      for (int e = beg; e < beg + deg; ++e)
+        gatres_axpy4(acc, alpha[(unsigned)((ab2 + e) * H + hd)], ld4(hsrc + (unsigned)((hb + (int)col[e]) * HC + c0)));
     }
     add4(acc, b);
     if (RELU) {
@@ -684,7 +734,7 @@ __device__ __forceinline__ void seg_lin1_bwd(int n, int n0, const float* __restr
   for (int r = rg; r < n; r += R) {
     const size_t node = (size_t)n0 + r;
     const float go = g_out[node];
-    const float xv = x[node * NC + c];
+    const float xv = x[(unsigned)(r * NC + c)];          // x: the segment's saved final activation, local rows
     aw = fmaf(go, xv, aw);
     ab += go;
     const float gv = (relu_mask && !(xv > 0.f)) ? 0.f : go * wv;
@@ -754,14 +804,36 @@ __global__ __launch_bounds__(THREADS) void gatres_fused_kernel(const FusedArgs a
     u16* col = tp;             tp += even(eg);
     u16* mrp = tp;             tp += even(n + 1);
     u16* mcol = tp;
+    tp += even(em);
+    // LDS staging for a projection's W + att (seg_proj): with the tables cached, proj1 borrows the h2 region and
+    // proj2 the h1 region (each is dead exactly then); otherwise a slot behind the topology
+    constexpr int WL_FLOATS = 2 * NC * (2 * NC + 4) + 4 * NC;           // max over the block's projections
+    constexpr bool WLDS = WL_FLOATS * 4 <= 40960;
+    // The slot is always a real LDS address chosen by OFFSET (a nullable LDS pointer makes the compiler build flat
+    // addresses with null checks, hoist them out of the block loop and spill them).  If the cached tables leave
+    // room, a private slot at the end of LDS; otherwise proj1 borrows the h2 table and proj2 the h1 table.
+    const int used_b = (int)(reinterpret_cast<unsigned char*>(tp) - lds_raw);
+    const bool priv = used_b + WL_FLOATS * 4 + 16 <= LDS_BYTES;
+    const int slot_b = LDS_BYTES - ((WL_FLOATS * 4 + 15) & ~15);
+    float* wl1 = reinterpret_cast<float*>(lds_raw + (priv ? slot_b : (int)((unsigned char*)hB - lds_raw)));
+    float* wl2 = reinterpret_cast<float*>(lds_raw + (priv ? slot_b : 0));
     copy_rowptr16<THREADS>(rp, a.rowptr, n0, n, e0);
     copy_idx16<THREADS>(col, a.col, e0, eg, n0);
     copy_rowptr16<THREADS>(mrp, a.m_rowptr, n0, n, em0);
     copy_idx16<THREADS>(mcol, a.m_col, em0, em, n0);
 
+    // saved tables: this segment's contiguous slot with LOCAL indices (training), or the shared evaluation block of
+    // the scratch area with global indices (inference)
+    const SegLayout& SL = a.SL;
+    float* segbase = a.saved ? a.saved + (int64_t)seg * SL.total : nullptr;
+    const int nbS = a.saved ? 0 : n0, ebS = a.saved ? 0 : e0;
+    const int64_t o_h1 = a.saved ? SL.h1 : L.s_h1, o_as1 = a.saved ? SL.as1 : L.s_as1, o_ad1 = a.saved ? SL.ad1 : L.s_ad1,
+                  o_al1 = a.saved ? SL.al1 : L.s_al1, o_o1 = a.saved ? SL.o1 : L.s_o1, o_h2 = a.saved ? SL.h2 : L.s_h2,
+                  o_as2 = a.saved ? SL.as2 : L.s_as2, o_ad2 = a.saved ? SL.ad2 : L.s_ad2,
+                  o_al2 = a.saved ? SL.al2 : L.s_al2;
     float* xa = sc + L.sc_xa;
     float* xb = sc + L.sc_xb;
-    float* xcur = a.saved ? a.saved + L.s_xin : xa;
+    float* xcur = a.saved ? segbase + SL.xin : xa;
     {  // lin0 (+ the caller-side x[mask] = 0)
       const float* w = P + L.p_lin0_w;
       const float* b = P + L.p_lin0_b;
@@ -772,49 +844,70 @@ __global__ __launch_bounds__(THREADS) void gatres_fused_kernel(const FusedArgs a
         const float4 wv = ld4(w + c0), bv = ld4(b + c0);
         float4 o;
         o.x = xv * wv.x + bv.x; o.y = xv * wv.y + bv.y; o.z = xv * wv.z + bv.z; o.w = xv * wv.w + bv.w;
-        st4(xcur + node * NC + c0, o);
+        st4(xcur + (unsigned)((nbS + r) * NC + c0), o);
       }
     }
     __syncthreads();
     STAMP();
     for (int b = 0; b < L.nb; ++b) {
-      float* base = a.saved ? a.saved + (int64_t)b * L.s_stride : sc + L.sc_ev;
-      float* xnext = a.saved ? a.saved + (int64_t)(b + 1) * L.s_stride + L.s_xin : (xcur == xa ? xb : xa);
+      float* base = a.saved ? segbase + (int64_t)b * SL.bstride : sc + L.sc_ev;
+      float* xnext = a.saved ? segbase + (int64_t)(b + 1) * SL.bstride + SL.xin : (xcur == xa ? xb : xa);
       const float* pb = P + L.p_block0 + (int64_t)b * L.p_block_stride;
       float* y2g = sc + L.sc_y2;
       // conv1: K1, then K2 (+bias+ReLU)
-      seg_proj<NC, 2 * NC, 2, EPI_ATT, THREADS>(n, xcur, n0, pb + L.c1_W, base + L.s_h1, n0, CACHE ? hA : nullptr, 0,
-                                                 pb + L.c1_as, pb + L.c1_ad, base + L.s_as1, base + L.s_ad1, n0,
-                                                 CACHE ? sa : nullptr, CACHE ? sd : nullptr, nullptr, 0, nullptr, 0);
+      seg_proj<NC, 2 * NC, 2, EPI_ATT, THREADS, WLDS>(n, xcur, nbS, pb + L.c1_W, base + o_h1, nbS, CACHE ? hA : nullptr, 0,
+                                                 pb + L.c1_as, pb + L.c1_ad, base + o_as1, base + o_ad1, nbS,
+                                                 CACHE ? sa : nullptr, CACHE ? sd : nullptr, nullptr, 0, nullptr, 0, wl1,
+                                                 (a.stamps && seg == 0 && b == 1) ? a.stamps + a.stamp_cap + 8 : nullptr);
+      if (a.stamps && seg == 0 && b == 1 && tid == 0) a.stamps[a.stamp_cap + 7] = wall_clock64();
       __syncthreads();
       STAMP();
-      if (CACHE)
-        seg_agg_fwd<true, 2, NC, THREADS>(n, rp, col, hA, 0, sa, sd, 0, pb + L.c1_b, base + L.s_o1, n0,
-                                          base + L.s_al1, e0);
-      else
-        seg_agg_fwd<true, 2, NC, THREADS>(n, rp, col, base + L.s_h1, n0, base + L.s_as1, base + L.s_ad1, n0,
-                                          pb + L.c1_b, base + L.s_o1, n0, base + L.s_al1, e0);
+      // K2 conv1: softmax (alpha -> HBM + LDS: the h2 table is dead now), then the gather
+      if (CACHE && 2 * eg <= n * NC) {           // (wave-uniform) the alpha table fits the borrowed region
+        seg_softmax<2, true, THREADS>(n, rp, col, sa, sd, 0, base + o_al1, ebS, hB);
+        __syncthreads();
+        seg_gather<true, 2, NC, THREADS>(n, rp, col, hA, 0, hB, 0, pb + L.c1_b, base + o_o1, nbS);
+      } else if (CACHE) {
+        seg_softmax<2, false, THREADS>(n, rp, col, sa, sd, 0, base + o_al1, ebS, nullptr);
+        __syncthreads();
+        seg_gather<true, 2, NC, THREADS>(n, rp, col, hA, 0, base + o_al1, ebS, pb + L.c1_b, base + o_o1, nbS);
+      } else {
+        seg_softmax<2, false, THREADS>(n, rp, col, base + o_as1, base + o_ad1, nbS, base + o_al1, ebS, nullptr);
+        __syncthreads();
+        seg_gather<true, 2, NC, THREADS>(n, rp, col, base + o_h1, nbS, base + o_al1, ebS, pb + L.c1_b, base + o_o1,
+                                         nbS);
+      }
       __syncthreads();
       STAMP();
       // conv2
-      seg_proj<2 * NC, NC, 1, EPI_ATT, THREADS>(n, base + L.s_o1, n0, pb + L.c2_W, base + L.s_h2, n0,
-                                                 CACHE ? hB : nullptr, 0, pb + L.c2_as, pb + L.c2_ad, base + L.s_as2,
-                                                 base + L.s_ad2, n0, CACHE ? sa : nullptr, CACHE ? sd : nullptr,
-                                                 nullptr, 0, nullptr, 0);
+      seg_proj<2 * NC, NC, 1, EPI_ATT, THREADS, WLDS>(n, base + o_o1, nbS, pb + L.c2_W, base + o_h2, nbS,
+                                                 CACHE ? hB : nullptr, 0, pb + L.c2_as, pb + L.c2_ad, base + o_as2,
+                                                 base + o_ad2, nbS, CACHE ? sa : nullptr, CACHE ? sd : nullptr,
+                                                 nullptr, 0, nullptr, 0, wl2);
       __syncthreads();
       STAMP();
-      if (CACHE)
-        seg_agg_fwd<false, 1, NC, THREADS>(n, rp, col, hB, 0, sa, sd, 0, pb + L.c2_b, hA, 0, base + L.s_al2, e0);
-      else
-        seg_agg_fwd<false, 1, NC, THREADS>(n, rp, col, base + L.s_h2, n0, base + L.s_as2, base + L.s_ad2, n0,
-                                           pb + L.c2_b, y2g, n0, base + L.s_al2, e0);
+      // K2 conv2: alpha's LDS table sits in the upper half of the h1 region (y2 is written to the lower half)
+      if (CACHE && eg <= n * NC) {
+        float* al2L = hA + (size_t)n * NC;
+        seg_softmax<1, true, THREADS>(n, rp, col, sa, sd, 0, base + o_al2, ebS, al2L);
+        __syncthreads();
+        seg_gather<false, 1, NC, THREADS>(n, rp, col, hB, 0, al2L, 0, pb + L.c2_b, hA, 0);
+      } else if (CACHE) {
+        seg_softmax<1, false, THREADS>(n, rp, col, sa, sd, 0, base + o_al2, ebS, nullptr);
+        __syncthreads();
+        seg_gather<false, 1, NC, THREADS>(n, rp, col, hB, 0, base + o_al2, ebS, pb + L.c2_b, hA, 0);
+      } else {
+        seg_softmax<1, false, THREADS>(n, rp, col, base + o_as2, base + o_ad2, nbS, base + o_al2, ebS, nullptr);
+        __syncthreads();
+        seg_gather<false, 1, NC, THREADS>(n, rp, col, base + o_h2, nbS, base + o_al2, ebS, pb + L.c2_b, y2g, n0);
+      }
       __syncthreads();
       STAMP();
       // K3
       if (CACHE)
-        seg_mean_fwd<NC, THREADS>(n, em, mrp, mcol, hA, 0, xcur, n0, xnext, n0);
+        seg_mean_fwd<NC, THREADS>(n, em, mrp, mcol, hA, 0, xcur, nbS, xnext, nbS);
       else
-        seg_mean_fwd<NC, THREADS>(n, em, mrp, mcol, y2g, n0, xcur, n0, xnext, n0);
+        seg_mean_fwd<NC, THREADS>(n, em, mrp, mcol, y2g, n0, xcur, nbS, xnext, nbS);
       __syncthreads();
       STAMP();
       xcur = xnext;
@@ -828,7 +921,7 @@ __global__ __launch_bounds__(THREADS) void gatres_fused_kernel(const FusedArgs a
         int r = it * (THREADS / G) + tid / G;
         const bool valid = r < n;
         if (!valid) r = n - 1;
-        const float4 xv = ld4(xcur + ((size_t)n0 + r) * NC + (tid % G) * 4);
+        const float4 xv = ld4(xcur + (unsigned)((nbS + r) * NC + (tid % G) * 4));
         float d = xv.x * wv.x;
         d = fmaf(xv.y, wv.y, d); d = fmaf(xv.z, wv.z, d); d = fmaf(xv.w, wv.w, d);
         for (int off = G >> 1; off > 0; off >>= 1) d += __shfl_xor(d, off);
@@ -882,6 +975,10 @@ __global__ __launch_bounds__(THREADS) void gatres_fused_kernel(const FusedArgs a
     u16* mrp = tp;             tp += even(n + 1);
     u16* mtrp = tp;            tp += even(n + 1);
     u16* mtdst = tp;
+    tp += even(em);
+    constexpr int WL_FLOATS = 2 * NC * (2 * NC + 4) + 4 * NC;
+    constexpr bool WLDS = WL_FLOATS * 4 <= 40960;
+    float* wlB = reinterpret_cast<float*>(lds_raw + ((reinterpret_cast<unsigned char*>(tp) - lds_raw + 15) & ~15));
     __syncthreads();           // forward's LDS contents are dead from here
     copy_rowptr16<THREADS>(rp, a.rowptr, n0, n, e0);
     copy_idx16<THREADS>(col, a.col, e0, eg, n0);
@@ -892,7 +989,8 @@ __global__ __launch_bounds__(THREADS) void gatres_fused_kernel(const FusedArgs a
     copy_rowptr16<THREADS>(mtrp, a.mt_rowptr, n0, n, em0);
     copy_idx16<THREADS>(mtdst, a.mt_dst, em0, em, n0);
 
-    const float* saved = a.saved;
+    const SegLayout& SL = a.SL;
+    const float* segbase = a.saved + (int64_t)seg * SL.total;
     float* gp_cur = sc + L.sc_gpa;       // global copies of g_pre (row-wise residual reads)
     float* gp_nxt = sc + L.sc_gpb;
     float* gh = sc + L.sc_gh;
@@ -909,13 +1007,13 @@ __global__ __launch_bounds__(THREADS) void gatres_fused_kernel(const FusedArgs a
     float* gas2T = CACHE ? gasL : sc + L.sc_gas2;
     float* slab = a.slabs + (int64_t)seg * L.slab_stride;
     const int64_t w = 2LL * NC * NC;
-    const float* xfinal = saved + (int64_t)L.nb * L.s_stride + L.s_xin;
+    const float* xfinal = segbase + (int64_t)L.nb * SL.bstride + SL.xin;
     seg_lin1_bwd<NC, THREADS>(n, n0, a.g_out, xfinal, P + L.p_lin1_w, gp_cur, gpT, slab + L.p_lin1_w,
                               slab + L.p_lin1_b, L.nb > 0 ? 1 : 0, red);
     __syncthreads();
     STAMP();
     for (int b = L.nb - 1; b >= 0; --b) {
-      const float* base = saved + (int64_t)b * L.s_stride;
+      const float* base = segbase + (int64_t)b * SL.bstride;
       const int64_t po = L.p_block0 + (int64_t)b * L.p_block_stride;
       const float* pb = P + po;
       float* sb = slab + po;
@@ -927,44 +1025,44 @@ __global__ __launch_bounds__(THREADS) void gatres_fused_kernel(const FusedArgs a
       __syncthreads();
       STAMP();
       // conv2
-      seg_agg_bwd_dst<1, NC, THREADS>(n, n0, e0, rp, col, gy2T, gy2b, base + L.s_h2, base + L.s_al2, base + L.s_as2,
-                                      base + L.s_ad2, ge2T, ge_b, gad2T, gd_b);
+      seg_agg_bwd_dst<1, NC, THREADS>(n, 0, 0, rp, col, gy2T, gy2b, base + SL.h2, base + SL.al2, base + SL.as2,
+                                      base + SL.ad2, ge2T, ge_b, gad2T, gd_b);
       __syncthreads();
       STAMP();
-      seg_agg_bwd_src<1, NC, THREADS>(n, e0, trp, teid, tdst, gy2T, gy2b, base + L.s_al2, ge2T, ge_b, gad2T, gd_b,
+      seg_agg_bwd_src<1, NC, THREADS>(n, 0, trp, teid, tdst, gy2T, gy2b, base + SL.al2, ge2T, ge_b, gad2T, gd_b,
                                       pb + L.c2_as, pb + L.c2_ad, gh2, n0, gas2T);
       __syncthreads();
       STAMP();
-      seg_conv_param_grads<1, NC, THREADS>(n, n0, base + L.s_h2, gas2T, gad2T, gd_b, gy2T, gy2b, sb + L.c2_as,
+      seg_conv_param_grads<1, NC, THREADS>(n, 0, base + SL.h2, gas2T, gad2T, gd_b, gy2T, gy2b, sb + L.c2_as,
                                            sb + L.c2_ad, sb + L.c2_b, red);
       STAMP();
-      seg_dw<NC, 2 * NC, THREADS>(n, gh2, n0, base + L.s_o1, n0, sb + L.c2_W, red);
+      seg_dw<NC, 2 * NC, THREADS>(n, gh2, n0, base + SL.o1, 0, sb + L.c2_W, red);
       __syncthreads();         // g_y2 (RA) is dead: dx2 overwrites RA with g_out1
       STAMP();
-      seg_proj<NC, 2 * NC, 1, EPI_RESID_MASK, THREADS>(n, gh2, n0, wt2, go1T, go1b, nullptr, 0, nullptr, nullptr,
+      seg_proj<NC, 2 * NC, 1, EPI_RESID_MASK, THREADS, WLDS>(n, gh2, n0, wt2, go1T, go1b, nullptr, 0, nullptr, nullptr,
                                                         nullptr, nullptr, 0, nullptr, nullptr, nullptr, 0,
-                                                        base + L.s_o1, n0);
+                                                        base + SL.o1, 0, wlB);
       __syncthreads();
       STAMP();
       // conv1
-      seg_agg_bwd_dst<2, NC, THREADS>(n, n0, e0, rp, col, go1T, go1b, base + L.s_h1, base + L.s_al1, base + L.s_as1,
-                                      base + L.s_ad1, ge1T, ge_b, gad1T, gd_b);
+      seg_agg_bwd_dst<2, NC, THREADS>(n, 0, 0, rp, col, go1T, go1b, base + SL.h1, base + SL.al1, base + SL.as1,
+                                      base + SL.ad1, ge1T, ge_b, gad1T, gd_b);
       __syncthreads();
       STAMP();
-      seg_agg_bwd_src<2, NC, THREADS>(n, e0, trp, teid, tdst, go1T, go1b, base + L.s_al1, ge1T, ge_b, gad1T, gd_b,
+      seg_agg_bwd_src<2, NC, THREADS>(n, 0, trp, teid, tdst, go1T, go1b, base + SL.al1, ge1T, ge_b, gad1T, gd_b,
                                       pb + L.c1_as, pb + L.c1_ad, gh, n0, gas1T);
       __syncthreads();
       STAMP();
-      seg_conv_param_grads<2, NC, THREADS>(n, n0, base + L.s_h1, gas1T, gad1T, gd_b, go1T, go1b, sb + L.c1_as,
+      seg_conv_param_grads<2, NC, THREADS>(n, 0, base + SL.h1, gas1T, gad1T, gd_b, go1T, go1b, sb + L.c1_as,
                                            sb + L.c1_ad, sb + L.c1_b, red);
       STAMP();
-      seg_dw<2 * NC, NC, THREADS>(n, gh, n0, base + L.s_xin, n0, sb + L.c1_W, red);
+      seg_dw<2 * NC, NC, THREADS>(n, gh, n0, base + SL.xin, 0, sb + L.c1_W, red);
       __syncthreads();         // g_out1 (RA) is dead: dx1 writes the next g_pre into RA's low half
       STAMP();
       // d/d xin = conv1 path + residual, masked by the previous block's ReLU (block 0's input is lin0: no ReLU)
-      seg_proj<2 * NC, NC, 1, EPI_RESID_MASK, THREADS>(n, gh, n0, wt1, gp_nxt, n0, gpT, 0, nullptr, nullptr, nullptr,
+      seg_proj<2 * NC, NC, 1, EPI_RESID_MASK, THREADS, WLDS>(n, gh, n0, wt1, gp_nxt, n0, gpT, 0, nullptr, nullptr, nullptr,
                                                         nullptr, 0, nullptr, nullptr, gp_cur, n0,
-                                                        b > 0 ? base + L.s_xin : nullptr, n0);
+                                                        b > 0 ? base + SL.xin : nullptr, 0, wlB);
       __syncthreads();
       STAMP();
       float* t = gp_cur; gp_cur = gp_nxt; gp_nxt = t;
@@ -1069,7 +1167,7 @@ extern "C" int gatres_fused_supported(const gatres_model_t* m, const gatres_grap
   if (!m || !g || g->num_segments <= 0 || !g->seg_ptr) return 0;
   if (!(m->nc >= 4 && m->nc <= 128 && gatres_is_pow2(m->nc))) return 0;
   if (g->max_segment_nodes > 4096) return 0;      // beyond this a snapshot should be spread over many CUs
-  return nocache_fits(threads_for(m->nc), g->max_segment_nodes, g->max_segment_edges_gat, g->max_segment_edges_mean)
+  return nocache_fits(m->nc, threads_for(m->nc), g->max_segment_nodes, g->max_segment_edges_gat, g->max_segment_edges_mean)
              ? 1 : 0;
 }
 
@@ -1107,6 +1205,7 @@ extern "C" int gatres_fused_run(const gatres_model_t* m, const gatres_graph_t* g
   a.params = params; a.wt = scratch + a.L.sc_wt;
   a.x = x; a.mask = mask; a.y = y; a.out = out; a.g_out = g_out; a.loss_part = loss_part; a.g_x = g_x;
   a.saved = saved; a.scratch = scratch; a.slabs = scratch + a.L.sc_slabs;
+  a.SL = make_seg_layout(a.L.nb, a.L.nc, g->max_segment_nodes, g->max_segment_edges_gat);
   a.stamps = g_stamps; a.stamp_cap = g_stamp_cap;
   a.phases = (phases & (GATRES_PHASE_FORWARD | GATRES_PHASE_BACKWARD)) | ((phases & GATRES_PHASE_LOSS) ? PH_LOSS : 0);
   hipStream_t st = gatres_stream(stream);

@@ -25,8 +25,14 @@ extern "C" int64_t gatres_param_count(int32_t num_blocks, int32_t nc) {
 extern "C" int64_t gatres_saved_floats(const gatres_model_t* m, const gatres_graph_t* g) {
   Layout L;
   if (!g) return GATRES_E_BADARG;
-  return make_layout(m, g->num_nodes, g->num_edges_gat, g->num_segments, &L) ? L.saved_total
-                                                                             : (int64_t)GATRES_E_UNSUPPORTED;
+  if (!make_layout(m, g->num_nodes, g->num_edges_gat, g->num_segments, &L)) return GATRES_E_UNSUPPORTED;
+  int64_t total = L.saved_total;
+  if (gatres_fused_supported(m, g)) {       // the fused kernels keep a segment-major copy instead (gatres_layout.h)
+    const SegLayout S = make_seg_layout(L.nb, L.nc, g->max_segment_nodes, g->max_segment_edges_gat);
+    const int64_t fused_total = (int64_t)g->num_segments * S.total;
+    if (fused_total > total) total = fused_total;
+  }
+  return total;
 }
 
 extern "C" int64_t gatres_scratch_floats(const gatres_model_t* m, const gatres_graph_t* g) {
