@@ -32,3 +32,27 @@ __device__ __forceinline__ float4 f4zero() { return make_float4(0.f, 0.f, 0.f, 0
 __device__ __forceinline__ void gatres_axpy4(float4& acc, float a, const float4 v) {
   acc.x = fmaf(a, v.x, acc.x); acc.y = fmaf(a, v.y, acc.y); acc.z = fmaf(a, v.z, acc.z); acc.w = fmaf(a, v.w, acc.w);
 }
+
+// Sum of `d` over the LH adjacent lanes that own one attention head of a row (LH = C/4, a power of two).
+// DPP row operations (quad_perm xor-1, xor-2, row_half_mirror, row_mirror) are register-to-register VALU modifiers:
+// no LDS round trip, unlike __shfl_xor (ds_bpermute).  Every lane of the group ends with the same value.  Used by
+// the fused and the per-op kernels alike so that both associate the sum identically.
+template <int CTRL>
+__device__ __forceinline__ float gatres_dpp(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
+}
+template <int LH>
+__device__ __forceinline__ float gatres_head_reduce(float d) {
+  if constexpr (LH >= 2) d += gatres_dpp<0xB1>(d);     // quad_perm [1,0,3,2]
+  if constexpr (LH >= 4) d += gatres_dpp<0x4E>(d);     // quad_perm [2,3,0,1]
+  if constexpr (LH >= 8) d += gatres_dpp<0x141>(d);    // row_half_mirror: lane i <-> 7 - i
+  if constexpr (LH >= 16) d += gatres_dpp<0x140>(d);   // row_mirror:      lane i <-> 15 - i
+  if constexpr (LH >= 32) d += __shfl_xor(d, 16);      // beyond one 16-lane DPP row
+  return d;
+}
+__device__ __forceinline__ float gatres_head_dot4(const float4 a, const float4 b) {
+  float d = a.x * b.x;
+  d = fmaf(a.y, b.y, d);
+  d = fmaf(a.z, b.z, d);
+  return fmaf(a.w, b.w, d);
+}

@@ -98,12 +98,15 @@ __global__ __launch_bounds__(256) void gat_aggregate_fwd_kernel(
 //   g_a_dst[i] = sum_e g_e
 // ------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ float head_dot(const float4 a, const float4 b, int lanes_per_head) {
-  float d = a.x * b.x;
-  d = fmaf(a.y, b.y, d);
-  d = fmaf(a.z, b.z, d);
-  d = fmaf(a.w, b.w, d);
-  for (int off = lanes_per_head >> 1; off > 0; off >>= 1) d += __shfl_xor(d, off);
-  return d;
+  const float d = gatres_head_dot4(a, b);
+  switch (lanes_per_head) {                      // wave-uniform
+    case 1: return d;
+    case 2: return gatres_head_reduce<2>(d);
+    case 4: return gatres_head_reduce<4>(d);
+    case 8: return gatres_head_reduce<8>(d);
+    case 16: return gatres_head_reduce<16>(d);
+    default: return gatres_head_reduce<32>(d);
+  }
 }
 
 __global__ __launch_bounds__(256) void gat_aggregate_bwd_dst_kernel(

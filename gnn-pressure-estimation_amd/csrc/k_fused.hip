@@ -354,6 +354,63 @@ __device__ __forceinline__ void seg_dw(int n, const float* G, int gb, const floa
   }
 }
 
+// dW partial, block form (HC, K in {16, 32, 64}): ONE wave computes the whole [HC, K] gradient block for a range
+// of rows, with the permuted output map of k_proj.hip's dw_kernel (c = VC*i + tc, k = VK*j + tk) so both MFMA
+// operands come from per-lane VECTOR loads (float4 / float2) of contiguous features instead of 4-byte column
+// slices; R row ranges run on R waves, their partial blocks meet in LDS (`part`, R*HC*K floats: the backward's idle
+// g_pre|g_y2 / g_out1 region) and are summed in range order -> the segment's slab.  Deterministic.
+template <int HC, int K, int THREADS>
+__device__ __forceinline__ void seg_dw_blk(int n, int R, const float* G, int gb, const float* X, int xb,
+                                           float* __restrict__ slab, float* part) {
+  constexpr int VC = HC / 16, VK = K / 16, STEPS = 4;              // 4 steps (16 rows) of loads in flight
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int i = lane & 15, q = lane >> 4;
+  if (wave < R) {                                                   // wave-uniform
+    const int chunk = (((n + R - 1) / R) + 3) & ~3;
+    const int rbeg = wave * chunk, rend = min(n, rbeg + chunk);
+    f32x4 acc[VC][VK];
+#pragma unroll
+    for (int a = 0; a < VC; ++a)
+#pragma unroll
+      for (int b = 0; b < VK; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int nb = rbeg; nb < rend; nb += 4 * STEPS) {
+      float av[STEPS][VC], bv[STEPS][VK];
+#pragma unroll
+      for (int st = 0; st < STEPS; ++st) {
+        const int r = nb + 4 * st + q;
+        const bool ok = r < rend;
+        const int rr = ok ? r : rbeg;
+        load_frag<VC>(G + (unsigned)((gb + rr) * HC + VC * i), av[st]);
+        load_frag<VK>(X + (unsigned)((xb + rr) * K + VK * i), bv[st]);
+        if (!ok) {
+#pragma unroll
+          for (int a = 0; a < VC; ++a) av[st][a] = 0.f;
+        }
+      }
+#pragma unroll
+      for (int st = 0; st < STEPS; ++st)
+#pragma unroll
+        for (int a = 0; a < VC; ++a)
+#pragma unroll
+          for (int b = 0; b < VK; ++b)
+            acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[st][a], bv[st][b], acc[a][b], 0, 0, 0);
+    }
+    float* mine = part + wave * (HC * K);
+#pragma unroll
+    for (int a = 0; a < VC; ++a)
+#pragma unroll
+      for (int b = 0; b < VK; ++b)
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) mine[(VC * (4 * q + rr) + a) * K + VK * i + b] = acc[a][b][rr];
+  }
+  __syncthreads();
+  for (int idx = threadIdx.x; idx < HC * K; idx += THREADS) {
+    float sum = 0.f;
+    for (int w = 0; w < R; ++w) sum += part[w * (HC * K) + idx];
+    slab[idx] = sum;
+  }
+}
+
 // ------------------------------------------------------------------------------------------ sparse stages
 // Conventions.  Row r of the segment; tables are addressed as  base + (tb + local_index) * width  with tb = 0 for an
 // LDS copy and tb = n0 for the global array; rp/col/...: LDS, 16-bit local indices.
@@ -545,15 +602,6 @@ __device__ __forceinline__ void seg_mean_bwd(int n, int em, const u16* mrp, cons
   }
 }
 
-__device__ __forceinline__ float head_dot(const float4 a, const float4 b, int lanes_per_head) {
-  float d = a.x * b.x;
-  d = fmaf(a.y, b.y, d);
-  d = fmaf(a.z, b.z, d);
-  d = fmaf(a.w, b.w, d);
-  for (int off = lanes_per_head >> 1; off > 0; off >>= 1) d += __shfl_xor(d, off);
-  return d;
-}
-
 // K2 backward, destination-major.  g_out: [gb + r]; h / a_src / a_dst: global saved arrays (base n0);
 // alpha: global (base e0); g_e / g_a_dst: [eb2 + e], [db + r] (LDS or global scratch).
 template <int H, int C, int THREADS>
@@ -592,7 +640,7 @@ __device__ __forceinline__ void seg_agg_bwd_dst(int n, int n0, int e0, const u16
       for (int k = 0; k < MAXD; ++k)
         if (k < dmax) {
           al[k] = k < deg ? al[k] : 0.f;                                 // padding slots weigh nothing
-          ga[k] = head_dot(go, hv[k], LH);
+          ga[k] = gatres_head_reduce<LH>(gatres_head_dot4(go, hv[k]));
           S = fmaf(al[k], ga[k], S);
         }
 #pragma unroll
@@ -606,12 +654,12 @@ __device__ __forceinline__ void seg_agg_bwd_dst(int n, int n0, int e0, const u16
     } else {
       const int end = beg + deg;
       for (int e = beg; e < end; ++e) {
-        const float ga = head_dot(go, ld4(h + (unsigned)((n0 + col[e]) * HC + c0)), LH);
+        const float ga = gatres_head_reduce<LH>(gatres_head_dot4(go, ld4(h + (unsigned)((n0 + col[e]) * HC + c0))));
         S = fmaf(alpha[(unsigned)((e0 + e) * H + hd)], ga, S);
       }
       for (int e = beg; e < end; ++e) {
         const int jj = col[e];
-        const float ga = head_dot(go, ld4(h + (unsigned)((n0 + jj) * HC + c0)), LH);
+        const float ga = gatres_head_reduce<LH>(gatres_head_dot4(go, ld4(h + (unsigned)((n0 + jj) * HC + c0))));
         const float gs = alpha[(unsigned)((e0 + e) * H + hd)] * (ga - S);
         const float rw = a_src[(unsigned)((n0 + jj) * H + hd)] + adst;
         const float ge = rw > 0.f ? gs : gs * GATRES_NEG_SLOPE;
@@ -1036,7 +1084,13 @@ __global__ __launch_bounds__(THREADS) void gatres_fused_kernel(const FusedArgs a
       seg_conv_param_grads<1, NC, THREADS>(n, 0, base + SL.h2, gas2T, gad2T, gd_b, gy2T, gy2b, sb + L.c2_as,
                                            sb + L.c2_ad, sb + L.c2_b, red);
       STAMP();
-      seg_dw<NC, 2 * NC, THREADS>(n, gh2, n0, base + SL.o1, 0, sb + L.c2_W, red);
+      if constexpr (CACHE && NC >= 16 && NC <= 32) {             // block form: partials through the idle RA region
+        const int R = min(8, (n * 2 * NC) / (2 * NC * NC));
+        if (R >= 1) seg_dw_blk<NC, 2 * NC, THREADS>(n, R, gh2, n0, base + SL.o1, 0, sb + L.c2_W, RA);
+        else        seg_dw<NC, 2 * NC, THREADS>(n, gh2, n0, base + SL.o1, 0, sb + L.c2_W, red);
+      } else {
+        seg_dw<NC, 2 * NC, THREADS>(n, gh2, n0, base + SL.o1, 0, sb + L.c2_W, red);
+      }
       __syncthreads();         // g_y2 (RA) is dead: dx2 overwrites RA with g_out1
       STAMP();
       seg_proj<NC, 2 * NC, 1, EPI_RESID_MASK, THREADS, WLDS>(n, gh2, n0, wt2, go1T, go1b, nullptr, 0, nullptr, nullptr,
@@ -1056,7 +1110,13 @@ __global__ __launch_bounds__(THREADS) void gatres_fused_kernel(const FusedArgs a
       seg_conv_param_grads<2, NC, THREADS>(n, 0, base + SL.h1, gas1T, gad1T, gd_b, go1T, go1b, sb + L.c1_as,
                                            sb + L.c1_ad, sb + L.c1_b, red);
       STAMP();
-      seg_dw<2 * NC, NC, THREADS>(n, gh, n0, base + SL.xin, 0, sb + L.c1_W, red);
+      if constexpr (CACHE && NC >= 16 && NC <= 32) {
+        const int R = min(8, (n * 2 * NC) / (2 * NC * NC));
+        if (R >= 1) seg_dw_blk<2 * NC, NC, THREADS>(n, R, gh, n0, base + SL.xin, 0, sb + L.c1_W, RA);
+        else        seg_dw<2 * NC, NC, THREADS>(n, gh, n0, base + SL.xin, 0, sb + L.c1_W, red);
+      } else {
+        seg_dw<2 * NC, NC, THREADS>(n, gh, n0, base + SL.xin, 0, sb + L.c1_W, red);
+      }
       __syncthreads();         // g_out1 (RA) is dead: dx1 writes the next g_pre into RA's low half
       STAMP();
       // d/d xin = conv1 path + residual, masked by the previous block's ReLU (block 0's input is lin0: no ReLU)
