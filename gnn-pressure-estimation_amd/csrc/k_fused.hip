@@ -31,7 +31,8 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned short u16;
 
 constexpr int LDS_BYTES = 163840;   // the whole CU LDS; one workgroup per CU
-constexpr int MAXD = 8;             // neighbour loads issued together per row (rows with more edges take a loop)
+constexpr int MAXD = 6;             // neighbour loads issued together per row (rows with more edges take a loop);
+                                    // C-Town's largest in-degree is 5 (+1 self loop)
 
 struct FusedArgs {
   const int* seg_ptr;
@@ -427,6 +428,14 @@ __device__ __forceinline__ int wave_max_deg(int deg) {
   return d;
 }
 
+template <int U>
+__device__ __forceinline__ int max_of(const int (&d)[U]) {
+  int m = d[0];
+#pragma unroll
+  for (int u = 1; u < U; ++u) m = max(m, d[u]);
+  return m;
+}
+
 // K2 forward, sub-stage A: attention coefficients.  ONE thread per (row, head): no cross-lane traffic, one exp and
 // one divide per edge.  alpha goes to HBM (saved for the backward pass) and, when ALDS, to an LDS table for sub-stage B.
 template <int H, bool ALDS, int THREADS>
@@ -479,7 +488,9 @@ __device__ __forceinline__ void seg_softmax(int n, const u16* rp, const u16* col
 
 // K2 forward, sub-stage B: out[r] = sum_e alpha_e * h[src(e)] + bias (+ReLU).  HC/4 lanes per row; the per-row chain is
 // rowptr -> col -> {alpha, h rows} -> fma.  alpha: [ab2 + e] (LDS table with ab2 = 0, or the global array with ab2 = eb).
-template <bool RELU, int H, int C, int THREADS>
+// TWO rows per lane group per trip (UR): one workgroup has no spare parallelism to hide the dependent LDS/L2 hops,
+// so the two rows' loads are issued together and their chains overlap.
+template <bool RELU, int H, int C, int THREADS, int UR = 2>
 __device__ __forceinline__ void seg_gather(int n, const u16* rp, const u16* col, const float* hsrc, int hb,
                                            const float* alpha, int ab2, const float* __restrict__ bias, float* out,
                                            int ob) {
@@ -487,192 +498,287 @@ __device__ __forceinline__ void seg_gather(int n, const u16* rp, const u16* col,
   const int c0 = (threadIdx.x % G) * 4;
   const int hd = c0 / C;
   const float4 b = ld4(bias + c0);
-  const int rounds = (n + RPP - 1) / RPP;
+  const int rounds = (n + RPP * UR - 1) / (RPP * UR);
   for (int it = 0; it < rounds; ++it) {
-    int r = it * RPP + threadIdx.x / G;
-    const bool valid = r < n;
-    if (!valid) r = n - 1;
-    const int beg = rp[r], deg = (int)rp[r + 1] - beg;
-    const int dmax = wave_max_deg(deg);
-    float4 acc = f4zero();
-    if (deg <= MAXD) {
-      float4 v[MAXD];
-      float al[MAXD];
+    int r[UR], beg[UR], deg[UR];
+    bool valid[UR];
+#pragma unroll
+    for (int u = 0; u < UR; ++u) {
+      r[u] = (it * UR + u) * RPP + threadIdx.x / G;
+      valid[u] = r[u] < n;
+      if (!valid[u]) r[u] = n - 1;
+    }
+#pragma unroll
+    for (int u = 0; u < UR; ++u) { beg[u] = rp[r[u]]; deg[u] = (int)rp[r[u] + 1] - beg[u]; }
+    const int dmax = wave_max_deg(max_of<UR>(deg));
+    float4 acc[UR];
+#pragma unroll
+    for (int u = 0; u < UR; ++u) acc[u] = f4zero();
+    if (max_of<UR>(deg) <= MAXD) {
+      float4 v[UR][MAXD];
+      float al[UR][MAXD];
 #pragma unroll
       for (int k = 0; k < MAXD; ++k)
         if (k < dmax) {
-          const int e = beg + min(k, deg - 1);
-          v[k] = ld4(hsrc + (unsigned)((hb + (int)col[e]) * HC + c0));
-          al[k] = alpha[(unsigned)((ab2 + e) * H + hd)];
+#pragma unroll
+          for (int u = 0; u < UR; ++u) {
+            const int e = beg[u] + min(k, deg[u] - 1);
+            v[u][k] = ld4(hsrc + (unsigned)((hb + (int)col[e]) * HC + c0));
+            al[u][k] = alpha[(unsigned)((ab2 + e) * H + hd)];
+          }
         }
 #pragma unroll
       for (int k = 0; k < MAXD; ++k)
-        if (k < dmax) gatres_axpy4(acc, k < deg ? al[k] : 0.f, v[k]);     // weight 0 on padding slots
+        if (k < dmax) {
+#pragma unroll
+          for (int u = 0; u < UR; ++u) gatres_axpy4(acc[u], k < deg[u] ? al[u][k] : 0.f, v[u][k]);   // 0 on padding
+        }
     } else {
-      for (int e = beg; e < beg + deg; ++e)
-        gatres_axpy4(acc, alpha[(unsigned)((ab2 + e) * H + hd)], ld4(hsrc + (unsigned)((hb + (int)col[e]) * HC + c0)));
+#pragma unroll
+      for (int u = 0; u < UR; ++u)
+        for (int e = beg[u]; e < beg[u] + deg[u]; ++e)
+          gatres_axpy4(acc[u], alpha[(unsigned)((ab2 + e) * H + hd)],
+                       ld4(hsrc + (unsigned)((hb + (int)col[e]) * HC + c0)));
     }
-    add4(acc, b);
-    if (RELU) {
-      acc.x = fmaxf(acc.x, 0.f); acc.y = fmaxf(acc.y, 0.f); acc.z = fmaxf(acc.z, 0.f); acc.w = fmaxf(acc.w, 0.f);
+#pragma unroll
+    for (int u = 0; u < UR; ++u) {
+      add4(acc[u], b);
+      if (RELU) {
+        acc[u].x = fmaxf(acc[u].x, 0.f); acc[u].y = fmaxf(acc[u].y, 0.f);
+        acc[u].z = fmaxf(acc[u].z, 0.f); acc[u].w = fmaxf(acc[u].w, 0.f);
+      }
+      if (valid[u]) st4(out + (unsigned)((ob + r[u]) * HC + c0), acc[u]);
     }
-    if (valid) st4(out + (unsigned)((ob + r) * HC + c0), acc);
   }
 }
 
-// K3 forward: out = relu(mean_{j->r} y[j] + x0[r])
-template <int C, int THREADS>
+// K3 forward: out = relu(mean_{j->r} y[j] + x0[r]).  UR rows per lane group per trip.
+template <int C, int THREADS, int UR = 2>
 __device__ __forceinline__ void seg_mean_fwd(int n, int em, const u16* mrp, const u16* mcol, const float* y, int yb,
                                              const float* x0, int xb, float* out, int ob) {
   constexpr int G = C / 4, RPP = THREADS / G;
   const int c0 = (threadIdx.x % G) * 4;
-  const int rounds = (n + RPP - 1) / RPP;
+  const int rounds = (n + RPP * UR - 1) / (RPP * UR);
   const int elast = max(em - 1, 0);
   for (int it = 0; it < rounds; ++it) {
-    int r = it * RPP + threadIdx.x / G;
-    const bool valid = r < n;
-    if (!valid) r = n - 1;
-    const int beg = mrp[r], deg = (int)mrp[r + 1] - beg;
-    const int dmax = wave_max_deg(deg);
-    const float4 rr = ld4(x0 + (unsigned)((xb + r) * C + c0));
-    float4 acc = f4zero();
-    if (deg <= MAXD) {
-      float4 v[MAXD];
+    int r[UR], beg[UR], deg[UR];
+    bool valid[UR];
+    float4 rr[UR], acc[UR];
+#pragma unroll
+    for (int u = 0; u < UR; ++u) {
+      r[u] = (it * UR + u) * RPP + threadIdx.x / G;
+      valid[u] = r[u] < n;
+      if (!valid[u]) r[u] = n - 1;
+      acc[u] = f4zero();
+    }
+#pragma unroll
+    for (int u = 0; u < UR; ++u) {
+      beg[u] = mrp[r[u]]; deg[u] = (int)mrp[r[u] + 1] - beg[u];
+      rr[u] = ld4(x0 + (unsigned)((xb + r[u]) * C + c0));
+    }
+    const int dmax = wave_max_deg(max_of<UR>(deg));
+    if (max_of<UR>(deg) <= MAXD) {
+      float4 v[UR][MAXD];
 #pragma unroll
       for (int k = 0; k < MAXD; ++k)
         if (k < dmax) {
-          const int jj = k < deg ? (int)mcol[min(beg + k, elast)] : r;
-          v[k] = ld4(y + (unsigned)((yb + jj) * C + c0));
+#pragma unroll
+          for (int u = 0; u < UR; ++u) {
+            const int jj = k < deg[u] ? (int)mcol[min(beg[u] + k, elast)] : r[u];
+            v[u][k] = ld4(y + (unsigned)((yb + jj) * C + c0));
+          }
         }
 #pragma unroll
       for (int k = 0; k < MAXD; ++k)
-        if (k < dmax) gatres_axpy4(acc, k < deg ? 1.f : 0.f, v[k]);      // fma(1, v, acc) == acc + v exactly
+        if (k < dmax) {
+#pragma unroll
+          for (int u = 0; u < UR; ++u) gatres_axpy4(acc[u], k < deg[u] ? 1.f : 0.f, v[u][k]);   // fma(1,v,acc) = acc+v
+        }
     } else {
-      for (int e = beg; e < beg + deg; ++e) add4(acc, ld4(y + (unsigned)((yb + mcol[e]) * C + c0)));
+#pragma unroll
+      for (int u = 0; u < UR; ++u)
+        for (int e = beg[u]; e < beg[u] + deg[u]; ++e) add4(acc[u], ld4(y + (unsigned)((yb + mcol[e]) * C + c0)));
     }
-    const float cnt = (float)max(deg, 1);
-    float4 o;
-    o.x = fmaxf(acc.x / cnt + rr.x, 0.f); o.y = fmaxf(acc.y / cnt + rr.y, 0.f);
-    o.z = fmaxf(acc.z / cnt + rr.z, 0.f); o.w = fmaxf(acc.w / cnt + rr.w, 0.f);
-    if (valid) st4(out + (unsigned)((ob + r) * C + c0), o);
+#pragma unroll
+    for (int u = 0; u < UR; ++u) {
+      const float cnt = (float)max(deg[u], 1);
+      float4 o;
+      o.x = fmaxf(acc[u].x / cnt + rr[u].x, 0.f); o.y = fmaxf(acc[u].y / cnt + rr[u].y, 0.f);
+      o.z = fmaxf(acc[u].z / cnt + rr[u].z, 0.f); o.w = fmaxf(acc[u].w / cnt + rr[u].w, 0.f);
+      if (valid[u]) st4(out + (unsigned)((ob + r[u]) * C + c0), o);
+    }
   }
 }
 
 // K3 backward: g_y[r] = sum over out-edges (r -> i) of g_pre[i] / max(indeg(i), 1)
-template <int C, int THREADS>
+template <int C, int THREADS, int UR = 1>
 __device__ __forceinline__ void seg_mean_bwd(int n, int em, const u16* mrp, const u16* mtrp, const u16* mtdst,
                                              const float* g_pre, int pb, float* g_y, int yb) {
   constexpr int G = C / 4, RPP = THREADS / G;
   const int c0 = (threadIdx.x % G) * 4;
-  const int rounds = (n + RPP - 1) / RPP;
+  const int rounds = (n + RPP * UR - 1) / (RPP * UR);
   const int elast = max(em - 1, 0);
   for (int it = 0; it < rounds; ++it) {
-    int r = it * RPP + threadIdx.x / G;
-    const bool valid = r < n;
-    if (!valid) r = n - 1;
-    const int beg = mtrp[r], deg = (int)mtrp[r + 1] - beg;
-    const int dmax = wave_max_deg(deg);
-    float4 acc = f4zero();
-    if (deg <= MAXD) {
-      float4 v[MAXD];
-      float cnt[MAXD];
+    int r[UR], beg[UR], deg[UR];
+    bool valid[UR];
+    float4 acc[UR];
+#pragma unroll
+    for (int u = 0; u < UR; ++u) {
+      r[u] = (it * UR + u) * RPP + threadIdx.x / G;
+      valid[u] = r[u] < n;
+      if (!valid[u]) r[u] = n - 1;
+      acc[u] = f4zero();
+    }
+#pragma unroll
+    for (int u = 0; u < UR; ++u) { beg[u] = mtrp[r[u]]; deg[u] = (int)mtrp[r[u] + 1] - beg[u]; }
+    const int dmax = wave_max_deg(max_of<UR>(deg));
+    if (max_of<UR>(deg) <= MAXD) {
+      float4 v[UR][MAXD];
+      float cnt[UR][MAXD];
 #pragma unroll
       for (int k = 0; k < MAXD; ++k)
         if (k < dmax) {
-          const int ii = k < deg ? (int)mtdst[min(beg + k, elast)] : r;
-          cnt[k] = (float)max((int)mrp[ii + 1] - (int)mrp[ii], 1);
-          v[k] = ld4(g_pre + (unsigned)((pb + ii) * C + c0));
+#pragma unroll
+          for (int u = 0; u < UR; ++u) {
+            const int ii = k < deg[u] ? (int)mtdst[min(beg[u] + k, elast)] : r[u];
+            cnt[u][k] = (float)max((int)mrp[ii + 1] - (int)mrp[ii], 1);
+            v[u][k] = ld4(g_pre + (unsigned)((pb + ii) * C + c0));
+          }
         }
 #pragma unroll
       for (int k = 0; k < MAXD; ++k)
         if (k < dmax) {
-          const float w = k < deg ? 1.f : 0.f;                           // x + 0 * q == x exactly
-          acc.x = fmaf(w, v[k].x / cnt[k], acc.x); acc.y = fmaf(w, v[k].y / cnt[k], acc.y);
-          acc.z = fmaf(w, v[k].z / cnt[k], acc.z); acc.w = fmaf(w, v[k].w / cnt[k], acc.w);
+#pragma unroll
+          for (int u = 0; u < UR; ++u) {
+            const float w = k < deg[u] ? 1.f : 0.f;                      // x + 0 * q == x exactly
+            acc[u].x = fmaf(w, v[u][k].x / cnt[u][k], acc[u].x); acc[u].y = fmaf(w, v[u][k].y / cnt[u][k], acc[u].y);
+            acc[u].z = fmaf(w, v[u][k].z / cnt[u][k], acc[u].z); acc[u].w = fmaf(w, v[u][k].w / cnt[u][k], acc[u].w);
+          }
         }
     } else {
-      for (int t = beg; t < beg + deg; ++t) {
-        const int ii = mtdst[t];
-        const float cnt = (float)max((int)mrp[ii + 1] - (int)mrp[ii], 1);
-        const float4 v = ld4(g_pre + (unsigned)((pb + ii) * C + c0));
-        acc.x = acc.x + v.x / cnt; acc.y = acc.y + v.y / cnt; acc.z = acc.z + v.z / cnt; acc.w = acc.w + v.w / cnt;
-      }
+#pragma unroll
+      for (int u = 0; u < UR; ++u)
+        for (int t = beg[u]; t < beg[u] + deg[u]; ++t) {
+          const int ii = mtdst[t];
+          const float cnt = (float)max((int)mrp[ii + 1] - (int)mrp[ii], 1);
+          const float4 v = ld4(g_pre + (unsigned)((pb + ii) * C + c0));
+          acc[u].x = acc[u].x + v.x / cnt; acc[u].y = acc[u].y + v.y / cnt;
+          acc[u].z = acc[u].z + v.z / cnt; acc[u].w = acc[u].w + v.w / cnt;
+        }
     }
-    if (valid) st4(g_y + (unsigned)((yb + r) * C + c0), acc);
+#pragma unroll
+    for (int u = 0; u < UR; ++u)
+      if (valid[u]) st4(g_y + (unsigned)((yb + r[u]) * C + c0), acc[u]);
   }
 }
 
-// K2 backward, destination-major.  g_out: [gb + r]; h / a_src / a_dst: global saved arrays (base n0);
-// alpha: global (base e0); g_e / g_a_dst: [eb2 + e], [db + r] (LDS or global scratch).
-template <int H, int C, int THREADS>
-__device__ __forceinline__ void seg_agg_bwd_dst(int n, int n0, int e0, const u16* rp, const u16* col,
-                                                const float* g_out, int gb, const float* __restrict__ h,
-                                                const float* __restrict__ alpha, const float* __restrict__ a_src,
-                                                const float* __restrict__ a_dst, float* g_e, int eb2,
-                                                float* g_a_dst, int db) {
+// K2 backward, destination-major, in two sub-stages (same arithmetic and order as the per-op kernel):
+//   A  seg_edge_dots   : ga_e = <g_out[i,h,:], h[j,h,:]> for every in-edge, HC/4 lanes per row, UR rows per trip,
+//                        head sum by DPP row operations; ga goes to the g_e table ([eb2 + e], LDS or scratch).
+//   B  seg_softmax_bwd : ONE thread per (row, head): S = sum alpha*ga ; g_e = alpha*(ga - S) * LeakyReLU' ;
+//                        g_a_dst = sum g_e.  Overwrites ga with g_e in place.
+template <int H, int C, int THREADS, int UR>
+__device__ __forceinline__ void seg_edge_dots(int n, int n0, const u16* rp, const u16* col, const float* g_out, int gb,
+                                              const float* __restrict__ h, float* g_e, int eb2) {
   constexpr int HC = H * C, G = HC / 4, LH = C / 4, RPP = THREADS / G;
   const int c0 = (threadIdx.x % G) * 4;
   const int hd = c0 / C;
-  const int rounds = (n + RPP - 1) / RPP;
+  const int rounds = (n + RPP * UR - 1) / (RPP * UR);
   for (int it = 0; it < rounds; ++it) {
-    int r = it * RPP + threadIdx.x / G;
-    const bool valid = r < n;              // every lane stays in the loop: head_dot shuffles across the head's lanes
-    if (!valid) r = n - 1;
-    const bool leader = valid && (c0 % C) == 0;
-    const int beg = rp[r], deg = (int)rp[r + 1] - beg;
-    const int dmax = wave_max_deg(deg);
-    const float4 go = ld4(g_out + (unsigned)((gb + r) * HC + c0));
-    const float adst = a_dst[(unsigned)((n0 + r) * H + hd)];
-    float S = 0.f, gad = 0.f;
-    if (deg <= MAXD) {
-      float al[MAXD], raw[MAXD], ga[MAXD];
-      float4 hv[MAXD];
+    int r[UR], beg[UR], deg[UR];
+    bool leader[UR];
+    float4 go[UR];
+#pragma unroll
+    for (int u = 0; u < UR; ++u) {
+      r[u] = (it * UR + u) * RPP + threadIdx.x / G;
+      const bool valid = r[u] < n;         // every lane stays in the loop: the head reduction spans the head's lanes
+      if (!valid) r[u] = n - 1;
+      leader[u] = valid && (c0 % C) == 0;
+    }
+#pragma unroll
+    for (int u = 0; u < UR; ++u) {
+      beg[u] = rp[r[u]]; deg[u] = (int)rp[r[u] + 1] - beg[u];
+      go[u] = ld4(g_out + (unsigned)((gb + r[u]) * HC + c0));
+    }
+    const int dmax = wave_max_deg(max_of<UR>(deg));
+    if (max_of<UR>(deg) <= MAXD) {
+      float4 hv[UR][MAXD];
 #pragma unroll
       for (int k = 0; k < MAXD; ++k)
         if (k < dmax) {
-          const int kk = min(k, deg - 1);
-          const int jj = col[beg + kk];
-          hv[k] = ld4(h + (unsigned)((n0 + jj) * HC + c0));
-          al[k] = alpha[(unsigned)((e0 + beg + kk) * H + hd)];
-          raw[k] = a_src[(unsigned)((n0 + jj) * H + hd)] + adst;
+#pragma unroll
+          for (int u = 0; u < UR; ++u)
+            hv[u][k] = ld4(h + (unsigned)((n0 + (int)col[beg[u] + min(k, deg[u] - 1)]) * HC + c0));
         }
 #pragma unroll
       for (int k = 0; k < MAXD; ++k)
         if (k < dmax) {
-          al[k] = k < deg ? al[k] : 0.f;                                 // padding slots weigh nothing
-          ga[k] = gatres_head_reduce<LH>(gatres_head_dot4(go, hv[k]));
-          S = fmaf(al[k], ga[k], S);
-        }
 #pragma unroll
-      for (int k = 0; k < MAXD; ++k)
-        if (k < dmax) {
-          const float gs = al[k] * (ga[k] - S);
-          const float ge = raw[k] > 0.f ? gs : gs * GATRES_NEG_SLOPE;
-          if (leader && k < deg) g_e[(unsigned)((eb2 + beg + k) * H + hd)] = ge;
-          gad = gad + ge;                                                // ge == 0 on padding slots
+          for (int u = 0; u < UR; ++u) {
+            const float ga = gatres_head_reduce<LH>(gatres_head_dot4(go[u], hv[u][k]));
+            if (leader[u] && k < deg[u]) g_e[(unsigned)((eb2 + beg[u] + k) * H + hd)] = ga;
+          }
         }
     } else {
-      const int end = beg + deg;
-      for (int e = beg; e < end; ++e) {
-        const float ga = gatres_head_reduce<LH>(gatres_head_dot4(go, ld4(h + (unsigned)((n0 + col[e]) * HC + c0))));
-        S = fmaf(alpha[(unsigned)((e0 + e) * H + hd)], ga, S);
-      }
-      for (int e = beg; e < end; ++e) {
-        const int jj = col[e];
-        const float ga = gatres_head_reduce<LH>(gatres_head_dot4(go, ld4(h + (unsigned)((n0 + jj) * HC + c0))));
-        const float gs = alpha[(unsigned)((e0 + e) * H + hd)] * (ga - S);
-        const float rw = a_src[(unsigned)((n0 + jj) * H + hd)] + adst;
-        const float ge = rw > 0.f ? gs : gs * GATRES_NEG_SLOPE;
-        if (leader) g_e[(unsigned)((eb2 + e) * H + hd)] = ge;
-        gad = gad + ge;
-      }
+#pragma unroll
+      for (int u = 0; u < UR; ++u)
+        for (int e = beg[u]; e < beg[u] + deg[u]; ++e) {
+          const float ga = gatres_head_reduce<LH>(gatres_head_dot4(go[u], ld4(h + (unsigned)((n0 + col[e]) * HC + c0))));
+          if (leader[u]) g_e[(unsigned)((eb2 + e) * H + hd)] = ga;
+        }
     }
-    if (leader) g_a_dst[(unsigned)((db + r) * H + hd)] = gad;
   }
 }
 
-// K2 backward, source-major over CSR^T.
-template <int H, int C, int THREADS>
+template <int H, int THREADS>
+__device__ __forceinline__ void seg_softmax_bwd(int n, int n0, int e0, const u16* rp, const u16* col,
+                                                const float* __restrict__ alpha, const float* __restrict__ a_src,
+                                                const float* __restrict__ a_dst, float* g_e, int eb2,
+                                                float* g_a_dst, int db) {
+  for (int idx = threadIdx.x; idx < n * H; idx += THREADS) {
+    const int r = idx / H, hd = idx % H;
+    const int beg = rp[r], deg = (int)rp[r + 1] - beg;
+    const float adst = a_dst[(unsigned)((n0 + r) * H + hd)];
+    float S = 0.f, gad = 0.f;
+    if (deg <= MAXD) {
+      float al[MAXD], ga[MAXD], raw[MAXD];
+#pragma unroll
+      for (int k = 0; k < MAXD; ++k) {
+        const int kk = min(k, deg - 1);
+        al[k] = alpha[(unsigned)((e0 + beg + kk) * H + hd)];
+        ga[k] = g_e[(unsigned)((eb2 + beg + kk) * H + hd)];
+        raw[k] = a_src[(unsigned)((n0 + (int)col[beg + kk]) * H + hd)] + adst;
+      }
+#pragma unroll
+      for (int k = 0; k < MAXD; ++k) {
+        al[k] = k < deg ? al[k] : 0.f;                                   // padding slots weigh nothing
+        S = fmaf(al[k], ga[k], S);
+      }
+#pragma unroll
+      for (int k = 0; k < MAXD; ++k) {
+        const float gs = al[k] * (ga[k] - S);
+        const float ge = raw[k] > 0.f ? gs : gs * GATRES_NEG_SLOPE;
+        if (k < deg) g_e[(unsigned)((eb2 + beg + k) * H + hd)] = ge;
+        gad = gad + ge;                                                  // ge == 0 on padding slots
+      }
+    } else {
+      const int end = beg + deg;
+      for (int e = beg; e < end; ++e)
+        S = fmaf(alpha[(unsigned)((e0 + e) * H + hd)], g_e[(unsigned)((eb2 + e) * H + hd)], S);
+      for (int e = beg; e < end; ++e) {
+        const float gs = alpha[(unsigned)((e0 + e) * H + hd)] * (g_e[(unsigned)((eb2 + e) * H + hd)] - S);
+        const float rw = a_src[(unsigned)((n0 + (int)col[e]) * H + hd)] + adst;
+        const float ge = rw > 0.f ? gs : gs * GATRES_NEG_SLOPE;
+        g_e[(unsigned)((eb2 + e) * H + hd)] = ge;
+        gad = gad + ge;
+      }
+    }
+    g_a_dst[(unsigned)((db + r) * H + hd)] = gad;
+  }
+}
+
+// K2 backward, source-major over CSR^T.  UR rows per lane group per trip.
+template <int H, int C, int THREADS, int UR = 1>
 __device__ __forceinline__ void seg_agg_bwd_src(int n, int e0, const u16* trp, const u16* teid, const u16* tdst,
                                                 const float* g_out, int gb, const float* __restrict__ alpha,
                                                 const float* g_e, int eb2, const float* g_a_dst, int db,
@@ -683,47 +789,66 @@ __device__ __forceinline__ void seg_agg_bwd_src(int n, int e0, const u16* trp, c
   const int c0 = (threadIdx.x % G) * 4;
   const int hd = c0 / C;
   const float4 as = ld4(att_src + c0), ad = ld4(att_dst + c0);
-  const int rounds = (n + RPP - 1) / RPP;
+  const int rounds = (n + RPP * UR - 1) / (RPP * UR);
   for (int it = 0; it < rounds; ++it) {
-    int r = it * RPP + threadIdx.x / G;
-    const bool valid = r < n;
-    if (!valid) r = n - 1;
-    const bool leader = valid && (c0 % C) == 0;
-    const int beg = trp[r], deg = (int)trp[r + 1] - beg;   // deg >= 1 (self loop)
-    const int dmax = wave_max_deg(deg);
-    float4 acc = f4zero();
-    float gas = 0.f;
-    if (deg <= MAXD) {
-      float al[MAXD], ge[MAXD];
-      float4 v[MAXD];
+    int r[UR], beg[UR], deg[UR];
+    bool valid[UR];
+    float4 acc[UR];
+    float gas[UR];
+#pragma unroll
+    for (int u = 0; u < UR; ++u) {
+      r[u] = (it * UR + u) * RPP + threadIdx.x / G;
+      valid[u] = r[u] < n;
+      if (!valid[u]) r[u] = n - 1;
+      acc[u] = f4zero();
+      gas[u] = 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < UR; ++u) { beg[u] = trp[r[u]]; deg[u] = (int)trp[r[u] + 1] - beg[u]; }   // deg >= 1
+    const int dmax = wave_max_deg(max_of<UR>(deg));
+    if (max_of<UR>(deg) <= MAXD) {
+      float al[UR][MAXD], ge[UR][MAXD];
+      float4 v[UR][MAXD];
 #pragma unroll
       for (int k = 0; k < MAXD; ++k)
         if (k < dmax) {
-          const int kk = beg + min(k, deg - 1);
-          const int e = teid[kk], ii = tdst[kk];
-          v[k] = ld4(g_out + (unsigned)((gb + ii) * HC + c0));
-          al[k] = alpha[(unsigned)((e0 + e) * H + hd)];
-          ge[k] = g_e[(unsigned)((eb2 + e) * H + hd)];
+#pragma unroll
+          for (int u = 0; u < UR; ++u) {
+            const int kk = beg[u] + min(k, deg[u] - 1);
+            const int e = teid[kk], ii = tdst[kk];
+            v[u][k] = ld4(g_out + (unsigned)((gb + ii) * HC + c0));
+            al[u][k] = alpha[(unsigned)((e0 + e) * H + hd)];
+            ge[u][k] = g_e[(unsigned)((eb2 + e) * H + hd)];
+          }
         }
 #pragma unroll
       for (int k = 0; k < MAXD; ++k)
         if (k < dmax) {
-          const bool ok = k < deg;
-          gas = gas + (ok ? ge[k] : 0.f);
-          gatres_axpy4(acc, ok ? al[k] : 0.f, v[k]);
+#pragma unroll
+          for (int u = 0; u < UR; ++u) {
+            const bool ok = k < deg[u];
+            gas[u] = gas[u] + (ok ? ge[u][k] : 0.f);
+            gatres_axpy4(acc[u], ok ? al[u][k] : 0.f, v[u][k]);
+          }
         }
     } else {
-      for (int t = beg; t < beg + deg; ++t) {
-        const int e = teid[t], ii = tdst[t];
-        gas = gas + g_e[(unsigned)((eb2 + e) * H + hd)];
-        gatres_axpy4(acc, alpha[(unsigned)((e0 + e) * H + hd)], ld4(g_out + (unsigned)((gb + ii) * HC + c0)));
-      }
+#pragma unroll
+      for (int u = 0; u < UR; ++u)
+        for (int t = beg[u]; t < beg[u] + deg[u]; ++t) {
+          const int e = teid[t], ii = tdst[t];
+          gas[u] = gas[u] + g_e[(unsigned)((eb2 + e) * H + hd)];
+          gatres_axpy4(acc[u], alpha[(unsigned)((e0 + e) * H + hd)], ld4(g_out + (unsigned)((gb + ii) * HC + c0)));
+        }
     }
-    if (leader) g_a_src[(unsigned)((db + r) * H + hd)] = gas;
-    const float gad = g_a_dst[(unsigned)((db + r) * H + hd)];
-    gatres_axpy4(acc, gas, as);
-    gatres_axpy4(acc, gad, ad);
-    if (valid) st4(g_h + (unsigned)((hb + r) * HC + c0), acc);
+#pragma unroll
+    for (int u = 0; u < UR; ++u) {
+      const bool leader = valid[u] && (c0 % C) == 0;
+      if (leader) g_a_src[(unsigned)((db + r[u]) * H + hd)] = gas[u];
+      const float gad = g_a_dst[(unsigned)((db + r[u]) * H + hd)];
+      gatres_axpy4(acc[u], gas[u], as);
+      gatres_axpy4(acc[u], gad, ad);
+      if (valid[u]) st4(g_h + (unsigned)((hb + r[u]) * HC + c0), acc[u]);
+    }
   }
 }
 
@@ -835,6 +960,9 @@ __global__ __launch_bounds__(THREADS) void gatres_fused_kernel(const FusedArgs a
   const int e0 = a.rowptr[n0], eg = a.rowptr[n0 + n] - e0;            // GATConv edges of this segment
   const int em0 = a.m_rowptr[n0], em = a.m_rowptr[n0 + n] - em0;      // SimpleConv edges
   const int tid = threadIdx.x;
+  // rows per lane group per trip: 16 waves x 128 VGPRs cannot hold more than this without spilling; 8 waves x 256 can
+  constexpr int UF = THREADS <= 512 ? 4 : 2;     // forward gathers
+  constexpr int UB = THREADS <= 512 ? 2 : 1;     // backward sparse stages
   const float* P = a.params;
   float* sc = a.scratch;
   int stamp_i = 0;
@@ -914,15 +1042,15 @@ __global__ __launch_bounds__(THREADS) void gatres_fused_kernel(const FusedArgs a
       if (CACHE && 2 * eg <= n * NC) {           // (wave-uniform) the alpha table fits the borrowed region
         seg_softmax<2, true, THREADS>(n, rp, col, sa, sd, 0, base + o_al1, ebS, hB);
         __syncthreads();
-        seg_gather<true, 2, NC, THREADS>(n, rp, col, hA, 0, hB, 0, pb + L.c1_b, base + o_o1, nbS);
+        seg_gather<true, 2, NC, THREADS, UF>(n, rp, col, hA, 0, hB, 0, pb + L.c1_b, base + o_o1, nbS);
       } else if (CACHE) {
         seg_softmax<2, false, THREADS>(n, rp, col, sa, sd, 0, base + o_al1, ebS, nullptr);
         __syncthreads();
-        seg_gather<true, 2, NC, THREADS>(n, rp, col, hA, 0, base + o_al1, ebS, pb + L.c1_b, base + o_o1, nbS);
+        seg_gather<true, 2, NC, THREADS, UF>(n, rp, col, hA, 0, base + o_al1, ebS, pb + L.c1_b, base + o_o1, nbS);
       } else {
         seg_softmax<2, false, THREADS>(n, rp, col, base + o_as1, base + o_ad1, nbS, base + o_al1, ebS, nullptr);
         __syncthreads();
-        seg_gather<true, 2, NC, THREADS>(n, rp, col, base + o_h1, nbS, base + o_al1, ebS, pb + L.c1_b, base + o_o1,
+        seg_gather<true, 2, NC, THREADS, UF>(n, rp, col, base + o_h1, nbS, base + o_al1, ebS, pb + L.c1_b, base + o_o1,
                                          nbS);
       }
       __syncthreads();
@@ -939,23 +1067,23 @@ __global__ __launch_bounds__(THREADS) void gatres_fused_kernel(const FusedArgs a
         float* al2L = hA + (size_t)n * NC;
         seg_softmax<1, true, THREADS>(n, rp, col, sa, sd, 0, base + o_al2, ebS, al2L);
         __syncthreads();
-        seg_gather<false, 1, NC, THREADS>(n, rp, col, hB, 0, al2L, 0, pb + L.c2_b, hA, 0);
+        seg_gather<false, 1, NC, THREADS, UF>(n, rp, col, hB, 0, al2L, 0, pb + L.c2_b, hA, 0);
       } else if (CACHE) {
         seg_softmax<1, false, THREADS>(n, rp, col, sa, sd, 0, base + o_al2, ebS, nullptr);
         __syncthreads();
-        seg_gather<false, 1, NC, THREADS>(n, rp, col, hB, 0, base + o_al2, ebS, pb + L.c2_b, hA, 0);
+        seg_gather<false, 1, NC, THREADS, UF>(n, rp, col, hB, 0, base + o_al2, ebS, pb + L.c2_b, hA, 0);
       } else {
         seg_softmax<1, false, THREADS>(n, rp, col, base + o_as2, base + o_ad2, nbS, base + o_al2, ebS, nullptr);
         __syncthreads();
-        seg_gather<false, 1, NC, THREADS>(n, rp, col, base + o_h2, nbS, base + o_al2, ebS, pb + L.c2_b, y2g, n0);
+        seg_gather<false, 1, NC, THREADS, UF>(n, rp, col, base + o_h2, nbS, base + o_al2, ebS, pb + L.c2_b, y2g, n0);
       }
       __syncthreads();
       STAMP();
       // K3
       if (CACHE)
-        seg_mean_fwd<NC, THREADS>(n, em, mrp, mcol, hA, 0, xcur, nbS, xnext, nbS);
+        seg_mean_fwd<NC, THREADS, UF>(n, em, mrp, mcol, hA, 0, xcur, nbS, xnext, nbS);
       else
-        seg_mean_fwd<NC, THREADS>(n, em, mrp, mcol, y2g, n0, xcur, nbS, xnext, nbS);
+        seg_mean_fwd<NC, THREADS, UF>(n, em, mrp, mcol, y2g, n0, xcur, nbS, xnext, nbS);
       __syncthreads();
       STAMP();
       xcur = xnext;
@@ -1068,16 +1196,18 @@ __global__ __launch_bounds__(THREADS) void gatres_fused_kernel(const FusedArgs a
       const float* wt1 = a.wt + (int64_t)b * 2 * w;
       const float* wt2 = wt1 + w;
       // K3 backward
-      if (CACHE) seg_mean_bwd<NC, THREADS>(n, em, mrp, mtrp, mtdst, gpT, 0, gy2T, gy2b);
-      else       seg_mean_bwd<NC, THREADS>(n, em, mrp, mtrp, mtdst, gp_cur, n0, gy2T, gy2b);
+      if (CACHE) seg_mean_bwd<NC, THREADS, UB>(n, em, mrp, mtrp, mtdst, gpT, 0, gy2T, gy2b);
+      else       seg_mean_bwd<NC, THREADS, UB>(n, em, mrp, mtrp, mtdst, gp_cur, n0, gy2T, gy2b);
       __syncthreads();
       STAMP();
       // conv2
-      seg_agg_bwd_dst<1, NC, THREADS>(n, 0, 0, rp, col, gy2T, gy2b, base + SL.h2, base + SL.al2, base + SL.as2,
-                                      base + SL.ad2, ge2T, ge_b, gad2T, gd_b);
+      seg_edge_dots<1, NC, THREADS, 2>(n, 0, rp, col, gy2T, gy2b, base + SL.h2, ge2T, ge_b);
+      __syncthreads();
+      seg_softmax_bwd<1, THREADS>(n, 0, 0, rp, col, base + SL.al2, base + SL.as2, base + SL.ad2, ge2T, ge_b, gad2T,
+                                  gd_b);
       __syncthreads();
       STAMP();
-      seg_agg_bwd_src<1, NC, THREADS>(n, 0, trp, teid, tdst, gy2T, gy2b, base + SL.al2, ge2T, ge_b, gad2T, gd_b,
+      seg_agg_bwd_src<1, NC, THREADS, UB>(n, 0, trp, teid, tdst, gy2T, gy2b, base + SL.al2, ge2T, ge_b, gad2T, gd_b,
                                       pb + L.c2_as, pb + L.c2_ad, gh2, n0, gas2T);
       __syncthreads();
       STAMP();
@@ -1099,11 +1229,13 @@ __global__ __launch_bounds__(THREADS) void gatres_fused_kernel(const FusedArgs a
       __syncthreads();
       STAMP();
       // conv1
-      seg_agg_bwd_dst<2, NC, THREADS>(n, 0, 0, rp, col, go1T, go1b, base + SL.h1, base + SL.al1, base + SL.as1,
-                                      base + SL.ad1, ge1T, ge_b, gad1T, gd_b);
+      seg_edge_dots<2, NC, THREADS, 2>(n, 0, rp, col, go1T, go1b, base + SL.h1, ge1T, ge_b);
+      __syncthreads();
+      seg_softmax_bwd<2, THREADS>(n, 0, 0, rp, col, base + SL.al1, base + SL.as1, base + SL.ad1, ge1T, ge_b, gad1T,
+                                  gd_b);
       __syncthreads();
       STAMP();
-      seg_agg_bwd_src<2, NC, THREADS>(n, 0, trp, teid, tdst, go1T, go1b, base + SL.al1, ge1T, ge_b, gad1T, gd_b,
+      seg_agg_bwd_src<2, NC, THREADS, UB>(n, 0, trp, teid, tdst, go1T, go1b, base + SL.al1, ge1T, ge_b, gad1T, gd_b,
                                       pb + L.c1_as, pb + L.c1_ad, gh, n0, gas1T);
       __syncthreads();
       STAMP();
@@ -1174,7 +1306,15 @@ __global__ __launch_bounds__(256) void reduce_adam_kernel(const float* __restric
   const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
   if (idx < count) {
     float acc = 0.f;
-    for (int s = 0; s < num_slabs; ++s) acc += slabs[(size_t)s * stride + idx];
+    int s0 = 0;
+    for (; s0 + 8 <= num_slabs; s0 += 8) {              // 8 loads in flight, summed in slab order
+      float v8[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v8[u] = slabs[(size_t)(s0 + u) * stride + idx];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) acc += v8[u];
+    }
+    for (; s0 < num_slabs; ++s0) acc += slabs[(size_t)s0 * stride + idx];
     grads[idx] = acc;
     if (do_adam) {
       const float pv = p[idx];

@@ -201,6 +201,8 @@ __device__ __forceinline__ uint64_t mask_key(uint64_t seed, uint64_t step, int g
 __global__ __launch_bounds__(256) void mask_generate_kernel(const int* __restrict__ node_ptr, double rate,
                                                             uint64_t seed, const uint64_t* __restrict__ step_counter,
                                                             uint8_t* __restrict__ mask) {
+  constexpr int SMALL = 2048;                      // graphs up to this size: all-pairs rank in LDS (~1 us for C-Town)
+  __shared__ uint64_t s_keys[SMALL];
   __shared__ int hist[256];
   __shared__ uint64_t s_prefix;
   __shared__ int s_k;
@@ -210,6 +212,18 @@ __global__ __launch_bounds__(256) void mask_generate_kernel(const int* __restric
   const int k = (int)((double)n * rate);          // Python: int(num_nodes * masking_rate)
   if (k <= 0) {
     for (int v = tid; v < n; v += 256) mask[n0 + v] = 0;
+    return;
+  }
+  if (n <= SMALL) {
+    // keys are unique, so "masked" == "fewer than k keys are smaller than mine"
+    for (int v = tid; v < n; v += 256) s_keys[v] = mask_key(seed, step, n0 + v, v);
+    __syncthreads();
+    for (int v = tid; v < n; v += 256) {
+      const uint64_t mine = s_keys[v];
+      int rank = 0;
+      for (int u = 0; u < n; ++u) rank += s_keys[u] < mine ? 1 : 0;      // broadcast LDS reads
+      mask[n0 + v] = rank < k ? 1 : 0;
+    }
     return;
   }
   if (tid == 0) { s_prefix = 0; s_k = k; }
