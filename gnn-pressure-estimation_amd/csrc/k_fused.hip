@@ -147,13 +147,9 @@ __device__ __forceinline__ void seg_proj(int n, const float* X, int xb, const fl
                                          int ob, float* OUT2, int o2b, const float* __restrict__ att_src,
                                          const float* __restrict__ att_dst, float* as_g, float* ad_g, int ag_b,
                                          float* as_l, float* ad_l, const float* resid, int rb,
-                                         const float* relu_ref, int mb_, float* wl,
-                                         unsigned long long* dbg = nullptr) {
+                                         const float* relu_ref, int mb_, float* wl) {
   constexpr int KQ = K / 4, NT = (M + 15) / 16, NW = THREADS / 64;
   constexpr int KP = K + 4;                  // padded LDS row: 16 lanes x float4 at stride KP hit distinct banks
-  int di = 0;
-#define PSTAMP() do { if (dbg && threadIdx.x == 0 && di < 24) dbg[di++] = wall_clock64(); } while (0)
-  PSTAMP();
   constexpr int SC = (KQ % 4 == 0) ? 4 : ((KQ % 2 == 0) ? 2 : 1);
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int i = lane & 15, q = lane >> 4;
@@ -256,12 +252,9 @@ __device__ __forceinline__ void seg_proj(int n, const float* X, int xb, const fl
     const int r0 = wave * 16 + i;
     load_frag<KQ>(X + (unsigned)((xb + min(r0, n - 1)) * K + q * KQ), xcur);
   }
-  PSTAMP();
   for (int t0 = wave; t0 < ntiles; t0 += NW) {
     const int rA = t0 * 16 + i;
     const bool okA = rA < n;
-    if (dbg) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
-    PSTAMP();
     const int rN = (t0 + NW) * 16 + i;
     if (t0 + NW < ntiles) load_frag<KQ>(X + (unsigned)((xb + min(rN, n - 1)) * K + q * KQ), xnxt);   // uniform branch
     f32x4 acc[NT];
@@ -290,15 +283,10 @@ __device__ __forceinline__ void seg_proj(int n, const float* X, int xb, const fl
           acc[tt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[u], xcur[s + u], acc[tt], 0, 0, 0);
       }
     }
-    if (dbg) { asm volatile("" :: "v"(acc[0][0]), "v"(acc[NT - 1][3])); }
-    PSTAMP();
     epilogue(acc, rA, okA);
-    PSTAMP();
 #pragma unroll
     for (int s = 0; s < KQ; ++s) xcur[s] = xnxt[s];
   }
-  PSTAMP();
-#undef PSTAMP
 }
 
 // dW partial of this segment: slab[c*K + k] = sum_r G[gb + r, c] * X[xb + r, k].  One 16x16 output tile per wave
@@ -363,7 +351,7 @@ __device__ __forceinline__ void seg_dw(int n, const float* G, int gb, const floa
 template <int HC, int K, int THREADS>
 __device__ __forceinline__ void seg_dw_blk(int n, int R, const float* G, int gb, const float* X, int xb,
                                            float* __restrict__ slab, float* part) {
-  constexpr int VC = HC / 16, VK = K / 16, STEPS = 4;              // 4 steps (16 rows) of loads in flight
+  constexpr int VC = HC / 16, VK = K / 16, STEPS = 5;              // 5 steps (20 rows) of loads in flight
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int i = lane & 15, q = lane >> 4;
   if (wave < R) {                                                   // wave-uniform
@@ -1033,9 +1021,7 @@ __global__ __launch_bounds__(THREADS) void gatres_fused_kernel(const FusedArgs a
       // conv1: K1, then K2 (+bias+ReLU)
       seg_proj<NC, 2 * NC, 2, EPI_ATT, THREADS, WLDS>(n, xcur, nbS, pb + L.c1_W, base + o_h1, nbS, CACHE ? hA : nullptr, 0,
                                                  pb + L.c1_as, pb + L.c1_ad, base + o_as1, base + o_ad1, nbS,
-                                                 CACHE ? sa : nullptr, CACHE ? sd : nullptr, nullptr, 0, nullptr, 0, wl1,
-                                                 (a.stamps && seg == 0 && b == 1) ? a.stamps + a.stamp_cap + 8 : nullptr);
-      if (a.stamps && seg == 0 && b == 1 && tid == 0) a.stamps[a.stamp_cap + 7] = wall_clock64();
+                                                 CACHE ? sa : nullptr, CACHE ? sd : nullptr, nullptr, 0, nullptr, 0, wl1);
       __syncthreads();
       STAMP();
       // K2 conv1: softmax (alpha -> HBM + LDS: the h2 table is dead now), then the gather
@@ -1215,7 +1201,7 @@ __global__ __launch_bounds__(THREADS) void gatres_fused_kernel(const FusedArgs a
                                            sb + L.c2_ad, sb + L.c2_b, red);
       STAMP();
       if constexpr (CACHE && NC >= 16 && NC <= 32) {             // block form: partials through the idle RA region
-        const int R = min(8, (n * 2 * NC) / (2 * NC * NC));
+        const int R = min(THREADS / 64, (n * 2 * NC) / (2 * NC * NC));
         if (R >= 1) seg_dw_blk<NC, 2 * NC, THREADS>(n, R, gh2, n0, base + SL.o1, 0, sb + L.c2_W, RA);
         else        seg_dw<NC, 2 * NC, THREADS>(n, gh2, n0, base + SL.o1, 0, sb + L.c2_W, red);
       } else {
@@ -1243,7 +1229,7 @@ __global__ __launch_bounds__(THREADS) void gatres_fused_kernel(const FusedArgs a
                                            sb + L.c1_ad, sb + L.c1_b, red);
       STAMP();
       if constexpr (CACHE && NC >= 16 && NC <= 32) {
-        const int R = min(8, (n * 2 * NC) / (2 * NC * NC));
+        const int R = min(THREADS / 64, (n * 2 * NC) / (2 * NC * NC));
         if (R >= 1) seg_dw_blk<2 * NC, NC, THREADS>(n, R, gh, n0, base + SL.xin, 0, sb + L.c1_W, RA);
         else        seg_dw<2 * NC, NC, THREADS>(n, gh, n0, base + SL.xin, 0, sb + L.c1_W, red);
       } else {

@@ -23,10 +23,6 @@ raw = stamps.cpu().numpy()
 clk = raw[cap:cap + 3]
 s = raw[:cap]
 s = s[s > 0]
-pd = raw[cap + 7:cap + 36]; pd = pd[pd > 0]
-if len(pd) > 1: print('proj1 internals (us since entry):', [round((v - pd[1]) / 100.0, 2) for v in pd[1:]], ' pre-barrier at', round((pd[0] - pd[1]) / 100.0, 2))
-ad = raw[cap + 40:cap + 80]; ad = ad[ad > 0]
-if len(ad) > 1: print('agg1 internals (us since entry):', [round((v - ad[0]) / 100.0, 2) for v in ad])
 print('shader clock MHz ~', (clk[1] - clk[0]) / ((clk[2] - s[0]) / 100.0))
 d = (s[1:] - s[:-1]) / 100.0   # us
 print("stamps", len(s), "total us", (s[-1] - s[0]) / 100.0)
