@@ -45,6 +45,11 @@ def parse():
     ap.add_argument("--pipes", type=int, default=430)
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
     ap.add_argument("--per-op", action="store_true", help="one launch per stage instead of the fused per-snapshot kernel")
+    ap.add_argument("--force-collective-path", action="store_true",
+                    help="run the multi-GPU sequence (backward | RCCL all-reduce | Adam) even at world size 1")
+    ap.add_argument("--drop-in", action="store_true",
+                    help="time the reference loop body verbatim (train.py:160-188): nn.Module forward, loss.backward(), "
+                         "torch.optim.Adam, host-side numpy mask, a fresh edge_index tensor every batch")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--no-roofline", action="store_true")
@@ -207,6 +212,45 @@ def cpu_baseline(args, nb, nc):
                        f"(best of {cands} on a host with {avail} hardware threads)")
 
 
+def drop_in_loop(args, G, model, topo, device, nb, nc):
+    """The reference's loop body on the drop-in module (single GPU): what a user gets by only swapping the import."""
+    import numpy as np
+    opt = torch.optim.Adam(model.parameters(), lr=5e-4, weight_decay=6e-6)
+    crit = torch.nn.MSELoss()
+    bs, npg = args.batch_size, args.nodes
+    snaps = G.wdn_synth.make_snapshots(8 * bs, npg, seed=100)
+    ei_cpu = G.wdn_synth.collate_edge_index(topo, npg, bs)
+    rng = np.random.RandomState(0)
+
+    def step(i):
+        opt.zero_grad()
+        y = G.wdn_synth.collate_snapshots(snaps, range((i % 8) * bs, (i % 8 + 1) * bs))
+        x, yd, ei = y.clone().to(device), y.to(device), ei_cpu.clone().to(device)       # train.py:162-164
+        batch_mask = G.wdn_synth.generate_batch_mask([npg] * bs, 0.95, rng)             # auxil.py:166-182
+        x[batch_mask] = 0
+        out = model(x, ei, None, None)
+        loss = crit(out[batch_mask], yd[batch_mask])
+        loss.backward()
+        opt.step()
+        return float(loss)                                                               # train.py:190 (sync)
+
+    for i in range(args.warmup):
+        step(i)
+    torch.cuda.synchronize(device)
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        last = step(i)
+    torch.cuda.synchronize(device)
+    dt = time.perf_counter() - t0
+    print(json.dumps({"metric": "train snapshots/sec", "value": bs * args.steps / dt, "unit": "snapshots/s", "n_gpus": 1,
+                      "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+                      "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+                      "data": "synthetic",
+                      "config": {"workload": f"{args.model}, drop-in nn.Module + torch.optim.Adam + host numpy mask, "
+                                             f"reference loop body verbatim (train.py:160-190), batch_size={bs}",
+                                 "final_loss": last}}))
+
+
 def main():
     args = parse()
     nb, nc = MODELS[args.model]
@@ -220,9 +264,13 @@ def main():
         print(f"warning: --gpus {args.gpus} but WORLD_SIZE {world}", file=sys.stderr)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP engine has no CPU path")
+    # host-side tensor ops here are tiny (collation, masks): a 256-wide OpenMP team makes each of them ~20 ms
+    torch.set_num_threads(min(8, os.cpu_count() or 1))
     device = torch.device("cuda", local_rank)
     torch.cuda.set_device(device)
-    if world > 1:
+    if world > 1 or args.force_collective_path:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
         torch.distributed.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
     import gnn_pressure_estimation_amd as G
@@ -232,7 +280,10 @@ def main():
     topo = G.wdn_synth.make_wdn_topology(args.nodes, args.pipes, seed=0)
     ei = G.wdn_synth.collate_edge_index(topo, args.nodes, args.batch_size).to(device)
     trainer = G.GATResTrainer(model, ei, N, nodes_per_graph=[args.nodes] * args.batch_size, seed=1000 + rank,
-                              use_graph=not args.no_graph, fused=not args.per_op)
+                              use_graph=not args.no_graph, fused=not args.per_op,
+                              force_collective_path=args.force_collective_path)
+    if args.drop_in:
+        return drop_in_loop(args, G, model, topo, device, nb, nc)
     nbatches = 8
     snaps = G.wdn_synth.make_snapshots(nbatches * args.batch_size, args.nodes, seed=100 + rank).to(device)
     batches = [snaps[i * args.batch_size:(i + 1) * args.batch_size].reshape(-1).contiguous() for i in range(nbatches)]
@@ -303,7 +354,7 @@ def main():
             result["kernels"] = [{k: (round(v, 3) if isinstance(v, float) else v) for k, v in r.items()} for r in rows]
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(args, nb, nc)
-    if world > 1:
+    if torch.distributed.is_available() and torch.distributed.is_initialized():
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
     if rank == 0:

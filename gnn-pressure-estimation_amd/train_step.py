@@ -44,7 +44,8 @@ class GATResTrainer:
     def __init__(self, model: GATResMeanConv, edge_index: torch.Tensor, num_nodes: int,
                  nodes_per_graph: Optional[Sequence[int]] = None, lr: float = 5e-4, weight_decay: float = 6e-6,
                  betas=(0.9, 0.999), eps: float = 1e-8, mask_rate: float = 0.95, seed: int = 0,
-                 process_group=None, use_graph: bool = True, fused: bool = True):
+                 process_group=None, use_graph: bool = True, fused: bool = True,
+                 force_collective_path: bool = False):
         self.lib = _native.load()
         self.model = model
         params = model.flat_parameters
@@ -78,6 +79,8 @@ class GATResTrainer:
         self.world = 1
         if process_group is not None or (torch.distributed.is_available() and torch.distributed.is_initialized()):
             self.world = torch.distributed.get_world_size(process_group)
+        # force_collective_path: run the multi-GPU sequence (backward | all-reduce | Adam) even at world size 1
+        self.split = force_collective_path or self.world > 1
         self.use_graph = use_graph
         self._graphs = {}
         self._params_ptr = params.data_ptr()
@@ -137,11 +140,12 @@ class GATResTrainer:
         """One optimisation step on the staged batch.  Nothing is synchronised; read ``self.loss`` afterwards."""
         if device_mask and self.node_ptr is None:
             raise ValueError("device mask sampling needs nodes_per_graph at construction")
-        if self.world == 1:
+        if not self.split:
             self._run(PHASE_MASK | PHASE_FORWARD | PHASE_BACKWARD | PHASE_ADAM, device_mask)
         else:
             self._run(PHASE_MASK | PHASE_FORWARD | PHASE_BACKWARD, device_mask)
-            torch.distributed.all_reduce(self.grads, op=torch.distributed.ReduceOp.SUM, group=self.pg)
+            if torch.distributed.is_available() and torch.distributed.is_initialized():
+                torch.distributed.all_reduce(self.grads, op=torch.distributed.ReduceOp.SUM, group=self.pg)
             self._run(PHASE_ADAM, device_mask)
 
     def step(self, x: torch.Tensor, y: torch.Tensor, mask: Optional[torch.Tensor] = None) -> torch.Tensor:

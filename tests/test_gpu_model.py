@@ -317,3 +317,23 @@ def test_golden_vectors(pkg, name, fused):
     assert float((model.flat_parameters.cpu() - torch.from_numpy(d["params_after"])).abs().max()) <= 2 * 5e-4
     frac = float(((model.flat_parameters.cpu() - torch.from_numpy(d["params_after"])).abs() > 1e-5).double().mean())
     assert frac < 0.01
+
+
+def test_collective_path_equals_single_call(pkg, oracle):
+    """The multi-GPU sequence (mask+fwd+bwd | all-reduce | Adam as separate graph replays) must give exactly the
+    single-call step at world size 1."""
+    bs = 4
+    ei = pkg.wdn_synth.collate_edge_index(pkg.wdn_synth.make_wdn_topology(), 388, bs).cuda()
+    snaps = pkg.wdn_synth.make_snapshots(12, 388, seed=8).cuda()
+    res = []
+    for split in (False, True):
+        model, _ = build(pkg, oracle, 15, 32, seed=2)
+        tr = pkg.GATResTrainer(model, ei, 388 * bs, nodes_per_graph=[388] * bs, seed=77, force_collective_path=split)
+        assert tr.split == split
+        losses = []
+        for it in range(3):
+            y = snaps[it * bs:(it + 1) * bs].reshape(-1)
+            losses.append(float(tr.step(y, y)))
+        res.append((losses, model.flat_parameters.clone(), tr.mask.clone()))
+    assert res[0][0] == res[1][0]
+    assert torch.equal(res[0][1], res[1][1]) and torch.equal(res[0][2], res[1][2])
