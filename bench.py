@@ -121,12 +121,16 @@ def kernel_table(G, model, plan, nc):
     return rows
 
 
-def algorithmic_bytes_per_step(rows, N, nc, P):
-    """Compulsory-traffic model of one training step: every stage's inputs read once and
-    outputs written once at full row width, no cache credit; = sum over the per-op stages + lin0/lin1/loss/Adam."""
-    stages = sum(r[1] * r[2] for r in rows)
-    small = 4 * (N + 2 * N * nc) * 2 + 4 * (2 * N * nc + 2 * N) + 4 * 4 * N + 4 * 7 * P
-    return stages + small
+def algorithmic_bytes_per_step(rows, N, nc, P, S, nb):
+    """Compulsory-traffic model: every stage's inputs read once and outputs written once at
+    full row width, no cache credit.  Returns (fused per-snapshot kernel, deferred parameter-gradient kernel): the
+    dW / attention-vector gradient stages run in the second launch, the bias column sums stay in the first."""
+    deferred = sum(r[1] * r[2] for r in rows if r[0].startswith(("proj_bwd_dw", "conv_param_grads")))
+    bias = nb * 4 * ((N * 2 * nc + S * 2 * nc) + (N * nc + S * nc))       # g_out tables read, slab rows written
+    deferred -= bias
+    stages = sum(r[1] * r[2] for r in rows) - deferred
+    small = 4 * (N + 2 * N * nc) * 2 + 4 * (2 * N * nc + 2 * N) + 4 * 4 * N     # lin0 / lin1 (+bwd) / loss
+    return stages + small, deferred
 
 
 def time_fused(G, trainer, device, reps=50):
@@ -147,13 +151,19 @@ def time_fused(G, trainer, device, reps=50):
     for _ in range(5):
         G._native.check(lib.gatres_fused_run(*args, st()), "fused_run")
     torch.cuda.synchronize(device)
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record(torch.cuda.current_stream(device))
-    for _ in range(reps):
-        lib.gatres_fused_run(*args, st())
-    e1.record(torch.cuda.current_stream(device))
-    e1.synchronize()
-    return e0.elapsed_time(e1) * 1e3 / reps
+
+    def avg_us(fn):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(torch.cuda.current_stream(device))
+        for _ in range(reps):
+            fn()
+        e1.record(torch.cuda.current_stream(device))
+        e1.synchronize()
+        return e0.elapsed_time(e1) * 1e3 / reps
+
+    pg = (m._cmodel_ref(), plan.ref(), L.saved.data_ptr(), L.scratch.data_ptr())
+    G._native.check(lib.gatres_fused_param_grads(*pg, st()), "param_grads")
+    return avg_us(lambda: lib.gatres_fused_run(*args, st())), avg_us(lambda: lib.gatres_fused_param_grads(*pg, st()))
 
 
 def time_kernels(rows, device, reps=200):
@@ -334,13 +344,17 @@ def main():
         table = kernel_table(G, model, trainer.plan, nc)
         if trainer.fused:
             log("timing the fused per-snapshot kernel ...")
-            nbytes = algorithmic_bytes_per_step(table, N, nc, trainer.P)
-            us = time_fused(G, trainer, device)
+            nbytes, nbytes_pg = algorithmic_bytes_per_step(table, N, nc, trainer.P, trainer.plan.num_segments, nb)
+            us, us_pg = time_fused(G, trainer, device)
             result["roofline"] = {"bound": "hbm", "kernel": "gatres_fused_kernel (forward+loss+backward, one launch)",
                                   "achieved": nbytes / us * 1e-3, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                   "frac": nbytes / us * 1e-3 / HBM_PEAK_GBS, "traffic": None,
                                   "avg_launch_us": us, "algorithmic_bytes_per_launch": nbytes,
-                                  "algorithmic_bytes_per_snapshot": nbytes / args.batch_size}
+                                  "algorithmic_bytes_per_snapshot": nbytes / args.batch_size,
+                                  "second_kernel": {"kernel": "param_grads_kernel (deferred dW / att gradients)",
+                                                    "avg_launch_us": us_pg,
+                                                    "algorithmic_bytes_per_launch": nbytes_pg,
+                                                    "achieved": nbytes_pg / us_pg * 1e-3}}
         else:
             log("per-kernel timing ...")
             rows = time_kernels(table, device)

@@ -75,6 +75,7 @@ SIGNATURES = {
     "gatres_fused_set_stamps": (C.c_int, [_P, _I32]),
     "gatres_fused_prepare_backward": (C.c_int, [_MP, _GP, _P, _P, _P]),
     "gatres_fused_run": (C.c_int, [_MP, _GP] + [_P] * 10 + [_I32, _P]),
+    "gatres_fused_param_grads": (C.c_int, [_MP, _GP, _P, _P, _P]),
     "gatres_fused_finish": (C.c_int, [_MP, _GP] + [_P] * 4 + [_I32] + [_P] * 4 + [_F64] * 5 + [_F32, _P]),
     "gatres_train_step": (C.c_int, [_P, _P]),
     "gatres_version": (C.c_char_p, []),

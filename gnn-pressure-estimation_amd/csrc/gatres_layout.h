@@ -16,6 +16,9 @@ struct Layout {
   // stages at the same time, so conv1 ([row*2], [row*2nc]) and conv2 ([row], [row*nc]) must not share an array.
   int64_t sc_y2, sc_ev, sc_xa, sc_xb, sc_gpa, sc_gpb, sc_gy2, sc_ge, sc_gad, sc_gas, sc_gh, sc_go1, sc_wt,
       sc_ge2, sc_gad2, sc_gas2, sc_gh2, sc_slabs, sc_loss_part, scratch_total;
+  // fused path only: every block keeps its g_h / g_alpha tables until the deferred parameter-gradient launch
+  // (k_fused.hip: param_grads_kernel) has consumed them.  Block-major, global node index.
+  int64_t sc_keep, keep_stride, k_gh1, k_gh2, k_gas1, k_gad1, k_gas2, k_gad2;
   int num_slabs;      // node-range slabs of the per-op path
   int slab_rows;      // slabs allocated = max(num_slabs, segments)
   int64_t slab_stride;
@@ -31,7 +34,9 @@ static inline int num_slabs_for(int64_t P, int64_t N) {
   return (int)s;
 }
 
-static inline bool make_layout(const gatres_model_t* m, int64_t N, int64_t Eg, int num_segments, Layout* L) {
+// fused_nodes: the plan's largest segment if the fused per-snapshot path can take it (fused_nodes_of), else 0
+static inline bool make_layout(const gatres_model_t* m, int64_t N, int64_t Eg, int num_segments, int fused_nodes,
+                               Layout* L) {
   if (!m || m->num_blocks < 0 || N <= 0 || Eg < 0) return false;
   const int nc = m->nc, nb = m->num_blocks;
   if (nc < 4 || nc > 128 || !gatres_is_pow2(nc)) return false;
@@ -82,8 +87,26 @@ static inline bool make_layout(const gatres_model_t* m, int64_t N, int64_t Eg, i
   L->slab_rows = L->num_slabs > num_segments ? L->num_slabs : num_segments;
   L->sc_slabs = o; o += (int64_t)L->slab_rows * L->slab_stride;
   L->sc_loss_part = o; o += r4((int64_t)L->slab_rows + 1);
+  L->sc_keep = o;
+  int64_t k = 0;
+  L->k_gh1 = k;  k += r4(N * 2 * nc);
+  L->k_gh2 = k;  k += r4(N * nc);
+  L->k_gas1 = k; k += r4(N * 2);
+  L->k_gad1 = k; k += r4(N * 2);
+  L->k_gas2 = k; k += r4(N);
+  L->k_gad2 = k; k += r4(N);
+  L->keep_stride = k;
+  if (fused_nodes > 0) o += (int64_t)nb * k;
   L->scratch_total = o;
   return true;
+}
+
+static inline int fused_nodes_of(const gatres_graph_t* g) {
+  return (g && g->num_segments > 0 && g->seg_ptr && g->max_segment_nodes > 0 && g->max_segment_nodes <= 4096)
+             ? g->max_segment_nodes : 0;
+}
+static inline bool make_layout_g(const gatres_model_t* m, const gatres_graph_t* g, Layout* L) {
+  return g && make_layout(m, g->num_nodes, g->num_edges_gat, g->num_segments, fused_nodes_of(g), L);
 }
 
 

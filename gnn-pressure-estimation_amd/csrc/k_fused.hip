@@ -155,8 +155,15 @@ __device__ __forceinline__ void seg_proj(int n, const float* X, int xb, const fl
   const int i = lane & 15, q = lane >> 4;
   const int ntiles = (n + 15) >> 4;
 
+  // the first tile's x fragment: in flight while W is staged
+  float xcur[KQ], xnxt[KQ];
+  {
+    const int r0 = wave * 16 + i;
+    load_frag<KQ>(X + (unsigned)((xb + min(r0, n - 1)) * K + q * KQ), xcur);
+  }
   // Stage W (rows padded to KP) and the attention vectors into LDS once per stage: every wave then feeds its MFMA
   // chain from 28-ns LDS reads instead of ~0.3-us L2 trips that the in-order wave exposes one after another.
+  // (Prefetching the W share into registers before the preceding barrier was measured: no gain, more spills.)
   const float* attS = att_src;
   const float* attD = att_dst;
   if constexpr (WLDS) {
@@ -247,11 +254,6 @@ __device__ __forceinline__ void seg_proj(int n, const float* X, int xb, const fl
   }
   // one 16-node tile per trip; the NEXT trip's x fragment is loaded before this trip's MFMA chain so its latency
   // hides behind the matrix work (a two-tiles-per-trip variant spilled at the 128-VGPR budget of a 16-wave workgroup)
-  float xcur[KQ], xnxt[KQ];
-  {
-    const int r0 = wave * 16 + i;
-    load_frag<KQ>(X + (unsigned)((xb + min(r0, n - 1)) * K + q * KQ), xcur);
-  }
   for (int t0 = wave; t0 < ntiles; t0 += NW) {
     const int rA = t0 * 16 + i;
     const bool okA = rA < n;
@@ -772,7 +774,7 @@ __device__ __forceinline__ void seg_agg_bwd_src(int n, int e0, const u16* trp, c
                                                 const float* g_e, int eb2, const float* g_a_dst, int db,
                                                 const float* __restrict__ att_src,
                                                 const float* __restrict__ att_dst, float* g_h, int hb,
-                                                float* g_a_src) {
+                                                float* keep_gas, float* keep_gad) {
   constexpr int HC = H * C, G = HC / 4, RPP = THREADS / G;
   const int c0 = (threadIdx.x % G) * 4;
   const int hd = c0 / C;
@@ -831,8 +833,11 @@ __device__ __forceinline__ void seg_agg_bwd_src(int n, int e0, const u16* trp, c
 #pragma unroll
     for (int u = 0; u < UR; ++u) {
       const bool leader = valid[u] && (c0 % C) == 0;
-      if (leader) g_a_src[(unsigned)((db + r[u]) * H + hd)] = gas[u];
       const float gad = g_a_dst[(unsigned)((db + r[u]) * H + hd)];
+      if (leader) {                      // kept (global row hb + r) for the deferred att_src / att_dst gradients
+        keep_gas[(unsigned)((hb + r[u]) * H + hd)] = gas[u];
+        keep_gad[(unsigned)((hb + r[u]) * H + hd)] = gad;
+      }
       gatres_axpy4(acc[u], gas[u], as);
       gatres_axpy4(acc[u], gad, ad);
       if (valid[u]) st4(g_h + (unsigned)((hb + r[u]) * HC + c0), acc[u]);
@@ -840,45 +845,75 @@ __device__ __forceinline__ void seg_agg_bwd_src(int n, int e0, const u16* trp, c
   }
 }
 
-// column sums of one GATConv for this segment (att_src / att_dst / bias gradients) -> the segment's slab.
+// att_src / att_dst gradients of one GATConv for this segment -> the segment's slab (deferred launch).
 // thread = (column c, row group rg); 4 rows in flight; partials combined across row groups through LDS.
 template <int H, int C, int THREADS>
-__device__ __forceinline__ void seg_conv_param_grads(int n, int n0, const float* __restrict__ h, const float* g_a_src,
-                                                     const float* g_a_dst, int db, const float* g_out, int gb,
-                                                     float* __restrict__ slab_as, float* __restrict__ slab_ad,
-                                                     float* __restrict__ slab_b, float* red) {
+__device__ __forceinline__ void seg_att_grads(int n, const float* __restrict__ h, int hb,
+                                              const float* __restrict__ g_a_src, const float* __restrict__ g_a_dst,
+                                              int db, float* __restrict__ slab_as, float* __restrict__ slab_ad,
+                                              float* red) {
   constexpr int HC = H * C, R = THREADS / HC;
   const int c = threadIdx.x % HC, rg = threadIdx.x / HC;
   const int hd = c / C;
-  float as = 0.f, ad = 0.f, ab = 0.f;
-  for (int r0 = rg; r0 < n; r0 += 4 * R) {
-    float hv[4], gs[4], gd[4], go[4];
+  float as = 0.f, ad = 0.f;
+  if (rg < R) {
+    for (int r0 = rg; r0 < n; r0 += 4 * R) {
+      float hv[4], gs[4], gd[4];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const int r = r0 + k * R;
-      const bool ok = r < n;
-      const int rr = ok ? r : 0;
-      hv[k] = ok ? h[(size_t)(n0 + rr) * HC + c] : 0.f;
-      gs[k] = ok ? g_a_src[(size_t)(db + rr) * H + hd] : 0.f;
-      gd[k] = ok ? g_a_dst[(size_t)(db + rr) * H + hd] : 0.f;
-      go[k] = ok ? g_out[(size_t)(gb + rr) * HC + c] : 0.f;
-    }
+      for (int k = 0; k < 4; ++k) {
+        const int r = r0 + k * R;
+        const bool ok = r < n;
+        const int rr = ok ? r : 0;
+        hv[k] = ok ? h[(size_t)(hb + rr) * HC + c] : 0.f;
+        gs[k] = ok ? g_a_src[(size_t)(db + rr) * H + hd] : 0.f;
+        gd[k] = ok ? g_a_dst[(size_t)(db + rr) * H + hd] : 0.f;
+      }
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      as = fmaf(gs[k], hv[k], as);
-      ad = fmaf(gd[k], hv[k], ad);
-      ab += go[k];
+      for (int k = 0; k < 4; ++k) {
+        as = fmaf(gs[k], hv[k], as);
+        ad = fmaf(gd[k], hv[k], ad);
+      }
     }
   }
   __syncthreads();
-  red[threadIdx.x] = as; red[THREADS + threadIdx.x] = ad; red[2 * THREADS + threadIdx.x] = ab;
+  red[threadIdx.x] = as; red[THREADS + threadIdx.x] = ad;
   __syncthreads();
-  if (rg == 0) {
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f;
-    for (int k = 0; k < R; ++k) {
-      s0 += red[k * HC + c]; s1 += red[THREADS + k * HC + c]; s2 += red[2 * THREADS + k * HC + c];
+  if (threadIdx.x < HC) {
+    float s0 = 0.f, s1 = 0.f;
+    for (int k = 0; k < R; ++k) { s0 += red[k * HC + c]; s1 += red[THREADS + k * HC + c]; }
+    slab_as[c] = s0; slab_ad[c] = s1;
+  }
+}
+
+// bias gradient of one GATConv = column sums of its g_out table.  Two halves that ride on barriers the backward
+// already has: `part` (per-thread partial -> red) runs inside the softmax-backward stage, `finish` (HC threads sum
+// the row groups -> slab) at the start of the source-major stage.
+template <int HC, int THREADS>
+__device__ __forceinline__ void seg_bias_part(int n, const float* g_out, int gb, float* red) {
+  constexpr int R = THREADS / HC;
+  const int c = threadIdx.x % HC, rg = threadIdx.x / HC;
+  float ab = 0.f;
+  if (rg < R) {
+    for (int r0 = rg; r0 < n; r0 += 4 * R) {
+      float go[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int r = r0 + k * R;
+        go[k] = r < n ? g_out[(unsigned)((gb + (r < n ? r : 0)) * HC + c)] : 0.f;
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) ab += go[k];
     }
-    slab_as[c] = s0; slab_ad[c] = s1; slab_b[c] = s2;
+  }
+  red[threadIdx.x] = ab;
+}
+template <int HC, int THREADS>
+__device__ __forceinline__ void seg_bias_finish(const float* red, float* __restrict__ slab_b) {
+  constexpr int R = THREADS / HC;
+  if (threadIdx.x < HC) {
+    float s = 0.f;
+    for (int k = 0; k < R; ++k) s += red[k * HC + threadIdx.x];
+    slab_b[threadIdx.x] = s;
   }
 }
 
@@ -1155,8 +1190,6 @@ __global__ __launch_bounds__(THREADS) void gatres_fused_kernel(const FusedArgs a
     const float* segbase = a.saved + (int64_t)seg * SL.total;
     float* gp_cur = sc + L.sc_gpa;       // global copies of g_pre (row-wise residual reads)
     float* gp_nxt = sc + L.sc_gpb;
-    float* gh = sc + L.sc_gh;
-    float* gh2 = sc + L.sc_gh2;
     // gathered / small backward tables: LDS when CACHE, else global scratch (conv2 has private arrays: see Layout)
     float* gpT = CACHE ? RA : nullptr;                                   // g_pre, LDS copy for the K3 gather
     float* gy2T = CACHE ? RA + (size_t)n * NC : sc + L.sc_gy2;  const int gy2b = CACHE ? 0 : n0;
@@ -1165,8 +1198,6 @@ __global__ __launch_bounds__(THREADS) void gatres_fused_kernel(const FusedArgs a
     float* ge2T = CACHE ? geL : sc + L.sc_ge2;
     float* gad1T = CACHE ? gadL : sc + L.sc_gad;                const int gd_b = CACHE ? 0 : n0;
     float* gad2T = CACHE ? gadL : sc + L.sc_gad2;
-    float* gas1T = CACHE ? gasL : sc + L.sc_gas;
-    float* gas2T = CACHE ? gasL : sc + L.sc_gas2;
     float* slab = a.slabs + (int64_t)seg * L.slab_stride;
     const int64_t w = 2LL * NC * NC;
     const float* xfinal = segbase + (int64_t)L.nb * SL.bstride + SL.xin;
@@ -1186,27 +1217,21 @@ __global__ __launch_bounds__(THREADS) void gatres_fused_kernel(const FusedArgs a
       else       seg_mean_bwd<NC, THREADS, UB>(n, em, mrp, mtrp, mtdst, gp_cur, n0, gy2T, gy2b);
       __syncthreads();
       STAMP();
-      // conv2
+      // conv2.  g_h2 / g_alpha tables go to this block's kept area: dx2 reads g_h2 back, the deferred
+      // parameter-gradient launch reads all of them (the dW / att gradients are off the critical path).
+      float* keep = sc + L.sc_keep + (int64_t)b * L.keep_stride;
+      float* gh = keep + L.k_gh1;
+      float* gh2 = keep + L.k_gh2;
       seg_edge_dots<1, NC, THREADS, 2>(n, 0, rp, col, gy2T, gy2b, base + SL.h2, ge2T, ge_b);
       __syncthreads();
+      seg_bias_part<NC, THREADS>(n, gy2T, gy2b, red);
       seg_softmax_bwd<1, THREADS>(n, 0, 0, rp, col, base + SL.al2, base + SL.as2, base + SL.ad2, ge2T, ge_b, gad2T,
                                   gd_b);
       __syncthreads();
       STAMP();
+      seg_bias_finish<NC, THREADS>(red, sb + L.c2_b);
       seg_agg_bwd_src<1, NC, THREADS, UB>(n, 0, trp, teid, tdst, gy2T, gy2b, base + SL.al2, ge2T, ge_b, gad2T, gd_b,
-                                      pb + L.c2_as, pb + L.c2_ad, gh2, n0, gas2T);
-      __syncthreads();
-      STAMP();
-      seg_conv_param_grads<1, NC, THREADS>(n, 0, base + SL.h2, gas2T, gad2T, gd_b, gy2T, gy2b, sb + L.c2_as,
-                                           sb + L.c2_ad, sb + L.c2_b, red);
-      STAMP();
-      if constexpr (CACHE && NC >= 16 && NC <= 32) {             // block form: partials through the idle RA region
-        const int R = min(THREADS / 64, (n * 2 * NC) / (2 * NC * NC));
-        if (R >= 1) seg_dw_blk<NC, 2 * NC, THREADS>(n, R, gh2, n0, base + SL.o1, 0, sb + L.c2_W, RA);
-        else        seg_dw<NC, 2 * NC, THREADS>(n, gh2, n0, base + SL.o1, 0, sb + L.c2_W, red);
-      } else {
-        seg_dw<NC, 2 * NC, THREADS>(n, gh2, n0, base + SL.o1, 0, sb + L.c2_W, red);
-      }
+                                      pb + L.c2_as, pb + L.c2_ad, gh2, n0, keep + L.k_gas2, keep + L.k_gad2);
       __syncthreads();         // g_y2 (RA) is dead: dx2 overwrites RA with g_out1
       STAMP();
       seg_proj<NC, 2 * NC, 1, EPI_RESID_MASK, THREADS, WLDS>(n, gh2, n0, wt2, go1T, go1b, nullptr, 0, nullptr, nullptr,
@@ -1217,24 +1242,14 @@ __global__ __launch_bounds__(THREADS) void gatres_fused_kernel(const FusedArgs a
       // conv1
       seg_edge_dots<2, NC, THREADS, 2>(n, 0, rp, col, go1T, go1b, base + SL.h1, ge1T, ge_b);
       __syncthreads();
+      seg_bias_part<2 * NC, THREADS>(n, go1T, go1b, red);
       seg_softmax_bwd<2, THREADS>(n, 0, 0, rp, col, base + SL.al1, base + SL.as1, base + SL.ad1, ge1T, ge_b, gad1T,
                                   gd_b);
       __syncthreads();
       STAMP();
+      seg_bias_finish<2 * NC, THREADS>(red, sb + L.c1_b);
       seg_agg_bwd_src<2, NC, THREADS, UB>(n, 0, trp, teid, tdst, go1T, go1b, base + SL.al1, ge1T, ge_b, gad1T, gd_b,
-                                      pb + L.c1_as, pb + L.c1_ad, gh, n0, gas1T);
-      __syncthreads();
-      STAMP();
-      seg_conv_param_grads<2, NC, THREADS>(n, 0, base + SL.h1, gas1T, gad1T, gd_b, go1T, go1b, sb + L.c1_as,
-                                           sb + L.c1_ad, sb + L.c1_b, red);
-      STAMP();
-      if constexpr (CACHE && NC >= 16 && NC <= 32) {
-        const int R = min(THREADS / 64, (n * 2 * NC) / (2 * NC * NC));
-        if (R >= 1) seg_dw_blk<2 * NC, NC, THREADS>(n, R, gh, n0, base + SL.xin, 0, sb + L.c1_W, RA);
-        else        seg_dw<2 * NC, NC, THREADS>(n, gh, n0, base + SL.xin, 0, sb + L.c1_W, red);
-      } else {
-        seg_dw<2 * NC, NC, THREADS>(n, gh, n0, base + SL.xin, 0, sb + L.c1_W, red);
-      }
+                                      pb + L.c1_as, pb + L.c1_ad, gh, n0, keep + L.k_gas1, keep + L.k_gad1);
       __syncthreads();         // g_out1 (RA) is dead: dx1 writes the next g_pre into RA's low half
       STAMP();
       // d/d xin = conv1 path + residual, masked by the previous block's ReLU (block 0's input is lin0: no ReLU)
@@ -1265,6 +1280,45 @@ __global__ __launch_bounds__(THREADS) void gatres_fused_kernel(const FusedArgs a
   if (a.stamps && blockIdx.x == 0 && threadIdx.x == 0) {
     a.stamps[a.stamp_cap + 1] = clock64();
     a.stamps[a.stamp_cap + 2] = wall_clock64();
+  }
+}
+
+// Deferred parameter gradients of the GATConvs.  Nothing on the backward's dependency chain reads dW / g_att, so
+// the per-snapshot kernel only keeps g_h and g_alpha_src / g_alpha_dst per block and this launch turns them into
+// slab entries with one workgroup per (segment, block, conv): nb * 2 * segments workgroups, the whole chip, instead
+// of ~20 % of the per-snapshot kernel's single-CU time.  Writes are disjoint slab ranges: deterministic.
+struct ParamGradArgs {
+  const int* seg_ptr;
+  const float* saved;
+  const float* keep;
+  float* slabs;
+  Layout L;
+  SegLayout SL;
+};
+
+template <int NC, int THREADS>
+__global__ __launch_bounds__(THREADS) void param_grads_kernel(const ParamGradArgs a) {
+  constexpr bool BLK = NC >= 16 && NC <= 32;
+  constexpr int NW = THREADS / 64;
+  __shared__ __attribute__((aligned(16))) float part[BLK ? NW * 2 * NC * NC : 4];
+  __shared__ float red[3 * THREADS];
+  const Layout& L = a.L;
+  const SegLayout& SL = a.SL;
+  const int conv = blockIdx.x & 1, b = (blockIdx.x >> 1) % L.nb, seg = (blockIdx.x >> 1) / L.nb;
+  const int n0 = a.seg_ptr[seg], n = a.seg_ptr[seg + 1] - n0;
+  const float* base = a.saved + (int64_t)seg * SL.total + (int64_t)b * SL.bstride;
+  const float* keep = a.keep + (int64_t)b * L.keep_stride;
+  float* sb = a.slabs + (int64_t)seg * L.slab_stride + L.p_block0 + (int64_t)b * L.p_block_stride;
+  if (conv == 0) {
+    if constexpr (BLK) seg_dw_blk<2 * NC, NC, THREADS>(n, NW, keep + L.k_gh1, n0, base + SL.xin, 0, sb + L.c1_W, part);
+    else               seg_dw<2 * NC, NC, THREADS>(n, keep + L.k_gh1, n0, base + SL.xin, 0, sb + L.c1_W, red);
+    seg_att_grads<2, NC, THREADS>(n, base + SL.h1, 0, keep + L.k_gas1, keep + L.k_gad1, n0, sb + L.c1_as,
+                                  sb + L.c1_ad, red);
+  } else {
+    if constexpr (BLK) seg_dw_blk<NC, 2 * NC, THREADS>(n, NW, keep + L.k_gh2, n0, base + SL.o1, 0, sb + L.c2_W, part);
+    else               seg_dw<NC, 2 * NC, THREADS>(n, keep + L.k_gh2, n0, base + SL.o1, 0, sb + L.c2_W, red);
+    seg_att_grads<1, NC, THREADS>(n, base + SL.h2, 0, keep + L.k_gas2, keep + L.k_gad2, n0, sb + L.c2_as,
+                                  sb + L.c2_ad, red);
   }
 }
 
@@ -1369,7 +1423,7 @@ extern "C" int gatres_fused_prepare_backward(const gatres_model_t* m, const gatr
                                              float* scratch, void* stream) {
   if (!m || !g || !params || !scratch) return GATRES_E_BADARG;
   Layout L;
-  if (!make_layout(m, g->num_nodes, g->num_edges_gat, g->num_segments, &L)) return GATRES_E_UNSUPPORTED;
+  if (!make_layout_g(m, g, &L)) return GATRES_E_UNSUPPORTED;
   return gatres_transpose_conv_weights(params, scratch + L.sc_wt, L.nb, L.nc, stream);
 }
 
@@ -1380,7 +1434,7 @@ extern "C" int gatres_fused_run(const gatres_model_t* m, const gatres_graph_t* g
   if (!m || !g || !params || !x || !scratch) return GATRES_E_BADARG;
   if (!gatres_fused_supported(m, g)) return GATRES_E_UNSUPPORTED;
   FusedArgs a;
-  if (!make_layout(m, g->num_nodes, g->num_edges_gat, g->num_segments, &a.L)) return GATRES_E_UNSUPPORTED;
+  if (!make_layout_g(m, g, &a.L)) return GATRES_E_UNSUPPORTED;
   if ((phases & GATRES_PHASE_FORWARD) && !out) return GATRES_E_BADARG;
   if ((phases & GATRES_PHASE_LOSS) && (!mask || !y || !out || !g_out || !loss_part)) return GATRES_E_BADARG;
   if ((phases & GATRES_PHASE_BACKWARD) && (!saved || !g_out)) return GATRES_E_BADARG;
@@ -1406,6 +1460,29 @@ extern "C" int gatres_fused_run(const gatres_model_t* m, const gatres_graph_t* g
   return GATRES_E_UNSUPPORTED;
 }
 
+extern "C" int gatres_fused_param_grads(const gatres_model_t* m, const gatres_graph_t* g, const float* saved,
+                                        float* scratch, void* stream) {
+  if (!m || !g || !saved || !scratch) return GATRES_E_BADARG;
+  if (!gatres_fused_supported(m, g)) return GATRES_E_UNSUPPORTED;
+  ParamGradArgs a;
+  if (!make_layout_g(m, g, &a.L)) return GATRES_E_UNSUPPORTED;
+  if (a.L.nb == 0) return 0;
+  a.seg_ptr = g->seg_ptr; a.saved = saved; a.keep = scratch + a.L.sc_keep; a.slabs = scratch + a.L.sc_slabs;
+  a.SL = make_seg_layout(a.L.nb, a.L.nc, g->max_segment_nodes, g->max_segment_edges_gat);
+  const dim3 grid((unsigned)(2 * a.L.nb * g->num_segments));
+  hipStream_t st = gatres_stream(stream);
+  switch (m->nc) {
+    case 4: hipLaunchKernelGGL((param_grads_kernel<4, 256>), grid, dim3(256), 0, st, a); break;
+    case 8: hipLaunchKernelGGL((param_grads_kernel<8, 256>), grid, dim3(256), 0, st, a); break;
+    case 16: hipLaunchKernelGGL((param_grads_kernel<16, 512>), grid, dim3(512), 0, st, a); break;
+    case 32: hipLaunchKernelGGL((param_grads_kernel<32, 512>), grid, dim3(512), 0, st, a); break;
+    case 64: hipLaunchKernelGGL((param_grads_kernel<64, 512>), grid, dim3(512), 0, st, a); break;
+    case 128: hipLaunchKernelGGL((param_grads_kernel<128, 512>), grid, dim3(512), 0, st, a); break;
+    default: return GATRES_E_UNSUPPORTED;
+  }
+  return gatres_launch_status();
+}
+
 extern "C" int gatres_fused_finish(const gatres_model_t* m, const gatres_graph_t* g, float* scratch, float* grads,
                                    const float* loss_part, float* loss, int32_t do_adam, float* params,
                                    float* exp_avg, float* exp_avg_sq, uint64_t* step_counter, double lr, double beta1,
@@ -1414,7 +1491,7 @@ extern "C" int gatres_fused_finish(const gatres_model_t* m, const gatres_graph_t
   if (do_adam && (!params || !exp_avg || !exp_avg_sq || !step_counter)) return GATRES_E_BADARG;
   if ((loss_part == nullptr) != (loss == nullptr)) return GATRES_E_BADARG;
   Layout L;
-  if (!make_layout(m, g->num_nodes, g->num_edges_gat, g->num_segments, &L)) return GATRES_E_UNSUPPORTED;
+  if (!make_layout_g(m, g, &L)) return GATRES_E_UNSUPPORTED;
   hipLaunchKernelGGL(reduce_adam_kernel, dim3((unsigned)((L.P + 255) / 256)), dim3(256), 0, gatres_stream(stream),
                      scratch + L.sc_slabs, g->num_segments, (long long)L.slab_stride, (long long)L.P, grads,
                      loss_part, loss, do_adam, params, exp_avg, exp_avg_sq,

@@ -25,7 +25,7 @@ extern "C" int64_t gatres_param_count(int32_t num_blocks, int32_t nc) {
 extern "C" int64_t gatres_saved_floats(const gatres_model_t* m, const gatres_graph_t* g) {
   Layout L;
   if (!g) return GATRES_E_BADARG;
-  if (!make_layout(m, g->num_nodes, g->num_edges_gat, g->num_segments, &L)) return GATRES_E_UNSUPPORTED;
+  if (!make_layout_g(m, g, &L)) return GATRES_E_UNSUPPORTED;
   int64_t total = L.saved_total;
   if (gatres_fused_supported(m, g)) {       // the fused kernels keep a segment-major copy instead (gatres_layout.h)
     const SegLayout S = make_seg_layout(L.nb, L.nc, g->max_segment_nodes, g->max_segment_edges_gat);
@@ -38,13 +38,13 @@ extern "C" int64_t gatres_saved_floats(const gatres_model_t* m, const gatres_gra
 extern "C" int64_t gatres_scratch_floats(const gatres_model_t* m, const gatres_graph_t* g) {
   Layout L;
   if (!g) return GATRES_E_BADARG;
-  return make_layout(m, g->num_nodes, g->num_edges_gat, g->num_segments, &L) ? L.scratch_total
+  return make_layout_g(m, g, &L) ? L.scratch_total
                                                                              : (int64_t)GATRES_E_UNSUPPORTED;
 }
 
 extern "C" int32_t gatres_num_slabs(const gatres_model_t* m, int32_t num_nodes) {
   Layout L;
-  return make_layout(m, num_nodes, 0, 0, &L) ? L.num_slabs : GATRES_E_UNSUPPORTED;
+  return make_layout(m, num_nodes, 0, 0, 0, &L) ? L.num_slabs : GATRES_E_UNSUPPORTED;
 }
 
 extern "C" const char* gatres_version(void) { return "gatres-gfx950 abi1"; }
@@ -66,7 +66,7 @@ extern "C" int gatres_model_forward_per_op(const gatres_model_t* m, const gatres
   if (!m || !g || !params || !x || !out || !scratch) return GATRES_E_BADARG;
   if (!gatres_aligned16(params) || !gatres_aligned16(saved) || !gatres_aligned16(scratch)) return GATRES_E_BADARG;
   Layout L;
-  if (!make_layout(m, g->num_nodes, g->num_edges_gat, g->num_segments, &L)) return GATRES_E_UNSUPPORTED;
+  if (!make_layout_g(m, g, &L)) return GATRES_E_UNSUPPORTED;
   const int N = g->num_nodes, nc = L.nc;
   float* y2 = scratch + L.sc_y2;
   float* xa = scratch + L.sc_xa;
@@ -101,6 +101,7 @@ extern "C" int gatres_model_backward(const gatres_model_t* m, const gatres_graph
     RC(gatres_fused_prepare_backward(m, g, params, scratch, stream));
     RC(gatres_fused_run(m, g, params, x, mask, nullptr, nullptr, const_cast<float*>(g_out), nullptr, g_x,
                         const_cast<float*>(saved), scratch, GATRES_PHASE_BACKWARD, stream));
+    RC(gatres_fused_param_grads(m, g, saved, scratch, stream));
     return gatres_fused_finish(m, g, scratch, grads, nullptr, nullptr, 0, nullptr, nullptr, nullptr, nullptr, 0, 0, 0,
                                0, 0, 1.f, stream);
   }
@@ -114,7 +115,7 @@ extern "C" int gatres_model_backward_per_op(const gatres_model_t* m, const gatre
   if (!m || !g || !params || !x || !g_out || !saved || !scratch || !grads) return GATRES_E_BADARG;
   if (!gatres_aligned16(params) || !gatres_aligned16(saved) || !gatres_aligned16(scratch)) return GATRES_E_BADARG;
   Layout L;
-  if (!make_layout(m, g->num_nodes, g->num_edges_gat, g->num_segments, &L)) return GATRES_E_UNSUPPORTED;
+  if (!make_layout_g(m, g, &L)) return GATRES_E_UNSUPPORTED;
   const int N = g->num_nodes, nc = L.nc, S = L.num_slabs;
   const int64_t st = L.slab_stride, w = 2LL * nc * nc;
   float* gp_cur = scratch + L.sc_gpa;

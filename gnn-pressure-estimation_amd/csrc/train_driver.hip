@@ -17,7 +17,7 @@ extern "C" int gatres_train_step(const gatres_train_step_t* ts, void* stream) {
   }
   if (fused) {
     Layout L;
-    if (!make_layout(&ts->model, N, ts->graph->num_edges_gat, ts->graph->num_segments, &L)) return GATRES_E_UNSUPPORTED;
+    if (!make_layout_g(&ts->model, ts->graph, &L)) return GATRES_E_UNSUPPORTED;
     float* loss_part = ts->scratch + L.sc_loss_part;
     const bool fwd = ts->phases & GATRES_PHASE_FORWARD, bwd = ts->phases & GATRES_PHASE_BACKWARD;
     const bool adam = ts->phases & GATRES_PHASE_ADAM;
@@ -31,6 +31,8 @@ extern "C" int gatres_train_step(const gatres_train_step_t* ts, void* stream) {
       rc = gatres_fused_run(&ts->model, ts->graph, ts->params, ts->x, ts->mask, ts->y, ts->out, ts->g_out, loss_part,
                             nullptr, ts->saved, ts->scratch,
                             GATRES_PHASE_FORWARD | GATRES_PHASE_LOSS | GATRES_PHASE_BACKWARD, stream);
+      if (rc) return rc;
+      rc = gatres_fused_param_grads(&ts->model, ts->graph, ts->saved, ts->scratch, stream);
       if (rc) return rc;
       return gatres_fused_finish(&ts->model, ts->graph, ts->scratch, ts->grads, loss_part, ts->loss, adam ? 1 : 0,
                                  ts->params, ts->exp_avg, ts->exp_avg_sq, ts->step_counter, ts->lr, ts->beta1,
@@ -46,6 +48,8 @@ extern "C" int gatres_train_step(const gatres_train_step_t* ts, void* stream) {
     if (bwd) {
       rc = gatres_fused_run(&ts->model, ts->graph, ts->params, ts->x, ts->mask, nullptr, nullptr, ts->g_out, nullptr,
                             nullptr, ts->saved, ts->scratch, GATRES_PHASE_BACKWARD, stream);
+      if (rc) return rc;
+      rc = gatres_fused_param_grads(&ts->model, ts->graph, ts->saved, ts->scratch, stream);
       if (rc) return rc;
       return gatres_fused_finish(&ts->model, ts->graph, ts->scratch, ts->grads, nullptr, nullptr, adam ? 1 : 0,
                                  ts->params, ts->exp_avg, ts->exp_avg_sq, ts->step_counter, ts->lr, ts->beta1,

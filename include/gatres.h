@@ -231,7 +231,10 @@ int gatres_model_backward_per_op(const gatres_model_t* m, const gatres_graph_t* 
  * Fused per-snapshot path (k_fused.hip): ONE launch carries every segment through the selected phases --
  * GATRES_PHASE_FORWARD (lin0 .. lin1), GATRES_PHASE_LOSS (masked MSE + d loss/d out; needs mask, y) and
  * GATRES_PHASE_BACKWARD (all gradients, as per-segment slabs in scratch) -- one workgroup per segment, neighbour
- * gathers of the forward pass served from LDS when a segment fits (C-Town at nc=32 does).  gatres_fused_finish
+ * gathers of the forward pass served from LDS when a segment fits (C-Town at nc=32 does).  The backward phase
+ * leaves the GATConv weight / attention-vector gradients to gatres_fused_param_grads (they are off the backward's
+ * dependency chain: one workgroup per (segment, block, conv) over the kept g_h tables in scratch), which must run
+ * between gatres_fused_run(BACKWARD) and gatres_fused_finish.  gatres_fused_finish
  * sums the slabs into grads[P] and optionally applies Adam and finalises the loss in the same pass.
  * gatres_model_forward/backward and gatres_train_step take this path whenever gatres_fused_supported().
  * loss_part: device float[num_segments + 1].  GATRES_PHASE_BACKWARD reads the transposed conv weights from scratch:
@@ -246,6 +249,8 @@ int gatres_fused_prepare_backward(const gatres_model_t* m, const gatres_graph_t*
 int gatres_fused_run(const gatres_model_t* m, const gatres_graph_t* g, const float* params, const float* x,
                      const uint8_t* mask, const float* y, float* out, float* g_out, float* loss_part, float* g_x,
                      float* saved, float* scratch, int32_t phases, void* stream);
+int gatres_fused_param_grads(const gatres_model_t* m, const gatres_graph_t* g, const float* saved, float* scratch,
+                             void* stream);
 int gatres_fused_finish(const gatres_model_t* m, const gatres_graph_t* g, float* scratch, float* grads,
                         const float* loss_part, float* loss, int32_t do_adam, float* params, float* exp_avg,
                         float* exp_avg_sq, uint64_t* step_counter, double lr, double beta1, double beta2,

@@ -27,7 +27,7 @@ print('shader clock MHz ~', (clk[1] - clk[0]) / ((clk[2] - s[0]) / 100.0))
 d = (s[1:] - s[:-1]) / 100.0   # us
 print("stamps", len(s), "total us", (s[-1] - s[0]) / 100.0)
 names_f = ["proj1", "agg1", "proj2", "agg2", "mean"]
-names_b = ["mean_bwd", "dst2", "src2", "pgrad2", "dw2", "dx2", "dst1", "src1", "pgrad1", "dw1", "dx1"]
+names_b = ["mean_bwd", "dst2", "src2", "dx2", "dst1", "src1", "dx1"]
 i = 0
 print("lin0 %.2f" % d[i]); i += 1
 acc = {}
