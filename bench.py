@@ -141,7 +141,7 @@ def time_fused(G, trainer, device, reps=50):
     m, plan = trainer.model, trainer.plan
     L = trainer
     PH = 2 | 16 | 4
-    lp = torch.zeros(plan.num_segments + 1, dtype=torch.float32, device=device)
+    lp = torch.zeros(8 * plan.num_segments + 1, dtype=torch.float32, device=device)
     args = (m._cmodel_ref(), plan.ref(), m.flat_parameters.data_ptr(), L.x.data_ptr(), L.mask.data_ptr(),
             L.y.data_ptr(), L.out.data_ptr(), L.g_out.data_ptr(), lp.data_ptr(), None, L.saved.data_ptr(),
             L.scratch.data_ptr(), PH)

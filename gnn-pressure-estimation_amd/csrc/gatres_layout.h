@@ -19,6 +19,10 @@ struct Layout {
   // fused path only: every block keeps its g_h / g_alpha tables until the deferred parameter-gradient launch
   // (k_fused.hip: param_grads_kernel) has consumed them.  Block-major, global node index.
   int64_t sc_keep, keep_stride, k_gh1, k_gh2, k_gas1, k_gad1, k_gas2, k_gad2;
+  // fused path, segments split over several CUs: flag lines (8 x 32 words per segment, + one error word at the
+  // end) and one partial slab row per (segment, part)
+  int split_max;
+  int64_t sc_flags, flag_words, sc_part_slabs;
   int num_slabs;      // node-range slabs of the per-op path
   int slab_rows;      // slabs allocated = max(num_slabs, segments)
   int64_t slab_stride;
@@ -32,6 +36,16 @@ static inline int num_slabs_for(int64_t P, int64_t N) {
   if (s > cap) s = cap;
   if (s < 1) s = 1;
   return (int)s;
+}
+
+// Most workgroups (CUs) one segment may be split over: a power of two <= 8 such that every workgroup of the grid
+// (segments rounded up to a multiple of 8, times the split) is resident at once on the 256 CUs of an MI355X -- the
+// parts of a segment wait for each other, so none may be left undispatched.
+static inline int split_max_for(int num_segments) {
+  const int padded = ((num_segments + 7) / 8) * 8;
+  int m = 1;
+  while (m < 8 && padded * (m * 2) <= 256) m *= 2;
+  return padded > 0 && padded <= 256 ? m : 1;
 }
 
 // fused_nodes: the plan's largest segment if the fused per-snapshot path can take it (fused_nodes_of), else 0
@@ -86,7 +100,11 @@ static inline bool make_layout(const gatres_model_t* m, int64_t N, int64_t Eg, i
   L->sc_gh2 = o;  o += r4(N * nc);
   L->slab_rows = L->num_slabs > num_segments ? L->num_slabs : num_segments;
   L->sc_slabs = o; o += (int64_t)L->slab_rows * L->slab_stride;
-  L->sc_loss_part = o; o += r4((int64_t)L->slab_rows + 1);
+  L->split_max = fused_nodes > 0 ? split_max_for(num_segments) : 1;
+  {
+    const int64_t lp = (int64_t)num_segments * L->split_max;
+    L->sc_loss_part = o; o += r4((lp > L->slab_rows ? lp : L->slab_rows) + 1);
+  }
   L->sc_keep = o;
   int64_t k = 0;
   L->k_gh1 = k;  k += r4(N * 2 * nc);
@@ -97,6 +115,10 @@ static inline bool make_layout(const gatres_model_t* m, int64_t N, int64_t Eg, i
   L->k_gad2 = k; k += r4(N);
   L->keep_stride = k;
   if (fused_nodes > 0) o += (int64_t)nb * k;
+  L->sc_flags = o;
+  L->flag_words = r4((int64_t)((num_segments + 7) / 8) * 8 * 8 * 32 + 32);
+  L->sc_part_slabs = o + L->flag_words;
+  if (L->split_max > 1) o += L->flag_words + (int64_t)num_segments * L->split_max * L->slab_stride;
   L->scratch_total = o;
   return true;
 }

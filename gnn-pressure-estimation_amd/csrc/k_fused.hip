@@ -50,6 +50,11 @@ struct FusedArgs {
   float* saved;             // may be null for inference
   float* scratch;
   float* slabs;
+  float* part_slabs;        // split segments: one slab row per (segment, part), folded by param_grads_kernel
+  unsigned* flags;          // split segments: 8 flag lines per segment
+  int* err;
+  int num_segments;
+  int M;                    // workgroups (CUs) per segment
   Layout L;
   SegLayout SL;             // segment-major saved activations (training)
   int phases;               // GATRES_PHASE_FORWARD | _BACKWARD, bit 16: loss
@@ -90,6 +95,11 @@ static bool nocache_fits(int nc, int threads, int n, int eg, int em) {
   return 12LL * threads + topo_bwd_bytes(n, eg, em) + wl_bytes(nc) <= LDS_BYTES && n <= 65535 && eg <= 65535 &&
          em <= 65535;
 }
+
+// Rows [lo, hi) of the segment that THIS workgroup computes.  One workgroup per segment owns all rows; when a segment
+// is split over several CUs (see group_sync) each part owns a 16-aligned window and the tables it gathers from are
+// completed from the partners' global copies after a flag barrier.
+struct Rows { int lo, hi; };
 
 // ------------------------------------------------------------------------------------------ small helpers
 template <int THREADS>
@@ -143,7 +153,7 @@ enum { EPI_NONE = 0, EPI_ATT = 1, EPI_RESID_MASK = 2 };
 // OUT[ob + r, :] = X[xb + r, :] @ Wm^T for r in [0, n).  Same lane map / k order as proj_kernel (k_proj.hip), so
 // results are bit-identical; each wave takes TWO 16-node tiles per trip and feeds both from one W fragment load.
 template <int K, int M, int H, int EPI, int THREADS, bool WLDS>
-__device__ __forceinline__ void seg_proj(int n, const float* X, int xb, const float* __restrict__ Wm, float* OUT,
+__device__ __forceinline__ void seg_proj(Rows rw, const float* X, int xb, const float* __restrict__ Wm, float* OUT,
                                          int ob, float* OUT2, int o2b, const float* __restrict__ att_src,
                                          const float* __restrict__ att_dst, float* as_g, float* ad_g, int ag_b,
                                          float* as_l, float* ad_l, const float* resid, int rb,
@@ -153,13 +163,14 @@ __device__ __forceinline__ void seg_proj(int n, const float* X, int xb, const fl
   constexpr int SC = (KQ % 4 == 0) ? 4 : ((KQ % 2 == 0) ? 2 : 1);
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int i = lane & 15, q = lane >> 4;
-  const int ntiles = (n + 15) >> 4;
+  if (rw.hi <= rw.lo) return;                                  // (workgroup-uniform) an empty part of a split segment
+  const int tlo = rw.lo >> 4, ntiles = (rw.hi + 15) >> 4;      // rw.lo is 16-aligned
 
   // the first tile's x fragment: in flight while W is staged
   float xcur[KQ], xnxt[KQ];
   {
-    const int r0 = wave * 16 + i;
-    load_frag<KQ>(X + (unsigned)((xb + min(r0, n - 1)) * K + q * KQ), xcur);
+    const int r0 = (tlo + wave) * 16 + i;
+    load_frag<KQ>(X + (unsigned)((xb + min(r0, rw.hi - 1)) * K + q * KQ), xcur);
   }
   // Stage W (rows padded to KP) and the attention vectors into LDS once per stage: every wave then feeds its MFMA
   // chain from 28-ns LDS reads instead of ~0.3-us L2 trips that the in-order wave exposes one after another.
@@ -254,11 +265,11 @@ __device__ __forceinline__ void seg_proj(int n, const float* X, int xb, const fl
   }
   // one 16-node tile per trip; the NEXT trip's x fragment is loaded before this trip's MFMA chain so its latency
   // hides behind the matrix work (a two-tiles-per-trip variant spilled at the 128-VGPR budget of a 16-wave workgroup)
-  for (int t0 = wave; t0 < ntiles; t0 += NW) {
+  for (int t0 = tlo + wave; t0 < ntiles; t0 += NW) {
     const int rA = t0 * 16 + i;
-    const bool okA = rA < n;
+    const bool okA = rA < rw.hi;
     const int rN = (t0 + NW) * 16 + i;
-    if (t0 + NW < ntiles) load_frag<KQ>(X + (unsigned)((xb + min(rN, n - 1)) * K + q * KQ), xnxt);   // uniform branch
+    if (t0 + NW < ntiles) load_frag<KQ>(X + (unsigned)((xb + min(rN, rw.hi - 1)) * K + q * KQ), xnxt);   // uniform branch
     f32x4 acc[NT];
 #pragma unroll
     for (int tt = 0; tt < NT; ++tt) acc[tt] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -429,10 +440,10 @@ __device__ __forceinline__ int max_of(const int (&d)[U]) {
 // K2 forward, sub-stage A: attention coefficients.  ONE thread per (row, head): no cross-lane traffic, one exp and
 // one divide per edge.  alpha goes to HBM (saved for the backward pass) and, when ALDS, to an LDS table for sub-stage B.
 template <int H, bool ALDS, int THREADS>
-__device__ __forceinline__ void seg_softmax(int n, const u16* rp, const u16* col, const float* asrc,
+__device__ __forceinline__ void seg_softmax(Rows rw, const u16* rp, const u16* col, const float* asrc,
                                             const float* adst_t, int ab, float* __restrict__ alpha_g, int eb,
                                             float* alpha_l) {
-  for (int idx = threadIdx.x; idx < n * H; idx += THREADS) {
+  for (int idx = rw.lo * H + threadIdx.x; idx < rw.hi * H; idx += THREADS) {
     const int r = idx / H, hd = idx % H;
     const int beg = rp[r], deg = (int)rp[r + 1] - beg;            // deg >= 1 (self loop)
     const float adst = adst_t[(unsigned)((ab + r) * H + hd)];
@@ -481,22 +492,22 @@ __device__ __forceinline__ void seg_softmax(int n, const u16* rp, const u16* col
 // TWO rows per lane group per trip (UR): one workgroup has no spare parallelism to hide the dependent LDS/L2 hops,
 // so the two rows' loads are issued together and their chains overlap.
 template <bool RELU, int H, int C, int THREADS, int UR = 2>
-__device__ __forceinline__ void seg_gather(int n, const u16* rp, const u16* col, const float* hsrc, int hb,
+__device__ __forceinline__ void seg_gather(Rows rw, const u16* rp, const u16* col, const float* hsrc, int hb,
                                            const float* alpha, int ab2, const float* __restrict__ bias, float* out,
-                                           int ob) {
+                                           int ob, float* out_pub = nullptr, int opb = 0) {
   constexpr int HC = H * C, G = HC / 4, RPP = THREADS / G;
   const int c0 = (threadIdx.x % G) * 4;
   const int hd = c0 / C;
   const float4 b = ld4(bias + c0);
-  const int rounds = (n + RPP * UR - 1) / (RPP * UR);
+  const int rounds = (rw.hi - rw.lo + RPP * UR - 1) / (RPP * UR);
   for (int it = 0; it < rounds; ++it) {
     int r[UR], beg[UR], deg[UR];
     bool valid[UR];
 #pragma unroll
     for (int u = 0; u < UR; ++u) {
-      r[u] = (it * UR + u) * RPP + threadIdx.x / G;
-      valid[u] = r[u] < n;
-      if (!valid[u]) r[u] = n - 1;
+      r[u] = rw.lo + (it * UR + u) * RPP + threadIdx.x / G;
+      valid[u] = r[u] < rw.hi;
+      if (!valid[u]) r[u] = rw.hi - 1;
     }
 #pragma unroll
     for (int u = 0; u < UR; ++u) { beg[u] = rp[r[u]]; deg[u] = (int)rp[r[u] + 1] - beg[u]; }
@@ -537,18 +548,21 @@ __device__ __forceinline__ void seg_gather(int n, const u16* rp, const u16* col,
         acc[u].x = fmaxf(acc[u].x, 0.f); acc[u].y = fmaxf(acc[u].y, 0.f);
         acc[u].z = fmaxf(acc[u].z, 0.f); acc[u].w = fmaxf(acc[u].w, 0.f);
       }
-      if (valid[u]) st4(out + (unsigned)((ob + r[u]) * HC + c0), acc[u]);
+      if (valid[u]) {
+        st4(out + (unsigned)((ob + r[u]) * HC + c0), acc[u]);
+        if (out_pub) st4(out_pub + (unsigned)((opb + r[u]) * HC + c0), acc[u]);
+      }
     }
   }
 }
 
 // K3 forward: out = relu(mean_{j->r} y[j] + x0[r]).  UR rows per lane group per trip.
 template <int C, int THREADS, int UR = 2>
-__device__ __forceinline__ void seg_mean_fwd(int n, int em, const u16* mrp, const u16* mcol, const float* y, int yb,
+__device__ __forceinline__ void seg_mean_fwd(Rows rw, int em, const u16* mrp, const u16* mcol, const float* y, int yb,
                                              const float* x0, int xb, float* out, int ob) {
   constexpr int G = C / 4, RPP = THREADS / G;
   const int c0 = (threadIdx.x % G) * 4;
-  const int rounds = (n + RPP * UR - 1) / (RPP * UR);
+  const int rounds = (rw.hi - rw.lo + RPP * UR - 1) / (RPP * UR);
   const int elast = max(em - 1, 0);
   for (int it = 0; it < rounds; ++it) {
     int r[UR], beg[UR], deg[UR];
@@ -556,9 +570,9 @@ __device__ __forceinline__ void seg_mean_fwd(int n, int em, const u16* mrp, cons
     float4 rr[UR], acc[UR];
 #pragma unroll
     for (int u = 0; u < UR; ++u) {
-      r[u] = (it * UR + u) * RPP + threadIdx.x / G;
-      valid[u] = r[u] < n;
-      if (!valid[u]) r[u] = n - 1;
+      r[u] = rw.lo + (it * UR + u) * RPP + threadIdx.x / G;
+      valid[u] = r[u] < rw.hi;
+      if (!valid[u]) r[u] = rw.hi - 1;
       acc[u] = f4zero();
     }
 #pragma unroll
@@ -602,11 +616,12 @@ __device__ __forceinline__ void seg_mean_fwd(int n, int em, const u16* mrp, cons
 
 // K3 backward: g_y[r] = sum over out-edges (r -> i) of g_pre[i] / max(indeg(i), 1)
 template <int C, int THREADS, int UR = 1>
-__device__ __forceinline__ void seg_mean_bwd(int n, int em, const u16* mrp, const u16* mtrp, const u16* mtdst,
-                                             const float* g_pre, int pb, float* g_y, int yb) {
+__device__ __forceinline__ void seg_mean_bwd(Rows rw, int em, const u16* mrp, const u16* mtrp, const u16* mtdst,
+                                             const float* g_pre, int pb, float* g_y, int yb,
+                                             float* g_y_pub = nullptr, int ypb = 0) {
   constexpr int G = C / 4, RPP = THREADS / G;
   const int c0 = (threadIdx.x % G) * 4;
-  const int rounds = (n + RPP * UR - 1) / (RPP * UR);
+  const int rounds = (rw.hi - rw.lo + RPP * UR - 1) / (RPP * UR);
   const int elast = max(em - 1, 0);
   for (int it = 0; it < rounds; ++it) {
     int r[UR], beg[UR], deg[UR];
@@ -614,9 +629,9 @@ __device__ __forceinline__ void seg_mean_bwd(int n, int em, const u16* mrp, cons
     float4 acc[UR];
 #pragma unroll
     for (int u = 0; u < UR; ++u) {
-      r[u] = (it * UR + u) * RPP + threadIdx.x / G;
-      valid[u] = r[u] < n;
-      if (!valid[u]) r[u] = n - 1;
+      r[u] = rw.lo + (it * UR + u) * RPP + threadIdx.x / G;
+      valid[u] = r[u] < rw.hi;
+      if (!valid[u]) r[u] = rw.hi - 1;
       acc[u] = f4zero();
     }
 #pragma unroll
@@ -658,7 +673,10 @@ __device__ __forceinline__ void seg_mean_bwd(int n, int em, const u16* mrp, cons
     }
 #pragma unroll
     for (int u = 0; u < UR; ++u)
-      if (valid[u]) st4(g_y + (unsigned)((yb + r[u]) * C + c0), acc[u]);
+      if (valid[u]) {
+        st4(g_y + (unsigned)((yb + r[u]) * C + c0), acc[u]);
+        if (g_y_pub) st4(g_y_pub + (unsigned)((ypb + r[u]) * C + c0), acc[u]);
+      }
   }
 }
 
@@ -668,21 +686,21 @@ __device__ __forceinline__ void seg_mean_bwd(int n, int em, const u16* mrp, cons
 //   B  seg_softmax_bwd : ONE thread per (row, head): S = sum alpha*ga ; g_e = alpha*(ga - S) * LeakyReLU' ;
 //                        g_a_dst = sum g_e.  Overwrites ga with g_e in place.
 template <int H, int C, int THREADS, int UR>
-__device__ __forceinline__ void seg_edge_dots(int n, int n0, const u16* rp, const u16* col, const float* g_out, int gb,
+__device__ __forceinline__ void seg_edge_dots(Rows rw, int n0, const u16* rp, const u16* col, const float* g_out, int gb,
                                               const float* __restrict__ h, float* g_e, int eb2) {
   constexpr int HC = H * C, G = HC / 4, LH = C / 4, RPP = THREADS / G;
   const int c0 = (threadIdx.x % G) * 4;
   const int hd = c0 / C;
-  const int rounds = (n + RPP * UR - 1) / (RPP * UR);
+  const int rounds = (rw.hi - rw.lo + RPP * UR - 1) / (RPP * UR);
   for (int it = 0; it < rounds; ++it) {
     int r[UR], beg[UR], deg[UR];
     bool leader[UR];
     float4 go[UR];
 #pragma unroll
     for (int u = 0; u < UR; ++u) {
-      r[u] = (it * UR + u) * RPP + threadIdx.x / G;
-      const bool valid = r[u] < n;         // every lane stays in the loop: the head reduction spans the head's lanes
-      if (!valid) r[u] = n - 1;
+      r[u] = rw.lo + (it * UR + u) * RPP + threadIdx.x / G;
+      const bool valid = r[u] < rw.hi;         // every lane stays in the loop: the head reduction spans the head's lanes
+      if (!valid) r[u] = rw.hi - 1;
       leader[u] = valid && (c0 % C) == 0;
     }
 #pragma unroll
@@ -721,11 +739,12 @@ __device__ __forceinline__ void seg_edge_dots(int n, int n0, const u16* rp, cons
 }
 
 template <int H, int THREADS>
-__device__ __forceinline__ void seg_softmax_bwd(int n, int n0, int e0, const u16* rp, const u16* col,
+__device__ __forceinline__ void seg_softmax_bwd(Rows rw, int n0, int e0, const u16* rp, const u16* col,
                                                 const float* __restrict__ alpha, const float* __restrict__ a_src,
                                                 const float* __restrict__ a_dst, float* g_e, int eb2,
-                                                float* g_a_dst, int db) {
-  for (int idx = threadIdx.x; idx < n * H; idx += THREADS) {
+                                                float* g_a_dst, int db, float* g_e_pub, int epb, float* g_ad_pub,
+                                                int dpb) {
+  for (int idx = rw.lo * H + threadIdx.x; idx < rw.hi * H; idx += THREADS) {
     const int r = idx / H, hd = idx % H;
     const int beg = rp[r], deg = (int)rp[r + 1] - beg;
     const float adst = a_dst[(unsigned)((n0 + r) * H + hd)];
@@ -748,7 +767,10 @@ __device__ __forceinline__ void seg_softmax_bwd(int n, int n0, int e0, const u16
       for (int k = 0; k < MAXD; ++k) {
         const float gs = al[k] * (ga[k] - S);
         const float ge = raw[k] > 0.f ? gs : gs * GATRES_NEG_SLOPE;
-        if (k < deg) g_e[(unsigned)((eb2 + beg + k) * H + hd)] = ge;
+        if (k < deg) {
+          g_e[(unsigned)((eb2 + beg + k) * H + hd)] = ge;
+          if (g_e_pub) g_e_pub[(unsigned)((epb + beg + k) * H + hd)] = ge;      // global copy for the partner CUs
+        }
         gad = gad + ge;                                                  // ge == 0 on padding slots
       }
     } else {
@@ -760,16 +782,18 @@ __device__ __forceinline__ void seg_softmax_bwd(int n, int n0, int e0, const u16
         const float rw = a_src[(unsigned)((n0 + (int)col[e]) * H + hd)] + adst;
         const float ge = rw > 0.f ? gs : gs * GATRES_NEG_SLOPE;
         g_e[(unsigned)((eb2 + e) * H + hd)] = ge;
+        if (g_e_pub) g_e_pub[(unsigned)((epb + e) * H + hd)] = ge;
         gad = gad + ge;
       }
     }
     g_a_dst[(unsigned)((db + r) * H + hd)] = gad;
+    if (g_ad_pub) g_ad_pub[(unsigned)((dpb + r) * H + hd)] = gad;
   }
 }
 
 // K2 backward, source-major over CSR^T.  UR rows per lane group per trip.
 template <int H, int C, int THREADS, int UR = 1>
-__device__ __forceinline__ void seg_agg_bwd_src(int n, int e0, const u16* trp, const u16* teid, const u16* tdst,
+__device__ __forceinline__ void seg_agg_bwd_src(Rows rw, int e0, const u16* trp, const u16* teid, const u16* tdst,
                                                 const float* g_out, int gb, const float* __restrict__ alpha,
                                                 const float* g_e, int eb2, const float* g_a_dst, int db,
                                                 const float* __restrict__ att_src,
@@ -779,7 +803,7 @@ __device__ __forceinline__ void seg_agg_bwd_src(int n, int e0, const u16* trp, c
   const int c0 = (threadIdx.x % G) * 4;
   const int hd = c0 / C;
   const float4 as = ld4(att_src + c0), ad = ld4(att_dst + c0);
-  const int rounds = (n + RPP * UR - 1) / (RPP * UR);
+  const int rounds = (rw.hi - rw.lo + RPP * UR - 1) / (RPP * UR);
   for (int it = 0; it < rounds; ++it) {
     int r[UR], beg[UR], deg[UR];
     bool valid[UR];
@@ -787,9 +811,9 @@ __device__ __forceinline__ void seg_agg_bwd_src(int n, int e0, const u16* trp, c
     float gas[UR];
 #pragma unroll
     for (int u = 0; u < UR; ++u) {
-      r[u] = (it * UR + u) * RPP + threadIdx.x / G;
-      valid[u] = r[u] < n;
-      if (!valid[u]) r[u] = n - 1;
+      r[u] = rw.lo + (it * UR + u) * RPP + threadIdx.x / G;
+      valid[u] = r[u] < rw.hi;
+      if (!valid[u]) r[u] = rw.hi - 1;
       acc[u] = f4zero();
       gas[u] = 0.f;
     }
@@ -889,17 +913,17 @@ __device__ __forceinline__ void seg_att_grads(int n, const float* __restrict__ h
 // already has: `part` (per-thread partial -> red) runs inside the softmax-backward stage, `finish` (HC threads sum
 // the row groups -> slab) at the start of the source-major stage.
 template <int HC, int THREADS>
-__device__ __forceinline__ void seg_bias_part(int n, const float* g_out, int gb, float* red) {
+__device__ __forceinline__ void seg_bias_part(Rows rw, const float* g_out, int gb, float* red) {
   constexpr int R = THREADS / HC;
   const int c = threadIdx.x % HC, rg = threadIdx.x / HC;
   float ab = 0.f;
   if (rg < R) {
-    for (int r0 = rg; r0 < n; r0 += 4 * R) {
+    for (int r0 = rw.lo + rg; r0 < rw.hi; r0 += 4 * R) {
       float go[4];
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
         const int r = r0 + k * R;
-        go[k] = r < n ? g_out[(unsigned)((gb + (r < n ? r : 0)) * HC + c)] : 0.f;
+        go[k] = r < rw.hi ? g_out[(unsigned)((gb + (r < rw.hi ? r : rw.lo)) * HC + c)] : 0.f;
       }
 #pragma unroll
       for (int k = 0; k < 4; ++k) ab += go[k];
@@ -919,7 +943,7 @@ __device__ __forceinline__ void seg_bias_finish(const float* red, float* __restr
 
 // lin1 backward for this segment: g_x = g_out (x) w (ReLU-masked), slab partials of g_w, g_b.
 template <int NC, int THREADS>
-__device__ __forceinline__ void seg_lin1_bwd(int n, int n0, const float* __restrict__ g_out,
+__device__ __forceinline__ void seg_lin1_bwd(Rows rw, int n0, const float* __restrict__ g_out,
                                              const float* __restrict__ x, const float* __restrict__ w, float* g_x,
                                              float* g_x2, float* __restrict__ slab_w, float* __restrict__ slab_b,
                                              int relu_mask, float* red) {
@@ -927,7 +951,7 @@ __device__ __forceinline__ void seg_lin1_bwd(int n, int n0, const float* __restr
   const int c = threadIdx.x % NC, rg = threadIdx.x / NC;
   const float wv = w[c];
   float aw = 0.f, ab = 0.f;
-  for (int r = rg; r < n; r += R) {
+  for (int r = rw.lo + rg; r < rw.hi; r += R) {
     const size_t node = (size_t)n0 + r;
     const float go = g_out[node];
     const float xv = x[(unsigned)(r * NC + c)];          // x: the segment's saved final activation, local rows
@@ -949,13 +973,13 @@ __device__ __forceinline__ void seg_lin1_bwd(int n, int n0, const float* __restr
 }
 
 template <int NC, int THREADS>
-__device__ __forceinline__ void seg_lin0_bwd(int n, int n0, const float* __restrict__ g, const float* __restrict__ x,
+__device__ __forceinline__ void seg_lin0_bwd(Rows rw, int n0, const float* __restrict__ g, const float* __restrict__ x,
                                              const uint8_t* __restrict__ mask, float* __restrict__ slab_w,
                                              float* __restrict__ slab_b, float* red) {
   constexpr int R = THREADS / NC;
   const int c = threadIdx.x % NC, rg = threadIdx.x / NC;
   float aw = 0.f, ab = 0.f;
-  for (int r = rg; r < n; r += R) {
+  for (int r = rw.lo + rg; r < rw.hi; r += R) {
     const size_t node = (size_t)n0 + r;
     const float xv = (mask && mask[node]) ? 0.f : x[node];
     const float gv = g[node * NC + c];
@@ -972,17 +996,87 @@ __device__ __forceinline__ void seg_lin0_bwd(int n, int n0, const float* __restr
   }
 }
 
+// ------------------------------------------------------------------------------------------ split segments
+// One segment may be carried by M workgroups on M CUs (M a power of two, chosen by the host so that every workgroup
+// of the grid is resident at once).  Part p owns a 16-aligned row window; the dense stages touch own rows only, the
+// sparse stages gather from neighbours, so at the six points per block where a stage reads rows that a partner
+// produced the parts meet in a flag barrier through global memory (~0.7 us on MI355X, tests/micro/xcu_sync.hip) and
+// then complete their LDS tables from the partners' global copies.  Workgroup ids of one segment differ by multiples
+// of 8: consecutive ids are dispatched round-robin over the 8 XCDs, so partners share an XCD and its L2.
+constexpr int FLAG_STRIDE = 32;                 // one 128-byte line per flag
+constexpr int SPIN_LIMIT = 1 << 20;             // a lost partner poisons the results instead of hanging the GPU
+
+struct Group {
+  unsigned* flags;        // this segment's M flags: epochs that keep counting across launches (all parts of a
+                          // segment pass the same number of barriers per launch, so they stay equal between
+                          // launches; the scratch buffer starts zeroed)
+  int M, part;
+  unsigned epoch;
+  int* err;
+  bool dead;              // (per thread) this poller gave up once: never spin again
+};
+
+template <int THREADS>
+__device__ __forceinline__ void group_sync(Group& g) {
+  __syncthreads();                               // every wave's global stores have been acknowledged by L2
+  if (g.M == 1) return;
+  ++g.epoch;
+  if (threadIdx.x == 0)
+    __hip_atomic_store(g.flags + g.part * FLAG_STRIDE, g.epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+  if ((int)threadIdx.x < g.M && (int)threadIdx.x != g.part && !g.dead) {
+    int spin = 0;
+    while ((int)(__hip_atomic_load(g.flags + threadIdx.x * FLAG_STRIDE, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) -
+                 g.epoch) < 0)
+      if (++spin > SPIN_LIMIT) { *g.err = 1; g.dead = true; break; }
+  }
+  __syncthreads();
+}
+
+// dst[k] = src[k] for k in [0, a) and [b, total): the partners' part of a table whose own part is [a, b).
+template <int THREADS>
+__device__ __forceinline__ void pull_flat(float* dst, const float* src, int a, int b, int total) {
+  const int cnt = a + (total - b);
+  for (int k = threadIdx.x; k < cnt; k += THREADS) {
+    const int j = k < a ? k : k - a + b;
+    dst[j] = src[j];
+  }
+}
+// same for rows of W floats (W % 4 == 0, 16-byte aligned tables), float4 at a time
+template <int THREADS>
+__device__ __forceinline__ void pull_rows4(float* dst, const float* src, int W, Rows rw, int n) {
+  const int a = rw.lo * (W / 4), b = rw.hi * (W / 4), total = n * (W / 4);
+  const int cnt = a + (total - b);
+  for (int k = threadIdx.x; k < cnt; k += THREADS) {
+    const int j = k < a ? k : k - a + b;
+    st4(dst + 4 * j, ld4(src + 4 * j));
+  }
+}
+
 // ------------------------------------------------------------------------------------------ the kernel
 template <int NC, int THREADS, bool CACHE>
 __global__ __launch_bounds__(THREADS) void gatres_fused_kernel(const FusedArgs a) {
   __shared__ __attribute__((aligned(16))) unsigned char lds_raw[LDS_BYTES];
   float* ldsf = reinterpret_cast<float*>(lds_raw);
   const Layout& L = a.L;
-  const int seg = blockIdx.x;
+  // workgroup id -> (segment, part): ids of one segment are 8 apart (same XCD)
+  const int M = a.M;
+  const int within = blockIdx.x % (8 * M);
+  const int seg = (blockIdx.x / (8 * M)) * 8 + (within & 7), part = within >> 3;
+  if (seg >= a.num_segments) return;
+  const bool split = M > 1;
   const int n0 = a.seg_ptr[seg], n = a.seg_ptr[seg + 1] - n0;
   const int e0 = a.rowptr[n0], eg = a.rowptr[n0 + n] - e0;            // GATConv edges of this segment
   const int em0 = a.m_rowptr[n0], em = a.m_rowptr[n0 + n] - em0;      // SimpleConv edges
   const int tid = threadIdx.x;
+  Rows rw;                                                            // own rows: whole 16-row tiles
+  {
+    const int tiles = (n + 15) >> 4;
+    rw.lo = 16 * (int)((long long)tiles * part / M);
+    rw.hi = min(n, 16 * (int)((long long)tiles * (part + 1) / M));
+  }
+  Group grp;
+  grp.flags = a.flags + (size_t)seg * 8 * FLAG_STRIDE; grp.M = M; grp.part = part; grp.err = a.err; grp.dead = false;
+  grp.epoch = M > 1 ? __hip_atomic_load(grp.flags + part * FLAG_STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
   // rows per lane group per trip: 16 waves x 128 VGPRs cannot hold more than this without spilling; 8 waves x 256 can
   constexpr int UF = THREADS <= 512 ? 4 : 2;     // forward gathers
   constexpr int UB = THREADS <= 512 ? 2 : 1;     // backward sparse stages
@@ -1036,7 +1130,7 @@ __global__ __launch_bounds__(THREADS) void gatres_fused_kernel(const FusedArgs a
     {  // lin0 (+ the caller-side x[mask] = 0)
       const float* w = P + L.p_lin0_w;
       const float* b = P + L.p_lin0_b;
-      for (int idx = tid; idx < n * (NC / 4); idx += THREADS) {
+      for (int idx = rw.lo * (NC / 4) + tid; idx < rw.hi * (NC / 4); idx += THREADS) {
         const int r = idx / (NC / 4), c0 = (idx % (NC / 4)) * 4;
         const size_t node = (size_t)n0 + r;
         const float xv = (a.mask && a.mask[node]) ? 0.f : a.x[node];
@@ -1054,57 +1148,72 @@ __global__ __launch_bounds__(THREADS) void gatres_fused_kernel(const FusedArgs a
       const float* pb = P + L.p_block0 + (int64_t)b * L.p_block_stride;
       float* y2g = sc + L.sc_y2;
       // conv1: K1, then K2 (+bias+ReLU)
-      seg_proj<NC, 2 * NC, 2, EPI_ATT, THREADS, WLDS>(n, xcur, nbS, pb + L.c1_W, base + o_h1, nbS, CACHE ? hA : nullptr, 0,
+      seg_proj<NC, 2 * NC, 2, EPI_ATT, THREADS, WLDS>(rw, xcur, nbS, pb + L.c1_W, base + o_h1, nbS, CACHE ? hA : nullptr, 0,
                                                  pb + L.c1_as, pb + L.c1_ad, base + o_as1, base + o_ad1, nbS,
                                                  CACHE ? sa : nullptr, CACHE ? sd : nullptr, nullptr, 0, nullptr, 0, wl1);
-      __syncthreads();
+      group_sync<THREADS>(grp);                   // the gathers below read every row of h1 / a_src
+      if (CACHE && split) {
+        pull_rows4<THREADS>(hA, base + o_h1 + (size_t)nbS * 2 * NC, 2 * NC, rw, n);
+        pull_flat<THREADS>(sa, base + o_as1 + (size_t)nbS * 2, rw.lo * 2, rw.hi * 2, n * 2);
+        __syncthreads();
+      }
       STAMP();
       // K2 conv1: softmax (alpha -> HBM + LDS: the h2 table is dead now), then the gather
       if (CACHE && 2 * eg <= n * NC) {           // (wave-uniform) the alpha table fits the borrowed region
-        seg_softmax<2, true, THREADS>(n, rp, col, sa, sd, 0, base + o_al1, ebS, hB);
+        seg_softmax<2, true, THREADS>(rw, rp, col, sa, sd, 0, base + o_al1, ebS, hB);
         __syncthreads();
-        seg_gather<true, 2, NC, THREADS, UF>(n, rp, col, hA, 0, hB, 0, pb + L.c1_b, base + o_o1, nbS);
+        seg_gather<true, 2, NC, THREADS, UF>(rw, rp, col, hA, 0, hB, 0, pb + L.c1_b, base + o_o1, nbS);
       } else if (CACHE) {
-        seg_softmax<2, false, THREADS>(n, rp, col, sa, sd, 0, base + o_al1, ebS, nullptr);
+        seg_softmax<2, false, THREADS>(rw, rp, col, sa, sd, 0, base + o_al1, ebS, nullptr);
         __syncthreads();
-        seg_gather<true, 2, NC, THREADS, UF>(n, rp, col, hA, 0, base + o_al1, ebS, pb + L.c1_b, base + o_o1, nbS);
+        seg_gather<true, 2, NC, THREADS, UF>(rw, rp, col, hA, 0, base + o_al1, ebS, pb + L.c1_b, base + o_o1, nbS);
       } else {
-        seg_softmax<2, false, THREADS>(n, rp, col, base + o_as1, base + o_ad1, nbS, base + o_al1, ebS, nullptr);
+        seg_softmax<2, false, THREADS>(rw, rp, col, base + o_as1, base + o_ad1, nbS, base + o_al1, ebS, nullptr);
         __syncthreads();
-        seg_gather<true, 2, NC, THREADS, UF>(n, rp, col, base + o_h1, nbS, base + o_al1, ebS, pb + L.c1_b, base + o_o1,
+        seg_gather<true, 2, NC, THREADS, UF>(rw, rp, col, base + o_h1, nbS, base + o_al1, ebS, pb + L.c1_b, base + o_o1,
                                          nbS);
       }
       __syncthreads();
       STAMP();
       // conv2
-      seg_proj<2 * NC, NC, 1, EPI_ATT, THREADS, WLDS>(n, base + o_o1, nbS, pb + L.c2_W, base + o_h2, nbS,
+      seg_proj<2 * NC, NC, 1, EPI_ATT, THREADS, WLDS>(rw, base + o_o1, nbS, pb + L.c2_W, base + o_h2, nbS,
                                                  CACHE ? hB : nullptr, 0, pb + L.c2_as, pb + L.c2_ad, base + o_as2,
                                                  base + o_ad2, nbS, CACHE ? sa : nullptr, CACHE ? sd : nullptr,
                                                  nullptr, 0, nullptr, 0, wl2);
-      __syncthreads();
+      group_sync<THREADS>(grp);
+      if (CACHE && split) {
+        pull_rows4<THREADS>(hB, base + o_h2 + (size_t)nbS * NC, NC, rw, n);
+        pull_flat<THREADS>(sa, base + o_as2 + (size_t)nbS, rw.lo, rw.hi, n);
+        __syncthreads();
+      }
       STAMP();
       // K2 conv2: alpha's LDS table sits in the upper half of the h1 region (y2 is written to the lower half)
+      float* y2pub = split ? y2g : nullptr;       // partners read y2 from the global copy
       if (CACHE && eg <= n * NC) {
         float* al2L = hA + (size_t)n * NC;
-        seg_softmax<1, true, THREADS>(n, rp, col, sa, sd, 0, base + o_al2, ebS, al2L);
+        seg_softmax<1, true, THREADS>(rw, rp, col, sa, sd, 0, base + o_al2, ebS, al2L);
         __syncthreads();
-        seg_gather<false, 1, NC, THREADS, UF>(n, rp, col, hB, 0, al2L, 0, pb + L.c2_b, hA, 0);
+        seg_gather<false, 1, NC, THREADS, UF>(rw, rp, col, hB, 0, al2L, 0, pb + L.c2_b, hA, 0, y2pub, n0);
       } else if (CACHE) {
-        seg_softmax<1, false, THREADS>(n, rp, col, sa, sd, 0, base + o_al2, ebS, nullptr);
+        seg_softmax<1, false, THREADS>(rw, rp, col, sa, sd, 0, base + o_al2, ebS, nullptr);
         __syncthreads();
-        seg_gather<false, 1, NC, THREADS, UF>(n, rp, col, hB, 0, base + o_al2, ebS, pb + L.c2_b, hA, 0);
+        seg_gather<false, 1, NC, THREADS, UF>(rw, rp, col, hB, 0, base + o_al2, ebS, pb + L.c2_b, hA, 0, y2pub, n0);
       } else {
-        seg_softmax<1, false, THREADS>(n, rp, col, base + o_as2, base + o_ad2, nbS, base + o_al2, ebS, nullptr);
+        seg_softmax<1, false, THREADS>(rw, rp, col, base + o_as2, base + o_ad2, nbS, base + o_al2, ebS, nullptr);
         __syncthreads();
-        seg_gather<false, 1, NC, THREADS, UF>(n, rp, col, base + o_h2, nbS, base + o_al2, ebS, pb + L.c2_b, y2g, n0);
+        seg_gather<false, 1, NC, THREADS, UF>(rw, rp, col, base + o_h2, nbS, base + o_al2, ebS, pb + L.c2_b, y2g, n0);
       }
-      __syncthreads();
+      group_sync<THREADS>(grp);                   // K3 averages y2 over neighbours
+      if (CACHE && split) {
+        pull_rows4<THREADS>(hA, y2g + (size_t)n0 * NC, NC, rw, n);
+        __syncthreads();
+      }
       STAMP();
       // K3
       if (CACHE)
-        seg_mean_fwd<NC, THREADS, UF>(n, em, mrp, mcol, hA, 0, xcur, nbS, xnext, nbS);
+        seg_mean_fwd<NC, THREADS, UF>(rw, em, mrp, mcol, hA, 0, xcur, nbS, xnext, nbS);
       else
-        seg_mean_fwd<NC, THREADS, UF>(n, em, mrp, mcol, y2g, n0, xcur, nbS, xnext, nbS);
+        seg_mean_fwd<NC, THREADS, UF>(rw, em, mrp, mcol, y2g, n0, xcur, nbS, xnext, nbS);
       __syncthreads();
       STAMP();
       xcur = xnext;
@@ -1113,11 +1222,11 @@ __global__ __launch_bounds__(THREADS) void gatres_fused_kernel(const FusedArgs a
       constexpr int G = NC / 4;
       const float4 wv = ld4(P + L.p_lin1_w + (tid % G) * 4);
       const float bias = P[L.p_lin1_b];
-      const int rounds = (n + THREADS / G - 1) / (THREADS / G);
+      const int rounds = (rw.hi - rw.lo + THREADS / G - 1) / (THREADS / G);
       for (int it = 0; it < rounds; ++it) {
-        int r = it * (THREADS / G) + tid / G;
-        const bool valid = r < n;
-        if (!valid) r = n - 1;
+        int r = rw.lo + it * (THREADS / G) + tid / G;
+        const bool valid = r < rw.hi;
+        if (!valid) r = rw.hi - 1;
         const float4 xv = ld4(xcur + (unsigned)((nbS + r) * NC + (tid % G) * 4));
         float d = xv.x * wv.x;
         d = fmaf(xv.y, wv.y, d); d = fmaf(xv.z, wv.z, d); d = fmaf(xv.w, wv.w, d);
@@ -1133,22 +1242,22 @@ __global__ __launch_bounds__(THREADS) void gatres_fused_kernel(const FusedArgs a
     // M = number of masked nodes in the WHOLE batch (every workgroup counts them itself: N bytes from L2)
     float cnt = 0.f;
     for (int i = tid; i < a.N; i += THREADS) cnt += a.mask[i] ? 1.f : 0.f;
-    const float M = block_sum<THREADS>(cnt, ldsf);
-    float part = 0.f;
-    for (int r = tid; r < n; r += THREADS) {
+    const float Mn = block_sum<THREADS>(cnt, ldsf);
+    float part_sum = 0.f;
+    for (int r = rw.lo + tid; r < rw.hi; r += THREADS) {
       const int node = n0 + r;
       if (a.mask[node]) {
         const float d = a.out[node] - a.y[node];
-        part = fmaf(d, d, part);
+        part_sum = fmaf(d, d, part_sum);
       }
     }
-    part = block_sum<THREADS>(part, ldsf);
+    part_sum = block_sum<THREADS>(part_sum, ldsf);
     if (tid == 0) {
-      a.loss_part[seg] = part;
-      if (seg == 0) a.loss_part[gridDim.x] = M;
+      a.loss_part[seg * M + part] = part_sum;
+      if (seg == 0 && part == 0) a.loss_part[a.num_segments * M] = Mn;
     }
-    const float scale = M > 0.f ? 2.f / M : 0.f;
-    for (int r = tid; r < n; r += THREADS) {
+    const float scale = Mn > 0.f ? 2.f / Mn : 0.f;
+    for (int r = rw.lo + tid; r < rw.hi; r += THREADS) {
       const int node = n0 + r;
       a.g_out[node] = a.mask[node] ? (a.out[node] - a.y[node]) * scale : 0.f;
     }
@@ -1157,13 +1266,13 @@ __global__ __launch_bounds__(THREADS) void gatres_fused_kernel(const FusedArgs a
   }
 
   if (a.phases & GATRES_PHASE_BACKWARD) {
-    // LDS map: [red 3*THREADS] ( [RA n x 2NC : g_pre | g_y2, later g_out1] [ge 2*eg] [gad 2n] [gas 2n] ) topology
+    // LDS map: [red 3*THREADS] ( [RA n x 2NC : g_pre | g_y2, later g_out1] [ge 2*eg] [gad 2n] [spare 2n] ) topology
     float* red = ldsf;
     float* RA = red + 3 * THREADS;
     float* geL = RA + (size_t)n * 2 * NC;
     float* gadL = geL + 2 * (size_t)even(eg);
-    float* gasL = gadL + 2 * (size_t)n;
-    u16* tp = reinterpret_cast<u16*>(CACHE ? (gasL + 2 * (size_t)n) : RA);
+    float* spareL = gadL + 2 * (size_t)n;
+    u16* tp = reinterpret_cast<u16*>(CACHE ? (spareL + 2 * (size_t)n) : RA);
     u16* rp = tp;              tp += even(n + 1);
     u16* col = tp;             tp += even(eg);
     u16* trp = tp;             tp += even(n + 1);
@@ -1188,9 +1297,11 @@ __global__ __launch_bounds__(THREADS) void gatres_fused_kernel(const FusedArgs a
 
     const SegLayout& SL = a.SL;
     const float* segbase = a.saved + (int64_t)seg * SL.total;
-    float* gp_cur = sc + L.sc_gpa;       // global copies of g_pre (row-wise residual reads)
+    float* gp_cur = sc + L.sc_gpa;       // global copies of g_pre (row-wise residual reads, partners' gathers)
     float* gp_nxt = sc + L.sc_gpb;
-    // gathered / small backward tables: LDS when CACHE, else global scratch (conv2 has private arrays: see Layout)
+    // gathered / small backward tables: LDS when CACHE, else global scratch (conv2 has private arrays: see Layout).
+    // With a split segment the LDS tables are completed from the *_pub global copies after each flag barrier.
+    const bool pub = CACHE && split;
     float* gpT = CACHE ? RA : nullptr;                                   // g_pre, LDS copy for the K3 gather
     float* gy2T = CACHE ? RA + (size_t)n * NC : sc + L.sc_gy2;  const int gy2b = CACHE ? 0 : n0;
     float* go1T = CACHE ? RA : sc + L.sc_go1;                   const int go1b = CACHE ? 0 : n0;
@@ -1198,12 +1309,12 @@ __global__ __launch_bounds__(THREADS) void gatres_fused_kernel(const FusedArgs a
     float* ge2T = CACHE ? geL : sc + L.sc_ge2;
     float* gad1T = CACHE ? gadL : sc + L.sc_gad;                const int gd_b = CACHE ? 0 : n0;
     float* gad2T = CACHE ? gadL : sc + L.sc_gad2;
-    float* slab = a.slabs + (int64_t)seg * L.slab_stride;
+    float* slab = split ? a.part_slabs + ((int64_t)seg * M + part) * L.slab_stride
+                        : a.slabs + (int64_t)seg * L.slab_stride;
     const int64_t w = 2LL * NC * NC;
     const float* xfinal = segbase + (int64_t)L.nb * SL.bstride + SL.xin;
-    seg_lin1_bwd<NC, THREADS>(n, n0, a.g_out, xfinal, P + L.p_lin1_w, gp_cur, gpT, slab + L.p_lin1_w,
+    seg_lin1_bwd<NC, THREADS>(rw, n0, a.g_out, xfinal, P + L.p_lin1_w, gp_cur, gpT, slab + L.p_lin1_w,
                               slab + L.p_lin1_b, L.nb > 0 ? 1 : 0, red);
-    __syncthreads();
     STAMP();
     for (int b = L.nb - 1; b >= 0; --b) {
       const float* base = segbase + (int64_t)b * SL.bstride;
@@ -1212,9 +1323,15 @@ __global__ __launch_bounds__(THREADS) void gatres_fused_kernel(const FusedArgs a
       float* sb = slab + po;
       const float* wt1 = a.wt + (int64_t)b * 2 * w;
       const float* wt2 = wt1 + w;
+      group_sync<THREADS>(grp);                  // K3 backward gathers g_pre of neighbours
+      const int elo = rp[rw.lo], ehi = rp[rw.hi];       // own in-edge range (edges are dst-sorted)
+      if (pub) {
+        pull_rows4<THREADS>(gpT, gp_cur + (size_t)n0 * NC, NC, rw, n);
+        __syncthreads();
+      }
       // K3 backward
-      if (CACHE) seg_mean_bwd<NC, THREADS, UB>(n, em, mrp, mtrp, mtdst, gpT, 0, gy2T, gy2b);
-      else       seg_mean_bwd<NC, THREADS, UB>(n, em, mrp, mtrp, mtdst, gp_cur, n0, gy2T, gy2b);
+      if (CACHE) seg_mean_bwd<NC, THREADS, UB>(rw, em, mrp, mtrp, mtdst, gpT, 0, gy2T, gy2b, pub ? sc + L.sc_gy2 : nullptr, n0);
+      else       seg_mean_bwd<NC, THREADS, UB>(rw, em, mrp, mtrp, mtdst, gp_cur, n0, gy2T, gy2b);
       __syncthreads();
       STAMP();
       // conv2.  g_h2 / g_alpha tables go to this block's kept area: dx2 reads g_h2 back, the deferred
@@ -1222,53 +1339,65 @@ __global__ __launch_bounds__(THREADS) void gatres_fused_kernel(const FusedArgs a
       float* keep = sc + L.sc_keep + (int64_t)b * L.keep_stride;
       float* gh = keep + L.k_gh1;
       float* gh2 = keep + L.k_gh2;
-      seg_edge_dots<1, NC, THREADS, 2>(n, 0, rp, col, gy2T, gy2b, base + SL.h2, ge2T, ge_b);
+      seg_edge_dots<1, NC, THREADS, 2>(rw, 0, rp, col, gy2T, gy2b, base + SL.h2, ge2T, ge_b);
       __syncthreads();
-      seg_bias_part<NC, THREADS>(n, gy2T, gy2b, red);
-      seg_softmax_bwd<1, THREADS>(n, 0, 0, rp, col, base + SL.al2, base + SL.as2, base + SL.ad2, ge2T, ge_b, gad2T,
-                                  gd_b);
-      __syncthreads();
+      seg_bias_part<NC, THREADS>(rw, gy2T, gy2b, red);
+      seg_softmax_bwd<1, THREADS>(rw, 0, 0, rp, col, base + SL.al2, base + SL.as2, base + SL.ad2, ge2T, ge_b, gad2T,
+                                  gd_b, pub ? sc + L.sc_ge2 : nullptr, e0, pub ? sc + L.sc_gad2 : nullptr, n0);
+      group_sync<THREADS>(grp);                  // the source-major stage reads g_y2 / g_e / g_a_dst of every dst
+      if (pub) {
+        pull_rows4<THREADS>(gy2T, sc + L.sc_gy2 + (size_t)n0 * NC, NC, rw, n);
+        pull_flat<THREADS>(ge2T, sc + L.sc_ge2 + e0, elo, ehi, eg);
+        pull_flat<THREADS>(gad2T, sc + L.sc_gad2 + n0, rw.lo, rw.hi, n);
+        __syncthreads();
+      }
       STAMP();
       seg_bias_finish<NC, THREADS>(red, sb + L.c2_b);
-      seg_agg_bwd_src<1, NC, THREADS, UB>(n, 0, trp, teid, tdst, gy2T, gy2b, base + SL.al2, ge2T, ge_b, gad2T, gd_b,
+      seg_agg_bwd_src<1, NC, THREADS, UB>(rw, 0, trp, teid, tdst, gy2T, gy2b, base + SL.al2, ge2T, ge_b, gad2T, gd_b,
                                       pb + L.c2_as, pb + L.c2_ad, gh2, n0, keep + L.k_gas2, keep + L.k_gad2);
       __syncthreads();         // g_y2 (RA) is dead: dx2 overwrites RA with g_out1
       STAMP();
-      seg_proj<NC, 2 * NC, 1, EPI_RESID_MASK, THREADS, WLDS>(n, gh2, n0, wt2, go1T, go1b, nullptr, 0, nullptr, nullptr,
-                                                        nullptr, nullptr, 0, nullptr, nullptr, nullptr, 0,
-                                                        base + SL.o1, 0, wlB);
+      seg_proj<NC, 2 * NC, 1, EPI_RESID_MASK, THREADS, WLDS>(rw, gh2, n0, wt2, go1T, go1b, pub ? sc + L.sc_go1 : nullptr,
+                                                        n0, nullptr, nullptr, nullptr, nullptr, 0, nullptr, nullptr,
+                                                        nullptr, 0, base + SL.o1, 0, wlB);
       __syncthreads();
       STAMP();
       // conv1
-      seg_edge_dots<2, NC, THREADS, 2>(n, 0, rp, col, go1T, go1b, base + SL.h1, ge1T, ge_b);
+      seg_edge_dots<2, NC, THREADS, 2>(rw, 0, rp, col, go1T, go1b, base + SL.h1, ge1T, ge_b);
       __syncthreads();
-      seg_bias_part<2 * NC, THREADS>(n, go1T, go1b, red);
-      seg_softmax_bwd<2, THREADS>(n, 0, 0, rp, col, base + SL.al1, base + SL.as1, base + SL.ad1, ge1T, ge_b, gad1T,
-                                  gd_b);
-      __syncthreads();
+      seg_bias_part<2 * NC, THREADS>(rw, go1T, go1b, red);
+      seg_softmax_bwd<2, THREADS>(rw, 0, 0, rp, col, base + SL.al1, base + SL.as1, base + SL.ad1, ge1T, ge_b, gad1T,
+                                  gd_b, pub ? sc + L.sc_ge : nullptr, e0, pub ? sc + L.sc_gad : nullptr, n0);
+      group_sync<THREADS>(grp);
+      if (pub) {
+        pull_rows4<THREADS>(go1T, sc + L.sc_go1 + (size_t)n0 * 2 * NC, 2 * NC, rw, n);
+        pull_flat<THREADS>(ge1T, sc + L.sc_ge + (size_t)e0 * 2, elo * 2, ehi * 2, eg * 2);
+        pull_flat<THREADS>(gad1T, sc + L.sc_gad + (size_t)n0 * 2, rw.lo * 2, rw.hi * 2, n * 2);
+        __syncthreads();
+      }
       STAMP();
       seg_bias_finish<2 * NC, THREADS>(red, sb + L.c1_b);
-      seg_agg_bwd_src<2, NC, THREADS, UB>(n, 0, trp, teid, tdst, go1T, go1b, base + SL.al1, ge1T, ge_b, gad1T, gd_b,
+      seg_agg_bwd_src<2, NC, THREADS, UB>(rw, 0, trp, teid, tdst, go1T, go1b, base + SL.al1, ge1T, ge_b, gad1T, gd_b,
                                       pb + L.c1_as, pb + L.c1_ad, gh, n0, keep + L.k_gas1, keep + L.k_gad1);
       __syncthreads();         // g_out1 (RA) is dead: dx1 writes the next g_pre into RA's low half
       STAMP();
       // d/d xin = conv1 path + residual, masked by the previous block's ReLU (block 0's input is lin0: no ReLU)
-      seg_proj<2 * NC, NC, 1, EPI_RESID_MASK, THREADS, WLDS>(n, gh, n0, wt1, gp_nxt, n0, gpT, 0, nullptr, nullptr, nullptr,
+      seg_proj<2 * NC, NC, 1, EPI_RESID_MASK, THREADS, WLDS>(rw, gh, n0, wt1, gp_nxt, n0, gpT, 0, nullptr, nullptr, nullptr,
                                                         nullptr, 0, nullptr, nullptr, gp_cur, n0,
                                                         b > 0 ? base + SL.xin : nullptr, 0, wlB);
-      __syncthreads();
       STAMP();
       float* t = gp_cur; gp_cur = gp_nxt; gp_nxt = t;
     }
-    seg_lin0_bwd<NC, THREADS>(n, n0, gp_cur, a.x, a.mask, slab + L.p_lin0_w, slab + L.p_lin0_b, red);
+    __syncthreads();
+    seg_lin0_bwd<NC, THREADS>(rw, n0, gp_cur, a.x, a.mask, slab + L.p_lin0_w, slab + L.p_lin0_b, red);
     if (a.g_x) {
       constexpr int G = NC / 4;
       const float4 wv = ld4(P + L.p_lin0_w + (tid % G) * 4);
-      const int rounds = (n + THREADS / G - 1) / (THREADS / G);
+      const int rounds = (rw.hi - rw.lo + THREADS / G - 1) / (THREADS / G);
       for (int it = 0; it < rounds; ++it) {
-        int r = it * (THREADS / G) + tid / G;
-        const bool valid = r < n;
-        if (!valid) r = n - 1;
+        int r = rw.lo + it * (THREADS / G) + tid / G;
+        const bool valid = r < rw.hi;
+        if (!valid) r = rw.hi - 1;
         const float4 xv = ld4(gp_cur + ((size_t)n0 + r) * NC + (tid % G) * 4);
         float d = xv.x * wv.x;
         d = fmaf(xv.y, wv.y, d); d = fmaf(xv.z, wv.z, d); d = fmaf(xv.w, wv.w, d);
@@ -1276,6 +1405,10 @@ __global__ __launch_bounds__(THREADS) void gatres_fused_kernel(const FusedArgs a
         if (valid && (tid % G) == 0) a.g_x[n0 + r] = d;
       }
     }
+  }
+  if (split && tid == 0 && *a.err) {        // a partner never arrived: make the failure visible in the results
+    if ((a.phases & GATRES_PHASE_FORWARD) && a.out) a.out[n0] = NAN;
+    if (a.phases & GATRES_PHASE_BACKWARD) a.slabs[(int64_t)seg * L.slab_stride + L.p_lin1_b] = NAN;
   }
   if (a.stamps && blockIdx.x == 0 && threadIdx.x == 0) {
     a.stamps[a.stamp_cap + 1] = clock64();
@@ -1292,9 +1425,21 @@ struct ParamGradArgs {
   const float* saved;
   const float* keep;
   float* slabs;
+  const float* part_slabs;
+  int M;
   Layout L;
   SegLayout SL;
 };
+
+// slab[off .. off+cnt) of a segment = sum over its parts' partial rows (fixed order)
+template <int THREADS>
+__device__ __forceinline__ void fold_parts(const ParamGradArgs& a, int seg, int64_t off, int cnt) {
+  for (int idx = threadIdx.x; idx < cnt; idx += THREADS) {
+    float sum = 0.f;
+    for (int p = 0; p < a.M; ++p) sum += a.part_slabs[((int64_t)seg * a.M + p) * a.L.slab_stride + off + idx];
+    a.slabs[(int64_t)seg * a.L.slab_stride + off + idx] = sum;
+  }
+}
 
 template <int NC, int THREADS>
 __global__ __launch_bounds__(THREADS) void param_grads_kernel(const ParamGradArgs a) {
@@ -1308,7 +1453,16 @@ __global__ __launch_bounds__(THREADS) void param_grads_kernel(const ParamGradArg
   const int n0 = a.seg_ptr[seg], n = a.seg_ptr[seg + 1] - n0;
   const float* base = a.saved + (int64_t)seg * SL.total + (int64_t)b * SL.bstride;
   const float* keep = a.keep + (int64_t)b * L.keep_stride;
-  float* sb = a.slabs + (int64_t)seg * L.slab_stride + L.p_block0 + (int64_t)b * L.p_block_stride;
+  const int64_t po = L.p_block0 + (int64_t)b * L.p_block_stride;
+  float* sb = a.slabs + (int64_t)seg * L.slab_stride + po;
+  if (a.M > 1) {          // bias / lin0 / lin1 partials of a split segment
+    if (conv == 0) fold_parts<THREADS>(a, seg, po + L.c1_b, 2 * NC);
+    else           fold_parts<THREADS>(a, seg, po + L.c2_b, NC);
+    if (b == 0 && conv == 0) {
+      fold_parts<THREADS>(a, seg, L.p_lin0_w, 2 * NC);
+      fold_parts<THREADS>(a, seg, L.p_lin1_w, NC + 1);
+    }
+  }
   if (conv == 0) {
     if constexpr (BLK) seg_dw_blk<2 * NC, NC, THREADS>(n, NW, keep + L.k_gh1, n0, base + SL.xin, 0, sb + L.c1_W, part);
     else               seg_dw<2 * NC, NC, THREADS>(n, keep + L.k_gh1, n0, base + SL.xin, 0, sb + L.c1_W, red);
@@ -1324,7 +1478,7 @@ __global__ __launch_bounds__(THREADS) void param_grads_kernel(const ParamGradArg
 
 // grads = sum of segment slabs (fixed order) ; optionally the Adam update and the loss finalisation in the same pass
 __global__ __launch_bounds__(256) void reduce_adam_kernel(const float* __restrict__ slabs, int num_slabs,
-                                                          long long stride, long long count,
+                                                          int num_loss, long long stride, long long count,
                                                           float* __restrict__ grads, const float* loss_part,
                                                           float* loss, int do_adam, float* __restrict__ p,
                                                           float* __restrict__ m, float* __restrict__ v,
@@ -1339,8 +1493,8 @@ __global__ __launch_bounds__(256) void reduce_adam_kernel(const float* __restric
   }
   if (loss_part && blockIdx.x == 0 && threadIdx.x == 0) {
     float s = 0.f;
-    for (int k = 0; k < num_slabs; ++k) s += loss_part[k];
-    loss[0] = s / loss_part[num_slabs];
+    for (int k = 0; k < num_loss; ++k) s += loss_part[k];
+    loss[0] = s / loss_part[num_loss];
   }
   __syncthreads();
   const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
@@ -1388,14 +1542,27 @@ static int fused_threads_small() {
 }
 static int threads_for(int nc) { return nc <= 32 ? fused_threads_small() : (nc == 64 ? 512 : 256); }
 
+// CUs per segment: the layout's co-residency bound, no more parts than 16-row tiles; GATRES_FUSED_SPLIT overrides
+static int fused_split(const Layout& L, const gatres_graph_t* g) {
+  int m = L.split_max < 4 ? L.split_max : 4;        // measured on C-Town / nc=32: 4 CUs per snapshot is the knee
+  if (const char* e = getenv("GATRES_FUSED_SPLIT")) {
+    const int v = atoi(e);
+    if (v >= 1 && v <= L.split_max && gatres_is_pow2(v)) m = v;
+  }
+  const int tiles = (g->max_segment_nodes + 15) / 16;
+  while (m > 1 && (m > tiles || L.nb == 0)) m >>= 1;
+  return m;
+}
+
 template <int NC, int THREADS>
 static int launch_fused(const FusedArgs& a, const gatres_graph_t* g, hipStream_t st) {
   const bool cache = !getenv("GATRES_FUSED_NOCACHE") &&
                      cache_fits(NC, THREADS, g->max_segment_nodes, g->max_segment_edges_gat, g->max_segment_edges_mean);
+  const dim3 grid((unsigned)(((g->num_segments + 7) / 8) * 8 * a.M));
   if (cache)
-    hipLaunchKernelGGL((gatres_fused_kernel<NC, THREADS, true>), dim3(g->num_segments), dim3(THREADS), 0, st, a);
+    hipLaunchKernelGGL((gatres_fused_kernel<NC, THREADS, true>), grid, dim3(THREADS), 0, st, a);
   else
-    hipLaunchKernelGGL((gatres_fused_kernel<NC, THREADS, false>), dim3(g->num_segments), dim3(THREADS), 0, st, a);
+    hipLaunchKernelGGL((gatres_fused_kernel<NC, THREADS, false>), grid, dim3(THREADS), 0, st, a);
   return gatres_launch_status();
 }
 
@@ -1445,6 +1612,11 @@ extern "C" int gatres_fused_run(const gatres_model_t* m, const gatres_graph_t* g
   a.params = params; a.wt = scratch + a.L.sc_wt;
   a.x = x; a.mask = mask; a.y = y; a.out = out; a.g_out = g_out; a.loss_part = loss_part; a.g_x = g_x;
   a.saved = saved; a.scratch = scratch; a.slabs = scratch + a.L.sc_slabs;
+  a.num_segments = g->num_segments;
+  a.M = fused_split(a.L, g);
+  a.flags = reinterpret_cast<unsigned*>(scratch + a.L.sc_flags);
+  a.err = reinterpret_cast<int*>(a.flags + a.L.flag_words - 32);
+  a.part_slabs = scratch + a.L.sc_part_slabs;
   a.SL = make_seg_layout(a.L.nb, a.L.nc, g->max_segment_nodes, g->max_segment_edges_gat);
   a.stamps = g_stamps; a.stamp_cap = g_stamp_cap;
   a.phases = (phases & (GATRES_PHASE_FORWARD | GATRES_PHASE_BACKWARD)) | ((phases & GATRES_PHASE_LOSS) ? PH_LOSS : 0);
@@ -1468,6 +1640,7 @@ extern "C" int gatres_fused_param_grads(const gatres_model_t* m, const gatres_gr
   if (!make_layout_g(m, g, &a.L)) return GATRES_E_UNSUPPORTED;
   if (a.L.nb == 0) return 0;
   a.seg_ptr = g->seg_ptr; a.saved = saved; a.keep = scratch + a.L.sc_keep; a.slabs = scratch + a.L.sc_slabs;
+  a.M = fused_split(a.L, g); a.part_slabs = scratch + a.L.sc_part_slabs;
   a.SL = make_seg_layout(a.L.nb, a.L.nc, g->max_segment_nodes, g->max_segment_edges_gat);
   const dim3 grid((unsigned)(2 * a.L.nb * g->num_segments));
   hipStream_t st = gatres_stream(stream);
@@ -1493,8 +1666,8 @@ extern "C" int gatres_fused_finish(const gatres_model_t* m, const gatres_graph_t
   Layout L;
   if (!make_layout_g(m, g, &L)) return GATRES_E_UNSUPPORTED;
   hipLaunchKernelGGL(reduce_adam_kernel, dim3((unsigned)((L.P + 255) / 256)), dim3(256), 0, gatres_stream(stream),
-                     scratch + L.sc_slabs, g->num_segments, (long long)L.slab_stride, (long long)L.P, grads,
-                     loss_part, loss, do_adam, params, exp_avg, exp_avg_sq,
+                     scratch + L.sc_slabs, g->num_segments, g->num_segments * fused_split(L, g),
+                     (long long)L.slab_stride, (long long)L.P, grads, loss_part, loss, do_adam, params, exp_avg, exp_avg_sq,
                      reinterpret_cast<unsigned long long*>(step_counter), lr, beta1, beta2, eps, weight_decay,
                      grad_scale);
   return gatres_launch_status();

@@ -267,7 +267,8 @@ class GATResMeanConv(nn.Module):
             n = lib.gatres_scratch_floats(self._cmodel_ref(), plan.ref())
             if n < 0:
                 _native.check(int(n), "gatres_scratch_floats")
-            self._scratch = {key: torch.empty(int(n), dtype=torch.float32, device=plan.device)}
+            # zeroed once: the split-segment barrier epochs of the fused kernel live in here (include/gatres.h)
+            self._scratch = {key: torch.zeros(int(n), dtype=torch.float32, device=plan.device)}
             buf = self._scratch[key]
         return buf
 

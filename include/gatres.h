@@ -237,7 +237,12 @@ int gatres_model_backward_per_op(const gatres_model_t* m, const gatres_graph_t* 
  * between gatres_fused_run(BACKWARD) and gatres_fused_finish.  gatres_fused_finish
  * sums the slabs into grads[P] and optionally applies Adam and finalises the loss in the same pass.
  * gatres_model_forward/backward and gatres_train_step take this path whenever gatres_fused_supported().
- * loss_part: device float[num_segments + 1].  GATRES_PHASE_BACKWARD reads the transposed conv weights from scratch:
+ * A segment may be carried by up to 8 workgroups on 8 CUs (flag barriers through scratch; the split is chosen so
+ * that the whole grid is resident; environment GATRES_FUSED_SPLIT=1|2|4|8 caps it).  The barrier epochs persist
+ * in `scratch` from launch to launch: ZERO the scratch buffer once after allocating it and do not share it between
+ * streams.  A partner that never arrives (e.g. the GPU is shared and the grid is not resident) turns out[first node
+ * of the segment] / the lin1 bias gradient into NaN instead of hanging.
+ * loss_part: device float[8 * num_segments + 1].  GATRES_PHASE_BACKWARD reads the transposed conv weights from scratch:
  * call gatres_fused_prepare_backward (one small launch) after the parameters last changed.
  * ------------------------------------------------------------------------------------------------------ */
 #define GATRES_PHASE_LOSS 16
