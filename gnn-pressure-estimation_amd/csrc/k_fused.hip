@@ -55,6 +55,7 @@ struct FusedArgs {
   int* err;
   int num_segments;
   int M;                    // workgroups (CUs) per segment
+  int safe_sync;            // diagnostic (GATRES_FUSED_SAFE_SYNC=1): always use agent-scope barriers
   Layout L;
   SegLayout SL;             // segment-major saved activations (training)
   int phases;               // GATRES_PHASE_FORWARD | _BACKWARD, bit 16: loss
@@ -1007,29 +1008,63 @@ constexpr int FLAG_STRIDE = 32;                 // one 128-byte line per flag
 constexpr int SPIN_LIMIT = 1 << 20;             // a lost partner poisons the results instead of hanging the GPU
 
 struct Group {
-  unsigned* flags;        // this segment's M flags: epochs that keep counting across launches (all parts of a
-                          // segment pass the same number of barriers per launch, so they stay equal between
-                          // launches; the scratch buffer starts zeroed)
+  unsigned* flags;        // this segment's M flag lines: word 0 = epoch, word 1 = the XCD the part runs on.  Epochs
+                          // keep counting across launches (all parts of a segment pass the same number of barriers
+                          // per launch, so they stay equal between launches; the scratch buffer starts zeroed)
   int M, part;
   unsigned epoch;
   int* err;
   bool dead;              // (per thread) this poller gave up once: never spin again
+  bool local;             // all parts run on one XCD (one L2): no L2 write-back / invalidate needed
 };
 
+__device__ __forceinline__ unsigned xcc_id() {
+  unsigned v;
+  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(v));
+  return v & 0xfu;
+}
+
+// Barrier over the M workgroups of a segment, making every global store issued before it visible to every part
+// after it.  Measured in tests/micro/xcu_sync.hip: with agent-scope release/acquire (L2 write-back + invalidate; the
+// only correct form when parts sit on different XCDs) every barrier costs microseconds once all 256 CUs do it; parts on
+// the SAME XCD share the L2, so after the workgroup barrier (s_waitcnt vmcnt(0): the stores are in L2) a relaxed
+// flag store, relaxed polling and one "buffer_inv sc1" (drops the CU's stale L1 lines; "sc0" does not) suffice.
 template <int THREADS>
 __device__ __forceinline__ void group_sync(Group& g) {
   __syncthreads();                               // every wave's global stores have been acknowledged by L2
   if (g.M == 1) return;
   ++g.epoch;
-  if (threadIdx.x == 0)
-    __hip_atomic_store(g.flags + g.part * FLAG_STRIDE, g.epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-  if ((int)threadIdx.x < g.M && (int)threadIdx.x != g.part && !g.dead) {
-    int spin = 0;
-    while ((int)(__hip_atomic_load(g.flags + threadIdx.x * FLAG_STRIDE, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) -
-                 g.epoch) < 0)
-      if (++spin > SPIN_LIMIT) { *g.err = 1; g.dead = true; break; }
+  if (threadIdx.x == 0) {
+    if (!g.local) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    __hip_atomic_store(g.flags + g.part * FLAG_STRIDE, g.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  if (threadIdx.x < 64) {                        // wave 0: lanes 0..M-1 poll one partner each
+    if ((int)threadIdx.x < g.M && (int)threadIdx.x != g.part && !g.dead) {
+      int spin = 0;
+      while ((int)(__hip_atomic_load(g.flags + threadIdx.x * FLAG_STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) -
+                   g.epoch) < 0)
+        if (++spin > SPIN_LIMIT) { *g.err = 1; g.dead = true; break; }
+    }
+    if (g.local) asm volatile("buffer_inv sc1" ::: "memory");
+    else         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
   }
   __syncthreads();
+}
+
+// First barrier of a launch: publishes the XCD ids (always with the safe agent-scope form) and decides `local`.
+template <int THREADS>
+__device__ __forceinline__ void group_init(Group& g) {
+  g.dead = false; g.local = false;
+  if (g.M == 1) { g.epoch = 0u; return; }
+  g.epoch = __hip_atomic_load(g.flags + g.part * FLAG_STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (threadIdx.x == 0)
+    __hip_atomic_store(g.flags + g.part * FLAG_STRIDE + 1, xcc_id(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  group_sync<THREADS>(g);
+  bool same = true;
+  const unsigned mine = xcc_id();
+  for (int p = 0; p < g.M; ++p)
+    same = same && (__hip_atomic_load(g.flags + p * FLAG_STRIDE + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == mine);
+  g.local = same;
 }
 
 // dst[k] = src[k] for k in [0, a) and [b, total): the partners' part of a table whose own part is [a, b).
@@ -1049,6 +1084,47 @@ __device__ __forceinline__ void pull_rows4(float* dst, const float* src, int W, 
   for (int k = threadIdx.x; k < cnt; k += THREADS) {
     const int j = k < a ? k : k - a + b;
     st4(dst + 4 * j, ld4(src + 4 * j));
+  }
+}
+
+// Halo lists.  A part only ever gathers partner rows that are NEIGHBOURS of its own rows, and the topology is the
+// same for every block, so each phase builds the list once in spare LDS: the forward list holds the remote sources
+// of own in-edges, the backward list the remote destinations (and edge ids) of own out-edges.  Duplicates are kept
+// (copies are idempotent).  With a locality-preserving node order (water networks are near-planar) the halo is a few
+// percent of the segment; if the list overflows the spare LDS the bulk pulls above are used instead.
+template <int THREADS>
+__device__ __forceinline__ int build_halo(const u16* ptr, const u16* idx, const u16* eid, Rows rw, u16* list,
+                                          u16* elist, int cap, int* counter) {
+  if (threadIdx.x == 0) *counter = 0;
+  __syncthreads();
+  const int beg = ptr[rw.lo], end = ptr[rw.hi];
+  for (int t = beg + threadIdx.x; t < end; t += THREADS) {
+    const int j = idx[t];
+    if (j < rw.lo || j >= rw.hi) {
+      const int pos = atomicAdd(counter, 1);
+      if (pos < cap) {
+        list[pos] = (u16)j;
+        if (elist) elist[pos] = eid[t];
+      }
+    }
+  }
+  __syncthreads();
+  return *counter;
+}
+template <int W, int THREADS>
+__device__ __forceinline__ void pull_list_rows(float* dst, const float* src, const u16* list, int cnt) {
+  constexpr int G = W / 4;
+  const int c0 = (threadIdx.x % G) * 4;
+  for (int k = threadIdx.x / G; k < cnt; k += THREADS / G) {
+    const int j = list[k];
+    st4(dst + j * W + c0, ld4(src + (unsigned)(j * W + c0)));
+  }
+}
+template <int H, int THREADS>
+__device__ __forceinline__ void pull_list_small(float* dst, const float* src, const u16* list, int cnt) {
+  for (int k = threadIdx.x; k < cnt * H; k += THREADS) {
+    const int j = list[k / H] * H + k % H;
+    dst[j] = src[j];
   }
 }
 
@@ -1075,8 +1151,9 @@ __global__ __launch_bounds__(THREADS) void gatres_fused_kernel(const FusedArgs a
     rw.hi = min(n, 16 * (int)((long long)tiles * (part + 1) / M));
   }
   Group grp;
-  grp.flags = a.flags + (size_t)seg * 8 * FLAG_STRIDE; grp.M = M; grp.part = part; grp.err = a.err; grp.dead = false;
-  grp.epoch = M > 1 ? __hip_atomic_load(grp.flags + part * FLAG_STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+  grp.flags = a.flags + (size_t)seg * 8 * FLAG_STRIDE; grp.M = M; grp.part = part; grp.err = a.err;
+  group_init<THREADS>(grp);
+  if (a.safe_sync) grp.local = false;
   // rows per lane group per trip: 16 waves x 128 VGPRs cannot hold more than this without spilling; 8 waves x 256 can
   constexpr int UF = THREADS <= 512 ? 4 : 2;     // forward gathers
   constexpr int UB = THREADS <= 512 ? 2 : 1;     // backward sparse stages
@@ -1141,6 +1218,17 @@ __global__ __launch_bounds__(THREADS) void gatres_fused_kernel(const FusedArgs a
       }
     }
     __syncthreads();
+    // forward halo list in the LDS left over behind the topology (the W slot only lives there when it is `priv`)
+    u16* hlist = tp + 2;
+    int hcnt = 0;
+    bool halo = false;
+    if (CACHE && split) {
+      const int cap = ((priv ? slot_b : LDS_BYTES) - used_b - 8) / 2;
+      if (cap > 0) {
+        hcnt = build_halo<THREADS>(rp, col, nullptr, rw, hlist, nullptr, cap, reinterpret_cast<int*>(tp));
+        halo = hcnt <= cap;
+      }
+    }
     STAMP();
     for (int b = 0; b < L.nb; ++b) {
       float* base = a.saved ? segbase + (int64_t)b * SL.bstride : sc + L.sc_ev;
@@ -1153,8 +1241,13 @@ __global__ __launch_bounds__(THREADS) void gatres_fused_kernel(const FusedArgs a
                                                  CACHE ? sa : nullptr, CACHE ? sd : nullptr, nullptr, 0, nullptr, 0, wl1);
       group_sync<THREADS>(grp);                   // the gathers below read every row of h1 / a_src
       if (CACHE && split) {
-        pull_rows4<THREADS>(hA, base + o_h1 + (size_t)nbS * 2 * NC, 2 * NC, rw, n);
-        pull_flat<THREADS>(sa, base + o_as1 + (size_t)nbS * 2, rw.lo * 2, rw.hi * 2, n * 2);
+        if (halo) {
+          pull_list_rows<2 * NC, THREADS>(hA, base + o_h1 + (size_t)nbS * 2 * NC, hlist, hcnt);
+          pull_list_small<2, THREADS>(sa, base + o_as1 + (size_t)nbS * 2, hlist, hcnt);
+        } else {
+          pull_rows4<THREADS>(hA, base + o_h1 + (size_t)nbS * 2 * NC, 2 * NC, rw, n);
+          pull_flat<THREADS>(sa, base + o_as1 + (size_t)nbS * 2, rw.lo * 2, rw.hi * 2, n * 2);
+        }
         __syncthreads();
       }
       STAMP();
@@ -1182,8 +1275,13 @@ __global__ __launch_bounds__(THREADS) void gatres_fused_kernel(const FusedArgs a
                                                  nullptr, 0, nullptr, 0, wl2);
       group_sync<THREADS>(grp);
       if (CACHE && split) {
-        pull_rows4<THREADS>(hB, base + o_h2 + (size_t)nbS * NC, NC, rw, n);
-        pull_flat<THREADS>(sa, base + o_as2 + (size_t)nbS, rw.lo, rw.hi, n);
+        if (halo) {
+          pull_list_rows<NC, THREADS>(hB, base + o_h2 + (size_t)nbS * NC, hlist, hcnt);
+          pull_list_small<1, THREADS>(sa, base + o_as2 + (size_t)nbS, hlist, hcnt);
+        } else {
+          pull_rows4<THREADS>(hB, base + o_h2 + (size_t)nbS * NC, NC, rw, n);
+          pull_flat<THREADS>(sa, base + o_as2 + (size_t)nbS, rw.lo, rw.hi, n);
+        }
         __syncthreads();
       }
       STAMP();
@@ -1205,7 +1303,8 @@ __global__ __launch_bounds__(THREADS) void gatres_fused_kernel(const FusedArgs a
       }
       group_sync<THREADS>(grp);                   // K3 averages y2 over neighbours
       if (CACHE && split) {
-        pull_rows4<THREADS>(hA, y2g + (size_t)n0 * NC, NC, rw, n);
+        if (halo) pull_list_rows<NC, THREADS>(hA, y2g + (size_t)n0 * NC, hlist, hcnt);
+        else      pull_rows4<THREADS>(hA, y2g + (size_t)n0 * NC, NC, rw, n);
         __syncthreads();
       }
       STAMP();
@@ -1315,6 +1414,18 @@ __global__ __launch_bounds__(THREADS) void gatres_fused_kernel(const FusedArgs a
     const float* xfinal = segbase + (int64_t)L.nb * SL.bstride + SL.xin;
     seg_lin1_bwd<NC, THREADS>(rw, n0, a.g_out, xfinal, P + L.p_lin1_w, gp_cur, gpT, slab + L.p_lin1_w,
                               slab + L.p_lin1_b, L.nb > 0 ? 1 : 0, red);
+    // backward halo list (remote dst rows + edge ids of own out-edges) in the LDS behind the W slot
+    u16* hrow = reinterpret_cast<u16*>(wlB + (WLDS ? ((WL_FLOATS + 3) & ~3) : 0)) + 2;
+    int hcnt = 0;
+    bool halo = false;
+    if (pub) {
+      const int cap = (int)((lds_raw + LDS_BYTES - reinterpret_cast<unsigned char*>(hrow)) / 4) - 4;
+      if (cap > 0) {
+        hcnt = build_halo<THREADS>(trp, tdst, teid, rw, hrow, hrow + cap, cap, reinterpret_cast<int*>(hrow - 2));
+        halo = hcnt <= cap;
+      }
+    }
+    const u16* hedge = hrow + ((int)((lds_raw + LDS_BYTES - reinterpret_cast<unsigned char*>(hrow)) / 4) - 4);
     STAMP();
     for (int b = L.nb - 1; b >= 0; --b) {
       const float* base = segbase + (int64_t)b * SL.bstride;
@@ -1326,7 +1437,8 @@ __global__ __launch_bounds__(THREADS) void gatres_fused_kernel(const FusedArgs a
       group_sync<THREADS>(grp);                  // K3 backward gathers g_pre of neighbours
       const int elo = rp[rw.lo], ehi = rp[rw.hi];       // own in-edge range (edges are dst-sorted)
       if (pub) {
-        pull_rows4<THREADS>(gpT, gp_cur + (size_t)n0 * NC, NC, rw, n);
+        if (halo) pull_list_rows<NC, THREADS>(gpT, gp_cur + (size_t)n0 * NC, hrow, hcnt);
+        else      pull_rows4<THREADS>(gpT, gp_cur + (size_t)n0 * NC, NC, rw, n);
         __syncthreads();
       }
       // K3 backward
@@ -1343,12 +1455,16 @@ __global__ __launch_bounds__(THREADS) void gatres_fused_kernel(const FusedArgs a
       __syncthreads();
       seg_bias_part<NC, THREADS>(rw, gy2T, gy2b, red);
       seg_softmax_bwd<1, THREADS>(rw, 0, 0, rp, col, base + SL.al2, base + SL.as2, base + SL.ad2, ge2T, ge_b, gad2T,
-                                  gd_b, pub ? sc + L.sc_ge2 : nullptr, e0, pub ? sc + L.sc_gad2 : nullptr, n0);
+                                  gd_b, pub ? sc + L.sc_ge2 : nullptr, e0, nullptr, 0);
       group_sync<THREADS>(grp);                  // the source-major stage reads g_y2 / g_e / g_a_dst of every dst
-      if (pub) {
-        pull_rows4<THREADS>(gy2T, sc + L.sc_gy2 + (size_t)n0 * NC, NC, rw, n);
-        pull_flat<THREADS>(ge2T, sc + L.sc_ge2 + e0, elo, ehi, eg);
-        pull_flat<THREADS>(gad2T, sc + L.sc_gad2 + n0, rw.lo, rw.hi, n);
+      if (pub) {                 // (g_a_dst is only read for own rows: no pull)
+        if (halo) {
+          pull_list_rows<NC, THREADS>(gy2T, sc + L.sc_gy2 + (size_t)n0 * NC, hrow, hcnt);
+          pull_list_small<1, THREADS>(ge2T, sc + L.sc_ge2 + e0, hedge, hcnt);
+        } else {
+          pull_rows4<THREADS>(gy2T, sc + L.sc_gy2 + (size_t)n0 * NC, NC, rw, n);
+          pull_flat<THREADS>(ge2T, sc + L.sc_ge2 + e0, elo, ehi, eg);
+        }
         __syncthreads();
       }
       STAMP();
@@ -1367,12 +1483,16 @@ __global__ __launch_bounds__(THREADS) void gatres_fused_kernel(const FusedArgs a
       __syncthreads();
       seg_bias_part<2 * NC, THREADS>(rw, go1T, go1b, red);
       seg_softmax_bwd<2, THREADS>(rw, 0, 0, rp, col, base + SL.al1, base + SL.as1, base + SL.ad1, ge1T, ge_b, gad1T,
-                                  gd_b, pub ? sc + L.sc_ge : nullptr, e0, pub ? sc + L.sc_gad : nullptr, n0);
+                                  gd_b, pub ? sc + L.sc_ge : nullptr, e0, nullptr, 0);
       group_sync<THREADS>(grp);
       if (pub) {
-        pull_rows4<THREADS>(go1T, sc + L.sc_go1 + (size_t)n0 * 2 * NC, 2 * NC, rw, n);
-        pull_flat<THREADS>(ge1T, sc + L.sc_ge + (size_t)e0 * 2, elo * 2, ehi * 2, eg * 2);
-        pull_flat<THREADS>(gad1T, sc + L.sc_gad + (size_t)n0 * 2, rw.lo * 2, rw.hi * 2, n * 2);
+        if (halo) {
+          pull_list_rows<2 * NC, THREADS>(go1T, sc + L.sc_go1 + (size_t)n0 * 2 * NC, hrow, hcnt);
+          pull_list_small<2, THREADS>(ge1T, sc + L.sc_ge + (size_t)e0 * 2, hedge, hcnt);
+        } else {
+          pull_rows4<THREADS>(go1T, sc + L.sc_go1 + (size_t)n0 * 2 * NC, 2 * NC, rw, n);
+          pull_flat<THREADS>(ge1T, sc + L.sc_ge + (size_t)e0 * 2, elo * 2, ehi * 2, eg * 2);
+        }
         __syncthreads();
       }
       STAMP();
@@ -1614,6 +1734,7 @@ extern "C" int gatres_fused_run(const gatres_model_t* m, const gatres_graph_t* g
   a.saved = saved; a.scratch = scratch; a.slabs = scratch + a.L.sc_slabs;
   a.num_segments = g->num_segments;
   a.M = fused_split(a.L, g);
+  a.safe_sync = getenv("GATRES_FUSED_SAFE_SYNC") ? 1 : 0;
   a.flags = reinterpret_cast<unsigned*>(scratch + a.L.sc_flags);
   a.err = reinterpret_cast<int*>(a.flags + a.L.flag_words - 32);
   a.part_slabs = scratch + a.L.sc_part_slabs;

@@ -28,12 +28,46 @@ __global__ __launch_bounds__(1024) void k_where(unsigned* out) {
 constexpr long long SPIN_LIMIT = 20000000;   // ~ tens of ms: a lost partner ends the test instead of hanging the GPU
 
 // Workgroups pa and pb ping-pong `iters` times.  flags[0]: a -> b, flags[1]: b -> a.  PAYLOAD floats per hand-off.
-template <int PAYLOAD>
+// MODE 0: agent-scope release / acquire (what the memory model asks for: L2 write-back + invalidate on a multi-XCD part)
+// MODE 1: relaxed agent-scope flag accesses + "buffer_inv sc0" (L1 only) on the consumer: enough when both CUs share an L2?
+// MODE 2: relaxed + "buffer_inv sc1"      MODE 3: relaxed, no invalidate (expected to read stale L1 lines)
+template <int MODE>
+__device__ __forceinline__ void flag_store(unsigned* f, unsigned v) {
+  if (MODE == 0) __hip_atomic_store(f, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+  else           __hip_atomic_store(f, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+template <int MODE>
+__device__ __forceinline__ bool flag_wait(unsigned* f, unsigned v) {
+  long long spin = 0;
+  bool ok = true;
+  if (MODE == 0) {
+    while (__hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != v) if (++spin > 20000000) { ok = false; break; }
+  } else {
+    while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != v) if (++spin > 20000000) { ok = false; break; }
+    if (MODE == 1) asm volatile("buffer_inv sc0" ::: "memory");
+    if (MODE == 2) asm volatile("buffer_inv sc1" ::: "memory");
+  }
+  return ok;
+}
+
+// background traffic: every other workgroup keeps writing its own 256-KB region (dirty L2 lines) until told to stop
+__device__ __forceinline__ void background(float* big, const unsigned* stop) {
+  float4* mine = reinterpret_cast<float4*>(big) + (size_t)blockIdx.x * 16384;
+  for (int it = 0; it < 200000; ++it) {
+    for (int k = threadIdx.x; k < 16384; k += 1024) mine[k] = make_float4(it, k, 0.f, 0.f);
+    if (__hip_atomic_load(stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
+  }
+}
+
+template <int PAYLOAD, int MODE, bool BG>
 __global__ __launch_bounds__(1024) void k_pingpong(int pa, int pb, unsigned* flags, float* buf, unsigned long long* t,
-                                                   float* sink, int iters, int* err) {
+                                                   float* sink, int iters, int* err, float* big) {
   extern __shared__ float lds[];
   const int me = blockIdx.x == pa ? 0 : (blockIdx.x == pb ? 1 : -1);
-  if (me < 0) return;
+  if (me < 0) {
+    if (BG) background(big, flags + 64);
+    return;
+  }
   float acc = 0.f;
   float4* mine = reinterpret_cast<float4*>(buf) + (size_t)me * (PAYLOAD / 4 + 1024);
   const float4* theirs = reinterpret_cast<const float4*>(buf) + (size_t)(1 - me) * (PAYLOAD / 4 + 1024);
@@ -44,27 +78,24 @@ __global__ __launch_bounds__(1024) void k_pingpong(int pa, int pb, unsigned* fla
       for (int k = threadIdx.x; k < PAYLOAD / 4; k += 1024) mine[k] = make_float4(it, it, it, k);
       __syncthreads();
       if (threadIdx.x == 0) {
-        __hip_atomic_store(&flags[0], (unsigned)it, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-        long long spin = 0;
-        while (__hip_atomic_load(&flags[1], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != (unsigned)it)
-          if (++spin > SPIN_LIMIT) { *err = 1; break; }
+        flag_store<MODE>(&flags[0], (unsigned)it);
+        if (!flag_wait<MODE>(&flags[32], (unsigned)it)) *err = 1;
       }
       __syncthreads();
       for (int k = threadIdx.x; k < PAYLOAD / 4; k += 1024) { const float4 v = theirs[k]; acc += v.x - (float)it; }
     } else {
-      if (threadIdx.x == 0) {
-        long long spin = 0;
-        while (__hip_atomic_load(&flags[0], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != (unsigned)it)
-          if (++spin > SPIN_LIMIT) { *err = 1; break; }
-      }
+      if (threadIdx.x == 0 && !flag_wait<MODE>(&flags[0], (unsigned)it)) *err = 1;
       __syncthreads();
       for (int k = threadIdx.x; k < PAYLOAD / 4; k += 1024) { const float4 v = theirs[k]; acc += v.x - (float)it; }
       for (int k = threadIdx.x; k < PAYLOAD / 4; k += 1024) mine[k] = make_float4(it, it, it, k);
       __syncthreads();
-      if (threadIdx.x == 0) __hip_atomic_store(&flags[1], (unsigned)it, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+      if (threadIdx.x == 0) flag_store<MODE>(&flags[32], (unsigned)it);
     }
   }
-  if (threadIdx.x == 0) t[me] = wall_clock64() - t0;
+  if (threadIdx.x == 0) {
+    t[me] = wall_clock64() - t0;
+    if (BG) __hip_atomic_store(flags + 64, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
   // acc must be exactly 0 if every payload read saw the value of its own iteration
   atomicAdd(sink, fabsf(acc));
 }
@@ -94,12 +125,11 @@ __global__ __launch_bounds__(1024) void k_group_barrier(int base, int stride, in
 
 int main() {
   const int G = 64, LDS = 160 * 1024;
-  unsigned* where; unsigned* flags; float* buf; unsigned long long* t; float* sink; int* err;
+  unsigned* where; unsigned* flags; float* buf; unsigned long long* t; float* sink; int* err; float* big;
+  CK(hipMalloc(&big, (size_t)64 * 16384 * 16));
   CK(hipMalloc(&where, 2 * G * 4)); CK(hipMalloc(&flags, 4096)); CK(hipMalloc(&buf, 4 << 20));
   CK(hipMalloc(&t, 64 * 8)); CK(hipMalloc(&sink, 4)); CK(hipMalloc(&err, 4));
   CK(hipFuncSetAttribute((const void*)k_where, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
-  CK(hipFuncSetAttribute((const void*)k_pingpong<0>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
-  CK(hipFuncSetAttribute((const void*)k_pingpong<12288>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
   CK(hipFuncSetAttribute((const void*)k_group_barrier, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
   hipLaunchKernelGGL(k_where, dim3(G), dim3(1024), LDS, 0, where);
   CK(hipDeviceSynchronize());
@@ -110,15 +140,29 @@ int main() {
   printf("HW_ID of wg 0, 1, 8, 9: %08x %08x %08x %08x\n", hw[1], hw[3], hw[17], hw[19]);
 
   const int iters = 2000;
-  auto pingpong = [&](const char* name, int pa, int pb, int payload) -> int {
+#define PP(PAY, MODE, BG) do { CK(hipFuncSetAttribute((const void*)k_pingpong<PAY, MODE, BG>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS)); \
+    hipLaunchKernelGGL((k_pingpong<PAY, MODE, BG>), dim3(G), dim3(1024), LDS, 0, pa, pb, flags, buf, t, sink, iters, err, big); } while (0)
+  auto pingpong = [&](const char* name, int pa, int pb, int variant) -> int {
     CK(hipMemset(flags, 0, 4096)); CK(hipMemset(sink, 0, 4)); CK(hipMemset(err, 0, 4)); CK(hipMemset(t, 0, 16));
-    if (payload) hipLaunchKernelGGL(k_pingpong<12288>, dim3(G), dim3(1024), LDS, 0, pa, pb, flags, buf, t, sink, iters, err);
-    else         hipLaunchKernelGGL(k_pingpong<0>, dim3(G), dim3(1024), LDS, 0, pa, pb, flags, buf, t, sink, iters, err);
+    switch (variant) {
+      case 0: PP(0, 0, false); break;
+      case 1: PP(12288, 0, false); break;
+      case 10: PP(12288, 0, true); break;
+      case 11: PP(12288, 1, true); break;
+      case 12: PP(12288, 2, true); break;
+      case 13: PP(12288, 3, true); break;
+      case 21: PP(12288, 1, false); break;
+      case 30: PP(512, 0, false); break;
+      case 31: PP(512, 1, false); break;
+      case 32: PP(512, 2, false); break;
+      case 33: PP(512, 3, false); break;
+      case 23: PP(12288, 3, false); break;
+    }
     CK(hipDeviceSynchronize());
     unsigned long long ht[2]; float hs; int he;
     CK(hipMemcpy(ht, t, 16, hipMemcpyDeviceToHost)); CK(hipMemcpy(&hs, sink, 4, hipMemcpyDeviceToHost));
     CK(hipMemcpy(&he, err, 4, hipMemcpyDeviceToHost));
-    printf("%-46s wg %2d <-> %2d (XCD %u / %u): %.3f us per ONE-WAY hand-off   stale-read sum %.1f  timeout %d\n", name, pa,
+    printf("%-52s wg %2d <-> %2d (XCD %u / %u): %.3f us per ONE-WAY hand-off   stale-read sum %.1f  timeout %d\n", name, pa,
            pb, hw[2 * pa], hw[2 * pb], ht[0] / 100.0 / iters / 2.0, hs, he);
     return 0;
   };
@@ -128,7 +172,20 @@ int main() {
     if (same < 0 && hw[2 * i] == hw[0]) same = i;
     if (diff < 0 && hw[2 * i] != hw[0]) diff = i;
   }
-  if (same > 0) { pingpong("flag only, same XCD", 0, same, 0); pingpong("flag + 48 KB payload, same XCD", 0, same, 1); }
+  if (same > 0) {
+    pingpong("flag only, same XCD", 0, same, 0);
+    pingpong("flag + 48 KB payload, same XCD", 0, same, 1);
+    pingpong("48 KB, relaxed + buffer_inv sc0, quiet", 0, same, 21);
+    pingpong("48 KB, relaxed, NO invalidate, quiet", 0, same, 23);
+    pingpong("2 KB (L1-resident), agent acq/rel", 0, same, 30);
+    pingpong("2 KB (L1-resident), relaxed + buffer_inv sc0", 0, same, 31);
+    pingpong("2 KB (L1-resident), relaxed + buffer_inv sc1", 0, same, 32);
+    pingpong("2 KB (L1-resident), relaxed, NO invalidate", 0, same, 33);
+    pingpong("48 KB, agent acq/rel, 62 WGs writing", 0, same, 10);
+    pingpong("48 KB, relaxed + buffer_inv sc0, 62 WGs writing", 0, same, 11);
+    pingpong("48 KB, relaxed + buffer_inv sc1, 62 WGs writing", 0, same, 12);
+    pingpong("48 KB, relaxed, NO invalidate, 62 WGs writing", 0, same, 13);
+  }
   if (diff > 0) { pingpong("flag only, different XCD", 0, diff, 0); pingpong("flag + 48 KB payload, different XCD", 0, diff, 1); }
 
   auto group = [&](const char* name, int base, int stride, int M) -> int {
