@@ -327,6 +327,7 @@ def main():
     if not (loss == loss) or loss > 1e6:
         raise SystemExit(f"training diverged (loss={loss})")
 
+    cus = G._native.load().gatres_fused_cus_per_segment(model._cmodel_ref(), trainer.plan.ref()) if trainer.fused else 0
     result = {
         "metric": "train snapshots/sec", "value": world * args.batch_size * args.steps / dt, "unit": "snapshots/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
@@ -334,7 +335,7 @@ def main():
         "config": {"workload": f"{args.model} ({nb} blocks, nc={nc}), C-Town-sized WDN ({args.nodes} nodes, "
                                f"{2 * args.pipes} directed edges), batch_size={args.batch_size} per GPU, fp32, "
                                f"full training step (device mask 0.95 -> fwd -> masked MSE -> bwd -> Adam), "
-                               f"{'per-op kernels' if not trainer.fused else 'fused per-snapshot kernel'}, "
+                               f"{'per-op kernels' if not trainer.fused else f'fused per-snapshot kernel ({cus} CUs per snapshot)'}, "
                                f"{'eager launches' if args.no_graph else 'hipGraph replay'}",
                    "global_batch": world * args.batch_size, "parallelism": f"dp{world}",
                    "final_loss": loss},
@@ -346,15 +347,18 @@ def main():
             log("timing the fused per-snapshot kernel ...")
             nbytes, nbytes_pg = algorithmic_bytes_per_step(table, N, nc, trainer.P, trainer.plan.num_segments, nb)
             us, us_pg = time_fused(G, trainer, device)
+            inline_pg = us_pg < 10.0         # a no-op call: the deferred gradients ran on consumer workgroups of the same launch
+            if inline_pg:
+                nbytes += nbytes_pg
             result["roofline"] = {"bound": "hbm", "kernel": "gatres_fused_kernel (forward+loss+backward, one launch)",
                                   "achieved": nbytes / us * 1e-3, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                   "frac": nbytes / us * 1e-3 / HBM_PEAK_GBS, "traffic": None,
                                   "avg_launch_us": us, "algorithmic_bytes_per_launch": nbytes,
                                   "algorithmic_bytes_per_snapshot": nbytes / args.batch_size,
-                                  "second_kernel": {"kernel": "param_grads_kernel (deferred dW / att gradients)",
-                                                    "avg_launch_us": us_pg,
-                                                    "algorithmic_bytes_per_launch": nbytes_pg,
-                                                    "achieved": nbytes_pg / us_pg * 1e-3}}
+                                  "second_kernel": None if inline_pg else
+                                  {"kernel": "param_grads_kernel (deferred dW / att gradients)",
+                                   "avg_launch_us": us_pg, "algorithmic_bytes_per_launch": nbytes_pg,
+                                   "achieved": nbytes_pg / us_pg * 1e-3}}
         else:
             log("per-kernel timing ...")
             rows = time_kernels(table, device)

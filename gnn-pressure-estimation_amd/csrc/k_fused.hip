@@ -56,6 +56,8 @@ struct FusedArgs {
   int num_segments;
   int M;                    // workgroups (CUs) per segment
   int safe_sync;            // diagnostic (GATRES_FUSED_SAFE_SYNC=1): always use agent-scope barriers
+  int C;                    // consumer workgroups per segment (deferred parameter gradients on spare CUs), 0 = none
+  unsigned* ready;          // [segment][4] lines: items published by the segment's part 0 for each consumer
   Layout L;
   SegLayout SL;             // segment-major saved activations (training)
   int phases;               // GATRES_PHASE_FORWARD | _BACKWARD, bit 16: loss
@@ -877,15 +879,15 @@ __device__ __forceinline__ void seg_att_grads(int n, const float* __restrict__ h
                                               const float* __restrict__ g_a_src, const float* __restrict__ g_a_dst,
                                               int db, float* __restrict__ slab_as, float* __restrict__ slab_ad,
                                               float* red) {
-  constexpr int HC = H * C, R = THREADS / HC;
+  constexpr int HC = H * C, R = THREADS / HC, U = 16;      // U rows in flight per thread: the loop is latency-bound
   const int c = threadIdx.x % HC, rg = threadIdx.x / HC;
   const int hd = c / C;
   float as = 0.f, ad = 0.f;
   if (rg < R) {
-    for (int r0 = rg; r0 < n; r0 += 4 * R) {
-      float hv[4], gs[4], gd[4];
+    for (int r0 = rg; r0 < n; r0 += U * R) {
+      float hv[U], gs[U], gd[U];
 #pragma unroll
-      for (int k = 0; k < 4; ++k) {
+      for (int k = 0; k < U; ++k) {
         const int r = r0 + k * R;
         const bool ok = r < n;
         const int rr = ok ? r : 0;
@@ -894,7 +896,7 @@ __device__ __forceinline__ void seg_att_grads(int n, const float* __restrict__ h
         gd[k] = ok ? g_a_dst[(size_t)(db + rr) * H + hd] : 0.f;
       }
 #pragma unroll
-      for (int k = 0; k < 4; ++k) {
+      for (int k = 0; k < U; ++k) {
         as = fmaf(gs[k], hv[k], as);
         ad = fmaf(gd[k], hv[k], ad);
       }
@@ -995,6 +997,77 @@ __device__ __forceinline__ void seg_lin0_bwd(Rows rw, int n0, const float* __res
     for (int k = 0; k < R; ++k) { s0 += red[k * NC + c]; s1 += red[THREADS + k * NC + c]; }
     slab_w[c] = s0; slab_b[c] = s1;
   }
+}
+
+// ------------------------------------------------------------------------------------------ deferred gradients
+// Deferred parameter gradients of the GATConvs.  Nothing on the backward's dependency chain reads dW / g_att, so
+// the per-snapshot workgroups only keep g_h and g_alpha_src / g_alpha_dst per block; one ITEM = (segment, block,
+// conv) turns them into slab entries (and folds the bias partials of a split segment).  Items run either on spare
+// CUs of the same launch (consumer workgroups, see gatres_fused_kernel) or in a second launch with one workgroup
+// per item (param_grads_kernel).  Writes are disjoint slab ranges: deterministic.
+struct ParamGradArgs {
+  const int* seg_ptr;
+  const float* saved;
+  const float* keep;
+  float* slabs;
+  const float* part_slabs;
+  int M;
+  Layout L;
+  SegLayout SL;
+};
+
+// slab[off .. off+cnt) of a segment = sum over its parts' partial rows (fixed order)
+template <int THREADS>
+__device__ __forceinline__ void fold_parts(const ParamGradArgs& a, int seg, int64_t off, int cnt) {
+  for (int idx = threadIdx.x; idx < cnt; idx += THREADS) {
+    float sum = 0.f;
+    for (int p = 0; p < a.M; ++p) sum += a.part_slabs[((int64_t)seg * a.M + p) * a.L.slab_stride + off + idx];
+    a.slabs[(int64_t)seg * a.L.slab_stride + off + idx] = sum;
+  }
+}
+
+// part: NW * 2*NC*NC floats of LDS when the block form applies (nc 16 / 32), red: 3 * THREADS floats
+template <int NC, int THREADS>
+__device__ __forceinline__ void param_grads_item(const ParamGradArgs& a, int seg, int b, int conv, bool fold_lin,
+                                                 float* part, float* red) {
+  constexpr bool BLK = NC >= 16 && NC <= 32;
+  constexpr int NW = THREADS / 64;
+  const Layout& L = a.L;
+  const SegLayout& SL = a.SL;
+  const int n0 = a.seg_ptr[seg], n = a.seg_ptr[seg + 1] - n0;
+  const float* base = a.saved + (int64_t)seg * SL.total + (int64_t)b * SL.bstride;
+  const float* keep = a.keep + (int64_t)b * L.keep_stride;
+  const int64_t po = L.p_block0 + (int64_t)b * L.p_block_stride;
+  float* sb = a.slabs + (int64_t)seg * L.slab_stride + po;
+  if (a.M > 1) {          // bias / lin0 / lin1 partials of a split segment
+    if (conv == 0) fold_parts<THREADS>(a, seg, po + L.c1_b, 2 * NC);
+    else           fold_parts<THREADS>(a, seg, po + L.c2_b, NC);
+    if (fold_lin) {
+      fold_parts<THREADS>(a, seg, L.p_lin0_w, 2 * NC);
+      fold_parts<THREADS>(a, seg, L.p_lin1_w, NC + 1);
+    }
+  }
+  if (conv == 0) {
+    if constexpr (BLK) seg_dw_blk<2 * NC, NC, THREADS>(n, NW, keep + L.k_gh1, n0, base + SL.xin, 0, sb + L.c1_W, part);
+    else               seg_dw<2 * NC, NC, THREADS>(n, keep + L.k_gh1, n0, base + SL.xin, 0, sb + L.c1_W, red);
+    seg_att_grads<2, NC, THREADS>(n, base + SL.h1, 0, keep + L.k_gas1, keep + L.k_gad1, n0, sb + L.c1_as,
+                                  sb + L.c1_ad, red);
+  } else {
+    if constexpr (BLK) seg_dw_blk<NC, 2 * NC, THREADS>(n, NW, keep + L.k_gh2, n0, base + SL.o1, 0, sb + L.c2_W, part);
+    else               seg_dw<NC, 2 * NC, THREADS>(n, keep + L.k_gh2, n0, base + SL.o1, 0, sb + L.c2_W, red);
+    seg_att_grads<1, NC, THREADS>(n, base + SL.h2, 0, keep + L.k_gas2, keep + L.k_gad2, n0, sb + L.c2_as,
+                                  sb + L.c2_ad, red);
+  }
+}
+
+template <int NC, int THREADS>
+__global__ __launch_bounds__(THREADS) void param_grads_kernel(const ParamGradArgs a) {
+  constexpr bool BLK = NC >= 16 && NC <= 32;
+  constexpr int NW = THREADS / 64;
+  __shared__ __attribute__((aligned(16))) float part[BLK ? NW * 2 * NC * NC : 4];
+  __shared__ float red[3 * THREADS];
+  const int conv = blockIdx.x & 1, b = (blockIdx.x >> 1) % a.L.nb, seg = (blockIdx.x >> 1) / a.L.nb;
+  param_grads_item<NC, THREADS>(a, seg, b, conv, b == 0 && conv == 0, part, red);
 }
 
 // ------------------------------------------------------------------------------------------ split segments
@@ -1128,6 +1201,61 @@ __device__ __forceinline__ void pull_list_small(float* dst, const float* src, co
   }
 }
 
+// Deferred-gradient items of a segment, in production order: item 2*(nb-1-b) is (block b, conv2), the next one
+// (block b, conv1); a split segment adds one last item that folds the lin0 / lin1 partials.  Part 0 publishes the
+// number of finished items after a barrier that all parts have passed; consumer c takes items c, c + C, ...
+template <int THREADS>
+__device__ __forceinline__ void publish_items(const FusedArgs& a, int seg, int part, int count) {
+  if (a.C > 0 && part == 0 && (int)threadIdx.x < a.C)
+    __hip_atomic_store(a.ready + ((size_t)seg * 4 + threadIdx.x) * FLAG_STRIDE, (unsigned)count, __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_AGENT);
+}
+
+template <int NC, int THREADS>
+__device__ __forceinline__ void consumer_main(const FusedArgs& a, int cid, float* ldsf) {
+  const int C = a.C;
+  const int within = cid % (8 * C);
+  const int seg = (cid / (8 * C)) * 8 + (within & 7), c = within >> 3;
+  if (seg >= a.num_segments) return;
+  ParamGradArgs pg;
+  pg.seg_ptr = a.seg_ptr; pg.saved = a.saved; pg.keep = a.scratch + a.L.sc_keep; pg.slabs = a.slabs;
+  pg.part_slabs = a.part_slabs; pg.M = a.M; pg.L = a.L; pg.SL = a.SL;
+  unsigned* my = a.ready + ((size_t)seg * 4 + c) * FLAG_STRIDE;
+  float* part = ldsf;
+  float* red = ldsf + (LDS_BYTES / 4 - 3 * THREADS);
+  const int nb = a.L.nb, items = 2 * nb + (a.M > 1 ? 1 : 0);
+  bool dead = false;
+  for (int i = c; i < items; i += C) {
+    if (threadIdx.x < 64) {
+      if (threadIdx.x == 0 && !dead) {
+        int spin = 0;
+        while ((int)__hip_atomic_load(my, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < i + 1)
+          if (++spin > SPIN_LIMIT) { *a.err = 1; dead = true; break; }
+        // the producers' XCD (published at their first barrier): the cheap hand-off below needs a shared L2
+        if (__hip_atomic_load(a.flags + (size_t)seg * 8 * FLAG_STRIDE + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) !=
+            xcc_id() && a.M > 1)
+          *a.err = 1;
+      }
+      asm volatile("buffer_inv sc1" ::: "memory");
+    }
+    __syncthreads();
+    if (i < 2 * nb) {
+      param_grads_item<NC, THREADS>(pg, seg, nb - 1 - i / 2, (i & 1) ? 0 : 1, false, part, red);
+    } else {
+      fold_parts<THREADS>(pg, seg, a.L.p_lin0_w, 2 * NC);
+      fold_parts<THREADS>(pg, seg, a.L.p_lin1_w, NC + 1);
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    // reset the line for the next launch -- only after the producer's LAST publication, or that one would survive
+    int spin = 0;
+    while (!dead && (int)__hip_atomic_load(my, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < items)
+      if (++spin > SPIN_LIMIT) { *a.err = 1; break; }
+    __hip_atomic_store(my, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
 // ------------------------------------------------------------------------------------------ the kernel
 template <int NC, int THREADS, bool CACHE>
 __global__ __launch_bounds__(THREADS) void gatres_fused_kernel(const FusedArgs a) {
@@ -1136,6 +1264,13 @@ __global__ __launch_bounds__(THREADS) void gatres_fused_kernel(const FusedArgs a
   const Layout& L = a.L;
   // workgroup id -> (segment, part): ids of one segment are 8 apart (same XCD)
   const int M = a.M;
+  {
+    const int F = ((a.num_segments + 7) / 8) * 8 * M;       // per-snapshot workgroups come first, consumers after
+    if ((int)blockIdx.x >= F) {
+      if constexpr (THREADS == 1024) consumer_main<NC, THREADS>(a, (int)blockIdx.x - F, ldsf);
+      return;
+    }
+  }
   const int within = blockIdx.x % (8 * M);
   const int seg = (blockIdx.x / (8 * M)) * 8 + (within & 7), part = within >> 3;
   if (seg >= a.num_segments) return;
@@ -1435,6 +1570,7 @@ __global__ __launch_bounds__(THREADS) void gatres_fused_kernel(const FusedArgs a
       const float* wt1 = a.wt + (int64_t)b * 2 * w;
       const float* wt2 = wt1 + w;
       group_sync<THREADS>(grp);                  // K3 backward gathers g_pre of neighbours
+      publish_items<THREADS>(a, seg, part, 2 * (L.nb - 1 - b));          // everything of the blocks above is kept
       const int elo = rp[rw.lo], ehi = rp[rw.hi];       // own in-edge range (edges are dst-sorted)
       if (pub) {
         if (halo) pull_list_rows<NC, THREADS>(gpT, gp_cur + (size_t)n0 * NC, hrow, hcnt);
@@ -1485,6 +1621,7 @@ __global__ __launch_bounds__(THREADS) void gatres_fused_kernel(const FusedArgs a
       seg_softmax_bwd<2, THREADS>(rw, 0, 0, rp, col, base + SL.al1, base + SL.as1, base + SL.ad1, ge1T, ge_b, gad1T,
                                   gd_b, pub ? sc + L.sc_ge : nullptr, e0, nullptr, 0);
       group_sync<THREADS>(grp);
+      publish_items<THREADS>(a, seg, part, 2 * (L.nb - 1 - b) + 1);      // this block's conv2 tables are complete
       if (pub) {
         if (halo) {
           pull_list_rows<2 * NC, THREADS>(go1T, sc + L.sc_go1 + (size_t)n0 * 2 * NC, hrow, hcnt);
@@ -1508,8 +1645,13 @@ __global__ __launch_bounds__(THREADS) void gatres_fused_kernel(const FusedArgs a
       STAMP();
       float* t = gp_cur; gp_cur = gp_nxt; gp_nxt = t;
     }
-    __syncthreads();
+    group_sync<THREADS>(grp);
+    publish_items<THREADS>(a, seg, part, 2 * L.nb);
     seg_lin0_bwd<NC, THREADS>(rw, n0, gp_cur, a.x, a.mask, slab + L.p_lin0_w, slab + L.p_lin0_b, red);
+    if (split && a.C > 0) {                   // last item: fold the lin0 / lin1 partial rows
+      group_sync<THREADS>(grp);
+      publish_items<THREADS>(a, seg, part, 2 * L.nb + 1);
+    }
     if (a.g_x) {
       constexpr int G = NC / 4;
       const float4 wv = ld4(P + L.p_lin0_w + (tid % G) * 4);
@@ -1533,66 +1675,6 @@ __global__ __launch_bounds__(THREADS) void gatres_fused_kernel(const FusedArgs a
   if (a.stamps && blockIdx.x == 0 && threadIdx.x == 0) {
     a.stamps[a.stamp_cap + 1] = clock64();
     a.stamps[a.stamp_cap + 2] = wall_clock64();
-  }
-}
-
-// Deferred parameter gradients of the GATConvs.  Nothing on the backward's dependency chain reads dW / g_att, so
-// the per-snapshot kernel only keeps g_h and g_alpha_src / g_alpha_dst per block and this launch turns them into
-// slab entries with one workgroup per (segment, block, conv): nb * 2 * segments workgroups, the whole chip, instead
-// of ~20 % of the per-snapshot kernel's single-CU time.  Writes are disjoint slab ranges: deterministic.
-struct ParamGradArgs {
-  const int* seg_ptr;
-  const float* saved;
-  const float* keep;
-  float* slabs;
-  const float* part_slabs;
-  int M;
-  Layout L;
-  SegLayout SL;
-};
-
-// slab[off .. off+cnt) of a segment = sum over its parts' partial rows (fixed order)
-template <int THREADS>
-__device__ __forceinline__ void fold_parts(const ParamGradArgs& a, int seg, int64_t off, int cnt) {
-  for (int idx = threadIdx.x; idx < cnt; idx += THREADS) {
-    float sum = 0.f;
-    for (int p = 0; p < a.M; ++p) sum += a.part_slabs[((int64_t)seg * a.M + p) * a.L.slab_stride + off + idx];
-    a.slabs[(int64_t)seg * a.L.slab_stride + off + idx] = sum;
-  }
-}
-
-template <int NC, int THREADS>
-__global__ __launch_bounds__(THREADS) void param_grads_kernel(const ParamGradArgs a) {
-  constexpr bool BLK = NC >= 16 && NC <= 32;
-  constexpr int NW = THREADS / 64;
-  __shared__ __attribute__((aligned(16))) float part[BLK ? NW * 2 * NC * NC : 4];
-  __shared__ float red[3 * THREADS];
-  const Layout& L = a.L;
-  const SegLayout& SL = a.SL;
-  const int conv = blockIdx.x & 1, b = (blockIdx.x >> 1) % L.nb, seg = (blockIdx.x >> 1) / L.nb;
-  const int n0 = a.seg_ptr[seg], n = a.seg_ptr[seg + 1] - n0;
-  const float* base = a.saved + (int64_t)seg * SL.total + (int64_t)b * SL.bstride;
-  const float* keep = a.keep + (int64_t)b * L.keep_stride;
-  const int64_t po = L.p_block0 + (int64_t)b * L.p_block_stride;
-  float* sb = a.slabs + (int64_t)seg * L.slab_stride + po;
-  if (a.M > 1) {          // bias / lin0 / lin1 partials of a split segment
-    if (conv == 0) fold_parts<THREADS>(a, seg, po + L.c1_b, 2 * NC);
-    else           fold_parts<THREADS>(a, seg, po + L.c2_b, NC);
-    if (b == 0 && conv == 0) {
-      fold_parts<THREADS>(a, seg, L.p_lin0_w, 2 * NC);
-      fold_parts<THREADS>(a, seg, L.p_lin1_w, NC + 1);
-    }
-  }
-  if (conv == 0) {
-    if constexpr (BLK) seg_dw_blk<2 * NC, NC, THREADS>(n, NW, keep + L.k_gh1, n0, base + SL.xin, 0, sb + L.c1_W, part);
-    else               seg_dw<2 * NC, NC, THREADS>(n, keep + L.k_gh1, n0, base + SL.xin, 0, sb + L.c1_W, red);
-    seg_att_grads<2, NC, THREADS>(n, base + SL.h1, 0, keep + L.k_gas1, keep + L.k_gad1, n0, sb + L.c1_as,
-                                  sb + L.c1_ad, red);
-  } else {
-    if constexpr (BLK) seg_dw_blk<NC, 2 * NC, THREADS>(n, NW, keep + L.k_gh2, n0, base + SL.o1, 0, sb + L.c2_W, part);
-    else               seg_dw<NC, 2 * NC, THREADS>(n, keep + L.k_gh2, n0, base + SL.o1, 0, sb + L.c2_W, red);
-    seg_att_grads<1, NC, THREADS>(n, base + SL.h2, 0, keep + L.k_gas2, keep + L.k_gad2, n0, sb + L.c2_as,
-                                  sb + L.c2_ad, red);
   }
 }
 
@@ -1674,11 +1756,24 @@ static int fused_split(const Layout& L, const gatres_graph_t* g) {
   return m;
 }
 
+// Consumer workgroups per segment for the deferred parameter gradients: only in launches that run the backward
+// phase, only with the 1024-thread kernel (the consumers reuse its LDS), and only if the whole grid -- per-snapshot
+// workgroups plus consumers, one per CU -- is still resident at once.
+static int fused_consumers(const Layout& L, const gatres_graph_t* g, int M) {
+  if (getenv("GATRES_FUSED_NO_CONSUMERS") || L.nb == 0 || threads_for(L.nc) != 1024) return 0;
+  const int padded = ((g->num_segments + 7) / 8) * 8;
+  int c = (256 - padded * M) / padded;
+  int cap = 2;             // measured: 1, 2 and 4 consumers per snapshot give the same step time
+  if (const char* e = getenv("GATRES_FUSED_CONSUMERS")) cap = atoi(e) < 4 ? atoi(e) : 4;
+  if (c > cap) c = cap;
+  return c > 0 ? c : 0;
+}
+
 template <int NC, int THREADS>
 static int launch_fused(const FusedArgs& a, const gatres_graph_t* g, hipStream_t st) {
   const bool cache = !getenv("GATRES_FUSED_NOCACHE") &&
                      cache_fits(NC, THREADS, g->max_segment_nodes, g->max_segment_edges_gat, g->max_segment_edges_mean);
-  const dim3 grid((unsigned)(((g->num_segments + 7) / 8) * 8 * a.M));
+  const dim3 grid((unsigned)(((g->num_segments + 7) / 8) * 8 * (a.M + a.C)));
   if (cache)
     hipLaunchKernelGGL((gatres_fused_kernel<NC, THREADS, true>), grid, dim3(THREADS), 0, st, a);
   else
@@ -1696,6 +1791,12 @@ extern "C" int gatres_fused_supported(const gatres_model_t* m, const gatres_grap
   if (g->max_segment_nodes > 4096) return 0;      // beyond this a snapshot should be spread over many CUs
   return nocache_fits(m->nc, threads_for(m->nc), g->max_segment_nodes, g->max_segment_edges_gat, g->max_segment_edges_mean)
              ? 1 : 0;
+}
+
+extern "C" int gatres_fused_cus_per_segment(const gatres_model_t* m, const gatres_graph_t* g) {
+  Layout L;
+  if (!gatres_fused_supported(m, g) || !make_layout_g(m, g, &L)) return 0;
+  return fused_split(L, g);
 }
 
 // Diagnostic: segment 0 of the next fused launches writes a 100 MHz wall-clock stamp at every stage boundary into
@@ -1735,8 +1836,10 @@ extern "C" int gatres_fused_run(const gatres_model_t* m, const gatres_graph_t* g
   a.num_segments = g->num_segments;
   a.M = fused_split(a.L, g);
   a.safe_sync = getenv("GATRES_FUSED_SAFE_SYNC") ? 1 : 0;
+  a.C = (phases & GATRES_PHASE_BACKWARD) ? fused_consumers(a.L, g, a.M) : 0;
   a.flags = reinterpret_cast<unsigned*>(scratch + a.L.sc_flags);
   a.err = reinterpret_cast<int*>(a.flags + a.L.flag_words - 32);
+  a.ready = a.flags + a.L.flag_words;
   a.part_slabs = scratch + a.L.sc_part_slabs;
   a.SL = make_seg_layout(a.L.nb, a.L.nc, g->max_segment_nodes, g->max_segment_edges_gat);
   a.stamps = g_stamps; a.stamp_cap = g_stamp_cap;
@@ -1760,6 +1863,7 @@ extern "C" int gatres_fused_param_grads(const gatres_model_t* m, const gatres_gr
   ParamGradArgs a;
   if (!make_layout_g(m, g, &a.L)) return GATRES_E_UNSUPPORTED;
   if (a.L.nb == 0) return 0;
+  if (fused_consumers(a.L, g, fused_split(a.L, g)) > 0) return 0;     // done by the backward launch's consumers
   a.seg_ptr = g->seg_ptr; a.saved = saved; a.keep = scratch + a.L.sc_keep; a.slabs = scratch + a.L.sc_slabs;
   a.M = fused_split(a.L, g); a.part_slabs = scratch + a.L.sc_part_slabs;
   a.SL = make_seg_layout(a.L.nb, a.L.nc, g->max_segment_nodes, g->max_segment_edges_gat);

@@ -198,40 +198,53 @@ __device__ __forceinline__ uint64_t mask_key(uint64_t seed, uint64_t step, int g
   return ((z >> 32) << 32) | (uint32_t)local;
 }
 
-__global__ __launch_bounds__(256) void mask_generate_kernel(const int* __restrict__ node_ptr, double rate,
-                                                            uint64_t seed, const uint64_t* __restrict__ step_counter,
-                                                            uint8_t* __restrict__ mask) {
-  constexpr int SMALL = 2048;                      // graphs up to this size: all-pairs rank in LDS (~1 us for C-Town)
+constexpr int MASK_WGS = 4;
+__global__ __launch_bounds__(1024) void mask_generate_kernel(const int* __restrict__ node_ptr, double rate,
+                                                             uint64_t seed, const uint64_t* __restrict__ step_counter,
+                                                             uint8_t* __restrict__ mask) {
+  constexpr int SMALL = 2048, T = 1024;            // graphs up to SMALL nodes: all-pairs rank in LDS (~2 us for C-Town)
   __shared__ uint64_t s_keys[SMALL];
+  __shared__ int s_rank[SMALL];
   __shared__ int hist[256];
   __shared__ uint64_t s_prefix;
   __shared__ int s_k;
-  const int g = blockIdx.x, tid = threadIdx.x;
+  // MASK_WGS workgroups per graph: each ranks one slice of the graph's nodes (the all-pairs compare is ALU work)
+  const int g = blockIdx.x / MASK_WGS, wq = blockIdx.x % MASK_WGS, tid = threadIdx.x;
   const int n0 = node_ptr[g], n = node_ptr[g + 1] - n0;
   const uint64_t step = step_counter ? step_counter[0] : 0;
   const int k = (int)((double)n * rate);          // Python: int(num_nodes * masking_rate)
   if (k <= 0) {
-    for (int v = tid; v < n; v += 256) mask[n0 + v] = 0;
+    if (wq == 0)
+      for (int v = tid; v < n; v += T) mask[n0 + v] = 0;
     return;
   }
+  if (n > SMALL && wq != 0) return;               // the radix-select path runs in one workgroup
   if (n <= SMALL) {
-    // keys are unique, so "masked" == "fewer than k keys are smaller than mine"
-    for (int v = tid; v < n; v += 256) s_keys[v] = mask_key(seed, step, n0 + v, v);
+    // keys are unique, so "masked" == "fewer than k keys are smaller than mine".  The n x n comparisons are spread
+    // over all threads: Q threads per node, each ranks the node against one slice of the keys.
+    for (int v = tid; v < n; v += T) { s_keys[v] = mask_key(seed, step, n0 + v, v); s_rank[v] = 0; }
     __syncthreads();
-    for (int v = tid; v < n; v += 256) {
+    const int Q = min(16, max(1, (n + 63) / 64));   // slices of ~64 keys: 7 for C-Town's 388 nodes
+    const int slice = (n + Q - 1) / Q;
+    const int per = (n + MASK_WGS - 1) / MASK_WGS, vlo = wq * per, vhi = min(n, vlo + per);
+    for (int w = tid; w < (vhi - vlo) * Q; w += T) {
+      const int v = vlo + w / Q, q = w % Q;
       const uint64_t mine = s_keys[v];
+      const int ub = q * slice, ue = min(n, ub + slice);
       int rank = 0;
-      for (int u = 0; u < n; ++u) rank += s_keys[u] < mine ? 1 : 0;      // broadcast LDS reads
-      mask[n0 + v] = rank < k ? 1 : 0;
+      for (int u = ub; u < ue; ++u) rank += s_keys[u] < mine ? 1 : 0;
+      if (Q == 1) s_rank[v] = rank; else atomicAdd(&s_rank[v], rank);
     }
+    __syncthreads();
+    for (int v = vlo + tid; v < vhi; v += T) mask[n0 + v] = s_rank[v] < k ? 1 : 0;
     return;
   }
   if (tid == 0) { s_prefix = 0; s_k = k; }
   for (int pass = 7; pass >= 0; --pass) {
-    hist[tid] = 0;
+    if (tid < 256) hist[tid] = 0;
     __syncthreads();
     const uint64_t prefix = s_prefix;
-    for (int v = tid; v < n; v += 256) {
+    for (int v = tid; v < n; v += T) {
       const uint64_t key = mask_key(seed, step, n0 + v, v);
       const bool match = (pass == 7) || ((key >> (8 * (pass + 1))) == prefix);
       if (match) atomicAdd(&hist[(int)((key >> (8 * pass)) & 255)], 1);
@@ -246,7 +259,7 @@ __global__ __launch_bounds__(256) void mask_generate_kernel(const int* __restric
     __syncthreads();
   }
   const uint64_t kth = s_prefix;
-  for (int v = tid; v < n; v += 256) mask[n0 + v] = mask_key(seed, step, n0 + v, v) <= kth ? 1 : 0;
+  for (int v = tid; v < n; v += T) mask[n0 + v] = mask_key(seed, step, n0 + v, v) <= kth ? 1 : 0;
 }
 
 // ------------------------------------------------------------------------------------------- masked MSE
@@ -407,7 +420,7 @@ extern "C" int gatres_edge_index_hash(const int64_t* edge_index, int64_t num_edg
 extern "C" int gatres_mask_generate(const int32_t* node_ptr, int32_t num_graphs, double mask_rate, uint64_t seed,
                                     const uint64_t* step_counter, uint8_t* mask, void* stream) {
   if (!node_ptr || !mask || num_graphs <= 0 || !(mask_rate >= 0.0 && mask_rate <= 1.0)) return GATRES_E_BADARG;
-  hipLaunchKernelGGL(mask_generate_kernel, dim3(num_graphs), dim3(256), 0, gatres_stream(stream), node_ptr, mask_rate,
+  hipLaunchKernelGGL(mask_generate_kernel, dim3(num_graphs * MASK_WGS), dim3(1024), 0, gatres_stream(stream), node_ptr, mask_rate,
                      seed, step_counter, mask);
   return gatres_launch_status();
 }
