@@ -133,6 +133,21 @@ def algorithmic_bytes_per_step(rows, N, nc, P, S, nb):
     return stages + small, deferred
 
 
+def pmc_traffic(args):
+    """HBM-side bytes per fused launch from the committed rocprofv3 --pmc passes (profiles/r01_fused_pmc_raw.json:
+    FETCH_SIZE and WRITE_SIZE collected in separate runs of this script, KB per launch; FETCH_SIZE doubled as
+    MI355X_MICROARCH.md prescribes for wide coalesced reads on gfx950).  Only for the workload they were taken on."""
+    if args.model != "gatres_small" or args.batch_size != 32 or args.nodes != 388 or args.per_op:
+        return None
+    try:
+        import json
+        with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_fused_pmc_raw.json")) as f:
+            raw = json.load(f)
+        return int((2.0 * raw["FETCH_SIZE"]["mean_counter_value_KB"] + raw["WRITE_SIZE"]["mean_counter_value_KB"]) * 1024)
+    except Exception:
+        return None
+
+
 def time_fused(G, trainer, device, reps=50):
     """Average duration of the fused per-snapshot kernel (forward + loss + backward in ONE launch), HIP events on
     the launch stream."""
@@ -352,7 +367,7 @@ def main():
                 nbytes += nbytes_pg
             result["roofline"] = {"bound": "hbm", "kernel": "gatres_fused_kernel (forward+loss+backward, one launch)",
                                   "achieved": nbytes / us * 1e-3, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                  "frac": nbytes / us * 1e-3 / HBM_PEAK_GBS, "traffic": None,
+                                  "frac": nbytes / us * 1e-3 / HBM_PEAK_GBS, "traffic": pmc_traffic(args),
                                   "avg_launch_us": us, "algorithmic_bytes_per_launch": nbytes,
                                   "algorithmic_bytes_per_snapshot": nbytes / args.batch_size,
                                   "second_kernel": None if inline_pg else
