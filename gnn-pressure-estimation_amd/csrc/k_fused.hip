@@ -56,6 +56,7 @@ struct FusedArgs {
   int num_segments;
   int M;                    // workgroups (CUs) per segment
   int safe_sync;            // diagnostic (GATRES_FUSED_SAFE_SYNC=1): always use agent-scope barriers
+  int no_halo;              // diagnostic (GATRES_FUSED_NO_HALO=1): always take the bulk-pull fallback
   int C;                    // consumer workgroups per segment (deferred parameter gradients on spare CUs), 0 = none
   unsigned* ready;          // [segment][4] lines: items published by the segment's part 0 for each consumer
   Layout L;
@@ -1359,7 +1360,7 @@ __global__ __launch_bounds__(THREADS) void gatres_fused_kernel(const FusedArgs a
     bool halo = false;
     if (CACHE && split) {
       const int cap = ((priv ? slot_b : LDS_BYTES) - used_b - 8) / 2;
-      if (cap > 0) {
+      if (cap > 0 && !a.no_halo) {
         hcnt = build_halo<THREADS>(rp, col, nullptr, rw, hlist, nullptr, cap, reinterpret_cast<int*>(tp));
         halo = hcnt <= cap;
       }
@@ -1555,7 +1556,7 @@ __global__ __launch_bounds__(THREADS) void gatres_fused_kernel(const FusedArgs a
     bool halo = false;
     if (pub) {
       const int cap = (int)((lds_raw + LDS_BYTES - reinterpret_cast<unsigned char*>(hrow)) / 4) - 4;
-      if (cap > 0) {
+      if (cap > 0 && !a.no_halo) {
         hcnt = build_halo<THREADS>(trp, tdst, teid, rw, hrow, hrow + cap, cap, reinterpret_cast<int*>(hrow - 2));
         halo = hcnt <= cap;
       }
@@ -1836,6 +1837,7 @@ extern "C" int gatres_fused_run(const gatres_model_t* m, const gatres_graph_t* g
   a.num_segments = g->num_segments;
   a.M = fused_split(a.L, g);
   a.safe_sync = getenv("GATRES_FUSED_SAFE_SYNC") ? 1 : 0;
+  a.no_halo = getenv("GATRES_FUSED_NO_HALO") ? 1 : 0;
   a.C = (phases & GATRES_PHASE_BACKWARD) ? fused_consumers(a.L, g, a.M) : 0;
   a.flags = reinterpret_cast<unsigned*>(scratch + a.L.sc_flags);
   a.err = reinterpret_cast<int*>(a.flags + a.L.flag_words - 32);

@@ -296,6 +296,48 @@ def test_fused_equals_per_op_bitwise_forward(pkg, oracle):
         assert relerr(gf, gp) < 2e-5, (nb, nc, nodes, relerr(gf, gp))
 
 
+@pytest.mark.parametrize("split,mode", [(1, ""), (2, ""), (4, ""), (8, ""), (4, "GATRES_FUSED_NO_HALO"),
+                                        (4, "GATRES_FUSED_SAFE_SYNC"), (2, "GATRES_FUSED_NO_CONSUMERS")])
+def test_fused_split_over_cus_matches_per_op(pkg, oracle, split, mode, monkeypatch):
+    """One snapshot carried by 1 / 2 / 4 / 8 workgroups (row windows + flag barriers + halo pulls): predictions stay
+    bit-identical to the per-op kernels, gradients agree up to the slab partition.  The batch is ragged (a 388-node
+    graph, a 40-node graph whose tiles do not cover every part, a 388-node graph with SHUFFLED node ids: most of its
+    neighbours are halo rows) and the launches are repeated so that the persistent barrier epochs are exercised."""
+    monkeypatch.setenv("GATRES_FUSED_SPLIT", str(split))
+    if mode:                 # the fallbacks: bulk pulls, agent-scope barriers, parameter gradients in a second launch
+        monkeypatch.setenv(mode, "1")
+    nb, nc = 4, 32
+    t_big = pkg.wdn_synth.make_wdn_topology(388, 430, seed=0)
+    t_small = pkg.wdn_synth.make_wdn_topology(40, 45, seed=1)
+    perm = torch.from_numpy(np.random.RandomState(3).permutation(388))
+    t_shuf = perm[pkg.wdn_synth.make_wdn_topology(388, 430, seed=2)]
+    t_shuf = t_shuf[:, torch.argsort(t_shuf[0], stable=True)]
+    ei = torch.cat([t_big, t_small + 388, t_shuf + 428], dim=1)
+    N = 388 + 40 + 388
+    x = torch.randn(N, 1, generator=torch.Generator().manual_seed(9))
+    mf, _ = build(pkg, oracle, nb, nc, seed=21, fused=True)          # a fresh model = a fresh (zeroed) scratch buffer
+    mp, _ = build(pkg, oracle, nb, nc, seed=21, fused=False)
+    dx, dei = x.cuda(), ei.cuda()
+    plan = mf._plans.get(dei, N)
+    assert plan.num_segments == 3
+    lib = pkg._native.load()
+    assert lib.gatres_fused_cus_per_segment(mf._cmodel_ref(), plan.ref()) == split
+    for rep in range(3):
+        of, op = mf(dx, dei), mp(dx, dei)
+        assert torch.equal(of, op), (split, rep)
+        g = torch.randn(of.shape, generator=torch.Generator().manual_seed(rep)).cuda()
+        for m in (mf, mp):
+            m.zero_grad()
+        of.backward(g)
+        op.backward(g)
+        gf = torch.cat([q.grad.reshape(-1) for q in mf.parameters()])
+        gp = torch.cat([q.grad.reshape(-1) for q in mp.parameters()])
+        assert torch.isfinite(gf).all()
+        assert relerr(gf, gp) < 2e-5, (split, rep, relerr(gf, gp))
+        with torch.no_grad():
+            assert torch.equal(mf(dx, dei), of)                      # inference launches (forward-only barriers)
+
+
 @pytest.mark.parametrize("fused", [True, False], ids=["fused", "per_op"])
 @pytest.mark.parametrize("name", ["tiny_nb2_nc8", "ctown_small_bs2"])
 def test_golden_vectors(pkg, name, fused):
