@@ -131,7 +131,7 @@ class _GATResFunction(torch.autograd.Function):
                       "gatres_model_forward")
         ctx.module, ctx.plan, ctx.saved_acts = module, plan, saved
         ctx.save_for_backward(x)
-        ctx.param_shapes = [p.shape for p in params]
+        ctx.params_like = params
         return out
 
     @staticmethod
@@ -151,13 +151,8 @@ class _GATResFunction(torch.autograd.Function):
         _native.check(lib.gatres_model_backward(module._cmodel_ref(), plan.ref(), module._flat.data_ptr(), x.data_ptr(),
                                                 None, g_out.data_ptr(), saved.data_ptr(), scratch.data_ptr(),
                                                 grads.data_ptr(), _native.ptr(g_x), stream), "gatres_model_backward")
-        outs: List[Optional[Tensor]] = [None, None, None, g_x]
-        off = 0
-        for shape in ctx.param_shapes:
-            n = int(math.prod(shape))
-            outs.append(grads[off:off + n].view(shape))
-            off += n
-        return tuple(outs)
+        # one C++ call instead of 182 Python slice+view pairs: views of `grads` shaped like the parameters
+        return (None, None, None, g_x) + tuple(torch._utils._unflatten_dense_tensors(grads, ctx.params_like))
 
 
 # ----------------------------------------------------------------------------------------------
@@ -189,7 +184,7 @@ class GATResMeanConv(nn.Module):
     # ---- copy / pickle: engine handles (ctypes structs, device plans, scratch) are rebuilt, not copied ---------
     def __getstate__(self):
         state = self.__dict__.copy()
-        for k in ("_plans", "_scratch", "_cmodel", "_flat"):
+        for k in ("_plans", "_scratch", "_cmodel", "_flat", "_param_table", "_param_list"):
             state.pop(k, None)
         return state
 
@@ -221,17 +216,32 @@ class GATResMeanConv(nn.Module):
                 off += n
         self._flat = flat
         self._scratch = {}
+        # (owner dict, name, parameter, byte offset) of every parameter in state_dict order: Module.parameters() walks
+        # the whole module tree (0.4 ms for 182 parameters), too slow to repeat in every forward
+        table = []
+        off = 0
+        seen = set()
+        for mod in self.modules():
+            for name, q in mod._parameters.items():
+                if q is not None and id(q) not in seen:
+                    seen.add(id(q))
+                    table.append((mod._parameters, name, q, 4 * off))
+                    off += q.numel()
+        if len(table) != len(params) or any(t[2] is not q for t, q in zip(table, params)):
+            raise RuntimeError("parameter traversal order changed")
+        self._param_table = table
+        self._param_list = params
 
     def _flat_is_current(self) -> bool:
         flat = self._flat
-        if flat is None:
+        table = getattr(self, "_param_table", None)
+        if flat is None or table is None:
             return False
-        off = 0
         base = flat.data_ptr()
-        for p in self.parameters():
-            if p.data_ptr() != base + 4 * off:
+        for owner, name, q, off in table:
+            # the registered object is still the one we flattened, and it still points into the flat buffer
+            if owner.get(name) is not q or q.data_ptr() != base + off:
                 return False
-            off += p.numel()
         return True
 
     def _apply(self, fn, *args, **kwargs):
@@ -289,7 +299,7 @@ class GATResMeanConv(nn.Module):
         if self._flat.device != x.device:
             raise ValueError(f"model is on {self._flat.device}, x on {x.device}")
         plan = self._plans.get(edge_index, x.shape[0])
-        params = list(self.parameters())
+        params = self._param_list
         # grad mode is switched off inside Function.forward, so decide here whether activations must be kept
         needs_grad = torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in params))
         return _GATResFunction.apply(self, plan, needs_grad, x, *params)
