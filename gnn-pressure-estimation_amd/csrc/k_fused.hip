@@ -442,7 +442,9 @@ __device__ __forceinline__ int max_of(const int (&d)[U]) {
 }
 
 // K2 forward, sub-stage A: attention coefficients.  ONE thread per (row, head): no cross-lane traffic, one exp and
-// one divide per edge.  alpha goes to HBM (saved for the backward pass) and, when ALDS, to an LDS table for sub-stage B.
+// one divide per edge.  (A single-stage K2 in which every lane of a head recomputes the coefficients was measured
+// twice -- one CU per snapshot and ~100 rows per part of a split snapshot: the redundant exp / divide work costs more
+// than the barrier and the LDS hop it removes, 2.8 -> 4.7 us for conv1 at 4 CUs per snapshot.)  alpha goes to HBM (saved for the backward pass) and, when ALDS, to an LDS table for sub-stage B.
 template <int H, bool ALDS, int THREADS>
 __device__ __forceinline__ void seg_softmax(Rows rw, const u16* rp, const u16* col, const float* asrc,
                                             const float* adst_t, int ab, float* __restrict__ alpha_g, int eb,
@@ -1745,6 +1747,20 @@ static int fused_threads_small() {
 }
 static int threads_for(int nc) { return nc <= 32 ? fused_threads_small() : (nc == 64 ? 512 : 256); }
 
+// CUs of the current device (cached): every workgroup of a split launch must be resident at once, one per CU.
+static int device_cus() {
+  static int cus = 0;
+  if (cus == 0) {
+    int dev = 0, v = 0;
+    if (hipGetDevice(&dev) == hipSuccess &&
+        hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0)
+      cus = v;
+    else
+      cus = 1;               // unknown: never split
+  }
+  return cus;
+}
+
 // CUs per segment: the layout's co-residency bound, no more parts than 16-row tiles; GATRES_FUSED_SPLIT overrides
 static int fused_split(const Layout& L, const gatres_graph_t* g) {
   int m = L.split_max < 4 ? L.split_max : 4;        // measured on C-Town / nc=32: 4 CUs per snapshot is the knee
@@ -1753,7 +1769,8 @@ static int fused_split(const Layout& L, const gatres_graph_t* g) {
     if (v >= 1 && v <= L.split_max && gatres_is_pow2(v)) m = v;
   }
   const int tiles = (g->max_segment_nodes + 15) / 16;
-  while (m > 1 && (m > tiles || L.nb == 0)) m >>= 1;
+  const int padded = ((g->num_segments + 7) / 8) * 8;
+  while (m > 1 && (m > tiles || L.nb == 0 || padded * m > device_cus())) m >>= 1;   // (a partitioned / smaller device)
   return m;
 }
 
@@ -1763,7 +1780,7 @@ static int fused_split(const Layout& L, const gatres_graph_t* g) {
 static int fused_consumers(const Layout& L, const gatres_graph_t* g, int M) {
   if (getenv("GATRES_FUSED_NO_CONSUMERS") || L.nb == 0 || threads_for(L.nc) != 1024) return 0;
   const int padded = ((g->num_segments + 7) / 8) * 8;
-  int c = (256 - padded * M) / padded;
+  int c = (device_cus() - padded * M) / padded;
   int cap = 2;             // measured: 1, 2 and 4 consumers per snapshot give the same step time
   if (const char* e = getenv("GATRES_FUSED_CONSUMERS")) cap = atoi(e) < 4 ? atoi(e) : 4;
   if (c > cap) c = cap;
