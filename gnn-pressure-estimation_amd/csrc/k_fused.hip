@@ -118,6 +118,27 @@ __device__ __forceinline__ float block_sum(float v, float* red) {
   return s;
 }
 
+// streaming read (nt): the deferred-gradient items read every kept / saved table exactly once; keep them from
+// evicting the L2 lines the per-snapshot workgroups on the same XCD are working with
+__device__ __forceinline__ float4 ld4_nt(const float* p) {
+  typedef float v4f __attribute__((ext_vector_type(4)));
+  const v4f v = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(p));
+  return make_float4(v.x, v.y, v.z, v.w);
+}
+template <int KQ>
+__device__ __forceinline__ void load_frag_nt(const float* p, float (&f)[KQ]) {
+  if constexpr (KQ % 4 == 0) {
+#pragma unroll
+    for (int s = 0; s < KQ; s += 4) {
+      const float4 v = ld4_nt(p + s);
+      f[s] = v.x; f[s + 1] = v.y; f[s + 2] = v.z; f[s + 3] = v.w;
+    }
+  } else {
+#pragma unroll
+    for (int s = 0; s < KQ; ++s) f[s] = __builtin_nontemporal_load(p + s);
+  }
+}
+
 template <int KQ>
 __device__ __forceinline__ void load_frag(const float* p, float (&f)[KQ]) {
   if constexpr (KQ % 4 == 0) {
@@ -365,7 +386,7 @@ __device__ __forceinline__ void seg_dw(int n, const float* G, int gb, const floa
 // operands come from per-lane VECTOR loads (float4 / float2) of contiguous features instead of 4-byte column
 // slices; R row ranges run on R waves, their partial blocks meet in LDS (`part`, R*HC*K floats: the backward's idle
 // g_pre|g_y2 / g_out1 region) and are summed in range order -> the segment's slab.  Deterministic.
-template <int HC, int K, int THREADS>
+template <int HC, int K, int THREADS, bool NT = false>
 __device__ __forceinline__ void seg_dw_blk(int n, int R, const float* G, int gb, const float* X, int xb,
                                            float* __restrict__ slab, float* part) {
   constexpr int VC = HC / 16, VK = K / 16, STEPS = 5;              // 5 steps (20 rows) of loads in flight
@@ -386,8 +407,13 @@ __device__ __forceinline__ void seg_dw_blk(int n, int R, const float* G, int gb,
         const int r = nb + 4 * st + q;
         const bool ok = r < rend;
         const int rr = ok ? r : rbeg;
-        load_frag<VC>(G + (unsigned)((gb + rr) * HC + VC * i), av[st]);
-        load_frag<VK>(X + (unsigned)((xb + rr) * K + VK * i), bv[st]);
+        if constexpr (NT) {           // streaming reads when running beside the per-snapshot workgroups
+          load_frag_nt<VC>(G + (unsigned)((gb + rr) * HC + VC * i), av[st]);
+          load_frag_nt<VK>(X + (unsigned)((xb + rr) * K + VK * i), bv[st]);
+        } else {
+          load_frag<VC>(G + (unsigned)((gb + rr) * HC + VC * i), av[st]);
+          load_frag<VK>(X + (unsigned)((xb + rr) * K + VK * i), bv[st]);
+        }
         if (!ok) {
 #pragma unroll
           for (int a = 0; a < VC; ++a) av[st][a] = 0.f;
@@ -877,7 +903,7 @@ __device__ __forceinline__ void seg_agg_bwd_src(Rows rw, int e0, const u16* trp,
 
 // att_src / att_dst gradients of one GATConv for this segment -> the segment's slab (deferred launch).
 // thread = (column c, row group rg); 4 rows in flight; partials combined across row groups through LDS.
-template <int H, int C, int THREADS>
+template <int H, int C, int THREADS, bool NT = false>
 __device__ __forceinline__ void seg_att_grads(int n, const float* __restrict__ h, int hb,
                                               const float* __restrict__ g_a_src, const float* __restrict__ g_a_dst,
                                               int db, float* __restrict__ slab_as, float* __restrict__ slab_ad,
@@ -894,7 +920,7 @@ __device__ __forceinline__ void seg_att_grads(int n, const float* __restrict__ h
         const int r = r0 + k * R;
         const bool ok = r < n;
         const int rr = ok ? r : 0;
-        hv[k] = ok ? h[(size_t)(hb + rr) * HC + c] : 0.f;
+        hv[k] = !ok ? 0.f : (NT ? __builtin_nontemporal_load(h + (size_t)(hb + rr) * HC + c) : h[(size_t)(hb + rr) * HC + c]);
         gs[k] = ok ? g_a_src[(size_t)(db + rr) * H + hd] : 0.f;
         gd[k] = ok ? g_a_dst[(size_t)(db + rr) * H + hd] : 0.f;
       }
@@ -1030,7 +1056,7 @@ __device__ __forceinline__ void fold_parts(const ParamGradArgs& a, int seg, int6
 }
 
 // part: NW * 2*NC*NC floats of LDS when the block form applies (nc 16 / 32), red: 3 * THREADS floats
-template <int NC, int THREADS>
+template <int NC, int THREADS, bool NT>
 __device__ __forceinline__ void param_grads_item(const ParamGradArgs& a, int seg, int b, int conv, bool fold_lin,
                                                  float* part, float* red) {
   constexpr bool BLK = NC >= 16 && NC <= 32;
@@ -1051,14 +1077,14 @@ __device__ __forceinline__ void param_grads_item(const ParamGradArgs& a, int seg
     }
   }
   if (conv == 0) {
-    if constexpr (BLK) seg_dw_blk<2 * NC, NC, THREADS>(n, NW, keep + L.k_gh1, n0, base + SL.xin, 0, sb + L.c1_W, part);
+    if constexpr (BLK) seg_dw_blk<2 * NC, NC, THREADS, NT>(n, NW, keep + L.k_gh1, n0, base + SL.xin, 0, sb + L.c1_W, part);
     else               seg_dw<2 * NC, NC, THREADS>(n, keep + L.k_gh1, n0, base + SL.xin, 0, sb + L.c1_W, red);
-    seg_att_grads<2, NC, THREADS>(n, base + SL.h1, 0, keep + L.k_gas1, keep + L.k_gad1, n0, sb + L.c1_as,
+    seg_att_grads<2, NC, THREADS, NT>(n, base + SL.h1, 0, keep + L.k_gas1, keep + L.k_gad1, n0, sb + L.c1_as,
                                   sb + L.c1_ad, red);
   } else {
-    if constexpr (BLK) seg_dw_blk<NC, 2 * NC, THREADS>(n, NW, keep + L.k_gh2, n0, base + SL.o1, 0, sb + L.c2_W, part);
+    if constexpr (BLK) seg_dw_blk<NC, 2 * NC, THREADS, NT>(n, NW, keep + L.k_gh2, n0, base + SL.o1, 0, sb + L.c2_W, part);
     else               seg_dw<NC, 2 * NC, THREADS>(n, keep + L.k_gh2, n0, base + SL.o1, 0, sb + L.c2_W, red);
-    seg_att_grads<1, NC, THREADS>(n, base + SL.h2, 0, keep + L.k_gas2, keep + L.k_gad2, n0, sb + L.c2_as,
+    seg_att_grads<1, NC, THREADS, NT>(n, base + SL.h2, 0, keep + L.k_gas2, keep + L.k_gad2, n0, sb + L.c2_as,
                                   sb + L.c2_ad, red);
   }
 }
@@ -1070,7 +1096,7 @@ __global__ __launch_bounds__(THREADS) void param_grads_kernel(const ParamGradArg
   __shared__ __attribute__((aligned(16))) float part[BLK ? NW * 2 * NC * NC : 4];
   __shared__ float red[3 * THREADS];
   const int conv = blockIdx.x & 1, b = (blockIdx.x >> 1) % a.L.nb, seg = (blockIdx.x >> 1) / a.L.nb;
-  param_grads_item<NC, THREADS>(a, seg, b, conv, b == 0 && conv == 0, part, red);
+  param_grads_item<NC, THREADS, false>(a, seg, b, conv, b == 0 && conv == 0, part, red);
 }
 
 // ------------------------------------------------------------------------------------------ split segments
@@ -1243,7 +1269,7 @@ __device__ __forceinline__ void consumer_main(const FusedArgs& a, int cid, float
     }
     __syncthreads();
     if (i < 2 * nb) {
-      param_grads_item<NC, THREADS>(pg, seg, nb - 1 - i / 2, (i & 1) ? 0 : 1, false, part, red);
+      param_grads_item<NC, THREADS, true>(pg, seg, nb - 1 - i / 2, (i & 1) ? 0 : 1, false, part, red);
     } else {
       fold_parts<THREADS>(pg, seg, a.L.p_lin0_w, 2 * NC);
       fold_parts<THREADS>(pg, seg, a.L.p_lin1_w, NC + 1);
