@@ -1233,11 +1233,21 @@ __device__ __forceinline__ void pull_list_small(float* dst, const float* src, co
 // Deferred-gradient items of a segment, in production order: item 2*(nb-1-b) is (block b, conv2), the next one
 // (block b, conv1); a split segment adds one last item that folds the lin0 / lin1 partials.  Part 0 publishes the
 // number of finished items after a barrier that all parts have passed; consumer c takes items c, c + C, ...
+// The published word also says where the data is: bits 16..19 the XCD of part 0, bit 24 "every part runs on that
+// XCD".  A consumer on the same XCD reads the tables through the shared L2 as soon as they are published; the LAST
+// publication is preceded by an agent-scope release, so a consumer that finds itself anywhere else waits for it,
+// acquires at agent scope and only then works through its items (correct wherever the workgroups were placed).
+constexpr unsigned PUB_COUNT_MASK = 0xffffu, PUB_LOCAL = 1u << 24;
 template <int THREADS>
-__device__ __forceinline__ void publish_items(const FusedArgs& a, int seg, int part, int count) {
-  if (a.C > 0 && part == 0 && (int)threadIdx.x < a.C)
-    __hip_atomic_store(a.ready + ((size_t)seg * 4 + threadIdx.x) * FLAG_STRIDE, (unsigned)count, __ATOMIC_RELAXED,
-                       __HIP_MEMORY_SCOPE_AGENT);
+__device__ __forceinline__ void publish_items(const FusedArgs& a, int seg, int part, int count, bool parts_local,
+                                              bool last) {
+  if (a.C > 0 && part == 0 && (int)threadIdx.x < 64) {
+    if (last) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    if ((int)threadIdx.x < a.C)
+      __hip_atomic_store(a.ready + ((size_t)seg * 4 + threadIdx.x) * FLAG_STRIDE,
+                         (unsigned)count | (xcc_id() << 16) | (parts_local ? PUB_LOCAL : 0u), __ATOMIC_RELAXED,
+                         __HIP_MEMORY_SCOPE_AGENT);
+  }
 }
 
 template <int NC, int THREADS>
@@ -1252,24 +1262,31 @@ __device__ __forceinline__ void consumer_main(const FusedArgs& a, int cid, float
   unsigned* my = a.ready + ((size_t)seg * 4 + c) * FLAG_STRIDE;
   float* part = ldsf;
   float* red = ldsf + (LDS_BYTES / 4 - 3 * THREADS);
+  int* mode = reinterpret_cast<int*>(red + 3 * THREADS - 1);   // LDS word: 0 = hand-off through the shared L2, 1 = remote
   const int nb = a.L.nb, items = 2 * nb + (a.M > 1 ? 1 : 0);
-  bool dead = false;
+  bool dead = false, remote = false;
   for (int i = c; i < items; i += C) {
     if (threadIdx.x < 64) {
-      if (threadIdx.x == 0 && !dead) {
+      if (threadIdx.x == 0 && !dead && !remote) {
         int spin = 0;
-        while ((int)__hip_atomic_load(my, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < i + 1)
+        unsigned w = 0;
+        while ((int)((w = __hip_atomic_load(my, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) & PUB_COUNT_MASK) < i + 1)
           if (++spin > SPIN_LIMIT) { *a.err = 1; dead = true; break; }
-        // the producers' XCD (published at their first barrier): the cheap hand-off below needs a shared L2
-        if (__hip_atomic_load(a.flags + (size_t)seg * 8 * FLAG_STRIDE + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) !=
-            xcc_id() && a.M > 1)
-          *a.err = 1;
+        if (!dead && (!(w & PUB_LOCAL) || ((w >> 16) & 0xfu) != xcc_id() || a.safe_sync)) {
+          // not behind the producers' L2: wait for the released, final publication
+          remote = true;
+          while ((int)(__hip_atomic_load(my, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & PUB_COUNT_MASK) < items)
+            if (++spin > SPIN_LIMIT) { *a.err = 1; dead = true; break; }
+        }
+        *mode = remote ? 1 : 0;
       }
-      asm volatile("buffer_inv sc1" ::: "memory");
+      if (threadIdx.x == 0 && remote) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      else                            asm volatile("buffer_inv sc1" ::: "memory");
     }
     __syncthreads();
     if (i < 2 * nb) {
-      param_grads_item<NC, THREADS, true>(pg, seg, nb - 1 - i / 2, (i & 1) ? 0 : 1, false, part, red);
+      if (*mode) param_grads_item<NC, THREADS, false>(pg, seg, nb - 1 - i / 2, (i & 1) ? 0 : 1, false, part, red);
+      else       param_grads_item<NC, THREADS, true>(pg, seg, nb - 1 - i / 2, (i & 1) ? 0 : 1, false, part, red);
     } else {
       fold_parts<THREADS>(pg, seg, a.L.p_lin0_w, 2 * NC);
       fold_parts<THREADS>(pg, seg, a.L.p_lin1_w, NC + 1);
@@ -1279,7 +1296,7 @@ __device__ __forceinline__ void consumer_main(const FusedArgs& a, int cid, float
   if (threadIdx.x == 0) {
     // reset the line for the next launch -- only after the producer's LAST publication, or that one would survive
     int spin = 0;
-    while (!dead && (int)__hip_atomic_load(my, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < items)
+    while (!dead && (int)(__hip_atomic_load(my, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & PUB_COUNT_MASK) < items)
       if (++spin > SPIN_LIMIT) { *a.err = 1; break; }
     __hip_atomic_store(my, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
@@ -1599,7 +1616,7 @@ __global__ __launch_bounds__(THREADS) void gatres_fused_kernel(const FusedArgs a
       const float* wt1 = a.wt + (int64_t)b * 2 * w;
       const float* wt2 = wt1 + w;
       group_sync<THREADS>(grp);                  // K3 backward gathers g_pre of neighbours
-      publish_items<THREADS>(a, seg, part, 2 * (L.nb - 1 - b));          // everything of the blocks above is kept
+      publish_items<THREADS>(a, seg, part, 2 * (L.nb - 1 - b), grp.local || !split, false);   // the blocks above are kept
       const int elo = rp[rw.lo], ehi = rp[rw.hi];       // own in-edge range (edges are dst-sorted)
       if (pub) {
         if (halo) pull_list_rows<NC, THREADS>(gpT, gp_cur + (size_t)n0 * NC, hrow, hcnt);
@@ -1650,7 +1667,7 @@ __global__ __launch_bounds__(THREADS) void gatres_fused_kernel(const FusedArgs a
       seg_softmax_bwd<2, THREADS>(rw, 0, 0, rp, col, base + SL.al1, base + SL.as1, base + SL.ad1, ge1T, ge_b, gad1T,
                                   gd_b, pub ? sc + L.sc_ge : nullptr, e0, nullptr, 0);
       group_sync<THREADS>(grp);
-      publish_items<THREADS>(a, seg, part, 2 * (L.nb - 1 - b) + 1);      // this block's conv2 tables are complete
+      publish_items<THREADS>(a, seg, part, 2 * (L.nb - 1 - b) + 1, grp.local || !split, false);   // conv2 tables complete
       if (pub) {
         if (halo) {
           pull_list_rows<2 * NC, THREADS>(go1T, sc + L.sc_go1 + (size_t)n0 * 2 * NC, hrow, hcnt);
@@ -1675,11 +1692,11 @@ __global__ __launch_bounds__(THREADS) void gatres_fused_kernel(const FusedArgs a
       float* t = gp_cur; gp_cur = gp_nxt; gp_nxt = t;
     }
     group_sync<THREADS>(grp);
-    publish_items<THREADS>(a, seg, part, 2 * L.nb);
+    publish_items<THREADS>(a, seg, part, 2 * L.nb, grp.local || !split, !split);
     seg_lin0_bwd<NC, THREADS>(rw, n0, gp_cur, a.x, a.mask, slab + L.p_lin0_w, slab + L.p_lin0_b, red);
     if (split && a.C > 0) {                   // last item: fold the lin0 / lin1 partial rows
       group_sync<THREADS>(grp);
-      publish_items<THREADS>(a, seg, part, 2 * L.nb + 1);
+      publish_items<THREADS>(a, seg, part, 2 * L.nb + 1, grp.local, true);
     }
     if (a.g_x) {
       constexpr int G = NC / 4;
