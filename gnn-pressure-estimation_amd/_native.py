@@ -27,7 +27,8 @@ class GatresGraph(C.Structure):
                 ("rowptr", C.c_void_p), ("col", C.c_void_p), ("t_rowptr", C.c_void_p), ("t_eid", C.c_void_p),
                 ("t_dst", C.c_void_p), ("m_rowptr", C.c_void_p), ("m_col", C.c_void_p), ("mt_rowptr", C.c_void_p),
                 ("mt_dst", C.c_void_p), ("seg_ptr", C.c_void_p), ("max_segment_nodes", C.c_int32),
-                ("max_segment_edges_gat", C.c_int32), ("max_segment_edges_mean", C.c_int32), ("reserved", C.c_int32)]
+                ("max_segment_edges_gat", C.c_int32), ("max_segment_edges_mean", C.c_int32), ("reserved", C.c_int32),
+                ("window", C.c_int32 * 9), ("reserved2", C.c_int32)]
 
 
 class GatresModel(C.Structure):
@@ -44,6 +45,7 @@ SIGNATURES = {
     "gatres_graph_count_host": (C.c_int, [_P, _I64, _I64, C.POINTER(_I64)]),
     "gatres_graph_build_host": (C.c_int, [_P, _I64, _I64] + [_P] * 9),
     "gatres_graph_segments_host": (C.c_int, [_P, _I64, _I64, _I32, _P] + [C.POINTER(_I32)] * 4),
+    "gatres_graph_windows_host": (C.c_int, [_P, _I64, _I64, _P, _I32, _P]),
     "gatres_edge_index_hash": (C.c_int, [_P, _I64, _P, _P]),
     "gatres_lin0_fwd": (C.c_int, [_P, _P, _P, _P, _P, _I32, _I32, _P]),
     "gatres_proj_attn_fwd": (C.c_int, [_P] * 7 + [_I32] * 4 + [_P]),

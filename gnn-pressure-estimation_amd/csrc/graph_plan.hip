@@ -125,3 +125,67 @@ extern "C" int gatres_graph_segments_host(const int64_t* ei, int64_t E, int64_t 
   *max_edges_mean_out = (int32_t)(mm > INT32_MAX ? INT32_MAX : mm);
   return 0;
 }
+
+// Row windows of split segments.  When a segment is carried by M workgroups, part p owns the 16-aligned row range
+// [16*(tiles*p/M), 16*(tiles*(p+1)/M)) and only ever touches the rows its own rows are adjacent to; the smallest
+// contiguous row range holding both is the part's WINDOW.  With a locality-preserving node order the window is a
+// fraction of the segment, and the kernels can size their LDS tables by it.  For M = 2, 4, 8 (out[3*k + ...]):
+// the largest window in rows, in GATConv edges (in-edges of the window's rows, self loops included) and in
+// SimpleConv edges, over all segments and parts.
+extern "C" int gatres_graph_windows_host(const int64_t* ei, int64_t E, int64_t N, const int32_t* seg_ptr,
+                                         int32_t num_segments, int32_t* out9) {
+  if ((!ei && E > 0) || !seg_ptr || !out9 || num_segments <= 0 || N <= 0 || E < 0) return GATRES_E_BADARG;
+  std::vector<int32_t> seg_of(N);
+  for (int32_t s = 0; s < num_segments; ++s)
+    for (int32_t i = seg_ptr[s]; i < seg_ptr[s + 1]; ++i) seg_of[i] = s;
+  std::vector<int64_t> in_all(N + 1, 0), in_gat(N + 1, 0);
+  for (int64_t e = 0; e < E; ++e) {
+    in_all[ei[E + e] + 1]++;
+    in_gat[ei[E + e] + 1] += (ei[e] != ei[E + e]);
+  }
+  for (int64_t i = 0; i < N; ++i) { in_all[i + 1] += in_all[i]; in_gat[i + 1] += in_gat[i] + 1; }
+  const int Ms[3] = {2, 4, 8};
+  for (int k = 0; k < 3; ++k) {
+    const int M = Ms[k];
+    std::vector<int32_t> wlo((size_t)num_segments * M), whi((size_t)num_segments * M);
+    auto bound = [&](int32_t s, int p) {
+      const int32_t n = seg_ptr[s + 1] - seg_ptr[s], tiles = (n + 15) / 16;
+      const int64_t b = 16 * ((int64_t)tiles * p / M);
+      return (int32_t)(b < n ? b : n);
+    };
+    auto part_of = [&](int32_t s, int32_t r) {        // r: row inside segment s
+      int p = 0;
+      while (p + 1 < M && bound(s, p + 1) <= r) ++p;
+      return p;
+    };
+    for (int32_t s = 0; s < num_segments; ++s)
+      for (int p = 0; p < M; ++p) { wlo[(size_t)s * M + p] = bound(s, p); whi[(size_t)s * M + p] = bound(s, p + 1); }
+    for (int64_t e = 0; e < E; ++e) {
+      const int64_t a = ei[e], b = ei[E + e];
+      if (a == b) continue;
+      const int32_t s = seg_of[a];
+      if (seg_of[b] != s) return GATRES_E_GRAPH;
+      const int32_t ra = (int32_t)(a - seg_ptr[s]), rb = (int32_t)(b - seg_ptr[s]);
+      const int pa = part_of(s, ra), pb = part_of(s, rb);
+      if (pa == pb) continue;
+      int32_t& la = wlo[(size_t)s * M + pa]; int32_t& ha = whi[(size_t)s * M + pa];
+      int32_t& lb = wlo[(size_t)s * M + pb]; int32_t& hb = whi[(size_t)s * M + pb];
+      if (rb < la) la = rb;
+      if (rb + 1 > ha) ha = rb + 1;
+      if (ra < lb) lb = ra;
+      if (ra + 1 > hb) hb = ra + 1;
+    }
+    int64_t mr = 0, mg = 0, mm = 0;
+    for (int32_t s = 0; s < num_segments; ++s)
+      for (int p = 0; p < M; ++p) {
+        const int64_t lo = seg_ptr[s] + wlo[(size_t)s * M + p], hi = seg_ptr[s] + whi[(size_t)s * M + p];
+        if (hi - lo > mr) mr = hi - lo;
+        if (in_gat[hi] - in_gat[lo] > mg) mg = in_gat[hi] - in_gat[lo];
+        if (in_all[hi] - in_all[lo] > mm) mm = in_all[hi] - in_all[lo];
+      }
+    out9[3 * k + 0] = (int32_t)mr;
+    out9[3 * k + 1] = (int32_t)(mg > INT32_MAX ? INT32_MAX : mg);
+    out9[3 * k + 2] = (int32_t)(mm > INT32_MAX ? INT32_MAX : mm);
+  }
+  return 0;
+}

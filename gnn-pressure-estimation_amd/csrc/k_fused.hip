@@ -177,7 +177,7 @@ enum { EPI_NONE = 0, EPI_ATT = 1, EPI_RESID_MASK = 2 };
 // ------------------------------------------------------------------------------------------ K1 (MFMA)
 // OUT[ob + r, :] = X[xb + r, :] @ Wm^T for r in [0, n).  Same lane map / k order as proj_kernel (k_proj.hip), so
 // results are bit-identical; each wave takes TWO 16-node tiles per trip and feeds both from one W fragment load.
-template <int K, int M, int H, int EPI, int THREADS, bool WLDS>
+template <int K, int M, int H, int EPI, int THREADS, bool WLDS, bool WPRE = false>
 __device__ __forceinline__ void seg_proj(Rows rw, const float* X, int xb, const float* __restrict__ Wm, float* OUT,
                                          int ob, float* OUT2, int o2b, const float* __restrict__ att_src,
                                          const float* __restrict__ att_dst, float* as_g, float* ad_g, int ag_b,
@@ -202,7 +202,9 @@ __device__ __forceinline__ void seg_proj(Rows rw, const float* X, int xb, const 
   // (Prefetching the W share into registers before the preceding barrier was measured: no gain, more spills.)
   const float* attS = att_src;
   const float* attD = att_dst;
-  if constexpr (WLDS) {
+  if constexpr (WLDS && WPRE) {          // W (+ att) was put into the slot by w_prefetch during an earlier stage
+    if constexpr (EPI == EPI_ATT) { attS = wl + M * KP; attD = wl + M * KP + M; }
+  } else if constexpr (WLDS) {
     for (int idx = threadIdx.x; idx < M * (K / 4); idx += THREADS) {
       const int m = idx / (K / 4), k4 = (idx % (K / 4)) * 4;
       st4(wl + m * KP + k4, ld4(Wm + (unsigned)(m * K + k4)));
@@ -591,7 +593,8 @@ __device__ __forceinline__ void seg_gather(Rows rw, const u16* rp, const u16* co
 // K3 forward: out = relu(mean_{j->r} y[j] + x0[r]).  UR rows per lane group per trip.
 template <int C, int THREADS, int UR = 2>
 __device__ __forceinline__ void seg_mean_fwd(Rows rw, int em, const u16* mrp, const u16* mcol, const float* y, int yb,
-                                             const float* x0, int xb, float* out, int ob) {
+                                             const float* x0, int xb, float* out, int ob, float* out2 = nullptr,
+                                             int o2b = 0) {
   constexpr int G = C / 4, RPP = THREADS / G;
   const int c0 = (threadIdx.x % G) * 4;
   const int rounds = (rw.hi - rw.lo + RPP * UR - 1) / (RPP * UR);
@@ -641,7 +644,10 @@ __device__ __forceinline__ void seg_mean_fwd(Rows rw, int em, const u16* mrp, co
       float4 o;
       o.x = fmaxf(acc[u].x / cnt + rr[u].x, 0.f); o.y = fmaxf(acc[u].y / cnt + rr[u].y, 0.f);
       o.z = fmaxf(acc[u].z / cnt + rr[u].z, 0.f); o.w = fmaxf(acc[u].w / cnt + rr[u].w, 0.f);
-      if (valid[u]) st4(out + (unsigned)((ob + r[u]) * C + c0), o);
+      if (valid[u]) {
+        st4(out + (unsigned)((ob + r[u]) * C + c0), o);
+        if (out2) st4(out2 + (unsigned)((o2b + r[u]) * C + c0), o);
+      }
     }
   }
 }
@@ -830,7 +836,8 @@ __device__ __forceinline__ void seg_agg_bwd_src(Rows rw, int e0, const u16* trp,
                                                 const float* g_e, int eb2, const float* g_a_dst, int db,
                                                 const float* __restrict__ att_src,
                                                 const float* __restrict__ att_dst, float* g_h, int hb,
-                                                float* keep_gas, float* keep_gad) {
+                                                float* keep_gas, float* keep_gad, float* g_h2 = nullptr,
+                                                int h2b = 0) {
   constexpr int HC = H * C, G = HC / 4, RPP = THREADS / G;
   const int c0 = (threadIdx.x % G) * 4;
   const int hd = c0 / C;
@@ -896,7 +903,10 @@ __device__ __forceinline__ void seg_agg_bwd_src(Rows rw, int e0, const u16* trp,
       }
       gatres_axpy4(acc[u], gas[u], as);
       gatres_axpy4(acc[u], gad, ad);
-      if (valid[u]) st4(g_h + (unsigned)((hb + r[u]) * HC + c0), acc[u]);
+      if (valid[u]) {
+        st4(g_h + (unsigned)((hb + r[u]) * HC + c0), acc[u]);
+        if (g_h2) st4(g_h2 + (unsigned)((h2b + r[u]) * HC + c0), acc[u]);
+      }
     }
   }
 }
@@ -1724,6 +1734,530 @@ __global__ __launch_bounds__(THREADS) void gatres_fused_kernel(const FusedArgs a
   }
 }
 
+// ------------------------------------------------------------------------------------------ window kernel
+// The same per-snapshot pipeline for split segments whose parts have compact ROW WINDOWS (gatres_graph_t.window: own
+// rows + the rows adjacent to them form a contiguous range that is a fraction of the segment when the node order is
+// local, as in water networks).  Every LDS table covers the window only (plain index shift: pointer - wlo * width),
+// which frees more than half of the LDS.  The space buys what the one-table-per-segment layout has no room for:
+//   * the x operand of every MFMA stage comes from an LDS copy of the producer stage's own rows, and W / W^T sit in
+//     two slots filled by LDS-DMA (global_load_lds) one or more stages ahead: a projection starts computing at once
+//     instead of after a W staging pass and a global round trip (~1.9 us each, four per block);
+//   * the backward's gathers of SAVED tables (h, a_src, alpha: independent of the backward chain) read LDS copies of
+//     the window that LDS-DMA prefetches a stage ahead, instead of going to L2 / Infinity Cache per neighbour.
+// Stage functions, arithmetic and barrier protocol are exactly those of gatres_fused_kernel.
+// LDS-DMA helpers.  Only waves w0 .. NW-1 issue: the compiler cannot prove that a wave's later LDS reads do not alias
+// the DMA's destination (every table is a run-time offset into one LDS array), so it makes an issuing wave wait for
+// its DMA (s_waitcnt vmcnt(0)) before its next ds_read -- which would serialise the copy with the stage it is meant to
+// hide behind.  The MFMA stages of a split segment leave most waves idle (one 16-row tile per wave): those issue.
+template <int THREADS>
+__device__ __forceinline__ void dma_copy16(float* dst, const float* src, int nfloat, int w0) {   // nfloat % 4 == 0, 16-B aligned
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  if (wave < w0) return;
+  for (int c = (wave - w0) * 256; c < nfloat; c += (THREADS / 64 - w0) * 256)
+    if (c + lane * 4 < nfloat) __builtin_amdgcn_global_load_lds(src + c + lane * 4, dst + c, 16, 0, 0);
+}
+template <int THREADS>
+__device__ __forceinline__ void dma_copy4(float* dst, const float* src, int nfloat, int w0) {
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  if (wave < w0) return;
+  for (int c = (wave - w0) * 64; c < nfloat; c += (THREADS / 64 - w0) * 64)
+    if (c + lane < nfloat) __builtin_amdgcn_global_load_lds(src + c + lane, dst + c, 4, 0, 0);
+}
+// W [M][K] (+ the two attention vectors) -> LDS slot in seg_proj's padded layout, one LDS-DMA instruction per row
+template <int K, int M, int EPI, int THREADS>
+__device__ __forceinline__ void w_prefetch(float* wl, const float* __restrict__ Wm, const float* __restrict__ att_src,
+                                           const float* __restrict__ att_dst, int w0) {
+  constexpr int KP = K + 4;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  if (wave < w0) return;
+  for (int m = wave - w0; m < M; m += THREADS / 64 - w0)
+    if (lane < K / 4) __builtin_amdgcn_global_load_lds(Wm + m * K + lane * 4, wl + m * KP, 16, 0, 0);
+  if constexpr (EPI == EPI_ATT) {
+    if (wave == THREADS / 64 - 1 && lane < M / 4) __builtin_amdgcn_global_load_lds(att_src + lane * 4, wl + M * KP, 16, 0, 0);
+    if (wave == THREADS / 64 - 2 && lane < M / 4) __builtin_amdgcn_global_load_lds(att_dst + lane * 4, wl + M * KP + M, 16, 0, 0);
+  }
+}
+
+// LDS bytes of the two phases for given maxima (host + device): wr window rows, ow own rows, ge / gm window edges
+__host__ __device__ inline long long win_fwd_bytes(int nc, int wr, int ow, int ge, int gm) {
+  const long long wlf = 2LL * nc * (2 * nc + 4) + 4 * nc;
+  return 4LL * (wr * (3LL * nc + 2) + ow * (3LL * nc + 2)) + 2 * (4 * wlf + 16) + 2LL * (2 * even(ow + 2) + even(ge) + even(gm)) +
+         512;                                                             // + room for a short halo list
+}
+__host__ __device__ inline long long win_bwd_bytes(int nc, int threads, int wr, int ow, int ge, int gm) {
+  const long long wlf = 2LL * nc * (2 * nc + 4) + 4 * nc;
+  return 12LL * threads + 4LL * (wr * (4LL * nc + 2) + ow * (2LL * nc + 4) + 4LL * even(ge)) + 2 * (4 * wlf + 16) +
+         2LL * (3 * even(ow + 2) + 3 * even(ge) + even(wr + 2) + even(gm)) + 512;      // + room for a short halo list
+}
+
+// Barrier between two stages of the window kernel whose hand-off goes through LDS only: waits for the wave's LDS
+// operations, NOT for its outstanding global stores / LDS-DMA (s_waitcnt vmcnt), so the saved-activation stores of
+// one stage drain while the next stages run.  Every stage that reads global data of the previous stage, or LDS data
+// that a DMA delivers, is preceded by a full __syncthreads() / group_sync instead.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+template <int NC, int THREADS>
+__global__ __launch_bounds__(THREADS) void gatres_window_kernel(const FusedArgs a) {
+  __shared__ __attribute__((aligned(16))) unsigned char lds_raw[LDS_BYTES];
+  float* ldsf = reinterpret_cast<float*>(lds_raw);
+  const Layout& L = a.L;
+  const int M = a.M;
+  {
+    const int F = ((a.num_segments + 7) / 8) * 8 * M;
+    if ((int)blockIdx.x >= F) {
+      consumer_main<NC, THREADS>(a, (int)blockIdx.x - F, ldsf);
+      return;
+    }
+  }
+  const int within = blockIdx.x % (8 * M);
+  const int seg = (blockIdx.x / (8 * M)) * 8 + (within & 7), part = within >> 3;
+  if (seg >= a.num_segments) return;
+  const int n0 = a.seg_ptr[seg], n = a.seg_ptr[seg + 1] - n0;
+  const int e0 = a.rowptr[n0], em0 = a.m_rowptr[n0], t0 = a.t_rowptr[n0], mt0 = a.mt_rowptr[n0];
+  const int tid = threadIdx.x;
+  Rows rw;
+  {
+    const int tiles = (n + 15) >> 4;
+    rw.lo = 16 * (int)((long long)tiles * part / M);
+    rw.hi = min(n, 16 * (int)((long long)tiles * (part + 1) / M));
+  }
+  const int lo = rw.lo, ow = rw.hi - rw.lo;
+  Group grp;
+  grp.flags = a.flags + (size_t)seg * 8 * FLAG_STRIDE; grp.M = M; grp.part = part; grp.err = a.err;
+  group_init<THREADS>(grp);
+  if (a.safe_sync) grp.local = false;
+  constexpr int UF = 2, UB = 1;
+  // first wave that issues LDS-DMA inside MFMA stages: the waves below it own a 16-row tile there (dma_copy16)
+  const int dw0 = min((ow + 15) >> 4, THREADS / 64 - 4);
+  constexpr int WL_FLOATS = 2 * NC * (2 * NC + 4) + 4 * NC;
+  constexpr int WLB = (WL_FLOATS + 3) & ~3;
+  const float* P = a.params;
+  float* sc = a.scratch;
+  int stamp_i = 0;
+  STAMP();
+  if (a.stamps && blockIdx.x == 0 && threadIdx.x == 0) a.stamps[a.stamp_cap] = clock64();
+
+  // ---- the window: own rows and every row adjacent to them (in- and out-neighbours), as one contiguous range
+  int wlo, whi;
+  {
+    int* mm = reinterpret_cast<int*>(lds_raw);
+    if (tid == 0) { mm[0] = lo; mm[1] = rw.hi; }
+    __syncthreads();
+    int vmin = lo, vmax = rw.hi;
+    for (int e = a.rowptr[n0 + lo] + tid; e < a.rowptr[n0 + rw.hi]; e += THREADS) {
+      const int j = a.col[e] - n0; vmin = min(vmin, j); vmax = max(vmax, j + 1);
+    }
+    for (int t = a.t_rowptr[n0 + lo] + tid; t < a.t_rowptr[n0 + rw.hi]; t += THREADS) {
+      const int j = a.t_dst[t] - n0; vmin = min(vmin, j); vmax = max(vmax, j + 1);
+    }
+    for (int e = a.m_rowptr[n0 + lo] + tid; e < a.m_rowptr[n0 + rw.hi]; e += THREADS) {
+      const int j = a.m_col[e] - n0; vmin = min(vmin, j); vmax = max(vmax, j + 1);
+    }
+    for (int t = a.mt_rowptr[n0 + lo] + tid; t < a.mt_rowptr[n0 + rw.hi]; t += THREADS) {
+      const int j = a.mt_dst[t] - n0; vmin = min(vmin, j); vmax = max(vmax, j + 1);
+    }
+    if (vmin < lo) atomicMin(&mm[0], vmin);
+    if (vmax > rw.hi) atomicMax(&mm[1], vmax);
+    __syncthreads();
+    wlo = mm[0]; whi = mm[1];
+    __syncthreads();
+  }
+  const int wr = whi - wlo;
+  // edge ranges (local ids = position - e0): own in-edges [elo, ehi), window in-edges [ewlo, ewhi)
+  const int elo = a.rowptr[n0 + lo] - e0, ehi = a.rowptr[n0 + rw.hi] - e0, oeg = ehi - elo;
+  const int ewlo = a.rowptr[n0 + wlo] - e0, ewhi = a.rowptr[n0 + whi] - e0, weg = ewhi - ewlo;
+  const int melo = a.m_rowptr[n0 + lo] - em0, oem = a.m_rowptr[n0 + rw.hi] - em0 - melo;
+  const int tlo = a.t_rowptr[n0 + lo] - t0, otg = a.t_rowptr[n0 + rw.hi] - t0 - tlo;
+  const int mtlo = a.mt_rowptr[n0 + lo] - mt0, otm = a.mt_rowptr[n0 + rw.hi] - mt0 - mtlo;
+
+  const SegLayout& SL = a.SL;
+  float* segbase = a.saved + (int64_t)seg * SL.total;                 // training only: saved is never null here
+
+  if (a.phases & GATRES_PHASE_FORWARD) {
+    // LDS: [hA wr x 2NC | hB wr x NC | sa wr x 2 | sd own x 2 | xA own x NC | xB own x 2NC | W slot A | W slot B] topology
+    float* hAw = ldsf;
+    float* hBw = hAw + (size_t)wr * 2 * NC;
+    float* saw = hBw + (size_t)wr * NC;
+    float* sdo = saw + (size_t)wr * 2;
+    float* xAo = sdo + (size_t)((ow * 2 + 3) & ~3);
+    float* xBo = xAo + (size_t)ow * NC;
+    float* wlA = reinterpret_cast<float*>(lds_raw + ((reinterpret_cast<unsigned char*>(xBo + (size_t)ow * 2 * NC) - lds_raw + 15) & ~15));
+    float* wlB = wlA + WLB;
+    u16* tp = reinterpret_cast<u16*>(wlB + WLB);
+    u16* rpo = tp;             tp += even(ow + 1);
+    u16* colo = tp;            tp += even(oeg);
+    u16* mrpo = tp;            tp += even(ow + 1);
+    u16* mcolo = tp;           tp += even(oem);
+    int* hcounter = reinterpret_cast<int*>(tp);
+    u16* hlist = tp + 2;
+    const int hcap = (int)((lds_raw + LDS_BYTES - reinterpret_cast<unsigned char*>(hlist)) / 2);
+    // index-shifted views: absolute local row / relative own-edge indices work unchanged in the stage functions
+    float* hA = hAw - wlo * 2 * NC;
+    float* hB = hBw - wlo * NC;
+    float* sa2 = saw - wlo * 2;  float* sa1 = saw - wlo;                 // a_src tables (H = 2 / H = 1)
+    float* sd2 = sdo - lo * 2;   float* sd1 = sdo - lo;
+    float* xA = xAo - lo * NC;
+    float* xB = xBo - lo * 2 * NC;
+    const u16* rp = rpo - lo;  const u16* mrp = mrpo - lo;
+    copy_rowptr16<THREADS>(rpo, a.rowptr, n0 + lo, ow, e0 + elo);
+    copy_idx16<THREADS>(colo, a.col, e0 + elo, oeg, n0);
+    copy_rowptr16<THREADS>(mrpo, a.m_rowptr, n0 + lo, ow, em0 + melo);
+    copy_idx16<THREADS>(mcolo, a.m_col, em0 + melo, oem, n0);
+    float* xcur = segbase + SL.xin;
+    if (L.nb > 0) {
+      const float* pb0 = P + L.p_block0;
+      w_prefetch<NC, 2 * NC, EPI_ATT, THREADS>(wlA, pb0 + L.c1_W, pb0 + L.c1_as, pb0 + L.c1_ad, 0);
+    }
+    {  // lin0 (+ the caller-side x[mask] = 0)
+      const float* w = P + L.p_lin0_w;
+      const float* b = P + L.p_lin0_b;
+      for (int idx = rw.lo * (NC / 4) + tid; idx < rw.hi * (NC / 4); idx += THREADS) {
+        const int r = idx / (NC / 4), c0 = (idx % (NC / 4)) * 4;
+        const size_t node = (size_t)n0 + r;
+        const float xv = (a.mask && a.mask[node]) ? 0.f : a.x[node];
+        const float4 wv = ld4(w + c0), bv = ld4(b + c0);
+        float4 o;
+        o.x = xv * wv.x + bv.x; o.y = xv * wv.y + bv.y; o.z = xv * wv.z + bv.z; o.w = xv * wv.w + bv.w;
+        st4(xcur + (unsigned)(r * NC + c0), o);
+        st4(xA + (unsigned)(r * NC + c0), o);
+      }
+    }
+    __syncthreads();
+    int hcnt = 0;
+    bool halo = false;
+    if (M > 1 && hcap > 0 && !a.no_halo) {
+      hcnt = build_halo<THREADS>(rp, colo, nullptr, rw, hlist, nullptr, hcap, hcounter);
+      halo = hcnt <= hcap;
+    }
+    STAMP();
+    for (int b = 0; b < L.nb; ++b) {
+      float* base = segbase + (int64_t)b * SL.bstride;
+      float* xnext = segbase + (int64_t)(b + 1) * SL.bstride + SL.xin;
+      const float* pb = P + L.p_block0 + (int64_t)b * L.p_block_stride;
+      float* y2g = sc + L.sc_y2;
+      // LDS-DMA rides on the MFMA stages (the longest ones; a DMA has to land before its host stage's closing barrier):
+      // W2 of this block while proj1 runs, W1 of the next block while proj2 runs
+      w_prefetch<2 * NC, NC, EPI_ATT, THREADS>(wlB, pb + L.c2_W, pb + L.c2_as, pb + L.c2_ad, dw0);
+      seg_proj<NC, 2 * NC, 2, EPI_ATT, THREADS, true, true>(rw, xA, 0, pb + L.c1_W, base + SL.h1, 0, hA, 0, pb + L.c1_as,
+                                                        pb + L.c1_ad, base + SL.as1, base + SL.ad1, 0, sa2, sd2,
+                                                        nullptr, 0, nullptr, 0, wlA);
+      group_sync<THREADS>(grp);
+      if (M > 1) {
+        if (halo) {
+          pull_list_rows<2 * NC, THREADS>(hA, base + SL.h1, hlist, hcnt);
+          pull_list_small<2, THREADS>(sa2, base + SL.as1, hlist, hcnt);
+        } else {
+          Rows wv; wv.lo = lo - wlo; wv.hi = rw.hi - wlo;
+          pull_rows4<THREADS>(hAw, base + SL.h1 + (size_t)wlo * 2 * NC, 2 * NC, wv, wr);
+          pull_flat<THREADS>(saw, base + SL.as1 + (size_t)wlo * 2, wv.lo * 2, wv.hi * 2, wr * 2);
+        }
+        lds_barrier();
+      }
+      STAMP();
+      // K2 conv1: alpha -> HBM + the h2 window's LDS (dead now), then the gather (o1 -> HBM + the x buffer of proj2)
+      if (2 * oeg <= wr * NC) {
+        seg_softmax<2, true, THREADS>(rw, rp, colo, sa2, sd2, 0, base + SL.al1, elo, hBw);
+        lds_barrier();
+        seg_gather<true, 2, NC, THREADS, UF>(rw, rp, colo, hA, 0, hBw, 0, pb + L.c1_b, base + SL.o1, 0, xB, 0);
+      } else {
+        seg_softmax<2, false, THREADS>(rw, rp, colo, sa2, sd2, 0, base + SL.al1, elo, nullptr);
+        __syncthreads();
+        seg_gather<true, 2, NC, THREADS, UF>(rw, rp, colo, hA, 0, base + SL.al1, elo, pb + L.c1_b, base + SL.o1, 0, xB, 0);
+      }
+      lds_barrier();
+      STAMP();
+      if (b + 1 < L.nb) {
+        const float* pn = pb + L.p_block_stride;
+        w_prefetch<NC, 2 * NC, EPI_ATT, THREADS>(wlA, pn + L.c1_W, pn + L.c1_as, pn + L.c1_ad, dw0);
+      }
+      seg_proj<2 * NC, NC, 1, EPI_ATT, THREADS, true, true>(rw, xB, 0, pb + L.c2_W, base + SL.h2, 0, hB, 0, pb + L.c2_as,
+                                                        pb + L.c2_ad, base + SL.as2, base + SL.ad2, 0, sa1, sd1,
+                                                        nullptr, 0, nullptr, 0, wlB);
+      group_sync<THREADS>(grp);
+      if (M > 1) {
+        if (halo) {
+          pull_list_rows<NC, THREADS>(hB, base + SL.h2, hlist, hcnt);
+          pull_list_small<1, THREADS>(sa1, base + SL.as2, hlist, hcnt);
+        } else {
+          Rows wv; wv.lo = lo - wlo; wv.hi = rw.hi - wlo;
+          pull_rows4<THREADS>(hBw, base + SL.h2 + (size_t)wlo * NC, NC, wv, wr);
+          pull_flat<THREADS>(saw, base + SL.as2 + (size_t)wlo, wv.lo, wv.hi, wr);
+        }
+        lds_barrier();
+      }
+      STAMP();
+      // K2 conv2: alpha's LDS table in the upper half of the h1 window, y2 in the lower half (+ HBM for the partners)
+      float* y2pub = M > 1 ? y2g : nullptr;
+      if (oeg <= wr * NC) {
+        float* al2L = hAw + (size_t)wr * NC;
+        seg_softmax<1, true, THREADS>(rw, rp, colo, sa1, sd1, 0, base + SL.al2, elo, al2L);
+        lds_barrier();
+        seg_gather<false, 1, NC, THREADS, UF>(rw, rp, colo, hB, 0, al2L, 0, pb + L.c2_b, hAw - wlo * NC, 0, y2pub, n0);
+      } else {
+        seg_softmax<1, false, THREADS>(rw, rp, colo, sa1, sd1, 0, base + SL.al2, elo, nullptr);
+        __syncthreads();
+        seg_gather<false, 1, NC, THREADS, UF>(rw, rp, colo, hB, 0, base + SL.al2, elo, pb + L.c2_b, hAw - wlo * NC, 0,
+                                          y2pub, n0);
+      }
+      group_sync<THREADS>(grp);
+      if (M > 1) {
+        if (halo) pull_list_rows<NC, THREADS>(hAw - wlo * NC, y2g + (size_t)n0 * NC, hlist, hcnt);
+        else {
+          Rows wv; wv.lo = lo - wlo; wv.hi = rw.hi - wlo;
+          pull_rows4<THREADS>(hAw, y2g + (size_t)(n0 + wlo) * NC, NC, wv, wr);
+        }
+        lds_barrier();
+      }
+      STAMP();
+      // K3: residual from the x buffer, result back into it (and to HBM: saved xin of the next block)
+      seg_mean_fwd<NC, THREADS, UF>(rw, oem, mrp, mcolo, hAw - wlo * NC, 0, xA, 0, xnext, 0, xA, 0);
+      lds_barrier();
+      STAMP();
+      xcur = xnext;
+    }
+    {  // lin1
+      constexpr int G = NC / 4;
+      const float4 wv = ld4(P + L.p_lin1_w + (tid % G) * 4);
+      const float bias = P[L.p_lin1_b];
+      const int rounds = (rw.hi - rw.lo + THREADS / G - 1) / (THREADS / G);
+      for (int it = 0; it < rounds; ++it) {
+        int r = rw.lo + it * (THREADS / G) + tid / G;
+        const bool valid = r < rw.hi;
+        if (!valid) r = rw.hi - 1;
+        const float4 xv = ld4(xA + (unsigned)(r * NC + (tid % G) * 4));
+        float d = xv.x * wv.x;
+        d = fmaf(xv.y, wv.y, d); d = fmaf(xv.z, wv.z, d); d = fmaf(xv.w, wv.w, d);
+        for (int off = G >> 1; off > 0; off >>= 1) d += __shfl_xor(d, off);
+        if (valid && (tid % G) == 0) a.out[n0 + r] = d + bias;
+      }
+    }
+    __syncthreads();
+    STAMP();
+  }
+
+  if (a.phases & PH_LOSS) {
+    float cnt = 0.f;
+    for (int i = tid; i < a.N; i += THREADS) cnt += a.mask[i] ? 1.f : 0.f;
+    const float Mn = block_sum<THREADS>(cnt, ldsf);
+    float part_sum = 0.f;
+    for (int r = rw.lo + tid; r < rw.hi; r += THREADS) {
+      const int node = n0 + r;
+      if (a.mask[node]) {
+        const float d = a.out[node] - a.y[node];
+        part_sum = fmaf(d, d, part_sum);
+      }
+    }
+    part_sum = block_sum<THREADS>(part_sum, ldsf);
+    if (tid == 0) {
+      a.loss_part[seg * M + part] = part_sum;
+      if (seg == 0 && part == 0) a.loss_part[a.num_segments * M] = Mn;
+    }
+    const float scale = Mn > 0.f ? 2.f / Mn : 0.f;
+    for (int r = rw.lo + tid; r < rw.hi; r += THREADS) {
+      const int node = n0 + r;
+      a.g_out[node] = a.mask[node] ? (a.out[node] - a.y[node]) * scale : 0.f;
+    }
+    __syncthreads();
+    STAMP();
+  }
+
+  if (a.phases & GATRES_PHASE_BACKWARD) {
+    // LDS: red | RA wr x 2NC | ge weg x 2 | gad own x 2 | hT wr x 2NC | asT wr x 2 | adT own x 2 | alT weg x 2 |
+    //      xG own x 2NC | W slot A | W slot B | topology | halo lists
+    float* red = ldsf;
+    float* RAw = red + 3 * THREADS;
+    float* gew = RAw + (size_t)wr * 2 * NC;
+    float* gado = gew + 2 * (size_t)even(weg);
+    float* hTw = gado + (size_t)((ow * 2 + 3) & ~3);
+    float* asTw = hTw + (size_t)wr * 2 * NC;
+    float* adTo = asTw + (size_t)((wr * 2 + 3) & ~3);
+    float* alTw = adTo + (size_t)((ow * 2 + 3) & ~3);
+    float* xGo = alTw + 2 * (size_t)even(weg);
+    float* wlA = reinterpret_cast<float*>(lds_raw + ((reinterpret_cast<unsigned char*>(xGo + (size_t)ow * 2 * NC) - lds_raw + 15) & ~15));
+    float* wlB = wlA + WLB;
+    u16* tp = reinterpret_cast<u16*>(wlB + WLB);
+    u16* rpo = tp;             tp += even(ow + 1);
+    u16* colo = tp;            tp += even(oeg);
+    u16* trpo = tp;            tp += even(ow + 1);
+    u16* teido = tp;           tp += even(otg);
+    u16* tdsto = tp;           tp += even(otg);
+    u16* mrpw = tp;            tp += even(wr + 1);
+    u16* mtrpo = tp;           tp += even(ow + 1);
+    u16* mtdsto = tp;          tp += even(otm);
+    int* hcounter = reinterpret_cast<int*>(tp);
+    u16* hrow = tp + 2;
+    const int hcap = (int)((lds_raw + LDS_BYTES - reinterpret_cast<unsigned char*>(hrow)) / 4);
+    u16* hedge = hrow + (hcap > 0 ? hcap : 0);
+    __syncthreads();           // forward's LDS contents are dead from here
+    copy_rowptr16<THREADS>(rpo, a.rowptr, n0 + lo, ow, e0 + elo);
+    copy_idx16<THREADS>(colo, a.col, e0 + elo, oeg, n0);
+    copy_rowptr16<THREADS>(trpo, a.t_rowptr, n0 + lo, ow, t0 + tlo);
+    copy_idx16<THREADS>(teido, a.t_eid, t0 + tlo, otg, e0);
+    copy_idx16<THREADS>(tdsto, a.t_dst, t0 + tlo, otg, n0);
+    copy_rowptr16<THREADS>(mrpw, a.m_rowptr, n0 + wlo, wr, a.m_rowptr[n0 + wlo]);
+    copy_rowptr16<THREADS>(mtrpo, a.mt_rowptr, n0 + lo, ow, mt0 + mtlo);
+    copy_idx16<THREADS>(mtdsto, a.mt_dst, mt0 + mtlo, otm, n0);
+    const u16* rp = rpo - lo;  const u16* trp = trpo - lo;  const u16* mrp = mrpw - wlo;  const u16* mtrp = mtrpo - lo;
+    float* RA = RAw - wlo * 2 * NC;              // [row][2NC] view: g_out1
+    float* gpT = RAw - wlo * NC;                 // [row][NC] views of the lower / upper half: g_pre, g_y2
+    float* gy2T = RAw + (size_t)wr * NC - wlo * NC;
+    float* ge2 = gew - ewlo;      float* ge1 = gew - ewlo * 2;          // by absolute local edge id
+    float* gad2 = gado - lo;      float* gad1 = gado - lo * 2;
+    float* hT2 = hTw - wlo * NC;  float* hT1 = hTw - wlo * 2 * NC;
+    float* asT2 = asTw - wlo;     float* asT1 = asTw - wlo * 2;
+    float* adT2 = adTo - lo;      float* adT1 = adTo - lo * 2;
+    float* alT2 = alTw - ewlo;    float* alT1 = alTw - ewlo * 2;
+    float* xG2 = xGo - lo * NC;   float* xG1 = xGo - lo * 2 * NC;
+
+    float* gp_cur = sc + L.sc_gpa;
+    float* gp_nxt = sc + L.sc_gpb;
+    const bool pub = M > 1;
+    float* slab = pub ? a.part_slabs + ((int64_t)seg * M + part) * L.slab_stride
+                      : a.slabs + (int64_t)seg * L.slab_stride;
+    const int64_t w = 2LL * NC * NC;
+    const float* xfinal = segbase + (int64_t)L.nb * SL.bstride + SL.xin;
+    // LDS-DMA of saved tables (independent of the backward chain) and transposed weights always rides on an MFMA
+    // stage or, for the first block, on this prologue: conv2 tables + W2^T of block b during dX1 of block b + 1,
+    // conv1 tables + W1^T of block b during dX2 of block b.
+    auto dma_conv2 = [&](int blk, int w0) {
+      const float* bs = segbase + (int64_t)blk * SL.bstride;
+      dma_copy16<THREADS>(hTw, bs + SL.h2 + (size_t)wlo * NC, wr * NC, w0);
+      dma_copy4<THREADS>(asTw, bs + SL.as2 + wlo, wr, w0);
+      dma_copy4<THREADS>(adTo, bs + SL.ad2 + lo, ow, w0);
+      dma_copy4<THREADS>(alTw, bs + SL.al2 + ewlo, weg, w0);
+      w_prefetch<NC, 2 * NC, EPI_RESID_MASK, THREADS>(wlA, a.wt + (int64_t)blk * 2 * w + w, nullptr, nullptr, w0);
+    };
+    if (L.nb > 0) dma_conv2(L.nb - 1, 0);
+    seg_lin1_bwd<NC, THREADS>(rw, n0, a.g_out, xfinal, P + L.p_lin1_w, gp_cur, gpT, slab + L.p_lin1_w,
+                              slab + L.p_lin1_b, L.nb > 0 ? 1 : 0, red);
+    int hcnt = 0;
+    bool halo = false;
+    if (pub && hcap > 0 && !a.no_halo) {
+      hcnt = build_halo<THREADS>(trp, tdsto, teido, rw, hrow, hedge, hcap, hcounter);
+      halo = hcnt <= hcap;
+    }
+    STAMP();
+    for (int b = L.nb - 1; b >= 0; --b) {
+      const float* base = segbase + (int64_t)b * SL.bstride;
+      const int64_t po = L.p_block0 + (int64_t)b * L.p_block_stride;
+      const float* pb = P + po;
+      float* sb = slab + po;
+      const float* wt1 = a.wt + (int64_t)b * 2 * w;
+      const float* wt2 = wt1 + w;
+      group_sync<THREADS>(grp);                  // K3 backward gathers g_pre of neighbours
+      publish_items<THREADS>(a, seg, part, 2 * (L.nb - 1 - b), grp.local || !pub, false);
+      if (pub) {
+        if (halo) pull_list_rows<NC, THREADS>(gpT, gp_cur + (size_t)n0 * NC, hrow, hcnt);
+        else {
+          Rows wv; wv.lo = lo - wlo; wv.hi = rw.hi - wlo;
+          pull_rows4<THREADS>(RAw, gp_cur + (size_t)(n0 + wlo) * NC, NC, wv, wr);
+        }
+        lds_barrier();
+      }
+      seg_mean_bwd<NC, THREADS, UB>(rw, otm, mrp, mtrp, mtdsto, gpT, 0, gy2T, 0, pub ? sc + L.sc_gy2 : nullptr, n0);
+      lds_barrier();
+      STAMP();
+      float* keep = sc + L.sc_keep + (int64_t)b * L.keep_stride;
+      float* gh = keep + L.k_gh1;
+      float* gh2 = keep + L.k_gh2;
+      seg_edge_dots<1, NC, THREADS, 2>(rw, 0, rp, colo, gy2T, 0, hT2, ge2 + elo, 0);
+      lds_barrier();
+      seg_bias_part<NC, THREADS>(rw, gy2T, 0, red);
+      seg_softmax_bwd<1, THREADS>(rw, 0, 0, rp, colo, alT2 + elo, asT2, adT2, ge2 + elo, 0, gad2, 0,
+                                  pub ? sc + L.sc_ge2 : nullptr, e0 + elo, nullptr, 0);
+      group_sync<THREADS>(grp);
+      if (pub) {
+        if (halo) {
+          pull_list_rows<NC, THREADS>(gy2T, sc + L.sc_gy2 + (size_t)n0 * NC, hrow, hcnt);
+          pull_list_small<1, THREADS>(ge2, sc + L.sc_ge2 + e0, hedge, hcnt);
+        } else {
+          Rows wv; wv.lo = lo - wlo; wv.hi = rw.hi - wlo;
+          pull_rows4<THREADS>(RAw + (size_t)wr * NC, sc + L.sc_gy2 + (size_t)(n0 + wlo) * NC, NC, wv, wr);
+          pull_flat<THREADS>(gew, sc + L.sc_ge2 + e0 + ewlo, elo - ewlo, ehi - ewlo, weg);
+        }
+        lds_barrier();
+      }
+      STAMP();
+      seg_bias_finish<NC, THREADS>(red, sb + L.c2_b);
+      seg_agg_bwd_src<1, NC, THREADS, UB>(rw, 0, trp, teido, tdsto, gy2T, 0, alT2, ge2, 0, gad2, 0, pb + L.c2_as,
+                                      pb + L.c2_ad, gh2, n0, keep + L.k_gas2, keep + L.k_gad2, xG2, 0);
+      lds_barrier();           // g_y2 (RA) and the conv2 tables are dead
+      STAMP();
+      // LDS-DMA of this block's conv1 tables and W1^T while the matrix cores run dX2
+      w_prefetch<2 * NC, NC, EPI_RESID_MASK, THREADS>(wlB, wt1, nullptr, nullptr, dw0);
+      dma_copy16<THREADS>(hTw, base + SL.h1 + (size_t)wlo * 2 * NC, wr * 2 * NC, dw0);
+      dma_copy4<THREADS>(asTw, base + SL.as1 + wlo * 2, wr * 2, dw0);
+      dma_copy4<THREADS>(adTo, base + SL.ad1 + lo * 2, ow * 2, dw0);
+      dma_copy4<THREADS>(alTw, base + SL.al1 + ewlo * 2, weg * 2, dw0);
+      seg_proj<NC, 2 * NC, 1, EPI_RESID_MASK, THREADS, true, true>(rw, xG2, 0, wt2, RA, 0, pub ? sc + L.sc_go1 : nullptr, n0,
+                                                               nullptr, nullptr, nullptr, nullptr, 0, nullptr, nullptr,
+                                                               nullptr, 0, base + SL.o1, 0, wlA);
+      __syncthreads();
+      STAMP();
+      seg_edge_dots<2, NC, THREADS, 2>(rw, 0, rp, colo, RA, 0, hT1, ge1 + elo * 2, 0);
+      lds_barrier();
+      seg_bias_part<2 * NC, THREADS>(rw, RA, 0, red);
+      seg_softmax_bwd<2, THREADS>(rw, 0, 0, rp, colo, alT1 + elo * 2, asT1, adT1, ge1 + elo * 2, 0, gad1, 0,
+                                  pub ? sc + L.sc_ge : nullptr, e0 + elo, nullptr, 0);
+      group_sync<THREADS>(grp);
+      publish_items<THREADS>(a, seg, part, 2 * (L.nb - 1 - b) + 1, grp.local || !pub, false);
+      if (pub) {
+        if (halo) {
+          pull_list_rows<2 * NC, THREADS>(RA, sc + L.sc_go1 + (size_t)n0 * 2 * NC, hrow, hcnt);
+          pull_list_small<2, THREADS>(ge1, sc + L.sc_ge + (size_t)e0 * 2, hedge, hcnt);
+        } else {
+          Rows wv; wv.lo = lo - wlo; wv.hi = rw.hi - wlo;
+          pull_rows4<THREADS>(RAw, sc + L.sc_go1 + (size_t)(n0 + wlo) * 2 * NC, 2 * NC, wv, wr);
+          pull_flat<THREADS>(gew, sc + L.sc_ge + (size_t)(e0 + ewlo) * 2, (elo - ewlo) * 2, (ehi - ewlo) * 2, weg * 2);
+        }
+        lds_barrier();
+      }
+      STAMP();
+      seg_bias_finish<2 * NC, THREADS>(red, sb + L.c1_b);
+      seg_agg_bwd_src<2, NC, THREADS, UB>(rw, 0, trp, teido, tdsto, RA, 0, alT1, ge1, 0, gad1, 0, pb + L.c1_as,
+                                      pb + L.c1_ad, gh, n0, keep + L.k_gas1, keep + L.k_gad1, xG1, 0);
+      lds_barrier();
+      STAMP();
+      if (b > 0) dma_conv2(b - 1, dw0);
+      seg_proj<2 * NC, NC, 1, EPI_RESID_MASK, THREADS, true, true>(rw, xG1, 0, wt1, gp_nxt, n0, gpT, 0, nullptr, nullptr,
+                                                               nullptr, nullptr, 0, nullptr, nullptr, gp_cur, n0,
+                                                               b > 0 ? base + SL.xin : nullptr, 0, wlB);
+      STAMP();
+      float* t = gp_cur; gp_cur = gp_nxt; gp_nxt = t;
+    }
+    group_sync<THREADS>(grp);
+    publish_items<THREADS>(a, seg, part, 2 * L.nb, grp.local || !pub, !pub);
+    seg_lin0_bwd<NC, THREADS>(rw, n0, gp_cur, a.x, a.mask, slab + L.p_lin0_w, slab + L.p_lin0_b, red);
+    if (pub && a.C > 0) {
+      group_sync<THREADS>(grp);
+      publish_items<THREADS>(a, seg, part, 2 * L.nb + 1, grp.local, true);
+    }
+    if (a.g_x) {
+      constexpr int G = NC / 4;
+      const float4 wv = ld4(P + L.p_lin0_w + (tid % G) * 4);
+      const int rounds = (rw.hi - rw.lo + THREADS / G - 1) / (THREADS / G);
+      for (int it = 0; it < rounds; ++it) {
+        int r = rw.lo + it * (THREADS / G) + tid / G;
+        const bool valid = r < rw.hi;
+        if (!valid) r = rw.hi - 1;
+        const float4 xv = ld4(gp_cur + ((size_t)n0 + r) * NC + (tid % G) * 4);
+        float d = xv.x * wv.x;
+        d = fmaf(xv.y, wv.y, d); d = fmaf(xv.z, wv.z, d); d = fmaf(xv.w, wv.w, d);
+        for (int off = G >> 1; off > 0; off >>= 1) d += __shfl_xor(d, off);
+        if (valid && (tid % G) == 0) a.g_x[n0 + r] = d;
+      }
+    }
+  }
+  if (M > 1 && tid == 0 && *a.err) {
+    if ((a.phases & GATRES_PHASE_FORWARD) && a.out) a.out[n0] = NAN;
+    if (a.phases & GATRES_PHASE_BACKWARD) a.slabs[(int64_t)seg * L.slab_stride + L.p_lin1_b] = NAN;
+  }
+  if (a.stamps && blockIdx.x == 0 && threadIdx.x == 0) {
+    a.stamps[a.stamp_cap + 1] = clock64();
+    a.stamps[a.stamp_cap + 2] = wall_clock64();
+  }
+}
+
 // grads = sum of segment slabs (fixed order) ; optionally the Adam update and the loss finalisation in the same pass
 __global__ __launch_bounds__(256) void reduce_adam_kernel(const float* __restrict__ slabs, int num_slabs,
                                                           int num_loss, long long stride, long long count,
@@ -1830,8 +2364,27 @@ static int fused_consumers(const Layout& L, const gatres_graph_t* g, int M) {
   return c > 0 ? c : 0;
 }
 
+// The window kernel applies when the plan knows the parts' row windows and both LDS layouts fit with them.
+static bool use_window_kernel(const FusedArgs& a, const gatres_graph_t* g) {
+  if (getenv("GATRES_FUSED_NO_WINDOW") || !a.saved || a.M < 2 || a.L.nc > 32 || threads_for(a.L.nc) != 1024) return false;
+  const int k = a.M == 2 ? 0 : (a.M == 4 ? 1 : 2);
+  const int wr = g->window[k][0], ge = g->window[k][1], gm = g->window[k][2];
+  if (wr <= 0) return false;
+  const int tiles = (g->max_segment_nodes + 15) / 16;
+  const int ow = 16 * ((tiles + a.M - 1) / a.M);
+  return win_fwd_bytes(a.L.nc, wr, ow, ge, gm) <= LDS_BYTES && win_bwd_bytes(a.L.nc, 1024, wr, ow, ge, gm) <= LDS_BYTES &&
+         wr <= 65535 && ge <= 65535 && gm <= 65535;
+}
+
 template <int NC, int THREADS>
 static int launch_fused(const FusedArgs& a, const gatres_graph_t* g, hipStream_t st) {
+  if constexpr (THREADS == 1024 && NC <= 32) {
+    if (use_window_kernel(a, g)) {
+      const dim3 wgrid((unsigned)(((g->num_segments + 7) / 8) * 8 * (a.M + a.C)));
+      hipLaunchKernelGGL((gatres_window_kernel<NC, THREADS>), wgrid, dim3(THREADS), 0, st, a);
+      return gatres_launch_status();
+    }
+  }
   const bool cache = !getenv("GATRES_FUSED_NOCACHE") &&
                      cache_fits(NC, THREADS, g->max_segment_nodes, g->max_segment_edges_gat, g->max_segment_edges_mean);
   const dim3 grid((unsigned)(((g->num_segments + 7) / 8) * 8 * (a.M + a.C)));

@@ -61,9 +61,16 @@ class GraphPlan:
             self.segment_ptr_host = seg[: self.num_segments + 1].clone()
             self.arrays["seg_ptr"] = self.segment_ptr_host.to(device)
             seg_dev_ptr = self.arrays["seg_ptr"].data_ptr()
+            # row windows of split segments (2 / 4 / 8 workgroups per segment): rows, GATConv edges, SimpleConv edges
+            win = torch.zeros(9, **i32)
+            _native.check(lib.gatres_graph_windows_host(ei_host.data_ptr(), E, N, self.segment_ptr_host.data_ptr(),
+                                                        self.num_segments, win.data_ptr()), "gatres_graph_windows_host")
+            self.windows = [int(v) for v in win]
+        else:
+            self.windows = [0] * 9
         self.c = _native.GatresGraph(N, Eg, E, self.num_segments, *[self.arrays[k].data_ptr() for k in host.keys()],
                                      seg_dev_ptr, self.max_segment_nodes, self.max_segment_edges_gat,
-                                     self.max_segment_edges_mean, 0)
+                                     self.max_segment_edges_mean, 0, (C.c_int32 * 9)(*self.windows), 0)
 
     def ref(self):
         return C.byref(self.c)

@@ -65,6 +65,11 @@ typedef struct gatres_graph {
   int32_t max_segment_edges_gat;   /* most GATConv edges (self loops included) inside one segment */
   int32_t max_segment_edges_mean;  /* most SimpleConv edges inside one segment                    */
   int32_t reserved;
+  /* Row windows of split segments, from gatres_graph_windows_host: window[k] = {rows, GATConv edges, SimpleConv
+   * edges} for 2 << k workgroups per segment.  All zero = unknown (the fused kernels then size their LDS tables by
+   * the whole segment). */
+  int32_t window[3][3];
+  int32_t reserved2;
 } gatres_graph_t;
 
 /* Host-side plan builder (runs on the CPU, once per topology).  edge_index_host: int64 [2, E] row-major as
@@ -81,6 +86,12 @@ int gatres_graph_segments_host(const int64_t* edge_index_host, int64_t num_edges
                                int32_t merge_upto, int32_t* seg_ptr_host, int32_t* num_segments_out,
                                int32_t* max_segment_nodes_out, int32_t* max_segment_edges_gat_out,
                                int32_t* max_segment_edges_mean_out);
+
+/* Row windows of split segments (see gatres_graph_t.window): for M = 2, 4, 8 workgroups per segment, the largest
+ * contiguous row range a part needs (own rows + the rows adjacent to them), in rows / GATConv edges / SimpleConv
+ * edges: out9 = {rows2, gat2, mean2, rows4, gat4, mean4, rows8, gat8, mean8}. */
+int gatres_graph_windows_host(const int64_t* edge_index, int64_t num_edges, int64_t num_nodes, const int32_t* seg_ptr,
+                              int32_t num_segments, int32_t* out9);
 
 /* 64-bit content hash of an int64 [2,E] DEVICE edge_index (for plan caching); hash_out: device uint64[1],
  * must be zeroed by the caller on the same stream before the call. */
