@@ -1878,7 +1878,7 @@ __global__ __launch_bounds__(THREADS) void gatres_window_kernel(const FusedArgs 
     float* hAw = ldsf;
     float* hBw = hAw + (size_t)wr * 2 * NC;
     float* saw = hBw + (size_t)wr * NC;
-    float* sdo = saw + (size_t)wr * 2;
+    float* sdo = saw + (size_t)((wr * 2 + 3) & ~3);      // (every table starts 16-byte aligned: ds_read_b128)
     float* xAo = sdo + (size_t)((ow * 2 + 3) & ~3);
     float* xBo = xAo + (size_t)ow * NC;
     float* wlA = reinterpret_cast<float*>(lds_raw + ((reinterpret_cast<unsigned char*>(xBo + (size_t)ow * 2 * NC) - lds_raw + 15) & ~15));
