@@ -365,7 +365,8 @@ def main():
             inline_pg = us_pg < 10.0         # a no-op call: the deferred gradients ran on consumer workgroups of the same launch
             if inline_pg:
                 nbytes += nbytes_pg
-            result["roofline"] = {"bound": "hbm", "kernel": "gatres_fused_kernel (forward+loss+backward, one launch)",
+            result["roofline"] = {"bound": "hbm", "kernel": "gatres_window_kernel / gatres_fused_kernel (forward+loss+backward, "
+                                                                     "one launch)",
                                   "achieved": nbytes / us * 1e-3, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                   "frac": nbytes / us * 1e-3 / HBM_PEAK_GBS, "traffic": pmc_traffic(args),
                                   "avg_launch_us": us, "algorithmic_bytes_per_launch": nbytes,
