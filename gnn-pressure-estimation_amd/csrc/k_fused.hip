@@ -481,7 +481,7 @@ __device__ __forceinline__ void seg_softmax(Rows rw, const u16* rp, const u16* c
     const int r = idx / H, hd = idx % H;
     const int beg = rp[r], deg = (int)rp[r + 1] - beg;            // deg >= 1 (self loop)
     const float adst = adst_t[(unsigned)((ab + r) * H + hd)];
-    if (deg <= MAXD) {
+    if (__builtin_expect(deg <= MAXD, 1)) {
       float so[MAXD];
       float m = -INFINITY;
 #pragma unroll
@@ -549,7 +549,7 @@ __device__ __forceinline__ void seg_gather(Rows rw, const u16* rp, const u16* co
     float4 acc[UR];
 #pragma unroll
     for (int u = 0; u < UR; ++u) acc[u] = f4zero();
-    if (max_of<UR>(deg) <= MAXD) {
+    if (__builtin_expect(max_of<UR>(deg) <= MAXD, 1)) {      // (the edge-at-a-time path is cold: laid out of line)
       float4 v[UR][MAXD];
       float al[UR][MAXD];
 #pragma unroll
@@ -616,7 +616,7 @@ __device__ __forceinline__ void seg_mean_fwd(Rows rw, int em, const u16* mrp, co
       rr[u] = ld4(x0 + (unsigned)((xb + r[u]) * C + c0));
     }
     const int dmax = wave_max_deg(max_of<UR>(deg));
-    if (max_of<UR>(deg) <= MAXD) {
+    if (__builtin_expect(max_of<UR>(deg) <= MAXD, 1)) {      // (the edge-at-a-time path is cold: laid out of line)
       float4 v[UR][MAXD];
 #pragma unroll
       for (int k = 0; k < MAXD; ++k)
@@ -675,7 +675,7 @@ __device__ __forceinline__ void seg_mean_bwd(Rows rw, int em, const u16* mrp, co
 #pragma unroll
     for (int u = 0; u < UR; ++u) { beg[u] = mtrp[r[u]]; deg[u] = (int)mtrp[r[u] + 1] - beg[u]; }
     const int dmax = wave_max_deg(max_of<UR>(deg));
-    if (max_of<UR>(deg) <= MAXD) {
+    if (__builtin_expect(max_of<UR>(deg) <= MAXD, 1)) {      // (the edge-at-a-time path is cold: laid out of line)
       float4 v[UR][MAXD];
       float cnt[UR][MAXD];
 #pragma unroll
@@ -747,7 +747,7 @@ __device__ __forceinline__ void seg_edge_dots(Rows rw, int n0, const u16* rp, co
       go[u] = ld4(g_out + (unsigned)((gb + r[u]) * HC + c0));
     }
     const int dmax = wave_max_deg(max_of<UR>(deg));
-    if (max_of<UR>(deg) <= MAXD) {
+    if (__builtin_expect(max_of<UR>(deg) <= MAXD, 1)) {      // (the edge-at-a-time path is cold: laid out of line)
       float4 hv[UR][MAXD];
 #pragma unroll
       for (int k = 0; k < MAXD; ++k)
@@ -787,7 +787,7 @@ __device__ __forceinline__ void seg_softmax_bwd(Rows rw, int n0, int e0, const u
     const int beg = rp[r], deg = (int)rp[r + 1] - beg;
     const float adst = a_dst[(unsigned)((n0 + r) * H + hd)];
     float S = 0.f, gad = 0.f;
-    if (deg <= MAXD) {
+    if (__builtin_expect(deg <= MAXD, 1)) {
       float al[MAXD], ga[MAXD], raw[MAXD];
 #pragma unroll
       for (int k = 0; k < MAXD; ++k) {
@@ -859,7 +859,7 @@ __device__ __forceinline__ void seg_agg_bwd_src(Rows rw, int e0, const u16* trp,
 #pragma unroll
     for (int u = 0; u < UR; ++u) { beg[u] = trp[r[u]]; deg[u] = (int)trp[r[u] + 1] - beg[u]; }   // deg >= 1
     const int dmax = wave_max_deg(max_of<UR>(deg));
-    if (max_of<UR>(deg) <= MAXD) {
+    if (__builtin_expect(max_of<UR>(deg) <= MAXD, 1)) {      // (the edge-at-a-time path is cold: laid out of line)
       float al[UR][MAXD], ge[UR][MAXD];
       float4 v[UR][MAXD];
 #pragma unroll
