@@ -1943,7 +1943,7 @@ __global__ __launch_bounds__(THREADS) void gatres_window_kernel(const FusedArgs 
                                                         nullptr, 0, nullptr, 0, wlA);
       group_sync<THREADS>(grp);
       if (M > 1) {
-        if (halo) {
+        if (__builtin_expect(halo, 1)) {
           pull_list_rows<2 * NC, THREADS>(hA, base + SL.h1, hlist, hcnt);
           pull_list_small<2, THREADS>(sa2, base + SL.as1, hlist, hcnt);
         } else {
@@ -1955,7 +1955,7 @@ __global__ __launch_bounds__(THREADS) void gatres_window_kernel(const FusedArgs 
       }
       STAMP();
       // K2 conv1: alpha -> HBM + the h2 window's LDS (dead now), then the gather (o1 -> HBM + the x buffer of proj2)
-      if (2 * oeg <= wr * NC) {
+      if (__builtin_expect(2 * oeg <= wr * NC, 1)) {
         seg_softmax<2, true, THREADS>(rw, rp, colo, sa2, sd2, 0, base + SL.al1, elo, hBw);
         lds_barrier();
         seg_gather<true, 2, NC, THREADS, UF>(rw, rp, colo, hA, 0, hBw, 0, pb + L.c1_b, base + SL.o1, 0, xB, 0);
@@ -1975,7 +1975,7 @@ __global__ __launch_bounds__(THREADS) void gatres_window_kernel(const FusedArgs 
                                                         nullptr, 0, nullptr, 0, wlB);
       group_sync<THREADS>(grp);
       if (M > 1) {
-        if (halo) {
+        if (__builtin_expect(halo, 1)) {
           pull_list_rows<NC, THREADS>(hB, base + SL.h2, hlist, hcnt);
           pull_list_small<1, THREADS>(sa1, base + SL.as2, hlist, hcnt);
         } else {
@@ -1988,7 +1988,7 @@ __global__ __launch_bounds__(THREADS) void gatres_window_kernel(const FusedArgs 
       STAMP();
       // K2 conv2: alpha's LDS table in the upper half of the h1 window, y2 in the lower half (+ HBM for the partners)
       float* y2pub = M > 1 ? y2g : nullptr;
-      if (oeg <= wr * NC) {
+      if (__builtin_expect(oeg <= wr * NC, 1)) {
         float* al2L = hAw + (size_t)wr * NC;
         seg_softmax<1, true, THREADS>(rw, rp, colo, sa1, sd1, 0, base + SL.al2, elo, al2L);
         lds_barrier();
@@ -2001,7 +2001,7 @@ __global__ __launch_bounds__(THREADS) void gatres_window_kernel(const FusedArgs 
       }
       group_sync<THREADS>(grp);
       if (M > 1) {
-        if (halo) pull_list_rows<NC, THREADS>(hAw - wlo * NC, y2g + (size_t)n0 * NC, hlist, hcnt);
+        if (__builtin_expect(halo, 1)) pull_list_rows<NC, THREADS>(hAw - wlo * NC, y2g + (size_t)n0 * NC, hlist, hcnt);
         else {
           Rows wv; wv.lo = lo - wlo; wv.hi = rw.hi - wlo;
           pull_rows4<THREADS>(hAw, y2g + (size_t)(n0 + wlo) * NC, NC, wv, wr);
@@ -2147,7 +2147,7 @@ __global__ __launch_bounds__(THREADS) void gatres_window_kernel(const FusedArgs 
       group_sync<THREADS>(grp);                  // K3 backward gathers g_pre of neighbours
       publish_items<THREADS>(a, seg, part, 2 * (L.nb - 1 - b), grp.local || !pub, false);
       if (pub) {
-        if (halo) pull_list_rows<NC, THREADS>(gpT, gp_cur + (size_t)n0 * NC, hrow, hcnt);
+        if (__builtin_expect(halo, 1)) pull_list_rows<NC, THREADS>(gpT, gp_cur + (size_t)n0 * NC, hrow, hcnt);
         else {
           Rows wv; wv.lo = lo - wlo; wv.hi = rw.hi - wlo;
           pull_rows4<THREADS>(RAw, gp_cur + (size_t)(n0 + wlo) * NC, NC, wv, wr);
@@ -2167,7 +2167,7 @@ __global__ __launch_bounds__(THREADS) void gatres_window_kernel(const FusedArgs 
                                   pub ? sc + L.sc_ge2 : nullptr, e0 + elo, nullptr, 0);
       group_sync<THREADS>(grp);
       if (pub) {
-        if (halo) {
+        if (__builtin_expect(halo, 1)) {
           pull_list_rows<NC, THREADS>(gy2T, sc + L.sc_gy2 + (size_t)n0 * NC, hrow, hcnt);
           pull_list_small<1, THREADS>(ge2, sc + L.sc_ge2 + e0, hedge, hcnt);
         } else {
@@ -2202,7 +2202,7 @@ __global__ __launch_bounds__(THREADS) void gatres_window_kernel(const FusedArgs 
       group_sync<THREADS>(grp);
       publish_items<THREADS>(a, seg, part, 2 * (L.nb - 1 - b) + 1, grp.local || !pub, false);
       if (pub) {
-        if (halo) {
+        if (__builtin_expect(halo, 1)) {
           pull_list_rows<2 * NC, THREADS>(RA, sc + L.sc_go1 + (size_t)n0 * 2 * NC, hrow, hcnt);
           pull_list_small<2, THREADS>(ge1, sc + L.sc_ge + (size_t)e0 * 2, hedge, hcnt);
         } else {
