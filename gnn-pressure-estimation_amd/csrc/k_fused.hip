@@ -1826,7 +1826,9 @@ __global__ __launch_bounds__(THREADS) void gatres_window_kernel(const FusedArgs 
   grp.flags = a.flags + (size_t)seg * 8 * FLAG_STRIDE; grp.M = M; grp.part = part; grp.err = a.err;
   group_init<THREADS>(grp);
   if (a.safe_sync) grp.local = false;
-  constexpr int UF = 2, UB = 1;
+  // rows per lane group per trip: a part owns ~100 rows, one trip covers them in every stage but conv1's edge dots;
+  // more unrolling only costs registers and code (the block loop does not fit the instruction cache as it is)
+  constexpr int UF = 1, UB = 1;
   // first wave that issues LDS-DMA inside MFMA stages: the waves below it own a 16-row tile there (dma_copy16)
   const int dw0 = min((ow + 15) >> 4, THREADS / 64 - 4);
   constexpr int WL_FLOATS = 2 * NC * (2 * NC + 4) + 4 * NC;
@@ -2160,7 +2162,7 @@ __global__ __launch_bounds__(THREADS) void gatres_window_kernel(const FusedArgs 
       float* keep = sc + L.sc_keep + (int64_t)b * L.keep_stride;
       float* gh = keep + L.k_gh1;
       float* gh2 = keep + L.k_gh2;
-      seg_edge_dots<1, NC, THREADS, 2>(rw, 0, rp, colo, gy2T, 0, hT2, ge2 + elo, 0);
+      seg_edge_dots<1, NC, THREADS, 1>(rw, 0, rp, colo, gy2T, 0, hT2, ge2 + elo, 0);
       lds_barrier();
       seg_bias_part<NC, THREADS>(rw, gy2T, 0, red);
       seg_softmax_bwd<1, THREADS>(rw, 0, 0, rp, colo, alT2 + elo, asT2, adT2, ge2 + elo, 0, gad2, 0,
