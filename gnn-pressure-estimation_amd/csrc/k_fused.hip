@@ -2268,7 +2268,7 @@ __global__ __launch_bounds__(256) void reduce_adam_kernel(const float* __restric
                                                           float* __restrict__ m, float* __restrict__ v,
                                                           unsigned long long* __restrict__ step_counter, double lr,
                                                           double b1, double b2, double eps, double wd,
-                                                          float grad_scale) {
+                                                          float grad_scale, float* __restrict__ wt, int nb, int nc) {
   __shared__ float s_step_size, s_bc2_sqrt;
   if (do_adam && threadIdx.x == 0) {
     const double t = (double)(step_counter[0] + 1ULL);
@@ -2302,9 +2302,23 @@ __global__ __launch_bounds__(256) void reduce_adam_kernel(const float* __restric
       mv = mv + (float)(1.0 - b1) * (gv - mv);
       const float vv = (float)b2 * v[idx] + (float)(1.0 - b2) * gv * gv;
       const float denom = sqrtf(vv) / s_bc2_sqrt + (float)eps;
-      p[idx] = pv + (-s_step_size * mv) / denom;
+      const float pn = pv + (-s_step_size * mv) / denom;
+      p[idx] = pn;
       m[idx] = mv;
       v[idx] = vv;
+      if (wt) {                   // keep the transposed conv weights of the next backward current (k_misc.hip layout)
+        const long long per = 2LL * nc * nc, stride = 9LL * nc + 2 * per, off = idx - 2LL * nc;
+        if (off >= 0 && off < (long long)nb * stride) {
+          const long long b = off / stride, o = off % stride;
+          if (o >= 6LL * nc && o < 6LL * nc + per) {                        // W1 [2nc][nc] -> [nc][2nc]
+            const long long e = o - 6LL * nc, row = e / nc, col = e % nc;
+            wt[b * 2 * per + col * 2 * nc + row] = pn;
+          } else if (o >= 9LL * nc + per) {                                 // W2 [nc][2nc] -> [2nc][nc]
+            const long long e = o - 9LL * nc - per, row = e / (2 * nc), col = e % (2 * nc);
+            wt[b * 2 * per + per + col * nc + row] = pn;
+          }
+        }
+      }
     }
   }
   if (do_adam) {
@@ -2511,6 +2525,6 @@ extern "C" int gatres_fused_finish(const gatres_model_t* m, const gatres_graph_t
                      scratch + L.sc_slabs, g->num_segments, g->num_segments * fused_split(L, g),
                      (long long)L.slab_stride, (long long)L.P, grads, loss_part, loss, do_adam, params, exp_avg, exp_avg_sq,
                      reinterpret_cast<unsigned long long*>(step_counter), lr, beta1, beta2, eps, weight_decay,
-                     grad_scale);
+                     grad_scale, do_adam ? scratch + L.sc_wt : nullptr, L.nb, L.nc);
   return gatres_launch_status();
 }

@@ -23,7 +23,7 @@ extern "C" int gatres_train_step(const gatres_train_step_t* ts, void* stream) {
     const bool adam = ts->phases & GATRES_PHASE_ADAM;
     if ((bwd && !ts->grads) || (adam && (!ts->grads || !ts->exp_avg || !ts->exp_avg_sq || !ts->step_counter)))
       return GATRES_E_BADARG;
-    if (bwd) {
+    if (bwd && !(ts->flags & GATRES_FLAG_WT_VALID)) {      // (the fused Adam pass keeps scratch's W^T current)
       rc = gatres_fused_prepare_backward(&ts->model, ts->graph, ts->params, ts->scratch, stream);
       if (rc) return rc;
     }

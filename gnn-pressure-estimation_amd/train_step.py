@@ -84,9 +84,10 @@ class GATResTrainer:
         self.use_graph = use_graph
         self._graphs = {}
         self._params_ptr = params.data_ptr()
+        self._wt_version = None
 
     # ------------------------------------------------------------------------------------------
-    def _desc(self, phases: int, device_mask: bool) -> _TrainStepC:
+    def _desc(self, phases: int, device_mask: bool, wt_valid: bool = False) -> _TrainStepC:
         m = self.model
         params = m.flat_parameters
         if params.data_ptr() != self._params_ptr:
@@ -99,32 +100,54 @@ class GATResTrainer:
             self.node_ptr.data_ptr() if (device_mask and self.node_ptr is not None) else None,
             self.num_graphs, phases, self.mask_rate, self.seed, self.out.data_ptr(), self.g_out.data_ptr(),
             self.loss.data_ptr(), self.saved.data_ptr(), self.scratch.data_ptr(), h["lr"], h["beta1"], h["beta2"],
-            h["eps"], h["weight_decay"], 1.0 / self.world, 0 if self.fused else 1)
+            h["eps"], h["weight_decay"], 1.0 / self.world, (0 if self.fused else 1) | (2 if wt_valid else 0))
 
-    def _enqueue(self, phases: int, device_mask: bool) -> None:
-        ts = self._desc(phases, device_mask)
+    def _wt_current(self) -> bool:
+        """scratch's transposed conv weights are current: our last fused Adam step wrote them and nothing else has
+        modified the parameter storage since (torch bumps the version counter on every in-place op; our kernels do
+        not go through torch)."""
+        return self._wt_version is not None and self._wt_version == self.model.flat_parameters._version
+
+    def _enqueue(self, phases: int, device_mask: bool, wt_valid: bool = False) -> None:
+        ts = self._desc(phases, device_mask, wt_valid)
         _native.check(self.lib.gatres_train_step(C.byref(ts), _native.current_stream(self.device)),
                       "gatres_train_step")
 
     def _run(self, phases: int, device_mask: bool) -> None:
+        full = PHASE_BACKWARD | PHASE_ADAM
+        wt_valid = self.fused and (phases & PHASE_BACKWARD) != 0 and self._wt_current()
+        try:
+            self._run_inner(phases, device_mask, wt_valid)
+        finally:
+            # a fused backward + Adam step leaves the transposed weights of the NEW parameters in scratch
+            if self.fused and (phases & full) == full:
+                self._wt_version = self.model.flat_parameters._version
+
+    def _run_inner(self, phases: int, device_mask: bool, wt_valid: bool) -> None:
         if not self.use_graph:
-            self._enqueue(phases, device_mask)
+            self._enqueue(phases, device_mask, wt_valid)
             return
-        key = (phases, device_mask)
+        key = (phases, device_mask, wt_valid)
         g = self._graphs.get(key)
         if g is None:
             # warm-up launch outside capture (module load, lazy init), then capture the same sequence once
             state = (self.step_counter.clone(), self.model.flat_parameters.clone(), self.exp_avg.clone(),
                      self.exp_avg_sq.clone())
-            self._enqueue(phases, device_mask)
+            self._enqueue(phases, device_mask, wt_valid)
             torch.cuda.synchronize(self.device)
             self.step_counter.copy_(state[0]); self.model.flat_parameters.copy_(state[1])
             self.exp_avg.copy_(state[2]); self.exp_avg_sq.copy_(state[3])
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
-                self._enqueue(phases, device_mask)
+                self._enqueue(phases, device_mask, wt_valid)
             self.step_counter.copy_(state[0]); self.model.flat_parameters.copy_(state[1])
             self.exp_avg.copy_(state[2]); self.exp_avg_sq.copy_(state[3])
+            if wt_valid:
+                # the warm-up step left the transposes of ITS updated weights in scratch; the parameters were rolled
+                # back, so make the promise this graph relies on true again
+                _native.check(self.lib.gatres_fused_prepare_backward(
+                    self.model._cmodel_ref(), self.plan.ref(), self.model.flat_parameters.data_ptr(),
+                    self.scratch.data_ptr(), _native.current_stream(self.device)), "gatres_fused_prepare_backward")
             self._graphs[key] = g
         g.replay()
 

@@ -315,6 +315,9 @@ typedef struct gatres_train_step {
   int32_t flags;                   /* GATRES_FLAG_PER_OP: force the per-op kernels       */
 } gatres_train_step_t;
 #define GATRES_FLAG_PER_OP 1
+/* The transposed conv weights in `scratch` already match `params`: true right after a fused PHASE_ADAM step on the
+ * same scratch (its Adam pass rewrites them) as long as nobody else has touched the parameters; skips the transposes. */
+#define GATRES_FLAG_WT_VALID 2
 
 int gatres_train_step(const gatres_train_step_t* ts, void* stream);
 

@@ -226,6 +226,32 @@ def test_native_train_step_matches_oracle(pkg, oracle, use_graph, fused):
     assert torch.isfinite(tr.loss).all()
 
 
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_transposed_weights_follow_external_parameter_changes(pkg, oracle, use_graph):
+    """The fused Adam pass keeps the backward's transposed conv weights current, and the trainer then skips the
+    transposes (GATRES_FLAG_WT_VALID) -- but only while nobody else touches the parameters.  Overwriting them through
+    torch between two steps must be noticed (torch's version counter): gradients of the next step match a trainer that
+    starts from the overwritten parameters."""
+    nb, nc, bs = 3, 32, 2
+    ei = pkg.wdn_synth.collate_edge_index(pkg.wdn_synth.make_wdn_topology(), 388, bs).cuda()
+    y = pkg.wdn_synth.collate_snapshots(pkg.wdn_synth.make_snapshots(4, 388, seed=2), range(bs)).cuda()
+    mask = torch.from_numpy(pkg.wdn_synth.generate_batch_mask([388] * bs, 0.95, np.random.RandomState(5))).cuda()
+    model, _ = build(pkg, oracle, nb, nc, seed=31)
+    tr = pkg.GATResTrainer(model, ei, 388 * bs, nodes_per_graph=[388] * bs, use_graph=use_graph)
+    for _ in range(3):
+        tr.step(y, y, mask)                          # from the second step on the transposes are skipped
+    fresh, _ = build(pkg, oracle, nb, nc, seed=77)   # other weights
+    with torch.no_grad():
+        model.flat_parameters.copy_(fresh.flat_parameters)
+    tr.forward_backward(y, y, mask)
+    g_after = tr.grads.clone()
+    tr.step(y, y, mask)                              # and through the (graph) step path as well
+    tr2 = pkg.GATResTrainer(fresh, ei, 388 * bs, nodes_per_graph=[388] * bs, use_graph=False)
+    tr2.forward_backward(y, y, mask)
+    assert relerr(g_after, tr2.grads) < 1e-6
+    assert relerr(tr.grads, tr2.grads) < 1e-6
+
+
 def test_edge_cases_and_determinism(pkg, oracle):
     model, p = build(pkg, oracle, 2, 8, seed=9)
     n = 30
