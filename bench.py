@@ -47,6 +47,8 @@ def parse():
     ap.add_argument("--per-op", action="store_true", help="one launch per stage instead of the fused per-snapshot kernel")
     ap.add_argument("--force-collective-path", action="store_true",
                     help="run the multi-GPU sequence (backward | RCCL all-reduce | Adam) even at world size 1")
+    ap.add_argument("--fused-adam", action="store_true",
+                    help="with --drop-in: FusedAdam (one native launch) instead of torch.optim.Adam")
     ap.add_argument("--drop-in", action="store_true",
                     help="time the reference loop body verbatim (train.py:160-188): nn.Module forward, loss.backward(), "
                          "torch.optim.Adam, host-side numpy mask, a fresh edge_index tensor every batch")
@@ -240,7 +242,10 @@ def cpu_baseline(args, nb, nc):
 def drop_in_loop(args, G, model, topo, device, nb, nc):
     """The reference's loop body on the drop-in module (single GPU): what a user gets by only swapping the import."""
     import numpy as np
-    opt = torch.optim.Adam(model.parameters(), lr=5e-4, weight_decay=6e-6)
+    if args.fused_adam:
+        opt = G.FusedAdam(model, lr=5e-4, weight_decay=6e-6)
+    else:
+        opt = torch.optim.Adam(model.parameters(), lr=5e-4, weight_decay=6e-6)
     crit = torch.nn.MSELoss()
     bs, npg = args.batch_size, args.nodes
     snaps = G.wdn_synth.make_snapshots(8 * bs, npg, seed=100)
@@ -271,7 +276,8 @@ def drop_in_loop(args, G, model, topo, device, nb, nc):
                       "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
                       "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
                       "data": "synthetic",
-                      "config": {"workload": f"{args.model}, drop-in nn.Module + torch.optim.Adam + host numpy mask, "
+                      "config": {"workload": f"{args.model}, drop-in nn.Module + "
+                                             f"{'FusedAdam' if args.fused_adam else 'torch.optim.Adam'} + host numpy mask, "
                                              f"reference loop body verbatim (train.py:160-190), batch_size={bs}",
                                  "final_loss": last}}))
 
