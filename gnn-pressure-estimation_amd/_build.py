@@ -29,8 +29,9 @@ def _hipcc() -> str:
 
 
 def _flags():
+    extra = os.environ.get("GATRES_HIPCC_FLAGS", "").split()        # experiments only (e.g. -mllvm options)
     return ["-O3", f"--offload-arch={ARCH}", "-fPIC", "-std=c++17", "-ffp-contract=off", "-Wall",
-            "-Wno-unused-function", f"-I{os.path.join(REPO_DIR, 'include')}", f"-I{CSRC}"]
+            "-Wno-unused-function", f"-I{os.path.join(REPO_DIR, 'include')}", f"-I{CSRC}"] + extra
 
 
 def _stale(target: str, deps) -> bool:
