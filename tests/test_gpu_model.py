@@ -226,6 +226,27 @@ def test_native_train_step_matches_oracle(pkg, oracle, use_graph, fused):
     assert torch.isfinite(tr.loss).all()
 
 
+@pytest.mark.parametrize("nc", [8, 16])
+def test_window_kernel_narrow_models(pkg, oracle, nc):
+    """The window kernel at nc = 8 / 16 (different lane groups, W slot sizes, alpha-table fits) against the per-op path
+    and the oracle on C-Town-sized graphs."""
+    nb, bs = 4, 3
+    x, y, ei, mask = ctown_batch(pkg, bs, 388, 430)
+    mf, p = build(pkg, oracle, nb, nc, seed=61, fused=True)
+    mp, _ = build(pkg, oracle, nb, nc, seed=61, fused=False)
+    tf = pkg.GATResTrainer(mf, ei.cuda(), 388 * bs, nodes_per_graph=[388] * bs, use_graph=False, fused=True)
+    tp = pkg.GATResTrainer(mp, ei.cuda(), 388 * bs, nodes_per_graph=[388] * bs, use_graph=False, fused=False)
+    ref = oracle.OracleTrainer(p)
+    for it in range(2):
+        l_ref, o_ref = ref.step(y.clone(), y, ei, mask)
+        lf = tf.step(y.cuda(), y.cuda(), mask.cuda())
+        lp = tp.step(y.cuda(), y.cuda(), mask.cuda())
+        if it == 0:
+            assert torch.equal(tf.out, tp.out)
+        assert relerr(tf.out, o_ref) < 2e-5 and relerr(lf, l_ref) < 2e-5
+        assert relerr(tf.grads, tp.grads) < 2e-5 and relerr(tf.grads, ref.flat("grads")) < 1e-4
+
+
 @pytest.mark.parametrize("split", [4, 8])
 def test_window_kernel_on_a_ragged_batch(pkg, oracle, split, monkeypatch):
     """Graphs of different sizes whose node order is local (compact row windows): the window kernel carries them,
