@@ -22,6 +22,18 @@ static inline int gatres_row_lanes(int width) {
   return g;
 }
 
+// beta^t for the Adam bias corrections: square-and-multiply in double (<= 2 * 64 multiplications, a few ulp from
+// pow(); every workgroup of the update kernels needs it before it can start, and pow() costs ~1 us there)
+__device__ __forceinline__ double gatres_powi(double b, unsigned long long t) {
+  double r = 1.0;
+  while (t) {
+    if (t & 1ULL) r *= b;
+    b *= b;
+    t >>= 1;
+  }
+  return r;
+}
+
 __device__ __forceinline__ float gatres_leaky(float v) { return v > 0.f ? v : v * GATRES_NEG_SLOPE; }
 
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }

@@ -2271,14 +2271,17 @@ __global__ __launch_bounds__(256) void reduce_adam_kernel(const float* __restric
                                                           float grad_scale, float* __restrict__ wt, int nb, int nc) {
   __shared__ float s_step_size, s_bc2_sqrt;
   if (do_adam && threadIdx.x == 0) {
-    const double t = (double)(step_counter[0] + 1ULL);
-    s_step_size = (float)(lr / (1.0 - pow(b1, t)));
-    s_bc2_sqrt = (float)sqrt(1.0 - pow(b2, t));
+    const unsigned long long t = step_counter[0] + 1ULL;
+    s_step_size = (float)(lr / (1.0 - gatres_powi(b1, t)));
+    s_bc2_sqrt = (float)sqrt(1.0 - gatres_powi(b2, t));
   }
-  if (loss_part && blockIdx.x == 0 && threadIdx.x == 0) {
+  if (loss_part && blockIdx.x == 0 && threadIdx.x < 64) {
+    // the loss: sum of the per-(segment, part) squared errors / masked-node count.  One wave, strided partial sums
+    // and a fixed-order butterfly (a single thread walking 128 dependent loads made block 0 the kernel's critical path)
     float s = 0.f;
-    for (int k = 0; k < num_loss; ++k) s += loss_part[k];
-    loss[0] = s / loss_part[num_loss];
+    for (int k = threadIdx.x; k < num_loss; k += 64) s += loss_part[k];
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+    if (threadIdx.x == 0) loss[0] = s / loss_part[num_loss];
   }
   __syncthreads();
   const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;

@@ -300,8 +300,8 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
                                                    float grad_scale) {
   __shared__ float s_step_size, s_bc2_sqrt;
   if (threadIdx.x == 0) {
-    const double t = (double)(step_counter[0] + 1ULL);
-    const double bc1 = 1.0 - pow(b1, t), bc2 = 1.0 - pow(b2, t);
+    const unsigned long long t = step_counter[0] + 1ULL;
+    const double bc1 = 1.0 - gatres_powi(b1, t), bc2 = 1.0 - gatres_powi(b2, t);
     s_step_size = (float)(lr / bc1);
     s_bc2_sqrt = (float)sqrt(bc2);
   }
