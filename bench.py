@@ -312,7 +312,8 @@ def main():
     ei = G.wdn_synth.collate_edge_index(topo, args.nodes, args.batch_size).to(device)
     trainer = G.GATResTrainer(model, ei, N, nodes_per_graph=[args.nodes] * args.batch_size, seed=1000 + rank,
                               use_graph=not args.no_graph, fused=not args.per_op,
-                              force_collective_path=args.force_collective_path)
+                              force_collective_path=args.force_collective_path,
+                              targets_are_inputs=True)        # synthetic snapshots: y is x before masking
     if args.drop_in:
         return drop_in_loop(args, G, model, topo, device, nb, nc)
     nbatches = 8

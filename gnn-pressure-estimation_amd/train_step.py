@@ -45,7 +45,7 @@ class GATResTrainer:
                  nodes_per_graph: Optional[Sequence[int]] = None, lr: float = 5e-4, weight_decay: float = 6e-6,
                  betas=(0.9, 0.999), eps: float = 1e-8, mask_rate: float = 0.95, seed: int = 0,
                  process_group=None, use_graph: bool = True, fused: bool = True,
-                 force_collective_path: bool = False):
+                 force_collective_path: bool = False, targets_are_inputs: bool = False):
         self.lib = _native.load()
         self.model = model
         params = model.flat_parameters
@@ -64,7 +64,10 @@ class GATResTrainer:
         self.exp_avg_sq = torch.zeros(self.P, **f32)
         self.step_counter = torch.zeros(2, dtype=torch.int64, device=dev)
         self.x = torch.zeros(N, **f32)
-        self.y = torch.zeros(N, **f32)
+        # targets_are_inputs: the reference's snapshots have data.y == data.x until the loop masks x (train.py:162-166),
+        # and the masking happens inside the kernels here (x itself is never overwritten): one buffer serves both
+        self.targets_are_inputs = bool(targets_are_inputs)
+        self.y = self.x if self.targets_are_inputs else torch.zeros(N, **f32)
         self.mask = torch.zeros(N, dtype=torch.uint8, device=dev)
         self.out = torch.zeros(N, **f32)
         self.g_out = torch.zeros(N, **f32)
@@ -155,7 +158,8 @@ class GATResTrainer:
     def load_batch(self, x: torch.Tensor, y: torch.Tensor, mask: Optional[torch.Tensor] = None) -> None:
         """Stage a batch into the static buffers (async copies on the current stream)."""
         self.x.copy_(x.reshape(-1), non_blocking=True)
-        self.y.copy_(y.reshape(-1), non_blocking=True)
+        if not self.targets_are_inputs:
+            self.y.copy_(y.reshape(-1), non_blocking=True)
         if mask is not None:
             self.mask.copy_(mask.reshape(-1).to(torch.uint8), non_blocking=True)
 

@@ -335,6 +335,26 @@ def test_fused_adam_matches_torch_adam(pkg, oracle):
         assert float(d.max()) <= (it + 1) * 5e-4 * 1.01 and float((d > 1e-6).double().mean()) < 0.01, (it, float(d.max()))
 
 
+def test_targets_are_inputs_alias(pkg, oracle):
+    """targets_are_inputs=True lets x and y share one device buffer (the kernels never overwrite x: the masking is
+    applied on the fly): same loss and gradients as with separate buffers, for both kernel paths."""
+    nb, nc, bs = 2, 32, 2
+    ei = pkg.wdn_synth.collate_edge_index(pkg.wdn_synth.make_wdn_topology(), 388, bs).cuda()
+    y = pkg.wdn_synth.collate_snapshots(pkg.wdn_synth.make_snapshots(2, 388, seed=8), range(bs)).cuda()
+    mask = torch.from_numpy(pkg.wdn_synth.generate_batch_mask([388] * bs, 0.95, np.random.RandomState(6))).cuda()
+    for fused in (True, False):
+        res = []
+        for alias in (False, True):
+            model, _ = build(pkg, oracle, nb, nc, seed=13, fused=fused)
+            tr = pkg.GATResTrainer(model, ei, 388 * bs, nodes_per_graph=[388] * bs, use_graph=False, fused=fused,
+                                   targets_are_inputs=alias)
+            tr.step(y, y, mask)
+            tr.step(y, y, mask)
+            res.append((tr.loss.clone(), tr.grads.clone(), tr.x.clone()))
+        assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+        assert torch.equal(res[1][2], y.reshape(-1))  # x is still the unmasked batch
+
+
 def test_edge_cases_and_determinism(pkg, oracle):
     model, p = build(pkg, oracle, 2, 8, seed=9)
     n = 30
