@@ -14,6 +14,8 @@
 // fed from per-lane contiguous float4 loads (the k order inside the MFMA chain is permuted, which a sum allows).
 // One wave = 16 nodes x all M outputs: N = 12.4k nodes gives 776 waves, enough to cover the 1024 SIMDs' worth
 // of a launch-bound problem better than 32-row tiles would.
+#include <cstdlib>
+
 #include "gatres_common.h"
 
 namespace {
@@ -137,6 +139,108 @@ __global__ __launch_bounds__(256) void proj_kernel(const float* __restrict__ X, 
 }
 
 // ------------------------------------------------------------------------------------------------------
+// The same projection for wide models on large graphs (nc >= 64, tens of thousands of rows): persistent workgroups,
+// one per CU, that stage W (+ the attention vectors) in LDS ONCE and then walk their share of 16-row tiles.  proj_kernel
+// re-reads the whole of W from L1/L2 for every tile (128 KB per 16 rows at nc = 128: five times the activation
+// traffic) and ran at a quarter of the fp32 matrix rate; here W fragments come from LDS, every wave has a SIMD to
+// itself (four waves, up to 512 VGPRs), and the MFMAs of one k step are issued across all output tiles before the next
+// k step so consecutive instructions are independent.  Lane map and k order per output are those of proj_kernel:
+// bit-identical results.
+// ------------------------------------------------------------------------------------------------------
+template <int K, int M, int H, int EPI>
+__global__ __launch_bounds__(256) void proj_lds_kernel(const float* __restrict__ X, const float* __restrict__ Wm,
+                                                       float* __restrict__ OUT, int N,
+                                                       const float* __restrict__ att_src,
+                                                       const float* __restrict__ att_dst, float* __restrict__ a_src,
+                                                       float* __restrict__ a_dst, const float* __restrict__ resid,
+                                                       const float* __restrict__ relu_ref, int rows_per_wg) {
+  constexpr int KQ = K / 4, NT = M / 16, SC = 4, KP = K + 4;        // K, M multiples of 16 here
+  __shared__ __attribute__((aligned(16))) float wl[M * KP + 2 * M];
+  for (int idx = threadIdx.x; idx < M * (K / 4); idx += 256) {
+    const int m = idx / (K / 4), k4 = (idx % (K / 4)) * 4;
+    st4(wl + m * KP + k4, ld4(Wm + (size_t)m * K + k4));
+  }
+  if constexpr (EPI == EPI_ATT) {
+    for (int idx = threadIdx.x; idx < 2 * (M / 4); idx += 256) {
+      const int which = idx / (M / 4), c4 = (idx % (M / 4)) * 4;
+      st4(wl + M * KP + which * M + c4, ld4((which ? att_dst : att_src) + c4));
+    }
+  }
+  __syncthreads();
+  const float* attS = wl + M * KP;
+  const float* attD = attS + M;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int i = lane & 15, q = lane >> 4;
+  const int r0 = blockIdx.x * rows_per_wg, r1 = min(N, r0 + rows_per_wg);
+  for (int n0 = r0 + wave * 16; n0 < r1; n0 += 64) {
+    const int n = n0 + i;
+    const bool nok = n < r1;
+    const int nl = nok ? n : r1 - 1;
+    float xf[KQ];
+    load_frag<KQ>(X + (size_t)nl * K + q * KQ, xf);
+    f32x4 acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < KQ; s += SC) {
+      float wf[NT][SC];
+#pragma unroll
+      for (int t = 0; t < NT; ++t) load_frag<SC>(wl + (t * 16 + i) * KP + q * KQ + s, wf[t]);
+#pragma unroll
+      for (int u = 0; u < SC; ++u)
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+          acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[t][u], xf[s + u], acc[t], 0, 0, 0);
+    }
+    if constexpr (EPI == EPI_ATT) {
+      constexpr int C = M / H;
+      float ps[H], pd[H];
+#pragma unroll
+      for (int hh = 0; hh < H; ++hh) { ps[hh] = 0.f; pd[hh] = 0.f; }
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        const int mb = t * 16 + q * 4;
+        const float4 as = ld4(attS + mb), ad = ld4(attD + mb);
+        const float ds = fmaf(acc[t][3], as.w, fmaf(acc[t][2], as.z, fmaf(acc[t][1], as.y, acc[t][0] * as.x)));
+        const float dd = fmaf(acc[t][3], ad.w, fmaf(acc[t][2], ad.z, fmaf(acc[t][1], ad.y, acc[t][0] * ad.x)));
+        const int hd = mb / C;
+#pragma unroll
+        for (int hh = 0; hh < H; ++hh)
+          if (hh == hd) { ps[hh] += ds; pd[hh] += dd; }
+      }
+#pragma unroll
+      for (int hh = 0; hh < H; ++hh) {
+        ps[hh] += __shfl_xor(ps[hh], 16); ps[hh] += __shfl_xor(ps[hh], 32);
+        pd[hh] += __shfl_xor(pd[hh], 16); pd[hh] += __shfl_xor(pd[hh], 32);
+      }
+      if (q == 0 && nok) {
+#pragma unroll
+        for (int hh = 0; hh < H; ++hh) { a_src[n * H + hh] = ps[hh]; a_dst[n * H + hh] = pd[hh]; }
+      }
+    }
+    if (nok) {
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        const int mb = t * 16 + q * 4;
+        float4 o = make_float4(acc[t][0], acc[t][1], acc[t][2], acc[t][3]);
+        if constexpr (EPI == EPI_RESID_MASK) {
+          if (resid) {
+            const float4 r = ld4(resid + (size_t)n * M + mb);
+            o.x = o.x + r.x; o.y = o.y + r.y; o.z = o.z + r.z; o.w = o.w + r.w;
+          }
+          if (relu_ref) {
+            const float4 r = ld4(relu_ref + (size_t)n * M + mb);
+            o.x = r.x > 0.f ? o.x : 0.f; o.y = r.y > 0.f ? o.y : 0.f;
+            o.z = r.z > 0.f ? o.z : 0.f; o.w = r.w > 0.f ? o.w : 0.f;
+          }
+        }
+        st4(OUT + (size_t)n * M + mb, o);
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------
 // dW partials.  One wave = one (slab, output block) pair; a slab is a contiguous range of nodes.  Per MFMA
 // step the four lane groups q supply four consecutive nodes; lane i of a group loads VC consecutive features
 // of G (A operand, rows c) and VK consecutive features of X (B operand, cols k), which are spread over VC*VK
@@ -210,6 +314,16 @@ template <int K, int M, int H, int EPI>
 int launch_proj(const float* X, const float* Wm, float* OUT, int N, const float* att_src, const float* att_dst,
                 float* a_src, float* a_dst, const float* resid, const float* relu_ref, hipStream_t st) {
   const int waves = (N + 15) / 16;
+  if constexpr (K % 16 == 0 && M % 16 == 0 && K * M >= 64 * 128 && (M * (K + 4) + 2 * M) * 4 <= 160 * 1024) {
+    if (N >= 16384 && !getenv("GATRES_NO_PROJ_LDS")) {        // W staging per workgroup must amortise over many tiles
+      const int grid = 256;                                   // one persistent workgroup per CU
+      int rows = (N + grid - 1) / grid;
+      rows = (rows + 63) & ~63;
+      hipLaunchKernelGGL((proj_lds_kernel<K, M, H, EPI>), dim3((N + rows - 1) / rows), dim3(256), 0, st, X, Wm, OUT, N,
+                         att_src, att_dst, a_src, a_dst, resid, relu_ref, rows);
+      return gatres_launch_status();
+    }
+  }
   hipLaunchKernelGGL((proj_kernel<K, M, H, EPI>), dim3((waves + 3) / 4), dim3(256), 0, st, X, Wm, OUT, N, att_src,
                      att_dst, a_src, a_dst, resid, relu_ref);
   return gatres_launch_status();

@@ -162,3 +162,26 @@ def test_masked_mse_and_adam_match_torch(ops):
         ops.adam_step(pd, (gr * (it + 1)).cuda(), m, v, step, 5e-4, 0.9, 0.999, 1e-8, 6e-6)
         assert relerr(pd, pt) < 1e-6
     assert int(step[0]) == 3 and int(step[1]) == 0
+
+
+@pytest.mark.parametrize("K,H,C", [(128, 2, 128), (256, 1, 128), (64, 2, 64), (128, 1, 64)])
+def test_wide_projection_on_many_rows_matches_the_tile_kernel(ops, K, H, C, monkeypatch):
+    """Wide models on tens of thousands of rows take the persistent LDS-staged projection kernel (k_proj.hip:
+    proj_lds_kernel); its outputs, attention logits and the dX epilogue must be BIT-identical to the tile-per-wave
+    kernel it replaces there, and agree with a float64 torch product."""
+    n, M = 20000 + 37, H * C
+    g = torch.Generator().manual_seed(K + M)
+    x = torch.randn(n, K, generator=g).cuda()
+    W = (torch.randn(M, K, generator=g) / K ** 0.5).cuda()
+    a_s, a_d = torch.randn(M, generator=g).cuda(), torch.randn(M, generator=g).cuda()
+    resid, ref = torch.randn(n, M, generator=g).cuda(), torch.randn(n, M, generator=g).cuda()
+    h1, s1, d1 = ops.proj_attn_fwd(x, W, a_s, a_d, H)
+    o1 = ops.proj_bwd_dx(x, W, resid, ref)
+    monkeypatch.setenv("GATRES_NO_PROJ_LDS", "1")
+    h0, s0, d0 = ops.proj_attn_fwd(x, W, a_s, a_d, H)
+    o0 = ops.proj_bwd_dx(x, W, resid, ref)
+    assert torch.equal(h1, h0) and torch.equal(s1, s0) and torch.equal(d1, d0) and torch.equal(o1, o0)
+    h64 = (x.double() @ W.double().t())
+    assert float((h1.double() - h64).abs().max() / h64.abs().max()) < 1e-6
+    s64 = (h64.view(n, H, C) * a_s.double().view(1, H, C)).sum(-1)
+    assert float((s1.double() - s64).abs().max() / s64.abs().max()) < 1e-5
