@@ -2421,6 +2421,10 @@ static int launch_fused(const FusedArgs& a, const gatres_graph_t* g, hipStream_t
 extern "C" int gatres_fused_supported(const gatres_model_t* m, const gatres_graph_t* g) {
   if (!m || !g || g->num_segments <= 0 || !g->seg_ptr) return 0;
   if (!(m->nc >= 4 && m->nc <= 128 && gatres_is_pow2(m->nc))) return 0;
+  // Wide models (gatres_large, nc = 128): the per-snapshot tables do not fit the LDS, the per-snapshot kernel would
+  // run without them at 256 / 512 threads, and the per-op kernels (LDS-staged persistent projections, 256 slabs) are
+  // then 1.6-1.8x faster on C-Town batches of 32 .. 128 snapshots.  GATRES_FUSED_WIDE=1 keeps the fused path for them.
+  if (m->nc > 32 && !getenv("GATRES_FUSED_WIDE")) return 0;
   if (g->max_segment_nodes > 4096) return 0;      // beyond this a snapshot should be spread over many CUs
   return nocache_fits(m->nc, threads_for(m->nc), g->max_segment_nodes, g->max_segment_edges_gat, g->max_segment_edges_mean)
              ? 1 : 0;
