@@ -172,12 +172,13 @@ __global__ __launch_bounds__(256) void proj_lds_kernel(const float* __restrict__
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int i = lane & 15, q = lane >> 4;
   const int r0 = blockIdx.x * rows_per_wg, r1 = min(N, r0 + rows_per_wg);
+  float xf[KQ], xn[KQ];
+  if (r0 + wave * 16 < r1) load_frag<KQ>(X + (size_t)min(r0 + wave * 16 + i, r1 - 1) * K + q * KQ, xf);
   for (int n0 = r0 + wave * 16; n0 < r1; n0 += 64) {
     const int n = n0 + i;
     const bool nok = n < r1;
-    const int nl = nok ? n : r1 - 1;
-    float xf[KQ];
-    load_frag<KQ>(X + (size_t)nl * K + q * KQ, xf);
+    // the next tile's x fragment is in flight while this tile's 8 * NT * ... MFMAs run
+    if (n0 + 64 < r1) load_frag<KQ>(X + (size_t)min(n + 64, r1 - 1) * K + q * KQ, xn);
     f32x4 acc[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -237,6 +238,8 @@ __global__ __launch_bounds__(256) void proj_lds_kernel(const float* __restrict__
         st4(OUT + (size_t)n * M + mb, o);
       }
     }
+#pragma unroll
+    for (int k = 0; k < KQ; ++k) xf[k] = xn[k];
   }
 }
 
