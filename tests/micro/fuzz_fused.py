@@ -1,0 +1,79 @@
+"""Diagnostic fuzzer (not collected by pytest): random batches of random graphs -- directed / undirected edges, degrees
+beyond the slot paths' 6, isolated nodes, self loops, ragged sizes, local and shuffled node orders -- through the fused
+kernels (whichever of window / whole-segment / split the plan selects) against the per-op kernels.
+    python tests/micro/fuzz_fused.py [cases] [seed]         (GATRES_FUSED_SPLIT etc. apply)"""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import numpy as np
+import torch
+import gnn_pressure_estimation_amd as G
+
+cases = int(sys.argv[1]) if len(sys.argv) > 1 else 30
+rng = np.random.RandomState(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+
+
+def random_graph(n):
+    kind = rng.randint(4)
+    if kind == 0:                                   # WDN-like, local order
+        return G.wdn_synth.make_wdn_topology(n, n - 1 + rng.randint(0, max(1, n // 8)), seed=int(rng.randint(1 << 30)))
+    src, dst = [], []
+    for v in range(1, n):                           # random tree with a locality window, then extra edges
+        u = rng.randint(max(0, v - rng.randint(1, 40)), v)
+        src += [u, v]; dst += [v, u]
+    extra = rng.randint(0, n)
+    for _ in range(extra):
+        u, v = rng.randint(n), rng.randint(n)
+        if kind == 1 and u != v:                    # undirected extras (degrees may exceed 6)
+            src += [u, v]; dst += [v, u]
+        elif kind == 2:                             # directed extras, self loops allowed
+            src.append(u); dst.append(v)
+        elif kind == 3 and u != v:                  # hub: many edges into node 0's neighbourhood
+            w = rng.randint(min(n, 5))
+            src += [u, w]; dst += [w, u]
+    ei = torch.tensor([src, dst], dtype=torch.int64)
+    if rng.rand() < 0.3:                            # shuffled node ids
+        perm = torch.from_numpy(rng.permutation(n))
+        ei = perm[ei]
+    return ei[:, torch.argsort(ei[0], stable=True)]
+
+
+def relerr(a, b):
+    return float((a.double() - b.double()).abs().max() / max(float(b.double().abs().max()), 1e-30))
+
+
+bad = 0
+for case in range(cases):
+    nb, nc = int(rng.choice([1, 2, 3])), int(rng.choice([8, 16, 32, 32, 32]))
+    sizes = [int(rng.choice([17, 33, 60, 120, 200, 388, 388, 450])) for _ in range(rng.randint(1, 9))]
+    tops = [random_graph(n) for n in sizes]
+    offs = np.cumsum([0] + sizes)
+    ei = torch.cat([t + int(o) for t, o in zip(tops, offs[:-1])], dim=1)
+    N = int(offs[-1])
+    torch.manual_seed(case)
+    mf = G.GATResMeanConv(num_blocks=nb, nc=nc, fused=True).cuda()
+    mp = G.GATResMeanConv(num_blocks=nb, nc=nc, fused=False).cuda()
+    with torch.no_grad():
+        mp.flat_parameters.copy_(mf.flat_parameters)
+    x = torch.randn(N, 1).cuda()
+    dei = ei.cuda()
+    ok = True
+    for rep in range(2):
+        of, op = mf(x, dei), mp(x, dei)
+        if not torch.equal(of, op):
+            ok = False; print("case", case, "rep", rep, "FORWARD differs", relerr(of, op))
+        g = torch.randn_like(of)
+        mf.zero_grad(); mp.zero_grad()
+        of.backward(g); op.backward(g)
+        gf = torch.cat([q.grad.reshape(-1) for q in mf.parameters()])
+        gp = torch.cat([q.grad.reshape(-1) for q in mp.parameters()])
+        e = relerr(gf, gp)
+        if not (e < 5e-5) or not torch.isfinite(gf).all():
+            ok = False; print("case", case, "rep", rep, "GRADS differ", e)
+    plan = mf._plans.get(dei, N)
+    lib = G._native.load()
+    cus = lib.gatres_fused_cus_per_segment(mf._cmodel_ref(), plan.ref())
+    print(f"case {case:3d} nb {nb} nc {nc:2d} sizes {sizes} segments {plan.num_segments} CUs/segment {cus} windows {plan.windows[3:6]}"
+          f" -> {'ok' if ok else 'FAIL'}")
+    bad += 0 if ok else 1
+print("failures:", bad, "of", cases)
+sys.exit(1 if bad else 0)
