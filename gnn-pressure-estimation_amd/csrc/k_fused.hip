@@ -2384,15 +2384,18 @@ static int fused_consumers(const Layout& L, const gatres_graph_t* g, int M) {
 }
 
 // The window kernel applies when the plan knows the parts' row windows and both LDS layouts fit with them.
-static bool use_window_kernel(const FusedArgs& a, const gatres_graph_t* g) {
-  if (getenv("GATRES_FUSED_NO_WINDOW") || !a.saved || a.M < 2 || a.L.nc > 32 || threads_for(a.L.nc) != 1024) return false;
-  const int k = a.M == 2 ? 0 : (a.M == 4 ? 1 : 2);
+static bool window_kernel_fits(const Layout& L, const gatres_graph_t* g, int M) {
+  if (getenv("GATRES_FUSED_NO_WINDOW") || M < 2 || L.nc > 32 || threads_for(L.nc) != 1024) return false;
+  const int k = M == 2 ? 0 : (M == 4 ? 1 : 2);
   const int wr = g->window[k][0], ge = g->window[k][1], gm = g->window[k][2];
   if (wr <= 0) return false;
   const int tiles = (g->max_segment_nodes + 15) / 16;
-  const int ow = 16 * ((tiles + a.M - 1) / a.M);
-  return win_fwd_bytes(a.L.nc, wr, ow, ge, gm) <= LDS_BYTES && win_bwd_bytes(a.L.nc, 1024, wr, ow, ge, gm) <= LDS_BYTES &&
+  const int ow = 16 * ((tiles + M - 1) / M);
+  return win_fwd_bytes(L.nc, wr, ow, ge, gm) <= LDS_BYTES && win_bwd_bytes(L.nc, 1024, wr, ow, ge, gm) <= LDS_BYTES &&
          wr <= 65535 && ge <= 65535 && gm <= 65535;
+}
+static bool use_window_kernel(const FusedArgs& a, const gatres_graph_t* g) {
+  return a.saved && window_kernel_fits(a.L, g, a.M);        // (it writes the saved tables: training launches only)
 }
 
 template <int NC, int THREADS>
@@ -2434,6 +2437,12 @@ extern "C" int gatres_fused_cus_per_segment(const gatres_model_t* m, const gatre
   Layout L;
   if (!gatres_fused_supported(m, g) || !make_layout_g(m, g, &L)) return 0;
   return fused_split(L, g);
+}
+
+extern "C" int gatres_fused_window_kernel(const gatres_model_t* m, const gatres_graph_t* g) {
+  Layout L;
+  if (!gatres_fused_supported(m, g) || !make_layout_g(m, g, &L)) return 0;
+  return window_kernel_fits(L, g, fused_split(L, g)) ? 1 : 0;
 }
 
 // Diagnostic: segment 0 of the next fused launches writes a 100 MHz wall-clock stamp at every stage boundary into

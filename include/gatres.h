@@ -260,6 +260,10 @@ int gatres_model_backward_per_op(const gatres_model_t* m, const gatres_graph_t* 
 int gatres_fused_supported(const gatres_model_t* m, const gatres_graph_t* g);
 /* Workgroups (CUs) that carry one segment in the fused launches (1, 2, 4 or 8); 0 if the fused path is unavailable. */
 int gatres_fused_cus_per_segment(const gatres_model_t* m, const gatres_graph_t* g);
+/* 1 if launches that are given a `saved` buffer take the window kernel (LDS tables sized by the parts' row windows,
+ * gatres_graph_t.window).  It is faster than the whole-segment-table kernel even for inference, so a caller that only
+ * wants predictions may pass a throw-away `saved` buffer of gatres_saved_floats() to gatres_model_forward. */
+int gatres_fused_window_kernel(const gatres_model_t* m, const gatres_graph_t* g);
 /* Diagnostic only: per-stage wall-clock stamps (100 MHz) of segment 0 for the following fused launches. */
 int gatres_fused_set_stamps(uint64_t* stamps, int32_t capacity);
 int gatres_fused_prepare_backward(const gatres_model_t* m, const gatres_graph_t* g, const float* params,
