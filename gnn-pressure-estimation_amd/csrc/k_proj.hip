@@ -286,17 +286,23 @@ __global__ __launch_bounds__(256) void dw_kernel(const float* __restrict__ G, co
   const int nbeg = s * nodes_per_slab;
   const int nend = min(N, nbeg + nodes_per_slab);
 
-  for (int nb = nbeg; nb < nend; nb += 4) {
-    const int n = nb + q;
-    const bool nok = n < nend;
-    float a[VC], b[VK];
-    load_vec<VC>(G + (size_t)(nok ? n : 0) * HC + cl, nok && cok, a);
-    load_vec<VK>(X + (size_t)(nok ? n : 0) * K + kl, nok && kok, b);
+  constexpr int STEPS = 4;               // 16 rows of operands in flight per wave (same accumulation order as one by one)
+  for (int nb = nbeg; nb < nend; nb += 4 * STEPS) {
+    float a[STEPS][VC], b[STEPS][VK];
 #pragma unroll
-    for (int tc = 0; tc < VC; ++tc)
+    for (int st = 0; st < STEPS; ++st) {
+      const int n = nb + 4 * st + q;
+      const bool nok = n < nend;
+      load_vec<VC>(G + (size_t)(nok ? n : 0) * HC + cl, nok && cok, a[st]);
+      load_vec<VK>(X + (size_t)(nok ? n : 0) * K + kl, nok && kok, b[st]);
+    }
 #pragma unroll
-      for (int tk = 0; tk < VK; ++tk)
-        acc[tc][tk] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[tc], b[tk], acc[tc][tk], 0, 0, 0);
+    for (int st = 0; st < STEPS; ++st)
+#pragma unroll
+      for (int tc = 0; tc < VC; ++tc)
+#pragma unroll
+        for (int tk = 0; tk < VK; ++tk)
+          acc[tc][tk] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[st][tc], b[st][tk], acc[tc][tk], 0, 0, 0);
   }
 
   float* out = slab + (size_t)s * slab_stride;
