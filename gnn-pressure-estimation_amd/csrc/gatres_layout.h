@@ -29,11 +29,11 @@ struct Layout {
 };
 
 // Node-range slabs of the per-op parameter-gradient kernels: one workgroup per slab, so their number is the
-// parallelism of those kernels.  Bounded by 4 GB of slab storage (gatres_large: 6.7 MB per slab -> 256 slabs; a 64-MB
+// parallelism of those kernels.  Bounded by 2 GB of slab storage and 1024 (gatres_large: 6.7 MB per slab -> 305 slabs; a 64-MB
 // bound left it 16 workgroups, and dW + the column sums took 77 % of a 50k-node step).
 static inline int num_slabs_for(int64_t P, int64_t N) {
-  int64_t cap = (4096LL << 20) / (4 * (P > 0 ? P : 1));
-  if (cap > 256) cap = 256;
+  int64_t cap = (2048LL << 20) / (4 * (P > 0 ? P : 1));
+  if (cap > 1024) cap = 1024;      // (256 left the dW / column-sum kernels of narrow models on 800k-row batches at a quarter of the chip)
   if (cap < 16) cap = 16;
   int64_t s = (N + 63) / 64;
   if (s > cap) s = cap;
