@@ -48,7 +48,43 @@ __global__ __launch_bounds__(256) void gat_aggregate_fwd_kernel(
   const int H = gm.H, HC = gm.HC;
   const int beg = rowptr[row], end = rowptr[row + 1];
   const float adst = a_dst[row * H + hd];
-
+  float4 acc = f4zero();
+  constexpr int MAXD = 6;                      // rows with <= 6 in-edges (every water-network row): slot path
+  if (__builtin_expect(end - beg <= MAXD, 1)) {
+    // every neighbour index, logit and feature row of this destination is requested at once: one dependent round
+    // trip (col -> {a_src, h}) instead of three passes of edge-at-a-time chains.  Statement for statement the
+    // arithmetic of the loop form below (and of the fused kernels' seg_softmax / seg_gather): bit-identical.
+    const int deg = end - beg;
+    int jj[MAXD];
+#pragma unroll
+    for (int k = 0; k < MAXD; ++k) jj[k] = col[beg + min(k, deg - 1)];
+    float so[MAXD];
+    float4 v[MAXD];
+    float m = -INFINITY;
+#pragma unroll
+    for (int k = 0; k < MAXD; ++k) {
+      v[k] = ld4(h + (size_t)jj[k] * HC + c0);
+      const float sv = gatres_leaky(a_src[jj[k] * H + hd] + adst);
+      so[k] = k < deg ? sv : -INFINITY;
+    }
+#pragma unroll
+    for (int k = 0; k < MAXD; ++k) m = fmaxf(m, so[k]);
+    float Z = 0.f;
+#pragma unroll
+    for (int k = 0; k < MAXD; ++k) {
+      so[k] = expf(so[k] - m);                 // exp(-inf) = 0 on padding slots
+      Z = Z + so[k];
+    }
+    Z = Z + GATRES_SOFTMAX_EPS;
+#pragma unroll
+    for (int k = 0; k < MAXD; ++k) {
+      const float al = so[k] / Z;
+      if (k < deg) {
+        if (leader) alpha[(size_t)(beg + k) * H + hd] = al;
+        gatres_axpy4(acc, al, v[k]);
+      }
+    }
+  } else {
   float m = -INFINITY;
   for (int e = beg; e < end; ++e) {
     const float s = gatres_leaky(a_src[col[e] * H + hd] + adst);
@@ -61,7 +97,6 @@ __global__ __launch_bounds__(256) void gat_aggregate_fwd_kernel(
   }
   Z = Z + GATRES_SOFTMAX_EPS;
 
-  float4 acc = f4zero();
   int e = beg;
   // two edges per trip so both neighbour rows are in flight together
   for (; e + 1 < end; e += 2) {
@@ -80,6 +115,7 @@ __global__ __launch_bounds__(256) void gat_aggregate_fwd_kernel(
     const float al0 = expf(gatres_leaky(a_src[j0 * H + hd] + adst) - m) / Z;
     if (leader) alpha[(size_t)e * H + hd] = al0;
     gatres_axpy4(acc, al0, v0);
+  }
   }
   const float4 b = ld4(bias + c0);
   acc.x = acc.x + b.x; acc.y = acc.y + b.y; acc.z = acc.z + b.z; acc.w = acc.w + b.w;
