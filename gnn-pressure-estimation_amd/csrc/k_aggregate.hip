@@ -162,25 +162,32 @@ __global__ __launch_bounds__(256) void gat_aggregate_bwd_dst_kernel(
   const float adst = a_dst[row * H + hd];
 
   float S = 0.f, gad = 0.f;
-  if (end - beg <= 8) {                 // the common case: cache the per-edge dots in registers
+  if (__builtin_expect(end - beg <= 8, 1)) {   // the common case: every load of the row issued together (slot path)
+    const int deg = end - beg;
+    int jj[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) jj[k] = col[beg + min(k, deg - 1)];
+    float4 hv[8];
+    float al[8], as[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      hv[k] = ld4(h + (size_t)jj[k] * HC + c0);
+      al[k] = alpha[(size_t)(beg + min(k, deg - 1)) * H + hd];
+      as[k] = a_src[jj[k] * H + hd];
+    }
     float ga[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
-      ga[k] = 0.f;
-      if (beg + k < end) {
-        const int j = col[beg + k];
-        ga[k] = head_dot(go, ld4(h + (size_t)j * HC + c0), LH);
-        S = fmaf(alpha[(size_t)(beg + k) * H + hd], ga[k], S);
-      }
+      ga[k] = head_dot(go, hv[k], LH);
+      if (k < deg) S = fmaf(al[k], ga[k], S);
     }
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
-      if (beg + k < end) {
-        const int e = beg + k;
-        const float gs = alpha[(size_t)e * H + hd] * (ga[k] - S);
-        const float raw = a_src[col[e] * H + hd] + adst;
+      if (k < deg) {
+        const float gs = al[k] * (ga[k] - S);
+        const float raw = as[k] + adst;
         const float ge = raw > 0.f ? gs : gs * GATRES_NEG_SLOPE;
-        if (leader) g_e[(size_t)e * H + hd] = ge;
+        if (leader) g_e[(size_t)(beg + k) * H + hd] = ge;
         gad = gad + ge;
       }
     }
