@@ -47,6 +47,9 @@ def parse():
     ap.add_argument("--per-op", action="store_true", help="one launch per stage instead of the fused per-snapshot kernel")
     ap.add_argument("--force-collective-path", action="store_true",
                     help="run the multi-GPU sequence (backward | RCCL all-reduce | Adam) even at world size 1")
+    ap.add_argument("--host-batches", action="store_true",
+                    help="batches start in pinned host memory: the timed step includes the H2D copy (PCIe-inclusive "
+                         "rate for DESIGN.md; never the headline value)")
     ap.add_argument("--fused-adam", action="store_true",
                     help="with --drop-in: FusedAdam (one native launch) instead of torch.optim.Adam")
     ap.add_argument("--drop-in", action="store_true",
@@ -319,6 +322,8 @@ def main():
     nbatches = 8
     snaps = G.wdn_synth.make_snapshots(nbatches * args.batch_size, args.nodes, seed=100 + rank).to(device)
     batches = [snaps[i * args.batch_size:(i + 1) * args.batch_size].reshape(-1).contiguous() for i in range(nbatches)]
+    if args.host_batches:
+        batches = [b.cpu().pin_memory() for b in batches]
 
     def one_step(i):
         b = batches[i % nbatches]
