@@ -325,9 +325,16 @@ def main():
     if args.host_batches:
         batches = [b.cpu().pin_memory() for b in batches]
 
+    if args.host_batches:
+        trainer.prefetch_batch(batches[0])
+
     def one_step(i):
-        b = batches[i % nbatches]
-        trainer.load_batch(b, b)
+        if args.host_batches:                       # batch i was prefetched during step i - 1; start fetching i + 1
+            trainer.commit_batch()
+            trainer.prefetch_batch(batches[(i + 1) % nbatches])
+        else:
+            b = batches[i % nbatches]
+            trainer.load_batch(b, b)
         trainer.run_step(device_mask=True)
 
     log(f"model/trainer ready on {device}; warm-up {args.warmup} steps")

@@ -163,6 +163,43 @@ class GATResTrainer:
         if mask is not None:
             self.mask.copy_(mask.reshape(-1).to(torch.uint8), non_blocking=True)
 
+    def prefetch_batch(self, x: torch.Tensor, y: Optional[torch.Tensor] = None) -> None:
+        """Start copying the NEXT batch (typically pinned host memory) into a staging buffer on a side stream, so the
+        PCIe transfer overlaps the step that is running; ``commit_batch()`` then moves it into place with a device copy.
+        Two staging slots: at most one prefetch may be outstanding per ``commit_batch()``."""
+        if not hasattr(self, "_stage"):
+            f32 = dict(dtype=torch.float32, device=self.device)
+            n = self.x.numel()
+            self._stage = [(torch.empty(n, **f32), None if self.targets_are_inputs else torch.empty(n, **f32))
+                           for _ in range(2)]
+            self._copy_stream = torch.cuda.Stream(device=self.device)
+            self._ready = [torch.cuda.Event() for _ in range(2)]
+            self._free = [torch.cuda.Event() for _ in range(2)]
+            for ev in self._free:
+                ev.record(torch.cuda.current_stream(self.device))
+            self._slot_in, self._slot_out = 0, 0
+        k = self._slot_in
+        sx, sy = self._stage[k]
+        with torch.cuda.stream(self._copy_stream):
+            self._copy_stream.wait_event(self._free[k])
+            sx.copy_(x.reshape(-1), non_blocking=True)
+            if sy is not None:
+                sy.copy_((x if y is None else y).reshape(-1), non_blocking=True)
+            self._ready[k].record(self._copy_stream)
+        self._slot_in = 1 - k
+
+    def commit_batch(self) -> None:
+        """Make the prefetched batch the current one (device-to-device copies on the compute stream)."""
+        k = self._slot_out
+        cur = torch.cuda.current_stream(self.device)
+        cur.wait_event(self._ready[k])
+        sx, sy = self._stage[k]
+        self.x.copy_(sx, non_blocking=True)
+        if sy is not None:
+            self.y.copy_(sy, non_blocking=True)
+        self._free[k].record(cur)
+        self._slot_out = 1 - k
+
     def run_step(self, device_mask: bool = True) -> None:
         """One optimisation step on the staged batch.  Nothing is synchronised; read ``self.loss`` afterwards."""
         if device_mask and self.node_ptr is None:

@@ -355,6 +355,34 @@ def test_targets_are_inputs_alias(pkg, oracle):
         assert torch.equal(res[1][2], y.reshape(-1))  # x is still the unmasked batch
 
 
+def test_prefetched_host_batches_match_direct_loading(pkg, oracle):
+    """prefetch_batch (side-stream H2D into a staging slot) + commit_batch give the same training trajectory as
+    load_batch, including the two-slot rotation."""
+    nb, nc, bs = 2, 32, 2
+    ei = pkg.wdn_synth.collate_edge_index(pkg.wdn_synth.make_wdn_topology(), 388, bs).cuda()
+    snaps = pkg.wdn_synth.make_snapshots(5 * bs, 388, seed=15)
+    host = [pkg.wdn_synth.collate_snapshots(snaps, range(i * bs, (i + 1) * bs)).reshape(-1).pin_memory() for i in range(5)]
+    losses = []
+    for mode in ("direct", "prefetch"):
+        model, _ = build(pkg, oracle, nb, nc, seed=19)
+        tr = pkg.GATResTrainer(model, ei, 388 * bs, nodes_per_graph=[388] * bs, use_graph=True, seed=3,
+                               targets_are_inputs=True)
+        out = []
+        if mode == "prefetch":
+            tr.prefetch_batch(host[0])
+        for i in range(5):
+            if mode == "prefetch":
+                tr.commit_batch()
+                if i + 1 < 5:
+                    tr.prefetch_batch(host[i + 1])
+            else:
+                tr.load_batch(host[i].cuda(), host[i].cuda())
+            tr.run_step(device_mask=True)
+            out.append(float(tr.loss.item()))
+        losses.append(out)
+    assert losses[0] == losses[1], losses
+
+
 def test_edge_cases_and_determinism(pkg, oracle):
     model, p = build(pkg, oracle, 2, 8, seed=9)
     n = 30
