@@ -76,6 +76,7 @@ SIGNATURES = {
     "gatres_fused_supported": (C.c_int, [_MP, _GP]),
     "gatres_fused_cus_per_segment": (C.c_int, [_MP, _GP]),
     "gatres_fused_window_kernel": (C.c_int, [_MP, _GP]),
+    "gatres_fused_reset_sync": (C.c_int, [_MP, _GP, _P, _P]),
     "gatres_fused_set_stamps": (C.c_int, [_P, _I32]),
     "gatres_fused_prepare_backward": (C.c_int, [_MP, _GP, _P, _P, _P]),
     "gatres_fused_run": (C.c_int, [_MP, _GP] + [_P] * 10 + [_I32, _P]),

@@ -2439,6 +2439,16 @@ extern "C" int gatres_fused_cus_per_segment(const gatres_model_t* m, const gatre
   return fused_split(L, g);
 }
 
+// Zero the split-segment barrier state (epochs, XCD words, consumer counters, error word) of a scratch buffer: what a
+// freshly zeroed buffer has.  Only needed after a launch was aborted or the buffer was handed over from elsewhere.
+extern "C" int gatres_fused_reset_sync(const gatres_model_t* m, const gatres_graph_t* g, float* scratch, void* stream) {
+  if (!m || !g || !scratch) return GATRES_E_BADARG;
+  Layout L;
+  if (!make_layout_g(m, g, &L)) return GATRES_E_UNSUPPORTED;
+  if (fused_nodes_of(g) == 0) return 0;
+  return (int)hipMemsetAsync(scratch + L.sc_flags, 0, (size_t)(L.flag_words + L.ready_words) * 4, gatres_stream(stream));
+}
+
 extern "C" int gatres_fused_window_kernel(const gatres_model_t* m, const gatres_graph_t* g) {
   Layout L;
   if (!gatres_fused_supported(m, g) || !make_layout_g(m, g, &L)) return 0;

@@ -264,6 +264,9 @@ int gatres_fused_cus_per_segment(const gatres_model_t* m, const gatres_graph_t* 
  * gatres_graph_t.window).  It is faster than the whole-segment-table kernel even for inference, so a caller that only
  * wants predictions may pass a throw-away `saved` buffer of gatres_saved_floats() to gatres_model_forward. */
 int gatres_fused_window_kernel(const gatres_model_t* m, const gatres_graph_t* g);
+/* Zero the split-segment barrier state inside `scratch` (as in a freshly zeroed buffer).  Only needed after an aborted
+ * launch or when the buffer comes from elsewhere; not inside a captured graph that also holds fused launches. */
+int gatres_fused_reset_sync(const gatres_model_t* m, const gatres_graph_t* g, float* scratch, void* stream);
 /* Diagnostic only: per-stage wall-clock stamps (100 MHz) of segment 0 for the following fused launches. */
 int gatres_fused_set_stamps(uint64_t* stamps, int32_t capacity);
 int gatres_fused_prepare_backward(const gatres_model_t* m, const gatres_graph_t* g, const float* params,

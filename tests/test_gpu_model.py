@@ -383,6 +383,30 @@ def test_prefetched_host_batches_match_direct_loading(pkg, oracle):
     assert losses[0] == losses[1], losses
 
 
+def test_reset_sync_recovers_a_corrupted_barrier_state(pkg, oracle):
+    """Scribbling over the barrier epochs in scratch makes the parts of a split snapshot miss each other (bounded
+    spins -> NaN, no hang); gatres_fused_reset_sync puts the state back and the next step is correct again."""
+    nb, nc, bs = 2, 32, 2
+    ei = pkg.wdn_synth.collate_edge_index(pkg.wdn_synth.make_wdn_topology(), 388, bs).cuda()
+    y = pkg.wdn_synth.collate_snapshots(pkg.wdn_synth.make_snapshots(2, 388, seed=8), range(bs)).cuda()
+    mask = torch.from_numpy(pkg.wdn_synth.generate_batch_mask([388] * bs, 0.95, np.random.RandomState(6))).cuda()
+    model, _ = build(pkg, oracle, nb, nc, seed=23)
+    tr = pkg.GATResTrainer(model, ei, 388 * bs, nodes_per_graph=[388] * bs, use_graph=False)
+    lib = pkg._native.load()
+    if lib.gatres_fused_cus_per_segment(model._cmodel_ref(), tr.plan.ref()) < 2:
+        pytest.skip("snapshots are not split on this device")
+    tr.forward_backward(y, y, mask)
+    good = tr.grads.clone()
+    assert torch.isfinite(good).all()
+    tr.scratch.view(torch.int32)[-(1 << 22):].random_(1, 1000)            # the barrier state sits near the end of scratch
+    tr.forward_backward(y, y, mask)
+    torch.cuda.synchronize()
+    pkg._native.check(lib.gatres_fused_reset_sync(model._cmodel_ref(), tr.plan.ref(), tr.scratch.data_ptr(),
+                                                 pkg._native.current_stream(tr.device)), "reset")
+    tr.forward_backward(y, y, mask)
+    assert torch.equal(tr.grads, good)
+
+
 def test_edge_cases_and_determinism(pkg, oracle):
     model, p = build(pkg, oracle, 2, 8, seed=9)
     n = 30
