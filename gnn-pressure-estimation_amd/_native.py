@@ -28,7 +28,7 @@ class GatresGraph(C.Structure):
                 ("t_dst", C.c_void_p), ("m_rowptr", C.c_void_p), ("m_col", C.c_void_p), ("mt_rowptr", C.c_void_p),
                 ("mt_dst", C.c_void_p), ("seg_ptr", C.c_void_p), ("max_segment_nodes", C.c_int32),
                 ("max_segment_edges_gat", C.c_int32), ("max_segment_edges_mean", C.c_int32), ("reserved", C.c_int32),
-                ("window", C.c_int32 * 9), ("reserved2", C.c_int32)]
+                ("window", C.c_int32 * 9), ("reserved2", C.c_int32), ("perm", C.c_void_p)]
 
 
 class GatresModel(C.Structure):
@@ -46,7 +46,12 @@ SIGNATURES = {
     "gatres_graph_build_host": (C.c_int, [_P, _I64, _I64] + [_P] * 9),
     "gatres_graph_segments_host": (C.c_int, [_P, _I64, _I64, _I32, _P] + [C.POINTER(_I32)] * 4),
     "gatres_graph_windows_host": (C.c_int, [_P, _I64, _I64, _P, _I32, _P]),
+    "gatres_graph_reorder_host": (C.c_int, [_P, _I64, _I64, _P, _I32, _P]),
     "gatres_edge_index_hash": (C.c_int, [_P, _I64, _P, _P]),
+    "gatres_permute_f32": (C.c_int, [_P, _P, _P, _I32, _I32, _P]),
+    "gatres_gather_u8": (C.c_int, [_P, _P, _P, _I32, _P]),
+    "gatres_fused_serialize": (C.c_int, [_P]),
+    "gatres_fused_status_offset": (_I64, [_MP, _GP]),
     "gatres_lin0_fwd": (C.c_int, [_P, _P, _P, _P, _P, _I32, _I32, _P]),
     "gatres_proj_attn_fwd": (C.c_int, [_P] * 7 + [_I32] * 4 + [_P]),
     "gatres_gat_aggregate_fwd": (C.c_int, [_GP] + [_P] * 6 + [_I32] * 3 + [_P]),
@@ -73,6 +78,7 @@ SIGNATURES = {
     "gatres_model_backward": (C.c_int, [_MP, _GP] + [_P] * 8 + [_P]),
     "gatres_model_forward_per_op": (C.c_int, [_MP, _GP] + [_P] * 6 + [_P]),
     "gatres_model_backward_per_op": (C.c_int, [_MP, _GP] + [_P] * 8 + [_P]),
+    "gatres_model_backward_per_op_part": (C.c_int, [_MP, _GP] + [_P] * 8 + [_I32, _I32, _I32, _P]),
     "gatres_fused_supported": (C.c_int, [_MP, _GP]),
     "gatres_fused_cus_per_segment": (C.c_int, [_MP, _GP]),
     "gatres_fused_window_kernel": (C.c_int, [_MP, _GP]),

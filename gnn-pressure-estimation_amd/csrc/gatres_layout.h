@@ -16,6 +16,8 @@ struct Layout {
   // stages at the same time, so conv1 ([row*2], [row*2nc]) and conv2 ([row], [row*nc]) must not share an array.
   int64_t sc_y2, sc_ev, sc_xa, sc_xb, sc_gpa, sc_gpb, sc_gy2, sc_ge, sc_gad, sc_gas, sc_gh, sc_go1, sc_wt,
       sc_ge2, sc_gad2, sc_gas2, sc_gh2, sc_slabs, sc_loss_part, scratch_total;
+  // per-op path of a relabelled plan: plan-order copies of x, mask (bytes), out, g_out, g_x
+  int64_t sc_px, sc_pmask, sc_pout, sc_pgout, sc_pgx;
   // fused path only: every block keeps its g_h / g_alpha tables until the deferred parameter-gradient launch
   // (k_fused.hip: param_grads_kernel) has consumed them.  Block-major, global node index.
   int64_t sc_keep, keep_stride, k_gh1, k_gh2, k_gas1, k_gad1, k_gas2, k_gad2;
@@ -124,6 +126,11 @@ static inline bool make_layout(const gatres_model_t* m, int64_t N, int64_t Eg, i
   L->sc_part_slabs = o + L->flag_words + L->ready_words;
   if (fused_nodes > 0) o += L->flag_words + L->ready_words;
   if (L->split_max > 1) o += (int64_t)num_segments * L->split_max * L->slab_stride;
+  L->sc_px = o;    o += r4(N);
+  L->sc_pmask = o; o += r4((N + 3) / 4);
+  L->sc_pout = o;  o += r4(N);
+  L->sc_pgout = o; o += r4(N);
+  L->sc_pgx = o;   o += r4(N);
   L->scratch_total = o;
   return true;
 }

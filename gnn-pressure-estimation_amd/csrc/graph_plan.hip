@@ -5,6 +5,7 @@
 //
 // Edge order matters for fp32 reproducibility: inside a destination row the edges keep PyG's order (original
 // edges in edge_index order, the appended self loop last), which is the order index_add_/scatter visits them.
+#include <algorithm>
 #include <vector>
 
 #include "gatres_common.h"
@@ -186,6 +187,95 @@ extern "C" int gatres_graph_windows_host(const int64_t* ei, int64_t E, int64_t N
     out9[3 * k + 0] = (int32_t)mr;
     out9[3 * k + 1] = (int32_t)(mg > INT32_MAX ? INT32_MAX : mg);
     out9[3 * k + 2] = (int32_t)(mm > INT32_MAX ? INT32_MAX : mm);
+  }
+  return 0;
+}
+
+// Reverse Cuthill-McKee inside every segment.  The fused kernels give part p of a split segment a contiguous row range
+// and size its LDS tables by the range of rows those rows are adjacent to (gatres_graph_windows_host); that range is
+// part + 2 x bandwidth, so a bandwidth-reducing order is what keeps the window a fraction of the segment.  EPANET files
+// list junctions in drawing order, not in a locality-preserving one (utils/DataLoader.py:28-37 keeps the file order).
+// Deterministic: ties broken by the caller's node id.
+extern "C" int gatres_graph_reorder_host(const int64_t* ei, int64_t E, int64_t N, const int32_t* seg_ptr,
+                                         int32_t num_segments, int32_t* perm) {
+  if ((!ei && E > 0) || !seg_ptr || !perm || num_segments <= 0 || N <= 0 || E < 0) return GATRES_E_BADARG;
+  if (N > INT32_MAX || 2 * E > INT32_MAX) return GATRES_E_UNSUPPORTED;
+  // undirected adjacency (self loops dropped; duplicates are harmless)
+  std::vector<int32_t> key(2 * E), val(2 * E);
+  int64_t k = 0;
+  for (int64_t e = 0; e < E; ++e) {
+    const int64_t s = ei[e], d = ei[E + e];
+    if (s < 0 || s >= N || d < 0 || d >= N) return GATRES_E_GRAPH;
+    if (s == d) continue;
+    key[k] = (int32_t)s; val[k] = (int32_t)d; ++k;
+    key[k] = (int32_t)d; val[k] = (int32_t)s; ++k;
+  }
+  key.resize(k); val.resize(k);
+  std::vector<int32_t> ptr(N + 1), order;
+  counting_sort(key, N, ptr.data(), order);
+  std::vector<int32_t> adj(k);
+  for (int64_t p = 0; p < k; ++p) adj[p] = val[order[p]];
+  auto deg = [&](int32_t v) { return ptr[v + 1] - ptr[v]; };
+
+  std::vector<int32_t> level(N, -1), queue;
+  std::vector<char> done(N, 0);
+  queue.reserve(1024);
+  // BFS from `root` over not-yet-numbered nodes; fills `queue` (visit order, neighbours by increasing degree) and
+  // returns the eccentricity; `stamp` marks this traversal in level[]
+  std::vector<int32_t> nb;
+  auto bfs = [&](int32_t root, std::vector<int32_t>& out) {
+    out.clear();
+    out.push_back(root);
+    level[root] = 0;
+    int32_t ecc = 0;
+    for (size_t head = 0; head < out.size(); ++head) {
+      const int32_t v = out[head];
+      nb.clear();
+      for (int32_t p = ptr[v]; p < ptr[v + 1]; ++p) {
+        const int32_t u = adj[p];
+        if (!done[u] && level[u] < 0) { level[u] = level[v] + 1; nb.push_back(u); }
+      }
+      std::sort(nb.begin(), nb.end(), [&](int32_t a, int32_t b) { return deg(a) != deg(b) ? deg(a) < deg(b) : a < b; });
+      for (int32_t u : nb) { out.push_back(u); if (level[u] > ecc) ecc = level[u]; }
+    }
+    return ecc;
+  };
+  auto clear_levels = [&](const std::vector<int32_t>& out) { for (int32_t v : out) level[v] = -1; };
+
+  std::vector<int32_t> comp, trial;
+  for (int32_t s = 0; s < num_segments; ++s) {
+    const int32_t a = seg_ptr[s], b = seg_ptr[s + 1];
+    if (a < 0 || b > N || a > b) return GATRES_E_BADARG;
+    int32_t next = a;                                 // next new id of this segment
+    std::vector<int32_t> seg_order;
+    seg_order.reserve(b - a);
+    for (int32_t v0 = a; v0 < b; ++v0) {
+      if (done[v0]) continue;
+      // component of v0: start from its minimum-degree node, then walk to a pseudo-peripheral one
+      bfs(v0, comp);
+      clear_levels(comp);
+      int32_t root = comp[0];
+      for (int32_t v : comp) {
+        if (v < a || v >= b) return GATRES_E_GRAPH;    // an edge leaves the segment
+        if (deg(v) < deg(root) || (deg(v) == deg(root) && v < root)) root = v;
+      }
+      int32_t ecc = bfs(root, trial);
+      for (int it = 0; it < 8; ++it) {
+        // candidate: a minimum-degree node of the last level
+        int32_t cand = trial.back();
+        for (size_t i = trial.size(); i-- > 0 && level[trial[i]] == ecc;)
+          if (deg(trial[i]) < deg(cand) || (deg(trial[i]) == deg(cand) && trial[i] < cand)) cand = trial[i];
+        clear_levels(trial);
+        std::vector<int32_t> t2;
+        const int32_t ecc2 = bfs(cand, t2);
+        if (ecc2 > ecc) { ecc = ecc2; root = cand; trial.swap(t2); }
+        else { clear_levels(t2); bfs(root, trial); break; }
+      }
+      for (int32_t v : trial) { done[v] = 1; seg_order.push_back(v); }
+      clear_levels(trial);
+    }
+    if ((int32_t)seg_order.size() != b - a) return GATRES_E_GRAPH;
+    for (size_t i = seg_order.size(); i-- > 0;) perm[next++] = seg_order[i];      // reversed
   }
   return 0;
 }

@@ -20,6 +20,7 @@
 //   * dense projections on the matrix cores (v_mfma_f32_16x16x4_f32, exact fp32), two 16-node tiles per wave
 //     sharing each W fragment; dW partials with 8 operand pairs in flight per wave.
 #include <cstdlib>
+#include <mutex>
 #include <type_traits>
 
 #include "gatres_common.h"
@@ -40,6 +41,7 @@ struct FusedArgs {
   int N;
   const float* params;
   const float* wt;          // transposed conv weights (backward)
+  const int* perm;          // plan's node relabelling (new id -> caller's id) for x / y / mask / out / g_out / g_x; null = identity
   const float* x;
   const uint8_t* mask;      // may be null (no masking of x; the loss phase needs it)
   const float* y;
@@ -104,6 +106,9 @@ static bool nocache_fits(int nc, int threads, int n, int eg, int em) {
 // is split over several CUs (see group_sync) each part owns a 16-aligned window and the tables it gathers from are
 // completed from the partners' global copies after a flag barrier.
 struct Rows { int lo, hi; };
+
+// caller-side index of plan node `node` (gatres_graph_t.perm): only x / y / mask / out / g_out / g_x are indexed with it
+__device__ __forceinline__ int ext_id(const int* __restrict__ perm, int node) { return perm ? perm[node] : node; }
 
 // ------------------------------------------------------------------------------------------ small helpers
 template <int THREADS>
@@ -985,7 +990,7 @@ __device__ __forceinline__ void seg_bias_finish(const float* red, float* __restr
 
 // lin1 backward for this segment: g_x = g_out (x) w (ReLU-masked), slab partials of g_w, g_b.
 template <int NC, int THREADS>
-__device__ __forceinline__ void seg_lin1_bwd(Rows rw, int n0, const float* __restrict__ g_out,
+__device__ __forceinline__ void seg_lin1_bwd(Rows rw, int n0, const int* __restrict__ perm, const float* __restrict__ g_out,
                                              const float* __restrict__ x, const float* __restrict__ w, float* g_x,
                                              float* g_x2, float* __restrict__ slab_w, float* __restrict__ slab_b,
                                              int relu_mask, float* red) {
@@ -995,7 +1000,7 @@ __device__ __forceinline__ void seg_lin1_bwd(Rows rw, int n0, const float* __res
   float aw = 0.f, ab = 0.f;
   for (int r = rw.lo + rg; r < rw.hi; r += R) {
     const size_t node = (size_t)n0 + r;
-    const float go = g_out[node];
+    const float go = g_out[ext_id(perm, n0 + r)];
     const float xv = x[(unsigned)(r * NC + c)];          // x: the segment's saved final activation, local rows
     aw = fmaf(go, xv, aw);
     ab += go;
@@ -1015,7 +1020,7 @@ __device__ __forceinline__ void seg_lin1_bwd(Rows rw, int n0, const float* __res
 }
 
 template <int NC, int THREADS>
-__device__ __forceinline__ void seg_lin0_bwd(Rows rw, int n0, const float* __restrict__ g, const float* __restrict__ x,
+__device__ __forceinline__ void seg_lin0_bwd(Rows rw, int n0, const int* __restrict__ perm, const float* __restrict__ g, const float* __restrict__ x,
                                              const uint8_t* __restrict__ mask, float* __restrict__ slab_w,
                                              float* __restrict__ slab_b, float* red) {
   constexpr int R = THREADS / NC;
@@ -1023,7 +1028,8 @@ __device__ __forceinline__ void seg_lin0_bwd(Rows rw, int n0, const float* __res
   float aw = 0.f, ab = 0.f;
   for (int r = rw.lo + rg; r < rw.hi; r += R) {
     const size_t node = (size_t)n0 + r;
-    const float xv = (mask && mask[node]) ? 0.f : x[node];
+    const int en = ext_id(perm, n0 + r);
+    const float xv = (mask && mask[en]) ? 0.f : x[en];
     const float gv = g[node * NC + c];
     aw = fmaf(gv, xv, aw);
     ab += gv;
@@ -1117,6 +1123,14 @@ __global__ __launch_bounds__(THREADS) void param_grads_kernel(const ParamGradArg
 // then complete their LDS tables from the partners' global copies.  Workgroup ids of one segment differ by multiples
 // of 8: consecutive ids are dispatched round-robin over the 8 XCDs, so partners share an XCD and its L2.
 constexpr int FLAG_STRIDE = 32;                 // one 128-byte line per flag
+// buffer_inv completes asynchronously; the s_waitcnt after it keeps the issuing wave (and, through the barrier that
+// follows, the workgroup) from loading a partner's lines before this CU's stale L1 copies are gone
+// (cdna_hip_programming.md Guideline 16: fence, that lane's vmcnt(0), barrier, then the other waves' loads).
+#ifndef GATRES_NO_INV_WAIT
+#define INV_WAIT() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+#else
+#define INV_WAIT() do {} while (0)
+#endif
 constexpr int SPIN_LIMIT = 1 << 20;             // a lost partner poisons the results instead of hanging the GPU
 
 struct Group {
@@ -1143,11 +1157,18 @@ __device__ __forceinline__ unsigned xcc_id() {
 // flag store, relaxed polling and one "buffer_inv sc1" (drops the CU's stale L1 lines; "sc0" does not) suffice.
 template <int THREADS>
 __device__ __forceinline__ void group_sync(Group& g) {
-  __syncthreads();                               // every wave's global stores have been acknowledged by L2
+  // EVERY wave drains its own global stores (and LDS-DMA) before the workgroup barrier: s_barrier waits for no counter,
+  // and hipcc's workgroup-scope release before it only waits lgkmcnt -- without this wait the flag below could overtake
+  // another wave's halo / table stores (MI355X_MICROARCH.md, Valid forms: "every storing wave's s_waitcnt vmcnt(0)")
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
   if (g.M == 1) return;
   ++g.epoch;
   if (threadIdx.x == 0) {
-    if (!g.local) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    if (!g.local) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (the compiler may drop the fence's own wait)
+    }
     __hip_atomic_store(g.flags + g.part * FLAG_STRIDE, g.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   if (threadIdx.x < 64) {                        // wave 0: lanes 0..M-1 poll one partner each
@@ -1159,6 +1180,7 @@ __device__ __forceinline__ void group_sync(Group& g) {
     }
     if (g.local) asm volatile("buffer_inv sc1" ::: "memory");
     else         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    INV_WAIT();                                  // hold the barrier until the invalidate has completed
   }
   __syncthreads();
 }
@@ -1252,7 +1274,10 @@ template <int THREADS>
 __device__ __forceinline__ void publish_items(const FusedArgs& a, int seg, int part, int count, bool parts_local,
                                               bool last) {
   if (a.C > 0 && part == 0 && (int)threadIdx.x < 64) {
-    if (last) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    if (last) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
     if ((int)threadIdx.x < a.C)
       __hip_atomic_store(a.ready + ((size_t)seg * 4 + threadIdx.x) * FLAG_STRIDE,
                          (unsigned)count | (xcc_id() << 16) | (parts_local ? PUB_LOCAL : 0u), __ATOMIC_RELAXED,
@@ -1292,6 +1317,7 @@ __device__ __forceinline__ void consumer_main(const FusedArgs& a, int cid, float
       }
       if (threadIdx.x == 0 && remote) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
       else                            asm volatile("buffer_inv sc1" ::: "memory");
+      INV_WAIT();
     }
     __syncthreads();
     if (i < 2 * nb) {
@@ -1400,7 +1426,7 @@ __global__ __launch_bounds__(THREADS) void gatres_fused_kernel(const FusedArgs a
       const float* b = P + L.p_lin0_b;
       for (int idx = rw.lo * (NC / 4) + tid; idx < rw.hi * (NC / 4); idx += THREADS) {
         const int r = idx / (NC / 4), c0 = (idx % (NC / 4)) * 4;
-        const size_t node = (size_t)n0 + r;
+        const int node = ext_id(a.perm, n0 + r);
         const float xv = (a.mask && a.mask[node]) ? 0.f : a.x[node];
         const float4 wv = ld4(w + c0), bv = ld4(b + c0);
         float4 o;
@@ -1521,7 +1547,7 @@ __global__ __launch_bounds__(THREADS) void gatres_fused_kernel(const FusedArgs a
         float d = xv.x * wv.x;
         d = fmaf(xv.y, wv.y, d); d = fmaf(xv.z, wv.z, d); d = fmaf(xv.w, wv.w, d);
         for (int off = G >> 1; off > 0; off >>= 1) d += __shfl_xor(d, off);
-        if (valid && (tid % G) == 0) a.out[n0 + r] = d + bias;
+        if (valid && (tid % G) == 0) a.out[ext_id(a.perm, n0 + r)] = d + bias;
       }
     }
     __syncthreads();
@@ -1535,7 +1561,7 @@ __global__ __launch_bounds__(THREADS) void gatres_fused_kernel(const FusedArgs a
     const float Mn = block_sum<THREADS>(cnt, ldsf);
     float part_sum = 0.f;
     for (int r = rw.lo + tid; r < rw.hi; r += THREADS) {
-      const int node = n0 + r;
+      const int node = ext_id(a.perm, n0 + r);
       if (a.mask[node]) {
         const float d = a.out[node] - a.y[node];
         part_sum = fmaf(d, d, part_sum);
@@ -1548,7 +1574,7 @@ __global__ __launch_bounds__(THREADS) void gatres_fused_kernel(const FusedArgs a
     }
     const float scale = Mn > 0.f ? 2.f / Mn : 0.f;
     for (int r = rw.lo + tid; r < rw.hi; r += THREADS) {
-      const int node = n0 + r;
+      const int node = ext_id(a.perm, n0 + r);
       a.g_out[node] = a.mask[node] ? (a.out[node] - a.y[node]) * scale : 0.f;
     }
     __syncthreads();
@@ -1603,7 +1629,7 @@ __global__ __launch_bounds__(THREADS) void gatres_fused_kernel(const FusedArgs a
                         : a.slabs + (int64_t)seg * L.slab_stride;
     const int64_t w = 2LL * NC * NC;
     const float* xfinal = segbase + (int64_t)L.nb * SL.bstride + SL.xin;
-    seg_lin1_bwd<NC, THREADS>(rw, n0, a.g_out, xfinal, P + L.p_lin1_w, gp_cur, gpT, slab + L.p_lin1_w,
+    seg_lin1_bwd<NC, THREADS>(rw, n0, a.perm, a.g_out, xfinal, P + L.p_lin1_w, gp_cur, gpT, slab + L.p_lin1_w,
                               slab + L.p_lin1_b, L.nb > 0 ? 1 : 0, red);
     // backward halo list (remote dst rows + edge ids of own out-edges) in the LDS behind the W slot
     u16* hrow = reinterpret_cast<u16*>(wlB + (WLDS ? ((WL_FLOATS + 3) & ~3) : 0)) + 2;
@@ -1703,7 +1729,7 @@ __global__ __launch_bounds__(THREADS) void gatres_fused_kernel(const FusedArgs a
     }
     group_sync<THREADS>(grp);
     publish_items<THREADS>(a, seg, part, 2 * L.nb, grp.local || !split, !split);
-    seg_lin0_bwd<NC, THREADS>(rw, n0, gp_cur, a.x, a.mask, slab + L.p_lin0_w, slab + L.p_lin0_b, red);
+    seg_lin0_bwd<NC, THREADS>(rw, n0, a.perm, gp_cur, a.x, a.mask, slab + L.p_lin0_w, slab + L.p_lin0_b, red);
     if (split && a.C > 0) {                   // last item: fold the lin0 / lin1 partial rows
       group_sync<THREADS>(grp);
       publish_items<THREADS>(a, seg, part, 2 * L.nb + 1, grp.local, true);
@@ -1720,7 +1746,7 @@ __global__ __launch_bounds__(THREADS) void gatres_fused_kernel(const FusedArgs a
         float d = xv.x * wv.x;
         d = fmaf(xv.y, wv.y, d); d = fmaf(xv.z, wv.z, d); d = fmaf(xv.w, wv.w, d);
         for (int off = G >> 1; off > 0; off >>= 1) d += __shfl_xor(d, off);
-        if (valid && (tid % G) == 0) a.g_x[n0 + r] = d;
+        if (valid && (tid % G) == 0) a.g_x[ext_id(a.perm, n0 + r)] = d;
       }
     }
   }
@@ -1915,7 +1941,7 @@ __global__ __launch_bounds__(THREADS) void gatres_window_kernel(const FusedArgs 
       const float* b = P + L.p_lin0_b;
       for (int idx = rw.lo * (NC / 4) + tid; idx < rw.hi * (NC / 4); idx += THREADS) {
         const int r = idx / (NC / 4), c0 = (idx % (NC / 4)) * 4;
-        const size_t node = (size_t)n0 + r;
+        const int node = ext_id(a.perm, n0 + r);
         const float xv = (a.mask && a.mask[node]) ? 0.f : a.x[node];
         const float4 wv = ld4(w + c0), bv = ld4(b + c0);
         float4 o;
@@ -2030,7 +2056,7 @@ __global__ __launch_bounds__(THREADS) void gatres_window_kernel(const FusedArgs 
         float d = xv.x * wv.x;
         d = fmaf(xv.y, wv.y, d); d = fmaf(xv.z, wv.z, d); d = fmaf(xv.w, wv.w, d);
         for (int off = G >> 1; off > 0; off >>= 1) d += __shfl_xor(d, off);
-        if (valid && (tid % G) == 0) a.out[n0 + r] = d + bias;
+        if (valid && (tid % G) == 0) a.out[ext_id(a.perm, n0 + r)] = d + bias;
       }
     }
     __syncthreads();
@@ -2043,7 +2069,7 @@ __global__ __launch_bounds__(THREADS) void gatres_window_kernel(const FusedArgs 
     const float Mn = block_sum<THREADS>(cnt, ldsf);
     float part_sum = 0.f;
     for (int r = rw.lo + tid; r < rw.hi; r += THREADS) {
-      const int node = n0 + r;
+      const int node = ext_id(a.perm, n0 + r);
       if (a.mask[node]) {
         const float d = a.out[node] - a.y[node];
         part_sum = fmaf(d, d, part_sum);
@@ -2056,7 +2082,7 @@ __global__ __launch_bounds__(THREADS) void gatres_window_kernel(const FusedArgs 
     }
     const float scale = Mn > 0.f ? 2.f / Mn : 0.f;
     for (int r = rw.lo + tid; r < rw.hi; r += THREADS) {
-      const int node = n0 + r;
+      const int node = ext_id(a.perm, n0 + r);
       a.g_out[node] = a.mask[node] ? (a.out[node] - a.y[node]) * scale : 0.f;
     }
     __syncthreads();
@@ -2130,7 +2156,7 @@ __global__ __launch_bounds__(THREADS) void gatres_window_kernel(const FusedArgs 
       w_prefetch<NC, 2 * NC, EPI_RESID_MASK, THREADS>(wlA, a.wt + (int64_t)blk * 2 * w + w, nullptr, nullptr, w0);
     };
     if (L.nb > 0) dma_conv2(L.nb - 1, 0);
-    seg_lin1_bwd<NC, THREADS>(rw, n0, a.g_out, xfinal, P + L.p_lin1_w, gp_cur, gpT, slab + L.p_lin1_w,
+    seg_lin1_bwd<NC, THREADS>(rw, n0, a.perm, a.g_out, xfinal, P + L.p_lin1_w, gp_cur, gpT, slab + L.p_lin1_w,
                               slab + L.p_lin1_b, L.nb > 0 ? 1 : 0, red);
     int hcnt = 0;
     bool halo = false;
@@ -2229,7 +2255,7 @@ __global__ __launch_bounds__(THREADS) void gatres_window_kernel(const FusedArgs 
     }
     group_sync<THREADS>(grp);
     publish_items<THREADS>(a, seg, part, 2 * L.nb, grp.local || !pub, !pub);
-    seg_lin0_bwd<NC, THREADS>(rw, n0, gp_cur, a.x, a.mask, slab + L.p_lin0_w, slab + L.p_lin0_b, red);
+    seg_lin0_bwd<NC, THREADS>(rw, n0, a.perm, gp_cur, a.x, a.mask, slab + L.p_lin0_w, slab + L.p_lin0_b, red);
     if (pub && a.C > 0) {
       group_sync<THREADS>(grp);
       publish_items<THREADS>(a, seg, part, 2 * L.nb + 1, grp.local, true);
@@ -2246,7 +2272,7 @@ __global__ __launch_bounds__(THREADS) void gatres_window_kernel(const FusedArgs 
         float d = xv.x * wv.x;
         d = fmaf(xv.y, wv.y, d); d = fmaf(xv.z, wv.z, d); d = fmaf(xv.w, wv.w, d);
         for (int off = G >> 1; off > 0; off >>= 1) d += __shfl_xor(d, off);
-        if (valid && (tid % G) == 0) a.g_x[n0 + r] = d;
+        if (valid && (tid % G) == 0) a.g_x[ext_id(a.perm, n0 + r)] = d;
       }
     }
   }
@@ -2268,8 +2294,14 @@ __global__ __launch_bounds__(256) void reduce_adam_kernel(const float* __restric
                                                           float* __restrict__ m, float* __restrict__ v,
                                                           unsigned long long* __restrict__ step_counter, double lr,
                                                           double b1, double b2, double eps, double wd,
-                                                          float grad_scale, float* __restrict__ wt, int nb, int nc) {
+                                                          float grad_scale, float* __restrict__ wt, int nb, int nc,
+                                                          unsigned* __restrict__ status) {
   __shared__ float s_step_size, s_bc2_sqrt;
+  __shared__ unsigned s_fault;
+  // status[0]: a split launch of this step gave up waiting for a partner workgroup (its results are poisoned).  The step
+  // is then DROPPED: no Adam update, no step count, loss = NaN, gradients = NaN; the last block clears the word and
+  // counts the event in status[1], so one transient stall costs one step instead of the whole run.
+  if (threadIdx.x == 0) s_fault = status ? __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
   if (do_adam && threadIdx.x == 0) {
     const unsigned long long t = step_counter[0] + 1ULL;
     s_step_size = (float)(lr / (1.0 - gatres_powi(b1, t)));
@@ -2284,6 +2316,8 @@ __global__ __launch_bounds__(256) void reduce_adam_kernel(const float* __restric
     if (threadIdx.x == 0) loss[0] = s / loss_part[num_loss];
   }
   __syncthreads();
+  const bool fault = s_fault != 0u;
+  if (fault && loss && blockIdx.x == 0 && threadIdx.x == 0) loss[0] = NAN;
   const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
   if (idx < count) {
     float acc = 0.f;
@@ -2296,8 +2330,8 @@ __global__ __launch_bounds__(256) void reduce_adam_kernel(const float* __restric
       for (int u = 0; u < 8; ++u) acc += v8[u];
     }
     for (; s0 < num_slabs; ++s0) acc += slabs[(size_t)s0 * stride + idx];
-    grads[idx] = acc;
-    if (do_adam) {
+    grads[idx] = fault ? NAN : acc;
+    if (do_adam && !fault) {
       const float pv = p[idx];
       float gv = acc * grad_scale;
       gv = gv + (float)wd * pv;
@@ -2324,7 +2358,7 @@ __global__ __launch_bounds__(256) void reduce_adam_kernel(const float* __restric
       }
     }
   }
-  if (do_adam) {
+  if (do_adam && !fault) {
     __syncthreads();
     if (threadIdx.x == 0) {
       __threadfence();
@@ -2335,6 +2369,52 @@ __global__ __launch_bounds__(256) void reduce_adam_kernel(const float* __restric
       }
     }
   }
+  if (fault && threadIdx.x == 0) {               // every block has read status[0] before the last ticket is drawn
+    __threadfence();
+    if (atomicAdd(status + 2, 1u) == gridDim.x - 1u) {
+      status[2] = 0u;
+      status[1] += 1u;
+      __hip_atomic_store(status, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+}
+
+// The same bookkeeping after a split launch that no gatres_fused_finish follows (forward / inference launches)
+__global__ __launch_bounds__(64) void fused_status_kernel(unsigned* __restrict__ status) {
+  if (threadIdx.x == 0 && __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
+    status[1] += 1u;
+    __hip_atomic_store(status, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
+// Two split launches must never be in flight on one device at the same time: each needs its whole grid resident, and
+// each could hold CUs the other waits for (the bounded spins would then poison both).  Launches on ONE stream are
+// ordered anyway; when the stream changes, the new stream first waits for everything enqueued on the previous one.
+// Skipped while `st` is being captured: the host that replays the graph calls gatres_fused_serialize before the replay.
+static std::mutex g_split_mu;
+static hipStream_t g_split_stream[64];
+static bool g_split_seen[64] = {};
+static int serialize_split_launch(hipStream_t st) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 0;
+  std::lock_guard<std::mutex> lk(g_split_mu);
+  hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(st, &cs) != hipSuccess) { (void)hipGetLastError(); return 0; }
+  if (cs != hipStreamCaptureStatusNone) return 0;
+  if (g_split_seen[dev] && g_split_stream[dev] != st) {
+    hipStream_t prev = g_split_stream[dev];
+    hipStreamCaptureStatus ps = hipStreamCaptureStatusNone;
+    hipEvent_t ev;
+    if (hipStreamIsCapturing(prev, &ps) == hipSuccess && ps == hipStreamCaptureStatusNone &&
+        hipEventCreateWithFlags(&ev, hipEventDisableTiming) == hipSuccess) {
+      if (hipEventRecord(ev, prev) == hipSuccess) (void)hipStreamWaitEvent(st, ev, 0);
+      (void)hipEventDestroy(ev);
+    }
+    (void)hipGetLastError();                     // (a stream the caller has destroyed meanwhile: nothing left to wait for)
+  }
+  g_split_stream[dev] = st;
+  g_split_seen[dev] = true;
+  return 0;
 }
 
 static int fused_threads_small() {
@@ -2486,6 +2566,7 @@ extern "C" int gatres_fused_run(const gatres_model_t* m, const gatres_graph_t* g
   a.rowptr = g->rowptr; a.col = g->col; a.t_rowptr = g->t_rowptr; a.t_eid = g->t_eid; a.t_dst = g->t_dst;
   a.m_rowptr = g->m_rowptr; a.m_col = g->m_col; a.mt_rowptr = g->mt_rowptr; a.mt_dst = g->mt_dst;
   a.N = g->num_nodes;
+  a.perm = g->perm;
   a.params = params; a.wt = scratch + a.L.sc_wt;
   a.x = x; a.mask = mask; a.y = y; a.out = out; a.g_out = g_out; a.loss_part = loss_part; a.g_x = g_x;
   a.saved = saved; a.scratch = scratch; a.slabs = scratch + a.L.sc_slabs;
@@ -2502,15 +2583,29 @@ extern "C" int gatres_fused_run(const gatres_model_t* m, const gatres_graph_t* g
   a.stamps = g_stamps; a.stamp_cap = g_stamp_cap;
   a.phases = (phases & (GATRES_PHASE_FORWARD | GATRES_PHASE_BACKWARD)) | ((phases & GATRES_PHASE_LOSS) ? PH_LOSS : 0);
   hipStream_t st = gatres_stream(stream);
+  if (a.M > 1) serialize_split_launch(st);
+  int rc = GATRES_E_UNSUPPORTED;
   switch (m->nc) {
-    case 4: return launch_fused<4, 1024>(a, g, st);
-    case 8: return launch_fused<8, 1024>(a, g, st);
-    case 16: return launch_fused<16, 1024>(a, g, st);
-    case 32: return fused_threads_small() == 512 ? launch_fused<32, 512>(a, g, st) : launch_fused<32, 1024>(a, g, st);
-    case 64: return launch_fused<64, 512>(a, g, st);
-    case 128: return launch_fused<128, 256>(a, g, st);
+    case 4: rc = launch_fused<4, 1024>(a, g, st); break;
+    case 8: rc = launch_fused<8, 1024>(a, g, st); break;
+    case 16: rc = launch_fused<16, 1024>(a, g, st); break;
+    case 32: rc = fused_threads_small() == 512 ? launch_fused<32, 512>(a, g, st) : launch_fused<32, 1024>(a, g, st); break;
+    case 64: rc = launch_fused<64, 512>(a, g, st); break;
+    case 128: rc = launch_fused<128, 256>(a, g, st); break;
   }
-  return GATRES_E_UNSUPPORTED;
+  if (rc == 0 && a.M > 1 && !(phases & GATRES_PHASE_BACKWARD)) {      // (a backward launch is followed by gatres_fused_finish)
+    hipLaunchKernelGGL(fused_status_kernel, dim3(1), dim3(64), 0, st, reinterpret_cast<unsigned*>(a.err));
+    rc = gatres_launch_status();
+  }
+  return rc;
+}
+
+extern "C" int gatres_fused_serialize(void* stream) { return serialize_split_launch(gatres_stream(stream)); }
+
+extern "C" int64_t gatres_fused_status_offset(const gatres_model_t* m, const gatres_graph_t* g) {
+  Layout L;
+  if (!gatres_fused_supported(m, g) || !make_layout_g(m, g, &L)) return -1;
+  return L.sc_flags + L.flag_words - 32;
 }
 
 extern "C" int gatres_fused_param_grads(const gatres_model_t* m, const gatres_graph_t* g, const float* saved,
@@ -2551,6 +2646,7 @@ extern "C" int gatres_fused_finish(const gatres_model_t* m, const gatres_graph_t
                      scratch + L.sc_slabs, g->num_segments, g->num_segments * fused_split(L, g),
                      (long long)L.slab_stride, (long long)L.P, grads, loss_part, loss, do_adam, params, exp_avg, exp_avg_sq,
                      reinterpret_cast<unsigned long long*>(step_counter), lr, beta1, beta2, eps, weight_decay,
-                     grad_scale, do_adam ? scratch + L.sc_wt : nullptr, L.nb, L.nc);
+                     grad_scale, do_adam ? scratch + L.sc_wt : nullptr, L.nb, L.nc,
+                     fused_nodes_of(g) > 0 ? reinterpret_cast<unsigned*>(scratch + L.sc_flags + L.flag_words - 32) : nullptr);
   return gatres_launch_status();
 }

@@ -206,6 +206,22 @@ __global__ __launch_bounds__(256) void transpose_conv_weights_kernel(const float
   wt[(size_t)b * 2 * per + (size_t)conv * per + e] = W[(size_t)ocol * cols + orow];
 }
 
+// ------------------------------------------------------------------------------------- node relabelling
+// Per-op path of a relabelled plan (gatres_graph_t.perm): caller-order vectors are gathered into plan order before
+// lin0 / the backward, and the results scattered back.  (The fused kernels index through perm directly.)
+__global__ __launch_bounds__(256) void permute_f32_kernel(const float* __restrict__ src, const int* __restrict__ perm,
+                                                          float* __restrict__ dst, int N, int scatter) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= N) return;
+  if (scatter) dst[perm[i]] = src[i];
+  else         dst[i] = src[perm[i]];
+}
+__global__ __launch_bounds__(256) void gather_u8_kernel(const uint8_t* __restrict__ src, const int* __restrict__ perm,
+                                                        uint8_t* __restrict__ dst, int N) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < N) dst[i] = src[perm[i]];
+}
+
 // ------------------------------------------------------------------------------------------ edge_index hash
 __device__ __forceinline__ uint64_t mix64(uint64_t z) {
   z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
@@ -344,7 +360,10 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
   }
   __syncthreads();
   const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
-  if (idx < count) {
+  // A NaN gradient entry leaves its parameter and moments untouched: a data-parallel step whose fused launch faulted
+  // (gatres_fused_finish marks every entry NaN, the all-reduce spreads that to all ranks) is dropped on every replica
+  // alike instead of destroying the run.  (torch.optim.Adam would propagate the NaN.)
+  if (idx < count && g[idx] == g[idx]) {
     const float pv = p[idx];
     float gv = g[idx] * grad_scale;
     gv = gv + (float)wd * pv;
@@ -477,5 +496,20 @@ extern "C" int gatres_adam_step(float* params, const float* grads, float* exp_av
   hipLaunchKernelGGL(adam_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, gatres_stream(stream), params,
                      grads, exp_avg, exp_avg_sq, reinterpret_cast<unsigned long long*>(step_counter),
                      (long long)count, lr, beta1, beta2, eps, weight_decay, grad_scale);
+  return gatres_launch_status();
+}
+
+extern "C" int gatres_permute_f32(const float* src, const int32_t* perm, float* dst, int32_t num_nodes, int32_t scatter,
+                                  void* stream) {
+  if (!src || !perm || !dst || num_nodes <= 0) return GATRES_E_BADARG;
+  hipLaunchKernelGGL(permute_f32_kernel, dim3((unsigned)((num_nodes + 255) / 256)), dim3(256), 0, gatres_stream(stream),
+                     src, perm, dst, num_nodes, scatter);
+  return gatres_launch_status();
+}
+
+extern "C" int gatres_gather_u8(const uint8_t* src, const int32_t* perm, uint8_t* dst, int32_t num_nodes, void* stream) {
+  if (!src || !perm || !dst || num_nodes <= 0) return GATRES_E_BADARG;
+  hipLaunchKernelGGL(gather_u8_kernel, dim3((unsigned)((num_nodes + 255) / 256)), dim3(256), 0, gatres_stream(stream),
+                     src, perm, dst, num_nodes);
   return gatres_launch_status();
 }

@@ -72,6 +72,17 @@ extern "C" int gatres_model_forward_per_op(const gatres_model_t* m, const gatres
   float* xa = scratch + L.sc_xa;
   float* xb = scratch + L.sc_xb;
   float* xcur = saved ? saved + L.s_xin : xa;
+  float* out_caller = out;
+  if (g->perm) {          // relabelled plan: x / mask into plan order, predictions back into the caller's order at the end
+    RC(gatres_permute_f32(x, g->perm, scratch + L.sc_px, N, 0, stream));
+    x = scratch + L.sc_px;
+    if (mask) {
+      uint8_t* pm = reinterpret_cast<uint8_t*>(scratch + L.sc_pmask);
+      RC(gatres_gather_u8(mask, g->perm, pm, N, stream));
+      mask = pm;
+    }
+    out = scratch + L.sc_pout;
+  }
   RC(gatres_lin0_fwd(x, mask, params + L.p_lin0_w, params + L.p_lin0_b, xcur, N, nc, stream));
   for (int b = 0; b < L.nb; ++b) {
     float* base = saved ? saved + (int64_t)b * L.s_stride : scratch + L.sc_ev;
@@ -89,6 +100,7 @@ extern "C" int gatres_model_forward_per_op(const gatres_model_t* m, const gatres
     xcur = xnext;
   }
   RC(gatres_lin1_fwd(xcur, params + L.p_lin1_w, params + L.p_lin1_b, out, N, nc, stream));
+  if (g->perm) RC(gatres_permute_f32(out, g->perm, out_caller, N, 1, stream));
   return 0;
 }
 
@@ -112,14 +124,33 @@ extern "C" int gatres_model_backward_per_op(const gatres_model_t* m, const gatre
                                             const float* x, const uint8_t* mask, const float* g_out,
                                             const float* saved, float* scratch, float* grads, float* g_x,
                                             void* stream) {
+  if (!m) return GATRES_E_BADARG;
+  RC(gatres_model_backward_per_op_part(m, g, params, x, mask, g_out, saved, scratch, grads, g_x, m->num_blocks, 0,
+                                       GATRES_PART_FIRST | GATRES_PART_LAST, stream));
+  Layout L;
+  if (!make_layout_g(m, g, &L)) return GATRES_E_UNSUPPORTED;
+  return gatres_reduce_slabs(scratch + L.sc_slabs, L.num_slabs, L.slab_stride, L.P, grads, stream);
+}
+
+// One piece of the per-op backward: [lin1 backward] blocks b_hi-1 .. b_lo [lin0 backward].  With GATRES_PART_REDUCE the
+// slab partials of exactly the parameters this piece finishes are summed into `grads` right away, so a data-parallel
+// caller can start the all-reduce of that range while the next piece runs (gradient buckets in reverse block order).
+extern "C" int gatres_model_backward_per_op_part(const gatres_model_t* m, const gatres_graph_t* g, const float* params,
+                                                 const float* x, const uint8_t* mask, const float* g_out,
+                                                 const float* saved, float* scratch, float* grads, float* g_x,
+                                                 int32_t b_hi, int32_t b_lo, int32_t flags, void* stream) {
   if (!m || !g || !params || !x || !g_out || !saved || !scratch || !grads) return GATRES_E_BADARG;
   if (!gatres_aligned16(params) || !gatres_aligned16(saved) || !gatres_aligned16(scratch)) return GATRES_E_BADARG;
   Layout L;
   if (!make_layout_g(m, g, &L)) return GATRES_E_UNSUPPORTED;
+  const bool first = flags & GATRES_PART_FIRST, last = flags & GATRES_PART_LAST;
+  if (b_lo < 0 || b_hi > L.nb || b_lo > b_hi || (first && b_hi != L.nb) || (last && b_lo != 0)) return GATRES_E_BADARG;
   const int N = g->num_nodes, nc = L.nc, S = L.num_slabs;
   const int64_t st = L.slab_stride, w = 2LL * nc * nc;
-  float* gp_cur = scratch + L.sc_gpa;
-  float* gp_nxt = scratch + L.sc_gpb;
+  // g_pre ping-pongs between two buffers, one swap per block: where it stands depends only on the blocks done so far
+  const bool odd = ((L.nb - b_hi) & 1) != 0;
+  float* gp_cur = scratch + (odd ? L.sc_gpb : L.sc_gpa);
+  float* gp_nxt = scratch + (odd ? L.sc_gpa : L.sc_gpb);
   float* gy2 = scratch + L.sc_gy2;
   float* ge = scratch + L.sc_ge;
   float* gad = scratch + L.sc_gad;
@@ -129,11 +160,25 @@ extern "C" int gatres_model_backward_per_op(const gatres_model_t* m, const gatre
   float* wt = scratch + L.sc_wt;
   float* slabs = scratch + L.sc_slabs;
 
-  RC(gatres_transpose_conv_weights(params, wt, L.nb, nc, stream));
-  const float* xfinal = saved + (int64_t)L.nb * L.s_stride + L.s_xin;
-  RC(gatres_lin1_bwd(g_out, xfinal, params + L.p_lin1_w, gp_cur, slabs + L.p_lin1_w, slabs + L.p_lin1_b, S, st, N, nc,
-                     L.nb > 0 ? 1 : 0, stream));
-  for (int b = L.nb - 1; b >= 0; --b) {
+  float* g_x_caller = g_x;
+  if (g->perm) {          // relabelled plan: caller-order vectors into plan order (see the forward driver)
+    if (first) {
+      RC(gatres_permute_f32(g_out, g->perm, scratch + L.sc_pgout, N, 0, stream));
+      RC(gatres_permute_f32(x, g->perm, scratch + L.sc_px, N, 0, stream));
+      if (mask) RC(gatres_gather_u8(mask, g->perm, reinterpret_cast<uint8_t*>(scratch + L.sc_pmask), N, stream));
+    }
+    g_out = scratch + L.sc_pgout;
+    x = scratch + L.sc_px;
+    if (mask) mask = reinterpret_cast<const uint8_t*>(scratch + L.sc_pmask);
+    if (g_x) g_x = scratch + L.sc_pgx;
+  }
+  if (first) {
+    RC(gatres_transpose_conv_weights(params, wt, L.nb, nc, stream));
+    const float* xfinal = saved + (int64_t)L.nb * L.s_stride + L.s_xin;
+    RC(gatres_lin1_bwd(g_out, xfinal, params + L.p_lin1_w, gp_cur, slabs + L.p_lin1_w, slabs + L.p_lin1_b, S, st, N, nc,
+                       L.nb > 0 ? 1 : 0, stream));
+  }
+  for (int b = b_hi - 1; b >= b_lo; --b) {
     const float* base = saved + (int64_t)b * L.s_stride;
     const int64_t po = L.p_block0 + (int64_t)b * L.p_block_stride;
     const float* pb = params + po;
@@ -163,8 +208,17 @@ extern "C" int gatres_model_backward_per_op(const gatres_model_t* m, const gatre
     RC(gatres_proj_bwd_dx(gh, wt1, gp_cur, b > 0 ? base + L.s_xin : nullptr, gp_nxt, N, nc, 2 * nc, stream));
     float* t = gp_cur; gp_cur = gp_nxt; gp_nxt = t;
   }
-  RC(gatres_lin0_bwd(gp_cur, x, mask, slabs + L.p_lin0_w, slabs + L.p_lin0_b, S, st, N, nc, stream));
-  if (g_x) RC(gatres_lin1_fwd(gp_cur, params + L.p_lin0_w, nullptr, g_x, N, nc, stream));
-  RC(gatres_reduce_slabs(slabs, S, st, L.P, grads, stream));
+  if (last) {
+    RC(gatres_lin0_bwd(gp_cur, x, mask, slabs + L.p_lin0_w, slabs + L.p_lin0_b, S, st, N, nc, stream));
+    if (g_x) {
+      RC(gatres_lin1_fwd(gp_cur, params + L.p_lin0_w, nullptr, g_x, N, nc, stream));
+      if (g->perm) RC(gatres_permute_f32(g_x, g->perm, g_x_caller, N, 1, stream));
+    }
+  }
+  if (flags & GATRES_PART_REDUCE) {
+    const int64_t lo = last ? 0 : L.p_block0 + (int64_t)b_lo * L.p_block_stride;
+    const int64_t hi = first ? L.P : L.p_block0 + (int64_t)b_hi * L.p_block_stride;
+    if (hi > lo) RC(gatres_reduce_slabs(slabs + lo, S, st, hi - lo, grads + lo, stream));
+  }
   return 0;
 }

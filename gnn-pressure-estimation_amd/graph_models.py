@@ -276,23 +276,32 @@ class GATResMeanConv(nn.Module):
 
     def _scratch_for(self, plan: GraphPlan) -> Tensor:
         key = (plan.num_nodes, plan.num_edges_gat, plan.num_segments, str(plan.device))
-        buf = self._scratch.get(key)
+        buf = self._scratch.pop(key, None)
+        if buf is not None:
+            self._scratch[key] = buf          # most recently used last
         if buf is None:
             lib = _native.load()
             n = lib.gatres_scratch_floats(self._cmodel_ref(), plan.ref())
             if n < 0:
                 _native.check(int(n), "gatres_scratch_floats")
             # zeroed once: the split-segment barrier epochs of the fused kernel live in here (include/gatres.h)
-            self._scratch = {key: torch.zeros(int(n), dtype=torch.float32, device=plan.device)}
-            buf = self._scratch[key]
+            buf = torch.zeros(int(n), dtype=torch.float32, device=plan.device)
+            self._remember(key, buf)
         return buf
+
+    def _remember(self, key, buf: Tensor, bound: int = 6) -> None:
+        """Small LRU of per-plan work buffers: alternating plans (train / validation batch sizes, a ragged last batch)
+        keep their buffers -- and the barrier state inside them -- instead of re-allocating on every switch."""
+        self._scratch[key] = buf
+        while len(self._scratch) > bound:
+            self._scratch.pop(next(iter(self._scratch)))
 
     def _eval_saved_for(self, plan: GraphPlan) -> Tensor:
         key = ("eval_saved", plan.num_nodes, plan.num_edges_gat, plan.num_segments, str(plan.device))
         buf = self._scratch.get(key)
         if buf is None:
             buf = torch.empty(self._saved_floats(plan), dtype=torch.float32, device=plan.device)
-            self._scratch[key] = buf
+            self._remember(key, buf)
         return buf
 
     def plan_for(self, edge_index: Tensor, num_nodes: int) -> GraphPlan:

@@ -8,7 +8,8 @@ once (``gatres_graph_build_host``) and cached on the content of ``edge_index``.
 from __future__ import annotations
 
 import ctypes as C
-from typing import Dict, Tuple
+import os
+from typing import Dict, Optional, Tuple
 
 import torch
 
@@ -19,7 +20,11 @@ class GraphPlan:
     """Device-resident destination-/source-sorted CSR of one (batched) topology."""
 
     def __init__(self, edge_index: torch.Tensor, num_nodes: int, device=None, segments: bool = True,
-                 merge_upto: int = 64):
+                 merge_upto: int = 64, reorder: Optional[bool] = None):
+        """``reorder``: relabel the nodes inside every segment with reverse Cuthill-McKee (``gatres_graph_reorder_host``)
+        so that the fused kernels' row windows stay compact whatever order the caller's file lists the junctions in.
+        ``None`` (default) = automatic: adopted when it shrinks the 4-part row window by more than 10 %; the environment
+        variable GATRES_REORDER=0|1 overrides.  x / y / mask / out keep the CALLER's node order either way."""
         if edge_index.dim() != 2 or edge_index.shape[0] != 2:
             raise ValueError(f"edge_index must be [2, E], got {tuple(edge_index.shape)}")
         if edge_index.dtype != torch.int64:
@@ -35,6 +40,45 @@ class GraphPlan:
         _native.check(lib.gatres_graph_count_host(ei_host.data_ptr(), E, N, C.byref(e_gat)), "gatres_graph_count_host")
         Eg = int(e_gat.value)
         i32 = dict(dtype=torch.int32)
+        # segment table first: it does not depend on the labelling inside a segment, the relabelling below needs it
+        self.num_segments, self.max_segment_nodes = 0, 0
+        self.max_segment_edges_gat, self.max_segment_edges_mean = 0, 0
+        self.perm_host: Optional[torch.Tensor] = None          # int32 [N]: plan node id -> caller's node id
+        seg = None
+        if segments:
+            seg = torch.empty(N + 1, **i32)
+            ns, mx, mg, mm = C.c_int32(0), C.c_int32(0), C.c_int32(0), C.c_int32(0)
+            _native.check(lib.gatres_graph_segments_host(ei_host.data_ptr(), E, N, int(merge_upto), seg.data_ptr(),
+                                                         C.byref(ns), C.byref(mx), C.byref(mg), C.byref(mm)),
+                          "gatres_graph_segments_host")
+            self.num_segments, self.max_segment_nodes = int(ns.value), int(mx.value)
+            self.max_segment_edges_gat, self.max_segment_edges_mean = int(mg.value), int(mm.value)
+            self.segment_ptr_host = seg[: self.num_segments + 1].clone()
+
+            def windows_of(ei_t):
+                win = torch.zeros(9, **i32)
+                _native.check(lib.gatres_graph_windows_host(ei_t.data_ptr(), E, N, self.segment_ptr_host.data_ptr(),
+                                                            self.num_segments, win.data_ptr()),
+                              "gatres_graph_windows_host")
+                return [int(v) for v in win]
+
+            self.windows = windows_of(ei_host)
+            env = os.environ.get("GATRES_REORDER")
+            want = reorder if reorder is not None else (None if env is None else env not in ("0", ""))
+            # (automatic only where the fused kernels apply: segments of up to 4096 nodes, include/gatres.h)
+            if want is not False and E > 0 and self.max_segment_nodes > 32 and (want or self.max_segment_nodes <= 4096):
+                perm = torch.empty(N, **i32)
+                _native.check(lib.gatres_graph_reorder_host(ei_host.data_ptr(), E, N, self.segment_ptr_host.data_ptr(),
+                                                            self.num_segments, perm.data_ptr()),
+                              "gatres_graph_reorder_host")
+                old2new = torch.empty(N, dtype=torch.int64)
+                old2new[perm.long()] = torch.arange(N, dtype=torch.int64)
+                ei_new = old2new[ei_host].contiguous()
+                win_new = windows_of(ei_new)
+                if want is True or win_new[3] < 0.9 * self.windows[3]:
+                    self.perm_host, self.windows, ei_host = perm, win_new, ei_new
+        else:
+            self.windows = [0] * 9
         host = {
             "rowptr": torch.empty(N + 1, **i32), "col": torch.empty(Eg, **i32),
             "t_rowptr": torch.empty(N + 1, **i32), "t_eid": torch.empty(Eg, **i32), "t_dst": torch.empty(Eg, **i32),
@@ -46,31 +90,17 @@ class GraphPlan:
         self.num_nodes, self.num_edges_gat, self.num_edges_mean = N, Eg, E
         self.device = device
         self.arrays: Dict[str, torch.Tensor] = {k: v.to(device) for k, v in host.items()}
-        # segment table: the snapshots of the batch (one workgroup each in the fused kernels)
-        self.num_segments, self.max_segment_nodes = 0, 0
-        self.max_segment_edges_gat, self.max_segment_edges_mean = 0, 0
         seg_dev_ptr = None
         if segments:
-            seg = torch.empty(N + 1, **i32)
-            ns, mx, mg, mm = C.c_int32(0), C.c_int32(0), C.c_int32(0), C.c_int32(0)
-            _native.check(lib.gatres_graph_segments_host(ei_host.data_ptr(), E, N, int(merge_upto), seg.data_ptr(),
-                                                         C.byref(ns), C.byref(mx), C.byref(mg), C.byref(mm)),
-                          "gatres_graph_segments_host")
-            self.num_segments, self.max_segment_nodes = int(ns.value), int(mx.value)
-            self.max_segment_edges_gat, self.max_segment_edges_mean = int(mg.value), int(mm.value)
-            self.segment_ptr_host = seg[: self.num_segments + 1].clone()
             self.arrays["seg_ptr"] = self.segment_ptr_host.to(device)
             seg_dev_ptr = self.arrays["seg_ptr"].data_ptr()
-            # row windows of split segments (2 / 4 / 8 workgroups per segment): rows, GATConv edges, SimpleConv edges
-            win = torch.zeros(9, **i32)
-            _native.check(lib.gatres_graph_windows_host(ei_host.data_ptr(), E, N, self.segment_ptr_host.data_ptr(),
-                                                        self.num_segments, win.data_ptr()), "gatres_graph_windows_host")
-            self.windows = [int(v) for v in win]
-        else:
-            self.windows = [0] * 9
+        perm_dev_ptr = None
+        if self.perm_host is not None:
+            self.arrays["perm"] = self.perm_host.to(device)
+            perm_dev_ptr = self.arrays["perm"].data_ptr()
         self.c = _native.GatresGraph(N, Eg, E, self.num_segments, *[self.arrays[k].data_ptr() for k in host.keys()],
                                      seg_dev_ptr, self.max_segment_nodes, self.max_segment_edges_gat,
-                                     self.max_segment_edges_mean, 0, (C.c_int32 * 9)(*self.windows), 0)
+                                     self.max_segment_edges_mean, 0, (C.c_int32 * 9)(*self.windows), 0, perm_dev_ptr)
 
     def ref(self):
         return C.byref(self.c)

@@ -11,15 +11,18 @@ mean-losses equal the global-batch mean loss, so the result matches single-proce
 from __future__ import annotations
 
 import ctypes as C
-from typing import Optional, Sequence
+from collections import OrderedDict
+from typing import Callable, Dict, Optional, Sequence, Tuple
 
 import torch
 
-from . import _native
+from . import _native, dp
 from .graph_models import GATResMeanConv
 from .graph_plan import GraphPlan
 
 PHASE_MASK, PHASE_FORWARD, PHASE_BACKWARD, PHASE_ADAM = 1, 2, 4, 8
+PART_FIRST, PART_LAST, PART_REDUCE = 1, 2, 4
+MAX_CACHED_GRAPHS = 8
 
 
 class _TrainStepC(C.Structure):
@@ -45,7 +48,8 @@ class GATResTrainer:
                  nodes_per_graph: Optional[Sequence[int]] = None, lr: float = 5e-4, weight_decay: float = 6e-6,
                  betas=(0.9, 0.999), eps: float = 1e-8, mask_rate: float = 0.95, seed: int = 0,
                  process_group=None, use_graph: bool = True, fused: bool = True,
-                 force_collective_path: bool = False, targets_are_inputs: bool = False):
+                 force_collective_path: bool = False, targets_are_inputs: bool = False,
+                 blocks_per_bucket: int = 5, _share_state_with: Optional["GATResTrainer"] = None):
         self.lib = _native.load()
         self.model = model
         params = model.flat_parameters
@@ -60,9 +64,13 @@ class GATResTrainer:
         self.P = params.numel()
         f32 = dict(dtype=torch.float32, device=dev)
         self.grads = torch.zeros(self.P, **f32)
-        self.exp_avg = torch.zeros(self.P, **f32)
-        self.exp_avg_sq = torch.zeros(self.P, **f32)
-        self.step_counter = torch.zeros(2, dtype=torch.int64, device=dev)
+        if _share_state_with is not None:            # a sibling trainer for another batch size: ONE optimizer state
+            self.exp_avg, self.exp_avg_sq = _share_state_with.exp_avg, _share_state_with.exp_avg_sq
+            self.step_counter = _share_state_with.step_counter
+        else:
+            self.exp_avg = torch.zeros(self.P, **f32)
+            self.exp_avg_sq = torch.zeros(self.P, **f32)
+            self.step_counter = torch.zeros(2, dtype=torch.int64, device=dev)
         self.x = torch.zeros(N, **f32)
         # targets_are_inputs: the reference's snapshots have data.y == data.x until the loop masks x (train.py:162-166),
         # and the masking happens inside the kernels here (x itself is never overwritten): one buffer serves both
@@ -77,17 +85,26 @@ class GATResTrainer:
         self.node_ptr = self.plan.node_ptr_for(nodes_per_graph) if nodes_per_graph is not None else None
         self.num_graphs = len(nodes_per_graph) if nodes_per_graph is not None else 0
         self.hparams = dict(lr=lr, weight_decay=weight_decay, beta1=betas[0], beta2=betas[1], eps=eps)
-        self.mask_rate, self.seed = mask_rate, seed
         self.pg = process_group
-        self.world = 1
+        self.world, self.rank = 1, 0
         if process_group is not None or (torch.distributed.is_available() and torch.distributed.is_initialized()):
             self.world = torch.distributed.get_world_size(process_group)
+            self.rank = torch.distributed.get_rank(process_group)
+        # every rank draws its own masks (its shard holds different snapshots): the rank is mixed into the sampler's seed
+        self.mask_rate, self.seed = mask_rate, int(seed) * max(self.world, 1) + self.rank
         # force_collective_path: run the multi-GPU sequence (backward | all-reduce | Adam) even at world size 1
         self.split = force_collective_path or self.world > 1
+        if self.world > 1 and _share_state_with is None:
+            dp.broadcast_params_(params, src=0, group=process_group)      # identical replicas, whatever each rank initialised
+        self.reducer = dp.BucketedAllReduce(self.grads, process_group, force=force_collective_path) if self.split else None
+        self.blocks_per_bucket = int(blocks_per_bucket)
         self.use_graph = use_graph
-        self._graphs = {}
+        self._graphs: "OrderedDict[tuple, torch.cuda.CUDAGraph]" = OrderedDict()
         self._params_ptr = params.data_ptr()
-        self._wt_version = None
+        self._wt_sig = None
+        self._siblings: Dict[int, "GATResTrainer"] = {}
+        off = self.lib.gatres_fused_status_offset(model._cmodel_ref(), self.plan.ref()) if self.fused else -1
+        self._status = self.scratch[off:off + 3].view(torch.int32) if off >= 0 else None
 
     # ------------------------------------------------------------------------------------------
     def _desc(self, phases: int, device_mask: bool, wt_valid: bool = False) -> _TrainStepC:
@@ -105,11 +122,47 @@ class GATResTrainer:
             self.loss.data_ptr(), self.saved.data_ptr(), self.scratch.data_ptr(), h["lr"], h["beta1"], h["beta2"],
             h["eps"], h["weight_decay"], 1.0 / self.world, (0 if self.fused else 1) | (2 if wt_valid else 0))
 
+    def _param_signature(self) -> Tuple[int, int]:
+        """Changes whenever anything wrote to the parameters THROUGH TORCH: the flat vector or any of the nn.Parameters
+        that are views of it (every Parameter has its own version counter: ``load_state_dict``, ``torch.optim`` steps,
+        ``init_`` / ``clip_`` calls bump those, not the flat vector's).  Writes that bypass autograd's bookkeeping
+        (``p.data.mul_()``) are invisible to it: call ``invalidate_weights()`` after such an edit."""
+        return self.model.flat_parameters._version, sum(p._version for p in self.model._param_list)
+
     def _wt_current(self) -> bool:
-        """scratch's transposed conv weights are current: our last fused Adam step wrote them and nothing else has
-        modified the parameter storage since (torch bumps the version counter on every in-place op; our kernels do
-        not go through torch)."""
-        return self._wt_version is not None and self._wt_version == self.model.flat_parameters._version
+        """scratch's transposed conv weights are current: our last fused Adam step wrote them and nothing has modified
+        the parameters since (our kernels do not go through torch, so they leave the signature alone)."""
+        return self._wt_sig is not None and self._wt_sig == self._param_signature()
+
+    def invalidate_weights(self) -> None:
+        """The parameters were edited behind torch's back: re-derive the transposed weights at the next step."""
+        self._wt_sig = None
+
+    def set_lr(self, lr: float) -> None:
+        """Learning-rate schedules (the reference runs ReduceLROnPlateau, train.py:349-350,510).  Hyper-parameters are
+        kernel arguments baked into a captured hipGraph, so the graph cache is keyed by them: a new value captures a
+        new graph (milliseconds, once per distinct value), an old value finds its graph again."""
+        self.hparams["lr"] = float(lr)
+
+    def set_hparams(self, **kw) -> None:
+        for k, v in kw.items():
+            if k == "mask_rate":
+                self.mask_rate = float(v)
+            elif k in self.hparams:
+                self.hparams[k] = float(v)
+            else:
+                raise KeyError(k)
+
+    def _graph_key(self, what, device_mask: bool, wt_valid: bool) -> tuple:
+        h = self.hparams
+        return (what, device_mask, wt_valid, h["lr"], h["weight_decay"], h["beta1"], h["beta2"], h["eps"], self.mask_rate,
+                self.seed, self.world)
+
+    @property
+    def fault_count(self) -> int:
+        """Split launches that gave up waiting for a partner workgroup so far (each cost exactly one dropped step: loss
+        NaN, no update).  Synchronises."""
+        return int(self._status[1].item()) if self._status is not None else 0
 
     def _enqueue(self, phases: int, device_mask: bool, wt_valid: bool = False) -> None:
         ts = self._desc(phases, device_mask, wt_valid)
@@ -120,31 +173,35 @@ class GATResTrainer:
         full = PHASE_BACKWARD | PHASE_ADAM
         wt_valid = self.fused and (phases & PHASE_BACKWARD) != 0 and self._wt_current()
         try:
-            self._run_inner(phases, device_mask, wt_valid)
+            self._replay(self._graph_key(phases, device_mask, wt_valid),
+                         lambda: self._enqueue(phases, device_mask, wt_valid), wt_valid)
         finally:
             # a fused backward + Adam step leaves the transposed weights of the NEW parameters in scratch
             if self.fused and (phases & full) == full:
-                self._wt_version = self.model.flat_parameters._version
+                self._wt_sig = self._param_signature()
 
-    def _run_inner(self, phases: int, device_mask: bool, wt_valid: bool) -> None:
+    def _replay(self, key: tuple, enqueue: Callable[[], None], wt_valid: bool = False) -> None:
+        """Run ``enqueue`` -- eagerly, or captured once into a hipGraph (cached by ``key``) and replayed."""
         if not self.use_graph:
-            self._enqueue(phases, device_mask, wt_valid)
+            enqueue()
             return
-        key = (phases, device_mask, wt_valid)
         g = self._graphs.get(key)
         if g is None:
-            # warm-up launch outside capture (module load, lazy init), then capture the same sequence once
+            # warm-up launch outside capture (module load, lazy init, RCCL communicator), then capture the same sequence
             state = (self.step_counter.clone(), self.model.flat_parameters.clone(), self.exp_avg.clone(),
                      self.exp_avg_sq.clone())
-            self._enqueue(phases, device_mask, wt_valid)
+
+            def rollback():
+                self.step_counter.copy_(state[0]); self.model.flat_parameters.copy_(state[1])
+                self.exp_avg.copy_(state[2]); self.exp_avg_sq.copy_(state[3])
+
+            enqueue()
             torch.cuda.synchronize(self.device)
-            self.step_counter.copy_(state[0]); self.model.flat_parameters.copy_(state[1])
-            self.exp_avg.copy_(state[2]); self.exp_avg_sq.copy_(state[3])
+            rollback()
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
-                self._enqueue(phases, device_mask, wt_valid)
-            self.step_counter.copy_(state[0]); self.model.flat_parameters.copy_(state[1])
-            self.exp_avg.copy_(state[2]); self.exp_avg_sq.copy_(state[3])
+                enqueue()
+            rollback()
             if wt_valid:
                 # the warm-up step left the transposes of ITS updated weights in scratch; the parameters were rolled
                 # back, so make the promise this graph relies on true again
@@ -152,7 +209,47 @@ class GATResTrainer:
                     self.model._cmodel_ref(), self.plan.ref(), self.model.flat_parameters.data_ptr(),
                     self.scratch.data_ptr(), _native.current_stream(self.device)), "gatres_fused_prepare_backward")
             self._graphs[key] = g
+            while len(self._graphs) > MAX_CACHED_GRAPHS:
+                self._graphs.popitem(last=False)
+        else:
+            self._graphs.move_to_end(key)
+        if self.fused:
+            # a captured split launch cannot order itself behind one on another stream (include/gatres.h)
+            _native.check(self.lib.gatres_fused_serialize(_native.current_stream(self.device)), "gatres_fused_serialize")
         g.replay()
+
+    # ---- the multi-rank step: backward pieces | bucketed all-reduce | Adam, as ONE launch sequence / hipGraph ---------
+    def _backward_pieces(self, device_mask: bool, wt_valid: bool):
+        """Pieces for ``dp.run_data_parallel_step``.  Fused path (gatres_small): one piece -- mask, forward, loss and the
+        whole backward are a single launch whose gradient exists only after the slab reduction that ends it.  Per-op
+        path (gatres_large, large graphs): forward, then one piece per ``blocks_per_bucket`` blocks in reverse order,
+        each ending with the slab reduction of exactly its parameters."""
+        if self.fused:
+            def whole():
+                self._enqueue(PHASE_MASK | PHASE_FORWARD | PHASE_BACKWARD, device_mask, wt_valid)
+                return 0, self.P
+            return [whole]
+        m = self.model
+        pieces = []
+        for k, (b_hi, b_lo, lo, hi) in enumerate(dp.block_buckets(m.num_blocks, m.nc, self.blocks_per_bucket)):
+            def piece(k=k, b_hi=b_hi, b_lo=b_lo, lo=lo, hi=hi):
+                if k == 0:
+                    self._enqueue(PHASE_MASK | PHASE_FORWARD, device_mask)
+                flags = PART_REDUCE | (PART_FIRST if b_hi == m.num_blocks else 0) | (PART_LAST if b_lo == 0 else 0)
+                _native.check(self.lib.gatres_model_backward_per_op_part(
+                    m._cmodel_ref(), self.plan.ref(), m.flat_parameters.data_ptr(), self.x.data_ptr(),
+                    self.mask.data_ptr(), self.g_out.data_ptr(), self.saved.data_ptr(), self.scratch.data_ptr(),
+                    self.grads.data_ptr(), None, b_hi, b_lo, flags, _native.current_stream(self.device)),
+                    "gatres_model_backward_per_op_part")
+                return lo, hi
+            pieces.append(piece)
+        return pieces
+
+    def _run_split(self, device_mask: bool) -> None:
+        wt_valid = False         # (the stand-alone Adam launch does not refresh scratch's transposed weights)
+        self._replay(self._graph_key("split", device_mask, wt_valid),
+                     lambda: dp.run_data_parallel_step(self._backward_pieces(device_mask, wt_valid), self.reducer,
+                                                       lambda: self._enqueue(PHASE_ADAM, device_mask)))
 
     # ------------------------------------------------------------------------------------------
     def load_batch(self, x: torch.Tensor, y: torch.Tensor, mask: Optional[torch.Tensor] = None) -> None:
@@ -207,10 +304,7 @@ class GATResTrainer:
         if not self.split:
             self._run(PHASE_MASK | PHASE_FORWARD | PHASE_BACKWARD | PHASE_ADAM, device_mask)
         else:
-            self._run(PHASE_MASK | PHASE_FORWARD | PHASE_BACKWARD, device_mask)
-            if torch.distributed.is_available() and torch.distributed.is_initialized():
-                torch.distributed.all_reduce(self.grads, op=torch.distributed.ReduceOp.SUM, group=self.pg)
-            self._run(PHASE_ADAM, device_mask)
+            self._run_split(device_mask)
 
     def step(self, x: torch.Tensor, y: torch.Tensor, mask: Optional[torch.Tensor] = None) -> torch.Tensor:
         """Reference-shaped call: one iteration of train.py:159-190.  Returns the (device) loss tensor."""
@@ -227,3 +321,56 @@ class GATResTrainer:
     @property
     def optimizer_step(self) -> int:
         return int(self.step_counter[0].item())
+
+    # ---- epoch-level loop (train.py:112-202) ---------------------------------------------------------------------------
+    def _sibling(self, num_graphs: int, nodes_per_graph: int, edge_index: torch.Tensor) -> "GATResTrainer":
+        """Trainer for another batch size of the same dataset (the ragged last batch of an epoch): its own plan and
+        buffers, the SAME model, Adam moments and step counter."""
+        t = self._siblings.get(num_graphs)
+        if t is None:
+            t = GATResTrainer(self.model, edge_index, num_graphs * nodes_per_graph,
+                              nodes_per_graph=[nodes_per_graph] * num_graphs, lr=self.hparams["lr"],
+                              weight_decay=self.hparams["weight_decay"],
+                              betas=(self.hparams["beta1"], self.hparams["beta2"]), eps=self.hparams["eps"],
+                              mask_rate=self.mask_rate, seed=0, process_group=self.pg, use_graph=self.use_graph,
+                              fused=self.fused, force_collective_path=self.split and self.world == 1,
+                              targets_are_inputs=True, blocks_per_bucket=self.blocks_per_bucket,
+                              _share_state_with=self)
+            t.seed = self.seed
+            self._siblings[num_graphs] = t
+        t.hparams, t.mask_rate = dict(self.hparams), self.mask_rate
+        return t
+
+    def fit_epoch(self, store, batch_size: Optional[int] = None, shuffle: bool = True, drop_last: bool = False,
+                  generator: Optional[torch.Generator] = None, metric_fn_dict: Optional[Dict[str, Callable]] = None,
+                  ) -> Tuple[float, Dict[str, float]]:
+        """One epoch over a ``SnapshotStore`` -- the loop of ``train_one_epoch`` (train.py:159-198): shuffled batches, a
+        fresh per-graph mask every batch, one optimisation step each, loss weighted by the batch's graph count.
+        Batches are row gathers of the device-resident store (no host collation, no H2D); a ragged last batch runs on
+        a sibling trainer that shares this one's optimizer state.  Returns ``(mean loss, metrics)``; metrics (the
+        reference's de-normalised per-batch metrics, train.py:179-198) are only computed when ``metric_fn_dict`` is
+        given, since they need a boolean gather per batch.  Under data parallelism every rank passes its own shard of
+        the snapshots (``dp.shard_graphs``)."""
+        npg = store.nodes_per_graph
+        bs = int(batch_size) if batch_size is not None else self.num_graphs
+        if bs != self.num_graphs or npg * bs != self.N:
+            raise ValueError(f"this trainer was built for batches of {self.num_graphs} graphs x {self.N // max(self.num_graphs, 1)} nodes")
+        if self.world > 1:
+            drop_last = True                 # equal graph counts on every rank keep plain gradient averaging exact
+        total = torch.zeros(1, dtype=torch.float32, device=self.device)
+        sums = {k: 0.0 for k in (metric_fn_dict or {})}
+        seen = 0
+        for x, edge_index, ng in store.batches(bs, shuffle=shuffle, drop_last=drop_last, generator=generator):
+            tr = self if ng == bs else self._sibling(ng, npg, edge_index)
+            tr.load_batch(x, x)
+            tr.run_step(device_mask=True)
+            total.add_(tr.loss, alpha=float(ng))
+            if metric_fn_dict:
+                m = tr.mask.bool()
+                p, t = store.descale(tr.out[m]), store.descale(x.reshape(-1)[m])
+                for k, fn in metric_fn_dict.items():
+                    sums[k] += float(fn(p, t)) * ng
+            seen += ng
+        if seen == 0:
+            raise ValueError("the store yielded no batch")
+        return float(total.item()) / seen, {k: v / seen for k, v in sums.items()}

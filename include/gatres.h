@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define GATRES_ABI_VERSION 1
+#define GATRES_ABI_VERSION 2
 
 #define GATRES_E_BADARG      (-1)  /* null pointer, negative size, misaligned pointer            */
 #define GATRES_E_UNSUPPORTED (-2)  /* width not supported by the gfx950 kernels                  */
@@ -70,6 +70,12 @@ typedef struct gatres_graph {
    * the whole segment). */
   int32_t window[3][3];
   int32_t reserved2;
+  /* Node relabelling of the plan (gatres_graph_reorder_host): every array above is built on the RELABELLED graph and
+   * perm[new id] = the caller's node id.  Only the arrays the caller hands over or gets back -- x, y, mask, out, g_out,
+   * g_x -- are indexed through it, inside lin0 / lin1 / the loss, so the nn.Module contract is unchanged.  NULL = identity.
+   * A relabelling permutes nodes, never a row's edge list: inside a destination row the edges keep PyG's order, so every
+   * fp32 sum associates exactly as without it. */
+  const int32_t* perm;
 } gatres_graph_t;
 
 /* Host-side plan builder (runs on the CPU, once per topology).  edge_index_host: int64 [2, E] row-major as
@@ -92,6 +98,12 @@ int gatres_graph_segments_host(const int64_t* edge_index_host, int64_t num_edges
  * edges: out9 = {rows2, gat2, mean2, rows4, gat4, mean4, rows8, gat8, mean8}. */
 int gatres_graph_windows_host(const int64_t* edge_index, int64_t num_edges, int64_t num_nodes, const int32_t* seg_ptr,
                               int32_t num_segments, int32_t* out9);
+
+/* Bandwidth-reducing relabelling (host): reverse Cuthill-McKee inside every segment (nodes never leave their segment, so
+ * seg_ptr stays valid).  perm_new2old_host[new] = old, N entries.  The fused kernels' row windows (above) are what it
+ * shrinks: real .inp junction orders are not locality-preserving (utils/DataLoader.py:28-37 keeps the file order). */
+int gatres_graph_reorder_host(const int64_t* edge_index_host, int64_t num_edges, int64_t num_nodes,
+                              const int32_t* seg_ptr_host, int32_t num_segments, int32_t* perm_new2old_host);
 
 /* 64-bit content hash of an int64 [2,E] DEVICE edge_index (for plan caching); hash_out: device uint64[1],
  * must be zeroed by the caller on the same stream before the call. */
@@ -178,6 +190,11 @@ int gatres_conv_param_grads(const float* h, const float* g_a_src, const float* g
 int gatres_lin0_bwd(const float* g, const float* x, const uint8_t* mask, float* slab_w, float* slab_b,
                     int32_t num_slabs, int64_t slab_stride, int32_t num_nodes, int32_t nc, void* stream);
 
+/* Relabelled plans (gatres_graph_t.perm), per-op path: dst[i] = src[perm[i]] (scatter == 0) or dst[perm[i]] = src[i]. */
+int gatres_permute_f32(const float* src, const int32_t* perm, float* dst, int32_t num_nodes, int32_t scatter,
+                       void* stream);
+int gatres_gather_u8(const uint8_t* src, const int32_t* perm, uint8_t* dst, int32_t num_nodes, void* stream);
+
 /* out[c*rows + r] = in[r*cols + c] for every GATConv weight of the flat parameter vector (see layout below). */
 int gatres_transpose_conv_weights(const float* params, float* wt, int32_t num_blocks, int32_t nc, void* stream);
 
@@ -238,6 +255,20 @@ int gatres_model_backward_per_op(const gatres_model_t* m, const gatres_graph_t* 
                                  const float* x, const uint8_t* mask, const float* g_out, const float* saved,
                                  float* scratch, float* grads, float* g_x, void* stream);
 
+/* One piece of gatres_model_backward_per_op: [lin1 backward] + blocks b_hi-1 .. b_lo + [lin0 backward].  FIRST must
+ * come with b_hi == num_blocks, LAST with b_lo == 0; pieces are issued in that order on one stream.  With REDUCE the
+ * piece ends by summing its slab partials into grads[lo, hi), lo = LAST ? 0 : 2nc + b_lo*(9nc + 4nc^2),
+ * hi = FIRST ? P : 2nc + b_hi*(9nc + 4nc^2) -- final values, so a data-parallel caller can start the all-reduce of that
+ * range while the next piece runs (gradient buckets in reverse block order).  Without REDUCE nothing is summed (the
+ * caller runs gatres_reduce_slabs over the whole vector after the LAST piece, as gatres_model_backward_per_op does). */
+#define GATRES_PART_FIRST  1
+#define GATRES_PART_LAST   2
+#define GATRES_PART_REDUCE 4
+int gatres_model_backward_per_op_part(const gatres_model_t* m, const gatres_graph_t* g, const float* params,
+                                      const float* x, const uint8_t* mask, const float* g_out, const float* saved,
+                                      float* scratch, float* grads, float* g_x, int32_t b_hi, int32_t b_lo,
+                                      int32_t flags, void* stream);
+
 /* --------------------------------------------------------------------------------------------------------
  * Fused per-snapshot path (k_fused.hip): ONE launch carries every segment through the selected phases --
  * GATRES_PHASE_FORWARD (lin0 .. lin1), GATRES_PHASE_LOSS (masked MSE + d loss/d out; needs mask, y) and
@@ -267,6 +298,15 @@ int gatres_fused_window_kernel(const gatres_model_t* m, const gatres_graph_t* g)
 /* Zero the split-segment barrier state inside `scratch` (as in a freshly zeroed buffer).  Only needed after an aborted
  * launch or when the buffer comes from elsewhere; not inside a captured graph that also holds fused launches. */
 int gatres_fused_reset_sync(const gatres_model_t* m, const gatres_graph_t* g, float* scratch, void* stream);
+/* Two split launches must not run concurrently on one device (each needs its whole grid resident).  gatres_fused_run
+ * orders itself behind the previous split launch when the stream changes; a captured launch cannot do that, so call
+ * this on `stream` before REPLAYING a hipGraph that contains fused launches. */
+int gatres_fused_serialize(void* stream);
+/* Float index inside `scratch` of the split-launch status words {uint32 fault (set by a launch whose partner never
+ * arrived; cleared by gatres_fused_finish / the next forward launch's epilogue), uint32 faults seen so far, uint32
+ * internal}; -1 if the fused path does not apply.  A faulted training step is dropped: loss = NaN, gradients = NaN,
+ * no Adam update, no step count. */
+int64_t gatres_fused_status_offset(const gatres_model_t* m, const gatres_graph_t* g);
 /* Diagnostic only: per-stage wall-clock stamps (100 MHz) of segment 0 for the following fused launches. */
 int gatres_fused_set_stamps(uint64_t* stamps, int32_t capacity);
 int gatres_fused_prepare_backward(const gatres_model_t* m, const gatres_graph_t* g, const float* params,

@@ -1,6 +1,10 @@
-"""The N>1 path on CPU: world_size-2 gloo processes, snapshots sharded by graph, ONE all-reduce of the flat gradient.
-The compute inside each rank is the oracle (no GPU here); what is under test is the data-parallel scheme the
-trainer uses on the GPU box: shard assignment, gradient averaging == global-batch gradient, identical replicas."""
+"""The N>1 path on CPU: world_size-2 gloo processes, snapshots sharded by graph, bucketed all-reduce of the flat gradient.
+
+What runs here is the PRODUCT's data-parallel orchestration -- ``dp.run_data_parallel_step`` with ``dp.BucketedAllReduce``
+and the bucket table ``dp.block_buckets``, exactly the objects ``GATResTrainer`` drives its multi-rank step with (there the
+pieces enqueue HIP launches and the collectives are RCCL; here the per-rank compute is the oracle and the backend gloo).
+Checked: shard assignment, parameter broadcast at start, the buckets tile the gradient, averaged gradient == gradient of
+the global batch, replicas stay bit-identical over several steps and follow single-process training on the global batch."""
 import os
 import sys
 
@@ -11,14 +15,63 @@ import torch.distributed as dist
 import torch.multiprocessing as mp
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-NB, NC, B, NODES, PIPES = 2, 8, 4, 40, 47
+NB, NC, B, NODES, PIPES, STEPS = 3, 8, 4, 40, 47, 3
 
 
-def _global_batch(pkg):
+def _global_batches(pkg):
     ei1 = pkg.wdn_synth.make_wdn_topology(NODES, PIPES)
-    snaps = pkg.wdn_synth.make_snapshots(B, NODES, seed=11)
-    mask = pkg.wdn_synth.generate_batch_mask([NODES] * B, 0.9, np.random.RandomState(5))
-    return ei1, snaps, torch.from_numpy(mask)
+    snaps = [pkg.wdn_synth.make_snapshots(B, NODES, seed=11 + s) for s in range(STEPS)]
+    masks = [torch.from_numpy(pkg.wdn_synth.generate_batch_mask([NODES] * B, 0.9, np.random.RandomState(5 + s)))
+             for s in range(STEPS)]
+    return ei1, snaps, masks
+
+
+class _RankStep:
+    """A GATResTrainer-shaped step with the oracle as compute: flat params / grads / Adam moments, backward in pieces."""
+
+    def __init__(self, G, O, flat_params, world):
+        self.G, self.O, self.world = G, O, world
+        self.shapes = O.param_shapes(NB, NC)
+        self.flat = flat_params
+        self.grads = torch.zeros_like(flat_params)
+        self.m, self.v, self.t = torch.zeros_like(flat_params), torch.zeros_like(flat_params), 0
+        self.reducer = G.dp.BucketedAllReduce(self.grads)
+        self.loss = None
+
+    def _unflatten(self):
+        out, off = {}, 0
+        for k, shp in self.shapes.items():
+            n = int(np.prod(shp))
+            out[k] = self.flat[off:off + n].view(shp).clone().requires_grad_(True)
+            off += n
+        return out
+
+    def run(self, x, ei, mask):
+        def backward_all():
+            p = self._unflatten()
+            xin = x.clone(); xin[mask] = 0
+            out = self.O.gatres_forward(p, xin, ei)
+            self.loss = torch.nn.functional.mse_loss(out[mask], x[mask])
+            g = torch.autograd.grad(self.loss, list(p.values()))
+            self.grads.copy_(torch.cat([t.reshape(-1) for t in g]))
+
+        pieces = []
+        for k, (b_hi, b_lo, lo, hi) in enumerate(self.G.dp.block_buckets(NB, NC, 1)):      # one bucket per block
+            def piece(k=k, lo=lo, hi=hi):
+                if k == 0:
+                    backward_all()          # (autograd delivers every gradient at once; the buckets still go out one by one)
+                return lo, hi
+            pieces.append(piece)
+
+        def adam(lr=5e-4, wd=6e-6, b1=0.9, b2=0.999, eps=1e-8):      # gatres_adam_step with grad_scale = 1/world
+            self.t += 1
+            g = self.grads * (1.0 / self.world) + wd * self.flat
+            self.m.mul_(b1).add_(g, alpha=1 - b1)
+            self.v.mul_(b2).addcmul_(g, g, value=1 - b2)
+            denom = self.v.sqrt() / np.sqrt(1 - b2 ** self.t) + eps
+            self.flat.sub_((lr / (1 - b1 ** self.t)) * self.m / denom)
+
+        self.G.dp.run_data_parallel_step(pieces, self.reducer, adam)
 
 
 def _worker(rank, world, port, out_dir):
@@ -28,51 +81,49 @@ def _worker(rank, world, port, out_dir):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     import gnn_pressure_estimation_amd as G
     from oracle import gatres_oracle as O
-    ei1, snaps, mask = _global_batch(G)
+    ei1, snaps, masks = _global_batches(G)
     rows = G.dp.shard_graphs(B, rank, world)
     per = len(rows)
-    x = G.wdn_synth.collate_snapshots(snaps, rows)
     ei = G.wdn_synth.collate_edge_index(ei1, NODES, per)
-    m = mask[rows[0] * NODES:(rows[-1] + 1) * NODES]
-    # replicas: rank 1 starts from different weights on purpose; broadcast must fix that
-    p = O.init_params(NB, NC, seed=1 + 10 * rank)
-    flat = O.flatten(p).clone()
+    # replicas: rank 1 starts from different weights on purpose; the broadcast the trainer does at construction fixes it
+    flat = O.flatten(O.init_params(NB, NC, seed=1 + 10 * rank)).clone()
     G.dp.broadcast_params_(flat)
-    off = 0
-    for k in p:
-        n = p[k].numel(); p[k] = flat[off:off + n].view(p[k].shape).clone(); off += n
-    tr = O.OracleTrainer(p)
-    xin = x.clone(); xin[m] = 0
-    out = O.gatres_forward(tr.params, xin, ei)
-    loss = torch.nn.functional.mse_loss(out[m], x[m])
-    loss.backward()
-    g = tr.flat("grads").clone()
-    G.dp.allreduce_mean_(g)
-    lsum = loss.detach().clone(); dist.all_reduce(lsum)
-    torch.save({"grads": g, "loss": lsum / world, "params": flat}, os.path.join(out_dir, f"r{rank}.pt"))
+    step = _RankStep(G, O, flat, world)
+    first_grads, losses = None, []
+    for s in range(STEPS):
+        x = G.wdn_synth.collate_snapshots(snaps[s], rows)
+        m = masks[s][rows[0] * NODES:(rows[-1] + 1) * NODES]
+        step.run(x, ei, m)
+        if s == 0:
+            first_grads = step.grads.clone() / world
+        l = step.loss.detach().clone(); dist.all_reduce(l); losses.append(float(l) / world)
+    torch.save({"grads0": first_grads, "losses": losses, "params": step.flat.clone()}, os.path.join(out_dir, f"r{rank}.pt"))
     dist.barrier()
     dist.destroy_process_group()
 
 
-def test_two_rank_gradient_average_equals_global_batch(pkg, oracle, tmp_path):
+def test_two_rank_training_equals_global_batch(pkg, oracle, tmp_path):
     world, port = 2, 29500 + os.getpid() % 2000
     mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
     r0, r1 = torch.load(tmp_path / "r0.pt"), torch.load(tmp_path / "r1.pt")
-    assert torch.equal(r0["params"], r1["params"])                       # replicas identical after broadcast
-    assert torch.equal(r0["grads"], r1["grads"])                         # every rank holds the same averaged gradient
-    # single-process global batch
-    ei1, snaps, mask = _global_batch(pkg)
-    x = pkg.wdn_synth.collate_snapshots(snaps, range(B))
+    assert torch.equal(r0["grads0"], r1["grads0"])                       # every rank holds the same averaged gradient
+    assert torch.equal(r0["params"], r1["params"])                       # replicas bit-identical after STEPS updates
+    # single-process training on the global batch (torch.optim.Adam, the reference's optimizer object)
+    ei1, snaps, masks = _global_batches(pkg)
     ei = pkg.wdn_synth.collate_edge_index(ei1, NODES, B)
-    p = oracle.init_params(NB, NC, seed=1)
-    tr = oracle.OracleTrainer(p)
-    xin = x.clone(); xin[mask] = 0
-    out = oracle.gatres_forward(tr.params, xin, ei)
-    loss = torch.nn.functional.mse_loss(out[mask], x[mask])
-    loss.backward()
-    g = tr.flat("grads")
-    assert float((r0["grads"] - g).abs().max() / g.abs().max()) < 1e-5
-    assert abs(float(r0["loss"]) - float(loss)) < 1e-6 * abs(float(loss))
+    tr = oracle.OracleTrainer(oracle.init_params(NB, NC, seed=1))
+    ref_losses = []
+    for s in range(STEPS):
+        x = pkg.wdn_synth.collate_snapshots(snaps[s], range(B))
+        loss, _ = tr.step(x.clone(), x, ei, masks[s])
+        if s == 0:
+            g = tr.flat("grads")
+            assert float((r0["grads0"] - g).abs().max() / g.abs().max()) < 1e-5
+        ref_losses.append(float(loss))
+    for a, b in zip(r0["losses"], ref_losses):
+        assert abs(a - b) < 1e-5 * abs(b)
+    ref = tr.flat("params")
+    assert float((r0["params"] - ref).abs().max()) < 2e-5                # a few ulp of lr-sized updates over 3 steps
 
 
 def test_shard_assignment(pkg):
@@ -80,3 +131,20 @@ def test_shard_assignment(pkg):
     assert len(pkg.dp.shard_graphs(35, 3, 4)) == 8                       # ragged tail dropped: equal shards
     with pytest.raises(ValueError):
         pkg.dp.shard_graphs(8, 2, 2)
+
+
+def test_block_buckets_tile_the_parameter_vector(pkg, lib):
+    """The bucket table must agree with the native layout (include/gatres.h): reverse block order, first bucket carries
+    lin1, last one lin0, ranges tile [0, P) -- for both registry models and for bucket sizes that do not divide nb."""
+    for nb, nc in ((15, 32), (25, 128), (3, 8), (0, 16)):
+        P = lib.gatres_param_count(nb, nc)
+        for per in (1, 2, 5, 7, 100):
+            buckets = pkg.dp.block_buckets(nb, nc, per)
+            assert buckets[0][0] == nb and buckets[-1][1] == 0 and buckets[0][3] == P and buckets[-1][2] == 0
+            for (h0, l0, lo0, hi0), (h1, l1, lo1, hi1) in zip(buckets, buckets[1:]):
+                assert l0 == h1 and lo0 == hi1 and h0 > l0
+            assert sum(hi - lo for _, _, lo, hi in buckets) == P
+    red = pkg.dp.BucketedAllReduce(torch.zeros(10))
+    red.launch(0, 4)
+    with pytest.raises(RuntimeError):
+        red.wait_all()                                                    # a step whose buckets leave a gap is an error
