@@ -6,15 +6,21 @@ GPU: device mask sampling -> x[mask]=0 -> forward -> MSE on masked nodes -> back
 replayed from a hipGraph.  Inputs (several batches, rotated) are resident in HBM before the timed region.
 
   python bench.py --gpus 1 --steps 200 --warmup 20
+  python bench.py --gpus 8                      # starts 8 ranks itself (torch.distributed.run), before any GPU call
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
          bench.py --gpus N --steps K --warmup W
 
-Rank 0 prints ONE JSON line.  Data: synthetic (seeded WDN topology with C-Town's size, N(0,1) pressures,
-PyG-style random-init weights); the reference's C-Town files are not shipped.
+Protocol: W untimed warm-up steps, then `--repeats` (default 5) timed blocks of EXACTLY K steps,
+each bracketed by a barrier + torch.cuda.synchronize() on both sides and reduced with MAX over ranks; `value` and
+`ms_per_step` come from the MEDIAN block, min / max are reported beside it.  Rank 0 prints ONE JSON line.
+Data: synthetic (seeded WDN topology with C-Town's size, N(0,1) pressures, PyG-style random-init weights); the
+reference's C-Town files are not shipped.
 """
 import argparse
 import json
 import os
+import statistics
+import subprocess
 import sys
 import time
 
@@ -22,7 +28,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-import torch  # noqa: E402
+import torch  # noqa: E402   (importing torch does not initialise the GPU)
 
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
 
@@ -58,7 +64,30 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--repeats", type=int, default=5, help="timed blocks of --steps steps; the median block is reported")
+    ap.add_argument("--shuffle-nodes", action="store_true",
+                    help="randomly relabel the nodes of the synthetic topology (a junction order with no locality, as an "
+                         "EPANET file may have): the plan's reverse Cuthill-McKee relabelling has to restore the row windows")
+    ap.add_argument("--from-store", action="store_true",
+                    help="batches come from a device-resident SnapshotStore through GATResTrainer.fit_epoch (shuffled row "
+                         "gathers; the epoch loop of train.py:159-198) instead of pre-collated rotating batches")
+    ap.add_argument("--dtype", default="fp32", choices=["fp32", "bf16"],
+                    help="storage / MFMA type of the projections (bf16: gatres_large per-op path, BASELINE config 3)")
     return ap.parse_args()
+
+
+def self_launch(args):
+    """`bench.py --gpus N` without a launcher: start N ranks with torch.distributed.run as a CHILD process (never exec a
+    process that may have touched the GPU) and hand its output and exit code through."""
+    n_dev = torch.cuda.device_count()                 # (counting devices does not initialise the GPU on this image)
+    if n_dev < args.gpus:
+        raise SystemExit(f"bench.py --gpus {args.gpus}: only {n_dev} GPU(s) visible; refusing to report a smaller job")
+    port = 29400 + os.getpid() % 500
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1")
+    log(f"no WORLD_SIZE in the environment: launching {args.gpus} ranks: {' '.join(cmd)}")
+    raise SystemExit(subprocess.run(cmd, env=env).returncode)
 
 
 # ------------------------------------------------------------------------------------------------------------------
@@ -138,19 +167,49 @@ def algorithmic_bytes_per_step(rows, N, nc, P, S, nb):
     return stages + small, deferred
 
 
+def survey_bytes_per_snapshot(nb, nc, n_g, e_g, s):
+    """SURVEY.md section 8(d), "Algorithmic bytes per unit of work", restated term by term: per training SNAPSHOT, forward +
+    backward, compulsory traffic (gathers at full row width, no cache credit); s = bytes per activation element, index
+    words 4 B; N, E per snapshot, E' = E + N (self loops)."""
+    N, E, Ep = n_g, e_g, e_g + n_g
+
+    def gatconv(F, H, C, concat):
+        HC, D = H * C, (H * C if concat else C)
+        fwd_p = N * F * s + N * HC * s + 2 * N * H * s + F * HC * s
+        fwd_a = 4 * (N + 1) + 4 * Ep + Ep * H * s + N * H * s + Ep * HC * s + N * D * s + Ep * H * s
+        bwd_a = 12 * Ep + 8 * (N + 1) + Ep * HC * s + Ep * D * s + 3 * Ep * H * s + N * D * s + N * HC * s + 2 * N * H * s
+        bwd_p = 2 * (N * HC * s + N * F * s) + 2 * F * HC * s
+        return fwd_p + fwd_a + bwd_a + bwd_p
+
+    conv1, conv2 = gatconv(nc, 2, nc, True), gatconv(2 * nc, 1, nc, False)
+    mean = 2 * (4 * (N + 1) + 4 * E + E * nc * s + 2 * N * nc * s)
+    lin = 6 * (N * s + N * nc * s)
+    return dict(total=nb * (conv1 + conv2 + mean) + lin, conv1=conv1, conv2=conv2, mean_conv=mean, lin0_lin1=lin,
+                inputs=dict(num_blocks=nb, nc=nc, N=N, E=E, E_prime=Ep, bytes_per_element=s, index_bytes=4))
+
+
+# The figure SURVEY.md section 8(d) / BASELINE.md state for the headline config (gatres_small fp32 on a 388-node /
+# 860-edge snapshot).  The formula above evaluates to 51.37 MB; the survey's table says 50.6 MB.  `roofline.achieved`
+# uses the STATED (smaller) figure so that the fraction is never flattered; the formula value rides along.
+SURVEY_STATED_BYTES = {("gatres_small", 388, 860, "fp32"): 50.6e6, ("gatres_large", 388, 860, "bf16"): 163e6}
+
+
 def pmc_traffic(args):
     """HBM-side bytes per fused launch from the committed rocprofv3 --pmc passes (profiles/r01_fused_pmc_raw.json:
     FETCH_SIZE and WRITE_SIZE collected in separate runs of this script, KB per launch; FETCH_SIZE doubled as
     MI355X_MICROARCH.md prescribes for wide coalesced reads on gfx950).  Only for the workload they were taken on."""
-    if args.model != "gatres_small" or args.batch_size != 32 or args.nodes != 388 or args.per_op:
-        return None
-    try:
-        import json
-        with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_fused_pmc_raw.json")) as f:
-            raw = json.load(f)
-        return int((2.0 * raw["FETCH_SIZE"]["mean_counter_value_KB"] + raw["WRITE_SIZE"]["mean_counter_value_KB"]) * 1024)
-    except Exception:
-        return None
+    if args.model != "gatres_small" or args.batch_size != 32 or args.nodes != 388 or args.per_op or args.shuffle_nodes:
+        return None, None
+    for name in ("r02_fused_pmc_raw.json", "r01_fused_pmc_raw.json"):
+        try:
+            with open(os.path.join(ROOT, "profiles", name)) as f:
+                raw = json.load(f)
+            val = int((2.0 * raw["FETCH_SIZE"]["mean_counter_value_KB"] + raw["WRITE_SIZE"]["mean_counter_value_KB"]) * 1024)
+            return val, f"profiles/{name}: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, " \
+                        f"2 x FETCH + WRITE per launch; a committed constant, NOT measured in this run"
+        except Exception:
+            continue
+    return None, None
 
 
 def time_fused(G, trainer, device, reps=50):
@@ -207,39 +266,54 @@ def time_kernels(rows, device, reps=200):
 
 def cpu_baseline(args, nb, nc):
     """The oracle (a torch-CPU restatement of the PyG path; PyG itself is not installable here) timed on the host
-    cores for the same step on the same batch shape."""
+    cores for the same step: at the benchmark's batch size (like for like) and at bs = 8 (BASELINE.json config 1, the
+    reference's own CPU-runnable case).  A bounded sample: about --cpu-seconds of CPU work per leg."""
     from oracle import gatres_oracle as O
     import gnn_pressure_estimation_amd as G
     try:
         avail = len(os.sched_getaffinity(0))
     except AttributeError:
         avail = os.cpu_count() or 1
-    x, y, ei, mask = G.wdn_synth.make_batch(args.batch_size, args.nodes, args.pipes)
-    tr = O.OracleTrainer(O.init_params(nb, nc, seed=3))
-    # These are ~2400 tiny ops per step: an OpenMP team as wide as a 256-thread host makes every one of them
-    # slower, so the thread count is chosen by a short calibration (one step each) and reported as `cores`.
-    cands = sorted({c for c in (8, 16, 32) if c <= avail} or {avail})
-    torch.set_num_threads(cands[0])
-    tr.step(x, y, ei, mask)                           # warm-up (thread pool, autograd graph)
-    best, cores = None, cands[0]
-    for c in cands:
-        torch.set_num_threads(c)
-        t0 = time.perf_counter()
-        tr.step(x, y, ei, mask)
-        dt1 = time.perf_counter() - t0
-        log(f"cpu baseline calibration: {c} threads -> {dt1:.3f} s/step")
-        if best is None or dt1 < best:
-            best, cores = dt1, c
-    torch.set_num_threads(cores)
-    t0, n = time.perf_counter(), 0
-    while n < 3 or (time.perf_counter() - t0 < args.cpu_seconds and n < 50):
-        tr.step(x, y, ei, mask)
-        n += 1
-    dt = time.perf_counter() - t0
-    return dict(value=args.batch_size * n / dt, unit="snapshots/s", cores=cores, kind="port",
-                sample=f"{n} full training steps (mask->fwd->MSE->bwd->Adam) of {args.model} on one "
-                       f"bs={args.batch_size} batch after warm-up, torch {torch.__version__} CPU ops, {cores} threads "
-                       f"(best of {cands} on a host with {avail} hardware threads)")
+
+    def leg(bs, seconds, cores=None):
+        x, y, ei, mask = G.wdn_synth.make_batch(bs, args.nodes, args.pipes)
+        tr = O.OracleTrainer(O.init_params(nb, nc, seed=3))
+        # These are ~2400 tiny ops per step: an OpenMP team as wide as a 256-thread host makes every one of them
+        # slower, so the thread count is chosen by a short calibration (one step each) and reported as `cores`.
+        cands = sorted({c for c in (8, 16, 32) if c <= avail} or {avail})
+        if cores is None:
+            torch.set_num_threads(cands[0])
+            tr.step(x, y, ei, mask)                           # warm-up (thread pool, autograd graph)
+            best = None
+            for c in cands:
+                torch.set_num_threads(c)
+                t0 = time.perf_counter()
+                tr.step(x, y, ei, mask)
+                dt1 = time.perf_counter() - t0
+                log(f"cpu baseline calibration (bs {bs}): {c} threads -> {dt1:.3f} s/step")
+                if best is None or dt1 < best:
+                    best, cores = dt1, c
+        torch.set_num_threads(cores)
+        for _ in range(2):
+            tr.step(x, y, ei, mask)
+        t0, n = time.perf_counter(), 0
+        while n < 5 or (time.perf_counter() - t0 < seconds and n < 200):
+            tr.step(x, y, ei, mask)
+            n += 1
+        dt = time.perf_counter() - t0
+        return bs * n / dt, cores, n, cands
+
+    v, cores, n, cands = leg(args.batch_size, args.cpu_seconds)
+    out = dict(value=v, unit="snapshots/s", cores=cores, kind="port",
+               sample=f"{n} full training steps (mask->fwd->MSE->bwd->Adam) of {args.model} on one "
+                      f"bs={args.batch_size} batch after warm-up, torch {torch.__version__} CPU ops, {cores} threads "
+                      f"(best of {cands} on a host with {avail} hardware threads)")
+    if args.batch_size != 8:
+        v8, c8, n8, _ = leg(8, min(args.cpu_seconds, 8.0))
+        out["config1_bs8"] = dict(value=v8, unit="snapshots/s", cores=c8,
+                                  sample=f"{n8} steps at batch_size=8 (BASELINE.json configs[0]: the reference's own "
+                                         f"CPU case; synthetic C-Town-shaped batch, the oracle standing in for PyG)")
+    return out
 
 
 def drop_in_loop(args, G, model, topo, device, nb, nc):
@@ -288,14 +362,16 @@ def drop_in_loop(args, G, model, topo, device, nb, nc):
 def main():
     args = parse()
     nb, nc = MODELS[args.model]
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        self_launch(args)                                  # (does not return)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py --gpus {args.gpus} but WORLD_SIZE={world}: the job that runs must be the job that is reported")
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    if args.gpus != world and rank == 0 and world > 1:
-        print(f"warning: --gpus {args.gpus} but WORLD_SIZE {world}", file=sys.stderr)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP engine has no CPU path")
     # host-side tensor ops here are tiny (collation, masks): a 256-wide OpenMP team makes each of them ~20 ms
@@ -306,14 +382,23 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29531")
         torch.distributed.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        if torch.distributed.get_world_size() != args.gpus:
+            raise SystemExit(f"{torch.distributed.get_world_size()} ranks joined, --gpus {args.gpus} were asked for")
 
     import gnn_pressure_estimation_amd as G
-    torch.manual_seed(3)                                   # identical replicas on every rank
+    torch.manual_seed(3 + rank)            # replicas start DIFFERENT on purpose: the trainer broadcasts rank 0's parameters
     model = G.GATResMeanConv(name=args.model, num_blocks=nb, nc=nc).to(device)
+    if args.dtype == "bf16":
+        if not hasattr(model, "set_compute_dtype"):
+            raise SystemExit("--dtype bf16: the bf16 projection path is not built in this tree")
+        model.set_compute_dtype("bf16")
     N = args.nodes * args.batch_size
     topo = G.wdn_synth.make_wdn_topology(args.nodes, args.pipes, seed=0)
+    if args.shuffle_nodes:
+        g = torch.Generator().manual_seed(12345)
+        topo = torch.randperm(args.nodes, generator=g)[topo]
     ei = G.wdn_synth.collate_edge_index(topo, args.nodes, args.batch_size).to(device)
-    trainer = G.GATResTrainer(model, ei, N, nodes_per_graph=[args.nodes] * args.batch_size, seed=1000 + rank,
+    trainer = G.GATResTrainer(model, ei, N, nodes_per_graph=[args.nodes] * args.batch_size, seed=1000,
                               use_graph=not args.no_graph, fused=not args.per_op,
                               force_collective_path=args.force_collective_path,
                               targets_are_inputs=True)        # synthetic snapshots: y is x before masking
@@ -322,10 +407,13 @@ def main():
     nbatches = 8
     snaps = G.wdn_synth.make_snapshots(nbatches * args.batch_size, args.nodes, seed=100 + rank).to(device)
     batches = [snaps[i * args.batch_size:(i + 1) * args.batch_size].reshape(-1).contiguous() for i in range(nbatches)]
+    store = None
+    if args.from_store:
+        # one epoch of the store == one timed block of --steps steps
+        store = G.SnapshotStore(G.wdn_synth.make_snapshots(args.steps * args.batch_size, args.nodes, seed=100 + rank),
+                                topo, device=device)
     if args.host_batches:
         batches = [b.cpu().pin_memory() for b in batches]
-
-    if args.host_batches:
         trainer.prefetch_batch(batches[0])
 
     def one_step(i):
@@ -337,59 +425,97 @@ def main():
             trainer.load_batch(b, b)
         trainer.run_step(device_mask=True)
 
+    def fence():
+        torch.cuda.synchronize(device)
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize(device)
+
+    def timed_block(k):
+        fence()
+        t0 = time.perf_counter()
+        if store is not None:
+            trainer.fit_epoch(store, args.batch_size, shuffle=True)
+        else:
+            for i in range(k):
+                one_step(i)
+        fence()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dt], dtype=torch.float64, device=device)
+            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt
+
     log(f"model/trainer ready on {device}; warm-up {args.warmup} steps")
     for i in range(args.warmup):
         one_step(i)
-    torch.cuda.synchronize(device)
-    if world > 1:
-        torch.distributed.barrier()
-    torch.cuda.synchronize(device)
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        one_step(i)
-    torch.cuda.synchronize(device)
-    if world > 1:
-        torch.distributed.barrier()
-    torch.cuda.synchronize(device)
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=device)
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-        dt = float(t.item())
+    times = [timed_block(args.steps) for _ in range(max(1, args.repeats))]
+    dt = statistics.median(times)
     loss = float(trainer.loss.item())
-    log(f"timed {args.steps} steps in {dt:.4f}s, loss {loss:.5f}")
+    log(f"timed {len(times)} x {args.steps} steps: median {dt:.4f}s (min {min(times):.4f}, max {max(times):.4f}), loss {loss:.5f}")
     if not (loss == loss) or loss > 1e6:
-        raise SystemExit(f"training diverged (loss={loss})")
+        raise SystemExit(f"training diverged (loss={loss}; dropped steps: {trainer.fault_count})")
 
-    cus = G._native.load().gatres_fused_cus_per_segment(model._cmodel_ref(), trainer.plan.ref()) if trainer.fused else 0
+    lib = G._native.load()
+    cus = lib.gatres_fused_cus_per_segment(model._cmodel_ref(), trainer.plan.ref()) if trainer.fused else 0
+    window = bool(lib.gatres_fused_window_kernel(model._cmodel_ref(), trainer.plan.ref())) if trainer.fused else False
+    per_snap = lambda t: world * args.batch_size * args.steps / t
     result = {
-        "metric": "train snapshots/sec", "value": world * args.batch_size * args.steps / dt, "unit": "snapshots/s",
+        "metric": "train snapshots/sec", "value": per_snap(dt), "unit": "snapshots/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "bf16" if args.dtype == "bf16" else "f32", "data": "synthetic",
+        "repeats": {"blocks": len(times), "statistic": "median", "ms_per_step_min": min(times) / args.steps * 1e3,
+                    "ms_per_step_max": max(times) / args.steps * 1e3, "value_min": per_snap(max(times)),
+                    "value_max": per_snap(min(times))},
         "config": {"workload": f"{args.model} ({nb} blocks, nc={nc}), C-Town-sized WDN ({args.nodes} nodes, "
-                               f"{2 * args.pipes} directed edges), batch_size={args.batch_size} per GPU, fp32, "
-                               f"full training step (device mask 0.95 -> fwd -> masked MSE -> bwd -> Adam), "
-                               f"{'per-op kernels' if not trainer.fused else f'fused per-snapshot kernel ({cus} CUs per snapshot)'}, "
-                               f"{'eager launches' if args.no_graph else 'hipGraph replay'}",
+                               f"{2 * args.pipes} directed edges{', randomly relabelled nodes' if args.shuffle_nodes else ''}), "
+                               f"batch_size={args.batch_size} per GPU, {args.dtype}, "
+                               f"full training step (device mask 0.95 -> fwd -> masked MSE -> bwd -> "
+                               f"{'RCCL all-reduce -> ' if trainer.split else ''}Adam), "
+                               f"{'per-op kernels' if not trainer.fused else f'fused per-snapshot kernel ({cus} CUs per snapshot, ' + ('row-window' if window else 'whole-segment') + ' tables)'}, "
+                               f"{'eager launches' if args.no_graph else 'hipGraph replay'}"
+                               f"{', batches from SnapshotStore.fit_epoch' if store is not None else ''}",
                    "global_batch": world * args.batch_size, "parallelism": f"dp{world}",
-                   "final_loss": loss},
+                   "plan_relabelled": trainer.plan.perm_host is not None, "row_window_4parts": trainer.plan.windows[3],
+                   "dropped_steps": trainer.fault_count, "final_loss": loss},
     }
 
     if rank == 0 and not args.no_roofline:
+        sb = survey_bytes_per_snapshot(nb, nc, args.nodes, 2 * args.pipes, 2 if args.dtype == "bf16" else 4)
+        stated = SURVEY_STATED_BYTES.get((args.model, args.nodes, 2 * args.pipes, args.dtype))
+        unit_bytes = stated if stated is not None else sb["total"]
         table = kernel_table(G, model, trainer.plan, nc)
         if trainer.fused:
             log("timing the fused per-snapshot kernel ...")
-            nbytes, nbytes_pg = algorithmic_bytes_per_step(table, N, nc, trainer.P, trainer.plan.num_segments, nb)
+            nbytes_model, nbytes_pg = algorithmic_bytes_per_step(table, N, nc, trainer.P, trainer.plan.num_segments, nb)
             us, us_pg = time_fused(G, trainer, device)
             inline_pg = us_pg < 10.0         # a no-op call: the deferred gradients ran on consumer workgroups of the same launch
             if inline_pg:
-                nbytes += nbytes_pg
-            result["roofline"] = {"bound": "hbm", "kernel": "gatres_window_kernel / gatres_fused_kernel (forward+loss+backward, "
-                                                                     "one launch)",
-                                  "achieved": nbytes / us * 1e-3, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                  "frac": nbytes / us * 1e-3 / HBM_PEAK_GBS, "traffic": pmc_traffic(args),
+                nbytes_model += nbytes_pg
+            # achieved = algorithmic bytes per snapshot x snapshots per launch / the launch's duration.  The
+            # survey's per-snapshot figure covers the whole step; when the deferred parameter gradients run as a second
+            # launch their time is added (one "launch" = everything that carries the snapshot's forward + backward).
+            us_all = us + (0.0 if inline_pg else us_pg)
+            nbytes = unit_bytes * args.batch_size
+            traffic, traffic_source = pmc_traffic(args)
+            result["roofline"] = {"bound": "hbm", "kernel": ("gatres_window_kernel" if window else "gatres_fused_kernel") +
+                                                            " (forward + loss + backward, one launch)",
+                                  "achieved": nbytes / us_all * 1e-3, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                  "frac": nbytes / us_all * 1e-3 / HBM_PEAK_GBS, "traffic": traffic,
+                                  "traffic_source": traffic_source,
                                   "avg_launch_us": us, "algorithmic_bytes_per_launch": nbytes,
-                                  "algorithmic_bytes_per_snapshot": nbytes / args.batch_size,
+                                  "algorithmic_bytes_per_snapshot": unit_bytes,
+                                  "bytes_per_snapshot_source": ("SURVEY.md 8(d) / BASELINE.md stated figure" if stated is not None
+                                                                else "SURVEY.md 8(d) formula"),
+                                  "survey_formula": sb,
+                                  "frac_with_formula_bytes": sb["total"] * args.batch_size / us_all * 1e-3 / HBM_PEAK_GBS,
+                                  "frac_of_step_time": unit_bytes * args.batch_size / (dt / args.steps * 1e6) * 1e-3 / HBM_PEAK_GBS,
+                                  "per_op_byte_model": {"algorithmic_bytes_per_launch": nbytes_model,
+                                                        "frac": nbytes_model / us * 1e-3 / HBM_PEAK_GBS,
+                                                        "note": "round-1 accounting (slab partials, index reads, per-op "
+                                                                "intermediates): fatter than SURVEY 8(d); kept for comparison only"},
                                   "second_kernel": None if inline_pg else
                                   {"kernel": "param_grads_kernel (deferred dW / att gradients)",
                                    "avg_launch_us": us_pg, "algorithmic_bytes_per_launch": nbytes_pg,
@@ -402,8 +528,10 @@ def main():
             dom = max(rows, key=lambda r: r["step_share_us"])
             result["roofline"] = {"bound": "hbm", "kernel": dom["kernel"], "achieved": dom["gbs"],
                                   "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": dom["gbs"] / HBM_PEAK_GBS,
-                                  "traffic": None, "avg_launch_us": dom["avg_us"],
-                                  "algorithmic_bytes_per_launch": dom["algorithmic_bytes"]}
+                                  "traffic": None, "traffic_source": None, "avg_launch_us": dom["avg_us"],
+                                  "algorithmic_bytes_per_launch": dom["algorithmic_bytes"],
+                                  "algorithmic_bytes_per_snapshot": unit_bytes, "survey_formula": sb,
+                                  "frac_of_step_time": unit_bytes * args.batch_size / (dt / args.steps * 1e6) * 1e-3 / HBM_PEAK_GBS}
             result["kernels"] = [{k: (round(v, 3) if isinstance(v, float) else v) for k, v in r.items()} for r in rows]
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(args, nb, nc)

@@ -18,6 +18,9 @@ struct Layout {
       sc_ge2, sc_gad2, sc_gas2, sc_gh2, sc_slabs, sc_loss_part, scratch_total;
   // per-op path of a relabelled plan: plan-order copies of x, mask (bytes), out, g_out, g_x
   int64_t sc_px, sc_pmask, sc_pout, sc_pgout, sc_pgx;
+  // window kernel, split segments: tagged 8-byte granules {value, epoch} through which the parts of a segment hand each
+  // other the rows / edge values their neighbours need (k_fused.hip: xch_*), one region per segment
+  int64_t sc_xch, xch_stride;        // in floats (a granule = 2 floats)
   // fused path only: every block keeps its g_h / g_alpha tables until the deferred parameter-gradient launch
   // (k_fused.hip: param_grads_kernel) has consumed them.  Block-major, global node index.
   int64_t sc_keep, keep_stride, k_gh1, k_gh2, k_gas1, k_gad1, k_gas2, k_gad2;
@@ -54,8 +57,32 @@ static inline int split_max_for(int num_segments) {
 }
 
 // fused_nodes: the plan's largest segment if the fused per-snapshot path can take it (fused_nodes_of), else 0
+// Granule exchange regions of one segment (offsets in granules; mn / me: the plan's largest segment in rows / GATConv
+// edges).  Row tables are indexed [local row][feature], edge tables [local edge][head]; one table per exchange point,
+// so a cell is rewritten only six exchanges later.  hb: one heartbeat granule per (exchange point, part).
+struct XchLayout {
+  int64_t f1h, f1a, f2h, f2a, f3, b1, b2y, b2e, b3o, b3e, hb, total;
+};
+static inline __host__ __device__ XchLayout make_xch_layout(int nc, int64_t mn, int64_t me) {
+  XchLayout X;
+  int64_t o = 0;
+  X.f1h = o; o += mn * 2 * nc;
+  X.f1a = o; o += mn * 2;
+  X.f2h = o; o += mn * nc;
+  X.f2a = o; o += mn;
+  X.f3 = o;  o += mn * nc;
+  X.b1 = o;  o += mn * nc;
+  X.b2y = o; o += mn * nc;
+  X.b2e = o; o += me;
+  X.b3o = o; o += mn * 2 * nc;
+  X.b3e = o; o += me * 2;
+  X.hb = o;  o += 6 * 8;
+  X.total = (o + 15) & ~(int64_t)15;
+  return X;
+}
+
 static inline bool make_layout(const gatres_model_t* m, int64_t N, int64_t Eg, int num_segments, int fused_nodes,
-                               Layout* L) {
+                               int fused_edges, Layout* L) {
   if (!m || m->num_blocks < 0 || N <= 0 || Eg < 0) return false;
   const int nc = m->nc, nb = m->num_blocks;
   if (nc < 4 || nc > 128 || !gatres_is_pow2(nc)) return false;
@@ -126,6 +153,13 @@ static inline bool make_layout(const gatres_model_t* m, int64_t N, int64_t Eg, i
   L->sc_part_slabs = o + L->flag_words + L->ready_words;
   if (fused_nodes > 0) o += L->flag_words + L->ready_words;
   if (L->split_max > 1) o += (int64_t)num_segments * L->split_max * L->slab_stride;
+  L->sc_xch = o;
+  L->xch_stride = 0;
+  if (L->split_max > 1 && nc <= 32) {       // (the window kernel only exists for nc <= 32)
+    const XchLayout X = make_xch_layout(nc, fused_nodes, fused_edges);
+    L->xch_stride = 2 * X.total;
+    o += (int64_t)num_segments * L->xch_stride;
+  }
   L->sc_px = o;    o += r4(N);
   L->sc_pmask = o; o += r4((N + 3) / 4);
   L->sc_pout = o;  o += r4(N);
@@ -140,7 +174,8 @@ static inline int fused_nodes_of(const gatres_graph_t* g) {
              ? g->max_segment_nodes : 0;
 }
 static inline bool make_layout_g(const gatres_model_t* m, const gatres_graph_t* g, Layout* L) {
-  return g && make_layout(m, g->num_nodes, g->num_edges_gat, g->num_segments, fused_nodes_of(g), L);
+  return g && make_layout(m, g->num_nodes, g->num_edges_gat, g->num_segments, fused_nodes_of(g),
+                          g->max_segment_edges_gat, L);
 }
 
 

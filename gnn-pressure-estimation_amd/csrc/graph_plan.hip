@@ -135,6 +135,7 @@ extern "C" int gatres_graph_segments_host(const int64_t* ei, int64_t E, int64_t 
 // SimpleConv edges, over all segments and parts.
 extern "C" int gatres_graph_windows_host(const int64_t* ei, int64_t E, int64_t N, const int32_t* seg_ptr,
                                          int32_t num_segments, int32_t* out9) {
+  // (out9 holds 12 entries: the nine window figures, then the halo sizes for 2 / 4 / 8 parts)
   if ((!ei && E > 0) || !seg_ptr || !out9 || num_segments <= 0 || N <= 0 || E < 0) return GATRES_E_BADARG;
   std::vector<int32_t> seg_of(N);
   for (int32_t s = 0; s < num_segments; ++s)
@@ -149,6 +150,7 @@ extern "C" int gatres_graph_windows_host(const int64_t* ei, int64_t E, int64_t N
   for (int k = 0; k < 3; ++k) {
     const int M = Ms[k];
     std::vector<int32_t> wlo((size_t)num_segments * M), whi((size_t)num_segments * M);
+    std::vector<int32_t> hin((size_t)num_segments * M, 0), hout((size_t)num_segments * M, 0);   // remote in- / out-edges
     auto bound = [&](int32_t s, int p) {
       const int32_t n = seg_ptr[s + 1] - seg_ptr[s], tiles = (n + 15) / 16;
       const int64_t b = 16 * ((int64_t)tiles * p / M);
@@ -169,6 +171,8 @@ extern "C" int gatres_graph_windows_host(const int64_t* ei, int64_t E, int64_t N
       const int32_t ra = (int32_t)(a - seg_ptr[s]), rb = (int32_t)(b - seg_ptr[s]);
       const int pa = part_of(s, ra), pb = part_of(s, rb);
       if (pa == pb) continue;
+      hout[(size_t)s * M + pa]++;                   // edge a -> b: an out-edge of a's part, an in-edge of b's part
+      hin[(size_t)s * M + pb]++;
       int32_t& la = wlo[(size_t)s * M + pa]; int32_t& ha = whi[(size_t)s * M + pa];
       int32_t& lb = wlo[(size_t)s * M + pb]; int32_t& hb = whi[(size_t)s * M + pb];
       if (rb < la) la = rb;
@@ -187,6 +191,9 @@ extern "C" int gatres_graph_windows_host(const int64_t* ei, int64_t E, int64_t N
     out9[3 * k + 0] = (int32_t)mr;
     out9[3 * k + 1] = (int32_t)(mg > INT32_MAX ? INT32_MAX : mg);
     out9[3 * k + 2] = (int32_t)(mm > INT32_MAX ? INT32_MAX : mm);
+    int32_t mh = 0;
+    for (size_t i = 0; i < hin.size(); ++i) mh = std::max(mh, std::max(hin[i], hout[i]));
+    out9[9 + k] = mh;
   }
   return 0;
 }

@@ -61,6 +61,8 @@ struct FusedArgs {
   int no_halo;              // diagnostic (GATRES_FUSED_NO_HALO=1): always take the bulk-pull fallback
   int C;                    // consumer workgroups per segment (deferred parameter gradients on spare CUs), 0 = none
   unsigned* ready;          // [segment][4] lines: items published by the segment's part 0 for each consumer
+  unsigned long long* xch;  // window kernel: granule exchange regions, one per segment (Layout::sc_xch)
+  XchLayout XL;
   Layout L;
   SegLayout SL;             // segment-major saved activations (training)
   int phases;               // GATRES_PHASE_FORWARD | _BACKWARD, bit 16: loss
@@ -1243,7 +1245,9 @@ __device__ __forceinline__ int build_halo(const u16* ptr, const u16* idx, const 
     }
   }
   __syncthreads();
-  return *counter;
+  const int total = *counter;
+  __syncthreads();               // (the caller may reuse the counter at once)
+  return total;
 }
 template <int W, int THREADS>
 __device__ __forceinline__ void pull_list_rows(float* dst, const float* src, const u16* list, int cnt) {
@@ -1262,6 +1266,125 @@ __device__ __forceinline__ void pull_list_small(float* dst, const float* src, co
   }
 }
 
+// ------------------------------------------------------------------------------------------ granule exchange
+// Window kernel: the parts of a split segment hand each other halo rows as tagged 8-byte GRANULES {value, epoch}
+// (cdna_hip_programming.md Guideline 16, form R2: "the data IS the flag").  The producer stores a granule with one
+// relaxed agent-scope 8-byte store (sc1: write-through, visible wherever the consumer runs); the consumer re-reads its
+// granules with relaxed agent-scope loads (sc1: never served from its L1) until every tag equals the epoch of THIS
+// exchange.  No flag, no fence, no cache invalidate, no store drain in front of the hand-off: one memory round trip
+// instead of the drain -> flag -> poll -> invalidate -> pull chain of group_sync (2.2 us -> ~1 us per exchange, six
+// exchanges per block).  Placement-independent: nothing relies on the parts sharing an XCD.
+//   * one table per exchange point (XchLayout), indexed by the segment's local row / edge id, so a cell is rewritten only
+//     six exchanges later; the HEARTBEAT granules (one per point and part, swept by every part at every exchange) keep
+//     the parts within one exchange of each other, so a cell is never rewritten before its readers are done, whatever
+//     the graph looks like (a directed edge list may make the data dependencies one-sided);
+//   * epochs count exchanges and persist in the segment's flag lines across launches (word 2 of the part's line); every
+//     part passes the same number of exchanges per launch;
+//   * a producer that never delivers ends the sweep after SPIN_LIMIT rounds with the error word set (results poisoned,
+//     the step dropped by gatres_fused_finish), never a hang.
+typedef unsigned long long u64;
+__device__ __forceinline__ void gran_store(u64* p, float v, unsigned tag) {
+  __hip_atomic_store(p, ((u64)tag << 32) | (u64)__float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ u64 gran_load(u64* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+struct Xch {
+  u64* base;            // this segment's region
+  u64* base_hb;         // its heartbeat granules [6 points][8 parts]
+  unsigned ep;          // epoch of the current exchange
+  int M, part;
+  int* err;
+  bool dead;
+};
+
+// table[(idx)*W + c] of every listed row / edge -> granules.  src: LDS table addressed by the same index.
+template <int W, int THREADS>
+__device__ __forceinline__ void xch_export(const Xch& x, const u16* list, int cnt, const float* src, u64* dst) {
+  for (int k = threadIdx.x; k < cnt * W; k += THREADS) {
+    const int o = (int)list[k / W] * W + (k % W);
+    gran_store(dst + o, src[o], x.ep);
+  }
+}
+
+// granules of every listed row / edge -> table, re-read until their tags carry this exchange's epoch
+template <int W, int THREADS>
+__device__ __forceinline__ void xch_import(Xch& x, const u16* list, int cnt, u64* src, float* dst) {
+  constexpr int U = 2;
+  const int total = cnt * W;
+  for (int base = 0; base < total; base += U * THREADS) {
+    int o[U];
+    bool valid[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int k = base + u * THREADS + (int)threadIdx.x;
+      valid[u] = k < total;
+      o[u] = valid[u] ? (int)list[k / W] * W + (k % W) : 0;
+    }
+    if (!__any(valid[0])) continue;                                   // (wave-uniform)
+    u64 v[U];
+    int spin = 0;
+    for (;;) {
+      bool ok = true;
+#pragma unroll
+      for (int u = 0; u < U; ++u) v[u] = valid[u] ? gran_load(src + o[u]) : ((u64)x.ep << 32);
+#pragma unroll
+      for (int u = 0; u < U; ++u) ok = ok && (unsigned)(v[u] >> 32) == x.ep;
+      if (__all(ok || x.dead)) break;
+      if (++spin > SPIN_LIMIT) { *x.err = 1; x.dead = true; }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+      if (valid[u]) dst[o[u]] = __uint_as_float((unsigned)v[u]);
+  }
+}
+
+// Every exchange: announce this part's arrival and wait for every other part's (keeps the parts in lockstep, see above);
+// then EVERY wave drains its own outstanding global stores -- the sweeping waves did so while waiting for their loads,
+// the others wait here, beside them -- so that after the barrier that follows the exchange all stores issued before it
+// (saved activations, kept gradient tables) are complete: publish_items relies on that.
+template <int THREADS>
+__device__ __forceinline__ void xch_heartbeat(Xch& x, int point) {
+  u64* hb = x.base_hb + point * 8;
+  if (threadIdx.x == 0) gran_store(hb + x.part, 0.f, x.ep);
+  const int lane = (int)threadIdx.x - (THREADS - 64);                 // the last wave polls: lanes 0 .. M-1, one part each
+  if (lane >= 0) {
+    const bool mine = lane < x.M && lane != x.part;
+    int spin = 0;
+    for (;;) {
+      const bool ok = !mine || x.dead || (unsigned)(gran_load(hb + lane) >> 32) == x.ep;
+      if (__all(ok)) break;
+      if (++spin > SPIN_LIMIT) { *x.err = 1; x.dead = true; }
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+// own rows with an out-edge to (FWD: a destination) / an in-edge from (BWD: a source) outside [lo, hi): the rows whose
+// values some partner's halo list names.  ptr / idx: global CSR arrays of the relevant direction; no duplicates.
+template <int THREADS>
+__device__ __forceinline__ int build_export_rows(const int* __restrict__ ptr, const int* __restrict__ idx, int n0, Rows rw,
+                                                 u16* list, int cap, int* counter) {
+  if (threadIdx.x == 0) *counter = 0;
+  __syncthreads();
+  for (int r = rw.lo + threadIdx.x; r < rw.hi; r += THREADS) {
+    bool remote = false;
+    for (int t = ptr[n0 + r]; t < ptr[n0 + r + 1]; ++t) {
+      const int j = idx[t] - n0;
+      remote = remote || j < rw.lo || j >= rw.hi;
+    }
+    if (remote) {
+      const int pos = atomicAdd(counter, 1);
+      if (pos < cap) list[pos] = (u16)r;
+    }
+  }
+  __syncthreads();
+  const int total = *counter;
+  __syncthreads();
+  return total;
+}
+
 // Deferred-gradient items of a segment, in production order: item 2*(nb-1-b) is (block b, conv2), the next one
 // (block b, conv1); a split segment adds one last item that folds the lin0 / lin1 partials.  Part 0 publishes the
 // number of finished items after a barrier that all parts have passed; consumer c takes items c, c + C, ...
@@ -1270,16 +1393,19 @@ __device__ __forceinline__ void pull_list_small(float* dst, const float* src, co
 // publication is preceded by an agent-scope release, so a consumer that finds itself anywhere else waits for it,
 // acquires at agent scope and only then works through its items (correct wherever the workgroups were placed).
 constexpr unsigned PUB_COUNT_MASK = 0xffffu, PUB_LOCAL = 1u << 24;
+// EVERY part publishes its own progress (word `part` of each consumer's line): the tables of an item are complete when all
+// M parts have published its number.  Called right after a point where every wave of the workgroup has drained its
+// global stores (group_sync, or the granule import of the window kernel) and a workgroup barrier has been passed.
 template <int THREADS>
 __device__ __forceinline__ void publish_items(const FusedArgs& a, int seg, int part, int count, bool parts_local,
                                               bool last) {
-  if (a.C > 0 && part == 0 && (int)threadIdx.x < 64) {
+  if (a.C > 0 && (int)threadIdx.x < 64) {
     if (last) {
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     if ((int)threadIdx.x < a.C)
-      __hip_atomic_store(a.ready + ((size_t)seg * 4 + threadIdx.x) * FLAG_STRIDE,
+      __hip_atomic_store(a.ready + ((size_t)seg * 4 + threadIdx.x) * FLAG_STRIDE + part,
                          (unsigned)count | (xcc_id() << 16) | (parts_local ? PUB_LOCAL : 0u), __ATOMIC_RELAXED,
                          __HIP_MEMORY_SCOPE_AGENT);
   }
@@ -1294,26 +1420,41 @@ __device__ __forceinline__ void consumer_main(const FusedArgs& a, int cid, float
   ParamGradArgs pg;
   pg.seg_ptr = a.seg_ptr; pg.saved = a.saved; pg.keep = a.scratch + a.L.sc_keep; pg.slabs = a.slabs;
   pg.part_slabs = a.part_slabs; pg.M = a.M; pg.L = a.L; pg.SL = a.SL;
-  unsigned* my = a.ready + ((size_t)seg * 4 + c) * FLAG_STRIDE;
+  unsigned* my = a.ready + ((size_t)seg * 4 + c) * FLAG_STRIDE;       // words 0 .. M-1: one per producing part
   float* part = ldsf;
   float* red = ldsf + (LDS_BYTES / 4 - 3 * THREADS);
   int* mode = reinterpret_cast<int*>(red + 3 * THREADS - 1);   // LDS word: 0 = hand-off through the shared L2, 1 = remote
   const int nb = a.L.nb, items = 2 * nb + (a.M > 1 ? 1 : 0);
   bool dead = false, remote = false;
+  const int lane = threadIdx.x;
+  const unsigned mine_xcc = xcc_id();
   for (int i = c; i < items; i += C) {
     if (threadIdx.x < 64) {
-      if (threadIdx.x == 0 && !dead && !remote) {
+      // lanes 0 .. M-1 poll one part each; the wave leaves the loop together
+      bool need_remote = false;
+      if (!remote) {
         int spin = 0;
-        unsigned w = 0;
-        while ((int)((w = __hip_atomic_load(my, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) & PUB_COUNT_MASK) < i + 1)
-          if (++spin > SPIN_LIMIT) { *a.err = 1; dead = true; break; }
-        if (!dead && (!(w & PUB_LOCAL) || ((w >> 16) & 0xfu) != xcc_id() || a.safe_sync)) {
-          // not behind the producers' L2: wait for the released, final publication
-          remote = true;
-          while ((int)(__hip_atomic_load(my, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & PUB_COUNT_MASK) < items)
-            if (++spin > SPIN_LIMIT) { *a.err = 1; dead = true; break; }
+        for (;;) {
+          unsigned w = PUB_COUNT_MASK;
+          if (lane < a.M && !dead) w = __hip_atomic_load(my + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          const bool ok = lane >= a.M || dead || (int)(w & PUB_COUNT_MASK) >= i + 1;
+          if (ok && lane < a.M && !dead && (!(w & PUB_LOCAL) || ((w >> 16) & 0xfu) != mine_xcc || a.safe_sync))
+            need_remote = true;
+          if (__all(ok)) break;
+          if (++spin > SPIN_LIMIT) { if (lane == 0) *a.err = 1; dead = true; }
         }
-        *mode = remote ? 1 : 0;
+        if (__any(need_remote)) {
+          // not behind every producer's L2: wait for the released, final publications
+          remote = true;
+          int spin2 = 0;
+          for (;;) {
+            unsigned w = PUB_COUNT_MASK;
+            if (lane < a.M && !dead) w = __hip_atomic_load(my + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (__all(lane >= a.M || dead || (int)(w & PUB_COUNT_MASK) >= items)) break;
+            if (++spin2 > SPIN_LIMIT) { if (lane == 0) *a.err = 1; dead = true; }
+          }
+        }
+        if (lane == 0) *mode = remote ? 1 : 0;
       }
       if (threadIdx.x == 0 && remote) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
       else                            asm volatile("buffer_inv sc1" ::: "memory");
@@ -1329,12 +1470,16 @@ __device__ __forceinline__ void consumer_main(const FusedArgs& a, int cid, float
     }
     __syncthreads();
   }
-  if (threadIdx.x == 0) {
-    // reset the line for the next launch -- only after the producer's LAST publication, or that one would survive
+  if (threadIdx.x < 64) {
+    // reset the line for the next launch -- only after every producer's LAST publication, or that one would survive
     int spin = 0;
-    while (!dead && (int)(__hip_atomic_load(my, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & PUB_COUNT_MASK) < items)
-      if (++spin > SPIN_LIMIT) { *a.err = 1; break; }
-    __hip_atomic_store(my, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (;;) {
+      unsigned w = PUB_COUNT_MASK;
+      if (lane < a.M && !dead) w = __hip_atomic_load(my + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (__all(lane >= a.M || dead || (int)(w & PUB_COUNT_MASK) >= items)) break;
+      if (++spin > SPIN_LIMIT) { if (lane == 0) *a.err = 1; dead = true; }
+    }
+    if (lane < a.M) __hip_atomic_store(my + lane, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
 }
 
@@ -1805,15 +1950,16 @@ __device__ __forceinline__ void w_prefetch(float* wl, const float* __restrict__ 
 }
 
 // LDS bytes of the two phases for given maxima (host + device): wr window rows, ow own rows, ge / gm window edges
-__host__ __device__ inline long long win_fwd_bytes(int nc, int wr, int ow, int ge, int gm) {
+// (hl: gatres_graph_t.halo -- the forward phase keeps two u16 lists of up to hl entries, the backward phase four)
+__host__ __device__ inline long long win_fwd_bytes(int nc, int wr, int ow, int ge, int gm, int hl) {
   const long long wlf = 2LL * nc * (2 * nc + 4) + 4 * nc;
   return 4LL * (wr * (3LL * nc + 2) + ow * (3LL * nc + 2)) + 2 * (4 * wlf + 16) + 2LL * (2 * even(ow + 2) + even(ge) + even(gm)) +
-         512;                                                             // + room for a short halo list
+         64 + 4LL * (hl + 4);
 }
-__host__ __device__ inline long long win_bwd_bytes(int nc, int threads, int wr, int ow, int ge, int gm) {
+__host__ __device__ inline long long win_bwd_bytes(int nc, int threads, int wr, int ow, int ge, int gm, int hl) {
   const long long wlf = 2LL * nc * (2 * nc + 4) + 4 * nc;
   return 12LL * threads + 4LL * (wr * (4LL * nc + 2) + ow * (2LL * nc + 4) + 4LL * even(ge)) + 2 * (4 * wlf + 16) +
-         2LL * (3 * even(ow + 2) + 3 * even(ge) + even(wr + 2) + even(gm)) + 512;      // + room for a short halo list
+         2LL * (3 * even(ow + 2) + 3 * even(ge) + even(wr + 2) + even(gm)) + 64 + 8LL * (hl + 4);
 }
 
 // Barrier between two stages of the window kernel whose hand-off goes through LDS only: waits for the wave's LDS
@@ -1852,6 +1998,13 @@ __global__ __launch_bounds__(THREADS) void gatres_window_kernel(const FusedArgs 
   grp.flags = a.flags + (size_t)seg * 8 * FLAG_STRIDE; grp.M = M; grp.part = part; grp.err = a.err;
   group_init<THREADS>(grp);
   if (a.safe_sync) grp.local = false;
+  // granule exchange state of this part (epochs persist in word 2 of the part's flag line)
+  const XchLayout& XL = a.XL;
+  Xch xc;
+  xc.base = a.xch + (size_t)seg * (size_t)(L.xch_stride / 2);
+  xc.base_hb = xc.base + XL.hb;
+  xc.M = M; xc.part = part; xc.err = a.err; xc.dead = false;
+  xc.ep = __hip_atomic_load(grp.flags + part * FLAG_STRIDE + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   // rows per lane group per trip: a part owns ~100 rows, one trip covers them in every stage but conv1's edge dots;
   // more unrolling only costs registers and code (the block loop does not fit the instruction cache as it is)
   constexpr int UF = 1, UB = 1;
@@ -1917,8 +2070,9 @@ __global__ __launch_bounds__(THREADS) void gatres_window_kernel(const FusedArgs 
     u16* mrpo = tp;            tp += even(ow + 1);
     u16* mcolo = tp;           tp += even(oem);
     int* hcounter = reinterpret_cast<int*>(tp);
-    u16* hlist = tp + 2;
-    const int hcap = (int)((lds_raw + LDS_BYTES - reinterpret_cast<unsigned char*>(hlist)) / 2);
+    u16* hlist = tp + 2;                 // import list: remote sources of own in-edges (one entry per edge)
+    const int hcap = max(0, (int)((lds_raw + LDS_BYTES - reinterpret_cast<unsigned char*>(hlist)) / 4));
+    u16* elist = hlist + hcap;           // export list: own rows some partner's row has an in-edge from
     // index-shifted views: absolute local row / relative own-edge indices work unchanged in the stage functions
     float* hA = hAw - wlo * 2 * NC;
     float* hB = hBw - wlo * NC;
@@ -1951,36 +2105,31 @@ __global__ __launch_bounds__(THREADS) void gatres_window_kernel(const FusedArgs 
       }
     }
     __syncthreads();
-    int hcnt = 0;
-    bool halo = false;
-    if (M > 1 && hcap > 0 && !a.no_halo) {
-      hcnt = build_halo<THREADS>(rp, colo, nullptr, rw, hlist, nullptr, hcap, hcounter);
-      halo = hcnt <= hcap;
+    int hcnt = build_halo<THREADS>(rp, colo, nullptr, rw, hlist, nullptr, hcap, hcounter);
+    int ecnt = build_export_rows<THREADS>(a.t_rowptr, a.t_dst, n0, rw, elist, hcap, hcounter);
+    if (hcnt > hcap || ecnt > hcap) {      // (the host sizes the lists from gatres_graph_t.halo: cannot happen with a sane plan)
+      if (tid == 0) *a.err = 1;
+      hcnt = min(hcnt, hcap); ecnt = min(ecnt, hcap);
     }
     STAMP();
     for (int b = 0; b < L.nb; ++b) {
       float* base = segbase + (int64_t)b * SL.bstride;
       float* xnext = segbase + (int64_t)(b + 1) * SL.bstride + SL.xin;
       const float* pb = P + L.p_block0 + (int64_t)b * L.p_block_stride;
-      float* y2g = sc + L.sc_y2;
       // LDS-DMA rides on the MFMA stages (the longest ones; a DMA has to land before its host stage's closing barrier):
       // W2 of this block while proj1 runs, W1 of the next block while proj2 runs
       w_prefetch<2 * NC, NC, EPI_ATT, THREADS>(wlB, pb + L.c2_W, pb + L.c2_as, pb + L.c2_ad, dw0);
       seg_proj<NC, 2 * NC, 2, EPI_ATT, THREADS, true, true>(rw, xA, 0, pb + L.c1_W, base + SL.h1, 0, hA, 0, pb + L.c1_as,
                                                         pb + L.c1_ad, base + SL.as1, base + SL.ad1, 0, sa2, sd2,
                                                         nullptr, 0, nullptr, 0, wlA);
-      group_sync<THREADS>(grp);
-      if (M > 1) {
-        if (__builtin_expect(halo, 1)) {
-          pull_list_rows<2 * NC, THREADS>(hA, base + SL.h1, hlist, hcnt);
-          pull_list_small<2, THREADS>(sa2, base + SL.as1, hlist, hcnt);
-        } else {
-          Rows wv; wv.lo = lo - wlo; wv.hi = rw.hi - wlo;
-          pull_rows4<THREADS>(hAw, base + SL.h1 + (size_t)wlo * 2 * NC, 2 * NC, wv, wr);
-          pull_flat<THREADS>(saw, base + SL.as1 + (size_t)wlo * 2, wv.lo * 2, wv.hi * 2, wr * 2);
-        }
-        lds_barrier();
-      }
+      lds_barrier();                              // own rows of h1 / a_src are in LDS; the saved copies drain meanwhile
+      ++xc.ep;                                    // exchange F1: the gathers below read h1 / a_src of neighbour rows
+      xch_export<2 * NC, THREADS>(xc, elist, ecnt, hA, xc.base + XL.f1h);
+      xch_export<2, THREADS>(xc, elist, ecnt, sa2, xc.base + XL.f1a);
+      xch_import<2 * NC, THREADS>(xc, hlist, hcnt, xc.base + XL.f1h, hA);
+      xch_import<2, THREADS>(xc, hlist, hcnt, xc.base + XL.f1a, sa2);
+      xch_heartbeat<THREADS>(xc, 0);
+      lds_barrier();
       STAMP();
       // K2 conv1: alpha -> HBM + the h2 window's LDS (dead now), then the gather (o1 -> HBM + the x buffer of proj2)
       if (__builtin_expect(2 * oeg <= wr * NC, 1)) {
@@ -2001,44 +2150,36 @@ __global__ __launch_bounds__(THREADS) void gatres_window_kernel(const FusedArgs 
       seg_proj<2 * NC, NC, 1, EPI_ATT, THREADS, true, true>(rw, xB, 0, pb + L.c2_W, base + SL.h2, 0, hB, 0, pb + L.c2_as,
                                                         pb + L.c2_ad, base + SL.as2, base + SL.ad2, 0, sa1, sd1,
                                                         nullptr, 0, nullptr, 0, wlB);
-      group_sync<THREADS>(grp);
-      if (M > 1) {
-        if (__builtin_expect(halo, 1)) {
-          pull_list_rows<NC, THREADS>(hB, base + SL.h2, hlist, hcnt);
-          pull_list_small<1, THREADS>(sa1, base + SL.as2, hlist, hcnt);
-        } else {
-          Rows wv; wv.lo = lo - wlo; wv.hi = rw.hi - wlo;
-          pull_rows4<THREADS>(hBw, base + SL.h2 + (size_t)wlo * NC, NC, wv, wr);
-          pull_flat<THREADS>(saw, base + SL.as2 + (size_t)wlo, wv.lo, wv.hi, wr);
-        }
-        lds_barrier();
-      }
+      lds_barrier();
+      ++xc.ep;                                    // exchange F2
+      xch_export<NC, THREADS>(xc, elist, ecnt, hB, xc.base + XL.f2h);
+      xch_export<1, THREADS>(xc, elist, ecnt, sa1, xc.base + XL.f2a);
+      xch_import<NC, THREADS>(xc, hlist, hcnt, xc.base + XL.f2h, hB);
+      xch_import<1, THREADS>(xc, hlist, hcnt, xc.base + XL.f2a, sa1);
+      xch_heartbeat<THREADS>(xc, 1);
+      lds_barrier();
       STAMP();
-      // K2 conv2: alpha's LDS table in the upper half of the h1 window, y2 in the lower half (+ HBM for the partners)
-      float* y2pub = M > 1 ? y2g : nullptr;
+      // K2 conv2: alpha's LDS table in the upper half of the h1 window, y2 in the lower half
+      float* y2T = hAw - wlo * NC;
       if (__builtin_expect(oeg <= wr * NC, 1)) {
         float* al2L = hAw + (size_t)wr * NC;
         seg_softmax<1, true, THREADS>(rw, rp, colo, sa1, sd1, 0, base + SL.al2, elo, al2L);
         lds_barrier();
-        seg_gather<false, 1, NC, THREADS, UF>(rw, rp, colo, hB, 0, al2L, 0, pb + L.c2_b, hAw - wlo * NC, 0, y2pub, n0);
+        seg_gather<false, 1, NC, THREADS, UF>(rw, rp, colo, hB, 0, al2L, 0, pb + L.c2_b, y2T, 0);
       } else {
         seg_softmax<1, false, THREADS>(rw, rp, colo, sa1, sd1, 0, base + SL.al2, elo, nullptr);
         __syncthreads();
-        seg_gather<false, 1, NC, THREADS, UF>(rw, rp, colo, hB, 0, base + SL.al2, elo, pb + L.c2_b, hAw - wlo * NC, 0,
-                                          y2pub, n0);
+        seg_gather<false, 1, NC, THREADS, UF>(rw, rp, colo, hB, 0, base + SL.al2, elo, pb + L.c2_b, y2T, 0);
       }
-      group_sync<THREADS>(grp);
-      if (M > 1) {
-        if (__builtin_expect(halo, 1)) pull_list_rows<NC, THREADS>(hAw - wlo * NC, y2g + (size_t)n0 * NC, hlist, hcnt);
-        else {
-          Rows wv; wv.lo = lo - wlo; wv.hi = rw.hi - wlo;
-          pull_rows4<THREADS>(hAw, y2g + (size_t)(n0 + wlo) * NC, NC, wv, wr);
-        }
-        lds_barrier();
-      }
+      lds_barrier();
+      ++xc.ep;                                    // exchange F3: K3 averages y2 over neighbour rows
+      xch_export<NC, THREADS>(xc, elist, ecnt, y2T, xc.base + XL.f3);
+      xch_import<NC, THREADS>(xc, hlist, hcnt, xc.base + XL.f3, y2T);
+      xch_heartbeat<THREADS>(xc, 2);
+      lds_barrier();
       STAMP();
       // K3: residual from the x buffer, result back into it (and to HBM: saved xin of the next block)
-      seg_mean_fwd<NC, THREADS, UF>(rw, oem, mrp, mcolo, hAw - wlo * NC, 0, xA, 0, xnext, 0, xA, 0);
+      seg_mean_fwd<NC, THREADS, UF>(rw, oem, mrp, mcolo, y2T, 0, xA, 0, xnext, 0, xA, 0);
       lds_barrier();
       STAMP();
       xcur = xnext;
@@ -2113,9 +2254,11 @@ __global__ __launch_bounds__(THREADS) void gatres_window_kernel(const FusedArgs 
     u16* mtrpo = tp;           tp += even(ow + 1);
     u16* mtdsto = tp;          tp += even(otm);
     int* hcounter = reinterpret_cast<int*>(tp);
-    u16* hrow = tp + 2;
-    const int hcap = (int)((lds_raw + LDS_BYTES - reinterpret_cast<unsigned char*>(hrow)) / 4);
-    u16* hedge = hrow + (hcap > 0 ? hcap : 0);
+    u16* hrow = tp + 2;                  // import lists: remote destinations (+ edge ids) of own out-edges
+    const int hcap = max(0, (int)((lds_raw + LDS_BYTES - reinterpret_cast<unsigned char*>(hrow)) / 8));
+    u16* hedge = hrow + hcap;
+    u16* erow = hedge + hcap;            // export lists: own rows with an in-edge from a partner's row, and those in-edges
+    u16* eedge = erow + hcap;
     __syncthreads();           // forward's LDS contents are dead from here
     copy_rowptr16<THREADS>(rpo, a.rowptr, n0 + lo, ow, e0 + elo);
     copy_idx16<THREADS>(colo, a.col, e0 + elo, oeg, n0);
@@ -2139,7 +2282,7 @@ __global__ __launch_bounds__(THREADS) void gatres_window_kernel(const FusedArgs 
 
     float* gp_cur = sc + L.sc_gpa;
     float* gp_nxt = sc + L.sc_gpb;
-    const bool pub = M > 1;
+    constexpr bool pub = true;           // (the window kernel only runs split segments)
     float* slab = pub ? a.part_slabs + ((int64_t)seg * M + part) * L.slab_stride
                       : a.slabs + (int64_t)seg * L.slab_stride;
     const int64_t w = 2LL * NC * NC;
@@ -2158,11 +2301,22 @@ __global__ __launch_bounds__(THREADS) void gatres_window_kernel(const FusedArgs 
     if (L.nb > 0) dma_conv2(L.nb - 1, 0);
     seg_lin1_bwd<NC, THREADS>(rw, n0, a.perm, a.g_out, xfinal, P + L.p_lin1_w, gp_cur, gpT, slab + L.p_lin1_w,
                               slab + L.p_lin1_b, L.nb > 0 ? 1 : 0, red);
-    int hcnt = 0;
-    bool halo = false;
-    if (pub && hcap > 0 && !a.no_halo) {
-      hcnt = build_halo<THREADS>(trp, tdsto, teido, rw, hrow, hedge, hcap, hcounter);
-      halo = hcnt <= hcap;
+    int hcnt = build_halo<THREADS>(trp, tdsto, teido, rw, hrow, hedge, hcap, hcounter);
+    int ercnt = build_export_rows<THREADS>(a.rowptr, a.col, n0, rw, erow, hcap, hcounter);
+    if (tid == 0) *hcounter = 0;
+    __syncthreads();
+    for (int k = tid; k < oeg; k += THREADS) {                 // own in-edges whose source is a partner's row
+      const int j = colo[k];
+      if (j < lo || j >= rw.hi) {
+        const int pos = atomicAdd(hcounter, 1);
+        if (pos < hcap) eedge[pos] = (u16)(elo + k);
+      }
+    }
+    __syncthreads();
+    int eecnt = *hcounter;
+    if (hcnt > hcap || ercnt > hcap || eecnt > hcap) {
+      if (tid == 0) *a.err = 1;
+      hcnt = min(hcnt, hcap); ercnt = min(ercnt, hcap); eecnt = min(eecnt, hcap);
     }
     STAMP();
     for (int b = L.nb - 1; b >= 0; --b) {
@@ -2172,17 +2326,14 @@ __global__ __launch_bounds__(THREADS) void gatres_window_kernel(const FusedArgs 
       float* sb = slab + po;
       const float* wt1 = a.wt + (int64_t)b * 2 * w;
       const float* wt2 = wt1 + w;
-      group_sync<THREADS>(grp);                  // K3 backward gathers g_pre of neighbours
-      publish_items<THREADS>(a, seg, part, 2 * (L.nb - 1 - b), grp.local || !pub, false);
-      if (pub) {
-        if (__builtin_expect(halo, 1)) pull_list_rows<NC, THREADS>(gpT, gp_cur + (size_t)n0 * NC, hrow, hcnt);
-        else {
-          Rows wv; wv.lo = lo - wlo; wv.hi = rw.hi - wlo;
-          pull_rows4<THREADS>(RAw, gp_cur + (size_t)(n0 + wlo) * NC, NC, wv, wr);
-        }
-        lds_barrier();
-      }
-      seg_mean_bwd<NC, THREADS, UB>(rw, otm, mrp, mtrp, mtdsto, gpT, 0, gy2T, 0, pub ? sc + L.sc_gy2 : nullptr, n0);
+      lds_barrier();                             // own rows of g_pre are in LDS (lin1 backward / the previous dX1)
+      ++xc.ep;                                   // exchange B1: K3 backward gathers g_pre of neighbour rows
+      xch_export<NC, THREADS>(xc, erow, ercnt, gpT, xc.base + XL.b1);
+      xch_import<NC, THREADS>(xc, hrow, hcnt, xc.base + XL.b1, gpT);
+      xch_heartbeat<THREADS>(xc, 3);
+      lds_barrier();
+      publish_items<THREADS>(a, seg, part, 2 * (L.nb - 1 - b), grp.local, false);      // the blocks above are kept
+      seg_mean_bwd<NC, THREADS, UB>(rw, otm, mrp, mtrp, mtdsto, gpT, 0, gy2T, 0);
       lds_barrier();
       STAMP();
       float* keep = sc + L.sc_keep + (int64_t)b * L.keep_stride;
@@ -2191,20 +2342,16 @@ __global__ __launch_bounds__(THREADS) void gatres_window_kernel(const FusedArgs 
       seg_edge_dots<1, NC, THREADS, 1>(rw, 0, rp, colo, gy2T, 0, hT2, ge2 + elo, 0);
       lds_barrier();
       seg_bias_part<NC, THREADS>(rw, gy2T, 0, red);
-      seg_softmax_bwd<1, THREADS>(rw, 0, 0, rp, colo, alT2 + elo, asT2, adT2, ge2 + elo, 0, gad2, 0,
-                                  pub ? sc + L.sc_ge2 : nullptr, e0 + elo, nullptr, 0);
-      group_sync<THREADS>(grp);
-      if (pub) {
-        if (__builtin_expect(halo, 1)) {
-          pull_list_rows<NC, THREADS>(gy2T, sc + L.sc_gy2 + (size_t)n0 * NC, hrow, hcnt);
-          pull_list_small<1, THREADS>(ge2, sc + L.sc_ge2 + e0, hedge, hcnt);
-        } else {
-          Rows wv; wv.lo = lo - wlo; wv.hi = rw.hi - wlo;
-          pull_rows4<THREADS>(RAw + (size_t)wr * NC, sc + L.sc_gy2 + (size_t)(n0 + wlo) * NC, NC, wv, wr);
-          pull_flat<THREADS>(gew, sc + L.sc_ge2 + e0 + ewlo, elo - ewlo, ehi - ewlo, weg);
-        }
-        lds_barrier();
-      }
+      seg_softmax_bwd<1, THREADS>(rw, 0, 0, rp, colo, alT2 + elo, asT2, adT2, ge2 + elo, 0, gad2, 0, nullptr, 0, nullptr,
+                                  0);
+      lds_barrier();
+      ++xc.ep;                                   // exchange B2: the source-major stage reads g_y2 / g_e of neighbour rows
+      xch_export<NC, THREADS>(xc, erow, ercnt, gy2T, xc.base + XL.b2y);
+      xch_export<1, THREADS>(xc, eedge, eecnt, ge2, xc.base + XL.b2e);
+      xch_import<NC, THREADS>(xc, hrow, hcnt, xc.base + XL.b2y, gy2T);
+      xch_import<1, THREADS>(xc, hedge, hcnt, xc.base + XL.b2e, ge2);
+      xch_heartbeat<THREADS>(xc, 4);
+      lds_barrier();
       STAMP();
       seg_bias_finish<NC, THREADS>(red, sb + L.c2_b);
       seg_agg_bwd_src<1, NC, THREADS, UB>(rw, 0, trp, teido, tdsto, gy2T, 0, alT2, ge2, 0, gad2, 0, pb + L.c2_as,
@@ -2217,7 +2364,7 @@ __global__ __launch_bounds__(THREADS) void gatres_window_kernel(const FusedArgs 
       dma_copy4<THREADS>(asTw, base + SL.as1 + wlo * 2, wr * 2, dw0);
       dma_copy4<THREADS>(adTo, base + SL.ad1 + lo * 2, ow * 2, dw0);
       dma_copy4<THREADS>(alTw, base + SL.al1 + ewlo * 2, weg * 2, dw0);
-      seg_proj<NC, 2 * NC, 1, EPI_RESID_MASK, THREADS, true, true>(rw, xG2, 0, wt2, RA, 0, pub ? sc + L.sc_go1 : nullptr, n0,
+      seg_proj<NC, 2 * NC, 1, EPI_RESID_MASK, THREADS, true, true>(rw, xG2, 0, wt2, RA, 0, nullptr, 0,
                                                                nullptr, nullptr, nullptr, nullptr, 0, nullptr, nullptr,
                                                                nullptr, 0, base + SL.o1, 0, wlA);
       __syncthreads();
@@ -2225,21 +2372,17 @@ __global__ __launch_bounds__(THREADS) void gatres_window_kernel(const FusedArgs 
       seg_edge_dots<2, NC, THREADS, 2>(rw, 0, rp, colo, RA, 0, hT1, ge1 + elo * 2, 0);
       lds_barrier();
       seg_bias_part<2 * NC, THREADS>(rw, RA, 0, red);
-      seg_softmax_bwd<2, THREADS>(rw, 0, 0, rp, colo, alT1 + elo * 2, asT1, adT1, ge1 + elo * 2, 0, gad1, 0,
-                                  pub ? sc + L.sc_ge : nullptr, e0 + elo, nullptr, 0);
-      group_sync<THREADS>(grp);
-      publish_items<THREADS>(a, seg, part, 2 * (L.nb - 1 - b) + 1, grp.local || !pub, false);
-      if (pub) {
-        if (__builtin_expect(halo, 1)) {
-          pull_list_rows<2 * NC, THREADS>(RA, sc + L.sc_go1 + (size_t)n0 * 2 * NC, hrow, hcnt);
-          pull_list_small<2, THREADS>(ge1, sc + L.sc_ge + (size_t)e0 * 2, hedge, hcnt);
-        } else {
-          Rows wv; wv.lo = lo - wlo; wv.hi = rw.hi - wlo;
-          pull_rows4<THREADS>(RAw, sc + L.sc_go1 + (size_t)(n0 + wlo) * 2 * NC, 2 * NC, wv, wr);
-          pull_flat<THREADS>(gew, sc + L.sc_ge + (size_t)(e0 + ewlo) * 2, (elo - ewlo) * 2, (ehi - ewlo) * 2, weg * 2);
-        }
-        lds_barrier();
-      }
+      seg_softmax_bwd<2, THREADS>(rw, 0, 0, rp, colo, alT1 + elo * 2, asT1, adT1, ge1 + elo * 2, 0, gad1, 0, nullptr, 0,
+                                  nullptr, 0);
+      lds_barrier();
+      ++xc.ep;                                   // exchange B3
+      xch_export<2 * NC, THREADS>(xc, erow, ercnt, RA, xc.base + XL.b3o);
+      xch_export<2, THREADS>(xc, eedge, eecnt, ge1, xc.base + XL.b3e);
+      xch_import<2 * NC, THREADS>(xc, hrow, hcnt, xc.base + XL.b3o, RA);
+      xch_import<2, THREADS>(xc, hedge, hcnt, xc.base + XL.b3e, ge1);
+      xch_heartbeat<THREADS>(xc, 5);
+      lds_barrier();
+      publish_items<THREADS>(a, seg, part, 2 * (L.nb - 1 - b) + 1, grp.local, false);      // conv2 tables complete
       STAMP();
       seg_bias_finish<2 * NC, THREADS>(red, sb + L.c1_b);
       seg_agg_bwd_src<2, NC, THREADS, UB>(rw, 0, trp, teido, tdsto, RA, 0, alT1, ge1, 0, gad1, 0, pb + L.c1_as,
@@ -2276,6 +2419,7 @@ __global__ __launch_bounds__(THREADS) void gatres_window_kernel(const FusedArgs 
       }
     }
   }
+  if (tid == 0) __hip_atomic_store(grp.flags + part * FLAG_STRIDE + 2, xc.ep, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   if (M > 1 && tid == 0 && *a.err) {
     if ((a.phases & GATRES_PHASE_FORWARD) && a.out) a.out[n0] = NAN;
     if (a.phases & GATRES_PHASE_BACKWARD) a.slabs[(int64_t)seg * L.slab_stride + L.p_lin1_b] = NAN;
@@ -2467,11 +2611,11 @@ static int fused_consumers(const Layout& L, const gatres_graph_t* g, int M) {
 static bool window_kernel_fits(const Layout& L, const gatres_graph_t* g, int M) {
   if (getenv("GATRES_FUSED_NO_WINDOW") || M < 2 || L.nc > 32 || threads_for(L.nc) != 1024) return false;
   const int k = M == 2 ? 0 : (M == 4 ? 1 : 2);
-  const int wr = g->window[k][0], ge = g->window[k][1], gm = g->window[k][2];
-  if (wr <= 0) return false;
+  const int wr = g->window[k][0], ge = g->window[k][1], gm = g->window[k][2], hl = g->halo[k];
+  if (wr <= 0 || L.xch_stride <= 0) return false;
   const int tiles = (g->max_segment_nodes + 15) / 16;
   const int ow = 16 * ((tiles + M - 1) / M);
-  return win_fwd_bytes(L.nc, wr, ow, ge, gm) <= LDS_BYTES && win_bwd_bytes(L.nc, 1024, wr, ow, ge, gm) <= LDS_BYTES &&
+  return win_fwd_bytes(L.nc, wr, ow, ge, gm, hl) <= LDS_BYTES && win_bwd_bytes(L.nc, 1024, wr, ow, ge, gm, hl) <= LDS_BYTES &&
          wr <= 65535 && ge <= 65535 && gm <= 65535;
 }
 static bool use_window_kernel(const FusedArgs& a, const gatres_graph_t* g) {
@@ -2526,6 +2670,10 @@ extern "C" int gatres_fused_reset_sync(const gatres_model_t* m, const gatres_gra
   Layout L;
   if (!make_layout_g(m, g, &L)) return GATRES_E_UNSUPPORTED;
   if (fused_nodes_of(g) == 0) return 0;
+  if (L.xch_stride > 0) {      // granule tags of an aborted run must not meet a restarted epoch count
+    const hipError_t e = hipMemsetAsync(scratch + L.sc_xch, 0, (size_t)g->num_segments * L.xch_stride * 4, gatres_stream(stream));
+    if (e != hipSuccess) return (int)e;
+  }
   return (int)hipMemsetAsync(scratch + L.sc_flags, 0, (size_t)(L.flag_words + L.ready_words) * 4, gatres_stream(stream));
 }
 
@@ -2580,6 +2728,8 @@ extern "C" int gatres_fused_run(const gatres_model_t* m, const gatres_graph_t* g
   a.ready = a.flags + a.L.flag_words;
   a.part_slabs = scratch + a.L.sc_part_slabs;
   a.SL = make_seg_layout(a.L.nb, a.L.nc, g->max_segment_nodes, g->max_segment_edges_gat);
+  a.xch = reinterpret_cast<unsigned long long*>(scratch + a.L.sc_xch);
+  a.XL = make_xch_layout(a.L.nc, g->max_segment_nodes, g->max_segment_edges_gat);
   a.stamps = g_stamps; a.stamp_cap = g_stamp_cap;
   a.phases = (phases & (GATRES_PHASE_FORWARD | GATRES_PHASE_BACKWARD)) | ((phases & GATRES_PHASE_LOSS) ? PH_LOSS : 0);
   hipStream_t st = gatres_stream(stream);

@@ -44,7 +44,7 @@ extern "C" int64_t gatres_scratch_floats(const gatres_model_t* m, const gatres_g
 
 extern "C" int32_t gatres_num_slabs(const gatres_model_t* m, int32_t num_nodes) {
   Layout L;
-  return make_layout(m, num_nodes, 0, 0, 0, &L) ? L.num_slabs : GATRES_E_UNSUPPORTED;
+  return make_layout(m, num_nodes, 0, 0, 0, 0, &L) ? L.num_slabs : GATRES_E_UNSUPPORTED;
 }
 
 extern "C" const char* gatres_version(void) { return "gatres-gfx950 abi1"; }

@@ -76,6 +76,11 @@ typedef struct gatres_graph {
    * A relabelling permutes nodes, never a row's edge list: inside a destination row the edges keep PyG's order, so every
    * fp32 sum associates exactly as without it. */
   const int32_t* perm;
+  /* Split segments: the most edges one part has to a row of ANOTHER part (in- or out-edges of the GATConv graph, whichever
+   * is more), for 2 / 4 / 8 workgroups per segment; from gatres_graph_windows_host.  The window kernel keeps its halo lists
+   * (one entry per such edge) in LDS and is only taken when they fit. */
+  int32_t halo[3];
+  int32_t reserved3;
 } gatres_graph_t;
 
 /* Host-side plan builder (runs on the CPU, once per topology).  edge_index_host: int64 [2, E] row-major as
@@ -95,9 +100,10 @@ int gatres_graph_segments_host(const int64_t* edge_index_host, int64_t num_edges
 
 /* Row windows of split segments (see gatres_graph_t.window): for M = 2, 4, 8 workgroups per segment, the largest
  * contiguous row range a part needs (own rows + the rows adjacent to them), in rows / GATConv edges / SimpleConv
- * edges: out9 = {rows2, gat2, mean2, rows4, gat4, mean4, rows8, gat8, mean8}. */
+ * edges, followed by gatres_graph_t.halo: out12 = {rows2, gat2, mean2, rows4, gat4, mean4, rows8, gat8, mean8, halo2,
+ * halo4, halo8}. */
 int gatres_graph_windows_host(const int64_t* edge_index, int64_t num_edges, int64_t num_nodes, const int32_t* seg_ptr,
-                              int32_t num_segments, int32_t* out9);
+                              int32_t num_segments, int32_t* out12);
 
 /* Bandwidth-reducing relabelling (host): reverse Cuthill-McKee inside every segment (nodes never leave their segment, so
  * seg_ptr stays valid).  perm_new2old_host[new] = old, N entries.  The fused kernels' row windows (above) are what it

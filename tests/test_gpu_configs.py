@@ -1,0 +1,326 @@
+"""BASELINE.json configs 3 and 5 on the GPU (fp32 part), the relabelled-plan path, and the round-2 host features:
+dropped faulted steps, external parameter edits, learning-rate changes under hipGraph replay, two streams, the epoch loop
+over a device SnapshotStore, and the in-graph bucketed all-reduce (RCCL with one rank).
+
+Sizes follow the test strategy of the task: values pinned by the oracle where it finishes in seconds (bs 4 C-Town for
+gatres_large, ONE 50 000-node graph), size-independent properties at BASELINE.json's full sizes (bs 128, batch of 2)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from test_gpu_model import build, ctown_batch, note, relerr      # noqa: E402
+
+
+def _flat_grads(model):
+    return torch.cat([q.grad.reshape(-1) for q in model.parameters()])
+
+
+# ---------------------------------------------------------------------------------------------------- config 3 (fp32)
+def test_gatres_large_ctown_bs128_properties(pkg, oracle):
+    """gatres_large (25 blocks, nc = 128; ConfigModels.py:22-32) at BASELINE config 3's size (C-Town, bs = 128): the
+    properties of test_full_size_properties_bs32, the oracle pinning one graph of the batch."""
+    nb, nc, bs = 25, 128, 128
+    model, p = build(pkg, oracle, nb, nc, seed=3)
+    x, y, ei, mask = ctown_batch(pkg, bs)
+    dx, dei = x.cuda(), ei.cuda()
+    out = model(dx, dei)
+    assert out.shape == (388 * bs, 1) and torch.isfinite(out).all()
+    one = pkg.wdn_synth.make_wdn_topology()
+    first = model(dx[:388], one.cuda())
+    assert torch.equal(out[:388], first)                                        # block-diagonal independence
+    last = model(dx[-388:], one.cuda())
+    assert torch.equal(out[-388:], last)
+    perm = torch.randperm(ei.shape[1], generator=torch.Generator().manual_seed(0))
+    assert relerr(model(dx, ei[:, perm].cuda()), out) < 1e-5                    # edge-order invariance
+    g1, g2 = torch.randn_like(out), torch.randn_like(out)
+
+    def grad_for(g):
+        model.zero_grad()
+        model(dx, dei).backward(g)
+        return _flat_grads(model).clone()
+
+    ga, gb, gab = grad_for(g1), grad_for(g2), grad_for(g1 + 2 * g2)
+    assert torch.isfinite(gab).all() and relerr(gab, ga + 2 * gb) < 1e-4        # backward is linear in the upstream gradient
+    assert torch.equal(grad_for(g1), ga)                                        # and bitwise reproducible
+    ref = oracle.gatres_forward(p, x[:388], one)
+    e = relerr(first, ref)
+    note("gatres_large 25x128 bs128: one graph of the batch vs oracle32", e)
+    assert e < 1e-5
+    # one native training step at full size: finite loss, every parameter moved by at most ~lr
+    before = model.flat_parameters.clone()
+    tr = pkg.GATResTrainer(model, dei, 388 * bs, nodes_per_graph=[388] * bs, use_graph=False)
+    assert not tr.fused                                                         # nc = 128 takes the per-op kernels
+    loss = tr.step(dx.reshape(-1), dx.reshape(-1))
+    assert torch.isfinite(loss).all() and int(tr.mask.sum()) == bs * 368
+    d = (model.flat_parameters - before).abs()
+    assert 0 < float(d.max()) <= 5e-4 * 1.01
+
+
+# ---------------------------------------------------------------------------------------------------- config 5 (fp32)
+@pytest.mark.parametrize("nb,nc", [(15, 32), (3, 128)], ids=["gatres_small", "3x128"])
+def test_50k_node_graph(pkg, oracle, nb, nc):
+    """One 50 000-node / 75 000-pipe WDN (BASELINE config 5's graph): per-op kernels vs the oracle on that single graph
+    (forward, loss, gradients of a training step), then a batch of 2: block-diagonal independence and bitwise repeats."""
+    n, pipes = 50000, 75000
+    one = pkg.wdn_synth.make_wdn_topology(n, pipes, seed=0, max_degree=6)
+    assert one.shape == (2, 2 * pipes) and int(torch.bincount(one[1], minlength=n).max()) <= 6
+    model, p = build(pkg, oracle, nb, nc, seed=7)
+    g = torch.Generator().manual_seed(1)
+    y = torch.randn(n, 1, generator=g)
+    mask = torch.from_numpy(pkg.wdn_synth.generate_batch_mask([n], 0.95, np.random.RandomState(2)))
+    leaves = {k: v.clone().requires_grad_(True) for k, v in p.items()}
+    xin = y.clone(); xin[mask] = 0
+    out_ref = oracle.gatres_forward(leaves, xin, one, num_blocks=nb)
+    loss_ref = torch.nn.functional.mse_loss(out_ref[mask], y[mask])
+    loss_ref.backward()
+    g_ref = torch.cat([v.grad.reshape(-1) for v in leaves.values()])
+    tr = pkg.GATResTrainer(model, one.cuda(), n, nodes_per_graph=[n], use_graph=False)
+    assert not tr.fused and tr.plan.num_segments == 1                           # > 4096 nodes: per-op path
+    tr.forward_backward(y.cuda(), y.cuda(), mask.cuda())
+    e_out, e_loss, e_g = relerr(tr.out, out_ref), relerr(tr.loss, loss_ref), relerr(tr.grads, g_ref)
+    note(f"50k-node graph {nb}x{nc}: out / loss / flat grad rel err vs oracle32", [e_out, e_loss, e_g])
+    assert e_out < 1e-5 and e_loss < 1e-5 and e_g < 1e-4
+    # batch of 2 (what one rank of config 5 holds): snapshots do not interact, results repeat bitwise
+    ei2 = pkg.wdn_synth.collate_edge_index(one, n, 2).cuda()
+    x2 = torch.cat([xin, torch.randn(n, 1, generator=g)]).cuda()
+    with torch.no_grad():
+        o2 = model(x2, ei2)
+        assert torch.equal(o2, model(x2, ei2.clone()))
+        assert torch.equal(o2[:n], model(x2[:n], one.cuda()))
+    assert relerr(o2[:n], out_ref) < 1e-5
+    o = model(x2, ei2)
+    gup = torch.randn(o.shape, generator=torch.Generator().manual_seed(3)).cuda()
+    o.backward(gup)
+    ga = _flat_grads(model).clone()
+    model.zero_grad()
+    model(x2, ei2).backward(gup)
+    assert torch.isfinite(ga).all() and torch.equal(ga, _flat_grads(model))
+
+
+# ---------------------------------------------------------------------------------------------------- relabelled plans
+@pytest.mark.parametrize("fused", [True, False], ids=["fused", "per_op"])
+def test_shuffled_node_order_is_relabelled_and_exact(pkg, oracle, fused):
+    """A C-Town-sized batch whose node ids carry no locality (random relabelling inside every snapshot).  The plan adopts
+    the reverse Cuthill-McKee order, the fused launch takes the window kernel at 4 CUs per snapshot again, and x / mask /
+    out / gradients keep the CALLER's node order: training steps match the oracle run on the shuffled graph itself, and
+    the predictions are bit-identical to the per-op kernels and to the same model on the un-shuffled graph."""
+    nb, nc, bs = 15, 32, 3
+    t1 = pkg.wdn_synth.make_wdn_topology(388, 430, seed=0)
+    rs = np.random.RandomState(11)
+    sigma = torch.from_numpy(np.concatenate([rs.permutation(388) + 388 * k for k in range(bs)]))      # old id -> shuffled id
+    ei0 = pkg.wdn_synth.collate_edge_index(t1, 388, bs)
+    ei = sigma[ei0]
+    N = 388 * bs
+    model, p = build(pkg, oracle, nb, nc, seed=3, fused=fused)
+    tr = pkg.GATResTrainer(model, ei.cuda(), N, nodes_per_graph=[388] * bs, use_graph=False, fused=fused)
+    lib = pkg._native.load()
+    if fused:
+        assert tr.plan.perm_host is not None and tr.plan.windows[3] < 388 // 2
+        assert lib.gatres_fused_cus_per_segment(model._cmodel_ref(), tr.plan.ref()) == 4
+        assert lib.gatres_fused_window_kernel(model._cmodel_ref(), tr.plan.ref()) == 1
+    snaps = pkg.wdn_synth.make_snapshots(2 * bs, 388, seed=4)
+    ref = oracle.OracleTrainer(p)
+    rng = np.random.RandomState(6)
+    for it in range(2):
+        y = pkg.wdn_synth.collate_snapshots(snaps, range(it * bs, (it + 1) * bs))
+        mask = torch.from_numpy(pkg.wdn_synth.generate_batch_mask([388] * bs, 0.95, rng))
+        l_ref, o_ref = ref.step(y.clone(), y, ei, mask)
+        loss = tr.step(y.cuda(), y.cuda(), mask.cuda())
+        assert relerr(tr.out, o_ref) < 1e-5 and relerr(loss, l_ref) < 1e-5, it
+        if it == 0:
+            e = relerr(tr.grads, ref.flat("grads"))
+            note(f"shuffled C-Town batch ({'fused' if fused else 'per-op'}): flat grad rel err vs oracle32", e)
+            assert e < 1e-4
+    # module surface: same model, shuffled vs original labelling -> the same numbers at the corresponding nodes, bitwise
+    m2, _ = build(pkg, oracle, nb, nc, seed=3, fused=fused)
+    x0 = torch.randn(N, 1, generator=torch.Generator().manual_seed(9))
+    xs = torch.empty_like(x0); xs[sigma] = x0                                    # x of shuffled node sigma[i] = x0[i]
+    o_orig = m2(x0.cuda(), ei0.cuda())
+    o_shuf = m2(xs.cuda(), ei.cuda())
+    assert torch.equal(o_shuf[sigma.cuda()], o_orig)
+    o_shuf.backward(torch.ones_like(o_shuf))
+    gs = _flat_grads(m2).clone()
+    m2.zero_grad()
+    m2(x0.cuda(), ei0.cuda()).backward(torch.ones_like(o_orig))
+    assert relerr(gs, _flat_grads(m2)) < 2e-5                                    # (slab partition differs, values do not)
+
+
+# ---------------------------------------------------------------------------------------------------- host features
+def _small_setup(pkg, oracle, nb=3, nc=32, bs=2, seed=31, **kw):
+    ei = pkg.wdn_synth.collate_edge_index(pkg.wdn_synth.make_wdn_topology(), 388, bs).cuda()
+    y = pkg.wdn_synth.collate_snapshots(pkg.wdn_synth.make_snapshots(4, 388, seed=2), range(bs)).cuda()
+    mask = torch.from_numpy(pkg.wdn_synth.generate_batch_mask([388] * bs, 0.95, np.random.RandomState(5))).cuda()
+    model, p = build(pkg, oracle, nb, nc, seed=seed)
+    tr = pkg.GATResTrainer(model, ei, 388 * bs, nodes_per_graph=[388] * bs, **kw)
+    return model, p, tr, ei, y, mask
+
+
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_transient_fault_drops_one_step_only(pkg, oracle, use_graph):
+    """A split launch that gives up waiting for a partner sets the status word.  That step must be DROPPED (loss NaN,
+    parameters / moments / step count untouched), the word cleared and counted, and the next step must be exactly the
+    step a healthy run would have taken -- no manual reset."""
+    model, p, tr, ei, y, mask = _small_setup(pkg, oracle, use_graph=use_graph)
+    if tr._status is None or pkg._native.load().gatres_fused_cus_per_segment(model._cmodel_ref(), tr.plan.ref()) < 2:
+        pytest.skip("snapshots are not split on this device")
+    for _ in range(3):                                       # (both graphs -- transposes skipped / not -- are captured now)
+        tr.step(y, y, mask)
+    before = (model.flat_parameters.clone(), tr.exp_avg.clone(), tr.exp_avg_sq.clone(), tr.optimizer_step)
+    tr._status[0] = 1                                        # what a timed-out poller writes
+    loss = tr.step(y, y, mask)
+    assert torch.isnan(loss).all()
+    assert torch.equal(model.flat_parameters, before[0]) and torch.equal(tr.exp_avg, before[1])
+    assert torch.equal(tr.exp_avg_sq, before[2]) and tr.optimizer_step == before[3]
+    assert int(tr._status[0]) == 0 and tr.fault_count == 1
+    loss2 = tr.step(y, y, mask)
+    twin, _, tr2, *_ = _small_setup(pkg, oracle, use_graph=False)
+    for _ in range(3):
+        tr2.step(y, y, mask)
+    l2 = tr2.step(y, y, mask)
+    assert torch.equal(loss2, l2) and torch.equal(model.flat_parameters, twin.flat_parameters)
+    # forward-only launches clear the word too (and poison their output once)
+    tr._status[0] = 1
+    with torch.no_grad():
+        o = model(y.reshape(-1, 1), ei)
+    assert torch.isnan(o).any() and int(tr._status[0]) == 0 and tr.fault_count == 2
+    with torch.no_grad():
+        assert torch.isfinite(model(y.reshape(-1, 1), ei)).all()
+
+
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_load_state_dict_between_steps_is_noticed(pkg, oracle, use_graph):
+    """every nn.Parameter has its own version counter, so load_state_dict / torch.optim steps never
+    bump the flat vector's.  The trainer's "transposed weights still valid" promise must see them anyway."""
+    model, p, tr, ei, y, mask = _small_setup(pkg, oracle, use_graph=use_graph)
+    for _ in range(3):
+        tr.step(y, y, mask)                                   # transposes are skipped from the second step on
+    fresh, _ = build(pkg, oracle, 3, 32, seed=77)
+    model.load_state_dict(fresh.state_dict())                 # per-parameter copy_: flat._version does not move
+    tr.forward_backward(y, y, mask)
+    g_fb = tr.grads.clone()
+    tr.step(y, y, mask)
+    tr2 = pkg.GATResTrainer(fresh, ei, 388 * 2, nodes_per_graph=[388] * 2, use_graph=False)
+    tr2.forward_backward(y, y, mask)
+    assert relerr(g_fb, tr2.grads) < 1e-6 and relerr(tr.grads, tr2.grads) < 1e-6
+    # an optimizer that writes through the parameters (torch.optim.SGD here) between two native steps
+    opt = torch.optim.SGD(model.parameters(), lr=0.05)
+    for q in model.parameters():
+        q.grad = torch.ones_like(q)
+    opt.step()
+    tr.forward_backward(y, y, mask)
+    twin, _ = build(pkg, oracle, 3, 32, seed=1)
+    with torch.no_grad():
+        twin.flat_parameters.copy_(model.flat_parameters)
+    tr3 = pkg.GATResTrainer(twin, ei, 388 * 2, nodes_per_graph=[388] * 2, use_graph=False)
+    tr3.forward_backward(y, y, mask)
+    assert relerr(tr.grads, tr3.grads) < 1e-6
+
+
+def test_set_lr_under_graph_replay(pkg, oracle):
+    """Hyper-parameters are baked into captured graphs: the cache is keyed by them, so a ReduceLROnPlateau-style change
+    (train.py:349-350) takes effect at the next step and switching back reuses the first graph."""
+    model, p, tr, ei, y, mask = _small_setup(pkg, oracle, use_graph=True)
+    twin, _, tr2, *_ = _small_setup(pkg, oracle, use_graph=False)
+    for lr in (5e-4, 5e-4, 1e-4, 1e-4, 5e-4):
+        tr.set_lr(lr); tr2.set_lr(lr)
+        tr.step(y, y, mask); tr2.step(y, y, mask)
+        assert torch.equal(model.flat_parameters, twin.flat_parameters), lr
+    assert len({k[3] for k in tr._graphs}) == 2               # two learning rates, two families of graphs
+
+
+def test_training_and_evaluation_on_two_streams(pkg, oracle):
+    """Split launches need their whole grid resident, so two of them must never overlap on one device.  Training on one
+    stream and evaluation on another (both split) must serialise behind each other: finite, and equal to running them
+    one after the other on one stream."""
+    nb, nc, bs = 4, 32, 4
+    ei = pkg.wdn_synth.collate_edge_index(pkg.wdn_synth.make_wdn_topology(), 388, bs).cuda()
+    snaps = pkg.wdn_synth.make_snapshots(6 * bs, 388, seed=21).cuda()
+    mask = torch.from_numpy(pkg.wdn_synth.generate_batch_mask([388] * bs, 0.95, np.random.RandomState(1))).cuda()
+    res = []
+    for concurrent in (False, True):
+        mt, _ = build(pkg, oracle, nb, nc, seed=5)
+        me, _ = build(pkg, oracle, nb, nc, seed=6)
+        tr = pkg.GATResTrainer(mt, ei, 388 * bs, nodes_per_graph=[388] * bs, use_graph=True)
+        s_train, s_eval = (torch.cuda.Stream(), torch.cuda.Stream()) if concurrent else (torch.cuda.current_stream(),) * 2
+        torch.cuda.synchronize()
+        outs = []
+        for it in range(6):
+            yb = snaps[it * bs:(it + 1) * bs].reshape(-1)
+            with torch.cuda.stream(s_train):
+                tr.step(yb, yb, mask)
+            with torch.cuda.stream(s_eval), torch.no_grad():
+                outs.append(me(yb.reshape(-1, 1), ei))
+        torch.cuda.synchronize()
+        assert all(torch.isfinite(o).all() for o in outs) and torch.isfinite(tr.loss).all() and tr.fault_count == 0
+        res.append((mt.flat_parameters.clone(), torch.stack(outs)))
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+
+
+def test_snapshot_store_collation_on_device_and_fit_epoch(pkg, oracle):
+    """SURVEY 8(f) rank 2 on the GPU: the store's batches equal the reference collation (device = cuda), and
+    GATResTrainer.fit_epoch (train.py:159-198: shuffled batches, ragged last batch, loss weighted by graph count) equals
+    the same loop written out by hand with the device mask sampler."""
+    one = pkg.wdn_synth.make_wdn_topology()
+    raw = pkg.wdn_synth.make_snapshots(11, 388, seed=3) * 6 + 35
+    st = pkg.SnapshotStore(raw, one, device="cuda")
+    mean, std = float(raw.mean()), float(raw.std(unbiased=False))
+    rows = torch.tensor([3, 0, 7])
+    x = st.batch(rows)
+    assert x.is_cuda and x.shape == (3 * 388, 1)
+    assert torch.allclose(x.cpu(), ((raw[rows] - mean) / (std + 1e-8)).reshape(-1, 1), atol=1e-5)
+    assert torch.equal(st.edge_index(3).cpu(), pkg.wdn_synth.collate_edge_index(one, 388, 3))
+    nb, nc, bs = 3, 32, 4
+    model, _ = build(pkg, oracle, nb, nc, seed=8)
+    tr = pkg.GATResTrainer(model, st.edge_index(bs), 388 * bs, nodes_per_graph=[388] * bs, seed=5, targets_are_inputs=True)
+    fns = pkg.evaluation.get_metric_fn_collection("train")
+    loss, metrics = tr.fit_epoch(st, bs, shuffle=True, generator=torch.Generator().manual_seed(7), metric_fn_dict=fns)
+    assert tr.optimizer_step == 3 and set(metrics) == set(fns) and np.isfinite(loss)      # 4 + 4 + 3 graphs
+    # by hand: same order, same per-batch trainers (a sibling for the ragged batch shares the optimizer state)
+    twin, _ = build(pkg, oracle, nb, nc, seed=8)
+    t4 = pkg.GATResTrainer(twin, st.edge_index(bs), 388 * bs, nodes_per_graph=[388] * bs, seed=5, targets_are_inputs=True)
+    t3 = pkg.GATResTrainer(twin, st.edge_index(3), 388 * 3, nodes_per_graph=[388] * 3, seed=5, targets_are_inputs=True,
+                           _share_state_with=t4)
+    tot, n = 0.0, 0
+    for xb, eib, ng in st.batches(bs, shuffle=True, generator=torch.Generator().manual_seed(7)):
+        t = t4 if ng == bs else t3
+        tot += float(t.step(xb, xb)) * ng
+        n += ng
+    assert n == 11 and abs(loss - tot / n) < 1e-6 * abs(tot / n)
+    assert torch.equal(model.flat_parameters, twin.flat_parameters)
+
+
+def test_bucketed_allreduce_in_graph_rccl_one_rank(pkg, oracle):
+    """The multi-rank step (backward pieces | bucketed RCCL all-reduce | Adam) captured into ONE hipGraph, exercised on
+    a single GPU with a one-rank nccl group: per-op path with one bucket per block (gatres_large's scheme) and the fused
+    path (one bucket) must both reproduce the plain step bit for bit."""
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ["MASTER_PORT"] = str(29600 + os.getpid() % 300)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        bs = 2
+        ei = pkg.wdn_synth.collate_edge_index(pkg.wdn_synth.make_wdn_topology(), 388, bs).cuda()
+        snaps = pkg.wdn_synth.make_snapshots(4 * bs, 388, seed=8).cuda()
+        for nb, nc, fused in ((4, 128, False), (5, 32, True)):
+            res = []
+            for split in (False, True):
+                model, _ = build(pkg, oracle, nb, nc, seed=2, fused=fused)
+                tr = pkg.GATResTrainer(model, ei, 388 * bs, nodes_per_graph=[388] * bs, seed=77, fused=fused,
+                                       force_collective_path=split, blocks_per_bucket=1, use_graph=True)
+                assert tr.split == split and tr.fused == fused
+                if split:
+                    assert tr.reducer.active
+                losses = []
+                for it in range(4):
+                    yb = snaps[it * bs:(it + 1) * bs].reshape(-1)
+                    losses.append(float(tr.step(yb, yb)))
+                if split:
+                    assert len(tr._graphs) == 1                       # the whole step is one captured graph
+                res.append((losses, model.flat_parameters.clone()))
+            assert res[0][0] == res[1][0] and torch.equal(res[0][1], res[1][1]), (nb, nc, fused)
+    finally:
+        dist.destroy_process_group()

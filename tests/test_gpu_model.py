@@ -56,7 +56,7 @@ def ctown_batch(pkg, bs, nodes=388, pipes=430):
 @pytest.mark.parametrize("fused", [True, False], ids=["fused", "per_op"])
 @pytest.mark.parametrize("nb,nc,bs,nodes,pipes", [(2, 8, 3, 40, 47), (15, 32, 2, 388, 430), (3, 128, 2, 60, 70),
                                                    (1, 4, 1, 9, 10), (0, 16, 2, 12, 14), (2, 64, 2, 130, 150),
-                                                   (2, 32, 1, 450, 500)])
+                                                   (2, 32, 1, 450, 500), (25, 128, 4, 388, 430)])
 def test_forward_backward_parity(pkg, oracle, nb, nc, bs, nodes, pipes, fused):
     x, y, ei, mask = ctown_batch(pkg, bs, nodes, pipes)
     model, p = build(pkg, oracle, nb, nc, seed=3, fused=fused)
@@ -93,32 +93,36 @@ def test_forward_backward_parity(pkg, oracle, nb, nc, bs, nodes, pipes, fused):
 
     def judge(g64):
         gscale = max(float(v.abs().max()) for v in g64.values())
-        worst_ratio, worst_rel, bad = 0.0, 0.0, []
+        worst_ratio, worst_rel, bad, kink = 0.0, 0.0, [], True
         for (k, ref), prm in zip(leaves.items(), model.parameters()):
             e_hip = float((prm.grad.double().cpu() - g64[k]).abs().max())
             e_ref = float((ref.grad.double() - g64[k]).abs().max())
-            tol = max(8 * e_ref, 1e-5 * float(g64[k].abs().max()), 2e-6 * gscale)
-            if e_hip > tol:
+            floor = max(1e-5 * float(g64[k].abs().max()), 2e-6 * gscale)
+            if e_hip > max(2 * e_ref, floor):
                 bad.append((k, e_hip, e_ref))
+                # a kink can only excuse a tensor on which the fp32 ORACLE is off its own fp64 gradient as well
+                kink = kink and e_ref > floor
             worst_ratio = max(worst_ratio, e_hip / max(e_ref, 1e-30))
             worst_rel = max(worst_rel, e_hip / gscale)
-        return bad, worst_rel, worst_ratio
+        return bad, worst_rel, worst_ratio, kink
 
     for k, prm in zip(leaves, model.parameters()):
         assert prm.grad is not None and prm.grad.shape == leaves[k].shape, k
     key = (nb, nc, bs, nodes, pipes)
     if key not in _G64_CACHE:
         _G64_CACHE[key] = [grads64(p64)]
-    bad, worst_rel, worst_ratio = judge(_G64_CACHE[key][0])
+    bad, worst_rel, worst_ratio, kink = judge(_G64_CACHE[key][0])
     branch = 0
     gen = torch.Generator().manual_seed(1234)
-    while bad and branch < 8:
+    # the kink fallback fires only where it demonstrably applies: every failing tensor is one on which the fp32 oracle
+    # itself disagrees with its fp64 gradient beyond the tolerance floor (committed runs: never needed, branch 0)
+    while bad and kink and branch < 8:
         branch += 1
         if len(_G64_CACHE[key]) <= branch:
             pert = {k: v * (1 + 1e-7 * torch.randn(v.shape, generator=gen, dtype=torch.float64)) for k, v in p64.items()}
             _G64_CACHE[key].append(grads64(pert))
-        bad, worst_rel, worst_ratio = judge(_G64_CACHE[key][branch])
-    assert not bad, bad[:3]
+        bad, worst_rel, worst_ratio, _ = judge(_G64_CACHE[key][branch])
+    assert not bad, (bad[:3], kink, branch)
     flat_hip = torch.cat([q.grad.reshape(-1) for q in model.parameters()])
     flat_ref = torch.cat([v.grad.reshape(-1) for v in leaves.values()])
     note(f"bwd nb{nb} nc{nc} {'fused' if fused else 'per-op'}: flat grad rel err vs oracle32 / worst err over |g|max vs "
@@ -485,6 +489,7 @@ def test_fused_split_over_cus_matches_per_op(pkg, oracle, split, mode, monkeypat
     graph, a 40-node graph whose tiles do not cover every part, a 388-node graph with SHUFFLED node ids: most of its
     neighbours are halo rows) and the launches are repeated so that the persistent barrier epochs are exercised."""
     monkeypatch.setenv("GATRES_FUSED_SPLIT", str(split))
+    monkeypatch.setenv("GATRES_REORDER", "0")          # keep the shuffled ids: this test is about large halos
     if mode:                 # the fallbacks: bulk pulls, agent-scope barriers, parameter gradients in a second launch
         monkeypatch.setenv(mode, "1")
     nb, nc = 4, 32

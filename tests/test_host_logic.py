@@ -115,9 +115,11 @@ def test_row_windows_of_split_segments(pkg):
     src, dst = ei[0].numpy(), ei[1].numpy()
     indeg_gat = np.bincount(dst[src != dst], minlength=N) + 1
     indeg_all = np.bincount(dst, minlength=N)
-    got = np.array(plan.windows).reshape(3, 3)
+    got = np.array(plan.windows[:9]).reshape(3, 3)
+    halo = plan.windows[9:12]                 # most edges of one part that cross to another part (in- or out-), per M
     for k, M in enumerate((2, 4, 8)):
         best = np.zeros(3, dtype=np.int64)
+        hin, hout = np.zeros((3, M), dtype=np.int64), np.zeros((3, M), dtype=np.int64)
         for s in range(3):
             a, b = int(seg[s]), int(seg[s + 1])
             n = b - a
@@ -129,12 +131,14 @@ def test_row_windows_of_split_segments(pkg):
                 if a <= u < b and u != v:
                     pu, pv = part[u - a], part[v - a]
                     if pu != pv:
+                        hout[s, pu] += 1; hin[s, pv] += 1
                         wlo[pu] = min(wlo[pu], v - a); whi[pu] = max(whi[pu], v - a + 1)
                         wlo[pv] = min(wlo[pv], u - a); whi[pv] = max(whi[pv], u - a + 1)
             for p in range(M):
                 rows = whi[p] - wlo[p]
                 best = np.maximum(best, [rows, indeg_gat[a + wlo[p]:a + whi[p]].sum(), indeg_all[a + wlo[p]:a + whi[p]].sum()])
         assert list(got[k]) == list(best), (M, got[k], best)
+        assert halo[k] == max(hin.max(), hout.max()), (M, halo[k], hin.max(), hout.max())
     # a locality-preserving order keeps the windows a fraction of the segment; a shuffled one does not
     assert got[1][0] < 388 // 2
     perm = torch.from_numpy(np.random.RandomState(1).permutation(388))
