@@ -478,7 +478,7 @@ def main():
                                f"{'eager launches' if args.no_graph else 'hipGraph replay'}"
                                f"{', batches from SnapshotStore.fit_epoch' if store is not None else ''}",
                    "global_batch": world * args.batch_size, "parallelism": f"dp{world}",
-                   "plan_relabelled": trainer.plan.perm_host is not None, "row_window_4parts": trainer.plan.windows[3],
+                   "plan_relabelled": trainer.plan.perm_host is not None, "row_window": trainer.plan.window_rows(cus) if cus >= 2 else None,
                    "dropped_steps": trainer.fault_count, "final_loss": loss},
     }
 

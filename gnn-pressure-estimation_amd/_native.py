@@ -28,8 +28,8 @@ class GatresGraph(C.Structure):
                 ("t_dst", C.c_void_p), ("m_rowptr", C.c_void_p), ("m_col", C.c_void_p), ("mt_rowptr", C.c_void_p),
                 ("mt_dst", C.c_void_p), ("seg_ptr", C.c_void_p), ("max_segment_nodes", C.c_int32),
                 ("max_segment_edges_gat", C.c_int32), ("max_segment_edges_mean", C.c_int32), ("reserved", C.c_int32),
-                ("window", C.c_int32 * 9), ("reserved2", C.c_int32), ("perm", C.c_void_p),
-                ("halo", C.c_int32 * 3), ("reserved3", C.c_int32)]
+                ("window", C.c_int32 * 21), ("reserved2", C.c_int32), ("perm", C.c_void_p),
+                ("halo", C.c_int32 * 7), ("reserved3", C.c_int32)]
 
 
 class GatresModel(C.Structure):

@@ -46,14 +46,14 @@ static inline int num_slabs_for(int64_t P, int64_t N) {
   return (int)s;
 }
 
-// Most workgroups (CUs) one segment may be split over: a power of two <= 8 such that every workgroup of the grid
-// (segments rounded up to a multiple of 8, times the split) is resident at once on the 256 CUs of an MI355X -- the
-// parts of a segment wait for each other, so none may be left undispatched.
+// Most workgroups (CUs) one segment may be split over: at most 8, and such that every workgroup of the grid (segments
+// rounded up to a multiple of 8, times the split) is resident at once on the 256 CUs of an MI355X -- the parts of a
+// segment wait for each other, so none may be left undispatched.
 static inline int split_max_for(int num_segments) {
   const int padded = ((num_segments + 7) / 8) * 8;
-  int m = 1;
-  while (m < 8 && padded * (m * 2) <= 256) m *= 2;
-  return padded > 0 && padded <= 256 ? m : 1;
+  if (padded <= 0 || padded > 256) return 1;
+  const int m = 256 / padded;
+  return m > 8 ? 8 : (m < 1 ? 1 : m);
 }
 
 // fused_nodes: the plan's largest segment if the fused per-snapshot path can take it (fused_nodes_of), else 0

@@ -132,10 +132,10 @@ extern "C" int gatres_graph_segments_host(const int64_t* ei, int64_t E, int64_t 
 // contiguous row range holding both is the part's WINDOW.  With a locality-preserving node order the window is a
 // fraction of the segment, and the kernels can size their LDS tables by it.  For M = 2, 4, 8 (out[3*k + ...]):
 // the largest window in rows, in GATConv edges (in-edges of the window's rows, self loops included) and in
-// SimpleConv edges, over all segments and parts.
+// SimpleConv edges, over all segments and parts; the same for every part count M = 2 .. 8.
 extern "C" int gatres_graph_windows_host(const int64_t* ei, int64_t E, int64_t N, const int32_t* seg_ptr,
                                          int32_t num_segments, int32_t* out9) {
-  // (out9 holds 12 entries: the nine window figures, then the halo sizes for 2 / 4 / 8 parts)
+  // (out9 holds 28 entries: three window figures for each M = 2 .. 8, then the seven halo sizes)
   if ((!ei && E > 0) || !seg_ptr || !out9 || num_segments <= 0 || N <= 0 || E < 0) return GATRES_E_BADARG;
   std::vector<int32_t> seg_of(N);
   for (int32_t s = 0; s < num_segments; ++s)
@@ -146,9 +146,8 @@ extern "C" int gatres_graph_windows_host(const int64_t* ei, int64_t E, int64_t N
     in_gat[ei[E + e] + 1] += (ei[e] != ei[E + e]);
   }
   for (int64_t i = 0; i < N; ++i) { in_all[i + 1] += in_all[i]; in_gat[i + 1] += in_gat[i] + 1; }
-  const int Ms[3] = {2, 4, 8};
-  for (int k = 0; k < 3; ++k) {
-    const int M = Ms[k];
+  for (int k = 0; k < 7; ++k) {
+    const int M = k + 2;
     std::vector<int32_t> wlo((size_t)num_segments * M), whi((size_t)num_segments * M);
     std::vector<int32_t> hin((size_t)num_segments * M, 0), hout((size_t)num_segments * M, 0);   // remote in- / out-edges
     auto bound = [&](int32_t s, int p) {
@@ -193,7 +192,7 @@ extern "C" int gatres_graph_windows_host(const int64_t* ei, int64_t E, int64_t N
     out9[3 * k + 2] = (int32_t)(mm > INT32_MAX ? INT32_MAX : mm);
     int32_t mh = 0;
     for (size_t i = 0; i < hin.size(); ++i) mh = std::max(mh, std::max(hin[i], hout[i]));
-    out9[9 + k] = mh;
+    out9[21 + k] = mh;
   }
   return 0;
 }

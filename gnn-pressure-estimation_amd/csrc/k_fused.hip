@@ -1283,8 +1283,14 @@ __device__ __forceinline__ void pull_list_small(float* dst, const float* src, co
 //   * a producer that never delivers ends the sweep after SPIN_LIMIT rounds with the error word set (results poisoned,
 //     the step dropped by gatres_fused_finish), never a hang.
 typedef unsigned long long u64;
-__device__ __forceinline__ void gran_store(u64* p, float v, unsigned tag) {
-  __hip_atomic_store(p, ((u64)tag << 32) | (u64)__float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+// local: every part of the segment runs on ONE XCD (verified from HW_REG_XCC_ID at the launch's first barrier).  Then a
+// plain 8-byte store is enough: it writes through the CU's L1 into the XCD's L2 and KEEPS the line there, where the
+// partner's sc1 load (L1 bypassed) finds it at L2 latency.  Anywhere else the store is an agent-scope one (sc1: written
+// through to memory, line dropped from this L2), which any XCD's sc1 load observes -- slower, never wrong.
+__device__ __forceinline__ void gran_store(u64* p, float v, unsigned tag, bool local) {
+  const u64 g = ((u64)tag << 32) | (u64)__float_as_uint(v);
+  if (local) __hip_atomic_store(p, g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+  else       __hip_atomic_store(p, g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 __device__ __forceinline__ u64 gran_load(u64* p) {
   return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1297,6 +1303,7 @@ struct Xch {
   int M, part;
   int* err;
   bool dead;
+  bool local;           // all parts on one XCD (Group::local)
 };
 
 // table[(idx)*W + c] of every listed row / edge -> granules.  src: LDS table addressed by the same index.
@@ -1304,7 +1311,7 @@ template <int W, int THREADS>
 __device__ __forceinline__ void xch_export(const Xch& x, const u16* list, int cnt, const float* src, u64* dst) {
   for (int k = threadIdx.x; k < cnt * W; k += THREADS) {
     const int o = (int)list[k / W] * W + (k % W);
-    gran_store(dst + o, src[o], x.ep);
+    gran_store(dst + o, src[o], x.ep, x.local);
   }
 }
 
@@ -1347,7 +1354,7 @@ __device__ __forceinline__ void xch_import(Xch& x, const u16* list, int cnt, u64
 template <int THREADS>
 __device__ __forceinline__ void xch_heartbeat(Xch& x, int point) {
   u64* hb = x.base_hb + point * 8;
-  if (threadIdx.x == 0) gran_store(hb + x.part, 0.f, x.ep);
+  if (threadIdx.x == 0) gran_store(hb + x.part, 0.f, x.ep, x.local);
   const int lane = (int)threadIdx.x - (THREADS - 64);                 // the last wave polls: lanes 0 .. M-1, one part each
   if (lane >= 0) {
     const bool mine = lane < x.M && lane != x.part;
@@ -1586,7 +1593,7 @@ __global__ __launch_bounds__(THREADS) void gatres_fused_kernel(const FusedArgs a
     bool halo = false;
     if (CACHE && split) {
       const int cap = ((priv ? slot_b : LDS_BYTES) - used_b - 8) / 2;
-      if (cap > 0 && !a.no_halo) {
+      if (cap > 0 && !(a.no_halo & 1)) {
         hcnt = build_halo<THREADS>(rp, col, nullptr, rw, hlist, nullptr, cap, reinterpret_cast<int*>(tp));
         halo = hcnt <= cap;
       }
@@ -1782,7 +1789,7 @@ __global__ __launch_bounds__(THREADS) void gatres_fused_kernel(const FusedArgs a
     bool halo = false;
     if (pub) {
       const int cap = (int)((lds_raw + LDS_BYTES - reinterpret_cast<unsigned char*>(hrow)) / 4) - 4;
-      if (cap > 0 && !a.no_halo) {
+      if (cap > 0 && !(a.no_halo & 1)) {
         hcnt = build_halo<THREADS>(trp, tdst, teid, rw, hrow, hrow + cap, cap, reinterpret_cast<int*>(hrow - 2));
         halo = hcnt <= cap;
       }
@@ -2003,7 +2010,9 @@ __global__ __launch_bounds__(THREADS) void gatres_window_kernel(const FusedArgs 
   Xch xc;
   xc.base = a.xch + (size_t)seg * (size_t)(L.xch_stride / 2);
   xc.base_hb = xc.base + XL.hb;
-  xc.M = M; xc.part = part; xc.err = a.err; xc.dead = false;
+  xc.M = M; xc.part = part; xc.err = a.err; xc.local = grp.local;
+  xc.dead = (a.no_halo & 2) != 0;      // diagnostic (GATRES_XCH_NOWAIT=1, WRONG results): never wait for a partner -- what
+                                       // the launch would take if every hand-off were free
   xc.ep = __hip_atomic_load(grp.flags + part * FLAG_STRIDE + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   // rows per lane group per trip: a part owns ~100 rows, one trip covers them in every stage but conv1's edge dots;
   // more unrolling only costs registers and code (the block loop does not fit the instruction cache as it is)
@@ -2581,16 +2590,39 @@ static int device_cus() {
   return cus;
 }
 
-// CUs per segment: the layout's co-residency bound, no more parts than 16-row tiles; GATRES_FUSED_SPLIT overrides
+// The window kernel applies when the plan knows the parts' row windows and both LDS layouts fit with them.
+static bool window_kernel_fits(const Layout& L, const gatres_graph_t* g, int M) {
+  if (getenv("GATRES_FUSED_NO_WINDOW") || M < 2 || M > 8 || L.nc > 32 || threads_for(L.nc) != 1024) return false;
+  const int k = M - 2;
+  const int wr = g->window[k][0], ge = g->window[k][1], gm = g->window[k][2], hl = g->halo[k];
+  if (wr <= 0 || L.xch_stride <= 0) return false;
+  const int tiles = (g->max_segment_nodes + 15) / 16;
+  const int ow = 16 * ((tiles + M - 1) / M);
+  return win_fwd_bytes(L.nc, wr, ow, ge, gm, hl) <= LDS_BYTES && win_bwd_bytes(L.nc, 1024, wr, ow, ge, gm, hl) <= LDS_BYTES &&
+         wr <= 65535 && ge <= 65535 && gm <= 65535;
+}
+
+// CUs per segment.  B = the co-residency bound of the layout (at most 8, whole grid resident, no more parts than 16-row
+// tiles).  Preferred: B - 2 parts on the window kernel, which leaves two CUs per segment for the consumer workgroups that
+// turn the kept gradient tables into parameter gradients inside the same launch.  Measured on gatres_small, C-Town,
+// bs = 32 (B = 8; profiles/r02_split_sweep.txt): 6 + 2 consumers 0.593 ms per launch; 7 + 1 0.727 ms (ONE consumer needs
+// ~23 us per item and cannot keep up with two items per 34-us block); 8 parts + a separate 52-us gradient launch 0.588 ms;
+// 4 + 2 (round 1's knee, when every hand-off cost a flag barrier) 0.600 ms.  Otherwise B parts if the window kernel
+// fits with them, otherwise the whole-segment-table kernel at min(B, 4).  The choice depends on the plan only, never on
+// the phases of a launch: the per-part hand-off epochs persist in scratch.  GATRES_FUSED_SPLIT=1..8 overrides.
 static int fused_split(const Layout& L, const gatres_graph_t* g) {
-  int m = L.split_max < 4 ? L.split_max : 4;        // measured on C-Town / nc=32: 4 CUs per snapshot is the knee
-  if (const char* e = getenv("GATRES_FUSED_SPLIT")) {
-    const int v = atoi(e);
-    if (v >= 1 && v <= L.split_max && gatres_is_pow2(v)) m = v;
-  }
   const int tiles = (g->max_segment_nodes + 15) / 16;
   const int padded = ((g->num_segments + 7) / 8) * 8;
-  while (m > 1 && (m > tiles || L.nb == 0 || padded * m > device_cus())) m >>= 1;   // (a partitioned / smaller device)
+  int B = L.split_max;
+  while (B > 1 && (B > tiles || L.nb == 0 || padded * B > device_cus())) --B;   // (a partitioned / smaller device)
+  if (const char* e = getenv("GATRES_FUSED_SPLIT")) {
+    const int v = atoi(e);
+    if (v >= 1 && v <= B) return v;
+  }
+  if (B >= 4 && window_kernel_fits(L, g, B - 2) && !getenv("GATRES_FUSED_NO_CONSUMERS")) return B - 2;
+  if (B >= 2 && window_kernel_fits(L, g, B)) return B;
+  int m = 1;
+  while (m * 2 <= B && m < 4) m *= 2;
   return m;
 }
 
@@ -2607,17 +2639,6 @@ static int fused_consumers(const Layout& L, const gatres_graph_t* g, int M) {
   return c > 0 ? c : 0;
 }
 
-// The window kernel applies when the plan knows the parts' row windows and both LDS layouts fit with them.
-static bool window_kernel_fits(const Layout& L, const gatres_graph_t* g, int M) {
-  if (getenv("GATRES_FUSED_NO_WINDOW") || M < 2 || L.nc > 32 || threads_for(L.nc) != 1024) return false;
-  const int k = M == 2 ? 0 : (M == 4 ? 1 : 2);
-  const int wr = g->window[k][0], ge = g->window[k][1], gm = g->window[k][2], hl = g->halo[k];
-  if (wr <= 0 || L.xch_stride <= 0) return false;
-  const int tiles = (g->max_segment_nodes + 15) / 16;
-  const int ow = 16 * ((tiles + M - 1) / M);
-  return win_fwd_bytes(L.nc, wr, ow, ge, gm, hl) <= LDS_BYTES && win_bwd_bytes(L.nc, 1024, wr, ow, ge, gm, hl) <= LDS_BYTES &&
-         wr <= 65535 && ge <= 65535 && gm <= 65535;
-}
 static bool use_window_kernel(const FusedArgs& a, const gatres_graph_t* g) {
   return a.saved && window_kernel_fits(a.L, g, a.M);        // (it writes the saved tables: training launches only)
 }
@@ -2721,7 +2742,7 @@ extern "C" int gatres_fused_run(const gatres_model_t* m, const gatres_graph_t* g
   a.num_segments = g->num_segments;
   a.M = fused_split(a.L, g);
   a.safe_sync = getenv("GATRES_FUSED_SAFE_SYNC") ? 1 : 0;
-  a.no_halo = getenv("GATRES_FUSED_NO_HALO") ? 1 : 0;
+  a.no_halo = (getenv("GATRES_FUSED_NO_HALO") ? 1 : 0) | (getenv("GATRES_XCH_NOWAIT") ? 2 : 0);
   a.C = (phases & GATRES_PHASE_BACKWARD) ? fused_consumers(a.L, g, a.M) : 0;
   a.flags = reinterpret_cast<unsigned*>(scratch + a.L.sc_flags);
   a.err = reinterpret_cast<int*>(a.flags + a.L.flag_words - 32);

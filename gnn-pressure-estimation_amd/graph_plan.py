@@ -55,8 +55,8 @@ class GraphPlan:
             self.max_segment_edges_gat, self.max_segment_edges_mean = int(mg.value), int(mm.value)
             self.segment_ptr_host = seg[: self.num_segments + 1].clone()
 
-            def windows_of(ei_t):                 # nine window figures + three halo sizes (gatres_graph_t.window / .halo)
-                win = torch.zeros(12, **i32)
+            def windows_of(ei_t):                 # 7 x 3 window figures + 7 halo sizes (gatres_graph_t.window / .halo)
+                win = torch.zeros(28, **i32)
                 _native.check(lib.gatres_graph_windows_host(ei_t.data_ptr(), E, N, self.segment_ptr_host.data_ptr(),
                                                             self.num_segments, win.data_ptr()),
                               "gatres_graph_windows_host")
@@ -75,10 +75,10 @@ class GraphPlan:
                 old2new[perm.long()] = torch.arange(N, dtype=torch.int64)
                 ei_new = old2new[ei_host].contiguous()
                 win_new = windows_of(ei_new)
-                if want is True or win_new[3] < 0.9 * self.windows[3]:
+                if want is True or win_new[6] < 0.9 * self.windows[6]:              # (rows of the 4-part window)
                     self.perm_host, self.windows, ei_host = perm, win_new, ei_new
         else:
-            self.windows = [0] * 12
+            self.windows = [0] * 28
         host = {
             "rowptr": torch.empty(N + 1, **i32), "col": torch.empty(Eg, **i32),
             "t_rowptr": torch.empty(N + 1, **i32), "t_eid": torch.empty(Eg, **i32), "t_dst": torch.empty(Eg, **i32),
@@ -100,11 +100,18 @@ class GraphPlan:
             perm_dev_ptr = self.arrays["perm"].data_ptr()
         self.c = _native.GatresGraph(N, Eg, E, self.num_segments, *[self.arrays[k].data_ptr() for k in host.keys()],
                                      seg_dev_ptr, self.max_segment_nodes, self.max_segment_edges_gat,
-                                     self.max_segment_edges_mean, 0, (C.c_int32 * 9)(*self.windows[:9]), 0, perm_dev_ptr,
-                                     (C.c_int32 * 3)(*self.windows[9:12]), 0)
+                                     self.max_segment_edges_mean, 0, (C.c_int32 * 21)(*self.windows[:21]), 0, perm_dev_ptr,
+                                     (C.c_int32 * 7)(*self.windows[21:28]), 0)
 
     def ref(self):
         return C.byref(self.c)
+
+    def window_rows(self, parts: int) -> int:
+        """Rows of the largest part window when a segment is carried by ``parts`` (2 .. 8) workgroups; 0 = unknown."""
+        return self.windows[3 * (parts - 2)] if 2 <= parts <= 8 else 0
+
+    def halo_edges(self, parts: int) -> int:
+        return self.windows[21 + parts - 2] if 2 <= parts <= 8 else 0
 
     def node_ptr_for(self, nodes_per_graph) -> torch.Tensor:
         """int32 [B+1] node offsets for the device mask sampler."""

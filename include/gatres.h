@@ -65,10 +65,10 @@ typedef struct gatres_graph {
   int32_t max_segment_edges_gat;   /* most GATConv edges (self loops included) inside one segment */
   int32_t max_segment_edges_mean;  /* most SimpleConv edges inside one segment                    */
   int32_t reserved;
-  /* Row windows of split segments, from gatres_graph_windows_host: window[k] = {rows, GATConv edges, SimpleConv
-   * edges} for 2 << k workgroups per segment.  All zero = unknown (the fused kernels then size their LDS tables by
+  /* Row windows of split segments, from gatres_graph_windows_host: window[M - 2] = {rows, GATConv edges, SimpleConv
+   * edges} for M = 2 .. 8 workgroups per segment.  All zero = unknown (the fused kernels then size their LDS tables by
    * the whole segment). */
-  int32_t window[3][3];
+  int32_t window[7][3];
   int32_t reserved2;
   /* Node relabelling of the plan (gatres_graph_reorder_host): every array above is built on the RELABELLED graph and
    * perm[new id] = the caller's node id.  Only the arrays the caller hands over or gets back -- x, y, mask, out, g_out,
@@ -77,9 +77,9 @@ typedef struct gatres_graph {
    * fp32 sum associates exactly as without it. */
   const int32_t* perm;
   /* Split segments: the most edges one part has to a row of ANOTHER part (in- or out-edges of the GATConv graph, whichever
-   * is more), for 2 / 4 / 8 workgroups per segment; from gatres_graph_windows_host.  The window kernel keeps its halo lists
-   * (one entry per such edge) in LDS and is only taken when they fit. */
-  int32_t halo[3];
+   * is more), halo[M - 2] for M = 2 .. 8 workgroups per segment; from gatres_graph_windows_host.  The window kernel keeps
+   * its halo lists (one entry per such edge) in LDS and is only taken when they fit. */
+  int32_t halo[7];
   int32_t reserved3;
 } gatres_graph_t;
 
@@ -98,12 +98,11 @@ int gatres_graph_segments_host(const int64_t* edge_index_host, int64_t num_edges
                                int32_t* max_segment_nodes_out, int32_t* max_segment_edges_gat_out,
                                int32_t* max_segment_edges_mean_out);
 
-/* Row windows of split segments (see gatres_graph_t.window): for M = 2, 4, 8 workgroups per segment, the largest
- * contiguous row range a part needs (own rows + the rows adjacent to them), in rows / GATConv edges / SimpleConv
- * edges, followed by gatres_graph_t.halo: out12 = {rows2, gat2, mean2, rows4, gat4, mean4, rows8, gat8, mean8, halo2,
- * halo4, halo8}. */
+/* Row windows of split segments (see gatres_graph_t.window): for M = 2 .. 8 workgroups per segment, the largest
+ * contiguous row range a part needs (own rows + the rows adjacent to them), in rows / GATConv edges / SimpleConv edges,
+ * followed by gatres_graph_t.halo: out28 = {rows2, gat2, mean2, ..., rows8, gat8, mean8, halo2, ..., halo8}. */
 int gatres_graph_windows_host(const int64_t* edge_index, int64_t num_edges, int64_t num_nodes, const int32_t* seg_ptr,
-                              int32_t num_segments, int32_t* out12);
+                              int32_t num_segments, int32_t* out28);
 
 /* Bandwidth-reducing relabelling (host): reverse Cuthill-McKee inside every segment (nodes never leave their segment, so
  * seg_ptr stays valid).  perm_new2old_host[new] = old, N entries.  The fused kernels' row windows (above) are what it
@@ -285,8 +284,8 @@ int gatres_model_backward_per_op_part(const gatres_model_t* m, const gatres_grap
  * between gatres_fused_run(BACKWARD) and gatres_fused_finish.  gatres_fused_finish
  * sums the slabs into grads[P] and optionally applies Adam and finalises the loss in the same pass.
  * gatres_model_forward/backward and gatres_train_step take this path whenever gatres_fused_supported().
- * A segment may be carried by up to 8 workgroups on 8 CUs (flag barriers through scratch; the split is chosen so
- * that the whole grid is resident; environment GATRES_FUSED_SPLIT=1|2|4|8 caps it).  The barrier epochs persist
+ * A segment may be carried by up to 8 workgroups on 8 CUs (hand-offs through scratch; the split is chosen so
+ * that the whole grid is resident; environment GATRES_FUSED_SPLIT=1..8 sets it).  The barrier epochs persist
  * in `scratch` from launch to launch: ZERO the scratch buffer once after allocating it and do not share it between
  * streams.  A partner that never arrives (e.g. the GPU is shared and the grid is not resident) turns out[first node
  * of the segment] / the lin1 bias gradient into NaN instead of hanging.

@@ -251,7 +251,7 @@ def test_window_kernel_narrow_models(pkg, oracle, nc):
         assert relerr(tf.grads, tp.grads) < 2e-5 and relerr(tf.grads, ref.flat("grads")) < 1e-4
 
 
-@pytest.mark.parametrize("split", [4, 8])
+@pytest.mark.parametrize("split", [3, 4, 7, 8])
 def test_window_kernel_on_a_ragged_batch(pkg, oracle, split, monkeypatch):
     """Graphs of different sizes whose node order is local (compact row windows): the window kernel carries them,
     including a 40-node graph that leaves parts without rows.  Training steps must match the per-op path."""
@@ -269,7 +269,7 @@ def test_window_kernel_on_a_ragged_batch(pkg, oracle, split, monkeypatch):
     mp, _ = build(pkg, oracle, nb, nc, seed=41, fused=False)
     tf = pkg.GATResTrainer(mf, ei.cuda(), N, nodes_per_graph=npg, use_graph=False, fused=True)
     tp = pkg.GATResTrainer(mp, ei.cuda(), N, nodes_per_graph=npg, use_graph=False, fused=False)
-    assert tf.plan.windows[3 if split == 4 else 6] < 200           # compact windows: the window kernel applies
+    assert tf.plan.window_rows(split) < 200           # compact windows: the window kernel applies
     for it in range(3):
         lf = tf.step(y.cuda(), y.cuda(), mask.cuda())
         lp = tp.step(y.cuda(), y.cuda(), mask.cuda())
@@ -481,7 +481,7 @@ def test_fused_equals_per_op_bitwise_forward(pkg, oracle):
         assert relerr(gf, gp) < 2e-5, (nb, nc, nodes, relerr(gf, gp))
 
 
-@pytest.mark.parametrize("split,mode", [(1, ""), (2, ""), (4, ""), (8, ""), (4, "GATRES_FUSED_NO_HALO"),
+@pytest.mark.parametrize("split,mode", [(1, ""), (2, ""), (4, ""), (8, ""), (3, ""), (7, ""), (4, "GATRES_FUSED_NO_HALO"),
                                         (4, "GATRES_FUSED_SAFE_SYNC"), (2, "GATRES_FUSED_NO_CONSUMERS")])
 def test_fused_split_over_cus_matches_per_op(pkg, oracle, split, mode, monkeypatch):
     """One snapshot carried by 1 / 2 / 4 / 8 workgroups (row windows + flag barriers + halo pulls): predictions stay

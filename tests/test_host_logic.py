@@ -115,9 +115,9 @@ def test_row_windows_of_split_segments(pkg):
     src, dst = ei[0].numpy(), ei[1].numpy()
     indeg_gat = np.bincount(dst[src != dst], minlength=N) + 1
     indeg_all = np.bincount(dst, minlength=N)
-    got = np.array(plan.windows[:9]).reshape(3, 3)
-    halo = plan.windows[9:12]                 # most edges of one part that cross to another part (in- or out-), per M
-    for k, M in enumerate((2, 4, 8)):
+    got = np.array(plan.windows[:21]).reshape(7, 3)
+    halo = plan.windows[21:28]                # most edges of one part that cross to another part (in- or out-), per M
+    for k, M in enumerate(range(2, 9)):
         best = np.zeros(3, dtype=np.int64)
         hin, hout = np.zeros((3, M), dtype=np.int64), np.zeros((3, M), dtype=np.int64)
         for s in range(3):
@@ -140,10 +140,10 @@ def test_row_windows_of_split_segments(pkg):
         assert list(got[k]) == list(best), (M, got[k], best)
         assert halo[k] == max(hin.max(), hout.max()), (M, halo[k], hin.max(), hout.max())
     # a locality-preserving order keeps the windows a fraction of the segment; a shuffled one does not
-    assert got[1][0] < 388 // 2
+    assert got[2][0] < 388 // 2 and plan.window_rows(4) == got[2][0] and plan.halo_edges(4) == halo[2]
     perm = torch.from_numpy(np.random.RandomState(1).permutation(388))
     shuf = perm[t1]
-    assert GraphPlan(shuf, 388, torch.device("cpu"), reorder=False).windows[3] > 300
+    assert GraphPlan(shuf, 388, torch.device("cpu"), reorder=False).window_rows(4) > 300
 
 
 def test_reordered_plan_restores_compact_windows(pkg):
@@ -163,8 +163,8 @@ def test_reordered_plan_restores_compact_windows(pkg):
     assert sorted(perm.tolist()) == list(range(N))
     for k in range(bs):                                                # a permutation of every snapshot's own id range
         assert sorted(perm[388 * k:388 * (k + 1)].tolist()) == list(range(388 * k, 388 * (k + 1)))
-    assert plan.windows[3] < 388 // 2 and plan.windows[3] <= 1.15 * GraphPlan(
-        pkg.wdn_synth.collate_edge_index(t1, 388, bs), N, torch.device("cpu"), reorder=False).windows[3]
+    assert plan.window_rows(4) < 388 // 2 and plan.window_rows(4) <= 1.15 * GraphPlan(
+        pkg.wdn_synth.collate_edge_index(t1, 388, bs), N, torch.device("cpu"), reorder=False).window_rows(4)
     old2new = torch.empty(N, dtype=torch.int64)
     old2new[perm] = torch.arange(N)
     ref = ref_plan(old2new[ei], N)                                     # same edge ORDER, relabelled endpoints
