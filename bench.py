@@ -94,64 +94,68 @@ def self_launch(args):
 # per-kernel timing (HIP events on the launch stream) and algorithmic bytes -- DESIGN.md section 4
 # ------------------------------------------------------------------------------------------------------------------
 def kernel_table(G, model, plan, nc):
-    """[(name, calls_per_step, algorithmic_bytes_per_launch, launcher)] for the kernels of one training step."""
-    import ctypes as C
+    """[(name, calls_per_step, algorithmic_bytes_per_launch, launcher)] for the kernels of one training step, through the
+    typed per-op entry points of include/gatres.h in the model's storage type (s = 4 or 2 bytes per activation element)."""
     lib = G._native.load()
     N, Eg, E = plan.num_nodes, plan.num_edges_gat, plan.num_edges_mean
     nb = model.num_blocks
     dev = plan.device
-    f = lambda *s: torch.randn(*s, dtype=torch.float32, device=dev)
+    dt = int(model._cmodel.act_dtype)
+    s = 2 if dt == G._native.DTYPE_BF16 else 4
+    adt = torch.bfloat16 if dt == G._native.DTYPE_BF16 else torch.float32
+    f = lambda *sh: torch.randn(*sh, dtype=torch.float32, device=dev)
+    a = lambda *sh: torch.randn(*sh, dtype=torch.float32, device=dev).to(adt)          # activation-sized tensors
     st = lambda: G._native.current_stream(dev)
     S = int(lib.gatres_num_slabs(model._cmodel_ref(), N))
     rows = []
 
     def conv(tag, K, H):
         HC = H * nc
-        x, W, Wt = f(N, K), f(HC, K), f(K, HC)
+        x, W, Wt = a(N, K), a(HC, K), a(K, HC)
         att_s, att_d, bias = f(HC), f(HC), f(HC)
-        h, a_s, a_d = f(N, HC), f(N, H), f(N, H)
-        out, alpha = f(N, HC), torch.rand(Eg, H, device=dev)
-        g_out, g_e, g_ad, g_as, g_h, g_x = f(N, HC), f(Eg, H), f(N, H), f(N, H), f(N, HC), f(N, K)
+        h, a_s, a_d = a(N, HC), f(N, H), f(N, H)
+        out, alpha = a(N, HC), torch.rand(Eg, H, device=dev)
+        g_out, g_e, g_ad, g_as, g_h, g_x = a(N, HC), f(Eg, H), f(N, H), f(N, H), a(N, HC), a(N, K)
         slab = torch.empty(S * (HC * K + 3 * HC), device=dev)
         gp = plan.ref()
         idx = 4 * (N + 1) + 4 * Eg
-        rows.append((f"proj_attn_fwd[{tag}]", nb, 4 * (N * K + HC * K + 2 * HC + N * HC + 2 * N * H),
-                     lambda: lib.gatres_proj_attn_fwd(x.data_ptr(), W.data_ptr(), att_s.data_ptr(), att_d.data_ptr(),
-                                                      h.data_ptr(), a_s.data_ptr(), a_d.data_ptr(), N, K, H, nc, st())))
+        rows.append((f"proj_attn_fwd[{tag}]", nb, s * (N * K + HC * K + N * HC) + 4 * (2 * HC + 2 * N * H),
+                     lambda: lib.gatres_t_proj_attn_fwd(x.data_ptr(), W.data_ptr(), att_s.data_ptr(), att_d.data_ptr(),
+                                                        h.data_ptr(), a_s.data_ptr(), a_d.data_ptr(), N, K, H, nc, dt, st())))
         rows.append((f"gat_aggregate_fwd[{tag}]", nb,
-                     idx + 4 * (Eg * H + N * H + Eg * HC + HC + N * HC + Eg * H),
-                     lambda: lib.gatres_gat_aggregate_fwd(gp, h.data_ptr(), a_s.data_ptr(), a_d.data_ptr(),
-                                                          bias.data_ptr(), out.data_ptr(), alpha.data_ptr(), H, nc, 1,
-                                                          st())))
+                     idx + 4 * (Eg * H + N * H + HC + Eg * H) + s * (Eg * HC + N * HC),
+                     lambda: lib.gatres_t_gat_aggregate_fwd(gp, h.data_ptr(), a_s.data_ptr(), a_d.data_ptr(),
+                                                            bias.data_ptr(), out.data_ptr(), alpha.data_ptr(), H, nc, 1,
+                                                            dt, st())))
         rows.append((f"gat_aggregate_bwd_dst[{tag}]", nb,
-                     idx + 4 * (N * HC + Eg * HC + Eg * H + Eg * H + N * H + Eg * H + N * H),
-                     lambda: lib.gatres_gat_aggregate_bwd_dst(gp, g_out.data_ptr(), h.data_ptr(), alpha.data_ptr(),
-                                                              a_s.data_ptr(), a_d.data_ptr(), g_e.data_ptr(),
-                                                              g_ad.data_ptr(), H, nc, st())))
+                     idx + s * (N * HC + Eg * HC) + 4 * (Eg * H + Eg * H + N * H + Eg * H + N * H),
+                     lambda: lib.gatres_t_gat_aggregate_bwd_dst(gp, g_out.data_ptr(), h.data_ptr(), alpha.data_ptr(),
+                                                                a_s.data_ptr(), a_d.data_ptr(), g_e.data_ptr(),
+                                                                g_ad.data_ptr(), H, nc, dt, st())))
         rows.append((f"gat_aggregate_bwd_src[{tag}]", nb,
-                     4 * (N + 1) + 8 * Eg + 4 * (Eg * HC + 2 * Eg * H + N * H + 2 * HC + N * HC + N * H),
-                     lambda: lib.gatres_gat_aggregate_bwd_src(gp, g_out.data_ptr(), alpha.data_ptr(), g_e.data_ptr(),
-                                                              g_ad.data_ptr(), att_s.data_ptr(), att_d.data_ptr(),
-                                                              g_h.data_ptr(), g_as.data_ptr(), H, nc, st())))
-        rows.append((f"proj_bwd_dx[{tag}]", nb, 4 * (N * HC + HC * K + 3 * N * K),
-                     lambda: lib.gatres_proj_bwd_dx(g_h.data_ptr(), Wt.data_ptr(), g_x.data_ptr(), x.data_ptr(),
-                                                    g_x.data_ptr(), N, K, HC, st())))
-        rows.append((f"proj_bwd_dw[{tag}]", nb, 4 * (N * HC + N * K + S * HC * K),
-                     lambda: lib.gatres_proj_bwd_dw(g_h.data_ptr(), x.data_ptr(), slab.data_ptr(), S, HC * K + 3 * HC,
-                                                    N, K, HC, st())))
-        rows.append((f"conv_param_grads[{tag}]", nb, 4 * (2 * N * HC + 2 * N * H + 3 * S * HC),
-                     lambda: lib.gatres_conv_param_grads(h.data_ptr(), g_as.data_ptr(), g_ad.data_ptr(),
-                                                         g_out.data_ptr(), slab.data_ptr(), slab.data_ptr() + 4 * HC,
-                                                         slab.data_ptr() + 8 * HC, S, HC * K + 3 * HC, N, H, nc, st())))
+                     4 * (N + 1) + 8 * Eg + s * (Eg * HC + N * HC) + 4 * (2 * Eg * H + N * H + 2 * HC + N * H),
+                     lambda: lib.gatres_t_gat_aggregate_bwd_src(gp, g_out.data_ptr(), alpha.data_ptr(), g_e.data_ptr(),
+                                                                g_ad.data_ptr(), att_s.data_ptr(), att_d.data_ptr(),
+                                                                g_h.data_ptr(), g_as.data_ptr(), H, nc, dt, st())))
+        rows.append((f"proj_bwd_dx[{tag}]", nb, s * (N * HC + HC * K + 3 * N * K),
+                     lambda: lib.gatres_t_proj_bwd_dx(g_h.data_ptr(), Wt.data_ptr(), g_x.data_ptr(), x.data_ptr(),
+                                                      g_x.data_ptr(), N, K, HC, dt, st())))
+        rows.append((f"proj_bwd_dw[{tag}]", nb, s * (N * HC + N * K) + 4 * S * HC * K,
+                     lambda: lib.gatres_t_proj_bwd_dw(g_h.data_ptr(), x.data_ptr(), slab.data_ptr(), S, HC * K + 3 * HC,
+                                                      N, K, HC, dt, st())))
+        rows.append((f"conv_param_grads[{tag}]", nb, s * 2 * N * HC + 4 * (2 * N * H + 3 * S * HC),
+                     lambda: lib.gatres_t_conv_param_grads(h.data_ptr(), g_as.data_ptr(), g_ad.data_ptr(),
+                                                           g_out.data_ptr(), slab.data_ptr(), slab.data_ptr() + 4 * HC,
+                                                           slab.data_ptr() + 8 * HC, S, HC * K + 3 * HC, N, H, nc, dt, st())))
 
     conv("conv1", nc, 2)
     conv("conv2", 2 * nc, 1)
-    y, x0, o = f(N, nc), f(N, nc), f(N, nc)
+    y, x0, o = a(N, nc), a(N, nc), a(N, nc)
     gp = plan.ref()
-    rows.append(("mean_residual_relu_fwd", nb, 4 * (N + 1) + 4 * E + 4 * (E * nc + 2 * N * nc),
-                 lambda: lib.gatres_mean_residual_relu_fwd(gp, y.data_ptr(), x0.data_ptr(), o.data_ptr(), nc, st())))
-    rows.append(("mean_bwd", nb, 8 * (N + 1) + 4 * E + 4 * (E * nc + N * nc),
-                 lambda: lib.gatres_mean_bwd(gp, y.data_ptr(), o.data_ptr(), nc, st())))
+    rows.append(("mean_residual_relu_fwd", nb, 4 * (N + 1) + 4 * E + s * (E * nc + 2 * N * nc),
+                 lambda: lib.gatres_t_mean_residual_relu_fwd(gp, y.data_ptr(), x0.data_ptr(), o.data_ptr(), nc, dt, st())))
+    rows.append(("mean_bwd", nb, 8 * (N + 1) + 4 * E + s * (E * nc + N * nc),
+                 lambda: lib.gatres_t_mean_bwd(gp, y.data_ptr(), o.data_ptr(), nc, dt, st())))
     return rows
 
 

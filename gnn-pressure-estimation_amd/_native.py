@@ -15,8 +15,11 @@ from . import _build
 
 _LIB: Optional[C.CDLL] = None
 
+DTYPE_F32, DTYPE_BF16 = 0, 1
+
 ERRORS = {-1: "GATRES_E_BADARG (null/misaligned pointer or bad size)",
-          -2: "GATRES_E_UNSUPPORTED (width not supported: nc must be a power of two in [4, 128])",
+          -2: "GATRES_E_UNSUPPORTED (width / storage type not supported: nc must be a power of two in [4, 128]; bf16 "
+              "needs nc >= 32)",
           -3: "GATRES_E_GRAPH (edge endpoint out of range)"}
 
 
@@ -34,7 +37,7 @@ class GatresGraph(C.Structure):
 
 class GatresModel(C.Structure):
     """gatres_model_t"""
-    _fields_ = [("num_blocks", C.c_int32), ("nc", C.c_int32)]
+    _fields_ = [("num_blocks", C.c_int32), ("nc", C.c_int32), ("act_dtype", C.c_int32), ("reserved", C.c_int32)]
 
 
 _P = C.c_void_p
@@ -71,6 +74,21 @@ SIGNATURES = {
     "gatres_mask_generate": (C.c_int, [_P, _I32, _F64, _U64, _P, _P, _P]),
     "gatres_masked_mse": (C.c_int, [_P] * 5 + [_I32, _P]),
     "gatres_adam_step": (C.c_int, [_P] * 5 + [_I64] + [_F64] * 5 + [_F32, _P]),
+    # typed per-op kernels (storage type argument): C ints
+    "gatres_t_gat_aggregate_fwd": (C.c_int, [_GP] + [_P] * 6 + [C.c_int] * 4 + [_P]),
+    "gatres_t_gat_aggregate_bwd_dst": (C.c_int, [_GP] + [_P] * 7 + [C.c_int] * 3 + [_P]),
+    "gatres_t_gat_aggregate_bwd_src": (C.c_int, [_GP] + [_P] * 8 + [C.c_int] * 3 + [_P]),
+    "gatres_t_mean_residual_relu_fwd": (C.c_int, [_GP, _P, _P, _P, C.c_int, C.c_int, _P]),
+    "gatres_t_mean_bwd": (C.c_int, [_GP, _P, _P, C.c_int, C.c_int, _P]),
+    "gatres_t_lin0_fwd": (C.c_int, [_P] * 5 + [C.c_int] * 3 + [_P]),
+    "gatres_t_lin0_bwd": (C.c_int, [_P] * 5 + [C.c_int, _I64, C.c_int, C.c_int, C.c_int, _P]),
+    "gatres_t_lin1_fwd": (C.c_int, [_P] * 4 + [C.c_int] * 3 + [_P]),
+    "gatres_t_lin1_bwd": (C.c_int, [_P] * 6 + [C.c_int, _I64, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
+    "gatres_t_conv_param_grads": (C.c_int, [_P] * 7 + [C.c_int, _I64, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
+    "gatres_convert_conv_weights_bf16": (C.c_int, [_P, _P, C.c_int, C.c_int, _P]),
+    "gatres_t_proj_attn_fwd": (C.c_int, [_P] * 7 + [C.c_int] * 5 + [_P]),
+    "gatres_t_proj_bwd_dx": (C.c_int, [_P] * 5 + [C.c_int] * 4 + [_P]),
+    "gatres_t_proj_bwd_dw": (C.c_int, [_P] * 3 + [C.c_int, _I64, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
     "gatres_param_count": (_I64, [_I32, _I32]),
     "gatres_saved_floats": (_I64, [_MP, _GP]),
     "gatres_scratch_floats": (_I64, [_MP, _GP]),

@@ -68,3 +68,31 @@ __device__ __forceinline__ float gatres_head_dot4(const float4 a, const float4 b
   d = fmaf(a.z, b.z, d);
   return fmaf(a.w, b.w, d);
 }
+
+// ---------------------------------------------------------------------------------------------------- storage types
+// Activation-sized tensors are stored as fp32 (GATRES_DTYPE_F32: every kernel's arithmetic is then bit-for-bit the fp32
+// statement the parity tests pin) or as bf16 (GATRES_DTYPE_BF16, BASELINE config 3): loads widen to fp32, every sum /
+// softmax / accumulator stays fp32, stores round to nearest-even (v_cvt_pk_bf16_f32).  A row segment of four features is
+// one 16-byte (fp32) or one 8-byte (bf16) access per lane either way.
+typedef __bf16 gatres_bf16;
+template <typename T> struct gatres_store;
+template <> struct gatres_store<float> { static constexpr int dtype = GATRES_DTYPE_F32; };
+template <> struct gatres_store<gatres_bf16> { static constexpr int dtype = GATRES_DTYPE_BF16; };
+
+__device__ __forceinline__ float4 ldrow4(const float* p) { return ld4(p); }
+__device__ __forceinline__ float4 ldrow4(const gatres_bf16* p) {
+  const uint2 u = *reinterpret_cast<const uint2*>(p);
+  return make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16),
+                     __uint_as_float(u.y & 0xffff0000u));
+}
+__device__ __forceinline__ void strow4(float* p, float4 v) { st4(p, v); }
+__device__ __forceinline__ void strow4(gatres_bf16* p, float4 v) {
+  typedef gatres_bf16 bf16x4 __attribute__((ext_vector_type(4)));
+  bf16x4 b;
+  b[0] = (gatres_bf16)v.x; b[1] = (gatres_bf16)v.y; b[2] = (gatres_bf16)v.z; b[3] = (gatres_bf16)v.w;
+  *reinterpret_cast<bf16x4*>(p) = b;
+}
+__device__ __forceinline__ float ldval(const float* p) { return *p; }
+__device__ __forceinline__ float ldval(const gatres_bf16* p) { return (float)*p; }
+__device__ __forceinline__ void stval(float* p, float v) { *p = v; }
+__device__ __forceinline__ void stval(gatres_bf16* p, float v) { *p = (gatres_bf16)v; }

@@ -18,6 +18,9 @@ struct Layout {
       sc_ge2, sc_gad2, sc_gas2, sc_gh2, sc_slabs, sc_loss_part, scratch_total;
   // per-op path of a relabelled plan: plan-order copies of x, mask (bytes), out, g_out, g_x
   int64_t sc_px, sc_pmask, sc_pout, sc_pgout, sc_pgx;
+  // bf16 mode (gatres_model_t.act_dtype): bf16 copies of every conv weight and its transpose, rewritten from the fp32
+  // master parameters at the start of every forward / backward (k_misc.hip: convert_conv_weights_bf16_kernel)
+  int64_t sc_wb;
   // window kernel, split segments: tagged 8-byte granules {value, epoch} through which the parts of a segment hand each
   // other the rows / edge values their neighbours need (k_fused.hip: xch_*), one region per segment
   int64_t sc_xch, xch_stride;        // in floats (a granule = 2 floats)
@@ -160,6 +163,7 @@ static inline bool make_layout(const gatres_model_t* m, int64_t N, int64_t Eg, i
     L->xch_stride = 2 * X.total;
     o += (int64_t)num_segments * L->xch_stride;
   }
+  L->sc_wb = o;    o += r4((int64_t)nb * 4 * nc * nc);        // nb * 4 matrices * 2nc^2 bf16 = nb * 4 nc^2 floats
   L->sc_px = o;    o += r4(N);
   L->sc_pmask = o; o += r4((N + 3) / 4);
   L->sc_pout = o;  o += r4(N);

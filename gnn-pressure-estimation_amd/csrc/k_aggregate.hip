@@ -13,6 +13,7 @@
 //   out_i = sum_e alpha_e * h[j] + bias                        GATConv.message / aggregate(sum) / bias
 //   mean  : out_i = (sum_{j->i} y[j]) / max(indeg(i), 1)       SimpleConv(aggr="mean")
 #include "gatres_common.h"
+#include "gatres_typed.h"
 
 namespace {
 
@@ -34,11 +35,11 @@ static inline bool make_geom(int H, int C, RowGeom* g) {
 // ------------------------------------------------------------------------------------------------------
 // K2 forward
 // ------------------------------------------------------------------------------------------------------
-template <bool RELU>
+template <bool RELU, typename T>
 __global__ __launch_bounds__(256) void gat_aggregate_fwd_kernel(
-    const int* __restrict__ rowptr, const int* __restrict__ col, const float* __restrict__ h,
+    const int* __restrict__ rowptr, const int* __restrict__ col, const T* __restrict__ h,
     const float* __restrict__ a_src, const float* __restrict__ a_dst, const float* __restrict__ bias,
-    float* __restrict__ out, float* __restrict__ alpha, int N, RowGeom gm) {
+    T* __restrict__ out, float* __restrict__ alpha, int N, RowGeom gm) {
   const int tid = blockIdx.x * 256 + threadIdx.x;
   const int row = tid >> gm.lgG;
   if (row >= N) return;
@@ -63,7 +64,7 @@ __global__ __launch_bounds__(256) void gat_aggregate_fwd_kernel(
     float m = -INFINITY;
 #pragma unroll
     for (int k = 0; k < MAXD; ++k) {
-      v[k] = ld4(h + (size_t)jj[k] * HC + c0);
+      v[k] = ldrow4(h + (size_t)jj[k] * HC + c0);
       const float sv = gatres_leaky(a_src[jj[k] * H + hd] + adst);
       so[k] = k < deg ? sv : -INFINITY;
     }
@@ -101,8 +102,8 @@ __global__ __launch_bounds__(256) void gat_aggregate_fwd_kernel(
   // two edges per trip so both neighbour rows are in flight together
   for (; e + 1 < end; e += 2) {
     const int j0 = col[e], j1 = col[e + 1];
-    const float4 v0 = ld4(h + (size_t)j0 * HC + c0);
-    const float4 v1 = ld4(h + (size_t)j1 * HC + c0);
+    const float4 v0 = ldrow4(h + (size_t)j0 * HC + c0);
+    const float4 v1 = ldrow4(h + (size_t)j1 * HC + c0);
     const float al0 = expf(gatres_leaky(a_src[j0 * H + hd] + adst) - m) / Z;
     const float al1 = expf(gatres_leaky(a_src[j1 * H + hd] + adst) - m) / Z;
     if (leader) { alpha[(size_t)e * H + hd] = al0; alpha[(size_t)(e + 1) * H + hd] = al1; }
@@ -111,7 +112,7 @@ __global__ __launch_bounds__(256) void gat_aggregate_fwd_kernel(
   }
   if (e < end) {
     const int j0 = col[e];
-    const float4 v0 = ld4(h + (size_t)j0 * HC + c0);
+    const float4 v0 = ldrow4(h + (size_t)j0 * HC + c0);
     const float al0 = expf(gatres_leaky(a_src[j0 * H + hd] + adst) - m) / Z;
     if (leader) alpha[(size_t)e * H + hd] = al0;
     gatres_axpy4(acc, al0, v0);
@@ -122,7 +123,7 @@ __global__ __launch_bounds__(256) void gat_aggregate_fwd_kernel(
   if (RELU) {
     acc.x = fmaxf(acc.x, 0.f); acc.y = fmaxf(acc.y, 0.f); acc.z = fmaxf(acc.z, 0.f); acc.w = fmaxf(acc.w, 0.f);
   }
-  st4(out + (size_t)row * HC + c0, acc);
+  strow4(out + (size_t)row * HC + c0, acc);
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -145,9 +146,10 @@ __device__ __forceinline__ float head_dot(const float4 a, const float4 b, int la
   }
 }
 
+template <typename T>
 __global__ __launch_bounds__(256) void gat_aggregate_bwd_dst_kernel(
-    const int* __restrict__ rowptr, const int* __restrict__ col, const float* __restrict__ g_out,
-    const float* __restrict__ h, const float* __restrict__ alpha, const float* __restrict__ a_src,
+    const int* __restrict__ rowptr, const int* __restrict__ col, const T* __restrict__ g_out,
+    const T* __restrict__ h, const float* __restrict__ alpha, const float* __restrict__ a_src,
     const float* __restrict__ a_dst, float* __restrict__ g_e, float* __restrict__ g_a_dst, int N, RowGeom gm) {
   const int tid = blockIdx.x * 256 + threadIdx.x;
   int row = tid >> gm.lgG;
@@ -158,7 +160,7 @@ __global__ __launch_bounds__(256) void gat_aggregate_bwd_dst_kernel(
   const bool leader = valid && (c0 & (gm.C - 1)) == 0;
   const int H = gm.H, HC = gm.HC, LH = gm.C >> 2;
   const int beg = rowptr[row], end = rowptr[row + 1];
-  const float4 go = ld4(g_out + (size_t)row * HC + c0);
+  const float4 go = ldrow4(g_out + (size_t)row * HC + c0);
   const float adst = a_dst[row * H + hd];
 
   float S = 0.f, gad = 0.f;
@@ -171,7 +173,7 @@ __global__ __launch_bounds__(256) void gat_aggregate_bwd_dst_kernel(
     float al[8], as[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
-      hv[k] = ld4(h + (size_t)jj[k] * HC + c0);
+      hv[k] = ldrow4(h + (size_t)jj[k] * HC + c0);
       al[k] = alpha[(size_t)(beg + min(k, deg - 1)) * H + hd];
       as[k] = a_src[jj[k] * H + hd];
     }
@@ -193,12 +195,12 @@ __global__ __launch_bounds__(256) void gat_aggregate_bwd_dst_kernel(
     }
   } else {                              // hub rows: recompute the dots in the second pass
     for (int e = beg; e < end; ++e) {
-      const float ga = head_dot(go, ld4(h + (size_t)col[e] * HC + c0), LH);
+      const float ga = head_dot(go, ldrow4(h + (size_t)col[e] * HC + c0), LH);
       S = fmaf(alpha[(size_t)e * H + hd], ga, S);
     }
     for (int e = beg; e < end; ++e) {
       const int j = col[e];
-      const float ga = head_dot(go, ld4(h + (size_t)j * HC + c0), LH);
+      const float ga = head_dot(go, ldrow4(h + (size_t)j * HC + c0), LH);
       const float gs = alpha[(size_t)e * H + hd] * (ga - S);
       const float raw = a_src[j * H + hd] + adst;
       const float ge = raw > 0.f ? gs : gs * GATRES_NEG_SLOPE;
@@ -214,11 +216,12 @@ __global__ __launch_bounds__(256) void gat_aggregate_bwd_dst_kernel(
 //   g_a_src[j] = sum_{e out of j} g_e
 //   g_h[j]     = sum_{e=(j->i)} alpha_e * g_out[i]  +  g_a_src[j] (x) att_src  +  g_a_dst[j] (x) att_dst
 // ------------------------------------------------------------------------------------------------------
+template <typename T>
 __global__ __launch_bounds__(256) void gat_aggregate_bwd_src_kernel(
     const int* __restrict__ t_rowptr, const int* __restrict__ t_eid, const int* __restrict__ t_dst,
-    const float* __restrict__ g_out, const float* __restrict__ alpha, const float* __restrict__ g_e,
+    const T* __restrict__ g_out, const float* __restrict__ alpha, const float* __restrict__ g_e,
     const float* __restrict__ g_a_dst, const float* __restrict__ att_src, const float* __restrict__ att_dst,
-    float* __restrict__ g_h, float* __restrict__ g_a_src, int N, RowGeom gm) {
+    T* __restrict__ g_h, float* __restrict__ g_a_src, int N, RowGeom gm) {
   const int tid = blockIdx.x * 256 + threadIdx.x;
   const int row = tid >> gm.lgG;
   if (row >= N) return;
@@ -233,8 +236,8 @@ __global__ __launch_bounds__(256) void gat_aggregate_bwd_src_kernel(
   for (; t + 1 < end; t += 2) {
     const int e0 = t_eid[t], e1 = t_eid[t + 1];
     const int i0 = t_dst[t], i1 = t_dst[t + 1];
-    const float4 v0 = ld4(g_out + (size_t)i0 * HC + c0);
-    const float4 v1 = ld4(g_out + (size_t)i1 * HC + c0);
+    const float4 v0 = ldrow4(g_out + (size_t)i0 * HC + c0);
+    const float4 v1 = ldrow4(g_out + (size_t)i1 * HC + c0);
     const float al0 = alpha[(size_t)e0 * H + hd], al1 = alpha[(size_t)e1 * H + hd];
     gas = gas + g_e[(size_t)e0 * H + hd];
     gas = gas + g_e[(size_t)e1 * H + hd];
@@ -243,7 +246,7 @@ __global__ __launch_bounds__(256) void gat_aggregate_bwd_src_kernel(
   }
   if (t < end) {
     const int e0 = t_eid[t], i0 = t_dst[t];
-    const float4 v0 = ld4(g_out + (size_t)i0 * HC + c0);
+    const float4 v0 = ldrow4(g_out + (size_t)i0 * HC + c0);
     const float al0 = alpha[(size_t)e0 * H + hd];
     gas = gas + g_e[(size_t)e0 * H + hd];
     gatres_axpy4(acc, al0, v0);
@@ -253,15 +256,16 @@ __global__ __launch_bounds__(256) void gat_aggregate_bwd_src_kernel(
   const float4 as = ld4(att_src + c0), ad = ld4(att_dst + c0);
   gatres_axpy4(acc, gas, as);
   gatres_axpy4(acc, gad, ad);
-  st4(g_h + (size_t)row * HC + c0, acc);
+  strow4(g_h + (size_t)row * HC + c0, acc);
 }
 
 // ------------------------------------------------------------------------------------------------------
 // K3: out_i = relu( (sum_{j->i} y[j]) / max(indeg(i),1) + x0_i )       and its backward
 // ------------------------------------------------------------------------------------------------------
+template <typename T>
 __global__ __launch_bounds__(256) void mean_residual_relu_fwd_kernel(
-    const int* __restrict__ rowptr, const int* __restrict__ col, const float* __restrict__ y,
-    const float* __restrict__ x0, float* __restrict__ out, int N, int C, int G, int lgG) {
+    const int* __restrict__ rowptr, const int* __restrict__ col, const T* __restrict__ y,
+    const T* __restrict__ x0, T* __restrict__ out, int N, int C, int G, int lgG) {
   const int tid = blockIdx.x * 256 + threadIdx.x;
   const int row = tid >> lgG;
   if (row >= N) return;
@@ -270,28 +274,29 @@ __global__ __launch_bounds__(256) void mean_residual_relu_fwd_kernel(
   float4 acc = f4zero();
   int e = beg;
   for (; e + 1 < end; e += 2) {
-    const float4 v0 = ld4(y + (size_t)col[e] * C + c0);
-    const float4 v1 = ld4(y + (size_t)col[e + 1] * C + c0);
+    const float4 v0 = ldrow4(y + (size_t)col[e] * C + c0);
+    const float4 v1 = ldrow4(y + (size_t)col[e + 1] * C + c0);
     acc.x = acc.x + v0.x; acc.y = acc.y + v0.y; acc.z = acc.z + v0.z; acc.w = acc.w + v0.w;
     acc.x = acc.x + v1.x; acc.y = acc.y + v1.y; acc.z = acc.z + v1.z; acc.w = acc.w + v1.w;
   }
   if (e < end) {
-    const float4 v0 = ld4(y + (size_t)col[e] * C + c0);
+    const float4 v0 = ldrow4(y + (size_t)col[e] * C + c0);
     acc.x = acc.x + v0.x; acc.y = acc.y + v0.y; acc.z = acc.z + v0.z; acc.w = acc.w + v0.w;
   }
   const float cnt = (float)max(end - beg, 1);
-  const float4 r = ld4(x0 + (size_t)row * C + c0);
+  const float4 r = ldrow4(x0 + (size_t)row * C + c0);
   float4 o;
   o.x = fmaxf(acc.x / cnt + r.x, 0.f);
   o.y = fmaxf(acc.y / cnt + r.y, 0.f);
   o.z = fmaxf(acc.z / cnt + r.z, 0.f);
   o.w = fmaxf(acc.w / cnt + r.w, 0.f);
-  st4(out + (size_t)row * C + c0, o);
+  strow4(out + (size_t)row * C + c0, o);
 }
 
+template <typename T>
 __global__ __launch_bounds__(256) void mean_bwd_kernel(
     const int* __restrict__ m_rowptr, const int* __restrict__ mt_rowptr, const int* __restrict__ mt_dst,
-    const float* __restrict__ g_pre, float* __restrict__ g_y, int N, int C, int G, int lgG) {
+    const T* __restrict__ g_pre, T* __restrict__ g_y, int N, int C, int G, int lgG) {
   const int tid = blockIdx.x * 256 + threadIdx.x;
   const int row = tid >> lgG;
   if (row >= N) return;
@@ -301,10 +306,10 @@ __global__ __launch_bounds__(256) void mean_bwd_kernel(
   for (int t = beg; t < end; ++t) {
     const int i = mt_dst[t];
     const float cnt = (float)max(m_rowptr[i + 1] - m_rowptr[i], 1);
-    const float4 v = ld4(g_pre + (size_t)i * C + c0);
+    const float4 v = ldrow4(g_pre + (size_t)i * C + c0);
     acc.x = acc.x + v.x / cnt; acc.y = acc.y + v.y / cnt; acc.z = acc.z + v.z / cnt; acc.w = acc.w + v.w / cnt;
   }
-  st4(g_y + (size_t)row * C + c0, acc);
+  strow4(g_y + (size_t)row * C + c0, acc);
 }
 
 static inline bool graph_ok(const gatres_graph_t* g) {
@@ -319,41 +324,53 @@ static inline int grid_rows(int N, int G) {
 
 }  // namespace
 
-extern "C" int gatres_gat_aggregate_fwd(const gatres_graph_t* g, const float* h, const float* a_src,
-                                        const float* a_dst, const float* bias, float* out, float* alpha,
-                                        int32_t H, int32_t C, int32_t apply_relu, void* stream) {
+// Typed launchers (gatres_typed.h): `dtype` says what the void* activation tensors hold.  The C-ABI entry points below are
+// their fp32 instances.
+#define GATRES_DISPATCH_T(dtype_, CALL_)                                  \
+  switch (dtype_) {                                                       \
+    case GATRES_DTYPE_F32: { using T = float; CALL_; break; }             \
+    case GATRES_DTYPE_BF16: { using T = gatres_bf16; CALL_; break; }      \
+    default: return GATRES_E_UNSUPPORTED;                                 \
+  }
+
+extern "C" int gatres_t_gat_aggregate_fwd(const gatres_graph_t* g, const void* h, const float* a_src, const float* a_dst,
+                               const float* bias, void* out, float* alpha, int H, int C, int apply_relu, int dtype,
+                               void* stream) {
   if (!graph_ok(g) || !h || !a_src || !a_dst || !bias || !out || !alpha) return GATRES_E_BADARG;
   if (!gatres_aligned16(h) || !gatres_aligned16(out) || !gatres_aligned16(bias)) return GATRES_E_BADARG;
   RowGeom gm;
   if (!make_geom(H, C, &gm)) return GATRES_E_UNSUPPORTED;
   const int N = g->num_nodes;
   dim3 grid(grid_rows(N, gm.G)), block(256);
-  if (apply_relu)
-    hipLaunchKernelGGL(gat_aggregate_fwd_kernel<true>, grid, block, 0, gatres_stream(stream), g->rowptr, g->col, h,
-                       a_src, a_dst, bias, out, alpha, N, gm);
-  else
-    hipLaunchKernelGGL(gat_aggregate_fwd_kernel<false>, grid, block, 0, gatres_stream(stream), g->rowptr, g->col, h,
-                       a_src, a_dst, bias, out, alpha, N, gm);
+  GATRES_DISPATCH_T(dtype, {
+    if (apply_relu)
+      hipLaunchKernelGGL((gat_aggregate_fwd_kernel<true, T>), grid, block, 0, gatres_stream(stream), g->rowptr, g->col,
+                         (const T*)h, a_src, a_dst, bias, (T*)out, alpha, N, gm);
+    else
+      hipLaunchKernelGGL((gat_aggregate_fwd_kernel<false, T>), grid, block, 0, gatres_stream(stream), g->rowptr, g->col,
+                         (const T*)h, a_src, a_dst, bias, (T*)out, alpha, N, gm);
+  })
   return gatres_launch_status();
 }
 
-extern "C" int gatres_gat_aggregate_bwd_dst(const gatres_graph_t* g, const float* g_out, const float* h,
-                                            const float* alpha, const float* a_src, const float* a_dst,
-                                            float* g_e, float* g_a_dst, int32_t H, int32_t C, void* stream) {
+extern "C" int gatres_t_gat_aggregate_bwd_dst(const gatres_graph_t* g, const void* g_out, const void* h, const float* alpha,
+                                   const float* a_src, const float* a_dst, float* g_e, float* g_a_dst, int H, int C,
+                                   int dtype, void* stream) {
   if (!graph_ok(g) || !g_out || !h || !alpha || !a_src || !a_dst || !g_e || !g_a_dst) return GATRES_E_BADARG;
   if (!gatres_aligned16(h) || !gatres_aligned16(g_out)) return GATRES_E_BADARG;
   RowGeom gm;
   if (!make_geom(H, C, &gm)) return GATRES_E_UNSUPPORTED;
   const int N = g->num_nodes;
-  hipLaunchKernelGGL(gat_aggregate_bwd_dst_kernel, dim3(grid_rows(N, gm.G)), dim3(256), 0, gatres_stream(stream),
-                     g->rowptr, g->col, g_out, h, alpha, a_src, a_dst, g_e, g_a_dst, N, gm);
+  GATRES_DISPATCH_T(dtype, {
+    hipLaunchKernelGGL((gat_aggregate_bwd_dst_kernel<T>), dim3(grid_rows(N, gm.G)), dim3(256), 0, gatres_stream(stream),
+                       g->rowptr, g->col, (const T*)g_out, (const T*)h, alpha, a_src, a_dst, g_e, g_a_dst, N, gm);
+  })
   return gatres_launch_status();
 }
 
-extern "C" int gatres_gat_aggregate_bwd_src(const gatres_graph_t* g, const float* g_out, const float* alpha,
-                                            const float* g_e, const float* g_a_dst, const float* att_src,
-                                            const float* att_dst, float* g_h, float* g_a_src, int32_t H,
-                                            int32_t C, void* stream) {
+extern "C" int gatres_t_gat_aggregate_bwd_src(const gatres_graph_t* g, const void* g_out, const float* alpha, const float* g_e,
+                                   const float* g_a_dst, const float* att_src, const float* att_dst, void* g_h,
+                                   float* g_a_src, int H, int C, int dtype, void* stream) {
   if (!graph_ok(g) || !g_out || !alpha || !g_e || !g_a_dst || !att_src || !att_dst || !g_h || !g_a_src)
     return GATRES_E_BADARG;
   if (!gatres_aligned16(g_out) || !gatres_aligned16(g_h) || !gatres_aligned16(att_src) ||
@@ -362,29 +379,64 @@ extern "C" int gatres_gat_aggregate_bwd_src(const gatres_graph_t* g, const float
   RowGeom gm;
   if (!make_geom(H, C, &gm)) return GATRES_E_UNSUPPORTED;
   const int N = g->num_nodes;
-  hipLaunchKernelGGL(gat_aggregate_bwd_src_kernel, dim3(grid_rows(N, gm.G)), dim3(256), 0, gatres_stream(stream),
-                     g->t_rowptr, g->t_eid, g->t_dst, g_out, alpha, g_e, g_a_dst, att_src, att_dst, g_h, g_a_src,
-                     N, gm);
+  GATRES_DISPATCH_T(dtype, {
+    hipLaunchKernelGGL((gat_aggregate_bwd_src_kernel<T>), dim3(grid_rows(N, gm.G)), dim3(256), 0, gatres_stream(stream),
+                       g->t_rowptr, g->t_eid, g->t_dst, (const T*)g_out, alpha, g_e, g_a_dst, att_src, att_dst,
+                       (T*)g_h, g_a_src, N, gm);
+  })
   return gatres_launch_status();
 }
 
-extern "C" int gatres_mean_residual_relu_fwd(const gatres_graph_t* g, const float* y, const float* x0,
-                                             float* out, int32_t C, void* stream) {
+extern "C" int gatres_t_mean_residual_relu_fwd(const gatres_graph_t* g, const void* y, const void* x0, void* out, int C, int dtype,
+                                    void* stream) {
   if (!graph_ok(g) || !y || !x0 || !out) return GATRES_E_BADARG;
   if (!gatres_aligned16(y) || !gatres_aligned16(x0) || !gatres_aligned16(out)) return GATRES_E_BADARG;
   if (C < 4 || !gatres_is_pow2(C) || C > 256) return GATRES_E_UNSUPPORTED;
   const int G = C / 4, N = g->num_nodes;
-  hipLaunchKernelGGL(mean_residual_relu_fwd_kernel, dim3(grid_rows(N, G)), dim3(256), 0, gatres_stream(stream),
-                     g->m_rowptr, g->m_col, y, x0, out, N, C, G, ilog2(G));
+  GATRES_DISPATCH_T(dtype, {
+    hipLaunchKernelGGL((mean_residual_relu_fwd_kernel<T>), dim3(grid_rows(N, G)), dim3(256), 0, gatres_stream(stream),
+                       g->m_rowptr, g->m_col, (const T*)y, (const T*)x0, (T*)out, N, C, G, ilog2(G));
+  })
   return gatres_launch_status();
 }
 
-extern "C" int gatres_mean_bwd(const gatres_graph_t* g, const float* g_pre, float* g_y, int32_t C, void* stream) {
+extern "C" int gatres_t_mean_bwd(const gatres_graph_t* g, const void* g_pre, void* g_y, int C, int dtype, void* stream) {
   if (!graph_ok(g) || !g_pre || !g_y) return GATRES_E_BADARG;
   if (!gatres_aligned16(g_pre) || !gatres_aligned16(g_y)) return GATRES_E_BADARG;
   if (C < 4 || !gatres_is_pow2(C) || C > 256) return GATRES_E_UNSUPPORTED;
   const int G = C / 4, N = g->num_nodes;
-  hipLaunchKernelGGL(mean_bwd_kernel, dim3(grid_rows(N, G)), dim3(256), 0, gatres_stream(stream), g->m_rowptr,
-                     g->mt_rowptr, g->mt_dst, g_pre, g_y, N, C, G, ilog2(G));
+  GATRES_DISPATCH_T(dtype, {
+    hipLaunchKernelGGL((mean_bwd_kernel<T>), dim3(grid_rows(N, G)), dim3(256), 0, gatres_stream(stream), g->m_rowptr,
+                       g->mt_rowptr, g->mt_dst, (const T*)g_pre, (T*)g_y, N, C, G, ilog2(G));
+  })
   return gatres_launch_status();
+}
+
+extern "C" int gatres_gat_aggregate_fwd(const gatres_graph_t* g, const float* h, const float* a_src,
+                                        const float* a_dst, const float* bias, float* out, float* alpha,
+                                        int32_t H, int32_t C, int32_t apply_relu, void* stream) {
+  return gatres_t_gat_aggregate_fwd(g, h, a_src, a_dst, bias, out, alpha, H, C, apply_relu, GATRES_DTYPE_F32, stream);
+}
+
+extern "C" int gatres_gat_aggregate_bwd_dst(const gatres_graph_t* g, const float* g_out, const float* h,
+                                            const float* alpha, const float* a_src, const float* a_dst,
+                                            float* g_e, float* g_a_dst, int32_t H, int32_t C, void* stream) {
+  return gatres_t_gat_aggregate_bwd_dst(g, g_out, h, alpha, a_src, a_dst, g_e, g_a_dst, H, C, GATRES_DTYPE_F32, stream);
+}
+
+extern "C" int gatres_gat_aggregate_bwd_src(const gatres_graph_t* g, const float* g_out, const float* alpha,
+                                            const float* g_e, const float* g_a_dst, const float* att_src,
+                                            const float* att_dst, float* g_h, float* g_a_src, int32_t H,
+                                            int32_t C, void* stream) {
+  return gatres_t_gat_aggregate_bwd_src(g, g_out, alpha, g_e, g_a_dst, att_src, att_dst, g_h, g_a_src, H, C,
+                                        GATRES_DTYPE_F32, stream);
+}
+
+extern "C" int gatres_mean_residual_relu_fwd(const gatres_graph_t* g, const float* y, const float* x0,
+                                             float* out, int32_t C, void* stream) {
+  return gatres_t_mean_residual_relu_fwd(g, y, x0, out, C, GATRES_DTYPE_F32, stream);
+}
+
+extern "C" int gatres_mean_bwd(const gatres_graph_t* g, const float* g_pre, float* g_y, int32_t C, void* stream) {
+  return gatres_t_mean_bwd(g, g_pre, g_y, C, GATRES_DTYPE_F32, stream);
 }

@@ -2669,6 +2669,7 @@ static int launch_fused(const FusedArgs& a, const gatres_graph_t* g, hipStream_t
 extern "C" int gatres_fused_supported(const gatres_model_t* m, const gatres_graph_t* g) {
   if (!m || !g || g->num_segments <= 0 || !g->seg_ptr) return 0;
   if (!(m->nc >= 4 && m->nc <= 128 && gatres_is_pow2(m->nc))) return 0;
+  if (m->act_dtype != GATRES_DTYPE_F32) return 0;        // the per-snapshot kernels are fp32 (the 1e-5 parity path)
   // Wide models (gatres_large, nc = 128): the per-snapshot tables do not fit the LDS, the per-snapshot kernel would
   // run without them at 256 / 512 threads, and the per-op kernels (LDS-staged persistent projections, 256 slabs) are
   // then 1.6-1.8x faster on C-Town batches of 32 .. 128 snapshots.  GATRES_FUSED_WIDE=1 keeps the fused path for them.

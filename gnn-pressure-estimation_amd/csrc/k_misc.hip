@@ -6,6 +6,7 @@
 // their own slab at the parameter's flat offset; gatres_reduce_slabs adds the slabs in index order.  No atomics,
 // bitwise reproducible.
 #include "gatres_common.h"
+#include "gatres_typed.h"
 
 namespace {
 
@@ -15,9 +16,10 @@ static inline int nodes_per_slab(int N, int num_slabs) {
 }
 
 // ---------------------------------------------------------------------------------------------------- lin0
+template <typename T>
 __global__ __launch_bounds__(256) void lin0_fwd_kernel(const float* __restrict__ x, const uint8_t* __restrict__ mask,
                                                        const float* __restrict__ w, const float* __restrict__ b,
-                                                       float* __restrict__ out, int N, int nc4) {
+                                                       T* __restrict__ out, int N, int nc4) {
   const long long tid = (long long)blockIdx.x * 256 + threadIdx.x;
   if (tid >= (long long)N * nc4) return;
   const int n = (int)(tid / nc4), c0 = (int)(tid % nc4) * 4;
@@ -25,11 +27,12 @@ __global__ __launch_bounds__(256) void lin0_fwd_kernel(const float* __restrict__
   const float4 wv = ld4(w + c0), bv = ld4(b + c0);
   float4 o;
   o.x = xv * wv.x + bv.x; o.y = xv * wv.y + bv.y; o.z = xv * wv.z + bv.z; o.w = xv * wv.w + bv.w;
-  st4(out + (size_t)n * nc4 * 4 + c0, o);
+  strow4(out + (size_t)n * nc4 * 4 + c0, o);
 }
 
 // g_w[c] = sum_n g[n,c]*xm[n] ; g_b[c] = sum_n g[n,c]        (one wave per slab, lane = column)
-__global__ __launch_bounds__(64) void lin0_bwd_kernel(const float* __restrict__ g, const float* __restrict__ x,
+template <typename T>
+__global__ __launch_bounds__(64) void lin0_bwd_kernel(const T* __restrict__ g, const float* __restrict__ x,
                                                       const uint8_t* __restrict__ mask, float* __restrict__ slab_w,
                                                       float* __restrict__ slab_b, long long stride, int N, int nc,
                                                       int nps) {
@@ -42,7 +45,7 @@ __global__ __launch_bounds__(64) void lin0_bwd_kernel(const float* __restrict__ 
     for (int cc = 0; cc < 4; ++cc) {
       const int c = lane + 64 * cc;
       if (c < nc) {
-        const float gv = g[(size_t)n * nc + c];
+        const float gv = ldval(g + (size_t)n * nc + c);
         aw[cc] = fmaf(gv, xv, aw[cc]);
         ab[cc] += gv;
       }
@@ -60,7 +63,8 @@ __global__ __launch_bounds__(64) void lin0_bwd_kernel(const float* __restrict__ 
 
 // ---------------------------------------------------------------------------------------------------- lin1
 // out[n] = sum_c x[n,c]*w[c] + b   (G = nc/4 lanes per row)
-__global__ __launch_bounds__(256) void lin1_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+template <typename T>
+__global__ __launch_bounds__(256) void lin1_fwd_kernel(const T* __restrict__ x, const float* __restrict__ w,
                                                        const float* __restrict__ b, float* __restrict__ out, int N,
                                                        int nc, int G, int lgG) {
   const int tid = blockIdx.x * 256 + threadIdx.x;
@@ -68,7 +72,7 @@ __global__ __launch_bounds__(256) void lin1_fwd_kernel(const float* __restrict__
   const bool valid = row < N;
   if (!valid) row = N - 1;
   const int c0 = (tid & (G - 1)) * 4;
-  const float4 xv = ld4(x + (size_t)row * nc + c0), wv = ld4(w + c0);
+  const float4 xv = ldrow4(x + (size_t)row * nc + c0), wv = ld4(w + c0);
   float d = xv.x * wv.x;
   d = fmaf(xv.y, wv.y, d); d = fmaf(xv.z, wv.z, d); d = fmaf(xv.w, wv.w, d);
   for (int off = G >> 1; off > 0; off >>= 1) d += __shfl_xor(d, off);
@@ -76,8 +80,9 @@ __global__ __launch_bounds__(256) void lin1_fwd_kernel(const float* __restrict__
 }
 
 // g_x[n,c] = g_out[n]*w[c] (ReLU-masked by x>0);  slabs: g_w[c] = sum_n g_out[n]*x[n,c], g_b = sum_n g_out[n]
-__global__ __launch_bounds__(64) void lin1_bwd_kernel(const float* __restrict__ g_out, const float* __restrict__ x,
-                                                      const float* __restrict__ w, float* __restrict__ g_x,
+template <typename T>
+__global__ __launch_bounds__(64) void lin1_bwd_kernel(const float* __restrict__ g_out, const T* __restrict__ x,
+                                                      const float* __restrict__ w, T* __restrict__ g_x,
                                                       float* __restrict__ slab_w, float* __restrict__ slab_b,
                                                       long long stride, int N, int nc, int nps, int relu_mask) {
   const int s = blockIdx.x, lane = threadIdx.x;
@@ -93,9 +98,9 @@ __global__ __launch_bounds__(64) void lin1_bwd_kernel(const float* __restrict__ 
     for (int cc = 0; cc < 4; ++cc) {
       const int c = lane + 64 * cc;
       if (c < nc) {
-        const float xv = x[(size_t)n * nc + c];
+        const float xv = ldval(x + (size_t)n * nc + c);
         aw[cc] = fmaf(go, xv, aw[cc]);
-        g_x[(size_t)n * nc + c] = (relu_mask && !(xv > 0.f)) ? 0.f : go * wv[cc];
+        stval(g_x + (size_t)n * nc + c, (relu_mask && !(xv > 0.f)) ? 0.f : go * wv[cc]);
       }
     }
   }
@@ -112,9 +117,10 @@ __global__ __launch_bounds__(64) void lin1_bwd_kernel(const float* __restrict__ 
 // One workgroup of four waves per slab: wave w takes rows nbeg + w, nbeg + w + 4, ... with four rows in flight (a
 // single wave walking its rows one dependent load at a time ran at 0.4 TB/s on 100k-row graphs); the four partial
 // sums meet in LDS in wave order, so the result is deterministic.
+template <typename T>
 __global__ __launch_bounds__(256) void conv_param_grads_kernel(
-    const float* __restrict__ h, const float* __restrict__ g_a_src, const float* __restrict__ g_a_dst,
-    const float* __restrict__ g_out, float* __restrict__ slab_as, float* __restrict__ slab_ad,
+    const T* __restrict__ h, const float* __restrict__ g_a_src, const float* __restrict__ g_a_dst,
+    const T* __restrict__ g_out, float* __restrict__ slab_as, float* __restrict__ slab_ad,
     float* __restrict__ slab_b, long long stride, int N, int H, int C, int nps) {
   __shared__ float part[3][3][256];                 // [as|ad|ab][waves 1..3][column]
   const int s = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -133,8 +139,8 @@ __global__ __launch_bounds__(256) void conv_param_grads_kernel(
         const int c = lane + 64 * cc;
         const bool cok = ok && c < HC;
         const int ci = c < HC ? c : 0;
-        hv[u][cc] = cok ? h[(size_t)nn * HC + ci] : 0.f;
-        go[u][cc] = cok ? g_out[(size_t)nn * HC + ci] : 0.f;
+        hv[u][cc] = cok ? ldval(h + (size_t)nn * HC + ci) : 0.f;
+        go[u][cc] = cok ? ldval(g_out + (size_t)nn * HC + ci) : 0.f;
         gs[u][cc] = cok ? g_a_src[nn * H + ci / C] : 0.f;
         gd[u][cc] = cok ? g_a_dst[nn * H + ci / C] : 0.f;
       }
@@ -167,6 +173,71 @@ __global__ __launch_bounds__(256) void conv_param_grads_kernel(
         slab_b[(size_t)s * stride + c] = ((ab[cc] + part[2][0][c]) + part[2][1][c]) + part[2][2][c];
       }
     }
+  }
+}
+
+// bf16 tables: a lane owns TWO adjacent columns (one 4-byte load per row and table instead of two 2-byte ones: the
+// 2-byte form ran 3x slower than the fp32 kernel on gatres_large).  Column sums do not depend on which lane forms them.
+__global__ __launch_bounds__(256) void conv_param_grads_bf16_kernel(
+    const gatres_bf16* __restrict__ h, const float* __restrict__ g_a_src, const float* __restrict__ g_a_dst,
+    const gatres_bf16* __restrict__ g_out, float* __restrict__ slab_as, float* __restrict__ slab_ad,
+    float* __restrict__ slab_b, long long stride, int N, int H, int C, int nps) {
+  __shared__ float part[3][3][256];                 // [as|ad|ab][waves 1..3][column]
+  const int s = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int HC = H * C;
+  const int nbeg = s * nps, nend = min(N, nbeg + nps);
+  float as[2][2] = {{0.f, 0.f}, {0.f, 0.f}}, ad[2][2] = {{0.f, 0.f}, {0.f, 0.f}}, ab[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
+  for (int n0 = nbeg + wave; n0 < nend; n0 += 32) {
+    unsigned hv[8][2], go[8][2];
+    float gs[8][2], gd[8][2];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int n = n0 + 4 * u;
+      const bool ok = n < nend;
+      const int nn = ok ? n : nbeg;
+#pragma unroll
+      for (int cc = 0; cc < 2; ++cc) {
+        const int c = 2 * lane + 128 * cc;
+        const bool cok = ok && c < HC;
+        const int ci = c < HC ? c : 0;
+        hv[u][cc] = cok ? *reinterpret_cast<const unsigned*>(h + (size_t)nn * HC + ci) : 0u;
+        go[u][cc] = cok ? *reinterpret_cast<const unsigned*>(g_out + (size_t)nn * HC + ci) : 0u;
+        gs[u][cc] = cok ? g_a_src[nn * H + ci / C] : 0.f;
+        gd[u][cc] = cok ? g_a_dst[nn * H + ci / C] : 0.f;
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+#pragma unroll
+      for (int cc = 0; cc < 2; ++cc) {
+        const float h0 = __uint_as_float(hv[u][cc] << 16), h1 = __uint_as_float(hv[u][cc] & 0xffff0000u);
+        as[cc][0] = fmaf(gs[u][cc], h0, as[cc][0]); as[cc][1] = fmaf(gs[u][cc], h1, as[cc][1]);
+        ad[cc][0] = fmaf(gd[u][cc], h0, ad[cc][0]); ad[cc][1] = fmaf(gd[u][cc], h1, ad[cc][1]);
+        ab[cc][0] += __uint_as_float(go[u][cc] << 16); ab[cc][1] += __uint_as_float(go[u][cc] & 0xffff0000u);
+      }
+  }
+  if (wave > 0) {
+#pragma unroll
+    for (int cc = 0; cc < 2; ++cc)
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        const int c = 2 * lane + 128 * cc + e;
+        part[0][wave - 1][c] = as[cc][e]; part[1][wave - 1][c] = ad[cc][e]; part[2][wave - 1][c] = ab[cc][e];
+      }
+  }
+  __syncthreads();
+  if (wave == 0) {
+#pragma unroll
+    for (int cc = 0; cc < 2; ++cc)
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        const int c = 2 * lane + 128 * cc + e;
+        if (c < HC) {
+          slab_as[(size_t)s * stride + c] = ((as[cc][e] + part[0][0][c]) + part[0][1][c]) + part[0][2][c];
+          slab_ad[(size_t)s * stride + c] = ((ad[cc][e] + part[1][0][c]) + part[1][1][c]) + part[1][2][c];
+          slab_b[(size_t)s * stride + c] = ((ab[cc][e] + part[2][0][c]) + part[2][1][c]) + part[2][2][c];
+        }
+      }
   }
 }
 
@@ -204,6 +275,26 @@ __global__ __launch_bounds__(256) void transpose_conv_weights_kernel(const float
   const int rows = conv == 0 ? 2 * nc : nc, cols = conv == 0 ? nc : 2 * nc;
   const int orow = e / rows, ocol = e % rows;        // output is [cols, rows]
   wt[(size_t)b * 2 * per + (size_t)conv * per + e] = W[(size_t)ocol * cols + orow];
+}
+
+// bf16 operand copies of the GATConv weights for the bf16 projections: per block [W1 | W2 | W1^T | W2^T], each 2nc^2 bf16
+__global__ __launch_bounds__(256) void convert_conv_weights_bf16_kernel(const float* __restrict__ params,
+                                                                        gatres_bf16* __restrict__ wb, int num_blocks,
+                                                                        int nc) {
+  const int per = 2 * nc * nc;
+  const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (long long)num_blocks * 4 * per) return;
+  const int b = (int)(idx / (4 * per));
+  const int r = (int)(idx % (4 * per));
+  const int which = r / per, e = r % per;                // 0: W1, 1: W2, 2: W1^T, 3: W2^T
+  const int conv = which & 1;
+  const long long blk = 2LL * nc + (long long)b * (9LL * nc + 4LL * nc * nc);
+  const float* W = params + blk + (conv == 0 ? 6LL * nc : 6LL * nc + per + 3LL * nc);
+  const int rows = conv == 0 ? 2 * nc : nc, cols = conv == 0 ? nc : 2 * nc;     // W is [rows, cols]
+  float v;
+  if (which < 2) v = W[e];
+  else { const int orow = e / rows, ocol = e % rows; v = W[(size_t)ocol * cols + orow]; }      // output [cols, rows]
+  wb[(size_t)b * 4 * per + (size_t)which * per + e] = (gatres_bf16)v;
 }
 
 // ------------------------------------------------------------------------------------- node relabelling
@@ -388,28 +479,47 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
 
 }  // namespace
 
-extern "C" int gatres_lin0_fwd(const float* x, const uint8_t* mask, const float* w, const float* b, float* out,
-                               int32_t num_nodes, int32_t nc, void* stream) {
+#define GATRES_DISPATCH_T(dtype_, CALL_)                                  \
+  switch (dtype_) {                                                       \
+    case GATRES_DTYPE_F32: { using T = float; CALL_; break; }             \
+    case GATRES_DTYPE_BF16: { using T = gatres_bf16; CALL_; break; }      \
+    default: return GATRES_E_UNSUPPORTED;                                 \
+  }
+
+extern "C" int gatres_t_lin0_fwd(const float* x, const uint8_t* mask, const float* w, const float* b, void* out, int num_nodes, int nc,
+                      int dtype, void* stream) {
   if (!x || !w || !b || !out || num_nodes <= 0) return GATRES_E_BADARG;
   if (nc < 4 || nc % 4) return GATRES_E_UNSUPPORTED;
   if (!gatres_aligned16(w) || !gatres_aligned16(b) || !gatres_aligned16(out)) return GATRES_E_BADARG;
   const long long total = (long long)num_nodes * (nc / 4);
-  hipLaunchKernelGGL(lin0_fwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, gatres_stream(stream), x,
-                     mask, w, b, out, num_nodes, nc / 4);
+  GATRES_DISPATCH_T(dtype, {
+    hipLaunchKernelGGL((lin0_fwd_kernel<T>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, gatres_stream(stream), x,
+                       mask, w, b, (T*)out, num_nodes, nc / 4);
+  })
   return gatres_launch_status();
 }
+extern "C" int gatres_lin0_fwd(const float* x, const uint8_t* mask, const float* w, const float* b, float* out,
+                               int32_t num_nodes, int32_t nc, void* stream) {
+  return gatres_t_lin0_fwd(x, mask, w, b, out, num_nodes, nc, GATRES_DTYPE_F32, stream);
+}
 
-extern "C" int gatres_lin0_bwd(const float* g, const float* x, const uint8_t* mask, float* slab_w, float* slab_b,
-                               int32_t num_slabs, int64_t slab_stride, int32_t num_nodes, int32_t nc, void* stream) {
+extern "C" int gatres_t_lin0_bwd(const void* g, const float* x, const uint8_t* mask, float* slab_w, float* slab_b, int num_slabs,
+                      int64_t slab_stride, int num_nodes, int nc, int dtype, void* stream) {
   if (!g || !x || !slab_w || !slab_b || num_nodes <= 0 || num_slabs <= 0) return GATRES_E_BADARG;
   if (nc < 1 || nc > 256) return GATRES_E_UNSUPPORTED;
-  hipLaunchKernelGGL(lin0_bwd_kernel, dim3(num_slabs), dim3(64), 0, gatres_stream(stream), g, x, mask, slab_w, slab_b,
-                     (long long)slab_stride, num_nodes, nc, nodes_per_slab(num_nodes, num_slabs));
+  GATRES_DISPATCH_T(dtype, {
+    hipLaunchKernelGGL((lin0_bwd_kernel<T>), dim3(num_slabs), dim3(64), 0, gatres_stream(stream), (const T*)g, x, mask,
+                       slab_w, slab_b, (long long)slab_stride, num_nodes, nc, nodes_per_slab(num_nodes, num_slabs));
+  })
   return gatres_launch_status();
 }
+extern "C" int gatres_lin0_bwd(const float* g, const float* x, const uint8_t* mask, float* slab_w, float* slab_b,
+                               int32_t num_slabs, int64_t slab_stride, int32_t num_nodes, int32_t nc, void* stream) {
+  return gatres_t_lin0_bwd(g, x, mask, slab_w, slab_b, num_slabs, slab_stride, num_nodes, nc, GATRES_DTYPE_F32, stream);
+}
 
-extern "C" int gatres_lin1_fwd(const float* x, const float* w, const float* b, float* out, int32_t num_nodes,
-                               int32_t nc, void* stream) {
+extern "C" int gatres_t_lin1_fwd(const void* x, const float* w, const float* b, float* out, int num_nodes, int nc, int dtype,
+                      void* stream) {
   if (!x || !w || !out || num_nodes <= 0) return GATRES_E_BADARG;
   if (nc < 4 || !gatres_is_pow2(nc) || nc > 256) return GATRES_E_UNSUPPORTED;
   if (!gatres_aligned16(x) || !gatres_aligned16(w)) return GATRES_E_BADARG;
@@ -417,32 +527,69 @@ extern "C" int gatres_lin1_fwd(const float* x, const float* w, const float* b, f
   int lgG = 0;
   while ((1 << lgG) < G) ++lgG;
   const long long threads = (long long)num_nodes * G;
-  hipLaunchKernelGGL(lin1_fwd_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, gatres_stream(stream), x,
-                     w, b, out, num_nodes, nc, G, lgG);
+  GATRES_DISPATCH_T(dtype, {
+    hipLaunchKernelGGL((lin1_fwd_kernel<T>), dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, gatres_stream(stream),
+                       (const T*)x, w, b, out, num_nodes, nc, G, lgG);
+  })
   return gatres_launch_status();
 }
+extern "C" int gatres_lin1_fwd(const float* x, const float* w, const float* b, float* out, int32_t num_nodes,
+                               int32_t nc, void* stream) {
+  return gatres_t_lin1_fwd(x, w, b, out, num_nodes, nc, GATRES_DTYPE_F32, stream);
+}
 
+extern "C" int gatres_t_lin1_bwd(const float* g_out, const void* x, const float* w, void* g_x, float* slab_w, float* slab_b,
+                      int num_slabs, int64_t slab_stride, int num_nodes, int nc, int relu_mask, int dtype, void* stream) {
+  if (!g_out || !x || !w || !g_x || !slab_w || !slab_b || num_nodes <= 0 || num_slabs <= 0) return GATRES_E_BADARG;
+  if (nc < 1 || nc > 256) return GATRES_E_UNSUPPORTED;
+  GATRES_DISPATCH_T(dtype, {
+    hipLaunchKernelGGL((lin1_bwd_kernel<T>), dim3(num_slabs), dim3(64), 0, gatres_stream(stream), g_out, (const T*)x, w,
+                       (T*)g_x, slab_w, slab_b, (long long)slab_stride, num_nodes, nc,
+                       nodes_per_slab(num_nodes, num_slabs), relu_mask);
+  })
+  return gatres_launch_status();
+}
 extern "C" int gatres_lin1_bwd(const float* g_out, const float* x, const float* w, float* g_x, float* slab_w,
                                float* slab_b, int32_t num_slabs, int64_t slab_stride, int32_t num_nodes, int32_t nc,
                                int32_t relu_mask, void* stream) {
-  if (!g_out || !x || !w || !g_x || !slab_w || !slab_b || num_nodes <= 0 || num_slabs <= 0) return GATRES_E_BADARG;
-  if (nc < 1 || nc > 256) return GATRES_E_UNSUPPORTED;
-  hipLaunchKernelGGL(lin1_bwd_kernel, dim3(num_slabs), dim3(64), 0, gatres_stream(stream), g_out, x, w, g_x, slab_w,
-                     slab_b, (long long)slab_stride, num_nodes, nc, nodes_per_slab(num_nodes, num_slabs), relu_mask);
-  return gatres_launch_status();
+  return gatres_t_lin1_bwd(g_out, x, w, g_x, slab_w, slab_b, num_slabs, slab_stride, num_nodes, nc, relu_mask,
+                           GATRES_DTYPE_F32, stream);
 }
 
-extern "C" int gatres_conv_param_grads(const float* h, const float* g_a_src, const float* g_a_dst,
-                                       const float* g_out, float* slab_att_src, float* slab_att_dst,
-                                       float* slab_bias, int32_t num_slabs, int64_t slab_stride, int32_t num_nodes,
-                                       int32_t H, int32_t C, void* stream) {
+extern "C" int gatres_t_conv_param_grads(const void* h, const float* g_a_src, const float* g_a_dst, const void* g_out,
+                              float* slab_att_src, float* slab_att_dst, float* slab_bias, int num_slabs,
+                              int64_t slab_stride, int num_nodes, int H, int C, int dtype, void* stream) {
   if (!h || !g_a_src || !g_a_dst || !g_out || !slab_att_src || !slab_att_dst || !slab_bias || num_nodes <= 0 ||
       num_slabs <= 0)
     return GATRES_E_BADARG;
   if (H < 1 || C < 1 || H * C > 256) return GATRES_E_UNSUPPORTED;
-  hipLaunchKernelGGL(conv_param_grads_kernel, dim3(num_slabs), dim3(256), 0, gatres_stream(stream), h, g_a_src, g_a_dst,
-                     g_out, slab_att_src, slab_att_dst, slab_bias, (long long)slab_stride, num_nodes, H, C,
-                     nodes_per_slab(num_nodes, num_slabs));
+  if (dtype == GATRES_DTYPE_BF16) {
+    if ((H * C) % 2 || C % 2) return GATRES_E_UNSUPPORTED;
+    hipLaunchKernelGGL(conv_param_grads_bf16_kernel, dim3(num_slabs), dim3(256), 0, gatres_stream(stream),
+                       (const gatres_bf16*)h, g_a_src, g_a_dst, (const gatres_bf16*)g_out, slab_att_src, slab_att_dst,
+                       slab_bias, (long long)slab_stride, num_nodes, H, C, nodes_per_slab(num_nodes, num_slabs));
+    return gatres_launch_status();
+  }
+  if (dtype != GATRES_DTYPE_F32) return GATRES_E_UNSUPPORTED;
+  hipLaunchKernelGGL((conv_param_grads_kernel<float>), dim3(num_slabs), dim3(256), 0, gatres_stream(stream),
+                     (const float*)h, g_a_src, g_a_dst, (const float*)g_out, slab_att_src, slab_att_dst, slab_bias,
+                     (long long)slab_stride, num_nodes, H, C, nodes_per_slab(num_nodes, num_slabs));
+  return gatres_launch_status();
+}
+extern "C" int gatres_conv_param_grads(const float* h, const float* g_a_src, const float* g_a_dst,
+                                       const float* g_out, float* slab_att_src, float* slab_att_dst,
+                                       float* slab_bias, int32_t num_slabs, int64_t slab_stride, int32_t num_nodes,
+                                       int32_t H, int32_t C, void* stream) {
+  return gatres_t_conv_param_grads(h, g_a_src, g_a_dst, g_out, slab_att_src, slab_att_dst, slab_bias, num_slabs,
+                                   slab_stride, num_nodes, H, C, GATRES_DTYPE_F32, stream);
+}
+
+extern "C" int gatres_convert_conv_weights_bf16(const float* params, void* wb, int num_blocks, int nc, void* stream) {
+  if (!params || !wb || num_blocks < 0 || nc < 1) return GATRES_E_BADARG;
+  if (num_blocks == 0) return 0;
+  const long long total = (long long)num_blocks * 8 * nc * nc;
+  hipLaunchKernelGGL(convert_conv_weights_bf16_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
+                     gatres_stream(stream), params, (gatres_bf16*)wb, num_blocks, nc);
   return gatres_launch_status();
 }
 

@@ -17,6 +17,7 @@
 #include <cstdlib>
 
 #include "gatres_common.h"
+#include "gatres_typed.h"
 
 namespace {
 
@@ -258,9 +259,34 @@ __device__ __forceinline__ void load_vec(const float* __restrict__ p, bool ok, f
   }
   load_frag<V>(p, f);
 }
+template <int V>
+__device__ __forceinline__ void load_vec(const gatres_bf16* __restrict__ p, bool ok, float (&f)[V]) {
+  if (!ok) {
+#pragma unroll
+    for (int v = 0; v < V; ++v) f[v] = 0.f;
+    return;
+  }
+  if constexpr (V % 4 == 0) {
+#pragma unroll
+    for (int v = 0; v < V; v += 4) {
+      const float4 x = ldrow4(p + v);
+      f[v] = x.x; f[v + 1] = x.y; f[v + 2] = x.z; f[v + 3] = x.w;
+    }
+  } else if constexpr (V % 2 == 0) {
+#pragma unroll
+    for (int v = 0; v < V; v += 2) {
+      const unsigned u = *reinterpret_cast<const unsigned*>(p + v);
+      f[v] = __uint_as_float(u << 16); f[v + 1] = __uint_as_float(u & 0xffff0000u);
+    }
+  } else {
+#pragma unroll
+    for (int v = 0; v < V; ++v) f[v] = (float)p[v];
+  }
+}
 
-template <int HC, int K>
-__global__ __launch_bounds__(256) void dw_kernel(const float* __restrict__ G, const float* __restrict__ X,
+// (T: storage type of G and X; the products and the slab stay fp32 -- v_mfma_f32_16x16x4_f32 on widened operands)
+template <int HC, int K, typename T>
+__global__ __launch_bounds__(256) void dw_kernel(const T* __restrict__ G, const T* __restrict__ X,
                                                  float* __restrict__ slab, int num_slabs, long long slab_stride,
                                                  int N, int nodes_per_slab) {
   constexpr int CB = HC < 64 ? (HC < 16 ? 16 : HC) : 64;   // rows of g_W per wave
@@ -319,6 +345,161 @@ __global__ __launch_bounds__(256) void dw_kernel(const float* __restrict__ G, co
     }
 }
 
+// ------------------------------------------------------------------------------------------------------
+// bf16 projections (gatres_model_t.act_dtype == GATRES_DTYPE_BF16; BASELINE config 3): X, W, OUT (and resid / relu_ref)
+// are bf16 in HBM, the products run on v_mfma_f32_16x16x32_bf16 with fp32 accumulators, the attention logits are taken
+// from the fp32 accumulators BEFORE the output is rounded.  Same transposed formulation as above (D = W . X^T: a lane
+// owns one node and four consecutive output features per 16-row output tile), so the epilogues carry over; per k step of
+// 32 a lane feeds 8 consecutive k of its W row (A operand, LDS) and 8 consecutive k of its node's row (B operand, one
+// 16-byte global load).  Persistent workgroups stage W once in LDS with rows padded by 16 bytes (row stride K*2 + 16:
+// the 16 lanes of a ds_read_b128 group land on 16 different 16-byte slots).  At 16x the fp32 matrix rate the kernel is
+// memory-bound: x is read once, W once per workgroup, h written once.
+// ------------------------------------------------------------------------------------------------------
+typedef gatres_bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+// Feature permutation inside the kernel: output tile t, accumulator row 4*qq + reg  <->  feature qq*(M/4) + 4*t + reg,
+// i.e. lane group q owns the CONTIGUOUS quarter [q*M/4, (q+1)*M/4) of a node's output row and consecutive tiles are
+// consecutive 4-feature pieces of it: two tiles make one 16-byte bf16 store, the four lane groups of a node write a whole
+// row between them (with the natural map, feature 16*t + 4*q + reg, every store was an 8-byte piece 32 bytes apart).
+// The permutation is applied where W rows are picked for the A operand; the arithmetic per output is unchanged.
+template <int K, int M, int H, int EPI>
+__global__ __launch_bounds__(256) void proj_bf16_kernel(const gatres_bf16* __restrict__ X,
+                                                        const gatres_bf16* __restrict__ Wm,
+                                                        gatres_bf16* __restrict__ OUT, int N,
+                                                        const float* __restrict__ att_src,
+                                                        const float* __restrict__ att_dst, float* __restrict__ a_src,
+                                                        float* __restrict__ a_dst, const gatres_bf16* __restrict__ resid,
+                                                        const gatres_bf16* __restrict__ relu_ref, int rows_per_wg) {
+  constexpr int KS = K / 32, NT = M / 16, KP = K + 8, MQ = M / 4;  // K, M multiples of 32 here; NT even
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  gatres_bf16* wl = reinterpret_cast<gatres_bf16*>(smem);
+  float* attl = reinterpret_cast<float*>(smem + (size_t)M * KP * 2);
+  // LDS row 16*t + i holds W row (i>>2)*MQ + 4*t + (i&3): the permutation is applied while staging, so the 16 lanes of an
+  // A-operand read touch 16 CONSECUTIVE LDS rows (stride K*2 + 16 bytes: conflict-free)
+  for (int idx = threadIdx.x; idx < M * (K / 8); idx += 256) {
+    const int l = idx / (K / 8), k8 = (idx % (K / 8)) * 8;
+    const int t = l >> 4, ii = l & 15;
+    const int m = (ii >> 2) * MQ + 4 * t + (ii & 3);
+    *reinterpret_cast<uint4*>(wl + l * KP + k8) = *reinterpret_cast<const uint4*>(Wm + (size_t)m * K + k8);
+  }
+  if constexpr (EPI == EPI_ATT) {
+    for (int idx = threadIdx.x; idx < 2 * (M / 4); idx += 256) {
+      const int which = idx / (M / 4), c4 = (idx % (M / 4)) * 4;
+      st4(attl + which * M + c4, ld4((which ? att_dst : att_src) + c4));
+    }
+  }
+  __syncthreads();
+  const float* attS = attl;
+  const float* attD = attl + M;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int i = lane & 15, q = lane >> 4;
+  const int r0 = blockIdx.x * rows_per_wg, r1 = min(N, r0 + rows_per_wg);
+  bf16x8 xf[KS], xn[KS];
+  auto load_x = [&](int n, bf16x8 (&f)[KS]) {
+    const gatres_bf16* p = X + (size_t)n * K + q * 8;
+#pragma unroll
+    for (int s = 0; s < KS; ++s) f[s] = *reinterpret_cast<const bf16x8*>(p + s * 32);
+  };
+  if (r0 + wave * 16 < r1) load_x(min(r0 + wave * 16 + i, r1 - 1), xf);
+  for (int n0 = r0 + wave * 16; n0 < r1; n0 += 64) {
+    const int n = n0 + i;
+    const bool nok = n < r1;
+    if (n0 + 64 < r1) load_x(min(n + 64, r1 - 1), xn);          // next tile's rows in flight behind this tile's MFMAs
+    f32x4 acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        const bf16x8 wf = *reinterpret_cast<const bf16x8*>(wl + (t * 16 + i) * KP + s * 32 + q * 8);
+        acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, xf[s], acc[t], 0, 0, 0);
+      }
+    }
+    // acc[t][reg] = output feature q*MQ + 4*t + reg of node n
+    if constexpr (EPI == EPI_ATT) {
+      constexpr int C = M / H;
+      float ps[H], pd[H];
+#pragma unroll
+      for (int hh = 0; hh < H; ++hh) { ps[hh] = 0.f; pd[hh] = 0.f; }
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        const int mb = q * MQ + 4 * t;
+        const float4 as = ld4(attS + mb), ad = ld4(attD + mb);
+        const float ds = fmaf(acc[t][3], as.w, fmaf(acc[t][2], as.z, fmaf(acc[t][1], as.y, acc[t][0] * as.x)));
+        const float dd = fmaf(acc[t][3], ad.w, fmaf(acc[t][2], ad.z, fmaf(acc[t][1], ad.y, acc[t][0] * ad.x)));
+        const int hd = mb / C;               // (a lane group's quarter row lies inside one head: H <= 4)
+#pragma unroll
+        for (int hh = 0; hh < H; ++hh)
+          if (hh == hd) { ps[hh] += ds; pd[hh] += dd; }
+      }
+#pragma unroll
+      for (int hh = 0; hh < H; ++hh) {
+        ps[hh] += __shfl_xor(ps[hh], 16); ps[hh] += __shfl_xor(ps[hh], 32);
+        pd[hh] += __shfl_xor(pd[hh], 16); pd[hh] += __shfl_xor(pd[hh], 32);
+      }
+      if (q == 0 && nok) {
+#pragma unroll
+        for (int hh = 0; hh < H; ++hh) { a_src[n * H + hh] = ps[hh]; a_dst[n * H + hh] = pd[hh]; }
+      }
+    }
+    if (nok) {
+#pragma unroll
+      for (int t = 0; t < NT; t += 2) {
+        const int mb = q * MQ + 4 * t;               // 8 consecutive features: tiles t and t + 1
+        float4 o0 = make_float4(acc[t][0], acc[t][1], acc[t][2], acc[t][3]);
+        float4 o1 = make_float4(acc[t + 1][0], acc[t + 1][1], acc[t + 1][2], acc[t + 1][3]);
+        if constexpr (EPI == EPI_RESID_MASK) {
+          if (resid) {
+            const float4 ra = ldrow4(resid + (size_t)n * M + mb), rb = ldrow4(resid + (size_t)n * M + mb + 4);
+            o0.x += ra.x; o0.y += ra.y; o0.z += ra.z; o0.w += ra.w;
+            o1.x += rb.x; o1.y += rb.y; o1.z += rb.z; o1.w += rb.w;
+          }
+          if (relu_ref) {
+            const float4 ra = ldrow4(relu_ref + (size_t)n * M + mb), rb = ldrow4(relu_ref + (size_t)n * M + mb + 4);
+            o0.x = ra.x > 0.f ? o0.x : 0.f; o0.y = ra.y > 0.f ? o0.y : 0.f;
+            o0.z = ra.z > 0.f ? o0.z : 0.f; o0.w = ra.w > 0.f ? o0.w : 0.f;
+            o1.x = rb.x > 0.f ? o1.x : 0.f; o1.y = rb.y > 0.f ? o1.y : 0.f;
+            o1.z = rb.z > 0.f ? o1.z : 0.f; o1.w = rb.w > 0.f ? o1.w : 0.f;
+          }
+        }
+        bf16x8 ob;
+        ob[0] = (gatres_bf16)o0.x; ob[1] = (gatres_bf16)o0.y; ob[2] = (gatres_bf16)o0.z; ob[3] = (gatres_bf16)o0.w;
+        ob[4] = (gatres_bf16)o1.x; ob[5] = (gatres_bf16)o1.y; ob[6] = (gatres_bf16)o1.z; ob[7] = (gatres_bf16)o1.w;
+        *reinterpret_cast<bf16x8*>(OUT + (size_t)n * M + mb) = ob;
+      }
+    }
+#pragma unroll
+    for (int s = 0; s < KS; ++s) xf[s] = xn[s];
+  }
+}
+
+template <int K, int M, int H, int EPI>
+int launch_proj_bf16(const gatres_bf16* X, const gatres_bf16* Wm, gatres_bf16* OUT, int N, const float* att_src,
+                     const float* att_dst, float* a_src, float* a_dst, const gatres_bf16* resid,
+                     const gatres_bf16* relu_ref, hipStream_t st) {
+  if constexpr (K % 32 == 0 && M % 32 == 0 && (H == 1 || H == 2 || H == 4)) {   // (a lane group's quarter row inside one head)
+    constexpr size_t lds = (size_t)M * (K + 8) * 2 + 2 * M * 4;
+    static bool attr_set = false;
+    if (!attr_set) {
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(&proj_bf16_kernel<K, M, H, EPI>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        (void)hipGetLastError();
+      attr_set = true;
+    }
+    // persistent workgroups: W staging must amortise over many 16-row tiles, and small batches still want every CU
+    int grid = (N + 63) / 64;
+    if (grid > 512) grid = 512;
+    int rows = (N + grid - 1) / grid;
+    rows = (rows + 63) & ~63;
+    hipLaunchKernelGGL((proj_bf16_kernel<K, M, H, EPI>), dim3((N + rows - 1) / rows), dim3(256), lds, st, X, Wm, OUT, N,
+                       att_src, att_dst, a_src, a_dst, resid, relu_ref, rows);
+    return gatres_launch_status();
+  } else {
+    return GATRES_E_UNSUPPORTED;      // bf16 MFMA needs a reduction length that is a multiple of 32 (nc >= 32)
+  }
+}
+
 template <int K, int M, int H, int EPI>
 int launch_proj(const float* X, const float* Wm, float* OUT, int N, const float* att_src, const float* att_dst,
                 float* a_src, float* a_dst, const float* resid, const float* relu_ref, hipStream_t st) {
@@ -338,15 +519,15 @@ int launch_proj(const float* X, const float* Wm, float* OUT, int N, const float*
   return gatres_launch_status();
 }
 
-template <int HC, int K>
-int launch_dw(const float* G, const float* X, float* slab, int num_slabs, long long stride, int N, hipStream_t st) {
+template <int HC, int K, typename T>
+int launch_dw(const T* G, const T* X, float* slab, int num_slabs, long long stride, int N, hipStream_t st) {
   constexpr int CB = HC < 64 ? (HC < 16 ? 16 : HC) : 64;
   constexpr int KB = K < 64 ? (K < 16 ? 16 : K) : 64;
   constexpr int NBLK = ((HC + CB - 1) / CB) * ((K + KB - 1) / KB);
   int nps = (N + num_slabs - 1) / num_slabs;
   nps = (nps + 3) & ~3;
   const long long waves = (long long)num_slabs * NBLK;
-  hipLaunchKernelGGL((dw_kernel<HC, K>), dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, st, G, X, slab, num_slabs,
+  hipLaunchKernelGGL((dw_kernel<HC, K, T>), dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, st, G, X, slab, num_slabs,
                      stride, N, nps);
   return gatres_launch_status();
 }
@@ -358,52 +539,103 @@ int launch_dw(const float* G, const float* X, float* slab, int num_slabs, long l
   X_(4, 8) X_(8, 4) X_(8, 16) X_(16, 8) X_(16, 32) X_(32, 16) X_(32, 64) X_(64, 32) X_(64, 128)   \
   X_(128, 64) X_(128, 256) X_(256, 128)
 
-extern "C" int gatres_proj_attn_fwd(const float* x, const float* W, const float* att_src, const float* att_dst,
-                                    float* h, float* a_src, float* a_dst, int32_t num_nodes, int32_t K, int32_t H,
-                                    int32_t C, void* stream) {
+extern "C" int gatres_t_proj_attn_fwd(const void* x, const void* W, const float* att_src, const float* att_dst, void* h, float* a_src,
+                           float* a_dst, int num_nodes, int K, int H, int C, int dtype, void* stream) {
   if (!x || !W || !att_src || !att_dst || !h || !a_src || !a_dst || num_nodes <= 0) return GATRES_E_BADARG;
   if (!gatres_aligned16(x) || !gatres_aligned16(W) || !gatres_aligned16(h) || !gatres_aligned16(att_src) ||
       !gatres_aligned16(att_dst))
     return GATRES_E_BADARG;
   const int M = H * C;
   hipStream_t st = gatres_stream(stream);
-#define CASE_(K_, M_)                                                                                         \
-  if (K == K_ && M == M_) {                                                                                   \
-    if (H == 1) return launch_proj<K_, M_, 1, EPI_ATT>(x, W, h, num_nodes, att_src, att_dst, a_src, a_dst,   \
-                                                         nullptr, nullptr, st);                               \
-    if (H == 2) return launch_proj<K_, M_, 2, EPI_ATT>(x, W, h, num_nodes, att_src, att_dst, a_src, a_dst,   \
-                                                         nullptr, nullptr, st);                               \
+  if (dtype == GATRES_DTYPE_BF16) {
+    const gatres_bf16* xb = (const gatres_bf16*)x; const gatres_bf16* Wb = (const gatres_bf16*)W; gatres_bf16* hb = (gatres_bf16*)h;
+#define CASE_(K_, M_)                                                                                               \
+  if (K == K_ && M == M_) {                                                                                         \
+    if (H == 1) return launch_proj_bf16<K_, M_, 1, EPI_ATT>(xb, Wb, hb, num_nodes, att_src, att_dst, a_src, a_dst, \
+                                                              nullptr, nullptr, st);                                \
+    if (H == 2) return launch_proj_bf16<K_, M_, 2, EPI_ATT>(xb, Wb, hb, num_nodes, att_src, att_dst, a_src, a_dst, \
+                                                              nullptr, nullptr, st);                                \
+  }
+    GATRES_FOR_SHAPES(CASE_)
+#undef CASE_
+    return GATRES_E_UNSUPPORTED;
+  }
+  if (dtype != GATRES_DTYPE_F32) return GATRES_E_UNSUPPORTED;
+  const float* xf = (const float*)x; const float* Wf = (const float*)W; float* hf = (float*)h;
+#define CASE_(K_, M_)                                                                                          \
+  if (K == K_ && M == M_) {                                                                                    \
+    if (H == 1) return launch_proj<K_, M_, 1, EPI_ATT>(xf, Wf, hf, num_nodes, att_src, att_dst, a_src, a_dst, \
+                                                         nullptr, nullptr, st);                                \
+    if (H == 2) return launch_proj<K_, M_, 2, EPI_ATT>(xf, Wf, hf, num_nodes, att_src, att_dst, a_src, a_dst, \
+                                                         nullptr, nullptr, st);                                \
   }
   GATRES_FOR_SHAPES(CASE_)
 #undef CASE_
   return GATRES_E_UNSUPPORTED;
 }
 
-extern "C" int gatres_proj_bwd_dx(const float* g_h, const float* Wt, const float* resid, const float* relu_ref,
-                                  float* g_x, int32_t num_nodes, int32_t K, int32_t HC, void* stream) {
+extern "C" int gatres_t_proj_bwd_dx(const void* g_h, const void* Wt, const void* resid, const void* relu_ref, void* g_x, int num_nodes,
+                         int K, int HC, int dtype, void* stream) {
   if (!g_h || !Wt || !g_x || num_nodes <= 0) return GATRES_E_BADARG;
   if (!gatres_aligned16(g_h) || !gatres_aligned16(Wt) || !gatres_aligned16(g_x) || !gatres_aligned16(resid) ||
       !gatres_aligned16(relu_ref))
     return GATRES_E_BADARG;
   hipStream_t st = gatres_stream(stream);
   // reduction length = HC, outputs = K
+  if (dtype == GATRES_DTYPE_BF16) {
+#define CASE_(K_, M_)                                                                                                 \
+  if (HC == K_ && K == M_)                                                                                            \
+    return launch_proj_bf16<K_, M_, 1, EPI_RESID_MASK>((const gatres_bf16*)g_h, (const gatres_bf16*)Wt, (gatres_bf16*)g_x, \
+                                                       num_nodes, nullptr, nullptr, nullptr, nullptr,                 \
+                                                       (const gatres_bf16*)resid, (const gatres_bf16*)relu_ref, st);
+    GATRES_FOR_SHAPES(CASE_)
+#undef CASE_
+    return GATRES_E_UNSUPPORTED;
+  }
+  if (dtype != GATRES_DTYPE_F32) return GATRES_E_UNSUPPORTED;
 #define CASE_(K_, M_)                                                                                          \
   if (HC == K_ && K == M_)                                                                                     \
-    return launch_proj<K_, M_, 1, EPI_RESID_MASK>(g_h, Wt, g_x, num_nodes, nullptr, nullptr, nullptr, nullptr, \
-                                                  resid, relu_ref, st);
+    return launch_proj<K_, M_, 1, EPI_RESID_MASK>((const float*)g_h, (const float*)Wt, (float*)g_x, num_nodes, \
+                                                  nullptr, nullptr, nullptr, nullptr, (const float*)resid,     \
+                                                  (const float*)relu_ref, st);
   GATRES_FOR_SHAPES(CASE_)
 #undef CASE_
   return GATRES_E_UNSUPPORTED;
 }
 
-extern "C" int gatres_proj_bwd_dw(const float* g_h, const float* x, float* slab_W, int32_t num_slabs,
-                                  int64_t slab_stride, int32_t num_nodes, int32_t K, int32_t HC, void* stream) {
+extern "C" int gatres_t_proj_bwd_dw(const void* g_h, const void* x, float* slab_W, int num_slabs, int64_t slab_stride, int num_nodes,
+                         int K, int HC, int dtype, void* stream) {
   if (!g_h || !x || !slab_W || num_nodes <= 0 || num_slabs <= 0) return GATRES_E_BADARG;
   if (!gatres_aligned16(g_h) || !gatres_aligned16(x)) return GATRES_E_BADARG;
   hipStream_t st = gatres_stream(stream);
+  if (dtype == GATRES_DTYPE_BF16) {
+#define CASE_(K_, M_)         \
+  if (K == K_ && HC == M_)    \
+    return launch_dw<M_, K_, gatres_bf16>((const gatres_bf16*)g_h, (const gatres_bf16*)x, slab_W, num_slabs, slab_stride, num_nodes, st);
+    GATRES_FOR_SHAPES(CASE_)
+#undef CASE_
+    return GATRES_E_UNSUPPORTED;
+  }
+  if (dtype != GATRES_DTYPE_F32) return GATRES_E_UNSUPPORTED;
 #define CASE_(K_, M_) \
-  if (K == K_ && HC == M_) return launch_dw<M_, K_>(g_h, x, slab_W, num_slabs, slab_stride, num_nodes, st);
+  if (K == K_ && HC == M_) return launch_dw<M_, K_, float>((const float*)g_h, (const float*)x, slab_W, num_slabs, slab_stride, num_nodes, st);
   GATRES_FOR_SHAPES(CASE_)
 #undef CASE_
   return GATRES_E_UNSUPPORTED;
+}
+
+extern "C" int gatres_proj_attn_fwd(const float* x, const float* W, const float* att_src, const float* att_dst,
+                                    float* h, float* a_src, float* a_dst, int32_t num_nodes, int32_t K, int32_t H,
+                                    int32_t C, void* stream) {
+  return gatres_t_proj_attn_fwd(x, W, att_src, att_dst, h, a_src, a_dst, num_nodes, K, H, C, GATRES_DTYPE_F32, stream);
+}
+
+extern "C" int gatres_proj_bwd_dx(const float* g_h, const float* Wt, const float* resid, const float* relu_ref,
+                                  float* g_x, int32_t num_nodes, int32_t K, int32_t HC, void* stream) {
+  return gatres_t_proj_bwd_dx(g_h, Wt, resid, relu_ref, g_x, num_nodes, K, HC, GATRES_DTYPE_F32, stream);
+}
+
+extern "C" int gatres_proj_bwd_dw(const float* g_h, const float* x, float* slab_W, int32_t num_slabs,
+                                  int64_t slab_stride, int32_t num_nodes, int32_t K, int32_t HC, void* stream) {
+  return gatres_t_proj_bwd_dw(g_h, x, slab_W, num_slabs, slab_stride, num_nodes, K, HC, GATRES_DTYPE_F32, stream);
 }

@@ -7,6 +7,7 @@
 //       -> K3 mean(y2)+xin, ReLU -> xin of block b+1
 #include "gatres_common.h"
 #include "gatres_layout.h"
+#include "gatres_typed.h"
 
 namespace {
 
@@ -67,7 +68,10 @@ extern "C" int gatres_model_forward_per_op(const gatres_model_t* m, const gatres
   if (!gatres_aligned16(params) || !gatres_aligned16(saved) || !gatres_aligned16(scratch)) return GATRES_E_BADARG;
   Layout L;
   if (!make_layout_g(m, g, &L)) return GATRES_E_UNSUPPORTED;
-  const int N = g->num_nodes, nc = L.nc;
+  const int N = g->num_nodes, nc = L.nc, dt = m->act_dtype;
+  if (dt != GATRES_DTYPE_F32 && (dt != GATRES_DTYPE_BF16 || nc < 32)) return GATRES_E_UNSUPPORTED;
+  // Activation tensors keep their fp32-sized slots in either mode (a bf16 tensor fills the first half), so every offset
+  // below is mode-independent; the typed launchers (gatres_typed.h) reinterpret the pointers.
   float* y2 = scratch + L.sc_y2;
   float* xa = scratch + L.sc_xa;
   float* xb = scratch + L.sc_xb;
@@ -83,23 +87,29 @@ extern "C" int gatres_model_forward_per_op(const gatres_model_t* m, const gatres
     }
     out = scratch + L.sc_pout;
   }
-  RC(gatres_lin0_fwd(x, mask, params + L.p_lin0_w, params + L.p_lin0_b, xcur, N, nc, stream));
+  const int64_t w = 2LL * nc * nc;
+  if (dt == GATRES_DTYPE_BF16) RC(gatres_convert_conv_weights_bf16(params, scratch + L.sc_wb, L.nb, nc, stream));
+  RC(gatres_t_lin0_fwd(x, mask, params + L.p_lin0_w, params + L.p_lin0_b, xcur, N, nc, dt, stream));
   for (int b = 0; b < L.nb; ++b) {
     float* base = saved ? saved + (int64_t)b * L.s_stride : scratch + L.sc_ev;
     float* xnext = saved ? saved + (int64_t)(b + 1) * L.s_stride + L.s_xin : (xcur == xa ? xb : xa);
     const float* pb = params + L.p_block0 + (int64_t)b * L.p_block_stride;
-    RC(gatres_proj_attn_fwd(xcur, pb + L.c1_W, pb + L.c1_as, pb + L.c1_ad, base + L.s_h1, base + L.s_as1,
-                            base + L.s_ad1, N, nc, 2, nc, stream));
-    RC(gatres_gat_aggregate_fwd(g, base + L.s_h1, base + L.s_as1, base + L.s_ad1, pb + L.c1_b, base + L.s_o1,
-                                base + L.s_al1, 2, nc, 1, stream));
-    RC(gatres_proj_attn_fwd(base + L.s_o1, pb + L.c2_W, pb + L.c2_as, pb + L.c2_ad, base + L.s_h2, base + L.s_as2,
-                            base + L.s_ad2, N, 2 * nc, 1, nc, stream));
-    RC(gatres_gat_aggregate_fwd(g, base + L.s_h2, base + L.s_as2, base + L.s_ad2, pb + L.c2_b, y2, base + L.s_al2, 1,
-                                nc, 0, stream));
-    RC(gatres_mean_residual_relu_fwd(g, y2, xcur, xnext, nc, stream));
+    // bf16: W1 / W2 of block b are the first two of its four 2nc^2-element bf16 matrices (= w/2 floats each)
+    const float* wbb = scratch + L.sc_wb + (int64_t)b * 2 * w;
+    const void* W1 = dt == GATRES_DTYPE_BF16 ? (const void*)wbb : (const void*)(pb + L.c1_W);
+    const void* W2 = dt == GATRES_DTYPE_BF16 ? (const void*)(wbb + w / 2) : (const void*)(pb + L.c2_W);
+    RC(gatres_t_proj_attn_fwd(xcur, W1, pb + L.c1_as, pb + L.c1_ad, base + L.s_h1, base + L.s_as1, base + L.s_ad1, N, nc,
+                              2, nc, dt, stream));
+    RC(gatres_t_gat_aggregate_fwd(g, base + L.s_h1, base + L.s_as1, base + L.s_ad1, pb + L.c1_b, base + L.s_o1,
+                                  base + L.s_al1, 2, nc, 1, dt, stream));
+    RC(gatres_t_proj_attn_fwd(base + L.s_o1, W2, pb + L.c2_as, pb + L.c2_ad, base + L.s_h2, base + L.s_as2,
+                              base + L.s_ad2, N, 2 * nc, 1, nc, dt, stream));
+    RC(gatres_t_gat_aggregate_fwd(g, base + L.s_h2, base + L.s_as2, base + L.s_ad2, pb + L.c2_b, y2, base + L.s_al2, 1,
+                                  nc, 0, dt, stream));
+    RC(gatres_t_mean_residual_relu_fwd(g, y2, xcur, xnext, nc, dt, stream));
     xcur = xnext;
   }
-  RC(gatres_lin1_fwd(xcur, params + L.p_lin1_w, params + L.p_lin1_b, out, N, nc, stream));
+  RC(gatres_t_lin1_fwd(xcur, params + L.p_lin1_w, params + L.p_lin1_b, out, N, nc, dt, stream));
   if (g->perm) RC(gatres_permute_f32(out, g->perm, out_caller, N, 1, stream));
   return 0;
 }
@@ -145,7 +155,8 @@ extern "C" int gatres_model_backward_per_op_part(const gatres_model_t* m, const 
   if (!make_layout_g(m, g, &L)) return GATRES_E_UNSUPPORTED;
   const bool first = flags & GATRES_PART_FIRST, last = flags & GATRES_PART_LAST;
   if (b_lo < 0 || b_hi > L.nb || b_lo > b_hi || (first && b_hi != L.nb) || (last && b_lo != 0)) return GATRES_E_BADARG;
-  const int N = g->num_nodes, nc = L.nc, S = L.num_slabs;
+  const int N = g->num_nodes, nc = L.nc, S = L.num_slabs, dt = m->act_dtype;
+  if (dt != GATRES_DTYPE_F32 && (dt != GATRES_DTYPE_BF16 || nc < 32)) return GATRES_E_UNSUPPORTED;
   const int64_t st = L.slab_stride, w = 2LL * nc * nc;
   // g_pre ping-pongs between two buffers, one swap per block: where it stands depends only on the blocks done so far
   const bool odd = ((L.nb - b_hi) & 1) != 0;
@@ -173,45 +184,48 @@ extern "C" int gatres_model_backward_per_op_part(const gatres_model_t* m, const 
     if (g_x) g_x = scratch + L.sc_pgx;
   }
   if (first) {
-    RC(gatres_transpose_conv_weights(params, wt, L.nb, nc, stream));
+    if (dt == GATRES_DTYPE_BF16) RC(gatres_convert_conv_weights_bf16(params, scratch + L.sc_wb, L.nb, nc, stream));
+    else                         RC(gatres_transpose_conv_weights(params, wt, L.nb, nc, stream));
     const float* xfinal = saved + (int64_t)L.nb * L.s_stride + L.s_xin;
-    RC(gatres_lin1_bwd(g_out, xfinal, params + L.p_lin1_w, gp_cur, slabs + L.p_lin1_w, slabs + L.p_lin1_b, S, st, N, nc,
-                       L.nb > 0 ? 1 : 0, stream));
+    RC(gatres_t_lin1_bwd(g_out, xfinal, params + L.p_lin1_w, gp_cur, slabs + L.p_lin1_w, slabs + L.p_lin1_b, S, st, N, nc,
+                         L.nb > 0 ? 1 : 0, dt, stream));
   }
   for (int b = b_hi - 1; b >= b_lo; --b) {
     const float* base = saved + (int64_t)b * L.s_stride;
     const int64_t po = L.p_block0 + (int64_t)b * L.p_block_stride;
     const float* pb = params + po;
     float* sb = slabs + po;
-    const float* wt1 = wt + (int64_t)b * 2 * w;        // W1^T [nc, 2nc]
-    const float* wt2 = wt1 + w;                        // W2^T [2nc, nc]
+    // W1^T [nc, 2nc] and W2^T [2nc, nc]: fp32 transposes, or the last two of the block's four bf16 matrices
+    const float* wbb = scratch + L.sc_wb + (int64_t)b * 2 * w;
+    const void* wt1 = dt == GATRES_DTYPE_BF16 ? (const void*)(wbb + w) : (const void*)(wt + (int64_t)b * 2 * w);
+    const void* wt2 = dt == GATRES_DTYPE_BF16 ? (const void*)(wbb + w + w / 2) : (const void*)(wt + (int64_t)b * 2 * w + w);
     // K3 backward: gradient w.r.t. conv2's output
-    RC(gatres_mean_bwd(g, gp_cur, gy2, nc, stream));
+    RC(gatres_t_mean_bwd(g, gp_cur, gy2, nc, dt, stream));
     // conv2 (H = 1, C = nc, K = 2nc); its output has no ReLU
-    RC(gatres_gat_aggregate_bwd_dst(g, gy2, base + L.s_h2, base + L.s_al2, base + L.s_as2, base + L.s_ad2, ge, gad, 1,
-                                    nc, stream));
-    RC(gatres_gat_aggregate_bwd_src(g, gy2, base + L.s_al2, ge, gad, pb + L.c2_as, pb + L.c2_ad, gh, gas, 1, nc,
-                                    stream));
-    RC(gatres_conv_param_grads(base + L.s_h2, gas, gad, gy2, sb + L.c2_as, sb + L.c2_ad, sb + L.c2_b, S, st, N, 1, nc,
-                               stream));
-    RC(gatres_proj_bwd_dw(gh, base + L.s_o1, sb + L.c2_W, S, st, N, 2 * nc, nc, stream));
-    RC(gatres_proj_bwd_dx(gh, wt2, nullptr, base + L.s_o1, go1, N, 2 * nc, nc, stream));   // ReLU mask of conv1
+    RC(gatres_t_gat_aggregate_bwd_dst(g, gy2, base + L.s_h2, base + L.s_al2, base + L.s_as2, base + L.s_ad2, ge, gad, 1,
+                                      nc, dt, stream));
+    RC(gatres_t_gat_aggregate_bwd_src(g, gy2, base + L.s_al2, ge, gad, pb + L.c2_as, pb + L.c2_ad, gh, gas, 1, nc, dt,
+                                      stream));
+    RC(gatres_t_conv_param_grads(base + L.s_h2, gas, gad, gy2, sb + L.c2_as, sb + L.c2_ad, sb + L.c2_b, S, st, N, 1, nc,
+                                 dt, stream));
+    RC(gatres_t_proj_bwd_dw(gh, base + L.s_o1, sb + L.c2_W, S, st, N, 2 * nc, nc, dt, stream));
+    RC(gatres_t_proj_bwd_dx(gh, wt2, nullptr, base + L.s_o1, go1, N, 2 * nc, nc, dt, stream));   // ReLU mask of conv1
     // conv1 (H = 2, C = nc, K = nc)
-    RC(gatres_gat_aggregate_bwd_dst(g, go1, base + L.s_h1, base + L.s_al1, base + L.s_as1, base + L.s_ad1, ge, gad, 2,
-                                    nc, stream));
-    RC(gatres_gat_aggregate_bwd_src(g, go1, base + L.s_al1, ge, gad, pb + L.c1_as, pb + L.c1_ad, gh, gas, 2, nc,
-                                    stream));
-    RC(gatres_conv_param_grads(base + L.s_h1, gas, gad, go1, sb + L.c1_as, sb + L.c1_ad, sb + L.c1_b, S, st, N, 2, nc,
-                               stream));
-    RC(gatres_proj_bwd_dw(gh, base + L.s_xin, sb + L.c1_W, S, st, N, nc, 2 * nc, stream));
+    RC(gatres_t_gat_aggregate_bwd_dst(g, go1, base + L.s_h1, base + L.s_al1, base + L.s_as1, base + L.s_ad1, ge, gad, 2,
+                                      nc, dt, stream));
+    RC(gatres_t_gat_aggregate_bwd_src(g, go1, base + L.s_al1, ge, gad, pb + L.c1_as, pb + L.c1_ad, gh, gas, 2, nc, dt,
+                                      stream));
+    RC(gatres_t_conv_param_grads(base + L.s_h1, gas, gad, go1, sb + L.c1_as, sb + L.c1_ad, sb + L.c1_b, S, st, N, 2, nc,
+                                 dt, stream));
+    RC(gatres_t_proj_bwd_dw(gh, base + L.s_xin, sb + L.c1_W, S, st, N, nc, 2 * nc, dt, stream));
     // d/d xin = conv1 path + residual; masked by the previous block's ReLU (block 0's input is lin0, no ReLU)
-    RC(gatres_proj_bwd_dx(gh, wt1, gp_cur, b > 0 ? base + L.s_xin : nullptr, gp_nxt, N, nc, 2 * nc, stream));
+    RC(gatres_t_proj_bwd_dx(gh, wt1, gp_cur, b > 0 ? base + L.s_xin : nullptr, gp_nxt, N, nc, 2 * nc, dt, stream));
     float* t = gp_cur; gp_cur = gp_nxt; gp_nxt = t;
   }
   if (last) {
-    RC(gatres_lin0_bwd(gp_cur, x, mask, slabs + L.p_lin0_w, slabs + L.p_lin0_b, S, st, N, nc, stream));
+    RC(gatres_t_lin0_bwd(gp_cur, x, mask, slabs + L.p_lin0_w, slabs + L.p_lin0_b, S, st, N, nc, dt, stream));
     if (g_x) {
-      RC(gatres_lin1_fwd(gp_cur, params + L.p_lin0_w, nullptr, g_x, N, nc, stream));
+      RC(gatres_t_lin1_fwd(gp_cur, params + L.p_lin0_w, nullptr, g_x, N, nc, dt, stream));
       if (g->perm) RC(gatres_permute_f32(g_x, g->perm, g_x_caller, N, 1, stream));
     }
   }

@@ -191,6 +191,7 @@ class GATResMeanConv(nn.Module):
         state = self.__dict__.copy()
         for k in ("_plans", "_scratch", "_cmodel", "_flat", "_param_table", "_param_list"):
             state.pop(k, None)
+        state["_act_dtype"] = int(self._cmodel.act_dtype)
         return state
 
     def __setstate__(self, state):
@@ -198,7 +199,7 @@ class GATResMeanConv(nn.Module):
         self._flat = None
         self._plans = PlanCache(segments=getattr(self, 'fused', True))
         self._scratch = {}
-        self._cmodel = _native.GatresModel(self.num_blocks, self.nc)
+        self._cmodel = _native.GatresModel(self.num_blocks, self.nc, int(getattr(self, "_act_dtype", 0)), 0)
         self._flatten_parameters()
 
     # ---- flat parameter storage (state_dict order == include/gatres.h layout) ------------------
@@ -261,6 +262,27 @@ class GATResMeanConv(nn.Module):
         if not self._flat_is_current():
             self._flatten_parameters()
         return self._flat
+
+    # ---- storage type of the activations (BASELINE config 3) ------------------------------------
+    def set_compute_dtype(self, dtype: str) -> "GATResMeanConv":
+        """``"fp32"`` (default: exact fp32 everywhere, the 1e-5 parity path, fused per-snapshot kernels where they apply)
+        or ``"bf16"``: activation-sized tensors are stored as bf16 between kernels and the projections run on bf16 MFMA
+        with fp32 accumulation; attention logits, softmax, neighbour sums, parameter gradients, the master parameters
+        (this module's fp32 nn.Parameters) and Adam stay fp32.  The reference has no reduced-precision mode
+        (SURVEY.md F1); predictions then agree with fp32 to about 1e-2 relative.  Per-op kernels, nc >= 32."""
+        code = {"fp32": _native.DTYPE_F32, "float32": _native.DTYPE_F32, "bf16": _native.DTYPE_BF16,
+                "bfloat16": _native.DTYPE_BF16}.get(str(dtype).replace("torch.", ""))
+        if code is None:
+            raise ValueError(f"unknown compute dtype {dtype!r}")
+        if code == _native.DTYPE_BF16 and self.nc < 32:
+            raise ValueError("bf16 projections need nc >= 32 (a 32-deep MFMA reduction)")
+        self._cmodel.act_dtype = code
+        self._plans.clear()
+        return self
+
+    @property
+    def compute_dtype(self) -> str:
+        return "bf16" if self._cmodel.act_dtype == _native.DTYPE_BF16 else "fp32"
 
     # ---- engine plumbing -------------------------------------------------------------------
     def _cmodel_ref(self):

@@ -114,7 +114,7 @@ class GATResTrainer:
             raise RuntimeError("the model's parameter storage moved (e.g. .to()/deepcopy); build a new GATResTrainer")
         h = self.hparams
         return _TrainStepC(
-            _native.GatresModel(m.num_blocks, m.nc), C.pointer(self.plan.c), params.data_ptr(), self.grads.data_ptr(),
+            _native.GatresModel(m.num_blocks, m.nc, m._cmodel.act_dtype, 0), C.pointer(self.plan.c), params.data_ptr(), self.grads.data_ptr(),
             self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr(), self.step_counter.data_ptr(), self.x.data_ptr(),
             self.y.data_ptr(), self.mask.data_ptr(),
             self.node_ptr.data_ptr() if (device_mask and self.node_ptr is not None) else None,

@@ -32,6 +32,9 @@ extern "C" {
 #define GATRES_E_UNSUPPORTED (-2)  /* width not supported by the gfx950 kernels                  */
 #define GATRES_E_GRAPH       (-3)  /* edge endpoint out of range while building the graph plan   */
 
+#define GATRES_DTYPE_F32  0        /* storage types of activation-sized tensors (gatres_model_t.act_dtype) */
+#define GATRES_DTYPE_BF16 1
+
 /* --------------------------------------------------------------------------------------------------------
  * Graph plan (K0).  Replaces what PyG re-derives inside every GATConv.forward call --
  * remove_self_loops + add_self_loops (torch_geometric.utils.loop; reference call sites
@@ -223,6 +226,51 @@ int gatres_adam_step(float* params, const float* grads, float* exp_avg, float* e
                      double weight_decay, float grad_scale, void* stream);
 
 /* --------------------------------------------------------------------------------------------------------
+ * Typed per-op kernels: the per-op kernels above with the storage type of the activation-sized tensors as an argument
+ * (`dtype`: GATRES_DTYPE_F32 or GATRES_DTYPE_BF16, defined with gatres_model_t below).  `void*` arguments are the tensors
+ * whose element type `dtype` selects; every other pointer is fp32 / int32 exactly as in the fp32 entry point of the same
+ * name, which is the GATRES_DTYPE_F32 instance.  bf16: loads widen to fp32, sums / softmax / accumulators stay fp32,
+ * stores round to nearest-even; the projections run on v_mfma_f32_16x16x32_bf16 and need nc >= 32.
+ * ------------------------------------------------------------------------------------------------------ */
+/* k_aggregate.hip */
+int gatres_t_gat_aggregate_fwd(const gatres_graph_t* g, const void* h, const float* a_src, const float* a_dst,
+                               const float* bias, void* out, float* alpha, int H, int C, int apply_relu, int dtype,
+                               void* stream);
+int gatres_t_gat_aggregate_bwd_dst(const gatres_graph_t* g, const void* g_out, const void* h, const float* alpha,
+                                   const float* a_src, const float* a_dst, float* g_e, float* g_a_dst, int H, int C,
+                                   int dtype, void* stream);
+int gatres_t_gat_aggregate_bwd_src(const gatres_graph_t* g, const void* g_out, const float* alpha, const float* g_e,
+                                   const float* g_a_dst, const float* att_src, const float* att_dst, void* g_h,
+                                   float* g_a_src, int H, int C, int dtype, void* stream);
+int gatres_t_mean_residual_relu_fwd(const gatres_graph_t* g, const void* y, const void* x0, void* out, int C, int dtype,
+                                    void* stream);
+int gatres_t_mean_bwd(const gatres_graph_t* g, const void* g_pre, void* g_y, int C, int dtype, void* stream);
+
+/* k_misc.hip */
+int gatres_t_lin0_fwd(const float* x, const uint8_t* mask, const float* w, const float* b, void* out, int num_nodes, int nc,
+                      int dtype, void* stream);
+int gatres_t_lin0_bwd(const void* g, const float* x, const uint8_t* mask, float* slab_w, float* slab_b, int num_slabs,
+                      int64_t slab_stride, int num_nodes, int nc, int dtype, void* stream);
+int gatres_t_lin1_fwd(const void* x, const float* w, const float* b, float* out, int num_nodes, int nc, int dtype,
+                      void* stream);
+int gatres_t_lin1_bwd(const float* g_out, const void* x, const float* w, void* g_x, float* slab_w, float* slab_b,
+                      int num_slabs, int64_t slab_stride, int num_nodes, int nc, int relu_mask, int dtype, void* stream);
+int gatres_t_conv_param_grads(const void* h, const float* g_a_src, const float* g_a_dst, const void* g_out,
+                              float* slab_att_src, float* slab_att_dst, float* slab_bias, int num_slabs,
+                              int64_t slab_stride, int num_nodes, int H, int C, int dtype, void* stream);
+/* bf16 copies of every GATConv weight and of its transpose: wb block layout [W1 : 2nc x nc][W2 : nc x 2nc] */
+/* [W1^T : nc x 2nc][W2^T : 2nc x nc] (4 * 2nc^2 bf16 per block) */
+int gatres_convert_conv_weights_bf16(const float* params, void* wb, int num_blocks, int nc, void* stream);
+
+/* k_proj.hip.  W / Wt: fp32 for GATRES_DTYPE_F32, bf16 (from gatres_convert_conv_weights_bf16) for GATRES_DTYPE_BF16. */
+int gatres_t_proj_attn_fwd(const void* x, const void* W, const float* att_src, const float* att_dst, void* h, float* a_src,
+                           float* a_dst, int num_nodes, int K, int H, int C, int dtype, void* stream);
+int gatres_t_proj_bwd_dx(const void* g_h, const void* Wt, const void* resid, const void* relu_ref, void* g_x, int num_nodes,
+                         int K, int HC, int dtype, void* stream);
+int gatres_t_proj_bwd_dw(const void* g_h, const void* x, float* slab_W, int num_slabs, int64_t slab_stride, int num_nodes,
+                         int K, int HC, int dtype, void* stream);
+
+/* --------------------------------------------------------------------------------------------------------
  * Whole-network drivers: enqueue every kernel of GATResMeanConv.forward / its backward natively.
  *
  * Flat parameter layout (fp32, state_dict order; GraphModels.py:472-484, :455-460):
@@ -234,6 +282,14 @@ int gatres_adam_step(float* params, const float* grads, float* exp_avg, float* e
 typedef struct gatres_model {
   int32_t num_blocks;
   int32_t nc;
+  /* Storage type of the activation-sized tensors between kernels (saved activations, their gradients) and operand type of
+   * the projections' MFMAs.  GATRES_DTYPE_F32: exact fp32 everywhere (the 1e-5 parity path).  GATRES_DTYPE_BF16 (BASELINE
+   * config 3): bf16 in HBM, v_mfma_f32_16x16x32_bf16 for lin(x) and its data gradient with fp32 accumulation; attention
+   * logits, softmax, every neighbour sum, parameter gradients, master weights and Adam stay fp32.  Per-op kernels only
+   * (the fused per-snapshot path is fp32).  Buffers keep their fp32 SIZES (gatres_saved_floats / gatres_scratch_floats):
+   * a bf16 tensor occupies the first half of its fp32 slot.  x, y, out, g_out, g_x, params, grads are always fp32. */
+  int32_t act_dtype;
+  int32_t reserved;
 } gatres_model_t;
 
 int64_t gatres_param_count(int32_t num_blocks, int32_t nc);

@@ -1,0 +1,156 @@
+"""bf16 storage + bf16 MFMA projections (gatres_model_t.act_dtype = GATRES_DTYPE_BF16; BASELINE.json config 3).
+
+The reference has no reduced-precision mode; the bar SURVEY 8(d) sets for config 3 is ~1e-2 relative on
+the predictions against the fp32 oracle plus a loss trajectory that follows fp32 training.  Written tolerances:
+  * single kernels against torch on the SAME bf16-rounded inputs: outputs within bf16 rounding (2^-8 relative), fp32
+    side outputs (attention logits, parameter-gradient slabs) within 2e-4 of an fp32 matmul of those inputs;
+  * whole model vs the fp32 oracle: predictions <= 1e-2 relative in the L2 norm (<= 2.5e-2 at the worst node); the flat
+    gradient within 1.5e-1 (L2) -- 15 to 25 blocks of bf16 rounding, on gradients that are themselves cancellation-heavy;
+  * 4 training steps: the first loss within 5e-3 of the fp32 trainer's, every later one within 1e-1 (the fp32 run itself
+    moves 0.97 -> 2.13 -> 1.03 -> 1.58 over these steps on fresh batches: differences are amplified, not damped)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from test_gpu_model import build, ctown_batch, note, relerr      # noqa: E402
+
+BF16 = 1
+
+
+def _st(t):
+    import gnn_pressure_estimation_amd as G
+    return G._native.current_stream(t.device)
+
+
+@pytest.mark.parametrize("nc,H", [(32, 2), (32, 1), (64, 2), (128, 2), (128, 1)])
+def test_bf16_projection_kernels(pkg, lib, nc, H):
+    """v_mfma_f32_16x16x32_bf16 projection (forward with the attention-logit epilogue, data gradient with the residual /
+    ReLU-mask epilogue) and the fp32-accumulated weight gradient on bf16 operands, against torch."""
+    N = 1000 + 7                                         # a ragged last tile
+    K = nc if H == 2 else 2 * nc
+    C, HC = nc, H * nc
+    g = torch.Generator().manual_seed(nc * 10 + H)
+    x = torch.randn(N, K, generator=g).cuda().bfloat16()
+    W = (torch.randn(HC, K, generator=g) / K ** 0.5).cuda().bfloat16()
+    att_s, att_d = torch.randn(HC, generator=g).cuda(), torch.randn(HC, generator=g).cuda()
+    h = torch.empty(N, HC, dtype=torch.bfloat16, device="cuda")
+    a_s, a_d = torch.empty(N, H, device="cuda"), torch.empty(N, H, device="cuda")
+    pkg._native.check(lib.gatres_t_proj_attn_fwd(x.data_ptr(), W.data_ptr(), att_s.data_ptr(), att_d.data_ptr(),
+                                                 h.data_ptr(), a_s.data_ptr(), a_d.data_ptr(), N, K, H, C, BF16, _st(x)),
+                      "proj_attn_fwd bf16")
+    h_ref = x.float() @ W.float().t()                    # fp32 accumulation of the same bf16 operands
+    assert relerr(h.float(), h_ref) < 2 ** -8
+    assert relerr(a_s, (h_ref.view(N, H, C) * att_s.view(1, H, C)).sum(-1)) < 2e-4       # logits: from the fp32 accumulators
+    assert relerr(a_d, (h_ref.view(N, H, C) * att_d.view(1, H, C)).sum(-1)) < 2e-4
+    # data gradient: g_x = (g_h @ W + resid) masked by relu_ref > 0, with Wt = W^T [K, HC] row-major
+    g_h = torch.randn(N, HC, generator=g).cuda().bfloat16()
+    Wt = W.t().contiguous()
+    resid = torch.randn(N, K, generator=g).cuda().bfloat16()
+    ref_act = torch.randn(N, K, generator=g).cuda().bfloat16()
+    g_x = torch.empty(N, K, dtype=torch.bfloat16, device="cuda")
+    pkg._native.check(lib.gatres_t_proj_bwd_dx(g_h.data_ptr(), Wt.data_ptr(), resid.data_ptr(), ref_act.data_ptr(),
+                                               g_x.data_ptr(), N, K, HC, BF16, _st(x)), "proj_bwd_dx bf16")
+    gx_ref = (g_h.float() @ W.float() + resid.float()) * (ref_act.float() > 0)
+    assert relerr(g_x.float(), gx_ref) < 2 ** -7
+    # weight gradient partials (fp32 MFMA on widened operands), summed over the slabs
+    S = 8
+    stride = HC * K
+    slab = torch.zeros(S * stride, device="cuda")
+    pkg._native.check(lib.gatres_t_proj_bwd_dw(g_h.data_ptr(), x.data_ptr(), slab.data_ptr(), S, stride, N, K, HC, BF16,
+                                               _st(x)), "proj_bwd_dw bf16")
+    assert relerr(slab.view(S, HC, K).sum(0), g_h.float().t() @ x.float()) < 2e-4
+
+
+def test_bf16_weight_copies(pkg, lib, oracle):
+    nb, nc = 3, 32
+    model, p = build(pkg, oracle, nb, nc, seed=5)
+    per = 2 * nc * nc
+    wb = torch.empty(nb * 4 * per, dtype=torch.bfloat16, device="cuda")
+    pkg._native.check(lib.gatres_convert_conv_weights_bf16(model.flat_parameters.data_ptr(), wb.data_ptr(), nb, nc,
+                                                           _st(wb)), "convert")
+    wb = wb.view(nb, 4, per)
+    for b in range(nb):
+        W1, W2 = p[f"blocks.{b}.conv1.lin_src.weight"].cuda(), p[f"blocks.{b}.conv2.lin_src.weight"].cuda()
+        assert torch.equal(wb[b, 0].view(2 * nc, nc), W1.bfloat16()) and torch.equal(wb[b, 1].view(nc, 2 * nc), W2.bfloat16())
+        assert torch.equal(wb[b, 2].view(nc, 2 * nc), W1.t().bfloat16()) and torch.equal(wb[b, 3].view(2 * nc, nc), W2.t().bfloat16())
+
+
+@pytest.mark.parametrize("nb,nc,bs", [(3, 128, 2), (15, 32, 2), (2, 64, 3), (25, 128, 4)])
+def test_bf16_model_vs_fp32_oracle(pkg, oracle, nb, nc, bs):
+    x, y, ei, mask = ctown_batch(pkg, bs)
+    model, p = build(pkg, oracle, nb, nc, seed=3)
+    model.set_compute_dtype("bf16")
+    assert model.compute_dtype == "bf16"
+    leaves = {k: v.clone().requires_grad_(True) for k, v in p.items()}
+    xin = x.clone(); xin[mask] = 0
+    out_ref = oracle.gatres_forward(leaves, xin, ei, num_blocks=nb)
+    loss_ref = torch.nn.functional.mse_loss(out_ref[mask], y[mask])
+    loss_ref.backward()
+    g_ref = torch.cat([v.grad.reshape(-1) for v in leaves.values()])
+    out = model(xin.cuda(), ei.cuda())
+    assert out.dtype == torch.float32 and torch.isfinite(out).all()
+    e_out = relerr(out, out_ref)                                                  # max-norm: max |err| / max |ref|
+    e_l2 = float((out.detach().cpu().double() - out_ref.double()).norm() / out_ref.double().norm())
+    m = mask.cuda()
+    loss = torch.nn.functional.mse_loss(out[m], y.cuda()[m])
+    loss.backward()
+    g = torch.cat([q.grad.reshape(-1) for q in model.parameters()])
+    e_loss, e_g = relerr(loss, loss_ref), relerr(g, g_ref)
+    e_g2 = float((g.cpu().double() - g_ref.double()).norm() / g_ref.double().norm())
+    note(f"bf16 {nb}x{nc} bs{bs}: predictions rel-L2 / max-norm, loss, flat gradient rel-L2 / max-norm vs fp32 oracle",
+         [e_l2, e_out, e_loss, e_g2, e_g])
+    # ~1e-2 relative on the predictions.  Measured on gatres_large (25 x 128): 4e-3 in the L2 norm,
+    # 1.4e-2 at the single worst node (bf16 rounding of the residual stream accumulates over 25 blocks)
+    assert e_l2 < 1e-2 and e_out < 2.5e-2 and e_loss < 2e-2
+    assert torch.isfinite(g).all() and e_g2 < 1.5e-1 and e_g < 1.5e-1      # (measured: 1.0e-1 / 3e-2 on gatres_large)
+    # inference path (no saved activations) == training path, and repeatable bit for bit
+    with torch.no_grad():
+        o2 = model(xin.cuda(), ei.cuda())
+    assert torch.equal(o2, out.detach())
+
+
+def test_bf16_loss_trajectory_follows_fp32(pkg, oracle):
+    """four optimisation steps (device masks, Adam on the fp32 master parameters) in bf16 against the
+    same steps in fp32 (tolerances: module docstring), parameters within a few learning rates."""
+    nb, nc, bs = 6, 128, 4
+    ei = pkg.wdn_synth.collate_edge_index(pkg.wdn_synth.make_wdn_topology(), 388, bs).cuda()
+    snaps = pkg.wdn_synth.make_snapshots(4 * bs, 388, seed=9).cuda()
+    res = []
+    for dtype in ("fp32", "bf16"):
+        model, _ = build(pkg, oracle, nb, nc, seed=12)
+        model.set_compute_dtype(dtype)
+        tr = pkg.GATResTrainer(model, ei, 388 * bs, nodes_per_graph=[388] * bs, seed=3, use_graph=(dtype == "bf16"))
+        assert not tr.fused
+        losses = []
+        for it in range(4):
+            yb = snaps[it * bs:(it + 1) * bs].reshape(-1)
+            losses.append(float(tr.step(yb, yb)))
+        res.append((losses, model.flat_parameters.clone()))
+    note("bf16 vs fp32 training, 4 steps: losses fp32 / bf16", [res[0][0], res[1][0]])
+    assert abs(res[0][0][0] - res[1][0][0]) <= 5e-3 * abs(res[0][0][0])
+    for a, b in zip(res[0][0], res[1][0]):
+        assert abs(a - b) <= 1e-1 * abs(a), (res[0][0], res[1][0])
+    assert float((res[0][1] - res[1][1]).abs().max()) <= 2 * 4 * 5e-4 * 1.01  # Adam moves a weight by <= ~lr per step, either way
+
+
+def test_bf16_relabelled_plan_and_bucketed_backward(pkg, oracle):
+    """bf16 through the other per-op drivers: a relabelled plan (gather / scatter of the fp32 caller-order vectors) and the
+    bucketed backward of the data-parallel step must give exactly the plain bf16 step."""
+    nb, nc, bs = 4, 64, 2
+    t1 = pkg.wdn_synth.make_wdn_topology(388, 430, seed=0)
+    sigma = torch.from_numpy(np.concatenate([np.random.RandomState(3).permutation(388) + 388 * k for k in range(bs)]))
+    ei = sigma[pkg.wdn_synth.collate_edge_index(t1, 388, bs)].cuda()
+    y = torch.randn(388 * bs, generator=torch.Generator().manual_seed(2)).cuda()
+    res = []
+    for split in (False, True):
+        model, _ = build(pkg, oracle, nb, nc, seed=21)
+        model.set_compute_dtype("bf16")
+        tr = pkg.GATResTrainer(model, ei, 388 * bs, nodes_per_graph=[388] * bs, seed=5, use_graph=False,
+                               force_collective_path=split, blocks_per_bucket=1)
+        for _ in range(2):
+            tr.step(y, y)
+        res.append((tr.loss.clone(), model.flat_parameters.clone()))
+    assert torch.isfinite(res[0][0]).all()
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
