@@ -285,3 +285,46 @@ extern "C" int gatres_graph_reorder_host(const int64_t* ei, int64_t E, int64_t N
   }
   return 0;
 }
+
+// LZ4 block decompression (host), for the Blosc-compressed chunks of the reference's zarr stores
+// (gnn_pressure_estimation/utils/DataLoader.py:212-242 reads what scenegenv7.py:701-725 writes; zarr's default
+// compressor is Blosc(cname='lz4')).  The published LZ4 block format: sequences of [token][literal length ext]
+// [literals][offset lo hi][match length ext]; the last sequence ends after its literals.  Returns the number of bytes
+// produced, or a negative GATRES_E_* code on malformed input (never reads or writes out of bounds).
+extern "C" int64_t gatres_lz4_decompress_host(const uint8_t* src, int64_t src_len, uint8_t* dst, int64_t dst_cap) {
+  if (!src || !dst || src_len < 0 || dst_cap < 0) return GATRES_E_BADARG;
+  int64_t ip = 0, op = 0;
+  while (ip < src_len) {
+    const uint8_t token = src[ip++];
+    int64_t lit = token >> 4;
+    if (lit == 15) {
+      uint8_t b;
+      do {
+        if (ip >= src_len) return GATRES_E_BADARG;
+        b = src[ip++];
+        lit += b;
+      } while (b == 255);
+    }
+    if (ip + lit > src_len || op + lit > dst_cap) return GATRES_E_BADARG;
+    for (int64_t k = 0; k < lit; ++k) dst[op + k] = src[ip + k];
+    ip += lit; op += lit;
+    if (ip >= src_len) break;                          // last sequence: literals only
+    if (ip + 2 > src_len) return GATRES_E_BADARG;
+    const int64_t off = src[ip] | ((int64_t)src[ip + 1] << 8);
+    ip += 2;
+    if (off == 0 || off > op) return GATRES_E_BADARG;
+    int64_t ml = (token & 15) + 4;
+    if ((token & 15) == 15) {
+      uint8_t b;
+      do {
+        if (ip >= src_len) return GATRES_E_BADARG;
+        b = src[ip++];
+        ml += b;
+      } while (b == 255);
+    }
+    if (op + ml > dst_cap) return GATRES_E_BADARG;
+    for (int64_t k = 0; k < ml; ++k) dst[op + k] = dst[op + k - off];      // byte by byte: matches may overlap themselves
+    op += ml;
+  }
+  return op;
+}

@@ -113,6 +113,10 @@ int gatres_graph_windows_host(const int64_t* edge_index, int64_t num_edges, int6
 int gatres_graph_reorder_host(const int64_t* edge_index_host, int64_t num_edges, int64_t num_nodes,
                               const int32_t* seg_ptr_host, int32_t num_segments, int32_t* perm_new2old_host);
 
+/* LZ4 block decompression on the host (the Blosc-lz4 chunks of the reference's zarr stores, utils/DataLoader.py:212-242).
+ * Returns the number of bytes written to dst, or GATRES_E_BADARG on malformed input / a dst that is too small. */
+int64_t gatres_lz4_decompress_host(const uint8_t* src, int64_t src_len, uint8_t* dst, int64_t dst_cap);
+
 /* 64-bit content hash of an int64 [2,E] DEVICE edge_index (for plan caching); hash_out: device uint64[1],
  * must be zeroed by the caller on the same stream before the call. */
 int gatres_edge_index_hash(const int64_t* edge_index, int64_t num_edges, uint64_t* hash_out, void* stream);
