@@ -543,7 +543,16 @@ def main():
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
     if rank == 0:
-        print(json.dumps(result))
+        # RCCL writes a version banner to the C-level stdout buffer; push it out first so that the JSON line is the LAST line
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        sys.stdout.flush()
+        print(json.dumps(result), flush=True)
+        if world > 1 or args.force_collective_path:
+            os._exit(0)           # (nothing may follow the JSON line: skip exit handlers that print, e.g. RCCL's)
 
 
 if __name__ == "__main__":

@@ -519,6 +519,93 @@ int launch_proj(const float* X, const float* Wm, float* OUT, int N, const float*
   return gatres_launch_status();
 }
 
+// ------------------------------------------------------------------------------------------------------
+// dW on the bf16 matrix cores: slab[s][c, k] = sum_{n in slab s} G[n, c] * X[n, k] with both operands bf16 in HBM.
+// The reduction runs over NODES, the row index of both row-major operands, while v_mfma_f32_16x16x32_bf16 wants 8
+// consecutive reduction indices per lane for A (= G^T) and for B (= X): a column access.  So a workgroup stages 32-node
+// chunks of G and X TRANSPOSED in LDS ([feature][32 nodes], rows padded to 80 bytes: the 16 lanes of an operand read
+// fall on 16 different 16-byte slots), coalesced 16-byte global loads in, 2-byte LDS stores out; every operand fragment
+// is then one ds_read_b128.  One workgroup per node slab (the slabs of the fp32 kernel: same partition, same
+// fixed-order slab reduction afterwards), wave w owns a CTW x KTW block of the [HC/16] x [K/16] output tiles in
+// registers for the whole slab.  fp32 accumulation; at 16x the fp32 matrix rate the kernel is bound by its reads.
+// ------------------------------------------------------------------------------------------------------
+template <int HC, int K>
+__global__ __launch_bounds__(256) void dw_bf16_kernel(const gatres_bf16* __restrict__ G, const gatres_bf16* __restrict__ X,
+                                                      float* __restrict__ slab, long long slab_stride, int N,
+                                                      int nodes_per_slab) {
+  constexpr int NCT = HC / 16, NKT = K / 16, TOT = NCT * NKT, TPW = TOT / 4;      // tiles per wave (4 waves)
+  constexpr int KTW = NKT < TPW ? NKT : TPW, CTW = TPW / KTW;                     // a wave's block of tiles
+  constexpr int ROW = 40;                                                         // bf16 per LDS row: 32 nodes + 8 pad
+  __shared__ __attribute__((aligned(16))) gatres_bf16 gt[HC * ROW];
+  __shared__ __attribute__((aligned(16))) gatres_bf16 xt[K * ROW];
+  const int s = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int i = lane & 15, q = lane >> 4;
+  const int nbeg = s * nodes_per_slab, nend = min(N, nbeg + nodes_per_slab);
+  const int t0 = wave * TPW, ct0 = t0 / NKT, kt0 = t0 % NKT;                      // block origin (KTW divides NKT)
+  f32x4 acc[CTW][KTW];
+#pragma unroll
+  for (int a = 0; a < CTW; ++a)
+#pragma unroll
+    for (int b = 0; b < KTW; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  for (int n0 = nbeg; n0 < nend; n0 += 32) {
+    // stage the chunk transposed: a thread moves 8 consecutive features of one node per step
+    for (int p = tid; p < 32 * (HC / 8); p += 256) {
+      const int nl = p / (HC / 8), c8 = (p % (HC / 8)) * 8;
+      const int n = n0 + nl;
+      uint4 v = make_uint4(0u, 0u, 0u, 0u);
+      if (n < nend) v = *reinterpret_cast<const uint4*>(G + (size_t)n * HC + c8);
+      const unsigned w[4] = {v.x, v.y, v.z, v.w};
+      unsigned short* d = reinterpret_cast<unsigned short*>(gt) + c8 * ROW + nl;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { d[(2 * j) * ROW] = (unsigned short)(w[j] & 0xffffu); d[(2 * j + 1) * ROW] = (unsigned short)(w[j] >> 16); }
+    }
+    for (int p = tid; p < 32 * (K / 8); p += 256) {
+      const int nl = p / (K / 8), k8 = (p % (K / 8)) * 8;
+      const int n = n0 + nl;
+      uint4 v = make_uint4(0u, 0u, 0u, 0u);
+      if (n < nend) v = *reinterpret_cast<const uint4*>(X + (size_t)n * K + k8);
+      const unsigned w[4] = {v.x, v.y, v.z, v.w};
+      unsigned short* d = reinterpret_cast<unsigned short*>(xt) + k8 * ROW + nl;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { d[(2 * j) * ROW] = (unsigned short)(w[j] & 0xffffu); d[(2 * j + 1) * ROW] = (unsigned short)(w[j] >> 16); }
+    }
+    __syncthreads();
+    bf16x8 af[CTW], bfr[KTW];
+#pragma unroll
+    for (int a = 0; a < CTW; ++a) af[a] = *reinterpret_cast<const bf16x8*>(gt + ((ct0 + a) * 16 + i) * ROW + q * 8);
+#pragma unroll
+    for (int b = 0; b < KTW; ++b) bfr[b] = *reinterpret_cast<const bf16x8*>(xt + ((kt0 + b) * 16 + i) * ROW + q * 8);
+#pragma unroll
+    for (int a = 0; a < CTW; ++a)
+#pragma unroll
+      for (int b = 0; b < KTW; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[a], bfr[b], acc[a][b], 0, 0, 0);
+    __syncthreads();
+  }
+  float* out = slab + (size_t)s * slab_stride;
+#pragma unroll
+  for (int a = 0; a < CTW; ++a)
+#pragma unroll
+    for (int b = 0; b < KTW; ++b)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        out[(size_t)((ct0 + a) * 16 + 4 * q + r) * K + (kt0 + b) * 16 + i] = acc[a][b][r];
+}
+
+template <int HC, int K>
+int launch_dw_bf16(const gatres_bf16* G, const gatres_bf16* X, float* slab, int num_slabs, long long stride, int N,
+                   hipStream_t st) {
+  if constexpr (HC % 16 == 0 && K % 16 == 0 && (HC / 16) * (K / 16) >= 4 && ((HC / 16) * (K / 16)) % 4 == 0 &&
+                (HC + K) * 80 <= 160 * 1024) {
+    int nps = (N + num_slabs - 1) / num_slabs;
+    nps = (nps + 3) & ~3;                         // the slab boundaries of every other parameter-gradient kernel
+    hipLaunchKernelGGL((dw_bf16_kernel<HC, K>), dim3(num_slabs), dim3(256), 0, st, G, X, slab, stride, N, nps);
+    return gatres_launch_status();
+  } else {
+    return GATRES_E_UNSUPPORTED;
+  }
+}
+
 template <int HC, int K, typename T>
 int launch_dw(const T* G, const T* X, float* slab, int num_slabs, long long stride, int N, hipStream_t st) {
   constexpr int CB = HC < 64 ? (HC < 16 ? 16 : HC) : 64;
@@ -609,9 +696,14 @@ extern "C" int gatres_t_proj_bwd_dw(const void* g_h, const void* x, float* slab_
   if (!gatres_aligned16(g_h) || !gatres_aligned16(x)) return GATRES_E_BADARG;
   hipStream_t st = gatres_stream(stream);
   if (dtype == GATRES_DTYPE_BF16) {
-#define CASE_(K_, M_)         \
-  if (K == K_ && HC == M_)    \
-    return launch_dw<M_, K_, gatres_bf16>((const gatres_bf16*)g_h, (const gatres_bf16*)x, slab_W, num_slabs, slab_stride, num_nodes, st);
+#define CASE_(K_, M_)                                                                                                  \
+  if (K == K_ && HC == M_) {                                                                                           \
+    if (K_ >= 32 && M_ >= 32 && !getenv("GATRES_DW_FP32"))                                                             \
+      return launch_dw_bf16<M_, K_>((const gatres_bf16*)g_h, (const gatres_bf16*)x, slab_W, num_slabs, slab_stride,   \
+                                    num_nodes, st);                                                                    \
+    return launch_dw<M_, K_, gatres_bf16>((const gatres_bf16*)g_h, (const gatres_bf16*)x, slab_W, num_slabs,          \
+                                          slab_stride, num_nodes, st);                                                 \
+  }
     GATRES_FOR_SHAPES(CASE_)
 #undef CASE_
     return GATRES_E_UNSUPPORTED;
