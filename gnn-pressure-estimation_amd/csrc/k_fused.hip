@@ -542,6 +542,9 @@ __device__ __forceinline__ void seg_gather(Rows rw, const u16* rp, const u16* co
   const float4 b = ld4(bias + c0);
   const int rounds = (rw.hi - rw.lo + RPP * UR - 1) / (RPP * UR);
   for (int it = 0; it < rounds; ++it) {
+    // waves whose rows of this trip all lie beyond the part skip it (wave-uniform): an idle wave that walks the trip with
+    // clamped rows costs the busy waves of its SIMD their issue slots
+    if (rw.lo + it * UR * RPP + (int)((threadIdx.x & ~63u) / G) >= rw.hi) continue;
     int r[UR], beg[UR], deg[UR];
     bool valid[UR];
 #pragma unroll
@@ -607,6 +610,9 @@ __device__ __forceinline__ void seg_mean_fwd(Rows rw, int em, const u16* mrp, co
   const int rounds = (rw.hi - rw.lo + RPP * UR - 1) / (RPP * UR);
   const int elast = max(em - 1, 0);
   for (int it = 0; it < rounds; ++it) {
+    // waves whose rows of this trip all lie beyond the part skip it (wave-uniform): an idle wave that walks the trip with
+    // clamped rows costs the busy waves of its SIMD their issue slots
+    if (rw.lo + it * UR * RPP + (int)((threadIdx.x & ~63u) / G) >= rw.hi) continue;
     int r[UR], beg[UR], deg[UR];
     bool valid[UR];
     float4 rr[UR], acc[UR];
@@ -669,6 +675,9 @@ __device__ __forceinline__ void seg_mean_bwd(Rows rw, int em, const u16* mrp, co
   const int rounds = (rw.hi - rw.lo + RPP * UR - 1) / (RPP * UR);
   const int elast = max(em - 1, 0);
   for (int it = 0; it < rounds; ++it) {
+    // waves whose rows of this trip all lie beyond the part skip it (wave-uniform): an idle wave that walks the trip with
+    // clamped rows costs the busy waves of its SIMD their issue slots
+    if (rw.lo + it * UR * RPP + (int)((threadIdx.x & ~63u) / G) >= rw.hi) continue;
     int r[UR], beg[UR], deg[UR];
     bool valid[UR];
     float4 acc[UR];
@@ -738,6 +747,9 @@ __device__ __forceinline__ void seg_edge_dots(Rows rw, int n0, const u16* rp, co
   const int hd = c0 / C;
   const int rounds = (rw.hi - rw.lo + RPP * UR - 1) / (RPP * UR);
   for (int it = 0; it < rounds; ++it) {
+    // waves whose rows of this trip all lie beyond the part skip it (wave-uniform): an idle wave that walks the trip with
+    // clamped rows costs the busy waves of its SIMD their issue slots
+    if (rw.lo + it * UR * RPP + (int)((threadIdx.x & ~63u) / G) >= rw.hi) continue;
     int r[UR], beg[UR], deg[UR];
     bool leader[UR];
     float4 go[UR];
@@ -851,6 +863,9 @@ __device__ __forceinline__ void seg_agg_bwd_src(Rows rw, int e0, const u16* trp,
   const float4 as = ld4(att_src + c0), ad = ld4(att_dst + c0);
   const int rounds = (rw.hi - rw.lo + RPP * UR - 1) / (RPP * UR);
   for (int it = 0; it < rounds; ++it) {
+    // waves whose rows of this trip all lie beyond the part skip it (wave-uniform): an idle wave that walks the trip with
+    // clamped rows costs the busy waves of its SIMD their issue slots
+    if (rw.lo + it * UR * RPP + (int)((threadIdx.x & ~63u) / G) >= rw.hi) continue;
     int r[UR], beg[UR], deg[UR];
     bool valid[UR];
     float4 acc[UR];
@@ -2378,7 +2393,7 @@ __global__ __launch_bounds__(THREADS) void gatres_window_kernel(const FusedArgs 
                                                                nullptr, 0, base + SL.o1, 0, wlA);
       __syncthreads();
       STAMP();
-      seg_edge_dots<2, NC, THREADS, 2>(rw, 0, rp, colo, RA, 0, hT1, ge1 + elo * 2, 0);
+      seg_edge_dots<2, NC, THREADS, 1>(rw, 0, rp, colo, RA, 0, hT1, ge1 + elo * 2, 0);
       lds_barrier();
       seg_bias_part<2 * NC, THREADS>(rw, RA, 0, red);
       seg_softmax_bwd<2, THREADS>(rw, 0, 0, rp, colo, alT1 + elo * 2, asT1, adT1, ge1 + elo * 2, 0, gad1, 0, nullptr, 0,
