@@ -33,6 +33,43 @@ static inline bool make_geom(int H, int C, RowGeom* g) {
 }
 
 // ------------------------------------------------------------------------------------------------------
+// Hub rows: wavefront-level segmented reductions with LDS-staged partial sums.
+// A destination (or, in the source-major pass, a source) with more edges than the slot paths take is not walked edge by
+// edge by its G lanes: the WHOLE wave turns to it.  The 64 lanes form S = 64/G edge slots of G feature lanes; slot k
+// takes edges beg + k, beg + k + S, ...; every reduction over the row's edges (softmax max, softmax sum, weighted
+// neighbour sum, ...) is formed as S partial results that are staged in LDS (hub_lds: one [S][4G] float tile per wave)
+// and summed in slot order by the row's own lanes.  Deterministic; the association differs from the edge-by-edge order
+// (fp32 reassociation only).  Water networks never take this path (degree <= 6); power-law graphs do.
+// ------------------------------------------------------------------------------------------------------
+constexpr int HUB_FLOATS_PER_WAVE = 64 * 4;
+__device__ __forceinline__ float* hub_tile(float* hub_lds) { return hub_lds + (threadIdx.x >> 6) * HUB_FLOATS_PER_WAVE; }
+// one scalar per lane -> the row's value for head-feature lane f: combine(slot 0, slot 1, ...) in slot order
+template <bool MAX>
+__device__ __forceinline__ float hub_reduce1(float v, float* tile, int G, int S, int f) {
+  const int lane = threadIdx.x & 63;
+  tile[lane] = v;
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_s_waitcnt(0xc07f);                 // lgkmcnt(0): the wave's own LDS writes have landed
+  float r = tile[f];
+  for (int k = 1; k < S; ++k) r = MAX ? fmaxf(r, tile[k * G + f]) : r + tile[k * G + f];
+  __builtin_amdgcn_wave_barrier();
+  return r;
+}
+__device__ __forceinline__ float4 hub_reduce4(float4 v, float* tile, int G, int S, int f) {
+  const int lane = threadIdx.x & 63;
+  st4(tile + lane * 4, v);
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_s_waitcnt(0xc07f);
+  float4 r = ld4(tile + f * 4);
+  for (int k = 1; k < S; ++k) {
+    const float4 t = ld4(tile + (k * G + f) * 4);
+    r.x = r.x + t.x; r.y = r.y + t.y; r.z = r.z + t.z; r.w = r.w + t.w;
+  }
+  __builtin_amdgcn_wave_barrier();
+  return r;
+}
+
+// ------------------------------------------------------------------------------------------------------
 // K2 forward
 // ------------------------------------------------------------------------------------------------------
 template <bool RELU, typename T>
@@ -40,18 +77,53 @@ __global__ __launch_bounds__(256) void gat_aggregate_fwd_kernel(
     const int* __restrict__ rowptr, const int* __restrict__ col, const T* __restrict__ h,
     const float* __restrict__ a_src, const float* __restrict__ a_dst, const float* __restrict__ bias,
     T* __restrict__ out, float* __restrict__ alpha, int N, RowGeom gm) {
+  __shared__ __attribute__((aligned(16))) float hub_lds[4 * HUB_FLOATS_PER_WAVE];
   const int tid = blockIdx.x * 256 + threadIdx.x;
-  const int row = tid >> gm.lgG;
-  if (row >= N) return;
+  int row = tid >> gm.lgG;
+  const bool valid = row < N;                  // (every lane stays: hub rows are processed by the whole wave)
+  if (!valid) row = N - 1;
   const int c0 = (tid & (gm.G - 1)) * 4;
   const int hd = c0 >> gm.lgC;
-  const bool leader = (c0 & (gm.C - 1)) == 0;
+  const bool leader = valid && (c0 & (gm.C - 1)) == 0;
   const int H = gm.H, HC = gm.HC;
   const int beg = rowptr[row], end = rowptr[row + 1];
   const float adst = a_dst[row * H + hd];
   float4 acc = f4zero();
   constexpr int MAXD = 6;                      // rows with <= 6 in-edges (every water-network row): slot path
-  if (__builtin_expect(end - beg <= MAXD, 1)) {
+  const bool hub = valid && end - beg > MAXD;
+  const unsigned long long hubs = __ballot(hub && c0 == 0);         // first lane of every hub row in this wave
+  if (__builtin_expect(hubs != 0ULL, 0)) {
+    const int lane = threadIdx.x & 63, G = gm.G, S = 64 >> gm.lgG;
+    const int f = lane & (G - 1), slot = lane >> gm.lgG;
+    float* tile = hub_tile(hub_lds);
+    unsigned long long todo = hubs;
+    while (todo) {
+      const int owner = __ffsll((long long)todo) - 1;                 // first lane of the hub row's lane group
+      todo &= todo - 1;
+      const int hrow = __shfl(row, owner), hbeg = __shfl(beg, owner), hend = __shfl(end, owner);
+      const int fc0 = f * 4, fhd = fc0 >> gm.lgC;
+      const bool fleader = (fc0 & (gm.C - 1)) == 0;
+      const float hadst = a_dst[hrow * H + fhd];
+      float m = -INFINITY;
+      for (int e = hbeg + slot; e < hend; e += S) m = fmaxf(m, gatres_leaky(a_src[col[e] * H + fhd] + hadst));
+      m = hub_reduce1<true>(m, tile, G, S, f);
+      float z = 0.f;
+      for (int e = hbeg + slot; e < hend; e += S) z = z + expf(gatres_leaky(a_src[col[e] * H + fhd] + hadst) - m);
+      const float Z = hub_reduce1<false>(z, tile, G, S, f) + GATRES_SOFTMAX_EPS;
+      float4 part = f4zero();
+      for (int e = hbeg + slot; e < hend; e += S) {
+        const int j = col[e];
+        const float al = expf(gatres_leaky(a_src[j * H + fhd] + hadst) - m) / Z;
+        if (fleader) alpha[(size_t)e * H + fhd] = al;
+        gatres_axpy4(part, al, ldrow4(h + (size_t)j * HC + fc0));
+      }
+      const float4 sum = hub_reduce4(part, tile, G, S, f);
+      if ((lane >> gm.lgG) == (owner >> gm.lgG)) acc = sum;            // the row's own lanes keep it (f == their feature lane)
+    }
+  }
+  if (hub) {
+    // (acc was formed above)
+  } else if (__builtin_expect(end - beg <= MAXD, 1)) {
     // every neighbour index, logit and feature row of this destination is requested at once: one dependent round
     // trip (col -> {a_src, h}) instead of three passes of edge-at-a-time chains.  Statement for statement the
     // arithmetic of the loop form below (and of the fused kernels' seg_softmax / seg_gather): bit-identical.
@@ -85,45 +157,13 @@ __global__ __launch_bounds__(256) void gat_aggregate_fwd_kernel(
         gatres_axpy4(acc, al, v[k]);
       }
     }
-  } else {
-  float m = -INFINITY;
-  for (int e = beg; e < end; ++e) {
-    const float s = gatres_leaky(a_src[col[e] * H + hd] + adst);
-    m = fmaxf(m, s);
-  }
-  float Z = 0.f;
-  for (int e = beg; e < end; ++e) {
-    const float s = gatres_leaky(a_src[col[e] * H + hd] + adst);
-    Z = Z + expf(s - m);
-  }
-  Z = Z + GATRES_SOFTMAX_EPS;
-
-  int e = beg;
-  // two edges per trip so both neighbour rows are in flight together
-  for (; e + 1 < end; e += 2) {
-    const int j0 = col[e], j1 = col[e + 1];
-    const float4 v0 = ldrow4(h + (size_t)j0 * HC + c0);
-    const float4 v1 = ldrow4(h + (size_t)j1 * HC + c0);
-    const float al0 = expf(gatres_leaky(a_src[j0 * H + hd] + adst) - m) / Z;
-    const float al1 = expf(gatres_leaky(a_src[j1 * H + hd] + adst) - m) / Z;
-    if (leader) { alpha[(size_t)e * H + hd] = al0; alpha[(size_t)(e + 1) * H + hd] = al1; }
-    gatres_axpy4(acc, al0, v0);
-    gatres_axpy4(acc, al1, v1);
-  }
-  if (e < end) {
-    const int j0 = col[e];
-    const float4 v0 = ldrow4(h + (size_t)j0 * HC + c0);
-    const float al0 = expf(gatres_leaky(a_src[j0 * H + hd] + adst) - m) / Z;
-    if (leader) alpha[(size_t)e * H + hd] = al0;
-    gatres_axpy4(acc, al0, v0);
-  }
   }
   const float4 b = ld4(bias + c0);
   acc.x = acc.x + b.x; acc.y = acc.y + b.y; acc.z = acc.z + b.z; acc.w = acc.w + b.w;
   if (RELU) {
     acc.x = fmaxf(acc.x, 0.f); acc.y = fmaxf(acc.y, 0.f); acc.z = fmaxf(acc.z, 0.f); acc.w = fmaxf(acc.w, 0.f);
   }
-  strow4(out + (size_t)row * HC + c0, acc);
+  if (valid) strow4(out + (size_t)row * HC + c0, acc);
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -151,6 +191,7 @@ __global__ __launch_bounds__(256) void gat_aggregate_bwd_dst_kernel(
     const int* __restrict__ rowptr, const int* __restrict__ col, const T* __restrict__ g_out,
     const T* __restrict__ h, const float* __restrict__ alpha, const float* __restrict__ a_src,
     const float* __restrict__ a_dst, float* __restrict__ g_e, float* __restrict__ g_a_dst, int N, RowGeom gm) {
+  __shared__ __attribute__((aligned(16))) float hub_lds[4 * HUB_FLOATS_PER_WAVE];
   const int tid = blockIdx.x * 256 + threadIdx.x;
   int row = tid >> gm.lgG;
   const bool valid = row < N;
@@ -164,7 +205,7 @@ __global__ __launch_bounds__(256) void gat_aggregate_bwd_dst_kernel(
   const float adst = a_dst[row * H + hd];
 
   float S = 0.f, gad = 0.f;
-  if (__builtin_expect(end - beg <= 8, 1)) {   // the common case: every load of the row issued together (slot path)
+  if (end - beg <= 8) {                        // the common case: every load of the row issued together (slot path)
     const int deg = end - beg;
     int jj[8];
 #pragma unroll
@@ -193,19 +234,40 @@ __global__ __launch_bounds__(256) void gat_aggregate_bwd_dst_kernel(
         gad = gad + ge;
       }
     }
-  } else {                              // hub rows: recompute the dots in the second pass
-    for (int e = beg; e < end; ++e) {
-      const float ga = head_dot(go, ldrow4(h + (size_t)col[e] * HC + c0), LH);
-      S = fmaf(alpha[(size_t)e * H + hd], ga, S);
-    }
-    for (int e = beg; e < end; ++e) {
-      const int j = col[e];
-      const float ga = head_dot(go, ldrow4(h + (size_t)j * HC + c0), LH);
-      const float gs = alpha[(size_t)e * H + hd] * (ga - S);
-      const float raw = a_src[j * H + hd] + adst;
-      const float ge = raw > 0.f ? gs : gs * GATRES_NEG_SLOPE;
-      if (leader) g_e[(size_t)e * H + hd] = ge;
-      gad = gad + ge;
+  }
+  // hub rows (more than 8 in-edges): the whole wave, S edge slots of G lanes, partial sums through LDS (see hub_reduce1)
+  const unsigned long long hubs = __ballot(valid && end - beg > 8 && c0 == 0);
+  if (__builtin_expect(hubs != 0ULL, 0)) {
+    const int lane = threadIdx.x & 63, G = gm.G, S = 64 >> gm.lgG;
+    const int f = lane & (G - 1), slot = lane >> gm.lgG;
+    float* tile = hub_tile(hub_lds);
+    unsigned long long todo = hubs;
+    while (todo) {
+      const int owner = __ffsll((long long)todo) - 1;
+      todo &= todo - 1;
+      const int hrow = __shfl(row, owner), hbeg = __shfl(beg, owner), hend = __shfl(end, owner);
+      const int fc0 = f * 4, fhd = fc0 >> gm.lgC;
+      const bool fleader = (fc0 & (gm.C - 1)) == 0;
+      const float4 hgo = ldrow4(g_out + (size_t)hrow * HC + fc0);
+      const float hadst = a_dst[hrow * H + fhd];
+      float sp = 0.f;
+      for (int e = hbeg + slot; e < hend; e += S) {
+        const float ga = head_dot(hgo, ldrow4(h + (size_t)col[e] * HC + fc0), LH);
+        sp = fmaf(alpha[(size_t)e * H + fhd], ga, sp);
+      }
+      const float Ss = hub_reduce1<false>(sp, tile, G, S, f);
+      float gp = 0.f;
+      for (int e = hbeg + slot; e < hend; e += S) {
+        const int j = col[e];
+        const float ga = head_dot(hgo, ldrow4(h + (size_t)j * HC + fc0), LH);
+        const float gs = alpha[(size_t)e * H + fhd] * (ga - Ss);
+        const float raw = a_src[j * H + fhd] + hadst;
+        const float ge = raw > 0.f ? gs : gs * GATRES_NEG_SLOPE;
+        if (fleader) g_e[(size_t)e * H + fhd] = ge;
+        gp = gp + ge;
+      }
+      const float gsum = hub_reduce1<false>(gp, tile, G, S, f);
+      if ((lane >> gm.lgG) == (owner >> gm.lgG)) gad = gsum;
     }
   }
   if (leader) g_a_dst[row * H + hd] = gad;
@@ -222,16 +284,44 @@ __global__ __launch_bounds__(256) void gat_aggregate_bwd_src_kernel(
     const T* __restrict__ g_out, const float* __restrict__ alpha, const float* __restrict__ g_e,
     const float* __restrict__ g_a_dst, const float* __restrict__ att_src, const float* __restrict__ att_dst,
     T* __restrict__ g_h, float* __restrict__ g_a_src, int N, RowGeom gm) {
+  __shared__ __attribute__((aligned(16))) float hub_lds[4 * HUB_FLOATS_PER_WAVE];
   const int tid = blockIdx.x * 256 + threadIdx.x;
-  const int row = tid >> gm.lgG;
-  if (row >= N) return;
+  int row = tid >> gm.lgG;
+  const bool valid = row < N;
+  if (!valid) row = N - 1;
   const int c0 = (tid & (gm.G - 1)) * 4;
   const int hd = c0 >> gm.lgC;
-  const bool leader = (c0 & (gm.C - 1)) == 0;
+  const bool leader = valid && (c0 & (gm.C - 1)) == 0;
   const int H = gm.H, HC = gm.HC;
-  const int beg = t_rowptr[row], end = t_rowptr[row + 1];
+  const int beg = t_rowptr[row], end0 = t_rowptr[row + 1];
   float4 acc = f4zero();
   float gas = 0.f;
+  // hub sources (more than 16 out-edges): the whole wave, S edge slots of G lanes, partial sums through LDS
+  const bool hub = valid && end0 - beg > 16;
+  const unsigned long long hubs = __ballot(hub && c0 == 0);
+  if (__builtin_expect(hubs != 0ULL, 0)) {
+    const int lane = threadIdx.x & 63, G = gm.G, S = 64 >> gm.lgG;
+    const int f = lane & (G - 1), slot = lane >> gm.lgG;
+    float* tile = hub_tile(hub_lds);
+    unsigned long long todo = hubs;
+    while (todo) {
+      const int owner = __ffsll((long long)todo) - 1;
+      todo &= todo - 1;
+      const int hbeg = __shfl(beg, owner), hend = __shfl(end0, owner);
+      const int fc0 = f * 4, fhd = fc0 >> gm.lgC;
+      float4 part = f4zero();
+      float gp = 0.f;
+      for (int tt = hbeg + slot; tt < hend; tt += S) {
+        const int e = t_eid[tt], i = t_dst[tt];
+        gp = gp + g_e[(size_t)e * H + fhd];
+        gatres_axpy4(part, alpha[(size_t)e * H + fhd], ldrow4(g_out + (size_t)i * HC + fc0));
+      }
+      const float4 sum = hub_reduce4(part, tile, G, S, f);
+      const float gsum = hub_reduce1<false>(gp, tile, G, S, f);
+      if ((lane >> gm.lgG) == (owner >> gm.lgG)) { acc = sum; gas = gsum; }
+    }
+  }
+  const int end = hub ? beg : end0;            // (a hub's edges are done)
   int t = beg;
   for (; t + 1 < end; t += 2) {
     const int e0 = t_eid[t], e1 = t_eid[t + 1];
@@ -256,7 +346,7 @@ __global__ __launch_bounds__(256) void gat_aggregate_bwd_src_kernel(
   const float4 as = ld4(att_src + c0), ad = ld4(att_dst + c0);
   gatres_axpy4(acc, gas, as);
   gatres_axpy4(acc, gad, ad);
-  strow4(g_h + (size_t)row * HC + c0, acc);
+  if (valid) strow4(g_h + (size_t)row * HC + c0, acc);
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -266,12 +356,35 @@ template <typename T>
 __global__ __launch_bounds__(256) void mean_residual_relu_fwd_kernel(
     const int* __restrict__ rowptr, const int* __restrict__ col, const T* __restrict__ y,
     const T* __restrict__ x0, T* __restrict__ out, int N, int C, int G, int lgG) {
+  __shared__ __attribute__((aligned(16))) float hub_lds[4 * HUB_FLOATS_PER_WAVE];
   const int tid = blockIdx.x * 256 + threadIdx.x;
-  const int row = tid >> lgG;
-  if (row >= N) return;
+  int row = tid >> lgG;
+  const bool valid = row < N;
+  if (!valid) row = N - 1;
   const int c0 = (tid & (G - 1)) * 4;
-  const int beg = rowptr[row], end = rowptr[row + 1];
+  const int beg = rowptr[row], end0 = rowptr[row + 1];
   float4 acc = f4zero();
+  const bool hub = valid && end0 - beg > 16;                    // hub rows: whole wave + LDS-staged partial sums
+  const unsigned long long hubs = __ballot(hub && c0 == 0);
+  if (__builtin_expect(hubs != 0ULL, 0)) {
+    const int lane = threadIdx.x & 63, S = 64 >> lgG;
+    const int f = lane & (G - 1), slot = lane >> lgG;
+    float* tile = hub_tile(hub_lds);
+    unsigned long long todo = hubs;
+    while (todo) {
+      const int owner = __ffsll((long long)todo) - 1;
+      todo &= todo - 1;
+      const int hbeg = __shfl(beg, owner), hend = __shfl(end0, owner);
+      float4 part = f4zero();
+      for (int e = hbeg + slot; e < hend; e += S) {
+        const float4 v = ldrow4(y + (size_t)col[e] * C + f * 4);
+        part.x = part.x + v.x; part.y = part.y + v.y; part.z = part.z + v.z; part.w = part.w + v.w;
+      }
+      const float4 sum = hub_reduce4(part, tile, G, S, f);
+      if ((lane >> lgG) == (owner >> lgG)) acc = sum;
+    }
+  }
+  const int end = hub ? beg : end0;
   int e = beg;
   for (; e + 1 < end; e += 2) {
     const float4 v0 = ldrow4(y + (size_t)col[e] * C + c0);
@@ -283,33 +396,58 @@ __global__ __launch_bounds__(256) void mean_residual_relu_fwd_kernel(
     const float4 v0 = ldrow4(y + (size_t)col[e] * C + c0);
     acc.x = acc.x + v0.x; acc.y = acc.y + v0.y; acc.z = acc.z + v0.z; acc.w = acc.w + v0.w;
   }
-  const float cnt = (float)max(end - beg, 1);
+  const float cnt = (float)max(end0 - beg, 1);
   const float4 r = ldrow4(x0 + (size_t)row * C + c0);
   float4 o;
   o.x = fmaxf(acc.x / cnt + r.x, 0.f);
   o.y = fmaxf(acc.y / cnt + r.y, 0.f);
   o.z = fmaxf(acc.z / cnt + r.z, 0.f);
   o.w = fmaxf(acc.w / cnt + r.w, 0.f);
-  strow4(out + (size_t)row * C + c0, o);
+  if (valid) strow4(out + (size_t)row * C + c0, o);
 }
 
 template <typename T>
 __global__ __launch_bounds__(256) void mean_bwd_kernel(
     const int* __restrict__ m_rowptr, const int* __restrict__ mt_rowptr, const int* __restrict__ mt_dst,
     const T* __restrict__ g_pre, T* __restrict__ g_y, int N, int C, int G, int lgG) {
+  __shared__ __attribute__((aligned(16))) float hub_lds[4 * HUB_FLOATS_PER_WAVE];
   const int tid = blockIdx.x * 256 + threadIdx.x;
-  const int row = tid >> lgG;
-  if (row >= N) return;
+  int row = tid >> lgG;
+  const bool valid = row < N;
+  if (!valid) row = N - 1;
   const int c0 = (tid & (G - 1)) * 4;
-  const int beg = mt_rowptr[row], end = mt_rowptr[row + 1];
+  const int beg = mt_rowptr[row], end0 = mt_rowptr[row + 1];
   float4 acc = f4zero();
+  const bool hub = valid && end0 - beg > 16;                    // hub sources: whole wave + LDS-staged partial sums
+  const unsigned long long hubs = __ballot(hub && c0 == 0);
+  if (__builtin_expect(hubs != 0ULL, 0)) {
+    const int lane = threadIdx.x & 63, S = 64 >> lgG;
+    const int f = lane & (G - 1), slot = lane >> lgG;
+    float* tile = hub_tile(hub_lds);
+    unsigned long long todo = hubs;
+    while (todo) {
+      const int owner = __ffsll((long long)todo) - 1;
+      todo &= todo - 1;
+      const int hbeg = __shfl(beg, owner), hend = __shfl(end0, owner);
+      float4 part = f4zero();
+      for (int t = hbeg + slot; t < hend; t += S) {
+        const int i = mt_dst[t];
+        const float cnt = (float)max(m_rowptr[i + 1] - m_rowptr[i], 1);
+        const float4 v = ldrow4(g_pre + (size_t)i * C + f * 4);
+        part.x = part.x + v.x / cnt; part.y = part.y + v.y / cnt; part.z = part.z + v.z / cnt; part.w = part.w + v.w / cnt;
+      }
+      const float4 sum = hub_reduce4(part, tile, G, S, f);
+      if ((lane >> lgG) == (owner >> lgG)) acc = sum;
+    }
+  }
+  const int end = hub ? beg : end0;
   for (int t = beg; t < end; ++t) {
     const int i = mt_dst[t];
     const float cnt = (float)max(m_rowptr[i + 1] - m_rowptr[i], 1);
     const float4 v = ldrow4(g_pre + (size_t)i * C + c0);
     acc.x = acc.x + v.x / cnt; acc.y = acc.y + v.y / cnt; acc.z = acc.z + v.z / cnt; acc.w = acc.w + v.w / cnt;
   }
-  strow4(g_y + (size_t)row * C + c0, acc);
+  if (valid) strow4(g_y + (size_t)row * C + c0, acc);
 }
 
 static inline bool graph_ok(const gatres_graph_t* g) {

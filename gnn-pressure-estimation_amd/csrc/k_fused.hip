@@ -1450,6 +1450,11 @@ __device__ __forceinline__ void consumer_main(const FusedArgs& a, int cid, float
   bool dead = false, remote = false;
   const int lane = threadIdx.x;
   const unsigned mine_xcc = xcc_id();
+  int cst = 1024;            // diagnostic stamps of consumer 0 (gatres_fused_set_stamps): [item available, item done] pairs
+#define CSTAMP()                                                                                    \
+  do {                                                                                              \
+    if (a.stamps && cid == 0 && threadIdx.x == 0 && cst < a.stamp_cap) a.stamps[cst++] = wall_clock64(); \
+  } while (0)
   for (int i = c; i < items; i += C) {
     if (threadIdx.x < 64) {
       // lanes 0 .. M-1 poll one part each; the wave leaves the loop together
@@ -1483,6 +1488,7 @@ __device__ __forceinline__ void consumer_main(const FusedArgs& a, int cid, float
       INV_WAIT();
     }
     __syncthreads();
+    CSTAMP();
     if (i < 2 * nb) {
       if (*mode) param_grads_item<NC, THREADS, false>(pg, seg, nb - 1 - i / 2, (i & 1) ? 0 : 1, false, part, red);
       else       param_grads_item<NC, THREADS, true>(pg, seg, nb - 1 - i / 2, (i & 1) ? 0 : 1, false, part, red);
@@ -1491,7 +1497,9 @@ __device__ __forceinline__ void consumer_main(const FusedArgs& a, int cid, float
       fold_parts<THREADS>(pg, seg, a.L.p_lin1_w, NC + 1);
     }
     __syncthreads();
+    CSTAMP();
   }
+#undef CSTAMP
   if (threadIdx.x < 64) {
     // reset the line for the next launch -- only after every producer's LAST publication, or that one would survive
     int spin = 0;

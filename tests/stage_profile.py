@@ -21,8 +21,10 @@ torch.cuda.synchronize()
 lib.gatres_fused_set_stamps(None, 0)
 raw = stamps.cpu().numpy()
 clk = raw[cap:cap + 3]
-s = raw[:cap]
+s = raw[:1024]
 s = s[s > 0]
+cs = raw[1024:cap]
+cs = cs[cs > 0]
 print('shader clock MHz ~', (clk[1] - clk[0]) / ((clk[2] - s[0]) / 100.0))
 d = (s[1:] - s[:-1]) / 100.0   # us
 print("stamps", len(s), "total us", (s[-1] - s[0]) / 100.0)
@@ -45,3 +47,14 @@ for k, v in acc.items():
     print(f"{k:12s} mean {sum(v)/len(v):8.2f} us  x{len(v)}  sum {sum(v):8.1f}")
     tot += sum(v)
 print("sum of block stages", tot, "remaining stamps", len(d) - i)
+
+if len(cs) >= 2:
+    # consumer workgroup 0: [item available, item done] pairs (100 MHz wall clock)
+    t0 = s[0]
+    avail, done = cs[0::2], cs[1::2]
+    n = min(len(avail), len(done))
+    work = (done[:n] - avail[:n]) / 100.0
+    print("consumer 0: %d items, work per item mean %.2f us (min %.2f max %.2f), first available at %.1f us, last done at %.1f us"
+          % (n, work.mean(), work.min(), work.max(), (avail[0] - t0) / 100.0, (done[n - 1] - t0) / 100.0))
+    print("   wait before each item (us):", " ".join("%.1f" % w for w in ((avail[1:n] - done[:n - 1]) / 100.0)))
+    print("   work of each item (us):   ", " ".join("%.1f" % w for w in work))

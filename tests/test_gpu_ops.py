@@ -12,7 +12,7 @@ def relerr(a, b):
     return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
 
 
-def graph(n, e, seed, self_loops=0, dup=0, hub=False):
+def graph(n, e, seed, self_loops=0, dup=0, hub=False, star=False):
     g = torch.Generator().manual_seed(seed)
     src = torch.randint(0, n, (e,), generator=g)
     dst = torch.randint(0, n, (e,), generator=g)
@@ -21,6 +21,13 @@ def graph(n, e, seed, self_loops=0, dup=0, hub=False):
     if hub:      # one destination with far more than 8 in-edges, and one isolated node (n-1)
         s = torch.arange(1, min(n - 1, 40))
         ei = torch.cat([ei[:, (ei[0] != n - 1) & (ei[1] != n - 1)], torch.stack([s, torch.zeros_like(s)])], 1)
+    if star:     # in- AND out-degree hubs handled by whole waves (k_aggregate.hip hub paths): node 0 <-> everyone, two
+        #          hubs in one wave (nodes 0, 1) and one in the ragged last wave (node n-1)
+        o = torch.arange(1, n)
+        a, b = torch.arange(2, 62), torch.arange(40, 70)
+        ei = torch.cat([ei, torch.stack([o, torch.zeros_like(o)]), torch.stack([torch.zeros_like(o), o]),
+                        torch.stack([a, torch.ones_like(a)]), torch.stack([torch.ones_like(a), a]),
+                        torch.stack([b, torch.full_like(b, n - 1)]), torch.stack([torch.full_like(b, n - 1), b])], 1)
     if self_loops:
         l = torch.randint(0, n - 1, (self_loops,), generator=g)
         ei = torch.cat([ei, torch.stack([l, l])], 1)
@@ -39,7 +46,8 @@ CASES = [(8, 1), (8, 2), (32, 2), (32, 1), (128, 2), (128, 1), (4, 2), (16, 2), 
 
 
 @pytest.mark.parametrize("C,H", CASES)
-@pytest.mark.parametrize("n,e,kw", [(97, 260, dict(self_loops=3, dup=5, hub=True)), (388 * 2, 860 * 2, {})])
+@pytest.mark.parametrize("n,e,kw", [(97, 260, dict(self_loops=3, dup=5, hub=True)), (388 * 2, 860 * 2, {}),
+                                    (203, 500, dict(self_loops=2, dup=4, star=True))])
 def test_gatconv_forward_and_backward(pkg, oracle, ops, C, H, n, e, kw):
     torch.manual_seed(C * 10 + H)
     K = C if H == 2 else 2 * C
@@ -82,10 +90,11 @@ def test_gatconv_forward_and_backward(pkg, oracle, ops, C, H, n, e, kw):
     assert relerr(g_b, leaves[4].grad) < 2e-5
 
 
+@pytest.mark.parametrize("star", [False, True])
 @pytest.mark.parametrize("C", [4, 32, 128])
-def test_mean_residual_relu_and_backward(pkg, oracle, ops, C):
+def test_mean_residual_relu_and_backward(pkg, oracle, ops, C, star):
     n = 131
-    ei = graph(n, 400, 3, self_loops=4, dup=6, hub=True)
+    ei = graph(n, 400, 3, self_loops=4, dup=6, hub=True, star=star)
     y = torch.randn(n, C, requires_grad=True)
     x0 = torch.randn(n, C, requires_grad=True)
     ref = (oracle.simple_conv_mean(y, ei) + x0).relu()
@@ -94,7 +103,8 @@ def test_mean_residual_relu_and_backward(pkg, oracle, ops, C):
     plan = pkg.GraphPlan(ei, n, device="cuda", reorder=False)
     out = ops.mean_residual_relu_fwd(plan, y.detach().cuda(), x0.detach().cuda())
     assert relerr(out, ref) < 1e-6
-    assert float(out[n - 1].cpu().sub(x0.detach()[n - 1].relu()).abs().max()) == 0.0   # isolated node: mean = 0
+    if not star:
+        assert float(out[n - 1].cpu().sub(x0.detach()[n - 1].relu()).abs().max()) == 0.0   # isolated node: mean = 0
     g_pre = (g_up * (ref.detach() > 0)).cuda()
     assert relerr(ops.mean_bwd(plan, g_pre), y.grad) < 1e-6
     assert relerr(g_pre, x0.grad) == 0.0
