@@ -39,9 +39,10 @@ static inline bool make_geom(int H, int C, RowGeom* g) {
 // takes edges beg + k, beg + k + S, ...; every reduction over the row's edges (softmax max, softmax sum, weighted
 // neighbour sum, ...) is formed as S partial results that are staged in LDS (hub_lds: one [S][4G] float tile per wave)
 // and summed in slot order by the row's own lanes.  Deterministic; the association differs from the edge-by-edge order
-// (fp32 reassociation only).  Water networks never take this path (degree <= 6); power-law graphs do.
+// (fp32 reassociation only).  Water networks never take this path (degree <= 6); power-law graphs do, for rows with more than HUB_MIN_DEGREE edges.
 // ------------------------------------------------------------------------------------------------------
 constexpr int HUB_FLOATS_PER_WAVE = 64 * 4;
+constexpr int HUB_MIN_DEGREE = 32;             // up to here a row's own G lanes walk its edges (4 to 16 rows per wave in flight)
 __device__ __forceinline__ float* hub_tile(float* hub_lds) { return hub_lds + (threadIdx.x >> 6) * HUB_FLOATS_PER_WAVE; }
 // one scalar per lane -> the row's value for head-feature lane f: combine(slot 0, slot 1, ...) in slot order
 template <bool MAX>
@@ -73,7 +74,7 @@ __device__ __forceinline__ float4 hub_reduce4(float4 v, float* tile, int G, int 
 // K2 forward
 // ------------------------------------------------------------------------------------------------------
 template <bool RELU, typename T>
-__global__ __launch_bounds__(256) void gat_aggregate_fwd_kernel(
+__global__ __launch_bounds__(256, 8) void gat_aggregate_fwd_kernel(
     const int* __restrict__ rowptr, const int* __restrict__ col, const T* __restrict__ h,
     const float* __restrict__ a_src, const float* __restrict__ a_dst, const float* __restrict__ bias,
     T* __restrict__ out, float* __restrict__ alpha, int N, RowGeom gm) {
@@ -90,7 +91,7 @@ __global__ __launch_bounds__(256) void gat_aggregate_fwd_kernel(
   const float adst = a_dst[row * H + hd];
   float4 acc = f4zero();
   constexpr int MAXD = 6;                      // rows with <= 6 in-edges (every water-network row): slot path
-  const bool hub = valid && end - beg > MAXD;
+  const bool hub = valid && end - beg > HUB_MIN_DEGREE;
   const unsigned long long hubs = __ballot(hub && c0 == 0);         // first lane of every hub row in this wave
   if (__builtin_expect(hubs != 0ULL, 0)) {
     const int lane = threadIdx.x & 63, G = gm.G, S = 64 >> gm.lgG;
@@ -105,13 +106,13 @@ __global__ __launch_bounds__(256) void gat_aggregate_fwd_kernel(
       const bool fleader = (fc0 & (gm.C - 1)) == 0;
       const float hadst = a_dst[hrow * H + fhd];
       float m = -INFINITY;
-      for (int e = hbeg + slot; e < hend; e += S) m = fmaxf(m, gatres_leaky(a_src[col[e] * H + fhd] + hadst));
+      _Pragma("unroll 2") for (int e = hbeg + slot; e < hend; e += S) m = fmaxf(m, gatres_leaky(a_src[col[e] * H + fhd] + hadst));
       m = hub_reduce1<true>(m, tile, G, S, f);
       float z = 0.f;
-      for (int e = hbeg + slot; e < hend; e += S) z = z + expf(gatres_leaky(a_src[col[e] * H + fhd] + hadst) - m);
+      _Pragma("unroll 2") for (int e = hbeg + slot; e < hend; e += S) z = z + expf(gatres_leaky(a_src[col[e] * H + fhd] + hadst) - m);
       const float Z = hub_reduce1<false>(z, tile, G, S, f) + GATRES_SOFTMAX_EPS;
       float4 part = f4zero();
-      for (int e = hbeg + slot; e < hend; e += S) {
+      _Pragma("unroll 2") for (int e = hbeg + slot; e < hend; e += S) {
         const int j = col[e];
         const float al = expf(gatres_leaky(a_src[j * H + fhd] + hadst) - m) / Z;
         if (fleader) alpha[(size_t)e * H + fhd] = al;
@@ -157,6 +158,38 @@ __global__ __launch_bounds__(256) void gat_aggregate_fwd_kernel(
         gatres_axpy4(acc, al, v[k]);
       }
     }
+  } else {                                     // up to HUB_MIN_DEGREE in-edges: the row's own lanes, edge after edge
+  float m = -INFINITY;
+  for (int e = beg; e < end; ++e) {
+    const float s = gatres_leaky(a_src[col[e] * H + hd] + adst);
+    m = fmaxf(m, s);
+  }
+  float Z = 0.f;
+  for (int e = beg; e < end; ++e) {
+    const float s = gatres_leaky(a_src[col[e] * H + hd] + adst);
+    Z = Z + expf(s - m);
+  }
+  Z = Z + GATRES_SOFTMAX_EPS;
+
+  int e = beg;
+  // two edges per trip so both neighbour rows are in flight together
+  for (; e + 1 < end; e += 2) {
+    const int j0 = col[e], j1 = col[e + 1];
+    const float4 v0 = ldrow4(h + (size_t)j0 * HC + c0);
+    const float4 v1 = ldrow4(h + (size_t)j1 * HC + c0);
+    const float al0 = expf(gatres_leaky(a_src[j0 * H + hd] + adst) - m) / Z;
+    const float al1 = expf(gatres_leaky(a_src[j1 * H + hd] + adst) - m) / Z;
+    if (leader) { alpha[(size_t)e * H + hd] = al0; alpha[(size_t)(e + 1) * H + hd] = al1; }
+    gatres_axpy4(acc, al0, v0);
+    gatres_axpy4(acc, al1, v1);
+  }
+  if (e < end) {
+    const int j0 = col[e];
+    const float4 v0 = ldrow4(h + (size_t)j0 * HC + c0);
+    const float al0 = expf(gatres_leaky(a_src[j0 * H + hd] + adst) - m) / Z;
+    if (leader) alpha[(size_t)e * H + hd] = al0;
+    gatres_axpy4(acc, al0, v0);
+  }
   }
   const float4 b = ld4(bias + c0);
   acc.x = acc.x + b.x; acc.y = acc.y + b.y; acc.z = acc.z + b.z; acc.w = acc.w + b.w;
@@ -187,7 +220,7 @@ __device__ __forceinline__ float head_dot(const float4 a, const float4 b, int la
 }
 
 template <typename T>
-__global__ __launch_bounds__(256) void gat_aggregate_bwd_dst_kernel(
+__global__ __launch_bounds__(256, 7) void gat_aggregate_bwd_dst_kernel(
     const int* __restrict__ rowptr, const int* __restrict__ col, const T* __restrict__ g_out,
     const T* __restrict__ h, const float* __restrict__ alpha, const float* __restrict__ a_src,
     const float* __restrict__ a_dst, float* __restrict__ g_e, float* __restrict__ g_a_dst, int N, RowGeom gm) {
@@ -201,42 +234,9 @@ __global__ __launch_bounds__(256) void gat_aggregate_bwd_dst_kernel(
   const bool leader = valid && (c0 & (gm.C - 1)) == 0;
   const int H = gm.H, HC = gm.HC, LH = gm.C >> 2;
   const int beg = rowptr[row], end = rowptr[row + 1];
-  const float4 go = ldrow4(g_out + (size_t)row * HC + c0);
-  const float adst = a_dst[row * H + hd];
-
   float S = 0.f, gad = 0.f;
-  if (end - beg <= 8) {                        // the common case: every load of the row issued together (slot path)
-    const int deg = end - beg;
-    int jj[8];
-#pragma unroll
-    for (int k = 0; k < 8; ++k) jj[k] = col[beg + min(k, deg - 1)];
-    float4 hv[8];
-    float al[8], as[8];
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      hv[k] = ldrow4(h + (size_t)jj[k] * HC + c0);
-      al[k] = alpha[(size_t)(beg + min(k, deg - 1)) * H + hd];
-      as[k] = a_src[jj[k] * H + hd];
-    }
-    float ga[8];
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      ga[k] = head_dot(go, hv[k], LH);
-      if (k < deg) S = fmaf(al[k], ga[k], S);
-    }
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      if (k < deg) {
-        const float gs = al[k] * (ga[k] - S);
-        const float raw = as[k] + adst;
-        const float ge = raw > 0.f ? gs : gs * GATRES_NEG_SLOPE;
-        if (leader) g_e[(size_t)(beg + k) * H + hd] = ge;
-        gad = gad + ge;
-      }
-    }
-  }
-  // hub rows (more than 8 in-edges): the whole wave, S edge slots of G lanes, partial sums through LDS (see hub_reduce1)
-  const unsigned long long hubs = __ballot(valid && end - beg > 8 && c0 == 0);
+  // hub rows: the whole wave, S edge slots of G lanes, partial sums through LDS (see hub_reduce1)
+  const unsigned long long hubs = __ballot(valid && end - beg > HUB_MIN_DEGREE && c0 == 0);
   if (__builtin_expect(hubs != 0ULL, 0)) {
     const int lane = threadIdx.x & 63, G = gm.G, S = 64 >> gm.lgG;
     const int f = lane & (G - 1), slot = lane >> gm.lgG;
@@ -270,6 +270,52 @@ __global__ __launch_bounds__(256) void gat_aggregate_bwd_dst_kernel(
       if ((lane >> gm.lgG) == (owner >> gm.lgG)) gad = gsum;
     }
   }
+  const float4 go = ldrow4(g_out + (size_t)row * HC + c0);
+  const float adst = a_dst[row * H + hd];
+  if (end - beg <= 8) {                        // the common case: every load of the row issued together (slot path)
+    const int deg = end - beg;
+    int jj[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) jj[k] = col[beg + min(k, deg - 1)];
+    float4 hv[8];
+    float al[8], as[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      hv[k] = ldrow4(h + (size_t)jj[k] * HC + c0);
+      al[k] = alpha[(size_t)(beg + min(k, deg - 1)) * H + hd];
+      as[k] = a_src[jj[k] * H + hd];
+    }
+    float ga[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      ga[k] = head_dot(go, hv[k], LH);
+      if (k < deg) S = fmaf(al[k], ga[k], S);
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      if (k < deg) {
+        const float gs = al[k] * (ga[k] - S);
+        const float raw = as[k] + adst;
+        const float ge = raw > 0.f ? gs : gs * GATRES_NEG_SLOPE;
+        if (leader) g_e[(size_t)(beg + k) * H + hd] = ge;
+        gad = gad + ge;
+      }
+    }
+  } else if (end - beg <= HUB_MIN_DEGREE) {    // the row's own lanes, edge after edge; the dots are recomputed in the second pass
+    for (int e = beg; e < end; ++e) {
+      const float ga = head_dot(go, ldrow4(h + (size_t)col[e] * HC + c0), LH);
+      S = fmaf(alpha[(size_t)e * H + hd], ga, S);
+    }
+    for (int e = beg; e < end; ++e) {
+      const int j = col[e];
+      const float ga = head_dot(go, ldrow4(h + (size_t)j * HC + c0), LH);
+      const float gs = alpha[(size_t)e * H + hd] * (ga - S);
+      const float raw = a_src[j * H + hd] + adst;
+      const float ge = raw > 0.f ? gs : gs * GATRES_NEG_SLOPE;
+      if (leader) g_e[(size_t)e * H + hd] = ge;
+      gad = gad + ge;
+    }
+  }
   if (leader) g_a_dst[row * H + hd] = gad;
 }
 
@@ -279,7 +325,7 @@ __global__ __launch_bounds__(256) void gat_aggregate_bwd_dst_kernel(
 //   g_h[j]     = sum_{e=(j->i)} alpha_e * g_out[i]  +  g_a_src[j] (x) att_src  +  g_a_dst[j] (x) att_dst
 // ------------------------------------------------------------------------------------------------------
 template <typename T>
-__global__ __launch_bounds__(256) void gat_aggregate_bwd_src_kernel(
+__global__ __launch_bounds__(256, 8) void gat_aggregate_bwd_src_kernel(
     const int* __restrict__ t_rowptr, const int* __restrict__ t_eid, const int* __restrict__ t_dst,
     const T* __restrict__ g_out, const float* __restrict__ alpha, const float* __restrict__ g_e,
     const float* __restrict__ g_a_dst, const float* __restrict__ att_src, const float* __restrict__ att_dst,
@@ -296,8 +342,8 @@ __global__ __launch_bounds__(256) void gat_aggregate_bwd_src_kernel(
   const int beg = t_rowptr[row], end0 = t_rowptr[row + 1];
   float4 acc = f4zero();
   float gas = 0.f;
-  // hub sources (more than 16 out-edges): the whole wave, S edge slots of G lanes, partial sums through LDS
-  const bool hub = valid && end0 - beg > 16;
+  // hub sources (more than HUB_MIN_DEGREE out-edges): the whole wave, S edge slots of G lanes, partial sums through LDS
+  const bool hub = valid && end0 - beg > HUB_MIN_DEGREE;
   const unsigned long long hubs = __ballot(hub && c0 == 0);
   if (__builtin_expect(hubs != 0ULL, 0)) {
     const int lane = threadIdx.x & 63, G = gm.G, S = 64 >> gm.lgG;
@@ -311,7 +357,7 @@ __global__ __launch_bounds__(256) void gat_aggregate_bwd_src_kernel(
       const int fc0 = f * 4, fhd = fc0 >> gm.lgC;
       float4 part = f4zero();
       float gp = 0.f;
-      for (int tt = hbeg + slot; tt < hend; tt += S) {
+      _Pragma("unroll 2") for (int tt = hbeg + slot; tt < hend; tt += S) {
         const int e = t_eid[tt], i = t_dst[tt];
         gp = gp + g_e[(size_t)e * H + fhd];
         gatres_axpy4(part, alpha[(size_t)e * H + fhd], ldrow4(g_out + (size_t)i * HC + fc0));
@@ -353,7 +399,7 @@ __global__ __launch_bounds__(256) void gat_aggregate_bwd_src_kernel(
 // K3: out_i = relu( (sum_{j->i} y[j]) / max(indeg(i),1) + x0_i )       and its backward
 // ------------------------------------------------------------------------------------------------------
 template <typename T>
-__global__ __launch_bounds__(256) void mean_residual_relu_fwd_kernel(
+__global__ __launch_bounds__(256, 8) void mean_residual_relu_fwd_kernel(
     const int* __restrict__ rowptr, const int* __restrict__ col, const T* __restrict__ y,
     const T* __restrict__ x0, T* __restrict__ out, int N, int C, int G, int lgG) {
   __shared__ __attribute__((aligned(16))) float hub_lds[4 * HUB_FLOATS_PER_WAVE];
@@ -364,7 +410,7 @@ __global__ __launch_bounds__(256) void mean_residual_relu_fwd_kernel(
   const int c0 = (tid & (G - 1)) * 4;
   const int beg = rowptr[row], end0 = rowptr[row + 1];
   float4 acc = f4zero();
-  const bool hub = valid && end0 - beg > 16;                    // hub rows: whole wave + LDS-staged partial sums
+  const bool hub = valid && end0 - beg > HUB_MIN_DEGREE;                    // hub rows: whole wave + LDS-staged partial sums
   const unsigned long long hubs = __ballot(hub && c0 == 0);
   if (__builtin_expect(hubs != 0ULL, 0)) {
     const int lane = threadIdx.x & 63, S = 64 >> lgG;
@@ -376,7 +422,7 @@ __global__ __launch_bounds__(256) void mean_residual_relu_fwd_kernel(
       todo &= todo - 1;
       const int hbeg = __shfl(beg, owner), hend = __shfl(end0, owner);
       float4 part = f4zero();
-      for (int e = hbeg + slot; e < hend; e += S) {
+      _Pragma("unroll 2") for (int e = hbeg + slot; e < hend; e += S) {
         const float4 v = ldrow4(y + (size_t)col[e] * C + f * 4);
         part.x = part.x + v.x; part.y = part.y + v.y; part.z = part.z + v.z; part.w = part.w + v.w;
       }
@@ -407,7 +453,7 @@ __global__ __launch_bounds__(256) void mean_residual_relu_fwd_kernel(
 }
 
 template <typename T>
-__global__ __launch_bounds__(256) void mean_bwd_kernel(
+__global__ __launch_bounds__(256, 8) void mean_bwd_kernel(
     const int* __restrict__ m_rowptr, const int* __restrict__ mt_rowptr, const int* __restrict__ mt_dst,
     const T* __restrict__ g_pre, T* __restrict__ g_y, int N, int C, int G, int lgG) {
   __shared__ __attribute__((aligned(16))) float hub_lds[4 * HUB_FLOATS_PER_WAVE];
@@ -418,7 +464,7 @@ __global__ __launch_bounds__(256) void mean_bwd_kernel(
   const int c0 = (tid & (G - 1)) * 4;
   const int beg = mt_rowptr[row], end0 = mt_rowptr[row + 1];
   float4 acc = f4zero();
-  const bool hub = valid && end0 - beg > 16;                    // hub sources: whole wave + LDS-staged partial sums
+  const bool hub = valid && end0 - beg > HUB_MIN_DEGREE;                    // hub sources: whole wave + LDS-staged partial sums
   const unsigned long long hubs = __ballot(hub && c0 == 0);
   if (__builtin_expect(hubs != 0ULL, 0)) {
     const int lane = threadIdx.x & 63, S = 64 >> lgG;
@@ -430,7 +476,7 @@ __global__ __launch_bounds__(256) void mean_bwd_kernel(
       todo &= todo - 1;
       const int hbeg = __shfl(beg, owner), hend = __shfl(end0, owner);
       float4 part = f4zero();
-      for (int t = hbeg + slot; t < hend; t += S) {
+      _Pragma("unroll 2") for (int t = hbeg + slot; t < hend; t += S) {
         const int i = mt_dst[t];
         const float cnt = (float)max(m_rowptr[i + 1] - m_rowptr[i], 1);
         const float4 v = ldrow4(g_pre + (size_t)i * C + f * 4);
