@@ -58,6 +58,7 @@ struct FusedArgs {
   int num_segments;
   int M;                    // workgroups (CUs) per segment
   int safe_sync;            // diagnostic (GATRES_FUSED_SAFE_SYNC=1): always use agent-scope barriers
+  int keep_lds;             // window kernel, forward + backward in one launch: ReLU sign masks and own-row g_pre stay in LDS
   int no_halo;              // diagnostic (GATRES_FUSED_NO_HALO=1): always take the bulk-pull fallback
   int C;                    // consumer workgroups per segment (deferred parameter gradients on spare CUs), 0 = none
   unsigned* ready;          // [segment][4] lines: items published by the segment's part 0 for each consumer
@@ -108,6 +109,9 @@ static bool nocache_fits(int nc, int threads, int n, int eg, int em) {
 // is split over several CUs (see group_sync) each part owns a 16-aligned window and the tables it gathers from are
 // completed from the partners' global copies after a flag barrier.
 struct Rows { int lo, hi; };
+// workgroup-uniform values that reach the kernel through vector loads (LDS words, global CSR entries the compiler does not
+// scalarise): pinned to SGPRs, so everything derived from them -- table bases, counts, loop bounds -- is scalar as well
+__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
 
 // caller-side index of plan node `node` (gatres_graph_t.perm): only x / y / mask / out / g_out / g_x are indexed with it
 __device__ __forceinline__ int ext_id(const int* __restrict__ perm, int node) { return perm ? perm[node] : node; }
@@ -181,6 +185,22 @@ __device__ __forceinline__ void copy_idx16(u16* dst, const int* __restrict__ src
 
 enum { EPI_NONE = 0, EPI_ATT = 1, EPI_RESID_MASK = 2 };
 
+// ReLU sign mask of one row: G lanes hold the row's float4 column groups; the word packs four fields FS bits apart, field c
+// bit l = (component c of lane l's float4 is positive).  The forward stages of the window kernel leave these in LDS so
+// the dX epilogues of the backward phase mask without reading the saved activations back from HBM.  (Every lane of the
+// wave calls this.)
+template <int G, int FS>
+__device__ __forceinline__ unsigned long long relu_bits(const float4 o) {
+  static_assert(G <= FS && 4 * FS <= 64 && 64 % G == 0, "field layout");
+  const int sh = ((threadIdx.x & 63) / G) * G;
+  const unsigned long long fm = (1ull << G) - 1;
+  unsigned long long w = (__ballot(o.x > 0.f) >> sh) & fm;
+  w |= ((__ballot(o.y > 0.f) >> sh) & fm) << FS;
+  w |= ((__ballot(o.z > 0.f) >> sh) & fm) << (2 * FS);
+  w |= ((__ballot(o.w > 0.f) >> sh) & fm) << (3 * FS);
+  return w;
+}
+
 // ------------------------------------------------------------------------------------------ K1 (MFMA)
 // OUT[ob + r, :] = X[xb + r, :] @ Wm^T for r in [0, n).  Same lane map / k order as proj_kernel (k_proj.hip), so
 // results are bit-identical; each wave takes TWO 16-node tiles per trip and feeds both from one W fragment load.
@@ -189,7 +209,11 @@ __device__ __forceinline__ void seg_proj(Rows rw, const float* X, int xb, const 
                                          int ob, float* OUT2, int o2b, const float* __restrict__ att_src,
                                          const float* __restrict__ att_dst, float* as_g, float* ad_g, int ag_b,
                                          float* as_l, float* ad_l, const float* resid, int rb,
-                                         const float* relu_ref, int mb_, float* wl) {
+                                         const float* relu_ref, int mb_, float* wl,
+                                         const float* resid_l = nullptr, float* OUT3 = nullptr,
+                                         const unsigned long long* m64 = nullptr, const unsigned* m32 = nullptr) {
+  // (resid_l / OUT3: LDS [row][M] copies used instead of resid / in addition to OUT; m64 / m32: relu_bits words per row,
+  //  fields 16 / 8 bits apart, used instead of relu_ref)
   constexpr int KQ = K / 4, NT = (M + 15) / 16, NW = THREADS / 64;
   constexpr int KP = K + 4;                  // padded LDS row: 16 lanes x float4 at stride KP hit distinct banks
   constexpr int SC = (KQ % 4 == 0) ? 4 : ((KQ % 2 == 0) ? 2 : 1);
@@ -261,14 +285,25 @@ __device__ __forceinline__ void seg_proj(Rows rw, const float* X, int xb, const 
       }
     }
     if (rok) {
+      unsigned long long mw = 0;
+      int fs = 16;
+      if constexpr (EPI == EPI_RESID_MASK) {
+        if (m64) mw = m64[r];
+        else if (m32) { mw = m32[r]; fs = 8; }
+      }
 #pragma unroll
       for (int tt = 0; tt < NT; ++tt) {
         const int mb = tt * 16 + q * 4;
         if ((M % 16 == 0) || (mb < M)) {
           float4 o = make_float4(acc[tt][0], acc[tt][1], acc[tt][2], acc[tt][3]);
           if constexpr (EPI == EPI_RESID_MASK) {
-            if (resid) add4(o, ld4(resid + (unsigned)((rb + r) * M + mb)));
-            if (relu_ref) {
+            if (resid_l) add4(o, ld4(resid_l + (unsigned)(r * M + mb)));
+            else if (resid) add4(o, ld4(resid + (unsigned)((rb + r) * M + mb)));
+            if (m64 || m32) {
+              const unsigned long long b = mw >> (mb >> 2);
+              o.x = (b & 1) ? o.x : 0.f;                 o.y = ((b >> fs) & 1) ? o.y : 0.f;
+              o.z = ((b >> (2 * fs)) & 1) ? o.z : 0.f;   o.w = ((b >> (3 * fs)) & 1) ? o.w : 0.f;
+            } else if (relu_ref) {
               const float4 rr = ld4(relu_ref + (unsigned)((mb_ + r) * M + mb));
               o.x = rr.x > 0.f ? o.x : 0.f; o.y = rr.y > 0.f ? o.y : 0.f;
               o.z = rr.z > 0.f ? o.z : 0.f; o.w = rr.w > 0.f ? o.w : 0.f;
@@ -276,6 +311,7 @@ __device__ __forceinline__ void seg_proj(Rows rw, const float* X, int xb, const 
           }
           st4(OUT + (unsigned)((ob + r) * M + mb), o);
           if (OUT2) st4(OUT2 + (unsigned)((o2b + r) * M + mb), o);
+          if (OUT3) st4(OUT3 + (unsigned)(r * M + mb), o);
         }
       }
     }
@@ -476,6 +512,32 @@ __device__ __forceinline__ int max_of(const int (&d)[U]) {
   return m;
 }
 
+constexpr int SPIN_LIMIT = 1 << 20;             // a lost partner poisons the results instead of hanging the GPU
+// ---- granule primitives of the window kernel's exchange (described at xch_export below)
+typedef unsigned long long u64;
+// local: every part of the segment runs on ONE XCD (verified from HW_REG_XCC_ID at the launch's first barrier).  Then a
+// plain 8-byte store is enough: it writes through the CU's L1 into the XCD's L2 and KEEPS the line there, where the
+// partner's sc1 load (L1 bypassed) finds it at L2 latency.  Anywhere else the store is an agent-scope one (sc1: written
+// through to memory, line dropped from this L2), which any XCD's sc1 load observes -- slower, never wrong.
+__device__ __forceinline__ void gran_store(u64* p, float v, unsigned tag, bool local) {
+  const u64 g = ((u64)tag << 32) | (u64)__float_as_uint(v);
+  if (local) __hip_atomic_store(p, g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+  else       __hip_atomic_store(p, g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ u64 gran_load(u64* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+struct Xch {
+  u64* base;            // this segment's region
+  u64* base_hb;         // its heartbeat granules [6 points][8 parts]
+  unsigned ep;          // epoch of the current exchange
+  int M, part;
+  int* err;
+  bool dead;
+  bool local;           // all parts on one XCD (Group::local)
+};
+
 // K2 forward, sub-stage A: attention coefficients.  ONE thread per (row, head): no cross-lane traffic, one exp and
 // one divide per edge.  (A single-stage K2 in which every lane of a head recomputes the coefficients was measured
 // twice -- one CU per snapshot and ~100 rows per part of a split snapshot: the redundant exp / divide work costs more
@@ -514,13 +576,14 @@ __device__ __forceinline__ void seg_softmax(Rows rw, const u16* rp, const u16* c
         }
     } else {
       const int end = beg + deg;
+      auto at = [&](int e) -> float { return asrc[(unsigned)((ab + col[e]) * H + hd)]; };
       float m = -INFINITY;
-      for (int e = beg; e < end; ++e) m = fmaxf(m, gatres_leaky(asrc[(unsigned)((ab + col[e]) * H + hd)] + adst));
+      for (int e = beg; e < end; ++e) m = fmaxf(m, gatres_leaky(at(e) + adst));
       float Z = 0.f;
-      for (int e = beg; e < end; ++e) Z = Z + expf(gatres_leaky(asrc[(unsigned)((ab + col[e]) * H + hd)] + adst) - m);
+      for (int e = beg; e < end; ++e) Z = Z + expf(gatres_leaky(at(e) + adst) - m);
       Z = Z + GATRES_SOFTMAX_EPS;
       for (int e = beg; e < end; ++e) {
-        const float al = expf(gatres_leaky(asrc[(unsigned)((ab + col[e]) * H + hd)] + adst) - m) / Z;
+        const float al = expf(gatres_leaky(at(e) + adst) - m) / Z;
         alpha_g[(unsigned)((eb + e) * H + hd)] = al;
         if constexpr (ALDS) alpha_l[e * H + hd] = al;
       }
@@ -535,7 +598,8 @@ __device__ __forceinline__ void seg_softmax(Rows rw, const u16* rp, const u16* c
 template <bool RELU, int H, int C, int THREADS, int UR = 2>
 __device__ __forceinline__ void seg_gather(Rows rw, const u16* rp, const u16* col, const float* hsrc, int hb,
                                            const float* alpha, int ab2, const float* __restrict__ bias, float* out,
-                                           int ob, float* out_pub = nullptr, int opb = 0) {
+                                           int ob, float* out_pub = nullptr, int opb = 0,
+                                           unsigned long long* mask64 = nullptr) {
   constexpr int HC = H * C, G = HC / 4, RPP = THREADS / G;
   const int c0 = (threadIdx.x % G) * 4;
   const int hd = c0 / C;
@@ -596,6 +660,12 @@ __device__ __forceinline__ void seg_gather(Rows rw, const u16* rp, const u16* co
         st4(out + (unsigned)((ob + r[u]) * HC + c0), acc[u]);
         if (out_pub) st4(out_pub + (unsigned)((opb + r[u]) * HC + c0), acc[u]);
       }
+      if constexpr (RELU && G <= 16) {
+        if (mask64) {                                             // (workgroup-uniform)
+          const unsigned long long w = relu_bits<G, 16>(acc[u]);
+          if (valid[u] && threadIdx.x % G == 0) mask64[r[u]] = w;
+        }
+      }
     }
   }
 }
@@ -604,7 +674,7 @@ __device__ __forceinline__ void seg_gather(Rows rw, const u16* rp, const u16* co
 template <int C, int THREADS, int UR = 2>
 __device__ __forceinline__ void seg_mean_fwd(Rows rw, int em, const u16* mrp, const u16* mcol, const float* y, int yb,
                                              const float* x0, int xb, float* out, int ob, float* out2 = nullptr,
-                                             int o2b = 0) {
+                                             int o2b = 0, unsigned* mask32 = nullptr) {
   constexpr int G = C / 4, RPP = THREADS / G;
   const int c0 = (threadIdx.x % G) * 4;
   const int rounds = (rw.hi - rw.lo + RPP * UR - 1) / (RPP * UR);
@@ -660,6 +730,12 @@ __device__ __forceinline__ void seg_mean_fwd(Rows rw, int em, const u16* mrp, co
       if (valid[u]) {
         st4(out + (unsigned)((ob + r[u]) * C + c0), o);
         if (out2) st4(out2 + (unsigned)((o2b + r[u]) * C + c0), o);
+      }
+      if constexpr (G <= 8) {
+        if (mask32) {                                             // (workgroup-uniform)
+          const unsigned w = (unsigned)relu_bits<G, 8>(o);
+          if (valid[u] && threadIdx.x % G == 0) mask32[r[u]] = w;
+        }
       }
     }
   }
@@ -1010,7 +1086,7 @@ template <int NC, int THREADS>
 __device__ __forceinline__ void seg_lin1_bwd(Rows rw, int n0, const int* __restrict__ perm, const float* __restrict__ g_out,
                                              const float* __restrict__ x, const float* __restrict__ w, float* g_x,
                                              float* g_x2, float* __restrict__ slab_w, float* __restrict__ slab_b,
-                                             int relu_mask, float* red) {
+                                             int relu_mask, float* red, float* g_x3 = nullptr) {
   constexpr int R = THREADS / NC;
   const int c = threadIdx.x % NC, rg = threadIdx.x / NC;
   const float wv = w[c];
@@ -1024,6 +1100,7 @@ __device__ __forceinline__ void seg_lin1_bwd(Rows rw, int n0, const int* __restr
     const float gv = (relu_mask && !(xv > 0.f)) ? 0.f : go * wv;
     g_x[node * NC + c] = gv;
     if (g_x2) g_x2[(size_t)r * NC + c] = gv;
+    if (g_x3) g_x3[(size_t)r * NC + c] = gv;
   }
   __syncthreads();
   red[threadIdx.x] = aw; red[THREADS + threadIdx.x] = ab;
@@ -1096,7 +1173,7 @@ __device__ __forceinline__ void param_grads_item(const ParamGradArgs& a, int seg
   constexpr int NW = THREADS / 64;
   const Layout& L = a.L;
   const SegLayout& SL = a.SL;
-  const int n0 = a.seg_ptr[seg], n = a.seg_ptr[seg + 1] - n0;
+  const int n0 = uni(a.seg_ptr[seg]), n = uni(a.seg_ptr[seg + 1]) - n0;
   const float* base = a.saved + (int64_t)seg * SL.total + (int64_t)b * SL.bstride;
   const float* keep = a.keep + (int64_t)b * L.keep_stride;
   const int64_t po = L.p_block0 + (int64_t)b * L.p_block_stride;
@@ -1148,7 +1225,6 @@ constexpr int FLAG_STRIDE = 32;                 // one 128-byte line per flag
 #else
 #define INV_WAIT() do {} while (0)
 #endif
-constexpr int SPIN_LIMIT = 1 << 20;             // a lost partner poisons the results instead of hanging the GPU
 
 struct Group {
   unsigned* flags;        // this segment's M flag lines: word 0 = epoch, word 1 = the XCD the part runs on.  Epochs
@@ -1297,30 +1373,6 @@ __device__ __forceinline__ void pull_list_small(float* dst, const float* src, co
 //     part passes the same number of exchanges per launch;
 //   * a producer that never delivers ends the sweep after SPIN_LIMIT rounds with the error word set (results poisoned,
 //     the step dropped by gatres_fused_finish), never a hang.
-typedef unsigned long long u64;
-// local: every part of the segment runs on ONE XCD (verified from HW_REG_XCC_ID at the launch's first barrier).  Then a
-// plain 8-byte store is enough: it writes through the CU's L1 into the XCD's L2 and KEEPS the line there, where the
-// partner's sc1 load (L1 bypassed) finds it at L2 latency.  Anywhere else the store is an agent-scope one (sc1: written
-// through to memory, line dropped from this L2), which any XCD's sc1 load observes -- slower, never wrong.
-__device__ __forceinline__ void gran_store(u64* p, float v, unsigned tag, bool local) {
-  const u64 g = ((u64)tag << 32) | (u64)__float_as_uint(v);
-  if (local) __hip_atomic_store(p, g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-  else       __hip_atomic_store(p, g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ u64 gran_load(u64* p) {
-  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
-struct Xch {
-  u64* base;            // this segment's region
-  u64* base_hb;         // its heartbeat granules [6 points][8 parts]
-  unsigned ep;          // epoch of the current exchange
-  int M, part;
-  int* err;
-  bool dead;
-  bool local;           // all parts on one XCD (Group::local)
-};
-
 // table[(idx)*W + c] of every listed row / edge -> granules.  src: LDS table addressed by the same index.
 template <int W, int THREADS>
 __device__ __forceinline__ void xch_export(const Xch& x, const u16* list, int cnt, const float* src, u64* dst) {
@@ -1331,16 +1383,19 @@ __device__ __forceinline__ void xch_export(const Xch& x, const u16* list, int cn
 }
 
 // granules of every listed row / edge -> table, re-read until their tags carry this exchange's epoch
+// (w0: the sweep is carried by the waves from w0 up -- the ones below are busy with the softmax of the same exchange)
 template <int W, int THREADS>
-__device__ __forceinline__ void xch_import(Xch& x, const u16* list, int cnt, u64* src, float* dst) {
+__device__ __forceinline__ void xch_import(Xch& x, const u16* list, int cnt, u64* src, float* dst, int w0 = 0) {
   constexpr int U = 2;
   const int total = cnt * W;
-  for (int base = 0; base < total; base += U * THREADS) {
+  const int t = (int)threadIdx.x - 64 * w0, PT = THREADS - 64 * w0;
+  if (t < 0) return;                                                     // (wave-uniform)
+  for (int base = 0; base < total; base += U * PT) {
     int o[U];
     bool valid[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      const int k = base + u * THREADS + (int)threadIdx.x;
+      const int k = base + u * PT + t;
       valid[u] = k < total;
       o[u] = valid[u] ? (int)list[k / W] * W + (k % W) : 0;
     }
@@ -1366,10 +1421,12 @@ __device__ __forceinline__ void xch_import(Xch& x, const u16* list, int cnt, u64
 // then EVERY wave drains its own outstanding global stores -- the sweeping waves did so while waiting for their loads,
 // the others wait here, beside them -- so that after the barrier that follows the exchange all stores issued before it
 // (saved activations, kept gradient tables) are complete: publish_items relies on that.
-template <int THREADS>
+template <int THREADS, bool ANNOUNCED = false>
 __device__ __forceinline__ void xch_heartbeat(Xch& x, int point) {
   u64* hb = x.base_hb + point * 8;
-  if (threadIdx.x == 0) gran_store(hb + x.part, 0.f, x.ep, x.local);
+  if constexpr (!ANNOUNCED) {
+    if (threadIdx.x == 0) gran_store(hb + x.part, 0.f, x.ep, x.local);
+  }
   const int lane = (int)threadIdx.x - (THREADS - 64);                 // the last wave polls: lanes 0 .. M-1, one part each
   if (lane >= 0) {
     const bool mine = lane < x.M && lane != x.part;
@@ -1381,6 +1438,12 @@ __device__ __forceinline__ void xch_heartbeat(Xch& x, int point) {
     }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+// the arrival half of xch_heartbeat on its own (then xch_heartbeat<THREADS, true> later): for exchanges in which thread 0
+// has waiting work between its exports and the sweep
+__device__ __forceinline__ void xch_announce(Xch& x, int point) {
+  if (threadIdx.x == 0) gran_store(x.base_hb + point * 8 + x.part, 0.f, x.ep, x.local);
 }
 
 // own rows with an out-edge to (FWD: a destination) / an in-edge from (BWD: a source) outside [lo, hi): the rows whose
@@ -1992,6 +2055,10 @@ __host__ __device__ inline long long win_bwd_bytes(int nc, int threads, int wr, 
          2LL * (3 * even(ow + 2) + 3 * even(ge) + even(wr + 2) + even(gm)) + 64 + 8LL * (hl + 4);
 }
 
+// Persistent LDS (top of the array, forward -> backward of one launch): per block and own row one 64-bit relu_bits word
+// of conv1's output and one 32-bit word of the block input; the backward phase adds an own-row table of g_pre.
+__host__ __device__ inline long long win_keep_bytes(int nb, int ow) { return (12LL * nb * ow + 15) & ~15LL; }
+
 // Barrier between two stages of the window kernel whose hand-off goes through LDS only: waits for the wave's LDS
 // operations, NOT for its outstanding global stores / LDS-DMA (s_waitcnt vmcnt), so the saved-activation stores of
 // one stage drain while the next stages run.  Every stage that reads global data of the previous stage, or LDS data
@@ -2014,8 +2081,8 @@ __global__ __launch_bounds__(THREADS) void gatres_window_kernel(const FusedArgs 
   const int within = blockIdx.x % (8 * M);
   const int seg = (blockIdx.x / (8 * M)) * 8 + (within & 7), part = within >> 3;
   if (seg >= a.num_segments) return;
-  const int n0 = a.seg_ptr[seg], n = a.seg_ptr[seg + 1] - n0;
-  const int e0 = a.rowptr[n0], em0 = a.m_rowptr[n0], t0 = a.t_rowptr[n0], mt0 = a.mt_rowptr[n0];
+  const int n0 = uni(a.seg_ptr[seg]), n = uni(a.seg_ptr[seg + 1]) - n0;
+  const int e0 = uni(a.rowptr[n0]), em0 = uni(a.m_rowptr[n0]), t0 = uni(a.t_rowptr[n0]), mt0 = uni(a.mt_rowptr[n0]);
   const int tid = threadIdx.x;
   Rows rw;
   {
@@ -2036,7 +2103,7 @@ __global__ __launch_bounds__(THREADS) void gatres_window_kernel(const FusedArgs 
   xc.M = M; xc.part = part; xc.err = a.err; xc.local = grp.local;
   xc.dead = (a.no_halo & 2) != 0;      // diagnostic (GATRES_XCH_NOWAIT=1, WRONG results): never wait for a partner -- what
                                        // the launch would take if every hand-off were free
-  xc.ep = __hip_atomic_load(grp.flags + part * FLAG_STRIDE + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  xc.ep = (unsigned)uni((int)__hip_atomic_load(grp.flags + part * FLAG_STRIDE + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
   // rows per lane group per trip: a part owns ~100 rows, one trip covers them in every stage but conv1's edge dots;
   // more unrolling only costs registers and code (the block loop does not fit the instruction cache as it is)
   constexpr int UF = 1, UB = 1;
@@ -2046,6 +2113,10 @@ __global__ __launch_bounds__(THREADS) void gatres_window_kernel(const FusedArgs 
   constexpr int WLB = (WL_FLOATS + 3) & ~3;
   const float* P = a.params;
   float* sc = a.scratch;
+  // a.keep_lds: the top of LDS carries the ReLU sign masks from the forward to the backward phase of this launch
+  unsigned char* lds_top = lds_raw + LDS_BYTES - (a.keep_lds ? win_keep_bytes(L.nb, ow) : 0);
+  unsigned long long* mo1 = a.keep_lds ? reinterpret_cast<unsigned long long*>(lds_top) - lo : nullptr;   // [b * ow + row]
+  unsigned* mxin = a.keep_lds ? reinterpret_cast<unsigned*>(lds_top + 8LL * L.nb * ow) - lo : nullptr;
   int stamp_i = 0;
   STAMP();
   if (a.stamps && blockIdx.x == 0 && threadIdx.x == 0) a.stamps[a.stamp_cap] = clock64();
@@ -2072,16 +2143,16 @@ __global__ __launch_bounds__(THREADS) void gatres_window_kernel(const FusedArgs 
     if (vmin < lo) atomicMin(&mm[0], vmin);
     if (vmax > rw.hi) atomicMax(&mm[1], vmax);
     __syncthreads();
-    wlo = mm[0]; whi = mm[1];
+    wlo = uni(mm[0]); whi = uni(mm[1]);
     __syncthreads();
   }
   const int wr = whi - wlo;
   // edge ranges (local ids = position - e0): own in-edges [elo, ehi), window in-edges [ewlo, ewhi)
-  const int elo = a.rowptr[n0 + lo] - e0, ehi = a.rowptr[n0 + rw.hi] - e0, oeg = ehi - elo;
-  const int ewlo = a.rowptr[n0 + wlo] - e0, ewhi = a.rowptr[n0 + whi] - e0, weg = ewhi - ewlo;
-  const int melo = a.m_rowptr[n0 + lo] - em0, oem = a.m_rowptr[n0 + rw.hi] - em0 - melo;
-  const int tlo = a.t_rowptr[n0 + lo] - t0, otg = a.t_rowptr[n0 + rw.hi] - t0 - tlo;
-  const int mtlo = a.mt_rowptr[n0 + lo] - mt0, otm = a.mt_rowptr[n0 + rw.hi] - mt0 - mtlo;
+  const int elo = uni(a.rowptr[n0 + lo]) - e0, ehi = uni(a.rowptr[n0 + rw.hi]) - e0, oeg = ehi - elo;
+  const int ewlo = uni(a.rowptr[n0 + wlo]) - e0, ewhi = uni(a.rowptr[n0 + whi]) - e0, weg = ewhi - ewlo;
+  const int melo = uni(a.m_rowptr[n0 + lo]) - em0, oem = uni(a.m_rowptr[n0 + rw.hi]) - em0 - melo;
+  const int tlo = uni(a.t_rowptr[n0 + lo]) - t0, otg = uni(a.t_rowptr[n0 + rw.hi]) - t0 - tlo;
+  const int mtlo = uni(a.mt_rowptr[n0 + lo]) - mt0, otm = uni(a.mt_rowptr[n0 + rw.hi]) - mt0 - mtlo;
 
   const SegLayout& SL = a.SL;
   float* segbase = a.saved + (int64_t)seg * SL.total;                 // training only: saved is never null here
@@ -2103,7 +2174,7 @@ __global__ __launch_bounds__(THREADS) void gatres_window_kernel(const FusedArgs 
     u16* mcolo = tp;           tp += even(oem);
     int* hcounter = reinterpret_cast<int*>(tp);
     u16* hlist = tp + 2;                 // import list: remote sources of own in-edges (one entry per edge)
-    const int hcap = max(0, (int)((lds_raw + LDS_BYTES - reinterpret_cast<unsigned char*>(hlist)) / 4));
+    const int hcap = max(0, (int)((lds_top - reinterpret_cast<unsigned char*>(hlist)) / 4));
     u16* elist = hlist + hcap;           // export list: own rows some partner's row has an in-edge from
     // index-shifted views: absolute local row / relative own-edge indices work unchanged in the stage functions
     float* hA = hAw - wlo * 2 * NC;
@@ -2137,8 +2208,8 @@ __global__ __launch_bounds__(THREADS) void gatres_window_kernel(const FusedArgs 
       }
     }
     __syncthreads();
-    int hcnt = build_halo<THREADS>(rp, colo, nullptr, rw, hlist, nullptr, hcap, hcounter);
-    int ecnt = build_export_rows<THREADS>(a.t_rowptr, a.t_dst, n0, rw, elist, hcap, hcounter);
+    int hcnt = uni(build_halo<THREADS>(rp, colo, nullptr, rw, hlist, nullptr, hcap, hcounter));
+    int ecnt = uni(build_export_rows<THREADS>(a.t_rowptr, a.t_dst, n0, rw, elist, hcap, hcounter));
     if (hcnt > hcap || ecnt > hcap) {      // (the host sizes the lists from gatres_graph_t.halo: cannot happen with a sane plan)
       if (tid == 0) *a.err = 1;
       hcnt = min(hcnt, hcap); ecnt = min(ecnt, hcap);
@@ -2163,15 +2234,19 @@ __global__ __launch_bounds__(THREADS) void gatres_window_kernel(const FusedArgs 
       xch_heartbeat<THREADS>(xc, 0);
       lds_barrier();
       STAMP();
-      // K2 conv1: alpha -> HBM + the h2 window's LDS (dead now), then the gather (o1 -> HBM + the x buffer of proj2)
+      // K2 conv1: alpha -> HBM + the h2 window's LDS (dead now), then the gather (o1 -> HBM + the x buffer of proj2).
+      // (Coefficients computed INSIDE the exchange -- softmax threads reading a partner's a_src straight from its granule
+      // while the other waves sweep h1 in, one barrier less -- was measured: 545 -> 557 us per launch, and 28 KB of code.)
       if (__builtin_expect(2 * oeg <= wr * NC, 1)) {
         seg_softmax<2, true, THREADS>(rw, rp, colo, sa2, sd2, 0, base + SL.al1, elo, hBw);
         lds_barrier();
-        seg_gather<true, 2, NC, THREADS, UF>(rw, rp, colo, hA, 0, hBw, 0, pb + L.c1_b, base + SL.o1, 0, xB, 0);
+        seg_gather<true, 2, NC, THREADS, UF>(rw, rp, colo, hA, 0, hBw, 0, pb + L.c1_b, base + SL.o1, 0, xB, 0,
+                                             mo1 ? mo1 + b * ow : nullptr);
       } else {
         seg_softmax<2, false, THREADS>(rw, rp, colo, sa2, sd2, 0, base + SL.al1, elo, nullptr);
         __syncthreads();
-        seg_gather<true, 2, NC, THREADS, UF>(rw, rp, colo, hA, 0, base + SL.al1, elo, pb + L.c1_b, base + SL.o1, 0, xB, 0);
+        seg_gather<true, 2, NC, THREADS, UF>(rw, rp, colo, hA, 0, base + SL.al1, elo, pb + L.c1_b, base + SL.o1, 0, xB, 0,
+                                             mo1 ? mo1 + b * ow : nullptr);
       }
       lds_barrier();
       STAMP();
@@ -2211,7 +2286,8 @@ __global__ __launch_bounds__(THREADS) void gatres_window_kernel(const FusedArgs 
       lds_barrier();
       STAMP();
       // K3: residual from the x buffer, result back into it (and to HBM: saved xin of the next block)
-      seg_mean_fwd<NC, THREADS, UF>(rw, oem, mrp, mcolo, y2T, 0, xA, 0, xnext, 0, xA, 0);
+      seg_mean_fwd<NC, THREADS, UF>(rw, oem, mrp, mcolo, y2T, 0, xA, 0, xnext, 0, xA, 0,
+                                    (mxin && b + 1 < L.nb) ? mxin + (b + 1) * ow : nullptr);
       lds_barrier();
       STAMP();
       xcur = xnext;
@@ -2274,7 +2350,8 @@ __global__ __launch_bounds__(THREADS) void gatres_window_kernel(const FusedArgs 
     float* adTo = asTw + (size_t)((wr * 2 + 3) & ~3);
     float* alTw = adTo + (size_t)((ow * 2 + 3) & ~3);
     float* xGo = alTw + 2 * (size_t)even(weg);
-    float* wlA = reinterpret_cast<float*>(lds_raw + ((reinterpret_cast<unsigned char*>(xGo + (size_t)ow * 2 * NC) - lds_raw + 15) & ~15));
+    float* gko = xGo + (size_t)ow * 2 * NC;                              // a.keep_lds: g_pre of the own rows (dX1's residual term)
+    float* wlA = reinterpret_cast<float*>(lds_raw + ((reinterpret_cast<unsigned char*>(gko + (a.keep_lds ? (size_t)ow * NC : 0)) - lds_raw + 15) & ~15));
     float* wlB = wlA + WLB;
     u16* tp = reinterpret_cast<u16*>(wlB + WLB);
     u16* rpo = tp;             tp += even(ow + 1);
@@ -2287,7 +2364,7 @@ __global__ __launch_bounds__(THREADS) void gatres_window_kernel(const FusedArgs 
     u16* mtdsto = tp;          tp += even(otm);
     int* hcounter = reinterpret_cast<int*>(tp);
     u16* hrow = tp + 2;                  // import lists: remote destinations (+ edge ids) of own out-edges
-    const int hcap = max(0, (int)((lds_raw + LDS_BYTES - reinterpret_cast<unsigned char*>(hrow)) / 8));
+    const int hcap = max(0, (int)((lds_top - reinterpret_cast<unsigned char*>(hrow)) / 8));
     u16* hedge = hrow + hcap;
     u16* erow = hedge + hcap;            // export lists: own rows with an in-edge from a partner's row, and those in-edges
     u16* eedge = erow + hcap;
@@ -2311,6 +2388,7 @@ __global__ __launch_bounds__(THREADS) void gatres_window_kernel(const FusedArgs 
     float* adT2 = adTo - lo;      float* adT1 = adTo - lo * 2;
     float* alT2 = alTw - ewlo;    float* alT1 = alTw - ewlo * 2;
     float* xG2 = xGo - lo * NC;   float* xG1 = xGo - lo * 2 * NC;
+    float* gkeep = a.keep_lds ? gko - lo * NC : nullptr;
 
     float* gp_cur = sc + L.sc_gpa;
     float* gp_nxt = sc + L.sc_gpb;
@@ -2332,9 +2410,9 @@ __global__ __launch_bounds__(THREADS) void gatres_window_kernel(const FusedArgs 
     };
     if (L.nb > 0) dma_conv2(L.nb - 1, 0);
     seg_lin1_bwd<NC, THREADS>(rw, n0, a.perm, a.g_out, xfinal, P + L.p_lin1_w, gp_cur, gpT, slab + L.p_lin1_w,
-                              slab + L.p_lin1_b, L.nb > 0 ? 1 : 0, red);
-    int hcnt = build_halo<THREADS>(trp, tdsto, teido, rw, hrow, hedge, hcap, hcounter);
-    int ercnt = build_export_rows<THREADS>(a.rowptr, a.col, n0, rw, erow, hcap, hcounter);
+                              slab + L.p_lin1_b, L.nb > 0 ? 1 : 0, red, gkeep);
+    int hcnt = uni(build_halo<THREADS>(trp, tdsto, teido, rw, hrow, hedge, hcap, hcounter));
+    int ercnt = uni(build_export_rows<THREADS>(a.rowptr, a.col, n0, rw, erow, hcap, hcounter));
     if (tid == 0) *hcounter = 0;
     __syncthreads();
     for (int k = tid; k < oeg; k += THREADS) {                 // own in-edges whose source is a partner's row
@@ -2345,7 +2423,7 @@ __global__ __launch_bounds__(THREADS) void gatres_window_kernel(const FusedArgs 
       }
     }
     __syncthreads();
-    int eecnt = *hcounter;
+    int eecnt = uni(*hcounter);
     if (hcnt > hcap || ercnt > hcap || eecnt > hcap) {
       if (tid == 0) *a.err = 1;
       hcnt = min(hcnt, hcap); ercnt = min(ercnt, hcap); eecnt = min(eecnt, hcap);
@@ -2398,7 +2476,8 @@ __global__ __launch_bounds__(THREADS) void gatres_window_kernel(const FusedArgs 
       dma_copy4<THREADS>(alTw, base + SL.al1 + ewlo * 2, weg * 2, dw0);
       seg_proj<NC, 2 * NC, 1, EPI_RESID_MASK, THREADS, true, true>(rw, xG2, 0, wt2, RA, 0, nullptr, 0,
                                                                nullptr, nullptr, nullptr, nullptr, 0, nullptr, nullptr,
-                                                               nullptr, 0, base + SL.o1, 0, wlA);
+                                                               nullptr, 0, (a.no_halo & 4) ? nullptr : base + SL.o1, 0, wlA,
+                                                               nullptr, nullptr, mo1 ? mo1 + b * ow : nullptr, nullptr);
       __syncthreads();
       STAMP();
       seg_edge_dots<2, NC, THREADS, 1>(rw, 0, rp, colo, RA, 0, hT1, ge1 + elo * 2, 0);
@@ -2423,8 +2502,10 @@ __global__ __launch_bounds__(THREADS) void gatres_window_kernel(const FusedArgs 
       STAMP();
       if (b > 0) dma_conv2(b - 1, dw0);
       seg_proj<2 * NC, NC, 1, EPI_RESID_MASK, THREADS, true, true>(rw, xG1, 0, wt1, gp_nxt, n0, gpT, 0, nullptr, nullptr,
-                                                               nullptr, nullptr, 0, nullptr, nullptr, gp_cur, n0,
-                                                               b > 0 ? base + SL.xin : nullptr, 0, wlB);
+                                                               nullptr, nullptr, 0, nullptr, nullptr,
+                                                               (a.no_halo & 4) ? nullptr : gp_cur, n0,
+                                                               (b > 0 && !(a.no_halo & 4)) ? base + SL.xin : nullptr, 0, wlB,
+                                                               gkeep, gkeep, nullptr, (mxin && b > 0) ? mxin + b * ow : nullptr);
       STAMP();
       float* t = gp_cur; gp_cur = gp_nxt; gp_nxt = t;
     }
@@ -2624,14 +2705,16 @@ static int device_cus() {
 }
 
 // The window kernel applies when the plan knows the parts' row windows and both LDS layouts fit with them.
-static bool window_kernel_fits(const Layout& L, const gatres_graph_t* g, int M) {
+static bool window_kernel_fits(const Layout& L, const gatres_graph_t* g, int M, bool keep = false) {
   if (getenv("GATRES_FUSED_NO_WINDOW") || M < 2 || M > 8 || L.nc > 32 || threads_for(L.nc) != 1024) return false;
   const int k = M - 2;
   const int wr = g->window[k][0], ge = g->window[k][1], gm = g->window[k][2], hl = g->halo[k];
   if (wr <= 0 || L.xch_stride <= 0) return false;
   const int tiles = (g->max_segment_nodes + 15) / 16;
   const int ow = 16 * ((tiles + M - 1) / M);
-  return win_fwd_bytes(L.nc, wr, ow, ge, gm, hl) <= LDS_BYTES && win_bwd_bytes(L.nc, 1024, wr, ow, ge, gm, hl) <= LDS_BYTES &&
+  const long long kb = keep ? win_keep_bytes(L.nb, ow) : 0;
+  return win_fwd_bytes(L.nc, wr, ow, ge, gm, hl) + kb <= LDS_BYTES &&
+         win_bwd_bytes(L.nc, 1024, wr, ow, ge, gm, hl) + kb + (keep ? 4LL * ow * L.nc + 16 : 0) <= LDS_BYTES &&
          wr <= 65535 && ge <= 65535 && gm <= 65535;
 }
 
@@ -2776,8 +2859,11 @@ extern "C" int gatres_fused_run(const gatres_model_t* m, const gatres_graph_t* g
   a.num_segments = g->num_segments;
   a.M = fused_split(a.L, g);
   a.safe_sync = getenv("GATRES_FUSED_SAFE_SYNC") ? 1 : 0;
-  a.no_halo = (getenv("GATRES_FUSED_NO_HALO") ? 1 : 0) | (getenv("GATRES_XCH_NOWAIT") ? 2 : 0);
+  a.no_halo = (getenv("GATRES_FUSED_NO_HALO") ? 1 : 0) | (getenv("GATRES_XCH_NOWAIT") ? 2 : 0) |
+              (getenv("GATRES_DIAG_NOMASK") ? 4 : 0);      // diagnostic, WRONG results: dX epilogues without their global reads
   a.C = (phases & GATRES_PHASE_BACKWARD) ? fused_consumers(a.L, g, a.M) : 0;
+  a.keep_lds = (phases & GATRES_PHASE_FORWARD) && (phases & GATRES_PHASE_BACKWARD) && !getenv("GATRES_FUSED_NO_KEEP") &&
+           window_kernel_fits(a.L, g, a.M, true) ? 1 : 0;
   a.flags = reinterpret_cast<unsigned*>(scratch + a.L.sc_flags);
   a.err = reinterpret_cast<int*>(a.flags + a.L.flag_words - 32);
   a.ready = a.flags + a.L.flag_words;
