@@ -82,6 +82,15 @@ static int g_stamp_cap = 0;
       a.stamps[stamp_i++] = wall_clock64();                                                      \
   } while (0)
 
+// finer diagnostic of ONE backward block of segment 0 (tests/stage_profile.py --xstamps): wave 0 and the last wave of every
+// part stamp the steps of the block's three exchanges; slots [2048 + (part * 2 + who) * 64 + step]
+#define XSTAMP()                                                                                 \
+  do {                                                                                           \
+    if (xs_on && (threadIdx.x == 0 || threadIdx.x == THREADS - 64) && xs_i < 64)                 \
+      a.stamps[2048 + (part * 2 + (threadIdx.x ? 1 : 0)) * 64 + xs_i] = wall_clock64();         \
+    ++xs_i;                                                                                      \
+  } while (0)
+
 // ------------------------------------------------------------------------------------------ LDS budget (host+device)
 __host__ __device__ inline int even(int v) { return (v + 1) & ~1; }
 __host__ __device__ inline int topo_fwd_bytes(int n, int eg, int em) {
@@ -112,6 +121,8 @@ struct Rows { int lo, hi; };
 // workgroup-uniform values that reach the kernel through vector loads (LDS words, global CSR entries the compiler does not
 // scalarise): pinned to SGPRs, so everything derived from them -- table bases, counts, loop bounds -- is scalar as well
 __device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+// workgroup barrier that waits for the wave's LDS operations only (not for its global stores / LDS-DMA in flight)
+__device__ __forceinline__ void lds_barrier_raw() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 // caller-side index of plan node `node` (gatres_graph_t.perm): only x / y / mask / out / g_out / g_x are indexed with it
 __device__ __forceinline__ int ext_id(const int* __restrict__ perm, int node) { return perm ? perm[node] : node; }
@@ -530,7 +541,7 @@ __device__ __forceinline__ u64 gran_load(u64* p) {
 
 struct Xch {
   u64* base;            // this segment's region
-  u64* base_hb;         // its heartbeat granules [6 points][8 parts]
+  u64* base_hb;         // its heartbeat granules, one per part (the first row of XchLayout.hb)
   unsigned ep;          // epoch of the current exchange
   int M, part;
   int* err;
@@ -1153,6 +1164,8 @@ struct ParamGradArgs {
   int M;
   Layout L;
   SegLayout SL;
+  const float* wt = nullptr;                  // (consumer_item_dma: the transposed conv weights, gatres_fused_prepare_backward)
+  unsigned long long* dstamps = nullptr;      // diagnostic (consumer 0 under gatres_fused_set_stamps): steps inside an item
 };
 
 // slab[off .. off+cnt) of a segment = sum over its parts' partial rows (fixed order)
@@ -1199,6 +1212,9 @@ __device__ __forceinline__ void param_grads_item(const ParamGradArgs& a, int seg
   }
 }
 
+template <int NC>
+__global__ __launch_bounds__(1024) void param_grads_stream_kernel(const ParamGradArgs a);
+
 template <int NC, int THREADS>
 __global__ __launch_bounds__(THREADS) void param_grads_kernel(const ParamGradArgs a) {
   constexpr bool BLK = NC >= 16 && NC <= 32;
@@ -1207,6 +1223,226 @@ __global__ __launch_bounds__(THREADS) void param_grads_kernel(const ParamGradArg
   __shared__ float red[3 * THREADS];
   const int conv = blockIdx.x & 1, b = (blockIdx.x >> 1) % a.L.nb, seg = (blockIdx.x >> 1) / a.L.nb;
   param_grads_item<NC, THREADS, false>(a, seg, b, conv, b == 0 && conv == 0, part, red);
+}
+
+
+// ---- consumer items, streamed form (nc 16 / 32, 1024 threads): the item's tables flow through four LDS chunk buffers of
+// 64 rows.  The LAST FOUR waves only issue LDS-DMA (global_load_lds: no registers, no waits in the issuing wave) two
+// chunks ahead of the TWELVE compute waves, which read operands from LDS only -- an item then costs its bytes over
+// what one CU streams from HBM beside 192 busy ones (~40 GB/s measured) instead of five dependent rounds of register
+// loads (13 - 15 us per item before; profiles/r02_consumer_items.txt).  One barrier per chunk.
+//   dW:  wave w takes 4-row steps w, w + 12 of a chunk and keeps the whole [HC, K] block in MFMA accumulators (the
+//        permuted operand map of seg_dw_blk: vector LDS reads of contiguous features); the twelve partial blocks meet
+//        in LDS after the last chunk and are summed in wave order -> slab.  Deterministic.
+//   attention-vector gradients WITHOUT reading h (a third of the item's bytes): with h = x W^T,
+//        g_att_src[c] = sum_r g_a_src[r, hd(c)] h[r, c] = sum_k W[c, k] T[hd(c), k],  T = [g_a_src | g_a_dst]^T x  ([2H, K]),
+//        and T is one more MFMA tile row on the x operands the dW already has in registers.  Same value up to fp32
+//        reassociation (sum over rows first, then over k); the parameter-gradient tests hold it to their usual tolerance.
+constexpr int CI_DMA_WAVES = 4, CI_NBUF = 4, CI_DEPTH = CI_NBUF - 1, CI_CR = 64;   // chunks in flight ahead of the compute waves: DEPTH - 1
+template <int NC, int CONV>
+struct CiGeom {
+  static constexpr int HC = CONV == 0 ? 2 * NC : NC, K = CONV == 0 ? NC : 2 * NC, H = CONV == 0 ? 2 : 1;
+  static constexpr int ROW = HC + K + 2 * H;                     // floats of one row over the four tables
+  static constexpr int CB = CI_CR * ROW;                         // floats of one chunk buffer
+  // LDS-DMA instructions one DMA wave issues per chunk (16-byte form: 256 floats per instruction; the two small tables
+  // share one 4-byte-form instruction per wave)
+  static constexpr int N_G = CI_CR * HC / 256 / CI_DMA_WAVES, N_X = CI_CR * K / 256 / CI_DMA_WAVES;
+  static constexpr int PER_WAVE = N_G + N_X + 1;
+  static_assert(CI_CR * HC % (256 * CI_DMA_WAVES) == 0 && CI_CR * K % (256 * CI_DMA_WAVES) == 0, "chunk / wave split");
+  static_assert(2 * CI_CR * H <= 64 * CI_DMA_WAVES && 2 * CI_CR * H % CI_DMA_WAVES == 0, "small tables: one 4-byte DMA instruction per wave");
+};
+
+template <int NC, int THREADS, int CONV>
+__device__ __forceinline__ void consumer_item_dma(const ParamGradArgs& a, int seg, int b, float* lds) {
+  using Gm = CiGeom<NC, CONV>;
+  constexpr int HC = Gm::HC, K = Gm::K, H = Gm::H, CB = Gm::CB, CR = CI_CR;
+  constexpr int NW = THREADS / 64, CW = NW - CI_DMA_WAVES, CT = CW * 64;          // compute waves / threads
+  constexpr int VC = HC / 16, VK = K / 16;
+  const Layout& L = a.L;
+  const SegLayout& SL = a.SL;
+  const int n0 = uni(a.seg_ptr[seg]), n = uni(a.seg_ptr[seg + 1]) - n0;
+  const float* base = a.saved + (int64_t)seg * SL.total + (int64_t)b * SL.bstride;
+  const float* keep = a.keep + (int64_t)b * L.keep_stride;
+  const int64_t po = L.p_block0 + (int64_t)b * L.p_block_stride;
+  float* sb = a.slabs + (int64_t)seg * L.slab_stride + po;
+  const float* gG = keep + (CONV == 0 ? L.k_gh1 : L.k_gh2) + (int64_t)n0 * HC;      // [n][HC]
+  const float* gX = base + (CONV == 0 ? SL.xin : SL.o1);                              // [n][K]
+  const float* gS = keep + (CONV == 0 ? L.k_gas1 : L.k_gas2) + (int64_t)n0 * H;      // [n][H]
+  const float* gD = keep + (CONV == 0 ? L.k_gad1 : L.k_gad2) + (int64_t)n0 * H;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int chunks = (n + CR - 1) / CR;
+  // chunk buffer: [G CR x HC | X CR x K | g_a_src CR x H | g_a_dst CR x H]
+  auto bufp = [&](int c) { return lds + (c % CI_NBUF) * CB; };
+  float* tred = lds + CI_NBUF * CB;                              // [CW][4][K]: the waves' T blocks, after the loop
+  float* tsum = tred + CW * 4 * K;                               // [4][K]
+#define ISTAMP(k) do { if (a.dstamps && threadIdx.x == 0) a.dstamps[k] = wall_clock64(); } while (0)
+  ISTAMP(0);
+  if (wave >= CW) {
+    // ------------------------------------------------------------------ DMA waves
+    const int dw = wave - CW;
+    auto issue = [&](int c) {
+      float* B = bufp(c);
+      const int r0 = c * CR;
+      // rows beyond the segment are read from its last row (never used: the compute waves zero them) so that every
+      // chunk costs the same number of instructions -- the waits below count them
+      auto rows16 = [&](const float* src, float* dst, int W, int cnt) {
+        for (int k = 0; k < cnt; ++k) {
+          const int f = (dw * cnt + k) * 256 + lane * 4;                 // float index inside the chunk's table
+          const int r = min(r0 + f / W, n - 1);
+          __builtin_amdgcn_global_load_lds(src + (size_t)r * W + f % W, dst + (dw * cnt + k) * 256, 16, 0, 0);
+        }
+      };
+      rows16(gG, B, HC, Gm::N_G);
+      rows16(gX, B + CR * HC, K, Gm::N_X);
+      {  // g_a_src | g_a_dst: 2 * CR * H floats, 4 bytes per lane, the same share (and ONE instruction) for every DMA wave
+        constexpr int SH = 2 * CR * H / CI_DMA_WAVES;
+        const int f = dw * SH + min(lane, SH - 1);
+        const int which = f / (CR * H), e = f % (CR * H);
+        const int r = min(r0 + e / H, n - 1);
+        const float* src = (which ? gD : gS) + (size_t)r * H + e % H;
+        if (lane < SH) __builtin_amdgcn_global_load_lds(src, B + CR * (HC + K) + dw * SH, 4, 0, 0);
+      }
+    };
+    for (int c = 0; c < min(chunks, CI_DEPTH); ++c) issue(c);
+    for (int c = 0; c < chunks; ++c) {
+      // chunk c has landed when at most the instructions of the younger chunks in flight are outstanding
+      static_assert(CI_DEPTH == 3 && 2 * Gm::PER_WAVE < 64, "the waits below");
+      switch (min(chunks - 1 - c, CI_DEPTH - 1)) {               // (wave-uniform)
+        case 0:  asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+        case 1:  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(Gm::PER_WAVE) : "memory"); break;
+        default: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * Gm::PER_WAVE) : "memory"); break;
+      }
+      lds_barrier_raw();
+      if (c + CI_DEPTH < chunks) issue(c + CI_DEPTH);            // into the buffer of chunk c - 1: every compute wave is past it
+    }
+    lds_barrier_raw();                                            // (the compute waves' "chunk buffers are dead" barrier)
+  } else {
+    // ------------------------------------------------------------------ compute waves
+    // bias partials of a split segment: loaded now, folded after the loop (their latency rides on the first chunks)
+    constexpr int MAXM = 8;
+    float bp[MAXM];
+    const bool folds = a.M > 1 && (int)threadIdx.x < HC;
+    const int64_t boff = po + (CONV == 0 ? L.c1_b : L.c2_b) + threadIdx.x;
+#pragma unroll
+    for (int p = 0; p < MAXM; ++p)
+      bp[p] = (folds && p < a.M) ? a.part_slabs[((int64_t)seg * a.M + p) * L.slab_stride + boff] : 0.f;
+    const int i = lane & 15, q = lane >> 4;
+    f32x4 acc[VC][VK], accT[VK];
+#pragma unroll
+    for (int y = 0; y < VK; ++y) {
+      accT[y] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int x = 0; x < VC; ++x) acc[x][y] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    ISTAMP(1);
+    for (int c = 0; c < chunks; ++c) {
+      lds_barrier_raw();
+      if (c == 0) ISTAMP(2);
+      if (c == 1) ISTAMP(3);
+      if (c == chunks - 1) ISTAMP(4);
+      const float* B = bufp(c);
+      const float* Sc = B + CR * (HC + K);                        // [CR][H] g_a_src, then [CR][H] g_a_dst
+      const int r0 = c * CR;
+      for (int st = wave; st < CR / 4; st += CW) {                // (wave-uniform)
+        const int r = 4 * st + q;
+        float av[VC], bv[VK];
+        load_frag<VC>(B + r * HC + VC * i, av);
+        load_frag<VK>(B + CR * HC + r * K + VK * i, bv);
+        // the extra tile row: column i < H is g_a_src[r, i], H <= i < 2H is g_a_dst[r, i - H]
+        float ae = i < 2 * H ? Sc[(i < H ? 0 : CR * H) + r * H + (i < H ? i : i - H)] : 0.f;
+        if (r0 + r >= n) {
+          ae = 0.f;
+#pragma unroll
+          for (int x = 0; x < VC; ++x) av[x] = 0.f;
+        }
+#pragma unroll
+        for (int y = 0; y < VK; ++y) {
+          accT[y] = __builtin_amdgcn_mfma_f32_16x16x4f32(ae, bv[y], accT[y], 0, 0, 0);
+#pragma unroll
+          for (int x = 0; x < VC; ++x) acc[x][y] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[x], bv[y], acc[x][y], 0, 0, 0);
+        }
+      }
+    }
+    ISTAMP(5);
+    lds_barrier_raw();                                            // every chunk buffer is dead: the partial blocks meet in them
+    float* mine = lds + wave * (HC * K);
+#pragma unroll
+    for (int x = 0; x < VC; ++x)
+#pragma unroll
+      for (int y = 0; y < VK; ++y)
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) mine[(VC * (4 * q + rr) + x) * K + VK * i + y] = acc[x][y][rr];
+    if (q == 0) {                                                 // T rows 0 .. 3 live in the q = 0 lanes
+#pragma unroll
+      for (int y = 0; y < VK; ++y)
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) tred[(wave * 4 + rr) * K + VK * i + y] = accT[y][rr];
+    }
+    if (folds) {
+      float sum = 0.f;
+#pragma unroll
+      for (int p = 0; p < MAXM; ++p)
+        if (p < a.M) sum += bp[p];
+      a.slabs[(int64_t)seg * L.slab_stride + boff] = sum;
+    }
+  }
+  lds_barrier_raw();
+  ISTAMP(6);
+  for (int idx = threadIdx.x; idx < HC * K; idx += THREADS) {
+    float sum = 0.f;
+#pragma unroll
+    for (int w = 0; w < CW; ++w) sum += lds[w * (HC * K) + idx];
+    (sb + (CONV == 0 ? L.c1_W : L.c2_W))[idx] = sum;
+  }
+  if ((int)threadIdx.x < 4 * K) {
+    float sum = 0.f;
+#pragma unroll
+    for (int w = 0; w < CW; ++w) sum += tred[w * 4 * K + threadIdx.x];
+    tsum[threadIdx.x] = sum;
+  }
+  lds_barrier_raw();
+  {
+    // g_att[c] = sum_k W^T[k][c] T[hd(c)][k]: W^T [K][HC] is the scratch copy the dX stages use (L2-resident).  Thread
+    // (c, kg) takes k = kg, kg + KG, ... (coalesced over c), the KG partial sums meet in LDS and are added in order.
+    constexpr int KG = THREADS / HC, KPT = (K + KG - 1) / KG;
+    const int c = threadIdx.x % HC, kg = threadIdx.x / HC, hd = c / (HC / H);
+    const float* Wt = a.wt + ((int64_t)b * 2 + CONV) * (2LL * NC * NC) + c;
+    float wv[KPT];
+#pragma unroll
+    for (int j = 0; j < KPT; ++j) wv[j] = (kg + j * KG < K) ? Wt[(kg + j * KG) * HC] : 0.f;
+    float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+    for (int j = 0; j < KPT; ++j) {
+      const int k = min(kg + j * KG, K - 1);
+      s0 = fmaf(wv[j], tsum[hd * K + k], s0);
+      s1 = fmaf(wv[j], tsum[(H + hd) * K + k], s1);
+    }
+    float* ared = lds;                                             // (the dW partial blocks are folded: reuse)  [2][KG][HC]
+    ared[kg * HC + c] = s0; ared[(KG + kg) * HC + c] = s1;
+    lds_barrier_raw();
+    if ((int)threadIdx.x < HC) {
+      float t0 = 0.f, t1 = 0.f;
+#pragma unroll 4
+      for (int g = 0; g < KG; ++g) { t0 += ared[g * HC + c]; t1 += ared[(KG + g) * HC + c]; }
+      (sb + (CONV == 0 ? L.c1_as : L.c2_as))[c] = t0;
+      (sb + (CONV == 0 ? L.c1_ad : L.c2_ad))[c] = t1;
+    }
+  }
+  ISTAMP(7);
+#undef ISTAMP
+}
+
+// the second-launch form of the streamed items (8 parts per snapshot leave no CU for consumers): one item per workgroup
+template <int NC>
+__global__ __launch_bounds__(1024) void param_grads_stream_kernel(const ParamGradArgs a) {
+  __shared__ __attribute__((aligned(16))) float lds[CI_NBUF * CI_CR * (3 * NC + 4) + 12 * 4 * 2 * NC + 4 * 2 * NC];
+  const int conv = blockIdx.x & 1, b = (blockIdx.x >> 1) % a.L.nb, seg = (blockIdx.x >> 1) / a.L.nb;
+  if (conv == 0) consumer_item_dma<NC, 1024, 0>(a, seg, b, lds);
+  else           consumer_item_dma<NC, 1024, 1>(a, seg, b, lds);
+  if (a.M > 1 && b == 0 && conv == 0) {
+    fold_parts<1024>(a, seg, a.L.p_lin0_w, 2 * NC);
+    fold_parts<1024>(a, seg, a.L.p_lin1_w, NC + 1);
+  }
 }
 
 // ------------------------------------------------------------------------------------------ split segments
@@ -1417,33 +1653,30 @@ __device__ __forceinline__ void xch_import(Xch& x, const u16* list, int cnt, u64
   }
 }
 
-// Every exchange: announce this part's arrival and wait for every other part's (keeps the parts in lockstep, see above);
-// then EVERY wave drains its own outstanding global stores -- the sweeping waves did so while waiting for their loads,
+// Every exchange, after the part's own sweep: announce "exchange ep is behind me" (one heartbeat granule per part, its
+// tag only ever grows) and make sure every other part has announced exchange ep - 1.  That is all the pacing the tables
+// need: a table is rewritten three exchanges after it was read (the same point of the next block), the writer has seen
+// the reader's announcement of the exchange in between, and the reader announced that one after the sweep in question.
+// Nobody waits for the slowest part of THIS exchange (round 2 until here: all parts met at every exchange, 0.5 - 1 us
+// each, profiles/r02_exchange_steps.txt) -- a late part only delays the neighbours whose halo rows it owes.
+// Then EVERY wave drains its own outstanding global stores -- the sweeping waves did so while waiting for their loads,
 // the others wait here, beside them -- so that after the barrier that follows the exchange all stores issued before it
 // (saved activations, kept gradient tables) are complete: publish_items relies on that.
-template <int THREADS, bool ANNOUNCED = false>
-__device__ __forceinline__ void xch_heartbeat(Xch& x, int point) {
-  u64* hb = x.base_hb + point * 8;
-  if constexpr (!ANNOUNCED) {
-    if (threadIdx.x == 0) gran_store(hb + x.part, 0.f, x.ep, x.local);
-  }
+template <int THREADS>
+__device__ __forceinline__ void xch_heartbeat(Xch& x, int /*point*/) {
+  u64* hb = x.base_hb;
+  if (threadIdx.x == 0) gran_store(hb + x.part, 0.f, x.ep, x.local);
   const int lane = (int)threadIdx.x - (THREADS - 64);                 // the last wave polls: lanes 0 .. M-1, one part each
   if (lane >= 0) {
     const bool mine = lane < x.M && lane != x.part;
     int spin = 0;
     for (;;) {
-      const bool ok = !mine || x.dead || (unsigned)(gran_load(hb + lane) >> 32) == x.ep;
+      const bool ok = !mine || x.dead || (int)((unsigned)(gran_load(hb + lane) >> 32) - (x.ep - 1u)) >= 0;
       if (__all(ok)) break;
       if (++spin > SPIN_LIMIT) { *x.err = 1; x.dead = true; }
     }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-}
-
-// the arrival half of xch_heartbeat on its own (then xch_heartbeat<THREADS, true> later): for exchanges in which thread 0
-// has waiting work between its exports and the sweep
-__device__ __forceinline__ void xch_announce(Xch& x, int point) {
-  if (threadIdx.x == 0) gran_store(x.base_hb + point * 8 + x.part, 0.f, x.ep, x.local);
 }
 
 // own rows with an out-edge to (FWD: a destination) / an in-edge from (BWD: a source) outside [lo, hi): the rows whose
@@ -1505,6 +1738,8 @@ __device__ __forceinline__ void consumer_main(const FusedArgs& a, int cid, float
   ParamGradArgs pg;
   pg.seg_ptr = a.seg_ptr; pg.saved = a.saved; pg.keep = a.scratch + a.L.sc_keep; pg.slabs = a.slabs;
   pg.part_slabs = a.part_slabs; pg.M = a.M; pg.L = a.L; pg.SL = a.SL;
+  pg.wt = a.wt;
+  pg.dstamps = (a.stamps && cid == 0 && a.stamp_cap >= 4096) ? a.stamps + 3072 : nullptr;
   unsigned* my = a.ready + ((size_t)seg * 4 + c) * FLAG_STRIDE;       // words 0 .. M-1: one per producing part
   float* part = ldsf;
   float* red = ldsf + (LDS_BYTES / 4 - 3 * THREADS);
@@ -1553,8 +1788,14 @@ __device__ __forceinline__ void consumer_main(const FusedArgs& a, int cid, float
     __syncthreads();
     CSTAMP();
     if (i < 2 * nb) {
-      if (*mode) param_grads_item<NC, THREADS, false>(pg, seg, nb - 1 - i / 2, (i & 1) ? 0 : 1, false, part, red);
-      else       param_grads_item<NC, THREADS, true>(pg, seg, nb - 1 - i / 2, (i & 1) ? 0 : 1, false, part, red);
+      if constexpr (THREADS == 1024 && (NC == 16 || NC == 32)) {
+        if (pg.dstamps) pg.dstamps += 8;
+        if (i & 1) consumer_item_dma<NC, THREADS, 0>(pg, seg, nb - 1 - i / 2, ldsf);
+        else       consumer_item_dma<NC, THREADS, 1>(pg, seg, nb - 1 - i / 2, ldsf);
+      } else {
+        if (*mode) param_grads_item<NC, THREADS, false>(pg, seg, nb - 1 - i / 2, (i & 1) ? 0 : 1, false, part, red);
+        else       param_grads_item<NC, THREADS, true>(pg, seg, nb - 1 - i / 2, (i & 1) ? 0 : 1, false, part, red);
+      }
     } else {
       fold_parts<THREADS>(pg, seg, a.L.p_lin0_w, 2 * NC);
       fold_parts<THREADS>(pg, seg, a.L.p_lin1_w, NC + 1);
@@ -2436,37 +2677,53 @@ __global__ __launch_bounds__(THREADS) void gatres_window_kernel(const FusedArgs 
       float* sb = slab + po;
       const float* wt1 = a.wt + (int64_t)b * 2 * w;
       const float* wt2 = wt1 + w;
+      const bool xs_on = a.stamps && a.stamp_cap >= 4096 && seg == 0 && b == L.nb / 2;
+      int xs_i = 0;
+      XSTAMP();
       lds_barrier();                             // own rows of g_pre are in LDS (lin1 backward / the previous dX1)
+      XSTAMP();
       ++xc.ep;                                   // exchange B1: K3 backward gathers g_pre of neighbour rows
       xch_export<NC, THREADS>(xc, erow, ercnt, gpT, xc.base + XL.b1);
+      XSTAMP();
       xch_import<NC, THREADS>(xc, hrow, hcnt, xc.base + XL.b1, gpT);
+      XSTAMP();
       xch_heartbeat<THREADS>(xc, 3);
+      XSTAMP();
       lds_barrier();
+      XSTAMP();
       publish_items<THREADS>(a, seg, part, 2 * (L.nb - 1 - b), grp.local, false);      // the blocks above are kept
       seg_mean_bwd<NC, THREADS, UB>(rw, otm, mrp, mtrp, mtdsto, gpT, 0, gy2T, 0);
       lds_barrier();
+      XSTAMP();
       STAMP();
       float* keep = sc + L.sc_keep + (int64_t)b * L.keep_stride;
       float* gh = keep + L.k_gh1;
       float* gh2 = keep + L.k_gh2;
       seg_edge_dots<1, NC, THREADS, 1>(rw, 0, rp, colo, gy2T, 0, hT2, ge2 + elo, 0);
       lds_barrier();
+      XSTAMP();
       seg_bias_part<NC, THREADS>(rw, gy2T, 0, red);
       seg_softmax_bwd<1, THREADS>(rw, 0, 0, rp, colo, alT2 + elo, asT2, adT2, ge2 + elo, 0, gad2, 0, nullptr, 0, nullptr,
                                   0);
       lds_barrier();
+      XSTAMP();
       ++xc.ep;                                   // exchange B2: the source-major stage reads g_y2 / g_e of neighbour rows
       xch_export<NC, THREADS>(xc, erow, ercnt, gy2T, xc.base + XL.b2y);
       xch_export<1, THREADS>(xc, eedge, eecnt, ge2, xc.base + XL.b2e);
+      XSTAMP();
       xch_import<NC, THREADS>(xc, hrow, hcnt, xc.base + XL.b2y, gy2T);
       xch_import<1, THREADS>(xc, hedge, hcnt, xc.base + XL.b2e, ge2);
+      XSTAMP();
       xch_heartbeat<THREADS>(xc, 4);
+      XSTAMP();
       lds_barrier();
+      XSTAMP();
       STAMP();
       seg_bias_finish<NC, THREADS>(red, sb + L.c2_b);
       seg_agg_bwd_src<1, NC, THREADS, UB>(rw, 0, trp, teido, tdsto, gy2T, 0, alT2, ge2, 0, gad2, 0, pb + L.c2_as,
                                       pb + L.c2_ad, gh2, n0, keep + L.k_gas2, keep + L.k_gad2, xG2, 0);
       lds_barrier();           // g_y2 (RA) and the conv2 tables are dead
+      XSTAMP();
       STAMP();
       // LDS-DMA of this block's conv1 tables and W1^T while the matrix cores run dX2
       w_prefetch<2 * NC, NC, EPI_RESID_MASK, THREADS>(wlB, wt1, nullptr, nullptr, dw0);
@@ -2479,26 +2736,34 @@ __global__ __launch_bounds__(THREADS) void gatres_window_kernel(const FusedArgs 
                                                                nullptr, 0, (a.no_halo & 4) ? nullptr : base + SL.o1, 0, wlA,
                                                                nullptr, nullptr, mo1 ? mo1 + b * ow : nullptr, nullptr);
       __syncthreads();
+      XSTAMP();
       STAMP();
       seg_edge_dots<2, NC, THREADS, 1>(rw, 0, rp, colo, RA, 0, hT1, ge1 + elo * 2, 0);
       lds_barrier();
+      XSTAMP();
       seg_bias_part<2 * NC, THREADS>(rw, RA, 0, red);
       seg_softmax_bwd<2, THREADS>(rw, 0, 0, rp, colo, alT1 + elo * 2, asT1, adT1, ge1 + elo * 2, 0, gad1, 0, nullptr, 0,
                                   nullptr, 0);
       lds_barrier();
+      XSTAMP();
       ++xc.ep;                                   // exchange B3
       xch_export<2 * NC, THREADS>(xc, erow, ercnt, RA, xc.base + XL.b3o);
       xch_export<2, THREADS>(xc, eedge, eecnt, ge1, xc.base + XL.b3e);
+      XSTAMP();
       xch_import<2 * NC, THREADS>(xc, hrow, hcnt, xc.base + XL.b3o, RA);
       xch_import<2, THREADS>(xc, hedge, hcnt, xc.base + XL.b3e, ge1);
+      XSTAMP();
       xch_heartbeat<THREADS>(xc, 5);
+      XSTAMP();
       lds_barrier();
+      XSTAMP();
       publish_items<THREADS>(a, seg, part, 2 * (L.nb - 1 - b) + 1, grp.local, false);      // conv2 tables complete
       STAMP();
       seg_bias_finish<2 * NC, THREADS>(red, sb + L.c1_b);
       seg_agg_bwd_src<2, NC, THREADS, UB>(rw, 0, trp, teido, tdsto, RA, 0, alT1, ge1, 0, gad1, 0, pb + L.c1_as,
                                       pb + L.c1_ad, gh, n0, keep + L.k_gas1, keep + L.k_gad1, xG1, 0);
       lds_barrier();
+      XSTAMP();
       STAMP();
       if (b > 0) dma_conv2(b - 1, dw0);
       seg_proj<2 * NC, NC, 1, EPI_RESID_MASK, THREADS, true, true>(rw, xG1, 0, wt1, gp_nxt, n0, gpT, 0, nullptr, nullptr,
@@ -2506,6 +2771,7 @@ __global__ __launch_bounds__(THREADS) void gatres_window_kernel(const FusedArgs 
                                                                (a.no_halo & 4) ? nullptr : gp_cur, n0,
                                                                (b > 0 && !(a.no_halo & 4)) ? base + SL.xin : nullptr, 0, wlB,
                                                                gkeep, gkeep, nullptr, (mxin && b > 0) ? mxin + b * ow : nullptr);
+      XSTAMP();
       STAMP();
       float* t = gp_cur; gp_cur = gp_nxt; gp_nxt = t;
     }
@@ -2910,8 +3176,14 @@ extern "C" int gatres_fused_param_grads(const gatres_model_t* m, const gatres_gr
   a.seg_ptr = g->seg_ptr; a.saved = saved; a.keep = scratch + a.L.sc_keep; a.slabs = scratch + a.L.sc_slabs;
   a.M = fused_split(a.L, g); a.part_slabs = scratch + a.L.sc_part_slabs;
   a.SL = make_seg_layout(a.L.nb, a.L.nc, g->max_segment_nodes, g->max_segment_edges_gat);
+  a.wt = scratch + a.L.sc_wt;
   const dim3 grid((unsigned)(2 * a.L.nb * g->num_segments));
   hipStream_t st = gatres_stream(stream);
+  if ((m->nc == 16 || m->nc == 32) && !getenv("GATRES_PARAM_GRADS_NO_STREAM")) {
+    if (m->nc == 16) hipLaunchKernelGGL((param_grads_stream_kernel<16>), grid, dim3(1024), 0, st, a);
+    else             hipLaunchKernelGGL((param_grads_stream_kernel<32>), grid, dim3(1024), 0, st, a);
+    return gatres_launch_status();
+  }
   switch (m->nc) {
     case 4: hipLaunchKernelGGL((param_grads_kernel<4, 256>), grid, dim3(256), 0, st, a); break;
     case 8: hipLaunchKernelGGL((param_grads_kernel<8, 256>), grid, dim3(256), 0, st, a); break;

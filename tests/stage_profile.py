@@ -23,7 +23,7 @@ raw = stamps.cpu().numpy()
 clk = raw[cap:cap + 3]
 s = raw[:1024]
 s = s[s > 0]
-cs = raw[1024:cap]
+cs = raw[1024:2048]
 cs = cs[cs > 0]
 print('shader clock MHz ~', (clk[1] - clk[0]) / ((clk[2] - s[0]) / 100.0))
 d = (s[1:] - s[:-1]) / 100.0   # us
@@ -58,3 +58,26 @@ if len(cs) >= 2:
           % (n, work.mean(), work.min(), work.max(), (avail[0] - t0) / 100.0, (done[n - 1] - t0) / 100.0))
     print("   wait before each item (us):", " ".join("%.1f" % w for w in ((avail[1:n] - done[:n - 1]) / 100.0)))
     print("   work of each item (us):   ", " ".join("%.1f" % w for w in work))
+
+# one backward block of segment 0, every part, wave 0 / last wave (k_fused.hip XSTAMP)
+xs = raw[2048:2048 + 16 * 64].reshape(16, 64)
+names_x = ["top", "bar", "B1 export", "B1 import", "B1 heartbeat", "bar", "mean_bwd+bar", "edge_dots2+bar", "softmax_bwd2+bar",
+           "B2 export", "B2 import", "B2 heartbeat", "bar", "agg_src2+bar", "dX2+sync", "edge_dots1+bar", "softmax_bwd1+bar",
+           "B3 export", "B3 import", "B3 heartbeat", "bar", "agg_src1+bar", "dX1"]
+if xs[0, 0] > 0:
+    t0 = min(int(xs[r, 0]) for r in range(16) if xs[r, 0] > 0)
+    print("\none backward block, times in us since the first part entered it; columns: part p wave 0 | last wave")
+    rows = [r for r in range(16) if xs[r, 0] > 0]
+    print("%-18s" % "step" + "".join("   p%d w0   wL " % (r // 2) for r in rows if r % 2 == 0))
+    for k, nme in enumerate(names_x):
+        print("%-18s" % nme + "".join(" %6.2f" % ((int(xs[r, k]) - t0) / 100.0) + ("" if r % 2 else "") for r in rows))
+
+# steps inside the consumer's streamed items (k_fused.hip ISTAMP): 8 stamps per item from slot 3072 + 8
+it = raw[3072 + 8:3072 + 8 + 8 * 40].reshape(40, 8)
+it = it[it[:, 0] > 0]
+if len(it):
+    d = (it[:, 1:] - it[:, :1]) / 100.0
+    print("\nconsumer item steps, us since the item's start (mean over %d items):" % len(it))
+    for k, nme in enumerate(["fold done (compute waves)", "chunk 0 landed", "chunk 1 landed", "last chunk landed", "last chunk computed",
+                             "partials in LDS", "slab written"]):
+        print("  %-28s %6.2f" % (nme, d[:, k].mean()))
