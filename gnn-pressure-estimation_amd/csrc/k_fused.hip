@@ -61,8 +61,6 @@ struct FusedArgs {
   int keep_lds;             // window kernel, forward + backward in one launch: ReLU sign masks and own-row g_pre stay in LDS
   int no_halo;              // diagnostic (GATRES_FUSED_NO_HALO=1): always take the bulk-pull fallback
   int C;                    // consumer workgroups per segment (deferred parameter gradients on spare CUs), 0 = none
-  int instage;              // window kernel: every part forms the parameter gradients of its own rows inside the dX stages
-                            // (seg_dw_tiles) -> its row of part_slabs; no kept tables, no consumers, no second launch
   unsigned* ready;          // [segment][4] lines: items published by the segment's part 0 for each consumer
   unsigned long long* xch;  // window kernel: granule exchange regions, one per segment (Layout::sc_xch)
   XchLayout XL;
@@ -180,20 +178,6 @@ __device__ __forceinline__ void load_frag(const float* p, float (&f)[KQ]) {
   } else {
 #pragma unroll
     for (int s = 0; s < KQ; ++s) f[s] = p[s];
-  }
-}
-
-template <int KQ>
-__device__ __forceinline__ void store_frag(float* p, const float (&f)[KQ]) {
-  if constexpr (KQ % 4 == 0) {
-#pragma unroll
-    for (int s = 0; s < KQ; s += 4) st4(p + s, make_float4(f[s], f[s + 1], f[s + 2], f[s + 3]));
-  } else if constexpr (KQ % 2 == 0) {
-#pragma unroll
-    for (int s = 0; s < KQ; s += 2) *reinterpret_cast<float2*>(p + s) = make_float2(f[s], f[s + 1]);
-  } else {
-#pragma unroll
-    for (int s = 0; s < KQ; ++s) p[s] = f[s];
   }
 }
 
@@ -959,10 +943,7 @@ __device__ __forceinline__ void seg_agg_bwd_src(Rows rw, int e0, const u16* trp,
                                                 const float* __restrict__ att_src,
                                                 const float* __restrict__ att_dst, float* g_h, int hb,
                                                 float* keep_gas, float* keep_gad, float* g_h2 = nullptr,
-                                                int h2b = 0, float* sd_l = nullptr) {
-  // (g_h / keep_gas / keep_gad: global tables for the deferred parameter gradients, null when the gradients are formed
-  //  in-stage; g_h2: the LDS copy the dX stage reads; sd_l: LDS table [db + row][2H] = g_a_src | g_a_dst of the row, the
-  //  A operand of the T tiles)
+                                                int h2b = 0) {
   constexpr int HC = H * C, G = HC / 4, RPP = THREADS / G;
   const int c0 = (threadIdx.x % G) * 4;
   const int hd = c0 / C;
@@ -1025,20 +1006,14 @@ __device__ __forceinline__ void seg_agg_bwd_src(Rows rw, int e0, const u16* trp,
     for (int u = 0; u < UR; ++u) {
       const bool leader = valid[u] && (c0 % C) == 0;
       const float gad = g_a_dst[(unsigned)((db + r[u]) * H + hd)];
-      if (leader) {
-        if (keep_gas) {                  // kept (global row hb + r) for the deferred att_src / att_dst gradients
-          keep_gas[(unsigned)((hb + r[u]) * H + hd)] = gas[u];
-          keep_gad[(unsigned)((hb + r[u]) * H + hd)] = gad;
-        }
-        if (sd_l) {
-          sd_l[(unsigned)((db + r[u]) * 2 * H + hd)] = gas[u];
-          sd_l[(unsigned)((db + r[u]) * 2 * H + H + hd)] = gad;
-        }
+      if (leader) {                      // kept (global row hb + r) for the deferred att_src / att_dst gradients
+        keep_gas[(unsigned)((hb + r[u]) * H + hd)] = gas[u];
+        keep_gad[(unsigned)((hb + r[u]) * H + hd)] = gad;
       }
       gatres_axpy4(acc[u], gas[u], as);
       gatres_axpy4(acc[u], gad, ad);
       if (valid[u]) {
-        if (g_h) st4(g_h + (unsigned)((hb + r[u]) * HC + c0), acc[u]);
+        st4(g_h + (unsigned)((hb + r[u]) * HC + c0), acc[u]);
         if (g_h2) st4(g_h2 + (unsigned)((h2b + r[u]) * HC + c0), acc[u]);
       }
     }
@@ -1174,112 +1149,6 @@ __device__ __forceinline__ void seg_lin0_bwd(Rows rw, int n0, const int* __restr
   }
 }
 
-// ------------------------------------------------------------------------------------------ in-stage gradients
-// Window kernel, FusedArgs.instage: the parameter gradients of a GATConv are formed by the part itself, for its OWN rows,
-// on waves that idle anyway: the softmax-backward stage of the NEXT GATConv of the backward chain keeps two waves busy (one
-// thread per row and head) and is followed by an exchange whose granule loads hide the latency of the slab stores.  Both
-// dW operands are in LDS then: g_h of the own rows (the dX stage's x operand, still in place) and the conv's saved input
-// rows (xin / o1, brought in by LDS-DMA during an earlier MFMA stage).  The deferred form streamed every kept table back
-// from memory (155 KB per item, 149 MB per bs-32 step, on consumer CUs or in a second launch): none of that traffic
-// exists here, and every CU of the co-residency bound carries the dependent chain.  The partial blocks go to the part's
-// row of part_slabs; reduce_adam_kernel sums the rows of all parts of all segments.
-//   seg_dw_tiles: dW[c][k] = sum_r G[r][c] X[r][k], one 16 x 16 tile per wave (wrel of nwaves), rows in order,
-//                 v_mfma_f32_16x16x4_f32;
-//   attention-vector gradients without h (h = x W^T: the identity consumer_item_dma uses): T = [g_a_src | g_a_dst]^T X
-//                 ([2H][K]) is one more tile row of the same product -- seg_dw_tiles<2H, K> on the interleaved [row][2H]
-//                 table that the source-major stage leaves in LDS, run by the waves the conv's own dX stage leaves idle
-//                 -- and seg_att_from_T (ONE wave, a later stage) forms g_att_src[c] = sum_k W[c][k] T[hd(c)][k],
-//                 g_att_dst[c] with row H + hd(c), W^T from the dX stage's LDS slot.
-template <int HC, int K>
-__device__ __forceinline__ void seg_dw_tiles(int wrel, int nwaves, int ow, const float* G, const float* X,
-                                             float* __restrict__ slabW) {
-  constexpr int NCT = (HC + 15) / 16, NKT = (K + 15) / 16;
-  const int lane = threadIdx.x & 63, i = lane & 15, q = lane >> 4;
-  const bool full = (ow & 63) == 0;                                  // (workgroup-uniform) no ragged trip: no row predicates
-  for (int t = wrel; t < NCT * NKT; t += nwaves) {                  // (wave-uniform)
-    const int ct = t / NKT, kt = t % NKT;
-    const int c = ct * 16 + i, k = kt * 16 + i;
-    const bool cok = (HC % 16 == 0) || c < HC, kok = (K % 16 == 0) || k < K;
-    const float* gp = G + (cok ? c : 0) + q * HC;
-    const float* xp = X + (kok ? k : 0) + q * K;
-    // 64 rows per trip: all 32 operand reads of the trip are issued before the first MFMA, from ONE address register each
-    // with immediate offsets -- a wave that runs alone pays ~5 cycles per instruction, so the trip is written to be
-    // ~50 instructions; two accumulators (even / odd 4-row steps), summed at the end: a fixed order
-    f32x4 acc0 = (f32x4){0.f, 0.f, 0.f, 0.f}, acc1 = (f32x4){0.f, 0.f, 0.f, 0.f};
-    for (int r0 = 0; r0 < ow; r0 += 64, gp += 64 * HC, xp += 64 * K) {
-      float av[16], bv[16];
-      if (full) {
-#pragma unroll
-        for (int u = 0; u < 16; ++u) { av[u] = gp[4 * u * HC]; bv[u] = xp[4 * u * K]; }
-      } else {
-#pragma unroll
-        for (int u = 0; u < 16; ++u) {
-          const int rr = r0 + 4 * u + q < ow ? 4 * u : -r0 - q;       // (a row of the table: masked below)
-          av[u] = gp[rr * HC];
-          bv[u] = xp[rr * K];
-        }
-      }
-      __builtin_amdgcn_sched_barrier(0);          // (left alone, the scheduler sinks every read to its MFMA: 16 LDS round trips)
-      if (!full) {
-#pragma unroll
-        for (int u = 0; u < 16; ++u)
-          if (!(r0 + 4 * u + q < ow)) { av[u] = 0.f; bv[u] = 0.f; }
-      }
-      if constexpr (HC % 16 != 0) {
-#pragma unroll
-        for (int u = 0; u < 16; ++u) av[u] = cok ? av[u] : 0.f;
-      }
-      if constexpr (K % 16 != 0) {
-#pragma unroll
-        for (int u = 0; u < 16; ++u) bv[u] = kok ? bv[u] : 0.f;
-      }
-#pragma unroll
-      for (int u = 0; u < 16; u += 2) {
-        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u], bv[u], acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u + 1], bv[u + 1], acc1, 0, 0, 0);
-      }
-    }
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int cr = ct * 16 + 4 * q + j;
-      if (((HC % 16 == 0) || cr < HC) && kok) slabW[cr * K + k] = acc0[j] + acc1[j];
-    }
-  }
-}
-// g_att_src[c] = sum_k W[c][k] T[hd(c)][k], g_att_dst[c] = sum_k W[c][k] T[H + hd(c)][k], k in order, as one more
-// matrix product: D[c][j] = sum_k W[c][k] T[j][k], one 16-column tile of c per wave (wrel of nwaves), K / 4 MFMAs.
-// wl: a dX stage's LDS copy of W^T in seg_proj's padded layout, wl[k * (HC + 4) + c] = W[c][k]; Tl: [2H][K].
-template <int HC, int K, int H>
-__device__ __forceinline__ void seg_att_from_T(int wrel, int nwaves, const float* Tl, const float* wl,
-                                               float* __restrict__ slab_as, float* __restrict__ slab_ad) {
-  static_assert(HC % 16 == 0 && K % 4 == 0 && 2 * H <= 16, "tile shapes");
-  constexpr int KS = K / 4;                                          // MFMA steps
-  const int lane = threadIdx.x & 63, i = lane & 15, q = lane >> 4;
-  for (int t = wrel; t < HC / 16; t += nwaves) {                     // (wave-uniform)
-    const float* wp = wl + q * (HC + 4) + t * 16 + i;                // A[m = i][k = q] = W[c0 + i][k0 + q]
-    const float* tp = Tl + (i < 2 * H ? i : 0) * K + q;              // B[k = q][n = i] = T[i][k0 + q]  (i < 2H)
-    float av[KS], bv[KS];
-#pragma unroll
-    for (int u = 0; u < KS; ++u) { av[u] = wp[4 * u * (HC + 4)]; bv[u] = tp[4 * u]; }
-    __builtin_amdgcn_sched_barrier(0);
-    f32x4 acc0 = (f32x4){0.f, 0.f, 0.f, 0.f}, acc1 = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int u = 0; u < KS; ++u) bv[u] = i < 2 * H ? bv[u] : 0.f;
-#pragma unroll
-    for (int u = 0; u < KS; u += 2) {
-      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u], bv[u], acc0, 0, 0, 0);
-      if (u + 1 < KS) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u + 1], bv[u + 1], acc1, 0, 0, 0);
-    }
-    // lane (i, q) holds D[c0 + 4q + j][i]; the head of a 16-column tile is tile-uniform
-    const int hd = (t * 16) / (HC / H);
-    if (i == hd || i == H + hd) {
-      float* dst = (i == hd ? slab_as : slab_ad) + t * 16 + 4 * q;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) dst[j] = acc0[j] + acc1[j];
-    }
-  }
-}
-
 // ------------------------------------------------------------------------------------------ deferred gradients
 // Deferred parameter gradients of the GATConvs.  Nothing on the backward's dependency chain reads dW / g_att, so
 // the per-snapshot workgroups only keep g_h and g_alpha_src / g_alpha_dst per block; one ITEM = (segment, block,
@@ -1369,9 +1238,7 @@ __global__ __launch_bounds__(THREADS) void param_grads_kernel(const ParamGradArg
 //        g_att_src[c] = sum_r g_a_src[r, hd(c)] h[r, c] = sum_k W[c, k] T[hd(c), k],  T = [g_a_src | g_a_dst]^T x  ([2H, K]),
 //        and T is one more MFMA tile row on the x operands the dW already has in registers.  Same value up to fp32
 //        reassociation (sum over rows first, then over k); the parameter-gradient tests hold it to their usual tolerance.
-// Six 64-row buffers: a C-Town item (388 rows, 155 KB) is in flight almost whole from its first instruction -- with two
-// chunks (51 KB) in flight the stream ran at 51 KB per memory round trip (~2.3 us beside 192 busy CUs) = 22 GB/s, 7 us an item.
-constexpr int CI_DMA_WAVES = 4, CI_NBUF = 6, CI_DEPTH = CI_NBUF - 1, CI_CR = 64;   // chunks in flight ahead of the compute waves: DEPTH - 1
+constexpr int CI_DMA_WAVES = 4, CI_NBUF = 4, CI_DEPTH = CI_NBUF - 1, CI_CR = 64;   // chunks in flight ahead of the compute waves: DEPTH - 1
 template <int NC, int CONV>
 struct CiGeom {
   static constexpr int HC = CONV == 0 ? 2 * NC : NC, K = CONV == 0 ? NC : 2 * NC, H = CONV == 0 ? 2 : 1;
@@ -1406,20 +1273,10 @@ __device__ __forceinline__ void consumer_item_dma(const ParamGradArgs& a, int se
   const int chunks = (n + CR - 1) / CR;
   // chunk buffer: [G CR x HC | X CR x K | g_a_src CR x H | g_a_dst CR x H]
   auto bufp = [&](int c) { return lds + (c % CI_NBUF) * CB; };
-  float* tred = lds + CW * HC * K;                               // [CW][4][K]: the waves' T blocks, after the loop (behind
-  float* tsum = tred + CW * 4 * K;                               // [4][K]       the partial dW blocks, in the dead chunk buffers)
-  static_assert(CW * HC * K + CW * 4 * K + 4 * K <= CI_NBUF * CB, "the item's epilogue lives in the chunk buffers");
+  float* tred = lds + CI_NBUF * CB;                              // [CW][4][K]: the waves' T blocks, after the loop
+  float* tsum = tred + CW * 4 * K;                               // [4][K]
 #define ISTAMP(k) do { if (a.dstamps && threadIdx.x == 0) a.dstamps[k] = wall_clock64(); } while (0)
   ISTAMP(0);
-  // the epilogue's W^T values (attention-vector gradients): loaded now, their latency rides on the item's stream
-  constexpr int KG = THREADS / HC, KPT = (K + KG - 1) / KG;
-  float wv[KPT];
-  {
-    const int c = threadIdx.x % HC, kg = threadIdx.x / HC;
-    const float* Wt = a.wt + ((int64_t)b * 2 + CONV) * (2LL * NC * NC) + c;
-#pragma unroll
-    for (int j = 0; j < KPT; ++j) wv[j] = (kg + j * KG < K) ? Wt[(kg + j * KG) * HC] : 0.f;
-  }
   if (wave >= CW) {
     // ------------------------------------------------------------------ DMA waves
     const int dw = wave - CW;
@@ -1449,13 +1306,11 @@ __device__ __forceinline__ void consumer_item_dma(const ParamGradArgs& a, int se
     for (int c = 0; c < min(chunks, CI_DEPTH); ++c) issue(c);
     for (int c = 0; c < chunks; ++c) {
       // chunk c has landed when at most the instructions of the younger chunks in flight are outstanding
-      static_assert(CI_DEPTH == 5 && 4 * Gm::PER_WAVE < 64, "the waits below");
+      static_assert(CI_DEPTH == 3 && 2 * Gm::PER_WAVE < 64, "the waits below");
       switch (min(chunks - 1 - c, CI_DEPTH - 1)) {               // (wave-uniform)
         case 0:  asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
         case 1:  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(Gm::PER_WAVE) : "memory"); break;
-        case 2:  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * Gm::PER_WAVE) : "memory"); break;
-        case 3:  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * Gm::PER_WAVE) : "memory"); break;
-        default: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * Gm::PER_WAVE) : "memory"); break;
+        default: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * Gm::PER_WAVE) : "memory"); break;
       }
       lds_barrier_raw();
       if (c + CI_DEPTH < chunks) issue(c + CI_DEPTH);            // into the buffer of chunk c - 1: every compute wave is past it
@@ -1514,20 +1369,14 @@ __device__ __forceinline__ void consumer_item_dma(const ParamGradArgs& a, int se
 #pragma unroll
     for (int x = 0; x < VC; ++x)
 #pragma unroll
-      for (int rr = 0; rr < 4; ++rr) {                            // the lane's VK outputs of a row are contiguous: one store
-        float ov[VK];
+      for (int y = 0; y < VK; ++y)
 #pragma unroll
-        for (int y = 0; y < VK; ++y) ov[y] = acc[x][y][rr];
-        store_frag<VK>(mine + (VC * (4 * q + rr) + x) * K + VK * i, ov);
-      }
+        for (int rr = 0; rr < 4; ++rr) mine[(VC * (4 * q + rr) + x) * K + VK * i + y] = acc[x][y][rr];
     if (q == 0) {                                                 // T rows 0 .. 3 live in the q = 0 lanes
 #pragma unroll
-      for (int rr = 0; rr < 4; ++rr) {
-        float ov[VK];
+      for (int y = 0; y < VK; ++y)
 #pragma unroll
-        for (int y = 0; y < VK; ++y) ov[y] = accT[y][rr];
-        store_frag<VK>(tred + (wave * 4 + rr) * K + VK * i, ov);
-      }
+        for (int rr = 0; rr < 4; ++rr) tred[(wave * 4 + rr) * K + VK * i + y] = accT[y][rr];
     }
     if (folds) {
       float sum = 0.f;
@@ -1539,27 +1388,28 @@ __device__ __forceinline__ void consumer_item_dma(const ParamGradArgs& a, int se
   }
   lds_barrier_raw();
   ISTAMP(6);
-  // the twelve partial blocks, summed in wave order: float4 at a time by the first HC * K / 4 threads, while the LAST waves
-  // sum the T blocks
-  static_assert(HC * K / 4 + 4 * K <= THREADS, "epilogue thread split");
-  if ((int)threadIdx.x < HC * K / 4) {
-    const int idx = threadIdx.x * 4;
-    float4 sum = ld4(lds + idx);
-#pragma unroll
-    for (int w = 1; w < CW; ++w) add4(sum, ld4(lds + w * (HC * K) + idx));
-    st4(sb + (CONV == 0 ? L.c1_W : L.c2_W) + idx, sum);
-  } else if ((int)threadIdx.x >= THREADS - 4 * K) {
-    const int t = threadIdx.x - (THREADS - 4 * K);
+  for (int idx = threadIdx.x; idx < HC * K; idx += THREADS) {
     float sum = 0.f;
 #pragma unroll
-    for (int w = 0; w < CW; ++w) sum += tred[w * 4 * K + t];
-    tsum[t] = sum;
+    for (int w = 0; w < CW; ++w) sum += lds[w * (HC * K) + idx];
+    (sb + (CONV == 0 ? L.c1_W : L.c2_W))[idx] = sum;
+  }
+  if ((int)threadIdx.x < 4 * K) {
+    float sum = 0.f;
+#pragma unroll
+    for (int w = 0; w < CW; ++w) sum += tred[w * 4 * K + threadIdx.x];
+    tsum[threadIdx.x] = sum;
   }
   lds_barrier_raw();
   {
     // g_att[c] = sum_k W^T[k][c] T[hd(c)][k]: W^T [K][HC] is the scratch copy the dX stages use (L2-resident).  Thread
     // (c, kg) takes k = kg, kg + KG, ... (coalesced over c), the KG partial sums meet in LDS and are added in order.
+    constexpr int KG = THREADS / HC, KPT = (K + KG - 1) / KG;
     const int c = threadIdx.x % HC, kg = threadIdx.x / HC, hd = c / (HC / H);
+    const float* Wt = a.wt + ((int64_t)b * 2 + CONV) * (2LL * NC * NC) + c;
+    float wv[KPT];
+#pragma unroll
+    for (int j = 0; j < KPT; ++j) wv[j] = (kg + j * KG < K) ? Wt[(kg + j * KG) * HC] : 0.f;
     float s0 = 0.f, s1 = 0.f;
 #pragma unroll
     for (int j = 0; j < KPT; ++j) {
@@ -1585,7 +1435,7 @@ __device__ __forceinline__ void consumer_item_dma(const ParamGradArgs& a, int se
 // the second-launch form of the streamed items (8 parts per snapshot leave no CU for consumers): one item per workgroup
 template <int NC>
 __global__ __launch_bounds__(1024) void param_grads_stream_kernel(const ParamGradArgs a) {
-  __shared__ __attribute__((aligned(16))) float lds[CI_NBUF * CI_CR * (3 * NC + 4)];
+  __shared__ __attribute__((aligned(16))) float lds[CI_NBUF * CI_CR * (3 * NC + 4) + 12 * 4 * 2 * NC + 4 * 2 * NC];
   const int conv = blockIdx.x & 1, b = (blockIdx.x >> 1) % a.L.nb, seg = (blockIdx.x >> 1) / a.L.nb;
   if (conv == 0) consumer_item_dma<NC, 1024, 0>(a, seg, b, lds);
   else           consumer_item_dma<NC, 1024, 1>(a, seg, b, lds);
@@ -2404,29 +2254,28 @@ __global__ __launch_bounds__(THREADS) void gatres_fused_kernel(const FusedArgs a
 // the DMA's destination (every table is a run-time offset into one LDS array), so it makes an issuing wave wait for
 // its DMA (s_waitcnt vmcnt(0)) before its next ds_read -- which would serialise the copy with the stage it is meant to
 // hide behind.  The MFMA stages of a split segment leave most waves idle (one 16-row tile per wave): those issue.
-// (waves [w0, w1) issue)
 template <int THREADS>
-__device__ __forceinline__ void dma_copy16(float* dst, const float* src, int nfloat, int w0, int w1 = THREADS / 64) {   // nfloat % 4 == 0, 16-B aligned
+__device__ __forceinline__ void dma_copy16(float* dst, const float* src, int nfloat, int w0) {   // nfloat % 4 == 0, 16-B aligned
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  if (wave < w0 || wave >= w1) return;
-  for (int c = (wave - w0) * 256; c < nfloat; c += (w1 - w0) * 256)
+  if (wave < w0) return;
+  for (int c = (wave - w0) * 256; c < nfloat; c += (THREADS / 64 - w0) * 256)
     if (c + lane * 4 < nfloat) __builtin_amdgcn_global_load_lds(src + c + lane * 4, dst + c, 16, 0, 0);
 }
 template <int THREADS>
-__device__ __forceinline__ void dma_copy4(float* dst, const float* src, int nfloat, int w0, int w1 = THREADS / 64) {
+__device__ __forceinline__ void dma_copy4(float* dst, const float* src, int nfloat, int w0) {
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  if (wave < w0 || wave >= w1) return;
-  for (int c = (wave - w0) * 64; c < nfloat; c += (w1 - w0) * 64)
+  if (wave < w0) return;
+  for (int c = (wave - w0) * 64; c < nfloat; c += (THREADS / 64 - w0) * 64)
     if (c + lane < nfloat) __builtin_amdgcn_global_load_lds(src + c + lane, dst + c, 4, 0, 0);
 }
 // W [M][K] (+ the two attention vectors) -> LDS slot in seg_proj's padded layout, one LDS-DMA instruction per row
 template <int K, int M, int EPI, int THREADS>
 __device__ __forceinline__ void w_prefetch(float* wl, const float* __restrict__ Wm, const float* __restrict__ att_src,
-                                           const float* __restrict__ att_dst, int w0, int w1 = THREADS / 64) {
+                                           const float* __restrict__ att_dst, int w0) {
   constexpr int KP = K + 4;
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  if (wave < w0 || wave >= w1) return;
-  for (int m = wave - w0; m < M; m += w1 - w0)
+  if (wave < w0) return;
+  for (int m = wave - w0; m < M; m += THREADS / 64 - w0)
     if (lane < K / 4) __builtin_amdgcn_global_load_lds(Wm + m * K + lane * 4, wl + m * KP, 16, 0, 0);
   if constexpr (EPI == EPI_ATT) {
     if (wave == THREADS / 64 - 1 && lane < M / 4) __builtin_amdgcn_global_load_lds(att_src + lane * 4, wl + M * KP, 16, 0, 0);
@@ -2436,20 +2285,15 @@ __device__ __forceinline__ void w_prefetch(float* wl, const float* __restrict__ 
 
 // LDS bytes of the two phases for given maxima (host + device): wr window rows, ow own rows, ge / gm window edges
 // (hl: gatres_graph_t.halo -- the forward phase keeps two u16 lists of up to hl entries, the backward phase four)
-// (a W slot holds [M][K + 4] + the two attention vectors of the larger of the two shapes: conv1, M = 2nc, K = nc)
 __host__ __device__ inline long long win_fwd_bytes(int nc, int wr, int ow, int ge, int gm, int hl) {
-  const long long wlf = 2LL * nc * (nc + 4) + 4 * nc;
+  const long long wlf = 2LL * nc * (2 * nc + 4) + 4 * nc;
   return 4LL * (wr * (3LL * nc + 2) + ow * (3LL * nc + 2)) + 2 * (4 * wlf + 16) + 2LL * (2 * even(ow + 2) + even(ge) + even(gm)) +
          64 + 4LL * (hl + 4);
 }
 __host__ __device__ inline long long win_bwd_bytes(int nc, int threads, int wr, int ow, int ge, int gm, int hl) {
-  const long long wlf = 2LL * nc * (nc + 4) + 4 * nc;
+  const long long wlf = 2LL * nc * (2 * nc + 4) + 4 * nc;
   return 12LL * threads + 4LL * (wr * (4LL * nc + 2) + ow * (2LL * nc + 4) + 4LL * even(ge)) + 2 * (4 * wlf + 16) +
          2LL * (3 * even(ow + 2) + 3 * even(ge) + even(wr + 2) + even(gm)) + 64 + 8LL * (hl + 4);
-}
-// in-stage parameter gradients: saved xin / o1 of the own rows (the dW operands, by LDS-DMA), g_a_src of the own rows, T blocks
-__host__ __device__ inline long long win_instage_bytes(int nc, int ow) {
-  return 4LL * (3LL * ow * nc + 4LL * ow + 8LL * nc) + 16;
 }
 
 // Persistent LDS (top of the array, forward -> backward of one launch): per block and own row one 64-bit relu_bits word
@@ -2462,15 +2306,13 @@ __host__ __device__ inline long long win_keep_bytes(int nb, int ow) { return (12
 // that a DMA delivers, is preceded by a full __syncthreads() / group_sync instead.
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-// IS: the in-stage parameter-gradient form (FusedArgs.instage) as its own instantiation -- no consumer workgroups, no
-// kept tables, no progress words -- so that neither form carries the other's code through the instruction cache.
-template <int NC, int THREADS, bool IS>
+template <int NC, int THREADS>
 __global__ __launch_bounds__(THREADS) void gatres_window_kernel(const FusedArgs a) {
   __shared__ __attribute__((aligned(16))) unsigned char lds_raw[LDS_BYTES];
   float* ldsf = reinterpret_cast<float*>(lds_raw);
   const Layout& L = a.L;
   const int M = a.M;
-  if constexpr (!IS) {
+  {
     const int F = ((a.num_segments + 7) / 8) * 8 * M;
     if ((int)blockIdx.x >= F) {
       consumer_main<NC, THREADS>(a, (int)blockIdx.x - F, ldsf);
@@ -2508,12 +2350,7 @@ __global__ __launch_bounds__(THREADS) void gatres_window_kernel(const FusedArgs 
   constexpr int UF = 1, UB = 1;
   // first wave that issues LDS-DMA inside MFMA stages: the waves below it own a 16-row tile there (dma_copy16)
   const int dw0 = min((ow + 15) >> 4, THREADS / 64 - 4);
-  const int wave = uni((int)(threadIdx.x >> 6));
-  // in-stage parameter gradients: the last four waves of the backward dX stages form the T tiles instead of issuing DMA
-  constexpr int TW0 = THREADS / 64 - 4;
-  const int dw1 = IS ? TW0 : THREADS / 64;
-  constexpr int WL_FLOATS = 2 * NC * (NC + 4) + 4 * NC;        // conv1's [2NC][NC + 4] + att vectors (conv2's [NC][2NC + 4] is smaller)
-  static_assert(WL_FLOATS >= NC * (2 * NC + 4) + 2 * NC, "W slot");
+  constexpr int WL_FLOATS = 2 * NC * (2 * NC + 4) + 4 * NC;
   constexpr int WLB = (WL_FLOATS + 3) & ~3;
   const float* P = a.params;
   float* sc = a.scratch;
@@ -2755,13 +2592,7 @@ __global__ __launch_bounds__(THREADS) void gatres_window_kernel(const FusedArgs 
     float* alTw = adTo + (size_t)((ow * 2 + 3) & ~3);
     float* xGo = alTw + 2 * (size_t)even(weg);
     float* gko = xGo + (size_t)ow * 2 * NC;                              // a.keep_lds: g_pre of the own rows (dX1's residual term)
-    // a.instage: saved xin / o1 of the own rows (dW operands), [row][2H] = g_a_src | g_a_dst of the own rows, T of conv1 / conv2
-    float* xS1o = gko + (a.keep_lds ? (size_t)ow * NC : 0);
-    float* xS2o = xS1o + (size_t)ow * NC;
-    float* sdo = xS2o + (size_t)ow * 2 * NC;
-    float* T1l = sdo + (size_t)ow * 4;
-    float* T2l = T1l + 4 * NC;
-    float* wlA = reinterpret_cast<float*>(lds_raw + ((reinterpret_cast<unsigned char*>(IS ? T2l + 4 * NC : xS1o) - lds_raw + 15) & ~15));
+    float* wlA = reinterpret_cast<float*>(lds_raw + ((reinterpret_cast<unsigned char*>(gko + (a.keep_lds ? (size_t)ow * NC : 0)) - lds_raw + 15) & ~15));
     float* wlB = wlA + WLB;
     u16* tp = reinterpret_cast<u16*>(wlB + WLB);
     u16* rpo = tp;             tp += even(ow + 1);
@@ -2810,25 +2641,15 @@ __global__ __launch_bounds__(THREADS) void gatres_window_kernel(const FusedArgs 
     // LDS-DMA of saved tables (independent of the backward chain) and transposed weights always rides on an MFMA
     // stage or, for the first block, on this prologue: conv2 tables + W2^T of block b during dX1 of block b + 1,
     // conv1 tables + W1^T of block b during dX2 of block b.
-    auto dma_conv2 = [&](int blk, int w0, int w1) {
+    auto dma_conv2 = [&](int blk, int w0) {
       const float* bs = segbase + (int64_t)blk * SL.bstride;
-      dma_copy16<THREADS>(hTw, bs + SL.h2 + (size_t)wlo * NC, wr * NC, w0, w1);
-      dma_copy4<THREADS>(asTw, bs + SL.as2 + wlo, wr, w0, w1);
-      dma_copy4<THREADS>(adTo, bs + SL.ad2 + lo, ow, w0, w1);
-      dma_copy4<THREADS>(alTw, bs + SL.al2 + ewlo, weg, w0, w1);
-      w_prefetch<NC, 2 * NC, EPI_RESID_MASK, THREADS>(wlA, a.wt + (int64_t)blk * 2 * w + w, nullptr, nullptr, w0, w1);
+      dma_copy16<THREADS>(hTw, bs + SL.h2 + (size_t)wlo * NC, wr * NC, w0);
+      dma_copy4<THREADS>(asTw, bs + SL.as2 + wlo, wr, w0);
+      dma_copy4<THREADS>(adTo, bs + SL.ad2 + lo, ow, w0);
+      dma_copy4<THREADS>(alTw, bs + SL.al2 + ewlo, weg, w0);
+      w_prefetch<NC, 2 * NC, EPI_RESID_MASK, THREADS>(wlA, a.wt + (int64_t)blk * 2 * w + w, nullptr, nullptr, w0);
     };
-    auto instage_conv1 = [&](int blk) {         // dW1 and the attention-vector gradients of conv1 of block blk
-      if constexpr (IS) {
-        float* sbk = slab + L.p_block0 + (int64_t)blk * L.p_block_stride;
-        if (wave >= 2 && wave < 10 && !(a.no_halo & 8)) seg_dw_tiles<2 * NC, NC>(wave - 2, 8, ow, xGo, xS1o, sbk + L.c1_W);
-        if (wave >= 10 && wave < 14 && !(a.no_halo & 32))
-          seg_att_from_T<2 * NC, NC, 2>(wave - 10, 4, T1l, wlB, sbk + L.c1_as, sbk + L.c1_ad);
-      }
-    };
-    if (L.nb > 0) dma_conv2(L.nb - 1, 0, THREADS / 64);
-    if (IS && L.nb > 0)
-      dma_copy16<THREADS>(xS2o, segbase + (int64_t)(L.nb - 1) * SL.bstride + SL.o1 + (size_t)lo * 2 * NC, ow * 2 * NC, 0);
+    if (L.nb > 0) dma_conv2(L.nb - 1, 0);
     seg_lin1_bwd<NC, THREADS>(rw, n0, a.perm, a.g_out, xfinal, P + L.p_lin1_w, gp_cur, gpT, slab + L.p_lin1_w,
                               slab + L.p_lin1_b, L.nb > 0 ? 1 : 0, red, gkeep);
     int hcnt = uni(build_halo<THREADS>(trp, tdsto, teido, rw, hrow, hedge, hcap, hcounter));
@@ -2870,7 +2691,7 @@ __global__ __launch_bounds__(THREADS) void gatres_window_kernel(const FusedArgs 
       XSTAMP();
       lds_barrier();
       XSTAMP();
-      if constexpr (!IS) publish_items<THREADS>(a, seg, part, 2 * (L.nb - 1 - b), grp.local, false);      // the blocks above are kept
+      publish_items<THREADS>(a, seg, part, 2 * (L.nb - 1 - b), grp.local, false);      // the blocks above are kept
       seg_mean_bwd<NC, THREADS, UB>(rw, otm, mrp, mtrp, mtdsto, gpT, 0, gy2T, 0);
       lds_barrier();
       XSTAMP();
@@ -2882,15 +2703,8 @@ __global__ __launch_bounds__(THREADS) void gatres_window_kernel(const FusedArgs 
       lds_barrier();
       XSTAMP();
       seg_bias_part<NC, THREADS>(rw, gy2T, 0, red);
-      if constexpr (IS) { if (wave < 2) __builtin_amdgcn_s_setprio(3); }    // (beside the dW waves below)
       seg_softmax_bwd<1, THREADS>(rw, 0, 0, rp, colo, alT2 + elo, asT2, adT2, ge2 + elo, 0, gad2, 0, nullptr, 0, nullptr,
                                   0);
-      if constexpr (IS) { if (wave < 2) __builtin_amdgcn_s_setprio(0); }
-      // conv1 of the block above: its g_h rows are still the dX operand table, its saved input rows came by LDS-DMA during
-      // dX2 of that block, W1^T stays in its slot until dX2 of this block; the stores drain during the exchange below
-      if constexpr (IS) {
-        if (b + 1 < L.nb) instage_conv1(b + 1);
-      }
       lds_barrier();
       XSTAMP();
       ++xc.ep;                                   // exchange B2: the source-major stage reads g_y2 / g_e of neighbour rows
@@ -2907,23 +2721,16 @@ __global__ __launch_bounds__(THREADS) void gatres_window_kernel(const FusedArgs 
       STAMP();
       seg_bias_finish<NC, THREADS>(red, sb + L.c2_b);
       seg_agg_bwd_src<1, NC, THREADS, UB>(rw, 0, trp, teido, tdsto, gy2T, 0, alT2, ge2, 0, gad2, 0, pb + L.c2_as,
-                                      pb + L.c2_ad, IS ? nullptr : gh2, n0, IS ? nullptr : keep + L.k_gas2,
-                                      IS ? nullptr : keep + L.k_gad2, xG2, 0, IS ? sdo - lo * 2 : nullptr);
+                                      pb + L.c2_ad, gh2, n0, keep + L.k_gas2, keep + L.k_gad2, xG2, 0);
       lds_barrier();           // g_y2 (RA) and the conv2 tables are dead
       XSTAMP();
       STAMP();
       // LDS-DMA of this block's conv1 tables and W1^T while the matrix cores run dX2
-      w_prefetch<2 * NC, NC, EPI_RESID_MASK, THREADS>(wlB, wt1, nullptr, nullptr, dw0, dw1);
-      dma_copy16<THREADS>(hTw, base + SL.h1 + (size_t)wlo * 2 * NC, wr * 2 * NC, dw0, dw1);
-      dma_copy4<THREADS>(asTw, base + SL.as1 + wlo * 2, wr * 2, dw0, dw1);
-      dma_copy4<THREADS>(adTo, base + SL.ad1 + lo * 2, ow * 2, dw0, dw1);
-      dma_copy4<THREADS>(alTw, base + SL.al1 + ewlo * 2, weg * 2, dw0, dw1);
-      if constexpr (IS) {
-        if (!(a.no_halo & 16))        // xin of the own rows: conv1's dW operand
-          dma_copy16<THREADS>(xS1o, base + SL.xin + (size_t)lo * NC, ow * NC, dw0, dw1);
-        // T of conv2 = [g_a_src | g_a_dst]^T o1 on the last four waves
-        if (wave >= TW0 && !(a.no_halo & 32)) seg_dw_tiles<2, 2 * NC>(wave - TW0, 4, ow, sdo, xS2o, T2l);
-      }
+      w_prefetch<2 * NC, NC, EPI_RESID_MASK, THREADS>(wlB, wt1, nullptr, nullptr, dw0);
+      dma_copy16<THREADS>(hTw, base + SL.h1 + (size_t)wlo * 2 * NC, wr * 2 * NC, dw0);
+      dma_copy4<THREADS>(asTw, base + SL.as1 + wlo * 2, wr * 2, dw0);
+      dma_copy4<THREADS>(adTo, base + SL.ad1 + lo * 2, ow * 2, dw0);
+      dma_copy4<THREADS>(alTw, base + SL.al1 + ewlo * 2, weg * 2, dw0);
       seg_proj<NC, 2 * NC, 1, EPI_RESID_MASK, THREADS, true, true>(rw, xG2, 0, wt2, RA, 0, nullptr, 0,
                                                                nullptr, nullptr, nullptr, nullptr, 0, nullptr, nullptr,
                                                                nullptr, 0, (a.no_halo & 4) ? nullptr : base + SL.o1, 0, wlA,
@@ -2934,21 +2741,9 @@ __global__ __launch_bounds__(THREADS) void gatres_window_kernel(const FusedArgs 
       seg_edge_dots<2, NC, THREADS, 1>(rw, 0, rp, colo, RA, 0, hT1, ge1 + elo * 2, 0);
       lds_barrier();
       XSTAMP();
-#define WSTAMP(k) do { if (xs_on && part == 0 && (threadIdx.x & 63) == 0) a.stamps[3000 + wave * 8 + (k)] = wall_clock64(); } while (0)
-      WSTAMP(0);
       seg_bias_part<2 * NC, THREADS>(rw, RA, 0, red);
-      WSTAMP(3);
-      if constexpr (IS) { if (wave < 2) __builtin_amdgcn_s_setprio(3); }
       seg_softmax_bwd<2, THREADS>(rw, 0, 0, rp, colo, alT1 + elo * 2, asT1, adT1, ge1 + elo * 2, 0, gad1, 0, nullptr, 0,
                                   nullptr, 0);
-      if constexpr (IS) { if (wave < 2) __builtin_amdgcn_s_setprio(0); }
-      WSTAMP(1);
-      if constexpr (IS) {    // conv2 of this block (W2^T stays in its slot until dX1)
-        if (wave >= 2 && wave < 10 && !(a.no_halo & 8)) seg_dw_tiles<NC, 2 * NC>(wave - 2, 8, ow, xGo, xS2o, sb + L.c2_W);
-        if (wave >= 10 && wave < 14 && !(a.no_halo & 32))
-          seg_att_from_T<NC, 2 * NC, 1>(wave - 10, 4, T2l, wlA, sb + L.c2_as, sb + L.c2_ad);
-      }
-      WSTAMP(2);
       lds_barrier();
       XSTAMP();
       ++xc.ep;                                   // exchange B3
@@ -2962,22 +2757,15 @@ __global__ __launch_bounds__(THREADS) void gatres_window_kernel(const FusedArgs 
       XSTAMP();
       lds_barrier();
       XSTAMP();
-      if constexpr (!IS) publish_items<THREADS>(a, seg, part, 2 * (L.nb - 1 - b) + 1, grp.local, false);      // conv2 tables complete
+      publish_items<THREADS>(a, seg, part, 2 * (L.nb - 1 - b) + 1, grp.local, false);      // conv2 tables complete
       STAMP();
       seg_bias_finish<2 * NC, THREADS>(red, sb + L.c1_b);
       seg_agg_bwd_src<2, NC, THREADS, UB>(rw, 0, trp, teido, tdsto, RA, 0, alT1, ge1, 0, gad1, 0, pb + L.c1_as,
-                                      pb + L.c1_ad, IS ? nullptr : gh, n0, IS ? nullptr : keep + L.k_gas1,
-                                      IS ? nullptr : keep + L.k_gad1, xG1, 0, IS ? sdo - lo * 4 : nullptr);
+                                      pb + L.c1_ad, gh, n0, keep + L.k_gas1, keep + L.k_gad1, xG1, 0);
       lds_barrier();
       XSTAMP();
       STAMP();
-      if (b > 0) dma_conv2(b - 1, dw0, dw1);
-      if constexpr (IS) {
-        if (b > 0 && !(a.no_halo & 16))      // o1 of the next block's own rows: conv2's dW operand
-          dma_copy16<THREADS>(xS2o, base - SL.bstride + SL.o1 + (size_t)lo * 2 * NC, ow * 2 * NC, dw0, dw1);
-        // T of conv1 = [g_a_src | g_a_dst]^T xin
-        if (wave >= TW0 && !(a.no_halo & 32)) seg_dw_tiles<4, NC>(wave - TW0, 4, ow, sdo, xS1o, T1l);
-      }
+      if (b > 0) dma_conv2(b - 1, dw0);
       seg_proj<2 * NC, NC, 1, EPI_RESID_MASK, THREADS, true, true>(rw, xG1, 0, wt1, gp_nxt, n0, gpT, 0, nullptr, nullptr,
                                                                nullptr, nullptr, 0, nullptr, nullptr,
                                                                (a.no_halo & 4) ? nullptr : gp_cur, n0,
@@ -2987,22 +2775,12 @@ __global__ __launch_bounds__(THREADS) void gatres_window_kernel(const FusedArgs 
       STAMP();
       float* t = gp_cur; gp_cur = gp_nxt; gp_nxt = t;
     }
-    if constexpr (IS) {                       // (nothing of another part is read from here on: a workgroup barrier will do)
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();
-    } else {
-      group_sync<THREADS>(grp);
-    }
-    if constexpr (!IS) publish_items<THREADS>(a, seg, part, 2 * L.nb, grp.local || !pub, !pub);
-    if constexpr (IS) {
-      if (L.nb > 0) instage_conv1(0);
-    }
+    group_sync<THREADS>(grp);
+    publish_items<THREADS>(a, seg, part, 2 * L.nb, grp.local || !pub, !pub);
     seg_lin0_bwd<NC, THREADS>(rw, n0, a.perm, gp_cur, a.x, a.mask, slab + L.p_lin0_w, slab + L.p_lin0_b, red);
-    if constexpr (!IS) {
-      if (pub && a.C > 0) {
-        group_sync<THREADS>(grp);
-        publish_items<THREADS>(a, seg, part, 2 * L.nb + 1, grp.local, true);
-      }
+    if (pub && a.C > 0) {
+      group_sync<THREADS>(grp);
+      publish_items<THREADS>(a, seg, part, 2 * L.nb + 1, grp.local, true);
     }
     if (a.g_x) {
       constexpr int G = NC / 4;
@@ -3023,10 +2801,7 @@ __global__ __launch_bounds__(THREADS) void gatres_window_kernel(const FusedArgs 
   if (tid == 0) __hip_atomic_store(grp.flags + part * FLAG_STRIDE + 2, xc.ep, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   if (M > 1 && tid == 0 && *a.err) {
     if ((a.phases & GATRES_PHASE_FORWARD) && a.out) a.out[n0] = NAN;
-    if (a.phases & GATRES_PHASE_BACKWARD) {
-      a.slabs[(int64_t)seg * L.slab_stride + L.p_lin1_b] = NAN;
-      if (IS) a.part_slabs[((int64_t)seg * M + part) * L.slab_stride + L.p_lin1_b] = NAN;
-    }
+    if (a.phases & GATRES_PHASE_BACKWARD) a.slabs[(int64_t)seg * L.slab_stride + L.p_lin1_b] = NAN;
   }
   if (a.stamps && blockIdx.x == 0 && threadIdx.x == 0) {
     a.stamps[a.stamp_cap + 1] = clock64();
@@ -3034,14 +2809,8 @@ __global__ __launch_bounds__(THREADS) void gatres_window_kernel(const FusedArgs 
   }
 }
 
-// Slab rows are summed by RA_GROUPS waves per 256 parameters: wave g takes a contiguous range of rows for the workgroup's
-// 64 float4 columns with all its (<= 16) loads in flight, the group sums meet in LDS and are added in group order --
-// a fixed association whatever the timing.  With in-stage parameter gradients there is one row per (segment, part):
-// 256 rows x 263 KB for a bs-32 step, read once at memory bandwidth instead of by 4 waves per CU with 32 dependent
-// rounds of loads.
-constexpr int RA_GROUPS = 16, RA_THREADS = 64 * RA_GROUPS;
 // grads = sum of segment slabs (fixed order) ; optionally the Adam update and the loss finalisation in the same pass
-__global__ __launch_bounds__(RA_THREADS) void reduce_adam_kernel(const float* __restrict__ slabs, int num_slabs,
+__global__ __launch_bounds__(256) void reduce_adam_kernel(const float* __restrict__ slabs, int num_slabs,
                                                           int num_loss, long long stride, long long count,
                                                           float* __restrict__ grads, const float* loss_part,
                                                           float* loss, int do_adam, float* __restrict__ p,
@@ -3051,7 +2820,6 @@ __global__ __launch_bounds__(RA_THREADS) void reduce_adam_kernel(const float* __
                                                           float grad_scale, float* __restrict__ wt, int nb, int nc,
                                                           unsigned* __restrict__ status) {
   __shared__ float s_step_size, s_bc2_sqrt;
-  __shared__ __attribute__((aligned(16))) float s_part[RA_GROUPS][256];
   __shared__ unsigned s_fault;
   // status[0]: a split launch of this step gave up waiting for a partner workgroup (its results are poisoned).  The step
   // is then DROPPED: no Adam update, no step count, loss = NaN, gradients = NaN; the last block clears the word and
@@ -3073,36 +2841,29 @@ __global__ __launch_bounds__(RA_THREADS) void reduce_adam_kernel(const float* __
   __syncthreads();
   const bool fault = s_fault != 0u;
   if (fault && loss && blockIdx.x == 0 && threadIdx.x == 0) loss[0] = NAN;
-  {
-    const int g = threadIdx.x >> 6, j = threadIdx.x & 63;
-    const long long c4 = ((long long)blockIdx.x * 64 + j) * 4;              // first of this lane's four parameters
-    const int per = (num_slabs + RA_GROUPS - 1) / RA_GROUPS;
-    const int sb = g * per, se = min(num_slabs, sb + per);
-    float4 acc4 = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (c4 < stride) {
-      const float* col = slabs + c4;
-      for (int s0 = sb; s0 < se; s0 += 16) {                                // 16 rows in flight, added in row order
-        float4 v16[16];
-#pragma unroll
-        for (int u = 0; u < 16; ++u)
-          v16[u] = s0 + u < se ? *reinterpret_cast<const float4*>(col + (size_t)(s0 + u) * stride) : make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-        for (int u = 0; u < 16; ++u)
-          if (s0 + u < se) { acc4.x += v16[u].x; acc4.y += v16[u].y; acc4.z += v16[u].z; acc4.w += v16[u].w; }
-      }
-    }
-    *reinterpret_cast<float4*>(&s_part[g][4 * j]) = acc4;
-  }
-  // the parameter and its moments are requested before the groups meet: their latency rides on the slab loads
   const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
-  const bool mine = threadIdx.x < 256 && idx < count;
-  float pv = 0.f, mv0 = 0.f, vv0 = 0.f;
-  if (mine && do_adam && !fault) { pv = p[idx]; mv0 = m[idx]; vv0 = v[idx]; }
-  __syncthreads();
-  if (mine) {
+  if (idx < count) {
     float acc = 0.f;
+    int s0 = 0;
+    // the parameter and its moments are requested together with the first slab rows: one memory round trip for a
+    // 32-snapshot batch instead of five dependent ones (this launch is pure latency: 258 workgroups x 4 waves)
+    float pv = 0.f, mv0 = 0.f, vv0 = 0.f;
+    if (do_adam && !fault) { pv = p[idx]; mv0 = m[idx]; vv0 = v[idx]; }
+    for (; s0 + 32 <= num_slabs; s0 += 32) {            // 32 loads in flight, summed in slab order
+      float v32[32];
 #pragma unroll
-    for (int g = 0; g < RA_GROUPS; ++g) acc += s_part[g][threadIdx.x];
+      for (int u = 0; u < 32; ++u) v32[u] = slabs[(size_t)(s0 + u) * stride + idx];
+#pragma unroll
+      for (int u = 0; u < 32; ++u) acc += v32[u];
+    }
+    for (; s0 + 8 <= num_slabs; s0 += 8) {
+      float v8[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v8[u] = slabs[(size_t)(s0 + u) * stride + idx];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) acc += v8[u];
+    }
+    for (; s0 < num_slabs; ++s0) acc += slabs[(size_t)s0 * stride + idx];
     grads[idx] = fault ? NAN : acc;
     if (do_adam && !fault) {
       float gv = acc * grad_scale;
@@ -3210,7 +2971,7 @@ static int device_cus() {
 }
 
 // The window kernel applies when the plan knows the parts' row windows and both LDS layouts fit with them.
-static bool window_kernel_fits(const Layout& L, const gatres_graph_t* g, int M, bool keep = false, bool instage = false) {
+static bool window_kernel_fits(const Layout& L, const gatres_graph_t* g, int M, bool keep = false) {
   if (getenv("GATRES_FUSED_NO_WINDOW") || M < 2 || M > 8 || L.nc > 32 || threads_for(L.nc) != 1024) return false;
   const int k = M - 2;
   const int wr = g->window[k][0], ge = g->window[k][1], gm = g->window[k][2], hl = g->halo[k];
@@ -3219,8 +2980,7 @@ static bool window_kernel_fits(const Layout& L, const gatres_graph_t* g, int M, 
   const int ow = 16 * ((tiles + M - 1) / M);
   const long long kb = keep ? win_keep_bytes(L.nb, ow) : 0;
   return win_fwd_bytes(L.nc, wr, ow, ge, gm, hl) + kb <= LDS_BYTES &&
-         win_bwd_bytes(L.nc, 1024, wr, ow, ge, gm, hl) + kb + (keep ? 4LL * ow * L.nc + 16 : 0) +
-                 (instage ? win_instage_bytes(L.nc, ow) : 0) <= LDS_BYTES &&
+         win_bwd_bytes(L.nc, 1024, wr, ow, ge, gm, hl) + kb + (keep ? 4LL * ow * L.nc + 16 : 0) <= LDS_BYTES &&
          wr <= 65535 && ge <= 65535 && gm <= 65535;
 }
 
@@ -3232,12 +2992,6 @@ static bool window_kernel_fits(const Layout& L, const gatres_graph_t* g, int M, 
 // 4 + 2 (round 1's knee, when every hand-off cost a flag barrier) 0.600 ms.  Otherwise B parts if the window kernel
 // fits with them, otherwise the whole-segment-table kernel at min(B, 4).  The choice depends on the plan only, never on
 // the phases of a launch: the per-part hand-off epochs persist in scratch.  GATRES_FUSED_SPLIT=1..8 overrides.
-// In-stage parameter gradients (seg_dw_tiles) at M parts: the window kernel with the ReLU masks kept in LDS AND the dW
-// operand tables fits.  Then every CU of the co-residency bound carries the chain: no consumers, no second launch.
-static bool instage_at(const Layout& L, const gatres_graph_t* g, int M) {
-  return !getenv("GATRES_FUSED_NO_INSTAGE") && L.nb > 0 && M >= 2 && (L.nc == 16 || L.nc == 32) &&
-         window_kernel_fits(L, g, M, true, true);
-}
 static int fused_split(const Layout& L, const gatres_graph_t* g) {
   const int tiles = (g->max_segment_nodes + 15) / 16;
   const int padded = ((g->num_segments + 7) / 8) * 8;
@@ -3247,7 +3001,6 @@ static int fused_split(const Layout& L, const gatres_graph_t* g) {
     const int v = atoi(e);
     if (v >= 1 && v <= B) return v;
   }
-  if (instage_at(L, g, B)) return B;
   if (B >= 4 && window_kernel_fits(L, g, B - 2) && !getenv("GATRES_FUSED_NO_CONSUMERS")) return B - 2;
   if (B >= 2 && window_kernel_fits(L, g, B)) return B;
   int m = 1;
@@ -3259,7 +3012,7 @@ static int fused_split(const Layout& L, const gatres_graph_t* g) {
 // phase, only with the 1024-thread kernel (the consumers reuse its LDS), and only if the whole grid -- per-snapshot
 // workgroups plus consumers, one per CU -- is still resident at once.
 static int fused_consumers(const Layout& L, const gatres_graph_t* g, int M) {
-  if (getenv("GATRES_FUSED_NO_CONSUMERS") || L.nb == 0 || threads_for(L.nc) != 1024 || instage_at(L, g, M)) return 0;
+  if (getenv("GATRES_FUSED_NO_CONSUMERS") || L.nb == 0 || threads_for(L.nc) != 1024) return 0;
   const int padded = ((g->num_segments + 7) / 8) * 8;
   int c = (device_cus() - padded * M) / padded;
   int cap = 2;             // measured: 1, 2 and 4 consumers per snapshot give the same step time
@@ -3277,13 +3030,7 @@ static int launch_fused(const FusedArgs& a, const gatres_graph_t* g, hipStream_t
   if constexpr (THREADS == 1024 && NC <= 32) {
     if (use_window_kernel(a, g)) {
       const dim3 wgrid((unsigned)(((g->num_segments + 7) / 8) * 8 * (a.M + a.C)));
-      if constexpr (NC == 16 || NC == 32) {
-        if (a.instage) {
-          hipLaunchKernelGGL((gatres_window_kernel<NC, THREADS, true>), wgrid, dim3(THREADS), 0, st, a);
-          return gatres_launch_status();
-        }
-      }
-      hipLaunchKernelGGL((gatres_window_kernel<NC, THREADS, false>), wgrid, dim3(THREADS), 0, st, a);
+      hipLaunchKernelGGL((gatres_window_kernel<NC, THREADS>), wgrid, dim3(THREADS), 0, st, a);
       return gatres_launch_status();
     }
   }
@@ -3379,10 +3126,8 @@ extern "C" int gatres_fused_run(const gatres_model_t* m, const gatres_graph_t* g
   a.M = fused_split(a.L, g);
   a.safe_sync = getenv("GATRES_FUSED_SAFE_SYNC") ? 1 : 0;
   a.no_halo = (getenv("GATRES_FUSED_NO_HALO") ? 1 : 0) | (getenv("GATRES_XCH_NOWAIT") ? 2 : 0) |
-              (getenv("GATRES_DIAG_NOMASK") ? 4 : 0) |
-              (getenv("GATRES_DIAG_IS") ? atoi(getenv("GATRES_DIAG_IS")) << 3 : 0);    // 8: no dW tiles, 16: no xS DMA, 32: no T products      // diagnostic, WRONG results: dX epilogues without their global reads
+              (getenv("GATRES_DIAG_NOMASK") ? 4 : 0);      // diagnostic, WRONG results: dX epilogues without their global reads
   a.C = (phases & GATRES_PHASE_BACKWARD) ? fused_consumers(a.L, g, a.M) : 0;
-  a.instage = ((phases & GATRES_PHASE_BACKWARD) && saved && instage_at(a.L, g, a.M)) ? 1 : 0;
   a.keep_lds = (phases & GATRES_PHASE_FORWARD) && (phases & GATRES_PHASE_BACKWARD) && !getenv("GATRES_FUSED_NO_KEEP") &&
            window_kernel_fits(a.L, g, a.M, true) ? 1 : 0;
   a.flags = reinterpret_cast<unsigned*>(scratch + a.L.sc_flags);
@@ -3427,7 +3172,6 @@ extern "C" int gatres_fused_param_grads(const gatres_model_t* m, const gatres_gr
   ParamGradArgs a;
   if (!make_layout_g(m, g, &a.L)) return GATRES_E_UNSUPPORTED;
   if (a.L.nb == 0) return 0;
-  if (instage_at(a.L, g, fused_split(a.L, g))) return 0;               // formed inside the backward launch's dX stages
   if (fused_consumers(a.L, g, fused_split(a.L, g)) > 0) return 0;     // done by the backward launch's consumers
   a.seg_ptr = g->seg_ptr; a.saved = saved; a.keep = scratch + a.L.sc_keep; a.slabs = scratch + a.L.sc_slabs;
   a.M = fused_split(a.L, g); a.part_slabs = scratch + a.L.sc_part_slabs;
@@ -3461,12 +3205,8 @@ extern "C" int gatres_fused_finish(const gatres_model_t* m, const gatres_graph_t
   if ((loss_part == nullptr) != (loss == nullptr)) return GATRES_E_BADARG;
   Layout L;
   if (!make_layout_g(m, g, &L)) return GATRES_E_UNSUPPORTED;
-  // in-stage parameter gradients: one slab row per (segment, part), written whole by the part's workgroup
-  const int M = fused_nodes_of(g) > 0 && gatres_fused_supported(m, g) ? fused_split(L, g) : 1;
-  const bool per_part = M > 1 && instage_at(L, g, M);
-  hipLaunchKernelGGL(reduce_adam_kernel, dim3((unsigned)((L.P + 255) / 256)), dim3(RA_THREADS), 0, gatres_stream(stream),
-                     scratch + (per_part ? L.sc_part_slabs : L.sc_slabs), per_part ? g->num_segments * M : g->num_segments,
-                     g->num_segments * fused_split(L, g),
+  hipLaunchKernelGGL(reduce_adam_kernel, dim3((unsigned)((L.P + 255) / 256)), dim3(256), 0, gatres_stream(stream),
+                     scratch + L.sc_slabs, g->num_segments, g->num_segments * fused_split(L, g),
                      (long long)L.slab_stride, (long long)L.P, grads, loss_part, loss, do_adam, params, exp_avg, exp_avg_sq,
                      reinterpret_cast<unsigned long long*>(step_counter), lr, beta1, beta2, eps, weight_decay,
                      grad_scale, do_adam ? scratch + L.sc_wt : nullptr, L.nb, L.nc,

@@ -81,11 +81,3 @@ if len(it):
     for k, nme in enumerate(["fold done (compute waves)", "chunk 0 landed", "chunk 1 landed", "last chunk landed", "last chunk computed",
                              "partials in LDS", "slab written"]):
         print("  %-28s %6.2f" % (nme, d[:, k].mean()))
-
-# waves of part 0 in the softmax_bwd1 stage of that block (k_fused.hip WSTAMP): stage entry, after the softmax, after dW / att
-ws = raw[3000:3000 + 16 * 8].reshape(16, 8)
-if ws[0, 0] > 0:
-    t0 = int(ws[:, 0][ws[:, 0] > 0].min())
-    print("\nsoftmax_bwd1 stage, part 0, per wave: entry | bias part done | softmax done | dW / att done (us since the first wave entered)")
-    for w in range(16):
-        print("  wave %2d  %6.2f %6.2f %6.2f %6.2f" % (w, *[(int(ws[w, k]) - t0) / 100.0 for k in (0, 3, 1, 2)]))
