@@ -509,7 +509,11 @@ def main():
                                   "achieved": nbytes / us_all * 1e-3, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                   "frac": nbytes / us_all * 1e-3 / HBM_PEAK_GBS, "traffic": traffic,
                                   "traffic_source": traffic_source,
-                                  "avg_launch_us": us, "algorithmic_bytes_per_launch": nbytes,
+                                  "avg_launch_us": us, "counted_us": us_all,
+                                  "counted_us_note": "frac = algorithmic bytes / counted_us / peak; counted_us = avg_launch_us of the "
+                                                     "dominant kernel + second_kernel.avg_launch_us when the deferred parameter "
+                                                     "gradients run as a launch of their own",
+                                  "algorithmic_bytes_per_launch": nbytes,
                                   "algorithmic_bytes_per_snapshot": unit_bytes,
                                   "bytes_per_snapshot_source": ("SURVEY.md 8(d) / BASELINE.md stated figure" if stated is not None
                                                                 else "SURVEY.md 8(d) formula"),
@@ -521,7 +525,7 @@ def main():
                                                         "note": "round-1 accounting (slab partials, index reads, per-op "
                                                                 "intermediates): fatter than SURVEY 8(d); kept for comparison only"},
                                   "second_kernel": None if inline_pg else
-                                  {"kernel": "param_grads_kernel (deferred dW / att gradients)",
+                                  {"kernel": "param_grads_stream_kernel (deferred dW / att gradients)",
                                    "avg_launch_us": us_pg, "algorithmic_bytes_per_launch": nbytes_pg,
                                    "achieved": nbytes_pg / us_pg * 1e-3}}
         else:

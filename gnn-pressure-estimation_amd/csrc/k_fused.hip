@@ -1213,7 +1213,7 @@ __device__ __forceinline__ void param_grads_item(const ParamGradArgs& a, int seg
 }
 
 template <int NC>
-__global__ __launch_bounds__(1024) void param_grads_stream_kernel(const ParamGradArgs a);
+__global__ __launch_bounds__(512) void param_grads_stream_kernel(const ParamGradArgs a);
 
 template <int NC, int THREADS>
 __global__ __launch_bounds__(THREADS) void param_grads_kernel(const ParamGradArgs a) {
@@ -1252,9 +1252,12 @@ struct CiGeom {
   static_assert(2 * CI_CR * H <= 64 * CI_DMA_WAVES && 2 * CI_CR * H % CI_DMA_WAVES == 0, "small tables: one 4-byte DMA instruction per wave");
 };
 
-template <int NC, int THREADS, int CONV>
+// (NBUF chunk buffers: four in the consumers of the window kernel, which own a CU's whole LDS; three in the stand-alone
+//  launch, whose 512-thread workgroups then fit a CU in pairs -- one streams while the other folds its partial blocks)
+template <int NC, int THREADS, int CONV, int NBUF = CI_NBUF>
 __device__ __forceinline__ void consumer_item_dma(const ParamGradArgs& a, int seg, int b, float* lds) {
   using Gm = CiGeom<NC, CONV>;
+  constexpr int DEPTH = NBUF - 1;
   constexpr int HC = Gm::HC, K = Gm::K, H = Gm::H, CB = Gm::CB, CR = CI_CR;
   constexpr int NW = THREADS / 64, CW = NW - CI_DMA_WAVES, CT = CW * 64;          // compute waves / threads
   constexpr int VC = HC / 16, VK = K / 16;
@@ -1272,8 +1275,10 @@ __device__ __forceinline__ void consumer_item_dma(const ParamGradArgs& a, int se
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int chunks = (n + CR - 1) / CR;
   // chunk buffer: [G CR x HC | X CR x K | g_a_src CR x H | g_a_dst CR x H]
-  auto bufp = [&](int c) { return lds + (c % CI_NBUF) * CB; };
-  float* tred = lds + CI_NBUF * CB;                              // [CW][4][K]: the waves' T blocks, after the loop
+  auto bufp = [&](int c) { return lds + (c % NBUF) * CB; };
+  // [CW][4][K]: the waves' T blocks, after the loop (three buffers: behind the partial dW blocks, inside the dead buffers)
+  float* tred = NBUF < CI_NBUF ? lds + CW * HC * K : lds + NBUF * CB;
+  static_assert(NBUF >= CI_NBUF || CW * HC * K + CW * 4 * K + 4 * K <= NBUF * CB, "the item's epilogue lives in the chunk buffers");
   float* tsum = tred + CW * 4 * K;                               // [4][K]
 #define ISTAMP(k) do { if (a.dstamps && threadIdx.x == 0) a.dstamps[k] = wall_clock64(); } while (0)
   ISTAMP(0);
@@ -1303,17 +1308,17 @@ __device__ __forceinline__ void consumer_item_dma(const ParamGradArgs& a, int se
         if (lane < SH) __builtin_amdgcn_global_load_lds(src, B + CR * (HC + K) + dw * SH, 4, 0, 0);
       }
     };
-    for (int c = 0; c < min(chunks, CI_DEPTH); ++c) issue(c);
+    for (int c = 0; c < min(chunks, DEPTH); ++c) issue(c);
     for (int c = 0; c < chunks; ++c) {
       // chunk c has landed when at most the instructions of the younger chunks in flight are outstanding
-      static_assert(CI_DEPTH == 3 && 2 * Gm::PER_WAVE < 64, "the waits below");
-      switch (min(chunks - 1 - c, CI_DEPTH - 1)) {               // (wave-uniform)
+      static_assert((DEPTH == 3 || DEPTH == 2) && 2 * Gm::PER_WAVE < 64, "the waits below");
+      switch (min(chunks - 1 - c, DEPTH - 1)) {                  // (wave-uniform)
         case 0:  asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
         case 1:  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(Gm::PER_WAVE) : "memory"); break;
         default: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * Gm::PER_WAVE) : "memory"); break;
       }
       lds_barrier_raw();
-      if (c + CI_DEPTH < chunks) issue(c + CI_DEPTH);            // into the buffer of chunk c - 1: every compute wave is past it
+      if (c + DEPTH < chunks) issue(c + DEPTH);                  // into the buffer of chunk c - 1: every compute wave is past it
     }
     lds_barrier_raw();                                            // (the compute waves' "chunk buffers are dead" barrier)
   } else {
@@ -1432,16 +1437,19 @@ __device__ __forceinline__ void consumer_item_dma(const ParamGradArgs& a, int se
 #undef ISTAMP
 }
 
-// the second-launch form of the streamed items (8 parts per snapshot leave no CU for consumers): one item per workgroup
+// the second-launch form of the streamed items (8 parts per snapshot leave no CU for consumers): one item per workgroup,
+// 512 threads (4 DMA + 4 compute waves) and three chunk buffers (77 KB): TWO workgroups per CU, so that a CU keeps
+// streaming while one of its items is in its epilogue (one 1024-thread workgroup per CU streamed 64 % of the time)
+constexpr int PGS_THREADS = 512, PGS_NBUF = 3;
 template <int NC>
-__global__ __launch_bounds__(1024) void param_grads_stream_kernel(const ParamGradArgs a) {
-  __shared__ __attribute__((aligned(16))) float lds[CI_NBUF * CI_CR * (3 * NC + 4) + 12 * 4 * 2 * NC + 4 * 2 * NC];
+__global__ __launch_bounds__(PGS_THREADS) void param_grads_stream_kernel(const ParamGradArgs a) {
+  __shared__ __attribute__((aligned(16))) float lds[PGS_NBUF * CI_CR * (3 * NC + 4)];
   const int conv = blockIdx.x & 1, b = (blockIdx.x >> 1) % a.L.nb, seg = (blockIdx.x >> 1) / a.L.nb;
-  if (conv == 0) consumer_item_dma<NC, 1024, 0>(a, seg, b, lds);
-  else           consumer_item_dma<NC, 1024, 1>(a, seg, b, lds);
+  if (conv == 0) consumer_item_dma<NC, PGS_THREADS, 0, PGS_NBUF>(a, seg, b, lds);
+  else           consumer_item_dma<NC, PGS_THREADS, 1, PGS_NBUF>(a, seg, b, lds);
   if (a.M > 1 && b == 0 && conv == 0) {
-    fold_parts<1024>(a, seg, a.L.p_lin0_w, 2 * NC);
-    fold_parts<1024>(a, seg, a.L.p_lin1_w, NC + 1);
+    fold_parts<PGS_THREADS>(a, seg, a.L.p_lin0_w, 2 * NC);
+    fold_parts<PGS_THREADS>(a, seg, a.L.p_lin1_w, NC + 1);
   }
 }
 
@@ -2985,13 +2993,16 @@ static bool window_kernel_fits(const Layout& L, const gatres_graph_t* g, int M, 
 }
 
 // CUs per segment.  B = the co-residency bound of the layout (at most 8, whole grid resident, no more parts than 16-row
-// tiles).  Preferred: B - 2 parts on the window kernel, which leaves two CUs per segment for the consumer workgroups that
-// turn the kept gradient tables into parameter gradients inside the same launch.  Measured on gatres_small, C-Town,
-// bs = 32 (B = 8; profiles/r02_split_sweep.txt): 6 + 2 consumers 0.593 ms per launch; 7 + 1 0.727 ms (ONE consumer needs
-// ~23 us per item and cannot keep up with two items per 34-us block); 8 parts + a separate 52-us gradient launch 0.588 ms;
-// 4 + 2 (round 1's knee, when every hand-off cost a flag barrier) 0.600 ms.  Otherwise B parts if the window kernel
-// fits with them, otherwise the whole-segment-table kernel at min(B, 4).  The choice depends on the plan only, never on
-// the phases of a launch: the per-part hand-off epochs persist in scratch.  GATRES_FUSED_SPLIT=1..8 overrides.
+// tiles).  Preferred: B parts on the window kernel; the kept gradient tables then become parameter gradients on whatever
+// CUs are left for consumer workgroups (batches below 32 snapshots) or in the stand-alone launch that follows
+// (param_grads_stream_kernel).  Measured on gatres_small, C-Town, bs = 32 (B = 8; profiles/r02_split_sweep.txt), GPU time
+// of the two launches: 8 parts 462 + 38 us; 6 parts + 2 consumers 526 us (the part that owns a segment's last 68 rows
+// needs two trips through every conv1-width sparse stage and a fifth MFMA tile -- 384-node snapshots run 22 us faster --
+// and the consumers finish 15 - 20 us after the parts); 7 + 1 607 us (ONE consumer streams an item at ~23 GB/s, the
+// LDS-DMA rate of one CU beside 224 busy ones, and cannot keep up with two items per block).  GATRES_FUSED_PREFER_CONSUMERS=1
+// restores round 2's earlier choice (B - 2 parts + two consumers).  Otherwise the whole-segment-table kernel at
+// min(B, 4).  The choice depends on the plan only, never on the phases of a launch: the per-part hand-off epochs persist
+// in scratch.  GATRES_FUSED_SPLIT=1..8 overrides.
 static int fused_split(const Layout& L, const gatres_graph_t* g) {
   const int tiles = (g->max_segment_nodes + 15) / 16;
   const int padded = ((g->num_segments + 7) / 8) * 8;
@@ -3001,6 +3012,7 @@ static int fused_split(const Layout& L, const gatres_graph_t* g) {
     const int v = atoi(e);
     if (v >= 1 && v <= B) return v;
   }
+  if (B >= 2 && window_kernel_fits(L, g, B) && !getenv("GATRES_FUSED_PREFER_CONSUMERS")) return B;
   if (B >= 4 && window_kernel_fits(L, g, B - 2) && !getenv("GATRES_FUSED_NO_CONSUMERS")) return B - 2;
   if (B >= 2 && window_kernel_fits(L, g, B)) return B;
   int m = 1;
@@ -3180,8 +3192,8 @@ extern "C" int gatres_fused_param_grads(const gatres_model_t* m, const gatres_gr
   const dim3 grid((unsigned)(2 * a.L.nb * g->num_segments));
   hipStream_t st = gatres_stream(stream);
   if ((m->nc == 16 || m->nc == 32) && !getenv("GATRES_PARAM_GRADS_NO_STREAM")) {
-    if (m->nc == 16) hipLaunchKernelGGL((param_grads_stream_kernel<16>), grid, dim3(1024), 0, st, a);
-    else             hipLaunchKernelGGL((param_grads_stream_kernel<32>), grid, dim3(1024), 0, st, a);
+    if (m->nc == 16) hipLaunchKernelGGL((param_grads_stream_kernel<16>), grid, dim3(PGS_THREADS), 0, st, a);
+    else             hipLaunchKernelGGL((param_grads_stream_kernel<32>), grid, dim3(PGS_THREADS), 0, st, a);
     return gatres_launch_status();
   }
   switch (m->nc) {

@@ -120,7 +120,7 @@ def test_shuffled_node_order_is_relabelled_and_exact(pkg, oracle, fused):
     lib = pkg._native.load()
     if fused:
         assert tr.plan.perm_host is not None and tr.plan.window_rows(4) < 388 // 2
-        assert lib.gatres_fused_cus_per_segment(model._cmodel_ref(), tr.plan.ref()) == 6      # 6 parts + 2 consumer CUs
+        assert lib.gatres_fused_cus_per_segment(model._cmodel_ref(), tr.plan.ref()) == 8      # 8 parts (+ 2 consumer CUs: a batch of 3 leaves CUs free)
         assert lib.gatres_fused_window_kernel(model._cmodel_ref(), tr.plan.ref()) == 1
     snaps = pkg.wdn_synth.make_snapshots(2 * bs, 388, seed=4)
     ref = oracle.OracleTrainer(p)
