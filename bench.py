@@ -424,10 +424,10 @@ def main():
         if args.host_batches:                       # batch i was prefetched during step i - 1; start fetching i + 1
             trainer.commit_batch()
             trainer.prefetch_batch(batches[(i + 1) % nbatches])
-        else:
+            trainer.run_step(device_mask=True)
+        else:                                       # device-resident batch: the reference-shaped call (train.py:159-190)
             b = batches[i % nbatches]
-            trainer.load_batch(b, b)
-        trainer.run_step(device_mask=True)
+            trainer.step(b, b)
 
     def fence():
         torch.cuda.synchronize(device)

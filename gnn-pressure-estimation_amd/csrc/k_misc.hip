@@ -345,7 +345,18 @@ __device__ __forceinline__ uint64_t mask_key(uint64_t seed, uint64_t step, int g
 constexpr int MASK_WGS = 4;
 __global__ __launch_bounds__(1024) void mask_generate_kernel(const int* __restrict__ node_ptr, double rate,
                                                              uint64_t seed, const uint64_t* __restrict__ step_counter,
-                                                             uint8_t* __restrict__ mask) {
+                                                             uint8_t* __restrict__ mask,
+                                                             const float* __restrict__ x_src, const float* __restrict__ y_src,
+                                                             float* __restrict__ x_dst, float* __restrict__ y_dst,
+                                                             long long num_nodes) {
+  // gatres_stage_batch_mask: the batch copy rides on the sampler's launch (grid-stride, before the sampling: its stores
+  // drain while the keys are ranked)
+  if (x_src && x_src != x_dst) {
+    for (long long v = (long long)blockIdx.x * 1024 + threadIdx.x; v < num_nodes; v += (long long)gridDim.x * 1024) {
+      x_dst[v] = x_src[v];
+      if (y_src && y_dst) y_dst[v] = y_src[v];
+    }
+  }
   constexpr int SMALL = 2048, T = 1024;            // graphs up to SMALL nodes: all-pairs rank in LDS (~2 us for C-Town)
   __shared__ uint64_t s_keys[SMALL];
   __shared__ int s_rank[SMALL];
@@ -624,7 +635,17 @@ extern "C" int gatres_mask_generate(const int32_t* node_ptr, int32_t num_graphs,
                                     const uint64_t* step_counter, uint8_t* mask, void* stream) {
   if (!node_ptr || !mask || num_graphs <= 0 || !(mask_rate >= 0.0 && mask_rate <= 1.0)) return GATRES_E_BADARG;
   hipLaunchKernelGGL(mask_generate_kernel, dim3(num_graphs * MASK_WGS), dim3(1024), 0, gatres_stream(stream), node_ptr, mask_rate,
-                     seed, step_counter, mask);
+                     seed, step_counter, mask, nullptr, nullptr, nullptr, nullptr, 0LL);
+  return gatres_launch_status();
+}
+
+extern "C" int gatres_stage_batch_mask(const float* x_src, const float* y_src, float* x_dst, float* y_dst, int64_t num_nodes,
+                                       const int32_t* node_ptr, int32_t num_graphs, double mask_rate, uint64_t seed,
+                                       const uint64_t* step_counter, uint8_t* mask, void* stream) {
+  if (!node_ptr || !mask || num_graphs <= 0 || !(mask_rate >= 0.0 && mask_rate <= 1.0)) return GATRES_E_BADARG;
+  if (!x_src || !x_dst || num_nodes <= 0 || ((y_src == nullptr) != (y_dst == nullptr))) return GATRES_E_BADARG;
+  hipLaunchKernelGGL(mask_generate_kernel, dim3(num_graphs * MASK_WGS), dim3(1024), 0, gatres_stream(stream), node_ptr, mask_rate,
+                     seed, step_counter, mask, x_src, y_src, x_dst, y_dst, (long long)num_nodes);
   return gatres_launch_status();
 }
 

@@ -11,6 +11,7 @@ mean-losses equal the global-batch mean loss, so the result matches single-proce
 from __future__ import annotations
 
 import ctypes as C
+import os
 from collections import OrderedDict
 from typing import Callable, Dict, Optional, Sequence, Tuple
 
@@ -306,8 +307,28 @@ class GATResTrainer:
         else:
             self._run_split(device_mask)
 
+    def _stage_with_mask(self, x: torch.Tensor, y: torch.Tensor) -> bool:
+        """Device-resident batch + device mask on the single-rank path: the copy into the static buffers rides on the mask
+        sampler's launch (``gatres_stage_batch_mask``) -- one small kernel and one kernel boundary less per step than
+        ``load_batch`` followed by the sampler.  Returns False when the batch has to go through ``load_batch``."""
+        if self.split or self.node_ptr is None or os.environ.get("GATRES_NO_STAGE_MASK"):
+            return False
+        n = self.x.numel()
+        for t in (x, y):
+            if not (t.is_cuda and t.device == self.x.device and t.dtype == torch.float32 and t.numel() == n and t.is_contiguous()):
+                return False
+        ys = None if self.targets_are_inputs else y
+        _native.check(self.lib.gatres_stage_batch_mask(
+            x.data_ptr(), None if ys is None else ys.data_ptr(), self.x.data_ptr(), None if ys is None else self.y.data_ptr(), n,
+            self.node_ptr.data_ptr(), self.num_graphs, self.mask_rate, self.seed, self.step_counter.data_ptr(),
+            self.mask.data_ptr(), _native.current_stream(self.device)), "gatres_stage_batch_mask")
+        return True
+
     def step(self, x: torch.Tensor, y: torch.Tensor, mask: Optional[torch.Tensor] = None) -> torch.Tensor:
         """Reference-shaped call: one iteration of train.py:159-190.  Returns the (device) loss tensor."""
+        if mask is None and self._stage_with_mask(x, y):
+            self._run(PHASE_FORWARD | PHASE_BACKWARD | PHASE_ADAM, True)        # (the mask of this step is in place)
+            return self.loss
         self.load_batch(x, y, mask)
         self.run_step(device_mask=mask is None)
         return self.loss

@@ -218,6 +218,14 @@ int gatres_transpose_conv_weights(const float* params, float* wt, int32_t num_bl
 int gatres_mask_generate(const int32_t* node_ptr, int32_t num_graphs, double mask_rate, uint64_t seed,
                          const uint64_t* step_counter, uint8_t* mask, void* stream);
 
+/* The same sampler AND the staging of a device-resident batch in ONE launch: x_dst[0..N) = x_src (and y_dst = y_src when
+ * both are given; x_src may equal x_dst: nothing is copied then).  What `collate + mask` of train.py:159-173 amounts to
+ * once snapshots live on the device: one small kernel and one kernel boundary less per step than a copy followed by
+ * gatres_mask_generate. */
+int gatres_stage_batch_mask(const float* x_src, const float* y_src, float* x_dst, float* y_dst, int64_t num_nodes,
+                            const int32_t* node_ptr, int32_t num_graphs, double mask_rate, uint64_t seed,
+                            const uint64_t* step_counter, uint8_t* mask, void* stream);
+
 /* MSELoss(mean) over masked nodes + its gradient: loss[0] = mean_{mask}(out-y)^2, g_out[n] = mask ? 2(out-y)/M : 0. */
 int gatres_masked_mse(const float* out, const float* y, const uint8_t* mask, float* loss, float* g_out,
                       int32_t num_nodes, void* stream);

@@ -1,4 +1,5 @@
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-timeout 1500 python -m pytest tests -m gpu -x -q 2>&1 | grep -E "passed|failed|error" | tail -n 5
-timeout 300 python bench.py > gpurun_out/bench_final.json 2> gpurun_out/bench_final.err; cat gpurun_out/bench_final.json | cut -c1-900
-timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -n 2
+timeout 1500 python -m pytest tests/test_gpu_configs.py -x -q 2>&1 | grep -E "passed|failed|rror" | tail -n 5
+show='import sys,json; d=json.loads(sys.stdin.read()); r=d["roofline"]; print(round(d["value"]), round(d["ms_per_step"],4), round(r["avg_launch_us"],1), r["second_kernel"] and round(r["second_kernel"]["avg_launch_us"],1), round(r["frac"],4))'
+echo STAGED; timeout 300 python bench.py --no-cpu-baseline 2>/dev/null | tail -n 1 | python -c "$show"
+echo NO_STAGE; GATRES_NO_STAGE_MASK=1 timeout 300 python bench.py --no-cpu-baseline 2>/dev/null | tail -n 1 | python -c "$show"

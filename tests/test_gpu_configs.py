@@ -232,6 +232,24 @@ def test_set_lr_under_graph_replay(pkg, oracle):
     assert len({k[3] for k in tr._graphs}) == 2               # two learning rates, two families of graphs
 
 
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_staged_batch_with_device_mask_equals_copy_then_sampler(pkg, oracle, use_graph, monkeypatch):
+    """``step(x, y)`` with a device-resident batch stages it inside the mask sampler's launch (gatres_stage_batch_mask); the
+    mask stream, the loss and the weights must be those of ``load_batch`` + the sampler inside the step, bit for bit."""
+    model, p, tr, ei, y, _ = _small_setup(pkg, oracle, use_graph=use_graph)
+    monkeypatch.setenv("GATRES_NO_STAGE_MASK", "1")
+    twin, _, tr2, *_ = _small_setup(pkg, oracle, use_graph=use_graph)
+    xs = [torch.randn_like(y) for _ in range(3)]
+    for x in xs:
+        monkeypatch.delenv("GATRES_NO_STAGE_MASK", raising=False)
+        l1 = tr.step(x, x).clone()
+        monkeypatch.setenv("GATRES_NO_STAGE_MASK", "1")
+        l2 = tr2.step(x, x).clone()
+        assert torch.equal(tr.mask, tr2.mask) and int(tr.mask.sum()) > 0
+        assert torch.equal(tr.x, tr2.x) and torch.equal(l1, l2)
+        assert torch.equal(model.flat_parameters, twin.flat_parameters)
+
+
 def test_training_and_evaluation_on_two_streams(pkg, oracle):
     """Split launches need their whole grid resident, so two of them must never overlap on one device.  Training on one
     stream and evaluation on another (both split) must serialise behind each other: finite, and equal to running them
