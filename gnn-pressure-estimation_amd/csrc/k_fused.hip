@@ -2834,9 +2834,21 @@ __global__ __launch_bounds__(256) void reduce_adam_kernel(const float* __restric
   // counts the event in status[1], so one transient stall costs one step instead of the whole run.
   if (threadIdx.x == 0) s_fault = status ? __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
   if (do_adam && threadIdx.x == 0) {
-    const unsigned long long t = step_counter[0] + 1ULL;
+    const unsigned long long t = __hip_atomic_load(step_counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1ULL;
     s_step_size = (float)(lr / (1.0 - gatres_powi(b1, t)));
     s_bc2_sqrt = (float)sqrt(1.0 - gatres_powi(b2, t));
+    // The step is counted once every block has READ the counter: a ticket drawn right after this block's read (its value is
+    // in a register: the wait below), the last ticket increments.  Nothing orders the count behind the parameter stores --
+    // the next launch is -- so no fence: the ticket used to follow the block's stores behind a __threadfence(), an L2
+    // write-back + invalidate of ~3.5 us at the end of every block of a 14-us launch.
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    if (s_fault == 0u) {
+      const unsigned long long done = atomicAdd(&step_counter[1], 1ULL);
+      if (done == (unsigned long long)gridDim.x - 1ULL) {
+        step_counter[1] = 0ULL;
+        atomicAdd(&step_counter[0], 1ULL);
+      }
+    }
   }
   if (loss_part && blockIdx.x == 0 && threadIdx.x < 64) {
     // the loss: sum of the per-(segment, part) squared errors / masked-node count.  One wave, strided partial sums
@@ -2896,17 +2908,6 @@ __global__ __launch_bounds__(256) void reduce_adam_kernel(const float* __restric
             wt[b * 2 * per + per + col * nc + row] = pn;
           }
         }
-      }
-    }
-  }
-  if (do_adam && !fault) {
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      __threadfence();
-      const unsigned long long done = atomicAdd(&step_counter[1], 1ULL);
-      if (done == (unsigned long long)gridDim.x - 1ULL) {
-        step_counter[1] = 0ULL;
-        atomicAdd(&step_counter[0], 1ULL);
       }
     }
   }
