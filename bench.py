@@ -209,8 +209,12 @@ def pmc_traffic(args):
             with open(os.path.join(ROOT, "profiles", name)) as f:
                 raw = json.load(f)
             val = int((2.0 * raw["FETCH_SIZE"]["mean_counter_value_KB"] + raw["WRITE_SIZE"]["mean_counter_value_KB"]) * 1024)
+            sk = raw.get("second_kernel")
+            if sk:       # the deferred parameter gradients ran as a launch of their own: both launches, like counted_us
+                val += int((2.0 * sk["FETCH_SIZE"]["mean_counter_value_KB"] + sk["WRITE_SIZE"]["mean_counter_value_KB"]) * 1024)
             return val, f"profiles/{name}: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, " \
-                        f"2 x FETCH + WRITE per launch; a committed constant, NOT measured in this run"
+                        f"2 x FETCH + WRITE per launch{' (window kernel + parameter-gradient launch)' if sk else ''}; " \
+                        f"a committed constant, NOT measured in this run"
         except Exception:
             continue
     return None, None

@@ -1,6 +1,6 @@
 # Round-2 evidence run (MI355X): everything lands under gpurun_out/r02p/, the summaries are copied into profiles/ by hand.
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-O=gpurun_out/r02p; mkdir -p $O
+O=gpurun_out/r02q; mkdir -p $O
 B="python3 bench.py"
 short='import sys,json; d=json.loads(sys.stdin.read()); r=d.get("roofline") or {}; sk=r.get("second_kernel"); print(round(d["value"]), "snapshots/s", round(d["ms_per_step"],4), "ms/step | dominant:", r.get("kernel","")[:40], round(r.get("avg_launch_us",0),1), "us  frac", round(r.get("frac",0),4), "| 2nd launch us:", sk and round(sk["avg_launch_us"],1), "|", d["config"]["workload"][-95:])'
 timeout 600 $B 2>$O/bench.err | tail -1 > $O/bench_n1.json; python3 -c "$short" < $O/bench_n1.json
@@ -11,8 +11,11 @@ timeout 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -o w 
 timeout 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $O/pmc_sq -o s -- $B --steps 20 --warmup 5 --no-cpu-baseline --no-roofline > $O/pmc_sq.log 2>&1
 timeout 300 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SMEM SQ_LDS_BANK_CONFLICT SQ_INSTS_VALU_MFMA_MOPS_F32 --output-format csv -d $O/pmc_inst -o i -- $B --steps 20 --warmup 5 --no-cpu-baseline --no-roofline > $O/pmc_inst.log 2>&1
 python3 tests/micro/summarize_prof.py pmc $O/fused_pmc.json gatres_window_kernel $O/pmc_fetch $O/pmc_write $O/pmc_sq $O/pmc_inst; cat $O/fused_pmc.json | head -60
+python3 tests/micro/summarize_prof.py pmc $O/pgs_pmc.json param_grads_stream_kernel $O/pmc_fetch $O/pmc_write $O/pmc_sq $O/pmc_inst
 timeout 200 python3 tests/stage_profile.py > $O/stage_times.txt 2>&1; tail -17 $O/stage_times.txt
 { for m in 4 5 6 7 8; do echo "GATRES_FUSED_SPLIT=$m"; GATRES_FUSED_SPLIT=$m timeout 300 $B --no-cpu-baseline 2>/dev/null | tail -1 | python3 -c "$short"; done
+  echo "GATRES_FUSED_PREFER_CONSUMERS=1 (6 parts + 2 consumer CUs per snapshot)"; GATRES_FUSED_PREFER_CONSUMERS=1 timeout 300 $B --no-cpu-baseline 2>/dev/null | tail -1 | python3 -c "$short"
+  for n in 384 400; do echo "nodes=$n (24 / 25 full 16-row tiles) GATRES_FUSED_PREFER_CONSUMERS=1"; GATRES_FUSED_PREFER_CONSUMERS=1 timeout 300 $B --no-cpu-baseline --nodes $n --pipes $((n*430/388)) 2>/dev/null | tail -1 | python3 -c "$short"; echo "nodes=$n default"; timeout 300 $B --no-cpu-baseline --nodes $n --pipes $((n*430/388)) 2>/dev/null | tail -1 | python3 -c "$short"; done
   echo "GATRES_FUSED_SPLIT=8 GATRES_XCH_NOWAIT=1 (wrong results: no part ever waits)"; GATRES_FUSED_SPLIT=8 GATRES_XCH_NOWAIT=1 timeout 300 $B --no-cpu-baseline 2>/dev/null | tail -1 | python3 -c "$short"
   echo "GATRES_FUSED_SAFE_SYNC=1 (agent-scope granules: the cross-XCD form)"; GATRES_FUSED_SAFE_SYNC=1 timeout 300 $B --no-cpu-baseline 2>/dev/null | tail -1 | python3 -c "$short"; } > $O/split_sweep.txt 2>&1; cat $O/split_sweep.txt
 { for bs in 8 16 32 64 128 256; do echo "bs $bs"; timeout 300 $B --batch-size $bs --no-cpu-baseline 2>/dev/null | tail -1 | python3 -c "$short"; done; } > $O/batch_scaling.txt 2>&1; cat $O/batch_scaling.txt
