@@ -74,6 +74,7 @@ SIGNATURES = {
     "gatres_transpose_conv_weights": (C.c_int, [_P, _P, _I32, _I32, _P]),
     "gatres_mask_generate": (C.c_int, [_P, _I32, _F64, _U64, _P, _P, _P]),
     "gatres_stage_batch_mask": (C.c_int, [_P, _P, _P, _P, _I64, _P, _I32, _F64, _U64, _P, _P, _P]),
+    "gatres_stage_rows_mask": (C.c_int, [_P, _P, _I32, _P, _P, _P, _I32, _F64, _U64, _P, _P, _P]),
     "gatres_masked_mse": (C.c_int, [_P] * 5 + [_I32, _P]),
     "gatres_adam_step": (C.c_int, [_P] * 5 + [_I64] + [_F64] * 5 + [_F32, _P]),
     # typed per-op kernels (storage type argument): C ints

@@ -348,13 +348,15 @@ __global__ __launch_bounds__(1024) void mask_generate_kernel(const int* __restri
                                                              uint8_t* __restrict__ mask,
                                                              const float* __restrict__ x_src, const float* __restrict__ y_src,
                                                              float* __restrict__ x_dst, float* __restrict__ y_dst,
-                                                             long long num_nodes) {
-  // gatres_stage_batch_mask: the batch copy rides on the sampler's launch (grid-stride, before the sampling: its stores
-  // drain while the keys are ranked)
+                                                             long long num_nodes, const long long* __restrict__ rows,
+                                                             int rows_npg) {
+  // gatres_stage_batch_mask / gatres_stage_rows_mask: the batch copy -- or its collation from the snapshot matrix -- rides
+  // on the sampler's launch (grid-stride, before the sampling: its stores drain while the keys are ranked)
   if (x_src && x_src != x_dst) {
     for (long long v = (long long)blockIdx.x * 1024 + threadIdx.x; v < num_nodes; v += (long long)gridDim.x * 1024) {
-      x_dst[v] = x_src[v];
-      if (y_src && y_dst) y_dst[v] = y_src[v];
+      const long long u = rows ? rows[v / rows_npg] * rows_npg + v % rows_npg : v;
+      x_dst[v] = x_src[u];
+      if (y_src && y_dst) y_dst[v] = y_src[u];
     }
   }
   constexpr int SMALL = 2048, T = 1024;            // graphs up to SMALL nodes: all-pairs rank in LDS (~2 us for C-Town)
@@ -635,7 +637,7 @@ extern "C" int gatres_mask_generate(const int32_t* node_ptr, int32_t num_graphs,
                                     const uint64_t* step_counter, uint8_t* mask, void* stream) {
   if (!node_ptr || !mask || num_graphs <= 0 || !(mask_rate >= 0.0 && mask_rate <= 1.0)) return GATRES_E_BADARG;
   hipLaunchKernelGGL(mask_generate_kernel, dim3(num_graphs * MASK_WGS), dim3(1024), 0, gatres_stream(stream), node_ptr, mask_rate,
-                     seed, step_counter, mask, nullptr, nullptr, nullptr, nullptr, 0LL);
+                     seed, step_counter, mask, nullptr, nullptr, nullptr, nullptr, 0LL, nullptr, 1);
   return gatres_launch_status();
 }
 
@@ -645,7 +647,19 @@ extern "C" int gatres_stage_batch_mask(const float* x_src, const float* y_src, f
   if (!node_ptr || !mask || num_graphs <= 0 || !(mask_rate >= 0.0 && mask_rate <= 1.0)) return GATRES_E_BADARG;
   if (!x_src || !x_dst || num_nodes <= 0 || ((y_src == nullptr) != (y_dst == nullptr))) return GATRES_E_BADARG;
   hipLaunchKernelGGL(mask_generate_kernel, dim3(num_graphs * MASK_WGS), dim3(1024), 0, gatres_stream(stream), node_ptr, mask_rate,
-                     seed, step_counter, mask, x_src, y_src, x_dst, y_dst, (long long)num_nodes);
+                     seed, step_counter, mask, x_src, y_src, x_dst, y_dst, (long long)num_nodes, nullptr, 1);
+  return gatres_launch_status();
+}
+
+extern "C" int gatres_stage_rows_mask(const float* data, const int64_t* rows, int32_t nodes_per_graph, float* x_dst,
+                                      float* y_dst, const int32_t* node_ptr, int32_t num_graphs, double mask_rate,
+                                      uint64_t seed, const uint64_t* step_counter, uint8_t* mask, void* stream) {
+  if (!node_ptr || !mask || num_graphs <= 0 || !(mask_rate >= 0.0 && mask_rate <= 1.0)) return GATRES_E_BADARG;
+  if (!data || !rows || !x_dst || nodes_per_graph <= 0 || data == x_dst) return GATRES_E_BADARG;
+  static_assert(sizeof(long long) == sizeof(int64_t), "row indices");
+  hipLaunchKernelGGL(mask_generate_kernel, dim3(num_graphs * MASK_WGS), dim3(1024), 0, gatres_stream(stream), node_ptr, mask_rate,
+                     seed, step_counter, mask, data, y_dst ? data : nullptr, x_dst, y_dst,
+                     (long long)num_graphs * nodes_per_graph, reinterpret_cast<const long long*>(rows), (int)nodes_per_graph);
   return gatres_launch_status();
 }
 

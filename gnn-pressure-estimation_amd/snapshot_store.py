@@ -69,6 +69,18 @@ class SnapshotStore:
                 break
             yield self.batch(rows), self.edge_index(int(rows.numel())), int(rows.numel())
 
+    def row_batches(self, batch_size: int, shuffle: bool = True, drop_last: bool = False,
+                    generator: Optional[torch.Generator] = None) -> Iterator[Tuple[torch.Tensor, torch.Tensor, int]]:
+        """Yields ``(rows, edge_index, num_graphs)``: ``rows`` is a DEVICE int64 slice of the epoch's snapshot order
+        (uploaded once per epoch), for consumers that collate on the device themselves (``GATResTrainer.step_rows``)."""
+        order = (torch.randperm(self.num_snapshots, generator=generator) if shuffle
+                 else torch.arange(self.num_snapshots)).to(self.device)
+        for s in range(0, self.num_snapshots, batch_size):
+            rows = order[s:s + batch_size]
+            if drop_last and rows.numel() < batch_size:
+                break
+            yield rows, self.edge_index(int(rows.numel())), int(rows.numel())
+
     def descale(self, scaled: torch.Tensor) -> torch.Tensor:
         """auxil.py:42-64 for znorm: ``scaled * std + mean`` (note: no eps here, as in the reference)."""
         return scaled * self.std + self.mean if self.norm_type == "znorm" else scaled

@@ -324,6 +324,25 @@ class GATResTrainer:
             self.mask.data_ptr(), _native.current_stream(self.device)), "gatres_stage_batch_mask")
         return True
 
+    def step_rows(self, data: torch.Tensor, rows: torch.Tensor) -> bool:
+        """One step on the snapshots ``rows`` (device int64 ``[num_graphs]``) of the device-resident matrix ``data``
+        ``[S, N_g]`` (a ``SnapshotStore``): the batch is collated INSIDE the mask sampler's launch
+        (``gatres_stage_rows_mask``) -- no ``index_select``, no copy.  Returns False (nothing done) when this trainer
+        cannot take the path (multi-rank split step, no per-graph node counts, switched off)."""
+        if self.split or self.node_ptr is None or os.environ.get("GATRES_NO_STAGE_MASK"):
+            return False
+        npg = self.N // max(self.num_graphs, 1)
+        if not (data.is_cuda and data.device == self.x.device and data.dtype == torch.float32 and data.dim() == 2
+                and data.shape[1] == npg and data.is_contiguous() and rows.is_cuda and rows.dtype == torch.int64
+                and rows.numel() == self.num_graphs and rows.is_contiguous()):
+            return False
+        _native.check(self.lib.gatres_stage_rows_mask(
+            data.data_ptr(), rows.data_ptr(), npg, self.x.data_ptr(), None if self.targets_are_inputs else self.y.data_ptr(),
+            self.node_ptr.data_ptr(), self.num_graphs, self.mask_rate, self.seed, self.step_counter.data_ptr(),
+            self.mask.data_ptr(), _native.current_stream(self.device)), "gatres_stage_rows_mask")
+        self._run(PHASE_FORWARD | PHASE_BACKWARD | PHASE_ADAM, True)
+        return True
+
     def step(self, x: torch.Tensor, y: torch.Tensor, mask: Optional[torch.Tensor] = None) -> torch.Tensor:
         """Reference-shaped call: one iteration of train.py:159-190.  Returns the (device) loss tensor."""
         if mask is None and self._stage_with_mask(x, y):
@@ -381,14 +400,18 @@ class GATResTrainer:
         total = torch.zeros(1, dtype=torch.float32, device=self.device)
         sums = {k: 0.0 for k in (metric_fn_dict or {})}
         seen = 0
-        for x, edge_index, ng in store.batches(bs, shuffle=shuffle, drop_last=drop_last, generator=generator):
+        # the epoch's snapshot order goes to the device ONCE; a batch is a slice of it, collated inside the mask sampler's
+        # launch (step_rows) -- the reference collates on the host and copies every iteration (train.py:302-303)
+        for rows, edge_index, ng in store.row_batches(bs, shuffle=shuffle, drop_last=drop_last, generator=generator):
             tr = self if ng == bs else self._sibling(ng, npg, edge_index)
-            tr.load_batch(x, x)
-            tr.run_step(device_mask=True)
+            if not tr.step_rows(store.data, rows):
+                x = store.batch(rows)
+                tr.load_batch(x, x)
+                tr.run_step(device_mask=True)
             total.add_(tr.loss, alpha=float(ng))
             if metric_fn_dict:
                 m = tr.mask.bool()
-                p, t = store.descale(tr.out[m]), store.descale(x.reshape(-1)[m])
+                p, t = store.descale(tr.out[m]), store.descale(tr.x[m])
                 for k, fn in metric_fn_dict.items():
                     sums[k] += float(fn(p, t)) * ng
             seen += ng

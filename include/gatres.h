@@ -226,6 +226,14 @@ int gatres_stage_batch_mask(const float* x_src, const float* y_src, float* x_dst
                             const int32_t* node_ptr, int32_t num_graphs, double mask_rate, uint64_t seed,
                             const uint64_t* step_counter, uint8_t* mask, void* stream);
 
+/* The same with the batch COLLATED on the way (utils/DataLoader.py:191-204 + the PyG DataLoader of train.py:302-303 for a
+ * static topology): data is the device-resident snapshot matrix [S][nodes_per_graph], rows[num_graphs] (device, int64) the
+ * snapshots of this batch; x_dst[g * nodes_per_graph + v] = data[rows[g]][v] (and y_dst likewise when given: targets are
+ * the inputs before masking, utils/auxil.py:84-98). */
+int gatres_stage_rows_mask(const float* data, const int64_t* rows, int32_t nodes_per_graph, float* x_dst, float* y_dst,
+                           const int32_t* node_ptr, int32_t num_graphs, double mask_rate, uint64_t seed,
+                           const uint64_t* step_counter, uint8_t* mask, void* stream);
+
 /* MSELoss(mean) over masked nodes + its gradient: loss[0] = mean_{mask}(out-y)^2, g_out[n] = mask ? 2(out-y)/M : 0. */
 int gatres_masked_mse(const float* out, const float* y, const uint8_t* mask, float* loss, float* g_out,
                       int32_t num_nodes, void* stream);
