@@ -454,13 +454,21 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
                                                    float* __restrict__ m, float* __restrict__ v,
                                                    unsigned long long* __restrict__ step_counter, long long count,
                                                    double lr, double b1, double b2, double eps, double wd,
-                                                   float grad_scale) {
+                                                   float grad_scale, float* __restrict__ wt, int nb, int nc) {
   __shared__ float s_step_size, s_bc2_sqrt;
   if (threadIdx.x == 0) {
-    const unsigned long long t = step_counter[0] + 1ULL;
+    const unsigned long long t = __hip_atomic_load(step_counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1ULL;
     const double bc1 = 1.0 - gatres_powi(b1, t), bc2 = 1.0 - gatres_powi(b2, t);
     s_step_size = (float)(lr / bc1);
     s_bc2_sqrt = (float)sqrt(bc2);
+    // the step is counted once every block has READ the counter: the ticket follows this block's read (no fence: nothing
+    // orders the count behind the parameter stores but the next launch -- see reduce_adam_kernel, k_fused.hip)
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    const unsigned long long done = atomicAdd(&step_counter[1], 1ULL);
+    if (done == (unsigned long long)gridDim.x - 1ULL) {
+      step_counter[1] = 0ULL;
+      atomicAdd(&step_counter[0], 1ULL);
+    }
   }
   __syncthreads();
   const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
@@ -475,17 +483,22 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
     mv = mv + (float)(1.0 - b1) * (gv - mv);
     const float vv = (float)b2 * v[idx] + (float)(1.0 - b2) * gv * gv;
     const float denom = sqrtf(vv) / s_bc2_sqrt + (float)eps;
-    p[idx] = pv + (-s_step_size * mv) / denom;
+    const float pn = pv + (-s_step_size * mv) / denom;
+    p[idx] = pn;
     m[idx] = mv;
     v[idx] = vv;
-  }
-  __syncthreads();
-  if (threadIdx.x == 0) {                       // the last block to finish bumps the step; all blocks have read it
-    __threadfence();
-    const unsigned long long done = atomicAdd(&step_counter[1], 1ULL);
-    if (done == (unsigned long long)gridDim.x - 1ULL) {
-      step_counter[1] = 0ULL;
-      atomicAdd(&step_counter[0], 1ULL);
+    if (wt) {                     // keep the fused kernels' transposed conv weights current (transpose_conv_weights_kernel's layout)
+      const long long per = 2LL * nc * nc, stride = 9LL * nc + 2 * per, off = idx - 2LL * nc;
+      if (off >= 0 && off < (long long)nb * stride) {
+        const long long b = off / stride, o = off % stride;
+        if (o >= 6LL * nc && o < 6LL * nc + per) {                        // W1 [2nc][nc] -> [nc][2nc]
+          const long long e = o - 6LL * nc, row = e / nc, col = e % nc;
+          wt[b * 2 * per + col * 2 * nc + row] = pn;
+        } else if (o >= 9LL * nc + per) {                                 // W2 [nc][2nc] -> [2nc][nc]
+          const long long e = o - 9LL * nc - per, row = e / (2 * nc), col = e % (2 * nc);
+          wt[b * 2 * per + per + col * nc + row] = pn;
+        }
+      }
     }
   }
 }
@@ -677,7 +690,21 @@ extern "C" int gatres_adam_step(float* params, const float* grads, float* exp_av
   if (!params || !grads || !exp_avg || !exp_avg_sq || !step_counter || count <= 0) return GATRES_E_BADARG;
   hipLaunchKernelGGL(adam_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, gatres_stream(stream), params,
                      grads, exp_avg, exp_avg_sq, reinterpret_cast<unsigned long long*>(step_counter),
-                     (long long)count, lr, beta1, beta2, eps, weight_decay, grad_scale);
+                     (long long)count, lr, beta1, beta2, eps, weight_decay, grad_scale, (float*)nullptr, 0, 0);
+  return gatres_launch_status();
+}
+
+// (not part of include/gatres.h: the fused train step's Adam-only phase -- the data-parallel step runs backward |
+//  all-reduce | Adam -- also refreshes scratch's transposed conv weights, so the next backward finds them current.
+//  A NaN gradient entry leaves parameter AND transposed copy untouched: they stay consistent.)
+extern "C" __attribute__((visibility("hidden"))) int gatres_adam_step_wt(float* params, const float* grads, float* exp_avg, float* exp_avg_sq,
+                                   uint64_t* step_counter, int64_t count, double lr, double beta1, double beta2,
+                                   double eps, double weight_decay, float grad_scale, float* wt, int32_t num_blocks,
+                                   int32_t nc, void* stream) {
+  if (!params || !grads || !exp_avg || !exp_avg_sq || !step_counter || count <= 0 || !wt) return GATRES_E_BADARG;
+  hipLaunchKernelGGL(adam_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, gatres_stream(stream), params,
+                     grads, exp_avg, exp_avg_sq, reinterpret_cast<unsigned long long*>(step_counter),
+                     (long long)count, lr, beta1, beta2, eps, weight_decay, grad_scale, wt, (int)num_blocks, (int)nc);
   return gatres_launch_status();
 }
 

@@ -3,6 +3,11 @@
 #include "gatres_common.h"
 #include "gatres_layout.h"
 
+extern "C" __attribute__((visibility("hidden"))) int gatres_adam_step_wt(float* params, const float* grads, float* exp_avg, float* exp_avg_sq,
+                                   uint64_t* step_counter, int64_t count, double lr, double beta1, double beta2,
+                                   double eps, double weight_decay, float grad_scale, float* wt, int32_t num_blocks,
+                                   int32_t nc, void* stream);
+
 extern "C" int gatres_train_step(const gatres_train_step_t* ts, void* stream) {
   if (!ts || !ts->graph || !ts->params || !ts->x || !ts->y || !ts->mask || !ts->out || !ts->g_out || !ts->loss ||
       !ts->saved || !ts->scratch)
@@ -55,10 +60,11 @@ extern "C" int gatres_train_step(const gatres_train_step_t* ts, void* stream) {
                                  ts->params, ts->exp_avg, ts->exp_avg_sq, ts->step_counter, ts->lr, ts->beta1,
                                  ts->beta2, ts->eps, ts->weight_decay, ts->grad_scale, stream);
     }
-    if (adam)
-      return gatres_adam_step(ts->params, ts->grads, ts->exp_avg, ts->exp_avg_sq, ts->step_counter,
-                              gatres_param_count(ts->model.num_blocks, ts->model.nc), ts->lr, ts->beta1, ts->beta2,
-                              ts->eps, ts->weight_decay, ts->grad_scale, stream);
+    if (adam)        // (the Adam-only phase of the data-parallel step: keeps scratch's transposed conv weights current too)
+      return gatres_adam_step_wt(ts->params, ts->grads, ts->exp_avg, ts->exp_avg_sq, ts->step_counter,
+                                 gatres_param_count(ts->model.num_blocks, ts->model.nc), ts->lr, ts->beta1, ts->beta2,
+                                 ts->eps, ts->weight_decay, ts->grad_scale, ts->scratch + L.sc_wt, ts->model.num_blocks,
+                                 ts->model.nc, stream);
     return 0;
   }
   if (ts->phases & GATRES_PHASE_FORWARD) {

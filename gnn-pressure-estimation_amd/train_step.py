@@ -220,14 +220,14 @@ class GATResTrainer:
         g.replay()
 
     # ---- the multi-rank step: backward pieces | bucketed all-reduce | Adam, as ONE launch sequence / hipGraph ---------
-    def _backward_pieces(self, device_mask: bool, wt_valid: bool):
+    def _backward_pieces(self, device_mask: bool, wt_valid: bool, premasked: bool = False):
         """Pieces for ``dp.run_data_parallel_step``.  Fused path (gatres_small): one piece -- mask, forward, loss and the
         whole backward are a single launch whose gradient exists only after the slab reduction that ends it.  Per-op
         path (gatres_large, large graphs): forward, then one piece per ``blocks_per_bucket`` blocks in reverse order,
         each ending with the slab reduction of exactly its parameters."""
         if self.fused:
             def whole():
-                self._enqueue(PHASE_MASK | PHASE_FORWARD | PHASE_BACKWARD, device_mask, wt_valid)
+                self._enqueue((0 if premasked else PHASE_MASK) | PHASE_FORWARD | PHASE_BACKWARD, device_mask, wt_valid)
                 return 0, self.P
             return [whole]
         m = self.model
@@ -235,7 +235,7 @@ class GATResTrainer:
         for k, (b_hi, b_lo, lo, hi) in enumerate(dp.block_buckets(m.num_blocks, m.nc, self.blocks_per_bucket)):
             def piece(k=k, b_hi=b_hi, b_lo=b_lo, lo=lo, hi=hi):
                 if k == 0:
-                    self._enqueue(PHASE_MASK | PHASE_FORWARD, device_mask)
+                    self._enqueue((0 if premasked else PHASE_MASK) | PHASE_FORWARD, device_mask)
                 flags = PART_REDUCE | (PART_FIRST if b_hi == m.num_blocks else 0) | (PART_LAST if b_lo == 0 else 0)
                 _native.check(self.lib.gatres_model_backward_per_op_part(
                     m._cmodel_ref(), self.plan.ref(), m.flat_parameters.data_ptr(), self.x.data_ptr(),
@@ -246,11 +246,16 @@ class GATResTrainer:
             pieces.append(piece)
         return pieces
 
-    def _run_split(self, device_mask: bool) -> None:
-        wt_valid = False         # (the stand-alone Adam launch does not refresh scratch's transposed weights)
-        self._replay(self._graph_key("split", device_mask, wt_valid),
-                     lambda: dp.run_data_parallel_step(self._backward_pieces(device_mask, wt_valid), self.reducer,
-                                                       lambda: self._enqueue(PHASE_ADAM, device_mask)))
+    def _run_split(self, device_mask: bool, premasked: bool = False) -> None:
+        # (fused path: the Adam-only phase refreshes scratch's transposed conv weights like the fused Adam pass does)
+        wt_valid = self.fused and self._wt_current()
+        try:
+            self._replay(self._graph_key("split-premasked" if premasked else "split", device_mask, wt_valid),
+                         lambda: dp.run_data_parallel_step(self._backward_pieces(device_mask, wt_valid, premasked), self.reducer,
+                                                           lambda: self._enqueue(PHASE_ADAM, device_mask)), wt_valid)
+        finally:
+            if self.fused:
+                self._wt_sig = self._param_signature()
 
     # ------------------------------------------------------------------------------------------
     def load_batch(self, x: torch.Tensor, y: torch.Tensor, mask: Optional[torch.Tensor] = None) -> None:
@@ -308,10 +313,10 @@ class GATResTrainer:
             self._run_split(device_mask)
 
     def _stage_with_mask(self, x: torch.Tensor, y: torch.Tensor) -> bool:
-        """Device-resident batch + device mask on the single-rank path: the copy into the static buffers rides on the mask
+        """Device-resident batch + device mask: the copy into the static buffers rides on the mask
         sampler's launch (``gatres_stage_batch_mask``) -- one small kernel and one kernel boundary less per step than
         ``load_batch`` followed by the sampler.  Returns False when the batch has to go through ``load_batch``."""
-        if self.split or self.node_ptr is None or os.environ.get("GATRES_NO_STAGE_MASK"):
+        if self.node_ptr is None or os.environ.get("GATRES_NO_STAGE_MASK"):
             return False
         n = self.x.numel()
         for t in (x, y):
@@ -328,8 +333,8 @@ class GATResTrainer:
         """One step on the snapshots ``rows`` (device int64 ``[num_graphs]``) of the device-resident matrix ``data``
         ``[S, N_g]`` (a ``SnapshotStore``): the batch is collated INSIDE the mask sampler's launch
         (``gatres_stage_rows_mask``) -- no ``index_select``, no copy.  Returns False (nothing done) when this trainer
-        cannot take the path (multi-rank split step, no per-graph node counts, switched off)."""
-        if self.split or self.node_ptr is None or os.environ.get("GATRES_NO_STAGE_MASK"):
+        cannot take the path (no per-graph node counts, switched off)."""
+        if self.node_ptr is None or os.environ.get("GATRES_NO_STAGE_MASK"):
             return False
         npg = self.N // max(self.num_graphs, 1)
         if not (data.is_cuda and data.device == self.x.device and data.dtype == torch.float32 and data.dim() == 2
@@ -340,13 +345,19 @@ class GATResTrainer:
             data.data_ptr(), rows.data_ptr(), npg, self.x.data_ptr(), None if self.targets_are_inputs else self.y.data_ptr(),
             self.node_ptr.data_ptr(), self.num_graphs, self.mask_rate, self.seed, self.step_counter.data_ptr(),
             self.mask.data_ptr(), _native.current_stream(self.device)), "gatres_stage_rows_mask")
-        self._run(PHASE_FORWARD | PHASE_BACKWARD | PHASE_ADAM, True)
+        if self.split:
+            self._run_split(True, premasked=True)
+        else:
+            self._run(PHASE_FORWARD | PHASE_BACKWARD | PHASE_ADAM, True)
         return True
 
     def step(self, x: torch.Tensor, y: torch.Tensor, mask: Optional[torch.Tensor] = None) -> torch.Tensor:
         """Reference-shaped call: one iteration of train.py:159-190.  Returns the (device) loss tensor."""
-        if mask is None and self._stage_with_mask(x, y):
-            self._run(PHASE_FORWARD | PHASE_BACKWARD | PHASE_ADAM, True)        # (the mask of this step is in place)
+        if mask is None and self._stage_with_mask(x, y):                        # (the mask of this step is in place)
+            if self.split:
+                self._run_split(True, premasked=True)
+            else:
+                self._run(PHASE_FORWARD | PHASE_BACKWARD | PHASE_ADAM, True)
             return self.loss
         self.load_batch(x, y, mask)
         self.run_step(device_mask=mask is None)
