@@ -45,6 +45,8 @@ static inline int num_slabs_for(int64_t P, int64_t N) {
   if (cap < 16) cap = 16;
   int64_t s = (N + 63) / 64;
   if (s > cap) s = cap;
+  // whole rounds of the 256 CUs: 305 slabs (gatres_large) ran as one full round + a 49-workgroup tail that took as long
+  if (s > 256) s = (s / 256) * 256;
   if (s < 1) s = 1;
   return (int)s;
 }
