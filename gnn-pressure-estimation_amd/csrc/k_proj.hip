@@ -535,9 +535,18 @@ __global__ __launch_bounds__(256) void dw_bf16_kernel(const gatres_bf16* __restr
                                                       int nodes_per_slab) {
   constexpr int NCT = HC / 16, NKT = K / 16, TOT = NCT * NKT, TPW = TOT / 4;      // tiles per wave (4 waves)
   constexpr int KTW = NKT < TPW ? NKT : TPW, CTW = TPW / KTW;                     // a wave's block of tiles
-  constexpr int ROW = 40;                                                         // bf16 per LDS row: 32 nodes + 8 pad
-  __shared__ __attribute__((aligned(16))) gatres_bf16 gt[HC * ROW];
-  __shared__ __attribute__((aligned(16))) gatres_bf16 xt[K * ROW];
+  // The reduction runs over NODES, the row index of both operands, so an MFMA lane needs 8 consecutive nodes of ONE
+  // feature.  The 32-node chunk stays node-major in LDS, exactly as it lies in HBM (16-byte stores, no conflicts), and
+  // the operands come out of it through gfx950's transposing LDS read (ds_read_b64_tr_b16: per 16-lane group a block of
+  // 4 rows x 16 columns, delivered column-major): two reads per fragment.  (Before: the chunk was transposed on the way
+  // IN, 2 bytes at a time -- with feature rows a multiple of 32 dwords apart all 32 lanes of a store hit one bank.)
+  // Rows are padded by 16 elements: the four rows of a block fall into disjoint bank windows.
+  constexpr int GP = HC + 16, XP = K + 16;
+  constexpr int GLC = (32 * (HC / 8) + 255) / 256, XLC = (32 * (K / 8) + 255) / 256;   // 16-byte loads per thread and chunk
+  typedef short s16x4 __attribute__((ext_vector_type(4)));
+  typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+  __shared__ __attribute__((aligned(16))) gatres_bf16 gimg[32 * GP];
+  __shared__ __attribute__((aligned(16))) gatres_bf16 ximg[32 * XP];
   const int s = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int i = lane & 15, q = lane >> 4;
   const int nbeg = s * nodes_per_slab, nend = min(N, nbeg + nodes_per_slab);
@@ -548,34 +557,54 @@ __global__ __launch_bounds__(256) void dw_bf16_kernel(const gatres_bf16* __restr
 #pragma unroll
     for (int b = 0; b < KTW; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  for (int n0 = nbeg; n0 < nend; n0 += 32) {
-    // stage the chunk transposed: a thread moves 8 consecutive features of one node per step
-    for (int p = tid; p < 32 * (HC / 8); p += 256) {
-      const int nl = p / (HC / 8), c8 = (p % (HC / 8)) * 8;
-      const int n = n0 + nl;
-      uint4 v = make_uint4(0u, 0u, 0u, 0u);
-      if (n < nend) v = *reinterpret_cast<const uint4*>(G + (size_t)n * HC + c8);
-      const unsigned w[4] = {v.x, v.y, v.z, v.w};
-      unsigned short* d = reinterpret_cast<unsigned short*>(gt) + c8 * ROW + nl;
+  uint4 gv[GLC], xv[XLC];
+  auto fetch = [&](int n0) {                         // the chunk's 16-byte pieces of this thread: registers
 #pragma unroll
-      for (int j = 0; j < 4; ++j) { d[(2 * j) * ROW] = (unsigned short)(w[j] & 0xffffu); d[(2 * j + 1) * ROW] = (unsigned short)(w[j] >> 16); }
+    for (int u = 0; u < GLC; ++u) {
+      const int p = tid + 256 * u, nl = p / (HC / 8), c8 = (p % (HC / 8)) * 8, n = n0 + nl;
+      gv[u] = (p < 32 * (HC / 8) && n < nend) ? *reinterpret_cast<const uint4*>(G + (size_t)n * HC + c8) : make_uint4(0u, 0u, 0u, 0u);
     }
-    for (int p = tid; p < 32 * (K / 8); p += 256) {
-      const int nl = p / (K / 8), k8 = (p % (K / 8)) * 8;
-      const int n = n0 + nl;
-      uint4 v = make_uint4(0u, 0u, 0u, 0u);
-      if (n < nend) v = *reinterpret_cast<const uint4*>(X + (size_t)n * K + k8);
-      const unsigned w[4] = {v.x, v.y, v.z, v.w};
-      unsigned short* d = reinterpret_cast<unsigned short*>(xt) + k8 * ROW + nl;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) { d[(2 * j) * ROW] = (unsigned short)(w[j] & 0xffffu); d[(2 * j + 1) * ROW] = (unsigned short)(w[j] >> 16); }
+    for (int u = 0; u < XLC; ++u) {
+      const int p = tid + 256 * u, nl = p / (K / 8), k8 = (p % (K / 8)) * 8, n = n0 + nl;
+      xv[u] = (p < 32 * (K / 8) && n < nend) ? *reinterpret_cast<const uint4*>(X + (size_t)n * K + k8) : make_uint4(0u, 0u, 0u, 0u);
+    }
+  };
+  // this lane's block address inside a 16-column tile: lane 4qq + pp of the group supplies row qq, columns 4pp .. 4pp + 3
+  const int qq = i >> 2, pp = i & 3;
+  gatres_bf16* gbase = gimg + (8 * q + qq) * GP + ct0 * 16 + 4 * pp;
+  gatres_bf16* xbase = ximg + (8 * q + qq) * XP + kt0 * 16 + 4 * pp;
+  if (nbeg < nend) fetch(nbeg);
+  for (int n0 = nbeg; n0 < nend; n0 += 32) {
+#pragma unroll
+    for (int u = 0; u < GLC; ++u) {
+      const int p = tid + 256 * u, nl = p / (HC / 8), c8 = (p % (HC / 8)) * 8;
+      if (p < 32 * (HC / 8)) *reinterpret_cast<uint4*>(gimg + nl * GP + c8) = gv[u];
+    }
+#pragma unroll
+    for (int u = 0; u < XLC; ++u) {
+      const int p = tid + 256 * u, nl = p / (K / 8), k8 = (p % (K / 8)) * 8;
+      if (p < 32 * (K / 8)) *reinterpret_cast<uint4*>(ximg + nl * XP + k8) = xv[u];
     }
     __syncthreads();
+    if (n0 + 32 < nend) fetch(n0 + 32);              // the next chunk's loads fly during this chunk's matrix work
     bf16x8 af[CTW], bfr[KTW];
 #pragma unroll
-    for (int a = 0; a < CTW; ++a) af[a] = *reinterpret_cast<const bf16x8*>(gt + ((ct0 + a) * 16 + i) * ROW + q * 8);
+    for (int a = 0; a < CTW; ++a) {                  // nodes 8q .. 8q + 3 | 8q + 4 .. 8q + 7 of feature (ct0 + a) * 16 + i
+      const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(gbase + a * 16));
+      const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(gbase + 4 * GP + a * 16));
+      typedef short s16x8 __attribute__((ext_vector_type(8)));
+      const s16x8 both = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+      af[a] = __builtin_bit_cast(bf16x8, both);
+    }
 #pragma unroll
-    for (int b = 0; b < KTW; ++b) bfr[b] = *reinterpret_cast<const bf16x8*>(xt + ((kt0 + b) * 16 + i) * ROW + q * 8);
+    for (int b = 0; b < KTW; ++b) {
+      const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(xbase + b * 16));
+      const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(xbase + 4 * XP + b * 16));
+      typedef short s16x8 __attribute__((ext_vector_type(8)));
+      const s16x8 both = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+      bfr[b] = __builtin_bit_cast(bf16x8, both);
+    }
 #pragma unroll
     for (int a = 0; a < CTW; ++a)
 #pragma unroll
@@ -591,7 +620,6 @@ __global__ __launch_bounds__(256) void dw_bf16_kernel(const gatres_bf16* __restr
       for (int r = 0; r < 4; ++r)
         out[(size_t)((ct0 + a) * 16 + 4 * q + r) * K + (kt0 + b) * 16 + i] = acc[a][b][r];
 }
-
 template <int HC, int K>
 int launch_dw_bf16(const gatres_bf16* G, const gatres_bf16* X, float* slab, int num_slabs, long long stride, int N,
                    hipStream_t st) {
