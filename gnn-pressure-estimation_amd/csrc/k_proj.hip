@@ -157,9 +157,25 @@ __global__ __launch_bounds__(256) void proj_lds_kernel(const float* __restrict__
                                                        const float* __restrict__ relu_ref, int rows_per_wg) {
   constexpr int KQ = K / 4, NT = M / 16, SC = 4, KP = K + 4;        // K, M multiples of 16 here
   __shared__ __attribute__((aligned(16))) float wl[M * KP + 2 * M];
-  for (int idx = threadIdx.x; idx < M * (K / 4); idx += 256) {
-    const int m = idx / (K / 4), k4 = (idx % (K / 4)) * 4;
-    st4(wl + m * KP + k4, ld4(Wm + (size_t)m * K + k4));
+  {
+    // eight 16-byte loads in flight per thread, then their LDS stores (one load-store pair per trip made the staging a chain
+    // of M * K / 1024 dependent L2 round trips per workgroup)
+    constexpr int CH = M * (K / 4), PER = (CH + 255) / 256, UB = PER < 8 ? PER : 8;
+    for (int b0 = 0; b0 < PER; b0 += UB) {
+      float4 v[UB];
+#pragma unroll
+      for (int u = 0; u < UB; ++u) {
+        const int idx = threadIdx.x + 256 * (b0 + u);
+        const int m = idx / (K / 4), k4 = (idx % (K / 4)) * 4;
+        v[u] = (b0 + u < PER && idx < CH) ? ld4(Wm + (size_t)m * K + k4) : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+#pragma unroll
+      for (int u = 0; u < UB; ++u) {
+        const int idx = threadIdx.x + 256 * (b0 + u);
+        const int m = idx / (K / 4), k4 = (idx % (K / 4)) * 4;
+        if (b0 + u < PER && idx < CH) st4(wl + m * KP + k4, v[u]);
+      }
+    }
   }
   if constexpr (EPI == EPI_ATT) {
     for (int idx = threadIdx.x; idx < 2 * (M / 4); idx += 256) {
@@ -376,11 +392,27 @@ __global__ __launch_bounds__(256) void proj_bf16_kernel(const gatres_bf16* __res
   float* attl = reinterpret_cast<float*>(smem + (size_t)M * KP * 2);
   // LDS row 16*t + i holds W row (i>>2)*MQ + 4*t + (i&3): the permutation is applied while staging, so the 16 lanes of an
   // A-operand read touch 16 CONSECUTIVE LDS rows (stride K*2 + 16 bytes: conflict-free)
-  for (int idx = threadIdx.x; idx < M * (K / 8); idx += 256) {
-    const int l = idx / (K / 8), k8 = (idx % (K / 8)) * 8;
-    const int t = l >> 4, ii = l & 15;
-    const int m = (ii >> 2) * MQ + 4 * t + (ii & 3);
-    *reinterpret_cast<uint4*>(wl + l * KP + k8) = *reinterpret_cast<const uint4*>(Wm + (size_t)m * K + k8);
+  {
+    // eight 16-byte loads in flight per thread, then their LDS stores: written as one load-store pair per trip, the staging
+    // was M * K / 2048 dependent L2 round trips per workgroup (16 for gatres_large), most of a two-tile workgroup's life
+    constexpr int CH = M * (K / 8), PER = (CH + 255) / 256, UB = PER < 8 ? PER : 8;
+    for (int b0 = 0; b0 < PER; b0 += UB) {
+      uint4 v[UB];
+#pragma unroll
+      for (int u = 0; u < UB; ++u) {
+        const int idx = threadIdx.x + 256 * (b0 + u);
+        const int l = idx / (K / 8), k8 = (idx % (K / 8)) * 8;
+        const int t = l >> 4, ii = l & 15;
+        const int m = (ii >> 2) * MQ + 4 * t + (ii & 3);
+        v[u] = (b0 + u < PER && idx < CH) ? *reinterpret_cast<const uint4*>(Wm + (size_t)m * K + k8) : make_uint4(0u, 0u, 0u, 0u);
+      }
+#pragma unroll
+      for (int u = 0; u < UB; ++u) {
+        const int idx = threadIdx.x + 256 * (b0 + u);
+        const int l = idx / (K / 8), k8 = (idx % (K / 8)) * 8;
+        if (b0 + u < PER && idx < CH) *reinterpret_cast<uint4*>(wl + l * KP + k8) = v[u];
+      }
+    }
   }
   if constexpr (EPI == EPI_ATT) {
     for (int idx = threadIdx.x; idx < 2 * (M / 4); idx += 256) {
