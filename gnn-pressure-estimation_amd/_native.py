@@ -101,6 +101,7 @@ SIGNATURES = {
     "gatres_model_forward_per_op": (C.c_int, [_MP, _GP] + [_P] * 6 + [_P]),
     "gatres_model_backward_per_op": (C.c_int, [_MP, _GP] + [_P] * 8 + [_P]),
     "gatres_model_backward_per_op_part": (C.c_int, [_MP, _GP] + [_P] * 8 + [_I32, _I32, _I32, _P]),
+    "gatres_model_reduce_grads": (C.c_int, [_MP, _GP, _P, _P, _P]),
     "gatres_fused_supported": (C.c_int, [_MP, _GP]),
     "gatres_fused_cus_per_segment": (C.c_int, [_MP, _GP]),
     "gatres_fused_window_kernel": (C.c_int, [_MP, _GP]),

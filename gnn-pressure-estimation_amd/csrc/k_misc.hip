@@ -259,6 +259,35 @@ __global__ __launch_bounds__(256) void reduce_slabs_kernel(const float* __restri
   out[idx] = acc;
 }
 
+// The same for a range [lo_abs, lo_abs + count) of the flat parameter vector whose GATConv weight matrices only occupy the
+// first w_slabs rows (the per-op driver asks the bf16 dW kernel for fewer, two-dimensional partials: k_proj.hip
+// dw2d_bf16_kernel); every other parameter is summed over all num_slabs rows.  slabs / out point at the range's start.
+__global__ __launch_bounds__(256) void reduce_slabs_regions_kernel(const float* __restrict__ slabs, int num_slabs, int w_slabs,
+                                                                   long long stride, long long lo_abs, long long count,
+                                                                   int nc, int nb, float* __restrict__ out) {
+  const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= count) return;
+  int rows = num_slabs;
+  {
+    const long long per = 2LL * nc * nc, bstride = 9LL * nc + 2 * per, off = lo_abs + idx - 2LL * nc;
+    if (off >= 0 && off < (long long)nb * bstride) {
+      const long long o = off % bstride;
+      if ((o >= 6LL * nc && o < 6LL * nc + per) || o >= 9LL * nc + per) rows = w_slabs;
+    }
+  }
+  float acc = 0.f;
+  int s = 0;
+  for (; s + 8 <= rows; s += 8) {                       // 8 loads in flight, summed in slab order
+    float v8[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v8[u] = slabs[(size_t)(s + u) * stride + idx];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) acc += v8[u];
+  }
+  for (; s < rows; ++s) acc += slabs[(size_t)s * stride + idx];
+  out[idx] = acc;
+}
+
 // wt block layout: [W1^T : nc x 2nc][W2^T : 2nc x nc]
 __global__ __launch_bounds__(256) void transpose_conv_weights_kernel(const float* __restrict__ params,
                                                                      float* __restrict__ wt, int num_blocks,
@@ -624,6 +653,17 @@ extern "C" int gatres_reduce_slabs(const float* slabs, int32_t num_slabs, int64_
   if (!slabs || !out || num_slabs <= 0 || count <= 0 || slab_stride < count) return GATRES_E_BADARG;
   hipLaunchKernelGGL(reduce_slabs_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, gatres_stream(stream),
                      slabs, num_slabs, (long long)slab_stride, (long long)count, out);
+  return gatres_launch_status();
+}
+
+// (internal: model_driver.hip)
+extern "C" __attribute__((visibility("hidden"))) int gatres_reduce_slabs_regions(const float* slabs, int32_t num_slabs,
+                                                                                 int32_t w_slabs, int64_t slab_stride,
+                                                                                 int64_t lo_abs, int64_t count, int32_t nc,
+                                                                                 int32_t nb, float* out, void* stream) {
+  if (!slabs || !out || num_slabs <= 0 || w_slabs <= 0 || w_slabs > num_slabs || count <= 0) return GATRES_E_BADARG;
+  hipLaunchKernelGGL(reduce_slabs_regions_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, gatres_stream(stream),
+                     slabs, num_slabs, w_slabs, (long long)slab_stride, (long long)lo_abs, (long long)count, nc, nb, out);
   return gatres_launch_status();
 }
 

@@ -652,9 +652,88 @@ __global__ __launch_bounds__(256) void dw_bf16_kernel(const gatres_bf16* __restr
       for (int r = 0; r < 4; ++r)
         out[(size_t)((ct0 + a) * 16 + 4 * q + r) * K + (kt0 + b) * 16 + i] = acc[a][b][r];
 }
+// The same product cut in TWO dimensions: workgroup (rg, ob) forms the 64 x 64 output block ob over the rows of row group
+// rg and writes it into slab row rg.  With R row groups x (HC / 64)(K / 64) blocks filling the chip, a dW call writes R
+// partial matrices instead of one per workgroup, and the final reduction reads R rows: for gatres_large (25 x 128, C-Town
+// bs 128) the 256-row form wrote 33 MB per call and the reduction read 1.7 GB per step -- 1.6 of a 9-ms step.  Every
+// operand row is read by (K / 64) resp. (HC / 64) workgroups, which run at the same time: L2 absorbs the re-reads.
+template <int HC, int K>
+__global__ __launch_bounds__(256) void dw2d_bf16_kernel(const gatres_bf16* __restrict__ G, const gatres_bf16* __restrict__ X,
+                                                        float* __restrict__ slab, long long slab_stride, int N,
+                                                        int nodes_per_group) {
+  constexpr int OBK = K / 64, OB = (HC / 64) * OBK, CH = 64;          // 64-node chunks: two MFMA k steps
+  constexpr int RP = 64 + 16;                                         // LDS row: 64 features + pad (see dw_bf16_kernel)
+  typedef short s16x4 __attribute__((ext_vector_type(4)));
+  typedef short s16x8 __attribute__((ext_vector_type(8)));
+  typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+  __shared__ __attribute__((aligned(16))) gatres_bf16 gimg[CH * RP];
+  __shared__ __attribute__((aligned(16))) gatres_bf16 ximg[CH * RP];
+  const int rg = blockIdx.x / OB, ob = blockIdx.x % OB, cb = ob / OBK, kb = ob % OBK;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int i = lane & 15, q = lane >> 4, qq = i >> 2, pp = i & 3;
+  const int nbeg = rg * nodes_per_group, nend = min(N, nbeg + nodes_per_group);
+  const gatres_bf16* Gc = G + cb * 64;
+  const gatres_bf16* Xc = X + kb * 64;
+  f32x4 acc[4];                                                       // c tile `wave` of the block x its four k tiles
+#pragma unroll
+  for (int b = 0; b < 4; ++b) acc[b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  uint4 gv[2], xv[2];                                                 // 64 nodes x 8 pieces of 16 bytes = 2 per thread and table
+  auto fetch = [&](int n0) {
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int p = tid + 256 * u, nl = p >> 3, c8 = (p & 7) * 8, n = n0 + nl;
+      gv[u] = n < nend ? *reinterpret_cast<const uint4*>(Gc + (size_t)n * HC + c8) : make_uint4(0u, 0u, 0u, 0u);
+      xv[u] = n < nend ? *reinterpret_cast<const uint4*>(Xc + (size_t)n * K + c8) : make_uint4(0u, 0u, 0u, 0u);
+    }
+  };
+  gatres_bf16* gbase = gimg + (8 * q + qq) * RP + wave * 16 + 4 * pp;
+  gatres_bf16* xbase = ximg + (8 * q + qq) * RP + 4 * pp;
+  if (nbeg < nend) fetch(nbeg);
+  for (int n0 = nbeg; n0 < nend; n0 += CH) {
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int p = tid + 256 * u, nl = p >> 3, c8 = (p & 7) * 8;
+      *reinterpret_cast<uint4*>(gimg + nl * RP + c8) = gv[u];
+      *reinterpret_cast<uint4*>(ximg + nl * RP + c8) = xv[u];
+    }
+    __syncthreads();
+    if (n0 + CH < nend) fetch(n0 + CH);
+#pragma unroll
+    for (int ks = 0; ks < CH / 32; ++ks) {
+      const s16x4 alo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(gbase + (32 * ks) * RP));
+      const s16x4 ahi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(gbase + (32 * ks + 4) * RP));
+      const bf16x8 af = __builtin_bit_cast(bf16x8, (s16x8)__builtin_shufflevector(alo, ahi, 0, 1, 2, 3, 4, 5, 6, 7));
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        const s16x4 blo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(xbase + (32 * ks) * RP + b * 16));
+        const s16x4 bhi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(xbase + (32 * ks + 4) * RP + b * 16));
+        const bf16x8 bf = __builtin_bit_cast(bf16x8, (s16x8)__builtin_shufflevector(blo, bhi, 0, 1, 2, 3, 4, 5, 6, 7));
+        acc[b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bf, acc[b], 0, 0, 0);
+      }
+    }
+    __syncthreads();
+  }
+  float* out = slab + (size_t)rg * slab_stride;
+#pragma unroll
+  for (int b = 0; b < 4; ++b)
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      out[(size_t)(cb * 64 + wave * 16 + 4 * q + r) * K + kb * 64 + b * 16 + i] = acc[b][r];
+}
+
 template <int HC, int K>
 int launch_dw_bf16(const gatres_bf16* G, const gatres_bf16* X, float* slab, int num_slabs, long long stride, int N,
                    hipStream_t st) {
+  if constexpr (HC % 64 == 0 && K % 64 == 0) {
+    // few slab rows asked for (the per-op driver does for wide models): rows x output blocks instead of rows only
+    constexpr int OB = (HC / 64) * (K / 64);
+    if (num_slabs * OB <= 1024 && num_slabs <= 128 && !getenv("GATRES_DW_1D")) {
+      int npg = (N + num_slabs - 1) / num_slabs;
+      npg = (npg + 3) & ~3;
+      hipLaunchKernelGGL((dw2d_bf16_kernel<HC, K>), dim3(num_slabs * OB), dim3(256), 0, st, G, X, slab, stride, N, npg);
+      return gatres_launch_status();
+    }
+  }
   if constexpr (HC % 16 == 0 && K % 16 == 0 && (HC / 16) * (K / 16) >= 4 && ((HC / 16) * (K / 16)) % 4 == 0 &&
                 (HC + K) * 80 <= 160 * 1024) {
     int nps = (N + num_slabs - 1) / num_slabs;

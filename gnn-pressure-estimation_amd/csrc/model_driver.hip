@@ -130,6 +130,17 @@ extern "C" int gatres_model_backward(const gatres_model_t* m, const gatres_graph
   return gatres_model_backward_per_op(m, g, params, x, mask, g_out, saved, scratch, grads, g_x, stream);
 }
 
+extern "C" __attribute__((visibility("hidden"))) int gatres_reduce_slabs_regions(const float* slabs, int32_t num_slabs,
+                                                                                 int32_t w_slabs, int64_t slab_stride,
+                                                                                 int64_t lo_abs, int64_t count, int32_t nc,
+                                                                                 int32_t nb, float* out, void* stream);
+// Slab rows the GATConv weight gradients occupy: the bf16 dW kernel of wide models forms two-dimensional partials (64 rows of
+// 64 x 64 blocks instead of one whole [2nc, nc] matrix per workgroup): 4x less slab traffic in dW and in the final sum
+static int dw_slab_rows(const gatres_model_t* m, const Layout& L) {
+  if (m->act_dtype == GATRES_DTYPE_BF16 && L.nc == 128 && L.num_slabs > 64 && !getenv("GATRES_DW_1D")) return 64;
+  return L.num_slabs;
+}
+
 extern "C" int gatres_model_backward_per_op(const gatres_model_t* m, const gatres_graph_t* g, const float* params,
                                             const float* x, const uint8_t* mask, const float* g_out,
                                             const float* saved, float* scratch, float* grads, float* g_x,
@@ -137,9 +148,16 @@ extern "C" int gatres_model_backward_per_op(const gatres_model_t* m, const gatre
   if (!m) return GATRES_E_BADARG;
   RC(gatres_model_backward_per_op_part(m, g, params, x, mask, g_out, saved, scratch, grads, g_x, m->num_blocks, 0,
                                        GATRES_PART_FIRST | GATRES_PART_LAST, stream));
+  return gatres_model_reduce_grads(m, g, scratch, grads, stream);
+}
+
+extern "C" int gatres_model_reduce_grads(const gatres_model_t* m, const gatres_graph_t* g, float* scratch, float* grads,
+                                         void* stream) {
+  if (!m || !g || !scratch || !grads) return GATRES_E_BADARG;
   Layout L;
   if (!make_layout_g(m, g, &L)) return GATRES_E_UNSUPPORTED;
-  return gatres_reduce_slabs(scratch + L.sc_slabs, L.num_slabs, L.slab_stride, L.P, grads, stream);
+  return gatres_reduce_slabs_regions(scratch + L.sc_slabs, L.num_slabs, dw_slab_rows(m, L), L.slab_stride, 0, L.P, L.nc, L.nb,
+                                     grads, stream);
 }
 
 // One piece of the per-op backward: [lin1 backward] blocks b_hi-1 .. b_lo [lin0 backward].  With GATRES_PART_REDUCE the
@@ -155,7 +173,7 @@ extern "C" int gatres_model_backward_per_op_part(const gatres_model_t* m, const 
   if (!make_layout_g(m, g, &L)) return GATRES_E_UNSUPPORTED;
   const bool first = flags & GATRES_PART_FIRST, last = flags & GATRES_PART_LAST;
   if (b_lo < 0 || b_hi > L.nb || b_lo > b_hi || (first && b_hi != L.nb) || (last && b_lo != 0)) return GATRES_E_BADARG;
-  const int N = g->num_nodes, nc = L.nc, S = L.num_slabs, dt = m->act_dtype;
+  const int N = g->num_nodes, nc = L.nc, S = L.num_slabs, dt = m->act_dtype, Sw = dw_slab_rows(m, L);
   if (dt != GATRES_DTYPE_F32 && (dt != GATRES_DTYPE_BF16 || nc < 32)) return GATRES_E_UNSUPPORTED;
   const int64_t st = L.slab_stride, w = 2LL * nc * nc;
   // g_pre ping-pongs between two buffers, one swap per block: where it stands depends only on the blocks done so far
@@ -208,7 +226,7 @@ extern "C" int gatres_model_backward_per_op_part(const gatres_model_t* m, const 
                                       stream));
     RC(gatres_t_conv_param_grads(base + L.s_h2, gas, gad, gy2, sb + L.c2_as, sb + L.c2_ad, sb + L.c2_b, S, st, N, 1, nc,
                                  dt, stream));
-    RC(gatres_t_proj_bwd_dw(gh, base + L.s_o1, sb + L.c2_W, S, st, N, 2 * nc, nc, dt, stream));
+    RC(gatres_t_proj_bwd_dw(gh, base + L.s_o1, sb + L.c2_W, Sw, st, N, 2 * nc, nc, dt, stream));
     RC(gatres_t_proj_bwd_dx(gh, wt2, nullptr, base + L.s_o1, go1, N, 2 * nc, nc, dt, stream));   // ReLU mask of conv1
     // conv1 (H = 2, C = nc, K = nc)
     RC(gatres_t_gat_aggregate_bwd_dst(g, go1, base + L.s_h1, base + L.s_al1, base + L.s_as1, base + L.s_ad1, ge, gad, 2,
@@ -217,7 +235,7 @@ extern "C" int gatres_model_backward_per_op_part(const gatres_model_t* m, const 
                                       stream));
     RC(gatres_t_conv_param_grads(base + L.s_h1, gas, gad, go1, sb + L.c1_as, sb + L.c1_ad, sb + L.c1_b, S, st, N, 2, nc,
                                  dt, stream));
-    RC(gatres_t_proj_bwd_dw(gh, base + L.s_xin, sb + L.c1_W, S, st, N, nc, 2 * nc, dt, stream));
+    RC(gatres_t_proj_bwd_dw(gh, base + L.s_xin, sb + L.c1_W, Sw, st, N, nc, 2 * nc, dt, stream));
     // d/d xin = conv1 path + residual; masked by the previous block's ReLU (block 0's input is lin0, no ReLU)
     RC(gatres_t_proj_bwd_dx(gh, wt1, gp_cur, b > 0 ? base + L.s_xin : nullptr, gp_nxt, N, nc, 2 * nc, dt, stream));
     float* t = gp_cur; gp_cur = gp_nxt; gp_nxt = t;
@@ -232,7 +250,7 @@ extern "C" int gatres_model_backward_per_op_part(const gatres_model_t* m, const 
   if (flags & GATRES_PART_REDUCE) {
     const int64_t lo = last ? 0 : L.p_block0 + (int64_t)b_lo * L.p_block_stride;
     const int64_t hi = first ? L.P : L.p_block0 + (int64_t)b_hi * L.p_block_stride;
-    if (hi > lo) RC(gatres_reduce_slabs(slabs + lo, S, st, hi - lo, grads + lo, stream));
+    if (hi > lo) RC(gatres_reduce_slabs_regions(slabs + lo, S, Sw, st, lo, hi - lo, nc, L.nb, grads + lo, stream));
   }
   return 0;
 }

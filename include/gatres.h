@@ -340,8 +340,10 @@ int gatres_model_backward_per_op(const gatres_model_t* m, const gatres_graph_t* 
  * come with b_hi == num_blocks, LAST with b_lo == 0; pieces are issued in that order on one stream.  With REDUCE the
  * piece ends by summing its slab partials into grads[lo, hi), lo = LAST ? 0 : 2nc + b_lo*(9nc + 4nc^2),
  * hi = FIRST ? P : 2nc + b_hi*(9nc + 4nc^2) -- final values, so a data-parallel caller can start the all-reduce of that
- * range while the next piece runs (gradient buckets in reverse block order).  Without REDUCE nothing is summed (the
- * caller runs gatres_reduce_slabs over the whole vector after the LAST piece, as gatres_model_backward_per_op does). */
+ * range while the next piece runs (gradient buckets in reverse block order).  Without REDUCE nothing is summed and the
+ * slab partials stay in scratch in a layout private to the engine (wide bf16 models keep fewer rows for the weight
+ * matrices than for the other parameters): gatres_model_reduce_grads sums them after the LAST piece, as
+ * gatres_model_backward_per_op does. */
 #define GATRES_PART_FIRST  1
 #define GATRES_PART_LAST   2
 #define GATRES_PART_REDUCE 4
@@ -349,6 +351,9 @@ int gatres_model_backward_per_op_part(const gatres_model_t* m, const gatres_grap
                                       const float* x, const uint8_t* mask, const float* g_out, const float* saved,
                                       float* scratch, float* grads, float* g_x, int32_t b_hi, int32_t b_lo,
                                       int32_t flags, void* stream);
+
+/* grads[0, P) = the sum of the per-op backward's slab partials in scratch (fixed order, bitwise reproducible). */
+int gatres_model_reduce_grads(const gatres_model_t* m, const gatres_graph_t* g, float* scratch, float* grads, void* stream);
 
 /* --------------------------------------------------------------------------------------------------------
  * Fused per-snapshot path (k_fused.hip): ONE launch carries every segment through the selected phases --
