@@ -520,10 +520,14 @@ int launch_proj_bf16(const gatres_bf16* X, const gatres_bf16* Wm, gatres_bf16* O
       attr_set = true;
     }
     // persistent workgroups: W staging must amortise over many 16-row tiles, and small batches still want every CU
+    // (at most one workgroup per CU: 388 workgroups of 128 rows -- two on some CUs, one on others -- ran 3.5 % of a
+    //  gatres_large step slower than 194 of 256 rows)
     int grid = (N + 63) / 64;
-    if (grid > 512) grid = 512;
+    if (grid > 256) grid = 256;
     int rows = (N + grid - 1) / grid;
     rows = (rows + 63) & ~63;
+    if (const char* e = getenv("GATRES_PROJ_ROWS")) rows = (atoi(e) + 63) & ~63;      // (tuning experiments)
+    if (rows < 64) rows = 64;
     hipLaunchKernelGGL((proj_bf16_kernel<K, M, H, EPI>), dim3((N + rows - 1) / rows), dim3(256), lds, st, X, Wm, OUT, N,
                        att_src, att_dst, a_src, a_dst, resid, relu_ref, rows);
     return gatres_launch_status();

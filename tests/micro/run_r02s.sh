@@ -1,10 +1,7 @@
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/kt -o kt -- python3 bench.py --model gatres_large --batch-size 128 --steps 10 --warmup 3 --dtype bf16 --no-cpu-baseline --no-roofline > gpurun_out/kt.log 2>&1
-python3 tests/micro/summarize_prof.py stats gpurun_out/kt gpurun_out/large_bf16_kernel_stats.csv
-python3 - <<'PY'
-import csv
-rows=list(csv.reader(open('gpurun_out/large_bf16_kernel_stats.csv')))
-for r in rows[1:]:
-    print(f"{r[0][:90]:90s} calls {int(r[1]):5d} avg {float(r[3])/1000:8.1f} us  {float(r[4]):5.1f}%")
-PY
-rm -rf gpurun_out/kt
+show='import sys,json; d=json.loads(sys.stdin.read()); print(round(d["value"],1), round(d["ms_per_step"],4))'
+echo LARGE_bf16; timeout 600 python bench.py --no-cpu-baseline --no-roofline --model gatres_large --batch-size 128 --steps 20 --warmup 5 --dtype bf16 2>/dev/null | tail -n 1 | tee gpurun_out/large_bf16.json | python -c "$show"
+echo LARGE_50k_bf16; timeout 900 python bench.py --no-cpu-baseline --no-roofline --model gatres_large --nodes 50000 --pipes 75000 --batch-size 2 --steps 10 --warmup 3 --dtype bf16 2>/dev/null | tail -n 1 | python -c "$show"
+echo LARGE_bs32_bf16; timeout 600 python bench.py --no-cpu-baseline --no-roofline --model gatres_large --batch-size 32 --steps 20 --warmup 5 --dtype bf16 2>/dev/null | tail -n 1 | python -c "$show"
+timeout 1800 python -m pytest tests -m gpu -x -q 2>&1 | grep -E "passed|failed|rror|assert" | tail -n 5
+timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -n 1
