@@ -96,3 +96,12 @@ __device__ __forceinline__ float ldval(const float* p) { return *p; }
 __device__ __forceinline__ float ldval(const gatres_bf16* p) { return (float)*p; }
 __device__ __forceinline__ void stval(float* p, float v) { *p = v; }
 __device__ __forceinline__ void stval(gatres_bf16* p, float v) { *p = (gatres_bf16)v; }
+
+// Workgroup b of an n-workgroup grid -> the block of work it takes, such that the workgroups of ONE XCD (ids b, b + 8, ...
+// under round-robin dispatch: MI355X_MICROARCH.md, Workgroup dispatch) take a CONTIGUOUS range of blocks.  Row-sorted
+// sparse kernels gather neighbour rows that lie near their own: with the identity map every XCD's L2 sees the whole table,
+// with this one an eighth of it plus a halo.  A bijection for any n; speed only, never correctness.
+__device__ __forceinline__ int gatres_xcd_block(int b, int n) {
+  const int q = n >> 3, r = n & 7, x = b & 7, j = b >> 3;
+  return x * q + (x < r ? x : r) + j;
+}

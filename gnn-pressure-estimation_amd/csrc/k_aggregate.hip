@@ -79,7 +79,7 @@ __global__ __launch_bounds__(256, 8) void gat_aggregate_fwd_kernel(
     const float* __restrict__ a_src, const float* __restrict__ a_dst, const float* __restrict__ bias,
     T* __restrict__ out, float* __restrict__ alpha, int N, RowGeom gm) {
   __shared__ __attribute__((aligned(16))) float hub_lds[4 * HUB_FLOATS_PER_WAVE];
-  const int tid = blockIdx.x * 256 + threadIdx.x;
+  const int tid = gatres_xcd_block(blockIdx.x, gridDim.x) * 256 + threadIdx.x;      // (XCD-local row ranges)
   int row = tid >> gm.lgG;
   const bool valid = row < N;                  // (every lane stays: hub rows are processed by the whole wave)
   if (!valid) row = N - 1;
@@ -225,7 +225,7 @@ __global__ __launch_bounds__(256, 7) void gat_aggregate_bwd_dst_kernel(
     const T* __restrict__ h, const float* __restrict__ alpha, const float* __restrict__ a_src,
     const float* __restrict__ a_dst, float* __restrict__ g_e, float* __restrict__ g_a_dst, int N, RowGeom gm) {
   __shared__ __attribute__((aligned(16))) float hub_lds[4 * HUB_FLOATS_PER_WAVE];
-  const int tid = blockIdx.x * 256 + threadIdx.x;
+  const int tid = gatres_xcd_block(blockIdx.x, gridDim.x) * 256 + threadIdx.x;      // (XCD-local row ranges)
   int row = tid >> gm.lgG;
   const bool valid = row < N;
   if (!valid) row = N - 1;              // keep every lane alive for the shuffles; stores are predicated
@@ -331,7 +331,7 @@ __global__ __launch_bounds__(256, 8) void gat_aggregate_bwd_src_kernel(
     const float* __restrict__ g_a_dst, const float* __restrict__ att_src, const float* __restrict__ att_dst,
     T* __restrict__ g_h, float* __restrict__ g_a_src, int N, RowGeom gm) {
   __shared__ __attribute__((aligned(16))) float hub_lds[4 * HUB_FLOATS_PER_WAVE];
-  const int tid = blockIdx.x * 256 + threadIdx.x;
+  const int tid = gatres_xcd_block(blockIdx.x, gridDim.x) * 256 + threadIdx.x;      // (XCD-local row ranges)
   int row = tid >> gm.lgG;
   const bool valid = row < N;
   if (!valid) row = N - 1;
@@ -403,7 +403,7 @@ __global__ __launch_bounds__(256, 8) void mean_residual_relu_fwd_kernel(
     const int* __restrict__ rowptr, const int* __restrict__ col, const T* __restrict__ y,
     const T* __restrict__ x0, T* __restrict__ out, int N, int C, int G, int lgG) {
   __shared__ __attribute__((aligned(16))) float hub_lds[4 * HUB_FLOATS_PER_WAVE];
-  const int tid = blockIdx.x * 256 + threadIdx.x;
+  const int tid = gatres_xcd_block(blockIdx.x, gridDim.x) * 256 + threadIdx.x;      // (XCD-local row ranges)
   int row = tid >> lgG;
   const bool valid = row < N;
   if (!valid) row = N - 1;
@@ -457,7 +457,7 @@ __global__ __launch_bounds__(256, 8) void mean_bwd_kernel(
     const int* __restrict__ m_rowptr, const int* __restrict__ mt_rowptr, const int* __restrict__ mt_dst,
     const T* __restrict__ g_pre, T* __restrict__ g_y, int N, int C, int G, int lgG) {
   __shared__ __attribute__((aligned(16))) float hub_lds[4 * HUB_FLOATS_PER_WAVE];
-  const int tid = blockIdx.x * 256 + threadIdx.x;
+  const int tid = gatres_xcd_block(blockIdx.x, gridDim.x) * 256 + threadIdx.x;      // (XCD-local row ranges)
   int row = tid >> lgG;
   const bool valid = row < N;
   if (!valid) row = N - 1;
