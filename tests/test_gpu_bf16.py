@@ -154,3 +154,25 @@ def test_bf16_relabelled_plan_and_bucketed_backward(pkg, oracle):
         res.append((tr.loss.clone(), model.flat_parameters.clone()))
     assert torch.isfinite(res[0][0]).all()
     assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+
+
+def test_bf16_weight_gradients_two_dimensional_partials(pkg, oracle, monkeypatch):
+    """Wide bf16 models on large batches: the weight-gradient kernel forms 64 row groups x 64 x 64 output blocks and the final
+    sum reads 64 slab rows for the weight matrices, all rows for everything else (gatres_model_reduce_grads).  Against the
+    one-matrix-per-workgroup form (GATRES_DW_1D=1) only the fp32 summation order differs."""
+    nb, nc, bs = 2, 128, 12                         # 4656 rows -> 72 slabs > 64: the region-aware reduction is taken
+    ei = pkg.wdn_synth.collate_edge_index(pkg.wdn_synth.make_wdn_topology(388, 430, seed=0), 388, bs).cuda()
+    y = torch.randn(388 * bs, generator=torch.Generator().manual_seed(4)).cuda()
+    mask = torch.from_numpy(pkg.wdn_synth.generate_batch_mask([388] * bs, 0.95, np.random.RandomState(1))).cuda()
+    grads = []
+    for one_d in (False, True):
+        if one_d:
+            monkeypatch.setenv("GATRES_DW_1D", "1")
+        model, _ = build(pkg, oracle, nb, nc, seed=9)
+        model.set_compute_dtype("bf16")
+        tr = pkg.GATResTrainer(model, ei, 388 * bs, nodes_per_graph=[388] * bs, use_graph=False)
+        assert pkg._native.load().gatres_num_slabs(model._cmodel_ref(), 388 * bs) > 64
+        tr.forward_backward(y, y, mask)
+        grads.append(tr.grads.clone())
+    assert torch.isfinite(grads[0]).all() and float(grads[0].abs().max()) > 0
+    assert relerr(grads[0], grads[1]) < 1e-5
