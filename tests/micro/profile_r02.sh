@@ -1,6 +1,6 @@
 # Round-2 evidence run (MI355X): everything lands under gpurun_out/r02p/, the summaries are copied into profiles/ by hand.
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-O=gpurun_out/r02r; mkdir -p $O
+O=gpurun_out/r02s_final; mkdir -p $O
 B="python3 bench.py"
 short='import sys,json; d=json.loads(sys.stdin.read()); r=d.get("roofline") or {}; sk=r.get("second_kernel"); print(round(d["value"]), "snapshots/s", round(d["ms_per_step"],4), "ms/step | dominant:", r.get("kernel","")[:40], round(r.get("avg_launch_us",0),1), "us  frac", round(r.get("frac",0),4), "| 2nd launch us:", sk and round(sk["avg_launch_us"],1), "|", d["config"]["workload"][-95:])'
 timeout 600 $B 2>$O/bench.err | tail -1 > $O/bench_n1.json; python3 -c "$short" < $O/bench_n1.json
