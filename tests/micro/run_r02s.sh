@@ -1,11 +1,8 @@
+# scratch driver of the round-2 sessions: a few bench lines + the stage profile on the GPU box (see profile_r02.sh for the
+# evidence run that fills profiles/)
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-timeout 900 python -m pytest tests/test_gpu_bf16.py -x -q 2>&1 | grep -E "passed|failed|rror|assert" | tail -n 5
-timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/kt -o kt -- python3 bench.py --model gatres_large --batch-size 128 --steps 10 --warmup 3 --no-cpu-baseline --no-roofline > gpurun_out/kt.log 2>&1
-python3 tests/micro/summarize_prof.py stats gpurun_out/kt gpurun_out/large_fp32_kernel_stats.csv
-python3 - <<'PY'
-import csv
-rows=list(csv.reader(open('gpurun_out/large_fp32_kernel_stats.csv')))
-for r in rows[1:]:
-    print(f"{r[0][:100]:100s} calls {int(r[1]):5d} avg {float(r[3])/1000:8.1f} us  {float(r[4]):5.1f}%")
-PY
-rm -rf gpurun_out/kt
+show='import sys,json; d=json.loads(sys.stdin.read()); r=d.get("roofline") or {}; sk=r.get("second_kernel"); print(round(d["value"],1), round(d["ms_per_step"],4), r.get("avg_launch_us") and round(r["avg_launch_us"],1), sk and round(sk["avg_launch_us"],1), r.get("frac") and round(r["frac"],4))'
+echo DEFAULT; timeout 300 python bench.py --no-cpu-baseline 2>/dev/null | tail -n 1 | python -c "$show"
+echo "6 + 2 consumers"; GATRES_FUSED_PREFER_CONSUMERS=1 timeout 300 python bench.py --no-cpu-baseline 2>/dev/null | tail -n 1 | python -c "$show"
+echo LARGE_bf16; timeout 600 python bench.py --no-cpu-baseline --model gatres_large --batch-size 128 --steps 20 --warmup 5 --dtype bf16 2>/dev/null | tail -n 1 | python -c "$show"
+timeout 200 python tests/stage_profile.py 2>&1 | grep -v "^B\|^bar\|^agg\|^dX\|^edge\|^soft\|^mean\|^top\|^step" | tail -n 24
