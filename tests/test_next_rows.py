@@ -22,6 +22,13 @@ def test_snapshot_store_matches_reference_collation(pkg):
     assert [n for _, _, n in st.batches(4, shuffle=False, drop_last=True)] == [4, 4]
     with pytest.raises(ValueError):
         pkg.SnapshotStore(raw, torch.tensor([[0, 41], [1, 2]]), device="cpu")
+    # row_batches: the same epoch as batches(), as row indices for consumers that collate on the device themselves
+    a = list(st.batches(4, shuffle=True, generator=torch.Generator().manual_seed(9)))
+    b = list(st.row_batches(4, shuffle=True, generator=torch.Generator().manual_seed(9)))
+    assert len(a) == len(b) == 3
+    for (x1, e1, n1), (rows1, e2, n2) in zip(a, b):
+        assert n1 == n2 and e1 is e2 and rows1.dtype == torch.int64 and rows1.numel() == n1
+        assert torch.equal(st.batch(rows1), x1)
 
 
 def test_metrics_match_hand_values(pkg):
