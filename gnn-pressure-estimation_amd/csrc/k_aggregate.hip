@@ -70,15 +70,39 @@ __device__ __forceinline__ float4 hub_reduce4(float4 v, float* tile, int G, int 
   return r;
 }
 
+// Addressing.  Every table of these kernels is a kernel argument (a wave-uniform base) indexed by a node or edge id
+// times a power-of-two row width: offsets are formed in IDX = 32-bit BYTE arithmetic with shifts -- one or two full-rate
+// VALU operations and the `global_load v, voffset, s[base]` form -- instead of the 64-bit multiply-adds (quarter rate,
+// five instructions per load) that `base[(size_t)j * HC + c]` compiles to and that bounded these kernels (83 % VALU busy
+// on address arithmetic alone).  IDX = size_t is the instance for tables of 4 GiB and more (launchers: offsets_fit_32).
+template <typename IDX, typename T>
+__device__ __forceinline__ const T* gatres_at(const T* base, IDX elem) {
+  return reinterpret_cast<const T*>(reinterpret_cast<const char*>(base) + elem * (IDX)sizeof(T));
+}
+template <typename IDX, typename T>
+__device__ __forceinline__ T* gatres_at_w(T* base, IDX elem) {
+  return reinterpret_cast<T*>(reinterpret_cast<char*>(base) + elem * (IDX)sizeof(T));
+}
+// rowld(tab, j, c): four features of row j from column c;  hval / hptr(tab, i, hh): per-(row or edge, head) scalars;
+// ival(tab, i): an index table entry
+#define GATRES_AGG_ADDRESSING(LG_ROW, LG_H)                                                                              \
+  auto rowld = [&](const T* tab, int j, int c) { return ldrow4(gatres_at<IDX>(tab, ((IDX)j << (LG_ROW)) + (IDX)c)); };  \
+  auto hval = [&](const float* tab, int i, int hh) { return *gatres_at<IDX>(tab, ((IDX)i << (LG_H)) + (IDX)hh); };      \
+  auto hptr = [&](float* tab, int i, int hh) { return gatres_at_w<IDX>(tab, ((IDX)i << (LG_H)) + (IDX)hh); };           \
+  auto ival = [&](const int* tab, int i) { return *gatres_at<IDX>(tab, (IDX)i); };                                      \
+  (void)hval; (void)hptr; (void)rowld; (void)ival;
+
 // ------------------------------------------------------------------------------------------------------
 // K2 forward
 // ------------------------------------------------------------------------------------------------------
-template <bool RELU, typename T>
+template <bool RELU, typename T, typename IDX>
 __global__ __launch_bounds__(256, 8) void gat_aggregate_fwd_kernel(
     const int* __restrict__ rowptr, const int* __restrict__ col, const T* __restrict__ h,
     const float* __restrict__ a_src, const float* __restrict__ a_dst, const float* __restrict__ bias,
     T* __restrict__ out, float* __restrict__ alpha, int N, RowGeom gm) {
   __shared__ __attribute__((aligned(16))) float hub_lds[4 * HUB_FLOATS_PER_WAVE];
+  const int lgHC = gm.lgG + 2, lgH = lgHC - gm.lgC;
+  GATRES_AGG_ADDRESSING(lgHC, lgH)
   const int tid = gatres_xcd_block(blockIdx.x, gridDim.x) * 256 + threadIdx.x;      // (XCD-local row ranges)
   int row = tid >> gm.lgG;
   const bool valid = row < N;                  // (every lane stays: hub rows are processed by the whole wave)
@@ -87,8 +111,8 @@ __global__ __launch_bounds__(256, 8) void gat_aggregate_fwd_kernel(
   const int hd = c0 >> gm.lgC;
   const bool leader = valid && (c0 & (gm.C - 1)) == 0;
   const int H = gm.H, HC = gm.HC;
-  const int beg = rowptr[row], end = rowptr[row + 1];
-  const float adst = a_dst[row * H + hd];
+  const int beg = ival(rowptr, row), end = ival(rowptr, row + 1);
+  const float adst = hval(a_dst, row, hd);
   float4 acc = f4zero();
   constexpr int MAXD = 6;                      // rows with <= 6 in-edges (every water-network row): slot path
   const bool hub = valid && end - beg > HUB_MIN_DEGREE;
@@ -104,19 +128,19 @@ __global__ __launch_bounds__(256, 8) void gat_aggregate_fwd_kernel(
       const int hrow = __shfl(row, owner), hbeg = __shfl(beg, owner), hend = __shfl(end, owner);
       const int fc0 = f * 4, fhd = fc0 >> gm.lgC;
       const bool fleader = (fc0 & (gm.C - 1)) == 0;
-      const float hadst = a_dst[hrow * H + fhd];
+      const float hadst = hval(a_dst, hrow, fhd);
       float m = -INFINITY;
-      _Pragma("unroll 2") for (int e = hbeg + slot; e < hend; e += S) m = fmaxf(m, gatres_leaky(a_src[col[e] * H + fhd] + hadst));
+      _Pragma("unroll 2") for (int e = hbeg + slot; e < hend; e += S) m = fmaxf(m, gatres_leaky(hval(a_src, ival(col, e), fhd) + hadst));
       m = hub_reduce1<true>(m, tile, G, S, f);
       float z = 0.f;
-      _Pragma("unroll 2") for (int e = hbeg + slot; e < hend; e += S) z = z + expf(gatres_leaky(a_src[col[e] * H + fhd] + hadst) - m);
+      _Pragma("unroll 2") for (int e = hbeg + slot; e < hend; e += S) z = z + expf(gatres_leaky(hval(a_src, ival(col, e), fhd) + hadst) - m);
       const float Z = hub_reduce1<false>(z, tile, G, S, f) + GATRES_SOFTMAX_EPS;
       float4 part = f4zero();
       _Pragma("unroll 2") for (int e = hbeg + slot; e < hend; e += S) {
-        const int j = col[e];
-        const float al = expf(gatres_leaky(a_src[j * H + fhd] + hadst) - m) / Z;
-        if (fleader) alpha[(size_t)e * H + fhd] = al;
-        gatres_axpy4(part, al, ldrow4(h + (size_t)j * HC + fc0));
+        const int j = ival(col, e);
+        const float al = expf(gatres_leaky(hval(a_src, j, fhd) + hadst) - m) / Z;
+        if (fleader) *hptr(alpha, e, fhd) = al;
+        gatres_axpy4(part, al, rowld(h, j, fc0));
       }
       const float4 sum = hub_reduce4(part, tile, G, S, f);
       if ((lane >> gm.lgG) == (owner >> gm.lgG)) acc = sum;            // the row's own lanes keep it (f == their feature lane)
@@ -131,14 +155,14 @@ __global__ __launch_bounds__(256, 8) void gat_aggregate_fwd_kernel(
     const int deg = end - beg;
     int jj[MAXD];
 #pragma unroll
-    for (int k = 0; k < MAXD; ++k) jj[k] = col[beg + min(k, deg - 1)];
+    for (int k = 0; k < MAXD; ++k) jj[k] = ival(col, beg + min(k, deg - 1));
     float so[MAXD];
     float4 v[MAXD];
     float m = -INFINITY;
 #pragma unroll
     for (int k = 0; k < MAXD; ++k) {
-      v[k] = ldrow4(h + (size_t)jj[k] * HC + c0);
-      const float sv = gatres_leaky(a_src[jj[k] * H + hd] + adst);
+      v[k] = rowld(h, jj[k], c0);
+      const float sv = gatres_leaky(hval(a_src, jj[k], hd) + adst);
       so[k] = k < deg ? sv : -INFINITY;
     }
 #pragma unroll
@@ -154,19 +178,19 @@ __global__ __launch_bounds__(256, 8) void gat_aggregate_fwd_kernel(
     for (int k = 0; k < MAXD; ++k) {
       const float al = so[k] / Z;
       if (k < deg) {
-        if (leader) alpha[(size_t)(beg + k) * H + hd] = al;
+        if (leader) *hptr(alpha, (beg + k), hd) = al;
         gatres_axpy4(acc, al, v[k]);
       }
     }
   } else {                                     // up to HUB_MIN_DEGREE in-edges: the row's own lanes, edge after edge
   float m = -INFINITY;
   for (int e = beg; e < end; ++e) {
-    const float s = gatres_leaky(a_src[col[e] * H + hd] + adst);
+    const float s = gatres_leaky(hval(a_src, ival(col, e), hd) + adst);
     m = fmaxf(m, s);
   }
   float Z = 0.f;
   for (int e = beg; e < end; ++e) {
-    const float s = gatres_leaky(a_src[col[e] * H + hd] + adst);
+    const float s = gatres_leaky(hval(a_src, ival(col, e), hd) + adst);
     Z = Z + expf(s - m);
   }
   Z = Z + GATRES_SOFTMAX_EPS;
@@ -174,20 +198,20 @@ __global__ __launch_bounds__(256, 8) void gat_aggregate_fwd_kernel(
   int e = beg;
   // two edges per trip so both neighbour rows are in flight together
   for (; e + 1 < end; e += 2) {
-    const int j0 = col[e], j1 = col[e + 1];
-    const float4 v0 = ldrow4(h + (size_t)j0 * HC + c0);
-    const float4 v1 = ldrow4(h + (size_t)j1 * HC + c0);
-    const float al0 = expf(gatres_leaky(a_src[j0 * H + hd] + adst) - m) / Z;
-    const float al1 = expf(gatres_leaky(a_src[j1 * H + hd] + adst) - m) / Z;
-    if (leader) { alpha[(size_t)e * H + hd] = al0; alpha[(size_t)(e + 1) * H + hd] = al1; }
+    const int j0 = ival(col, e), j1 = ival(col, e + 1);
+    const float4 v0 = rowld(h, j0, c0);
+    const float4 v1 = rowld(h, j1, c0);
+    const float al0 = expf(gatres_leaky(hval(a_src, j0, hd) + adst) - m) / Z;
+    const float al1 = expf(gatres_leaky(hval(a_src, j1, hd) + adst) - m) / Z;
+    if (leader) { *hptr(alpha, e, hd) = al0; *hptr(alpha, (e + 1), hd) = al1; }
     gatres_axpy4(acc, al0, v0);
     gatres_axpy4(acc, al1, v1);
   }
   if (e < end) {
-    const int j0 = col[e];
-    const float4 v0 = ldrow4(h + (size_t)j0 * HC + c0);
-    const float al0 = expf(gatres_leaky(a_src[j0 * H + hd] + adst) - m) / Z;
-    if (leader) alpha[(size_t)e * H + hd] = al0;
+    const int j0 = ival(col, e);
+    const float4 v0 = rowld(h, j0, c0);
+    const float al0 = expf(gatres_leaky(hval(a_src, j0, hd) + adst) - m) / Z;
+    if (leader) *hptr(alpha, e, hd) = al0;
     gatres_axpy4(acc, al0, v0);
   }
   }
@@ -196,7 +220,7 @@ __global__ __launch_bounds__(256, 8) void gat_aggregate_fwd_kernel(
   if (RELU) {
     acc.x = fmaxf(acc.x, 0.f); acc.y = fmaxf(acc.y, 0.f); acc.z = fmaxf(acc.z, 0.f); acc.w = fmaxf(acc.w, 0.f);
   }
-  if (valid) strow4(out + (size_t)row * HC + c0, acc);
+  if (valid) strow4(gatres_at_w<IDX>(out, ((IDX)row << lgHC) + (IDX)c0), acc);
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -219,12 +243,14 @@ __device__ __forceinline__ float head_dot(const float4 a, const float4 b, int la
   }
 }
 
-template <typename T>
+template <typename T, typename IDX>
 __global__ __launch_bounds__(256, 7) void gat_aggregate_bwd_dst_kernel(
     const int* __restrict__ rowptr, const int* __restrict__ col, const T* __restrict__ g_out,
     const T* __restrict__ h, const float* __restrict__ alpha, const float* __restrict__ a_src,
     const float* __restrict__ a_dst, float* __restrict__ g_e, float* __restrict__ g_a_dst, int N, RowGeom gm) {
   __shared__ __attribute__((aligned(16))) float hub_lds[4 * HUB_FLOATS_PER_WAVE];
+  const int lgHC = gm.lgG + 2, lgH = lgHC - gm.lgC;
+  GATRES_AGG_ADDRESSING(lgHC, lgH)
   const int tid = gatres_xcd_block(blockIdx.x, gridDim.x) * 256 + threadIdx.x;      // (XCD-local row ranges)
   int row = tid >> gm.lgG;
   const bool valid = row < N;
@@ -233,7 +259,7 @@ __global__ __launch_bounds__(256, 7) void gat_aggregate_bwd_dst_kernel(
   const int hd = c0 >> gm.lgC;
   const bool leader = valid && (c0 & (gm.C - 1)) == 0;
   const int H = gm.H, HC = gm.HC, LH = gm.C >> 2;
-  const int beg = rowptr[row], end = rowptr[row + 1];
+  const int beg = ival(rowptr, row), end = ival(rowptr, row + 1);
   float S = 0.f, gad = 0.f;
   // hub rows: the whole wave, S edge slots of G lanes, partial sums through LDS (see hub_reduce1)
   const unsigned long long hubs = __ballot(valid && end - beg > HUB_MIN_DEGREE && c0 == 0);
@@ -248,42 +274,42 @@ __global__ __launch_bounds__(256, 7) void gat_aggregate_bwd_dst_kernel(
       const int hrow = __shfl(row, owner), hbeg = __shfl(beg, owner), hend = __shfl(end, owner);
       const int fc0 = f * 4, fhd = fc0 >> gm.lgC;
       const bool fleader = (fc0 & (gm.C - 1)) == 0;
-      const float4 hgo = ldrow4(g_out + (size_t)hrow * HC + fc0);
-      const float hadst = a_dst[hrow * H + fhd];
+      const float4 hgo = rowld(g_out, hrow, fc0);
+      const float hadst = hval(a_dst, hrow, fhd);
       float sp = 0.f;
       for (int e = hbeg + slot; e < hend; e += S) {
-        const float ga = head_dot(hgo, ldrow4(h + (size_t)col[e] * HC + fc0), LH);
-        sp = fmaf(alpha[(size_t)e * H + fhd], ga, sp);
+        const float ga = head_dot(hgo, rowld(h, ival(col, e), fc0), LH);
+        sp = fmaf(hval(alpha, e, fhd), ga, sp);
       }
       const float Ss = hub_reduce1<false>(sp, tile, G, S, f);
       float gp = 0.f;
       for (int e = hbeg + slot; e < hend; e += S) {
-        const int j = col[e];
-        const float ga = head_dot(hgo, ldrow4(h + (size_t)j * HC + fc0), LH);
-        const float gs = alpha[(size_t)e * H + fhd] * (ga - Ss);
-        const float raw = a_src[j * H + fhd] + hadst;
+        const int j = ival(col, e);
+        const float ga = head_dot(hgo, rowld(h, j, fc0), LH);
+        const float gs = hval(alpha, e, fhd) * (ga - Ss);
+        const float raw = hval(a_src, j, fhd) + hadst;
         const float ge = raw > 0.f ? gs : gs * GATRES_NEG_SLOPE;
-        if (fleader) g_e[(size_t)e * H + fhd] = ge;
+        if (fleader) *hptr(g_e, e, fhd) = ge;
         gp = gp + ge;
       }
       const float gsum = hub_reduce1<false>(gp, tile, G, S, f);
       if ((lane >> gm.lgG) == (owner >> gm.lgG)) gad = gsum;
     }
   }
-  const float4 go = ldrow4(g_out + (size_t)row * HC + c0);
-  const float adst = a_dst[row * H + hd];
+  const float4 go = rowld(g_out, row, c0);
+  const float adst = hval(a_dst, row, hd);
   if (end - beg <= 8) {                        // the common case: every load of the row issued together (slot path)
     const int deg = end - beg;
     int jj[8];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) jj[k] = col[beg + min(k, deg - 1)];
+    for (int k = 0; k < 8; ++k) jj[k] = ival(col, beg + min(k, deg - 1));
     float4 hv[8];
     float al[8], as[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
-      hv[k] = ldrow4(h + (size_t)jj[k] * HC + c0);
-      al[k] = alpha[(size_t)(beg + min(k, deg - 1)) * H + hd];
-      as[k] = a_src[jj[k] * H + hd];
+      hv[k] = rowld(h, jj[k], c0);
+      al[k] = hval(alpha, (beg + min(k, deg - 1)), hd);
+      as[k] = hval(a_src, jj[k], hd);
     }
     float ga[8];
 #pragma unroll
@@ -297,26 +323,26 @@ __global__ __launch_bounds__(256, 7) void gat_aggregate_bwd_dst_kernel(
         const float gs = al[k] * (ga[k] - S);
         const float raw = as[k] + adst;
         const float ge = raw > 0.f ? gs : gs * GATRES_NEG_SLOPE;
-        if (leader) g_e[(size_t)(beg + k) * H + hd] = ge;
+        if (leader) *hptr(g_e, (beg + k), hd) = ge;
         gad = gad + ge;
       }
     }
   } else if (end - beg <= HUB_MIN_DEGREE) {    // the row's own lanes, edge after edge; the dots are recomputed in the second pass
     for (int e = beg; e < end; ++e) {
-      const float ga = head_dot(go, ldrow4(h + (size_t)col[e] * HC + c0), LH);
-      S = fmaf(alpha[(size_t)e * H + hd], ga, S);
+      const float ga = head_dot(go, rowld(h, ival(col, e), c0), LH);
+      S = fmaf(hval(alpha, e, hd), ga, S);
     }
     for (int e = beg; e < end; ++e) {
-      const int j = col[e];
-      const float ga = head_dot(go, ldrow4(h + (size_t)j * HC + c0), LH);
-      const float gs = alpha[(size_t)e * H + hd] * (ga - S);
-      const float raw = a_src[j * H + hd] + adst;
+      const int j = ival(col, e);
+      const float ga = head_dot(go, rowld(h, j, c0), LH);
+      const float gs = hval(alpha, e, hd) * (ga - S);
+      const float raw = hval(a_src, j, hd) + adst;
       const float ge = raw > 0.f ? gs : gs * GATRES_NEG_SLOPE;
-      if (leader) g_e[(size_t)e * H + hd] = ge;
+      if (leader) *hptr(g_e, e, hd) = ge;
       gad = gad + ge;
     }
   }
-  if (leader) g_a_dst[row * H + hd] = gad;
+  if (leader) *hptr(g_a_dst, row, hd) = gad;
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -324,13 +350,15 @@ __global__ __launch_bounds__(256, 7) void gat_aggregate_bwd_dst_kernel(
 //   g_a_src[j] = sum_{e out of j} g_e
 //   g_h[j]     = sum_{e=(j->i)} alpha_e * g_out[i]  +  g_a_src[j] (x) att_src  +  g_a_dst[j] (x) att_dst
 // ------------------------------------------------------------------------------------------------------
-template <typename T>
+template <typename T, typename IDX>
 __global__ __launch_bounds__(256, 8) void gat_aggregate_bwd_src_kernel(
     const int* __restrict__ t_rowptr, const int* __restrict__ t_eid, const int* __restrict__ t_dst,
     const T* __restrict__ g_out, const float* __restrict__ alpha, const float* __restrict__ g_e,
     const float* __restrict__ g_a_dst, const float* __restrict__ att_src, const float* __restrict__ att_dst,
     T* __restrict__ g_h, float* __restrict__ g_a_src, int N, RowGeom gm) {
   __shared__ __attribute__((aligned(16))) float hub_lds[4 * HUB_FLOATS_PER_WAVE];
+  const int lgHC = gm.lgG + 2, lgH = lgHC - gm.lgC;
+  GATRES_AGG_ADDRESSING(lgHC, lgH)
   const int tid = gatres_xcd_block(blockIdx.x, gridDim.x) * 256 + threadIdx.x;      // (XCD-local row ranges)
   int row = tid >> gm.lgG;
   const bool valid = row < N;
@@ -339,7 +367,7 @@ __global__ __launch_bounds__(256, 8) void gat_aggregate_bwd_src_kernel(
   const int hd = c0 >> gm.lgC;
   const bool leader = valid && (c0 & (gm.C - 1)) == 0;
   const int H = gm.H, HC = gm.HC;
-  const int beg = t_rowptr[row], end0 = t_rowptr[row + 1];
+  const int beg = ival(t_rowptr, row), end0 = ival(t_rowptr, row + 1);
   float4 acc = f4zero();
   float gas = 0.f;
   // hub sources (more than HUB_MIN_DEGREE out-edges): the whole wave, S edge slots of G lanes, partial sums through LDS
@@ -358,9 +386,9 @@ __global__ __launch_bounds__(256, 8) void gat_aggregate_bwd_src_kernel(
       float4 part = f4zero();
       float gp = 0.f;
       _Pragma("unroll 2") for (int tt = hbeg + slot; tt < hend; tt += S) {
-        const int e = t_eid[tt], i = t_dst[tt];
-        gp = gp + g_e[(size_t)e * H + fhd];
-        gatres_axpy4(part, alpha[(size_t)e * H + fhd], ldrow4(g_out + (size_t)i * HC + fc0));
+        const int e = ival(t_eid, tt), i = ival(t_dst, tt);
+        gp = gp + hval(g_e, e, fhd);
+        gatres_axpy4(part, hval(alpha, e, fhd), rowld(g_out, i, fc0));
       }
       const float4 sum = hub_reduce4(part, tile, G, S, f);
       const float gsum = hub_reduce1<false>(gp, tile, G, S, f);
@@ -370,45 +398,47 @@ __global__ __launch_bounds__(256, 8) void gat_aggregate_bwd_src_kernel(
   const int end = hub ? beg : end0;            // (a hub's edges are done)
   int t = beg;
   for (; t + 1 < end; t += 2) {
-    const int e0 = t_eid[t], e1 = t_eid[t + 1];
-    const int i0 = t_dst[t], i1 = t_dst[t + 1];
-    const float4 v0 = ldrow4(g_out + (size_t)i0 * HC + c0);
-    const float4 v1 = ldrow4(g_out + (size_t)i1 * HC + c0);
-    const float al0 = alpha[(size_t)e0 * H + hd], al1 = alpha[(size_t)e1 * H + hd];
-    gas = gas + g_e[(size_t)e0 * H + hd];
-    gas = gas + g_e[(size_t)e1 * H + hd];
+    const int e0 = ival(t_eid, t), e1 = ival(t_eid, t + 1);
+    const int i0 = ival(t_dst, t), i1 = ival(t_dst, t + 1);
+    const float4 v0 = rowld(g_out, i0, c0);
+    const float4 v1 = rowld(g_out, i1, c0);
+    const float al0 = hval(alpha, e0, hd), al1 = hval(alpha, e1, hd);
+    gas = gas + hval(g_e, e0, hd);
+    gas = gas + hval(g_e, e1, hd);
     gatres_axpy4(acc, al0, v0);
     gatres_axpy4(acc, al1, v1);
   }
   if (t < end) {
-    const int e0 = t_eid[t], i0 = t_dst[t];
-    const float4 v0 = ldrow4(g_out + (size_t)i0 * HC + c0);
-    const float al0 = alpha[(size_t)e0 * H + hd];
-    gas = gas + g_e[(size_t)e0 * H + hd];
+    const int e0 = ival(t_eid, t), i0 = ival(t_dst, t);
+    const float4 v0 = rowld(g_out, i0, c0);
+    const float al0 = hval(alpha, e0, hd);
+    gas = gas + hval(g_e, e0, hd);
     gatres_axpy4(acc, al0, v0);
   }
-  if (leader) g_a_src[row * H + hd] = gas;
-  const float gad = g_a_dst[row * H + hd];
+  if (leader) *hptr(g_a_src, row, hd) = gas;
+  const float gad = hval(g_a_dst, row, hd);
   const float4 as = ld4(att_src + c0), ad = ld4(att_dst + c0);
   gatres_axpy4(acc, gas, as);
   gatres_axpy4(acc, gad, ad);
-  if (valid) strow4(g_h + (size_t)row * HC + c0, acc);
+  if (valid) strow4(gatres_at_w<IDX>(g_h, ((IDX)row << lgHC) + (IDX)c0), acc);
 }
 
 // ------------------------------------------------------------------------------------------------------
 // K3: out_i = relu( (sum_{j->i} y[j]) / max(indeg(i),1) + x0_i )       and its backward
 // ------------------------------------------------------------------------------------------------------
-template <typename T>
+template <typename T, typename IDX>
 __global__ __launch_bounds__(256, 8) void mean_residual_relu_fwd_kernel(
     const int* __restrict__ rowptr, const int* __restrict__ col, const T* __restrict__ y,
     const T* __restrict__ x0, T* __restrict__ out, int N, int C, int G, int lgG) {
   __shared__ __attribute__((aligned(16))) float hub_lds[4 * HUB_FLOATS_PER_WAVE];
+  const int lgHC = lgG + 2;
+  GATRES_AGG_ADDRESSING(lgHC, 0)
   const int tid = gatres_xcd_block(blockIdx.x, gridDim.x) * 256 + threadIdx.x;      // (XCD-local row ranges)
   int row = tid >> lgG;
   const bool valid = row < N;
   if (!valid) row = N - 1;
   const int c0 = (tid & (G - 1)) * 4;
-  const int beg = rowptr[row], end0 = rowptr[row + 1];
+  const int beg = ival(rowptr, row), end0 = ival(rowptr, row + 1);
   float4 acc = f4zero();
   const bool hub = valid && end0 - beg > HUB_MIN_DEGREE;                    // hub rows: whole wave + LDS-staged partial sums
   const unsigned long long hubs = __ballot(hub && c0 == 0);
@@ -423,7 +453,7 @@ __global__ __launch_bounds__(256, 8) void mean_residual_relu_fwd_kernel(
       const int hbeg = __shfl(beg, owner), hend = __shfl(end0, owner);
       float4 part = f4zero();
       _Pragma("unroll 2") for (int e = hbeg + slot; e < hend; e += S) {
-        const float4 v = ldrow4(y + (size_t)col[e] * C + f * 4);
+        const float4 v = rowld(y, ival(col, e), f * 4);
         part.x = part.x + v.x; part.y = part.y + v.y; part.z = part.z + v.z; part.w = part.w + v.w;
       }
       const float4 sum = hub_reduce4(part, tile, G, S, f);
@@ -433,36 +463,38 @@ __global__ __launch_bounds__(256, 8) void mean_residual_relu_fwd_kernel(
   const int end = hub ? beg : end0;
   int e = beg;
   for (; e + 1 < end; e += 2) {
-    const float4 v0 = ldrow4(y + (size_t)col[e] * C + c0);
-    const float4 v1 = ldrow4(y + (size_t)col[e + 1] * C + c0);
+    const float4 v0 = rowld(y, ival(col, e), c0);
+    const float4 v1 = rowld(y, ival(col, e + 1), c0);
     acc.x = acc.x + v0.x; acc.y = acc.y + v0.y; acc.z = acc.z + v0.z; acc.w = acc.w + v0.w;
     acc.x = acc.x + v1.x; acc.y = acc.y + v1.y; acc.z = acc.z + v1.z; acc.w = acc.w + v1.w;
   }
   if (e < end) {
-    const float4 v0 = ldrow4(y + (size_t)col[e] * C + c0);
+    const float4 v0 = rowld(y, ival(col, e), c0);
     acc.x = acc.x + v0.x; acc.y = acc.y + v0.y; acc.z = acc.z + v0.z; acc.w = acc.w + v0.w;
   }
   const float cnt = (float)max(end0 - beg, 1);
-  const float4 r = ldrow4(x0 + (size_t)row * C + c0);
+  const float4 r = rowld(x0, row, c0);
   float4 o;
   o.x = fmaxf(acc.x / cnt + r.x, 0.f);
   o.y = fmaxf(acc.y / cnt + r.y, 0.f);
   o.z = fmaxf(acc.z / cnt + r.z, 0.f);
   o.w = fmaxf(acc.w / cnt + r.w, 0.f);
-  if (valid) strow4(out + (size_t)row * C + c0, o);
+  if (valid) strow4(gatres_at_w<IDX>(out, ((IDX)row << lgHC) + (IDX)c0), o);
 }
 
-template <typename T>
+template <typename T, typename IDX>
 __global__ __launch_bounds__(256, 8) void mean_bwd_kernel(
     const int* __restrict__ m_rowptr, const int* __restrict__ mt_rowptr, const int* __restrict__ mt_dst,
     const T* __restrict__ g_pre, T* __restrict__ g_y, int N, int C, int G, int lgG) {
   __shared__ __attribute__((aligned(16))) float hub_lds[4 * HUB_FLOATS_PER_WAVE];
+  const int lgHC = lgG + 2;
+  GATRES_AGG_ADDRESSING(lgHC, 0)
   const int tid = gatres_xcd_block(blockIdx.x, gridDim.x) * 256 + threadIdx.x;      // (XCD-local row ranges)
   int row = tid >> lgG;
   const bool valid = row < N;
   if (!valid) row = N - 1;
   const int c0 = (tid & (G - 1)) * 4;
-  const int beg = mt_rowptr[row], end0 = mt_rowptr[row + 1];
+  const int beg = ival(mt_rowptr, row), end0 = ival(mt_rowptr, row + 1);
   float4 acc = f4zero();
   const bool hub = valid && end0 - beg > HUB_MIN_DEGREE;                    // hub sources: whole wave + LDS-staged partial sums
   const unsigned long long hubs = __ballot(hub && c0 == 0);
@@ -477,9 +509,9 @@ __global__ __launch_bounds__(256, 8) void mean_bwd_kernel(
       const int hbeg = __shfl(beg, owner), hend = __shfl(end0, owner);
       float4 part = f4zero();
       _Pragma("unroll 2") for (int t = hbeg + slot; t < hend; t += S) {
-        const int i = mt_dst[t];
-        const float cnt = (float)max(m_rowptr[i + 1] - m_rowptr[i], 1);
-        const float4 v = ldrow4(g_pre + (size_t)i * C + f * 4);
+        const int i = ival(mt_dst, t);
+        const float cnt = (float)max(ival(m_rowptr, i + 1) - ival(m_rowptr, i), 1);
+        const float4 v = rowld(g_pre, i, f * 4);
         part.x = part.x + v.x / cnt; part.y = part.y + v.y / cnt; part.z = part.z + v.z / cnt; part.w = part.w + v.w / cnt;
       }
       const float4 sum = hub_reduce4(part, tile, G, S, f);
@@ -488,12 +520,12 @@ __global__ __launch_bounds__(256, 8) void mean_bwd_kernel(
   }
   const int end = hub ? beg : end0;
   for (int t = beg; t < end; ++t) {
-    const int i = mt_dst[t];
-    const float cnt = (float)max(m_rowptr[i + 1] - m_rowptr[i], 1);
-    const float4 v = ldrow4(g_pre + (size_t)i * C + c0);
+    const int i = ival(mt_dst, t);
+    const float cnt = (float)max(ival(m_rowptr, i + 1) - ival(m_rowptr, i), 1);
+    const float4 v = rowld(g_pre, i, c0);
     acc.x = acc.x + v.x / cnt; acc.y = acc.y + v.y / cnt; acc.z = acc.z + v.z / cnt; acc.w = acc.w + v.w / cnt;
   }
-  if (valid) strow4(g_y + (size_t)row * C + c0, acc);
+  if (valid) strow4(gatres_at_w<IDX>(g_y, ((IDX)row << lgHC) + (IDX)c0), acc);
 }
 
 static inline bool graph_ok(const gatres_graph_t* g) {
@@ -510,12 +542,26 @@ static inline int grid_rows(int N, int G) {
 
 // Typed launchers (gatres_typed.h): `dtype` says what the void* activation tensors hold.  The C-ABI entry points below are
 // their fp32 instances.
-#define GATRES_DISPATCH_T(dtype_, CALL_)                                  \
-  switch (dtype_) {                                                       \
-    case GATRES_DTYPE_F32: { using T = float; CALL_; break; }             \
-    case GATRES_DTYPE_BF16: { using T = gatres_bf16; CALL_; break; }      \
-    default: return GATRES_E_UNSUPPORTED;                                 \
+#define GATRES_DISPATCH_T(dtype_, fit32_, CALL_)                                                       \
+  switch (dtype_) {                                                                                    \
+    case GATRES_DTYPE_F32:                                                                             \
+      if (fit32_) { using T = float; using IDX = unsigned; CALL_; }                                    \
+      else { using T = float; using IDX = size_t; CALL_; }                                             \
+      break;                                                                                           \
+    case GATRES_DTYPE_BF16:                                                                            \
+      if (fit32_) { using T = gatres_bf16; using IDX = unsigned; CALL_; }                              \
+      else { using T = gatres_bf16; using IDX = size_t; CALL_; }                                       \
+      break;                                                                                           \
+    default: return GATRES_E_UNSUPPORTED;                                                              \
   }
+
+// every byte offset into a [rows or edges] x width table of 4-byte elements fits 32 bits (the IDX = unsigned instances)
+static inline bool offsets_fit_32(const gatres_graph_t* g, int width) {
+  long long most = g->num_nodes;
+  if (g->num_edges_gat > most) most = g->num_edges_gat;
+  if (g->num_edges_mean > most) most = g->num_edges_mean;
+  return (most + 2) * (long long)width * 4 < (1LL << 32) && !getenv("GATRES_AGG_WIDE_OFFSETS");
+}
 
 extern "C" int gatres_t_gat_aggregate_fwd(const gatres_graph_t* g, const void* h, const float* a_src, const float* a_dst,
                                const float* bias, void* out, float* alpha, int H, int C, int apply_relu, int dtype,
@@ -525,13 +571,14 @@ extern "C" int gatres_t_gat_aggregate_fwd(const gatres_graph_t* g, const void* h
   RowGeom gm;
   if (!make_geom(H, C, &gm)) return GATRES_E_UNSUPPORTED;
   const int N = g->num_nodes;
+  const bool fit32 = offsets_fit_32(g, gm.HC);
   dim3 grid(grid_rows(N, gm.G)), block(256);
-  GATRES_DISPATCH_T(dtype, {
+  GATRES_DISPATCH_T(dtype, fit32, {
     if (apply_relu)
-      hipLaunchKernelGGL((gat_aggregate_fwd_kernel<true, T>), grid, block, 0, gatres_stream(stream), g->rowptr, g->col,
+      hipLaunchKernelGGL((gat_aggregate_fwd_kernel<true, T, IDX>), grid, block, 0, gatres_stream(stream), g->rowptr, g->col,
                          (const T*)h, a_src, a_dst, bias, (T*)out, alpha, N, gm);
     else
-      hipLaunchKernelGGL((gat_aggregate_fwd_kernel<false, T>), grid, block, 0, gatres_stream(stream), g->rowptr, g->col,
+      hipLaunchKernelGGL((gat_aggregate_fwd_kernel<false, T, IDX>), grid, block, 0, gatres_stream(stream), g->rowptr, g->col,
                          (const T*)h, a_src, a_dst, bias, (T*)out, alpha, N, gm);
   })
   return gatres_launch_status();
@@ -545,8 +592,9 @@ extern "C" int gatres_t_gat_aggregate_bwd_dst(const gatres_graph_t* g, const voi
   RowGeom gm;
   if (!make_geom(H, C, &gm)) return GATRES_E_UNSUPPORTED;
   const int N = g->num_nodes;
-  GATRES_DISPATCH_T(dtype, {
-    hipLaunchKernelGGL((gat_aggregate_bwd_dst_kernel<T>), dim3(grid_rows(N, gm.G)), dim3(256), 0, gatres_stream(stream),
+  const bool fit32 = offsets_fit_32(g, gm.HC);
+  GATRES_DISPATCH_T(dtype, fit32, {
+    hipLaunchKernelGGL((gat_aggregate_bwd_dst_kernel<T, IDX>), dim3(grid_rows(N, gm.G)), dim3(256), 0, gatres_stream(stream),
                        g->rowptr, g->col, (const T*)g_out, (const T*)h, alpha, a_src, a_dst, g_e, g_a_dst, N, gm);
   })
   return gatres_launch_status();
@@ -563,8 +611,9 @@ extern "C" int gatres_t_gat_aggregate_bwd_src(const gatres_graph_t* g, const voi
   RowGeom gm;
   if (!make_geom(H, C, &gm)) return GATRES_E_UNSUPPORTED;
   const int N = g->num_nodes;
-  GATRES_DISPATCH_T(dtype, {
-    hipLaunchKernelGGL((gat_aggregate_bwd_src_kernel<T>), dim3(grid_rows(N, gm.G)), dim3(256), 0, gatres_stream(stream),
+  const bool fit32 = offsets_fit_32(g, gm.HC);
+  GATRES_DISPATCH_T(dtype, fit32, {
+    hipLaunchKernelGGL((gat_aggregate_bwd_src_kernel<T, IDX>), dim3(grid_rows(N, gm.G)), dim3(256), 0, gatres_stream(stream),
                        g->t_rowptr, g->t_eid, g->t_dst, (const T*)g_out, alpha, g_e, g_a_dst, att_src, att_dst,
                        (T*)g_h, g_a_src, N, gm);
   })
@@ -577,8 +626,9 @@ extern "C" int gatres_t_mean_residual_relu_fwd(const gatres_graph_t* g, const vo
   if (!gatres_aligned16(y) || !gatres_aligned16(x0) || !gatres_aligned16(out)) return GATRES_E_BADARG;
   if (C < 4 || !gatres_is_pow2(C) || C > 256) return GATRES_E_UNSUPPORTED;
   const int G = C / 4, N = g->num_nodes;
-  GATRES_DISPATCH_T(dtype, {
-    hipLaunchKernelGGL((mean_residual_relu_fwd_kernel<T>), dim3(grid_rows(N, G)), dim3(256), 0, gatres_stream(stream),
+  const bool fit32 = offsets_fit_32(g, C);
+  GATRES_DISPATCH_T(dtype, fit32, {
+    hipLaunchKernelGGL((mean_residual_relu_fwd_kernel<T, IDX>), dim3(grid_rows(N, G)), dim3(256), 0, gatres_stream(stream),
                        g->m_rowptr, g->m_col, (const T*)y, (const T*)x0, (T*)out, N, C, G, ilog2(G));
   })
   return gatres_launch_status();
@@ -589,8 +639,9 @@ extern "C" int gatres_t_mean_bwd(const gatres_graph_t* g, const void* g_pre, voi
   if (!gatres_aligned16(g_pre) || !gatres_aligned16(g_y)) return GATRES_E_BADARG;
   if (C < 4 || !gatres_is_pow2(C) || C > 256) return GATRES_E_UNSUPPORTED;
   const int G = C / 4, N = g->num_nodes;
-  GATRES_DISPATCH_T(dtype, {
-    hipLaunchKernelGGL((mean_bwd_kernel<T>), dim3(grid_rows(N, G)), dim3(256), 0, gatres_stream(stream), g->m_rowptr,
+  const bool fit32 = offsets_fit_32(g, C);
+  GATRES_DISPATCH_T(dtype, fit32, {
+    hipLaunchKernelGGL((mean_bwd_kernel<T, IDX>), dim3(grid_rows(N, G)), dim3(256), 0, gatres_stream(stream), g->m_rowptr,
                        g->mt_rowptr, g->mt_dst, (const T*)g_pre, (T*)g_y, N, C, G, ilog2(G));
   })
   return gatres_launch_status();
