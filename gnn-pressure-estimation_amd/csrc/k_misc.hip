@@ -30,6 +30,103 @@ __global__ __launch_bounds__(256) void lin0_fwd_kernel(const float* __restrict__
   strow4(out + (size_t)n * nc4 * 4 + c0, o);
 }
 
+// The same two sums with 256 threads per slab, for nc a power of two >= 4: G4 = nc / 4 lanes per node row (four columns
+// each: one 16- or 8-byte load) and R = 256 / G4 rows per trip, four trips' loads in flight.  A thread sums its rows
+// (nbeg + r, + R, ...) in order; the R partial sums of a column are then added in r order: deterministic.  The
+// one-wave-per-slab form below moved 128 bytes per load instruction with at most 64 loads outstanding -- 120 us for
+// 50 k x 128 bf16 -- and stays as the instance for other nc.
+template <typename T>
+__global__ __launch_bounds__(256) void lin0_bwd_rows_kernel(const T* __restrict__ g, const float* __restrict__ x,
+                                                            const uint8_t* __restrict__ mask, float* __restrict__ slab_w,
+                                                            float* __restrict__ slab_b, long long stride, int N, int nc,
+                                                            int nps, int lgG4) {
+  __shared__ __attribute__((aligned(16))) float red[256 * 8];
+  const int s = blockIdx.x, tid = threadIdx.x;
+  const int G4 = 1 << lgG4, f = tid & (G4 - 1), r = tid >> lgG4, R = 256 >> lgG4;
+  const int nbeg = s * nps, nend = min(N, nbeg + nps);
+  float4 aw = f4zero(), ab = f4zero();
+  auto take = [&](float4 gv, float xv) {
+    aw.x = fmaf(gv.x, xv, aw.x); aw.y = fmaf(gv.y, xv, aw.y); aw.z = fmaf(gv.z, xv, aw.z); aw.w = fmaf(gv.w, xv, aw.w);
+    ab.x += gv.x; ab.y += gv.y; ab.z += gv.z; ab.w += gv.w;
+  };
+  int n = nbeg + r;
+  for (; n + 3 * R < nend; n += 4 * R) {
+    float4 gv[4];
+    float xv[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int m = n + u * R;
+      gv[u] = ldrow4(g + (size_t)m * nc + f * 4);
+      const float xr = x[m];
+      xv[u] = (mask && mask[m]) ? 0.f : xr;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) take(gv[u], xv[u]);
+  }
+  for (; n < nend; n += R) take(ldrow4(g + (size_t)n * nc + f * 4), (mask && mask[n]) ? 0.f : x[n]);
+  st4(red + tid * 8, aw); st4(red + tid * 8 + 4, ab);
+  __syncthreads();
+  if (tid < G4) {
+    for (int k = 1; k < R; ++k) {
+      const float4 w = ld4(red + (k * G4 + f) * 8), b = ld4(red + (k * G4 + f) * 8 + 4);
+      aw.x += w.x; aw.y += w.y; aw.z += w.z; aw.w += w.w;
+      ab.x += b.x; ab.y += b.y; ab.z += b.z; ab.w += b.w;
+    }
+    float* ow = slab_w + (size_t)s * stride + f * 4;
+    float* ob = slab_b + (size_t)s * stride + f * 4;
+    ow[0] = aw.x; ow[1] = aw.y; ow[2] = aw.z; ow[3] = aw.w;
+    ob[0] = ab.x; ob[1] = ab.y; ob[2] = ab.z; ob[3] = ab.w;
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void lin1_bwd_rows_kernel(const float* __restrict__ g_out, const T* __restrict__ x,
+                                                            const float* __restrict__ w, T* __restrict__ g_x,
+                                                            float* __restrict__ slab_w, float* __restrict__ slab_b,
+                                                            long long stride, int N, int nc, int nps, int relu_mask,
+                                                            int lgG4) {
+  __shared__ __attribute__((aligned(16))) float red[256 * 5];
+  const int s = blockIdx.x, tid = threadIdx.x;
+  const int G4 = 1 << lgG4, f = tid & (G4 - 1), r = tid >> lgG4, R = 256 >> lgG4;
+  const int nbeg = s * nps, nend = min(N, nbeg + nps);
+  const float wv[4] = {w[f * 4], w[f * 4 + 1], w[f * 4 + 2], w[f * 4 + 3]};
+  float4 aw = f4zero();
+  float ab = 0.f;
+  auto take = [&](int m, float go, float4 xv) {
+    ab += go;
+    aw.x = fmaf(go, xv.x, aw.x); aw.y = fmaf(go, xv.y, aw.y); aw.z = fmaf(go, xv.z, aw.z); aw.w = fmaf(go, xv.w, aw.w);
+    float4 o;
+    o.x = (relu_mask && !(xv.x > 0.f)) ? 0.f : go * wv[0];
+    o.y = (relu_mask && !(xv.y > 0.f)) ? 0.f : go * wv[1];
+    o.z = (relu_mask && !(xv.z > 0.f)) ? 0.f : go * wv[2];
+    o.w = (relu_mask && !(xv.w > 0.f)) ? 0.f : go * wv[3];
+    strow4(g_x + (size_t)m * nc + f * 4, o);
+  };
+  int n = nbeg + r;
+  for (; n + 3 * R < nend; n += 4 * R) {
+    float4 xv[4];
+    float go[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { xv[u] = ldrow4(x + (size_t)(n + u * R) * nc + f * 4); go[u] = g_out[n + u * R]; }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) take(n + u * R, go[u], xv[u]);
+  }
+  for (; n < nend; n += R) take(n, g_out[n], ldrow4(x + (size_t)n * nc + f * 4));
+  st4(red + tid * 4, aw);
+  red[1024 + tid] = ab;
+  __syncthreads();
+  if (tid < G4) {
+    for (int k = 1; k < R; ++k) {
+      const float4 t = ld4(red + (k * G4 + f) * 4);
+      aw.x += t.x; aw.y += t.y; aw.z += t.z; aw.w += t.w;
+      ab += red[1024 + k * G4];                   // (the f == 0 thread of row lane k)
+    }
+    float* ow = slab_w + (size_t)s * stride + f * 4;
+    ow[0] = aw.x; ow[1] = aw.y; ow[2] = aw.z; ow[3] = aw.w;
+    if (tid == 0) slab_b[(size_t)s * stride] = ab;
+  }
+}
+
 // g_w[c] = sum_n g[n,c]*xm[n] ; g_b[c] = sum_n g[n,c]        (one wave per slab, lane = column)
 template <typename T>
 __global__ __launch_bounds__(64) void lin0_bwd_kernel(const T* __restrict__ g, const float* __restrict__ x,
@@ -457,7 +554,21 @@ __global__ __launch_bounds__(1024) void masked_mse_kernel(const float* __restric
   const int tid = threadIdx.x;
   float acc = 0.f;
   int cnt = 0;
-  for (int n = tid; n < N; n += 1024) {
+  int n = tid;
+  for (; n + 3 * 1024 < N; n += 4 * 1024) {   // (four strides' loads in flight; accumulated in stride order: same bits)
+    uint8_t mk[4];
+    float o[4], t[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { mk[u] = mask[n + u * 1024]; o[u] = out[n + u * 1024]; t[u] = y[n + u * 1024]; }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      if (mk[u]) {
+        const float d = o[u] - t[u];
+        acc = fmaf(d, d, acc);
+        ++cnt;
+      }
+  }
+  for (; n < N; n += 1024) {
     if (mask[n]) {
       const float d = out[n] - y[n];
       acc = fmaf(d, d, acc);
@@ -473,18 +584,20 @@ __global__ __launch_bounds__(1024) void masked_mse_kernel(const float* __restric
   const int M = s_cnt[0];
   if (tid == 0) loss[0] = s_sum[0] / (float)M;            // M == 0 -> NaN, like torch's mean of an empty tensor
   const float scale = M > 0 ? 2.f / (float)M : 0.f;
-  for (int n = tid; n < N; n += 1024) g_out[n] = mask[n] ? (out[n] - y[n]) * scale : 0.f;
+  _Pragma("unroll 4") for (int n = tid; n < N; n += 1024) g_out[n] = mask[n] ? (out[n] - y[n]) * scale : 0.f;
 }
 
 // ------------------------------------------------------------------------------------------------- Adam
 // torch.optim.Adam (single-tensor path): g += wd*p; m.lerp_(g, 1-b1); v = b2*v + (1-b2) g*g;
 // p += (-(lr/bc1) * m) / (sqrt(v)/sqrt(bc2) + eps).   step_counter[0] = step, [1] = block ticket.
+constexpr int ADAM_MAX_BLOCKS = 512;
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                    float* __restrict__ m, float* __restrict__ v,
                                                    unsigned long long* __restrict__ step_counter, long long count,
                                                    double lr, double b1, double b2, double eps, double wd,
                                                    float grad_scale, float* __restrict__ wt, int nb, int nc) {
   __shared__ float s_step_size, s_bc2_sqrt;
+  unsigned long long done = 0ULL;
   if (threadIdx.x == 0) {
     const unsigned long long t = __hip_atomic_load(step_counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1ULL;
     const double bc1 = 1.0 - gatres_powi(b1, t), bc2 = 1.0 - gatres_powi(b2, t);
@@ -493,18 +606,16 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
     // the step is counted once every block has READ the counter: the ticket follows this block's read (no fence: nothing
     // orders the count behind the parameter stores but the next launch -- see reduce_adam_kernel, k_fused.hip)
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    const unsigned long long done = atomicAdd(&step_counter[1], 1ULL);
-    if (done == (unsigned long long)gridDim.x - 1ULL) {
-      step_counter[1] = 0ULL;
-      atomicAdd(&step_counter[0], 1ULL);
-    }
+    done = atomicAdd(&step_counter[1], 1ULL);           // (its result is only looked at after this block's elements)
   }
   __syncthreads();
-  const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+  // Grid-stride: the launch has at most ADAM_MAX_BLOCKS blocks.  One block per 256 parameters meant 6.6 k tickets on ONE
+  // address for gatres_large -- they serialise in the L2 at ~20 ns each and were the whole 146 us of the launch.
+  for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < count; idx += (long long)gridDim.x * 256) {
   // A NaN gradient entry leaves its parameter and moments untouched: a data-parallel step whose fused launch faulted
   // (gatres_fused_finish marks every entry NaN, the all-reduce spreads that to all ranks) is dropped on every replica
   // alike instead of destroying the run.  (torch.optim.Adam would propagate the NaN.)
-  if (idx < count && g[idx] == g[idx]) {
+  if (g[idx] == g[idx]) {
     const float pv = p[idx];
     float gv = g[idx] * grad_scale;
     gv = gv + (float)wd * pv;
@@ -529,6 +640,11 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
         }
       }
     }
+  }
+  }
+  if (threadIdx.x == 0 && done == (unsigned long long)gridDim.x - 1ULL) {
+    step_counter[1] = 0ULL;
+    atomicAdd(&step_counter[0], 1ULL);
   }
 }
 
@@ -558,10 +674,24 @@ extern "C" int gatres_lin0_fwd(const float* x, const uint8_t* mask, const float*
   return gatres_t_lin0_fwd(x, mask, w, b, out, num_nodes, nc, GATRES_DTYPE_F32, stream);
 }
 
+// the row-wise lin0 / lin1 backward kernels take nc = 4, 8, ..., 256 (a power of two) and 16-byte aligned activations
+static inline int ilog2_(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
+static inline bool lin_rows_form(int nc, const void* act) {
+  return nc >= 4 && nc <= 256 && gatres_is_pow2(nc) && gatres_aligned16(act) && !getenv("GATRES_LIN_BWD_WAVE");
+}
+
 extern "C" int gatres_t_lin0_bwd(const void* g, const float* x, const uint8_t* mask, float* slab_w, float* slab_b, int num_slabs,
                       int64_t slab_stride, int num_nodes, int nc, int dtype, void* stream) {
   if (!g || !x || !slab_w || !slab_b || num_nodes <= 0 || num_slabs <= 0) return GATRES_E_BADARG;
   if (nc < 1 || nc > 256) return GATRES_E_UNSUPPORTED;
+  if (lin_rows_form(nc, g)) {
+    GATRES_DISPATCH_T(dtype, {
+      hipLaunchKernelGGL((lin0_bwd_rows_kernel<T>), dim3(num_slabs), dim3(256), 0, gatres_stream(stream), (const T*)g, x,
+                         mask, slab_w, slab_b, (long long)slab_stride, num_nodes, nc,
+                         nodes_per_slab(num_nodes, num_slabs), ilog2_(nc / 4));
+    })
+    return gatres_launch_status();
+  }
   GATRES_DISPATCH_T(dtype, {
     hipLaunchKernelGGL((lin0_bwd_kernel<T>), dim3(num_slabs), dim3(64), 0, gatres_stream(stream), (const T*)g, x, mask,
                        slab_w, slab_b, (long long)slab_stride, num_nodes, nc, nodes_per_slab(num_nodes, num_slabs));
@@ -597,6 +727,14 @@ extern "C" int gatres_t_lin1_bwd(const float* g_out, const void* x, const float*
                       int num_slabs, int64_t slab_stride, int num_nodes, int nc, int relu_mask, int dtype, void* stream) {
   if (!g_out || !x || !w || !g_x || !slab_w || !slab_b || num_nodes <= 0 || num_slabs <= 0) return GATRES_E_BADARG;
   if (nc < 1 || nc > 256) return GATRES_E_UNSUPPORTED;
+  if (lin_rows_form(nc, x) && gatres_aligned16(g_x)) {
+    GATRES_DISPATCH_T(dtype, {
+      hipLaunchKernelGGL((lin1_bwd_rows_kernel<T>), dim3(num_slabs), dim3(256), 0, gatres_stream(stream), g_out,
+                         (const T*)x, w, (T*)g_x, slab_w, slab_b, (long long)slab_stride, num_nodes, nc,
+                         nodes_per_slab(num_nodes, num_slabs), relu_mask, ilog2_(nc / 4));
+    })
+    return gatres_launch_status();
+  }
   GATRES_DISPATCH_T(dtype, {
     hipLaunchKernelGGL((lin1_bwd_kernel<T>), dim3(num_slabs), dim3(64), 0, gatres_stream(stream), g_out, (const T*)x, w,
                        (T*)g_x, slab_w, slab_b, (long long)slab_stride, num_nodes, nc,
@@ -724,11 +862,16 @@ extern "C" int gatres_masked_mse(const float* out, const float* y, const uint8_t
   return gatres_launch_status();
 }
 
+static inline unsigned adam_blocks(long long count) {
+  const long long need = (count + 255) / 256;
+  return (unsigned)(need < ADAM_MAX_BLOCKS ? need : ADAM_MAX_BLOCKS);
+}
+
 extern "C" int gatres_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq,
                                 uint64_t* step_counter, int64_t count, double lr, double beta1, double beta2,
                                 double eps, double weight_decay, float grad_scale, void* stream) {
   if (!params || !grads || !exp_avg || !exp_avg_sq || !step_counter || count <= 0) return GATRES_E_BADARG;
-  hipLaunchKernelGGL(adam_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, gatres_stream(stream), params,
+  hipLaunchKernelGGL(adam_kernel, dim3(adam_blocks(count)), dim3(256), 0, gatres_stream(stream), params,
                      grads, exp_avg, exp_avg_sq, reinterpret_cast<unsigned long long*>(step_counter),
                      (long long)count, lr, beta1, beta2, eps, weight_decay, grad_scale, (float*)nullptr, 0, 0);
   return gatres_launch_status();
@@ -742,7 +885,7 @@ extern "C" __attribute__((visibility("hidden"))) int gatres_adam_step_wt(float* 
                                    double eps, double weight_decay, float grad_scale, float* wt, int32_t num_blocks,
                                    int32_t nc, void* stream) {
   if (!params || !grads || !exp_avg || !exp_avg_sq || !step_counter || count <= 0 || !wt) return GATRES_E_BADARG;
-  hipLaunchKernelGGL(adam_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, gatres_stream(stream), params,
+  hipLaunchKernelGGL(adam_kernel, dim3(adam_blocks(count)), dim3(256), 0, gatres_stream(stream), params,
                      grads, exp_avg, exp_avg_sq, reinterpret_cast<unsigned long long*>(step_counter),
                      (long long)count, lr, beta1, beta2, eps, weight_decay, grad_scale, wt, (int)num_blocks, (int)nc);
   return gatres_launch_status();

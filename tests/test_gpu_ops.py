@@ -130,6 +130,47 @@ def test_lin0_lin1(ops):
     assert relerr(ops.lin1_fwd(z.cuda(), w1.cuda(), b1.cuda()), z @ w1 + b1) < 1e-6
 
 
+@pytest.mark.parametrize("nc,dtype", [(32, torch.float32), (128, torch.bfloat16), (24, torch.float32)])
+def test_lin0_lin1_backward_slabs(ops, nc, dtype, monkeypatch):
+    """lin0 / lin1 backward (train.py:181 through GraphModels.py:455 and :471): per-slab partial sums of the weight and
+    bias gradients and lin1's input gradient with conv-block ReLU mask.  nc = 32 / 128 take the row-wise 256-thread
+    kernels, nc = 24 the one-wave-per-slab form; GATRES_LIN_BWD_WAVE=1 must give the same sums."""
+    lib = ops.N_.load()
+    n, slabs = 3001, 7
+    DT = {torch.float32: 0, torch.bfloat16: 1}[dtype]
+    stride = 2 * nc + 8
+    torch.manual_seed(5)
+    g = torch.randn(n, nc).to(dtype).cuda()
+    x = torch.randn(n).cuda()
+    mask = (torch.rand(n) < 0.5).to(torch.uint8).cuda()
+    xm = torch.where(mask.bool(), torch.zeros_like(x), x).double()
+    go, w1 = torch.randn(n).cuda(), torch.randn(nc).cuda()
+    got = {}
+    for form in ("rows", "wave"):
+        if form == "wave":
+            monkeypatch.setenv("GATRES_LIN_BWD_WAVE", "1")
+        sw = torch.zeros(slabs, stride, device="cuda")
+        ops.N_.check(lib.gatres_t_lin0_bwd(g.data_ptr(), x.data_ptr(), mask.data_ptr(), sw.data_ptr(), sw.data_ptr() + 4 * nc,
+                                           slabs, stride, n, nc, DT, ops._s(g)), "lin0_bwd")
+        torch.cuda.synchronize()
+        gw, gb = sw[:, :nc].double().sum(0), sw[:, nc:2 * nc].double().sum(0)
+        assert relerr(gw, (g.double() * xm[:, None]).sum(0)) < 1e-5
+        assert relerr(gb, g.double().sum(0)) < 1e-5
+        # lin1: g_x = g_out (x) w under the ReLU mask of x, g_w = sum g_out * x, g_b = sum g_out
+        gx = torch.empty(n, nc, dtype=dtype, device="cuda")
+        sw1 = torch.zeros(slabs, stride, device="cuda")
+        ops.N_.check(lib.gatres_t_lin1_bwd(go.data_ptr(), g.data_ptr(), w1.data_ptr(), gx.data_ptr(), sw1.data_ptr(),
+                                           sw1.data_ptr() + 4 * nc, slabs, stride, n, nc, 1, DT, ops._s(g)), "lin1_bwd")
+        torch.cuda.synchronize()
+        assert relerr(sw1[:, :nc].double().sum(0), (go.double()[:, None] * g.double()).sum(0)) < 1e-5
+        assert abs(float(sw1[:, nc].double().sum(0)) - float(go.double().sum())) < 1e-6 * float(go.double().abs().sum())
+        exp = (go[:, None] * w1[None]) * (g.float() > 0)
+        assert torch.equal(gx.float(), exp.to(dtype).float())
+        got[form] = (gw, gb, sw1[:, :nc].double().sum(0))
+    for a, b in zip(got["rows"], got["wave"]):
+        assert relerr(a, b) < 1e-6
+
+
 def test_device_mask_sampler_exact_count_and_fresh_per_step(ops):
     sizes = [388] * 5 + [17, 1000, 3]
     off = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int32)
