@@ -243,7 +243,9 @@ __device__ __forceinline__ float head_dot(const float4 a, const float4 b, int la
   }
 }
 
-template <typename T, typename IDX>
+// LHT: the lanes per head (C / 4) as a compile-time constant for the model widths (8, 16, 32), 0 = any (wave-uniform switch
+// per dot: ~40 scalar branches per row)
+template <typename T, typename IDX, int LHT>
 __global__ __launch_bounds__(256, 7) void gat_aggregate_bwd_dst_kernel(
     const int* __restrict__ rowptr, const int* __restrict__ col, const T* __restrict__ g_out,
     const T* __restrict__ h, const float* __restrict__ alpha, const float* __restrict__ a_src,
@@ -259,6 +261,10 @@ __global__ __launch_bounds__(256, 7) void gat_aggregate_bwd_dst_kernel(
   const int hd = c0 >> gm.lgC;
   const bool leader = valid && (c0 & (gm.C - 1)) == 0;
   const int H = gm.H, HC = gm.HC, LH = gm.C >> 2;
+  auto hdot = [&](const float4 a, const float4 b) {
+    if constexpr (LHT != 0) return gatres_head_reduce<LHT>(gatres_head_dot4(a, b));
+    else return head_dot(a, b, LH);
+  };
   const int beg = ival(rowptr, row), end = ival(rowptr, row + 1);
   float S = 0.f, gad = 0.f;
   // hub rows: the whole wave, S edge slots of G lanes, partial sums through LDS (see hub_reduce1)
@@ -278,14 +284,14 @@ __global__ __launch_bounds__(256, 7) void gat_aggregate_bwd_dst_kernel(
       const float hadst = hval(a_dst, hrow, fhd);
       float sp = 0.f;
       for (int e = hbeg + slot; e < hend; e += S) {
-        const float ga = head_dot(hgo, rowld(h, ival(col, e), fc0), LH);
+        const float ga = hdot(hgo, rowld(h, ival(col, e), fc0));
         sp = fmaf(hval(alpha, e, fhd), ga, sp);
       }
       const float Ss = hub_reduce1<false>(sp, tile, G, S, f);
       float gp = 0.f;
       for (int e = hbeg + slot; e < hend; e += S) {
         const int j = ival(col, e);
-        const float ga = head_dot(hgo, rowld(h, j, fc0), LH);
+        const float ga = hdot(hgo, rowld(h, j, fc0));
         const float gs = hval(alpha, e, fhd) * (ga - Ss);
         const float raw = hval(a_src, j, fhd) + hadst;
         const float ge = raw > 0.f ? gs : gs * GATRES_NEG_SLOPE;
@@ -314,7 +320,7 @@ __global__ __launch_bounds__(256, 7) void gat_aggregate_bwd_dst_kernel(
     float ga[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
-      ga[k] = head_dot(go, hv[k], LH);
+      ga[k] = hdot(go, hv[k]);
       if (k < deg) S = fmaf(al[k], ga[k], S);
     }
 #pragma unroll
@@ -329,12 +335,12 @@ __global__ __launch_bounds__(256, 7) void gat_aggregate_bwd_dst_kernel(
     }
   } else if (end - beg <= HUB_MIN_DEGREE) {    // the row's own lanes, edge after edge; the dots are recomputed in the second pass
     for (int e = beg; e < end; ++e) {
-      const float ga = head_dot(go, rowld(h, ival(col, e), c0), LH);
+      const float ga = hdot(go, rowld(h, ival(col, e), c0));
       S = fmaf(hval(alpha, e, hd), ga, S);
     }
     for (int e = beg; e < end; ++e) {
       const int j = ival(col, e);
-      const float ga = head_dot(go, rowld(h, j, c0), LH);
+      const float ga = hdot(go, rowld(h, j, c0));
       const float gs = hval(alpha, e, hd) * (ga - S);
       const float raw = hval(a_src, j, hd) + adst;
       const float ge = raw > 0.f ? gs : gs * GATRES_NEG_SLOPE;
@@ -584,6 +590,21 @@ extern "C" int gatres_t_gat_aggregate_fwd(const gatres_graph_t* g, const void* h
   return gatres_launch_status();
 }
 
+template <typename T, typename IDX>
+static void launch_bwd_dst(const gatres_graph_t* g, const T* g_out, const T* h, const float* alpha, const float* a_src,
+                           const float* a_dst, float* g_e, float* g_a_dst, int N, const RowGeom& gm, void* stream) {
+#define GATRES_BWD_DST_LAUNCH(LHT_)                                                                                      \
+  hipLaunchKernelGGL((gat_aggregate_bwd_dst_kernel<T, IDX, LHT_>), dim3(grid_rows(N, gm.G)), dim3(256), 0,               \
+                     gatres_stream(stream), g->rowptr, g->col, g_out, h, alpha, a_src, a_dst, g_e, g_a_dst, N, gm)
+  switch (gm.C >> 2) {                         // lanes per head
+    case 8: GATRES_BWD_DST_LAUNCH(8); break;
+    case 16: GATRES_BWD_DST_LAUNCH(16); break;
+    case 32: GATRES_BWD_DST_LAUNCH(32); break;
+    default: GATRES_BWD_DST_LAUNCH(0); break;
+  }
+#undef GATRES_BWD_DST_LAUNCH
+}
+
 extern "C" int gatres_t_gat_aggregate_bwd_dst(const gatres_graph_t* g, const void* g_out, const void* h, const float* alpha,
                                    const float* a_src, const float* a_dst, float* g_e, float* g_a_dst, int H, int C,
                                    int dtype, void* stream) {
@@ -594,8 +615,7 @@ extern "C" int gatres_t_gat_aggregate_bwd_dst(const gatres_graph_t* g, const voi
   const int N = g->num_nodes;
   const bool fit32 = offsets_fit_32(g, gm.HC);
   GATRES_DISPATCH_T(dtype, fit32, {
-    hipLaunchKernelGGL((gat_aggregate_bwd_dst_kernel<T, IDX>), dim3(grid_rows(N, gm.G)), dim3(256), 0, gatres_stream(stream),
-                       g->rowptr, g->col, (const T*)g_out, (const T*)h, alpha, a_src, a_dst, g_e, g_a_dst, N, gm);
+    (launch_bwd_dst<T, IDX>)(g, (const T*)g_out, (const T*)h, alpha, a_src, a_dst, g_e, g_a_dst, N, gm, stream);
   })
   return gatres_launch_status();
 }
