@@ -432,20 +432,27 @@ __global__ __launch_bounds__(256, 8) void gat_aggregate_bwd_src_kernel(
 // ------------------------------------------------------------------------------------------------------
 // K3: out_i = relu( (sum_{j->i} y[j]) / max(indeg(i),1) + x0_i )       and its backward
 // ------------------------------------------------------------------------------------------------------
-template <typename T, typename IDX>
+// W = features per lane (4, or 8 for bf16 rows of 64 features and more: one 16-byte access, half the lanes per row).
+template <typename T, typename IDX, int W>
 __global__ __launch_bounds__(256, 8) void mean_residual_relu_fwd_kernel(
     const int* __restrict__ rowptr, const int* __restrict__ col, const T* __restrict__ y,
     const T* __restrict__ x0, T* __restrict__ out, int N, int C, int G, int lgG) {
   __shared__ __attribute__((aligned(16))) float hub_lds[4 * HUB_FLOATS_PER_WAVE];
-  const int lgHC = lgG + 2;
+  constexpr int LGW = W == 8 ? 3 : 2, Q = W / 4;
+  const int lgHC = lgG + LGW;
   GATRES_AGG_ADDRESSING(lgHC, 0)
+  auto rowldv = [&](const T* tab, int j, int c) { return ldrowv<W>(gatres_at<IDX>(tab, ((IDX)j << lgHC) + (IDX)c)); };
   const int tid = gatres_xcd_block(blockIdx.x, gridDim.x) * 256 + threadIdx.x;      // (XCD-local row ranges)
   int row = tid >> lgG;
   const bool valid = row < N;
   if (!valid) row = N - 1;
-  const int c0 = (tid & (G - 1)) * 4;
+  const int c0 = (tid & (G - 1)) * W;
   const int beg = ival(rowptr, row), end0 = ival(rowptr, row + 1);
-  float4 acc = f4zero();
+  gatres_rowv<W> acc = rowv_zero<W>();
+  auto add = [&](gatres_rowv<W>& a, const gatres_rowv<W>& v) {
+#pragma unroll
+    for (int q = 0; q < Q; ++q) { a.v[q].x = a.v[q].x + v.v[q].x; a.v[q].y = a.v[q].y + v.v[q].y; a.v[q].z = a.v[q].z + v.v[q].z; a.v[q].w = a.v[q].w + v.v[q].w; }
+  };
   const bool hub = valid && end0 - beg > HUB_MIN_DEGREE;                    // hub rows: whole wave + LDS-staged partial sums
   const unsigned long long hubs = __ballot(hub && c0 == 0);
   if (__builtin_expect(hubs != 0ULL, 0)) {
@@ -457,51 +464,59 @@ __global__ __launch_bounds__(256, 8) void mean_residual_relu_fwd_kernel(
       const int owner = __ffsll((long long)todo) - 1;
       todo &= todo - 1;
       const int hbeg = __shfl(beg, owner), hend = __shfl(end0, owner);
-      float4 part = f4zero();
-      _Pragma("unroll 2") for (int e = hbeg + slot; e < hend; e += S) {
-        const float4 v = rowld(y, ival(col, e), f * 4);
-        part.x = part.x + v.x; part.y = part.y + v.y; part.z = part.z + v.z; part.w = part.w + v.w;
-      }
-      const float4 sum = hub_reduce4(part, tile, G, S, f);
+      gatres_rowv<W> part = rowv_zero<W>();
+      _Pragma("unroll 2") for (int e = hbeg + slot; e < hend; e += S) add(part, rowldv(y, ival(col, e), f * W));
+      gatres_rowv<W> sum;
+#pragma unroll
+      for (int q = 0; q < Q; ++q) sum.v[q] = hub_reduce4(part.v[q], tile, G, S, f);
       if ((lane >> lgG) == (owner >> lgG)) acc = sum;
     }
   }
   const int end = hub ? beg : end0;
   int e = beg;
   for (; e + 1 < end; e += 2) {
-    const float4 v0 = rowld(y, ival(col, e), c0);
-    const float4 v1 = rowld(y, ival(col, e + 1), c0);
-    acc.x = acc.x + v0.x; acc.y = acc.y + v0.y; acc.z = acc.z + v0.z; acc.w = acc.w + v0.w;
-    acc.x = acc.x + v1.x; acc.y = acc.y + v1.y; acc.z = acc.z + v1.z; acc.w = acc.w + v1.w;
+    const gatres_rowv<W> v0 = rowldv(y, ival(col, e), c0);
+    const gatres_rowv<W> v1 = rowldv(y, ival(col, e + 1), c0);
+    add(acc, v0);
+    add(acc, v1);
   }
-  if (e < end) {
-    const float4 v0 = rowld(y, ival(col, e), c0);
-    acc.x = acc.x + v0.x; acc.y = acc.y + v0.y; acc.z = acc.z + v0.z; acc.w = acc.w + v0.w;
-  }
+  if (e < end) add(acc, rowldv(y, ival(col, e), c0));
   const float cnt = (float)max(end0 - beg, 1);
-  const float4 r = rowld(x0, row, c0);
-  float4 o;
-  o.x = fmaxf(acc.x / cnt + r.x, 0.f);
-  o.y = fmaxf(acc.y / cnt + r.y, 0.f);
-  o.z = fmaxf(acc.z / cnt + r.z, 0.f);
-  o.w = fmaxf(acc.w / cnt + r.w, 0.f);
-  if (valid) strow4(gatres_at_w<IDX>(out, ((IDX)row << lgHC) + (IDX)c0), o);
+  const gatres_rowv<W> r = rowldv(x0, row, c0);
+  gatres_rowv<W> o;
+#pragma unroll
+  for (int q = 0; q < Q; ++q) {
+    o.v[q].x = fmaxf(acc.v[q].x / cnt + r.v[q].x, 0.f);
+    o.v[q].y = fmaxf(acc.v[q].y / cnt + r.v[q].y, 0.f);
+    o.v[q].z = fmaxf(acc.v[q].z / cnt + r.v[q].z, 0.f);
+    o.v[q].w = fmaxf(acc.v[q].w / cnt + r.v[q].w, 0.f);
+  }
+  if (valid) strowv<W>(gatres_at_w<IDX>(out, ((IDX)row << lgHC) + (IDX)c0), o);
 }
 
-template <typename T, typename IDX>
+template <typename T, typename IDX, int W>
 __global__ __launch_bounds__(256, 8) void mean_bwd_kernel(
     const int* __restrict__ m_rowptr, const int* __restrict__ mt_rowptr, const int* __restrict__ mt_dst,
     const T* __restrict__ g_pre, T* __restrict__ g_y, int N, int C, int G, int lgG) {
   __shared__ __attribute__((aligned(16))) float hub_lds[4 * HUB_FLOATS_PER_WAVE];
-  const int lgHC = lgG + 2;
+  constexpr int LGW = W == 8 ? 3 : 2, Q = W / 4;
+  const int lgHC = lgG + LGW;
   GATRES_AGG_ADDRESSING(lgHC, 0)
+  auto rowldv = [&](const T* tab, int j, int c) { return ldrowv<W>(gatres_at<IDX>(tab, ((IDX)j << lgHC) + (IDX)c)); };
   const int tid = gatres_xcd_block(blockIdx.x, gridDim.x) * 256 + threadIdx.x;      // (XCD-local row ranges)
   int row = tid >> lgG;
   const bool valid = row < N;
   if (!valid) row = N - 1;
-  const int c0 = (tid & (G - 1)) * 4;
+  const int c0 = (tid & (G - 1)) * W;
   const int beg = ival(mt_rowptr, row), end0 = ival(mt_rowptr, row + 1);
-  float4 acc = f4zero();
+  gatres_rowv<W> acc = rowv_zero<W>();
+  auto add_div = [&](gatres_rowv<W>& a, const gatres_rowv<W>& v, float cnt) {
+#pragma unroll
+    for (int q = 0; q < Q; ++q) {
+      a.v[q].x = a.v[q].x + v.v[q].x / cnt; a.v[q].y = a.v[q].y + v.v[q].y / cnt;
+      a.v[q].z = a.v[q].z + v.v[q].z / cnt; a.v[q].w = a.v[q].w + v.v[q].w / cnt;
+    }
+  };
   const bool hub = valid && end0 - beg > HUB_MIN_DEGREE;                    // hub sources: whole wave + LDS-staged partial sums
   const unsigned long long hubs = __ballot(hub && c0 == 0);
   if (__builtin_expect(hubs != 0ULL, 0)) {
@@ -513,14 +528,15 @@ __global__ __launch_bounds__(256, 8) void mean_bwd_kernel(
       const int owner = __ffsll((long long)todo) - 1;
       todo &= todo - 1;
       const int hbeg = __shfl(beg, owner), hend = __shfl(end0, owner);
-      float4 part = f4zero();
+      gatres_rowv<W> part = rowv_zero<W>();
       _Pragma("unroll 2") for (int t = hbeg + slot; t < hend; t += S) {
         const int i = ival(mt_dst, t);
         const float cnt = (float)max(ival(m_rowptr, i + 1) - ival(m_rowptr, i), 1);
-        const float4 v = rowld(g_pre, i, f * 4);
-        part.x = part.x + v.x / cnt; part.y = part.y + v.y / cnt; part.z = part.z + v.z / cnt; part.w = part.w + v.w / cnt;
+        add_div(part, rowldv(g_pre, i, f * W), cnt);
       }
-      const float4 sum = hub_reduce4(part, tile, G, S, f);
+      gatres_rowv<W> sum;
+#pragma unroll
+      for (int q = 0; q < Q; ++q) sum.v[q] = hub_reduce4(part.v[q], tile, G, S, f);
       if ((lane >> lgG) == (owner >> lgG)) acc = sum;
     }
   }
@@ -528,15 +544,19 @@ __global__ __launch_bounds__(256, 8) void mean_bwd_kernel(
   for (int t = beg; t < end; ++t) {
     const int i = ival(mt_dst, t);
     const float cnt = (float)max(ival(m_rowptr, i + 1) - ival(m_rowptr, i), 1);
-    const float4 v = rowld(g_pre, i, c0);
-    acc.x = acc.x + v.x / cnt; acc.y = acc.y + v.y / cnt; acc.z = acc.z + v.z / cnt; acc.w = acc.w + v.w / cnt;
+    add_div(acc, rowldv(g_pre, i, c0), cnt);
   }
-  if (valid) strow4(gatres_at_w<IDX>(g_y, ((IDX)row << lgHC) + (IDX)c0), acc);
+  if (valid) strowv<W>(gatres_at_w<IDX>(g_y, ((IDX)row << lgHC) + (IDX)c0), acc);
 }
 
 static inline bool graph_ok(const gatres_graph_t* g) {
   return g && g->num_nodes > 0 && g->rowptr && g->col && g->t_rowptr && g->t_eid && g->t_dst && g->m_rowptr &&
          g->m_col && g->mt_rowptr && g->mt_dst;
+}
+
+// eight features per lane: bf16 rows of 64 features and more (one 16-byte access per lane, half the lanes per row)
+static inline bool wide_lanes(int dtype, int row_width) {
+  return dtype == GATRES_DTYPE_BF16 && row_width >= 64 && !getenv("GATRES_AGG_NARROW_LANES");
 }
 
 static inline int grid_rows(int N, int G) {
@@ -645,10 +665,19 @@ extern "C" int gatres_t_mean_residual_relu_fwd(const gatres_graph_t* g, const vo
   if (!graph_ok(g) || !y || !x0 || !out) return GATRES_E_BADARG;
   if (!gatres_aligned16(y) || !gatres_aligned16(x0) || !gatres_aligned16(out)) return GATRES_E_BADARG;
   if (C < 4 || !gatres_is_pow2(C) || C > 256) return GATRES_E_UNSUPPORTED;
-  const int G = C / 4, N = g->num_nodes;
+  const int N = g->num_nodes;
   const bool fit32 = offsets_fit_32(g, C);
+  if (wide_lanes(dtype, C)) {
+    const int G = C / 8;
+    GATRES_DISPATCH_T(dtype, fit32, {
+      hipLaunchKernelGGL((mean_residual_relu_fwd_kernel<T, IDX, 8>), dim3(grid_rows(N, G)), dim3(256), 0,
+                         gatres_stream(stream), g->m_rowptr, g->m_col, (const T*)y, (const T*)x0, (T*)out, N, C, G, ilog2(G));
+    })
+    return gatres_launch_status();
+  }
+  const int G = C / 4;
   GATRES_DISPATCH_T(dtype, fit32, {
-    hipLaunchKernelGGL((mean_residual_relu_fwd_kernel<T, IDX>), dim3(grid_rows(N, G)), dim3(256), 0, gatres_stream(stream),
+    hipLaunchKernelGGL((mean_residual_relu_fwd_kernel<T, IDX, 4>), dim3(grid_rows(N, G)), dim3(256), 0, gatres_stream(stream),
                        g->m_rowptr, g->m_col, (const T*)y, (const T*)x0, (T*)out, N, C, G, ilog2(G));
   })
   return gatres_launch_status();
@@ -658,10 +687,19 @@ extern "C" int gatres_t_mean_bwd(const gatres_graph_t* g, const void* g_pre, voi
   if (!graph_ok(g) || !g_pre || !g_y) return GATRES_E_BADARG;
   if (!gatres_aligned16(g_pre) || !gatres_aligned16(g_y)) return GATRES_E_BADARG;
   if (C < 4 || !gatres_is_pow2(C) || C > 256) return GATRES_E_UNSUPPORTED;
-  const int G = C / 4, N = g->num_nodes;
+  const int N = g->num_nodes;
   const bool fit32 = offsets_fit_32(g, C);
+  if (wide_lanes(dtype, C)) {
+    const int G = C / 8;
+    GATRES_DISPATCH_T(dtype, fit32, {
+      hipLaunchKernelGGL((mean_bwd_kernel<T, IDX, 8>), dim3(grid_rows(N, G)), dim3(256), 0, gatres_stream(stream),
+                         g->m_rowptr, g->mt_rowptr, g->mt_dst, (const T*)g_pre, (T*)g_y, N, C, G, ilog2(G));
+    })
+    return gatres_launch_status();
+  }
+  const int G = C / 4;
   GATRES_DISPATCH_T(dtype, fit32, {
-    hipLaunchKernelGGL((mean_bwd_kernel<T, IDX>), dim3(grid_rows(N, G)), dim3(256), 0, gatres_stream(stream), g->m_rowptr,
+    hipLaunchKernelGGL((mean_bwd_kernel<T, IDX, 4>), dim3(grid_rows(N, G)), dim3(256), 0, gatres_stream(stream), g->m_rowptr,
                        g->mt_rowptr, g->mt_dst, (const T*)g_pre, (T*)g_y, N, C, G, ilog2(G));
   })
   return gatres_launch_status();
