@@ -23,13 +23,18 @@ struct RowGeom {
 
 static inline int ilog2(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
 
-static inline bool make_geom(int H, int C, RowGeom* g) {
-  if (H < 1 || C < 4 || !gatres_is_pow2(C) || !gatres_is_pow2(H)) return false;
+static inline bool make_geom(int H, int C, RowGeom* g, int W = 4) {      // W = features per lane: a row has G = HC / W lanes
+  if (H < 1 || C < W || !gatres_is_pow2(C) || !gatres_is_pow2(H)) return false;
   int HC = H * C;
   if (HC > 256) return false;
   g->HC = HC; g->C = C; g->lgC = ilog2(C); g->H = H;
-  g->G = HC / 4; g->lgG = ilog2(g->G);
+  g->G = HC / W; g->lgG = ilog2(g->G);
   return true;
+}
+
+// eight features per lane: bf16 rows of 64 features and more (one 16-byte access per lane, half the lanes per row)
+static inline bool wide_lanes(int dtype, int row_width) {
+  return dtype == GATRES_DTYPE_BF16 && row_width >= 64 && !getenv("GATRES_AGG_NARROW_LANES");
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -95,25 +100,34 @@ __device__ __forceinline__ T* gatres_at_w(T* base, IDX elem) {
 // ------------------------------------------------------------------------------------------------------
 // K2 forward
 // ------------------------------------------------------------------------------------------------------
-template <bool RELU, typename T, typename IDX>
-__global__ __launch_bounds__(256, 8) void gat_aggregate_fwd_kernel(
+// W = features per lane (4; 8 for bf16 rows of 64 features and more: one 16-byte access per lane, half the lanes per row --
+// the lanes of a row all repeat its scalar work, which is what bounds these kernels)
+template <bool RELU, typename T, typename IDX, int W>
+__global__ __launch_bounds__(256, W == 8 ? 5 : 8) void gat_aggregate_fwd_kernel(
     const int* __restrict__ rowptr, const int* __restrict__ col, const T* __restrict__ h,
     const float* __restrict__ a_src, const float* __restrict__ a_dst, const float* __restrict__ bias,
     T* __restrict__ out, float* __restrict__ alpha, int N, RowGeom gm) {
   __shared__ __attribute__((aligned(16))) float hub_lds[4 * HUB_FLOATS_PER_WAVE];
-  const int lgHC = gm.lgG + 2, lgH = lgHC - gm.lgC;
+  constexpr int LGW = W == 8 ? 3 : 2, Q = W / 4;
+  const int lgHC = gm.lgG + LGW, lgH = lgHC - gm.lgC;
   GATRES_AGG_ADDRESSING(lgHC, lgH)
+  auto rowldv = [&](const T* tab, int j, int c) { return ldrowv<W>(gatres_at<IDX>(tab, ((IDX)j << lgHC) + (IDX)c)); };
+  auto axpyv = [&](gatres_rowv<W>& a, float s, const gatres_rowv<W>& v) {
+#pragma unroll
+    for (int q = 0; q < Q; ++q) gatres_axpy4(a.v[q], s, v.v[q]);
+  };
+  (void)axpyv; (void)rowldv;
   const int tid = gatres_xcd_block(blockIdx.x, gridDim.x) * 256 + threadIdx.x;      // (XCD-local row ranges)
   int row = tid >> gm.lgG;
   const bool valid = row < N;                  // (every lane stays: hub rows are processed by the whole wave)
   if (!valid) row = N - 1;
-  const int c0 = (tid & (gm.G - 1)) * 4;
+  const int c0 = (tid & (gm.G - 1)) * W;
   const int hd = c0 >> gm.lgC;
   const bool leader = valid && (c0 & (gm.C - 1)) == 0;
   const int H = gm.H, HC = gm.HC;
   const int beg = ival(rowptr, row), end = ival(rowptr, row + 1);
   const float adst = hval(a_dst, row, hd);
-  float4 acc = f4zero();
+  gatres_rowv<W> acc = rowv_zero<W>();
   constexpr int MAXD = 6;                      // rows with <= 6 in-edges (every water-network row): slot path
   const bool hub = valid && end - beg > HUB_MIN_DEGREE;
   const unsigned long long hubs = __ballot(hub && c0 == 0);         // first lane of every hub row in this wave
@@ -126,7 +140,7 @@ __global__ __launch_bounds__(256, 8) void gat_aggregate_fwd_kernel(
       const int owner = __ffsll((long long)todo) - 1;                 // first lane of the hub row's lane group
       todo &= todo - 1;
       const int hrow = __shfl(row, owner), hbeg = __shfl(beg, owner), hend = __shfl(end, owner);
-      const int fc0 = f * 4, fhd = fc0 >> gm.lgC;
+      const int fc0 = f * W, fhd = fc0 >> gm.lgC;
       const bool fleader = (fc0 & (gm.C - 1)) == 0;
       const float hadst = hval(a_dst, hrow, fhd);
       float m = -INFINITY;
@@ -135,14 +149,15 @@ __global__ __launch_bounds__(256, 8) void gat_aggregate_fwd_kernel(
       float z = 0.f;
       _Pragma("unroll 2") for (int e = hbeg + slot; e < hend; e += S) z = z + expf(gatres_leaky(hval(a_src, ival(col, e), fhd) + hadst) - m);
       const float Z = hub_reduce1<false>(z, tile, G, S, f) + GATRES_SOFTMAX_EPS;
-      float4 part = f4zero();
+      gatres_rowv<W> part = rowv_zero<W>();
       _Pragma("unroll 2") for (int e = hbeg + slot; e < hend; e += S) {
         const int j = ival(col, e);
         const float al = expf(gatres_leaky(hval(a_src, j, fhd) + hadst) - m) / Z;
         if (fleader) *hptr(alpha, e, fhd) = al;
-        gatres_axpy4(part, al, rowld(h, j, fc0));
+        axpyv(part, al, rowldv(h, j, fc0));
       }
-      const float4 sum = hub_reduce4(part, tile, G, S, f);
+      gatres_rowv<W> sum;
+      _Pragma("unroll") for (int q = 0; q < Q; ++q) sum.v[q] = hub_reduce4(part.v[q], tile, G, S, f);
       if ((lane >> gm.lgG) == (owner >> gm.lgG)) acc = sum;            // the row's own lanes keep it (f == their feature lane)
     }
   }
@@ -157,11 +172,11 @@ __global__ __launch_bounds__(256, 8) void gat_aggregate_fwd_kernel(
 #pragma unroll
     for (int k = 0; k < MAXD; ++k) jj[k] = ival(col, beg + min(k, deg - 1));
     float so[MAXD];
-    float4 v[MAXD];
+    gatres_rowv<W> v[MAXD];
     float m = -INFINITY;
 #pragma unroll
     for (int k = 0; k < MAXD; ++k) {
-      v[k] = rowld(h, jj[k], c0);
+      v[k] = rowldv(h, jj[k], c0);
       const float sv = gatres_leaky(hval(a_src, jj[k], hd) + adst);
       so[k] = k < deg ? sv : -INFINITY;
     }
@@ -179,7 +194,7 @@ __global__ __launch_bounds__(256, 8) void gat_aggregate_fwd_kernel(
       const float al = so[k] / Z;
       if (k < deg) {
         if (leader) *hptr(alpha, (beg + k), hd) = al;
-        gatres_axpy4(acc, al, v[k]);
+        axpyv(acc, al, v[k]);
       }
     }
   } else {                                     // up to HUB_MIN_DEGREE in-edges: the row's own lanes, edge after edge
@@ -199,28 +214,30 @@ __global__ __launch_bounds__(256, 8) void gat_aggregate_fwd_kernel(
   // two edges per trip so both neighbour rows are in flight together
   for (; e + 1 < end; e += 2) {
     const int j0 = ival(col, e), j1 = ival(col, e + 1);
-    const float4 v0 = rowld(h, j0, c0);
-    const float4 v1 = rowld(h, j1, c0);
+    const gatres_rowv<W> v0 = rowldv(h, j0, c0);
+    const gatres_rowv<W> v1 = rowldv(h, j1, c0);
     const float al0 = expf(gatres_leaky(hval(a_src, j0, hd) + adst) - m) / Z;
     const float al1 = expf(gatres_leaky(hval(a_src, j1, hd) + adst) - m) / Z;
     if (leader) { *hptr(alpha, e, hd) = al0; *hptr(alpha, (e + 1), hd) = al1; }
-    gatres_axpy4(acc, al0, v0);
-    gatres_axpy4(acc, al1, v1);
+    axpyv(acc, al0, v0);
+    axpyv(acc, al1, v1);
   }
   if (e < end) {
     const int j0 = ival(col, e);
-    const float4 v0 = rowld(h, j0, c0);
+    const gatres_rowv<W> v0 = rowldv(h, j0, c0);
     const float al0 = expf(gatres_leaky(hval(a_src, j0, hd) + adst) - m) / Z;
     if (leader) *hptr(alpha, e, hd) = al0;
-    gatres_axpy4(acc, al0, v0);
+    axpyv(acc, al0, v0);
   }
   }
-  const float4 b = ld4(bias + c0);
-  acc.x = acc.x + b.x; acc.y = acc.y + b.y; acc.z = acc.z + b.z; acc.w = acc.w + b.w;
-  if (RELU) {
-    acc.x = fmaxf(acc.x, 0.f); acc.y = fmaxf(acc.y, 0.f); acc.z = fmaxf(acc.z, 0.f); acc.w = fmaxf(acc.w, 0.f);
+#pragma unroll
+  for (int q = 0; q < Q; ++q) {
+    const float4 b = ld4(bias + c0 + 4 * q);
+    float4& a = acc.v[q];
+    a.x = a.x + b.x; a.y = a.y + b.y; a.z = a.z + b.z; a.w = a.w + b.w;
+    if (RELU) { a.x = fmaxf(a.x, 0.f); a.y = fmaxf(a.y, 0.f); a.z = fmaxf(a.z, 0.f); a.w = fmaxf(a.w, 0.f); }
   }
-  if (valid) strow4(gatres_at_w<IDX>(out, ((IDX)row << lgHC) + (IDX)c0), acc);
+  if (valid) strowv<W>(gatres_at_w<IDX>(out, ((IDX)row << lgHC) + (IDX)c0), acc);
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -231,8 +248,7 @@ __global__ __launch_bounds__(256, 8) void gat_aggregate_fwd_kernel(
 //   g_e   = gs_e * (raw_e > 0 ? 1 : 0.2)        LeakyReLU backward,  raw_e = a_src[j] + a_dst[i]
 //   g_a_dst[i] = sum_e g_e
 // ------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ float head_dot(const float4 a, const float4 b, int lanes_per_head) {
-  const float d = gatres_head_dot4(a, b);
+__device__ __forceinline__ float head_reduce_any(float d, int lanes_per_head) {
   switch (lanes_per_head) {                      // wave-uniform
     case 1: return d;
     case 2: return gatres_head_reduce<2>(d);
@@ -243,27 +259,40 @@ __device__ __forceinline__ float head_dot(const float4 a, const float4 b, int la
   }
 }
 
-// LHT: the lanes per head (C / 4) as a compile-time constant for the model widths (8, 16, 32), 0 = any (wave-uniform switch
+// LHT: the lanes per head (C / W) as a compile-time constant for the model widths (8, 16, 32), 0 = any (wave-uniform switch
 // per dot: ~40 scalar branches per row)
-template <typename T, typename IDX, int LHT>
-__global__ __launch_bounds__(256, 7) void gat_aggregate_bwd_dst_kernel(
+template <typename T, typename IDX, int W, int LHT>
+__global__ __launch_bounds__(256, W == 8 ? 4 : 7) void gat_aggregate_bwd_dst_kernel(
     const int* __restrict__ rowptr, const int* __restrict__ col, const T* __restrict__ g_out,
     const T* __restrict__ h, const float* __restrict__ alpha, const float* __restrict__ a_src,
     const float* __restrict__ a_dst, float* __restrict__ g_e, float* __restrict__ g_a_dst, int N, RowGeom gm) {
   __shared__ __attribute__((aligned(16))) float hub_lds[4 * HUB_FLOATS_PER_WAVE];
-  const int lgHC = gm.lgG + 2, lgH = lgHC - gm.lgC;
+  constexpr int LGW = W == 8 ? 3 : 2, Q = W / 4;
+  const int lgHC = gm.lgG + LGW, lgH = lgHC - gm.lgC;
   GATRES_AGG_ADDRESSING(lgHC, lgH)
+  auto rowldv = [&](const T* tab, int j, int c) { return ldrowv<W>(gatres_at<IDX>(tab, ((IDX)j << lgHC) + (IDX)c)); };
+  auto axpyv = [&](gatres_rowv<W>& a, float s, const gatres_rowv<W>& v) {
+#pragma unroll
+    for (int q = 0; q < Q; ++q) gatres_axpy4(a.v[q], s, v.v[q]);
+  };
+  (void)axpyv; (void)rowldv;
   const int tid = gatres_xcd_block(blockIdx.x, gridDim.x) * 256 + threadIdx.x;      // (XCD-local row ranges)
   int row = tid >> gm.lgG;
   const bool valid = row < N;
   if (!valid) row = N - 1;              // keep every lane alive for the shuffles; stores are predicated
-  const int c0 = (tid & (gm.G - 1)) * 4;
+  const int c0 = (tid & (gm.G - 1)) * W;
   const int hd = c0 >> gm.lgC;
   const bool leader = valid && (c0 & (gm.C - 1)) == 0;
-  const int H = gm.H, HC = gm.HC, LH = gm.C >> 2;
-  auto hdot = [&](const float4 a, const float4 b) {
-    if constexpr (LHT != 0) return gatres_head_reduce<LHT>(gatres_head_dot4(a, b));
-    else return head_dot(a, b, LH);
+  const int H = gm.H, HC = gm.HC, LH = gm.C >> LGW;      // lanes per head
+  auto hdot = [&](const gatres_rowv<W>& a, const gatres_rowv<W>& b) {
+    float d = gatres_head_dot4(a.v[0], b.v[0]);
+#pragma unroll
+    for (int q = 1; q < Q; ++q) {
+      d = fmaf(a.v[q].x, b.v[q].x, d); d = fmaf(a.v[q].y, b.v[q].y, d);
+      d = fmaf(a.v[q].z, b.v[q].z, d); d = fmaf(a.v[q].w, b.v[q].w, d);
+    }
+    if constexpr (LHT != 0) return gatres_head_reduce<LHT>(d);
+    else return head_reduce_any(d, LH);
   };
   const int beg = ival(rowptr, row), end = ival(rowptr, row + 1);
   float S = 0.f, gad = 0.f;
@@ -278,20 +307,20 @@ __global__ __launch_bounds__(256, 7) void gat_aggregate_bwd_dst_kernel(
       const int owner = __ffsll((long long)todo) - 1;
       todo &= todo - 1;
       const int hrow = __shfl(row, owner), hbeg = __shfl(beg, owner), hend = __shfl(end, owner);
-      const int fc0 = f * 4, fhd = fc0 >> gm.lgC;
+      const int fc0 = f * W, fhd = fc0 >> gm.lgC;
       const bool fleader = (fc0 & (gm.C - 1)) == 0;
-      const float4 hgo = rowld(g_out, hrow, fc0);
+      const gatres_rowv<W> hgo = rowldv(g_out, hrow, fc0);
       const float hadst = hval(a_dst, hrow, fhd);
       float sp = 0.f;
       for (int e = hbeg + slot; e < hend; e += S) {
-        const float ga = hdot(hgo, rowld(h, ival(col, e), fc0));
+        const float ga = hdot(hgo, rowldv(h, ival(col, e), fc0));
         sp = fmaf(hval(alpha, e, fhd), ga, sp);
       }
       const float Ss = hub_reduce1<false>(sp, tile, G, S, f);
       float gp = 0.f;
       for (int e = hbeg + slot; e < hend; e += S) {
         const int j = ival(col, e);
-        const float ga = hdot(hgo, rowld(h, j, fc0));
+        const float ga = hdot(hgo, rowldv(h, j, fc0));
         const float gs = hval(alpha, e, fhd) * (ga - Ss);
         const float raw = hval(a_src, j, fhd) + hadst;
         const float ge = raw > 0.f ? gs : gs * GATRES_NEG_SLOPE;
@@ -302,18 +331,18 @@ __global__ __launch_bounds__(256, 7) void gat_aggregate_bwd_dst_kernel(
       if ((lane >> gm.lgG) == (owner >> gm.lgG)) gad = gsum;
     }
   }
-  const float4 go = rowld(g_out, row, c0);
+  const gatres_rowv<W> go = rowldv(g_out, row, c0);
   const float adst = hval(a_dst, row, hd);
   if (end - beg <= 8) {                        // the common case: every load of the row issued together (slot path)
     const int deg = end - beg;
     int jj[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) jj[k] = ival(col, beg + min(k, deg - 1));
-    float4 hv[8];
+    gatres_rowv<W> hv[8];
     float al[8], as[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
-      hv[k] = rowld(h, jj[k], c0);
+      hv[k] = rowldv(h, jj[k], c0);
       al[k] = hval(alpha, (beg + min(k, deg - 1)), hd);
       as[k] = hval(a_src, jj[k], hd);
     }
@@ -335,12 +364,12 @@ __global__ __launch_bounds__(256, 7) void gat_aggregate_bwd_dst_kernel(
     }
   } else if (end - beg <= HUB_MIN_DEGREE) {    // the row's own lanes, edge after edge; the dots are recomputed in the second pass
     for (int e = beg; e < end; ++e) {
-      const float ga = hdot(go, rowld(h, ival(col, e), c0));
+      const float ga = hdot(go, rowldv(h, ival(col, e), c0));
       S = fmaf(hval(alpha, e, hd), ga, S);
     }
     for (int e = beg; e < end; ++e) {
       const int j = ival(col, e);
-      const float ga = hdot(go, rowld(h, j, c0));
+      const float ga = hdot(go, rowldv(h, j, c0));
       const float gs = hval(alpha, e, hd) * (ga - S);
       const float raw = hval(a_src, j, hd) + adst;
       const float ge = raw > 0.f ? gs : gs * GATRES_NEG_SLOPE;
@@ -356,25 +385,32 @@ __global__ __launch_bounds__(256, 7) void gat_aggregate_bwd_dst_kernel(
 //   g_a_src[j] = sum_{e out of j} g_e
 //   g_h[j]     = sum_{e=(j->i)} alpha_e * g_out[i]  +  g_a_src[j] (x) att_src  +  g_a_dst[j] (x) att_dst
 // ------------------------------------------------------------------------------------------------------
-template <typename T, typename IDX>
-__global__ __launch_bounds__(256, 8) void gat_aggregate_bwd_src_kernel(
+template <typename T, typename IDX, int W>
+__global__ __launch_bounds__(256, W == 8 ? 6 : 8) void gat_aggregate_bwd_src_kernel(
     const int* __restrict__ t_rowptr, const int* __restrict__ t_eid, const int* __restrict__ t_dst,
     const T* __restrict__ g_out, const float* __restrict__ alpha, const float* __restrict__ g_e,
     const float* __restrict__ g_a_dst, const float* __restrict__ att_src, const float* __restrict__ att_dst,
     T* __restrict__ g_h, float* __restrict__ g_a_src, int N, RowGeom gm) {
   __shared__ __attribute__((aligned(16))) float hub_lds[4 * HUB_FLOATS_PER_WAVE];
-  const int lgHC = gm.lgG + 2, lgH = lgHC - gm.lgC;
+  constexpr int LGW = W == 8 ? 3 : 2, Q = W / 4;
+  const int lgHC = gm.lgG + LGW, lgH = lgHC - gm.lgC;
   GATRES_AGG_ADDRESSING(lgHC, lgH)
+  auto rowldv = [&](const T* tab, int j, int c) { return ldrowv<W>(gatres_at<IDX>(tab, ((IDX)j << lgHC) + (IDX)c)); };
+  auto axpyv = [&](gatres_rowv<W>& a, float s, const gatres_rowv<W>& v) {
+#pragma unroll
+    for (int q = 0; q < Q; ++q) gatres_axpy4(a.v[q], s, v.v[q]);
+  };
+  (void)axpyv; (void)rowldv;
   const int tid = gatres_xcd_block(blockIdx.x, gridDim.x) * 256 + threadIdx.x;      // (XCD-local row ranges)
   int row = tid >> gm.lgG;
   const bool valid = row < N;
   if (!valid) row = N - 1;
-  const int c0 = (tid & (gm.G - 1)) * 4;
+  const int c0 = (tid & (gm.G - 1)) * W;
   const int hd = c0 >> gm.lgC;
   const bool leader = valid && (c0 & (gm.C - 1)) == 0;
   const int H = gm.H, HC = gm.HC;
   const int beg = ival(t_rowptr, row), end0 = ival(t_rowptr, row + 1);
-  float4 acc = f4zero();
+  gatres_rowv<W> acc = rowv_zero<W>();
   float gas = 0.f;
   // hub sources (more than HUB_MIN_DEGREE out-edges): the whole wave, S edge slots of G lanes, partial sums through LDS
   const bool hub = valid && end0 - beg > HUB_MIN_DEGREE;
@@ -388,15 +424,16 @@ __global__ __launch_bounds__(256, 8) void gat_aggregate_bwd_src_kernel(
       const int owner = __ffsll((long long)todo) - 1;
       todo &= todo - 1;
       const int hbeg = __shfl(beg, owner), hend = __shfl(end0, owner);
-      const int fc0 = f * 4, fhd = fc0 >> gm.lgC;
-      float4 part = f4zero();
+      const int fc0 = f * W, fhd = fc0 >> gm.lgC;
+      gatres_rowv<W> part = rowv_zero<W>();
       float gp = 0.f;
       _Pragma("unroll 2") for (int tt = hbeg + slot; tt < hend; tt += S) {
         const int e = ival(t_eid, tt), i = ival(t_dst, tt);
         gp = gp + hval(g_e, e, fhd);
-        gatres_axpy4(part, hval(alpha, e, fhd), rowld(g_out, i, fc0));
+        axpyv(part, hval(alpha, e, fhd), rowldv(g_out, i, fc0));
       }
-      const float4 sum = hub_reduce4(part, tile, G, S, f);
+      gatres_rowv<W> sum;
+      _Pragma("unroll") for (int q = 0; q < Q; ++q) sum.v[q] = hub_reduce4(part.v[q], tile, G, S, f);
       const float gsum = hub_reduce1<false>(gp, tile, G, S, f);
       if ((lane >> gm.lgG) == (owner >> gm.lgG)) { acc = sum; gas = gsum; }
     }
@@ -406,27 +443,30 @@ __global__ __launch_bounds__(256, 8) void gat_aggregate_bwd_src_kernel(
   for (; t + 1 < end; t += 2) {
     const int e0 = ival(t_eid, t), e1 = ival(t_eid, t + 1);
     const int i0 = ival(t_dst, t), i1 = ival(t_dst, t + 1);
-    const float4 v0 = rowld(g_out, i0, c0);
-    const float4 v1 = rowld(g_out, i1, c0);
+    const gatres_rowv<W> v0 = rowldv(g_out, i0, c0);
+    const gatres_rowv<W> v1 = rowldv(g_out, i1, c0);
     const float al0 = hval(alpha, e0, hd), al1 = hval(alpha, e1, hd);
     gas = gas + hval(g_e, e0, hd);
     gas = gas + hval(g_e, e1, hd);
-    gatres_axpy4(acc, al0, v0);
-    gatres_axpy4(acc, al1, v1);
+    axpyv(acc, al0, v0);
+    axpyv(acc, al1, v1);
   }
   if (t < end) {
     const int e0 = ival(t_eid, t), i0 = ival(t_dst, t);
-    const float4 v0 = rowld(g_out, i0, c0);
+    const gatres_rowv<W> v0 = rowldv(g_out, i0, c0);
     const float al0 = hval(alpha, e0, hd);
     gas = gas + hval(g_e, e0, hd);
-    gatres_axpy4(acc, al0, v0);
+    axpyv(acc, al0, v0);
   }
   if (leader) *hptr(g_a_src, row, hd) = gas;
   const float gad = hval(g_a_dst, row, hd);
-  const float4 as = ld4(att_src + c0), ad = ld4(att_dst + c0);
-  gatres_axpy4(acc, gas, as);
-  gatres_axpy4(acc, gad, ad);
-  if (valid) strow4(gatres_at_w<IDX>(g_h, ((IDX)row << lgHC) + (IDX)c0), acc);
+#pragma unroll
+  for (int q = 0; q < Q; ++q) {
+    const float4 as = ld4(att_src + c0 + 4 * q), ad = ld4(att_dst + c0 + 4 * q);
+    gatres_axpy4(acc.v[q], gas, as);
+    gatres_axpy4(acc.v[q], gad, ad);
+  }
+  if (valid) strowv<W>(gatres_at_w<IDX>(g_h, ((IDX)row << lgHC) + (IDX)c0), acc);
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -554,11 +594,6 @@ static inline bool graph_ok(const gatres_graph_t* g) {
          g->m_col && g->mt_rowptr && g->mt_dst;
 }
 
-// eight features per lane: bf16 rows of 64 features and more (one 16-byte access per lane, half the lanes per row)
-static inline bool wide_lanes(int dtype, int row_width) {
-  return dtype == GATRES_DTYPE_BF16 && row_width >= 64 && !getenv("GATRES_AGG_NARROW_LANES");
-}
-
 static inline int grid_rows(int N, int G) {
   const long long threads = (long long)N * G;
   return (int)((threads + 255) / 256);
@@ -581,6 +616,10 @@ static inline int grid_rows(int N, int G) {
     default: return GATRES_E_UNSUPPORTED;                                                              \
   }
 
+#define GATRES_DISPATCH_WIDE(fit32_, CALL_)                                                             \
+  if (fit32_) { using T = gatres_bf16; using IDX = unsigned; CALL_; }                                  \
+  else { using T = gatres_bf16; using IDX = size_t; CALL_; }
+
 // every byte offset into a [rows or edges] x width table of 4-byte elements fits 32 bits (the IDX = unsigned instances)
 static inline bool offsets_fit_32(const gatres_graph_t* g, int width) {
   long long most = g->num_nodes;
@@ -594,29 +633,43 @@ extern "C" int gatres_t_gat_aggregate_fwd(const gatres_graph_t* g, const void* h
                                void* stream) {
   if (!graph_ok(g) || !h || !a_src || !a_dst || !bias || !out || !alpha) return GATRES_E_BADARG;
   if (!gatres_aligned16(h) || !gatres_aligned16(out) || !gatres_aligned16(bias)) return GATRES_E_BADARG;
-  RowGeom gm;
-  if (!make_geom(H, C, &gm)) return GATRES_E_UNSUPPORTED;
   const int N = g->num_nodes;
+  RowGeom gm;
+  if (wide_lanes(dtype, H * C) && make_geom(H, C, &gm, 8)) {
+    const bool fit32 = offsets_fit_32(g, gm.HC);
+    dim3 grid(grid_rows(N, gm.G)), block(256);
+    GATRES_DISPATCH_WIDE(fit32, {
+      if (apply_relu)
+        hipLaunchKernelGGL((gat_aggregate_fwd_kernel<true, T, IDX, 8>), grid, block, 0, gatres_stream(stream), g->rowptr,
+                           g->col, (const T*)h, a_src, a_dst, bias, (T*)out, alpha, N, gm);
+      else
+        hipLaunchKernelGGL((gat_aggregate_fwd_kernel<false, T, IDX, 8>), grid, block, 0, gatres_stream(stream), g->rowptr,
+                           g->col, (const T*)h, a_src, a_dst, bias, (T*)out, alpha, N, gm);
+    })
+    return gatres_launch_status();
+  }
+  if (!make_geom(H, C, &gm)) return GATRES_E_UNSUPPORTED;
   const bool fit32 = offsets_fit_32(g, gm.HC);
   dim3 grid(grid_rows(N, gm.G)), block(256);
   GATRES_DISPATCH_T(dtype, fit32, {
     if (apply_relu)
-      hipLaunchKernelGGL((gat_aggregate_fwd_kernel<true, T, IDX>), grid, block, 0, gatres_stream(stream), g->rowptr, g->col,
+      hipLaunchKernelGGL((gat_aggregate_fwd_kernel<true, T, IDX, 4>), grid, block, 0, gatres_stream(stream), g->rowptr, g->col,
                          (const T*)h, a_src, a_dst, bias, (T*)out, alpha, N, gm);
     else
-      hipLaunchKernelGGL((gat_aggregate_fwd_kernel<false, T, IDX>), grid, block, 0, gatres_stream(stream), g->rowptr, g->col,
+      hipLaunchKernelGGL((gat_aggregate_fwd_kernel<false, T, IDX, 4>), grid, block, 0, gatres_stream(stream), g->rowptr, g->col,
                          (const T*)h, a_src, a_dst, bias, (T*)out, alpha, N, gm);
   })
   return gatres_launch_status();
 }
 
-template <typename T, typename IDX>
+template <typename T, typename IDX, int W>
 static void launch_bwd_dst(const gatres_graph_t* g, const T* g_out, const T* h, const float* alpha, const float* a_src,
                            const float* a_dst, float* g_e, float* g_a_dst, int N, const RowGeom& gm, void* stream) {
 #define GATRES_BWD_DST_LAUNCH(LHT_)                                                                                      \
-  hipLaunchKernelGGL((gat_aggregate_bwd_dst_kernel<T, IDX, LHT_>), dim3(grid_rows(N, gm.G)), dim3(256), 0,               \
+  hipLaunchKernelGGL((gat_aggregate_bwd_dst_kernel<T, IDX, W, LHT_>), dim3(grid_rows(N, gm.G)), dim3(256), 0,            \
                      gatres_stream(stream), g->rowptr, g->col, g_out, h, alpha, a_src, a_dst, g_e, g_a_dst, N, gm)
-  switch (gm.C >> 2) {                         // lanes per head
+  switch (gm.C / W) {                          // lanes per head
+    case 4: GATRES_BWD_DST_LAUNCH(4); break;
     case 8: GATRES_BWD_DST_LAUNCH(8); break;
     case 16: GATRES_BWD_DST_LAUNCH(16); break;
     case 32: GATRES_BWD_DST_LAUNCH(32); break;
@@ -631,11 +684,18 @@ extern "C" int gatres_t_gat_aggregate_bwd_dst(const gatres_graph_t* g, const voi
   if (!graph_ok(g) || !g_out || !h || !alpha || !a_src || !a_dst || !g_e || !g_a_dst) return GATRES_E_BADARG;
   if (!gatres_aligned16(h) || !gatres_aligned16(g_out)) return GATRES_E_BADARG;
   RowGeom gm;
-  if (!make_geom(H, C, &gm)) return GATRES_E_UNSUPPORTED;
   const int N = g->num_nodes;
+  if (wide_lanes(dtype, H * C) && make_geom(H, C, &gm, 8)) {
+    const bool fit32 = offsets_fit_32(g, gm.HC);
+    GATRES_DISPATCH_WIDE(fit32, {
+      (launch_bwd_dst<T, IDX, 8>)(g, (const T*)g_out, (const T*)h, alpha, a_src, a_dst, g_e, g_a_dst, N, gm, stream);
+    })
+    return gatres_launch_status();
+  }
+  if (!make_geom(H, C, &gm)) return GATRES_E_UNSUPPORTED;
   const bool fit32 = offsets_fit_32(g, gm.HC);
   GATRES_DISPATCH_T(dtype, fit32, {
-    (launch_bwd_dst<T, IDX>)(g, (const T*)g_out, (const T*)h, alpha, a_src, a_dst, g_e, g_a_dst, N, gm, stream);
+    (launch_bwd_dst<T, IDX, 4>)(g, (const T*)g_out, (const T*)h, alpha, a_src, a_dst, g_e, g_a_dst, N, gm, stream);
   })
   return gatres_launch_status();
 }
@@ -649,11 +709,20 @@ extern "C" int gatres_t_gat_aggregate_bwd_src(const gatres_graph_t* g, const voi
       !gatres_aligned16(att_dst))
     return GATRES_E_BADARG;
   RowGeom gm;
-  if (!make_geom(H, C, &gm)) return GATRES_E_UNSUPPORTED;
   const int N = g->num_nodes;
+  if (wide_lanes(dtype, H * C) && make_geom(H, C, &gm, 8)) {
+    const bool fit32 = offsets_fit_32(g, gm.HC);
+    GATRES_DISPATCH_WIDE(fit32, {
+      hipLaunchKernelGGL((gat_aggregate_bwd_src_kernel<T, IDX, 8>), dim3(grid_rows(N, gm.G)), dim3(256), 0,
+                         gatres_stream(stream), g->t_rowptr, g->t_eid, g->t_dst, (const T*)g_out, alpha, g_e, g_a_dst,
+                         att_src, att_dst, (T*)g_h, g_a_src, N, gm);
+    })
+    return gatres_launch_status();
+  }
+  if (!make_geom(H, C, &gm)) return GATRES_E_UNSUPPORTED;
   const bool fit32 = offsets_fit_32(g, gm.HC);
   GATRES_DISPATCH_T(dtype, fit32, {
-    hipLaunchKernelGGL((gat_aggregate_bwd_src_kernel<T, IDX>), dim3(grid_rows(N, gm.G)), dim3(256), 0, gatres_stream(stream),
+    hipLaunchKernelGGL((gat_aggregate_bwd_src_kernel<T, IDX, 4>), dim3(grid_rows(N, gm.G)), dim3(256), 0, gatres_stream(stream),
                        g->t_rowptr, g->t_eid, g->t_dst, (const T*)g_out, alpha, g_e, g_a_dst, att_src, att_dst,
                        (T*)g_h, g_a_src, N, gm);
   })
@@ -669,7 +738,7 @@ extern "C" int gatres_t_mean_residual_relu_fwd(const gatres_graph_t* g, const vo
   const bool fit32 = offsets_fit_32(g, C);
   if (wide_lanes(dtype, C)) {
     const int G = C / 8;
-    GATRES_DISPATCH_T(dtype, fit32, {
+    GATRES_DISPATCH_WIDE(fit32, {
       hipLaunchKernelGGL((mean_residual_relu_fwd_kernel<T, IDX, 8>), dim3(grid_rows(N, G)), dim3(256), 0,
                          gatres_stream(stream), g->m_rowptr, g->m_col, (const T*)y, (const T*)x0, (T*)out, N, C, G, ilog2(G));
     })
@@ -691,7 +760,7 @@ extern "C" int gatres_t_mean_bwd(const gatres_graph_t* g, const void* g_pre, voi
   const bool fit32 = offsets_fit_32(g, C);
   if (wide_lanes(dtype, C)) {
     const int G = C / 8;
-    GATRES_DISPATCH_T(dtype, fit32, {
+    GATRES_DISPATCH_WIDE(fit32, {
       hipLaunchKernelGGL((mean_bwd_kernel<T, IDX, 8>), dim3(grid_rows(N, G)), dim3(256), 0, gatres_stream(stream),
                          g->m_rowptr, g->mt_rowptr, g->mt_dst, (const T*)g_pre, (T*)g_y, N, C, G, ilog2(G));
     })
