@@ -92,8 +92,8 @@ __device__ __forceinline__ void strow4(gatres_bf16* p, float4 v) {
   b[0] = (gatres_bf16)v.x; b[1] = (gatres_bf16)v.y; b[2] = (gatres_bf16)v.z; b[3] = (gatres_bf16)v.w;
   *reinterpret_cast<bf16x4*>(p) = b;
 }
-// W consecutive features of a row per lane (W = 4: one float4; W = 8: two -- for bf16 ONE 16-byte access): the sparse kernels
-// give a row HC / W lanes, so W = 8 halves the lanes that repeat a row's scalar work (k_aggregate.hip).
+// W consecutive features of a row per lane (W = 4, 8 or 16: W / 4 float4s; bf16 rows in 16-byte accesses from W = 8): the
+// sparse kernels give a row HC / W lanes, so a larger W means fewer lanes repeating a row's scalar work (k_aggregate.hip).
 template <int W> struct gatres_rowv { float4 v[W / 4]; };
 template <int W> __device__ __forceinline__ gatres_rowv<W> rowv_zero() {
   gatres_rowv<W> r;
@@ -109,12 +109,15 @@ template <int W> __device__ __forceinline__ gatres_rowv<W> ldrowv(const float* p
 }
 template <int W> __device__ __forceinline__ gatres_rowv<W> ldrowv(const gatres_bf16* p) {
   gatres_rowv<W> r;
-  if constexpr (W == 8) {
-    const uint4 u = *reinterpret_cast<const uint4*>(p);
-    r.v[0] = make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16),
-                         __uint_as_float(u.y & 0xffff0000u));
-    r.v[1] = make_float4(__uint_as_float(u.z << 16), __uint_as_float(u.z & 0xffff0000u), __uint_as_float(u.w << 16),
-                         __uint_as_float(u.w & 0xffff0000u));
+  if constexpr (W % 8 == 0) {                    // 16-byte accesses: eight features each
+#pragma unroll
+    for (int k = 0; k < W / 8; ++k) {
+      const uint4 u = *reinterpret_cast<const uint4*>(p + 8 * k);
+      r.v[2 * k] = make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16),
+                               __uint_as_float(u.y & 0xffff0000u));
+      r.v[2 * k + 1] = make_float4(__uint_as_float(u.z << 16), __uint_as_float(u.z & 0xffff0000u),
+                                   __uint_as_float(u.w << 16), __uint_as_float(u.w & 0xffff0000u));
+    }
   } else {
 #pragma unroll
     for (int i = 0; i < W / 4; ++i) r.v[i] = ldrow4(p + 4 * i);
@@ -126,12 +129,16 @@ template <int W> __device__ __forceinline__ void strowv(float* p, const gatres_r
   for (int i = 0; i < W / 4; ++i) st4(p + 4 * i, r.v[i]);
 }
 template <int W> __device__ __forceinline__ void strowv(gatres_bf16* p, const gatres_rowv<W>& r) {
-  if constexpr (W == 8) {
+  if constexpr (W % 8 == 0) {
     typedef gatres_bf16 bf16x8 __attribute__((ext_vector_type(8)));
-    bf16x8 b;
-    b[0] = (gatres_bf16)r.v[0].x; b[1] = (gatres_bf16)r.v[0].y; b[2] = (gatres_bf16)r.v[0].z; b[3] = (gatres_bf16)r.v[0].w;
-    b[4] = (gatres_bf16)r.v[1].x; b[5] = (gatres_bf16)r.v[1].y; b[6] = (gatres_bf16)r.v[1].z; b[7] = (gatres_bf16)r.v[1].w;
-    *reinterpret_cast<bf16x8*>(p) = b;
+#pragma unroll
+    for (int k = 0; k < W / 8; ++k) {
+      const float4 lo = r.v[2 * k], hi = r.v[2 * k + 1];
+      bf16x8 b;
+      b[0] = (gatres_bf16)lo.x; b[1] = (gatres_bf16)lo.y; b[2] = (gatres_bf16)lo.z; b[3] = (gatres_bf16)lo.w;
+      b[4] = (gatres_bf16)hi.x; b[5] = (gatres_bf16)hi.y; b[6] = (gatres_bf16)hi.z; b[7] = (gatres_bf16)hi.w;
+      *reinterpret_cast<bf16x8*>(p + 8 * k) = b;
+    }
   } else {
 #pragma unroll
     for (int i = 0; i < W / 4; ++i) strow4(p + 4 * i, r.v[i]);

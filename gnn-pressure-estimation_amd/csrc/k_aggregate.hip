@@ -32,9 +32,19 @@ static inline bool make_geom(int H, int C, RowGeom* g, int W = 4) {      // W = 
   return true;
 }
 
-// eight features per lane: bf16 rows of 64 features and more (one 16-byte access per lane, half the lanes per row)
-static inline bool wide_lanes(int dtype, int row_width) {
-  return dtype == GATRES_DTYPE_BF16 && row_width >= 64 && !getenv("GATRES_AGG_NARROW_LANES");
+// Features per lane W (a row of `row_width` features has row_width / W lanes, a head of C features C / W of them).  The lanes
+// of a row all repeat its scalar work -- index / logit / coefficient loads, softmax, address arithmetic -- and that, not
+// bytes, bounds these kernels at model widths: rows of 64 features and more take 8 features per lane (bf16: one
+// 16-byte access, fp32: two).  Measured, gatres_large bs 128: bf16 7.51 -> 6.72 ms/step, fp32 13.96 -> 13.67; 16 per lane
+// gives nothing more (6.72) and is not instantiated.  GATRES_AGG_LANE_FEATURES=4|8 overrides the choice.
+static inline int lane_features(int row_width, int C) {
+  int w = row_width >= 64 ? 8 : 4;
+  if (const char* e = getenv("GATRES_AGG_LANE_FEATURES")) {
+    const int v = atoi(e);
+    if (v == 4 || v == 8) w = v;
+  }
+  while (w > 4 && (C < w || row_width < 4 * w)) w >>= 1;       // at least one lane per head, four per row
+  return w;
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -103,12 +113,12 @@ __device__ __forceinline__ T* gatres_at_w(T* base, IDX elem) {
 // W = features per lane (4; 8 for bf16 rows of 64 features and more: one 16-byte access per lane, half the lanes per row --
 // the lanes of a row all repeat its scalar work, which is what bounds these kernels)
 template <bool RELU, typename T, typename IDX, int W>
-__global__ __launch_bounds__(256, W == 8 ? 5 : 8) void gat_aggregate_fwd_kernel(
+__global__ __launch_bounds__(256, W == 16 ? 3 : W == 8 ? 5 : 8) void gat_aggregate_fwd_kernel(
     const int* __restrict__ rowptr, const int* __restrict__ col, const T* __restrict__ h,
     const float* __restrict__ a_src, const float* __restrict__ a_dst, const float* __restrict__ bias,
     T* __restrict__ out, float* __restrict__ alpha, int N, RowGeom gm) {
   __shared__ __attribute__((aligned(16))) float hub_lds[4 * HUB_FLOATS_PER_WAVE];
-  constexpr int LGW = W == 8 ? 3 : 2, Q = W / 4;
+  constexpr int LGW = W == 16 ? 4 : W == 8 ? 3 : 2, Q = W / 4;
   const int lgHC = gm.lgG + LGW, lgH = lgHC - gm.lgC;
   GATRES_AGG_ADDRESSING(lgHC, lgH)
   auto rowldv = [&](const T* tab, int j, int c) { return ldrowv<W>(gatres_at<IDX>(tab, ((IDX)j << lgHC) + (IDX)c)); };
@@ -262,12 +272,12 @@ __device__ __forceinline__ float head_reduce_any(float d, int lanes_per_head) {
 // LHT: the lanes per head (C / W) as a compile-time constant for the model widths (8, 16, 32), 0 = any (wave-uniform switch
 // per dot: ~40 scalar branches per row)
 template <typename T, typename IDX, int W, int LHT>
-__global__ __launch_bounds__(256, W == 8 ? 4 : 7) void gat_aggregate_bwd_dst_kernel(
+__global__ __launch_bounds__(256, W == 16 ? 2 : W == 8 ? 4 : 7) void gat_aggregate_bwd_dst_kernel(
     const int* __restrict__ rowptr, const int* __restrict__ col, const T* __restrict__ g_out,
     const T* __restrict__ h, const float* __restrict__ alpha, const float* __restrict__ a_src,
     const float* __restrict__ a_dst, float* __restrict__ g_e, float* __restrict__ g_a_dst, int N, RowGeom gm) {
   __shared__ __attribute__((aligned(16))) float hub_lds[4 * HUB_FLOATS_PER_WAVE];
-  constexpr int LGW = W == 8 ? 3 : 2, Q = W / 4;
+  constexpr int LGW = W == 16 ? 4 : W == 8 ? 3 : 2, Q = W / 4;
   const int lgHC = gm.lgG + LGW, lgH = lgHC - gm.lgC;
   GATRES_AGG_ADDRESSING(lgHC, lgH)
   auto rowldv = [&](const T* tab, int j, int c) { return ldrowv<W>(gatres_at<IDX>(tab, ((IDX)j << lgHC) + (IDX)c)); };
@@ -386,13 +396,13 @@ __global__ __launch_bounds__(256, W == 8 ? 4 : 7) void gat_aggregate_bwd_dst_ker
 //   g_h[j]     = sum_{e=(j->i)} alpha_e * g_out[i]  +  g_a_src[j] (x) att_src  +  g_a_dst[j] (x) att_dst
 // ------------------------------------------------------------------------------------------------------
 template <typename T, typename IDX, int W>
-__global__ __launch_bounds__(256, W == 8 ? 6 : 8) void gat_aggregate_bwd_src_kernel(
+__global__ __launch_bounds__(256, W == 16 ? 4 : W == 8 ? 6 : 8) void gat_aggregate_bwd_src_kernel(
     const int* __restrict__ t_rowptr, const int* __restrict__ t_eid, const int* __restrict__ t_dst,
     const T* __restrict__ g_out, const float* __restrict__ alpha, const float* __restrict__ g_e,
     const float* __restrict__ g_a_dst, const float* __restrict__ att_src, const float* __restrict__ att_dst,
     T* __restrict__ g_h, float* __restrict__ g_a_src, int N, RowGeom gm) {
   __shared__ __attribute__((aligned(16))) float hub_lds[4 * HUB_FLOATS_PER_WAVE];
-  constexpr int LGW = W == 8 ? 3 : 2, Q = W / 4;
+  constexpr int LGW = W == 16 ? 4 : W == 8 ? 3 : 2, Q = W / 4;
   const int lgHC = gm.lgG + LGW, lgH = lgHC - gm.lgC;
   GATRES_AGG_ADDRESSING(lgHC, lgH)
   auto rowldv = [&](const T* tab, int j, int c) { return ldrowv<W>(gatres_at<IDX>(tab, ((IDX)j << lgHC) + (IDX)c)); };
@@ -474,11 +484,11 @@ __global__ __launch_bounds__(256, W == 8 ? 6 : 8) void gat_aggregate_bwd_src_ker
 // ------------------------------------------------------------------------------------------------------
 // W = features per lane (4, or 8 for bf16 rows of 64 features and more: one 16-byte access, half the lanes per row).
 template <typename T, typename IDX, int W>
-__global__ __launch_bounds__(256, 8) void mean_residual_relu_fwd_kernel(
+__global__ __launch_bounds__(256, W == 16 ? 5 : 8) void mean_residual_relu_fwd_kernel(
     const int* __restrict__ rowptr, const int* __restrict__ col, const T* __restrict__ y,
     const T* __restrict__ x0, T* __restrict__ out, int N, int C, int G, int lgG) {
   __shared__ __attribute__((aligned(16))) float hub_lds[4 * HUB_FLOATS_PER_WAVE];
-  constexpr int LGW = W == 8 ? 3 : 2, Q = W / 4;
+  constexpr int LGW = W == 16 ? 4 : W == 8 ? 3 : 2, Q = W / 4;
   const int lgHC = lgG + LGW;
   GATRES_AGG_ADDRESSING(lgHC, 0)
   auto rowldv = [&](const T* tab, int j, int c) { return ldrowv<W>(gatres_at<IDX>(tab, ((IDX)j << lgHC) + (IDX)c)); };
@@ -535,11 +545,11 @@ __global__ __launch_bounds__(256, 8) void mean_residual_relu_fwd_kernel(
 }
 
 template <typename T, typename IDX, int W>
-__global__ __launch_bounds__(256, 8) void mean_bwd_kernel(
+__global__ __launch_bounds__(256, W == 16 ? 5 : 8) void mean_bwd_kernel(
     const int* __restrict__ m_rowptr, const int* __restrict__ mt_rowptr, const int* __restrict__ mt_dst,
     const T* __restrict__ g_pre, T* __restrict__ g_y, int N, int C, int G, int lgG) {
   __shared__ __attribute__((aligned(16))) float hub_lds[4 * HUB_FLOATS_PER_WAVE];
-  constexpr int LGW = W == 8 ? 3 : 2, Q = W / 4;
+  constexpr int LGW = W == 16 ? 4 : W == 8 ? 3 : 2, Q = W / 4;
   const int lgHC = lgG + LGW;
   GATRES_AGG_ADDRESSING(lgHC, 0)
   auto rowldv = [&](const T* tab, int j, int c) { return ldrowv<W>(gatres_at<IDX>(tab, ((IDX)j << lgHC) + (IDX)c)); };
@@ -616,9 +626,20 @@ static inline int grid_rows(int N, int G) {
     default: return GATRES_E_UNSUPPORTED;                                                              \
   }
 
-#define GATRES_DISPATCH_WIDE(fit32_, CALL_)                                                             \
-  if (fit32_) { using T = gatres_bf16; using IDX = unsigned; CALL_; }                                  \
-  else { using T = gatres_bf16; using IDX = size_t; CALL_; }
+// storage type x offset width x features per lane: T, IDX and the constant WV inside CALL_  (flat: CALL_ holds kernel
+// launches, whose expansion must not pass through another macro's argument list)
+#define GATRES_DISPATCH_TIW(dtype_, fit32_, w_, CALL_)                                                  \
+  switch (dtype_) {                                                                                    \
+    case GATRES_DTYPE_F32:                                                                             \
+      if ((w_) == 8) { if (fit32_) { using T = float; using IDX = unsigned; constexpr int WV = 8; CALL_; } else { using T = float; using IDX = size_t; constexpr int WV = 8; CALL_; } } \
+      else { if (fit32_) { using T = float; using IDX = unsigned; constexpr int WV = 4; CALL_; } else { using T = float; using IDX = size_t; constexpr int WV = 4; CALL_; } } \
+      break;                                                                                           \
+    case GATRES_DTYPE_BF16:                                                                            \
+      if ((w_) == 8) { if (fit32_) { using T = gatres_bf16; using IDX = unsigned; constexpr int WV = 8; CALL_; } else { using T = gatres_bf16; using IDX = size_t; constexpr int WV = 8; CALL_; } } \
+      else { if (fit32_) { using T = gatres_bf16; using IDX = unsigned; constexpr int WV = 4; CALL_; } else { using T = gatres_bf16; using IDX = size_t; constexpr int WV = 4; CALL_; } } \
+      break;                                                                                           \
+    default: return GATRES_E_UNSUPPORTED;                                                              \
+  }
 
 // every byte offset into a [rows or edges] x width table of 4-byte elements fits 32 bits (the IDX = unsigned instances)
 static inline bool offsets_fit_32(const gatres_graph_t* g, int width) {
@@ -633,31 +654,18 @@ extern "C" int gatres_t_gat_aggregate_fwd(const gatres_graph_t* g, const void* h
                                void* stream) {
   if (!graph_ok(g) || !h || !a_src || !a_dst || !bias || !out || !alpha) return GATRES_E_BADARG;
   if (!gatres_aligned16(h) || !gatres_aligned16(out) || !gatres_aligned16(bias)) return GATRES_E_BADARG;
-  const int N = g->num_nodes;
+  const int N = g->num_nodes, W = lane_features(H * C, C);
   RowGeom gm;
-  if (wide_lanes(dtype, H * C) && make_geom(H, C, &gm, 8)) {
-    const bool fit32 = offsets_fit_32(g, gm.HC);
-    dim3 grid(grid_rows(N, gm.G)), block(256);
-    GATRES_DISPATCH_WIDE(fit32, {
-      if (apply_relu)
-        hipLaunchKernelGGL((gat_aggregate_fwd_kernel<true, T, IDX, 8>), grid, block, 0, gatres_stream(stream), g->rowptr,
-                           g->col, (const T*)h, a_src, a_dst, bias, (T*)out, alpha, N, gm);
-      else
-        hipLaunchKernelGGL((gat_aggregate_fwd_kernel<false, T, IDX, 8>), grid, block, 0, gatres_stream(stream), g->rowptr,
-                           g->col, (const T*)h, a_src, a_dst, bias, (T*)out, alpha, N, gm);
-    })
-    return gatres_launch_status();
-  }
-  if (!make_geom(H, C, &gm)) return GATRES_E_UNSUPPORTED;
+  if (!make_geom(H, C, &gm, W)) return GATRES_E_UNSUPPORTED;
   const bool fit32 = offsets_fit_32(g, gm.HC);
   dim3 grid(grid_rows(N, gm.G)), block(256);
-  GATRES_DISPATCH_T(dtype, fit32, {
+  GATRES_DISPATCH_TIW(dtype, fit32, W, {
     if (apply_relu)
-      hipLaunchKernelGGL((gat_aggregate_fwd_kernel<true, T, IDX, 4>), grid, block, 0, gatres_stream(stream), g->rowptr, g->col,
-                         (const T*)h, a_src, a_dst, bias, (T*)out, alpha, N, gm);
+      hipLaunchKernelGGL((gat_aggregate_fwd_kernel<true, T, IDX, WV>), grid, block, 0, gatres_stream(stream), g->rowptr,
+                         g->col, (const T*)h, a_src, a_dst, bias, (T*)out, alpha, N, gm);
     else
-      hipLaunchKernelGGL((gat_aggregate_fwd_kernel<false, T, IDX, 4>), grid, block, 0, gatres_stream(stream), g->rowptr, g->col,
-                         (const T*)h, a_src, a_dst, bias, (T*)out, alpha, N, gm);
+      hipLaunchKernelGGL((gat_aggregate_fwd_kernel<false, T, IDX, WV>), grid, block, 0, gatres_stream(stream), g->rowptr,
+                         g->col, (const T*)h, a_src, a_dst, bias, (T*)out, alpha, N, gm);
   })
   return gatres_launch_status();
 }
@@ -669,6 +677,7 @@ static void launch_bwd_dst(const gatres_graph_t* g, const T* g_out, const T* h, 
   hipLaunchKernelGGL((gat_aggregate_bwd_dst_kernel<T, IDX, W, LHT_>), dim3(grid_rows(N, gm.G)), dim3(256), 0,            \
                      gatres_stream(stream), g->rowptr, g->col, g_out, h, alpha, a_src, a_dst, g_e, g_a_dst, N, gm)
   switch (gm.C / W) {                          // lanes per head
+    case 2: GATRES_BWD_DST_LAUNCH(2); break;
     case 4: GATRES_BWD_DST_LAUNCH(4); break;
     case 8: GATRES_BWD_DST_LAUNCH(8); break;
     case 16: GATRES_BWD_DST_LAUNCH(16); break;
@@ -684,18 +693,11 @@ extern "C" int gatres_t_gat_aggregate_bwd_dst(const gatres_graph_t* g, const voi
   if (!graph_ok(g) || !g_out || !h || !alpha || !a_src || !a_dst || !g_e || !g_a_dst) return GATRES_E_BADARG;
   if (!gatres_aligned16(h) || !gatres_aligned16(g_out)) return GATRES_E_BADARG;
   RowGeom gm;
-  const int N = g->num_nodes;
-  if (wide_lanes(dtype, H * C) && make_geom(H, C, &gm, 8)) {
-    const bool fit32 = offsets_fit_32(g, gm.HC);
-    GATRES_DISPATCH_WIDE(fit32, {
-      (launch_bwd_dst<T, IDX, 8>)(g, (const T*)g_out, (const T*)h, alpha, a_src, a_dst, g_e, g_a_dst, N, gm, stream);
-    })
-    return gatres_launch_status();
-  }
-  if (!make_geom(H, C, &gm)) return GATRES_E_UNSUPPORTED;
+  const int N = g->num_nodes, W = lane_features(H * C, C);
+  if (!make_geom(H, C, &gm, W)) return GATRES_E_UNSUPPORTED;
   const bool fit32 = offsets_fit_32(g, gm.HC);
-  GATRES_DISPATCH_T(dtype, fit32, {
-    (launch_bwd_dst<T, IDX, 4>)(g, (const T*)g_out, (const T*)h, alpha, a_src, a_dst, g_e, g_a_dst, N, gm, stream);
+  GATRES_DISPATCH_TIW(dtype, fit32, W, {
+    (launch_bwd_dst<T, IDX, WV>)(g, (const T*)g_out, (const T*)h, alpha, a_src, a_dst, g_e, g_a_dst, N, gm, stream);
   })
   return gatres_launch_status();
 }
@@ -709,22 +711,13 @@ extern "C" int gatres_t_gat_aggregate_bwd_src(const gatres_graph_t* g, const voi
       !gatres_aligned16(att_dst))
     return GATRES_E_BADARG;
   RowGeom gm;
-  const int N = g->num_nodes;
-  if (wide_lanes(dtype, H * C) && make_geom(H, C, &gm, 8)) {
-    const bool fit32 = offsets_fit_32(g, gm.HC);
-    GATRES_DISPATCH_WIDE(fit32, {
-      hipLaunchKernelGGL((gat_aggregate_bwd_src_kernel<T, IDX, 8>), dim3(grid_rows(N, gm.G)), dim3(256), 0,
-                         gatres_stream(stream), g->t_rowptr, g->t_eid, g->t_dst, (const T*)g_out, alpha, g_e, g_a_dst,
-                         att_src, att_dst, (T*)g_h, g_a_src, N, gm);
-    })
-    return gatres_launch_status();
-  }
-  if (!make_geom(H, C, &gm)) return GATRES_E_UNSUPPORTED;
+  const int N = g->num_nodes, W = lane_features(H * C, C);
+  if (!make_geom(H, C, &gm, W)) return GATRES_E_UNSUPPORTED;
   const bool fit32 = offsets_fit_32(g, gm.HC);
-  GATRES_DISPATCH_T(dtype, fit32, {
-    hipLaunchKernelGGL((gat_aggregate_bwd_src_kernel<T, IDX, 4>), dim3(grid_rows(N, gm.G)), dim3(256), 0, gatres_stream(stream),
-                       g->t_rowptr, g->t_eid, g->t_dst, (const T*)g_out, alpha, g_e, g_a_dst, att_src, att_dst,
-                       (T*)g_h, g_a_src, N, gm);
+  GATRES_DISPATCH_TIW(dtype, fit32, W, {
+    hipLaunchKernelGGL((gat_aggregate_bwd_src_kernel<T, IDX, WV>), dim3(grid_rows(N, gm.G)), dim3(256), 0,
+                       gatres_stream(stream), g->t_rowptr, g->t_eid, g->t_dst, (const T*)g_out, alpha, g_e, g_a_dst,
+                       att_src, att_dst, (T*)g_h, g_a_src, N, gm);
   })
   return gatres_launch_status();
 }
@@ -734,20 +727,11 @@ extern "C" int gatres_t_mean_residual_relu_fwd(const gatres_graph_t* g, const vo
   if (!graph_ok(g) || !y || !x0 || !out) return GATRES_E_BADARG;
   if (!gatres_aligned16(y) || !gatres_aligned16(x0) || !gatres_aligned16(out)) return GATRES_E_BADARG;
   if (C < 4 || !gatres_is_pow2(C) || C > 256) return GATRES_E_UNSUPPORTED;
-  const int N = g->num_nodes;
+  const int N = g->num_nodes, W = lane_features(C, C), G = C / W;
   const bool fit32 = offsets_fit_32(g, C);
-  if (wide_lanes(dtype, C)) {
-    const int G = C / 8;
-    GATRES_DISPATCH_WIDE(fit32, {
-      hipLaunchKernelGGL((mean_residual_relu_fwd_kernel<T, IDX, 8>), dim3(grid_rows(N, G)), dim3(256), 0,
-                         gatres_stream(stream), g->m_rowptr, g->m_col, (const T*)y, (const T*)x0, (T*)out, N, C, G, ilog2(G));
-    })
-    return gatres_launch_status();
-  }
-  const int G = C / 4;
-  GATRES_DISPATCH_T(dtype, fit32, {
-    hipLaunchKernelGGL((mean_residual_relu_fwd_kernel<T, IDX, 4>), dim3(grid_rows(N, G)), dim3(256), 0, gatres_stream(stream),
-                       g->m_rowptr, g->m_col, (const T*)y, (const T*)x0, (T*)out, N, C, G, ilog2(G));
+  GATRES_DISPATCH_TIW(dtype, fit32, W, {
+    hipLaunchKernelGGL((mean_residual_relu_fwd_kernel<T, IDX, WV>), dim3(grid_rows(N, G)), dim3(256), 0,
+                       gatres_stream(stream), g->m_rowptr, g->m_col, (const T*)y, (const T*)x0, (T*)out, N, C, G, ilog2(G));
   })
   return gatres_launch_status();
 }
@@ -756,20 +740,11 @@ extern "C" int gatres_t_mean_bwd(const gatres_graph_t* g, const void* g_pre, voi
   if (!graph_ok(g) || !g_pre || !g_y) return GATRES_E_BADARG;
   if (!gatres_aligned16(g_pre) || !gatres_aligned16(g_y)) return GATRES_E_BADARG;
   if (C < 4 || !gatres_is_pow2(C) || C > 256) return GATRES_E_UNSUPPORTED;
-  const int N = g->num_nodes;
+  const int N = g->num_nodes, W = lane_features(C, C), G = C / W;
   const bool fit32 = offsets_fit_32(g, C);
-  if (wide_lanes(dtype, C)) {
-    const int G = C / 8;
-    GATRES_DISPATCH_WIDE(fit32, {
-      hipLaunchKernelGGL((mean_bwd_kernel<T, IDX, 8>), dim3(grid_rows(N, G)), dim3(256), 0, gatres_stream(stream),
-                         g->m_rowptr, g->mt_rowptr, g->mt_dst, (const T*)g_pre, (T*)g_y, N, C, G, ilog2(G));
-    })
-    return gatres_launch_status();
-  }
-  const int G = C / 4;
-  GATRES_DISPATCH_T(dtype, fit32, {
-    hipLaunchKernelGGL((mean_bwd_kernel<T, IDX, 4>), dim3(grid_rows(N, G)), dim3(256), 0, gatres_stream(stream), g->m_rowptr,
-                       g->mt_rowptr, g->mt_dst, (const T*)g_pre, (T*)g_y, N, C, G, ilog2(G));
+  GATRES_DISPATCH_TIW(dtype, fit32, W, {
+    hipLaunchKernelGGL((mean_bwd_kernel<T, IDX, WV>), dim3(grid_rows(N, G)), dim3(256), 0, gatres_stream(stream),
+                       g->m_rowptr, g->mt_rowptr, g->mt_dst, (const T*)g_pre, (T*)g_y, N, C, G, ilog2(G));
   })
   return gatres_launch_status();
 }

@@ -90,6 +90,33 @@ def test_gatconv_forward_and_backward(pkg, oracle, ops, C, H, n, e, kw):
     assert relerr(g_b, leaves[4].grad) < 2e-5
 
 
+@pytest.mark.parametrize("C,H", [(32, 2), (128, 2), (128, 1)])
+def test_sparse_kernels_lane_feature_instances_agree(pkg, ops, C, H, monkeypatch):
+    """Rows of 64 features and more take eight features per lane (half the lanes per row), GATRES_AGG_LANE_FEATURES=4 the
+    four-per-lane instances: sums over a row's edges run per feature in edge order either way, so the forward results are
+    bit-identical; the backward head dots associate differently (fp32 rounding only)."""
+    torch.manual_seed(3)
+    n, HC = 500, H * C
+    h, g_pre = torch.randn(n, HC).cuda(), torch.randn(n, HC).cuda()
+    hs, hd = torch.randn(n, H).cuda(), torch.randn(n, H).cuda()
+    b, a_s, a_d = torch.randn(HC).cuda(), torch.randn(HC).cuda(), torch.randn(HC).cuda()
+    for hub in (False, True):                  # (hub rows: the wave's edge slots depend on the lanes per row -> rounding only)
+        ei = graph(n, 1300, 11, self_loops=2, dup=3, hub=hub)
+        plan = pkg.GraphPlan(ei, n, device="cuda", reorder=False)
+        res = {}
+        for w in ("8", "4"):
+            monkeypatch.setenv("GATRES_AGG_LANE_FEATURES", w)
+            out, alpha = ops.gat_aggregate_fwd(plan, h, hs, hd, b, H, relu=True)
+            g_h, g_as, g_ad, g_e = ops.gat_aggregate_bwd(plan, g_pre, h, alpha, hs, hd, a_s, a_d, H)
+            m = ops.mean_residual_relu_fwd(plan, h, g_pre)
+            mb = ops.mean_bwd(plan, g_pre)
+            torch.cuda.synchronize()
+            res[w] = (out, alpha, m, mb, g_h, g_as, g_ad)
+        for a, c in list(zip(res["8"], res["4"]))[:4]:
+            assert relerr(a, c) < 1e-5 if hub else torch.equal(a, c)
+        for a, c in list(zip(res["8"], res["4"]))[4:]:
+            assert relerr(a, c) < 1e-5
+
 @pytest.mark.parametrize("star", [False, True])
 @pytest.mark.parametrize("C", [4, 32, 128])
 def test_mean_residual_relu_and_backward(pkg, oracle, ops, C, star):
