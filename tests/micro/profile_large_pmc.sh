@@ -9,7 +9,7 @@ timeout 300 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INST
 python3 - <<'PY'
 import json, subprocess, sys
 out={}
-for k in ["proj_bf16_kernel<128, 256, 2, 1>", "proj_bf16_kernel<256, 128, 1, 2>", "dw2d_bf16_kernel<256, 128>", "gat_aggregate_bwd_dst", "gat_aggregate_bwd_src", "gat_aggregate_fwd_kernelILb1", "conv_param_grads_bf16"]:
+for k in ["proj_bf16_kernel<128, 256, 2, 1>", "proj_bf16_kernel<256, 128, 1, 2>", "dw2d_bf16_kernel<256, 128>", "gat_aggregate_bwd_dst", "gat_aggregate_bwd_src", "gat_aggregate_fwd_kernel<true", "conv_param_grads_bf16"]:
     subprocess.run([sys.executable, "tests/micro/summarize_prof.py", "pmc", "gpurun_out/pj/x.json", k, "gpurun_out/pj/a", "gpurun_out/pj/b", "gpurun_out/pj/c", "gpurun_out/pj/d"], check=True)
     d=json.load(open("gpurun_out/pj/x.json"))["counters"]
     out[k]={c: round(v["mean_per_launch"]) for c,v in d.items()}
