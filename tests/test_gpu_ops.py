@@ -198,6 +198,30 @@ def test_lin0_lin1_backward_slabs(ops, nc, dtype, monkeypatch):
         assert relerr(a, b) < 1e-6
 
 
+@pytest.mark.parametrize("H,C", [(2, 128), (1, 128), (2, 32)])
+def test_conv_param_grads_bf16(ops, H, C):
+    """att_src / att_dst / bias gradient partials from bf16 tables (GATConv's parameters, GraphModels.py:464-466 backward):
+    the per-slab partial sums add up to an fp64 statement of the sums."""
+    lib = ops.N_.load()
+    torch.manual_seed(9)
+    n, HC, slabs = 2999, H * C, 5
+    h = torch.randn(n, HC).to(torch.bfloat16).cuda()
+    go = torch.randn(n, HC).to(torch.bfloat16).cuda()
+    gs, gd = torch.randn(n, H).cuda(), torch.randn(n, H).cuda()
+    stride = 3 * HC
+    hd = h.double().view(n, H, C)
+    want = ((gs.double()[:, :, None] * hd).sum(0).reshape(-1), (gd.double()[:, :, None] * hd).sum(0).reshape(-1),
+            go.double().sum(0))
+    for _ in range(1):
+        sl = torch.zeros(slabs, stride, device="cuda")
+        ops.N_.check(lib.gatres_t_conv_param_grads(h.data_ptr(), gs.data_ptr(), gd.data_ptr(), go.data_ptr(), sl.data_ptr(),
+                                                   sl.data_ptr() + 4 * HC, sl.data_ptr() + 8 * HC, slabs, stride, n, H, C, 1,
+                                                   ops._s(h)), "conv_param_grads")
+        torch.cuda.synchronize()
+        for k in range(3):
+            assert relerr(sl[:, k * HC:(k + 1) * HC].double().sum(0), want[k]) < 1e-5
+
+
 def test_device_mask_sampler_exact_count_and_fresh_per_step(ops):
     sizes = [388] * 5 + [17, 1000, 3]
     off = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int32)
