@@ -252,7 +252,17 @@ def test_masked_mse_and_adam_match_torch(ops):
     ref.backward()
     loss, g = ops.masked_mse(out.cuda(), y.cuda(), mask.to(torch.uint8).cuda())
     assert relerr(loss, ref) < 1e-6 and relerr(g, o.grad) < 1e-6
-    P = 10007
+    _adam_against_torch(ops, 10007)
+
+
+@pytest.mark.parametrize("P", [512 * 256 + 77, 1700003])
+def test_adam_grid_stride_counts_the_step_once(ops, P):
+    """More parameters than ADAM_MAX_BLOCKS x 256 (gatres_large has 1.7 M): the launch is grid-strided and the step counter
+    still advances exactly once per launch (train.py:187 optimizer.step())."""
+    _adam_against_torch(ops, P)
+
+
+def _adam_against_torch(ops, P):
     p, gr = torch.randn(P), torch.randn(P)
     pt = p.clone().requires_grad_(True)
     opt = torch.optim.Adam([pt], lr=5e-4, weight_decay=6e-6)
