@@ -137,7 +137,13 @@ extern "C" __attribute__((visibility("hidden"))) int gatres_reduce_slabs_regions
 // Slab rows the GATConv weight gradients occupy: the bf16 dW kernel of wide models forms two-dimensional partials (64 rows of
 // 64 x 64 blocks instead of one whole [2nc, nc] matrix per workgroup): 4x less slab traffic in dW and in the final sum
 static int dw_slab_rows(const gatres_model_t* m, const Layout& L) {
-  if (m->act_dtype == GATRES_DTYPE_BF16 && L.nc == 128 && L.num_slabs > 64 && !getenv("GATRES_DW_1D")) return 64;
+  if (m->act_dtype == GATRES_DTYPE_BF16 && L.nc == 128 && L.num_slabs > 64 && !getenv("GATRES_DW_1D")) {
+    if (const char* e = getenv("GATRES_DW_SLAB_ROWS")) {           // (tuning experiments: 32 / 64 / 128 row groups)
+      const int v = atoi(e);
+      if (v >= 8 && v <= 128 && v % 8 == 0 && v < L.num_slabs) return v;
+    }
+    return 64;
+  }
   return L.num_slabs;
 }
 
