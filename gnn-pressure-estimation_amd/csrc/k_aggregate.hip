@@ -14,6 +14,7 @@
 //   mean  : out_i = (sum_{j->i} y[j]) / max(indeg(i), 1)       SimpleConv(aggr="mean")
 #include "gatres_common.h"
 #include "gatres_typed.h"
+#include <type_traits>
 
 namespace {
 
@@ -177,7 +178,10 @@ __global__ __launch_bounds__(256, W == 16 ? 3 : W == 8 ? 5 : 8) void gat_aggrega
     // every neighbour index, logit and feature row of this destination is requested at once: one dependent round
     // trip (col -> {a_src, h}) instead of three passes of edge-at-a-time chains.  Statement for statement the
     // arithmetic of the loop form below (and of the fused kernels' seg_softmax / seg_gather): bit-identical.
+    // (slot count: 4 when every row of the wave has <= 4 in-edges, else MAXD; padding slots only ever add exact zeros)
     const int deg = end - beg;
+    auto slots = [&](auto KC) {
+    constexpr int MAXD = decltype(KC)::value;
     int jj[MAXD];
 #pragma unroll
     for (int k = 0; k < MAXD; ++k) jj[k] = ival(col, beg + min(k, deg - 1));
@@ -207,6 +211,9 @@ __global__ __launch_bounds__(256, W == 16 ? 3 : W == 8 ? 5 : 8) void gat_aggrega
         axpyv(acc, al, v[k]);
       }
     }
+    };
+    if (__ballot(deg > 4) == 0ULL) slots(std::integral_constant<int, 4>{});
+    else slots(std::integral_constant<int, MAXD>{});
   } else {                                     // up to HUB_MIN_DEGREE in-edges: the row's own lanes, edge after edge
   float m = -INFINITY;
   for (int e = beg; e < end; ++e) {
@@ -345,33 +352,40 @@ __global__ __launch_bounds__(256, W == 16 ? 2 : W == 8 ? 4 : 7) void gat_aggrega
   const float adst = hval(a_dst, row, hd);
   if (end - beg <= 8) {                        // the common case: every load of the row issued together (slot path)
     const int deg = end - beg;
-    int jj[8];
+    // K edge slots: 4 when every row of the wave has <= 4 in-edges (three of four waves of a water network), else 8.
+    // Padding slots re-load the row's last neighbour and are masked out of every sum: the same bits either way.
+    auto slots = [&](auto KC) {
+      constexpr int K = decltype(KC)::value;
+      int jj[K];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) jj[k] = ival(col, beg + min(k, deg - 1));
-    gatres_rowv<W> hv[8];
-    float al[8], as[8];
+      for (int k = 0; k < K; ++k) jj[k] = ival(col, beg + min(k, deg - 1));
+      gatres_rowv<W> hv[K];
+      float al[K], as[K];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      hv[k] = rowldv(h, jj[k], c0);
-      al[k] = hval(alpha, (beg + min(k, deg - 1)), hd);
-      as[k] = hval(a_src, jj[k], hd);
-    }
-    float ga[8];
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      ga[k] = hdot(go, hv[k]);
-      if (k < deg) S = fmaf(al[k], ga[k], S);
-    }
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      if (k < deg) {
-        const float gs = al[k] * (ga[k] - S);
-        const float raw = as[k] + adst;
-        const float ge = raw > 0.f ? gs : gs * GATRES_NEG_SLOPE;
-        if (leader) *hptr(g_e, (beg + k), hd) = ge;
-        gad = gad + ge;
+      for (int k = 0; k < K; ++k) {
+        hv[k] = rowldv(h, jj[k], c0);
+        al[k] = hval(alpha, (beg + min(k, deg - 1)), hd);
+        as[k] = hval(a_src, jj[k], hd);
       }
-    }
+      float ga[K];
+#pragma unroll
+      for (int k = 0; k < K; ++k) {
+        ga[k] = hdot(go, hv[k]);
+        if (k < deg) S = fmaf(al[k], ga[k], S);
+      }
+#pragma unroll
+      for (int k = 0; k < K; ++k) {
+        if (k < deg) {
+          const float gs = al[k] * (ga[k] - S);
+          const float raw = as[k] + adst;
+          const float ge = raw > 0.f ? gs : gs * GATRES_NEG_SLOPE;
+          if (leader) *hptr(g_e, (beg + k), hd) = ge;
+          gad = gad + ge;
+        }
+      }
+    };
+    if (W == 8 && __ballot(deg > 4) == 0ULL) slots(std::integral_constant<int, 4>{});
+    else slots(std::integral_constant<int, 8>{});
   } else if (end - beg <= HUB_MIN_DEGREE) {    // the row's own lanes, edge after edge; the dots are recomputed in the second pass
     for (int e = beg; e < end; ++e) {
       const float ga = hdot(go, rowldv(h, ival(col, e), c0));
@@ -448,7 +462,28 @@ __global__ __launch_bounds__(256, W == 16 ? 4 : W == 8 ? 6 : 8) void gat_aggrega
       if ((lane >> gm.lgG) == (owner >> gm.lgG)) { acc = sum; gas = gsum; }
     }
   }
-  const int end = hub ? beg : end0;            // (a hub's edges are done)
+  int end = hub ? beg : end0;                  // (a hub's edges are done)
+  // every row of the wave has <= 4 out-edges (most waves of a water network): the rows' loads are all issued together --
+  // one dependent round trip {t_eid, t_dst} -> {alpha, g_e, g_out} instead of one per edge pair -- and summed in edge
+  // order: the same bits as the loop below
+  if (__ballot(end - beg > 4) == 0ULL) {
+    const int deg = end - beg;
+    int ee[4], ii[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { ee[k] = k < deg ? ival(t_eid, beg + k) : 0; ii[k] = k < deg ? ival(t_dst, beg + k) : row; }   // (padding: valid entries, masked out below)
+    gatres_rowv<W> gv[4];
+    float al[4], ge[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      gv[k] = rowldv(g_out, ii[k], c0);
+      al[k] = hval(alpha, ee[k], hd);
+      ge[k] = hval(g_e, ee[k], hd);
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      if (k < deg) { gas = gas + ge[k]; axpyv(acc, al[k], gv[k]); }
+    end = beg;
+  }
   int t = beg;
   for (; t + 1 < end; t += 2) {
     const int e0 = ival(t_eid, t), e1 = ival(t_eid, t + 1);
@@ -522,7 +557,20 @@ __global__ __launch_bounds__(256, W == 16 ? 5 : 8) void mean_residual_relu_fwd_k
       if ((lane >> lgG) == (owner >> lgG)) acc = sum;
     }
   }
-  const int end = hub ? beg : end0;
+  int end = hub ? beg : end0;
+  if (__ballot(end - beg > 4) == 0ULL) {       // (all rows of the wave: <= 4 neighbours -> their rows requested together, summed in edge order)
+    const int deg = end - beg;
+    int jj[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) jj[k] = k < deg ? ival(col, beg + k) : row;
+    gatres_rowv<W> v[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) v[k] = rowldv(y, jj[k], c0);
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      if (k < deg) add(acc, v[k]);
+    end = beg;
+  }
   int e = beg;
   for (; e + 1 < end; e += 2) {
     const gatres_rowv<W> v0 = rowldv(y, ival(col, e), c0);
@@ -590,7 +638,7 @@ __global__ __launch_bounds__(256, W == 16 ? 5 : 8) void mean_bwd_kernel(
       if ((lane >> lgG) == (owner >> lgG)) acc = sum;
     }
   }
-  const int end = hub ? beg : end0;
+  const int end = hub ? beg : end0;            // (the slot form of the other kernels measured slower here: 13.6 vs 12.8 us)
   for (int t = beg; t < end; ++t) {
     const int i = ival(mt_dst, t);
     const float cnt = (float)max(ival(m_rowptr, i + 1) - ival(m_rowptr, i), 1);
