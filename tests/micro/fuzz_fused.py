@@ -56,10 +56,13 @@ for case in range(cases):
         mp.flat_parameters.copy_(mf.flat_parameters)
     x = torch.randn(N, 1).cuda()
     dei = ei.cuda()
+    hubs = int(torch.bincount(ei[1][ei[0] != ei[1]], minlength=N).max()) + 1 > 32
     ok = True
     for rep in range(2):
         of, op = mf(x, dei), mp(x, dei)
-        if not torch.equal(of, op):
+        # bit-identical predictions, except on batches with hub rows (more than 32 in-edges): the per-op kernels reduce those
+        # by the whole wave with staged partial sums, the fused kernels edge after edge (fp32 reassociation only)
+        if not (torch.equal(of, op) or (hubs and relerr(of, op) < 1e-6)):
             ok = False; print("case", case, "rep", rep, "FORWARD differs", relerr(of, op))
         g = torch.randn_like(of)
         mf.zero_grad(); mp.zero_grad()
@@ -73,7 +76,7 @@ for case in range(cases):
     lib = G._native.load()
     cus = lib.gatres_fused_cus_per_segment(mf._cmodel_ref(), plan.ref())
     print(f"case {case:3d} nb {nb} nc {nc:2d} sizes {sizes} segments {plan.num_segments} CUs/segment {cus} windows {plan.windows[3:6]}"
-          f" -> {'ok' if ok else 'FAIL'}")
+          f" -> {'ok' if ok else 'FAIL'}{' (hub rows: last-bit forward differences allowed)' if hubs else ''}")
     bad += 0 if ok else 1
 print("failures:", bad, "of", cases)
 sys.exit(1 if bad else 0)
