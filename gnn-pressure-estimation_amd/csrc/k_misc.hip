@@ -7,6 +7,7 @@
 // bitwise reproducible.
 #include "gatres_common.h"
 #include "gatres_typed.h"
+#include "k_conv_grads_bf16.h"
 
 namespace {
 
@@ -273,69 +274,12 @@ __global__ __launch_bounds__(256) void conv_param_grads_kernel(
   }
 }
 
-// bf16 tables: a lane owns TWO adjacent columns (one 4-byte load per row and table instead of two 2-byte ones: the
-// 2-byte form ran 3x slower than the fp32 kernel on gatres_large).  Column sums do not depend on which lane forms them.
+// bf16 tables: k_conv_grads_bf16.h
 __global__ __launch_bounds__(256) void conv_param_grads_bf16_kernel(
     const gatres_bf16* __restrict__ h, const float* __restrict__ g_a_src, const float* __restrict__ g_a_dst,
     const gatres_bf16* __restrict__ g_out, float* __restrict__ slab_as, float* __restrict__ slab_ad,
     float* __restrict__ slab_b, long long stride, int N, int H, int C, int nps) {
-  __shared__ float part[3][3][256];                 // [as|ad|ab][waves 1..3][column]
-  const int s = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int HC = H * C;
-  const int nbeg = s * nps, nend = min(N, nbeg + nps);
-  float as[2][2] = {{0.f, 0.f}, {0.f, 0.f}}, ad[2][2] = {{0.f, 0.f}, {0.f, 0.f}}, ab[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
-  for (int n0 = nbeg + wave; n0 < nend; n0 += 32) {
-    unsigned hv[8][2], go[8][2];
-    float gs[8][2], gd[8][2];
-#pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      const int n = n0 + 4 * u;
-      const bool ok = n < nend;
-      const int nn = ok ? n : nbeg;
-#pragma unroll
-      for (int cc = 0; cc < 2; ++cc) {
-        const int c = 2 * lane + 128 * cc;
-        const bool cok = ok && c < HC;
-        const int ci = c < HC ? c : 0;
-        hv[u][cc] = cok ? *reinterpret_cast<const unsigned*>(h + (size_t)nn * HC + ci) : 0u;
-        go[u][cc] = cok ? *reinterpret_cast<const unsigned*>(g_out + (size_t)nn * HC + ci) : 0u;
-        gs[u][cc] = cok ? g_a_src[nn * H + ci / C] : 0.f;
-        gd[u][cc] = cok ? g_a_dst[nn * H + ci / C] : 0.f;
-      }
-    }
-#pragma unroll
-    for (int u = 0; u < 8; ++u)
-#pragma unroll
-      for (int cc = 0; cc < 2; ++cc) {
-        const float h0 = __uint_as_float(hv[u][cc] << 16), h1 = __uint_as_float(hv[u][cc] & 0xffff0000u);
-        as[cc][0] = fmaf(gs[u][cc], h0, as[cc][0]); as[cc][1] = fmaf(gs[u][cc], h1, as[cc][1]);
-        ad[cc][0] = fmaf(gd[u][cc], h0, ad[cc][0]); ad[cc][1] = fmaf(gd[u][cc], h1, ad[cc][1]);
-        ab[cc][0] += __uint_as_float(go[u][cc] << 16); ab[cc][1] += __uint_as_float(go[u][cc] & 0xffff0000u);
-      }
-  }
-  if (wave > 0) {
-#pragma unroll
-    for (int cc = 0; cc < 2; ++cc)
-#pragma unroll
-      for (int e = 0; e < 2; ++e) {
-        const int c = 2 * lane + 128 * cc + e;
-        part[0][wave - 1][c] = as[cc][e]; part[1][wave - 1][c] = ad[cc][e]; part[2][wave - 1][c] = ab[cc][e];
-      }
-  }
-  __syncthreads();
-  if (wave == 0) {
-#pragma unroll
-    for (int cc = 0; cc < 2; ++cc)
-#pragma unroll
-      for (int e = 0; e < 2; ++e) {
-        const int c = 2 * lane + 128 * cc + e;
-        if (c < HC) {
-          slab_as[(size_t)s * stride + c] = ((as[cc][e] + part[0][0][c]) + part[0][1][c]) + part[0][2][c];
-          slab_ad[(size_t)s * stride + c] = ((ad[cc][e] + part[1][0][c]) + part[1][1][c]) + part[1][2][c];
-          slab_b[(size_t)s * stride + c] = ((ab[cc][e] + part[2][0][c]) + part[2][1][c]) + part[2][2][c];
-        }
-      }
-  }
+  conv_param_grads_bf16_body(blockIdx.x, h, g_a_src, g_a_dst, g_out, slab_as, slab_ad, slab_b, stride, N, H, C, nps);
 }
 
 __global__ __launch_bounds__(256) void reduce_slabs_kernel(const float* __restrict__ slabs, int num_slabs,

@@ -17,6 +17,7 @@
 #include <cstdlib>
 
 #include "gatres_common.h"
+#include "k_conv_grads_bf16.h"
 #include "gatres_typed.h"
 
 namespace {
@@ -661,10 +662,31 @@ __global__ __launch_bounds__(256) void dw_bf16_kernel(const gatres_bf16* __restr
 // partial matrices instead of one per workgroup, and the final reduction reads R rows: for gatres_large (25 x 128, C-Town
 // bs 128) the 256-row form wrote 33 MB per call and the reduction read 1.7 GB per step -- 1.6 of a 9-ms step.  Every
 // operand row is read by (K / 64) resp. (HC / 64) workgroups, which run at the same time: L2 absorbs the re-reads.
+// Co-launch: with cg.h set, workgroups beyond the first `dw_grid` form the convolution's attention-vector / bias gradient
+// partials (conv_param_grads_bf16_body, slab cg.first + ...).  The two partial-sum launches of a convolution's backward
+// read the same tables, write disjoint slab regions and each leave most of the chip waiting on memory: as one launch they
+// overlap (as two parallel branches of the captured graph they cost more than they return).
+struct ConvGradsCo {
+  const gatres_bf16* h;
+  const float* g_a_src;
+  const float* g_a_dst;
+  const gatres_bf16* g_out;
+  float* slab_as;
+  float* slab_ad;
+  float* slab_b;
+  long long stride;
+  int H, C, nps;
+};
+
 template <int HC, int K>
 __global__ __launch_bounds__(256) void dw2d_bf16_kernel(const gatres_bf16* __restrict__ G, const gatres_bf16* __restrict__ X,
                                                         float* __restrict__ slab, long long slab_stride, int N,
-                                                        int nodes_per_group) {
+                                                        int nodes_per_group, int dw_grid, ConvGradsCo cg) {
+  if ((int)blockIdx.x >= dw_grid) {               // (workgroup-uniform)
+    conv_param_grads_bf16_body((int)blockIdx.x - dw_grid, cg.h, cg.g_a_src, cg.g_a_dst, cg.g_out, cg.slab_as, cg.slab_ad,
+                               cg.slab_b, cg.stride, N, cg.H, cg.C, cg.nps);
+    return;
+  }
   constexpr int OBK = K / 64, OB = (HC / 64) * OBK, CH = 64;          // 64-node chunks: two MFMA k steps
   constexpr int RP = 64 + 16;                                         // LDS row: 64 features + pad (see dw_bf16_kernel)
   typedef short s16x4 __attribute__((ext_vector_type(4)));
@@ -677,7 +699,7 @@ __global__ __launch_bounds__(256) void dw2d_bf16_kernel(const gatres_bf16* __res
   // sat on eight XCDs and every one of them fetched the rows from HBM: 110 MB per call instead of ~45).  Speed only.
   int rg = blockIdx.x / OB, ob = blockIdx.x % OB;
   {
-    const int groups = gridDim.x / OB;
+    const int groups = dw_grid / OB;
     if ((groups & 7) == 0) {
       const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
       rg = (j / OB) * 8 + xcd; ob = j % OB;
@@ -736,19 +758,26 @@ __global__ __launch_bounds__(256) void dw2d_bf16_kernel(const gatres_bf16* __res
       out[(size_t)(cb * 64 + wave * 16 + 4 * q + r) * K + kb * 64 + b * 16 + i] = acc[b][r];
 }
 
+// cg / cg_slabs: the co-launched attention-vector / bias partials (nullptr: none).  GATRES_E_UNSUPPORTED with a co-launch
+// asked for means "launch the two separately".
 template <int HC, int K>
 int launch_dw_bf16(const gatres_bf16* G, const gatres_bf16* X, float* slab, int num_slabs, long long stride, int N,
-                   hipStream_t st) {
+                   hipStream_t st, const ConvGradsCo* cg = nullptr, int cg_slabs = 0) {
   if constexpr (HC % 64 == 0 && K % 64 == 0) {
     // few slab rows asked for (the per-op driver does for wide models): rows x output blocks instead of rows only
     constexpr int OB = (HC / 64) * (K / 64);
     if (num_slabs * OB <= 1024 && num_slabs <= 128 && !getenv("GATRES_DW_1D")) {
       int npg = (N + num_slabs - 1) / num_slabs;
       npg = (npg + 3) & ~3;
-      hipLaunchKernelGGL((dw2d_bf16_kernel<HC, K>), dim3(num_slabs * OB), dim3(256), 0, st, G, X, slab, stride, N, npg);
+      ConvGradsCo co{};
+      if (cg) co = *cg;
+      const int dw_grid = num_slabs * OB;
+      hipLaunchKernelGGL((dw2d_bf16_kernel<HC, K>), dim3(dw_grid + (cg ? cg_slabs : 0)), dim3(256), 0, st, G, X, slab,
+                         stride, N, npg, dw_grid, co);
       return gatres_launch_status();
     }
   }
+  if (cg) return GATRES_E_UNSUPPORTED;
   if constexpr (HC % 16 == 0 && K % 16 == 0 && (HC / 16) * (K / 16) >= 4 && ((HC / 16) * (K / 16)) % 4 == 0 &&
                 (HC + K) * 80 <= 160 * 1024) {
     int nps = (N + num_slabs - 1) / num_slabs;
@@ -865,6 +894,38 @@ extern "C" int gatres_t_proj_bwd_dw(const void* g_h, const void* x, float* slab_
   if (dtype != GATRES_DTYPE_F32) return GATRES_E_UNSUPPORTED;
 #define CASE_(K_, M_) \
   if (K == K_ && HC == M_) return launch_dw<M_, K_, float>((const float*)g_h, (const float*)x, slab_W, num_slabs, slab_stride, num_nodes, st);
+  GATRES_FOR_SHAPES(CASE_)
+#undef CASE_
+  return GATRES_E_UNSUPPORTED;
+}
+
+// (not part of include/gatres.h: the per-op backward driver's co-launch of a convolution's two partial-sum kernels -- bf16
+//  storage, two-dimensional weight partials.  GATRES_E_UNSUPPORTED = launch gatres_t_proj_bwd_dw and
+//  gatres_t_conv_param_grads separately.)
+extern "C" __attribute__((visibility("hidden"))) int gatres_proj_bwd_dw_with_conv_grads(
+    const void* g_h, const void* x, float* slab_W, int w_slabs, int64_t slab_stride, int num_nodes, int K, int HC,
+    const void* h, const float* g_a_src, const float* g_a_dst, const void* g_out, float* slab_att_src, float* slab_att_dst,
+    float* slab_bias, int num_slabs, int H, int C, void* stream) {
+  if (!g_h || !x || !slab_W || !h || !g_a_src || !g_a_dst || !g_out || !slab_att_src || !slab_att_dst || !slab_bias ||
+      num_nodes <= 0 || w_slabs <= 0 || num_slabs <= 0)
+    return GATRES_E_BADARG;
+  if (!gatres_aligned16(g_h) || !gatres_aligned16(x)) return GATRES_E_BADARG;
+  if (H * C != HC || HC > 256 || (HC % 2) || (C % 2) || getenv("GATRES_NO_CO_LAUNCH") || getenv("GATRES_DW_FP32"))
+    return GATRES_E_UNSUPPORTED;
+  ConvGradsCo cg;
+  cg.h = (const gatres_bf16*)h; cg.g_a_src = g_a_src; cg.g_a_dst = g_a_dst; cg.g_out = (const gatres_bf16*)g_out;
+  cg.slab_as = slab_att_src; cg.slab_ad = slab_att_dst; cg.slab_b = slab_bias; cg.stride = (long long)slab_stride;
+  cg.H = H; cg.C = C;
+  cg.nps = (num_nodes + num_slabs - 1) / num_slabs;
+  cg.nps = (cg.nps + 3) & ~3;                    // (nodes_per_slab of k_misc.hip: the slab boundaries of every other kernel)
+  hipStream_t st = gatres_stream(stream);
+#define CASE_(K_, M_)                                                                                                 \
+  if (K == K_ && HC == M_) {                                                                                          \
+    if (K_ >= 32 && M_ >= 32)                                                                                         \
+      return launch_dw_bf16<M_, K_>((const gatres_bf16*)g_h, (const gatres_bf16*)x, slab_W, w_slabs, slab_stride,     \
+                                    num_nodes, st, &cg, num_slabs);                                                   \
+    return GATRES_E_UNSUPPORTED;                                                                                      \
+  }
   GATRES_FOR_SHAPES(CASE_)
 #undef CASE_
   return GATRES_E_UNSUPPORTED;

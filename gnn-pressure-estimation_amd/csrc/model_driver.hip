@@ -166,6 +166,24 @@ extern "C" int gatres_model_reduce_grads(const gatres_model_t* m, const gatres_g
                                      grads, stream);
 }
 
+extern "C" __attribute__((visibility("hidden"))) int gatres_proj_bwd_dw_with_conv_grads(
+    const void* g_h, const void* x, float* slab_W, int w_slabs, int64_t slab_stride, int num_nodes, int K, int HC,
+    const void* h, const float* g_a_src, const float* g_a_dst, const void* g_out, float* slab_att_src, float* slab_att_dst,
+    float* slab_bias, int num_slabs, int H, int C, void* stream);
+// A convolution's two partial-sum launches (attention-vector / bias partials, weight partials): one launch where the bf16
+// two-dimensional weight-gradient kernel applies, else one after the other.
+static int conv_partials(const void* gh, const void* xin, float* slab_W, int Sw, int64_t st, int N, int K, int HC,
+                         const void* h, const float* gas, const float* gad, const void* gout, float* s_as, float* s_ad,
+                         float* s_b, int S, int H, int C, int dt, void* stream) {
+  if (dt == GATRES_DTYPE_BF16) {
+    const int rc = gatres_proj_bwd_dw_with_conv_grads(gh, xin, slab_W, Sw, st, N, K, HC, h, gas, gad, gout, s_as, s_ad, s_b,
+                                                      S, H, C, stream);
+    if (rc != GATRES_E_UNSUPPORTED) return rc;
+  }
+  RC(gatres_t_conv_param_grads(h, gas, gad, gout, s_as, s_ad, s_b, S, st, N, H, C, dt, stream));
+  return gatres_t_proj_bwd_dw(gh, xin, slab_W, Sw, st, N, K, HC, dt, stream);
+}
+
 // One piece of the per-op backward: [lin1 backward] blocks b_hi-1 .. b_lo [lin0 backward].  With GATRES_PART_REDUCE the
 // slab partials of exactly the parameters this piece finishes are summed into `grads` right away, so a data-parallel
 // caller can start the all-reduce of that range while the next piece runs (gradient buckets in reverse block order).
@@ -230,18 +248,16 @@ extern "C" int gatres_model_backward_per_op_part(const gatres_model_t* m, const 
                                       nc, dt, stream));
     RC(gatres_t_gat_aggregate_bwd_src(g, gy2, base + L.s_al2, ge, gad, pb + L.c2_as, pb + L.c2_ad, gh, gas, 1, nc, dt,
                                       stream));
-    RC(gatres_t_conv_param_grads(base + L.s_h2, gas, gad, gy2, sb + L.c2_as, sb + L.c2_ad, sb + L.c2_b, S, st, N, 1, nc,
-                                 dt, stream));
-    RC(gatres_t_proj_bwd_dw(gh, base + L.s_o1, sb + L.c2_W, Sw, st, N, 2 * nc, nc, dt, stream));
+    RC(conv_partials(gh, base + L.s_o1, sb + L.c2_W, Sw, st, N, 2 * nc, nc, base + L.s_h2, gas, gad, gy2, sb + L.c2_as,
+                     sb + L.c2_ad, sb + L.c2_b, S, 1, nc, dt, stream));
     RC(gatres_t_proj_bwd_dx(gh, wt2, nullptr, base + L.s_o1, go1, N, 2 * nc, nc, dt, stream));   // ReLU mask of conv1
     // conv1 (H = 2, C = nc, K = nc)
     RC(gatres_t_gat_aggregate_bwd_dst(g, go1, base + L.s_h1, base + L.s_al1, base + L.s_as1, base + L.s_ad1, ge, gad, 2,
                                       nc, dt, stream));
     RC(gatres_t_gat_aggregate_bwd_src(g, go1, base + L.s_al1, ge, gad, pb + L.c1_as, pb + L.c1_ad, gh, gas, 2, nc, dt,
                                       stream));
-    RC(gatres_t_conv_param_grads(base + L.s_h1, gas, gad, go1, sb + L.c1_as, sb + L.c1_ad, sb + L.c1_b, S, st, N, 2, nc,
-                                 dt, stream));
-    RC(gatres_t_proj_bwd_dw(gh, base + L.s_xin, sb + L.c1_W, Sw, st, N, nc, 2 * nc, dt, stream));
+    RC(conv_partials(gh, base + L.s_xin, sb + L.c1_W, Sw, st, N, nc, 2 * nc, base + L.s_h1, gas, gad, go1, sb + L.c1_as,
+                     sb + L.c1_ad, sb + L.c1_b, S, 2, nc, dt, stream));
     // d/d xin = conv1 path + residual; masked by the previous block's ReLU (block 0's input is lin0, no ReLU)
     RC(gatres_t_proj_bwd_dx(gh, wt1, gp_cur, b > 0 ? base + L.s_xin : nullptr, gp_nxt, N, nc, 2 * nc, dt, stream));
     float* t = gp_cur; gp_cur = gp_nxt; gp_nxt = t;
