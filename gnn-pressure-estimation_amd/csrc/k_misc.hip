@@ -212,66 +212,13 @@ __global__ __launch_bounds__(64) void lin1_bwd_kernel(const float* __restrict__ 
 
 // -------------------------------------------------------------------------------- GATConv parameter grads
 // g_att_src[hc] = sum_n g_a_src[n,h]*h[n,hc];  g_att_dst likewise;  g_bias[hc] = sum_n g_out[n,hc]
-// One workgroup of four waves per slab: wave w takes rows nbeg + w, nbeg + w + 4, ... with four rows in flight (a
-// single wave walking its rows one dependent load at a time ran at 0.4 TB/s on 100k-row graphs); the four partial
-// sums meet in LDS in wave order, so the result is deterministic.
+// (generic storage type: k_conv_grads_bf16.h)
 template <typename T>
 __global__ __launch_bounds__(256) void conv_param_grads_kernel(
     const T* __restrict__ h, const float* __restrict__ g_a_src, const float* __restrict__ g_a_dst,
     const T* __restrict__ g_out, float* __restrict__ slab_as, float* __restrict__ slab_ad,
     float* __restrict__ slab_b, long long stride, int N, int H, int C, int nps) {
-  __shared__ float part[3][3][256];                 // [as|ad|ab][waves 1..3][column]
-  const int s = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int HC = H * C;
-  const int nbeg = s * nps, nend = min(N, nbeg + nps);
-  float as[4] = {0.f, 0.f, 0.f, 0.f}, ad[4] = {0.f, 0.f, 0.f, 0.f}, ab[4] = {0.f, 0.f, 0.f, 0.f};
-  for (int n0 = nbeg + wave; n0 < nend; n0 += 16) {
-    float hv[4][4], go[4][4], gs[4][4], gd[4][4];
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int n = n0 + 4 * u;
-      const bool ok = n < nend;
-      const int nn = ok ? n : nbeg;
-#pragma unroll
-      for (int cc = 0; cc < 4; ++cc) {
-        const int c = lane + 64 * cc;
-        const bool cok = ok && c < HC;
-        const int ci = c < HC ? c : 0;
-        hv[u][cc] = cok ? ldval(h + (size_t)nn * HC + ci) : 0.f;
-        go[u][cc] = cok ? ldval(g_out + (size_t)nn * HC + ci) : 0.f;
-        gs[u][cc] = cok ? g_a_src[nn * H + ci / C] : 0.f;
-        gd[u][cc] = cok ? g_a_dst[nn * H + ci / C] : 0.f;
-      }
-    }
-#pragma unroll
-    for (int u = 0; u < 4; ++u)
-#pragma unroll
-      for (int cc = 0; cc < 4; ++cc) {
-        as[cc] = fmaf(gs[u][cc], hv[u][cc], as[cc]);
-        ad[cc] = fmaf(gd[u][cc], hv[u][cc], ad[cc]);
-        ab[cc] += go[u][cc];
-      }
-  }
-  if (wave > 0) {
-#pragma unroll
-    for (int cc = 0; cc < 4; ++cc) {
-      part[0][wave - 1][lane + 64 * cc] = as[cc];
-      part[1][wave - 1][lane + 64 * cc] = ad[cc];
-      part[2][wave - 1][lane + 64 * cc] = ab[cc];
-    }
-  }
-  __syncthreads();
-  if (wave == 0) {
-#pragma unroll
-    for (int cc = 0; cc < 4; ++cc) {
-      const int c = lane + 64 * cc;
-      if (c < HC) {
-        slab_as[(size_t)s * stride + c] = ((as[cc] + part[0][0][c]) + part[0][1][c]) + part[0][2][c];
-        slab_ad[(size_t)s * stride + c] = ((ad[cc] + part[1][0][c]) + part[1][1][c]) + part[1][2][c];
-        slab_b[(size_t)s * stride + c] = ((ab[cc] + part[2][0][c]) + part[2][1][c]) + part[2][2][c];
-      }
-    }
-  }
+  conv_param_grads_body<T>(blockIdx.x, h, g_a_src, g_a_dst, g_out, slab_as, slab_ad, slab_b, stride, N, H, C, nps);
 }
 
 // bf16 tables: k_conv_grads_bf16.h

@@ -305,7 +305,11 @@ __device__ __forceinline__ void load_vec(const gatres_bf16* __restrict__ p, bool
 template <int HC, int K, typename T>
 __global__ __launch_bounds__(256) void dw_kernel(const T* __restrict__ G, const T* __restrict__ X,
                                                  float* __restrict__ slab, int num_slabs, long long slab_stride,
-                                                 int N, int nodes_per_slab) {
+                                                 int N, int nodes_per_slab, int dw_grid, gatres_conv_grads_co<T> cg) {
+  if ((int)blockIdx.x >= dw_grid) {               // co-launched attention-vector / bias partials (see dw2d_bf16_kernel)
+    conv_param_grads_co_run((int)blockIdx.x - dw_grid, cg, N);
+    return;
+  }
   constexpr int CB = HC < 64 ? (HC < 16 ? 16 : HC) : 64;   // rows of g_W per wave
   constexpr int KB = K < 64 ? (K < 16 ? 16 : K) : 64;      // cols of g_W per wave
   constexpr int VC = CB / 16, VK = KB / 16;
@@ -666,25 +670,14 @@ __global__ __launch_bounds__(256) void dw_bf16_kernel(const gatres_bf16* __restr
 // partials (conv_param_grads_bf16_body, slab cg.first + ...).  The two partial-sum launches of a convolution's backward
 // read the same tables, write disjoint slab regions and each leave most of the chip waiting on memory: as one launch they
 // overlap (as two parallel branches of the captured graph they cost more than they return).
-struct ConvGradsCo {
-  const gatres_bf16* h;
-  const float* g_a_src;
-  const float* g_a_dst;
-  const gatres_bf16* g_out;
-  float* slab_as;
-  float* slab_ad;
-  float* slab_b;
-  long long stride;
-  int H, C, nps;
-};
+typedef gatres_conv_grads_co<gatres_bf16> ConvGradsCo;
 
 template <int HC, int K>
 __global__ __launch_bounds__(256) void dw2d_bf16_kernel(const gatres_bf16* __restrict__ G, const gatres_bf16* __restrict__ X,
                                                         float* __restrict__ slab, long long slab_stride, int N,
                                                         int nodes_per_group, int dw_grid, ConvGradsCo cg) {
   if ((int)blockIdx.x >= dw_grid) {               // (workgroup-uniform)
-    conv_param_grads_bf16_body((int)blockIdx.x - dw_grid, cg.h, cg.g_a_src, cg.g_a_dst, cg.g_out, cg.slab_as, cg.slab_ad,
-                               cg.slab_b, cg.stride, N, cg.H, cg.C, cg.nps);
+    conv_param_grads_co_run((int)blockIdx.x - dw_grid, cg, N);
     return;
   }
   constexpr int OBK = K / 64, OB = (HC / 64) * OBK, CH = 64;          // 64-node chunks: two MFMA k steps
@@ -790,15 +783,19 @@ int launch_dw_bf16(const gatres_bf16* G, const gatres_bf16* X, float* slab, int 
 }
 
 template <int HC, int K, typename T>
-int launch_dw(const T* G, const T* X, float* slab, int num_slabs, long long stride, int N, hipStream_t st) {
+int launch_dw(const T* G, const T* X, float* slab, int num_slabs, long long stride, int N, hipStream_t st,
+              const gatres_conv_grads_co<T>* cg = nullptr, int cg_slabs = 0) {
   constexpr int CB = HC < 64 ? (HC < 16 ? 16 : HC) : 64;
   constexpr int KB = K < 64 ? (K < 16 ? 16 : K) : 64;
   constexpr int NBLK = ((HC + CB - 1) / CB) * ((K + KB - 1) / KB);
   int nps = (N + num_slabs - 1) / num_slabs;
   nps = (nps + 3) & ~3;
   const long long waves = (long long)num_slabs * NBLK;
-  hipLaunchKernelGGL((dw_kernel<HC, K, T>), dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, st, G, X, slab, num_slabs,
-                     stride, N, nps);
+  gatres_conv_grads_co<T> co{};
+  if (cg) co = *cg;
+  const int dw_grid = (int)((waves + 3) / 4);
+  hipLaunchKernelGGL((dw_kernel<HC, K, T>), dim3((unsigned)(dw_grid + (cg ? cg_slabs : 0))), dim3(256), 0, st, G, X, slab,
+                     num_slabs, stride, N, nps, dw_grid, co);
   return gatres_launch_status();
 }
 
@@ -905,20 +902,19 @@ extern "C" int gatres_t_proj_bwd_dw(const void* g_h, const void* x, float* slab_
 extern "C" __attribute__((visibility("hidden"))) int gatres_proj_bwd_dw_with_conv_grads(
     const void* g_h, const void* x, float* slab_W, int w_slabs, int64_t slab_stride, int num_nodes, int K, int HC,
     const void* h, const float* g_a_src, const float* g_a_dst, const void* g_out, float* slab_att_src, float* slab_att_dst,
-    float* slab_bias, int num_slabs, int H, int C, void* stream) {
+    float* slab_bias, int num_slabs, int H, int C, int dtype, void* stream) {
   if (!g_h || !x || !slab_W || !h || !g_a_src || !g_a_dst || !g_out || !slab_att_src || !slab_att_dst || !slab_bias ||
       num_nodes <= 0 || w_slabs <= 0 || num_slabs <= 0)
     return GATRES_E_BADARG;
   if (!gatres_aligned16(g_h) || !gatres_aligned16(x)) return GATRES_E_BADARG;
-  if (H * C != HC || HC > 256 || (HC % 2) || (C % 2) || getenv("GATRES_NO_CO_LAUNCH") || getenv("GATRES_DW_FP32"))
-    return GATRES_E_UNSUPPORTED;
-  ConvGradsCo cg;
-  cg.h = (const gatres_bf16*)h; cg.g_a_src = g_a_src; cg.g_a_dst = g_a_dst; cg.g_out = (const gatres_bf16*)g_out;
-  cg.slab_as = slab_att_src; cg.slab_ad = slab_att_dst; cg.slab_b = slab_bias; cg.stride = (long long)slab_stride;
-  cg.H = H; cg.C = C;
-  cg.nps = (num_nodes + num_slabs - 1) / num_slabs;
-  cg.nps = (cg.nps + 3) & ~3;                    // (nodes_per_slab of k_misc.hip: the slab boundaries of every other kernel)
+  if (H * C != HC || HC > 256 || getenv("GATRES_NO_CO_LAUNCH")) return GATRES_E_UNSUPPORTED;
+  int nps = (num_nodes + num_slabs - 1) / num_slabs;
+  nps = (nps + 3) & ~3;                          // (nodes_per_slab of k_misc.hip: the slab boundaries of every other kernel)
   hipStream_t st = gatres_stream(stream);
+  if (dtype == GATRES_DTYPE_BF16) {
+    if ((HC % 2) || (C % 2) || getenv("GATRES_DW_FP32")) return GATRES_E_UNSUPPORTED;
+    ConvGradsCo cg{(const gatres_bf16*)h, g_a_src, g_a_dst, (const gatres_bf16*)g_out, slab_att_src, slab_att_dst, slab_bias,
+                   (long long)slab_stride, H, C, nps};
 #define CASE_(K_, M_)                                                                                                 \
   if (K == K_ && HC == M_) {                                                                                          \
     if (K_ >= 32 && M_ >= 32)                                                                                         \
@@ -926,6 +922,18 @@ extern "C" __attribute__((visibility("hidden"))) int gatres_proj_bwd_dw_with_con
                                     num_nodes, st, &cg, num_slabs);                                                   \
     return GATRES_E_UNSUPPORTED;                                                                                      \
   }
+    GATRES_FOR_SHAPES(CASE_)
+#undef CASE_
+    return GATRES_E_UNSUPPORTED;
+  }
+  if (dtype != GATRES_DTYPE_F32) return GATRES_E_UNSUPPORTED;
+  // fp32: the per-wave weight-gradient kernel fills the chip by itself on large tables -- measured: gatres_small per-op
+  // (12 k rows) 1.21 -> 1.04 ms/step with the co-launch, gatres_large on 50 k / 100 k rows 13.53 -> 13.54 / 25.0 -> 25.4
+  if (num_nodes > 32768 && !getenv("GATRES_CO_LAUNCH_ALWAYS")) return GATRES_E_UNSUPPORTED;
+  gatres_conv_grads_co<float> cf{(const float*)h, g_a_src, g_a_dst, (const float*)g_out, slab_att_src, slab_att_dst,
+                                 slab_bias, (long long)slab_stride, H, C, nps};
+#define CASE_(K_, M_) \
+  if (K == K_ && HC == M_) return launch_dw<M_, K_, float>((const float*)g_h, (const float*)x, slab_W, w_slabs, slab_stride, num_nodes, st, &cf, num_slabs);
   GATRES_FOR_SHAPES(CASE_)
 #undef CASE_
   return GATRES_E_UNSUPPORTED;

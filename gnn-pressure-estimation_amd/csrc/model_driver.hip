@@ -169,15 +169,15 @@ extern "C" int gatres_model_reduce_grads(const gatres_model_t* m, const gatres_g
 extern "C" __attribute__((visibility("hidden"))) int gatres_proj_bwd_dw_with_conv_grads(
     const void* g_h, const void* x, float* slab_W, int w_slabs, int64_t slab_stride, int num_nodes, int K, int HC,
     const void* h, const float* g_a_src, const float* g_a_dst, const void* g_out, float* slab_att_src, float* slab_att_dst,
-    float* slab_bias, int num_slabs, int H, int C, void* stream);
-// A convolution's two partial-sum launches (attention-vector / bias partials, weight partials): one launch where the bf16
-// two-dimensional weight-gradient kernel applies, else one after the other.
+    float* slab_bias, int num_slabs, int H, int C, int dtype, void* stream);
+// A convolution's two partial-sum launches (attention-vector / bias partials, weight partials): ONE launch (extra workgroups
+// of the weight-gradient kernel run the column sums) where a co-launching kernel applies, else one after the other.
 static int conv_partials(const void* gh, const void* xin, float* slab_W, int Sw, int64_t st, int N, int K, int HC,
                          const void* h, const float* gas, const float* gad, const void* gout, float* s_as, float* s_ad,
                          float* s_b, int S, int H, int C, int dt, void* stream) {
-  if (dt == GATRES_DTYPE_BF16) {
+  {
     const int rc = gatres_proj_bwd_dw_with_conv_grads(gh, xin, slab_W, Sw, st, N, K, HC, h, gas, gad, gout, s_as, s_ad, s_b,
-                                                      S, H, C, stream);
+                                                      S, H, C, dt, stream);
     if (rc != GATRES_E_UNSUPPORTED) return rc;
   }
   RC(gatres_t_conv_param_grads(h, gas, gad, gout, s_as, s_ad, s_b, S, st, N, H, C, dt, stream));
