@@ -7,7 +7,7 @@
 // bitwise reproducible.
 #include "gatres_common.h"
 #include "gatres_typed.h"
-#include "k_conv_grads_bf16.h"
+#include "k_conv_grads.h"
 
 namespace {
 
@@ -212,7 +212,7 @@ __global__ __launch_bounds__(64) void lin1_bwd_kernel(const float* __restrict__ 
 
 // -------------------------------------------------------------------------------- GATConv parameter grads
 // g_att_src[hc] = sum_n g_a_src[n,h]*h[n,hc];  g_att_dst likewise;  g_bias[hc] = sum_n g_out[n,hc]
-// (generic storage type: k_conv_grads_bf16.h)
+// (generic storage type: k_conv_grads.h)
 template <typename T>
 __global__ __launch_bounds__(256) void conv_param_grads_kernel(
     const T* __restrict__ h, const float* __restrict__ g_a_src, const float* __restrict__ g_a_dst,
@@ -221,7 +221,7 @@ __global__ __launch_bounds__(256) void conv_param_grads_kernel(
   conv_param_grads_body<T>(blockIdx.x, h, g_a_src, g_a_dst, g_out, slab_as, slab_ad, slab_b, stride, N, H, C, nps);
 }
 
-// bf16 tables: k_conv_grads_bf16.h
+// bf16 tables: k_conv_grads.h
 __global__ __launch_bounds__(256) void conv_param_grads_bf16_kernel(
     const gatres_bf16* __restrict__ h, const float* __restrict__ g_a_src, const float* __restrict__ g_a_dst,
     const gatres_bf16* __restrict__ g_out, float* __restrict__ slab_as, float* __restrict__ slab_ad,

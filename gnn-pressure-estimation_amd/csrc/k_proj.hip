@@ -17,7 +17,7 @@
 #include <cstdlib>
 
 #include "gatres_common.h"
-#include "k_conv_grads_bf16.h"
+#include "k_conv_grads.h"
 #include "gatres_typed.h"
 
 namespace {
