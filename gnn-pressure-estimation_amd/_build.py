@@ -18,7 +18,8 @@ OBJ_DIR = os.path.join(PKG_DIR, "build")
 LIB_PATH = os.path.join(LIB_DIR, "libgatres_hip.so")
 ARCH = "gfx950"
 
-SOURCES = ["k_aggregate.hip", "k_proj.hip", "k_misc.hip", "graph_plan.hip", "model_driver.hip", "train_driver.hip", "k_fused.hip"]
+SOURCES = ["k_window.hip", "k_fused_whole.hip", "k_fused_host.hip", "k_aggregate.hip", "k_proj.hip", "k_misc.hip", "graph_plan.hip",
+           "model_driver.hip", "train_driver.hip"]
 
 
 def _hipcc() -> str:
@@ -41,10 +42,20 @@ def _stale(target: str, deps) -> bool:
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build_native(force: bool = False, verbose: bool = False) -> str:
-    """Compile (only what changed) and link; returns the path of the shared library."""
+DIAG_LIB_PATH = os.path.join(LIB_DIR, "libgatres_hip_diag.so")
+
+
+def build_native(force: bool = False, verbose: bool = False, diag: bool = False) -> str:
+    """Compile (only what changed) and link; returns the path of the shared library.
+
+    ``diag=True`` builds the DIAGNOSTIC library instead (lib/libgatres_hip_diag.so, -DGATRES_DIAG_BUILD): stage stamps
+    (gatres_fused_set_stamps), the wrong-result switches GATRES_XCH_NOWAIT / GATRES_DIAG_NOMASK and the nc > 32
+    instantiations of the per-snapshot kernels.  The product library carries none of them.  ``_native.load()`` takes
+    the diagnostic library when GATRES_DIAG_LIB=1 (tests/stage_profile.py)."""
     os.makedirs(LIB_DIR, exist_ok=True)
-    os.makedirs(OBJ_DIR, exist_ok=True)
+    obj_dir = OBJ_DIR + ("_diag" if diag else "")
+    lib_path = DIAG_LIB_PATH if diag else LIB_PATH
+    os.makedirs(obj_dir, exist_ok=True)
     headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
     headers.append(os.path.join(REPO_DIR, "include", "gatres.h"))
     srcs = [s for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
@@ -53,10 +64,10 @@ def build_native(force: bool = False, verbose: bool = False) -> str:
     objs = []
     for s in srcs:
         src = os.path.join(CSRC, s)
-        obj = os.path.join(OBJ_DIR, s.replace(".hip", ".o"))
+        obj = os.path.join(obj_dir, s.replace(".hip", ".o"))
         objs.append(obj)
         if force or _stale(obj, [src] + headers):
-            jobs.append([hipcc] + _flags() + ["-c", src, "-o", obj])
+            jobs.append([hipcc] + _flags() + (["-DGATRES_DIAG_BUILD"] if diag else []) + ["-c", src, "-o", obj])
 
     def run(cmd):
         if verbose:
@@ -70,10 +81,10 @@ def build_native(force: bool = False, verbose: bool = False) -> str:
     if jobs:
         with ThreadPoolExecutor(max_workers=min(4, len(jobs))) as ex:
             list(ex.map(run, jobs))
-    if jobs or force or _stale(LIB_PATH, objs):
-        run([hipcc, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", LIB_PATH] + objs)
-    return LIB_PATH
+    if jobs or force or _stale(lib_path, objs):
+        run([hipcc, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", lib_path] + objs)
+    return lib_path
 
 
 if __name__ == "__main__":
-    print(build_native(force="--force" in sys.argv, verbose=True))
+    print(build_native(force="--force" in sys.argv, verbose=True, diag="--diag" in sys.argv))

@@ -56,6 +56,7 @@ SIGNATURES = {
     "gatres_permute_f32": (C.c_int, [_P, _P, _P, _I32, _I32, _P]),
     "gatres_gather_u8": (C.c_int, [_P, _P, _P, _I32, _P]),
     "gatres_fused_serialize": (C.c_int, [_P]),
+    "gatres_knobs_reload": (C.c_int, []),
     "gatres_fused_status_offset": (_I64, [_MP, _GP]),
     "gatres_lin0_fwd": (C.c_int, [_P, _P, _P, _P, _P, _I32, _I32, _P]),
     "gatres_proj_attn_fwd": (C.c_int, [_P] * 7 + [_I32] * 4 + [_P]),
@@ -116,8 +117,17 @@ SIGNATURES = {
 }
 
 
+def diag_build() -> bool:
+    """GATRES_DIAG_LIB=1 selects the diagnostic build of the library (stage stamps, wrong-result switches); GATRES_LIB=<path>
+    any other build (A/B measurements of kernel variants)."""
+    return os.environ.get("GATRES_DIAG_LIB", "") not in ("", "0")
+
+
 def lib_path() -> str:
-    return _build.LIB_PATH
+    override = os.environ.get("GATRES_LIB")
+    if override:
+        return override
+    return _build.DIAG_LIB_PATH if diag_build() else _build.LIB_PATH
 
 
 def load(build_if_missing: bool = True) -> C.CDLL:
@@ -129,7 +139,7 @@ def load(build_if_missing: bool = True) -> C.CDLL:
     if not os.path.exists(path):
         if not build_if_missing:
             raise RuntimeError(f"{path} is missing; run `python __graft_entry__.py` (build()) first")
-        _build.build_native()
+        _build.build_native(diag=diag_build())
     lib = C.CDLL(path)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)     # AttributeError here == the library does not export the header's symbol

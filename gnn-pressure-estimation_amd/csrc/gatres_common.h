@@ -10,6 +10,38 @@
 #define GATRES_SOFTMAX_EPS 1e-16f    // torch_geometric.utils.softmax: out_sum + 1e-16
 #define GATRES_WAVE 64
 
+// Tuning / fallback switches of the library, read from the environment ONCE (first use) -- never on a launch path.  A
+// process that changes the environment afterwards (the tests do) calls gatres_knobs_reload().  Switches that produce WRONG
+// results exist only in the diagnostic build (GATRES_DIAG_BUILD).
+struct gatres_knobs_t {
+  int agg_lane_features;      // GATRES_AGG_LANE_FEATURES = 4 | 8 (0: automatic)
+  int agg_wide_offsets;       // GATRES_AGG_WIDE_OFFSETS
+  int fused_threads;          // GATRES_FUSED_THREADS = 512 (default 1024)
+  int fused_no_window;        // GATRES_FUSED_NO_WINDOW
+  int fused_split;            // GATRES_FUSED_SPLIT = 1 .. 8 (0: automatic)
+  int fused_prefer_consumers; // GATRES_FUSED_PREFER_CONSUMERS
+  int fused_no_consumers;     // GATRES_FUSED_NO_CONSUMERS
+  int fused_consumers_cap;    // GATRES_FUSED_CONSUMERS (default 2, at most 4)
+  int fused_nocache;          // GATRES_FUSED_NOCACHE
+  int fused_wide;             // GATRES_FUSED_WIDE (diagnostic build only: nc > 32 on the per-snapshot kernels)
+  int fused_safe_sync;        // GATRES_FUSED_SAFE_SYNC: always agent-scope hand-offs (slower, never wrong)
+  int fused_no_halo;          // GATRES_FUSED_NO_HALO: whole-segment kernel, bulk pulls instead of halo lists
+  int fused_no_keep;          // GATRES_FUSED_NO_KEEP
+  int fused_two_kernels;      // GATRES_FUSED_TWO_KERNELS: forward+loss and backward as two launches
+  int param_grads_no_stream;  // GATRES_PARAM_GRADS_NO_STREAM
+  int lin_bwd_wave;           // GATRES_LIN_BWD_WAVE
+  int proj_rows;              // GATRES_PROJ_ROWS (0: default)
+  int no_proj_lds;            // GATRES_NO_PROJ_LDS
+  int dw_1d;                  // GATRES_DW_1D
+  int dw_fp32;                // GATRES_DW_FP32
+  int no_co_launch;           // GATRES_NO_CO_LAUNCH
+  int co_launch_always;       // GATRES_CO_LAUNCH_ALWAYS
+  int dw_slab_rows;           // GATRES_DW_SLAB_ROWS (0: default)
+  int xch_nowait;             // diagnostic build only, WRONG results: GATRES_XCH_NOWAIT
+  int diag_nomask;            // diagnostic build only, WRONG results: GATRES_DIAG_NOMASK
+};
+extern "C" __attribute__((visibility("hidden"))) const gatres_knobs_t* gatres_knobs();
+
 static inline int gatres_launch_status() { return (int)hipGetLastError(); }
 static inline hipStream_t gatres_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
 static inline bool gatres_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }

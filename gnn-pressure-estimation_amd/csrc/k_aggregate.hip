@@ -13,7 +13,6 @@
 //   out_i = sum_e alpha_e * h[j] + bias                        GATConv.message / aggregate(sum) / bias
 //   mean  : out_i = (sum_{j->i} y[j]) / max(indeg(i), 1)       SimpleConv(aggr="mean")
 #include "gatres_common.h"
-#include "gatres_typed.h"
 #include <type_traits>
 
 namespace {
@@ -40,10 +39,7 @@ static inline bool make_geom(int H, int C, RowGeom* g, int W = 4) {      // W = 
 // gives nothing more (6.72) and is not instantiated.  GATRES_AGG_LANE_FEATURES=4|8 overrides the choice.
 static inline int lane_features(int row_width, int C) {
   int w = row_width >= 64 ? 8 : 4;
-  if (const char* e = getenv("GATRES_AGG_LANE_FEATURES")) {
-    const int v = atoi(e);
-    if (v == 4 || v == 8) w = v;
-  }
+  if (const int v = gatres_knobs()->agg_lane_features) w = v;
   while (w > 4 && (C < w || row_width < 4 * w)) w >>= 1;       // at least one lane per head, four per row
   return w;
 }
@@ -659,7 +655,7 @@ static inline int grid_rows(int N, int G) {
 
 }  // namespace
 
-// Typed launchers (gatres_typed.h): `dtype` says what the void* activation tensors hold.  The C-ABI entry points below are
+// Typed launchers (gatres_t_*): `dtype` says what the void* activation tensors hold.  The C-ABI entry points below are
 // their fp32 instances.
 #define GATRES_DISPATCH_T(dtype_, fit32_, CALL_)                                                       \
   switch (dtype_) {                                                                                    \
@@ -694,7 +690,7 @@ static inline bool offsets_fit_32(const gatres_graph_t* g, int width) {
   long long most = g->num_nodes;
   if (g->num_edges_gat > most) most = g->num_edges_gat;
   if (g->num_edges_mean > most) most = g->num_edges_mean;
-  return (most + 2) * (long long)width * 4 < (1LL << 32) && !getenv("GATRES_AGG_WIDE_OFFSETS");
+  return (most + 2) * (long long)width * 4 < (1LL << 32) && !gatres_knobs()->agg_wide_offsets;
 }
 
 extern "C" int gatres_t_gat_aggregate_fwd(const gatres_graph_t* g, const void* h, const float* a_src, const float* a_dst,

@@ -1,3 +1,5 @@
+// Device code shared by the per-snapshot GATRes kernels (k_fused.hip: whole-segment tables, k_window.hip: row windows,
+// k_fused_host.hip: the deferred parameter gradients and the C-ABI).  Everything here has internal linkage.
 // Fused per-snapshot GATRes kernels for gfx950: ONE workgroup owns ONE graph segment (a snapshot of the batch)
 // and carries it through lin0 -> num_blocks x [K1 conv1, K2 conv1, K1 conv2, K2 conv2, K3] -> lin1 -> masked-MSE ->
 // the whole backward, inside a single launch.
@@ -19,6 +21,7 @@
 //     g_a_src, g_a_dst stay in LDS;  only what the backward pass needs later is written to HBM (coalesced float4);
 //   * dense projections on the matrix cores (v_mfma_f32_16x16x4_f32, exact fp32), two 16-node tiles per wave
 //     sharing each W fragment; dW partials with 8 operand pairs in flight per wave.
+#pragma once
 #include <cstdlib>
 #include <mutex>
 #include <type_traits>
@@ -73,23 +76,35 @@ struct FusedArgs {
 
 enum { PH_LOSS = 16 };
 
-static unsigned long long* g_stamps = nullptr;
-static int g_stamp_cap = 0;
-
+// Stage stamps and the knobs that produce WRONG results (never-wait exchanges, unmasked dX epilogues) exist only in the
+// diagnostic build of the library (-DGATRES_DIAG_BUILD: _build.build_native(diag=True) -> lib/libgatres_hip_diag.so,
+// loaded when GATRES_DIAG_LIB=1); the product build carries neither the code nor the registers they cost.
+#ifdef GATRES_DIAG_BUILD
+#define GATRES_DIAG 1
+#define STAMPS_PTR (a.stamps)
 #define STAMP()                                                                                  \
   do {                                                                                           \
     if (a.stamps && blockIdx.x == 0 && threadIdx.x == 0 && stamp_i < a.stamp_cap)                \
       a.stamps[stamp_i++] = wall_clock64();                                                      \
   } while (0)
+#else
+#define GATRES_DIAG 0
+#define STAMPS_PTR (static_cast<unsigned long long*>(nullptr))
+#define STAMP() do {} while (0)
+#endif
 
 // finer diagnostic of ONE backward block of segment 0 (tests/stage_profile.py --xstamps): wave 0 and the last wave of every
 // part stamp the steps of the block's three exchanges; slots [2048 + (part * 2 + who) * 64 + step]
+#if GATRES_DIAG
 #define XSTAMP()                                                                                 \
   do {                                                                                           \
     if (xs_on && (threadIdx.x == 0 || threadIdx.x == THREADS - 64) && xs_i < 64)                 \
       a.stamps[2048 + (part * 2 + (threadIdx.x ? 1 : 0)) * 64 + xs_i] = wall_clock64();         \
     ++xs_i;                                                                                      \
   } while (0)
+#else
+#define XSTAMP() do {} while (0)
+#endif
 
 // ------------------------------------------------------------------------------------------ LDS budget (host+device)
 __host__ __device__ inline int even(int v) { return (v + 1) & ~1; }
@@ -1259,7 +1274,7 @@ __device__ __forceinline__ void consumer_item_dma(const ParamGradArgs& a, int se
   using Gm = CiGeom<NC, CONV>;
   constexpr int DEPTH = NBUF - 1;
   constexpr int HC = Gm::HC, K = Gm::K, H = Gm::H, CB = Gm::CB, CR = CI_CR;
-  constexpr int NW = THREADS / 64, CW = NW - CI_DMA_WAVES, CT = CW * 64;          // compute waves / threads
+  constexpr int NW = THREADS / 64, CW = NW - CI_DMA_WAVES;                         // compute waves
   constexpr int VC = HC / 16, VK = K / 16;
   const Layout& L = a.L;
   const SegLayout& SL = a.SL;
@@ -1280,7 +1295,7 @@ __device__ __forceinline__ void consumer_item_dma(const ParamGradArgs& a, int se
   float* tred = NBUF < CI_NBUF ? lds + CW * HC * K : lds + NBUF * CB;
   static_assert(NBUF >= CI_NBUF || CW * HC * K + CW * 4 * K + 4 * K <= NBUF * CB, "the item's epilogue lives in the chunk buffers");
   float* tsum = tred + CW * 4 * K;                               // [4][K]
-#define ISTAMP(k) do { if (a.dstamps && threadIdx.x == 0) a.dstamps[k] = wall_clock64(); } while (0)
+#define ISTAMP(k) do { if (GATRES_DIAG && a.dstamps && threadIdx.x == 0) a.dstamps[k] = wall_clock64(); } while (0)
   ISTAMP(0);
   if (wave >= CW) {
     // ------------------------------------------------------------------ DMA waves
@@ -1747,7 +1762,7 @@ __device__ __forceinline__ void consumer_main(const FusedArgs& a, int cid, float
   pg.seg_ptr = a.seg_ptr; pg.saved = a.saved; pg.keep = a.scratch + a.L.sc_keep; pg.slabs = a.slabs;
   pg.part_slabs = a.part_slabs; pg.M = a.M; pg.L = a.L; pg.SL = a.SL;
   pg.wt = a.wt;
-  pg.dstamps = (a.stamps && cid == 0 && a.stamp_cap >= 4096) ? a.stamps + 3072 : nullptr;
+  pg.dstamps = (STAMPS_PTR && cid == 0 && a.stamp_cap >= 4096) ? STAMPS_PTR + 3072 : nullptr;
   unsigned* my = a.ready + ((size_t)seg * 4 + c) * FLAG_STRIDE;       // words 0 .. M-1: one per producing part
   float* part = ldsf;
   float* red = ldsf + (LDS_BYTES / 4 - 3 * THREADS);
@@ -1759,7 +1774,7 @@ __device__ __forceinline__ void consumer_main(const FusedArgs& a, int cid, float
   int cst = 1024;            // diagnostic stamps of consumer 0 (gatres_fused_set_stamps): [item available, item done] pairs
 #define CSTAMP()                                                                                    \
   do {                                                                                              \
-    if (a.stamps && cid == 0 && threadIdx.x == 0 && cst < a.stamp_cap) a.stamps[cst++] = wall_clock64(); \
+    if (STAMPS_PTR && cid == 0 && threadIdx.x == 0 && cst < a.stamp_cap) STAMPS_PTR[cst++] = wall_clock64(); \
   } while (0)
   for (int i = c; i < items; i += C) {
     if (threadIdx.x < 64) {
@@ -1824,429 +1839,6 @@ __device__ __forceinline__ void consumer_main(const FusedArgs& a, int cid, float
     if (lane < a.M) __hip_atomic_store(my + lane, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
 }
-
-// ------------------------------------------------------------------------------------------ the kernel
-template <int NC, int THREADS, bool CACHE>
-__global__ __launch_bounds__(THREADS) void gatres_fused_kernel(const FusedArgs a) {
-  __shared__ __attribute__((aligned(16))) unsigned char lds_raw[LDS_BYTES];
-  float* ldsf = reinterpret_cast<float*>(lds_raw);
-  const Layout& L = a.L;
-  // workgroup id -> (segment, part): ids of one segment are 8 apart (same XCD)
-  const int M = a.M;
-  {
-    const int F = ((a.num_segments + 7) / 8) * 8 * M;       // per-snapshot workgroups come first, consumers after
-    if ((int)blockIdx.x >= F) {
-      if constexpr (THREADS == 1024) consumer_main<NC, THREADS>(a, (int)blockIdx.x - F, ldsf);
-      return;
-    }
-  }
-  const int within = blockIdx.x % (8 * M);
-  const int seg = (blockIdx.x / (8 * M)) * 8 + (within & 7), part = within >> 3;
-  if (seg >= a.num_segments) return;
-  const bool split = M > 1;
-  const int n0 = a.seg_ptr[seg], n = a.seg_ptr[seg + 1] - n0;
-  const int e0 = a.rowptr[n0], eg = a.rowptr[n0 + n] - e0;            // GATConv edges of this segment
-  const int em0 = a.m_rowptr[n0], em = a.m_rowptr[n0 + n] - em0;      // SimpleConv edges
-  const int tid = threadIdx.x;
-  Rows rw;                                                            // own rows: whole 16-row tiles
-  {
-    const int tiles = (n + 15) >> 4;
-    rw.lo = 16 * (int)((long long)tiles * part / M);
-    rw.hi = min(n, 16 * (int)((long long)tiles * (part + 1) / M));
-  }
-  Group grp;
-  grp.flags = a.flags + (size_t)seg * 8 * FLAG_STRIDE; grp.M = M; grp.part = part; grp.err = a.err;
-  group_init<THREADS>(grp);
-  if (a.safe_sync) grp.local = false;
-  // rows per lane group per trip: 16 waves x 128 VGPRs cannot hold more than this without spilling; 8 waves x 256 can
-  constexpr int UF = THREADS <= 512 ? 4 : 2;     // forward gathers
-  constexpr int UB = THREADS <= 512 ? 2 : 1;     // backward sparse stages
-  const float* P = a.params;
-  float* sc = a.scratch;
-  int stamp_i = 0;
-  STAMP();
-  if (a.stamps && blockIdx.x == 0 && threadIdx.x == 0) a.stamps[a.stamp_cap] = clock64();   // shader-clock probe
-
-  if (a.phases & GATRES_PHASE_FORWARD) {
-    // LDS map: [hA n x 2NC | hB n x NC | sa 2n | sd 2n] (CACHE) then the 16-bit topology
-    float* hA = ldsf;
-    float* hB = hA + (size_t)n * 2 * NC;
-    float* sa = hB + (size_t)n * NC;
-    float* sd = sa + (size_t)n * 2;
-    u16* tp = reinterpret_cast<u16*>(CACHE ? (sd + (size_t)n * 2) : ldsf);
-    u16* rp = tp;              tp += even(n + 1);
-    u16* col = tp;             tp += even(eg);
-    u16* mrp = tp;             tp += even(n + 1);
-    u16* mcol = tp;
-    tp += even(em);
-    // LDS staging for a projection's W + att (seg_proj): with the tables cached, proj1 borrows the h2 region and
-    // proj2 the h1 region (each is dead exactly then); otherwise a slot behind the topology
-    constexpr int WL_FLOATS = 2 * NC * (2 * NC + 4) + 4 * NC;           // max over the block's projections
-    constexpr bool WLDS = WL_FLOATS * 4 <= 40960;
-    // The slot is always a real LDS address chosen by OFFSET (a nullable LDS pointer makes the compiler build flat
-    // addresses with null checks, hoist them out of the block loop and spill them).  If the cached tables leave
-    // room, a private slot at the end of LDS; otherwise proj1 borrows the h2 table and proj2 the h1 table.
-    const int used_b = (int)(reinterpret_cast<unsigned char*>(tp) - lds_raw);
-    const bool priv = used_b + WL_FLOATS * 4 + 16 <= LDS_BYTES;
-    const int slot_b = LDS_BYTES - ((WL_FLOATS * 4 + 15) & ~15);
-    float* wl1 = reinterpret_cast<float*>(lds_raw + (priv ? slot_b : (int)((unsigned char*)hB - lds_raw)));
-    float* wl2 = reinterpret_cast<float*>(lds_raw + (priv ? slot_b : 0));
-    copy_rowptr16<THREADS>(rp, a.rowptr, n0, n, e0);
-    copy_idx16<THREADS>(col, a.col, e0, eg, n0);
-    copy_rowptr16<THREADS>(mrp, a.m_rowptr, n0, n, em0);
-    copy_idx16<THREADS>(mcol, a.m_col, em0, em, n0);
-
-    // saved tables: this segment's contiguous slot with LOCAL indices (training), or the shared evaluation block of
-    // the scratch area with global indices (inference)
-    const SegLayout& SL = a.SL;
-    float* segbase = a.saved ? a.saved + (int64_t)seg * SL.total : nullptr;
-    const int nbS = a.saved ? 0 : n0, ebS = a.saved ? 0 : e0;
-    const int64_t o_h1 = a.saved ? SL.h1 : L.s_h1, o_as1 = a.saved ? SL.as1 : L.s_as1, o_ad1 = a.saved ? SL.ad1 : L.s_ad1,
-                  o_al1 = a.saved ? SL.al1 : L.s_al1, o_o1 = a.saved ? SL.o1 : L.s_o1, o_h2 = a.saved ? SL.h2 : L.s_h2,
-                  o_as2 = a.saved ? SL.as2 : L.s_as2, o_ad2 = a.saved ? SL.ad2 : L.s_ad2,
-                  o_al2 = a.saved ? SL.al2 : L.s_al2;
-    float* xa = sc + L.sc_xa;
-    float* xb = sc + L.sc_xb;
-    float* xcur = a.saved ? segbase + SL.xin : xa;
-    {  // lin0 (+ the caller-side x[mask] = 0)
-      const float* w = P + L.p_lin0_w;
-      const float* b = P + L.p_lin0_b;
-      for (int idx = rw.lo * (NC / 4) + tid; idx < rw.hi * (NC / 4); idx += THREADS) {
-        const int r = idx / (NC / 4), c0 = (idx % (NC / 4)) * 4;
-        const int node = ext_id(a.perm, n0 + r);
-        const float xv = (a.mask && a.mask[node]) ? 0.f : a.x[node];
-        const float4 wv = ld4(w + c0), bv = ld4(b + c0);
-        float4 o;
-        o.x = xv * wv.x + bv.x; o.y = xv * wv.y + bv.y; o.z = xv * wv.z + bv.z; o.w = xv * wv.w + bv.w;
-        st4(xcur + (unsigned)((nbS + r) * NC + c0), o);
-      }
-    }
-    __syncthreads();
-    // forward halo list in the LDS left over behind the topology (the W slot only lives there when it is `priv`)
-    u16* hlist = tp + 2;
-    int hcnt = 0;
-    bool halo = false;
-    if (CACHE && split) {
-      const int cap = ((priv ? slot_b : LDS_BYTES) - used_b - 8) / 2;
-      if (cap > 0 && !(a.no_halo & 1)) {
-        hcnt = build_halo<THREADS>(rp, col, nullptr, rw, hlist, nullptr, cap, reinterpret_cast<int*>(tp));
-        halo = hcnt <= cap;
-      }
-    }
-    STAMP();
-    for (int b = 0; b < L.nb; ++b) {
-      float* base = a.saved ? segbase + (int64_t)b * SL.bstride : sc + L.sc_ev;
-      float* xnext = a.saved ? segbase + (int64_t)(b + 1) * SL.bstride + SL.xin : (xcur == xa ? xb : xa);
-      const float* pb = P + L.p_block0 + (int64_t)b * L.p_block_stride;
-      float* y2g = sc + L.sc_y2;
-      // conv1: K1, then K2 (+bias+ReLU)
-      seg_proj<NC, 2 * NC, 2, EPI_ATT, THREADS, WLDS>(rw, xcur, nbS, pb + L.c1_W, base + o_h1, nbS, CACHE ? hA : nullptr, 0,
-                                                 pb + L.c1_as, pb + L.c1_ad, base + o_as1, base + o_ad1, nbS,
-                                                 CACHE ? sa : nullptr, CACHE ? sd : nullptr, nullptr, 0, nullptr, 0, wl1);
-      group_sync<THREADS>(grp);                   // the gathers below read every row of h1 / a_src
-      if (CACHE && split) {
-        if (halo) {
-          pull_list_rows<2 * NC, THREADS>(hA, base + o_h1 + (size_t)nbS * 2 * NC, hlist, hcnt);
-          pull_list_small<2, THREADS>(sa, base + o_as1 + (size_t)nbS * 2, hlist, hcnt);
-        } else {
-          pull_rows4<THREADS>(hA, base + o_h1 + (size_t)nbS * 2 * NC, 2 * NC, rw, n);
-          pull_flat<THREADS>(sa, base + o_as1 + (size_t)nbS * 2, rw.lo * 2, rw.hi * 2, n * 2);
-        }
-        __syncthreads();
-      }
-      STAMP();
-      // K2 conv1: softmax (alpha -> HBM + LDS: the h2 table is dead now), then the gather
-      if (CACHE && 2 * eg <= n * NC) {           // (wave-uniform) the alpha table fits the borrowed region
-        seg_softmax<2, true, THREADS>(rw, rp, col, sa, sd, 0, base + o_al1, ebS, hB);
-        __syncthreads();
-        seg_gather<true, 2, NC, THREADS, UF>(rw, rp, col, hA, 0, hB, 0, pb + L.c1_b, base + o_o1, nbS);
-      } else if (CACHE) {
-        seg_softmax<2, false, THREADS>(rw, rp, col, sa, sd, 0, base + o_al1, ebS, nullptr);
-        __syncthreads();
-        seg_gather<true, 2, NC, THREADS, UF>(rw, rp, col, hA, 0, base + o_al1, ebS, pb + L.c1_b, base + o_o1, nbS);
-      } else {
-        seg_softmax<2, false, THREADS>(rw, rp, col, base + o_as1, base + o_ad1, nbS, base + o_al1, ebS, nullptr);
-        __syncthreads();
-        seg_gather<true, 2, NC, THREADS, UF>(rw, rp, col, base + o_h1, nbS, base + o_al1, ebS, pb + L.c1_b, base + o_o1,
-                                         nbS);
-      }
-      __syncthreads();
-      STAMP();
-      // conv2
-      seg_proj<2 * NC, NC, 1, EPI_ATT, THREADS, WLDS>(rw, base + o_o1, nbS, pb + L.c2_W, base + o_h2, nbS,
-                                                 CACHE ? hB : nullptr, 0, pb + L.c2_as, pb + L.c2_ad, base + o_as2,
-                                                 base + o_ad2, nbS, CACHE ? sa : nullptr, CACHE ? sd : nullptr,
-                                                 nullptr, 0, nullptr, 0, wl2);
-      group_sync<THREADS>(grp);
-      if (CACHE && split) {
-        if (halo) {
-          pull_list_rows<NC, THREADS>(hB, base + o_h2 + (size_t)nbS * NC, hlist, hcnt);
-          pull_list_small<1, THREADS>(sa, base + o_as2 + (size_t)nbS, hlist, hcnt);
-        } else {
-          pull_rows4<THREADS>(hB, base + o_h2 + (size_t)nbS * NC, NC, rw, n);
-          pull_flat<THREADS>(sa, base + o_as2 + (size_t)nbS, rw.lo, rw.hi, n);
-        }
-        __syncthreads();
-      }
-      STAMP();
-      // K2 conv2: alpha's LDS table sits in the upper half of the h1 region (y2 is written to the lower half)
-      float* y2pub = split ? y2g : nullptr;       // partners read y2 from the global copy
-      if (CACHE && eg <= n * NC) {
-        float* al2L = hA + (size_t)n * NC;
-        seg_softmax<1, true, THREADS>(rw, rp, col, sa, sd, 0, base + o_al2, ebS, al2L);
-        __syncthreads();
-        seg_gather<false, 1, NC, THREADS, UF>(rw, rp, col, hB, 0, al2L, 0, pb + L.c2_b, hA, 0, y2pub, n0);
-      } else if (CACHE) {
-        seg_softmax<1, false, THREADS>(rw, rp, col, sa, sd, 0, base + o_al2, ebS, nullptr);
-        __syncthreads();
-        seg_gather<false, 1, NC, THREADS, UF>(rw, rp, col, hB, 0, base + o_al2, ebS, pb + L.c2_b, hA, 0, y2pub, n0);
-      } else {
-        seg_softmax<1, false, THREADS>(rw, rp, col, base + o_as2, base + o_ad2, nbS, base + o_al2, ebS, nullptr);
-        __syncthreads();
-        seg_gather<false, 1, NC, THREADS, UF>(rw, rp, col, base + o_h2, nbS, base + o_al2, ebS, pb + L.c2_b, y2g, n0);
-      }
-      group_sync<THREADS>(grp);                   // K3 averages y2 over neighbours
-      if (CACHE && split) {
-        if (halo) pull_list_rows<NC, THREADS>(hA, y2g + (size_t)n0 * NC, hlist, hcnt);
-        else      pull_rows4<THREADS>(hA, y2g + (size_t)n0 * NC, NC, rw, n);
-        __syncthreads();
-      }
-      STAMP();
-      // K3
-      if (CACHE)
-        seg_mean_fwd<NC, THREADS, UF>(rw, em, mrp, mcol, hA, 0, xcur, nbS, xnext, nbS);
-      else
-        seg_mean_fwd<NC, THREADS, UF>(rw, em, mrp, mcol, y2g, n0, xcur, nbS, xnext, nbS);
-      __syncthreads();
-      STAMP();
-      xcur = xnext;
-    }
-    {  // lin1
-      constexpr int G = NC / 4;
-      const float4 wv = ld4(P + L.p_lin1_w + (tid % G) * 4);
-      const float bias = P[L.p_lin1_b];
-      const int rounds = (rw.hi - rw.lo + THREADS / G - 1) / (THREADS / G);
-      for (int it = 0; it < rounds; ++it) {
-        int r = rw.lo + it * (THREADS / G) + tid / G;
-        const bool valid = r < rw.hi;
-        if (!valid) r = rw.hi - 1;
-        const float4 xv = ld4(xcur + (unsigned)((nbS + r) * NC + (tid % G) * 4));
-        float d = xv.x * wv.x;
-        d = fmaf(xv.y, wv.y, d); d = fmaf(xv.z, wv.z, d); d = fmaf(xv.w, wv.w, d);
-        for (int off = G >> 1; off > 0; off >>= 1) d += __shfl_xor(d, off);
-        if (valid && (tid % G) == 0) a.out[ext_id(a.perm, n0 + r)] = d + bias;
-      }
-    }
-    __syncthreads();
-    STAMP();
-  }
-
-  if (a.phases & PH_LOSS) {
-    // M = number of masked nodes in the WHOLE batch (every workgroup counts them itself: N bytes from L2)
-    float cnt = 0.f;
-    for (int i = tid; i < a.N; i += THREADS) cnt += a.mask[i] ? 1.f : 0.f;
-    const float Mn = block_sum<THREADS>(cnt, ldsf);
-    float part_sum = 0.f;
-    for (int r = rw.lo + tid; r < rw.hi; r += THREADS) {
-      const int node = ext_id(a.perm, n0 + r);
-      if (a.mask[node]) {
-        const float d = a.out[node] - a.y[node];
-        part_sum = fmaf(d, d, part_sum);
-      }
-    }
-    part_sum = block_sum<THREADS>(part_sum, ldsf);
-    if (tid == 0) {
-      a.loss_part[seg * M + part] = part_sum;
-      if (seg == 0 && part == 0) a.loss_part[a.num_segments * M] = Mn;
-    }
-    const float scale = Mn > 0.f ? 2.f / Mn : 0.f;
-    for (int r = rw.lo + tid; r < rw.hi; r += THREADS) {
-      const int node = ext_id(a.perm, n0 + r);
-      a.g_out[node] = a.mask[node] ? (a.out[node] - a.y[node]) * scale : 0.f;
-    }
-    __syncthreads();
-    STAMP();
-  }
-
-  if (a.phases & GATRES_PHASE_BACKWARD) {
-    // LDS map: [red 3*THREADS] ( [RA n x 2NC : g_pre | g_y2, later g_out1] [ge 2*eg] [gad 2n] [spare 2n] ) topology
-    float* red = ldsf;
-    float* RA = red + 3 * THREADS;
-    float* geL = RA + (size_t)n * 2 * NC;
-    float* gadL = geL + 2 * (size_t)even(eg);
-    float* spareL = gadL + 2 * (size_t)n;
-    u16* tp = reinterpret_cast<u16*>(CACHE ? (spareL + 2 * (size_t)n) : RA);
-    u16* rp = tp;              tp += even(n + 1);
-    u16* col = tp;             tp += even(eg);
-    u16* trp = tp;             tp += even(n + 1);
-    u16* teid = tp;            tp += even(eg);
-    u16* tdst = tp;            tp += even(eg);
-    u16* mrp = tp;             tp += even(n + 1);
-    u16* mtrp = tp;            tp += even(n + 1);
-    u16* mtdst = tp;
-    tp += even(em);
-    constexpr int WL_FLOATS = 2 * NC * (2 * NC + 4) + 4 * NC;
-    constexpr bool WLDS = WL_FLOATS * 4 <= 40960;
-    float* wlB = reinterpret_cast<float*>(lds_raw + ((reinterpret_cast<unsigned char*>(tp) - lds_raw + 15) & ~15));
-    __syncthreads();           // forward's LDS contents are dead from here
-    copy_rowptr16<THREADS>(rp, a.rowptr, n0, n, e0);
-    copy_idx16<THREADS>(col, a.col, e0, eg, n0);
-    copy_rowptr16<THREADS>(trp, a.t_rowptr, n0, n, e0);
-    copy_idx16<THREADS>(teid, a.t_eid, e0, eg, e0);
-    copy_idx16<THREADS>(tdst, a.t_dst, e0, eg, n0);
-    copy_rowptr16<THREADS>(mrp, a.m_rowptr, n0, n, em0);
-    copy_rowptr16<THREADS>(mtrp, a.mt_rowptr, n0, n, em0);
-    copy_idx16<THREADS>(mtdst, a.mt_dst, em0, em, n0);
-
-    const SegLayout& SL = a.SL;
-    const float* segbase = a.saved + (int64_t)seg * SL.total;
-    float* gp_cur = sc + L.sc_gpa;       // global copies of g_pre (row-wise residual reads, partners' gathers)
-    float* gp_nxt = sc + L.sc_gpb;
-    // gathered / small backward tables: LDS when CACHE, else global scratch (conv2 has private arrays: see Layout).
-    // With a split segment the LDS tables are completed from the *_pub global copies after each flag barrier.
-    const bool pub = CACHE && split;
-    float* gpT = CACHE ? RA : nullptr;                                   // g_pre, LDS copy for the K3 gather
-    float* gy2T = CACHE ? RA + (size_t)n * NC : sc + L.sc_gy2;  const int gy2b = CACHE ? 0 : n0;
-    float* go1T = CACHE ? RA : sc + L.sc_go1;                   const int go1b = CACHE ? 0 : n0;
-    float* ge1T = CACHE ? geL : sc + L.sc_ge;                   const int ge_b = CACHE ? 0 : e0;
-    float* ge2T = CACHE ? geL : sc + L.sc_ge2;
-    float* gad1T = CACHE ? gadL : sc + L.sc_gad;                const int gd_b = CACHE ? 0 : n0;
-    float* gad2T = CACHE ? gadL : sc + L.sc_gad2;
-    float* slab = split ? a.part_slabs + ((int64_t)seg * M + part) * L.slab_stride
-                        : a.slabs + (int64_t)seg * L.slab_stride;
-    const int64_t w = 2LL * NC * NC;
-    const float* xfinal = segbase + (int64_t)L.nb * SL.bstride + SL.xin;
-    seg_lin1_bwd<NC, THREADS>(rw, n0, a.perm, a.g_out, xfinal, P + L.p_lin1_w, gp_cur, gpT, slab + L.p_lin1_w,
-                              slab + L.p_lin1_b, L.nb > 0 ? 1 : 0, red);
-    // backward halo list (remote dst rows + edge ids of own out-edges) in the LDS behind the W slot
-    u16* hrow = reinterpret_cast<u16*>(wlB + (WLDS ? ((WL_FLOATS + 3) & ~3) : 0)) + 2;
-    int hcnt = 0;
-    bool halo = false;
-    if (pub) {
-      const int cap = (int)((lds_raw + LDS_BYTES - reinterpret_cast<unsigned char*>(hrow)) / 4) - 4;
-      if (cap > 0 && !(a.no_halo & 1)) {
-        hcnt = build_halo<THREADS>(trp, tdst, teid, rw, hrow, hrow + cap, cap, reinterpret_cast<int*>(hrow - 2));
-        halo = hcnt <= cap;
-      }
-    }
-    const u16* hedge = hrow + ((int)((lds_raw + LDS_BYTES - reinterpret_cast<unsigned char*>(hrow)) / 4) - 4);
-    STAMP();
-    for (int b = L.nb - 1; b >= 0; --b) {
-      const float* base = segbase + (int64_t)b * SL.bstride;
-      const int64_t po = L.p_block0 + (int64_t)b * L.p_block_stride;
-      const float* pb = P + po;
-      float* sb = slab + po;
-      const float* wt1 = a.wt + (int64_t)b * 2 * w;
-      const float* wt2 = wt1 + w;
-      group_sync<THREADS>(grp);                  // K3 backward gathers g_pre of neighbours
-      publish_items<THREADS>(a, seg, part, 2 * (L.nb - 1 - b), grp.local || !split, false);   // the blocks above are kept
-      const int elo = rp[rw.lo], ehi = rp[rw.hi];       // own in-edge range (edges are dst-sorted)
-      if (pub) {
-        if (halo) pull_list_rows<NC, THREADS>(gpT, gp_cur + (size_t)n0 * NC, hrow, hcnt);
-        else      pull_rows4<THREADS>(gpT, gp_cur + (size_t)n0 * NC, NC, rw, n);
-        __syncthreads();
-      }
-      // K3 backward
-      if (CACHE) seg_mean_bwd<NC, THREADS, UB>(rw, em, mrp, mtrp, mtdst, gpT, 0, gy2T, gy2b, pub ? sc + L.sc_gy2 : nullptr, n0);
-      else       seg_mean_bwd<NC, THREADS, UB>(rw, em, mrp, mtrp, mtdst, gp_cur, n0, gy2T, gy2b);
-      __syncthreads();
-      STAMP();
-      // conv2.  g_h2 / g_alpha tables go to this block's kept area: dx2 reads g_h2 back, the deferred
-      // parameter-gradient launch reads all of them (the dW / att gradients are off the critical path).
-      float* keep = sc + L.sc_keep + (int64_t)b * L.keep_stride;
-      float* gh = keep + L.k_gh1;
-      float* gh2 = keep + L.k_gh2;
-      seg_edge_dots<1, NC, THREADS, 2>(rw, 0, rp, col, gy2T, gy2b, base + SL.h2, ge2T, ge_b);
-      __syncthreads();
-      seg_bias_part<NC, THREADS>(rw, gy2T, gy2b, red);
-      seg_softmax_bwd<1, THREADS>(rw, 0, 0, rp, col, base + SL.al2, base + SL.as2, base + SL.ad2, ge2T, ge_b, gad2T,
-                                  gd_b, pub ? sc + L.sc_ge2 : nullptr, e0, nullptr, 0);
-      group_sync<THREADS>(grp);                  // the source-major stage reads g_y2 / g_e / g_a_dst of every dst
-      if (pub) {                 // (g_a_dst is only read for own rows: no pull)
-        if (halo) {
-          pull_list_rows<NC, THREADS>(gy2T, sc + L.sc_gy2 + (size_t)n0 * NC, hrow, hcnt);
-          pull_list_small<1, THREADS>(ge2T, sc + L.sc_ge2 + e0, hedge, hcnt);
-        } else {
-          pull_rows4<THREADS>(gy2T, sc + L.sc_gy2 + (size_t)n0 * NC, NC, rw, n);
-          pull_flat<THREADS>(ge2T, sc + L.sc_ge2 + e0, elo, ehi, eg);
-        }
-        __syncthreads();
-      }
-      STAMP();
-      seg_bias_finish<NC, THREADS>(red, sb + L.c2_b);
-      seg_agg_bwd_src<1, NC, THREADS, UB>(rw, 0, trp, teid, tdst, gy2T, gy2b, base + SL.al2, ge2T, ge_b, gad2T, gd_b,
-                                      pb + L.c2_as, pb + L.c2_ad, gh2, n0, keep + L.k_gas2, keep + L.k_gad2);
-      __syncthreads();         // g_y2 (RA) is dead: dx2 overwrites RA with g_out1
-      STAMP();
-      seg_proj<NC, 2 * NC, 1, EPI_RESID_MASK, THREADS, WLDS>(rw, gh2, n0, wt2, go1T, go1b, pub ? sc + L.sc_go1 : nullptr,
-                                                        n0, nullptr, nullptr, nullptr, nullptr, 0, nullptr, nullptr,
-                                                        nullptr, 0, base + SL.o1, 0, wlB);
-      __syncthreads();
-      STAMP();
-      // conv1
-      seg_edge_dots<2, NC, THREADS, 2>(rw, 0, rp, col, go1T, go1b, base + SL.h1, ge1T, ge_b);
-      __syncthreads();
-      seg_bias_part<2 * NC, THREADS>(rw, go1T, go1b, red);
-      seg_softmax_bwd<2, THREADS>(rw, 0, 0, rp, col, base + SL.al1, base + SL.as1, base + SL.ad1, ge1T, ge_b, gad1T,
-                                  gd_b, pub ? sc + L.sc_ge : nullptr, e0, nullptr, 0);
-      group_sync<THREADS>(grp);
-      publish_items<THREADS>(a, seg, part, 2 * (L.nb - 1 - b) + 1, grp.local || !split, false);   // conv2 tables complete
-      if (pub) {
-        if (halo) {
-          pull_list_rows<2 * NC, THREADS>(go1T, sc + L.sc_go1 + (size_t)n0 * 2 * NC, hrow, hcnt);
-          pull_list_small<2, THREADS>(ge1T, sc + L.sc_ge + (size_t)e0 * 2, hedge, hcnt);
-        } else {
-          pull_rows4<THREADS>(go1T, sc + L.sc_go1 + (size_t)n0 * 2 * NC, 2 * NC, rw, n);
-          pull_flat<THREADS>(ge1T, sc + L.sc_ge + (size_t)e0 * 2, elo * 2, ehi * 2, eg * 2);
-        }
-        __syncthreads();
-      }
-      STAMP();
-      seg_bias_finish<2 * NC, THREADS>(red, sb + L.c1_b);
-      seg_agg_bwd_src<2, NC, THREADS, UB>(rw, 0, trp, teid, tdst, go1T, go1b, base + SL.al1, ge1T, ge_b, gad1T, gd_b,
-                                      pb + L.c1_as, pb + L.c1_ad, gh, n0, keep + L.k_gas1, keep + L.k_gad1);
-      __syncthreads();         // g_out1 (RA) is dead: dx1 writes the next g_pre into RA's low half
-      STAMP();
-      // d/d xin = conv1 path + residual, masked by the previous block's ReLU (block 0's input is lin0: no ReLU)
-      seg_proj<2 * NC, NC, 1, EPI_RESID_MASK, THREADS, WLDS>(rw, gh, n0, wt1, gp_nxt, n0, gpT, 0, nullptr, nullptr, nullptr,
-                                                        nullptr, 0, nullptr, nullptr, gp_cur, n0,
-                                                        b > 0 ? base + SL.xin : nullptr, 0, wlB);
-      STAMP();
-      float* t = gp_cur; gp_cur = gp_nxt; gp_nxt = t;
-    }
-    group_sync<THREADS>(grp);
-    publish_items<THREADS>(a, seg, part, 2 * L.nb, grp.local || !split, !split);
-    seg_lin0_bwd<NC, THREADS>(rw, n0, a.perm, gp_cur, a.x, a.mask, slab + L.p_lin0_w, slab + L.p_lin0_b, red);
-    if (split && a.C > 0) {                   // last item: fold the lin0 / lin1 partial rows
-      group_sync<THREADS>(grp);
-      publish_items<THREADS>(a, seg, part, 2 * L.nb + 1, grp.local, true);
-    }
-    if (a.g_x) {
-      constexpr int G = NC / 4;
-      const float4 wv = ld4(P + L.p_lin0_w + (tid % G) * 4);
-      const int rounds = (rw.hi - rw.lo + THREADS / G - 1) / (THREADS / G);
-      for (int it = 0; it < rounds; ++it) {
-        int r = rw.lo + it * (THREADS / G) + tid / G;
-        const bool valid = r < rw.hi;
-        if (!valid) r = rw.hi - 1;
-        const float4 xv = ld4(gp_cur + ((size_t)n0 + r) * NC + (tid % G) * 4);
-        float d = xv.x * wv.x;
-        d = fmaf(xv.y, wv.y, d); d = fmaf(xv.z, wv.z, d); d = fmaf(xv.w, wv.w, d);
-        for (int off = G >> 1; off > 0; off >>= 1) d += __shfl_xor(d, off);
-        if (valid && (tid % G) == 0) a.g_x[ext_id(a.perm, n0 + r)] = d;
-      }
-    }
-  }
-  if (split && tid == 0 && *a.err) {        // a partner never arrived: make the failure visible in the results
-    if ((a.phases & GATRES_PHASE_FORWARD) && a.out) a.out[n0] = NAN;
-    if (a.phases & GATRES_PHASE_BACKWARD) a.slabs[(int64_t)seg * L.slab_stride + L.p_lin1_b] = NAN;
-  }
-  if (a.stamps && blockIdx.x == 0 && threadIdx.x == 0) {
-    a.stamps[a.stamp_cap + 1] = clock64();
-    a.stamps[a.stamp_cap + 2] = wall_clock64();
-  }
-}
-
 // ------------------------------------------------------------------------------------------ window kernel
 // The same per-snapshot pipeline for split segments whose parts have compact ROW WINDOWS (gatres_graph_t.window: own
 // rows + the rows adjacent to them form a contiguous range that is a fraction of the segment when the node order is
@@ -2314,915 +1906,5 @@ __host__ __device__ inline long long win_keep_bytes(int nb, int ow) { return (12
 // that a DMA delivers, is preceded by a full __syncthreads() / group_sync instead.
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-template <int NC, int THREADS>
-__global__ __launch_bounds__(THREADS) void gatres_window_kernel(const FusedArgs a) {
-  __shared__ __attribute__((aligned(16))) unsigned char lds_raw[LDS_BYTES];
-  float* ldsf = reinterpret_cast<float*>(lds_raw);
-  const Layout& L = a.L;
-  const int M = a.M;
-  {
-    const int F = ((a.num_segments + 7) / 8) * 8 * M;
-    if ((int)blockIdx.x >= F) {
-      consumer_main<NC, THREADS>(a, (int)blockIdx.x - F, ldsf);
-      return;
-    }
-  }
-  const int within = blockIdx.x % (8 * M);
-  const int seg = (blockIdx.x / (8 * M)) * 8 + (within & 7), part = within >> 3;
-  if (seg >= a.num_segments) return;
-  const int n0 = uni(a.seg_ptr[seg]), n = uni(a.seg_ptr[seg + 1]) - n0;
-  const int e0 = uni(a.rowptr[n0]), em0 = uni(a.m_rowptr[n0]), t0 = uni(a.t_rowptr[n0]), mt0 = uni(a.mt_rowptr[n0]);
-  const int tid = threadIdx.x;
-  Rows rw;
-  {
-    const int tiles = (n + 15) >> 4;
-    rw.lo = 16 * (int)((long long)tiles * part / M);
-    rw.hi = min(n, 16 * (int)((long long)tiles * (part + 1) / M));
-  }
-  const int lo = rw.lo, ow = rw.hi - rw.lo;
-  Group grp;
-  grp.flags = a.flags + (size_t)seg * 8 * FLAG_STRIDE; grp.M = M; grp.part = part; grp.err = a.err;
-  group_init<THREADS>(grp);
-  if (a.safe_sync) grp.local = false;
-  // granule exchange state of this part (epochs persist in word 2 of the part's flag line)
-  const XchLayout& XL = a.XL;
-  Xch xc;
-  xc.base = a.xch + (size_t)seg * (size_t)(L.xch_stride / 2);
-  xc.base_hb = xc.base + XL.hb;
-  xc.M = M; xc.part = part; xc.err = a.err; xc.local = grp.local;
-  xc.dead = (a.no_halo & 2) != 0;      // diagnostic (GATRES_XCH_NOWAIT=1, WRONG results): never wait for a partner -- what
-                                       // the launch would take if every hand-off were free
-  xc.ep = (unsigned)uni((int)__hip_atomic_load(grp.flags + part * FLAG_STRIDE + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-  // rows per lane group per trip: a part owns ~100 rows, one trip covers them in every stage but conv1's edge dots;
-  // more unrolling only costs registers and code (the block loop does not fit the instruction cache as it is)
-  constexpr int UF = 1, UB = 1;
-  // first wave that issues LDS-DMA inside MFMA stages: the waves below it own a 16-row tile there (dma_copy16)
-  const int dw0 = min((ow + 15) >> 4, THREADS / 64 - 4);
-  constexpr int WL_FLOATS = 2 * NC * (2 * NC + 4) + 4 * NC;
-  constexpr int WLB = (WL_FLOATS + 3) & ~3;
-  const float* P = a.params;
-  float* sc = a.scratch;
-  // a.keep_lds: the top of LDS carries the ReLU sign masks from the forward to the backward phase of this launch
-  unsigned char* lds_top = lds_raw + LDS_BYTES - (a.keep_lds ? win_keep_bytes(L.nb, ow) : 0);
-  unsigned long long* mo1 = a.keep_lds ? reinterpret_cast<unsigned long long*>(lds_top) - lo : nullptr;   // [b * ow + row]
-  unsigned* mxin = a.keep_lds ? reinterpret_cast<unsigned*>(lds_top + 8LL * L.nb * ow) - lo : nullptr;
-  int stamp_i = 0;
-  STAMP();
-  if (a.stamps && blockIdx.x == 0 && threadIdx.x == 0) a.stamps[a.stamp_cap] = clock64();
-
-  // ---- the window: own rows and every row adjacent to them (in- and out-neighbours), as one contiguous range
-  int wlo, whi;
-  {
-    int* mm = reinterpret_cast<int*>(lds_raw);
-    if (tid == 0) { mm[0] = lo; mm[1] = rw.hi; }
-    __syncthreads();
-    int vmin = lo, vmax = rw.hi;
-    for (int e = a.rowptr[n0 + lo] + tid; e < a.rowptr[n0 + rw.hi]; e += THREADS) {
-      const int j = a.col[e] - n0; vmin = min(vmin, j); vmax = max(vmax, j + 1);
-    }
-    for (int t = a.t_rowptr[n0 + lo] + tid; t < a.t_rowptr[n0 + rw.hi]; t += THREADS) {
-      const int j = a.t_dst[t] - n0; vmin = min(vmin, j); vmax = max(vmax, j + 1);
-    }
-    for (int e = a.m_rowptr[n0 + lo] + tid; e < a.m_rowptr[n0 + rw.hi]; e += THREADS) {
-      const int j = a.m_col[e] - n0; vmin = min(vmin, j); vmax = max(vmax, j + 1);
-    }
-    for (int t = a.mt_rowptr[n0 + lo] + tid; t < a.mt_rowptr[n0 + rw.hi]; t += THREADS) {
-      const int j = a.mt_dst[t] - n0; vmin = min(vmin, j); vmax = max(vmax, j + 1);
-    }
-    if (vmin < lo) atomicMin(&mm[0], vmin);
-    if (vmax > rw.hi) atomicMax(&mm[1], vmax);
-    __syncthreads();
-    wlo = uni(mm[0]); whi = uni(mm[1]);
-    __syncthreads();
-  }
-  const int wr = whi - wlo;
-  // edge ranges (local ids = position - e0): own in-edges [elo, ehi), window in-edges [ewlo, ewhi)
-  const int elo = uni(a.rowptr[n0 + lo]) - e0, ehi = uni(a.rowptr[n0 + rw.hi]) - e0, oeg = ehi - elo;
-  const int ewlo = uni(a.rowptr[n0 + wlo]) - e0, ewhi = uni(a.rowptr[n0 + whi]) - e0, weg = ewhi - ewlo;
-  const int melo = uni(a.m_rowptr[n0 + lo]) - em0, oem = uni(a.m_rowptr[n0 + rw.hi]) - em0 - melo;
-  const int tlo = uni(a.t_rowptr[n0 + lo]) - t0, otg = uni(a.t_rowptr[n0 + rw.hi]) - t0 - tlo;
-  const int mtlo = uni(a.mt_rowptr[n0 + lo]) - mt0, otm = uni(a.mt_rowptr[n0 + rw.hi]) - mt0 - mtlo;
-
-  const SegLayout& SL = a.SL;
-  float* segbase = a.saved + (int64_t)seg * SL.total;                 // training only: saved is never null here
-
-  if (a.phases & GATRES_PHASE_FORWARD) {
-    // LDS: [hA wr x 2NC | hB wr x NC | sa wr x 2 | sd own x 2 | xA own x NC | xB own x 2NC | W slot A | W slot B] topology
-    float* hAw = ldsf;
-    float* hBw = hAw + (size_t)wr * 2 * NC;
-    float* saw = hBw + (size_t)wr * NC;
-    float* sdo = saw + (size_t)((wr * 2 + 3) & ~3);      // (every table starts 16-byte aligned: ds_read_b128)
-    float* xAo = sdo + (size_t)((ow * 2 + 3) & ~3);
-    float* xBo = xAo + (size_t)ow * NC;
-    float* wlA = reinterpret_cast<float*>(lds_raw + ((reinterpret_cast<unsigned char*>(xBo + (size_t)ow * 2 * NC) - lds_raw + 15) & ~15));
-    float* wlB = wlA + WLB;
-    u16* tp = reinterpret_cast<u16*>(wlB + WLB);
-    u16* rpo = tp;             tp += even(ow + 1);
-    u16* colo = tp;            tp += even(oeg);
-    u16* mrpo = tp;            tp += even(ow + 1);
-    u16* mcolo = tp;           tp += even(oem);
-    int* hcounter = reinterpret_cast<int*>(tp);
-    u16* hlist = tp + 2;                 // import list: remote sources of own in-edges (one entry per edge)
-    const int hcap = max(0, (int)((lds_top - reinterpret_cast<unsigned char*>(hlist)) / 4));
-    u16* elist = hlist + hcap;           // export list: own rows some partner's row has an in-edge from
-    // index-shifted views: absolute local row / relative own-edge indices work unchanged in the stage functions
-    float* hA = hAw - wlo * 2 * NC;
-    float* hB = hBw - wlo * NC;
-    float* sa2 = saw - wlo * 2;  float* sa1 = saw - wlo;                 // a_src tables (H = 2 / H = 1)
-    float* sd2 = sdo - lo * 2;   float* sd1 = sdo - lo;
-    float* xA = xAo - lo * NC;
-    float* xB = xBo - lo * 2 * NC;
-    const u16* rp = rpo - lo;  const u16* mrp = mrpo - lo;
-    copy_rowptr16<THREADS>(rpo, a.rowptr, n0 + lo, ow, e0 + elo);
-    copy_idx16<THREADS>(colo, a.col, e0 + elo, oeg, n0);
-    copy_rowptr16<THREADS>(mrpo, a.m_rowptr, n0 + lo, ow, em0 + melo);
-    copy_idx16<THREADS>(mcolo, a.m_col, em0 + melo, oem, n0);
-    float* xcur = segbase + SL.xin;
-    if (L.nb > 0) {
-      const float* pb0 = P + L.p_block0;
-      w_prefetch<NC, 2 * NC, EPI_ATT, THREADS>(wlA, pb0 + L.c1_W, pb0 + L.c1_as, pb0 + L.c1_ad, 0);
-    }
-    {  // lin0 (+ the caller-side x[mask] = 0)
-      const float* w = P + L.p_lin0_w;
-      const float* b = P + L.p_lin0_b;
-      for (int idx = rw.lo * (NC / 4) + tid; idx < rw.hi * (NC / 4); idx += THREADS) {
-        const int r = idx / (NC / 4), c0 = (idx % (NC / 4)) * 4;
-        const int node = ext_id(a.perm, n0 + r);
-        const float xv = (a.mask && a.mask[node]) ? 0.f : a.x[node];
-        const float4 wv = ld4(w + c0), bv = ld4(b + c0);
-        float4 o;
-        o.x = xv * wv.x + bv.x; o.y = xv * wv.y + bv.y; o.z = xv * wv.z + bv.z; o.w = xv * wv.w + bv.w;
-        st4(xcur + (unsigned)(r * NC + c0), o);
-        st4(xA + (unsigned)(r * NC + c0), o);
-      }
-    }
-    __syncthreads();
-    int hcnt = uni(build_halo<THREADS>(rp, colo, nullptr, rw, hlist, nullptr, hcap, hcounter));
-    int ecnt = uni(build_export_rows<THREADS>(a.t_rowptr, a.t_dst, n0, rw, elist, hcap, hcounter));
-    if (hcnt > hcap || ecnt > hcap) {      // (the host sizes the lists from gatres_graph_t.halo: cannot happen with a sane plan)
-      if (tid == 0) *a.err = 1;
-      hcnt = min(hcnt, hcap); ecnt = min(ecnt, hcap);
-    }
-    STAMP();
-    for (int b = 0; b < L.nb; ++b) {
-      float* base = segbase + (int64_t)b * SL.bstride;
-      float* xnext = segbase + (int64_t)(b + 1) * SL.bstride + SL.xin;
-      const float* pb = P + L.p_block0 + (int64_t)b * L.p_block_stride;
-      // LDS-DMA rides on the MFMA stages (the longest ones; a DMA has to land before its host stage's closing barrier):
-      // W2 of this block while proj1 runs, W1 of the next block while proj2 runs
-      w_prefetch<2 * NC, NC, EPI_ATT, THREADS>(wlB, pb + L.c2_W, pb + L.c2_as, pb + L.c2_ad, dw0);
-      seg_proj<NC, 2 * NC, 2, EPI_ATT, THREADS, true, true>(rw, xA, 0, pb + L.c1_W, base + SL.h1, 0, hA, 0, pb + L.c1_as,
-                                                        pb + L.c1_ad, base + SL.as1, base + SL.ad1, 0, sa2, sd2,
-                                                        nullptr, 0, nullptr, 0, wlA);
-      lds_barrier();                              // own rows of h1 / a_src are in LDS; the saved copies drain meanwhile
-      ++xc.ep;                                    // exchange F1: the gathers below read h1 / a_src of neighbour rows
-      xch_export<2 * NC, THREADS>(xc, elist, ecnt, hA, xc.base + XL.f1h);
-      xch_export<2, THREADS>(xc, elist, ecnt, sa2, xc.base + XL.f1a);
-      xch_import<2 * NC, THREADS>(xc, hlist, hcnt, xc.base + XL.f1h, hA);
-      xch_import<2, THREADS>(xc, hlist, hcnt, xc.base + XL.f1a, sa2);
-      xch_heartbeat<THREADS>(xc, 0);
-      lds_barrier();
-      STAMP();
-      // K2 conv1: alpha -> HBM + the h2 window's LDS (dead now), then the gather (o1 -> HBM + the x buffer of proj2).
-      // (Coefficients computed INSIDE the exchange -- softmax threads reading a partner's a_src straight from its granule
-      // while the other waves sweep h1 in, one barrier less -- was measured: 545 -> 557 us per launch, and 28 KB of code.)
-      if (__builtin_expect(2 * oeg <= wr * NC, 1)) {
-        seg_softmax<2, true, THREADS>(rw, rp, colo, sa2, sd2, 0, base + SL.al1, elo, hBw);
-        lds_barrier();
-        seg_gather<true, 2, NC, THREADS, UF>(rw, rp, colo, hA, 0, hBw, 0, pb + L.c1_b, base + SL.o1, 0, xB, 0,
-                                             mo1 ? mo1 + b * ow : nullptr);
-      } else {
-        seg_softmax<2, false, THREADS>(rw, rp, colo, sa2, sd2, 0, base + SL.al1, elo, nullptr);
-        __syncthreads();
-        seg_gather<true, 2, NC, THREADS, UF>(rw, rp, colo, hA, 0, base + SL.al1, elo, pb + L.c1_b, base + SL.o1, 0, xB, 0,
-                                             mo1 ? mo1 + b * ow : nullptr);
-      }
-      lds_barrier();
-      STAMP();
-      if (b + 1 < L.nb) {
-        const float* pn = pb + L.p_block_stride;
-        w_prefetch<NC, 2 * NC, EPI_ATT, THREADS>(wlA, pn + L.c1_W, pn + L.c1_as, pn + L.c1_ad, dw0);
-      }
-      seg_proj<2 * NC, NC, 1, EPI_ATT, THREADS, true, true>(rw, xB, 0, pb + L.c2_W, base + SL.h2, 0, hB, 0, pb + L.c2_as,
-                                                        pb + L.c2_ad, base + SL.as2, base + SL.ad2, 0, sa1, sd1,
-                                                        nullptr, 0, nullptr, 0, wlB);
-      lds_barrier();
-      ++xc.ep;                                    // exchange F2
-      xch_export<NC, THREADS>(xc, elist, ecnt, hB, xc.base + XL.f2h);
-      xch_export<1, THREADS>(xc, elist, ecnt, sa1, xc.base + XL.f2a);
-      xch_import<NC, THREADS>(xc, hlist, hcnt, xc.base + XL.f2h, hB);
-      xch_import<1, THREADS>(xc, hlist, hcnt, xc.base + XL.f2a, sa1);
-      xch_heartbeat<THREADS>(xc, 1);
-      lds_barrier();
-      STAMP();
-      // K2 conv2: alpha's LDS table in the upper half of the h1 window, y2 in the lower half
-      float* y2T = hAw - wlo * NC;
-      if (__builtin_expect(oeg <= wr * NC, 1)) {
-        float* al2L = hAw + (size_t)wr * NC;
-        seg_softmax<1, true, THREADS>(rw, rp, colo, sa1, sd1, 0, base + SL.al2, elo, al2L);
-        lds_barrier();
-        seg_gather<false, 1, NC, THREADS, UF>(rw, rp, colo, hB, 0, al2L, 0, pb + L.c2_b, y2T, 0);
-      } else {
-        seg_softmax<1, false, THREADS>(rw, rp, colo, sa1, sd1, 0, base + SL.al2, elo, nullptr);
-        __syncthreads();
-        seg_gather<false, 1, NC, THREADS, UF>(rw, rp, colo, hB, 0, base + SL.al2, elo, pb + L.c2_b, y2T, 0);
-      }
-      lds_barrier();
-      ++xc.ep;                                    // exchange F3: K3 averages y2 over neighbour rows
-      xch_export<NC, THREADS>(xc, elist, ecnt, y2T, xc.base + XL.f3);
-      xch_import<NC, THREADS>(xc, hlist, hcnt, xc.base + XL.f3, y2T);
-      xch_heartbeat<THREADS>(xc, 2);
-      lds_barrier();
-      STAMP();
-      // K3: residual from the x buffer, result back into it (and to HBM: saved xin of the next block)
-      seg_mean_fwd<NC, THREADS, UF>(rw, oem, mrp, mcolo, y2T, 0, xA, 0, xnext, 0, xA, 0,
-                                    (mxin && b + 1 < L.nb) ? mxin + (b + 1) * ow : nullptr);
-      lds_barrier();
-      STAMP();
-      xcur = xnext;
-    }
-    {  // lin1
-      constexpr int G = NC / 4;
-      const float4 wv = ld4(P + L.p_lin1_w + (tid % G) * 4);
-      const float bias = P[L.p_lin1_b];
-      const int rounds = (rw.hi - rw.lo + THREADS / G - 1) / (THREADS / G);
-      for (int it = 0; it < rounds; ++it) {
-        int r = rw.lo + it * (THREADS / G) + tid / G;
-        const bool valid = r < rw.hi;
-        if (!valid) r = rw.hi - 1;
-        const float4 xv = ld4(xA + (unsigned)(r * NC + (tid % G) * 4));
-        float d = xv.x * wv.x;
-        d = fmaf(xv.y, wv.y, d); d = fmaf(xv.z, wv.z, d); d = fmaf(xv.w, wv.w, d);
-        for (int off = G >> 1; off > 0; off >>= 1) d += __shfl_xor(d, off);
-        if (valid && (tid % G) == 0) a.out[ext_id(a.perm, n0 + r)] = d + bias;
-      }
-    }
-    __syncthreads();
-    STAMP();
-  }
-
-  if (a.phases & PH_LOSS) {
-    float cnt = 0.f;
-    for (int i = tid; i < a.N; i += THREADS) cnt += a.mask[i] ? 1.f : 0.f;
-    const float Mn = block_sum<THREADS>(cnt, ldsf);
-    float part_sum = 0.f;
-    for (int r = rw.lo + tid; r < rw.hi; r += THREADS) {
-      const int node = ext_id(a.perm, n0 + r);
-      if (a.mask[node]) {
-        const float d = a.out[node] - a.y[node];
-        part_sum = fmaf(d, d, part_sum);
-      }
-    }
-    part_sum = block_sum<THREADS>(part_sum, ldsf);
-    if (tid == 0) {
-      a.loss_part[seg * M + part] = part_sum;
-      if (seg == 0 && part == 0) a.loss_part[a.num_segments * M] = Mn;
-    }
-    const float scale = Mn > 0.f ? 2.f / Mn : 0.f;
-    for (int r = rw.lo + tid; r < rw.hi; r += THREADS) {
-      const int node = ext_id(a.perm, n0 + r);
-      a.g_out[node] = a.mask[node] ? (a.out[node] - a.y[node]) * scale : 0.f;
-    }
-    __syncthreads();
-    STAMP();
-  }
-
-  if (a.phases & GATRES_PHASE_BACKWARD) {
-    // LDS: red | RA wr x 2NC | ge weg x 2 | gad own x 2 | hT wr x 2NC | asT wr x 2 | adT own x 2 | alT weg x 2 |
-    //      xG own x 2NC | W slot A | W slot B | topology | halo lists
-    float* red = ldsf;
-    float* RAw = red + 3 * THREADS;
-    float* gew = RAw + (size_t)wr * 2 * NC;
-    float* gado = gew + 2 * (size_t)even(weg);
-    float* hTw = gado + (size_t)((ow * 2 + 3) & ~3);
-    float* asTw = hTw + (size_t)wr * 2 * NC;
-    float* adTo = asTw + (size_t)((wr * 2 + 3) & ~3);
-    float* alTw = adTo + (size_t)((ow * 2 + 3) & ~3);
-    float* xGo = alTw + 2 * (size_t)even(weg);
-    float* gko = xGo + (size_t)ow * 2 * NC;                              // a.keep_lds: g_pre of the own rows (dX1's residual term)
-    float* wlA = reinterpret_cast<float*>(lds_raw + ((reinterpret_cast<unsigned char*>(gko + (a.keep_lds ? (size_t)ow * NC : 0)) - lds_raw + 15) & ~15));
-    float* wlB = wlA + WLB;
-    u16* tp = reinterpret_cast<u16*>(wlB + WLB);
-    u16* rpo = tp;             tp += even(ow + 1);
-    u16* colo = tp;            tp += even(oeg);
-    u16* trpo = tp;            tp += even(ow + 1);
-    u16* teido = tp;           tp += even(otg);
-    u16* tdsto = tp;           tp += even(otg);
-    u16* mrpw = tp;            tp += even(wr + 1);
-    u16* mtrpo = tp;           tp += even(ow + 1);
-    u16* mtdsto = tp;          tp += even(otm);
-    int* hcounter = reinterpret_cast<int*>(tp);
-    u16* hrow = tp + 2;                  // import lists: remote destinations (+ edge ids) of own out-edges
-    const int hcap = max(0, (int)((lds_top - reinterpret_cast<unsigned char*>(hrow)) / 8));
-    u16* hedge = hrow + hcap;
-    u16* erow = hedge + hcap;            // export lists: own rows with an in-edge from a partner's row, and those in-edges
-    u16* eedge = erow + hcap;
-    __syncthreads();           // forward's LDS contents are dead from here
-    copy_rowptr16<THREADS>(rpo, a.rowptr, n0 + lo, ow, e0 + elo);
-    copy_idx16<THREADS>(colo, a.col, e0 + elo, oeg, n0);
-    copy_rowptr16<THREADS>(trpo, a.t_rowptr, n0 + lo, ow, t0 + tlo);
-    copy_idx16<THREADS>(teido, a.t_eid, t0 + tlo, otg, e0);
-    copy_idx16<THREADS>(tdsto, a.t_dst, t0 + tlo, otg, n0);
-    copy_rowptr16<THREADS>(mrpw, a.m_rowptr, n0 + wlo, wr, a.m_rowptr[n0 + wlo]);
-    copy_rowptr16<THREADS>(mtrpo, a.mt_rowptr, n0 + lo, ow, mt0 + mtlo);
-    copy_idx16<THREADS>(mtdsto, a.mt_dst, mt0 + mtlo, otm, n0);
-    const u16* rp = rpo - lo;  const u16* trp = trpo - lo;  const u16* mrp = mrpw - wlo;  const u16* mtrp = mtrpo - lo;
-    float* RA = RAw - wlo * 2 * NC;              // [row][2NC] view: g_out1
-    float* gpT = RAw - wlo * NC;                 // [row][NC] views of the lower / upper half: g_pre, g_y2
-    float* gy2T = RAw + (size_t)wr * NC - wlo * NC;
-    float* ge2 = gew - ewlo;      float* ge1 = gew - ewlo * 2;          // by absolute local edge id
-    float* gad2 = gado - lo;      float* gad1 = gado - lo * 2;
-    float* hT2 = hTw - wlo * NC;  float* hT1 = hTw - wlo * 2 * NC;
-    float* asT2 = asTw - wlo;     float* asT1 = asTw - wlo * 2;
-    float* adT2 = adTo - lo;      float* adT1 = adTo - lo * 2;
-    float* alT2 = alTw - ewlo;    float* alT1 = alTw - ewlo * 2;
-    float* xG2 = xGo - lo * NC;   float* xG1 = xGo - lo * 2 * NC;
-    float* gkeep = a.keep_lds ? gko - lo * NC : nullptr;
-
-    float* gp_cur = sc + L.sc_gpa;
-    float* gp_nxt = sc + L.sc_gpb;
-    constexpr bool pub = true;           // (the window kernel only runs split segments)
-    float* slab = pub ? a.part_slabs + ((int64_t)seg * M + part) * L.slab_stride
-                      : a.slabs + (int64_t)seg * L.slab_stride;
-    const int64_t w = 2LL * NC * NC;
-    const float* xfinal = segbase + (int64_t)L.nb * SL.bstride + SL.xin;
-    // LDS-DMA of saved tables (independent of the backward chain) and transposed weights always rides on an MFMA
-    // stage or, for the first block, on this prologue: conv2 tables + W2^T of block b during dX1 of block b + 1,
-    // conv1 tables + W1^T of block b during dX2 of block b.
-    auto dma_conv2 = [&](int blk, int w0) {
-      const float* bs = segbase + (int64_t)blk * SL.bstride;
-      dma_copy16<THREADS>(hTw, bs + SL.h2 + (size_t)wlo * NC, wr * NC, w0);
-      dma_copy4<THREADS>(asTw, bs + SL.as2 + wlo, wr, w0);
-      dma_copy4<THREADS>(adTo, bs + SL.ad2 + lo, ow, w0);
-      dma_copy4<THREADS>(alTw, bs + SL.al2 + ewlo, weg, w0);
-      w_prefetch<NC, 2 * NC, EPI_RESID_MASK, THREADS>(wlA, a.wt + (int64_t)blk * 2 * w + w, nullptr, nullptr, w0);
-    };
-    if (L.nb > 0) dma_conv2(L.nb - 1, 0);
-    seg_lin1_bwd<NC, THREADS>(rw, n0, a.perm, a.g_out, xfinal, P + L.p_lin1_w, gp_cur, gpT, slab + L.p_lin1_w,
-                              slab + L.p_lin1_b, L.nb > 0 ? 1 : 0, red, gkeep);
-    int hcnt = uni(build_halo<THREADS>(trp, tdsto, teido, rw, hrow, hedge, hcap, hcounter));
-    int ercnt = uni(build_export_rows<THREADS>(a.rowptr, a.col, n0, rw, erow, hcap, hcounter));
-    if (tid == 0) *hcounter = 0;
-    __syncthreads();
-    for (int k = tid; k < oeg; k += THREADS) {                 // own in-edges whose source is a partner's row
-      const int j = colo[k];
-      if (j < lo || j >= rw.hi) {
-        const int pos = atomicAdd(hcounter, 1);
-        if (pos < hcap) eedge[pos] = (u16)(elo + k);
-      }
-    }
-    __syncthreads();
-    int eecnt = uni(*hcounter);
-    if (hcnt > hcap || ercnt > hcap || eecnt > hcap) {
-      if (tid == 0) *a.err = 1;
-      hcnt = min(hcnt, hcap); ercnt = min(ercnt, hcap); eecnt = min(eecnt, hcap);
-    }
-    STAMP();
-    for (int b = L.nb - 1; b >= 0; --b) {
-      const float* base = segbase + (int64_t)b * SL.bstride;
-      const int64_t po = L.p_block0 + (int64_t)b * L.p_block_stride;
-      const float* pb = P + po;
-      float* sb = slab + po;
-      const float* wt1 = a.wt + (int64_t)b * 2 * w;
-      const float* wt2 = wt1 + w;
-      const bool xs_on = a.stamps && a.stamp_cap >= 4096 && seg == 0 && b == L.nb / 2;
-      int xs_i = 0;
-      XSTAMP();
-      lds_barrier();                             // own rows of g_pre are in LDS (lin1 backward / the previous dX1)
-      XSTAMP();
-      ++xc.ep;                                   // exchange B1: K3 backward gathers g_pre of neighbour rows
-      xch_export<NC, THREADS>(xc, erow, ercnt, gpT, xc.base + XL.b1);
-      XSTAMP();
-      xch_import<NC, THREADS>(xc, hrow, hcnt, xc.base + XL.b1, gpT);
-      XSTAMP();
-      xch_heartbeat<THREADS>(xc, 3);
-      XSTAMP();
-      lds_barrier();
-      XSTAMP();
-      publish_items<THREADS>(a, seg, part, 2 * (L.nb - 1 - b), grp.local, false);      // the blocks above are kept
-      seg_mean_bwd<NC, THREADS, UB>(rw, otm, mrp, mtrp, mtdsto, gpT, 0, gy2T, 0);
-      lds_barrier();
-      XSTAMP();
-      STAMP();
-      float* keep = sc + L.sc_keep + (int64_t)b * L.keep_stride;
-      float* gh = keep + L.k_gh1;
-      float* gh2 = keep + L.k_gh2;
-      seg_edge_dots<1, NC, THREADS, 1>(rw, 0, rp, colo, gy2T, 0, hT2, ge2 + elo, 0);
-      lds_barrier();
-      XSTAMP();
-      seg_bias_part<NC, THREADS>(rw, gy2T, 0, red);
-      seg_softmax_bwd<1, THREADS>(rw, 0, 0, rp, colo, alT2 + elo, asT2, adT2, ge2 + elo, 0, gad2, 0, nullptr, 0, nullptr,
-                                  0);
-      lds_barrier();
-      XSTAMP();
-      ++xc.ep;                                   // exchange B2: the source-major stage reads g_y2 / g_e of neighbour rows
-      xch_export<NC, THREADS>(xc, erow, ercnt, gy2T, xc.base + XL.b2y);
-      xch_export<1, THREADS>(xc, eedge, eecnt, ge2, xc.base + XL.b2e);
-      XSTAMP();
-      xch_import<NC, THREADS>(xc, hrow, hcnt, xc.base + XL.b2y, gy2T);
-      xch_import<1, THREADS>(xc, hedge, hcnt, xc.base + XL.b2e, ge2);
-      XSTAMP();
-      xch_heartbeat<THREADS>(xc, 4);
-      XSTAMP();
-      lds_barrier();
-      XSTAMP();
-      STAMP();
-      seg_bias_finish<NC, THREADS>(red, sb + L.c2_b);
-      seg_agg_bwd_src<1, NC, THREADS, UB>(rw, 0, trp, teido, tdsto, gy2T, 0, alT2, ge2, 0, gad2, 0, pb + L.c2_as,
-                                      pb + L.c2_ad, gh2, n0, keep + L.k_gas2, keep + L.k_gad2, xG2, 0);
-      lds_barrier();           // g_y2 (RA) and the conv2 tables are dead
-      XSTAMP();
-      STAMP();
-      // LDS-DMA of this block's conv1 tables and W1^T while the matrix cores run dX2
-      w_prefetch<2 * NC, NC, EPI_RESID_MASK, THREADS>(wlB, wt1, nullptr, nullptr, dw0);
-      dma_copy16<THREADS>(hTw, base + SL.h1 + (size_t)wlo * 2 * NC, wr * 2 * NC, dw0);
-      dma_copy4<THREADS>(asTw, base + SL.as1 + wlo * 2, wr * 2, dw0);
-      dma_copy4<THREADS>(adTo, base + SL.ad1 + lo * 2, ow * 2, dw0);
-      dma_copy4<THREADS>(alTw, base + SL.al1 + ewlo * 2, weg * 2, dw0);
-      seg_proj<NC, 2 * NC, 1, EPI_RESID_MASK, THREADS, true, true>(rw, xG2, 0, wt2, RA, 0, nullptr, 0,
-                                                               nullptr, nullptr, nullptr, nullptr, 0, nullptr, nullptr,
-                                                               nullptr, 0, (a.no_halo & 4) ? nullptr : base + SL.o1, 0, wlA,
-                                                               nullptr, nullptr, mo1 ? mo1 + b * ow : nullptr, nullptr);
-      __syncthreads();
-      XSTAMP();
-      STAMP();
-      seg_edge_dots<2, NC, THREADS, 1>(rw, 0, rp, colo, RA, 0, hT1, ge1 + elo * 2, 0);
-      lds_barrier();
-      XSTAMP();
-      seg_bias_part<2 * NC, THREADS>(rw, RA, 0, red);
-      seg_softmax_bwd<2, THREADS>(rw, 0, 0, rp, colo, alT1 + elo * 2, asT1, adT1, ge1 + elo * 2, 0, gad1, 0, nullptr, 0,
-                                  nullptr, 0);
-      lds_barrier();
-      XSTAMP();
-      ++xc.ep;                                   // exchange B3
-      xch_export<2 * NC, THREADS>(xc, erow, ercnt, RA, xc.base + XL.b3o);
-      xch_export<2, THREADS>(xc, eedge, eecnt, ge1, xc.base + XL.b3e);
-      XSTAMP();
-      xch_import<2 * NC, THREADS>(xc, hrow, hcnt, xc.base + XL.b3o, RA);
-      xch_import<2, THREADS>(xc, hedge, hcnt, xc.base + XL.b3e, ge1);
-      XSTAMP();
-      xch_heartbeat<THREADS>(xc, 5);
-      XSTAMP();
-      lds_barrier();
-      XSTAMP();
-      publish_items<THREADS>(a, seg, part, 2 * (L.nb - 1 - b) + 1, grp.local, false);      // conv2 tables complete
-      STAMP();
-      seg_bias_finish<2 * NC, THREADS>(red, sb + L.c1_b);
-      seg_agg_bwd_src<2, NC, THREADS, UB>(rw, 0, trp, teido, tdsto, RA, 0, alT1, ge1, 0, gad1, 0, pb + L.c1_as,
-                                      pb + L.c1_ad, gh, n0, keep + L.k_gas1, keep + L.k_gad1, xG1, 0);
-      lds_barrier();
-      XSTAMP();
-      STAMP();
-      if (b > 0) dma_conv2(b - 1, dw0);
-      seg_proj<2 * NC, NC, 1, EPI_RESID_MASK, THREADS, true, true>(rw, xG1, 0, wt1, gp_nxt, n0, gpT, 0, nullptr, nullptr,
-                                                               nullptr, nullptr, 0, nullptr, nullptr,
-                                                               (a.no_halo & 4) ? nullptr : gp_cur, n0,
-                                                               (b > 0 && !(a.no_halo & 4)) ? base + SL.xin : nullptr, 0, wlB,
-                                                               gkeep, gkeep, nullptr, (mxin && b > 0) ? mxin + b * ow : nullptr);
-      XSTAMP();
-      STAMP();
-      float* t = gp_cur; gp_cur = gp_nxt; gp_nxt = t;
-    }
-    group_sync<THREADS>(grp);
-    publish_items<THREADS>(a, seg, part, 2 * L.nb, grp.local || !pub, !pub);
-    seg_lin0_bwd<NC, THREADS>(rw, n0, a.perm, gp_cur, a.x, a.mask, slab + L.p_lin0_w, slab + L.p_lin0_b, red);
-    if (pub && a.C > 0) {
-      group_sync<THREADS>(grp);
-      publish_items<THREADS>(a, seg, part, 2 * L.nb + 1, grp.local, true);
-    }
-    if (a.g_x) {
-      constexpr int G = NC / 4;
-      const float4 wv = ld4(P + L.p_lin0_w + (tid % G) * 4);
-      const int rounds = (rw.hi - rw.lo + THREADS / G - 1) / (THREADS / G);
-      for (int it = 0; it < rounds; ++it) {
-        int r = rw.lo + it * (THREADS / G) + tid / G;
-        const bool valid = r < rw.hi;
-        if (!valid) r = rw.hi - 1;
-        const float4 xv = ld4(gp_cur + ((size_t)n0 + r) * NC + (tid % G) * 4);
-        float d = xv.x * wv.x;
-        d = fmaf(xv.y, wv.y, d); d = fmaf(xv.z, wv.z, d); d = fmaf(xv.w, wv.w, d);
-        for (int off = G >> 1; off > 0; off >>= 1) d += __shfl_xor(d, off);
-        if (valid && (tid % G) == 0) a.g_x[ext_id(a.perm, n0 + r)] = d;
-      }
-    }
-  }
-  if (tid == 0) __hip_atomic_store(grp.flags + part * FLAG_STRIDE + 2, xc.ep, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  if (M > 1 && tid == 0 && *a.err) {
-    if ((a.phases & GATRES_PHASE_FORWARD) && a.out) a.out[n0] = NAN;
-    if (a.phases & GATRES_PHASE_BACKWARD) a.slabs[(int64_t)seg * L.slab_stride + L.p_lin1_b] = NAN;
-  }
-  if (a.stamps && blockIdx.x == 0 && threadIdx.x == 0) {
-    a.stamps[a.stamp_cap + 1] = clock64();
-    a.stamps[a.stamp_cap + 2] = wall_clock64();
-  }
-}
-
-// grads = sum of segment slabs (fixed order) ; optionally the Adam update and the loss finalisation in the same pass
-__global__ __launch_bounds__(256) void reduce_adam_kernel(const float* __restrict__ slabs, int num_slabs,
-                                                          int num_loss, long long stride, long long count,
-                                                          float* __restrict__ grads, const float* loss_part,
-                                                          float* loss, int do_adam, float* __restrict__ p,
-                                                          float* __restrict__ m, float* __restrict__ v,
-                                                          unsigned long long* __restrict__ step_counter, double lr,
-                                                          double b1, double b2, double eps, double wd,
-                                                          float grad_scale, float* __restrict__ wt, int nb, int nc,
-                                                          unsigned* __restrict__ status) {
-  __shared__ float s_step_size, s_bc2_sqrt;
-  __shared__ unsigned s_fault;
-  // status[0]: a split launch of this step gave up waiting for a partner workgroup (its results are poisoned).  The step
-  // is then DROPPED: no Adam update, no step count, loss = NaN, gradients = NaN; the last block clears the word and
-  // counts the event in status[1], so one transient stall costs one step instead of the whole run.
-  if (threadIdx.x == 0) s_fault = status ? __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
-  if (do_adam && threadIdx.x == 0) {
-    const unsigned long long t = __hip_atomic_load(step_counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1ULL;
-    s_step_size = (float)(lr / (1.0 - gatres_powi(b1, t)));
-    s_bc2_sqrt = (float)sqrt(1.0 - gatres_powi(b2, t));
-    // The step is counted once every block has READ the counter: a ticket drawn right after this block's read (its value is
-    // in a register: the wait below), the last ticket increments.  Nothing orders the count behind the parameter stores --
-    // the next launch is -- so no fence: the ticket used to follow the block's stores behind a __threadfence(), an L2
-    // write-back + invalidate of ~3.5 us at the end of every block of a 14-us launch.
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    if (s_fault == 0u) {
-      const unsigned long long done = atomicAdd(&step_counter[1], 1ULL);
-      if (done == (unsigned long long)gridDim.x - 1ULL) {
-        step_counter[1] = 0ULL;
-        atomicAdd(&step_counter[0], 1ULL);
-      }
-    }
-  }
-  if (loss_part && blockIdx.x == 0 && threadIdx.x < 64) {
-    // the loss: sum of the per-(segment, part) squared errors / masked-node count.  One wave, strided partial sums
-    // and a fixed-order butterfly (a single thread walking 128 dependent loads made block 0 the kernel's critical path)
-    float s = 0.f;
-    for (int k = threadIdx.x; k < num_loss; k += 64) s += loss_part[k];
-    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
-    if (threadIdx.x == 0) loss[0] = s / loss_part[num_loss];
-  }
-  __syncthreads();
-  const bool fault = s_fault != 0u;
-  if (fault && loss && blockIdx.x == 0 && threadIdx.x == 0) loss[0] = NAN;
-  const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
-  if (idx < count) {
-    float acc = 0.f;
-    int s0 = 0;
-    // the parameter and its moments are requested together with the first slab rows: one memory round trip for a
-    // 32-snapshot batch instead of five dependent ones (this launch is pure latency: 258 workgroups x 4 waves)
-    float pv = 0.f, mv0 = 0.f, vv0 = 0.f;
-    if (do_adam && !fault) { pv = p[idx]; mv0 = m[idx]; vv0 = v[idx]; }
-    for (; s0 + 32 <= num_slabs; s0 += 32) {            // 32 loads in flight, summed in slab order
-      float v32[32];
-#pragma unroll
-      for (int u = 0; u < 32; ++u) v32[u] = slabs[(size_t)(s0 + u) * stride + idx];
-#pragma unroll
-      for (int u = 0; u < 32; ++u) acc += v32[u];
-    }
-    for (; s0 + 8 <= num_slabs; s0 += 8) {
-      float v8[8];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) v8[u] = slabs[(size_t)(s0 + u) * stride + idx];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) acc += v8[u];
-    }
-    for (; s0 < num_slabs; ++s0) acc += slabs[(size_t)s0 * stride + idx];
-    grads[idx] = fault ? NAN : acc;
-    if (do_adam && !fault) {
-      float gv = acc * grad_scale;
-      gv = gv + (float)wd * pv;
-      float mv = mv0;
-      mv = mv + (float)(1.0 - b1) * (gv - mv);
-      const float vv = (float)b2 * vv0 + (float)(1.0 - b2) * gv * gv;
-      const float denom = sqrtf(vv) / s_bc2_sqrt + (float)eps;
-      const float pn = pv + (-s_step_size * mv) / denom;
-      p[idx] = pn;
-      m[idx] = mv;
-      v[idx] = vv;
-      if (wt) {                   // keep the transposed conv weights of the next backward current (k_misc.hip layout)
-        const long long per = 2LL * nc * nc, stride = 9LL * nc + 2 * per, off = idx - 2LL * nc;
-        if (off >= 0 && off < (long long)nb * stride) {
-          const long long b = off / stride, o = off % stride;
-          if (o >= 6LL * nc && o < 6LL * nc + per) {                        // W1 [2nc][nc] -> [nc][2nc]
-            const long long e = o - 6LL * nc, row = e / nc, col = e % nc;
-            wt[b * 2 * per + col * 2 * nc + row] = pn;
-          } else if (o >= 9LL * nc + per) {                                 // W2 [nc][2nc] -> [2nc][nc]
-            const long long e = o - 9LL * nc - per, row = e / (2 * nc), col = e % (2 * nc);
-            wt[b * 2 * per + per + col * nc + row] = pn;
-          }
-        }
-      }
-    }
-  }
-  if (fault && threadIdx.x == 0) {               // every block has read status[0] before the last ticket is drawn
-    __threadfence();
-    if (atomicAdd(status + 2, 1u) == gridDim.x - 1u) {
-      status[2] = 0u;
-      status[1] += 1u;
-      __hip_atomic_store(status, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-  }
-}
-
-// The same bookkeeping after a split launch that no gatres_fused_finish follows (forward / inference launches)
-__global__ __launch_bounds__(64) void fused_status_kernel(unsigned* __restrict__ status) {
-  if (threadIdx.x == 0 && __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
-    status[1] += 1u;
-    __hip_atomic_store(status, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
-}
-
-// Two split launches must never be in flight on one device at the same time: each needs its whole grid resident, and
-// each could hold CUs the other waits for (the bounded spins would then poison both).  Launches on ONE stream are
-// ordered anyway; when the stream changes, the new stream first waits for everything enqueued on the previous one.
-// Skipped while `st` is being captured: the host that replays the graph calls gatres_fused_serialize before the replay.
-static std::mutex g_split_mu;
-static hipStream_t g_split_stream[64];
-static bool g_split_seen[64] = {};
-static int serialize_split_launch(hipStream_t st) {
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 0;
-  std::lock_guard<std::mutex> lk(g_split_mu);
-  hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-  if (hipStreamIsCapturing(st, &cs) != hipSuccess) { (void)hipGetLastError(); return 0; }
-  if (cs != hipStreamCaptureStatusNone) return 0;
-  if (g_split_seen[dev] && g_split_stream[dev] != st) {
-    hipStream_t prev = g_split_stream[dev];
-    hipStreamCaptureStatus ps = hipStreamCaptureStatusNone;
-    hipEvent_t ev;
-    if (hipStreamIsCapturing(prev, &ps) == hipSuccess && ps == hipStreamCaptureStatusNone &&
-        hipEventCreateWithFlags(&ev, hipEventDisableTiming) == hipSuccess) {
-      if (hipEventRecord(ev, prev) == hipSuccess) (void)hipStreamWaitEvent(st, ev, 0);
-      (void)hipEventDestroy(ev);
-    }
-    (void)hipGetLastError();                     // (a stream the caller has destroyed meanwhile: nothing left to wait for)
-  }
-  g_split_stream[dev] = st;
-  g_split_seen[dev] = true;
-  return 0;
-}
-
-static int fused_threads_small() {
-  const char* e = getenv("GATRES_FUSED_THREADS");
-  return (e && atoi(e) == 512) ? 512 : 1024;
-}
-static int threads_for(int nc) { return nc <= 32 ? fused_threads_small() : (nc == 64 ? 512 : 256); }
-
-// CUs of the current device (cached): every workgroup of a split launch must be resident at once, one per CU.
-static int device_cus() {
-  static int cus = 0;
-  if (cus == 0) {
-    int dev = 0, v = 0;
-    if (hipGetDevice(&dev) == hipSuccess &&
-        hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0)
-      cus = v;
-    else
-      cus = 1;               // unknown: never split
-  }
-  return cus;
-}
-
-// The window kernel applies when the plan knows the parts' row windows and both LDS layouts fit with them.
-static bool window_kernel_fits(const Layout& L, const gatres_graph_t* g, int M, bool keep = false) {
-  if (getenv("GATRES_FUSED_NO_WINDOW") || M < 2 || M > 8 || L.nc > 32 || threads_for(L.nc) != 1024) return false;
-  const int k = M - 2;
-  const int wr = g->window[k][0], ge = g->window[k][1], gm = g->window[k][2], hl = g->halo[k];
-  if (wr <= 0 || L.xch_stride <= 0) return false;
-  const int tiles = (g->max_segment_nodes + 15) / 16;
-  const int ow = 16 * ((tiles + M - 1) / M);
-  const long long kb = keep ? win_keep_bytes(L.nb, ow) : 0;
-  return win_fwd_bytes(L.nc, wr, ow, ge, gm, hl) + kb <= LDS_BYTES &&
-         win_bwd_bytes(L.nc, 1024, wr, ow, ge, gm, hl) + kb + (keep ? 4LL * ow * L.nc + 16 : 0) <= LDS_BYTES &&
-         wr <= 65535 && ge <= 65535 && gm <= 65535;
-}
-
-// CUs per segment.  B = the co-residency bound of the layout (at most 8, whole grid resident, no more parts than 16-row
-// tiles).  Preferred: B parts on the window kernel; the kept gradient tables then become parameter gradients on whatever
-// CUs are left for consumer workgroups (batches below 32 snapshots) or in the stand-alone launch that follows
-// (param_grads_stream_kernel).  Measured on gatres_small, C-Town, bs = 32 (B = 8; profiles/r02_split_sweep.txt), GPU time
-// of the two launches: 8 parts 462 + 38 us; 6 parts + 2 consumers 526 us (the part that owns a segment's last 68 rows
-// needs two trips through every conv1-width sparse stage and a fifth MFMA tile -- 384-node snapshots run 22 us faster --
-// and the consumers finish 15 - 20 us after the parts); 7 + 1 607 us (ONE consumer streams an item at ~23 GB/s, the
-// LDS-DMA rate of one CU beside 224 busy ones, and cannot keep up with two items per block).  GATRES_FUSED_PREFER_CONSUMERS=1
-// restores round 2's earlier choice (B - 2 parts + two consumers).  Otherwise the whole-segment-table kernel at
-// min(B, 4).  The choice depends on the plan only, never on the phases of a launch: the per-part hand-off epochs persist
-// in scratch.  GATRES_FUSED_SPLIT=1..8 overrides.
-static int fused_split(const Layout& L, const gatres_graph_t* g) {
-  const int tiles = (g->max_segment_nodes + 15) / 16;
-  const int padded = ((g->num_segments + 7) / 8) * 8;
-  int B = L.split_max;
-  while (B > 1 && (B > tiles || L.nb == 0 || padded * B > device_cus())) --B;   // (a partitioned / smaller device)
-  if (const char* e = getenv("GATRES_FUSED_SPLIT")) {
-    const int v = atoi(e);
-    if (v >= 1 && v <= B) return v;
-  }
-  if (B >= 2 && window_kernel_fits(L, g, B) && !getenv("GATRES_FUSED_PREFER_CONSUMERS")) return B;
-  if (B >= 4 && window_kernel_fits(L, g, B - 2) && !getenv("GATRES_FUSED_NO_CONSUMERS")) return B - 2;
-  if (B >= 2 && window_kernel_fits(L, g, B)) return B;
-  int m = 1;
-  while (m * 2 <= B && m < 4) m *= 2;
-  return m;
-}
-
-// Consumer workgroups per segment for the deferred parameter gradients: only in launches that run the backward
-// phase, only with the 1024-thread kernel (the consumers reuse its LDS), and only if the whole grid -- per-snapshot
-// workgroups plus consumers, one per CU -- is still resident at once.
-static int fused_consumers(const Layout& L, const gatres_graph_t* g, int M) {
-  if (getenv("GATRES_FUSED_NO_CONSUMERS") || L.nb == 0 || threads_for(L.nc) != 1024) return 0;
-  const int padded = ((g->num_segments + 7) / 8) * 8;
-  int c = (device_cus() - padded * M) / padded;
-  int cap = 2;             // measured: 1, 2 and 4 consumers per snapshot give the same step time
-  if (const char* e = getenv("GATRES_FUSED_CONSUMERS")) cap = atoi(e) < 4 ? atoi(e) : 4;
-  if (c > cap) c = cap;
-  return c > 0 ? c : 0;
-}
-
-static bool use_window_kernel(const FusedArgs& a, const gatres_graph_t* g) {
-  return a.saved && window_kernel_fits(a.L, g, a.M);        // (it writes the saved tables: training launches only)
-}
-
-template <int NC, int THREADS>
-static int launch_fused(const FusedArgs& a, const gatres_graph_t* g, hipStream_t st) {
-  if constexpr (THREADS == 1024 && NC <= 32) {
-    if (use_window_kernel(a, g)) {
-      const dim3 wgrid((unsigned)(((g->num_segments + 7) / 8) * 8 * (a.M + a.C)));
-      hipLaunchKernelGGL((gatres_window_kernel<NC, THREADS>), wgrid, dim3(THREADS), 0, st, a);
-      return gatres_launch_status();
-    }
-  }
-  const bool cache = !getenv("GATRES_FUSED_NOCACHE") &&
-                     cache_fits(NC, THREADS, g->max_segment_nodes, g->max_segment_edges_gat, g->max_segment_edges_mean);
-  const dim3 grid((unsigned)(((g->num_segments + 7) / 8) * 8 * (a.M + a.C)));
-  if (cache)
-    hipLaunchKernelGGL((gatres_fused_kernel<NC, THREADS, true>), grid, dim3(THREADS), 0, st, a);
-  else
-    hipLaunchKernelGGL((gatres_fused_kernel<NC, THREADS, false>), grid, dim3(THREADS), 0, st, a);
-  return gatres_launch_status();
-}
 
 }  // namespace
-
-// C-ABI ------------------------------------------------------------------------------------------------------
-
-extern "C" int gatres_fused_supported(const gatres_model_t* m, const gatres_graph_t* g) {
-  if (!m || !g || g->num_segments <= 0 || !g->seg_ptr) return 0;
-  if (!(m->nc >= 4 && m->nc <= 128 && gatres_is_pow2(m->nc))) return 0;
-  if (m->act_dtype != GATRES_DTYPE_F32) return 0;        // the per-snapshot kernels are fp32 (the 1e-5 parity path)
-  // Wide models (gatres_large, nc = 128): the per-snapshot tables do not fit the LDS, the per-snapshot kernel would
-  // run without them at 256 / 512 threads, and the per-op kernels (LDS-staged persistent projections, 256 slabs) are
-  // then 1.6-1.8x faster on C-Town batches of 32 .. 128 snapshots.  GATRES_FUSED_WIDE=1 keeps the fused path for them.
-  if (m->nc > 32 && !getenv("GATRES_FUSED_WIDE")) return 0;
-  if (g->max_segment_nodes > 4096) return 0;      // beyond this a snapshot should be spread over many CUs
-  return nocache_fits(m->nc, threads_for(m->nc), g->max_segment_nodes, g->max_segment_edges_gat, g->max_segment_edges_mean)
-             ? 1 : 0;
-}
-
-extern "C" int gatres_fused_cus_per_segment(const gatres_model_t* m, const gatres_graph_t* g) {
-  Layout L;
-  if (!gatres_fused_supported(m, g) || !make_layout_g(m, g, &L)) return 0;
-  return fused_split(L, g);
-}
-
-// Zero the split-segment barrier state (epochs, XCD words, consumer counters, error word) of a scratch buffer: what a
-// freshly zeroed buffer has.  Only needed after a launch was aborted or the buffer was handed over from elsewhere.
-extern "C" int gatres_fused_reset_sync(const gatres_model_t* m, const gatres_graph_t* g, float* scratch, void* stream) {
-  if (!m || !g || !scratch) return GATRES_E_BADARG;
-  Layout L;
-  if (!make_layout_g(m, g, &L)) return GATRES_E_UNSUPPORTED;
-  if (fused_nodes_of(g) == 0) return 0;
-  if (L.xch_stride > 0) {      // granule tags of an aborted run must not meet a restarted epoch count
-    const hipError_t e = hipMemsetAsync(scratch + L.sc_xch, 0, (size_t)g->num_segments * L.xch_stride * 4, gatres_stream(stream));
-    if (e != hipSuccess) return (int)e;
-  }
-  return (int)hipMemsetAsync(scratch + L.sc_flags, 0, (size_t)(L.flag_words + L.ready_words) * 4, gatres_stream(stream));
-}
-
-extern "C" int gatres_fused_window_kernel(const gatres_model_t* m, const gatres_graph_t* g) {
-  Layout L;
-  if (!gatres_fused_supported(m, g) || !make_layout_g(m, g, &L)) return 0;
-  return window_kernel_fits(L, g, fused_split(L, g)) ? 1 : 0;
-}
-
-// Diagnostic: segment 0 of the next fused launches writes a 100 MHz wall-clock stamp at every stage boundary into
-// stamps[0..capacity) (device memory).  Pass nullptr to switch it off.
-extern "C" int gatres_fused_set_stamps(uint64_t* stamps, int32_t capacity) {
-  g_stamps = reinterpret_cast<unsigned long long*>(stamps);
-  g_stamp_cap = stamps ? capacity : 0;
-  return 0;
-}
-
-extern "C" int gatres_fused_prepare_backward(const gatres_model_t* m, const gatres_graph_t* g, const float* params,
-                                             float* scratch, void* stream) {
-  if (!m || !g || !params || !scratch) return GATRES_E_BADARG;
-  Layout L;
-  if (!make_layout_g(m, g, &L)) return GATRES_E_UNSUPPORTED;
-  return gatres_transpose_conv_weights(params, scratch + L.sc_wt, L.nb, L.nc, stream);
-}
-
-extern "C" int gatres_fused_run(const gatres_model_t* m, const gatres_graph_t* g, const float* params,
-                                const float* x, const uint8_t* mask, const float* y, float* out, float* g_out,
-                                float* loss_part, float* g_x, float* saved, float* scratch, int32_t phases,
-                                void* stream) {
-  if (!m || !g || !params || !x || !scratch) return GATRES_E_BADARG;
-  if (!gatres_fused_supported(m, g)) return GATRES_E_UNSUPPORTED;
-  FusedArgs a;
-  if (!make_layout_g(m, g, &a.L)) return GATRES_E_UNSUPPORTED;
-  if ((phases & GATRES_PHASE_FORWARD) && !out) return GATRES_E_BADARG;
-  if ((phases & GATRES_PHASE_LOSS) && (!mask || !y || !out || !g_out || !loss_part)) return GATRES_E_BADARG;
-  if ((phases & GATRES_PHASE_BACKWARD) && (!saved || !g_out)) return GATRES_E_BADARG;
-  a.seg_ptr = g->seg_ptr;
-  a.rowptr = g->rowptr; a.col = g->col; a.t_rowptr = g->t_rowptr; a.t_eid = g->t_eid; a.t_dst = g->t_dst;
-  a.m_rowptr = g->m_rowptr; a.m_col = g->m_col; a.mt_rowptr = g->mt_rowptr; a.mt_dst = g->mt_dst;
-  a.N = g->num_nodes;
-  a.perm = g->perm;
-  a.params = params; a.wt = scratch + a.L.sc_wt;
-  a.x = x; a.mask = mask; a.y = y; a.out = out; a.g_out = g_out; a.loss_part = loss_part; a.g_x = g_x;
-  a.saved = saved; a.scratch = scratch; a.slabs = scratch + a.L.sc_slabs;
-  a.num_segments = g->num_segments;
-  a.M = fused_split(a.L, g);
-  a.safe_sync = getenv("GATRES_FUSED_SAFE_SYNC") ? 1 : 0;
-  a.no_halo = (getenv("GATRES_FUSED_NO_HALO") ? 1 : 0) | (getenv("GATRES_XCH_NOWAIT") ? 2 : 0) |
-              (getenv("GATRES_DIAG_NOMASK") ? 4 : 0);      // diagnostic, WRONG results: dX epilogues without their global reads
-  a.C = (phases & GATRES_PHASE_BACKWARD) ? fused_consumers(a.L, g, a.M) : 0;
-  a.keep_lds = (phases & GATRES_PHASE_FORWARD) && (phases & GATRES_PHASE_BACKWARD) && !getenv("GATRES_FUSED_NO_KEEP") &&
-           window_kernel_fits(a.L, g, a.M, true) ? 1 : 0;
-  a.flags = reinterpret_cast<unsigned*>(scratch + a.L.sc_flags);
-  a.err = reinterpret_cast<int*>(a.flags + a.L.flag_words - 32);
-  a.ready = a.flags + a.L.flag_words;
-  a.part_slabs = scratch + a.L.sc_part_slabs;
-  a.SL = make_seg_layout(a.L.nb, a.L.nc, g->max_segment_nodes, g->max_segment_edges_gat);
-  a.xch = reinterpret_cast<unsigned long long*>(scratch + a.L.sc_xch);
-  a.XL = make_xch_layout(a.L.nc, g->max_segment_nodes, g->max_segment_edges_gat);
-  a.stamps = g_stamps; a.stamp_cap = g_stamp_cap;
-  a.phases = (phases & (GATRES_PHASE_FORWARD | GATRES_PHASE_BACKWARD)) | ((phases & GATRES_PHASE_LOSS) ? PH_LOSS : 0);
-  hipStream_t st = gatres_stream(stream);
-  if (a.M > 1) serialize_split_launch(st);
-  int rc = GATRES_E_UNSUPPORTED;
-  switch (m->nc) {
-    case 4: rc = launch_fused<4, 1024>(a, g, st); break;
-    case 8: rc = launch_fused<8, 1024>(a, g, st); break;
-    case 16: rc = launch_fused<16, 1024>(a, g, st); break;
-    case 32: rc = fused_threads_small() == 512 ? launch_fused<32, 512>(a, g, st) : launch_fused<32, 1024>(a, g, st); break;
-    case 64: rc = launch_fused<64, 512>(a, g, st); break;
-    case 128: rc = launch_fused<128, 256>(a, g, st); break;
-  }
-  if (rc == 0 && a.M > 1 && !(phases & GATRES_PHASE_BACKWARD)) {      // (a backward launch is followed by gatres_fused_finish)
-    hipLaunchKernelGGL(fused_status_kernel, dim3(1), dim3(64), 0, st, reinterpret_cast<unsigned*>(a.err));
-    rc = gatres_launch_status();
-  }
-  return rc;
-}
-
-extern "C" int gatres_fused_serialize(void* stream) { return serialize_split_launch(gatres_stream(stream)); }
-
-extern "C" int64_t gatres_fused_status_offset(const gatres_model_t* m, const gatres_graph_t* g) {
-  Layout L;
-  if (!gatres_fused_supported(m, g) || !make_layout_g(m, g, &L)) return -1;
-  return L.sc_flags + L.flag_words - 32;
-}
-
-extern "C" int gatres_fused_param_grads(const gatres_model_t* m, const gatres_graph_t* g, const float* saved,
-                                        float* scratch, void* stream) {
-  if (!m || !g || !saved || !scratch) return GATRES_E_BADARG;
-  if (!gatres_fused_supported(m, g)) return GATRES_E_UNSUPPORTED;
-  ParamGradArgs a;
-  if (!make_layout_g(m, g, &a.L)) return GATRES_E_UNSUPPORTED;
-  if (a.L.nb == 0) return 0;
-  if (fused_consumers(a.L, g, fused_split(a.L, g)) > 0) return 0;     // done by the backward launch's consumers
-  a.seg_ptr = g->seg_ptr; a.saved = saved; a.keep = scratch + a.L.sc_keep; a.slabs = scratch + a.L.sc_slabs;
-  a.M = fused_split(a.L, g); a.part_slabs = scratch + a.L.sc_part_slabs;
-  a.SL = make_seg_layout(a.L.nb, a.L.nc, g->max_segment_nodes, g->max_segment_edges_gat);
-  a.wt = scratch + a.L.sc_wt;
-  const dim3 grid((unsigned)(2 * a.L.nb * g->num_segments));
-  hipStream_t st = gatres_stream(stream);
-  if ((m->nc == 16 || m->nc == 32) && !getenv("GATRES_PARAM_GRADS_NO_STREAM")) {
-    if (m->nc == 16) hipLaunchKernelGGL((param_grads_stream_kernel<16>), grid, dim3(PGS_THREADS), 0, st, a);
-    else             hipLaunchKernelGGL((param_grads_stream_kernel<32>), grid, dim3(PGS_THREADS), 0, st, a);
-    return gatres_launch_status();
-  }
-  switch (m->nc) {
-    case 4: hipLaunchKernelGGL((param_grads_kernel<4, 256>), grid, dim3(256), 0, st, a); break;
-    case 8: hipLaunchKernelGGL((param_grads_kernel<8, 256>), grid, dim3(256), 0, st, a); break;
-    case 16: hipLaunchKernelGGL((param_grads_kernel<16, 512>), grid, dim3(512), 0, st, a); break;
-    case 32: hipLaunchKernelGGL((param_grads_kernel<32, 512>), grid, dim3(512), 0, st, a); break;
-    case 64: hipLaunchKernelGGL((param_grads_kernel<64, 512>), grid, dim3(512), 0, st, a); break;
-    case 128: hipLaunchKernelGGL((param_grads_kernel<128, 512>), grid, dim3(512), 0, st, a); break;
-    default: return GATRES_E_UNSUPPORTED;
-  }
-  return gatres_launch_status();
-}
-
-extern "C" int gatres_fused_finish(const gatres_model_t* m, const gatres_graph_t* g, float* scratch, float* grads,
-                                   const float* loss_part, float* loss, int32_t do_adam, float* params,
-                                   float* exp_avg, float* exp_avg_sq, uint64_t* step_counter, double lr, double beta1,
-                                   double beta2, double eps, double weight_decay, float grad_scale, void* stream) {
-  if (!m || !g || !scratch || !grads) return GATRES_E_BADARG;
-  if (do_adam && (!params || !exp_avg || !exp_avg_sq || !step_counter)) return GATRES_E_BADARG;
-  if ((loss_part == nullptr) != (loss == nullptr)) return GATRES_E_BADARG;
-  Layout L;
-  if (!make_layout_g(m, g, &L)) return GATRES_E_UNSUPPORTED;
-  hipLaunchKernelGGL(reduce_adam_kernel, dim3((unsigned)((L.P + 255) / 256)), dim3(256), 0, gatres_stream(stream),
-                     scratch + L.sc_slabs, g->num_segments, g->num_segments * fused_split(L, g),
-                     (long long)L.slab_stride, (long long)L.P, grads, loss_part, loss, do_adam, params, exp_avg, exp_avg_sq,
-                     reinterpret_cast<unsigned long long*>(step_counter), lr, beta1, beta2, eps, weight_decay,
-                     grad_scale, do_adam ? scratch + L.sc_wt : nullptr, L.nb, L.nc,
-                     fused_nodes_of(g) > 0 ? reinterpret_cast<unsigned*>(scratch + L.sc_flags + L.flag_words - 32) : nullptr);
-  return gatres_launch_status();
-}

@@ -1,0 +1,401 @@
+// Host side of the fused per-snapshot path: launch geometry, the deferred parameter-gradient launch, the slab reduction +
+// Adam launch, and the C-ABI entry points (include/gatres.h: gatres_fused_*).
+#include "k_fused_dev.h"
+
+// the kernels live in translation units of their own (k_window.hip, k_fused_whole.hip); args: const FusedArgs*
+extern "C" __attribute__((visibility("hidden"))) int gatres_fused_launch_window(const void* args, int nc, unsigned grid, void* stream);
+extern "C" __attribute__((visibility("hidden"))) int gatres_fused_launch_whole(const void* args, int nc, int threads, int cache,
+                                                                              unsigned grid, void* stream);
+
+namespace {
+
+static unsigned long long* g_stamps = nullptr;      // gatres_fused_set_stamps (diagnostic build)
+static int g_stamp_cap = 0;
+
+// grads = sum of segment slabs (fixed order) ; optionally the Adam update and the loss finalisation in the same pass
+__global__ __launch_bounds__(256) void reduce_adam_kernel(const float* __restrict__ slabs, int num_slabs,
+                                                          int num_loss, long long stride, long long count,
+                                                          float* __restrict__ grads, const float* loss_part,
+                                                          float* loss, int do_adam, float* __restrict__ p,
+                                                          float* __restrict__ m, float* __restrict__ v,
+                                                          unsigned long long* __restrict__ step_counter, double lr,
+                                                          double b1, double b2, double eps, double wd,
+                                                          float grad_scale, float* __restrict__ wt, int nb, int nc,
+                                                          unsigned* __restrict__ status) {
+  __shared__ float s_step_size, s_bc2_sqrt;
+  __shared__ unsigned s_fault;
+  // status[0]: a split launch of this step gave up waiting for a partner workgroup (its results are poisoned).  The step
+  // is then DROPPED: no Adam update, no step count, loss = NaN, gradients = NaN; the last block clears the word and
+  // counts the event in status[1], so one transient stall costs one step instead of the whole run.
+  if (threadIdx.x == 0) s_fault = status ? __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+  if (do_adam && threadIdx.x == 0) {
+    const unsigned long long t = __hip_atomic_load(step_counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1ULL;
+    s_step_size = (float)(lr / (1.0 - gatres_powi(b1, t)));
+    s_bc2_sqrt = (float)sqrt(1.0 - gatres_powi(b2, t));
+    // The step is counted once every block has READ the counter: a ticket drawn right after this block's read (its value is
+    // in a register: the wait below), the last ticket increments.  Nothing orders the count behind the parameter stores --
+    // the next launch is -- so no fence: the ticket used to follow the block's stores behind a __threadfence(), an L2
+    // write-back + invalidate of ~3.5 us at the end of every block of a 14-us launch.
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    if (s_fault == 0u) {
+      const unsigned long long done = atomicAdd(&step_counter[1], 1ULL);
+      if (done == (unsigned long long)gridDim.x - 1ULL) {
+        step_counter[1] = 0ULL;
+        atomicAdd(&step_counter[0], 1ULL);
+      }
+    }
+  }
+  if (loss_part && blockIdx.x == 0 && threadIdx.x < 64) {
+    // the loss: sum of the per-(segment, part) squared errors / masked-node count.  One wave, strided partial sums
+    // and a fixed-order butterfly (a single thread walking 128 dependent loads made block 0 the kernel's critical path)
+    float s = 0.f;
+    for (int k = threadIdx.x; k < num_loss; k += 64) s += loss_part[k];
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+    if (threadIdx.x == 0) loss[0] = s / loss_part[num_loss];
+  }
+  __syncthreads();
+  const bool fault = s_fault != 0u;
+  if (fault && loss && blockIdx.x == 0 && threadIdx.x == 0) loss[0] = NAN;
+  const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (idx < count) {
+    float acc = 0.f;
+    int s0 = 0;
+    // the parameter and its moments are requested together with the first slab rows: one memory round trip for a
+    // 32-snapshot batch instead of five dependent ones (this launch is pure latency: 258 workgroups x 4 waves)
+    float pv = 0.f, mv0 = 0.f, vv0 = 0.f;
+    if (do_adam && !fault) { pv = p[idx]; mv0 = m[idx]; vv0 = v[idx]; }
+    for (; s0 + 32 <= num_slabs; s0 += 32) {            // 32 loads in flight, summed in slab order
+      float v32[32];
+#pragma unroll
+      for (int u = 0; u < 32; ++u) v32[u] = slabs[(size_t)(s0 + u) * stride + idx];
+#pragma unroll
+      for (int u = 0; u < 32; ++u) acc += v32[u];
+    }
+    for (; s0 + 8 <= num_slabs; s0 += 8) {
+      float v8[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v8[u] = slabs[(size_t)(s0 + u) * stride + idx];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) acc += v8[u];
+    }
+    for (; s0 < num_slabs; ++s0) acc += slabs[(size_t)s0 * stride + idx];
+    grads[idx] = fault ? NAN : acc;
+    if (do_adam && !fault) {
+      float gv = acc * grad_scale;
+      gv = gv + (float)wd * pv;
+      float mv = mv0;
+      mv = mv + (float)(1.0 - b1) * (gv - mv);
+      const float vv = (float)b2 * vv0 + (float)(1.0 - b2) * gv * gv;
+      const float denom = sqrtf(vv) / s_bc2_sqrt + (float)eps;
+      const float pn = pv + (-s_step_size * mv) / denom;
+      p[idx] = pn;
+      m[idx] = mv;
+      v[idx] = vv;
+      if (wt) {                   // keep the transposed conv weights of the next backward current (k_misc.hip layout)
+        const long long per = 2LL * nc * nc, stride = 9LL * nc + 2 * per, off = idx - 2LL * nc;
+        if (off >= 0 && off < (long long)nb * stride) {
+          const long long b = off / stride, o = off % stride;
+          if (o >= 6LL * nc && o < 6LL * nc + per) {                        // W1 [2nc][nc] -> [nc][2nc]
+            const long long e = o - 6LL * nc, row = e / nc, col = e % nc;
+            wt[b * 2 * per + col * 2 * nc + row] = pn;
+          } else if (o >= 9LL * nc + per) {                                 // W2 [nc][2nc] -> [2nc][nc]
+            const long long e = o - 9LL * nc - per, row = e / (2 * nc), col = e % (2 * nc);
+            wt[b * 2 * per + per + col * nc + row] = pn;
+          }
+        }
+      }
+    }
+  }
+  if (fault && threadIdx.x == 0) {               // every block has read status[0] before the last ticket is drawn
+    __threadfence();
+    if (atomicAdd(status + 2, 1u) == gridDim.x - 1u) {
+      status[2] = 0u;
+      status[1] += 1u;
+      __hip_atomic_store(status, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+}
+
+// The same bookkeeping after a split launch that no gatres_fused_finish follows (forward / inference launches)
+__global__ __launch_bounds__(64) void fused_status_kernel(unsigned* __restrict__ status) {
+  if (threadIdx.x == 0 && __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
+    status[1] += 1u;
+    __hip_atomic_store(status, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
+// Two split launches must never be in flight on one device at the same time: each needs its whole grid resident, and
+// each could hold CUs the other waits for (the bounded spins would then poison both).  Launches on ONE stream are
+// ordered anyway; when the stream changes, the new stream first waits for everything enqueued on the previous one.
+// Skipped while `st` is being captured: the host that replays the graph calls gatres_fused_serialize before the replay.
+static std::mutex g_split_mu;
+static hipStream_t g_split_stream[64];
+static bool g_split_seen[64] = {};
+static int serialize_split_launch(hipStream_t st) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 0;
+  std::lock_guard<std::mutex> lk(g_split_mu);
+  hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(st, &cs) != hipSuccess) { (void)hipGetLastError(); return 0; }
+  if (cs != hipStreamCaptureStatusNone) return 0;
+  if (g_split_seen[dev] && g_split_stream[dev] != st) {
+    hipStream_t prev = g_split_stream[dev];
+    hipStreamCaptureStatus ps = hipStreamCaptureStatusNone;
+    hipEvent_t ev;
+    if (hipStreamIsCapturing(prev, &ps) == hipSuccess && ps == hipStreamCaptureStatusNone &&
+        hipEventCreateWithFlags(&ev, hipEventDisableTiming) == hipSuccess) {
+      if (hipEventRecord(ev, prev) == hipSuccess) (void)hipStreamWaitEvent(st, ev, 0);
+      (void)hipEventDestroy(ev);
+    }
+    (void)hipGetLastError();                     // (a stream the caller has destroyed meanwhile: nothing left to wait for)
+  }
+  g_split_stream[dev] = st;
+  g_split_seen[dev] = true;
+  return 0;
+}
+
+static int fused_threads_small() {
+  return gatres_knobs()->fused_threads;
+}
+static int threads_for(int nc) { return nc <= 32 ? fused_threads_small() : (nc == 64 ? 512 : 256); }
+
+// CUs of the current device (cached): every workgroup of a split launch must be resident at once, one per CU.
+static int device_cus() {
+  static int cus = 0;
+  if (cus == 0) {
+    int dev = 0, v = 0;
+    if (hipGetDevice(&dev) == hipSuccess &&
+        hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0)
+      cus = v;
+    else
+      cus = 1;               // unknown: never split
+  }
+  return cus;
+}
+
+// The window kernel applies when the plan knows the parts' row windows and both LDS layouts fit with them.
+static bool window_kernel_fits(const Layout& L, const gatres_graph_t* g, int M, bool keep = false) {
+  if (gatres_knobs()->fused_no_window || M < 2 || M > 8 || L.nc > 32 || threads_for(L.nc) != 1024) return false;
+  const int k = M - 2;
+  const int wr = g->window[k][0], ge = g->window[k][1], gm = g->window[k][2], hl = g->halo[k];
+  if (wr <= 0 || L.xch_stride <= 0) return false;
+  const int tiles = (g->max_segment_nodes + 15) / 16;
+  const int ow = 16 * ((tiles + M - 1) / M);
+  const long long kb = keep ? win_keep_bytes(L.nb, ow) : 0;
+  return win_fwd_bytes(L.nc, wr, ow, ge, gm, hl) + kb <= LDS_BYTES &&
+         win_bwd_bytes(L.nc, 1024, wr, ow, ge, gm, hl) + kb + (keep ? 4LL * ow * L.nc + 16 : 0) <= LDS_BYTES &&
+         wr <= 65535 && ge <= 65535 && gm <= 65535;
+}
+
+// CUs per segment.  B = the co-residency bound of the layout (at most 8, whole grid resident, no more parts than 16-row
+// tiles).  Preferred: B parts on the window kernel; the kept gradient tables then become parameter gradients on whatever
+// CUs are left for consumer workgroups (batches below 32 snapshots) or in the stand-alone launch that follows
+// (param_grads_stream_kernel).  Measured on gatres_small, C-Town, bs = 32 (B = 8; profiles/r02_split_sweep.txt), GPU time
+// of the two launches: 8 parts 462 + 38 us; 6 parts + 2 consumers 526 us (the part that owns a segment's last 68 rows
+// needs two trips through every conv1-width sparse stage and a fifth MFMA tile -- 384-node snapshots run 22 us faster --
+// and the consumers finish 15 - 20 us after the parts); 7 + 1 607 us (ONE consumer streams an item at ~23 GB/s, the
+// LDS-DMA rate of one CU beside 224 busy ones, and cannot keep up with two items per block).  GATRES_FUSED_PREFER_CONSUMERS=1
+// restores round 2's earlier choice (B - 2 parts + two consumers).  Otherwise the whole-segment-table kernel at
+// min(B, 4).  The choice depends on the plan only, never on the phases of a launch: the per-part hand-off epochs persist
+// in scratch.  GATRES_FUSED_SPLIT=1..8 overrides.
+static int fused_split(const Layout& L, const gatres_graph_t* g) {
+  const int tiles = (g->max_segment_nodes + 15) / 16;
+  const int padded = ((g->num_segments + 7) / 8) * 8;
+  int B = L.split_max;
+  while (B > 1 && (B > tiles || L.nb == 0 || padded * B > device_cus())) --B;   // (a partitioned / smaller device)
+  if (const int v = gatres_knobs()->fused_split) {
+    if (v >= 1 && v <= B) return v;
+  }
+  if (B >= 2 && window_kernel_fits(L, g, B) && !gatres_knobs()->fused_prefer_consumers) return B;
+  if (B >= 4 && window_kernel_fits(L, g, B - 2) && !gatres_knobs()->fused_no_consumers) return B - 2;
+  if (B >= 2 && window_kernel_fits(L, g, B)) return B;
+  int m = 1;
+  while (m * 2 <= B && m < 4) m *= 2;
+  return m;
+}
+
+// Consumer workgroups per segment for the deferred parameter gradients: only in launches that run the backward
+// phase, only with the 1024-thread kernel (the consumers reuse its LDS), and only if the whole grid -- per-snapshot
+// workgroups plus consumers, one per CU -- is still resident at once.
+static int fused_consumers(const Layout& L, const gatres_graph_t* g, int M) {
+  if (gatres_knobs()->fused_no_consumers || L.nb == 0 || threads_for(L.nc) != 1024) return 0;
+  const int padded = ((g->num_segments + 7) / 8) * 8;
+  int c = (device_cus() - padded * M) / padded;
+  const int cap = gatres_knobs()->fused_consumers_cap;   // default 2; measured: 1, 2 and 4 consumers per snapshot give the same step time
+  if (c > cap) c = cap;
+  return c > 0 ? c : 0;
+}
+
+static bool use_window_kernel(const FusedArgs& a, const gatres_graph_t* g) {
+  return a.saved && window_kernel_fits(a.L, g, a.M);        // (it writes the saved tables: training launches only)
+}
+
+static int launch_fused(int nc, int threads, const FusedArgs& a, const gatres_graph_t* g, hipStream_t st) {
+  const unsigned grid = (unsigned)(((g->num_segments + 7) / 8) * 8 * (a.M + a.C));
+  if (threads == 1024 && nc <= 32 && use_window_kernel(a, g)) return gatres_fused_launch_window(&a, nc, grid, st);
+  const bool cache = !gatres_knobs()->fused_nocache &&
+                     cache_fits(nc, threads, g->max_segment_nodes, g->max_segment_edges_gat, g->max_segment_edges_mean);
+  return gatres_fused_launch_whole(&a, nc, threads, cache ? 1 : 0, grid, st);
+}
+}  // namespace
+
+// C-ABI ------------------------------------------------------------------------------------------------------
+
+extern "C" int gatres_fused_supported(const gatres_model_t* m, const gatres_graph_t* g) {
+  if (!m || !g || g->num_segments <= 0 || !g->seg_ptr) return 0;
+  if (!(m->nc >= 4 && m->nc <= 128 && gatres_is_pow2(m->nc))) return 0;
+  if (m->act_dtype != GATRES_DTYPE_F32) return 0;        // the per-snapshot kernels are fp32 (the 1e-5 parity path)
+  // Wide models (gatres_large, nc = 128): the per-snapshot tables do not fit the LDS, the per-snapshot kernel would
+  // run without them at 256 / 512 threads, and the per-op kernels (LDS-staged persistent projections, 256 slabs) are
+  // then 1.6-1.8x faster on C-Town batches of 32 .. 128 snapshots.  GATRES_FUSED_WIDE=1 keeps the fused path for them.
+  if (m->nc > 32 && !gatres_knobs()->fused_wide) return 0;
+  if (g->max_segment_nodes > 4096) return 0;      // beyond this a snapshot should be spread over many CUs
+  return nocache_fits(m->nc, threads_for(m->nc), g->max_segment_nodes, g->max_segment_edges_gat, g->max_segment_edges_mean)
+             ? 1 : 0;
+}
+
+extern "C" int gatres_fused_cus_per_segment(const gatres_model_t* m, const gatres_graph_t* g) {
+  Layout L;
+  if (!gatres_fused_supported(m, g) || !make_layout_g(m, g, &L)) return 0;
+  return fused_split(L, g);
+}
+
+// Zero the split-segment barrier state (epochs, XCD words, consumer counters, error word) of a scratch buffer: what a
+// freshly zeroed buffer has.  Only needed after a launch was aborted or the buffer was handed over from elsewhere.
+extern "C" int gatres_fused_reset_sync(const gatres_model_t* m, const gatres_graph_t* g, float* scratch, void* stream) {
+  if (!m || !g || !scratch) return GATRES_E_BADARG;
+  Layout L;
+  if (!make_layout_g(m, g, &L)) return GATRES_E_UNSUPPORTED;
+  if (fused_nodes_of(g) == 0) return 0;
+  if (L.xch_stride > 0) {      // granule tags of an aborted run must not meet a restarted epoch count
+    const hipError_t e = hipMemsetAsync(scratch + L.sc_xch, 0, (size_t)g->num_segments * L.xch_stride * 4, gatres_stream(stream));
+    if (e != hipSuccess) return (int)e;
+  }
+  return (int)hipMemsetAsync(scratch + L.sc_flags, 0, (size_t)(L.flag_words + L.ready_words) * 4, gatres_stream(stream));
+}
+
+extern "C" int gatres_fused_window_kernel(const gatres_model_t* m, const gatres_graph_t* g) {
+  Layout L;
+  if (!gatres_fused_supported(m, g) || !make_layout_g(m, g, &L)) return 0;
+  return window_kernel_fits(L, g, fused_split(L, g)) ? 1 : 0;
+}
+
+// Diagnostic: segment 0 of the next fused launches writes a 100 MHz wall-clock stamp at every stage boundary into
+// stamps[0..capacity) (device memory).  Pass nullptr to switch it off.
+extern "C" int gatres_fused_set_stamps(uint64_t* stamps, int32_t capacity) {
+  g_stamps = reinterpret_cast<unsigned long long*>(stamps);
+  g_stamp_cap = stamps ? capacity : 0;
+  return 0;
+}
+
+extern "C" int gatres_fused_prepare_backward(const gatres_model_t* m, const gatres_graph_t* g, const float* params,
+                                             float* scratch, void* stream) {
+  if (!m || !g || !params || !scratch) return GATRES_E_BADARG;
+  Layout L;
+  if (!make_layout_g(m, g, &L)) return GATRES_E_UNSUPPORTED;
+  return gatres_transpose_conv_weights(params, scratch + L.sc_wt, L.nb, L.nc, stream);
+}
+
+extern "C" int gatres_fused_run(const gatres_model_t* m, const gatres_graph_t* g, const float* params,
+                                const float* x, const uint8_t* mask, const float* y, float* out, float* g_out,
+                                float* loss_part, float* g_x, float* saved, float* scratch, int32_t phases,
+                                void* stream) {
+  if (!m || !g || !params || !x || !scratch) return GATRES_E_BADARG;
+  if (!gatres_fused_supported(m, g)) return GATRES_E_UNSUPPORTED;
+  FusedArgs a;
+  if (!make_layout_g(m, g, &a.L)) return GATRES_E_UNSUPPORTED;
+  if ((phases & GATRES_PHASE_FORWARD) && !out) return GATRES_E_BADARG;
+  if ((phases & GATRES_PHASE_LOSS) && (!mask || !y || !out || !g_out || !loss_part)) return GATRES_E_BADARG;
+  if ((phases & GATRES_PHASE_BACKWARD) && (!saved || !g_out)) return GATRES_E_BADARG;
+  a.seg_ptr = g->seg_ptr;
+  a.rowptr = g->rowptr; a.col = g->col; a.t_rowptr = g->t_rowptr; a.t_eid = g->t_eid; a.t_dst = g->t_dst;
+  a.m_rowptr = g->m_rowptr; a.m_col = g->m_col; a.mt_rowptr = g->mt_rowptr; a.mt_dst = g->mt_dst;
+  a.N = g->num_nodes;
+  a.perm = g->perm;
+  a.params = params; a.wt = scratch + a.L.sc_wt;
+  a.x = x; a.mask = mask; a.y = y; a.out = out; a.g_out = g_out; a.loss_part = loss_part; a.g_x = g_x;
+  a.saved = saved; a.scratch = scratch; a.slabs = scratch + a.L.sc_slabs;
+  a.num_segments = g->num_segments;
+  a.M = fused_split(a.L, g);
+  a.safe_sync = gatres_knobs()->fused_safe_sync;
+  // bits 1 / 2 (diagnostic build only, WRONG results): never-wait exchanges; dX epilogues without their global reads
+  a.no_halo = gatres_knobs()->fused_no_halo | (gatres_knobs()->xch_nowait ? 2 : 0) | (gatres_knobs()->diag_nomask ? 4 : 0);
+  a.C = (phases & GATRES_PHASE_BACKWARD) ? fused_consumers(a.L, g, a.M) : 0;
+  a.keep_lds = (phases & GATRES_PHASE_FORWARD) && (phases & GATRES_PHASE_BACKWARD) && !gatres_knobs()->fused_no_keep &&
+           window_kernel_fits(a.L, g, a.M, true) ? 1 : 0;
+  a.flags = reinterpret_cast<unsigned*>(scratch + a.L.sc_flags);
+  a.err = reinterpret_cast<int*>(a.flags + a.L.flag_words - 32);
+  a.ready = a.flags + a.L.flag_words;
+  a.part_slabs = scratch + a.L.sc_part_slabs;
+  a.SL = make_seg_layout(a.L.nb, a.L.nc, g->max_segment_nodes, g->max_segment_edges_gat);
+  a.xch = reinterpret_cast<unsigned long long*>(scratch + a.L.sc_xch);
+  a.XL = make_xch_layout(a.L.nc, g->max_segment_nodes, g->max_segment_edges_gat);
+  a.stamps = g_stamps; a.stamp_cap = g_stamp_cap;
+  a.phases = (phases & (GATRES_PHASE_FORWARD | GATRES_PHASE_BACKWARD)) | ((phases & GATRES_PHASE_LOSS) ? PH_LOSS : 0);
+  hipStream_t st = gatres_stream(stream);
+  if (a.M > 1) serialize_split_launch(st);
+  int rc = launch_fused(m->nc, threads_for(m->nc), a, g, st);
+  if (rc == 0 && a.M > 1 && !(phases & GATRES_PHASE_BACKWARD)) {      // (a backward launch is followed by gatres_fused_finish)
+    hipLaunchKernelGGL(fused_status_kernel, dim3(1), dim3(64), 0, st, reinterpret_cast<unsigned*>(a.err));
+    rc = gatres_launch_status();
+  }
+  return rc;
+}
+
+extern "C" int gatres_fused_serialize(void* stream) { return serialize_split_launch(gatres_stream(stream)); }
+
+extern "C" int64_t gatres_fused_status_offset(const gatres_model_t* m, const gatres_graph_t* g) {
+  Layout L;
+  if (!gatres_fused_supported(m, g) || !make_layout_g(m, g, &L)) return -1;
+  return L.sc_flags + L.flag_words - 32;
+}
+
+extern "C" int gatres_fused_param_grads(const gatres_model_t* m, const gatres_graph_t* g, const float* saved,
+                                        float* scratch, void* stream) {
+  if (!m || !g || !saved || !scratch) return GATRES_E_BADARG;
+  if (!gatres_fused_supported(m, g)) return GATRES_E_UNSUPPORTED;
+  ParamGradArgs a;
+  if (!make_layout_g(m, g, &a.L)) return GATRES_E_UNSUPPORTED;
+  if (a.L.nb == 0) return 0;
+  if (fused_consumers(a.L, g, fused_split(a.L, g)) > 0) return 0;     // done by the backward launch's consumers
+  a.seg_ptr = g->seg_ptr; a.saved = saved; a.keep = scratch + a.L.sc_keep; a.slabs = scratch + a.L.sc_slabs;
+  a.M = fused_split(a.L, g); a.part_slabs = scratch + a.L.sc_part_slabs;
+  a.SL = make_seg_layout(a.L.nb, a.L.nc, g->max_segment_nodes, g->max_segment_edges_gat);
+  a.wt = scratch + a.L.sc_wt;
+  const dim3 grid((unsigned)(2 * a.L.nb * g->num_segments));
+  hipStream_t st = gatres_stream(stream);
+  if ((m->nc == 16 || m->nc == 32) && !gatres_knobs()->param_grads_no_stream) {
+    if (m->nc == 16) hipLaunchKernelGGL((param_grads_stream_kernel<16>), grid, dim3(PGS_THREADS), 0, st, a);
+    else             hipLaunchKernelGGL((param_grads_stream_kernel<32>), grid, dim3(PGS_THREADS), 0, st, a);
+    return gatres_launch_status();
+  }
+  switch (m->nc) {
+    case 4: hipLaunchKernelGGL((param_grads_kernel<4, 256>), grid, dim3(256), 0, st, a); break;
+    case 8: hipLaunchKernelGGL((param_grads_kernel<8, 256>), grid, dim3(256), 0, st, a); break;
+    case 16: hipLaunchKernelGGL((param_grads_kernel<16, 512>), grid, dim3(512), 0, st, a); break;
+    case 32: hipLaunchKernelGGL((param_grads_kernel<32, 512>), grid, dim3(512), 0, st, a); break;
+    case 64: hipLaunchKernelGGL((param_grads_kernel<64, 512>), grid, dim3(512), 0, st, a); break;
+    case 128: hipLaunchKernelGGL((param_grads_kernel<128, 512>), grid, dim3(512), 0, st, a); break;
+    default: return GATRES_E_UNSUPPORTED;
+  }
+  return gatres_launch_status();
+}
+
+extern "C" int gatres_fused_finish(const gatres_model_t* m, const gatres_graph_t* g, float* scratch, float* grads,
+                                   const float* loss_part, float* loss, int32_t do_adam, float* params,
+                                   float* exp_avg, float* exp_avg_sq, uint64_t* step_counter, double lr, double beta1,
+                                   double beta2, double eps, double weight_decay, float grad_scale, void* stream) {
+  if (!m || !g || !scratch || !grads) return GATRES_E_BADARG;
+  if (do_adam && (!params || !exp_avg || !exp_avg_sq || !step_counter)) return GATRES_E_BADARG;
+  if ((loss_part == nullptr) != (loss == nullptr)) return GATRES_E_BADARG;
+  Layout L;
+  if (!make_layout_g(m, g, &L)) return GATRES_E_UNSUPPORTED;
+  hipLaunchKernelGGL(reduce_adam_kernel, dim3((unsigned)((L.P + 255) / 256)), dim3(256), 0, gatres_stream(stream),
+                     scratch + L.sc_slabs, g->num_segments, g->num_segments * fused_split(L, g),
+                     (long long)L.slab_stride, (long long)L.P, grads, loss_part, loss, do_adam, params, exp_avg, exp_avg_sq,
+                     reinterpret_cast<unsigned long long*>(step_counter), lr, beta1, beta2, eps, weight_decay,
+                     grad_scale, do_adam ? scratch + L.sc_wt : nullptr, L.nb, L.nc,
+                     fused_nodes_of(g) > 0 ? reinterpret_cast<unsigned*>(scratch + L.sc_flags + L.flag_words - 32) : nullptr);
+  return gatres_launch_status();
+}
+

@@ -6,8 +6,69 @@
 // their own slab at the parameter's flat offset; gatres_reduce_slabs adds the slabs in index order.  No atomics,
 // bitwise reproducible.
 #include "gatres_common.h"
-#include "gatres_typed.h"
 #include "k_conv_grads.h"
+
+// ---------------------------------------------------------------------------------------------------- environment knobs
+#include <atomic>
+#include <cstdlib>
+#include <mutex>
+namespace {
+gatres_knobs_t g_knobs;
+std::atomic<bool> g_knobs_ready{false};
+std::mutex g_knobs_mu;
+int env_flag(const char* n) { const char* e = getenv(n); return (e && *e && !(e[0] == '0' && !e[1])) ? 1 : 0; }
+int env_int(const char* n, int dflt) { const char* e = getenv(n); return (e && *e) ? atoi(e) : dflt; }
+void read_knobs(gatres_knobs_t* k) {
+  const int lf = env_int("GATRES_AGG_LANE_FEATURES", 0);
+  k->agg_lane_features = (lf == 4 || lf == 8) ? lf : 0;
+  k->agg_wide_offsets = env_flag("GATRES_AGG_WIDE_OFFSETS");
+  k->fused_threads = env_int("GATRES_FUSED_THREADS", 1024) == 512 ? 512 : 1024;
+  k->fused_no_window = env_flag("GATRES_FUSED_NO_WINDOW");
+  k->fused_split = env_int("GATRES_FUSED_SPLIT", 0);
+  k->fused_prefer_consumers = env_flag("GATRES_FUSED_PREFER_CONSUMERS");
+  k->fused_no_consumers = env_flag("GATRES_FUSED_NO_CONSUMERS");
+  { const int c = env_int("GATRES_FUSED_CONSUMERS", 2); k->fused_consumers_cap = c < 4 ? c : 4; }
+  k->fused_nocache = env_flag("GATRES_FUSED_NOCACHE");
+  k->fused_safe_sync = env_flag("GATRES_FUSED_SAFE_SYNC");
+  k->fused_no_halo = env_flag("GATRES_FUSED_NO_HALO");
+  k->fused_no_keep = env_flag("GATRES_FUSED_NO_KEEP");
+  k->fused_two_kernels = env_flag("GATRES_FUSED_TWO_KERNELS");
+  k->param_grads_no_stream = env_flag("GATRES_PARAM_GRADS_NO_STREAM");
+  k->lin_bwd_wave = env_flag("GATRES_LIN_BWD_WAVE");
+  k->proj_rows = (env_int("GATRES_PROJ_ROWS", 0) + 63) & ~63;
+  k->no_proj_lds = env_flag("GATRES_NO_PROJ_LDS");
+  k->dw_1d = env_flag("GATRES_DW_1D");
+  k->dw_fp32 = env_flag("GATRES_DW_FP32");
+  k->no_co_launch = env_flag("GATRES_NO_CO_LAUNCH");
+  k->co_launch_always = env_flag("GATRES_CO_LAUNCH_ALWAYS");
+  k->dw_slab_rows = env_int("GATRES_DW_SLAB_ROWS", 0);
+#ifdef GATRES_DIAG_BUILD
+  k->fused_wide = env_flag("GATRES_FUSED_WIDE");
+  k->xch_nowait = env_flag("GATRES_XCH_NOWAIT");
+  k->diag_nomask = env_flag("GATRES_DIAG_NOMASK");
+#else
+  k->fused_wide = 0; k->xch_nowait = 0; k->diag_nomask = 0;
+#endif
+}
+}  // namespace
+
+extern "C" __attribute__((visibility("hidden"))) const gatres_knobs_t* gatres_knobs() {
+  if (!g_knobs_ready.load(std::memory_order_acquire)) {
+    std::lock_guard<std::mutex> lk(g_knobs_mu);
+    if (!g_knobs_ready.load(std::memory_order_relaxed)) {
+      read_knobs(&g_knobs);
+      g_knobs_ready.store(true, std::memory_order_release);
+    }
+  }
+  return &g_knobs;
+}
+// Re-read the environment (a process that changed GATRES_* variables after the first call into the library).
+extern "C" int gatres_knobs_reload(void) {
+  std::lock_guard<std::mutex> lk(g_knobs_mu);
+  read_knobs(&g_knobs);
+  g_knobs_ready.store(true, std::memory_order_release);
+  return 0;
+}
 
 namespace {
 
@@ -568,7 +629,7 @@ extern "C" int gatres_lin0_fwd(const float* x, const uint8_t* mask, const float*
 // the row-wise lin0 / lin1 backward kernels take nc = 4, 8, ..., 256 (a power of two) and 16-byte aligned activations
 static inline int ilog2_(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
 static inline bool lin_rows_form(int nc, const void* act) {
-  return nc >= 4 && nc <= 256 && gatres_is_pow2(nc) && gatres_aligned16(act) && !getenv("GATRES_LIN_BWD_WAVE");
+  return nc >= 4 && nc <= 256 && gatres_is_pow2(nc) && gatres_aligned16(act) && !gatres_knobs()->lin_bwd_wave;
 }
 
 extern "C" int gatres_t_lin0_bwd(const void* g, const float* x, const uint8_t* mask, float* slab_w, float* slab_b, int num_slabs,

@@ -18,7 +18,6 @@
 
 #include "gatres_common.h"
 #include "k_conv_grads.h"
-#include "gatres_typed.h"
 
 namespace {
 
@@ -531,7 +530,7 @@ int launch_proj_bf16(const gatres_bf16* X, const gatres_bf16* Wm, gatres_bf16* O
     if (grid > 256) grid = 256;
     int rows = (N + grid - 1) / grid;
     rows = (rows + 63) & ~63;
-    if (const char* e = getenv("GATRES_PROJ_ROWS")) rows = (atoi(e) + 63) & ~63;      // (tuning experiments)
+    if (const int pr = gatres_knobs()->proj_rows) rows = pr;      // (tuning experiments)
     if (rows < 64) rows = 64;
     hipLaunchKernelGGL((proj_bf16_kernel<K, M, H, EPI>), dim3((N + rows - 1) / rows), dim3(256), lds, st, X, Wm, OUT, N,
                        att_src, att_dst, a_src, a_dst, resid, relu_ref, rows);
@@ -546,7 +545,7 @@ int launch_proj(const float* X, const float* Wm, float* OUT, int N, const float*
                 float* a_src, float* a_dst, const float* resid, const float* relu_ref, hipStream_t st) {
   const int waves = (N + 15) / 16;
   if constexpr (K % 16 == 0 && M % 16 == 0 && K * M >= 64 * 128 && (M * (K + 4) + 2 * M) * 4 <= 160 * 1024) {
-    if (N >= 16384 && !getenv("GATRES_NO_PROJ_LDS")) {        // W staging per workgroup must amortise over many tiles
+    if (N >= 16384 && !gatres_knobs()->no_proj_lds) {        // W staging per workgroup must amortise over many tiles
       const int grid = 256;                                   // one persistent workgroup per CU
       int rows = (N + grid - 1) / grid;
       rows = (rows + 63) & ~63;
@@ -759,7 +758,7 @@ int launch_dw_bf16(const gatres_bf16* G, const gatres_bf16* X, float* slab, int 
   if constexpr (HC % 64 == 0 && K % 64 == 0) {
     // few slab rows asked for (the per-op driver does for wide models): rows x output blocks instead of rows only
     constexpr int OB = (HC / 64) * (K / 64);
-    if (num_slabs * OB <= 1024 && num_slabs <= 128 && !getenv("GATRES_DW_1D")) {
+    if (num_slabs * OB <= 1024 && num_slabs <= 128 && !gatres_knobs()->dw_1d) {
       int npg = (N + num_slabs - 1) / num_slabs;
       npg = (npg + 3) & ~3;
       ConvGradsCo co{};
@@ -878,7 +877,7 @@ extern "C" int gatres_t_proj_bwd_dw(const void* g_h, const void* x, float* slab_
   if (dtype == GATRES_DTYPE_BF16) {
 #define CASE_(K_, M_)                                                                                                  \
   if (K == K_ && HC == M_) {                                                                                           \
-    if (K_ >= 32 && M_ >= 32 && !getenv("GATRES_DW_FP32"))                                                             \
+    if (K_ >= 32 && M_ >= 32 && !gatres_knobs()->dw_fp32)                                                             \
       return launch_dw_bf16<M_, K_>((const gatres_bf16*)g_h, (const gatres_bf16*)x, slab_W, num_slabs, slab_stride,   \
                                     num_nodes, st);                                                                    \
     return launch_dw<M_, K_, gatres_bf16>((const gatres_bf16*)g_h, (const gatres_bf16*)x, slab_W, num_slabs,          \
@@ -907,12 +906,12 @@ extern "C" __attribute__((visibility("hidden"))) int gatres_proj_bwd_dw_with_con
       num_nodes <= 0 || w_slabs <= 0 || num_slabs <= 0)
     return GATRES_E_BADARG;
   if (!gatres_aligned16(g_h) || !gatres_aligned16(x)) return GATRES_E_BADARG;
-  if (H * C != HC || HC > 256 || getenv("GATRES_NO_CO_LAUNCH")) return GATRES_E_UNSUPPORTED;
+  if (H * C != HC || HC > 256 || gatres_knobs()->no_co_launch) return GATRES_E_UNSUPPORTED;
   int nps = (num_nodes + num_slabs - 1) / num_slabs;
   nps = (nps + 3) & ~3;                          // (nodes_per_slab of k_misc.hip: the slab boundaries of every other kernel)
   hipStream_t st = gatres_stream(stream);
   if (dtype == GATRES_DTYPE_BF16) {
-    if ((HC % 2) || (C % 2) || getenv("GATRES_DW_FP32")) return GATRES_E_UNSUPPORTED;
+    if ((HC % 2) || (C % 2) || gatres_knobs()->dw_fp32) return GATRES_E_UNSUPPORTED;
     ConvGradsCo cg{(const gatres_bf16*)h, g_a_src, g_a_dst, (const gatres_bf16*)g_out, slab_att_src, slab_att_dst, slab_bias,
                    (long long)slab_stride, H, C, nps};
 #define CASE_(K_, M_)                                                                                                 \
@@ -929,7 +928,7 @@ extern "C" __attribute__((visibility("hidden"))) int gatres_proj_bwd_dw_with_con
   if (dtype != GATRES_DTYPE_F32) return GATRES_E_UNSUPPORTED;
   // fp32: the per-wave weight-gradient kernel fills the chip by itself on large tables -- measured: gatres_small per-op
   // (12 k rows) 1.21 -> 1.04 ms/step with the co-launch, gatres_large on 50 k / 100 k rows 13.53 -> 13.54 / 25.0 -> 25.4
-  if (num_nodes > 32768 && !getenv("GATRES_CO_LAUNCH_ALWAYS")) return GATRES_E_UNSUPPORTED;
+  if (num_nodes > 32768 && !gatres_knobs()->co_launch_always) return GATRES_E_UNSUPPORTED;
   gatres_conv_grads_co<float> cf{(const float*)h, g_a_src, g_a_dst, (const float*)g_out, slab_att_src, slab_att_dst,
                                  slab_bias, (long long)slab_stride, H, C, nps};
 #define CASE_(K_, M_) \

@@ -1,0 +1,523 @@
+// Window form of the fused per-snapshot kernel: the headline path (gatres_small, 8 parts per snapshot).
+// Device code and commentary: k_fused_dev.h.
+#include "k_fused_dev.h"
+
+namespace {
+
+template <int NC, int THREADS>
+__global__ __launch_bounds__(THREADS) void gatres_window_kernel(const FusedArgs a) {
+  __shared__ __attribute__((aligned(16))) unsigned char lds_raw[LDS_BYTES];
+  float* ldsf = reinterpret_cast<float*>(lds_raw);
+  const Layout& L = a.L;
+  const int M = a.M;
+  {
+    const int F = ((a.num_segments + 7) / 8) * 8 * M;
+    if ((int)blockIdx.x >= F) {
+      consumer_main<NC, THREADS>(a, (int)blockIdx.x - F, ldsf);
+      return;
+    }
+  }
+  const int within = blockIdx.x % (8 * M);
+  const int seg = (blockIdx.x / (8 * M)) * 8 + (within & 7), part = within >> 3;
+  if (seg >= a.num_segments) return;
+  const int n0 = uni(a.seg_ptr[seg]), n = uni(a.seg_ptr[seg + 1]) - n0;
+  const int e0 = uni(a.rowptr[n0]), em0 = uni(a.m_rowptr[n0]), t0 = uni(a.t_rowptr[n0]), mt0 = uni(a.mt_rowptr[n0]);
+  const int tid = threadIdx.x;
+  Rows rw;
+  {
+    const int tiles = (n + 15) >> 4;
+    rw.lo = 16 * (int)((long long)tiles * part / M);
+    rw.hi = min(n, 16 * (int)((long long)tiles * (part + 1) / M));
+  }
+  const int lo = rw.lo, ow = rw.hi - rw.lo;
+  Group grp;
+  grp.flags = a.flags + (size_t)seg * 8 * FLAG_STRIDE; grp.M = M; grp.part = part; grp.err = a.err;
+  group_init<THREADS>(grp);
+  if (a.safe_sync) grp.local = false;
+  // granule exchange state of this part (epochs persist in word 2 of the part's flag line)
+  const XchLayout& XL = a.XL;
+  Xch xc;
+  xc.base = a.xch + (size_t)seg * (size_t)(L.xch_stride / 2);
+  xc.base_hb = xc.base + XL.hb;
+  xc.M = M; xc.part = part; xc.err = a.err; xc.local = grp.local;
+  xc.dead = GATRES_DIAG && (a.no_halo & 2) != 0;      // diagnostic (GATRES_XCH_NOWAIT=1, WRONG results): never wait for a partner -- what
+                                       // the launch would take if every hand-off were free
+  xc.ep = (unsigned)uni((int)__hip_atomic_load(grp.flags + part * FLAG_STRIDE + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+  // rows per lane group per trip: a part owns ~100 rows, one trip covers them in every stage but conv1's edge dots;
+  // more unrolling only costs registers and code (the block loop does not fit the instruction cache as it is)
+  constexpr int UF = 1, UB = 1;
+  // first wave that issues LDS-DMA inside MFMA stages: the waves below it own a 16-row tile there (dma_copy16)
+  const int dw0 = min((ow + 15) >> 4, THREADS / 64 - 4);
+  constexpr int WL_FLOATS = 2 * NC * (2 * NC + 4) + 4 * NC;
+  constexpr int WLB = (WL_FLOATS + 3) & ~3;
+  const float* P = a.params;
+  float* sc = a.scratch;
+  // a.keep_lds: the top of LDS carries the ReLU sign masks from the forward to the backward phase of this launch
+  unsigned char* lds_top = lds_raw + LDS_BYTES - (a.keep_lds ? win_keep_bytes(L.nb, ow) : 0);
+  unsigned long long* mo1 = a.keep_lds ? reinterpret_cast<unsigned long long*>(lds_top) - lo : nullptr;   // [b * ow + row]
+  unsigned* mxin = a.keep_lds ? reinterpret_cast<unsigned*>(lds_top + 8LL * L.nb * ow) - lo : nullptr;
+  [[maybe_unused]] int stamp_i = 0;
+  STAMP();
+  if (STAMPS_PTR && blockIdx.x == 0 && threadIdx.x == 0) STAMPS_PTR[a.stamp_cap] = clock64();
+
+  // ---- the window: own rows and every row adjacent to them (in- and out-neighbours), as one contiguous range
+  int wlo, whi;
+  {
+    int* mm = reinterpret_cast<int*>(lds_raw);
+    if (tid == 0) { mm[0] = lo; mm[1] = rw.hi; }
+    __syncthreads();
+    int vmin = lo, vmax = rw.hi;
+    for (int e = a.rowptr[n0 + lo] + tid; e < a.rowptr[n0 + rw.hi]; e += THREADS) {
+      const int j = a.col[e] - n0; vmin = min(vmin, j); vmax = max(vmax, j + 1);
+    }
+    for (int t = a.t_rowptr[n0 + lo] + tid; t < a.t_rowptr[n0 + rw.hi]; t += THREADS) {
+      const int j = a.t_dst[t] - n0; vmin = min(vmin, j); vmax = max(vmax, j + 1);
+    }
+    for (int e = a.m_rowptr[n0 + lo] + tid; e < a.m_rowptr[n0 + rw.hi]; e += THREADS) {
+      const int j = a.m_col[e] - n0; vmin = min(vmin, j); vmax = max(vmax, j + 1);
+    }
+    for (int t = a.mt_rowptr[n0 + lo] + tid; t < a.mt_rowptr[n0 + rw.hi]; t += THREADS) {
+      const int j = a.mt_dst[t] - n0; vmin = min(vmin, j); vmax = max(vmax, j + 1);
+    }
+    if (vmin < lo) atomicMin(&mm[0], vmin);
+    if (vmax > rw.hi) atomicMax(&mm[1], vmax);
+    __syncthreads();
+    wlo = uni(mm[0]); whi = uni(mm[1]);
+    __syncthreads();
+  }
+  const int wr = whi - wlo;
+  // edge ranges (local ids = position - e0): own in-edges [elo, ehi), window in-edges [ewlo, ewhi)
+  const int elo = uni(a.rowptr[n0 + lo]) - e0, ehi = uni(a.rowptr[n0 + rw.hi]) - e0, oeg = ehi - elo;
+  const int ewlo = uni(a.rowptr[n0 + wlo]) - e0, ewhi = uni(a.rowptr[n0 + whi]) - e0, weg = ewhi - ewlo;
+  const int melo = uni(a.m_rowptr[n0 + lo]) - em0, oem = uni(a.m_rowptr[n0 + rw.hi]) - em0 - melo;
+  const int tlo = uni(a.t_rowptr[n0 + lo]) - t0, otg = uni(a.t_rowptr[n0 + rw.hi]) - t0 - tlo;
+  const int mtlo = uni(a.mt_rowptr[n0 + lo]) - mt0, otm = uni(a.mt_rowptr[n0 + rw.hi]) - mt0 - mtlo;
+
+  const SegLayout& SL = a.SL;
+  float* segbase = a.saved + (int64_t)seg * SL.total;                 // training only: saved is never null here
+
+  if (a.phases & GATRES_PHASE_FORWARD) {
+    // LDS: [hA wr x 2NC | hB wr x NC | sa wr x 2 | sd own x 2 | xA own x NC | xB own x 2NC | W slot A | W slot B] topology
+    float* hAw = ldsf;
+    float* hBw = hAw + (size_t)wr * 2 * NC;
+    float* saw = hBw + (size_t)wr * NC;
+    float* sdo = saw + (size_t)((wr * 2 + 3) & ~3);      // (every table starts 16-byte aligned: ds_read_b128)
+    float* xAo = sdo + (size_t)((ow * 2 + 3) & ~3);
+    float* xBo = xAo + (size_t)ow * NC;
+    float* wlA = reinterpret_cast<float*>(lds_raw + ((reinterpret_cast<unsigned char*>(xBo + (size_t)ow * 2 * NC) - lds_raw + 15) & ~15));
+    float* wlB = wlA + WLB;
+    u16* tp = reinterpret_cast<u16*>(wlB + WLB);
+    u16* rpo = tp;             tp += even(ow + 1);
+    u16* colo = tp;            tp += even(oeg);
+    u16* mrpo = tp;            tp += even(ow + 1);
+    u16* mcolo = tp;           tp += even(oem);
+    int* hcounter = reinterpret_cast<int*>(tp);
+    u16* hlist = tp + 2;                 // import list: remote sources of own in-edges (one entry per edge)
+    const int hcap = max(0, (int)((lds_top - reinterpret_cast<unsigned char*>(hlist)) / 4));
+    u16* elist = hlist + hcap;           // export list: own rows some partner's row has an in-edge from
+    // index-shifted views: absolute local row / relative own-edge indices work unchanged in the stage functions
+    float* hA = hAw - wlo * 2 * NC;
+    float* hB = hBw - wlo * NC;
+    float* sa2 = saw - wlo * 2;  float* sa1 = saw - wlo;                 // a_src tables (H = 2 / H = 1)
+    float* sd2 = sdo - lo * 2;   float* sd1 = sdo - lo;
+    float* xA = xAo - lo * NC;
+    float* xB = xBo - lo * 2 * NC;
+    const u16* rp = rpo - lo;  const u16* mrp = mrpo - lo;
+    copy_rowptr16<THREADS>(rpo, a.rowptr, n0 + lo, ow, e0 + elo);
+    copy_idx16<THREADS>(colo, a.col, e0 + elo, oeg, n0);
+    copy_rowptr16<THREADS>(mrpo, a.m_rowptr, n0 + lo, ow, em0 + melo);
+    copy_idx16<THREADS>(mcolo, a.m_col, em0 + melo, oem, n0);
+    float* xcur = segbase + SL.xin;
+    if (L.nb > 0) {
+      const float* pb0 = P + L.p_block0;
+      w_prefetch<NC, 2 * NC, EPI_ATT, THREADS>(wlA, pb0 + L.c1_W, pb0 + L.c1_as, pb0 + L.c1_ad, 0);
+    }
+    {  // lin0 (+ the caller-side x[mask] = 0)
+      const float* w = P + L.p_lin0_w;
+      const float* b = P + L.p_lin0_b;
+      for (int idx = rw.lo * (NC / 4) + tid; idx < rw.hi * (NC / 4); idx += THREADS) {
+        const int r = idx / (NC / 4), c0 = (idx % (NC / 4)) * 4;
+        const int node = ext_id(a.perm, n0 + r);
+        const float xv = (a.mask && a.mask[node]) ? 0.f : a.x[node];
+        const float4 wv = ld4(w + c0), bv = ld4(b + c0);
+        float4 o;
+        o.x = xv * wv.x + bv.x; o.y = xv * wv.y + bv.y; o.z = xv * wv.z + bv.z; o.w = xv * wv.w + bv.w;
+        st4(xcur + (unsigned)(r * NC + c0), o);
+        st4(xA + (unsigned)(r * NC + c0), o);
+      }
+    }
+    __syncthreads();
+    int hcnt = uni(build_halo<THREADS>(rp, colo, nullptr, rw, hlist, nullptr, hcap, hcounter));
+    int ecnt = uni(build_export_rows<THREADS>(a.t_rowptr, a.t_dst, n0, rw, elist, hcap, hcounter));
+    if (hcnt > hcap || ecnt > hcap) {      // (the host sizes the lists from gatres_graph_t.halo: cannot happen with a sane plan)
+      if (tid == 0) *a.err = 1;
+      hcnt = min(hcnt, hcap); ecnt = min(ecnt, hcap);
+    }
+    STAMP();
+    for (int b = 0; b < L.nb; ++b) {
+      float* base = segbase + (int64_t)b * SL.bstride;
+      float* xnext = segbase + (int64_t)(b + 1) * SL.bstride + SL.xin;
+      const float* pb = P + L.p_block0 + (int64_t)b * L.p_block_stride;
+      // LDS-DMA rides on the MFMA stages (the longest ones; a DMA has to land before its host stage's closing barrier):
+      // W2 of this block while proj1 runs, W1 of the next block while proj2 runs
+      w_prefetch<2 * NC, NC, EPI_ATT, THREADS>(wlB, pb + L.c2_W, pb + L.c2_as, pb + L.c2_ad, dw0);
+      seg_proj<NC, 2 * NC, 2, EPI_ATT, THREADS, true, true>(rw, xA, 0, pb + L.c1_W, base + SL.h1, 0, hA, 0, pb + L.c1_as,
+                                                        pb + L.c1_ad, base + SL.as1, base + SL.ad1, 0, sa2, sd2,
+                                                        nullptr, 0, nullptr, 0, wlA);
+      lds_barrier();                              // own rows of h1 / a_src are in LDS; the saved copies drain meanwhile
+      ++xc.ep;                                    // exchange F1: the gathers below read h1 / a_src of neighbour rows
+      xch_export<2 * NC, THREADS>(xc, elist, ecnt, hA, xc.base + XL.f1h);
+      xch_export<2, THREADS>(xc, elist, ecnt, sa2, xc.base + XL.f1a);
+      xch_import<2 * NC, THREADS>(xc, hlist, hcnt, xc.base + XL.f1h, hA);
+      xch_import<2, THREADS>(xc, hlist, hcnt, xc.base + XL.f1a, sa2);
+      xch_heartbeat<THREADS>(xc, 0);
+      lds_barrier();
+      STAMP();
+      // K2 conv1: alpha -> HBM + the h2 window's LDS (dead now), then the gather (o1 -> HBM + the x buffer of proj2).
+      // (Coefficients computed INSIDE the exchange -- softmax threads reading a partner's a_src straight from its granule
+      // while the other waves sweep h1 in, one barrier less -- was measured: 545 -> 557 us per launch, and 28 KB of code.)
+      if (__builtin_expect(2 * oeg <= wr * NC, 1)) {
+        seg_softmax<2, true, THREADS>(rw, rp, colo, sa2, sd2, 0, base + SL.al1, elo, hBw);
+        lds_barrier();
+        seg_gather<true, 2, NC, THREADS, UF>(rw, rp, colo, hA, 0, hBw, 0, pb + L.c1_b, base + SL.o1, 0, xB, 0,
+                                             mo1 ? mo1 + b * ow : nullptr);
+      } else {
+        seg_softmax<2, false, THREADS>(rw, rp, colo, sa2, sd2, 0, base + SL.al1, elo, nullptr);
+        __syncthreads();
+        seg_gather<true, 2, NC, THREADS, UF>(rw, rp, colo, hA, 0, base + SL.al1, elo, pb + L.c1_b, base + SL.o1, 0, xB, 0,
+                                             mo1 ? mo1 + b * ow : nullptr);
+      }
+      lds_barrier();
+      STAMP();
+      if (b + 1 < L.nb) {
+        const float* pn = pb + L.p_block_stride;
+        w_prefetch<NC, 2 * NC, EPI_ATT, THREADS>(wlA, pn + L.c1_W, pn + L.c1_as, pn + L.c1_ad, dw0);
+      }
+      seg_proj<2 * NC, NC, 1, EPI_ATT, THREADS, true, true>(rw, xB, 0, pb + L.c2_W, base + SL.h2, 0, hB, 0, pb + L.c2_as,
+                                                        pb + L.c2_ad, base + SL.as2, base + SL.ad2, 0, sa1, sd1,
+                                                        nullptr, 0, nullptr, 0, wlB);
+      lds_barrier();
+      ++xc.ep;                                    // exchange F2
+      xch_export<NC, THREADS>(xc, elist, ecnt, hB, xc.base + XL.f2h);
+      xch_export<1, THREADS>(xc, elist, ecnt, sa1, xc.base + XL.f2a);
+      xch_import<NC, THREADS>(xc, hlist, hcnt, xc.base + XL.f2h, hB);
+      xch_import<1, THREADS>(xc, hlist, hcnt, xc.base + XL.f2a, sa1);
+      xch_heartbeat<THREADS>(xc, 1);
+      lds_barrier();
+      STAMP();
+      // K2 conv2: alpha's LDS table in the upper half of the h1 window, y2 in the lower half
+      float* y2T = hAw - wlo * NC;
+      if (__builtin_expect(oeg <= wr * NC, 1)) {
+        float* al2L = hAw + (size_t)wr * NC;
+        seg_softmax<1, true, THREADS>(rw, rp, colo, sa1, sd1, 0, base + SL.al2, elo, al2L);
+        lds_barrier();
+        seg_gather<false, 1, NC, THREADS, UF>(rw, rp, colo, hB, 0, al2L, 0, pb + L.c2_b, y2T, 0);
+      } else {
+        seg_softmax<1, false, THREADS>(rw, rp, colo, sa1, sd1, 0, base + SL.al2, elo, nullptr);
+        __syncthreads();
+        seg_gather<false, 1, NC, THREADS, UF>(rw, rp, colo, hB, 0, base + SL.al2, elo, pb + L.c2_b, y2T, 0);
+      }
+      lds_barrier();
+      ++xc.ep;                                    // exchange F3: K3 averages y2 over neighbour rows
+      xch_export<NC, THREADS>(xc, elist, ecnt, y2T, xc.base + XL.f3);
+      xch_import<NC, THREADS>(xc, hlist, hcnt, xc.base + XL.f3, y2T);
+      xch_heartbeat<THREADS>(xc, 2);
+      lds_barrier();
+      STAMP();
+      // K3: residual from the x buffer, result back into it (and to HBM: saved xin of the next block)
+      seg_mean_fwd<NC, THREADS, UF>(rw, oem, mrp, mcolo, y2T, 0, xA, 0, xnext, 0, xA, 0,
+                                    (mxin && b + 1 < L.nb) ? mxin + (b + 1) * ow : nullptr);
+      lds_barrier();
+      STAMP();
+      xcur = xnext;
+    }
+    {  // lin1
+      constexpr int G = NC / 4;
+      const float4 wv = ld4(P + L.p_lin1_w + (tid % G) * 4);
+      const float bias = P[L.p_lin1_b];
+      const int rounds = (rw.hi - rw.lo + THREADS / G - 1) / (THREADS / G);
+      for (int it = 0; it < rounds; ++it) {
+        int r = rw.lo + it * (THREADS / G) + tid / G;
+        const bool valid = r < rw.hi;
+        if (!valid) r = rw.hi - 1;
+        const float4 xv = ld4(xA + (unsigned)(r * NC + (tid % G) * 4));
+        float d = xv.x * wv.x;
+        d = fmaf(xv.y, wv.y, d); d = fmaf(xv.z, wv.z, d); d = fmaf(xv.w, wv.w, d);
+        for (int off = G >> 1; off > 0; off >>= 1) d += __shfl_xor(d, off);
+        if (valid && (tid % G) == 0) a.out[ext_id(a.perm, n0 + r)] = d + bias;
+      }
+    }
+    __syncthreads();
+    STAMP();
+  }
+
+  if (a.phases & PH_LOSS) {
+    float cnt = 0.f;
+    for (int i = tid; i < a.N; i += THREADS) cnt += a.mask[i] ? 1.f : 0.f;
+    const float Mn = block_sum<THREADS>(cnt, ldsf);
+    float part_sum = 0.f;
+    for (int r = rw.lo + tid; r < rw.hi; r += THREADS) {
+      const int node = ext_id(a.perm, n0 + r);
+      if (a.mask[node]) {
+        const float d = a.out[node] - a.y[node];
+        part_sum = fmaf(d, d, part_sum);
+      }
+    }
+    part_sum = block_sum<THREADS>(part_sum, ldsf);
+    if (tid == 0) {
+      a.loss_part[seg * M + part] = part_sum;
+      if (seg == 0 && part == 0) a.loss_part[a.num_segments * M] = Mn;
+    }
+    const float scale = Mn > 0.f ? 2.f / Mn : 0.f;
+    for (int r = rw.lo + tid; r < rw.hi; r += THREADS) {
+      const int node = ext_id(a.perm, n0 + r);
+      a.g_out[node] = a.mask[node] ? (a.out[node] - a.y[node]) * scale : 0.f;
+    }
+    __syncthreads();
+    STAMP();
+  }
+
+  if (a.phases & GATRES_PHASE_BACKWARD) {
+    // LDS: red | RA wr x 2NC | ge weg x 2 | gad own x 2 | hT wr x 2NC | asT wr x 2 | adT own x 2 | alT weg x 2 |
+    //      xG own x 2NC | W slot A | W slot B | topology | halo lists
+    float* red = ldsf;
+    float* RAw = red + 3 * THREADS;
+    float* gew = RAw + (size_t)wr * 2 * NC;
+    float* gado = gew + 2 * (size_t)even(weg);
+    float* hTw = gado + (size_t)((ow * 2 + 3) & ~3);
+    float* asTw = hTw + (size_t)wr * 2 * NC;
+    float* adTo = asTw + (size_t)((wr * 2 + 3) & ~3);
+    float* alTw = adTo + (size_t)((ow * 2 + 3) & ~3);
+    float* xGo = alTw + 2 * (size_t)even(weg);
+    float* gko = xGo + (size_t)ow * 2 * NC;                              // a.keep_lds: g_pre of the own rows (dX1's residual term)
+    float* wlA = reinterpret_cast<float*>(lds_raw + ((reinterpret_cast<unsigned char*>(gko + (a.keep_lds ? (size_t)ow * NC : 0)) - lds_raw + 15) & ~15));
+    float* wlB = wlA + WLB;
+    u16* tp = reinterpret_cast<u16*>(wlB + WLB);
+    u16* rpo = tp;             tp += even(ow + 1);
+    u16* colo = tp;            tp += even(oeg);
+    u16* trpo = tp;            tp += even(ow + 1);
+    u16* teido = tp;           tp += even(otg);
+    u16* tdsto = tp;           tp += even(otg);
+    u16* mrpw = tp;            tp += even(wr + 1);
+    u16* mtrpo = tp;           tp += even(ow + 1);
+    u16* mtdsto = tp;          tp += even(otm);
+    int* hcounter = reinterpret_cast<int*>(tp);
+    u16* hrow = tp + 2;                  // import lists: remote destinations (+ edge ids) of own out-edges
+    const int hcap = max(0, (int)((lds_top - reinterpret_cast<unsigned char*>(hrow)) / 8));
+    u16* hedge = hrow + hcap;
+    u16* erow = hedge + hcap;            // export lists: own rows with an in-edge from a partner's row, and those in-edges
+    u16* eedge = erow + hcap;
+    __syncthreads();           // forward's LDS contents are dead from here
+    copy_rowptr16<THREADS>(rpo, a.rowptr, n0 + lo, ow, e0 + elo);
+    copy_idx16<THREADS>(colo, a.col, e0 + elo, oeg, n0);
+    copy_rowptr16<THREADS>(trpo, a.t_rowptr, n0 + lo, ow, t0 + tlo);
+    copy_idx16<THREADS>(teido, a.t_eid, t0 + tlo, otg, e0);
+    copy_idx16<THREADS>(tdsto, a.t_dst, t0 + tlo, otg, n0);
+    copy_rowptr16<THREADS>(mrpw, a.m_rowptr, n0 + wlo, wr, a.m_rowptr[n0 + wlo]);
+    copy_rowptr16<THREADS>(mtrpo, a.mt_rowptr, n0 + lo, ow, mt0 + mtlo);
+    copy_idx16<THREADS>(mtdsto, a.mt_dst, mt0 + mtlo, otm, n0);
+    const u16* rp = rpo - lo;  const u16* trp = trpo - lo;  const u16* mrp = mrpw - wlo;  const u16* mtrp = mtrpo - lo;
+    float* RA = RAw - wlo * 2 * NC;              // [row][2NC] view: g_out1
+    float* gpT = RAw - wlo * NC;                 // [row][NC] views of the lower / upper half: g_pre, g_y2
+    float* gy2T = RAw + (size_t)wr * NC - wlo * NC;
+    float* ge2 = gew - ewlo;      float* ge1 = gew - ewlo * 2;          // by absolute local edge id
+    float* gad2 = gado - lo;      float* gad1 = gado - lo * 2;
+    float* hT2 = hTw - wlo * NC;  float* hT1 = hTw - wlo * 2 * NC;
+    float* asT2 = asTw - wlo;     float* asT1 = asTw - wlo * 2;
+    float* adT2 = adTo - lo;      float* adT1 = adTo - lo * 2;
+    float* alT2 = alTw - ewlo;    float* alT1 = alTw - ewlo * 2;
+    float* xG2 = xGo - lo * NC;   float* xG1 = xGo - lo * 2 * NC;
+    float* gkeep = a.keep_lds ? gko - lo * NC : nullptr;
+
+    float* gp_cur = sc + L.sc_gpa;
+    float* gp_nxt = sc + L.sc_gpb;
+    constexpr bool pub = true;           // (the window kernel only runs split segments)
+    float* slab = pub ? a.part_slabs + ((int64_t)seg * M + part) * L.slab_stride
+                      : a.slabs + (int64_t)seg * L.slab_stride;
+    const int64_t w = 2LL * NC * NC;
+    const float* xfinal = segbase + (int64_t)L.nb * SL.bstride + SL.xin;
+    // LDS-DMA of saved tables (independent of the backward chain) and transposed weights always rides on an MFMA
+    // stage or, for the first block, on this prologue: conv2 tables + W2^T of block b during dX1 of block b + 1,
+    // conv1 tables + W1^T of block b during dX2 of block b.
+    auto dma_conv2 = [&](int blk, int w0) {
+      const float* bs = segbase + (int64_t)blk * SL.bstride;
+      dma_copy16<THREADS>(hTw, bs + SL.h2 + (size_t)wlo * NC, wr * NC, w0);
+      dma_copy4<THREADS>(asTw, bs + SL.as2 + wlo, wr, w0);
+      dma_copy4<THREADS>(adTo, bs + SL.ad2 + lo, ow, w0);
+      dma_copy4<THREADS>(alTw, bs + SL.al2 + ewlo, weg, w0);
+      w_prefetch<NC, 2 * NC, EPI_RESID_MASK, THREADS>(wlA, a.wt + (int64_t)blk * 2 * w + w, nullptr, nullptr, w0);
+    };
+    if (L.nb > 0) dma_conv2(L.nb - 1, 0);
+    seg_lin1_bwd<NC, THREADS>(rw, n0, a.perm, a.g_out, xfinal, P + L.p_lin1_w, gp_cur, gpT, slab + L.p_lin1_w,
+                              slab + L.p_lin1_b, L.nb > 0 ? 1 : 0, red, gkeep);
+    int hcnt = uni(build_halo<THREADS>(trp, tdsto, teido, rw, hrow, hedge, hcap, hcounter));
+    int ercnt = uni(build_export_rows<THREADS>(a.rowptr, a.col, n0, rw, erow, hcap, hcounter));
+    if (tid == 0) *hcounter = 0;
+    __syncthreads();
+    for (int k = tid; k < oeg; k += THREADS) {                 // own in-edges whose source is a partner's row
+      const int j = colo[k];
+      if (j < lo || j >= rw.hi) {
+        const int pos = atomicAdd(hcounter, 1);
+        if (pos < hcap) eedge[pos] = (u16)(elo + k);
+      }
+    }
+    __syncthreads();
+    int eecnt = uni(*hcounter);
+    if (hcnt > hcap || ercnt > hcap || eecnt > hcap) {
+      if (tid == 0) *a.err = 1;
+      hcnt = min(hcnt, hcap); ercnt = min(ercnt, hcap); eecnt = min(eecnt, hcap);
+    }
+    STAMP();
+    for (int b = L.nb - 1; b >= 0; --b) {
+      const float* base = segbase + (int64_t)b * SL.bstride;
+      const int64_t po = L.p_block0 + (int64_t)b * L.p_block_stride;
+      const float* pb = P + po;
+      float* sb = slab + po;
+      const float* wt1 = a.wt + (int64_t)b * 2 * w;
+      const float* wt2 = wt1 + w;
+      [[maybe_unused]] const bool xs_on = STAMPS_PTR && a.stamp_cap >= 4096 && seg == 0 && b == L.nb / 2;
+      [[maybe_unused]] int xs_i = 0;
+      XSTAMP();
+      lds_barrier();                             // own rows of g_pre are in LDS (lin1 backward / the previous dX1)
+      XSTAMP();
+      ++xc.ep;                                   // exchange B1: K3 backward gathers g_pre of neighbour rows
+      xch_export<NC, THREADS>(xc, erow, ercnt, gpT, xc.base + XL.b1);
+      XSTAMP();
+      xch_import<NC, THREADS>(xc, hrow, hcnt, xc.base + XL.b1, gpT);
+      XSTAMP();
+      xch_heartbeat<THREADS>(xc, 3);
+      XSTAMP();
+      lds_barrier();
+      XSTAMP();
+      publish_items<THREADS>(a, seg, part, 2 * (L.nb - 1 - b), grp.local, false);      // the blocks above are kept
+      seg_mean_bwd<NC, THREADS, UB>(rw, otm, mrp, mtrp, mtdsto, gpT, 0, gy2T, 0);
+      lds_barrier();
+      XSTAMP();
+      STAMP();
+      float* keep = sc + L.sc_keep + (int64_t)b * L.keep_stride;
+      float* gh = keep + L.k_gh1;
+      float* gh2 = keep + L.k_gh2;
+      seg_edge_dots<1, NC, THREADS, 1>(rw, 0, rp, colo, gy2T, 0, hT2, ge2 + elo, 0);
+      lds_barrier();
+      XSTAMP();
+      seg_bias_part<NC, THREADS>(rw, gy2T, 0, red);
+      seg_softmax_bwd<1, THREADS>(rw, 0, 0, rp, colo, alT2 + elo, asT2, adT2, ge2 + elo, 0, gad2, 0, nullptr, 0, nullptr,
+                                  0);
+      lds_barrier();
+      XSTAMP();
+      ++xc.ep;                                   // exchange B2: the source-major stage reads g_y2 / g_e of neighbour rows
+      xch_export<NC, THREADS>(xc, erow, ercnt, gy2T, xc.base + XL.b2y);
+      xch_export<1, THREADS>(xc, eedge, eecnt, ge2, xc.base + XL.b2e);
+      XSTAMP();
+      xch_import<NC, THREADS>(xc, hrow, hcnt, xc.base + XL.b2y, gy2T);
+      xch_import<1, THREADS>(xc, hedge, hcnt, xc.base + XL.b2e, ge2);
+      XSTAMP();
+      xch_heartbeat<THREADS>(xc, 4);
+      XSTAMP();
+      lds_barrier();
+      XSTAMP();
+      STAMP();
+      seg_bias_finish<NC, THREADS>(red, sb + L.c2_b);
+      seg_agg_bwd_src<1, NC, THREADS, UB>(rw, 0, trp, teido, tdsto, gy2T, 0, alT2, ge2, 0, gad2, 0, pb + L.c2_as,
+                                      pb + L.c2_ad, gh2, n0, keep + L.k_gas2, keep + L.k_gad2, xG2, 0);
+      lds_barrier();           // g_y2 (RA) and the conv2 tables are dead
+      XSTAMP();
+      STAMP();
+      // LDS-DMA of this block's conv1 tables and W1^T while the matrix cores run dX2
+      w_prefetch<2 * NC, NC, EPI_RESID_MASK, THREADS>(wlB, wt1, nullptr, nullptr, dw0);
+      dma_copy16<THREADS>(hTw, base + SL.h1 + (size_t)wlo * 2 * NC, wr * 2 * NC, dw0);
+      dma_copy4<THREADS>(asTw, base + SL.as1 + wlo * 2, wr * 2, dw0);
+      dma_copy4<THREADS>(adTo, base + SL.ad1 + lo * 2, ow * 2, dw0);
+      dma_copy4<THREADS>(alTw, base + SL.al1 + ewlo * 2, weg * 2, dw0);
+      seg_proj<NC, 2 * NC, 1, EPI_RESID_MASK, THREADS, true, true>(rw, xG2, 0, wt2, RA, 0, nullptr, 0,
+                                                               nullptr, nullptr, nullptr, nullptr, 0, nullptr, nullptr,
+                                                               nullptr, 0, (GATRES_DIAG && (a.no_halo & 4)) ? nullptr : base + SL.o1, 0, wlA,
+                                                               nullptr, nullptr, mo1 ? mo1 + b * ow : nullptr, nullptr);
+      __syncthreads();
+      XSTAMP();
+      STAMP();
+      seg_edge_dots<2, NC, THREADS, 1>(rw, 0, rp, colo, RA, 0, hT1, ge1 + elo * 2, 0);
+      lds_barrier();
+      XSTAMP();
+      seg_bias_part<2 * NC, THREADS>(rw, RA, 0, red);
+      seg_softmax_bwd<2, THREADS>(rw, 0, 0, rp, colo, alT1 + elo * 2, asT1, adT1, ge1 + elo * 2, 0, gad1, 0, nullptr, 0,
+                                  nullptr, 0);
+      lds_barrier();
+      XSTAMP();
+      ++xc.ep;                                   // exchange B3
+      xch_export<2 * NC, THREADS>(xc, erow, ercnt, RA, xc.base + XL.b3o);
+      xch_export<2, THREADS>(xc, eedge, eecnt, ge1, xc.base + XL.b3e);
+      XSTAMP();
+      xch_import<2 * NC, THREADS>(xc, hrow, hcnt, xc.base + XL.b3o, RA);
+      xch_import<2, THREADS>(xc, hedge, hcnt, xc.base + XL.b3e, ge1);
+      XSTAMP();
+      xch_heartbeat<THREADS>(xc, 5);
+      XSTAMP();
+      lds_barrier();
+      XSTAMP();
+      publish_items<THREADS>(a, seg, part, 2 * (L.nb - 1 - b) + 1, grp.local, false);      // conv2 tables complete
+      STAMP();
+      seg_bias_finish<2 * NC, THREADS>(red, sb + L.c1_b);
+      seg_agg_bwd_src<2, NC, THREADS, UB>(rw, 0, trp, teido, tdsto, RA, 0, alT1, ge1, 0, gad1, 0, pb + L.c1_as,
+                                      pb + L.c1_ad, gh, n0, keep + L.k_gas1, keep + L.k_gad1, xG1, 0);
+      lds_barrier();
+      XSTAMP();
+      STAMP();
+      if (b > 0) dma_conv2(b - 1, dw0);
+      seg_proj<2 * NC, NC, 1, EPI_RESID_MASK, THREADS, true, true>(rw, xG1, 0, wt1, gp_nxt, n0, gpT, 0, nullptr, nullptr,
+                                                               nullptr, nullptr, 0, nullptr, nullptr,
+                                                               (GATRES_DIAG && (a.no_halo & 4)) ? nullptr : gp_cur, n0,
+                                                               (b > 0 && !(GATRES_DIAG && (a.no_halo & 4))) ? base + SL.xin : nullptr, 0, wlB,
+                                                               gkeep, gkeep, nullptr, (mxin && b > 0) ? mxin + b * ow : nullptr);
+      XSTAMP();
+      STAMP();
+      float* t = gp_cur; gp_cur = gp_nxt; gp_nxt = t;
+    }
+    group_sync<THREADS>(grp);
+    publish_items<THREADS>(a, seg, part, 2 * L.nb, grp.local || !pub, !pub);
+    seg_lin0_bwd<NC, THREADS>(rw, n0, a.perm, gp_cur, a.x, a.mask, slab + L.p_lin0_w, slab + L.p_lin0_b, red);
+    if (pub && a.C > 0) {
+      group_sync<THREADS>(grp);
+      publish_items<THREADS>(a, seg, part, 2 * L.nb + 1, grp.local, true);
+    }
+    if (a.g_x) {
+      constexpr int G = NC / 4;
+      const float4 wv = ld4(P + L.p_lin0_w + (tid % G) * 4);
+      const int rounds = (rw.hi - rw.lo + THREADS / G - 1) / (THREADS / G);
+      for (int it = 0; it < rounds; ++it) {
+        int r = rw.lo + it * (THREADS / G) + tid / G;
+        const bool valid = r < rw.hi;
+        if (!valid) r = rw.hi - 1;
+        const float4 xv = ld4(gp_cur + ((size_t)n0 + r) * NC + (tid % G) * 4);
+        float d = xv.x * wv.x;
+        d = fmaf(xv.y, wv.y, d); d = fmaf(xv.z, wv.z, d); d = fmaf(xv.w, wv.w, d);
+        for (int off = G >> 1; off > 0; off >>= 1) d += __shfl_xor(d, off);
+        if (valid && (tid % G) == 0) a.g_x[ext_id(a.perm, n0 + r)] = d;
+      }
+    }
+  }
+  if (tid == 0) __hip_atomic_store(grp.flags + part * FLAG_STRIDE + 2, xc.ep, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (M > 1 && tid == 0 && *a.err) {
+    if ((a.phases & GATRES_PHASE_FORWARD) && a.out) a.out[n0] = NAN;
+    if (a.phases & GATRES_PHASE_BACKWARD) a.slabs[(int64_t)seg * L.slab_stride + L.p_lin1_b] = NAN;
+  }
+  if (STAMPS_PTR && blockIdx.x == 0 && threadIdx.x == 0) {
+    STAMPS_PTR[a.stamp_cap + 1] = clock64();
+    STAMPS_PTR[a.stamp_cap + 2] = wall_clock64();
+  }
+}
+
+}  // namespace
+
+extern "C" __attribute__((visibility("hidden"))) int gatres_fused_launch_window(const void* args, int nc, unsigned grid, void* stream) {
+  const FusedArgs& a = *static_cast<const FusedArgs*>(args);
+  hipStream_t st = gatres_stream(stream);
+  switch (nc) {
+    case 4: hipLaunchKernelGGL((gatres_window_kernel<4, 1024>), dim3(grid), dim3(1024), 0, st, a); break;
+    case 8: hipLaunchKernelGGL((gatres_window_kernel<8, 1024>), dim3(grid), dim3(1024), 0, st, a); break;
+    case 16: hipLaunchKernelGGL((gatres_window_kernel<16, 1024>), dim3(grid), dim3(1024), 0, st, a); break;
+    case 32: hipLaunchKernelGGL((gatres_window_kernel<32, 1024>), dim3(grid), dim3(1024), 0, st, a); break;
+    default: return GATRES_E_UNSUPPORTED;
+  }
+  return gatres_launch_status();
+}

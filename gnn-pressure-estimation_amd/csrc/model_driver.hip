@@ -7,7 +7,6 @@
 //       -> K3 mean(y2)+xin, ReLU -> xin of block b+1
 #include "gatres_common.h"
 #include "gatres_layout.h"
-#include "gatres_typed.h"
 
 namespace {
 
@@ -71,7 +70,7 @@ extern "C" int gatres_model_forward_per_op(const gatres_model_t* m, const gatres
   const int N = g->num_nodes, nc = L.nc, dt = m->act_dtype;
   if (dt != GATRES_DTYPE_F32 && (dt != GATRES_DTYPE_BF16 || nc < 32)) return GATRES_E_UNSUPPORTED;
   // Activation tensors keep their fp32-sized slots in either mode (a bf16 tensor fills the first half), so every offset
-  // below is mode-independent; the typed launchers (gatres_typed.h) reinterpret the pointers.
+  // below is mode-independent; the typed launchers (gatres_t_*) reinterpret the pointers.
   float* y2 = scratch + L.sc_y2;
   float* xa = scratch + L.sc_xa;
   float* xb = scratch + L.sc_xb;
@@ -137,9 +136,9 @@ extern "C" __attribute__((visibility("hidden"))) int gatres_reduce_slabs_regions
 // Slab rows the GATConv weight gradients occupy: the bf16 dW kernel of wide models forms two-dimensional partials (64 rows of
 // 64 x 64 blocks instead of one whole [2nc, nc] matrix per workgroup): 4x less slab traffic in dW and in the final sum
 static int dw_slab_rows(const gatres_model_t* m, const Layout& L) {
-  if (m->act_dtype == GATRES_DTYPE_BF16 && L.nc == 128 && L.num_slabs > 64 && !getenv("GATRES_DW_1D")) {
-    if (const char* e = getenv("GATRES_DW_SLAB_ROWS")) {           // (tuning experiments: 32 / 64 / 128 row groups)
-      const int v = atoi(e);
+  if (m->act_dtype == GATRES_DTYPE_BF16 && L.nc == 128 && L.num_slabs > 64 && !gatres_knobs()->dw_1d) {
+    {                                                              // (tuning experiments: 32 / 64 / 128 row groups)
+      const int v = gatres_knobs()->dw_slab_rows;
       if (v >= 8 && v <= 128 && v % 8 == 0 && v < L.num_slabs) return v;
     }
     return 64;

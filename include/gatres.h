@@ -117,6 +117,10 @@ int gatres_graph_reorder_host(const int64_t* edge_index_host, int64_t num_edges,
  * Returns the number of bytes written to dst, or GATRES_E_BADARG on malformed input / a dst that is too small. */
 int64_t gatres_lz4_decompress_host(const uint8_t* src, int64_t src_len, uint8_t* dst, int64_t dst_cap);
 
+/* The library reads its GATRES_* tuning / fallback switches from the environment once, at first use, never on a launch
+ * path.  A process that changes them afterwards calls this to have them read again.  Always returns 0. */
+int gatres_knobs_reload(void);
+
 /* 64-bit content hash of an int64 [2,E] DEVICE edge_index (for plan caching); hash_out: device uint64[1],
  * must be zeroed by the caller on the same stream before the call. */
 int gatres_edge_index_hash(const int64_t* edge_index, int64_t num_edges, uint64_t* hash_out, void* stream);

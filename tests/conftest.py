@@ -27,3 +27,32 @@ def oracle():
 @pytest.fixture(scope="session")
 def lib(pkg):
     return pkg._native.load()
+
+
+@pytest.fixture
+def monkeypatch(monkeypatch):
+    """pytest's monkeypatch, plus: the library reads its GATRES_* switches from the environment ONCE
+    (csrc/gatres_common.h: gatres_knobs), so every change of such a variable is followed by gatres_knobs_reload(),
+    and once more when the test's environment has been restored."""
+    import gnn_pressure_estimation_amd as G
+
+    def reload():
+        G._native.load().gatres_knobs_reload()
+
+    class _Env:
+        def __getattr__(self, name):
+            return getattr(monkeypatch, name)
+
+        def setenv(self, name, value, *a, **k):
+            monkeypatch.setenv(name, value, *a, **k)
+            if name.startswith("GATRES_"):
+                reload()
+
+        def delenv(self, name, *a, **k):
+            monkeypatch.delenv(name, *a, **k)
+            if name.startswith("GATRES_"):
+                reload()
+
+    yield _Env()
+    monkeypatch.undo()
+    reload()
