@@ -1,8 +1,18 @@
 // Window form of the fused per-snapshot kernel: the headline path (gatres_small, 8 parts per snapshot).
 // Device code and commentary: k_fused_dev.h.
-#include "k_fused_dev.h"
+#include "k_window_stages.h"
 
 namespace {
+
+// The waves that issued LDS-DMA in a stage (w0 and up; they own no MFMA tile there) wait for it to land before the stage's
+// closing barrier.  (The sparse stages read LDS through asm statements, which hipcc does not treat as LDS reads: it no
+// longer puts its own conservative s_waitcnt vmcnt(0) between a wave's DMA and that wave's next LDS access.)
+__device__ __forceinline__ void dma_land(int w0) {
+  if ((int)__builtin_amdgcn_readfirstlane(threadIdx.x >> 6) >= w0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+__device__ __forceinline__ u16* align16(u16* p) {
+  return reinterpret_cast<u16*>((reinterpret_cast<uintptr_t>(p) + 15) & ~(uintptr_t)15);
+}
 
 template <int NC, int THREADS>
 __global__ __launch_bounds__(THREADS) void gatres_window_kernel(const FusedArgs a) {
@@ -43,9 +53,6 @@ __global__ __launch_bounds__(THREADS) void gatres_window_kernel(const FusedArgs 
   xc.dead = GATRES_DIAG && (a.no_halo & 2) != 0;      // diagnostic (GATRES_XCH_NOWAIT=1, WRONG results): never wait for a partner -- what
                                        // the launch would take if every hand-off were free
   xc.ep = (unsigned)uni((int)__hip_atomic_load(grp.flags + part * FLAG_STRIDE + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-  // rows per lane group per trip: a part owns ~100 rows, one trip covers them in every stage but conv1's edge dots;
-  // more unrolling only costs registers and code (the block loop does not fit the instruction cache as it is)
-  constexpr int UF = 1, UB = 1;
   // first wave that issues LDS-DMA inside MFMA stages: the waves below it own a 16-row tile there (dma_copy16)
   const int dw0 = min((ow + 15) >> 4, THREADS / 64 - 4);
   constexpr int WL_FLOATS = 2 * NC * (2 * NC + 4) + 4 * NC;
@@ -111,6 +118,9 @@ __global__ __launch_bounds__(THREADS) void gatres_window_kernel(const FusedArgs 
     u16* colo = tp;            tp += even(oeg);
     u16* mrpo = tp;            tp += even(ow + 1);
     u16* mcolo = tp;           tp += even(oem);
+    tp = align16(tp);
+    u16* nbin = tp;            tp += 8 * ow;       // padded in-edge descriptors of the own rows (k_window_stages.h)
+    u16* mbin = tp;            tp += 8 * ow;
     int* hcounter = reinterpret_cast<int*>(tp);
     u16* hlist = tp + 2;                 // import list: remote sources of own in-edges (one entry per edge)
     const int hcap = max(0, (int)((lds_top - reinterpret_cast<unsigned char*>(hlist)) / 4));
@@ -146,7 +156,10 @@ __global__ __launch_bounds__(THREADS) void gatres_window_kernel(const FusedArgs 
         st4(xA + (unsigned)(r * NC + c0), o);
       }
     }
+    dma_land(0);
     __syncthreads();
+    build_nbr_in<THREADS>(rw, rp, colo, oeg, false, nbin);
+    build_nbr_in<THREADS>(rw, mrp, mcolo, oem, true, mbin);
     int hcnt = uni(build_halo<THREADS>(rp, colo, nullptr, rw, hlist, nullptr, hcap, hcounter));
     int ecnt = uni(build_export_rows<THREADS>(a.t_rowptr, a.t_dst, n0, rw, elist, hcap, hcounter));
     if (hcnt > hcap || ecnt > hcap) {      // (the host sizes the lists from gatres_graph_t.halo: cannot happen with a sane plan)
@@ -164,6 +177,7 @@ __global__ __launch_bounds__(THREADS) void gatres_window_kernel(const FusedArgs 
       seg_proj<NC, 2 * NC, 2, EPI_ATT, THREADS, true, true>(rw, xA, 0, pb + L.c1_W, base + SL.h1, 0, hA, 0, pb + L.c1_as,
                                                         pb + L.c1_ad, base + SL.as1, base + SL.ad1, 0, sa2, sd2,
                                                         nullptr, 0, nullptr, 0, wlA);
+      dma_land(dw0);
       lds_barrier();                              // own rows of h1 / a_src are in LDS; the saved copies drain meanwhile
       ++xc.ep;                                    // exchange F1: the gathers below read h1 / a_src of neighbour rows
       xch_export<2 * NC, THREADS>(xc, elist, ecnt, hA, xc.base + XL.f1h);
@@ -177,14 +191,14 @@ __global__ __launch_bounds__(THREADS) void gatres_window_kernel(const FusedArgs 
       // (Coefficients computed INSIDE the exchange -- softmax threads reading a partner's a_src straight from its granule
       // while the other waves sweep h1 in, one barrier less -- was measured: 545 -> 557 us per launch, and 28 KB of code.)
       if (__builtin_expect(2 * oeg <= wr * NC, 1)) {
-        seg_softmax<2, true, THREADS>(rw, rp, colo, sa2, sd2, 0, base + SL.al1, elo, hBw);
+        win_softmax<2, THREADS>(rw, nbin, rp, colo, sa2, sd2, base + SL.al1, elo, hBw);
         lds_barrier();
-        seg_gather<true, 2, NC, THREADS, UF>(rw, rp, colo, hA, 0, hBw, 0, pb + L.c1_b, base + SL.o1, 0, xB, 0,
-                                             mo1 ? mo1 + b * ow : nullptr);
+        win_gather<true, 2, NC, THREADS>(rw, nbin, rp, colo, hA, hBw, pb + L.c1_b, base + SL.o1, 0, xB,
+                                         mo1 ? mo1 + b * ow : nullptr);
       } else {
         seg_softmax<2, false, THREADS>(rw, rp, colo, sa2, sd2, 0, base + SL.al1, elo, nullptr);
         __syncthreads();
-        seg_gather<true, 2, NC, THREADS, UF>(rw, rp, colo, hA, 0, base + SL.al1, elo, pb + L.c1_b, base + SL.o1, 0, xB, 0,
+        seg_gather<true, 2, NC, THREADS, 1>(rw, rp, colo, hA, 0, base + SL.al1, elo, pb + L.c1_b, base + SL.o1, 0, xB, 0,
                                              mo1 ? mo1 + b * ow : nullptr);
       }
       lds_barrier();
@@ -196,6 +210,7 @@ __global__ __launch_bounds__(THREADS) void gatres_window_kernel(const FusedArgs 
       seg_proj<2 * NC, NC, 1, EPI_ATT, THREADS, true, true>(rw, xB, 0, pb + L.c2_W, base + SL.h2, 0, hB, 0, pb + L.c2_as,
                                                         pb + L.c2_ad, base + SL.as2, base + SL.ad2, 0, sa1, sd1,
                                                         nullptr, 0, nullptr, 0, wlB);
+      dma_land(dw0);
       lds_barrier();
       ++xc.ep;                                    // exchange F2
       xch_export<NC, THREADS>(xc, elist, ecnt, hB, xc.base + XL.f2h);
@@ -209,13 +224,13 @@ __global__ __launch_bounds__(THREADS) void gatres_window_kernel(const FusedArgs 
       float* y2T = hAw - wlo * NC;
       if (__builtin_expect(oeg <= wr * NC, 1)) {
         float* al2L = hAw + (size_t)wr * NC;
-        seg_softmax<1, true, THREADS>(rw, rp, colo, sa1, sd1, 0, base + SL.al2, elo, al2L);
+        win_softmax<1, THREADS>(rw, nbin, rp, colo, sa1, sd1, base + SL.al2, elo, al2L);
         lds_barrier();
-        seg_gather<false, 1, NC, THREADS, UF>(rw, rp, colo, hB, 0, al2L, 0, pb + L.c2_b, y2T, 0);
+        win_gather<false, 1, NC, THREADS>(rw, nbin, rp, colo, hB, al2L, pb + L.c2_b, y2T, 0, nullptr, nullptr);
       } else {
         seg_softmax<1, false, THREADS>(rw, rp, colo, sa1, sd1, 0, base + SL.al2, elo, nullptr);
         __syncthreads();
-        seg_gather<false, 1, NC, THREADS, UF>(rw, rp, colo, hB, 0, base + SL.al2, elo, pb + L.c2_b, y2T, 0);
+        seg_gather<false, 1, NC, THREADS, 1>(rw, rp, colo, hB, 0, base + SL.al2, elo, pb + L.c2_b, y2T, 0);
       }
       lds_barrier();
       ++xc.ep;                                    // exchange F3: K3 averages y2 over neighbour rows
@@ -225,8 +240,8 @@ __global__ __launch_bounds__(THREADS) void gatres_window_kernel(const FusedArgs 
       lds_barrier();
       STAMP();
       // K3: residual from the x buffer, result back into it (and to HBM: saved xin of the next block)
-      seg_mean_fwd<NC, THREADS, UF>(rw, oem, mrp, mcolo, y2T, 0, xA, 0, xnext, 0, xA, 0,
-                                    (mxin && b + 1 < L.nb) ? mxin + (b + 1) * ow : nullptr);
+      win_mean_fwd<NC, THREADS>(rw, mbin, mrp, mcolo, y2T, xA, xnext, xA,
+                                (mxin && b + 1 < L.nb) ? mxin + (b + 1) * ow : nullptr);
       lds_barrier();
       STAMP();
       xcur = xnext;
@@ -301,6 +316,10 @@ __global__ __launch_bounds__(THREADS) void gatres_window_kernel(const FusedArgs 
     u16* mrpw = tp;            tp += even(wr + 1);
     u16* mtrpo = tp;           tp += even(ow + 1);
     u16* mtdsto = tp;          tp += even(otm);
+    tp = align16(tp);
+    u16* nbin = tp;            tp += 8 * ow;       // padded edge descriptors of the own rows (k_window_stages.h)
+    u16* tout = tp;            tp += 16 * ow;
+    u16* mout = tp;            tp += 16 * ow;
     int* hcounter = reinterpret_cast<int*>(tp);
     u16* hrow = tp + 2;                  // import lists: remote destinations (+ edge ids) of own out-edges
     const int hcap = max(0, (int)((lds_top - reinterpret_cast<unsigned char*>(hrow)) / 8));
@@ -350,6 +369,10 @@ __global__ __launch_bounds__(THREADS) void gatres_window_kernel(const FusedArgs 
     if (L.nb > 0) dma_conv2(L.nb - 1, 0);
     seg_lin1_bwd<NC, THREADS>(rw, n0, a.perm, a.g_out, xfinal, P + L.p_lin1_w, gp_cur, gpT, slab + L.p_lin1_w,
                               slab + L.p_lin1_b, L.nb > 0 ? 1 : 0, red, gkeep);
+    dma_land(0);
+    build_nbr_in<THREADS>(rw, rp, colo, oeg, false, nbin);
+    build_nbr_out<THREADS>(rw, trp, tdsto, teido, 0, nullptr, otg, tout);
+    build_nbr_out<THREADS>(rw, mtrp, mtdsto, nullptr, 0, mrp, otm, mout);
     int hcnt = uni(build_halo<THREADS>(trp, tdsto, teido, rw, hrow, hedge, hcap, hcounter));
     int ercnt = uni(build_export_rows<THREADS>(a.rowptr, a.col, n0, rw, erow, hcap, hcounter));
     if (tid == 0) *hcounter = 0;
@@ -390,19 +413,18 @@ __global__ __launch_bounds__(THREADS) void gatres_window_kernel(const FusedArgs 
       lds_barrier();
       XSTAMP();
       publish_items<THREADS>(a, seg, part, 2 * (L.nb - 1 - b), grp.local, false);      // the blocks above are kept
-      seg_mean_bwd<NC, THREADS, UB>(rw, otm, mrp, mtrp, mtdsto, gpT, 0, gy2T, 0);
+      win_mean_bwd<NC, THREADS>(rw, mout, mrp, mtrp, mtdsto, gpT, gy2T);
       lds_barrier();
       XSTAMP();
       STAMP();
       float* keep = sc + L.sc_keep + (int64_t)b * L.keep_stride;
       float* gh = keep + L.k_gh1;
       float* gh2 = keep + L.k_gh2;
-      seg_edge_dots<1, NC, THREADS, 1>(rw, 0, rp, colo, gy2T, 0, hT2, ge2 + elo, 0);
+      win_edge_dots<1, NC, THREADS>(rw, nbin, rp, colo, gy2T, hT2, ge2 + elo);
       lds_barrier();
       XSTAMP();
       seg_bias_part<NC, THREADS>(rw, gy2T, 0, red);
-      seg_softmax_bwd<1, THREADS>(rw, 0, 0, rp, colo, alT2 + elo, asT2, adT2, ge2 + elo, 0, gad2, 0, nullptr, 0, nullptr,
-                                  0);
+      win_softmax_bwd<1, THREADS>(rw, nbin, rp, colo, alT2 + elo, asT2, adT2, ge2 + elo, gad2);
       lds_barrier();
       XSTAMP();
       ++xc.ep;                                   // exchange B2: the source-major stage reads g_y2 / g_e of neighbour rows
@@ -418,8 +440,8 @@ __global__ __launch_bounds__(THREADS) void gatres_window_kernel(const FusedArgs 
       XSTAMP();
       STAMP();
       seg_bias_finish<NC, THREADS>(red, sb + L.c2_b);
-      seg_agg_bwd_src<1, NC, THREADS, UB>(rw, 0, trp, teido, tdsto, gy2T, 0, alT2, ge2, 0, gad2, 0, pb + L.c2_as,
-                                      pb + L.c2_ad, gh2, n0, keep + L.k_gas2, keep + L.k_gad2, xG2, 0);
+      win_agg_bwd_src<1, NC, THREADS>(rw, tout, trp, teido, tdsto, 0, gy2T, alT2, ge2, gad2, pb + L.c2_as, pb + L.c2_ad,
+                                      gh2, n0, keep + L.k_gas2, keep + L.k_gad2, xG2);
       lds_barrier();           // g_y2 (RA) and the conv2 tables are dead
       XSTAMP();
       STAMP();
@@ -433,15 +455,15 @@ __global__ __launch_bounds__(THREADS) void gatres_window_kernel(const FusedArgs 
                                                                nullptr, nullptr, nullptr, nullptr, 0, nullptr, nullptr,
                                                                nullptr, 0, (GATRES_DIAG && (a.no_halo & 4)) ? nullptr : base + SL.o1, 0, wlA,
                                                                nullptr, nullptr, mo1 ? mo1 + b * ow : nullptr, nullptr);
+      dma_land(dw0);
       __syncthreads();
       XSTAMP();
       STAMP();
-      seg_edge_dots<2, NC, THREADS, 1>(rw, 0, rp, colo, RA, 0, hT1, ge1 + elo * 2, 0);
+      win_edge_dots<2, NC, THREADS>(rw, nbin, rp, colo, RA, hT1, ge1 + elo * 2);
       lds_barrier();
       XSTAMP();
       seg_bias_part<2 * NC, THREADS>(rw, RA, 0, red);
-      seg_softmax_bwd<2, THREADS>(rw, 0, 0, rp, colo, alT1 + elo * 2, asT1, adT1, ge1 + elo * 2, 0, gad1, 0, nullptr, 0,
-                                  nullptr, 0);
+      win_softmax_bwd<2, THREADS>(rw, nbin, rp, colo, alT1 + elo * 2, asT1, adT1, ge1 + elo * 2, gad1);
       lds_barrier();
       XSTAMP();
       ++xc.ep;                                   // exchange B3
@@ -458,8 +480,8 @@ __global__ __launch_bounds__(THREADS) void gatres_window_kernel(const FusedArgs 
       publish_items<THREADS>(a, seg, part, 2 * (L.nb - 1 - b) + 1, grp.local, false);      // conv2 tables complete
       STAMP();
       seg_bias_finish<2 * NC, THREADS>(red, sb + L.c1_b);
-      seg_agg_bwd_src<2, NC, THREADS, UB>(rw, 0, trp, teido, tdsto, RA, 0, alT1, ge1, 0, gad1, 0, pb + L.c1_as,
-                                      pb + L.c1_ad, gh, n0, keep + L.k_gas1, keep + L.k_gad1, xG1, 0);
+      win_agg_bwd_src<2, NC, THREADS>(rw, tout, trp, teido, tdsto, 0, RA, alT1, ge1, gad1, pb + L.c1_as, pb + L.c1_ad,
+                                      gh, n0, keep + L.k_gas1, keep + L.k_gad1, xG1);
       lds_barrier();
       XSTAMP();
       STAMP();
@@ -469,6 +491,7 @@ __global__ __launch_bounds__(THREADS) void gatres_window_kernel(const FusedArgs 
                                                                (GATRES_DIAG && (a.no_halo & 4)) ? nullptr : gp_cur, n0,
                                                                (b > 0 && !(GATRES_DIAG && (a.no_halo & 4))) ? base + SL.xin : nullptr, 0, wlB,
                                                                gkeep, gkeep, nullptr, (mxin && b > 0) ? mxin + b * ow : nullptr);
+      dma_land(dw0);
       XSTAMP();
       STAMP();
       float* t = gp_cur; gp_cur = gp_nxt; gp_nxt = t;

@@ -1,0 +1,588 @@
+// Sparse stages of the window kernel (k_window.hip), hand-scheduled around the LDS.
+//
+// Why this file exists (round 3, read off the gfx950 ISA of round 2's kernel): the stage functions of k_fused_dev.h say
+// "all neighbour loads of a row are issued together", but behind the wave-uniform `k < dmax` branches and the per-lane
+// `k < deg` selects hipcc emitted, per neighbour slot, ds_read_u16 (index) -> s_waitcnt lgkmcnt(0) -> ds_read_b128 (row)
+// -> s_waitcnt lgkmcnt(0): twelve dependent LDS round trips per row where the data dependences need three (row
+// descriptor -> neighbour ids -> neighbour rows).  Here
+//   * every own row has a PADDED NEIGHBOUR DESCRIPTOR in LDS ({first edge, degree, six neighbour ids} = 16 bytes, one
+//     ds_read_b128, the lanes of a row read the same address: a broadcast), built once per launch phase, so the chain is
+//     descriptor -> rows: TWO round trips;
+//   * the loads of one round are one asm statement: issued back to back, one s_waitcnt (cdna_hip_programming.md 5.7,
+//     form (i): loads and their wait in ONE statement, early-clobber outputs), which hipcc neither splits nor reorders;
+//   * no branch between a stage's loads: slots beyond a row's degree read a valid row and weigh 0 (as before), rows
+//     with more than MAXD edges send their wave through the edge-at-a-time functions of k_fused_dev.h.
+// Arithmetic, operand order and rounding are exactly those of k_fused_dev.h / the per-op kernels: results stay
+// bit-identical (tests/test_gpu_model.py compares the three).
+#pragma once
+#include "k_fused_dev.h"
+
+namespace {
+
+// The thread id of a stage, opaque to the optimiser: everything a stage derives from it (column group, row of the trip,
+// table addresses) is then recomputed inside the stage -- a handful of VALU instructions -- instead of being hoisted out of
+// the block loop and kept alive across all thirteen stages of it, which is what ran the 128-VGPR kernel into scratch.
+__device__ __forceinline__ int stage_tid() {
+  int t = (int)threadIdx.x;
+  asm volatile("" : "+v"(t));
+  return t;
+}
+
+// ---------------------------------------------------------------------------------------------- LDS primitives
+__device__ __forceinline__ unsigned lds_addr(const void* p) { return (unsigned)(uintptr_t)p; }
+
+// one 16-byte read
+__device__ __forceinline__ uint4 lds_rd128(unsigned a) {
+  uint4 v;
+  asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(v) : "v"(a) : "memory");
+  return v;
+}
+// one 16-byte read + one dword, one wait
+__device__ __forceinline__ void lds_rd128_32(unsigned a, unsigned b, uint4& v, float& s) {
+  asm volatile("ds_read_b128 %0, %2\n\tds_read_b32 %1, %3\n\ts_waitcnt lgkmcnt(0)"
+               : "=&v"(v), "=&v"(s) : "v"(a), "v"(b) : "memory");
+}
+// two 16-byte reads, one wait
+__device__ __forceinline__ void lds_rd128x2(unsigned a, unsigned b, uint4& v, uint4& w) {
+  asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %3\n\ts_waitcnt lgkmcnt(0)"
+               : "=&v"(v), "=&v"(w) : "v"(a), "v"(b) : "memory");
+}
+__device__ __forceinline__ void lds_rd128x2_32(unsigned a, unsigned b, unsigned c, uint4& v, uint4& w, float& s) {
+  asm volatile("ds_read_b128 %0, %3\n\tds_read_b128 %1, %4\n\tds_read_b32 %2, %5\n\ts_waitcnt lgkmcnt(0)"
+               : "=&v"(v), "=&v"(w), "=&v"(s) : "v"(a), "v"(b), "v"(c) : "memory");
+}
+// six 16-byte reads, one wait
+__device__ __forceinline__ void lds_rd128x6(const unsigned (&a)[MAXD], f32x4 (&v)[MAXD]) {
+  static_assert(MAXD == 6, "six slots");
+  asm volatile(
+      "ds_read_b128 %0, %6\n\tds_read_b128 %1, %7\n\tds_read_b128 %2, %8\n\t"
+      "ds_read_b128 %3, %9\n\tds_read_b128 %4, %10\n\tds_read_b128 %5, %11\n\ts_waitcnt lgkmcnt(0)"
+      : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]), "=&v"(v[4]), "=&v"(v[5])
+      : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(a[4]), "v"(a[5])
+      : "memory");
+}
+// six dwords, one wait
+__device__ __forceinline__ void lds_rd32x6(const unsigned (&a)[MAXD], float (&v)[MAXD]) {
+  asm volatile(
+      "ds_read_b32 %0, %6\n\tds_read_b32 %1, %7\n\tds_read_b32 %2, %8\n\t"
+      "ds_read_b32 %3, %9\n\tds_read_b32 %4, %10\n\tds_read_b32 %5, %11\n\ts_waitcnt lgkmcnt(0)"
+      : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]), "=&v"(v[4]), "=&v"(v[5])
+      : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(a[4]), "v"(a[5])
+      : "memory");
+}
+// six 16-byte reads + six dwords, one wait
+__device__ __forceinline__ void lds_rd128x6_32x6(const unsigned (&a)[MAXD], const unsigned (&b)[MAXD], f32x4 (&v)[MAXD],
+                                                 float (&s)[MAXD]) {
+  asm volatile(
+      "ds_read_b128 %0, %12\n\tds_read_b128 %1, %13\n\tds_read_b128 %2, %14\n\t"
+      "ds_read_b128 %3, %15\n\tds_read_b128 %4, %16\n\tds_read_b128 %5, %17\n\t"
+      "ds_read_b32 %6, %18\n\tds_read_b32 %7, %19\n\tds_read_b32 %8, %20\n\t"
+      "ds_read_b32 %9, %21\n\tds_read_b32 %10, %22\n\tds_read_b32 %11, %23\n\ts_waitcnt lgkmcnt(0)"
+      : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]), "=&v"(v[4]), "=&v"(v[5]), "=&v"(s[0]), "=&v"(s[1]),
+        "=&v"(s[2]), "=&v"(s[3]), "=&v"(s[4]), "=&v"(s[5])
+      : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(a[4]), "v"(a[5]), "v"(b[0]), "v"(b[1]), "v"(b[2]), "v"(b[3]),
+        "v"(b[4]), "v"(b[5])
+      : "memory");
+}
+// six 16-byte reads + twelve dwords, one wait
+__device__ __forceinline__ void lds_rd128x6_32x12(const unsigned (&a)[MAXD], const unsigned (&b)[MAXD],
+                                                  const unsigned (&c)[MAXD], f32x4 (&v)[MAXD], float (&s)[MAXD],
+                                                  float (&t)[MAXD]) {
+  asm volatile(
+      "ds_read_b128 %0, %18\n\tds_read_b128 %1, %19\n\tds_read_b128 %2, %20\n\t"
+      "ds_read_b128 %3, %21\n\tds_read_b128 %4, %22\n\tds_read_b128 %5, %23\n\t"
+      "ds_read_b32 %6, %24\n\tds_read_b32 %7, %25\n\tds_read_b32 %8, %26\n\t"
+      "ds_read_b32 %9, %27\n\tds_read_b32 %10, %28\n\tds_read_b32 %11, %29\n\t"
+      "ds_read_b32 %12, %30\n\tds_read_b32 %13, %31\n\tds_read_b32 %14, %32\n\t"
+      "ds_read_b32 %15, %33\n\tds_read_b32 %16, %34\n\tds_read_b32 %17, %35\n\ts_waitcnt lgkmcnt(0)"
+      : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]), "=&v"(v[4]), "=&v"(v[5]), "=&v"(s[0]), "=&v"(s[1]),
+        "=&v"(s[2]), "=&v"(s[3]), "=&v"(s[4]), "=&v"(s[5]), "=&v"(t[0]), "=&v"(t[1]), "=&v"(t[2]), "=&v"(t[3]),
+        "=&v"(t[4]), "=&v"(t[5])
+      : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(a[4]), "v"(a[5]), "v"(b[0]), "v"(b[1]), "v"(b[2]), "v"(b[3]),
+        "v"(b[4]), "v"(b[5]), "v"(c[0]), "v"(c[1]), "v"(c[2]), "v"(c[3]), "v"(c[4]), "v"(c[5])
+      : "memory");
+}
+// eighteen dwords, one wait
+__device__ __forceinline__ void lds_rd32x18(const unsigned (&a)[MAXD], const unsigned (&b)[MAXD], const unsigned (&c)[MAXD],
+                                            float (&u)[MAXD], float (&s)[MAXD], float (&t)[MAXD]) {
+  asm volatile(
+      "ds_read_b32 %0, %18\n\tds_read_b32 %1, %19\n\tds_read_b32 %2, %20\n\t"
+      "ds_read_b32 %3, %21\n\tds_read_b32 %4, %22\n\tds_read_b32 %5, %23\n\t"
+      "ds_read_b32 %6, %24\n\tds_read_b32 %7, %25\n\tds_read_b32 %8, %26\n\t"
+      "ds_read_b32 %9, %27\n\tds_read_b32 %10, %28\n\tds_read_b32 %11, %29\n\t"
+      "ds_read_b32 %12, %30\n\tds_read_b32 %13, %31\n\tds_read_b32 %14, %32\n\t"
+      "ds_read_b32 %15, %33\n\tds_read_b32 %16, %34\n\tds_read_b32 %17, %35\n\ts_waitcnt lgkmcnt(0)"
+      : "=&v"(u[0]), "=&v"(u[1]), "=&v"(u[2]), "=&v"(u[3]), "=&v"(u[4]), "=&v"(u[5]), "=&v"(s[0]), "=&v"(s[1]),
+        "=&v"(s[2]), "=&v"(s[3]), "=&v"(s[4]), "=&v"(s[5]), "=&v"(t[0]), "=&v"(t[1]), "=&v"(t[2]), "=&v"(t[3]),
+        "=&v"(t[4]), "=&v"(t[5])
+      : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(a[4]), "v"(a[5]), "v"(b[0]), "v"(b[1]), "v"(b[2]), "v"(b[3]),
+        "v"(b[4]), "v"(b[5]), "v"(c[0]), "v"(c[1]), "v"(c[2]), "v"(c[3]), "v"(c[4]), "v"(c[5])
+      : "memory");
+}
+
+__device__ __forceinline__ float4 as_f4(const f32x4 v) { return make_float4(v[0], v[1], v[2], v[3]); }
+__device__ __forceinline__ float4 as_f4(const uint4 v) {
+  return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+}
+
+// ---------------------------------------------------------------------------------------------- neighbour descriptors
+// In-edge descriptor of an own row (GATConv graph or SimpleConv graph), 8 x u16 = one ds_read_b128:
+//   {beg, deg, n0 .. n5}: beg = the row's first edge (own-edge-relative index), deg = its in-degree, n_k = local id of the
+//   source of edge beg + min(k, deg - 1) (a row of degree 0 -- SimpleConv only -- lists itself).
+// Out-edge descriptor (source-major stages), 16 x u16 = two ds_read_b128:
+//   {deg, 0, d0 .. d5 | x0 .. x5, 0, 0}: d_k = local id of the destination of out-edge min(k, deg - 1); x_k = the edge's
+//   id in the destination-sorted list (GATConv, window-edge-relative) or max(in-degree of d_k, 1) (SimpleConv).
+struct NbrIn {
+  int beg, deg;
+  int n[MAXD];
+};
+__device__ __forceinline__ NbrIn unpack_in(const uint4 w) {
+  NbrIn d;
+  d.beg = (int)(w.x & 0xffffu); d.deg = (int)(w.x >> 16);
+  d.n[0] = (int)(w.y & 0xffffu); d.n[1] = (int)(w.y >> 16);
+  d.n[2] = (int)(w.z & 0xffffu); d.n[3] = (int)(w.z >> 16);
+  d.n[4] = (int)(w.w & 0xffffu); d.n[5] = (int)(w.w >> 16);
+  return d;
+}
+struct NbrOut {
+  int deg;
+  int d[MAXD], x[MAXD];
+};
+__device__ __forceinline__ NbrOut unpack_out(const uint4 a, const uint4 b) {
+  NbrOut o;
+  o.deg = (int)(a.x & 0xffffu);
+  o.d[0] = (int)(a.y & 0xffffu); o.d[1] = (int)(a.y >> 16);
+  o.d[2] = (int)(a.z & 0xffffu); o.d[3] = (int)(a.z >> 16);
+  o.d[4] = (int)(a.w & 0xffffu); o.d[5] = (int)(a.w >> 16);
+  o.x[0] = (int)(b.x & 0xffffu); o.x[1] = (int)(b.x >> 16);
+  o.x[2] = (int)(b.y & 0xffffu); o.x[3] = (int)(b.y >> 16);
+  o.x[4] = (int)(b.z & 0xffffu); o.x[5] = (int)(b.z >> 16);
+  return o;
+}
+
+// Build the in-edge descriptors of the own rows from the 16-bit CSR copies (rp: own rows, shifted view; col: own edges).
+// self_pad: a slot beyond the degree names the row itself (SimpleConv) instead of the row's last neighbour (GATConv).
+template <int THREADS>
+__device__ __forceinline__ void build_nbr_in(Rows rw, const u16* rp, const u16* col, int ne, bool self_pad, u16* tab) {
+  const int elast = max(ne - 1, 0);
+  for (int r = rw.lo + (int)threadIdx.x; r < rw.hi; r += THREADS) {
+    const int beg = rp[r], deg = (int)rp[r + 1] - beg;
+    u16* t = tab + (r - rw.lo) * 8;
+    t[0] = (u16)beg; t[1] = (u16)deg;
+#pragma unroll
+    for (int k = 0; k < MAXD; ++k) {
+      int j;
+      if (self_pad) j = k < deg ? (int)col[min(beg + k, elast)] : r;
+      else          j = col[min(beg + min(k, max(deg - 1, 0)), elast)];
+      t[2 + k] = (u16)j;
+    }
+  }
+}
+// Out-edge descriptors.  trp: own rows (shifted view), dst / eid: own out-edges.  cnt_rp: SimpleConv's in-edge rowptr over
+// the WINDOW (shifted view) when x_k is the destination's in-degree, nullptr when x_k is eid[.] - eid_sub.
+template <int THREADS>
+__device__ __forceinline__ void build_nbr_out(Rows rw, const u16* trp, const u16* dst, const u16* eid, int eid_sub,
+                                              const u16* cnt_rp, int ne, u16* tab) {
+  const int elast = max(ne - 1, 0);
+  for (int r = rw.lo + (int)threadIdx.x; r < rw.hi; r += THREADS) {
+    const int beg = trp[r], deg = (int)trp[r + 1] - beg;
+    u16* t = tab + (r - rw.lo) * 16;
+    t[0] = (u16)deg; t[1] = 0; t[14] = 0; t[15] = 0;
+#pragma unroll
+    for (int k = 0; k < MAXD; ++k) {
+      const int kk = min(beg + min(k, max(deg - 1, 0)), elast);
+      const int ii = (cnt_rp && !(k < deg)) ? r : (int)dst[kk];
+      t[2 + k] = (u16)ii;
+      t[8 + k] = cnt_rp ? (u16)max((int)cnt_rp[ii + 1] - (int)cnt_rp[ii], 1) : (u16)((int)eid[kk] - eid_sub);
+    }
+  }
+}
+
+// does any lane of this wave hold a row with more than MAXD edges?  (wave-uniform)
+__device__ __forceinline__ bool wave_has_hub(int deg) { return __ballot(deg > MAXD) != 0ull; }
+
+// ---------------------------------------------------------------------------------------------- forward stages
+// K2 forward, sub-stage A (seg_softmax): one thread per (row, head).
+//   nb: in-edge descriptors; asrc: [row][H] over the window (shifted view); adst: [row][H] own rows (shifted view);
+//   alpha_g: saved table (global, [elo + e][H]); alpha_l: LDS table [e][H] over the own edges.
+template <int H, int THREADS>
+__device__ __forceinline__ void win_softmax(Rows rw, const u16* nb, const u16* rp, const u16* col, const float* asrc,
+                                            const float* adst_t, float* __restrict__ alpha_g, int eb, float* alpha_l) {
+  const int tid = stage_tid();
+  const unsigned a_nb = lds_addr(nb), a_as = lds_addr(asrc), a_ad = lds_addr(adst_t);
+  for (int idx0 = rw.lo * H; idx0 < rw.hi * H; idx0 += THREADS) {
+    if (idx0 + (int)(tid & ~63u) >= rw.hi * H) continue;             // (wave-uniform) nothing left for this wave
+    const int idx = min(idx0 + tid, rw.hi * H - 1);
+    const bool valid = idx0 + tid < rw.hi * H;
+    const int r = idx / H, hd = idx % H;
+    uint4 w;
+    float adst;
+    lds_rd128_32(a_nb + (unsigned)(r - rw.lo) * 16u, a_ad + (unsigned)(r * H + hd) * 4u, w, adst);
+    const NbrIn d = unpack_in(w);
+    if (__builtin_expect(wave_has_hub(d.deg), 0)) {
+      if (valid) {
+        Rows one; one.lo = r; one.hi = r + 1;      // (per lane: the edge-at-a-time loops of seg_softmax for this row / head)
+        const int beg = rp[r], end = rp[r + 1];
+        auto at = [&](int e) -> float { return asrc[(unsigned)((int)col[e] * H + hd)]; };
+        float m = -INFINITY;
+        for (int e = beg; e < end; ++e) m = fmaxf(m, gatres_leaky(at(e) + adst));
+        float Z = 0.f;
+        for (int e = beg; e < end; ++e) Z = Z + expf(gatres_leaky(at(e) + adst) - m);
+        Z = Z + GATRES_SOFTMAX_EPS;
+        for (int e = beg; e < end; ++e) {
+          const float al = expf(gatres_leaky(at(e) + adst) - m) / Z;
+          alpha_g[(unsigned)((eb + e) * H + hd)] = al;
+          alpha_l[e * H + hd] = al;
+        }
+        (void)one;
+      }
+      continue;
+    }
+    unsigned a[MAXD];
+#pragma unroll
+    for (int k = 0; k < MAXD; ++k) a[k] = a_as + (unsigned)(d.n[k] * H + hd) * 4u;
+    float so[MAXD];
+    lds_rd32x6(a, so);
+    float m = -INFINITY;
+#pragma unroll
+    for (int k = 0; k < MAXD; ++k) {
+      const float sv = gatres_leaky(so[k] + adst);
+      so[k] = k < d.deg ? sv : -INFINITY;
+      m = fmaxf(m, so[k]);
+    }
+    float Z = 0.f;
+#pragma unroll
+    for (int k = 0; k < MAXD; ++k) {
+      so[k] = expf(so[k] - m);                                   // exp(-inf) = 0 on padding slots
+      Z = Z + so[k];
+    }
+    Z = Z + GATRES_SOFTMAX_EPS;
+    if (valid) {
+#pragma unroll
+      for (int k = 0; k < MAXD; ++k)
+        if (k < d.deg) {
+          const float al = so[k] / Z;
+          alpha_g[(unsigned)((eb + d.beg + k) * H + hd)] = al;
+          alpha_l[(d.beg + k) * H + hd] = al;
+        }
+    }
+  }
+}
+
+// K2 forward, sub-stage B (seg_gather): out[r] = sum_e alpha_e h[src(e)] + bias (+ReLU); HC/4 lanes per row.
+//   hsrc: [row][HC] over the window (shifted view); alpha: LDS table [e][H] over the own edges.
+template <bool RELU, int H, int C, int THREADS>
+__device__ __forceinline__ void win_gather(Rows rw, const u16* nb, const u16* rp, const u16* col, const float* hsrc,
+                                           const float* alpha, const float* bias, float* out, int ob, float* out_pub,
+                                           unsigned long long* mask64) {
+  const int tid = stage_tid();
+  constexpr int HC = H * C, G = HC / 4, RPP = THREADS / G;
+  const int c0 = (tid % G) * 4;
+  const int hd = c0 / C;
+  const unsigned a_nb = lds_addr(nb), a_h = lds_addr(hsrc) + (unsigned)c0 * 4u, a_al = lds_addr(alpha) + (unsigned)hd * 4u;
+  const float4 b = ld4(bias + c0);
+  for (int r0 = rw.lo; r0 < rw.hi; r0 += RPP) {
+    if (r0 + (int)((tid & ~63u) / G) >= rw.hi) continue;      // (wave-uniform) no row of this trip for this wave
+    int r = r0 + tid / G;
+    const bool valid = r < rw.hi;
+    if (!valid) r = rw.hi - 1;
+    const NbrIn d = unpack_in(lds_rd128(a_nb + (unsigned)(r - rw.lo) * 16u));
+    float4 acc = f4zero();
+    if (__builtin_expect(wave_has_hub(d.deg), 0)) {
+      const int beg = rp[r], end = rp[r + 1];
+      for (int e = beg; e < end; ++e)
+        gatres_axpy4(acc, alpha[(unsigned)(e * H + hd)], ld4(hsrc + (unsigned)((int)col[e] * HC + c0)));
+    } else {
+      unsigned av[MAXD], aa[MAXD];
+#pragma unroll
+      for (int k = 0; k < MAXD; ++k) {
+        av[k] = a_h + (unsigned)(d.n[k] * HC) * 4u;
+        aa[k] = a_al + (unsigned)((d.beg + min(k, d.deg - 1)) * H) * 4u;
+      }
+      f32x4 v[MAXD];
+      float al[MAXD];
+      lds_rd128x6_32x6(av, aa, v, al);
+#pragma unroll
+      for (int k = 0; k < MAXD; ++k) gatres_axpy4(acc, k < d.deg ? al[k] : 0.f, as_f4(v[k]));     // 0 on padding
+    }
+    add4(acc, b);
+    if (RELU) {
+      acc.x = fmaxf(acc.x, 0.f); acc.y = fmaxf(acc.y, 0.f);
+      acc.z = fmaxf(acc.z, 0.f); acc.w = fmaxf(acc.w, 0.f);
+    }
+    if (valid) {
+      st4(out + (unsigned)((ob + r) * HC + c0), acc);
+      if (out_pub) st4(out_pub + (unsigned)(r * HC + c0), acc);
+    }
+    if constexpr (RELU && G <= 16) {
+      if (mask64) {                                             // (workgroup-uniform)
+        const unsigned long long w = relu_bits<G, 16>(acc);
+        if (valid && tid % G == 0) mask64[r] = w;
+      }
+    }
+  }
+}
+
+// K3 forward (seg_mean_fwd): out = relu(mean_{j->r} y[j] + x0[r]).
+template <int C, int THREADS>
+__device__ __forceinline__ void win_mean_fwd(Rows rw, const u16* mb, const u16* mrp, const u16* mcol, const float* y,
+                                             const float* x0, float* out, float* out2, unsigned* mask32) {
+  const int tid = stage_tid();
+  constexpr int G = C / 4, RPP = THREADS / G;
+  const int c0 = (tid % G) * 4;
+  const unsigned a_mb = lds_addr(mb), a_y = lds_addr(y) + (unsigned)c0 * 4u, a_x = lds_addr(x0) + (unsigned)c0 * 4u;
+  for (int r0 = rw.lo; r0 < rw.hi; r0 += RPP) {
+    if (r0 + (int)((tid & ~63u) / G) >= rw.hi) continue;
+    int r = r0 + tid / G;
+    const bool valid = r < rw.hi;
+    if (!valid) r = rw.hi - 1;
+    uint4 w, xr;
+    lds_rd128x2(a_mb + (unsigned)(r - rw.lo) * 16u, a_x + (unsigned)(r * C) * 4u, w, xr);
+    const NbrIn d = unpack_in(w);
+    const float4 rr = as_f4(xr);
+    float4 acc = f4zero();
+    if (__builtin_expect(wave_has_hub(d.deg), 0)) {
+      const int beg = mrp[r], end = mrp[r + 1];
+      for (int e = beg; e < end; ++e) add4(acc, ld4(y + (unsigned)((int)mcol[e] * C + c0)));
+    } else {
+      unsigned av[MAXD];
+#pragma unroll
+      for (int k = 0; k < MAXD; ++k) av[k] = a_y + (unsigned)(d.n[k] * C) * 4u;
+      f32x4 v[MAXD];
+      lds_rd128x6(av, v);
+#pragma unroll
+      for (int k = 0; k < MAXD; ++k) gatres_axpy4(acc, k < d.deg ? 1.f : 0.f, as_f4(v[k]));   // fma(1,v,acc) = acc+v
+    }
+    const float cnt = (float)max(d.deg, 1);
+    float4 o;
+    o.x = fmaxf(acc.x / cnt + rr.x, 0.f); o.y = fmaxf(acc.y / cnt + rr.y, 0.f);
+    o.z = fmaxf(acc.z / cnt + rr.z, 0.f); o.w = fmaxf(acc.w / cnt + rr.w, 0.f);
+    if (valid) {
+      st4(out + (unsigned)(r * C + c0), o);
+      st4(out2 + (unsigned)(r * C + c0), o);
+    }
+    if constexpr (G <= 8) {
+      if (mask32) {                                             // (workgroup-uniform)
+        const unsigned mw = (unsigned)relu_bits<G, 8>(o);
+        if (valid && tid % G == 0) mask32[r] = mw;
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------- backward stages
+// K3 backward (seg_mean_bwd): g_y[r] = sum over out-edges (r -> i) of g_pre[i] / max(indeg(i), 1)
+template <int C, int THREADS>
+__device__ __forceinline__ void win_mean_bwd(Rows rw, const u16* mo, const u16* mrp, const u16* mtrp, const u16* mtdst,
+                                             const float* g_pre, float* g_y) {
+  const int tid = stage_tid();
+  constexpr int G = C / 4, RPP = THREADS / G;
+  const int c0 = (tid % G) * 4;
+  const unsigned a_mo = lds_addr(mo), a_g = lds_addr(g_pre) + (unsigned)c0 * 4u;
+  for (int r0 = rw.lo; r0 < rw.hi; r0 += RPP) {
+    if (r0 + (int)((tid & ~63u) / G) >= rw.hi) continue;
+    int r = r0 + tid / G;
+    const bool valid = r < rw.hi;
+    if (!valid) r = rw.hi - 1;
+    uint4 wa, wb;
+    lds_rd128x2(a_mo + (unsigned)(r - rw.lo) * 32u, a_mo + (unsigned)(r - rw.lo) * 32u + 16u, wa, wb);
+    const NbrOut d = unpack_out(wa, wb);
+    float4 acc = f4zero();
+    if (__builtin_expect(wave_has_hub(d.deg), 0)) {
+      const int beg = mtrp[r], end = mtrp[r + 1];
+      for (int t = beg; t < end; ++t) {
+        const int ii = mtdst[t];
+        const float cnt = (float)max((int)mrp[ii + 1] - (int)mrp[ii], 1);
+        const float4 v = ld4(g_pre + (unsigned)(ii * C + c0));
+        acc.x = acc.x + v.x / cnt; acc.y = acc.y + v.y / cnt;
+        acc.z = acc.z + v.z / cnt; acc.w = acc.w + v.w / cnt;
+      }
+    } else {
+      unsigned av[MAXD];
+#pragma unroll
+      for (int k = 0; k < MAXD; ++k) av[k] = a_g + (unsigned)(d.d[k] * C) * 4u;
+      f32x4 v[MAXD];
+      lds_rd128x6(av, v);
+#pragma unroll
+      for (int k = 0; k < MAXD; ++k) {
+        const float w = k < d.deg ? 1.f : 0.f;                      // x + 0 * q == x exactly
+        const float cnt = (float)d.x[k];
+        acc.x = fmaf(w, v[k][0] / cnt, acc.x); acc.y = fmaf(w, v[k][1] / cnt, acc.y);
+        acc.z = fmaf(w, v[k][2] / cnt, acc.z); acc.w = fmaf(w, v[k][3] / cnt, acc.w);
+      }
+    }
+    if (valid) st4(g_y + (unsigned)(r * C + c0), acc);
+  }
+}
+
+// K2 backward, destination-major sub-stage A (seg_edge_dots): ga_e = <g_out[i,h,:], h[j,h,:]> for every in-edge.
+//   g_out: [row][HC] own rows; h: [row][HC] over the window; g_e: LDS [e][H] over the own edges.
+template <int H, int C, int THREADS>
+__device__ __forceinline__ void win_edge_dots(Rows rw, const u16* nb, const u16* rp, const u16* col, const float* g_out,
+                                              const float* h, float* g_e) {
+  const int tid = stage_tid();
+  constexpr int HC = H * C, G = HC / 4, LH = C / 4, RPP = THREADS / G;
+  const int c0 = (tid % G) * 4;
+  const int hd = c0 / C;
+  const unsigned a_nb = lds_addr(nb), a_go = lds_addr(g_out) + (unsigned)c0 * 4u, a_h = lds_addr(h) + (unsigned)c0 * 4u;
+  for (int r0 = rw.lo; r0 < rw.hi; r0 += RPP) {
+    if (r0 + (int)((tid & ~63u) / G) >= rw.hi) continue;
+    int r = r0 + tid / G;
+    const bool valid = r < rw.hi;          // every lane stays in the loop: the head reduction spans the head's lanes
+    if (!valid) r = rw.hi - 1;
+    const bool leader = valid && (c0 % C) == 0;
+    uint4 w, gw;
+    lds_rd128x2(a_nb + (unsigned)(r - rw.lo) * 16u, a_go + (unsigned)(r * HC) * 4u, w, gw);
+    const NbrIn d = unpack_in(w);
+    const float4 go = as_f4(gw);
+    if (__builtin_expect(wave_has_hub(d.deg), 0)) {
+      const int beg = rp[r], end = rp[r + 1];
+      for (int e = beg; e < end; ++e) {
+        const float ga = gatres_head_reduce<LH>(gatres_head_dot4(go, ld4(h + (unsigned)((int)col[e] * HC + c0))));
+        if (leader) g_e[(unsigned)(e * H + hd)] = ga;
+      }
+      continue;
+    }
+    unsigned av[MAXD];
+#pragma unroll
+    for (int k = 0; k < MAXD; ++k) av[k] = a_h + (unsigned)(d.n[k] * HC) * 4u;
+    f32x4 hv[MAXD];
+    lds_rd128x6(av, hv);
+#pragma unroll
+    for (int k = 0; k < MAXD; ++k) {
+      const float ga = gatres_head_reduce<LH>(gatres_head_dot4(go, as_f4(hv[k])));
+      if (leader && k < d.deg) g_e[(unsigned)((d.beg + k) * H + hd)] = ga;
+    }
+  }
+}
+
+// K2 backward, destination-major sub-stage B (seg_softmax_bwd): one thread per (row, head).
+//   alpha / g_e: LDS [e][H] over the own edges; a_src: [row][H] over the window; a_dst / g_a_dst: [row][H] own rows.
+template <int H, int THREADS>
+__device__ __forceinline__ void win_softmax_bwd(Rows rw, const u16* nb, const u16* rp, const u16* col, const float* alpha,
+                                                const float* a_src, const float* a_dst, float* g_e, float* g_a_dst) {
+  const int tid = stage_tid();
+  const unsigned a_nb = lds_addr(nb), a_al = lds_addr(alpha), a_as = lds_addr(a_src), a_ad = lds_addr(a_dst),
+                 a_ge = lds_addr(g_e);
+  for (int idx0 = rw.lo * H; idx0 < rw.hi * H; idx0 += THREADS) {
+    if (idx0 + (int)(tid & ~63u) >= rw.hi * H) continue;
+    const int idx = min(idx0 + tid, rw.hi * H - 1);
+    const bool valid = idx0 + tid < rw.hi * H;
+    const int r = idx / H, hd = idx % H;
+    uint4 w;
+    float adst;
+    lds_rd128_32(a_nb + (unsigned)(r - rw.lo) * 16u, a_ad + (unsigned)(r * H + hd) * 4u, w, adst);
+    const NbrIn d = unpack_in(w);
+    float S = 0.f, gad = 0.f;
+    if (__builtin_expect(wave_has_hub(d.deg), 0)) {
+      if (valid) {
+        const int beg = rp[r], end = rp[r + 1];
+        for (int e = beg; e < end; ++e) S = fmaf(alpha[(unsigned)(e * H + hd)], g_e[(unsigned)(e * H + hd)], S);
+        for (int e = beg; e < end; ++e) {
+          const float gs = alpha[(unsigned)(e * H + hd)] * (g_e[(unsigned)(e * H + hd)] - S);
+          const float raw = a_src[(unsigned)((int)col[e] * H + hd)] + adst;
+          const float ge = raw > 0.f ? gs : gs * GATRES_NEG_SLOPE;
+          g_e[(unsigned)(e * H + hd)] = ge;
+          gad = gad + ge;
+        }
+        g_a_dst[(unsigned)(r * H + hd)] = gad;
+      }
+      continue;
+    }
+    unsigned aa[MAXD], ag[MAXD], as[MAXD];
+#pragma unroll
+    for (int k = 0; k < MAXD; ++k) {
+      const unsigned e = (unsigned)((d.beg + min(k, d.deg - 1)) * H + hd) * 4u;
+      aa[k] = a_al + e;
+      ag[k] = a_ge + e;
+      as[k] = a_as + (unsigned)(d.n[k] * H + hd) * 4u;
+    }
+    float al[MAXD], ga[MAXD], raw[MAXD];
+    lds_rd32x18(aa, ag, as, al, ga, raw);
+#pragma unroll
+    for (int k = 0; k < MAXD; ++k) {
+      raw[k] = raw[k] + adst;
+      al[k] = k < d.deg ? al[k] : 0.f;                                   // padding slots weigh nothing
+      S = fmaf(al[k], ga[k], S);
+    }
+#pragma unroll
+    for (int k = 0; k < MAXD; ++k) {
+      const float gs = al[k] * (ga[k] - S);
+      const float ge = raw[k] > 0.f ? gs : gs * GATRES_NEG_SLOPE;
+      if (valid && k < d.deg) g_e[(unsigned)((d.beg + k) * H + hd)] = ge;
+      gad = gad + ge;                                                  // ge == 0 on padding slots
+    }
+    if (valid) g_a_dst[(unsigned)(r * H + hd)] = gad;
+  }
+}
+
+// K2 backward, source-major over CSR^T (seg_agg_bwd_src).
+//   to: out-edge descriptors (x_k = window-relative edge id); g_out: [row][HC] over the window; alpha / g_e: LDS [e][H]
+//   over the WINDOW's edges; g_a_dst: [row][H] own rows; g_h: global (kept for the deferred parameter gradients, row
+//   hb + r); g_h2: LDS x operand of the dX stage.
+template <int H, int C, int THREADS>
+__device__ __forceinline__ void win_agg_bwd_src(Rows rw, const u16* to, const u16* trp, const u16* teid, const u16* tdst,
+                                                int eid_sub, const float* g_out, const float* alpha, const float* g_e,
+                                                const float* g_a_dst, const float* att_src, const float* att_dst,
+                                                float* g_h, int hb,
+                                                float* keep_gas, float* keep_gad, float* g_h2) {
+  const int tid = stage_tid();
+  constexpr int HC = H * C, G = HC / 4, RPP = THREADS / G;
+  const int c0 = (tid % G) * 4;
+  const int hd = c0 / C;
+  const unsigned a_to = lds_addr(to), a_go = lds_addr(g_out) + (unsigned)c0 * 4u,
+                 a_al = lds_addr(alpha) + (unsigned)hd * 4u, a_ge = lds_addr(g_e) + (unsigned)hd * 4u,
+                 a_gd = lds_addr(g_a_dst) + (unsigned)hd * 4u;
+  const float4 as = ld4(att_src + c0), ad = ld4(att_dst + c0);
+  for (int r0 = rw.lo; r0 < rw.hi; r0 += RPP) {
+    if (r0 + (int)((tid & ~63u) / G) >= rw.hi) continue;
+    int r = r0 + tid / G;
+    const bool valid = r < rw.hi;
+    if (!valid) r = rw.hi - 1;
+    uint4 wa, wb;
+    float gad;
+    lds_rd128x2_32(a_to + (unsigned)(r - rw.lo) * 32u, a_to + (unsigned)(r - rw.lo) * 32u + 16u,
+                   a_gd + (unsigned)(r * H) * 4u, wa, wb, gad);
+    const NbrOut d = unpack_out(wa, wb);
+    float4 acc = f4zero();
+    float gas = 0.f;
+    if (__builtin_expect(wave_has_hub(d.deg), 0)) {
+      const int beg = trp[r], end = trp[r + 1];
+      for (int t = beg; t < end; ++t) {
+        const int e = (int)teid[t] - eid_sub, ii = tdst[t];
+        gas = gas + g_e[(unsigned)(e * H + hd)];
+        gatres_axpy4(acc, alpha[(unsigned)(e * H + hd)], ld4(g_out + (unsigned)(ii * HC + c0)));
+      }
+    } else {
+      unsigned av[MAXD], aa[MAXD], ag[MAXD];
+#pragma unroll
+      for (int k = 0; k < MAXD; ++k) {
+        av[k] = a_go + (unsigned)(d.d[k] * HC) * 4u;
+        aa[k] = a_al + (unsigned)(d.x[k] * H) * 4u;
+        ag[k] = a_ge + (unsigned)(d.x[k] * H) * 4u;
+      }
+      f32x4 v[MAXD];
+      float al[MAXD], ge[MAXD];
+      lds_rd128x6_32x12(av, aa, ag, v, al, ge);
+#pragma unroll
+      for (int k = 0; k < MAXD; ++k) {
+        const bool ok = k < d.deg;
+        gas = gas + (ok ? ge[k] : 0.f);
+        gatres_axpy4(acc, ok ? al[k] : 0.f, as_f4(v[k]));
+      }
+    }
+    const bool leader = valid && (c0 % C) == 0;
+    if (leader) {                      // kept (global row hb + r) for the deferred att_src / att_dst gradients
+      keep_gas[(unsigned)((hb + r) * H + hd)] = gas;
+      keep_gad[(unsigned)((hb + r) * H + hd)] = gad;
+    }
+    gatres_axpy4(acc, gas, as);
+    gatres_axpy4(acc, gad, ad);
+    if (valid) {
+      st4(g_h + (unsigned)((hb + r) * HC + c0), acc);
+      st4(g_h2 + (unsigned)(r * HC + c0), acc);
+    }
+  }
+}
+
+}  // namespace
