@@ -30,7 +30,7 @@ class GatresGraph(C.Structure):
                 ("rowptr", C.c_void_p), ("col", C.c_void_p), ("t_rowptr", C.c_void_p), ("t_eid", C.c_void_p),
                 ("t_dst", C.c_void_p), ("m_rowptr", C.c_void_p), ("m_col", C.c_void_p), ("mt_rowptr", C.c_void_p),
                 ("mt_dst", C.c_void_p), ("seg_ptr", C.c_void_p), ("max_segment_nodes", C.c_int32),
-                ("max_segment_edges_gat", C.c_int32), ("max_segment_edges_mean", C.c_int32), ("reserved", C.c_int32),
+                ("max_segment_edges_gat", C.c_int32), ("max_segment_edges_mean", C.c_int32), ("flags", C.c_int32),
                 ("window", C.c_int32 * 21), ("reserved2", C.c_int32), ("perm", C.c_void_p),
                 ("halo", C.c_int32 * 7), ("reserved3", C.c_int32)]
 
@@ -48,6 +48,7 @@ _GP, _MP = C.POINTER(GatresGraph), C.POINTER(GatresModel)
 SIGNATURES = {
     "gatres_graph_count_host": (C.c_int, [_P, _I64, _I64, C.POINTER(_I64)]),
     "gatres_graph_build_host": (C.c_int, [_P, _I64, _I64] + [_P] * 9),
+    "gatres_graph_flags_host": (C.c_int, [_P, _I64, _I64, C.POINTER(_I32)]),
     "gatres_graph_segments_host": (C.c_int, [_P, _I64, _I64, _I32, _P] + [C.POINTER(_I32)] * 4),
     "gatres_graph_windows_host": (C.c_int, [_P, _I64, _I64, _P, _I32, _P]),
     "gatres_graph_reorder_host": (C.c_int, [_P, _I64, _I64, _P, _I32, _P]),

@@ -27,7 +27,7 @@ struct gatres_knobs_t {
   int fused_safe_sync;        // GATRES_FUSED_SAFE_SYNC: always agent-scope hand-offs (slower, never wrong)
   int fused_no_halo;          // GATRES_FUSED_NO_HALO: whole-segment kernel, bulk pulls instead of halo lists
   int fused_no_keep;          // GATRES_FUSED_NO_KEEP
-  int fused_two_kernels;      // GATRES_FUSED_TWO_KERNELS: forward+loss and backward as two launches
+  int fused_heartbeat;        // GATRES_FUSED_HEARTBEAT: pace the hand-offs by heartbeat granules even on symmetric plans
   int param_grads_no_stream;  // GATRES_PARAM_GRADS_NO_STREAM
   int lin_bwd_wave;           // GATRES_LIN_BWD_WAVE
   int proj_rows;              // GATRES_PROJ_ROWS (0: default)

@@ -70,6 +70,25 @@ extern "C" int gatres_graph_build_host(const int64_t* ei, int64_t E, int64_t N, 
   return 0;
 }
 
+// GATRES_GRAPH_SYMMETRIC: the set of non-loop edges equals its reverse (multiplicities do not matter: a part needs a
+// partner's row if ANY edge joins them in that direction).
+extern "C" int gatres_graph_flags_host(const int64_t* ei, int64_t E, int64_t N, int32_t* flags_out) {
+  if ((!ei && E > 0) || !flags_out || E < 0 || N <= 0) return GATRES_E_BADARG;
+  std::vector<uint64_t> key;
+  key.reserve((size_t)E);
+  for (int64_t e = 0; e < E; ++e) {
+    const int64_t s = ei[e], d = ei[E + e];
+    if (s < 0 || s >= N || d < 0 || d >= N) return GATRES_E_GRAPH;
+    if (s != d) key.push_back(((uint64_t)s << 32) | (uint64_t)d);
+  }
+  std::sort(key.begin(), key.end());
+  bool sym = true;
+  for (size_t i = 0; i < key.size() && sym; ++i)
+    sym = std::binary_search(key.begin(), key.end(), (key[i] << 32) | (key[i] >> 32));
+  *flags_out = sym ? GATRES_GRAPH_SYMMETRIC : 0;
+  return 0;
+}
+
 // Segments: cut after node i iff no edge joins a node <= i with a node > i.  A PyG Batch yields one segment per
 // snapshot (or finer, if a snapshot is disconnected); neighbours smaller than `merge_upto` are then coalesced so a
 // workgroup never gets a degenerate handful of nodes.

@@ -64,6 +64,7 @@ struct FusedArgs {
   int keep_lds;             // window kernel, forward + backward in one launch: ReLU sign masks and own-row g_pre stay in LDS
   int no_halo;              // diagnostic (GATRES_FUSED_NO_HALO=1): always take the bulk-pull fallback
   int C;                    // consumer workgroups per segment (deferred parameter gradients on spare CUs), 0 = none
+  int sym;                  // the plan's GATRES_GRAPH_SYMMETRIC: partners owe each other halo rows in both directions
   unsigned* ready;          // [segment][4] lines: items published by the segment's part 0 for each consumer
   unsigned long long* xch;  // window kernel: granule exchange regions, one per segment (Layout::sc_xch)
   XchLayout XL;

@@ -53,6 +53,10 @@ __global__ __launch_bounds__(THREADS) void gatres_window_kernel(const FusedArgs 
   xc.dead = GATRES_DIAG && (a.no_halo & 2) != 0;      // diagnostic (GATRES_XCH_NOWAIT=1, WRONG results): never wait for a partner -- what
                                        // the launch would take if every hand-off were free
   xc.ep = (unsigned)uni((int)__hip_atomic_load(grp.flags + part * FLAG_STRIDE + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+  const XchBuf xbuf = xch_buffer(xc.base, XL.total);
+  // pacing of the hand-offs by heartbeat granules: only when the plan does not promise two-sided halos; store drain at
+  // every hand-off: only when consumer workgroups read this part's tables in the same launch (xch_after)
+  const bool pace = !a.sym, drain = a.C > 0;
   // first wave that issues LDS-DMA inside MFMA stages: the waves below it own a 16-row tile there (dma_copy16)
   const int dw0 = min((ow + 15) >> 4, THREADS / 64 - 4);
   constexpr int WL_FLOATS = 2 * NC * (2 * NC + 4) + 4 * NC;
@@ -180,11 +184,9 @@ __global__ __launch_bounds__(THREADS) void gatres_window_kernel(const FusedArgs 
       dma_land(dw0);
       lds_barrier();                              // own rows of h1 / a_src are in LDS; the saved copies drain meanwhile
       ++xc.ep;                                    // exchange F1: the gathers below read h1 / a_src of neighbour rows
-      xch_export<2 * NC, THREADS>(xc, elist, ecnt, hA, xc.base + XL.f1h);
-      xch_export<2, THREADS>(xc, elist, ecnt, sa2, xc.base + XL.f1a);
-      xch_import<2 * NC, THREADS>(xc, hlist, hcnt, xc.base + XL.f1h, hA);
-      xch_import<2, THREADS>(xc, hlist, hcnt, xc.base + XL.f1a, sa2);
-      xch_heartbeat<THREADS>(xc, 0);
+      xch_export2<2 * NC, 2, THREADS>(xc, xbuf, elist, ecnt, hA, (unsigned)XL.f1h, elist, ecnt, sa2, (unsigned)XL.f1a);
+      xch_import2<2 * NC, 2, THREADS>(xc, xbuf, hlist, hcnt, (unsigned)XL.f1h, hA, hlist, hcnt, (unsigned)XL.f1a, sa2);
+      xch_after<THREADS>(xc, pace, drain);
       lds_barrier();
       STAMP();
       // K2 conv1: alpha -> HBM + the h2 window's LDS (dead now), then the gather (o1 -> HBM + the x buffer of proj2).
@@ -213,11 +215,9 @@ __global__ __launch_bounds__(THREADS) void gatres_window_kernel(const FusedArgs 
       dma_land(dw0);
       lds_barrier();
       ++xc.ep;                                    // exchange F2
-      xch_export<NC, THREADS>(xc, elist, ecnt, hB, xc.base + XL.f2h);
-      xch_export<1, THREADS>(xc, elist, ecnt, sa1, xc.base + XL.f2a);
-      xch_import<NC, THREADS>(xc, hlist, hcnt, xc.base + XL.f2h, hB);
-      xch_import<1, THREADS>(xc, hlist, hcnt, xc.base + XL.f2a, sa1);
-      xch_heartbeat<THREADS>(xc, 1);
+      xch_export2<NC, 1, THREADS>(xc, xbuf, elist, ecnt, hB, (unsigned)XL.f2h, elist, ecnt, sa1, (unsigned)XL.f2a);
+      xch_import2<NC, 1, THREADS>(xc, xbuf, hlist, hcnt, (unsigned)XL.f2h, hB, hlist, hcnt, (unsigned)XL.f2a, sa1);
+      xch_after<THREADS>(xc, pace, drain);
       lds_barrier();
       STAMP();
       // K2 conv2: alpha's LDS table in the upper half of the h1 window, y2 in the lower half
@@ -234,9 +234,9 @@ __global__ __launch_bounds__(THREADS) void gatres_window_kernel(const FusedArgs 
       }
       lds_barrier();
       ++xc.ep;                                    // exchange F3: K3 averages y2 over neighbour rows
-      xch_export<NC, THREADS>(xc, elist, ecnt, y2T, xc.base + XL.f3);
-      xch_import<NC, THREADS>(xc, hlist, hcnt, xc.base + XL.f3, y2T);
-      xch_heartbeat<THREADS>(xc, 2);
+      xch_export2<NC, 0, THREADS>(xc, xbuf, elist, ecnt, y2T, (unsigned)XL.f3, elist, 0, y2T, 0u);
+      xch_import2<NC, 0, THREADS>(xc, xbuf, hlist, hcnt, (unsigned)XL.f3, y2T, hlist, 0, 0u, y2T);
+      xch_after<THREADS>(xc, pace, drain);
       lds_barrier();
       STAMP();
       // K3: residual from the x buffer, result back into it (and to HBM: saved xin of the next block)
@@ -404,37 +404,31 @@ __global__ __launch_bounds__(THREADS) void gatres_window_kernel(const FusedArgs 
       lds_barrier();                             // own rows of g_pre are in LDS (lin1 backward / the previous dX1)
       XSTAMP();
       ++xc.ep;                                   // exchange B1: K3 backward gathers g_pre of neighbour rows
-      xch_export<NC, THREADS>(xc, erow, ercnt, gpT, xc.base + XL.b1);
+      xch_export2<NC, 0, THREADS>(xc, xbuf, erow, ercnt, gpT, (unsigned)XL.b1, erow, 0, gpT, 0u);
       XSTAMP();
-      xch_import<NC, THREADS>(xc, hrow, hcnt, xc.base + XL.b1, gpT);
+      xch_import2<NC, 0, THREADS>(xc, xbuf, hrow, hcnt, (unsigned)XL.b1, gpT, hrow, 0, 0u, gpT);
       XSTAMP();
-      xch_heartbeat<THREADS>(xc, 3);
+      xch_after<THREADS>(xc, pace, drain);
       XSTAMP();
       lds_barrier();
       XSTAMP();
       publish_items<THREADS>(a, seg, part, 2 * (L.nb - 1 - b), grp.local, false);      // the blocks above are kept
-      win_mean_bwd<NC, THREADS>(rw, mout, mrp, mtrp, mtdsto, gpT, gy2T);
-      lds_barrier();
-      XSTAMP();
+      // K3 backward, conv2's edge dots and softmax backward: one stage (win_bwd_dst)
       STAMP();
       float* keep = sc + L.sc_keep + (int64_t)b * L.keep_stride;
       float* gh = keep + L.k_gh1;
       float* gh2 = keep + L.k_gh2;
-      win_edge_dots<1, NC, THREADS>(rw, nbin, rp, colo, gy2T, hT2, ge2 + elo);
+      win_bwd_dst<true, 1, NC, THREADS>(rw, nbin, rp, colo, gy2T, hT2, alT2 + elo, asT2, adT2, ge2 + elo, gad2, mout, mrp, mtrp,
+                                        mtdsto, gpT);
       lds_barrier();
       XSTAMP();
-      seg_bias_part<NC, THREADS>(rw, gy2T, 0, red);
-      win_softmax_bwd<1, THREADS>(rw, nbin, rp, colo, alT2 + elo, asT2, adT2, ge2 + elo, gad2);
-      lds_barrier();
-      XSTAMP();
+      seg_bias_part<NC, THREADS>(rw, gy2T, 0, red);        // (own rows of g_y2: the sweep below only writes halo rows)
       ++xc.ep;                                   // exchange B2: the source-major stage reads g_y2 / g_e of neighbour rows
-      xch_export<NC, THREADS>(xc, erow, ercnt, gy2T, xc.base + XL.b2y);
-      xch_export<1, THREADS>(xc, eedge, eecnt, ge2, xc.base + XL.b2e);
+      xch_export2<NC, 1, THREADS>(xc, xbuf, erow, ercnt, gy2T, (unsigned)XL.b2y, eedge, eecnt, ge2, (unsigned)XL.b2e);
       XSTAMP();
-      xch_import<NC, THREADS>(xc, hrow, hcnt, xc.base + XL.b2y, gy2T);
-      xch_import<1, THREADS>(xc, hedge, hcnt, xc.base + XL.b2e, ge2);
+      xch_import2<NC, 1, THREADS>(xc, xbuf, hrow, hcnt, (unsigned)XL.b2y, gy2T, hedge, hcnt, (unsigned)XL.b2e, ge2);
       XSTAMP();
-      xch_heartbeat<THREADS>(xc, 4);
+      xch_after<THREADS>(xc, pace, drain);
       XSTAMP();
       lds_barrier();
       XSTAMP();
@@ -459,21 +453,17 @@ __global__ __launch_bounds__(THREADS) void gatres_window_kernel(const FusedArgs 
       __syncthreads();
       XSTAMP();
       STAMP();
-      win_edge_dots<2, NC, THREADS>(rw, nbin, rp, colo, RA, hT1, ge1 + elo * 2);
-      lds_barrier();
-      XSTAMP();
       seg_bias_part<2 * NC, THREADS>(rw, RA, 0, red);
-      win_softmax_bwd<2, THREADS>(rw, nbin, rp, colo, alT1 + elo * 2, asT1, adT1, ge1 + elo * 2, gad1);
+      win_bwd_dst<false, 2, NC, THREADS>(rw, nbin, rp, colo, RA, hT1, alT1 + elo * 2, asT1, adT1, ge1 + elo * 2, gad1, nullptr,
+                                         nullptr, nullptr, nullptr, nullptr);
       lds_barrier();
       XSTAMP();
       ++xc.ep;                                   // exchange B3
-      xch_export<2 * NC, THREADS>(xc, erow, ercnt, RA, xc.base + XL.b3o);
-      xch_export<2, THREADS>(xc, eedge, eecnt, ge1, xc.base + XL.b3e);
+      xch_export2<2 * NC, 2, THREADS>(xc, xbuf, erow, ercnt, RA, (unsigned)XL.b3o, eedge, eecnt, ge1, (unsigned)XL.b3e);
       XSTAMP();
-      xch_import<2 * NC, THREADS>(xc, hrow, hcnt, xc.base + XL.b3o, RA);
-      xch_import<2, THREADS>(xc, hedge, hcnt, xc.base + XL.b3e, ge1);
+      xch_import2<2 * NC, 2, THREADS>(xc, xbuf, hrow, hcnt, (unsigned)XL.b3o, RA, hedge, hcnt, (unsigned)XL.b3e, ge1);
       XSTAMP();
-      xch_heartbeat<THREADS>(xc, 5);
+      xch_after<THREADS>(xc, pace, drain);
       XSTAMP();
       lds_barrier();
       XSTAMP();

@@ -125,6 +125,133 @@ __device__ __forceinline__ float4 as_f4(const uint4 v) {
   return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
 }
 
+// ---------------------------------------------------------------------------------------------- granule exchange, 16-byte form
+// The hand-offs of k_fused_dev.h (xch_export / xch_import: one 8-byte {value, epoch} granule per memory instruction, one
+// table per call) restated for the window kernel:
+//   * TWO granules per access -- {v0, ep, v1, ep} is one 16-byte store / load; each 8-byte half still carries its own
+//     tag, so a 16-byte access that the memory system splits is harmless (MI355X_MICROARCH.md: R2's granule, "also for
+//     16-B sc1 halves") -- half the memory instructions per exchange;
+//   * the row table and the small per-row / per-edge table of an exchange point go through ONE sweep: their polls are in
+//     flight together (two calls were two dependent L2 round trips);
+//   * accesses are raw-buffer builtins on one descriptor of the segment's exchange region (the compiler counts them:
+//     no hand-written waits), loads `sc1` (never served from this CU's L1), stores plain when every part of the segment
+//     sits on one XCD (the line stays in that L2) and `sc1` (write-through) otherwise -- as gran_store / gran_load.
+typedef unsigned v4u __attribute__((ext_vector_type(4)));
+struct XchBuf {
+  __amdgpu_buffer_rsrc_t r;
+};
+__device__ __forceinline__ XchBuf xch_buffer(u64* base, long long granules) {
+  XchBuf b;
+  b.r = __builtin_amdgcn_make_buffer_rsrc(base, 0, (int)(granules * 8), 0x00020000);
+  return b;
+}
+// one listed row / edge of a table W wide = P accesses of E elements
+template <int W> struct XchGeom {
+  static constexpr int E = W >= 2 ? 2 : 1, P = W >= 2 ? W / 2 : (W == 1 ? 1 : 0);
+  static_assert(W <= 1 || W % 2 == 0, "row width");
+};
+
+// tables 1 and 2 (either list may be the same): src: LDS table by the same index; t1 / t2: the tables' first granule
+template <int W1, int W2, int THREADS>
+__device__ __forceinline__ void xch_export2(const Xch& x, const XchBuf& xb, const u16* l1, int c1, const float* s1, unsigned t1,
+                                            const u16* l2, int c2, const float* s2, unsigned t2) {
+  constexpr int P1 = XchGeom<W1>::P, P2 = XchGeom<W2>::P, E1 = XchGeom<W1>::E, E2 = XchGeom<W2>::E;
+  const int tid = stage_tid();
+  const int n1 = c1 * P1, total = n1 + c2 * P2;
+  for (int k = tid; k < total; k += THREADS) {
+    const bool first = k < n1;
+    const int kk = first ? k : k - n1;
+    int o, two;
+    const float* src;
+    unsigned tb;
+    if (first) { o = (int)l1[kk / P1] * W1 + E1 * (kk % P1); two = E1 == 2; src = s1; tb = t1; }
+    else       { o = (int)l2[kk / (P2 ? P2 : 1)] * W2 + E2 * (kk % (P2 ? P2 : 1)); two = E2 == 2; src = s2; tb = t2; }
+    const float v0 = src[o], v1 = two ? src[o + 1] : 0.f;
+    const unsigned off = (tb + (unsigned)o) * 8u;
+    if (two) {
+      const v4u g = {__float_as_uint(v0), x.ep, __float_as_uint(v1), x.ep};
+      if (x.local) __builtin_amdgcn_raw_buffer_store_b128(g, xb.r, off, 0, 0);
+      else         __builtin_amdgcn_raw_buffer_store_b128(g, xb.r, off, 0, 16);
+    } else {
+      typedef unsigned v2u __attribute__((ext_vector_type(2)));
+      const v2u g = {__float_as_uint(v0), x.ep};
+      if (x.local) __builtin_amdgcn_raw_buffer_store_b64(g, xb.r, off, 0, 0);
+      else         __builtin_amdgcn_raw_buffer_store_b64(g, xb.r, off, 0, 16);
+    }
+  }
+}
+
+// granules of every listed row / edge of both tables -> the LDS tables, re-read until their tags carry this exchange's epoch
+template <int W1, int W2, int THREADS>
+__device__ __forceinline__ void xch_import2(Xch& x, const XchBuf& xb, const u16* l1, int c1, unsigned t1, float* d1,
+                                            const u16* l2, int c2, unsigned t2, float* d2) {
+  constexpr int P1 = XchGeom<W1>::P, P2 = XchGeom<W2>::P, E1 = XchGeom<W1>::E, E2 = XchGeom<W2>::E;
+  constexpr int U = 2;
+  const int tid = stage_tid();
+  const int n1 = c1 * P1, total = n1 + c2 * P2;
+  for (int base = 0; base < total; base += U * THREADS) {
+    if (base + (tid & ~63) >= total) continue;                             // nothing left for this wave
+    int o[U];
+    bool valid[U], two[U], first[U];
+    unsigned off[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int k = base + u * THREADS + tid;
+      valid[u] = k < total;
+      first[u] = k < n1;
+      const int kk = first[u] ? k : k - n1;
+      if (!valid[u])     { o[u] = 0; two[u] = false; off[u] = 0; }
+      else if (first[u]) { o[u] = (int)l1[kk / P1] * W1 + E1 * (kk % P1); two[u] = E1 == 2; off[u] = (t1 + (unsigned)o[u]) * 8u; }
+      else               { o[u] = (int)l2[kk / (P2 ? P2 : 1)] * W2 + E2 * (kk % (P2 ? P2 : 1)); two[u] = E2 == 2; off[u] = (t2 + (unsigned)o[u]) * 8u; }
+    }
+    v4u v[U];
+    int spin = 0;
+    for (;;) {
+      bool ok = true;
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+        if (valid[u]) v[u] = __builtin_amdgcn_raw_buffer_load_b128(xb.r, off[u], 0, 16);
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+        ok = ok && (!valid[u] || (v[u].y == x.ep && (!two[u] || v[u].w == x.ep)));
+      if (__all(ok || x.dead)) break;
+      if (++spin > SPIN_LIMIT) { *x.err = 1; x.dead = true; }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+      if (valid[u]) {
+        float* d = first[u] ? d1 : d2;
+        d[o[u]] = __uint_as_float(v[u].x);
+        if (two[u]) d[o[u] + 1] = __uint_as_float(v[u].z);
+      }
+  }
+}
+
+// After a part's sweep.  pace: announce "exchange ep is behind me" and wait until every other part has announced exchange
+// ep - 1 (k_fused_dev.h: xch_heartbeat) -- needed only when the plan cannot promise that partners owe each other rows in
+// both directions (GATRES_GRAPH_SYMMETRIC: then a part cannot reach the exchange that rewrites a cell before the cell's
+// readers have passed the exchange in between, because that one needs THEIR granules, which they store after their own
+// sweep).  drain: every wave waits for its outstanding global stores, so that the barrier that follows publishes them to
+// the consumer workgroups (publish_items) -- needed only in launches that have consumers.
+template <int THREADS>
+__device__ __forceinline__ void xch_after(Xch& x, bool pace, bool drain) {
+  if (pace) {
+    u64* hb = x.base_hb;
+    if (threadIdx.x == 0) gran_store(hb + x.part, 0.f, x.ep, x.local);
+    const int lane = (int)threadIdx.x - (THREADS - 64);                 // the last wave polls: lanes 0 .. M-1, one part each
+    if (lane >= 0) {
+      const bool mine = lane < x.M && lane != x.part;
+      int spin = 0;
+      for (;;) {
+        const bool ok = !mine || x.dead || (int)((unsigned)(gran_load(hb + lane) >> 32) - (x.ep - 1u)) >= 0;
+        if (__all(ok)) break;
+        if (++spin > SPIN_LIMIT) { *x.err = 1; x.dead = true; }
+      }
+    }
+  }
+  if (drain) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
 // ---------------------------------------------------------------------------------------------- neighbour descriptors
 // In-edge descriptor of an own row (GATConv graph or SimpleConv graph), 8 x u16 = one ds_read_b128:
 //   {beg, deg, n0 .. n5}: beg = the row's first edge (own-edge-relative index), deg = its in-degree, n_k = local id of the
@@ -513,6 +640,129 @@ __device__ __forceinline__ void win_softmax_bwd(Rows rw, const u16* nb, const u1
       gad = gad + ge;                                                  // ge == 0 on padding slots
     }
     if (valid) g_a_dst[(unsigned)(r * H + hd)] = gad;
+  }
+}
+
+// K2 backward, destination-major, BOTH sub-stages in one (win_edge_dots + win_softmax_bwd without the barrier and the LDS
+// hop between them): after the head reduction every lane of a head holds all of the row's edge dots, so the lanes compute
+// S, g_e and g_a_dst redundantly (no exp, no divide: ~40 VALU instructions) and the head's first lane stores them.
+// MEAN (conv2 only, H == 1): the stage starts with K3 backward (win_mean_bwd) for the same row -- its result g_y2[r] is
+// the g_out operand of the edge dots, held by the same lanes -- so  B1 exchange -> [K3 bwd, edge dots, softmax bwd] -> B2
+// exchange  is ONE stage.  g_out_rw: [row][HC] over the window (shifted view): read (MEAN = false) or written (MEAN).
+template <bool MEAN, int H, int C, int THREADS>
+__device__ __forceinline__ void win_bwd_dst(Rows rw, const u16* nb, const u16* rp, const u16* col, float* g_out_rw,
+                                            const float* h, const float* alpha, const float* a_src, const float* a_dst,
+                                            float* g_e, float* g_a_dst,
+                                            const u16* mo, const u16* mrp, const u16* mtrp, const u16* mtdst,
+                                            const float* g_pre) {
+  static_assert(!MEAN || H == 1, "K3 runs at conv2's width");
+  const int tid = stage_tid();
+  constexpr int HC = H * C, G = HC / 4, LH = C / 4, RPP = THREADS / G;
+  const int c0 = (tid % G) * 4;
+  const int hd = c0 / C;
+  const unsigned a_nb = lds_addr(nb), a_go = lds_addr(g_out_rw) + (unsigned)c0 * 4u, a_h = lds_addr(h) + (unsigned)c0 * 4u,
+                 a_al = lds_addr(alpha) + (unsigned)hd * 4u, a_as = lds_addr(a_src) + (unsigned)hd * 4u,
+                 a_ad = lds_addr(a_dst) + (unsigned)hd * 4u;
+  for (int r0 = rw.lo; r0 < rw.hi; r0 += RPP) {
+    if (r0 + (int)((tid & ~63u) / G) >= rw.hi) continue;
+    int r = r0 + tid / G;
+    const bool valid = r < rw.hi;          // every lane stays in the loop: the head reduction spans the head's lanes
+    if (!valid) r = rw.hi - 1;
+    const bool leader = valid && (c0 % C) == 0;
+    float4 go;
+    NbrIn d;
+    float adst;
+    if constexpr (MEAN) {
+      const unsigned a_mo = lds_addr(mo) + (unsigned)(r - rw.lo) * 32u;
+      uint4 wa, wb, w;
+      asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:16\n\tds_read_b128 %2, %5\n\tds_read_b32 %3, %6\n\t"
+                   "s_waitcnt lgkmcnt(0)"
+                   : "=&v"(wa), "=&v"(wb), "=&v"(w), "=&v"(adst)
+                   : "v"(a_mo), "v"(a_nb + (unsigned)(r - rw.lo) * 16u), "v"(a_ad + (unsigned)(r * H) * 4u)
+                   : "memory");
+      const NbrOut od = unpack_out(wa, wb);
+      d = unpack_in(w);
+      float4 acc = f4zero();
+      if (__builtin_expect(wave_has_hub(od.deg), 0)) {
+        const int beg = mtrp[r], end = mtrp[r + 1];
+        for (int t = beg; t < end; ++t) {
+          const int ii = mtdst[t];
+          const float cnt = (float)max((int)mrp[ii + 1] - (int)mrp[ii], 1);
+          const float4 v = ld4(g_pre + (unsigned)(ii * C + c0));
+          acc.x = acc.x + v.x / cnt; acc.y = acc.y + v.y / cnt;
+          acc.z = acc.z + v.z / cnt; acc.w = acc.w + v.w / cnt;
+        }
+      } else {
+        const unsigned a_g = lds_addr(g_pre) + (unsigned)c0 * 4u;
+        unsigned av[MAXD];
+#pragma unroll
+        for (int k = 0; k < MAXD; ++k) av[k] = a_g + (unsigned)(od.d[k] * C) * 4u;
+        f32x4 v[MAXD];
+        lds_rd128x6(av, v);
+#pragma unroll
+        for (int k = 0; k < MAXD; ++k) {
+          const float w1 = k < od.deg ? 1.f : 0.f;                      // x + 0 * q == x exactly
+          const float cnt = (float)od.x[k];
+          acc.x = fmaf(w1, v[k][0] / cnt, acc.x); acc.y = fmaf(w1, v[k][1] / cnt, acc.y);
+          acc.z = fmaf(w1, v[k][2] / cnt, acc.z); acc.w = fmaf(w1, v[k][3] / cnt, acc.w);
+        }
+      }
+      go = acc;
+      if (valid) st4(g_out_rw + (unsigned)(r * HC + c0), acc);
+    } else {
+      uint4 w, gw;
+      lds_rd128x2_32(a_nb + (unsigned)(r - rw.lo) * 16u, a_go + (unsigned)(r * HC) * 4u, a_ad + (unsigned)(r * H) * 4u, w,
+                     gw, adst);
+      d = unpack_in(w);
+      go = as_f4(gw);
+    }
+    if (__builtin_expect(wave_has_hub(d.deg), 0)) {
+      // edge at a time: the dots of the row through LDS (written and read by lanes of this wave, in program order)
+      const int beg = rp[r], end = rp[r + 1];
+      for (int e = beg; e < end; ++e) {
+        const float ga = gatres_head_reduce<LH>(gatres_head_dot4(go, ld4(h + (unsigned)((int)col[e] * HC + c0))));
+        if (leader) g_e[(unsigned)(e * H + hd)] = ga;
+      }
+      if (leader) {
+        float S = 0.f, gad = 0.f;
+        for (int e = beg; e < end; ++e) S = fmaf(alpha[(unsigned)(e * H + hd)], g_e[(unsigned)(e * H + hd)], S);
+        for (int e = beg; e < end; ++e) {
+          const float gs = alpha[(unsigned)(e * H + hd)] * (g_e[(unsigned)(e * H + hd)] - S);
+          const float raw = a_src[(unsigned)((int)col[e] * H + hd)] + adst;
+          const float ge = raw > 0.f ? gs : gs * GATRES_NEG_SLOPE;
+          g_e[(unsigned)(e * H + hd)] = ge;
+          gad = gad + ge;
+        }
+        g_a_dst[(unsigned)(r * H + hd)] = gad;
+      }
+      continue;
+    }
+    unsigned av[MAXD], aa[MAXD], as[MAXD];
+#pragma unroll
+    for (int k = 0; k < MAXD; ++k) {
+      av[k] = a_h + (unsigned)(d.n[k] * HC) * 4u;
+      aa[k] = a_al + (unsigned)((d.beg + min(k, d.deg - 1)) * H) * 4u;
+      as[k] = a_as + (unsigned)(d.n[k] * H) * 4u;
+    }
+    f32x4 hv[MAXD];
+    float al[MAXD], raw[MAXD], ga[MAXD];
+    lds_rd128x6_32x12(av, aa, as, hv, al, raw);
+    float S = 0.f, gad = 0.f;
+#pragma unroll
+    for (int k = 0; k < MAXD; ++k) {
+      ga[k] = gatres_head_reduce<LH>(gatres_head_dot4(go, as_f4(hv[k])));
+      raw[k] = raw[k] + adst;
+      al[k] = k < d.deg ? al[k] : 0.f;                                   // padding slots weigh nothing
+      S = fmaf(al[k], ga[k], S);
+    }
+#pragma unroll
+    for (int k = 0; k < MAXD; ++k) {
+      const float gs = al[k] * (ga[k] - S);
+      const float ge = raw[k] > 0.f ? gs : gs * GATRES_NEG_SLOPE;
+      if (leader && k < d.deg) g_e[(unsigned)((d.beg + k) * H + hd)] = ge;
+      gad = gad + ge;                                                  // ge == 0 on padding slots
+    }
+    if (leader) g_a_dst[(unsigned)(r * H + hd)] = gad;
   }
 }
 

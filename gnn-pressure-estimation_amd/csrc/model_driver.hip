@@ -47,7 +47,7 @@ extern "C" int32_t gatres_num_slabs(const gatres_model_t* m, int32_t num_nodes) 
   return make_layout(m, num_nodes, 0, 0, 0, 0, &L) ? L.num_slabs : GATRES_E_UNSUPPORTED;
 }
 
-extern "C" const char* gatres_version(void) { return "gatres-gfx950 abi2"; }
+extern "C" const char* gatres_version(void) { return "gatres-gfx950 abi3"; }
 
 extern "C" int gatres_model_forward(const gatres_model_t* m, const gatres_graph_t* g, const float* params,
                                     const float* x, const uint8_t* mask, float* out, float* saved, float* scratch,

@@ -39,6 +39,9 @@ class GraphPlan:
         e_gat = C.c_int64(0)
         _native.check(lib.gatres_graph_count_host(ei_host.data_ptr(), E, N, C.byref(e_gat)), "gatres_graph_count_host")
         Eg = int(e_gat.value)
+        gflags = C.c_int32(0)          # (properties of the edge SET: a relabelling of the nodes does not change them)
+        _native.check(lib.gatres_graph_flags_host(ei_host.data_ptr(), E, N, C.byref(gflags)), "gatres_graph_flags_host")
+        self.flags = int(gflags.value)
         i32 = dict(dtype=torch.int32)
         # segment table first: it does not depend on the labelling inside a segment, the relabelling below needs it
         self.num_segments, self.max_segment_nodes = 0, 0
@@ -100,7 +103,8 @@ class GraphPlan:
             perm_dev_ptr = self.arrays["perm"].data_ptr()
         self.c = _native.GatresGraph(N, Eg, E, self.num_segments, *[self.arrays[k].data_ptr() for k in host.keys()],
                                      seg_dev_ptr, self.max_segment_nodes, self.max_segment_edges_gat,
-                                     self.max_segment_edges_mean, 0, (C.c_int32 * 21)(*self.windows[:21]), 0, perm_dev_ptr,
+                                     self.max_segment_edges_mean, self.flags, (C.c_int32 * 21)(*self.windows[:21]), 0,
+                                     perm_dev_ptr,
                                      (C.c_int32 * 7)(*self.windows[21:28]), 0)
 
     def ref(self):

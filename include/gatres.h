@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define GATRES_ABI_VERSION 2
+#define GATRES_ABI_VERSION 3
 
 #define GATRES_E_BADARG      (-1)  /* null pointer, negative size, misaligned pointer            */
 #define GATRES_E_UNSUPPORTED (-2)  /* width not supported by the gfx950 kernels                  */
@@ -67,7 +67,7 @@ typedef struct gatres_graph {
   int32_t max_segment_nodes;
   int32_t max_segment_edges_gat;   /* most GATConv edges (self loops included) inside one segment */
   int32_t max_segment_edges_mean;  /* most SimpleConv edges inside one segment                    */
-  int32_t reserved;
+  int32_t flags;            /* GATRES_GRAPH_* bits from gatres_graph_flags_host (0 = nothing known)        */
   /* Row windows of split segments, from gatres_graph_windows_host: window[M - 2] = {rows, GATConv edges, SimpleConv
    * edges} for M = 2 .. 8 workgroups per segment.  All zero = unknown (the fused kernels then size their LDS tables by
    * the whole segment). */
@@ -86,6 +86,12 @@ typedef struct gatres_graph {
   int32_t reserved3;
 } gatres_graph_t;
 
+/* gatres_graph_t.flags */
+#define GATRES_GRAPH_SYMMETRIC 1   /* every edge (u, v), u != v, has its reverse (v, u) in edge_index -- what
+                                    * pgu.from_networkx gives for an undirected water network (utils/DataLoader.py:29).  The parts
+                                    * of a split segment then owe each other halo rows in BOTH directions at every hand-off,
+                                    * which paces them without the heartbeat granules (k_fused_dev.h: xch_heartbeat). */
+
 /* Host-side plan builder (runs on the CPU, once per topology).  edge_index_host: int64 [2, E] row-major as
  * torch stores it.  Step 1: count -> E'.  Step 2: fill caller-allocated HOST arrays sized from that count. */
 int gatres_graph_count_host(const int64_t* edge_index_host, int64_t num_edges, int64_t num_nodes,
@@ -93,6 +99,9 @@ int gatres_graph_count_host(const int64_t* edge_index_host, int64_t num_edges, i
 int gatres_graph_build_host(const int64_t* edge_index_host, int64_t num_edges, int64_t num_nodes,
                             int32_t* rowptr, int32_t* col, int32_t* t_rowptr, int32_t* t_eid, int32_t* t_dst,
                             int32_t* m_rowptr, int32_t* m_col, int32_t* mt_rowptr, int32_t* mt_dst);
+
+/* Properties of the edge list the kernels may rely on (host): *flags_out = OR of GATRES_GRAPH_* bits. */
+int gatres_graph_flags_host(const int64_t* edge_index_host, int64_t num_edges, int64_t num_nodes, int32_t* flags_out);
 
 /* Segment table (host): the finest partition of [0, N) into contiguous ranges closed under the edges, adjacent
  * ranges merged while the result stays <= merge_upto nodes.  seg_ptr_host must hold N + 1 entries. */

@@ -29,7 +29,7 @@ print('shader clock MHz ~', (clk[1] - clk[0]) / ((clk[2] - s[0]) / 100.0))
 d = (s[1:] - s[:-1]) / 100.0   # us
 print("stamps", len(s), "total us", (s[-1] - s[0]) / 100.0)
 names_f = ["proj1", "agg1", "proj2", "agg2", "mean"]
-names_b = ["mean_bwd", "dst2", "src2", "dx2", "dst1", "src1", "dx1"]
+names_b = ["xch_b1", "k3+dst2", "src2", "dx2", "dst1", "src1", "dx1"]
 i = 0
 print("lin0 %.2f" % d[i]); i += 1
 acc = {}
@@ -61,9 +61,9 @@ if len(cs) >= 2:
 
 # one backward block of segment 0, every part, wave 0 / last wave (k_fused.hip XSTAMP)
 xs = raw[2048:2048 + 16 * 64].reshape(16, 64)
-names_x = ["top", "bar", "B1 export", "B1 import", "B1 heartbeat", "bar", "mean_bwd+bar", "edge_dots2+bar", "softmax_bwd2+bar",
-           "B2 export", "B2 import", "B2 heartbeat", "bar", "agg_src2+bar", "dX2+sync", "edge_dots1+bar", "softmax_bwd1+bar",
-           "B3 export", "B3 import", "B3 heartbeat", "bar", "agg_src1+bar", "dX1"]
+names_x = ["top", "bar", "B1 export", "B1 import", "B1 after", "bar", "k3+dots2+smax2+bar",
+           "B2 export", "B2 import", "B2 after", "bar", "agg_src2+bar", "dX2+sync", "dots1+smax1+bar",
+           "B3 export", "B3 import", "B3 after", "bar", "agg_src1+bar", "dX1"]
 if xs[0, 0] > 0:
     t0 = min(int(xs[r, 0]) for r in range(16) if xs[r, 0] > 0)
     print("\none backward block, times in us since the first part entered it; columns: part p wave 0 | last wave")
