@@ -10,6 +10,12 @@ namespace {
 __device__ __forceinline__ void dma_land(int w0) {
   if ((int)__builtin_amdgcn_readfirstlane(threadIdx.x >> 6) >= w0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
+// n floats (n % 4 == 0, n <= 256) of small per-convolution vectors -> the tail of a W slot, by the last LDS-DMA wave
+template <int THREADS>
+__device__ __forceinline__ void vec_prefetch(float* dst, const float* __restrict__ src, int n) {
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  if (wave == THREADS / 64 - 1 && lane * 4 < n) __builtin_amdgcn_global_load_lds(src + lane * 4, dst, 16, 0, 0);
+}
 __device__ __forceinline__ u16* align16(u16* p) {
   return reinterpret_cast<u16*>((reinterpret_cast<uintptr_t>(p) + 15) & ~(uintptr_t)15);
 }
@@ -61,6 +67,12 @@ __global__ __launch_bounds__(THREADS) void gatres_window_kernel(const FusedArgs 
   const int dw0 = min((ow + 15) >> 4, THREADS / 64 - 4);
   constexpr int WL_FLOATS = 2 * NC * (2 * NC + 4) + 4 * NC;
   constexpr int WLB = (WL_FLOATS + 3) & ~3;
+  // small vectors in the tails of the W slots (filled by LDS-DMA with the slot's matrix: no stage starts with a global load)
+  constexpr int B1OFF = 2 * NC * (NC + 4) + 4 * NC;      // forward, slot A: conv1's bias behind W1 | att_src | att_dst
+  constexpr int B2OFF = NC * (2 * NC + 4) + 2 * NC;      // forward, slot B: conv2's bias
+  constexpr int A2OFF = 2 * NC * (NC + 4);               // backward, slot A: conv2's att_src | att_dst behind W2^T
+  constexpr int A1OFF = NC * (2 * NC + 4);               // backward, slot B: conv1's att_src | att_dst behind W1^T
+  static_assert(B1OFF + 2 * NC <= WLB && B2OFF + NC <= WLB && A2OFF + 2 * NC <= WLB && A1OFF + 4 * NC <= WLB, "W slot tails");
   const float* P = a.params;
   float* sc = a.scratch;
   // a.keep_lds: the top of LDS carries the ReLU sign masks from the forward to the backward phase of this launch
@@ -145,6 +157,7 @@ __global__ __launch_bounds__(THREADS) void gatres_window_kernel(const FusedArgs 
     if (L.nb > 0) {
       const float* pb0 = P + L.p_block0;
       w_prefetch<NC, 2 * NC, EPI_ATT, THREADS>(wlA, pb0 + L.c1_W, pb0 + L.c1_as, pb0 + L.c1_ad, 0);
+      vec_prefetch<THREADS>(wlA + B1OFF, pb0 + L.c1_b, 2 * NC);
     }
     {  // lin0 (+ the caller-side x[mask] = 0)
       const float* w = P + L.p_lin0_w;
@@ -175,29 +188,34 @@ __global__ __launch_bounds__(THREADS) void gatres_window_kernel(const FusedArgs 
       float* base = segbase + (int64_t)b * SL.bstride;
       float* xnext = segbase + (int64_t)(b + 1) * SL.bstride + SL.xin;
       const float* pb = P + L.p_block0 + (int64_t)b * L.p_block_stride;
-      // LDS-DMA rides on the MFMA stages (the longest ones; a DMA has to land before its host stage's closing barrier):
-      // W2 of this block while proj1 runs, W1 of the next block while proj2 runs
+      // LDS-DMA rides on the MFMA stages, issued by their tile-less waves: W2 | att | bias of this block while proj1 runs,
+      // W1 | att | bias of the next block while proj2 runs
       w_prefetch<2 * NC, NC, EPI_ATT, THREADS>(wlB, pb + L.c2_W, pb + L.c2_as, pb + L.c2_ad, dw0);
+      vec_prefetch<THREADS>(wlB + B2OFF, pb + L.c2_b, NC);
       seg_proj<NC, 2 * NC, 2, EPI_ATT, THREADS, true, true>(rw, xA, 0, pb + L.c1_W, base + SL.h1, 0, hA, 0, pb + L.c1_as,
-                                                        pb + L.c1_ad, base + SL.as1, base + SL.ad1, 0, sa2, sd2,
-                                                        nullptr, 0, nullptr, 0, wlA);
+                                                             pb + L.c1_ad, base + SL.as1, base + SL.ad1, 0, sa2, sd2,
+                                                             nullptr, 0, nullptr, 0, wlA);
       dma_land(dw0);
-      lds_barrier();                              // own rows of h1 / a_src are in LDS; the saved copies drain meanwhile
+      lds_barrier();                                      // own rows of h1 / a_src are in LDS; the saved copies drain meanwhile
       ++xc.ep;                                    // exchange F1: the gathers below read h1 / a_src of neighbour rows
       xch_export2<2 * NC, 2, THREADS>(xc, xbuf, elist, ecnt, hA, (unsigned)XL.f1h, elist, ecnt, sa2, (unsigned)XL.f1a);
       xch_import2<2 * NC, 2, THREADS>(xc, xbuf, hlist, hcnt, (unsigned)XL.f1h, hA, hlist, hcnt, (unsigned)XL.f1a, sa2);
       xch_after<THREADS>(xc, pace, drain);
       lds_barrier();
       STAMP();
-      // K2 conv1: alpha -> HBM + the h2 window's LDS (dead now), then the gather (o1 -> HBM + the x buffer of proj2).
-      // (Coefficients computed INSIDE the exchange -- softmax threads reading a partner's a_src straight from its granule
-      // while the other waves sweep h1 in, one barrier less -- was measured: 545 -> 557 us per launch, and 28 KB of code.)
+      // K2 conv1: alpha -> HBM, the gather's o1 -> HBM + the x buffer of proj2
       if (__builtin_expect(2 * oeg <= wr * NC, 1)) {
-        win_softmax<2, THREADS>(rw, nbin, rp, colo, sa2, sd2, base + SL.al1, elo, hBw);
-        lds_barrier();
-        win_gather<true, 2, NC, THREADS>(rw, nbin, rp, colo, hA, hBw, pb + L.c1_b, base + SL.o1, 0, xB,
-                                         mo1 ? mo1 + b * ow : nullptr);
+        if constexpr (NC == 32) {
+          win_fwd_agg<true, 2, NC, THREADS>(rw, nbin, rp, colo, hA, sa2, sd2, base + SL.al1, elo, hBw, wlA + B1OFF,
+                                                 base + SL.o1, 0, xB, mo1 ? mo1 + b * ow : nullptr);
+        } else {
+          win_softmax<2, THREADS>(rw, nbin, rp, colo, sa2, sd2, base + SL.al1, elo, hBw);
+          lds_barrier();
+          win_gather<true, 2, NC, THREADS>(rw, nbin, rp, colo, hA, hBw, wlA + B1OFF, base + SL.o1, 0, xB,
+                                           mo1 ? mo1 + b * ow : nullptr);
+        }
       } else {
+        dma_land(dw0);                            // (every wave reads LDS below)
         seg_softmax<2, false, THREADS>(rw, rp, colo, sa2, sd2, 0, base + SL.al1, elo, nullptr);
         __syncthreads();
         seg_gather<true, 2, NC, THREADS, 1>(rw, rp, colo, hA, 0, base + SL.al1, elo, pb + L.c1_b, base + SL.o1, 0, xB, 0,
@@ -208,10 +226,11 @@ __global__ __launch_bounds__(THREADS) void gatres_window_kernel(const FusedArgs 
       if (b + 1 < L.nb) {
         const float* pn = pb + L.p_block_stride;
         w_prefetch<NC, 2 * NC, EPI_ATT, THREADS>(wlA, pn + L.c1_W, pn + L.c1_as, pn + L.c1_ad, dw0);
+        vec_prefetch<THREADS>(wlA + B1OFF, pn + L.c1_b, 2 * NC);
       }
       seg_proj<2 * NC, NC, 1, EPI_ATT, THREADS, true, true>(rw, xB, 0, pb + L.c2_W, base + SL.h2, 0, hB, 0, pb + L.c2_as,
-                                                        pb + L.c2_ad, base + SL.as2, base + SL.ad2, 0, sa1, sd1,
-                                                        nullptr, 0, nullptr, 0, wlB);
+                                                             pb + L.c2_ad, base + SL.as2, base + SL.ad2, 0, sa1, sd1,
+                                                             nullptr, 0, nullptr, 0, wlB);
       dma_land(dw0);
       lds_barrier();
       ++xc.ep;                                    // exchange F2
@@ -220,14 +239,20 @@ __global__ __launch_bounds__(THREADS) void gatres_window_kernel(const FusedArgs 
       xch_after<THREADS>(xc, pace, drain);
       lds_barrier();
       STAMP();
-      // K2 conv2: alpha's LDS table in the upper half of the h1 window, y2 in the lower half
+      // K2 conv2: y2 in the lower half of the h1 window (its upper half: the alpha table of rows beyond the slot path)
       float* y2T = hAw - wlo * NC;
       if (__builtin_expect(oeg <= wr * NC, 1)) {
         float* al2L = hAw + (size_t)wr * NC;
-        win_softmax<1, THREADS>(rw, nbin, rp, colo, sa1, sd1, base + SL.al2, elo, al2L);
-        lds_barrier();
-        win_gather<false, 1, NC, THREADS>(rw, nbin, rp, colo, hB, al2L, pb + L.c2_b, y2T, 0, nullptr, nullptr);
+        if constexpr (NC == 32) {
+          win_fwd_agg<false, 1, NC, THREADS>(rw, nbin, rp, colo, hB, sa1, sd1, base + SL.al2, elo, al2L, wlB + B2OFF, y2T,
+                                                  0, nullptr, nullptr);
+        } else {
+          win_softmax<1, THREADS>(rw, nbin, rp, colo, sa1, sd1, base + SL.al2, elo, al2L);
+          lds_barrier();
+          win_gather<false, 1, NC, THREADS>(rw, nbin, rp, colo, hB, al2L, wlB + B2OFF, y2T, 0, nullptr, nullptr);
+        }
       } else {
+        dma_land(dw0);
         seg_softmax<1, false, THREADS>(rw, rp, colo, sa1, sd1, 0, base + SL.al2, elo, nullptr);
         __syncthreads();
         seg_gather<false, 1, NC, THREADS, 1>(rw, rp, colo, hB, 0, base + SL.al2, elo, pb + L.c2_b, y2T, 0);
@@ -241,7 +266,7 @@ __global__ __launch_bounds__(THREADS) void gatres_window_kernel(const FusedArgs 
       STAMP();
       // K3: residual from the x buffer, result back into it (and to HBM: saved xin of the next block)
       win_mean_fwd<NC, THREADS>(rw, mbin, mrp, mcolo, y2T, xA, xnext, xA,
-                                (mxin && b + 1 < L.nb) ? mxin + (b + 1) * ow : nullptr);
+                                     (mxin && b + 1 < L.nb) ? mxin + (b + 1) * ow : nullptr);
       lds_barrier();
       STAMP();
       xcur = xnext;
@@ -358,15 +383,25 @@ __global__ __launch_bounds__(THREADS) void gatres_window_kernel(const FusedArgs 
     // LDS-DMA of saved tables (independent of the backward chain) and transposed weights always rides on an MFMA
     // stage or, for the first block, on this prologue: conv2 tables + W2^T of block b during dX1 of block b + 1,
     // conv1 tables + W1^T of block b during dX2 of block b.
-    auto dma_conv2 = [&](int blk, int w0) {
+    // LDS-DMA of the saved tables (independent of the backward chain) rides on the dX stages, issued by their tile-less
+    // waves, which wait for it to land before the stage's closing barrier.  Every CU streams at the same moments, so a
+    // transfer costs its bytes over the CU's share of HBM (~25 GB/s: 1.3 us for conv1's 32 KB).  Measured in round 3
+    // and NOT kept: issuing it one or two stages earlier (in the hand-off: the sweeps queue behind the streams, +1.5 us
+    // per hand-off; in the source-major stage: that stage grows by what dX shrinks), and dedicated loader waves behind
+    // bare barriers (the issue itself is what takes the time: the CU accepts ~12 B per cycle).
+    auto dma_conv2_early = [&](int blk, int w0) {
       const float* bs = segbase + (int64_t)blk * SL.bstride;
       dma_copy16<THREADS>(hTw, bs + SL.h2 + (size_t)wlo * NC, wr * NC, w0);
       dma_copy4<THREADS>(asTw, bs + SL.as2 + wlo, wr, w0);
       dma_copy4<THREADS>(adTo, bs + SL.ad2 + lo, ow, w0);
-      dma_copy4<THREADS>(alTw, bs + SL.al2 + ewlo, weg, w0);
       w_prefetch<NC, 2 * NC, EPI_RESID_MASK, THREADS>(wlA, a.wt + (int64_t)blk * 2 * w + w, nullptr, nullptr, w0);
+      vec_prefetch<THREADS>(wlA + A2OFF, P + L.p_block0 + (int64_t)blk * L.p_block_stride + L.c2_as, 2 * NC);
     };
-    if (L.nb > 0) dma_conv2(L.nb - 1, 0);
+    auto dma_conv2_late = [&](int blk, int w0) {
+      const float* bs = segbase + (int64_t)blk * SL.bstride;
+      dma_copy4<THREADS>(alTw, bs + SL.al2 + ewlo, weg, w0);
+    };
+    if (L.nb > 0) { dma_conv2_early(L.nb - 1, 0); dma_conv2_late(L.nb - 1, 0); }
     seg_lin1_bwd<NC, THREADS>(rw, n0, a.perm, a.g_out, xfinal, P + L.p_lin1_w, gp_cur, gpT, slab + L.p_lin1_w,
                               slab + L.p_lin1_b, L.nb > 0 ? 1 : 0, red, gkeep);
     dma_land(0);
@@ -401,7 +436,7 @@ __global__ __launch_bounds__(THREADS) void gatres_window_kernel(const FusedArgs 
       [[maybe_unused]] const bool xs_on = STAMPS_PTR && a.stamp_cap >= 4096 && seg == 0 && b == L.nb / 2;
       [[maybe_unused]] int xs_i = 0;
       XSTAMP();
-      lds_barrier();                             // own rows of g_pre are in LDS (lin1 backward / the previous dX1)
+      lds_barrier();                                     // own rows of g_pre are in LDS (lin1 backward / the previous dX1)
       XSTAMP();
       ++xc.ep;                                   // exchange B1: K3 backward gathers g_pre of neighbour rows
       xch_export2<NC, 0, THREADS>(xc, xbuf, erow, ercnt, gpT, (unsigned)XL.b1, erow, 0, gpT, 0u);
@@ -418,11 +453,11 @@ __global__ __launch_bounds__(THREADS) void gatres_window_kernel(const FusedArgs 
       float* keep = sc + L.sc_keep + (int64_t)b * L.keep_stride;
       float* gh = keep + L.k_gh1;
       float* gh2 = keep + L.k_gh2;
-      win_bwd_dst<true, 1, NC, THREADS>(rw, nbin, rp, colo, gy2T, hT2, alT2 + elo, asT2, adT2, ge2 + elo, gad2, mout, mrp, mtrp,
-                                        mtdsto, gpT);
+      win_bwd_dst<true, 1, NC, THREADS>(rw, nbin, rp, colo, gy2T, hT2, alT2 + elo, asT2, adT2, ge2 + elo, gad2, mout, mrp,
+                                             mtrp, mtdsto, gpT);
       lds_barrier();
       XSTAMP();
-      seg_bias_part<NC, THREADS>(rw, gy2T, 0, red);        // (own rows of g_y2: the sweep below only writes halo rows)
+      seg_bias_part<NC, THREADS>(rw, gy2T, 0, red);  // (own rows of g_y2: the sweep below only writes halo rows)
       ++xc.ep;                                   // exchange B2: the source-major stage reads g_y2 / g_e of neighbour rows
       xch_export2<NC, 1, THREADS>(xc, xbuf, erow, ercnt, gy2T, (unsigned)XL.b2y, eedge, eecnt, ge2, (unsigned)XL.b2e);
       XSTAMP();
@@ -433,29 +468,33 @@ __global__ __launch_bounds__(THREADS) void gatres_window_kernel(const FusedArgs 
       lds_barrier();
       XSTAMP();
       STAMP();
+      // this block's conv1 tables and W1^T stream in while the matrix cores run dX2 (below)
+      auto dma_conv1_early = [&]() {
+        w_prefetch<2 * NC, NC, EPI_RESID_MASK, THREADS>(wlB, wt1, nullptr, nullptr, dw0);
+        vec_prefetch<THREADS>(wlB + A1OFF, pb + L.c1_as, 4 * NC);
+        dma_copy16<THREADS>(hTw, base + SL.h1 + (size_t)wlo * 2 * NC, wr * 2 * NC, dw0);
+        dma_copy4<THREADS>(asTw, base + SL.as1 + wlo * 2, wr * 2, dw0);
+        dma_copy4<THREADS>(adTo, base + SL.ad1 + lo * 2, ow * 2, dw0);
+      };
       seg_bias_finish<NC, THREADS>(red, sb + L.c2_b);
-      win_agg_bwd_src<1, NC, THREADS>(rw, tout, trp, teido, tdsto, 0, gy2T, alT2, ge2, gad2, pb + L.c2_as, pb + L.c2_ad,
-                                      gh2, n0, keep + L.k_gas2, keep + L.k_gad2, xG2);
-      lds_barrier();           // g_y2 (RA) and the conv2 tables are dead
+      win_agg_bwd_src<1, NC, THREADS>(rw, tout, trp, teido, tdsto, 0, gy2T, alT2, ge2, gad2, wlA + A2OFF, wlA + A2OFF + NC,
+                                           gh2, n0, keep + L.k_gas2, keep + L.k_gad2, xG2);
+      lds_barrier();                   // g_y2 (RA) and the conv2 tables are dead
       XSTAMP();
       STAMP();
-      // LDS-DMA of this block's conv1 tables and W1^T while the matrix cores run dX2
-      w_prefetch<2 * NC, NC, EPI_RESID_MASK, THREADS>(wlB, wt1, nullptr, nullptr, dw0);
-      dma_copy16<THREADS>(hTw, base + SL.h1 + (size_t)wlo * 2 * NC, wr * 2 * NC, dw0);
-      dma_copy4<THREADS>(asTw, base + SL.as1 + wlo * 2, wr * 2, dw0);
-      dma_copy4<THREADS>(adTo, base + SL.ad1 + lo * 2, ow * 2, dw0);
-      dma_copy4<THREADS>(alTw, base + SL.al1 + ewlo * 2, weg * 2, dw0);
-      seg_proj<NC, 2 * NC, 1, EPI_RESID_MASK, THREADS, true, true>(rw, xG2, 0, wt2, RA, 0, nullptr, 0,
-                                                               nullptr, nullptr, nullptr, nullptr, 0, nullptr, nullptr,
-                                                               nullptr, 0, (GATRES_DIAG && (a.no_halo & 4)) ? nullptr : base + SL.o1, 0, wlA,
-                                                               nullptr, nullptr, mo1 ? mo1 + b * ow : nullptr, nullptr);
-      dma_land(dw0);
+      dma_conv1_early();
+      dma_copy4<THREADS>(alTw, base + SL.al1 + ewlo * 2, weg * 2, dw0);      // conv1's alpha (its table held conv2's until here)
+      seg_proj<NC, 2 * NC, 1, EPI_RESID_MASK, THREADS, true, true>(
+          rw, xG2, 0, wt2, RA, 0, nullptr, 0, nullptr, nullptr, nullptr, nullptr, 0, nullptr, nullptr, nullptr, 0,
+          (GATRES_DIAG && (a.no_halo & 4)) ? nullptr : base + SL.o1, 0, wlA, nullptr, nullptr, mo1 ? mo1 + b * ow : nullptr,
+          nullptr);
+      dma_land(dw0);                             // the conv1 tables: the destination-major stage is next
       __syncthreads();
       XSTAMP();
       STAMP();
       seg_bias_part<2 * NC, THREADS>(rw, RA, 0, red);
-      win_bwd_dst<false, 2, NC, THREADS>(rw, nbin, rp, colo, RA, hT1, alT1 + elo * 2, asT1, adT1, ge1 + elo * 2, gad1, nullptr,
-                                         nullptr, nullptr, nullptr, nullptr);
+      win_bwd_dst<false, 2, NC, THREADS>(rw, nbin, rp, colo, RA, hT1, alT1 + elo * 2, asT1, adT1, ge1 + elo * 2, gad1,
+                                              nullptr, nullptr, nullptr, nullptr, nullptr);
       lds_barrier();
       XSTAMP();
       ++xc.ep;                                   // exchange B3
@@ -470,17 +509,17 @@ __global__ __launch_bounds__(THREADS) void gatres_window_kernel(const FusedArgs 
       publish_items<THREADS>(a, seg, part, 2 * (L.nb - 1 - b) + 1, grp.local, false);      // conv2 tables complete
       STAMP();
       seg_bias_finish<2 * NC, THREADS>(red, sb + L.c1_b);
-      win_agg_bwd_src<2, NC, THREADS>(rw, tout, trp, teido, tdsto, 0, RA, alT1, ge1, gad1, pb + L.c1_as, pb + L.c1_ad,
-                                      gh, n0, keep + L.k_gas1, keep + L.k_gad1, xG1);
+      win_agg_bwd_src<2, NC, THREADS>(rw, tout, trp, teido, tdsto, 0, RA, alT1, ge1, gad1, wlB + A1OFF, wlB + A1OFF + 2 * NC,
+                                           gh, n0, keep + L.k_gas1, keep + L.k_gad1, xG1);
       lds_barrier();
       XSTAMP();
       STAMP();
-      if (b > 0) dma_conv2(b - 1, dw0);
-      seg_proj<2 * NC, NC, 1, EPI_RESID_MASK, THREADS, true, true>(rw, xG1, 0, wt1, gp_nxt, n0, gpT, 0, nullptr, nullptr,
-                                                               nullptr, nullptr, 0, nullptr, nullptr,
-                                                               (GATRES_DIAG && (a.no_halo & 4)) ? nullptr : gp_cur, n0,
-                                                               (b > 0 && !(GATRES_DIAG && (a.no_halo & 4))) ? base + SL.xin : nullptr, 0, wlB,
-                                                               gkeep, gkeep, nullptr, (mxin && b > 0) ? mxin + b * ow : nullptr);
+      if (b > 0) { dma_conv2_early(b - 1, dw0); dma_conv2_late(b - 1, dw0); }
+      seg_proj<2 * NC, NC, 1, EPI_RESID_MASK, THREADS, true, true>(
+          rw, xG1, 0, wt1, gp_nxt, n0, gpT, 0, nullptr, nullptr, nullptr, nullptr, 0, nullptr, nullptr,
+          (GATRES_DIAG && (a.no_halo & 4)) ? nullptr : gp_cur, n0,
+          (b > 0 && !(GATRES_DIAG && (a.no_halo & 4))) ? base + SL.xin : nullptr, 0, wlB, gkeep, gkeep, nullptr,
+          (mxin && b > 0) ? mxin + b * ow : nullptr);
       dma_land(dw0);
       XSTAMP();
       STAMP();

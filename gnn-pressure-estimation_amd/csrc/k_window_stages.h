@@ -450,6 +450,116 @@ __device__ __forceinline__ void win_gather(Rows rw, const u16* nb, const u16* rp
   }
 }
 
+// K2 forward, BOTH sub-stages in one (win_softmax + win_gather without the barrier, the stage entry and the alpha table
+// between them), for heads of 32 channels = 8 lanes: lane j of a head's lane group owns edge slot j (slots 6 and 7 idle).
+// It forms the slot's logit and ONE exp; the maximum runs over the group by DPP (exact in any order); the six exponentials
+// go round the group (ds_swizzle: the LDS crossbar, no memory) so that every lane adds them up in CSR order -- the same
+// ((((e0 + e1) + e2) + e3) + e4) + e5 as the thread-per-head form, bit for bit -- ; ONE divide per lane, the coefficients
+// go round once more, and every lane weighs its four columns of the six neighbour rows it loaded at the start.
+// (All lanes of a head recomputing all six coefficients was measured in rounds 1 and 2: slower than two stages.)
+//   alpha_l: LDS table [e][H], used only by waves that hold a row with more than MAXD edges.
+template <int K> __device__ __forceinline__ float group8_bcast(float v) {
+  return __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(v), 0x18 | (K << 5)));      // lane (l & 0x18) | K
+}
+template <bool RELU, int H, int C, int THREADS>
+__device__ __forceinline__ void win_fwd_agg(Rows rw, const u16* nb, const u16* rp, const u16* col, const float* hsrc,
+                                            const float* asrc, const float* adst_t, float* __restrict__ alpha_g, int eb,
+                                            float* alpha_l, const float* bias, float* out, int ob, float* out_pub,
+                                            unsigned long long* mask64) {
+  static_assert(C == 32 && MAXD <= 8, "one edge slot per lane of a head's eight lanes");
+  const int tid = stage_tid();
+  constexpr int HC = H * C, G = HC / 4, LH = C / 4, RPP = THREADS / G;
+  const int c0 = (tid % G) * 4;
+  const int hd = c0 / C;
+  const int j = tid % LH;                                            // this lane's edge slot
+  const unsigned a_nb = lds_addr(nb), a_h = lds_addr(hsrc) + (unsigned)c0 * 4u, a_as = lds_addr(asrc) + (unsigned)hd * 4u,
+                 a_ad = lds_addr(adst_t) + (unsigned)hd * 4u;
+  const float4 b = ld4(bias + c0);
+  for (int r0 = rw.lo; r0 < rw.hi; r0 += RPP) {
+    if (r0 + (int)((tid & ~63u) / G) >= rw.hi) continue;      // no row of this trip for this wave
+    int r = r0 + tid / G;
+    const bool valid = r < rw.hi;
+    if (!valid) r = rw.hi - 1;
+    uint4 w;
+    float adst;
+    lds_rd128_32(a_nb + (unsigned)(r - rw.lo) * 16u, a_ad + (unsigned)(r * H) * 4u, w, adst);
+    const NbrIn d = unpack_in(w);
+    float4 acc = f4zero();
+    if (__builtin_expect(wave_has_hub(d.deg), 0)) {
+      // edge at a time: the head's first lane forms the coefficients (seg_softmax's loops), through the LDS table
+      const int beg = rp[r], end = rp[r + 1];
+      if (c0 % C == 0) {
+        auto at = [&](int e) -> float { return asrc[(unsigned)((int)col[e] * H + hd)]; };
+        float m = -INFINITY;
+        for (int e = beg; e < end; ++e) m = fmaxf(m, gatres_leaky(at(e) + adst));
+        float Z = 0.f;
+        for (int e = beg; e < end; ++e) Z = Z + expf(gatres_leaky(at(e) + adst) - m);
+        Z = Z + GATRES_SOFTMAX_EPS;
+        for (int e = beg; e < end; ++e) {
+          const float al = expf(gatres_leaky(at(e) + adst) - m) / Z;
+          if (valid) alpha_g[(unsigned)((eb + e) * H + hd)] = al;
+          alpha_l[e * H + hd] = al;
+        }
+      }
+      for (int e = beg; e < end; ++e)
+        gatres_axpy4(acc, alpha_l[(unsigned)(e * H + hd)], ld4(hsrc + (unsigned)((int)col[e] * HC + c0)));
+    } else {
+      // this lane's slot: source row n_j (slots 6, 7: n_5, never used)
+      const int jj = min(j, MAXD - 1);
+      const unsigned wsel = jj < 2 ? w.y : (jj < 4 ? w.z : w.w);
+      const int nj = (int)((jj & 1) ? (wsel >> 16) : (wsel & 0xffffu));
+      unsigned av[MAXD];
+#pragma unroll
+      for (int k = 0; k < MAXD; ++k) av[k] = a_h + (unsigned)(d.n[k] * HC) * 4u;
+      f32x4 v[MAXD];
+      float asj;
+      asm volatile(
+          "ds_read_b128 %0, %7\n\tds_read_b128 %1, %8\n\tds_read_b128 %2, %9\n\t"
+          "ds_read_b128 %3, %10\n\tds_read_b128 %4, %11\n\tds_read_b128 %5, %12\n\tds_read_b32 %6, %13\n\t"
+          "s_waitcnt lgkmcnt(0)"
+          : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]), "=&v"(v[4]), "=&v"(v[5]), "=&v"(asj)
+          : "v"(av[0]), "v"(av[1]), "v"(av[2]), "v"(av[3]), "v"(av[4]), "v"(av[5]), "v"(a_as + (unsigned)(nj * H) * 4u)
+          : "memory");
+      const float sv = gatres_leaky(asj + adst);
+      const float so = j < d.deg ? sv : -INFINITY;
+      float m = so;
+      m = fmaxf(m, gatres_dpp<0xB1>(m));       // quad_perm [1,0,3,2]
+      m = fmaxf(m, gatres_dpp<0x4E>(m));       // quad_perm [2,3,0,1]
+      m = fmaxf(m, gatres_dpp<0x141>(m));      // row_half_mirror
+      const float ex = expf(so - m);           // exp(-inf) = 0 on padding slots
+      float e[MAXD];
+      e[0] = group8_bcast<0>(ex); e[1] = group8_bcast<1>(ex); e[2] = group8_bcast<2>(ex);
+      e[3] = group8_bcast<3>(ex); e[4] = group8_bcast<4>(ex); e[5] = group8_bcast<5>(ex);
+      float Z = 0.f;
+#pragma unroll
+      for (int k = 0; k < MAXD; ++k) Z = Z + e[k];
+      Z = Z + GATRES_SOFTMAX_EPS;
+      const float alj = ex / Z;
+      if (valid && j < d.deg) alpha_g[(unsigned)((eb + d.beg + j) * H + hd)] = alj;
+      float al[MAXD];
+      al[0] = group8_bcast<0>(alj); al[1] = group8_bcast<1>(alj); al[2] = group8_bcast<2>(alj);
+      al[3] = group8_bcast<3>(alj); al[4] = group8_bcast<4>(alj); al[5] = group8_bcast<5>(alj);
+#pragma unroll
+      for (int k = 0; k < MAXD; ++k) gatres_axpy4(acc, k < d.deg ? al[k] : 0.f, as_f4(v[k]));     // 0 on padding
+    }
+    add4(acc, b);
+    if (RELU) {
+      acc.x = fmaxf(acc.x, 0.f); acc.y = fmaxf(acc.y, 0.f);
+      acc.z = fmaxf(acc.z, 0.f); acc.w = fmaxf(acc.w, 0.f);
+    }
+    if (valid) {
+      st4(out + (unsigned)((ob + r) * HC + c0), acc);
+      if (out_pub) st4(out_pub + (unsigned)(r * HC + c0), acc);
+    }
+    if constexpr (RELU && G <= 16) {
+      if (mask64) {                                             // (workgroup-uniform)
+        const unsigned long long mw = relu_bits<G, 16>(acc);
+        if (valid && tid % G == 0) mask64[r] = mw;
+      }
+    }
+  }
+}
+
 // K3 forward (seg_mean_fwd): out = relu(mean_{j->r} y[j] + x0[r]).
 template <int C, int THREADS>
 __device__ __forceinline__ void win_mean_fwd(Rows rw, const u16* mb, const u16* mrp, const u16* mcol, const float* y,
