@@ -32,7 +32,8 @@ class GatresGraph(C.Structure):
                 ("mt_dst", C.c_void_p), ("seg_ptr", C.c_void_p), ("max_segment_nodes", C.c_int32),
                 ("max_segment_edges_gat", C.c_int32), ("max_segment_edges_mean", C.c_int32), ("flags", C.c_int32),
                 ("window", C.c_int32 * 21), ("reserved2", C.c_int32), ("perm", C.c_void_p),
-                ("halo", C.c_int32 * 7), ("reserved3", C.c_int32)]
+                ("halo", C.c_int32 * 7), ("reserved3", C.c_int32),
+                ("part_tables", C.c_void_p), ("part_tables_m", C.c_int32), ("part_tables_stride", C.c_int32)]
 
 
 class GatresModel(C.Structure):
@@ -49,6 +50,7 @@ SIGNATURES = {
     "gatres_graph_count_host": (C.c_int, [_P, _I64, _I64, C.POINTER(_I64)]),
     "gatres_graph_build_host": (C.c_int, [_P, _I64, _I64] + [_P] * 9),
     "gatres_graph_flags_host": (C.c_int, [_P, _I64, _I64, C.POINTER(_I32)]),
+    "gatres_graph_part_tables_host": (C.c_int, [_P] * 10 + [_I32, _I32, _P, _I64, C.POINTER(_I64)]),
     "gatres_graph_segments_host": (C.c_int, [_P, _I64, _I64, _I32, _P] + [C.POINTER(_I32)] * 4),
     "gatres_graph_windows_host": (C.c_int, [_P, _I64, _I64, _P, _I32, _P]),
     "gatres_graph_reorder_host": (C.c_int, [_P, _I64, _I64, _P, _I32, _P]),

@@ -216,6 +216,177 @@ extern "C" int gatres_graph_windows_host(const int64_t* ei, int64_t E, int64_t N
   return 0;
 }
 
+// Part tables of split segments (gatres_graph_t.part_tables): everything the window kernel's two prologues used to derive
+// from the CSR arrays in every launch -- the part's row window, its edge ranges, 16-bit local copies of its CSR slices, the
+// padded edge descriptors of its rows (k_window_stages.h) and its hand-off lists -- built ONCE per (plan, M) on the host
+// and copied into LDS by the kernel (the topology of a WDN batch never changes: train.py:302-303 collates the same
+// edge_index every iteration).  Hand-off lists are de-duplicated here (the in-kernel builder kept one entry per edge).
+// Layout of one part (int32 words; u16 tables are padded to whole words):
+//   [0 .. GATRES_PT_HEADER)   header, see the enum below
+//   forward image             rpo | colo | mrpo | mcolo | pad to 16 B | nbin | mbin            (the LDS image, verbatim)
+//   backward image            rpo | colo | trpo | teido | tdsto | mrpw | mtrpo | mtdsto | pad | nbin | tout | mout
+//   lists                     f_hlist, f_elist, b_hrow, b_hedge, b_erow, b_eedge
+namespace {
+inline int even_i(int v) { return (v + 1) & ~1; }
+struct PartGeom {
+  int n0, n, e0, em0, t0, mt0, lo, hi, wlo, whi, elo, oeg, ewlo, weg, melo, oem, tlo, otg, mtlo, otm;
+};
+constexpr int PT_MAXD = 6;      // k_fused_dev.h: MAXD
+}  // namespace
+
+extern "C" int gatres_graph_part_tables_host(const int32_t* rowptr, const int32_t* col, const int32_t* t_rowptr,
+                                             const int32_t* t_eid, const int32_t* t_dst, const int32_t* m_rowptr,
+                                             const int32_t* m_col, const int32_t* mt_rowptr, const int32_t* mt_dst,
+                                             const int32_t* seg_ptr, int32_t num_segments, int32_t M, int32_t* out,
+                                             int64_t stride_words, int64_t* stride_words_out) {
+  if (!rowptr || !col || !t_rowptr || !t_eid || !t_dst || !m_rowptr || !m_col || !mt_rowptr || !mt_dst || !seg_ptr ||
+      num_segments <= 0 || M < 2 || M > 8 || !stride_words_out)
+    return GATRES_E_BADARG;
+  int64_t need = 0;
+  std::vector<uint16_t> img;
+  std::vector<int32_t> words;
+  for (int32_t s = 0; s < num_segments; ++s) {
+    PartGeom g;
+    g.n0 = seg_ptr[s]; g.n = seg_ptr[s + 1] - g.n0;
+    g.e0 = rowptr[g.n0]; g.em0 = m_rowptr[g.n0]; g.t0 = t_rowptr[g.n0]; g.mt0 = mt_rowptr[g.n0];
+    if (g.n > 65535 || rowptr[g.n0 + g.n] - g.e0 > 65535 || m_rowptr[g.n0 + g.n] - g.em0 > 65535) return GATRES_E_UNSUPPORTED;
+    const int tiles = (g.n + 15) >> 4;
+    for (int p = 0; p < M; ++p) {
+      g.lo = 16 * (int)((long long)tiles * p / M);
+      g.hi = std::min(g.n, 16 * (int)((long long)tiles * (p + 1) / M));
+      if (g.hi < g.lo) g.hi = g.lo;
+      const int ow = g.hi - g.lo;
+      int vmin = g.lo, vmax = g.hi;
+      auto widen = [&](const int32_t* ptr, const int32_t* idx) {
+        for (int e = ptr[g.n0 + g.lo]; e < ptr[g.n0 + g.hi]; ++e) {
+          const int j = idx[e] - g.n0;
+          vmin = std::min(vmin, j); vmax = std::max(vmax, j + 1);
+        }
+      };
+      widen(rowptr, col); widen(t_rowptr, t_dst); widen(m_rowptr, m_col); widen(mt_rowptr, mt_dst);
+      g.wlo = vmin; g.whi = vmax;
+      const int wr = g.whi - g.wlo;
+      g.elo = rowptr[g.n0 + g.lo] - g.e0;           g.oeg = rowptr[g.n0 + g.hi] - g.e0 - g.elo;
+      g.ewlo = rowptr[g.n0 + g.wlo] - g.e0;         g.weg = rowptr[g.n0 + g.whi] - g.e0 - g.ewlo;
+      g.melo = m_rowptr[g.n0 + g.lo] - g.em0;       g.oem = m_rowptr[g.n0 + g.hi] - g.em0 - g.melo;
+      g.tlo = t_rowptr[g.n0 + g.lo] - g.t0;         g.otg = t_rowptr[g.n0 + g.hi] - g.t0 - g.tlo;
+      g.mtlo = mt_rowptr[g.n0 + g.lo] - g.mt0;      g.otm = mt_rowptr[g.n0 + g.hi] - g.mt0 - g.mtlo;
+      // ---- 16-bit local CSR slices
+      std::vector<uint16_t> rpo(ow + 1), colo(g.oeg), mrpo(ow + 1), mcolo(g.oem), trpo(ow + 1), teido(g.otg), tdsto(g.otg),
+          mrpw(wr + 1), mtrpo(ow + 1), mtdsto(g.otm);
+      for (int r = 0; r <= ow; ++r) {
+        rpo[r] = (uint16_t)(rowptr[g.n0 + g.lo + r] - (g.e0 + g.elo));
+        mrpo[r] = (uint16_t)(m_rowptr[g.n0 + g.lo + r] - (g.em0 + g.melo));
+        trpo[r] = (uint16_t)(t_rowptr[g.n0 + g.lo + r] - (g.t0 + g.tlo));
+        mtrpo[r] = (uint16_t)(mt_rowptr[g.n0 + g.lo + r] - (g.mt0 + g.mtlo));
+      }
+      for (int k = 0; k < g.oeg; ++k) colo[k] = (uint16_t)(col[g.e0 + g.elo + k] - g.n0);
+      for (int k = 0; k < g.oem; ++k) mcolo[k] = (uint16_t)(m_col[g.em0 + g.melo + k] - g.n0);
+      for (int k = 0; k < g.otg; ++k) {
+        teido[k] = (uint16_t)(t_eid[g.t0 + g.tlo + k] - g.e0);
+        tdsto[k] = (uint16_t)(t_dst[g.t0 + g.tlo + k] - g.n0);
+      }
+      for (int r = 0; r <= wr; ++r) mrpw[r] = (uint16_t)(m_rowptr[g.n0 + g.wlo + r] - m_rowptr[g.n0 + g.wlo]);
+      for (int k = 0; k < g.otm; ++k) mtdsto[k] = (uint16_t)(mt_dst[g.mt0 + g.mtlo + k] - g.n0);
+      // ---- padded edge descriptors (k_window_stages.h: build_nbr_in / build_nbr_out)
+      std::vector<uint16_t> nbin(8 * ow), mbin(8 * ow), tout(16 * ow, 0), mout(16 * ow, 0);
+      for (int r = 0; r < ow; ++r) {
+        const int ra = g.lo + r;
+        {
+          const int beg = rpo[r], deg = (int)rpo[r + 1] - beg, elast = std::max(g.oeg - 1, 0);
+          nbin[8 * r] = (uint16_t)beg; nbin[8 * r + 1] = (uint16_t)deg;
+          for (int k = 0; k < PT_MAXD; ++k)
+            nbin[8 * r + 2 + k] = g.oeg > 0 ? colo[std::min(beg + std::min(k, std::max(deg - 1, 0)), elast)] : (uint16_t)ra;
+        }
+        {
+          const int beg = mrpo[r], deg = (int)mrpo[r + 1] - beg, elast = std::max(g.oem - 1, 0);
+          mbin[8 * r] = (uint16_t)beg; mbin[8 * r + 1] = (uint16_t)deg;
+          for (int k = 0; k < PT_MAXD; ++k) mbin[8 * r + 2 + k] = k < deg ? mcolo[std::min(beg + k, elast)] : (uint16_t)ra;
+        }
+        {
+          const int beg = trpo[r], deg = (int)trpo[r + 1] - beg, elast = std::max(g.otg - 1, 0);
+          tout[16 * r] = (uint16_t)deg;
+          for (int k = 0; k < PT_MAXD; ++k) {
+            const int kk = std::min(beg + std::min(k, std::max(deg - 1, 0)), elast);
+            tout[16 * r + 2 + k] = g.otg > 0 ? tdsto[kk] : (uint16_t)ra;
+            tout[16 * r + 8 + k] = g.otg > 0 ? teido[kk] : (uint16_t)0;
+          }
+        }
+        {
+          const int beg = mtrpo[r], deg = (int)mtrpo[r + 1] - beg, elast = std::max(g.otm - 1, 0);
+          mout[16 * r] = (uint16_t)deg;
+          for (int k = 0; k < PT_MAXD; ++k) {
+            const int kk = std::min(beg + std::min(k, std::max(deg - 1, 0)), elast);
+            const int ii = k < deg ? (int)mtdsto[kk] : ra;
+            mout[16 * r + 2 + k] = (uint16_t)ii;
+            mout[16 * r + 8 + k] = (uint16_t)std::max((int)mrpw[ii - g.wlo + 1] - (int)mrpw[ii - g.wlo], 1);
+          }
+        }
+      }
+      // ---- hand-off lists (sorted, unique)
+      auto remote = [&](int j) { return j < g.lo || j >= g.hi; };
+      std::vector<uint16_t> f_hlist, f_elist, b_hrow, b_hedge, b_erow, b_eedge;
+      for (int k = 0; k < g.oeg; ++k)
+        if (remote(colo[k])) { f_hlist.push_back(colo[k]); b_eedge.push_back((uint16_t)(g.elo + k)); }
+      for (int r = 0; r < ow; ++r) {
+        bool out_remote = false, in_remote = false;
+        for (int t = trpo[r]; t < trpo[r + 1]; ++t) out_remote = out_remote || remote(tdsto[t]);
+        for (int e = rpo[r]; e < rpo[r + 1]; ++e) in_remote = in_remote || remote(colo[e]);
+        if (out_remote) f_elist.push_back((uint16_t)(g.lo + r));
+        if (in_remote) b_erow.push_back((uint16_t)(g.lo + r));
+      }
+      for (int t = 0; t < g.otg; ++t)
+        if (remote(tdsto[t])) { b_hrow.push_back(tdsto[t]); b_hedge.push_back(teido[t]); }
+      auto uniq = [](std::vector<uint16_t>& v) { std::sort(v.begin(), v.end()); v.erase(std::unique(v.begin(), v.end()), v.end()); };
+      uniq(f_hlist); uniq(b_hrow); uniq(b_hedge);
+      // ---- assemble
+      img.clear();
+      auto put = [&](const std::vector<uint16_t>& v, int padded) {
+        img.insert(img.end(), v.begin(), v.end());
+        img.resize(img.size() + (size_t)(padded - (int)v.size()), 0);
+      };
+      auto pad16 = [&](size_t from) { while ((img.size() - from) % 8) img.push_back(0); };
+      int32_t hdr[GATRES_PT_HEADER] = {0};
+      hdr[GATRES_PT_MAGIC] = GATRES_PT_MAGIC_VALUE; hdr[GATRES_PT_M] = M;
+      hdr[GATRES_PT_N0] = g.n0; hdr[GATRES_PT_N] = g.n; hdr[GATRES_PT_E0] = g.e0; hdr[GATRES_PT_EM0] = g.em0;
+      hdr[GATRES_PT_T0] = g.t0; hdr[GATRES_PT_MT0] = g.mt0; hdr[GATRES_PT_LO] = g.lo; hdr[GATRES_PT_HI] = g.hi;
+      hdr[GATRES_PT_WLO] = g.wlo; hdr[GATRES_PT_WHI] = g.whi; hdr[GATRES_PT_ELO] = g.elo; hdr[GATRES_PT_OEG] = g.oeg;
+      hdr[GATRES_PT_EWLO] = g.ewlo; hdr[GATRES_PT_WEG] = g.weg; hdr[GATRES_PT_MELO] = g.melo; hdr[GATRES_PT_OEM] = g.oem;
+      hdr[GATRES_PT_TLO] = g.tlo; hdr[GATRES_PT_OTG] = g.otg; hdr[GATRES_PT_MTLO] = g.mtlo; hdr[GATRES_PT_OTM] = g.otm;
+      size_t from = img.size();
+      hdr[GATRES_PT_F_IMG] = GATRES_PT_HEADER + (int)(img.size() / 2);
+      put(rpo, even_i(ow + 1)); put(colo, even_i(g.oeg)); put(mrpo, even_i(ow + 1)); put(mcolo, even_i(g.oem));
+      pad16(from); put(nbin, 8 * ow); put(mbin, 8 * ow);
+      hdr[GATRES_PT_F_IMG_WORDS] = (int)((img.size() - from) / 2);
+      from = img.size();
+      hdr[GATRES_PT_B_IMG] = GATRES_PT_HEADER + (int)(img.size() / 2);
+      put(rpo, even_i(ow + 1)); put(colo, even_i(g.oeg)); put(trpo, even_i(ow + 1)); put(teido, even_i(g.otg));
+      put(tdsto, even_i(g.otg)); put(mrpw, even_i(wr + 1)); put(mtrpo, even_i(ow + 1)); put(mtdsto, even_i(g.otm));
+      pad16(from); put(nbin, 8 * ow); put(tout, 16 * ow); put(mout, 16 * ow);
+      hdr[GATRES_PT_B_IMG_WORDS] = (int)((img.size() - from) / 2);
+      auto put_list = [&](const std::vector<uint16_t>& v, int off_field, int cnt_field) {
+        hdr[off_field] = GATRES_PT_HEADER + (int)(img.size() / 2);
+        hdr[cnt_field] = (int)v.size();
+        put(v, even_i((int)v.size()));
+      };
+      put_list(f_hlist, GATRES_PT_F_HLIST, GATRES_PT_F_HCNT); put_list(f_elist, GATRES_PT_F_ELIST, GATRES_PT_F_ECNT);
+      put_list(b_hrow, GATRES_PT_B_HROW, GATRES_PT_B_HRCNT);   put_list(b_hedge, GATRES_PT_B_HEDGE, GATRES_PT_B_HECNT);
+      put_list(b_erow, GATRES_PT_B_EROW, GATRES_PT_B_ERCNT);   put_list(b_eedge, GATRES_PT_B_EEDGE, GATRES_PT_B_EECNT);
+      const int64_t total_words = GATRES_PT_HEADER + (int64_t)img.size() / 2;
+      need = std::max(need, total_words);
+      if (out) {
+        if (total_words > stride_words) return GATRES_E_BADARG;
+        int32_t* dst = out + ((int64_t)s * M + p) * stride_words;
+        for (int i = 0; i < GATRES_PT_HEADER; ++i) dst[i] = hdr[i];
+        for (size_t i = 0; i + 1 < img.size() + 1 && i < img.size(); i += 2)
+          dst[GATRES_PT_HEADER + i / 2] = (int32_t)((uint32_t)img[i] | ((uint32_t)img[i + 1] << 16));
+      }
+    }
+  }
+  *stride_words_out = (need + 3) & ~(int64_t)3;      // 16-byte multiples: every part starts 16-byte aligned
+  return 0;
+}
+
 // Reverse Cuthill-McKee inside every segment.  The fused kernels give part p of a split segment a contiguous row range
 // and size its LDS tables by the range of rows those rows are adjacent to (gatres_graph_windows_host); that range is
 // part + 2 x bandwidth, so a bandwidth-reducing order is what keeps the window a fraction of the segment.  EPANET files

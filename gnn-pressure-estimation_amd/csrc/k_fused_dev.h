@@ -65,6 +65,8 @@ struct FusedArgs {
   int no_halo;              // diagnostic (GATRES_FUSED_NO_HALO=1): always take the bulk-pull fallback
   int C;                    // consumer workgroups per segment (deferred parameter gradients on spare CUs), 0 = none
   int sym;                  // the plan's GATRES_GRAPH_SYMMETRIC: partners owe each other halo rows in both directions
+  const int* ptab;          // the plan's part tables (gatres_graph_t.part_tables) and what they were built for; may be null
+  int ptab_m, ptab_stride;
   unsigned* ready;          // [segment][4] lines: items published by the segment's part 0 for each consumer
   unsigned long long* xch;  // window kernel: granule exchange regions, one per segment (Layout::sc_xch)
   XchLayout XL;

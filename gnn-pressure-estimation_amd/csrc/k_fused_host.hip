@@ -322,6 +322,7 @@ extern "C" int gatres_fused_run(const gatres_model_t* m, const gatres_graph_t* g
   a.no_halo = gatres_knobs()->fused_no_halo | (gatres_knobs()->xch_nowait ? 2 : 0) | (gatres_knobs()->diag_nomask ? 4 : 0);
   a.C = (phases & GATRES_PHASE_BACKWARD) ? fused_consumers(a.L, g, a.M) : 0;
   a.sym = (g->flags & GATRES_GRAPH_SYMMETRIC) && !gatres_knobs()->fused_heartbeat ? 1 : 0;
+  a.ptab = g->part_tables; a.ptab_m = g->part_tables_m; a.ptab_stride = g->part_tables_stride;
   a.keep_lds = (phases & GATRES_PHASE_FORWARD) && (phases & GATRES_PHASE_BACKWARD) && !gatres_knobs()->fused_no_keep &&
            window_kernel_fits(a.L, g, a.M, true) ? 1 : 0;
   a.flags = reinterpret_cast<unsigned*>(scratch + a.L.sc_flags);

@@ -36,11 +36,29 @@ __global__ __launch_bounds__(THREADS) void gatres_window_kernel(const FusedArgs 
   const int within = blockIdx.x % (8 * M);
   const int seg = (blockIdx.x / (8 * M)) * 8 + (within & 7), part = within >> 3;
   if (seg >= a.num_segments) return;
-  const int n0 = uni(a.seg_ptr[seg]), n = uni(a.seg_ptr[seg + 1]) - n0;
-  const int e0 = uni(a.rowptr[n0]), em0 = uni(a.m_rowptr[n0]), t0 = uni(a.t_rowptr[n0]), mt0 = uni(a.mt_rowptr[n0]);
   const int tid = threadIdx.x;
+  // Part tables of the plan (gatres_graph_t.part_tables, built once per topology by gatres_graph_part_tables_host): the
+  // part's scalars come from the record's header -- ONE load per wave -- and its LDS tables are copied from the record
+  // by LDS-DMA in the two phase prologues.  Without them (a plan that carries none, or tables for another split) both are
+  // derived from the CSR arrays as in round 2: four barrier-separated passes with LDS atomics per phase.
+  const int* pt = (a.ptab && a.ptab_m == M) ? a.ptab + ((size_t)seg * M + part) * (size_t)a.ptab_stride : nullptr;
+  int hv = 0;
+  if (pt) hv = pt[min((int)(threadIdx.x & 63), GATRES_PT_HEADER - 1)];
+  auto H = [&](int field) { return __builtin_amdgcn_readlane(hv, field); };
+  int n0, n, e0, em0, t0, mt0;
   Rows rw;
-  {
+  if (pt) {
+    if (H(GATRES_PT_MAGIC) != GATRES_PT_MAGIC_VALUE || H(GATRES_PT_M) != M) {       // (not this plan's tables)
+      if (tid == 0) *a.err = 1;
+      pt = nullptr;
+    }
+  }
+  if (pt) {
+    n0 = H(GATRES_PT_N0); n = H(GATRES_PT_N); e0 = H(GATRES_PT_E0); em0 = H(GATRES_PT_EM0); t0 = H(GATRES_PT_T0);
+    mt0 = H(GATRES_PT_MT0); rw.lo = H(GATRES_PT_LO); rw.hi = H(GATRES_PT_HI);
+  } else {
+    n0 = uni(a.seg_ptr[seg]); n = uni(a.seg_ptr[seg + 1]) - n0;
+    e0 = uni(a.rowptr[n0]); em0 = uni(a.m_rowptr[n0]); t0 = uni(a.t_rowptr[n0]); mt0 = uni(a.mt_rowptr[n0]);
     const int tiles = (n + 15) >> 4;
     rw.lo = 16 * (int)((long long)tiles * part / M);
     rw.hi = min(n, 16 * (int)((long long)tiles * (part + 1) / M));
@@ -83,9 +101,14 @@ __global__ __launch_bounds__(THREADS) void gatres_window_kernel(const FusedArgs 
   STAMP();
   if (STAMPS_PTR && blockIdx.x == 0 && threadIdx.x == 0) STAMPS_PTR[a.stamp_cap] = clock64();
 
-  // ---- the window: own rows and every row adjacent to them (in- and out-neighbours), as one contiguous range
-  int wlo, whi;
-  {
+  // ---- the window: own rows and every row adjacent to them (in- and out-neighbours), as one contiguous range; edge ranges
+  // (local ids = position - e0): own in-edges [elo, elo + oeg), window in-edges [ewlo, ewlo + weg), ...
+  int wlo, whi, elo, oeg, ewlo, weg, melo, oem, tlo, otg, mtlo, otm;
+  if (pt) {
+    wlo = H(GATRES_PT_WLO); whi = H(GATRES_PT_WHI); elo = H(GATRES_PT_ELO); oeg = H(GATRES_PT_OEG); ewlo = H(GATRES_PT_EWLO);
+    weg = H(GATRES_PT_WEG); melo = H(GATRES_PT_MELO); oem = H(GATRES_PT_OEM); tlo = H(GATRES_PT_TLO); otg = H(GATRES_PT_OTG);
+    mtlo = H(GATRES_PT_MTLO); otm = H(GATRES_PT_OTM);
+  } else {
     int* mm = reinterpret_cast<int*>(lds_raw);
     if (tid == 0) { mm[0] = lo; mm[1] = rw.hi; }
     __syncthreads();
@@ -107,14 +130,13 @@ __global__ __launch_bounds__(THREADS) void gatres_window_kernel(const FusedArgs 
     __syncthreads();
     wlo = uni(mm[0]); whi = uni(mm[1]);
     __syncthreads();
+    elo = uni(a.rowptr[n0 + lo]) - e0;        oeg = uni(a.rowptr[n0 + rw.hi]) - e0 - elo;
+    ewlo = uni(a.rowptr[n0 + wlo]) - e0;      weg = uni(a.rowptr[n0 + whi]) - e0 - ewlo;
+    melo = uni(a.m_rowptr[n0 + lo]) - em0;    oem = uni(a.m_rowptr[n0 + rw.hi]) - em0 - melo;
+    tlo = uni(a.t_rowptr[n0 + lo]) - t0;      otg = uni(a.t_rowptr[n0 + rw.hi]) - t0 - tlo;
+    mtlo = uni(a.mt_rowptr[n0 + lo]) - mt0;   otm = uni(a.mt_rowptr[n0 + rw.hi]) - mt0 - mtlo;
   }
   const int wr = whi - wlo;
-  // edge ranges (local ids = position - e0): own in-edges [elo, ehi), window in-edges [ewlo, ewhi)
-  const int elo = uni(a.rowptr[n0 + lo]) - e0, ehi = uni(a.rowptr[n0 + rw.hi]) - e0, oeg = ehi - elo;
-  const int ewlo = uni(a.rowptr[n0 + wlo]) - e0, ewhi = uni(a.rowptr[n0 + whi]) - e0, weg = ewhi - ewlo;
-  const int melo = uni(a.m_rowptr[n0 + lo]) - em0, oem = uni(a.m_rowptr[n0 + rw.hi]) - em0 - melo;
-  const int tlo = uni(a.t_rowptr[n0 + lo]) - t0, otg = uni(a.t_rowptr[n0 + rw.hi]) - t0 - tlo;
-  const int mtlo = uni(a.mt_rowptr[n0 + lo]) - mt0, otm = uni(a.mt_rowptr[n0 + rw.hi]) - mt0 - mtlo;
 
   const SegLayout& SL = a.SL;
   float* segbase = a.saved + (int64_t)seg * SL.total;                 // training only: saved is never null here
@@ -138,8 +160,9 @@ __global__ __launch_bounds__(THREADS) void gatres_window_kernel(const FusedArgs 
     u16* nbin = tp;            tp += 8 * ow;       // padded in-edge descriptors of the own rows (k_window_stages.h)
     u16* mbin = tp;            tp += 8 * ow;
     int* hcounter = reinterpret_cast<int*>(tp);
-    u16* hlist = tp + 2;                 // import list: remote sources of own in-edges (one entry per edge)
-    const int hcap = max(0, (int)((lds_top - reinterpret_cast<unsigned char*>(hlist)) / 4));
+    const u16* f_img_end = tp;
+    u16* hlist = tp + 2;                 // import list: remote sources of own in-edges
+    const int hcap = max(0, (int)((lds_top - reinterpret_cast<unsigned char*>(hlist)) / 4)) & ~1;
     u16* elist = hlist + hcap;           // export list: own rows some partner's row has an in-edge from
     // index-shifted views: absolute local row / relative own-edge indices work unchanged in the stage functions
     float* hA = hAw - wlo * 2 * NC;
@@ -149,10 +172,25 @@ __global__ __launch_bounds__(THREADS) void gatres_window_kernel(const FusedArgs 
     float* xA = xAo - lo * NC;
     float* xB = xBo - lo * 2 * NC;
     const u16* rp = rpo - lo;  const u16* mrp = mrpo - lo;
-    copy_rowptr16<THREADS>(rpo, a.rowptr, n0 + lo, ow, e0 + elo);
-    copy_idx16<THREADS>(colo, a.col, e0 + elo, oeg, n0);
-    copy_rowptr16<THREADS>(mrpo, a.m_rowptr, n0 + lo, ow, em0 + melo);
-    copy_idx16<THREADS>(mcolo, a.m_col, em0 + melo, oem, n0);
+    int hcnt = 0, ecnt = 0;
+    if (pt) {
+      // the record's forward image is this LDS range, verbatim; the two hand-off lists follow it in the record
+      hcnt = H(GATRES_PT_F_HCNT); ecnt = H(GATRES_PT_F_ECNT);
+      if (H(GATRES_PT_F_IMG_WORDS) * 2 != (int)(f_img_end - rpo) || hcnt > hcap || ecnt > hcap) {
+        if (tid == 0) *a.err = 1;
+        hcnt = min(hcnt, hcap); ecnt = min(ecnt, hcap);
+      } else {
+        dma_copy4<THREADS>(reinterpret_cast<float*>(rpo), reinterpret_cast<const float*>(pt + H(GATRES_PT_F_IMG)),
+                           H(GATRES_PT_F_IMG_WORDS), 0);
+      }
+      dma_copy4<THREADS>(reinterpret_cast<float*>(hlist), reinterpret_cast<const float*>(pt + H(GATRES_PT_F_HLIST)), (hcnt + 1) / 2, 0);
+      dma_copy4<THREADS>(reinterpret_cast<float*>(elist), reinterpret_cast<const float*>(pt + H(GATRES_PT_F_ELIST)), (ecnt + 1) / 2, 0);
+    } else {
+      copy_rowptr16<THREADS>(rpo, a.rowptr, n0 + lo, ow, e0 + elo);
+      copy_idx16<THREADS>(colo, a.col, e0 + elo, oeg, n0);
+      copy_rowptr16<THREADS>(mrpo, a.m_rowptr, n0 + lo, ow, em0 + melo);
+      copy_idx16<THREADS>(mcolo, a.m_col, em0 + melo, oem, n0);
+    }
     float* xcur = segbase + SL.xin;
     if (L.nb > 0) {
       const float* pb0 = P + L.p_block0;
@@ -175,13 +213,15 @@ __global__ __launch_bounds__(THREADS) void gatres_window_kernel(const FusedArgs 
     }
     dma_land(0);
     __syncthreads();
-    build_nbr_in<THREADS>(rw, rp, colo, oeg, false, nbin);
-    build_nbr_in<THREADS>(rw, mrp, mcolo, oem, true, mbin);
-    int hcnt = uni(build_halo<THREADS>(rp, colo, nullptr, rw, hlist, nullptr, hcap, hcounter));
-    int ecnt = uni(build_export_rows<THREADS>(a.t_rowptr, a.t_dst, n0, rw, elist, hcap, hcounter));
-    if (hcnt > hcap || ecnt > hcap) {      // (the host sizes the lists from gatres_graph_t.halo: cannot happen with a sane plan)
-      if (tid == 0) *a.err = 1;
-      hcnt = min(hcnt, hcap); ecnt = min(ecnt, hcap);
+    if (!pt) {
+      build_nbr_in<THREADS>(rw, rp, colo, oeg, false, nbin);
+      build_nbr_in<THREADS>(rw, mrp, mcolo, oem, true, mbin);
+      hcnt = uni(build_halo<THREADS>(rp, colo, nullptr, rw, hlist, nullptr, hcap, hcounter));
+      ecnt = uni(build_export_rows<THREADS>(a.t_rowptr, a.t_dst, n0, rw, elist, hcap, hcounter));
+      if (hcnt > hcap || ecnt > hcap) {    // (the host sizes the lists from gatres_graph_t.halo: cannot happen with a sane plan)
+        if (tid == 0) *a.err = 1;
+        hcnt = min(hcnt, hcap); ecnt = min(ecnt, hcap);
+      }
     }
     STAMP();
     for (int b = 0; b < L.nb; ++b) {
@@ -346,20 +386,37 @@ __global__ __launch_bounds__(THREADS) void gatres_window_kernel(const FusedArgs 
     u16* tout = tp;            tp += 16 * ow;
     u16* mout = tp;            tp += 16 * ow;
     int* hcounter = reinterpret_cast<int*>(tp);
+    const u16* b_img_end = tp;
     u16* hrow = tp + 2;                  // import lists: remote destinations (+ edge ids) of own out-edges
-    const int hcap = max(0, (int)((lds_top - reinterpret_cast<unsigned char*>(hrow)) / 8));
+    const int hcap = max(0, (int)((lds_top - reinterpret_cast<unsigned char*>(hrow)) / 8)) & ~1;
     u16* hedge = hrow + hcap;
     u16* erow = hedge + hcap;            // export lists: own rows with an in-edge from a partner's row, and those in-edges
     u16* eedge = erow + hcap;
     __syncthreads();           // forward's LDS contents are dead from here
-    copy_rowptr16<THREADS>(rpo, a.rowptr, n0 + lo, ow, e0 + elo);
-    copy_idx16<THREADS>(colo, a.col, e0 + elo, oeg, n0);
-    copy_rowptr16<THREADS>(trpo, a.t_rowptr, n0 + lo, ow, t0 + tlo);
-    copy_idx16<THREADS>(teido, a.t_eid, t0 + tlo, otg, e0);
-    copy_idx16<THREADS>(tdsto, a.t_dst, t0 + tlo, otg, n0);
-    copy_rowptr16<THREADS>(mrpw, a.m_rowptr, n0 + wlo, wr, a.m_rowptr[n0 + wlo]);
-    copy_rowptr16<THREADS>(mtrpo, a.mt_rowptr, n0 + lo, ow, mt0 + mtlo);
-    copy_idx16<THREADS>(mtdsto, a.mt_dst, mt0 + mtlo, otm, n0);
+    int hrcnt = 0, hecnt = 0, ercnt = 0, eecnt = 0;      // import rows / import edges / export rows / export edges
+    if (pt) {
+      hrcnt = H(GATRES_PT_B_HRCNT); hecnt = H(GATRES_PT_B_HECNT); ercnt = H(GATRES_PT_B_ERCNT); eecnt = H(GATRES_PT_B_EECNT);
+      if (H(GATRES_PT_B_IMG_WORDS) * 2 != (int)(b_img_end - rpo) || hrcnt > hcap || hecnt > hcap || ercnt > hcap || eecnt > hcap) {
+        if (tid == 0) *a.err = 1;
+        hrcnt = min(hrcnt, hcap); hecnt = min(hecnt, hcap); ercnt = min(ercnt, hcap); eecnt = min(eecnt, hcap);
+      } else {
+        dma_copy4<THREADS>(reinterpret_cast<float*>(rpo), reinterpret_cast<const float*>(pt + H(GATRES_PT_B_IMG)),
+                           H(GATRES_PT_B_IMG_WORDS), 0);
+      }
+      dma_copy4<THREADS>(reinterpret_cast<float*>(hrow), reinterpret_cast<const float*>(pt + H(GATRES_PT_B_HROW)), (hrcnt + 1) / 2, 0);
+      dma_copy4<THREADS>(reinterpret_cast<float*>(hedge), reinterpret_cast<const float*>(pt + H(GATRES_PT_B_HEDGE)), (hecnt + 1) / 2, 0);
+      dma_copy4<THREADS>(reinterpret_cast<float*>(erow), reinterpret_cast<const float*>(pt + H(GATRES_PT_B_EROW)), (ercnt + 1) / 2, 0);
+      dma_copy4<THREADS>(reinterpret_cast<float*>(eedge), reinterpret_cast<const float*>(pt + H(GATRES_PT_B_EEDGE)), (eecnt + 1) / 2, 0);
+    } else {
+      copy_rowptr16<THREADS>(rpo, a.rowptr, n0 + lo, ow, e0 + elo);
+      copy_idx16<THREADS>(colo, a.col, e0 + elo, oeg, n0);
+      copy_rowptr16<THREADS>(trpo, a.t_rowptr, n0 + lo, ow, t0 + tlo);
+      copy_idx16<THREADS>(teido, a.t_eid, t0 + tlo, otg, e0);
+      copy_idx16<THREADS>(tdsto, a.t_dst, t0 + tlo, otg, n0);
+      copy_rowptr16<THREADS>(mrpw, a.m_rowptr, n0 + wlo, wr, a.m_rowptr[n0 + wlo]);
+      copy_rowptr16<THREADS>(mtrpo, a.mt_rowptr, n0 + lo, ow, mt0 + mtlo);
+      copy_idx16<THREADS>(mtdsto, a.mt_dst, mt0 + mtlo, otm, n0);
+    }
     const u16* rp = rpo - lo;  const u16* trp = trpo - lo;  const u16* mrp = mrpw - wlo;  const u16* mtrp = mtrpo - lo;
     float* RA = RAw - wlo * 2 * NC;              // [row][2NC] view: g_out1
     float* gpT = RAw - wlo * NC;                 // [row][NC] views of the lower / upper half: g_pre, g_y2
@@ -380,9 +437,6 @@ __global__ __launch_bounds__(THREADS) void gatres_window_kernel(const FusedArgs 
                       : a.slabs + (int64_t)seg * L.slab_stride;
     const int64_t w = 2LL * NC * NC;
     const float* xfinal = segbase + (int64_t)L.nb * SL.bstride + SL.xin;
-    // LDS-DMA of saved tables (independent of the backward chain) and transposed weights always rides on an MFMA
-    // stage or, for the first block, on this prologue: conv2 tables + W2^T of block b during dX1 of block b + 1,
-    // conv1 tables + W1^T of block b during dX2 of block b.
     // LDS-DMA of the saved tables (independent of the backward chain) rides on the dX stages, issued by their tile-less
     // waves, which wait for it to land before the stage's closing barrier.  Every CU streams at the same moments, so a
     // transfer costs its bytes over the CU's share of HBM (~25 GB/s: 1.3 us for conv1's 32 KB).  Measured in round 3
@@ -405,25 +459,29 @@ __global__ __launch_bounds__(THREADS) void gatres_window_kernel(const FusedArgs 
     seg_lin1_bwd<NC, THREADS>(rw, n0, a.perm, a.g_out, xfinal, P + L.p_lin1_w, gp_cur, gpT, slab + L.p_lin1_w,
                               slab + L.p_lin1_b, L.nb > 0 ? 1 : 0, red, gkeep);
     dma_land(0);
-    build_nbr_in<THREADS>(rw, rp, colo, oeg, false, nbin);
-    build_nbr_out<THREADS>(rw, trp, tdsto, teido, 0, nullptr, otg, tout);
-    build_nbr_out<THREADS>(rw, mtrp, mtdsto, nullptr, 0, mrp, otm, mout);
-    int hcnt = uni(build_halo<THREADS>(trp, tdsto, teido, rw, hrow, hedge, hcap, hcounter));
-    int ercnt = uni(build_export_rows<THREADS>(a.rowptr, a.col, n0, rw, erow, hcap, hcounter));
-    if (tid == 0) *hcounter = 0;
-    __syncthreads();
-    for (int k = tid; k < oeg; k += THREADS) {                 // own in-edges whose source is a partner's row
-      const int j = colo[k];
-      if (j < lo || j >= rw.hi) {
-        const int pos = atomicAdd(hcounter, 1);
-        if (pos < hcap) eedge[pos] = (u16)(elo + k);
+    if (pt) {
+      __syncthreads();         // the record's tables and the first block's conv2 tables have landed
+    } else {
+      build_nbr_in<THREADS>(rw, rp, colo, oeg, false, nbin);
+      build_nbr_out<THREADS>(rw, trp, tdsto, teido, 0, nullptr, otg, tout);
+      build_nbr_out<THREADS>(rw, mtrp, mtdsto, nullptr, 0, mrp, otm, mout);
+      hrcnt = hecnt = uni(build_halo<THREADS>(trp, tdsto, teido, rw, hrow, hedge, hcap, hcounter));
+      ercnt = uni(build_export_rows<THREADS>(a.rowptr, a.col, n0, rw, erow, hcap, hcounter));
+      if (tid == 0) *hcounter = 0;
+      __syncthreads();
+      for (int k = tid; k < oeg; k += THREADS) {               // own in-edges whose source is a partner's row
+        const int j = colo[k];
+        if (j < lo || j >= rw.hi) {
+          const int pos = atomicAdd(hcounter, 1);
+          if (pos < hcap) eedge[pos] = (u16)(elo + k);
+        }
       }
-    }
-    __syncthreads();
-    int eecnt = uni(*hcounter);
-    if (hcnt > hcap || ercnt > hcap || eecnt > hcap) {
-      if (tid == 0) *a.err = 1;
-      hcnt = min(hcnt, hcap); ercnt = min(ercnt, hcap); eecnt = min(eecnt, hcap);
+      __syncthreads();
+      eecnt = uni(*hcounter);
+      if (hrcnt > hcap || ercnt > hcap || eecnt > hcap) {
+        if (tid == 0) *a.err = 1;
+        hrcnt = hecnt = min(hrcnt, hcap); ercnt = min(ercnt, hcap); eecnt = min(eecnt, hcap);
+      }
     }
     STAMP();
     for (int b = L.nb - 1; b >= 0; --b) {
@@ -441,7 +499,7 @@ __global__ __launch_bounds__(THREADS) void gatres_window_kernel(const FusedArgs 
       ++xc.ep;                                   // exchange B1: K3 backward gathers g_pre of neighbour rows
       xch_export2<NC, 0, THREADS>(xc, xbuf, erow, ercnt, gpT, (unsigned)XL.b1, erow, 0, gpT, 0u);
       XSTAMP();
-      xch_import2<NC, 0, THREADS>(xc, xbuf, hrow, hcnt, (unsigned)XL.b1, gpT, hrow, 0, 0u, gpT);
+      xch_import2<NC, 0, THREADS>(xc, xbuf, hrow, hrcnt, (unsigned)XL.b1, gpT, hrow, 0, 0u, gpT);
       XSTAMP();
       xch_after<THREADS>(xc, pace, drain);
       XSTAMP();
@@ -461,7 +519,7 @@ __global__ __launch_bounds__(THREADS) void gatres_window_kernel(const FusedArgs 
       ++xc.ep;                                   // exchange B2: the source-major stage reads g_y2 / g_e of neighbour rows
       xch_export2<NC, 1, THREADS>(xc, xbuf, erow, ercnt, gy2T, (unsigned)XL.b2y, eedge, eecnt, ge2, (unsigned)XL.b2e);
       XSTAMP();
-      xch_import2<NC, 1, THREADS>(xc, xbuf, hrow, hcnt, (unsigned)XL.b2y, gy2T, hedge, hcnt, (unsigned)XL.b2e, ge2);
+      xch_import2<NC, 1, THREADS>(xc, xbuf, hrow, hrcnt, (unsigned)XL.b2y, gy2T, hedge, hecnt, (unsigned)XL.b2e, ge2);
       XSTAMP();
       xch_after<THREADS>(xc, pace, drain);
       XSTAMP();
@@ -500,7 +558,7 @@ __global__ __launch_bounds__(THREADS) void gatres_window_kernel(const FusedArgs 
       ++xc.ep;                                   // exchange B3
       xch_export2<2 * NC, 2, THREADS>(xc, xbuf, erow, ercnt, RA, (unsigned)XL.b3o, eedge, eecnt, ge1, (unsigned)XL.b3e);
       XSTAMP();
-      xch_import2<2 * NC, 2, THREADS>(xc, xbuf, hrow, hcnt, (unsigned)XL.b3o, RA, hedge, hcnt, (unsigned)XL.b3e, ge1);
+      xch_import2<2 * NC, 2, THREADS>(xc, xbuf, hrow, hrcnt, (unsigned)XL.b3o, RA, hedge, hecnt, (unsigned)XL.b3e, ge1);
       XSTAMP();
       xch_after<THREADS>(xc, pace, drain);
       XSTAMP();

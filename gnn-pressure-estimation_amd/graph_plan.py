@@ -92,6 +92,8 @@ class GraphPlan:
                       "gatres_graph_build_host")
         self.num_nodes, self.num_edges_gat, self.num_edges_mean = N, Eg, E
         self.device = device
+        self._host = host if segments else None          # kept for the part tables (bind)
+        self._part_tables: Dict[int, Tuple[torch.Tensor, int]] = {}
         self.arrays: Dict[str, torch.Tensor] = {k: v.to(device) for k, v in host.items()}
         seg_dev_ptr = None
         if segments:
@@ -105,7 +107,40 @@ class GraphPlan:
                                      seg_dev_ptr, self.max_segment_nodes, self.max_segment_edges_gat,
                                      self.max_segment_edges_mean, self.flags, (C.c_int32 * 21)(*self.windows[:21]), 0,
                                      perm_dev_ptr,
-                                     (C.c_int32 * 7)(*self.windows[21:28]), 0)
+                                     (C.c_int32 * 7)(*self.windows[21:28]), 0, None, 0, 0)
+
+    def bind(self, cmodel_ref) -> None:
+        """Attach the part tables (``gatres_graph_t.part_tables``) for the split the fused kernels will use with this
+        model: built once per (plan, workgroups per segment) on the host by ``gatres_graph_part_tables_host`` and kept on
+        the device.  Without them the window kernel derives the same tables in every launch (GATRES_NO_PART_TABLES=1
+        keeps it that way: the two must agree, tests/test_gpu_model.py)."""
+        if self._host is None or self.num_segments <= 0 or os.environ.get("GATRES_NO_PART_TABLES"):
+            self.c.part_tables, self.c.part_tables_m, self.c.part_tables_stride = None, 0, 0
+            return
+        lib = _native.load()
+        m = int(lib.gatres_fused_cus_per_segment(cmodel_ref, self.ref()))
+        if m < 2 or m > 8 or self.max_segment_nodes > 65535:
+            self.c.part_tables, self.c.part_tables_m, self.c.part_tables_stride = None, 0, 0
+            return
+        if self.c.part_tables and self.c.part_tables_m == m:
+            return
+        entry = self._part_tables.get(m)
+        if entry is None:
+            ptrs = [self._host[k].data_ptr() for k in ("rowptr", "col", "t_rowptr", "t_eid", "t_dst", "m_rowptr", "m_col",
+                                                       "mt_rowptr", "mt_dst")]
+            stride = C.c_int64(0)
+            rc = lib.gatres_graph_part_tables_host(*ptrs, self.segment_ptr_host.data_ptr(), self.num_segments, m, None, 0,
+                                                   C.byref(stride))
+            if rc != 0:                  # (segments beyond the 16-bit tables: the kernels do not take them either)
+                self.c.part_tables, self.c.part_tables_m, self.c.part_tables_stride = None, 0, 0
+                return
+            words = torch.zeros(self.num_segments * m * int(stride.value), dtype=torch.int32)
+            _native.check(lib.gatres_graph_part_tables_host(*ptrs, self.segment_ptr_host.data_ptr(), self.num_segments, m,
+                                                            words.data_ptr(), int(stride.value), C.byref(stride)),
+                          "gatres_graph_part_tables_host")
+            entry = (words.to(self.device), int(stride.value))
+            self._part_tables[m] = entry
+        self.c.part_tables, self.c.part_tables_m, self.c.part_tables_stride = entry[0].data_ptr(), m, entry[1]
 
     def ref(self):
         return C.byref(self.c)

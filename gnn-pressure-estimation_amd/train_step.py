@@ -60,6 +60,8 @@ class GATResTrainer:
         self.device = dev
         self.plan: GraphPlan = GraphPlan(edge_index, num_nodes, device=dev, segments=fused)
         self.fused = bool(fused and self.lib.gatres_fused_supported(model._cmodel_ref(), self.plan.ref()))
+        if self.fused:
+            self.plan.bind(model._cmodel_ref())
         N = num_nodes
         self.N = N
         self.P = params.numel()

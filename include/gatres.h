@@ -84,7 +84,25 @@ typedef struct gatres_graph {
    * its halo lists (one entry per such edge) in LDS and is only taken when they fit. */
   int32_t halo[7];
   int32_t reserved3;
+  /* Part tables of split segments (gatres_graph_part_tables_host), for part_tables_m workgroups per segment: one record of
+   * part_tables_stride int32 words per (segment, part), device memory.  NULL, or an m other than the one a launch uses: the
+   * window kernel derives the same tables from the CSR arrays in its prologues (correct, ~15 us slower per launch). */
+  const int32_t* part_tables;
+  int32_t part_tables_m;
+  int32_t part_tables_stride;
 } gatres_graph_t;
+
+/* Header words of one part-table record (the tables follow; offsets are in int32 words from the record's start) */
+enum {
+  GATRES_PT_MAGIC = 0, GATRES_PT_M, GATRES_PT_N0, GATRES_PT_N, GATRES_PT_E0, GATRES_PT_EM0, GATRES_PT_T0, GATRES_PT_MT0,
+  GATRES_PT_LO, GATRES_PT_HI, GATRES_PT_WLO, GATRES_PT_WHI, GATRES_PT_ELO, GATRES_PT_OEG, GATRES_PT_EWLO, GATRES_PT_WEG,
+  GATRES_PT_MELO, GATRES_PT_OEM, GATRES_PT_TLO, GATRES_PT_OTG, GATRES_PT_MTLO, GATRES_PT_OTM,
+  GATRES_PT_F_IMG, GATRES_PT_F_IMG_WORDS, GATRES_PT_F_HLIST, GATRES_PT_F_HCNT, GATRES_PT_F_ELIST, GATRES_PT_F_ECNT,
+  GATRES_PT_B_IMG, GATRES_PT_B_IMG_WORDS, GATRES_PT_B_HROW, GATRES_PT_B_HRCNT, GATRES_PT_B_HEDGE, GATRES_PT_B_HECNT,
+  GATRES_PT_B_EROW, GATRES_PT_B_ERCNT, GATRES_PT_B_EEDGE, GATRES_PT_B_EECNT,
+  GATRES_PT_HEADER = 48
+};
+#define GATRES_PT_MAGIC_VALUE 0x47545031
 
 /* gatres_graph_t.flags */
 #define GATRES_GRAPH_SYMMETRIC 1   /* every edge (u, v), u != v, has its reverse (v, u) in edge_index -- what
@@ -102,6 +120,16 @@ int gatres_graph_build_host(const int64_t* edge_index_host, int64_t num_edges, i
 
 /* Properties of the edge list the kernels may rely on (host): *flags_out = OR of GATRES_GRAPH_* bits. */
 int gatres_graph_flags_host(const int64_t* edge_index_host, int64_t num_edges, int64_t num_nodes, int32_t* flags_out);
+
+/* Part tables (host): see gatres_graph_t.part_tables.  Inputs: the plan's HOST arrays (as gatres_graph_build_host filled
+ * them) and its segment table; m = workgroups per segment (2 .. 8, gatres_fused_cus_per_segment).  Call once with
+ * out = NULL to learn the record size (*stride_words_out, a multiple of 4), then with an array of
+ * num_segments * m * stride words. */
+int gatres_graph_part_tables_host(const int32_t* rowptr, const int32_t* col, const int32_t* t_rowptr, const int32_t* t_eid,
+                                  const int32_t* t_dst, const int32_t* m_rowptr, const int32_t* m_col,
+                                  const int32_t* mt_rowptr, const int32_t* mt_dst, const int32_t* seg_ptr,
+                                  int32_t num_segments, int32_t m, int32_t* out, int64_t stride_words,
+                                  int64_t* stride_words_out);
 
 /* Segment table (host): the finest partition of [0, N) into contiguous ranges closed under the edges, adjacent
  * ranges merged while the result stays <= merge_upto nodes.  seg_ptr_host must hold N + 1 entries. */

@@ -565,3 +565,42 @@ def test_collective_path_equals_single_call(pkg, oracle):
         res.append((losses, model.flat_parameters.clone(), tr.mask.clone()))
     assert res[0][0] == res[1][0]
     assert torch.equal(res[0][1], res[1][1]) and torch.equal(res[0][2], res[1][2])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("directed", [False, True], ids=["symmetric", "directed"])
+def test_part_tables_equal_in_kernel_derivation(pkg, oracle, directed, monkeypatch):
+    """The window kernel with the plan's part tables (gatres_graph_part_tables_host: prologue = one LDS-DMA copy, hand-off
+    lists de-duplicated) and without them (GATRES_NO_PART_TABLES=1: tables derived from the CSR arrays in every launch)
+    must agree bit for bit: out, loss, gradients, parameters after two steps.  `directed`: half of the reverse edges
+    removed -- the plan then lacks GATRES_GRAPH_SYMMETRIC and the hand-offs keep their heartbeat pacing."""
+    nb, nc, bs = 4, 32, 3
+    ei = pkg.wdn_synth.collate_edge_index(pkg.wdn_synth.make_wdn_topology(388, 430, seed=0), 388, bs)
+    if directed:
+        keep = (ei[0] < ei[1]) | (torch.arange(ei.shape[1]) % 2 == 0)
+        ei = ei[:, keep]
+    N = 388 * bs
+    snaps = pkg.wdn_synth.make_snapshots(2 * bs, 388, seed=4)
+    res = []
+    for no_tables in (False, True):
+        if no_tables:
+            monkeypatch.setenv("GATRES_NO_PART_TABLES", "1")
+        model, _ = build(pkg, oracle, nb, nc, seed=3, fused=True)
+        tr = pkg.GATResTrainer(model, ei.cuda(), N, nodes_per_graph=[388] * bs, use_graph=False)
+        assert bool(tr.plan.c.part_tables) == (not no_tables)
+        assert (tr.plan.flags & 1) == (0 if directed else 1)
+        lib = pkg._native.load()
+        assert lib.gatres_fused_window_kernel(model._cmodel_ref(), tr.plan.ref()) == 1
+        rng = np.random.RandomState(6)
+        out = []
+        for it in range(2):
+            y = pkg.wdn_synth.collate_snapshots(snaps, range(it * bs, (it + 1) * bs))
+            mask = torch.from_numpy(pkg.wdn_synth.generate_batch_mask([388] * bs, 0.95, rng))
+            loss = tr.step(y.cuda(), y.cuda(), mask.cuda())
+            out.append((tr.out.clone(), loss.clone(), tr.grads.clone(), model.flat_parameters.clone()))
+        assert tr.fault_count == 0
+        res.append(out)
+    for a, b in zip(res[0], res[1]):
+        for u, v in zip(a, b):
+            assert torch.isfinite(u).all() and torch.equal(u, v)
+

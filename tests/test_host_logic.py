@@ -209,3 +209,91 @@ def test_synthetic_wdn_has_ctown_shape(pkg):
     x, y, bei, mask = pkg.wdn_synth.make_batch(4)
     assert x.shape == (1552, 1) and torch.equal(x, y) and bei.shape == (2, 3440) and int(bei.max()) == 1551
     assert mask.dtype == torch.bool and all(int(mask[i * 388:(i + 1) * 388].sum()) == 368 for i in range(4))
+
+
+def test_graph_flags_symmetric(pkg, lib):
+    """GATRES_GRAPH_SYMMETRIC: set for an undirected network listed in both directions (pgu.from_networkx), not for a
+    directed edge list; self loops and duplicate edges do not matter."""
+    import ctypes as C
+    t = pkg.wdn_synth.make_wdn_topology(60, 70, seed=2)
+
+    def flags(ei):
+        ei = ei.contiguous()
+        f = C.c_int32(-1)
+        assert lib.gatres_graph_flags_host(ei.data_ptr(), ei.shape[1], 60, C.byref(f)) == 0
+        return f.value
+
+    assert flags(t) == 1
+    assert flags(torch.cat([t, t[:, :5], torch.tensor([[3, 7], [3, 7]])], dim=1)) == 1       # duplicates + self loops
+    assert flags(t[:, 1:]) == 0                                                            # one direction missing
+    assert flags(t[:, t[0] < t[1]]) == 0
+
+
+@pytest.mark.parametrize("m", [2, 4, 8])
+def test_part_tables_match_numpy_restatement(pkg, lib, m):
+    """gatres_graph_part_tables_host against a direct numpy restatement of what the window kernel's prologues derive:
+    row window, edge ranges, padded edge descriptors, de-duplicated hand-off lists (a ragged batch, one shuffled graph)."""
+    import ctypes as C
+    t_big = pkg.wdn_synth.make_wdn_topology(388, 430, seed=0)
+    perm = torch.from_numpy(np.random.RandomState(3).permutation(100))
+    t_shuf = perm[pkg.wdn_synth.make_wdn_topology(100, 120, seed=2)]
+    ei = torch.cat([t_big, t_shuf + 388], dim=1)
+    N = 488
+    plan = pkg.GraphPlan(ei, N, device="cpu", reorder=False)
+    assert plan.num_segments == 2
+    H = {k: v.numpy() for k, v in plan._host.items()}
+    seg = plan.segment_ptr_host.numpy()
+    ptrs = [plan._host[k].data_ptr() for k in ("rowptr", "col", "t_rowptr", "t_eid", "t_dst", "m_rowptr", "m_col",
+                                               "mt_rowptr", "mt_dst")]
+    stride = C.c_int64(0)
+    assert lib.gatres_graph_part_tables_host(*ptrs, plan.segment_ptr_host.data_ptr(), 2, m, None, 0, C.byref(stride)) == 0
+    st = stride.value
+    assert st % 4 == 0 and st > 48
+    words = torch.zeros(2 * m * st, dtype=torch.int32)
+    assert lib.gatres_graph_part_tables_host(*ptrs, plan.segment_ptr_host.data_ptr(), 2, m, words.data_ptr(), st,
+                                             C.byref(stride)) == 0
+    w = words.numpy()
+    for s in range(2):
+        n0, n = int(seg[s]), int(seg[s + 1] - seg[s])
+        tiles = (n + 15) // 16
+        e0 = int(H["rowptr"][n0])
+        for p in range(m):
+            rec = w[(s * m + p) * st:(s * m + p + 1) * st]
+            u16 = rec.view(np.uint16)
+            lo, hi = 16 * (tiles * p // m), min(n, 16 * (tiles * (p + 1) // m))
+            assert rec[0] == 0x47545031 and rec[1] == m and rec[2] == n0 and rec[3] == n and rec[8] == lo and rec[9] == hi
+            rows = np.arange(n0 + lo, n0 + hi)
+            nbr = set(range(lo, hi))
+            for ptr, idx in (("rowptr", "col"), ("t_rowptr", "t_dst"), ("m_rowptr", "m_col"), ("mt_rowptr", "mt_dst")):
+                for r in rows:
+                    nbr.update(int(j) - n0 for j in H[idx][H[ptr][r]:H[ptr][r + 1]])
+            if not nbr:                                    # (more parts than 16-row tiles: an empty part)
+                assert rec[10] == lo and rec[11] == hi
+                continue
+            assert rec[10] == min(nbr) and rec[11] == max(nbr) + 1                  # the row window
+            elo = int(H["rowptr"][n0 + lo]) - e0
+            assert rec[12] == elo and rec[13] == int(H["rowptr"][n0 + hi]) - e0 - elo
+            # in-edge descriptors of the forward image
+            f_img = int(rec[22]) * 2
+            ow = hi - lo
+            ev = lambda v: (v + 1) & ~1
+            oeg, oem = int(rec[13]), int(rec[17])
+            off = ev(ow + 1) + ev(oeg) + ev(ow + 1) + ev(oem)
+            off = (off + 7) & ~7
+            nbin = u16[f_img + off:f_img + off + 8 * ow].reshape(ow, 8)
+            for r in range(ow):
+                srcs = H["col"][H["rowptr"][n0 + lo + r]:H["rowptr"][n0 + lo + r + 1]] - n0
+                assert nbin[r, 0] == H["rowptr"][n0 + lo + r] - e0 - elo and nbin[r, 1] == len(srcs)
+                for k in range(6):
+                    assert nbin[r, 2 + k] == srcs[min(k, len(srcs) - 1)]
+            # forward hand-off lists: unique remote sources of own in-edges; own rows with an out-edge to a remote row
+            srcs = H["col"][H["rowptr"][n0 + lo]:H["rowptr"][n0 + hi]] - n0
+            want = sorted(set(int(j) for j in srcs if j < lo or j >= hi))
+            got = u16[int(rec[24]) * 2:int(rec[24]) * 2 + int(rec[25])]
+            assert list(got) == want
+            want_e = [r - n0 for r in rows
+                      if any((j - n0 < lo or j - n0 >= hi) for j in H["t_dst"][H["t_rowptr"][r]:H["t_rowptr"][r + 1]])]
+            got_e = u16[int(rec[26]) * 2:int(rec[26]) * 2 + int(rec[27])]
+            assert list(got_e) == want_e
+            # symmetric graph: what a part imports in the forward pass is what its partners export, and vice versa
+            assert int(rec[31]) == len(want)          # backward import rows = forward import rows on a symmetric graph
