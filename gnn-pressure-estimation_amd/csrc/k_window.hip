@@ -82,7 +82,8 @@ __global__ __launch_bounds__(THREADS) void gatres_window_kernel(const FusedArgs 
   // every hand-off: only when consumer workgroups read this part's tables in the same launch (xch_after)
   const bool pace = !a.sym, drain = a.C > 0;
   // first wave that issues LDS-DMA inside MFMA stages: the waves below it own a 16-row tile there (dma_copy16)
-  const int dw0 = min((ow + 15) >> 4, THREADS / 64 - 4);
+  constexpr int PW = 8;                    // waves that carry the work units of an MFMA stage (win_proj); NC == 32
+  const int dw0 = NC == 32 ? PW : min((ow + 15) >> 4, THREADS / 64 - 4);
   constexpr int WL_FLOATS = 2 * NC * (2 * NC + 4) + 4 * NC;
   constexpr int WLB = (WL_FLOATS + 3) & ~3;
   // small vectors in the tails of the W slots (filled by LDS-DMA with the slot's matrix: no stage starts with a global load)
@@ -232,9 +233,13 @@ __global__ __launch_bounds__(THREADS) void gatres_window_kernel(const FusedArgs 
       // W1 | att | bias of the next block while proj2 runs
       w_prefetch<2 * NC, NC, EPI_ATT, THREADS>(wlB, pb + L.c2_W, pb + L.c2_as, pb + L.c2_ad, dw0);
       vec_prefetch<THREADS>(wlB + B2OFF, pb + L.c2_b, NC);
-      seg_proj<NC, 2 * NC, 2, EPI_ATT, THREADS, true, true>(rw, xA, 0, pb + L.c1_W, base + SL.h1, 0, hA, 0, pb + L.c1_as,
-                                                             pb + L.c1_ad, base + SL.as1, base + SL.ad1, 0, sa2, sd2,
-                                                             nullptr, 0, nullptr, 0, wlA);
+      if constexpr (NC == 32)
+        win_proj<NC, 2 * NC, 2, EPI_ATT, 2, PW, THREADS>(rw, xA, wlA, base + SL.h1, 0, hA, base + SL.as1, base + SL.ad1, sa2, sd2,
+                                                     nullptr, nullptr, nullptr, nullptr);
+      else
+        seg_proj<NC, 2 * NC, 2, EPI_ATT, THREADS, true, true>(rw, xA, 0, pb + L.c1_W, base + SL.h1, 0, hA, 0, pb + L.c1_as,
+                                                               pb + L.c1_ad, base + SL.as1, base + SL.ad1, 0, sa2, sd2,
+                                                               nullptr, 0, nullptr, 0, wlA);
       dma_land(dw0);
       lds_barrier();                                      // own rows of h1 / a_src are in LDS; the saved copies drain meanwhile
       ++xc.ep;                                    // exchange F1: the gathers below read h1 / a_src of neighbour rows
@@ -268,7 +273,11 @@ __global__ __launch_bounds__(THREADS) void gatres_window_kernel(const FusedArgs 
         w_prefetch<NC, 2 * NC, EPI_ATT, THREADS>(wlA, pn + L.c1_W, pn + L.c1_as, pn + L.c1_ad, dw0);
         vec_prefetch<THREADS>(wlA + B1OFF, pn + L.c1_b, 2 * NC);
       }
-      seg_proj<2 * NC, NC, 1, EPI_ATT, THREADS, true, true>(rw, xB, 0, pb + L.c2_W, base + SL.h2, 0, hB, 0, pb + L.c2_as,
+      if constexpr (NC == 32)
+        win_proj<2 * NC, NC, 1, EPI_ATT, 2, PW, THREADS>(rw, xB, wlB, base + SL.h2, 0, hB, base + SL.as2, base + SL.ad2, sa1, sd1,
+                                                     nullptr, nullptr, nullptr, nullptr);
+      else
+        seg_proj<2 * NC, NC, 1, EPI_ATT, THREADS, true, true>(rw, xB, 0, pb + L.c2_W, base + SL.h2, 0, hB, 0, pb + L.c2_as,
                                                              pb + L.c2_ad, base + SL.as2, base + SL.ad2, 0, sa1, sd1,
                                                              nullptr, 0, nullptr, 0, wlB);
       dma_land(dw0);
@@ -542,10 +551,16 @@ __global__ __launch_bounds__(THREADS) void gatres_window_kernel(const FusedArgs 
       STAMP();
       dma_conv1_early();
       dma_copy4<THREADS>(alTw, base + SL.al1 + ewlo * 2, weg * 2, dw0);      // conv1's alpha (its table held conv2's until here)
-      seg_proj<NC, 2 * NC, 1, EPI_RESID_MASK, THREADS, true, true>(
-          rw, xG2, 0, wt2, RA, 0, nullptr, 0, nullptr, nullptr, nullptr, nullptr, 0, nullptr, nullptr, nullptr, 0,
-          (GATRES_DIAG && (a.no_halo & 4)) ? nullptr : base + SL.o1, 0, wlA, nullptr, nullptr, mo1 ? mo1 + b * ow : nullptr,
-          nullptr);
+      if (NC == 32 && a.keep_lds) {              // (the ReLU sign masks of the forward phase are in LDS: no global operand)
+        if constexpr (NC == 32)
+          win_proj<NC, 2 * NC, 1, EPI_RESID_MASK, 1, PW, THREADS>(rw, xG2, wlA, RA, 0, nullptr, nullptr, nullptr, nullptr, nullptr,
+                                                              nullptr, nullptr, mo1 + b * ow, nullptr);
+      } else {
+        seg_proj<NC, 2 * NC, 1, EPI_RESID_MASK, THREADS, true, true>(
+            rw, xG2, 0, wt2, RA, 0, nullptr, 0, nullptr, nullptr, nullptr, nullptr, 0, nullptr, nullptr, nullptr, 0,
+            (GATRES_DIAG && (a.no_halo & 4)) ? nullptr : base + SL.o1, 0, wlA, nullptr, nullptr, mo1 ? mo1 + b * ow : nullptr,
+            nullptr);
+      }
       dma_land(dw0);                             // the conv1 tables: the destination-major stage is next
       __syncthreads();
       XSTAMP();
@@ -573,11 +588,17 @@ __global__ __launch_bounds__(THREADS) void gatres_window_kernel(const FusedArgs 
       XSTAMP();
       STAMP();
       if (b > 0) { dma_conv2_early(b - 1, dw0); dma_conv2_late(b - 1, dw0); }
-      seg_proj<2 * NC, NC, 1, EPI_RESID_MASK, THREADS, true, true>(
-          rw, xG1, 0, wt1, gp_nxt, n0, gpT, 0, nullptr, nullptr, nullptr, nullptr, 0, nullptr, nullptr,
-          (GATRES_DIAG && (a.no_halo & 4)) ? nullptr : gp_cur, n0,
-          (b > 0 && !(GATRES_DIAG && (a.no_halo & 4))) ? base + SL.xin : nullptr, 0, wlB, gkeep, gkeep, nullptr,
-          (mxin && b > 0) ? mxin + b * ow : nullptr);
+      if (NC == 32 && a.keep_lds) {
+        if constexpr (NC == 32)
+          win_proj<2 * NC, NC, 1, EPI_RESID_MASK, 1, PW, THREADS>(rw, xG1, wlB, gp_nxt, n0, gpT, nullptr, nullptr, nullptr, nullptr,
+                                                              gkeep, gkeep, nullptr, b > 0 ? mxin + b * ow : nullptr);
+      } else {
+        seg_proj<2 * NC, NC, 1, EPI_RESID_MASK, THREADS, true, true>(
+            rw, xG1, 0, wt1, gp_nxt, n0, gpT, 0, nullptr, nullptr, nullptr, nullptr, 0, nullptr, nullptr,
+            (GATRES_DIAG && (a.no_halo & 4)) ? nullptr : gp_cur, n0,
+            (b > 0 && !(GATRES_DIAG && (a.no_halo & 4))) ? base + SL.xin : nullptr, 0, wlB, gkeep, gkeep, nullptr,
+            (mxin && b > 0) ? mxin + b * ow : nullptr);
+      }
       dma_land(dw0);
       XSTAMP();
       STAMP();

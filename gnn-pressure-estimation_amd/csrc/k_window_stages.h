@@ -125,6 +125,154 @@ __device__ __forceinline__ float4 as_f4(const uint4 v) {
   return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
 }
 
+// N 16-byte reads, one wait (N = 4, 6, 8, 12: the operand fragments of one MFMA work unit)
+__device__ __forceinline__ void lds_rd128x4(const unsigned (&a)[4], f32x4 (&v)[4]) {
+  asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %5\n\tds_read_b128 %2, %6\n\tds_read_b128 %3, %7\n\ts_waitcnt lgkmcnt(0)"
+               : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]) : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]) : "memory");
+}
+__device__ __forceinline__ void lds_rd128x8(const unsigned (&a)[8], f32x4 (&v)[8]) {
+  asm volatile(
+      "ds_read_b128 %0, %8\n\tds_read_b128 %1, %9\n\tds_read_b128 %2, %10\n\tds_read_b128 %3, %11\n\t"
+      "ds_read_b128 %4, %12\n\tds_read_b128 %5, %13\n\tds_read_b128 %6, %14\n\tds_read_b128 %7, %15\n\ts_waitcnt lgkmcnt(0)"
+      : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]), "=&v"(v[4]), "=&v"(v[5]), "=&v"(v[6]), "=&v"(v[7])
+      : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(a[4]), "v"(a[5]), "v"(a[6]), "v"(a[7])
+      : "memory");
+}
+__device__ __forceinline__ void lds_rd128x12(const unsigned (&a)[12], f32x4 (&v)[12]) {
+  asm volatile(
+      "ds_read_b128 %0, %12\n\tds_read_b128 %1, %13\n\tds_read_b128 %2, %14\n\tds_read_b128 %3, %15\n\t"
+      "ds_read_b128 %4, %16\n\tds_read_b128 %5, %17\n\tds_read_b128 %6, %18\n\tds_read_b128 %7, %19\n\t"
+      "ds_read_b128 %8, %20\n\tds_read_b128 %9, %21\n\tds_read_b128 %10, %22\n\tds_read_b128 %11, %23\n\ts_waitcnt lgkmcnt(0)"
+      : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]), "=&v"(v[4]), "=&v"(v[5]), "=&v"(v[6]), "=&v"(v[7]), "=&v"(v[8]),
+        "=&v"(v[9]), "=&v"(v[10]), "=&v"(v[11])
+      : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(a[4]), "v"(a[5]), "v"(a[6]), "v"(a[7]), "v"(a[8]), "v"(a[9]),
+        "v"(a[10]), "v"(a[11])
+      : "memory");
+}
+template <int N> __device__ __forceinline__ void lds_rd128xN(const unsigned (&a)[N], f32x4 (&v)[N]) {
+  static_assert(N == 4 || N == 6 || N == 8 || N == 12, "batch sizes of win_proj");
+  if constexpr (N == 4) lds_rd128x4(a, v);
+  else if constexpr (N == 6) lds_rd128x6(a, v);
+  else if constexpr (N == 8) lds_rd128x8(a, v);
+  else lds_rd128x12(a, v);
+}
+
+// ---------------------------------------------------------------------------------------------- MFMA stages
+// seg_proj (k_fused_dev.h) restated for the window kernel's widths (K, M multiples of 16, W and x operands in LDS):
+//   * a WORK UNIT is (16-row tile, group of NTG 16-column tiles): a part has three or four row tiles, so one tile per wave
+//     left twelve waves idle behind a chain of 32 dependent-issue MFMAs (~0.45 us); with the column tiles of a row tile on
+//     different waves the chain is 8 or 16 (NTG = 1 for the dX stages: no reduction across columns; NTG = M / H / 16 for the
+//     forward projections: a wave owns whole heads, so the attention logits reduce inside it, in seg_proj's order);
+//   * the unit's operand fragments -- x: K / 16 reads, W: NTG * K / 16 reads of 16 bytes -- are ONE batch (one wait) in
+//     front of the MFMA chain; seg_proj's loop had a wait after every 16-byte read of W.
+// Same lane map, k order and epilogue arithmetic as seg_proj: bit-identical results.
+//   X: [row][K] own rows (LDS, shifted view); wl: W slot [M][K + 4] (+ att_src[M] | att_dst[M] for EPI_ATT);
+//   OUT (global, row ob + r) / OUT2 (LDS, shifted view) / OUT3 (LDS [row][M], shifted view); resid_l: LDS [row][M];
+//   m64 / m32: relu_bits words per row (fields 16 / 8 bits apart).
+//   MW: the units go round the first MW waves only -- the waves behind them issue the stage's LDS-DMA, and a wave that
+//   streams from HBM sits in its issue loop for up to a microsecond (every CU streams at the same moment; a work unit on
+//   such a wave would start that much later: measured, 4.0 -> 4.9 us for dX1 + the hand-off behind it).
+template <int K, int M, int H, int EPI, int NTG, int MW, int THREADS>
+__device__ __forceinline__ void win_proj(Rows rw, const float* X, const float* wl, float* OUT, int ob, float* OUT2,
+                                         float* as_g, float* ad_g, float* as_l, float* ad_l, const float* resid_l,
+                                         float* OUT3, const unsigned long long* m64, const unsigned* m32) {
+  static_assert(K % 16 == 0 && M % 16 == 0, "whole tiles");
+  constexpr int KQ = K / 4, NT = M / 16, GROUPS = NT / NTG, KP = K + 4;
+  static_assert(MW >= 1 && MW <= THREADS / 64, "waves that carry work units");
+  constexpr int XR = KQ / 4, WR = NTG * KQ / 4;                    // 16-byte reads per unit: x fragment, W fragments
+  static_assert(NT % NTG == 0 && (EPI != EPI_ATT || NTG * 16 * H == M || H == 1), "a wave owns whole heads");
+  const int tid = stage_tid();
+  const int lane = tid & 63, wave = tid >> 6;
+  const int i = lane & 15, q = lane >> 4;
+  if (rw.hi <= rw.lo) return;                                  // (workgroup-uniform) an empty part of a split segment
+  const int tlo = rw.lo >> 4, ntiles = (rw.hi + 15) >> 4;      // rw.lo is 16-aligned
+  const int units = (ntiles - tlo) * GROUPS;
+  const unsigned a_x = lds_addr(X) + (unsigned)(q * KQ) * 4u, a_w = lds_addr(wl) + (unsigned)(i * KP + q * KQ) * 4u;
+  if (wave >= MW) return;
+  for (int u = wave; u < units; u += MW) {                     // (wave-uniform bounds; `wave` sits in a VGPR: see stage_tid)
+    const int t0 = tlo + u / GROUPS, g = u % GROUPS;
+    const int r = t0 * 16 + i;
+    const bool rok = r < rw.hi;
+    unsigned ad[XR + WR];
+    f32x4 fr[XR + WR];
+#pragma unroll
+    for (int s = 0; s < XR; ++s) ad[s] = a_x + (unsigned)(min(r, rw.hi - 1) * K + 4 * s) * 4u;
+#pragma unroll
+    for (int tt = 0; tt < NTG; ++tt)
+#pragma unroll
+      for (int s = 0; s < XR; ++s) ad[XR + tt * XR + s] = a_w + (unsigned)(((g * NTG + tt) * 16) * KP + 4 * s) * 4u;
+    lds_rd128xN<XR + WR>(ad, fr);
+    f32x4 acc[NTG];
+#pragma unroll
+    for (int tt = 0; tt < NTG; ++tt) acc[tt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    // seg_proj's order: k in steps of SC = 4 (one 16-byte fragment), all column tiles per step
+#pragma unroll
+    for (int s = 0; s < XR; ++s)
+#pragma unroll
+      for (int tt = 0; tt < NTG; ++tt)
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          acc[tt] = __builtin_amdgcn_mfma_f32_16x16x4f32(fr[XR + tt * XR + s][e], fr[s][e], acc[tt], 0, 0, 0);
+    if constexpr (EPI == EPI_ATT) {
+      // attention logits of the head(s) this unit owns: sum over the head's column tiles in order, then over the 4 lane
+      // groups (q) by the same two shuffles as seg_proj
+      constexpr int C = M / H, TPH = C / 16;                   // column tiles per head
+      const float* attS = wl + M * KP;
+      const float* attD = attS + M;
+      constexpr int HG = (NTG + TPH - 1) / TPH;                // heads per unit (1, or H when the unit spans all columns)
+      float ps[HG], pd[HG];
+#pragma unroll
+      for (int hh = 0; hh < HG; ++hh) { ps[hh] = 0.f; pd[hh] = 0.f; }
+#pragma unroll
+      for (int tt = 0; tt < NTG; ++tt) {
+        const int mb = (g * NTG + tt) * 16 + q * 4;
+        const float4 as = ld4(attS + mb), adv = ld4(attD + mb);
+        const float ds = fmaf(acc[tt][3], as.w, fmaf(acc[tt][2], as.z, fmaf(acc[tt][1], as.y, acc[tt][0] * as.x)));
+        const float dd = fmaf(acc[tt][3], adv.w, fmaf(acc[tt][2], adv.z, fmaf(acc[tt][1], adv.y, acc[tt][0] * adv.x)));
+        ps[tt / TPH] += ds; pd[tt / TPH] += dd;
+      }
+#pragma unroll
+      for (int hh = 0; hh < HG; ++hh) {
+        ps[hh] += __shfl_xor(ps[hh], 16); ps[hh] += __shfl_xor(ps[hh], 32);
+        pd[hh] += __shfl_xor(pd[hh], 16); pd[hh] += __shfl_xor(pd[hh], 32);
+      }
+      if (q == 0 && rok) {
+#pragma unroll
+        for (int hh = 0; hh < HG; ++hh) {
+          const int hd = (g * NTG) / TPH + hh;
+          as_g[(unsigned)(r * H + hd)] = ps[hh];
+          ad_g[(unsigned)(r * H + hd)] = pd[hh];
+          as_l[r * H + hd] = ps[hh]; ad_l[r * H + hd] = pd[hh];
+        }
+      }
+    }
+    if (rok) {
+      unsigned long long mw = 0;
+      int fs = 16;
+      if constexpr (EPI == EPI_RESID_MASK) {
+        if (m64) mw = m64[r];
+        else if (m32) { mw = m32[r]; fs = 8; }
+      }
+#pragma unroll
+      for (int tt = 0; tt < NTG; ++tt) {
+        const int mb = (g * NTG + tt) * 16 + q * 4;
+        float4 o = make_float4(acc[tt][0], acc[tt][1], acc[tt][2], acc[tt][3]);
+        if constexpr (EPI == EPI_RESID_MASK) {
+          if (resid_l) add4(o, ld4(resid_l + (unsigned)(r * M + mb)));
+          if (m64 || m32) {
+            const unsigned long long b = mw >> (mb >> 2);
+            o.x = (b & 1) ? o.x : 0.f;                 o.y = ((b >> fs) & 1) ? o.y : 0.f;
+            o.z = ((b >> (2 * fs)) & 1) ? o.z : 0.f;   o.w = ((b >> (3 * fs)) & 1) ? o.w : 0.f;
+          }
+        }
+        st4(OUT + (unsigned)((ob + r) * M + mb), o);
+        if (OUT2) st4(OUT2 + (unsigned)(r * M + mb), o);
+        if (OUT3) st4(OUT3 + (unsigned)(r * M + mb), o);
+      }
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------------------------- granule exchange, 16-byte form
 // The hand-offs of k_fused_dev.h (xch_export / xch_import: one 8-byte {value, epoch} granule per memory instruction, one
 // table per call) restated for the window kernel:
