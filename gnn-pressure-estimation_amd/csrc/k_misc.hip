@@ -547,9 +547,18 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
                                                    float* __restrict__ m, float* __restrict__ v,
                                                    unsigned long long* __restrict__ step_counter, long long count,
                                                    double lr, double b1, double b2, double eps, double wd,
-                                                   float grad_scale, float* __restrict__ wt, int nb, int nc) {
+                                                   float grad_scale, float* __restrict__ wt, int nb, int nc,
+                                                   int drop_marked) {
   __shared__ float s_step_size, s_bc2_sqrt;
+  __shared__ int s_drop;
   unsigned long long done = 0ULL;
+  // drop_marked (the data-parallel Adam phase only): a fused launch that faulted marks EVERY gradient entry NaN
+  // (gatres_fused_finish) and the all-reduce spreads the mark to all ranks; the step is then dropped on every replica alike
+  // -- no update, no step count.  Everywhere else (gatres_adam_step, FusedAdam) a NaN gradient propagates exactly as in
+  // torch.optim.Adam, which the reference uses (train.py:348).
+  if (threadIdx.x == 0) s_drop = (drop_marked && g[0] != g[0]) ? 1 : 0;
+  __syncthreads();
+  if (s_drop) return;
   if (threadIdx.x == 0) {
     const unsigned long long t = __hip_atomic_load(step_counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1ULL;
     const double bc1 = 1.0 - gatres_powi(b1, t), bc2 = 1.0 - gatres_powi(b2, t);
@@ -564,10 +573,7 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
   // Grid-stride: the launch has at most ADAM_MAX_BLOCKS blocks.  One block per 256 parameters meant 6.6 k tickets on ONE
   // address for gatres_large -- they serialise in the L2 at ~20 ns each and were the whole 146 us of the launch.
   for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < count; idx += (long long)gridDim.x * 256) {
-  // A NaN gradient entry leaves its parameter and moments untouched: a data-parallel step whose fused launch faulted
-  // (gatres_fused_finish marks every entry NaN, the all-reduce spreads that to all ranks) is dropped on every replica
-  // alike instead of destroying the run.  (torch.optim.Adam would propagate the NaN.)
-  if (g[idx] == g[idx]) {
+  {
     const float pv = p[idx];
     float gv = g[idx] * grad_scale;
     gv = gv + (float)wd * pv;
@@ -825,13 +831,14 @@ extern "C" int gatres_adam_step(float* params, const float* grads, float* exp_av
   if (!params || !grads || !exp_avg || !exp_avg_sq || !step_counter || count <= 0) return GATRES_E_BADARG;
   hipLaunchKernelGGL(adam_kernel, dim3(adam_blocks(count)), dim3(256), 0, gatres_stream(stream), params,
                      grads, exp_avg, exp_avg_sq, reinterpret_cast<unsigned long long*>(step_counter),
-                     (long long)count, lr, beta1, beta2, eps, weight_decay, grad_scale, (float*)nullptr, 0, 0);
+                     (long long)count, lr, beta1, beta2, eps, weight_decay, grad_scale, (float*)nullptr, 0, 0, 0);
   return gatres_launch_status();
 }
 
 // (not part of include/gatres.h: the fused train step's Adam-only phase -- the data-parallel step runs backward |
 //  all-reduce | Adam -- also refreshes scratch's transposed conv weights, so the next backward finds them current.
-//  A NaN gradient entry leaves parameter AND transposed copy untouched: they stay consistent.)
+//  A step whose gradient carries the fault mark (every entry NaN) is dropped whole: parameters, moments, step count and the
+//  transposed copy stay as they were.)
 extern "C" __attribute__((visibility("hidden"))) int gatres_adam_step_wt(float* params, const float* grads, float* exp_avg, float* exp_avg_sq,
                                    uint64_t* step_counter, int64_t count, double lr, double beta1, double beta2,
                                    double eps, double weight_decay, float grad_scale, float* wt, int32_t num_blocks,
@@ -839,7 +846,7 @@ extern "C" __attribute__((visibility("hidden"))) int gatres_adam_step_wt(float* 
   if (!params || !grads || !exp_avg || !exp_avg_sq || !step_counter || count <= 0 || !wt) return GATRES_E_BADARG;
   hipLaunchKernelGGL(adam_kernel, dim3(adam_blocks(count)), dim3(256), 0, gatres_stream(stream), params,
                      grads, exp_avg, exp_avg_sq, reinterpret_cast<unsigned long long*>(step_counter),
-                     (long long)count, lr, beta1, beta2, eps, weight_decay, grad_scale, wt, (int)num_blocks, (int)nc);
+                     (long long)count, lr, beta1, beta2, eps, weight_decay, grad_scale, wt, (int)num_blocks, (int)nc, 1);
   return gatres_launch_status();
 }
 

@@ -125,12 +125,21 @@ class GATResTrainer:
             self.loss.data_ptr(), self.saved.data_ptr(), self.scratch.data_ptr(), h["lr"], h["beta1"], h["beta2"],
             h["eps"], h["weight_decay"], 1.0 / self.world, (0 if self.fused else 1) | (2 if wt_valid else 0))
 
-    def _param_signature(self) -> Tuple[int, int]:
+    def _count_native_update(self) -> None:
+        """A native kernel (fused Adam pass, Adam-only phase) just changed the parameters without touching torch's
+        version counters.  The count lives on the MODEL: trainers that share it (``fit_epoch``'s sibling for the ragged
+        last batch, a trainer per batch size) each keep transposed conv weights in their OWN scratch buffer, and a step
+        of one must invalidate the copies of the others (the sibling's step left the main trainer's W^T one
+        update behind while its signature still matched)."""
+        self.model._native_updates = getattr(self.model, "_native_updates", 0) + 1
+
+    def _param_signature(self) -> Tuple[int, int, int]:
         """Changes whenever anything wrote to the parameters THROUGH TORCH: the flat vector or any of the nn.Parameters
         that are views of it (every Parameter has its own version counter: ``load_state_dict``, ``torch.optim`` steps,
         ``init_`` / ``clip_`` calls bump those, not the flat vector's).  Writes that bypass autograd's bookkeeping
         (``p.data.mul_()``) are invisible to it: call ``invalidate_weights()`` after such an edit."""
-        return self.model.flat_parameters._version, sum(p._version for p in self.model._param_list)
+        return (self.model.flat_parameters._version, sum(p._version for p in self.model._param_list),
+                getattr(self.model, "_native_updates", 0))
 
     def _wt_current(self) -> bool:
         """scratch's transposed conv weights are current: our last fused Adam step wrote them and nothing has modified
@@ -179,7 +188,9 @@ class GATResTrainer:
             self._replay(self._graph_key(phases, device_mask, wt_valid),
                          lambda: self._enqueue(phases, device_mask, wt_valid), wt_valid)
         finally:
-            # a fused backward + Adam step leaves the transposed weights of the NEW parameters in scratch
+            if phases & PHASE_ADAM:
+                self._count_native_update()
+            # a fused backward + Adam step leaves the transposed weights of the NEW parameters in (this trainer's) scratch
             if self.fused and (phases & full) == full:
                 self._wt_sig = self._param_signature()
 
@@ -213,6 +224,7 @@ class GATResTrainer:
                     self.scratch.data_ptr(), _native.current_stream(self.device)), "gatres_fused_prepare_backward")
             self._graphs[key] = g
             while len(self._graphs) > MAX_CACHED_GRAPHS:
+                torch.cuda.synchronize(self.device)      # (its last replay may still be in flight on the stream)
                 self._graphs.popitem(last=False)
         else:
             self._graphs.move_to_end(key)
@@ -256,6 +268,7 @@ class GATResTrainer:
                          lambda: dp.run_data_parallel_step(self._backward_pieces(device_mask, wt_valid, premasked), self.reducer,
                                                            lambda: self._enqueue(PHASE_ADAM, device_mask)), wt_valid)
         finally:
+            self._count_native_update()
             if self.fused:
                 self._wt_sig = self._param_signature()
 

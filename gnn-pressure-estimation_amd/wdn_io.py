@@ -29,6 +29,9 @@ import zlib
 from collections import OrderedDict
 from typing import Dict, Iterable, List, Optional, Sequence, Tuple
 
+import os
+import warnings
+
 import numpy as np
 import torch
 
@@ -39,23 +42,32 @@ _NODE_SECTIONS = ("JUNCTIONS", "RESERVOIRS", "TANKS")
 _LINK_SECTIONS = ("PIPES", "PUMPS", "VALVES")
 
 
-def parse_inp(source) -> Dict[str, list]:
-    """Topology sections of an EPANET input file.  ``source``: a path, or the file's text.  Returns
+def parse_inp(source=None, *, text: Optional[str] = None) -> Dict[str, list]:
+    """Topology sections of an EPANET input file.  ``source``: a path (``str`` / ``os.PathLike``); ``text=``: the file's
+    text instead.  (A ``str`` that is not an existing path but contains a newline is still taken as text, as before; a path
+    with brackets in it -- ``/data/run[1]/ctown.inp`` -- is a path.)  Returns
     ``{"JUNCTIONS": [id, ...], "RESERVOIRS": [...], "TANKS": [...], "PIPES": [(id, node1, node2), ...], "PUMPS": [...],
     "VALVES": [...]}`` in file order.  ``;`` starts a comment, section names are case-insensitive, ids are the first
-    whitespace-separated tokens of a line (EPANET 2.2 users manual, appendix C)."""
-    text = source
-    if "\n" not in str(source) and "[" not in str(source):
-        with open(source, "r", encoding="latin-1") as f:
-            text = f.read()
+    whitespace-separated tokens of a line (EPANET 2.2 users manual, appendix C).  Raises if the text has no
+    ``[JUNCTIONS]`` section (not an EPANET input file)."""
+    if (source is None) == (text is None):
+        raise ValueError("parse_inp: give a path OR text=")
+    if text is None:
+        if isinstance(source, os.PathLike) or os.path.exists(str(source)) or "\n" not in str(source):
+            with open(source, "r", encoding="latin-1") as f:       # (a missing file raises FileNotFoundError here)
+                text = f.read()
+        else:
+            text = str(source)
     out: Dict[str, list] = {k: [] for k in _NODE_SECTIONS + _LINK_SECTIONS}
     section = None
+    seen_sections = set()
     for raw in str(text).splitlines():
         line = raw.split(";", 1)[0].strip()
         if not line:
             continue
         if line.startswith("["):
             section = line.strip("[]").strip().upper()
+            seen_sections.add(section)
             continue
         tok = line.split()
         if section in _NODE_SECTIONS:
@@ -64,6 +76,10 @@ def parse_inp(source) -> Dict[str, list]:
             if len(tok) < 3:
                 raise ValueError(f"[{section}] line needs an id and two node ids: {raw!r}")
             out[section].append((tok[0], tok[1], tok[2]))
+        if section is not None:
+            seen_sections.add(section)
+    if "JUNCTIONS" not in seen_sections:
+        raise ValueError("no [JUNCTIONS] section: not an EPANET .inp file")
     return out
 
 
@@ -108,19 +124,26 @@ def inp_edge_index(inp: Dict[str, list], removal: str = "keep_junction") -> Tupl
             if u not in seen[v]:
                 seen[v].add(u); adj[v].append(u)
     adj = _readd(nodes, adj)                                                               # .to_undirected()
+    subgraph = True
     if removal == "keep_junction":
         keep = set(inp["JUNCTIONS"])
     elif removal == "keep_all":
-        keep = set(nodes)
-    elif removal == "reservoir":
-        keep = set(nodes) - set(inp["RESERVOIRS"])
+        keep, subgraph = set(nodes), False
+    elif removal == "reservoir":           # (get_keep_list: no reservoirs / tanks = no keep list = the graph itself)
+        keep, subgraph = set(nodes) - set(inp["RESERVOIRS"]), bool(inp["RESERVOIRS"])
     elif removal == "tank":
-        keep = set(nodes) - set(inp["TANKS"])
+        keep, subgraph = set(nodes) - set(inp["TANKS"]), bool(inp["TANKS"])
     else:
         raise ValueError(f"removal {removal!r}: use keep_junction / keep_all / reservoir / tank")
     kept = [n for n in nodes if n in keep]
+    if subgraph and 2 * len(keep) < len(nodes):
+        # networkx walks the KEEP SET (hash order of the names) instead of the graph when it is the smaller one
+        # (FilterAtlas.__iter__): the reference's node order is then arbitrary from run to run
+        warnings.warn("fewer than half of the nodes are kept: the reference's node order is undefined here (networkx "
+                      "iterates the keep set); using the .inp registry order", stacklevel=2)
     sub = OrderedDict((n, [v for v in adj[n] if v in keep]) for n in kept)
-    sub = _readd(kept, sub)                                                                # .subgraph(keep).copy()
+    if subgraph:
+        sub = _readd(kept, sub)                                                            # .subgraph(keep).copy()
     # from_networkx: to_directed() keeps adjacency order; edges() = for u in nodes: for v in succ[u]
     new_id = {n: i for i, n in enumerate(kept)}
     src = [new_id[u] for u in kept for _ in sub[u]]

@@ -311,6 +311,37 @@ def test_snapshot_store_collation_on_device_and_fit_epoch(pkg, oracle):
     assert torch.equal(model.flat_parameters, twin.flat_parameters)
 
 
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_fit_epoch_two_epochs_with_a_ragged_tail_keeps_transposed_weights_current(pkg, oracle, use_graph):
+    """every trainer keeps the transposed conv weights of the fused backward in its OWN scratch buffer
+    and skips their re-derivation while "nothing changed the parameters since my last step" -- which a sibling trainer's
+    step (the ragged last batch of fit_epoch) does.  Two epochs of 4 + 4 + 3 graphs must equal, bit for bit, the same
+    loop on a twin whose trainers are told to re-derive the transposes before EVERY step."""
+    one = pkg.wdn_synth.make_wdn_topology()
+    raw = pkg.wdn_synth.make_snapshots(11, 388, seed=3) * 6 + 35
+    st = pkg.SnapshotStore(raw, one, device="cuda")
+    nb, nc, bs = 3, 32, 4
+    model, _ = build(pkg, oracle, nb, nc, seed=8)
+    tr = pkg.GATResTrainer(model, st.edge_index(bs), 388 * bs, nodes_per_graph=[388] * bs, seed=5, targets_are_inputs=True,
+                           use_graph=use_graph)
+    losses = [tr.fit_epoch(st, bs, shuffle=True, generator=torch.Generator().manual_seed(7 + ep))[0] for ep in range(2)]
+    assert tr.optimizer_step == 6
+    twin, _ = build(pkg, oracle, nb, nc, seed=8)
+    t4 = pkg.GATResTrainer(twin, st.edge_index(bs), 388 * bs, nodes_per_graph=[388] * bs, seed=5, targets_are_inputs=True,
+                           use_graph=False)
+    t3 = pkg.GATResTrainer(twin, st.edge_index(3), 388 * 3, nodes_per_graph=[388] * 3, seed=5, targets_are_inputs=True,
+                           use_graph=False, _share_state_with=t4)
+    for ep in range(2):
+        tot, n = 0.0, 0
+        for xb, eib, ng in st.batches(bs, shuffle=True, generator=torch.Generator().manual_seed(7 + ep)):
+            t = t4 if ng == bs else t3
+            t.invalidate_weights()
+            tot += float(t.step(xb, xb)) * ng
+            n += ng
+        assert abs(losses[ep] - tot / n) < 1e-6 * abs(tot / n), ep
+    assert torch.equal(model.flat_parameters, twin.flat_parameters)
+
+
 def test_bucketed_allreduce_in_graph_rccl_one_rank(pkg, oracle):
     """The multi-rank step (backward pieces | bucketed RCCL all-reduce | Adam) captured into ONE hipGraph, exercised on
     a single GPU with a one-rank nccl group: per-op path with one bucket per block (gatres_large's scheme) and the fused

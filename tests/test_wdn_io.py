@@ -191,3 +191,28 @@ def test_adam_state_moves_between_torch_and_the_native_trainer(pkg, oracle):
     io.load_adam_state_dict(tc, opt.state_dict())
     assert tc.optimizer_step == 4 and ta.optimizer_step == 4
     assert float((tc.exp_avg - ta.exp_avg).abs().max()) <= 1e-5 * float(ta.exp_avg.abs().max()) + 1e-9
+
+
+def test_parse_inp_paths_text_and_errors(pkg, tmp_path):
+    """ADVICE r2: a path with brackets in it is a path; text goes through ``text=``; a text without [JUNCTIONS] raises;
+    a keep set smaller than half of the network warns that the reference's node order is undefined there."""
+    io = pkg.wdn_io
+    src = open(os.path.join(GOLDEN, "wdn_tiny.inp")).read()
+    d = tmp_path / "run[1]"
+    d.mkdir()
+    p = d / "net.inp"
+    p.write_text(src)
+    ref = io.parse_inp(os.path.join(GOLDEN, "wdn_tiny.inp"))
+    assert io.parse_inp(str(p)) == ref and io.parse_inp(p) == ref and io.parse_inp(text=src) == ref
+    with pytest.raises(FileNotFoundError):
+        io.parse_inp(str(d / "missing.inp"))
+    with pytest.raises(ValueError):
+        io.parse_inp(text="[PIPES]\n P1 A B 1 1 1\n")
+    with pytest.raises(ValueError):
+        io.parse_inp()
+    few = dict(ref)
+    few = {k: list(v) for k, v in ref.items()}
+    few["JUNCTIONS"], few["TANKS"] = ref["JUNCTIONS"][:2], ref["TANKS"] + ref["JUNCTIONS"][2:]      # 2 of 9 nodes are junctions
+    with pytest.warns(UserWarning, match="undefined"):
+        ei, names = io.inp_edge_index(few, "keep_junction")
+    assert names == few["JUNCTIONS"]
