@@ -213,6 +213,77 @@ def gatres_forward(p: Dict[str, torch.Tensor], x, edge_index, num_blocks: Option
 
 
 # ----------------------------------------------------------------------------------------------
+# bf16 storage mode (BASELINE config 3): the same model with the build's rounding points
+# ----------------------------------------------------------------------------------------------
+# The reference has no reduced-precision mode; this section restates what the BUILD's bf16 mode does (csrc/model_driver.hip,
+# gatres_model_t.act_dtype) so that its whole-model tests can tell rounding from a bug: activation-sized tensors and their
+# gradients are STORED as bf16 (round to nearest even), conv weights are read as bf16 copies of the fp32 masters, and
+# everything else -- accumulators, attention logits (taken from the fp32 accumulators BEFORE h is rounded), alpha, softmax,
+# x / y / out, parameter gradients, Adam -- stays fp32.
+class _StoreBF16(torch.autograd.Function):
+    """A tensor that lives in HBM as bf16: the forward value is rounded, and so is the gradient that arrives for it
+    (the kernels store g_pre / g_y2 / g_h / g_out1 as bf16 after summing every contribution in fp32)."""
+
+    @staticmethod
+    def forward(ctx, t, round_value, round_grad):
+        ctx.round_grad = round_grad
+        return t.to(torch.bfloat16).to(t.dtype) if round_value else t.clone()
+
+    @staticmethod
+    def backward(ctx, g):
+        return (g.to(torch.bfloat16).to(g.dtype) if ctx.round_grad else g), None, None
+
+
+def _store(t):          # value and gradient rounded
+    return _StoreBF16.apply(t, True, True)
+
+
+def _grad_store(t):     # gradient rounded, value kept (the fp32 accumulators the attention logits are formed from)
+    return _StoreBF16.apply(t, False, True)
+
+
+def _value_store(t):    # value rounded, gradient kept (bf16 copies of the fp32 master weights; h for the messages)
+    return _StoreBF16.apply(t, True, False)
+
+
+def gat_conv_bf16(x, edge_index, weight, att_src, att_dst, bias, heads: int, concat: bool):
+    """gat_conv with the build's bf16 rounding points: x arrives rounded; h_acc = x @ bf16(W)^T in fp32; the logits use
+    h_acc; the messages use bf16(h_acc); the gradient of h_acc (message path + logit path, summed in fp32) is stored as
+    bf16 (gatres_t_gat_aggregate_bwd_src's g_h).  The caller rounds the output."""
+    N = x.shape[0]
+    H = heads
+    C = weight.shape[0] // H
+    h_acc = _grad_store(x @ _value_store(weight).t()).view(N, H, C)
+    a_src = (h_acc * att_src).sum(dim=-1)
+    a_dst = (h_acc * att_dst).sum(dim=-1)
+    h = _value_store(h_acc)
+    ei = add_self_loops(remove_self_loops(edge_index), N)
+    src, dst = ei[0], ei[1]
+    s = torch.nn.functional.leaky_relu(a_src.index_select(0, src) + a_dst.index_select(0, dst), NEG_SLOPE)
+    alpha = segment_softmax(s, dst, N)
+    out = torch.zeros((N, H, C), dtype=x.dtype).index_add_(0, dst, alpha.unsqueeze(-1) * h.index_select(0, src))
+    out = out.reshape(N, H * C) if concat else out.mean(dim=1)
+    return out + bias
+
+
+def gatres_forward_bf16(p: Dict[str, torch.Tensor], x, edge_index, num_blocks: Optional[int] = None):
+    """GATResMeanConv.forward in the build's bf16 storage mode (fp32 arithmetic, bf16 rounding where the kernels store
+    bf16: lin0's output, h1, relu(conv1), h2, conv2's output, every block output, and the gradients of those)."""
+    if num_blocks is None:
+        num_blocks = sum(1 for k in p if k.endswith("conv1.bias"))
+    x = _store(x @ p["lin0.weight"].t() + p["lin0.bias"])
+    for i in range(num_blocks):
+        pre = f"blocks.{i}."
+        x0 = x
+        o1 = _store(gat_conv_bf16(x, edge_index, p[pre + "conv1.lin_src.weight"], p[pre + "conv1.att_src"],
+                                  p[pre + "conv1.att_dst"], p[pre + "conv1.bias"], 2, True)).relu()
+        y2 = _store(gat_conv_bf16(o1, edge_index, p[pre + "conv2.lin_src.weight"], p[pre + "conv2.att_src"],
+                                  p[pre + "conv2.att_dst"], p[pre + "conv2.bias"], 1, False))
+        x = _store(simple_conv_mean(y2, edge_index) + x0).relu()
+    return x @ p["lin1.weight"].t() + p["lin1.bias"]
+
+
+# ----------------------------------------------------------------------------------------------
 # caller side: mask, loss, optimiser  (train.py:159-190, auxil.py:143-182)
 # ----------------------------------------------------------------------------------------------
 def mask_nodes(num_nodes: int, masking_rate: float, rng: np.random.RandomState) -> np.ndarray:
@@ -273,16 +344,17 @@ class OracleTrainer:
     (train.py:348), MSELoss (train.py:364), one ``step`` = train.py:160-188.  Used as the CPU baseline and as the
     multi-step parity checker."""
 
-    def __init__(self, params: Dict[str, torch.Tensor], lr: float = 5e-4, weight_decay: float = 6e-6):
+    def __init__(self, params: Dict[str, torch.Tensor], lr: float = 5e-4, weight_decay: float = 6e-6, bf16: bool = False):
         self.params = OrderedDict((k, v.detach().clone().requires_grad_(True)) for k, v in params.items())
         self.opt = torch.optim.Adam(list(self.params.values()), lr=lr, weight_decay=weight_decay)
+        self.forward = gatres_forward_bf16 if bf16 else gatres_forward      # (bf16: the build's storage mode, above)
 
     def step(self, x, y, edge_index, mask):
         self.opt.zero_grad()
         m = torch.as_tensor(mask, dtype=torch.bool)
         xin = x.clone()
         xin[m] = 0
-        out = gatres_forward(self.params, xin, edge_index)
+        out = self.forward(self.params, xin, edge_index)
         loss = torch.nn.functional.mse_loss(out[m], y[m])
         loss.backward()
         self.opt.step()

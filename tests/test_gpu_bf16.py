@@ -105,6 +105,23 @@ def test_bf16_model_vs_fp32_oracle(pkg, oracle, nb, nc, bs):
     # 1.4e-2 at the single worst node (bf16 rounding of the residual stream accumulates over 25 blocks)
     assert e_l2 < 1e-2 and e_out < 2.5e-2 and e_loss < 2e-2
     assert torch.isfinite(g).all() and e_g2 < 1.5e-1 and e_g < 1.5e-1      # (measured: 1.0e-1 / 3e-2 on gatres_large)
+    # ... and against the oracle that rounds to bf16 exactly where the kernels store bf16 (oracle.gatres_forward_bf16):
+    # what is left is fp32 summation order and the stored values it flips by one bf16 ulp.  Shallow models agree to 1e-4
+    # (measured: 2 x 64: 1.0e-4 / 1.6e-4, 3 x 128: 8.1e-4 / 2.1e-4 for predictions / flat gradient); through 15 - 25
+    # blocks every flip is a fresh 2^-8 perturbation of the residual stream, so the two bf16 trajectories drift apart
+    # (25 x 128: 4.5e-3 / 4.2e-3) -- the gradient bound is still 15 - 30x tighter than against the fp32 oracle (1.0e-1),
+    # which is what keeps a wrong-but-small term in the bf16 backward from hiding behind rounding
+    lb = {k: v.clone().requires_grad_(True) for k, v in p.items()}
+    out_b = oracle.gatres_forward_bf16(lb, xin, ei, num_blocks=nb)
+    loss_b = torch.nn.functional.mse_loss(out_b[mask], y[mask])
+    loss_b.backward()
+    g_b = torch.cat([v.grad.reshape(-1) for v in lb.values()])
+    f_l2 = float((out.detach().cpu().double() - out_b.detach().double()).norm() / out_b.detach().double().norm())
+    f_g2 = float((g.cpu().double() - g_b.double()).norm() / g_b.double().norm())
+    f_loss = relerr(loss, loss_b)
+    note(f"bf16 {nb}x{nc} bs{bs}: predictions rel-L2, loss, flat gradient rel-L2 vs the bf16-rounding oracle", [f_l2, f_loss, f_g2])
+    shallow = nb <= 3
+    assert f_l2 < (2e-3 if shallow else 8e-3) and f_loss < 2e-3 and f_g2 < (1e-3 if shallow else 1e-2), (f_l2, f_loss, f_g2)
     # inference path (no saved activations) == training path, and repeatable bit for bit
     with torch.no_grad():
         o2 = model(xin.cuda(), ei.cuda())
@@ -176,3 +193,49 @@ def test_bf16_weight_gradients_two_dimensional_partials(pkg, oracle, monkeypatch
         grads.append(tr.grads.clone())
     assert torch.isfinite(grads[0]).all() and float(grads[0].abs().max()) > 0
     assert relerr(grads[0], grads[1]) < 1e-5
+
+
+def test_bf16_gatres_large_full_batch_128(pkg, oracle):
+    """BASELINE config 3 at its real size in bf16 (25 x 128, C-Town, bs = 128: the 256-slab two-dimensional weight-gradient
+    partials run here, not at a toy batch): block-diagonal independence and bitwise repeatability of the predictions,
+    one graph of the batch against the bf16-rounding oracle, and one native training step -- finite loss, exactly
+    128 x 368 masked nodes, every parameter moved by at most ~lr, gradient of the step against the same oracle."""
+    nb, nc, bs = 25, 128, 128
+    model, p = build(pkg, oracle, nb, nc, seed=3)
+    model.set_compute_dtype("bf16")
+    x, y, ei, mask = ctown_batch(pkg, bs)
+    dx, dei = x.cuda(), ei.cuda()
+    with torch.no_grad():
+        out = model(dx, dei)
+        assert out.shape == (388 * bs, 1) and torch.isfinite(out).all()
+        one = pkg.wdn_synth.make_wdn_topology()
+        first = model(dx[:388], one.cuda())
+        assert torch.equal(out[:388], first) and torch.equal(model(dx, dei), out)
+        ref = oracle.gatres_forward_bf16(p, x[:388], one)
+    e = float((first.cpu().double() - ref.double()).norm() / ref.double().norm())
+    note("bf16 gatres_large 25x128 bs128: one graph of the batch vs the bf16-rounding oracle (rel-L2)", e)
+    assert e < 8e-3          # (measured 3.9e-3: 25 blocks, see test_bf16_model_vs_fp32_oracle)
+    # the step's gradient on a 4-graph slice of the same batch vs the oracle (the oracle needs ~1 min per 4 graphs)
+    sub = 4
+    xs, ys, ms = x[:388 * sub], y[:388 * sub], mask[:388 * sub]
+    eis = pkg.wdn_synth.collate_edge_index(one, 388, sub)
+    lb = {k: v.clone().requires_grad_(True) for k, v in p.items()}
+    xin = xs.clone(); xin[ms] = 0
+    ob = oracle.gatres_forward_bf16(lb, xin, eis, num_blocks=nb)
+    torch.nn.functional.mse_loss(ob[ms], ys[ms]).backward()
+    g_b = torch.cat([v.grad.reshape(-1) for v in lb.values()])
+    model.zero_grad()
+    o = model(xin.cuda(), eis.cuda())
+    torch.nn.functional.mse_loss(o[ms.cuda()], ys.cuda()[ms.cuda()]).backward()
+    g = torch.cat([q.grad.reshape(-1) for q in model.parameters()])
+    f_g2 = float((g.cpu().double() - g_b.double()).norm() / g_b.double().norm())
+    note("bf16 gatres_large 25x128: flat gradient (4 graphs) vs the bf16-rounding oracle (rel-L2)", f_g2)
+    assert f_g2 < 1e-2
+    before = model.flat_parameters.clone()
+    tr = pkg.GATResTrainer(model, dei, 388 * bs, nodes_per_graph=[388] * bs, use_graph=False)
+    assert not tr.fused
+    loss = tr.step(dx.reshape(-1), dx.reshape(-1))
+    assert torch.isfinite(loss).all() and int(tr.mask.sum()) == bs * 368
+    d = (model.flat_parameters - before).abs()
+    assert torch.isfinite(tr.grads).all() and 0 < float(d.max()) <= 5e-4 * 1.01
+
