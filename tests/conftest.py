@@ -10,6 +10,25 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # Multi-process GPU tests (tests/test_gpu_two_ranks.py) fork their ranks from a FORK SERVER that must exist before
+    # anything in this process initialises HIP: a process that has touched the GPU must not exec (the pool refuses it) and
+    # its forked copies cannot use the GPU.  Starting the server costs one exec of a small Python process, here and now.
+    import multiprocessing
+    import multiprocessing.forkserver
+    try:
+        multiprocessing.get_context("forkserver")
+        multiprocessing.forkserver.ensure_running()
+    except Exception as e:          # (platforms without forkserver: the tests that need it are skipped)
+        config._gatres_forkserver_error = e
+
+
+@pytest.fixture(scope="session")
+def fork_ctx(request):
+    err = getattr(request.config, "_gatres_forkserver_error", None)
+    if err is not None:
+        pytest.skip(f"no fork server: {err}")
+    import multiprocessing
+    return multiprocessing.get_context("forkserver")
 
 
 @pytest.fixture(scope="session")

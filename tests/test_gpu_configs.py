@@ -101,6 +101,57 @@ def test_50k_node_graph(pkg, oracle, nb, nc):
     assert torch.isfinite(ga).all() and torch.equal(ga, _flat_grads(model))
 
 
+def test_config5_real_size_25x128_on_two_50k_node_graphs(pkg, oracle, lib):
+    """BASELINE config 5 as ONE RANK holds it: gatres_large (25 x 128) on a batch of 2 x 50 000-node / 75 000-pipe graphs,
+    per-op kernels, fp32.  The saved activations are 7.9 GB: byte offsets pass 2^32 inside the second graph's half of
+    every table -- where a 32-bit offset breaks silently.  Checked: (1) block-diagonal independence and bitwise repeats
+    of the predictions; (2) the batch's gradient equals the masked-count-weighted mean of the two single-graph
+    gradients (each of which runs below the 4-GB line: the combination pins the upper half of every table);
+    (3) the oracle, 25 blocks on one graph: predictions, loss and the full gradient."""
+    nb, nc, n, pipes = 25, 128, 50000, 75000
+    one = pkg.wdn_synth.make_wdn_topology(n, pipes, seed=0, max_degree=6)
+    model, p = build(pkg, oracle, nb, nc, seed=7)
+    gen = torch.Generator().manual_seed(1)
+    ys = [torch.randn(n, 1, generator=gen) for _ in range(2)]
+    rng = np.random.RandomState(2)
+    masks = [torch.from_numpy(pkg.wdn_synth.generate_batch_mask([n], 0.95, rng)) for _ in range(2)]
+    ei2 = pkg.wdn_synth.collate_edge_index(one, n, 2).cuda()
+    y2, m2 = torch.cat(ys).cuda(), torch.cat(masks).cuda()
+    tr2 = pkg.GATResTrainer(model, ei2, 2 * n, nodes_per_graph=[n, n], use_graph=False)
+    assert not tr2.fused
+    saved_floats = int(lib.gatres_saved_floats(model._cmodel_ref(), tr2.plan.ref()))
+    assert saved_floats * 4 > 2 ** 32 and saved_floats > 1.9e9          # byte offsets beyond 32 bits are what runs here
+    tr2.forward_backward(y2, y2, m2)
+    out2, g2, l2 = tr2.out.clone(), tr2.grads.clone(), tr2.loss.clone()
+    assert torch.isfinite(out2).all() and torch.isfinite(g2).all()
+    tr2.forward_backward(y2, y2, m2)
+    assert torch.equal(tr2.out, out2) and torch.equal(tr2.grads, g2)                          # bitwise repeatable
+    del tr2
+    torch.cuda.empty_cache()
+    singles = []
+    for k in range(2):
+        tr1 = pkg.GATResTrainer(model, one.cuda(), n, nodes_per_graph=[n], use_graph=False)
+        tr1.forward_backward(ys[k].cuda(), ys[k].cuda(), masks[k].cuda())
+        assert torch.equal(tr1.out, out2[k * n:(k + 1) * n]), k                               # snapshots do not interact
+        singles.append((tr1.grads.clone(), tr1.loss.clone(), int(masks[k].sum())))
+        del tr1
+        torch.cuda.empty_cache()
+    (ga, la, ka), (gb, lb_, kb) = singles
+    comb = (ga * ka + gb * kb) / (ka + kb)
+    e_comb = relerr(g2, comb)
+    note("config 5 (25x128, 2 x 50k nodes): batch gradient vs weighted mean of the single-graph gradients", e_comb)
+    assert e_comb < 2e-5 and relerr(l2, (la * ka + lb_ * kb) / (ka + kb)) < 1e-5
+    leaves = {k: v.clone().requires_grad_(True) for k, v in p.items()}
+    xin = ys[1].clone(); xin[masks[1]] = 0
+    out_ref = oracle.gatres_forward(leaves, xin, one, num_blocks=nb)
+    loss_ref = torch.nn.functional.mse_loss(out_ref[masks[1]], ys[1][masks[1]])
+    loss_ref.backward()
+    g_ref = torch.cat([v.grad.reshape(-1) for v in leaves.values()])
+    e_out, e_loss, e_g = relerr(out2[n:], out_ref), relerr(lb_, loss_ref), relerr(gb, g_ref)
+    note("config 5 (25x128, 50k nodes): out / loss / flat grad of the batch's SECOND graph vs oracle32", [e_out, e_loss, e_g])
+    assert e_out < 1e-5 and e_loss < 1e-5 and e_g < 1e-4
+
+
 # ---------------------------------------------------------------------------------------------------- relabelled plans
 @pytest.mark.parametrize("fused", [True, False], ids=["fused", "per_op"])
 def test_shuffled_node_order_is_relabelled_and_exact(pkg, oracle, fused):
