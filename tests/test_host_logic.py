@@ -297,3 +297,17 @@ def test_part_tables_match_numpy_restatement(pkg, lib, m):
             assert list(got_e) == want_e
             # symmetric graph: what a part imports in the forward pass is what its partners export, and vice versa
             assert int(rec[31]) == len(want)          # backward import rows = forward import rows on a symmetric graph
+
+
+@pytest.mark.parametrize("name", ["tiny_nb2_nc8", "ctown_small_bs2"])
+def test_oracle_matches_pyg_replay(oracle, name):
+    """Holds the oracle to PyG's own numbers once somebody with torch_geometric has run tests/golden/replay_pyg.py and
+    committed its ``<fixture>.pyg.npz`` (the reference's GATResMeanConv on the fixture's batch).  Skipped until then:
+    parity stays UNPINNED."""
+    pyg = os.path.join(GOLDEN, name + ".pyg.npz")
+    if not os.path.exists(pyg):
+        pytest.skip("no PyG replay committed (tests/golden/replay_pyg.py needs a machine with torch_geometric)")
+    d, r = np.load(os.path.join(GOLDEN, name + ".npz")), np.load(pyg)
+    rel = lambda a, b: float(np.abs(a - b).max() / np.abs(b).max())
+    assert rel(d["out"], r["out"]) < 1e-5 and abs(float(d["loss"]) - float(r["loss"])) < 1e-5 * abs(float(r["loss"]))
+    assert rel(d["grads"], r["grads"]) < 1e-4

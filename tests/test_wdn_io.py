@@ -4,8 +4,12 @@ function of the native library).
 
 Pinned by: the networkx pipeline itself for the graph order (networkx is installed here; wntr and torch_geometric are
 not: the wntr registry order and from_networkx's edge order are restated from their sources, see wdn_io's docstring),
-hand-assembled LZ4 / Blosc byte strings that follow the published formats, and the committed fixture pair
-tests/golden/wdn_tiny.{inp,zip} (tests/golden/make_io_fixtures.py)."""
+byte strings ASSEMBLED BY HAND from the published formats -- LZ4 sequences, a split + shuffled multi-block Blosc frame with
+raw and compressed streams and a leftover block, a zarr-v2 ZipStore with numcodecs' compressor entry and edge chunks, an
+.inp with tabs / comments / pumps / valves: expected values are literals, no encoder of this repo is involved (the last
+section of this file) --, and, as a regression of the committed fixture pair tests/golden/wdn_tiny.{inp,zip}, the
+round trip through the test-side writer tests/golden/make_io_fixtures.py (which by itself only proves reader and writer
+consistent)."""
 import importlib.util
 import os
 import struct
@@ -216,3 +220,135 @@ def test_parse_inp_paths_text_and_errors(pkg, tmp_path):
     with pytest.warns(UserWarning, match="undefined"):
         ei, names = io.inp_edge_index(few, "keep_junction")
     assert names == few["JUNCTIONS"]
+
+
+# ------------------------------------------------------------------------------------- bytes this repo did not write
+# Everything below is assembled BY HAND from the published formats -- no encoder of tests/golden/make_io_fixtures.py is
+# involved, expected values are literals: a reader that agrees with its own writer only proves the pair consistent.
+#   LZ4 block format (lz4_Block_format.md): a sequence = token (high nibble: literal length, low nibble: match length - 4;
+#   a nibble of 15 is continued by extension bytes, each adding up to 255) | literals | 2-byte little-endian offset |
+#   match-length extension; the last sequence ends after its literals.
+#   C-Blosc 1.x frame (README_HEADER.rst + blosc.c): 16-byte header {version, versionlz, flags, typesize, nbytes,
+#   blocksize, cbytes}; flags: 0x01 byte shuffle, 0x02 memcpyed, 0x10 blocks NOT split, bits 5..7 compressor format
+#   (1 = LZ4); then one int32 offset per block; a block of a split frame (typesize <= 16, blocksize / typesize >= 128, not
+#   the leftover block) is `typesize` streams -- the bytes 0, 1, ... of every element after the shuffle --, every stream
+#   is {int32 compressed size | data}, and a stream whose size equals its uncompressed length is stored raw.
+#   zarr v2 (spec v2.0): `.zarray` JSON {chunks, compressor, dtype, fill_value, filters, order, shape, zarr_format}, chunk
+#   keys "i.j" under the array's prefix, EDGE chunks stored at the full chunk shape; `.zgroup`, `.zattrs`.
+def _lz4_run(byte: int, n: int) -> bytes:
+    """n >= 20 copies of one byte as two LZ4 sequences: 1 literal + an overlapping match (offset 1) of n - 6, then the
+    5 literals every block must end with."""
+    ml = n - 6 - 4                      # match length field: length - 4 (minmatch)
+    assert ml >= 15 and ml - 15 < 255
+    return bytes([0x1F, byte, 0x01, 0x00, ml - 15, 0x50]) + bytes([byte]) * 5
+
+
+def _hand_blosc_frame():
+    """Two full 512-byte blocks of float32 (split into 4 shuffled byte streams each) + a 64-byte leftover block (one
+    stream, stored raw).  Values: 128 x 1.0 | 0x40000000 + k for k = 0 .. 127 (2.0 .. 2.00003) | 16 x 3.0."""
+    import struct
+    streams0 = [_lz4_run(b, 128) for b in (0x00, 0x00, 0x80, 0x3F)]            # 1.0f = 3F 80 00 00, little endian bytes 0..3
+    assert all(len(s) == 11 for s in streams0)
+    block0 = b"".join(struct.pack("<i", len(s)) + s for s in streams0)
+    raw_lo = bytes(range(128))                                                # byte 0 of every element: 0 .. 127, incompressible
+    streams1 = [raw_lo] + [_lz4_run(b, 128) for b in (0x00, 0x00, 0x40)]       # 40 00 00 kk
+    block1 = b"".join(struct.pack("<i", len(s)) + s for s in streams1)         # the first stream: size == 128 -> raw
+    left = bytes([0x00] * 16 + [0x00] * 16 + [0x40] * 16 + [0x40] * 16)        # 3.0f = 40 40 00 00, shuffled, raw
+    block2 = struct.pack("<i", 64) + left
+    starts = [16 + 12, 16 + 12 + len(block0), 16 + 12 + len(block0) + len(block1)]
+    body = struct.pack("<3i", *starts) + block0 + block1 + block2
+    nbytes = 512 + 512 + 64
+    hdr = struct.pack("<BBBBIII", 2, 1, 0x01 | (1 << 5), 4, nbytes, 512, 16 + len(body))
+    frame = hdr + body
+    assert len(frame) == 333 and starts == [28, 88, 265]                       # (the sizes worked out by hand)
+    want = np.concatenate([np.full(128, 1.0, "<f4"), (np.arange(128, dtype="<u4") + 0x40000000).view("<f4"),
+                           np.full(16, 3.0, "<f4")])
+    return frame, want
+
+
+def test_blosc_frame_assembled_by_hand(pkg):
+    frame, want = _hand_blosc_frame()
+    got = np.frombuffer(pkg.wdn_io.blosc_decompress(frame), dtype="<f4")
+    assert got.shape == (272,) and np.array_equal(got.view("<u4"), want.view("<u4"))
+    assert got[0] == 1.0 and got[128] == 2.0 and got[255] > 2.0 and got[-1] == 3.0
+    # the same frame marked "blocks not split" must NOT decode (its first block would be read as one stream)
+    bad = bytearray(frame); bad[2] |= 0x10
+    with pytest.raises(Exception):
+        pkg.wdn_io.blosc_decompress(bytes(bad))
+    # truncated frame: refused
+    with pytest.raises(ValueError):
+        pkg.wdn_io.blosc_decompress(frame[:-10])
+
+
+def test_zarr_zip_assembled_by_hand(pkg, tmp_path):
+    """A ZipStore whose members are written byte for byte here: a 3 x 8 float32 array in 2 x 5 chunks (so the right and the
+    bottom chunks are EDGE chunks stored at full size), compressor entry exactly as numcodecs.Blosc serialises it; the
+    40-byte chunks are below Blosc's 128-byte minimum, so every chunk frame is the `memcpyed` form (flags 0x02, shuffle bit
+    recorded, payload NOT shuffled).  A second array uses the 272-element frame above as its single chunk; a third has no
+    compressor and a missing chunk (fill value)."""
+    import json
+    import struct
+    import zipfile
+    io = pkg.wdn_io
+    full = np.arange(24, dtype="<f4").reshape(3, 8) * 0.5 - 2.0
+    zarray = ('{\n    "chunks": [\n        2,\n        5\n    ],\n    "compressor": {\n        "blocksize": 0,\n        "clevel": 5,\n'
+              '        "cname": "lz4",\n        "id": "blosc",\n        "shuffle": 1\n    },\n    "dtype": "<f4",\n    "fill_value": 0.0,\n'
+              '    "filters": null,\n    "order": "C",\n    "shape": [\n        3,\n        8\n    ],\n    "zarr_format": 2\n}')
+    assert json.loads(zarray)["compressor"] == {"blocksize": 0, "clevel": 5, "cname": "lz4", "id": "blosc", "shuffle": 1}
+
+    def memcpy_frame(chunk):                       # blosc.c: nbytes < BLOSC_MIN_BUFFERSIZE (128) -> memcpyed, blocksize = nbytes
+        raw = chunk.astype("<f4").tobytes()
+        return struct.pack("<BBBBIII", 2, 1, 0x02 | 0x01 | (1 << 5), 4, len(raw), len(raw), 16 + len(raw)) + raw
+
+    def chunk_of(i, j):                            # zarr stores edge chunks at the full chunk shape, padded with the fill value
+        c = np.zeros((2, 5), "<f4")
+        part = full[2 * i:2 * i + 2, 5 * j:5 * j + 5]
+        c[:part.shape[0], :part.shape[1]] = part
+        return c
+
+    frame272, want272 = _hand_blosc_frame()
+    path = tmp_path / "hand.zip"
+    with zipfile.ZipFile(path, "w", zipfile.ZIP_STORED) as z:      # zarr.ZipStore: members stored, not deflated
+        z.writestr(".zgroup", '{\n    "zarr_format": 2\n}')
+        z.writestr(".zattrs", '{\n    "ordered_name_list": [\n        "J1",\n        "J2"\n    ]\n}')
+        z.writestr("pressure/.zgroup", '{\n    "zarr_format": 2\n}')
+        z.writestr("pressure/train/.zarray", zarray)
+        for i in range(2):
+            for j in range(2):
+                z.writestr(f"pressure/train/{i}.{j}", memcpy_frame(chunk_of(i, j)))
+        z.writestr("pressure/valid/.zarray", zarray.replace("3,\n        8", "272").replace("2,\n        5", "272"))
+        z.writestr("pressure/valid/0", frame272)
+        z.writestr("pressure/test/.zarray", '{"chunks": [2, 4], "compressor": null, "dtype": "<f4", "fill_value": -1.0, "filters": null, '
+                                            '"order": "C", "shape": [2, 8], "zarr_format": 2}')
+        z.writestr("pressure/test/0.1", np.full((2, 4), 7.0, "<f4").tobytes())      # chunk 0.0 was never written
+    root = io.ZarrZip(str(path))
+    assert root.group_keys() == ["pressure"] and root.attrs["ordered_name_list"] == ["J1", "J2"]
+    assert root.array_keys("pressure") == ["test", "train", "valid"]
+    assert np.array_equal(root.array("pressure/train"), full)
+    assert np.array_equal(root.array("pressure/valid").view("<u4"), want272.view("<u4"))
+    t = root.array("pressure/test")
+    assert np.array_equal(t[:, :4], np.full((2, 4), -1.0, "<f4")) and np.array_equal(t[:, 4:], np.full((2, 4), 7.0, "<f4"))
+    root.close()
+
+
+def test_inp_with_tabs_comments_pumps_and_valves(pkg):
+    """EPANET 2.2 users manual, appendix C: sections in any order and case, `;` comments (whole-line and trailing), tabs
+    as separators, [PUMPS] (id node1 node2 keyword value) and [VALVES] (id node1 node2 diameter type setting loss) lines;
+    expected topology written out by hand (DataLoader.py:212-254 order: junctions, reservoirs, tanks; pipes, pumps, valves)."""
+    io = pkg.wdn_io
+    text = ("[TITLE]\n a ; network\n\n[junctions]\n;ID\tElev\tDemand\tPattern\n A\t10\t1.5\t;first\n B  12 0\n\tC\t9\t2\tP1\n"
+            "[RESERVOIRS]\n;ID Head\n R\t100\n[TANKS]\n T 50 3 0 6 12 0\n"
+            "[VALVES]\n;ID Node1 Node2 Diameter Type Setting MinorLoss\n V1\tC\tT\t12\tPRV\t40\t0 ; to the tank\n"
+            "[PIPES]\n;ID Node1 Node2 Length Diameter Roughness MinorLoss Status\n P1 A B 100 12 100 0 Open\n P2\tB\tC\t50\t8\t100\t0\tOpen\n"
+            "[Pumps]\n PU1 R A HEAD 1 ; source\n[END]\n")
+    inp = io.parse_inp(text=text)
+    assert inp["JUNCTIONS"] == ["A", "B", "C"] and inp["RESERVOIRS"] == ["R"] and inp["TANKS"] == ["T"]
+    assert inp["PIPES"] == [("P1", "A", "B"), ("P2", "B", "C")] and inp["PUMPS"] == [("PU1", "R", "A")]
+    assert inp["VALVES"] == [("V1", "C", "T")]
+    ei, names = io.inp_edge_index(inp, "keep_junction")
+    assert names == ["A", "B", "C"] and ei.tolist() == [[0, 1, 1, 2], [1, 0, 2, 1]]        # A-B, B-C, both ways, by source
+    ei_all, names_all = io.inp_edge_index(inp, "keep_all")
+    assert names_all == ["A", "B", "C", "R", "T"]
+    # adjacency after nx.Graph(wn.to_graph()).to_undirected(): A: [B, R]; B: [A, C]; C: [B, T]; R: [A]; T: [C]
+    assert ei_all.tolist() == [[0, 0, 1, 1, 2, 2, 3, 4], [1, 3, 0, 2, 1, 4, 0, 2]]
+    assert io.inp_node_order(inp) == ["A", "B", "C", "R", "T"]
