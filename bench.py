@@ -140,13 +140,15 @@ def kernel_table(G, model, plan, nc):
         rows.append((f"proj_bwd_dx[{tag}]", nb, s * (N * HC + HC * K + 3 * N * K),
                      lambda: lib.gatres_t_proj_bwd_dx(g_h.data_ptr(), Wt.data_ptr(), g_x.data_ptr(), x.data_ptr(),
                                                       g_x.data_ptr(), N, K, HC, dt, st())))
-        rows.append((f"proj_bwd_dw[{tag}]", nb, s * (N * HC + N * K) + 4 * S * HC * K,
-                     lambda: lib.gatres_t_proj_bwd_dw(g_h.data_ptr(), x.data_ptr(), slab.data_ptr(), S, HC * K + 3 * HC,
-                                                      N, K, HC, dt, st())))
-        rows.append((f"conv_param_grads[{tag}]", nb, s * 2 * N * HC + 4 * (2 * N * H + 3 * S * HC),
-                     lambda: lib.gatres_t_conv_param_grads(h.data_ptr(), g_as.data_ptr(), g_ad.data_ptr(),
-                                                           g_out.data_ptr(), slab.data_ptr(), slab.data_ptr() + 4 * HC,
-                                                           slab.data_ptr() + 8 * HC, S, HC * K + 3 * HC, N, H, nc, dt, st())))
+        # the weight partials and the attention-vector / bias column sums exactly as the step launches them: ONE co-launched
+        # kernel where that form applies (gatres_t_conv_partials = model_driver.hip's conv_partials), else two launches
+        Sw = 64 if (dt == G._native.DTYPE_BF16 and nc == 128 and S > 64) else S      # model_driver.hip: dw_slab_rows
+        rows.append((f"conv_partials[{tag}]", nb,
+                     s * (N * HC + N * K) + 4 * Sw * HC * K + s * 2 * N * HC + 4 * (2 * N * H + 3 * S * HC),
+                     lambda: lib.gatres_t_conv_partials(g_h.data_ptr(), x.data_ptr(), slab.data_ptr() + 12 * HC, Sw,
+                                                        HC * K + 3 * HC, N, K, HC, h.data_ptr(), g_as.data_ptr(),
+                                                        g_ad.data_ptr(), g_out.data_ptr(), slab.data_ptr(),
+                                                        slab.data_ptr() + 4 * HC, slab.data_ptr() + 8 * HC, S, H, nc, dt, st())))
 
     conv("conv1", nc, 2)
     conv("conv2", 2 * nc, 1)
@@ -163,7 +165,7 @@ def algorithmic_bytes_per_step(rows, N, nc, P, S, nb):
     """Compulsory-traffic model: every stage's inputs read once and outputs written once at
     full row width, no cache credit.  Returns (fused per-snapshot kernel, deferred parameter-gradient kernel): the
     dW / attention-vector gradient stages run in the second launch, the bias column sums stay in the first."""
-    deferred = sum(r[1] * r[2] for r in rows if r[0].startswith(("proj_bwd_dw", "conv_param_grads")))
+    deferred = sum(r[1] * r[2] for r in rows if r[0].startswith(("proj_bwd_dw", "conv_param_grads", "conv_partials")))
     bias = nb * 4 * ((N * 2 * nc + S * 2 * nc) + (N * nc + S * nc))       # g_out tables read, slab rows written
     deferred -= bias
     stages = sum(r[1] * r[2] for r in rows) - deferred

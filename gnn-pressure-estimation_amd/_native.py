@@ -92,6 +92,7 @@ SIGNATURES = {
     "gatres_t_lin1_fwd": (C.c_int, [_P] * 4 + [C.c_int] * 3 + [_P]),
     "gatres_t_lin1_bwd": (C.c_int, [_P] * 6 + [C.c_int, _I64, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
     "gatres_t_conv_param_grads": (C.c_int, [_P] * 7 + [C.c_int, _I64, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
+    "gatres_t_conv_partials": (C.c_int, [_P] * 3 + [C.c_int, _I64, C.c_int, C.c_int, C.c_int] + [_P] * 7 + [C.c_int] * 4 + [_P]),
     "gatres_convert_conv_weights_bf16": (C.c_int, [_P, _P, C.c_int, C.c_int, _P]),
     "gatres_t_proj_attn_fwd": (C.c_int, [_P] * 7 + [C.c_int] * 5 + [_P]),
     "gatres_t_proj_bwd_dx": (C.c_int, [_P] * 5 + [C.c_int] * 4 + [_P]),

@@ -183,6 +183,16 @@ static int conv_partials(const void* gh, const void* xin, float* slab_W, int Sw,
   return gatres_t_proj_bwd_dw(gh, xin, slab_W, Sw, st, N, K, HC, dt, stream);
 }
 
+extern "C" int gatres_t_conv_partials(const void* g_h, const void* x, float* slab_W, int w_slabs, int64_t slab_stride,
+                                      int num_nodes, int K, int HC, const void* h, const float* g_a_src, const float* g_a_dst,
+                                      const void* g_out, float* slab_att_src, float* slab_att_dst, float* slab_bias,
+                                      int num_slabs, int H, int C, int dtype, void* stream) {
+  if (!g_h || !x || !slab_W || !h || !g_a_src || !g_a_dst || !g_out || !slab_att_src || !slab_att_dst || !slab_bias)
+    return GATRES_E_BADARG;
+  return conv_partials(g_h, x, slab_W, w_slabs, slab_stride, num_nodes, K, HC, h, g_a_src, g_a_dst, g_out, slab_att_src,
+                       slab_att_dst, slab_bias, num_slabs, H, C, dtype, stream);
+}
+
 // One piece of the per-op backward: [lin1 backward] blocks b_hi-1 .. b_lo [lin0 backward].  With GATRES_PART_REDUCE the
 // slab partials of exactly the parameters this piece finishes are summed into `grads` right away, so a data-parallel
 // caller can start the all-reduce of that range while the next piece runs (gradient buckets in reverse block order).

@@ -1,9 +1,12 @@
 """Evaluation path for GATRes: forward-only passes under fresh masks, the reference's seven metrics on de-normalised
 masked predictions, and event-timed latency / throughput.
 
-Mirrors gnn_pressure_estimation/evaluation.py:240-351 (``test_one_epoch``) for the configuration the GATRes models run
-with (no sensors, ``use_data_batch=False``, no edge attributes), utils/auxil.py:101-140,185-203 (metric functions and
-their registry) and utils/timer.py:12-66 (``Timer``: warm-up, then one event pair per inference call).
+Mirrors gnn_pressure_estimation/evaluation.py:240-351 (``test_one_epoch``: the all-nodes pass and the sensor pass, whose
+masks always contain ``required_idx``) and :355-403 (the trial loop that runs both passes per trial) for the configuration
+the GATRes models run with (``use_data_batch=False``, no edge attributes), utils/auxil.py:101-140,185-203 (metric functions
+and their registry) and utils/timer.py:12-66 (``Timer``: warm-up, then one event pair per inference call).  The sensor
+indices themselves come from a secrets file the reference does not ship (evaluation.py:27-66: without it ``get_sensors``
+returns empty lists and the second pass equals the first); here they are an argument.
 The model call is the fused forward kernel (no activations kept under ``torch.no_grad()``); everything else here is
 caller-side tensor arithmetic, exactly as in the reference.
 """
@@ -105,13 +108,18 @@ def test_one_epoch(model: torch.nn.Module, loader: Iterable[Tuple[torch.Tensor, 
                    mean=None, std=None, min_val=None, max_val=None, norm_type: str = "znorm",
                    criterion: Optional[Callable] = None, metric_fn_dict: Optional[Dict[str, Callable]] = None,
                    nodes_per_graph: Optional[int] = None, gpu_warmup_times: int = 10, use_same_mask: bool = False,
-                   rng: Optional[np.random.RandomState] = None) -> Tuple[float, Dict[str, float]]:
+                   rng: Optional[np.random.RandomState] = None, do_test_on_sensors: bool = False,
+                   required_idx: Sequence[int] = ()) -> Tuple[float, Dict[str, float]]:
     """``loader`` yields ``(x, edge_index, num_graphs)`` with x == y (e.g. ``SnapshotStore.batches``).  Returns
-    ``(loss, metrics)`` with the reference's keys plus ``{prefix}_time`` (ms/graph) and ``{prefix}_throughput``."""
+    ``(loss, metrics)`` with the reference's keys plus ``{prefix}_time`` (ms/graph) and ``{prefix}_throughput``.
+    ``do_test_on_sensors`` (evaluation.py:288-294): every mask contains ``required_idx`` (node indices inside a graph) and
+    the metric keys carry the ``_sensor`` postfix; with an empty ``required_idx`` it is the plain pass under other keys."""
     model.eval()
     criterion = criterion or torch.nn.MSELoss()
     metric_fn_dict = metric_fn_dict or get_metric_fn_collection("test")
     rng = rng or np.random
+    required = list(required_idx) if do_test_on_sensors else []
+    postfix = "_sensor" if do_test_on_sensors else ""
     total_loss, total = 0.0, {k: 0.0 for k in metric_fn_dict}
     timer, all_mask, n_graphs = Timer(), None, 0
     with torch.no_grad():
@@ -119,7 +127,7 @@ def test_one_epoch(model: torch.nn.Module, loader: Iterable[Tuple[torch.Tensor, 
             y = x
             npg = nodes_per_graph or x.shape[0] // num_graphs
             if all_mask is None or not use_same_mask or all_mask.shape[0] != x.shape[0]:
-                all_mask = generate_batch_mask([npg] * num_graphs, mask_rate, rng)
+                all_mask = generate_batch_mask([npg] * num_graphs, mask_rate, rng, required)
             x1 = x.clone()
             x1[all_mask] = 0
             out = timer.auto_measure(model, num_graphs, gpu_warmup_times)(x1, edge_index, None, None)
@@ -134,4 +142,22 @@ def test_one_epoch(model: torch.nn.Module, loader: Iterable[Tuple[torch.Tensor, 
     prefix = list(metric_fn_dict.keys())[0].split("_")[0]
     metrics[prefix + "_time"] = timer.compute_time(n_graphs)
     metrics[prefix + "_throughput"] = timer.compute_throughput(n_graphs)
-    return total_loss / n_graphs, metrics
+    return total_loss / n_graphs, {k + postfix: v for k, v in metrics.items()}
+
+
+def test_trials(model: torch.nn.Module, make_loader: Callable[[], Iterable], num_test_trials: int, mask_rate: float,
+                required_idx: Sequence[int] = (), **kw):
+    """The trial loop of evaluation.py:355-403: ``num_test_trials`` times an all-nodes pass and a sensor pass over a fresh
+    loader, results collected per trial.  Returns ``(test_losses, test_metrics, sensor_losses, sensor_metrics)`` with the
+    metric dicts mapping a key to the list of its per-trial values (``defaultdict(list)`` in the reference)."""
+    from collections import defaultdict
+    losses, metrics, s_losses, s_metrics = [], defaultdict(list), [], defaultdict(list)
+    for _ in range(int(num_test_trials)):
+        loss, m = test_one_epoch(model, make_loader(), mask_rate, do_test_on_sensors=False, **kw)
+        s_loss, s_m = test_one_epoch(model, make_loader(), mask_rate, do_test_on_sensors=True, required_idx=required_idx, **kw)
+        losses.append(loss); s_losses.append(s_loss)
+        for k, v in m.items():
+            metrics[k].append(v)
+        for k, v in s_m.items():
+            s_metrics[k].append(v)
+    return losses, dict(metrics), s_losses, dict(s_metrics)

@@ -85,22 +85,30 @@ def collate_snapshots(snapshots: torch.Tensor, rows: Sequence[int]) -> torch.Ten
     return snapshots[list(rows)].reshape(-1, 1).contiguous()
 
 
-def mask_nodes(num_nodes: int, masking_rate: float, rng: np.random.RandomState) -> np.ndarray:
-    """Reference host sampler, utils/auxil.py:143-163 (required_idx = []): exactly
-    ``int(num_nodes*rate)`` nodes chosen without replacement."""
-    mask_length = int(num_nodes * masking_rate)
+def mask_nodes(num_nodes: int, masking_rate: float, rng: np.random.RandomState,
+               required_idx: Sequence[int] = ()) -> np.ndarray:
+    """Reference host sampler, utils/auxil.py:143-163: exactly ``int(num_nodes * rate)`` nodes are masked -- the
+    ``required_idx`` ones (the sensor nodes of evaluation.py's second pass) always, the rest chosen without replacement
+    among the others."""
+    required = sorted(set(int(i) for i in required_idx))
+    mask_length = int(num_nodes * masking_rate) - len(required)
     if mask_length <= 0:
         raise ValueError("mask length must be positive")
-    idx = rng.choice(num_nodes, mask_length, replace=False)
+    if required:
+        selected = np.setdiff1d(np.arange(num_nodes), np.asarray(required))
+        idx = rng.choice(selected, mask_length, replace=False)
+    else:
+        idx = rng.choice(num_nodes, mask_length, replace=False)
     mask = np.zeros(num_nodes, dtype=bool)
     mask[idx] = True
+    mask[required] = True
     return mask
 
 
-def generate_batch_mask(num_nodes_per_graph: Sequence[int], mask_rate: float,
-                        rng: np.random.RandomState) -> np.ndarray:
-    """utils/auxil.py:166-182."""
-    return np.hstack([mask_nodes(int(n), mask_rate, rng) for n in num_nodes_per_graph])
+def generate_batch_mask(num_nodes_per_graph: Sequence[int], mask_rate: float, rng: np.random.RandomState,
+                        required_idx: Sequence[int] = ()) -> np.ndarray:
+    """utils/auxil.py:166-182 (``required_idx`` are node indices INSIDE a graph, the same for every graph of the batch)."""
+    return np.hstack([mask_nodes(int(n), mask_rate, rng, required_idx) for n in num_nodes_per_graph])
 
 
 def make_batch(batch_size: int, num_nodes: int = CTOWN_NODES, num_pipes: int = CTOWN_PIPES,

@@ -319,6 +319,14 @@ int gatres_t_lin1_bwd(const float* g_out, const void* x, const float* w, void* g
 int gatres_t_conv_param_grads(const void* h, const float* g_a_src, const float* g_a_dst, const void* g_out,
                               float* slab_att_src, float* slab_att_dst, float* slab_bias, int num_slabs,
                               int64_t slab_stride, int num_nodes, int H, int C, int dtype, void* stream);
+/* A convolution's parameter-gradient partials as the per-op backward launches them (model_driver.hip): the weight
+ * partials (gatres_t_proj_bwd_dw) and the attention-vector / bias column sums (gatres_t_conv_param_grads) as ONE launch where
+ * a co-launching kernel applies, else one after the other.  w_slabs: slab rows the weight partials use (== num_slabs, or
+ * fewer for the two-dimensional partials of wide bf16 models). */
+int gatres_t_conv_partials(const void* g_h, const void* x, float* slab_W, int w_slabs, int64_t slab_stride, int num_nodes,
+                           int K, int HC, const void* h, const float* g_a_src, const float* g_a_dst, const void* g_out,
+                           float* slab_att_src, float* slab_att_dst, float* slab_bias, int num_slabs, int H, int C, int dtype,
+                           void* stream);
 /* bf16 copies of every GATConv weight and of its transpose: wb block layout [W1 : 2nc x nc][W2 : nc x 2nc] */
 /* [W1^T : nc x 2nc][W2^T : 2nc x nc] (4 * 2nc^2 bf16 per block) */
 int gatres_convert_conv_weights_bf16(const float* params, void* wb, int num_blocks, int nc, void* stream);

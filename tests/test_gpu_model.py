@@ -23,12 +23,24 @@ def relerr(a, b):
 
 
 def note(name, val):
+    """Measured errors of the -m gpu tests, every module's (they all import this function), MERGED into
+    gpurun_out/parity_report.json: a run of one module or one test adds to what is there instead of replacing it.  The
+    copy judged with a round is committed as profiles/rNN_parity_report.json."""
     REPORT[name] = val
     d = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
     try:
         os.makedirs(d, exist_ok=True)
-        with open(os.path.join(d, "parity_report.json"), "w") as f:
-            json.dump(REPORT, f, indent=1, sort_keys=True)
+        path = os.path.join(d, "parity_report.json")
+        merged = {}
+        if os.path.exists(path):
+            try:
+                with open(path) as f:
+                    merged = json.load(f)
+            except ValueError:
+                merged = {}
+        merged.update(REPORT)
+        with open(path, "w") as f:
+            json.dump(merged, f, indent=1, sort_keys=True)
     except OSError:
         pass
 

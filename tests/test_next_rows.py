@@ -85,3 +85,64 @@ def test_evaluation_loop_on_device(pkg, oracle):
     assert abs(loss - tot / n) < 1e-5 * abs(tot / n)
     for k in fns:
         assert abs(m[k] - acc[k] / n) <= 1e-4 * max(1.0, abs(acc[k] / n)), k
+
+
+def test_mask_sampler_with_required_indices(pkg):
+    """utils/auxil.py:143-163: the required (sensor) nodes are always masked and count towards int(n * rate); without
+    them the sampler draws exactly what it drew before (same RandomState stream)."""
+    ws = pkg.wdn_synth
+    req = [3, 17, 200, 387]
+    m = ws.generate_batch_mask([388] * 5, 0.95, np.random.RandomState(4), req)
+    assert m.shape == (5 * 388,) and m.dtype == bool
+    for g in range(5):
+        mg = m[g * 388:(g + 1) * 388]
+        assert mg.sum() == int(388 * 0.95) and mg[req].all()
+    assert not np.array_equal(m[:388], m[388:776])
+    a = ws.generate_batch_mask([40, 388], 0.9, np.random.RandomState(1))
+    b = ws.generate_batch_mask([40, 388], 0.9, np.random.RandomState(1), [])
+    assert np.array_equal(a, b)
+    with pytest.raises(ValueError):
+        ws.mask_nodes(10, 0.5, np.random.RandomState(0), [0, 1, 2, 3, 4])          # nothing left to draw
+
+
+@pytest.mark.gpu
+def test_sensor_pass_and_trial_loop(pkg, oracle):
+    """evaluation.py:355-403: every trial runs an all-nodes pass and a sensor pass (masks that always contain the sensor
+    nodes, metric keys with the `_sensor` postfix); the sensor pass is checked against the oracle under the same masks."""
+    one = pkg.wdn_synth.make_wdn_topology()
+    raw = pkg.wdn_synth.make_snapshots(6, 388, seed=3) * 5 + 40
+    st = pkg.SnapshotStore(raw, one, device="cuda")
+    p = oracle.init_params(3, 32, seed=3)
+    model = pkg.GATResMeanConv(num_blocks=3, nc=32)
+    sd = {}
+    for k, v in p.items():
+        sd[k] = v
+        if k.endswith("lin_src.weight"):
+            sd[k.replace("lin_src", "lin_dst")] = v
+    model.load_state_dict(sd)
+    model = model.cuda()
+    req = [5, 9, 120, 300]
+    E = pkg.evaluation
+    losses, metrics, s_losses, s_metrics = E.test_trials(model, lambda: st.batches(3, shuffle=False), 2, 0.95, required_idx=req,
+                                                         mean=st.mean, std=st.std, norm_type="znorm", gpu_warmup_times=1,
+                                                         rng=np.random.RandomState(0))
+    assert len(losses) == 2 and len(s_losses) == 2 and all(np.isfinite(losses + s_losses))
+    assert set(metrics) == {"test_error", "test_0.1", "test_corr", "test_r2", "test_mae", "test_rmse", "test_mynse",
+                            "test_time", "test_throughput"}
+    assert set(s_metrics) == {k + "_sensor" for k in metrics} and all(len(v) == 2 for v in s_metrics.values())
+    # the masks of the run above, replayed: trial 0 = plain pass (2 batches), then the sensor pass (2 batches), ...
+    rng = np.random.RandomState(0)
+    cpu = pkg.SnapshotStore(raw, one, device="cpu")
+    for trial in range(2):
+        for sensors in (False, True):
+            tot, n = 0.0, 0
+            for x, ei, g in cpu.batches(3, shuffle=False):
+                mask = pkg.wdn_synth.generate_batch_mask([388] * g, 0.95, rng, req if sensors else [])
+                if sensors:
+                    assert all(mask[k * 388 + np.array(req)].all() for k in range(g))
+                x1 = x.clone(); x1[mask] = 0
+                out = oracle.gatres_forward(p, x1, ei)
+                tot += float(torch.nn.functional.mse_loss(out[mask], x[mask])) * g
+                n += g
+            got = (s_losses if sensors else losses)[trial]
+            assert abs(got - tot / n) < 1e-5 * abs(tot / n), (trial, sensors)
