@@ -510,10 +510,196 @@ __global__ __launch_bounds__(256) void proj_bf16_kernel(const gatres_bf16* __res
   }
 }
 
+// The same product for wide outputs (M a multiple of 128: gatres_large), retiled in round 3.  proj_bf16_kernel gives a wave
+// 16 rows x ALL M columns at once: 64 accumulator registers + operands = 256 VGPRs + AGPRs, ONE wave per SIMD, one
+// 256-thread workgroup per CU and 194 of 256 CUs busy on C-Town batches of 128 -- nothing hid an HBM round trip
+// (1.6 - 2.7 TB/s).  Here a wave still owns a 16-row tile, but walks its M columns in PASSES of 128 (32 accumulator
+// registers, ~110 VGPRs: four waves per SIMD), re-using the tile's x fragment; a 512-thread workgroup shares ONE LDS copy
+// of W, two workgroups share a CU, and the row tiles are dealt in contiguous, equal shares to all 512 workgroups: 3 104
+// tiles = 6 or 7 per workgroup, one per wave, ONE round on every CU (16-row x 128-column wave tiles dealt round a grid were
+// 1.5 rounds: half the chip idle in the second).  The tile's rows are requested before W is staged, the epilogue's operands
+// before the MFMA chain: a wave's life is a chain of round trips (W, x, epilogue operands, store) and they now overlap.
+// A pass covers whole heads for nc = 128 (C = 128): the attention logits reduce inside the wave, pass by pass.  Same
+// feature permutation as above within a pass: lane group q owns the contiguous 32 features [128 p + 32 q, + 32).
+template <int K, int M, int H, int EPI>
+__global__ __launch_bounds__(512, 4) void proj_bf16_tile_kernel(const gatres_bf16* __restrict__ X,
+                                                                const gatres_bf16* __restrict__ Wm,
+                                                                gatres_bf16* __restrict__ OUT, int N,
+                                                                const float* __restrict__ att_src,
+                                                                const float* __restrict__ att_dst, float* __restrict__ a_src,
+                                                                float* __restrict__ a_dst,
+                                                                const gatres_bf16* __restrict__ resid,
+                                                                const gatres_bf16* __restrict__ relu_ref) {
+  constexpr int KS = K / 32, KP = K + 8, WC = 128, NT = WC / 16, CG = M / WC, QF = WC / 4, C = M / H;
+  static_assert(M % WC == 0 && K % 32 == 0, "passes of 128 columns");
+  static_assert(EPI != EPI_ATT || (C % QF == 0 && (C <= WC ? WC % C == 0 : false)), "a pass covers whole heads");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  gatres_bf16* wl = reinterpret_cast<gatres_bf16*>(smem);
+  float* attl = reinterpret_cast<float*>(smem + (size_t)M * KP * 2);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int i = lane & 15, q = lane >> 4;
+  const int ntiles = (N + 15) >> 4;
+  // this workgroup's contiguous share of the row tiles, one tile per wave and trip
+  const int t_lo = (int)((long long)ntiles * blockIdx.x / gridDim.x), t_hi = (int)((long long)ntiles * (blockIdx.x + 1) / gridDim.x);
+  bf16x8 xf[KS];
+  auto load_x = [&](int tile, bf16x8 (&f)[KS]) {
+    const int n = min(tile * 16 + i, N - 1);
+    const gatres_bf16* p = X + (size_t)n * K + q * 8;
+#pragma unroll
+    for (int s = 0; s < KS; ++s) f[s] = *reinterpret_cast<const bf16x8*>(p + s * 32);
+  };
+  int tile = t_lo + wave;
+  if (tile < t_hi) load_x(tile, xf);                          // in flight while W is staged
+  {
+    // LDS row l = 128 p + 16 t + a holds W row 128 p + (a >> 2) * 32 + 4 t + (a & 3); eight 16-byte loads in flight per
+    // thread, then their LDS stores
+    constexpr int CH = M * (K / 8), PER = (CH + 511) / 512, UB = PER < 8 ? PER : 8;
+    for (int b0 = 0; b0 < PER; b0 += UB) {
+      uint4 v[UB];
+#pragma unroll
+      for (int u = 0; u < UB; ++u) {
+        const int idx = threadIdx.x + 512 * (b0 + u);
+        const int l = idx / (K / 8), k8 = (idx % (K / 8)) * 8;
+        const int lw = l % WC, t = lw >> 4, a = lw & 15;
+        const int m = (l / WC) * WC + (a >> 2) * QF + 4 * t + (a & 3);
+        v[u] = (b0 + u < PER && idx < CH) ? *reinterpret_cast<const uint4*>(Wm + (size_t)m * K + k8) : make_uint4(0u, 0u, 0u, 0u);
+      }
+#pragma unroll
+      for (int u = 0; u < UB; ++u) {
+        const int idx = threadIdx.x + 512 * (b0 + u);
+        const int l = idx / (K / 8), k8 = (idx % (K / 8)) * 8;
+        if (b0 + u < PER && idx < CH) *reinterpret_cast<uint4*>(wl + l * KP + k8) = v[u];
+      }
+    }
+  }
+  if constexpr (EPI == EPI_ATT) {
+    for (int idx = threadIdx.x; idx < 2 * (M / 4); idx += 512) {
+      const int which = idx / (M / 4), c4 = (idx % (M / 4)) * 4;
+      st4(attl + which * M + c4, ld4((which ? att_dst : att_src) + c4));
+    }
+  }
+  __syncthreads();
+  const float* attS = attl;
+  const float* attD = attl + M;
+  bool first = true;
+  for (; tile < t_hi; tile += 8) {
+    const int n = tile * 16 + i;
+    const bool nok = n < N;
+    if (!first) load_x(tile, xf);
+    first = false;
+    const size_t rowo = (size_t)min(n, N - 1) * M + q * QF;
+#pragma unroll
+    for (int p = 0; p < CG; ++p) {
+      const gatres_bf16* wbase = wl + (size_t)(p * WC + i) * KP + q * 8;
+      // the epilogue's operands (ReLU reference / residual rows: 16 bytes per pair of tiles) are requested BEFORE the MFMA
+      // chain: loaded in the epilogue they were one more exposed round trip per pass
+      uint4 rraw[EPI == EPI_RESID_MASK ? NT / 2 : 1], mraw[EPI == EPI_RESID_MASK ? NT / 2 : 1];
+      if constexpr (EPI == EPI_RESID_MASK) {
+#pragma unroll
+        for (int t = 0; t < NT; t += 2) {
+          if (resid) rraw[t / 2] = *reinterpret_cast<const uint4*>(resid + rowo + p * WC + 4 * t);
+          if (relu_ref) mraw[t / 2] = *reinterpret_cast<const uint4*>(relu_ref + rowo + p * WC + 4 * t);
+        }
+      }
+      f32x4 acc[NT];
+#pragma unroll
+      for (int t = 0; t < NT; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int s = 0; s < KS; ++s) {
+        // one k step: its eight W fragments (one batch of LDS reads), then its eight MFMAs.  The scheduling barrier keeps
+        // the compiler from hoisting the reads of ALL k steps in front of the first MFMA (K / 32 x 32 registers: it did,
+        // and spilled 260 of them at the 128-VGPR budget of four waves per SIMD)
+        bf16x8 wf[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) wf[t] = *reinterpret_cast<const bf16x8*>(wbase + (size_t)(t * 16) * KP + s * 32);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[t], xf[s], acc[t], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      // acc[t][reg] = output feature 128 p + 32 q + 4 t + reg of node n
+      if constexpr (EPI == EPI_ATT) {
+        constexpr int HP = WC / C;                   // heads per pass (1 for nc = 128)
+        const int hl = (q * QF) / C;                 // this lane group's head inside the pass
+        float psl = 0.f, pdl = 0.f;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+          const int mb = p * WC + q * QF + 4 * t;
+          const float4 as = ld4(attS + mb), ad = ld4(attD + mb);
+          psl += fmaf(acc[t][3], as.w, fmaf(acc[t][2], as.z, fmaf(acc[t][1], as.y, acc[t][0] * as.x)));
+          pdl += fmaf(acc[t][3], ad.w, fmaf(acc[t][2], ad.z, fmaf(acc[t][1], ad.y, acc[t][0] * ad.x)));
+        }
+        float ps[HP], pd[HP];
+#pragma unroll
+        for (int hh = 0; hh < HP; ++hh) {
+          ps[hh] = hh == hl ? psl : 0.f; pd[hh] = hh == hl ? pdl : 0.f;
+          ps[hh] += __shfl_xor(ps[hh], 16); ps[hh] += __shfl_xor(ps[hh], 32);
+          pd[hh] += __shfl_xor(pd[hh], 16); pd[hh] += __shfl_xor(pd[hh], 32);
+        }
+        if (q == 0 && nok) {
+#pragma unroll
+          for (int hh = 0; hh < HP; ++hh) { a_src[n * H + p * HP + hh] = ps[hh]; a_dst[n * H + p * HP + hh] = pd[hh]; }
+        }
+      }
+      if (nok) {
+#pragma unroll
+        for (int t = 0; t < NT; t += 2) {
+          float4 o0 = make_float4(acc[t][0], acc[t][1], acc[t][2], acc[t][3]);
+          float4 o1 = make_float4(acc[t + 1][0], acc[t + 1][1], acc[t + 1][2], acc[t + 1][3]);
+          if constexpr (EPI == EPI_RESID_MASK) {
+            auto widen = [](const uint4 u, float4& lo, float4& hi) {
+              lo = make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16),
+                               __uint_as_float(u.y & 0xffff0000u));
+              hi = make_float4(__uint_as_float(u.z << 16), __uint_as_float(u.z & 0xffff0000u), __uint_as_float(u.w << 16),
+                               __uint_as_float(u.w & 0xffff0000u));
+            };
+            if (resid) {
+              float4 ra, rb;
+              widen(rraw[t / 2], ra, rb);
+              o0.x += ra.x; o0.y += ra.y; o0.z += ra.z; o0.w += ra.w;
+              o1.x += rb.x; o1.y += rb.y; o1.z += rb.z; o1.w += rb.w;
+            }
+            if (relu_ref) {
+              float4 ra, rb;
+              widen(mraw[t / 2], ra, rb);
+              o0.x = ra.x > 0.f ? o0.x : 0.f; o0.y = ra.y > 0.f ? o0.y : 0.f;
+              o0.z = ra.z > 0.f ? o0.z : 0.f; o0.w = ra.w > 0.f ? o0.w : 0.f;
+              o1.x = rb.x > 0.f ? o1.x : 0.f; o1.y = rb.y > 0.f ? o1.y : 0.f;
+              o1.z = rb.z > 0.f ? o1.z : 0.f; o1.w = rb.w > 0.f ? o1.w : 0.f;
+            }
+          }
+          bf16x8 ob;
+          ob[0] = (gatres_bf16)o0.x; ob[1] = (gatres_bf16)o0.y; ob[2] = (gatres_bf16)o0.z; ob[3] = (gatres_bf16)o0.w;
+          ob[4] = (gatres_bf16)o1.x; ob[5] = (gatres_bf16)o1.y; ob[6] = (gatres_bf16)o1.z; ob[7] = (gatres_bf16)o1.w;
+          *reinterpret_cast<bf16x8*>(OUT + (size_t)n * M + p * WC + q * QF + 4 * t) = ob;
+        }
+      }
+    }
+  }
+}
+
 template <int K, int M, int H, int EPI>
 int launch_proj_bf16(const gatres_bf16* X, const gatres_bf16* Wm, gatres_bf16* OUT, int N, const float* att_src,
                      const float* att_dst, float* a_src, float* a_dst, const gatres_bf16* resid,
                      const gatres_bf16* relu_ref, hipStream_t st) {
+  if constexpr (K % 32 == 0 && M % 128 == 0 && M <= 256 && (EPI != EPI_ATT || (M / H) == 128 || (M / H) == 64 || (M / H) == 32)) {
+    // wide outputs: 16-row wave tiles walked in passes of 128 columns, 512-thread workgroups, two per CU (proj_bf16_tile_kernel)
+    if (!gatres_knobs()->proj_rows) {
+      constexpr size_t lds = (size_t)M * (K + 8) * 2 + 2 * M * 4;
+      static bool attr_set = false;
+      if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&proj_bf16_tile_kernel<K, M, H, EPI>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+          (void)hipGetLastError();
+        attr_set = true;
+      }
+      const int ntiles = (N + 15) / 16;
+      int grid = (ntiles + 7) / 8;
+      if (grid > 512) grid = 512;                 // two resident workgroups per CU, contiguous equal shares of the row tiles
+      hipLaunchKernelGGL((proj_bf16_tile_kernel<K, M, H, EPI>), dim3(grid), dim3(512), lds, st, X, Wm, OUT, N, att_src,
+                         att_dst, a_src, a_dst, resid, relu_ref);
+      return gatres_launch_status();
+    }
+  }
   if constexpr (K % 32 == 0 && M % 32 == 0 && (H == 1 || H == 2 || H == 4)) {   // (a lane group's quarter row inside one head)
     constexpr size_t lds = (size_t)M * (K + 8) * 2 + 2 * M * 4;
     static bool attr_set = false;
