@@ -163,8 +163,14 @@ __global__ __launch_bounds__(THREADS) void gatres_window_kernel(const FusedArgs 
     int* hcounter = reinterpret_cast<int*>(tp);
     const u16* f_img_end = tp;
     u16* hlist = tp + 2;                 // import list: remote sources of own in-edges
-    const int hcap = max(0, (int)((lds_top - reinterpret_cast<unsigned char*>(hlist)) / 4)) & ~1;
+    // export flags of the own rows (one byte each, from the export list; the top of the list space): the stages that
+    // produce exported rows store their granules themselves (XOut, k_window_stages.h) -- for NC == 32, where every
+    // producer is a win_* stage
+    unsigned char* fflag_o = lds_top - ((ow + 15) & ~15);
+    const int hcap = max(0, (int)((fflag_o - reinterpret_cast<unsigned char*>(hlist)) / 4)) & ~1;
     u16* elist = hlist + hcap;           // export list: own rows some partner's row has an in-edge from
+    const bool xreg = NC == 32;
+    const unsigned char* fflag = fflag_o - lo;
     // index-shifted views: absolute local row / relative own-edge indices work unchanged in the stage functions
     float* hA = hAw - wlo * 2 * NC;
     float* hB = hBw - wlo * NC;
@@ -192,6 +198,7 @@ __global__ __launch_bounds__(THREADS) void gatres_window_kernel(const FusedArgs 
       copy_rowptr16<THREADS>(mrpo, a.m_rowptr, n0 + lo, ow, em0 + melo);
       copy_idx16<THREADS>(mcolo, a.m_col, em0 + melo, oem, n0);
     }
+    for (int k = tid; k < ((ow + 15) & ~15) / 4; k += THREADS) reinterpret_cast<unsigned*>(fflag_o)[k] = 0u;
     float* xcur = segbase + SL.xin;
     if (L.nb > 0) {
       const float* pb0 = P + L.p_block0;
@@ -224,6 +231,16 @@ __global__ __launch_bounds__(THREADS) void gatres_window_kernel(const FusedArgs 
         hcnt = min(hcnt, hcap); ecnt = min(ecnt, hcap);
       }
     }
+    if (xreg) {
+      for (int k = tid; k < ecnt; k += THREADS) fflag_o[(int)elist[k] - lo] = 1;
+      __syncthreads();
+    }
+    auto xout = [&](bool on, const unsigned char* flag, long long t_rows, long long t_small) {
+      XOut x;
+      x.xb = xbuf; x.ep = xc.ep + 1u; x.local = xc.local; x.on = on; x.flag = flag;
+      x.t_rows = (unsigned)t_rows; x.t_small = (unsigned)t_small;
+      return x;
+    };
     STAMP();
     for (int b = 0; b < L.nb; ++b) {
       float* base = segbase + (int64_t)b * SL.bstride;
@@ -235,7 +252,7 @@ __global__ __launch_bounds__(THREADS) void gatres_window_kernel(const FusedArgs 
       vec_prefetch<THREADS>(wlB + B2OFF, pb + L.c2_b, NC);
       if constexpr (NC == 32)
         win_proj<NC, 2 * NC, 2, EPI_ATT, 2, PW, THREADS>(rw, xA, wlA, base + SL.h1, 0, hA, base + SL.as1, base + SL.ad1, sa2, sd2,
-                                                     nullptr, nullptr, nullptr, nullptr);
+                                                     nullptr, nullptr, nullptr, nullptr, xout(xreg, fflag, XL.f1h, XL.f1a));
       else
         seg_proj<NC, 2 * NC, 2, EPI_ATT, THREADS, true, true>(rw, xA, 0, pb + L.c1_W, base + SL.h1, 0, hA, 0, pb + L.c1_as,
                                                                pb + L.c1_ad, base + SL.as1, base + SL.ad1, 0, sa2, sd2,
@@ -243,7 +260,7 @@ __global__ __launch_bounds__(THREADS) void gatres_window_kernel(const FusedArgs 
       dma_land(dw0);
       lds_barrier();                                      // own rows of h1 / a_src are in LDS; the saved copies drain meanwhile
       ++xc.ep;                                    // exchange F1: the gathers below read h1 / a_src of neighbour rows
-      xch_export2<2 * NC, 2, THREADS>(xc, xbuf, elist, ecnt, hA, (unsigned)XL.f1h, elist, ecnt, sa2, (unsigned)XL.f1a);
+      if (!xreg) xch_export2<2 * NC, 2, THREADS>(xc, xbuf, elist, ecnt, hA, (unsigned)XL.f1h, elist, ecnt, sa2, (unsigned)XL.f1a);
       xch_import2<2 * NC, 2, THREADS>(xc, xbuf, hlist, hcnt, (unsigned)XL.f1h, hA, hlist, hcnt, (unsigned)XL.f1a, sa2);
       xch_after<THREADS>(xc, pace, drain);
       lds_barrier();
@@ -252,7 +269,7 @@ __global__ __launch_bounds__(THREADS) void gatres_window_kernel(const FusedArgs 
       if (__builtin_expect(2 * oeg <= wr * NC, 1)) {
         if constexpr (NC == 32) {
           win_fwd_agg<true, 2, NC, THREADS>(rw, nbin, rp, colo, hA, sa2, sd2, base + SL.al1, elo, hBw, wlA + B1OFF,
-                                                 base + SL.o1, 0, xB, mo1 ? mo1 + b * ow : nullptr);
+                                            base + SL.o1, 0, xB, mo1 ? mo1 + b * ow : nullptr, xout(false, fflag, 0, 0));
         } else {
           win_softmax<2, THREADS>(rw, nbin, rp, colo, sa2, sd2, base + SL.al1, elo, hBw);
           lds_barrier();
@@ -275,7 +292,7 @@ __global__ __launch_bounds__(THREADS) void gatres_window_kernel(const FusedArgs 
       }
       if constexpr (NC == 32)
         win_proj<2 * NC, NC, 1, EPI_ATT, 2, PW, THREADS>(rw, xB, wlB, base + SL.h2, 0, hB, base + SL.as2, base + SL.ad2, sa1, sd1,
-                                                     nullptr, nullptr, nullptr, nullptr);
+                                                     nullptr, nullptr, nullptr, nullptr, xout(xreg, fflag, XL.f2h, XL.f2a));
       else
         seg_proj<2 * NC, NC, 1, EPI_ATT, THREADS, true, true>(rw, xB, 0, pb + L.c2_W, base + SL.h2, 0, hB, 0, pb + L.c2_as,
                                                              pb + L.c2_ad, base + SL.as2, base + SL.ad2, 0, sa1, sd1,
@@ -283,7 +300,7 @@ __global__ __launch_bounds__(THREADS) void gatres_window_kernel(const FusedArgs 
       dma_land(dw0);
       lds_barrier();
       ++xc.ep;                                    // exchange F2
-      xch_export2<NC, 1, THREADS>(xc, xbuf, elist, ecnt, hB, (unsigned)XL.f2h, elist, ecnt, sa1, (unsigned)XL.f2a);
+      if (!xreg) xch_export2<NC, 1, THREADS>(xc, xbuf, elist, ecnt, hB, (unsigned)XL.f2h, elist, ecnt, sa1, (unsigned)XL.f2a);
       xch_import2<NC, 1, THREADS>(xc, xbuf, hlist, hcnt, (unsigned)XL.f2h, hB, hlist, hcnt, (unsigned)XL.f2a, sa1);
       xch_after<THREADS>(xc, pace, drain);
       lds_barrier();
@@ -294,7 +311,7 @@ __global__ __launch_bounds__(THREADS) void gatres_window_kernel(const FusedArgs 
         float* al2L = hAw + (size_t)wr * NC;
         if constexpr (NC == 32) {
           win_fwd_agg<false, 1, NC, THREADS>(rw, nbin, rp, colo, hB, sa1, sd1, base + SL.al2, elo, al2L, wlB + B2OFF, y2T,
-                                                  0, nullptr, nullptr);
+                                             0, nullptr, nullptr, xout(xreg, fflag, XL.f3, 0));
         } else {
           win_softmax<1, THREADS>(rw, nbin, rp, colo, sa1, sd1, base + SL.al2, elo, al2L);
           lds_barrier();
@@ -308,7 +325,7 @@ __global__ __launch_bounds__(THREADS) void gatres_window_kernel(const FusedArgs 
       }
       lds_barrier();
       ++xc.ep;                                    // exchange F3: K3 averages y2 over neighbour rows
-      xch_export2<NC, 0, THREADS>(xc, xbuf, elist, ecnt, y2T, (unsigned)XL.f3, elist, 0, y2T, 0u);
+      if (!(xreg && oeg <= wr * NC)) xch_export2<NC, 0, THREADS>(xc, xbuf, elist, ecnt, y2T, (unsigned)XL.f3, elist, 0, y2T, 0u);
       xch_import2<NC, 0, THREADS>(xc, xbuf, hlist, hcnt, (unsigned)XL.f3, y2T, hlist, 0, 0u, y2T);
       xch_after<THREADS>(xc, pace, drain);
       lds_barrier();
@@ -397,11 +414,16 @@ __global__ __launch_bounds__(THREADS) void gatres_window_kernel(const FusedArgs 
     int* hcounter = reinterpret_cast<int*>(tp);
     const u16* b_img_end = tp;
     u16* hrow = tp + 2;                  // import lists: remote destinations (+ edge ids) of own out-edges
-    const int hcap = max(0, (int)((lds_top - reinterpret_cast<unsigned char*>(hrow)) / 8)) & ~1;
+    unsigned char* bflag_o = lds_top - ((ow + 15) & ~15);      // export flags of the own rows (XOut), from erow
+    const int hcap = max(0, (int)((bflag_o - reinterpret_cast<unsigned char*>(hrow)) / 8)) & ~1;
     u16* hedge = hrow + hcap;
     u16* erow = hedge + hcap;            // export lists: own rows with an in-edge from a partner's row, and those in-edges
     u16* eedge = erow + hcap;
     __syncthreads();           // forward's LDS contents are dead from here
+    constexpr bool xedge = NC == 32;                 // win_bwd_dst stores the exported g_e granules itself
+    const bool xrows = xedge && a.keep_lds;          // ... and so do the dX stages (win_proj) with their rows
+    const unsigned char* bflag = bflag_o - lo;
+    for (int k = tid; k < ((ow + 15) & ~15) / 4; k += THREADS) reinterpret_cast<unsigned*>(bflag_o)[k] = 0u;
     int hrcnt = 0, hecnt = 0, ercnt = 0, eecnt = 0;      // import rows / import edges / export rows / export edges
     if (pt) {
       hrcnt = H(GATRES_PT_B_HRCNT); hecnt = H(GATRES_PT_B_HECNT); ercnt = H(GATRES_PT_B_ERCNT); eecnt = H(GATRES_PT_B_EECNT);
@@ -492,6 +514,12 @@ __global__ __launch_bounds__(THREADS) void gatres_window_kernel(const FusedArgs 
         hrcnt = hecnt = min(hrcnt, hcap); ercnt = min(ercnt, hcap); eecnt = min(eecnt, hcap);
       }
     }
+    for (int k = tid; k < ercnt; k += THREADS) bflag_o[(int)erow[k] - lo] = 1;      // (the top-of-loop barrier publishes them)
+    auto xout = [&](bool on, unsigned t_rows, unsigned t_small) {      // values of the hand-off that follows
+      XOut o;
+      o.xb = xbuf; o.ep = xc.ep + 1u; o.local = xc.local; o.on = on; o.flag = bflag; o.t_rows = t_rows; o.t_small = t_small;
+      return o;
+    };
     STAMP();
     for (int b = L.nb - 1; b >= 0; --b) {
       const float* base = segbase + (int64_t)b * SL.bstride;
@@ -506,7 +534,8 @@ __global__ __launch_bounds__(THREADS) void gatres_window_kernel(const FusedArgs 
       lds_barrier();                                     // own rows of g_pre are in LDS (lin1 backward / the previous dX1)
       XSTAMP();
       ++xc.ep;                                   // exchange B1: K3 backward gathers g_pre of neighbour rows
-      xch_export2<NC, 0, THREADS>(xc, xbuf, erow, ercnt, gpT, (unsigned)XL.b1, erow, 0, gpT, 0u);
+      if (!xrows || b == L.nb - 1)               // (else the previous block's dX1 stored them)
+        xch_export2<NC, 0, THREADS>(xc, xbuf, erow, ercnt, gpT, (unsigned)XL.b1, erow, 0, gpT, 0u);
       XSTAMP();
       xch_import2<NC, 0, THREADS>(xc, xbuf, hrow, hrcnt, (unsigned)XL.b1, gpT, hrow, 0, 0u, gpT);
       XSTAMP();
@@ -521,12 +550,12 @@ __global__ __launch_bounds__(THREADS) void gatres_window_kernel(const FusedArgs 
       float* gh = keep + L.k_gh1;
       float* gh2 = keep + L.k_gh2;
       win_bwd_dst<true, 1, NC, THREADS>(rw, nbin, rp, colo, gy2T, hT2, alT2 + elo, asT2, adT2, ge2 + elo, gad2, mout, mrp,
-                                             mtrp, mtdsto, gpT);
+                                             mtrp, mtdsto, gpT, xout(xedge, (unsigned)XL.b2y, (unsigned)XL.b2e), elo);
       lds_barrier();
       XSTAMP();
       seg_bias_part<NC, THREADS>(rw, gy2T, 0, red);  // (own rows of g_y2: the sweep below only writes halo rows)
       ++xc.ep;                                   // exchange B2: the source-major stage reads g_y2 / g_e of neighbour rows
-      xch_export2<NC, 1, THREADS>(xc, xbuf, erow, ercnt, gy2T, (unsigned)XL.b2y, eedge, eecnt, ge2, (unsigned)XL.b2e);
+      if (!xedge) xch_export2<NC, 1, THREADS>(xc, xbuf, erow, ercnt, gy2T, (unsigned)XL.b2y, eedge, eecnt, ge2, (unsigned)XL.b2e);
       XSTAMP();
       xch_import2<NC, 1, THREADS>(xc, xbuf, hrow, hrcnt, (unsigned)XL.b2y, gy2T, hedge, hecnt, (unsigned)XL.b2e, ge2);
       XSTAMP();
@@ -554,7 +583,8 @@ __global__ __launch_bounds__(THREADS) void gatres_window_kernel(const FusedArgs 
       if (NC == 32 && a.keep_lds) {              // (the ReLU sign masks of the forward phase are in LDS: no global operand)
         if constexpr (NC == 32)
           win_proj<NC, 2 * NC, 1, EPI_RESID_MASK, 1, PW, THREADS>(rw, xG2, wlA, RA, 0, nullptr, nullptr, nullptr, nullptr, nullptr,
-                                                              nullptr, nullptr, mo1 + b * ow, nullptr);
+                                                              nullptr, nullptr, mo1 + b * ow, nullptr,
+                                                              xout(xrows, (unsigned)XL.b3o, 0u));
       } else {
         seg_proj<NC, 2 * NC, 1, EPI_RESID_MASK, THREADS, true, true>(
             rw, xG2, 0, wt2, RA, 0, nullptr, 0, nullptr, nullptr, nullptr, nullptr, 0, nullptr, nullptr, nullptr, 0,
@@ -567,11 +597,14 @@ __global__ __launch_bounds__(THREADS) void gatres_window_kernel(const FusedArgs 
       STAMP();
       seg_bias_part<2 * NC, THREADS>(rw, RA, 0, red);
       win_bwd_dst<false, 2, NC, THREADS>(rw, nbin, rp, colo, RA, hT1, alT1 + elo * 2, asT1, adT1, ge1 + elo * 2, gad1,
-                                              nullptr, nullptr, nullptr, nullptr, nullptr);
+                                              nullptr, nullptr, nullptr, nullptr, nullptr,
+                                              xout(xedge, 0u, (unsigned)XL.b3e), elo);
       lds_barrier();
       XSTAMP();
       ++xc.ep;                                   // exchange B3
-      xch_export2<2 * NC, 2, THREADS>(xc, xbuf, erow, ercnt, RA, (unsigned)XL.b3o, eedge, eecnt, ge1, (unsigned)XL.b3e);
+      if (!xrows || !xedge)
+        xch_export2<2 * NC, 2, THREADS>(xc, xbuf, erow, xrows ? 0 : ercnt, RA, (unsigned)XL.b3o, eedge, xedge ? 0 : eecnt, ge1,
+                                        (unsigned)XL.b3e);
       XSTAMP();
       xch_import2<2 * NC, 2, THREADS>(xc, xbuf, hrow, hrcnt, (unsigned)XL.b3o, RA, hedge, hecnt, (unsigned)XL.b3e, ge1);
       XSTAMP();
@@ -591,7 +624,8 @@ __global__ __launch_bounds__(THREADS) void gatres_window_kernel(const FusedArgs 
       if (NC == 32 && a.keep_lds) {
         if constexpr (NC == 32)
           win_proj<2 * NC, NC, 1, EPI_RESID_MASK, 1, PW, THREADS>(rw, xG1, wlB, gp_nxt, n0, gpT, nullptr, nullptr, nullptr, nullptr,
-                                                              gkeep, gkeep, nullptr, b > 0 ? mxin + b * ow : nullptr);
+                                                              gkeep, gkeep, nullptr, b > 0 ? mxin + b * ow : nullptr,
+                                                              xout(xrows && b > 0, (unsigned)XL.b1, 0u));
       } else {
         seg_proj<2 * NC, NC, 1, EPI_RESID_MASK, THREADS, true, true>(
             rw, xG1, 0, wt1, gp_nxt, n0, gpT, 0, nullptr, nullptr, nullptr, nullptr, 0, nullptr, nullptr,

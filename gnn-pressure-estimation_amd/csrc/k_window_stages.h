@@ -157,122 +157,6 @@ template <int N> __device__ __forceinline__ void lds_rd128xN(const unsigned (&a)
   else lds_rd128x12(a, v);
 }
 
-// ---------------------------------------------------------------------------------------------- MFMA stages
-// seg_proj (k_fused_dev.h) restated for the window kernel's widths (K, M multiples of 16, W and x operands in LDS):
-//   * a WORK UNIT is (16-row tile, group of NTG 16-column tiles): a part has three or four row tiles, so one tile per wave
-//     left twelve waves idle behind a chain of 32 dependent-issue MFMAs (~0.45 us); with the column tiles of a row tile on
-//     different waves the chain is 8 or 16 (NTG = 1 for the dX stages: no reduction across columns; NTG = M / H / 16 for the
-//     forward projections: a wave owns whole heads, so the attention logits reduce inside it, in seg_proj's order);
-//   * the unit's operand fragments -- x: K / 16 reads, W: NTG * K / 16 reads of 16 bytes -- are ONE batch (one wait) in
-//     front of the MFMA chain; seg_proj's loop had a wait after every 16-byte read of W.
-// Same lane map, k order and epilogue arithmetic as seg_proj: bit-identical results.
-//   X: [row][K] own rows (LDS, shifted view); wl: W slot [M][K + 4] (+ att_src[M] | att_dst[M] for EPI_ATT);
-//   OUT (global, row ob + r) / OUT2 (LDS, shifted view) / OUT3 (LDS [row][M], shifted view); resid_l: LDS [row][M];
-//   m64 / m32: relu_bits words per row (fields 16 / 8 bits apart).
-//   MW: the units go round the first MW waves only -- the waves behind them issue the stage's LDS-DMA, and a wave that
-//   streams from HBM sits in its issue loop for up to a microsecond (every CU streams at the same moment; a work unit on
-//   such a wave would start that much later: measured, 4.0 -> 4.9 us for dX1 + the hand-off behind it).
-template <int K, int M, int H, int EPI, int NTG, int MW, int THREADS>
-__device__ __forceinline__ void win_proj(Rows rw, const float* X, const float* wl, float* OUT, int ob, float* OUT2,
-                                         float* as_g, float* ad_g, float* as_l, float* ad_l, const float* resid_l,
-                                         float* OUT3, const unsigned long long* m64, const unsigned* m32) {
-  static_assert(K % 16 == 0 && M % 16 == 0, "whole tiles");
-  constexpr int KQ = K / 4, NT = M / 16, GROUPS = NT / NTG, KP = K + 4;
-  static_assert(MW >= 1 && MW <= THREADS / 64, "waves that carry work units");
-  constexpr int XR = KQ / 4, WR = NTG * KQ / 4;                    // 16-byte reads per unit: x fragment, W fragments
-  static_assert(NT % NTG == 0 && (EPI != EPI_ATT || NTG * 16 * H == M || H == 1), "a wave owns whole heads");
-  const int tid = stage_tid();
-  const int lane = tid & 63, wave = tid >> 6;
-  const int i = lane & 15, q = lane >> 4;
-  if (rw.hi <= rw.lo) return;                                  // (workgroup-uniform) an empty part of a split segment
-  const int tlo = rw.lo >> 4, ntiles = (rw.hi + 15) >> 4;      // rw.lo is 16-aligned
-  const int units = (ntiles - tlo) * GROUPS;
-  const unsigned a_x = lds_addr(X) + (unsigned)(q * KQ) * 4u, a_w = lds_addr(wl) + (unsigned)(i * KP + q * KQ) * 4u;
-  if (wave >= MW) return;
-  for (int u = wave; u < units; u += MW) {                     // (wave-uniform bounds; `wave` sits in a VGPR: see stage_tid)
-    const int t0 = tlo + u / GROUPS, g = u % GROUPS;
-    const int r = t0 * 16 + i;
-    const bool rok = r < rw.hi;
-    unsigned ad[XR + WR];
-    f32x4 fr[XR + WR];
-#pragma unroll
-    for (int s = 0; s < XR; ++s) ad[s] = a_x + (unsigned)(min(r, rw.hi - 1) * K + 4 * s) * 4u;
-#pragma unroll
-    for (int tt = 0; tt < NTG; ++tt)
-#pragma unroll
-      for (int s = 0; s < XR; ++s) ad[XR + tt * XR + s] = a_w + (unsigned)(((g * NTG + tt) * 16) * KP + 4 * s) * 4u;
-    lds_rd128xN<XR + WR>(ad, fr);
-    f32x4 acc[NTG];
-#pragma unroll
-    for (int tt = 0; tt < NTG; ++tt) acc[tt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    // seg_proj's order: k in steps of SC = 4 (one 16-byte fragment), all column tiles per step
-#pragma unroll
-    for (int s = 0; s < XR; ++s)
-#pragma unroll
-      for (int tt = 0; tt < NTG; ++tt)
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-          acc[tt] = __builtin_amdgcn_mfma_f32_16x16x4f32(fr[XR + tt * XR + s][e], fr[s][e], acc[tt], 0, 0, 0);
-    if constexpr (EPI == EPI_ATT) {
-      // attention logits of the head(s) this unit owns: sum over the head's column tiles in order, then over the 4 lane
-      // groups (q) by the same two shuffles as seg_proj
-      constexpr int C = M / H, TPH = C / 16;                   // column tiles per head
-      const float* attS = wl + M * KP;
-      const float* attD = attS + M;
-      constexpr int HG = (NTG + TPH - 1) / TPH;                // heads per unit (1, or H when the unit spans all columns)
-      float ps[HG], pd[HG];
-#pragma unroll
-      for (int hh = 0; hh < HG; ++hh) { ps[hh] = 0.f; pd[hh] = 0.f; }
-#pragma unroll
-      for (int tt = 0; tt < NTG; ++tt) {
-        const int mb = (g * NTG + tt) * 16 + q * 4;
-        const float4 as = ld4(attS + mb), adv = ld4(attD + mb);
-        const float ds = fmaf(acc[tt][3], as.w, fmaf(acc[tt][2], as.z, fmaf(acc[tt][1], as.y, acc[tt][0] * as.x)));
-        const float dd = fmaf(acc[tt][3], adv.w, fmaf(acc[tt][2], adv.z, fmaf(acc[tt][1], adv.y, acc[tt][0] * adv.x)));
-        ps[tt / TPH] += ds; pd[tt / TPH] += dd;
-      }
-#pragma unroll
-      for (int hh = 0; hh < HG; ++hh) {
-        ps[hh] += __shfl_xor(ps[hh], 16); ps[hh] += __shfl_xor(ps[hh], 32);
-        pd[hh] += __shfl_xor(pd[hh], 16); pd[hh] += __shfl_xor(pd[hh], 32);
-      }
-      if (q == 0 && rok) {
-#pragma unroll
-        for (int hh = 0; hh < HG; ++hh) {
-          const int hd = (g * NTG) / TPH + hh;
-          as_g[(unsigned)(r * H + hd)] = ps[hh];
-          ad_g[(unsigned)(r * H + hd)] = pd[hh];
-          as_l[r * H + hd] = ps[hh]; ad_l[r * H + hd] = pd[hh];
-        }
-      }
-    }
-    if (rok) {
-      unsigned long long mw = 0;
-      int fs = 16;
-      if constexpr (EPI == EPI_RESID_MASK) {
-        if (m64) mw = m64[r];
-        else if (m32) { mw = m32[r]; fs = 8; }
-      }
-#pragma unroll
-      for (int tt = 0; tt < NTG; ++tt) {
-        const int mb = (g * NTG + tt) * 16 + q * 4;
-        float4 o = make_float4(acc[tt][0], acc[tt][1], acc[tt][2], acc[tt][3]);
-        if constexpr (EPI == EPI_RESID_MASK) {
-          if (resid_l) add4(o, ld4(resid_l + (unsigned)(r * M + mb)));
-          if (m64 || m32) {
-            const unsigned long long b = mw >> (mb >> 2);
-            o.x = (b & 1) ? o.x : 0.f;                 o.y = ((b >> fs) & 1) ? o.y : 0.f;
-            o.z = ((b >> (2 * fs)) & 1) ? o.z : 0.f;   o.w = ((b >> (3 * fs)) & 1) ? o.w : 0.f;
-          }
-        }
-        st4(OUT + (unsigned)((ob + r) * M + mb), o);
-        if (OUT2) st4(OUT2 + (unsigned)(r * M + mb), o);
-        if (OUT3) st4(OUT3 + (unsigned)(r * M + mb), o);
-      }
-    }
-  }
-}
-
 // ---------------------------------------------------------------------------------------------- granule exchange, 16-byte form
 // The hand-offs of k_fused_dev.h (xch_export / xch_import: one 8-byte {value, epoch} granule per memory instruction, one
 // table per call) restated for the window kernel:
@@ -398,6 +282,158 @@ __device__ __forceinline__ void xch_after(Xch& x, bool pace, bool drain) {
     }
   }
   if (drain) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+// EXPORT FROM THE PRODUCING STAGE.  xch_export2 runs behind the producer's closing barrier and re-reads the rows it
+// publishes from LDS: a barrier, an LDS round trip and a list walk in front of every hand-off (~0.3 us, ninety times per
+// launch).  The stages that PRODUCE exported values hold them in registers: they store the granules themselves, for the rows
+// / edges a per-row flag marks (rows: `flag`, own-row byte table; edges: the source row lies outside the part), tagged with
+// the epoch of the hand-off that FOLLOWS (ep).  The partner's sweep then finds them on its first pass more often, and the
+// hand-off itself is barrier -> sweep -> barrier.  on == false: the stage exports nothing (xch_export2 does).
+struct XOut {
+  XchBuf xb;
+  unsigned ep;          // epoch of the hand-off these values belong to
+  bool local, on;
+  const unsigned char* flag;    // own rows (shifted view: flag[row]): some partner imports this row
+  unsigned t_rows, t_small;     // first granule of the row table / of the per-row or per-edge table
+};
+// four consecutive granules (32 bytes) = two 16-byte stores
+__device__ __forceinline__ void xout_store4(const XOut& x, unsigned granule, const float4 v) {
+  const v4u g0 = {__float_as_uint(v.x), x.ep, __float_as_uint(v.y), x.ep};
+  const v4u g1 = {__float_as_uint(v.z), x.ep, __float_as_uint(v.w), x.ep};
+  const unsigned off = granule * 8u;
+  if (x.local) {
+    __builtin_amdgcn_raw_buffer_store_b128(g0, x.xb.r, off, 0, 0);
+    __builtin_amdgcn_raw_buffer_store_b128(g1, x.xb.r, off + 16u, 0, 0);
+  } else {
+    __builtin_amdgcn_raw_buffer_store_b128(g0, x.xb.r, off, 0, 16);
+    __builtin_amdgcn_raw_buffer_store_b128(g1, x.xb.r, off + 16u, 0, 16);
+  }
+}
+__device__ __forceinline__ void xout_store1(const XOut& x, unsigned granule, const float v) {
+  typedef unsigned v2u __attribute__((ext_vector_type(2)));
+  const v2u g = {__float_as_uint(v), x.ep};
+  if (x.local) __builtin_amdgcn_raw_buffer_store_b64(g, x.xb.r, granule * 8u, 0, 0);
+  else         __builtin_amdgcn_raw_buffer_store_b64(g, x.xb.r, granule * 8u, 0, 16);
+}
+
+// ---------------------------------------------------------------------------------------------- MFMA stages
+// seg_proj (k_fused_dev.h) restated for the window kernel's widths (K, M multiples of 16, W and x operands in LDS):
+//   * a WORK UNIT is (16-row tile, group of NTG 16-column tiles): a part has three or four row tiles, so one tile per wave
+//     left twelve waves idle behind a chain of 32 dependent-issue MFMAs (~0.45 us); with the column tiles of a row tile on
+//     different waves the chain is 8 or 16 (NTG = 1 for the dX stages: no reduction across columns; NTG = M / H / 16 for the
+//     forward projections: a wave owns whole heads, so the attention logits reduce inside it, in seg_proj's order);
+//   * the unit's operand fragments -- x: K / 16 reads, W: NTG * K / 16 reads of 16 bytes -- are ONE batch (one wait) in
+//     front of the MFMA chain; seg_proj's loop had a wait after every 16-byte read of W.
+// Same lane map, k order and epilogue arithmetic as seg_proj: bit-identical results.
+//   X: [row][K] own rows (LDS, shifted view); wl: W slot [M][K + 4] (+ att_src[M] | att_dst[M] for EPI_ATT);
+//   OUT (global, row ob + r) / OUT2 (LDS, shifted view) / OUT3 (LDS [row][M], shifted view); resid_l: LDS [row][M];
+//   m64 / m32: relu_bits words per row (fields 16 / 8 bits apart).
+//   MW: the units go round the first MW waves only -- the waves behind them issue the stage's LDS-DMA, and a wave that
+//   streams from HBM sits in its issue loop for up to a microsecond (every CU streams at the same moment; a work unit on
+//   such a wave would start that much later: measured, 4.0 -> 4.9 us for dX1 + the hand-off behind it).
+template <int K, int M, int H, int EPI, int NTG, int MW, int THREADS>
+__device__ __forceinline__ void win_proj(Rows rw, const float* X, const float* wl, float* OUT, int ob, float* OUT2,
+                                         float* as_g, float* ad_g, float* as_l, float* ad_l, const float* resid_l,
+                                         float* OUT3, const unsigned long long* m64, const unsigned* m32, const XOut& xo) {
+  static_assert(K % 16 == 0 && M % 16 == 0, "whole tiles");
+  constexpr int KQ = K / 4, NT = M / 16, GROUPS = NT / NTG, KP = K + 4;
+  static_assert(MW >= 1 && MW <= THREADS / 64, "waves that carry work units");
+  constexpr int XR = KQ / 4, WR = NTG * KQ / 4;                    // 16-byte reads per unit: x fragment, W fragments
+  static_assert(NT % NTG == 0 && (EPI != EPI_ATT || NTG * 16 * H == M || H == 1), "a wave owns whole heads");
+  const int tid = stage_tid();
+  const int lane = tid & 63, wave = tid >> 6;
+  const int i = lane & 15, q = lane >> 4;
+  if (rw.hi <= rw.lo) return;                                  // (workgroup-uniform) an empty part of a split segment
+  const int tlo = rw.lo >> 4, ntiles = (rw.hi + 15) >> 4;      // rw.lo is 16-aligned
+  const int units = (ntiles - tlo) * GROUPS;
+  const unsigned a_x = lds_addr(X) + (unsigned)(q * KQ) * 4u, a_w = lds_addr(wl) + (unsigned)(i * KP + q * KQ) * 4u;
+  if (wave >= MW) return;
+  for (int u = wave; u < units; u += MW) {                     // (wave-uniform bounds; `wave` sits in a VGPR: see stage_tid)
+    const int t0 = tlo + u / GROUPS, g = u % GROUPS;
+    const int r = t0 * 16 + i;
+    const bool rok = r < rw.hi;
+    const bool xrow = xo.on && rok && xo.flag[min(r, rw.hi - 1)] != 0;      // (read now: the wait falls behind the MFMA chain)
+    unsigned ad[XR + WR];
+    f32x4 fr[XR + WR];
+#pragma unroll
+    for (int s = 0; s < XR; ++s) ad[s] = a_x + (unsigned)(min(r, rw.hi - 1) * K + 4 * s) * 4u;
+#pragma unroll
+    for (int tt = 0; tt < NTG; ++tt)
+#pragma unroll
+      for (int s = 0; s < XR; ++s) ad[XR + tt * XR + s] = a_w + (unsigned)(((g * NTG + tt) * 16) * KP + 4 * s) * 4u;
+    lds_rd128xN<XR + WR>(ad, fr);
+    f32x4 acc[NTG];
+#pragma unroll
+    for (int tt = 0; tt < NTG; ++tt) acc[tt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    // seg_proj's order: k in steps of SC = 4 (one 16-byte fragment), all column tiles per step
+#pragma unroll
+    for (int s = 0; s < XR; ++s)
+#pragma unroll
+      for (int tt = 0; tt < NTG; ++tt)
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          acc[tt] = __builtin_amdgcn_mfma_f32_16x16x4f32(fr[XR + tt * XR + s][e], fr[s][e], acc[tt], 0, 0, 0);
+    if constexpr (EPI == EPI_ATT) {
+      // attention logits of the head(s) this unit owns: sum over the head's column tiles in order, then over the 4 lane
+      // groups (q) by the same two shuffles as seg_proj
+      constexpr int C = M / H, TPH = C / 16;                   // column tiles per head
+      const float* attS = wl + M * KP;
+      const float* attD = attS + M;
+      constexpr int HG = (NTG + TPH - 1) / TPH;                // heads per unit (1, or H when the unit spans all columns)
+      float ps[HG], pd[HG];
+#pragma unroll
+      for (int hh = 0; hh < HG; ++hh) { ps[hh] = 0.f; pd[hh] = 0.f; }
+#pragma unroll
+      for (int tt = 0; tt < NTG; ++tt) {
+        const int mb = (g * NTG + tt) * 16 + q * 4;
+        const float4 as = ld4(attS + mb), adv = ld4(attD + mb);
+        const float ds = fmaf(acc[tt][3], as.w, fmaf(acc[tt][2], as.z, fmaf(acc[tt][1], as.y, acc[tt][0] * as.x)));
+        const float dd = fmaf(acc[tt][3], adv.w, fmaf(acc[tt][2], adv.z, fmaf(acc[tt][1], adv.y, acc[tt][0] * adv.x)));
+        ps[tt / TPH] += ds; pd[tt / TPH] += dd;
+      }
+#pragma unroll
+      for (int hh = 0; hh < HG; ++hh) {
+        ps[hh] += __shfl_xor(ps[hh], 16); ps[hh] += __shfl_xor(ps[hh], 32);
+        pd[hh] += __shfl_xor(pd[hh], 16); pd[hh] += __shfl_xor(pd[hh], 32);
+      }
+      if (q == 0 && rok) {
+#pragma unroll
+        for (int hh = 0; hh < HG; ++hh) {
+          const int hd = (g * NTG) / TPH + hh;
+          as_g[(unsigned)(r * H + hd)] = ps[hh];
+          ad_g[(unsigned)(r * H + hd)] = pd[hh];
+          as_l[r * H + hd] = ps[hh]; ad_l[r * H + hd] = pd[hh];
+          if (xrow) xout_store1(xo, xo.t_small + (unsigned)(r * H + hd), ps[hh]);       // a_src goes to the partners
+        }
+      }
+    }
+    if (rok) {
+      unsigned long long mw = 0;
+      int fs = 16;
+      if constexpr (EPI == EPI_RESID_MASK) {
+        if (m64) mw = m64[r];
+        else if (m32) { mw = m32[r]; fs = 8; }
+      }
+#pragma unroll
+      for (int tt = 0; tt < NTG; ++tt) {
+        const int mb = (g * NTG + tt) * 16 + q * 4;
+        float4 o = make_float4(acc[tt][0], acc[tt][1], acc[tt][2], acc[tt][3]);
+        if constexpr (EPI == EPI_RESID_MASK) {
+          if (resid_l) add4(o, ld4(resid_l + (unsigned)(r * M + mb)));
+          if (m64 || m32) {
+            const unsigned long long b = mw >> (mb >> 2);
+            o.x = (b & 1) ? o.x : 0.f;                 o.y = ((b >> fs) & 1) ? o.y : 0.f;
+            o.z = ((b >> (2 * fs)) & 1) ? o.z : 0.f;   o.w = ((b >> (3 * fs)) & 1) ? o.w : 0.f;
+          }
+        }
+        st4(OUT + (unsigned)((ob + r) * M + mb), o);
+        if (OUT2) st4(OUT2 + (unsigned)(r * M + mb), o);
+        if (OUT3) st4(OUT3 + (unsigned)(r * M + mb), o);
+        if (xrow) xout_store4(xo, xo.t_rows + (unsigned)(r * M + mb), o);
+      }
+    }
+  }
 }
 
 // ---------------------------------------------------------------------------------------------- neighbour descriptors
@@ -613,7 +649,7 @@ template <bool RELU, int H, int C, int THREADS>
 __device__ __forceinline__ void win_fwd_agg(Rows rw, const u16* nb, const u16* rp, const u16* col, const float* hsrc,
                                             const float* asrc, const float* adst_t, float* __restrict__ alpha_g, int eb,
                                             float* alpha_l, const float* bias, float* out, int ob, float* out_pub,
-                                            unsigned long long* mask64) {
+                                            unsigned long long* mask64, const XOut& xo) {
   static_assert(C == 32 && MAXD <= 8, "one edge slot per lane of a head's eight lanes");
   const int tid = stage_tid();
   constexpr int HC = H * C, G = HC / 4, LH = C / 4, RPP = THREADS / G;
@@ -698,6 +734,7 @@ __device__ __forceinline__ void win_fwd_agg(Rows rw, const u16* nb, const u16* r
     if (valid) {
       st4(out + (unsigned)((ob + r) * HC + c0), acc);
       if (out_pub) st4(out_pub + (unsigned)(r * HC + c0), acc);
+      if (xo.on && xo.flag[r] != 0) xout_store4(xo, xo.t_rows + (unsigned)(r * HC + c0), acc);
     }
     if constexpr (RELU && G <= 16) {
       if (mask64) {                                             // (workgroup-uniform)
@@ -912,7 +949,8 @@ __device__ __forceinline__ void win_bwd_dst(Rows rw, const u16* nb, const u16* r
                                             const float* h, const float* alpha, const float* a_src, const float* a_dst,
                                             float* g_e, float* g_a_dst,
                                             const u16* mo, const u16* mrp, const u16* mtrp, const u16* mtdst,
-                                            const float* g_pre) {
+                                            const float* g_pre, const XOut& xo, int eabs) {
+  // (eabs: absolute local id of the part's first own edge -- the edge tables of the hand-offs are indexed by it)
   static_assert(!MEAN || H == 1, "K3 runs at conv2's width");
   const int tid = stage_tid();
   constexpr int HC = H * C, G = HC / 4, LH = C / 4, RPP = THREADS / G;
@@ -966,7 +1004,10 @@ __device__ __forceinline__ void win_bwd_dst(Rows rw, const u16* nb, const u16* r
         }
       }
       go = acc;
-      if (valid) st4(g_out_rw + (unsigned)(r * HC + c0), acc);
+      if (valid) {
+        st4(g_out_rw + (unsigned)(r * HC + c0), acc);
+        if (xo.on && xo.flag[r] != 0) xout_store4(xo, xo.t_rows + (unsigned)(r * HC + c0), acc);
+      }
     } else {
       uint4 w, gw;
       lds_rd128x2_32(a_nb + (unsigned)(r - rw.lo) * 16u, a_go + (unsigned)(r * HC) * 4u, a_ad + (unsigned)(r * H) * 4u, w,
@@ -989,6 +1030,8 @@ __device__ __forceinline__ void win_bwd_dst(Rows rw, const u16* nb, const u16* r
           const float raw = a_src[(unsigned)((int)col[e] * H + hd)] + adst;
           const float ge = raw > 0.f ? gs : gs * GATRES_NEG_SLOPE;
           g_e[(unsigned)(e * H + hd)] = ge;
+          const int j = col[e];
+          if (xo.on && (j < rw.lo || j >= rw.hi)) xout_store1(xo, xo.t_small + (unsigned)((eabs + e) * H + hd), ge);
           gad = gad + ge;
         }
         g_a_dst[(unsigned)(r * H + hd)] = gad;
@@ -1017,7 +1060,11 @@ __device__ __forceinline__ void win_bwd_dst(Rows rw, const u16* nb, const u16* r
     for (int k = 0; k < MAXD; ++k) {
       const float gs = al[k] * (ga[k] - S);
       const float ge = raw[k] > 0.f ? gs : gs * GATRES_NEG_SLOPE;
-      if (leader && k < d.deg) g_e[(unsigned)((d.beg + k) * H + hd)] = ge;
+      if (leader && k < d.deg) {
+        g_e[(unsigned)((d.beg + k) * H + hd)] = ge;
+        // the owner of the edge's SOURCE row needs g_e in its source-major stage
+        if (xo.on && (d.n[k] < rw.lo || d.n[k] >= rw.hi)) xout_store1(xo, xo.t_small + (unsigned)((eabs + d.beg + k) * H + hd), ge);
+      }
       gad = gad + ge;                                                  // ge == 0 on padding slots
     }
     if (leader) g_a_dst[(unsigned)(r * H + hd)] = gad;
