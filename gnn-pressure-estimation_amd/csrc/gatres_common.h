@@ -31,16 +31,29 @@ struct gatres_knobs_t {
   int param_grads_no_stream;  // GATRES_PARAM_GRADS_NO_STREAM
   int lin_bwd_wave;           // GATRES_LIN_BWD_WAVE
   int proj_rows;              // GATRES_PROJ_ROWS (0: default)
+  int proj_stream;            // GATRES_PROJ_STREAM=1: bf16 projections of gatres_large by proj_bf16_stream_kernel (measured, not the default)
   int no_proj_lds;            // GATRES_NO_PROJ_LDS
   int dw_1d;                  // GATRES_DW_1D
   int dw_fp32;                // GATRES_DW_FP32
   int no_co_launch;           // GATRES_NO_CO_LAUNCH
   int co_launch_always;       // GATRES_CO_LAUNCH_ALWAYS
   int dw_slab_rows;           // GATRES_DW_SLAB_ROWS (0: default)
+  int side_stream;            // GATRES_SIDE_STREAM = 0 | 1: the per-op backward's parameter-gradient launches never / always on the
+                              // library's side stream (-1, unset: where it was measured faster -- fp32, nc >= 128)
   int xch_nowait;             // diagnostic build only, WRONG results: GATRES_XCH_NOWAIT
   int diag_nomask;            // diagnostic build only, WRONG results: GATRES_DIAG_NOMASK
 };
 extern "C" __attribute__((visibility("hidden"))) const gatres_knobs_t* gatres_knobs();
+
+// The library's side stream of the current device (created at first use, never destroyed) and the events of the per-op
+// backward's fork / join: the parameter-gradient launches of a convolution feed nothing but the optimizer, so they may run
+// beside the chain of launches that carries the gradient down the network (model_driver.hip).  nullptr: the runtime refused
+// a stream / event.
+struct gatres_side_t {
+  hipStream_t stream;
+  hipEvent_t fork_a, fork_b, done_a, done_b;
+};
+extern "C" __attribute__((visibility("hidden"))) gatres_side_t* gatres_side();
 
 static inline int gatres_launch_status() { return (int)hipGetLastError(); }
 static inline hipStream_t gatres_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }

@@ -36,12 +36,14 @@ void read_knobs(gatres_knobs_t* k) {
   k->param_grads_no_stream = env_flag("GATRES_PARAM_GRADS_NO_STREAM");
   k->lin_bwd_wave = env_flag("GATRES_LIN_BWD_WAVE");
   k->proj_rows = (env_int("GATRES_PROJ_ROWS", 0) + 63) & ~63;
+  k->proj_stream = env_flag("GATRES_PROJ_STREAM");
   k->no_proj_lds = env_flag("GATRES_NO_PROJ_LDS");
   k->dw_1d = env_flag("GATRES_DW_1D");
   k->dw_fp32 = env_flag("GATRES_DW_FP32");
   k->no_co_launch = env_flag("GATRES_NO_CO_LAUNCH");
   k->co_launch_always = env_flag("GATRES_CO_LAUNCH_ALWAYS");
   k->dw_slab_rows = env_int("GATRES_DW_SLAB_ROWS", 0);
+  k->side_stream = env_int("GATRES_SIDE_STREAM", -1);
 #ifdef GATRES_DIAG_BUILD
   k->fused_wide = env_flag("GATRES_FUSED_WIDE");
   k->xch_nowait = env_flag("GATRES_XCH_NOWAIT");
@@ -68,6 +70,25 @@ extern "C" int gatres_knobs_reload(void) {
   read_knobs(&g_knobs);
   g_knobs_ready.store(true, std::memory_order_release);
   return 0;
+}
+
+extern "C" __attribute__((visibility("hidden"))) gatres_side_t* gatres_side() {
+  constexpr int MAXDEV = 64;
+  static gatres_side_t sides[MAXDEV];
+  static int state[MAXDEV];                // 0: not tried, 1: ready, -1: failed
+  static std::mutex mu;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAXDEV) { (void)hipGetLastError(); return nullptr; }
+  std::lock_guard<std::mutex> lk(mu);
+  if (state[dev] == 0) {
+    gatres_side_t& s = sides[dev];
+    bool ok = hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking) == hipSuccess;
+    hipEvent_t* ev[4] = {&s.fork_a, &s.fork_b, &s.done_a, &s.done_b};
+    for (int k = 0; k < 4 && ok; ++k) ok = hipEventCreateWithFlags(ev[k], hipEventDisableTiming) == hipSuccess;
+    if (!ok) (void)hipGetLastError();
+    state[dev] = ok ? 1 : -1;
+  }
+  return state[dev] == 1 ? &sides[dev] : nullptr;
 }
 
 namespace {

@@ -519,8 +519,12 @@ __global__ __launch_bounds__(256) void proj_bf16_kernel(const gatres_bf16* __res
 // tiles = 6 or 7 per workgroup, one per wave, ONE round on every CU (16-row x 128-column wave tiles dealt round a grid were
 // 1.5 rounds: half the chip idle in the second).  The tile's rows are requested before W is staged, the epilogue's operands
 // before the MFMA chain: a wave's life is a chain of round trips (W, x, epilogue operands, store) and they now overlap.
-// A pass covers whole heads for nc = 128 (C = 128): the attention logits reduce inside the wave, pass by pass.  Same
-// feature permutation as above within a pass: lane group q owns the contiguous 32 features [128 p + 32 q, + 32).
+// A pass covers whole heads for nc = 128 (C = 128): the attention logits reduce inside the wave, pass by pass.
+// Feature permutation within a pass: accumulator tile pair (2 j, 2 j + 1) of lane group q holds the 8 features
+// [128 p + 32 j + 8 q, + 8), so ONE 16-byte store / epilogue-operand load per lane covers 64 contiguous bytes of a row
+// across the row's four lanes.  (Lane group q owning a contiguous 32 features, as in proj_bf16_kernel above, made every
+// store a 16-byte write request of its own: 1.6 M requests per launch, one per L2-channel clock -- the store phase took
+// 7 of the kernel's 17 us whether the output sat in HBM or in cache; tests/micro/proj_probe.py.)
 template <int K, int M, int H, int EPI>
 __global__ __launch_bounds__(512, 4) void proj_bf16_tile_kernel(const gatres_bf16* __restrict__ X,
                                                                 const gatres_bf16* __restrict__ Wm,
@@ -551,8 +555,8 @@ __global__ __launch_bounds__(512, 4) void proj_bf16_tile_kernel(const gatres_bf1
   int tile = t_lo + wave;
   if (tile < t_hi) load_x(tile, xf);                          // in flight while W is staged
   {
-    // LDS row l = 128 p + 16 t + a holds W row 128 p + (a >> 2) * 32 + 4 t + (a & 3); eight 16-byte loads in flight per
-    // thread, then their LDS stores
+    // LDS row l = 128 p + 16 t + a holds W row 128 p + 32 (t >> 1) + 8 (a >> 2) + 4 (t & 1) + (a & 3) (see the header);
+    // eight 16-byte loads in flight per thread, then their LDS stores
     constexpr int CH = M * (K / 8), PER = (CH + 511) / 512, UB = PER < 8 ? PER : 8;
     for (int b0 = 0; b0 < PER; b0 += UB) {
       uint4 v[UB];
@@ -561,7 +565,7 @@ __global__ __launch_bounds__(512, 4) void proj_bf16_tile_kernel(const gatres_bf1
         const int idx = threadIdx.x + 512 * (b0 + u);
         const int l = idx / (K / 8), k8 = (idx % (K / 8)) * 8;
         const int lw = l % WC, t = lw >> 4, a = lw & 15;
-        const int m = (l / WC) * WC + (a >> 2) * QF + 4 * t + (a & 3);
+        const int m = (l / WC) * WC + 32 * (t >> 1) + 8 * (a >> 2) + 4 * (t & 1) + (a & 3);
         v[u] = (b0 + u < PER && idx < CH) ? *reinterpret_cast<const uint4*>(Wm + (size_t)m * K + k8) : make_uint4(0u, 0u, 0u, 0u);
       }
 #pragma unroll
@@ -587,7 +591,7 @@ __global__ __launch_bounds__(512, 4) void proj_bf16_tile_kernel(const gatres_bf1
     const bool nok = n < N;
     if (!first) load_x(tile, xf);
     first = false;
-    const size_t rowo = (size_t)min(n, N - 1) * M + q * QF;
+    const size_t rowo = (size_t)min(n, N - 1) * M + q * 8;
 #pragma unroll
     for (int p = 0; p < CG; ++p) {
       const gatres_bf16* wbase = wl + (size_t)(p * WC + i) * KP + q * 8;
@@ -597,8 +601,8 @@ __global__ __launch_bounds__(512, 4) void proj_bf16_tile_kernel(const gatres_bf1
       if constexpr (EPI == EPI_RESID_MASK) {
 #pragma unroll
         for (int t = 0; t < NT; t += 2) {
-          if (resid) rraw[t / 2] = *reinterpret_cast<const uint4*>(resid + rowo + p * WC + 4 * t);
-          if (relu_ref) mraw[t / 2] = *reinterpret_cast<const uint4*>(relu_ref + rowo + p * WC + 4 * t);
+          if (resid) rraw[t / 2] = *reinterpret_cast<const uint4*>(resid + rowo + p * WC + 16 * t);
+          if (relu_ref) mraw[t / 2] = *reinterpret_cast<const uint4*>(relu_ref + rowo + p * WC + 16 * t);
         }
       }
       f32x4 acc[NT];
@@ -616,22 +620,21 @@ __global__ __launch_bounds__(512, 4) void proj_bf16_tile_kernel(const gatres_bf1
         for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[t], xf[s], acc[t], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
       }
-      // acc[t][reg] = output feature 128 p + 32 q + 4 t + reg of node n
+      // acc[t][reg] = output feature 128 p + 32 (t >> 1) + 8 q + 4 (t & 1) + reg of node n
       if constexpr (EPI == EPI_ATT) {
         constexpr int HP = WC / C;                   // heads per pass (1 for nc = 128)
-        const int hl = (q * QF) / C;                 // this lane group's head inside the pass
-        float psl = 0.f, pdl = 0.f;
-#pragma unroll
-        for (int t = 0; t < NT; ++t) {
-          const int mb = p * WC + q * QF + 4 * t;
-          const float4 as = ld4(attS + mb), ad = ld4(attD + mb);
-          psl += fmaf(acc[t][3], as.w, fmaf(acc[t][2], as.z, fmaf(acc[t][1], as.y, acc[t][0] * as.x)));
-          pdl += fmaf(acc[t][3], ad.w, fmaf(acc[t][2], ad.z, fmaf(acc[t][1], ad.y, acc[t][0] * ad.x)));
-        }
         float ps[HP], pd[HP];
 #pragma unroll
+        for (int hh = 0; hh < HP; ++hh) { ps[hh] = 0.f; pd[hh] = 0.f; }
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+          const int mb = p * WC + 32 * (t >> 1) + 8 * q + 4 * (t & 1);
+          const float4 as = ld4(attS + mb), ad = ld4(attD + mb);
+          ps[(32 * (t >> 1)) / C] += fmaf(acc[t][3], as.w, fmaf(acc[t][2], as.z, fmaf(acc[t][1], as.y, acc[t][0] * as.x)));
+          pd[(32 * (t >> 1)) / C] += fmaf(acc[t][3], ad.w, fmaf(acc[t][2], ad.z, fmaf(acc[t][1], ad.y, acc[t][0] * ad.x)));
+        }
+#pragma unroll
         for (int hh = 0; hh < HP; ++hh) {
-          ps[hh] = hh == hl ? psl : 0.f; pd[hh] = hh == hl ? pdl : 0.f;
           ps[hh] += __shfl_xor(ps[hh], 16); ps[hh] += __shfl_xor(ps[hh], 32);
           pd[hh] += __shfl_xor(pd[hh], 16); pd[hh] += __shfl_xor(pd[hh], 32);
         }
@@ -670,17 +673,217 @@ __global__ __launch_bounds__(512, 4) void proj_bf16_tile_kernel(const gatres_bf1
           bf16x8 ob;
           ob[0] = (gatres_bf16)o0.x; ob[1] = (gatres_bf16)o0.y; ob[2] = (gatres_bf16)o0.z; ob[3] = (gatres_bf16)o0.w;
           ob[4] = (gatres_bf16)o1.x; ob[5] = (gatres_bf16)o1.y; ob[6] = (gatres_bf16)o1.z; ob[7] = (gatres_bf16)o1.w;
-          *reinterpret_cast<bf16x8*>(OUT + (size_t)n * M + p * WC + q * QF + 4 * t) = ob;
+          *reinterpret_cast<bf16x8*>(OUT + (size_t)n * M + p * WC + 16 * t + q * 8) = ob;
         }
       }
     }
   }
 }
 
+#ifdef PROJ_STAMPS
+__device__ unsigned long long g_pstamps[512 * 8 * 8];
+#define PSTAMP(k) do { if (lane == 0) g_pstamps[(blockIdx.x * 8 + wave) * 8 + (k)] = wall_clock64(); } while (0)
+#else
+#define PSTAMP(k) do {} while (0)
+#endif
+// Round 3, second retile: the STREAMING form for K = 128 / 256 (gatres_large).  What the stamps inside
+// proj_bf16_tile_kernel's successor showed (tests/micro/proj_probe.py --stamps; profiles/r03_proj_probe.txt): of a launch's
+// 15 us, 3 are dispatch, and 4 - 7 go by before the first MFMA because sixteen waves per CU each fetch W (or their slice of it)
+// from L2 -- 128 - 256 KB per CU, 33 - 66 MB chip-wide, every CU asking for the same 64 KB at the same moment -- while the
+// rows themselves (12.7 - 25 MB from HBM) land in the shadow of that; the stores drain within 0.3 us of the last MFMA.
+// So: ONE 512-thread workgroup per CU, and
+//   * a wave owns a 32-COLUMN slice of W for the whole launch, in REGISTERS (2 column tiles x K / 32 fragments = K / 4
+//     VGPRs, loaded once: 64 KB per CU for M = 256, 128 KB for M = 128, where two groups of four waves take even / odd
+//     tiles), and walks the row tiles of its workgroup: per tile K / 32 LDS reads of x, 2 K / 32 MFMAs, one 16-byte store
+//     per lane (the four lanes of a row write 64 contiguous bytes);
+//   * the workgroup's x tiles arrive by LDS-DMA in STAGES of eight (tile j by wave j % 8): the first stage is waited for
+//     with a counted vmcnt while the second is still in flight, and is computed while that lands;
+//   * the LDS image is swizzled on the SOURCE side: the DMA writes 64 lanes x 16 bytes lane-linearly, so lane L fetches the
+//     16-byte chunk that belongs in its slot -- slot (row r, c') holds chunk c' ^ (r & 15) -- and the B-operand read of
+//     lane (i, q) at k step s takes slot (4 s + q) ^ i: conflict-free for ds_read_b128's lane groups (rows are 256 or 512
+//     bytes: unswizzled, all 16 rows of a fragment sit on one bank group);
+//   * the epilogue operands of the dX forms (residual / ReLU reference rows, 16 bytes per lane and tile) of a stage are
+//     requested before the stage's wait, all at once (two waves per SIMD: 256 registers each);
+//   * attention logits: a head spans C / 32 waves; each wave leaves its 32-column partial dots in LDS and, behind the
+//     round's closing barrier, one thread per (row, head) adds the head's partials in wave order.
+// Feature map inside a wave's slice: accumulator (ct, reg) of lane group q = feature cb + 8 q + 4 ct + reg.
+// Shares longer than 16 tiles (50 k-node graphs) go round by round.
+template <int K, int M, int H, int EPI>
+__global__ __launch_bounds__(512, 2) void proj_bf16_stream_kernel(const gatres_bf16* __restrict__ X,
+                                                                  const gatres_bf16* __restrict__ Wm,
+                                                                  gatres_bf16* __restrict__ OUT, int N,
+                                                                  const float* __restrict__ att_src,
+                                                                  const float* __restrict__ att_dst, float* __restrict__ a_src,
+                                                                  float* __restrict__ a_dst,
+                                                                  const gatres_bf16* __restrict__ resid,
+                                                                  const gatres_bf16* __restrict__ relu_ref) {
+  constexpr int KS = K / 32, G = M / 32, TG = 8 / G, ROWB = K * 2, TILEB = 16 * ROWB, C = M / H, WPH = C / 32;
+  constexpr int TMAX = 16, SPW = 8 / TG;            // tiles per round; tiles of one stage per wave
+  static_assert(K % 128 == 0 && (M == 128 || M == 256) && C % 32 == 0, "gatres_large's widths");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  float2* part = reinterpret_cast<float2*>(smem + (size_t)TMAX * TILEB);       // [tile][wave][16]: partial attention dots
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int i = lane & 15, q = lane >> 4;
+  const int ntiles = (N + 15) >> 4;
+  const int t_lo = (int)((long long)ntiles * blockIdx.x / gridDim.x), t_hi = (int)((long long)ntiles * (blockIdx.x + 1) / gridDim.x);
+  const int tg = wave / G, cb = (wave % G) * 32;                   // tile group; first column of this wave's slice
+  PSTAMP(0);
+  // the W slice: A-operand row a = lane i of column tile ct  <->  feature cb + 8 (i >> 2) + 4 ct + (i & 3)
+  bf16x8 wr[2][KS];
+#pragma unroll
+  for (int ct = 0; ct < 2; ++ct) {
+    const gatres_bf16* wp = Wm + (size_t)(cb + 8 * (i >> 2) + 4 * ct + (i & 3)) * K + q * 8;
+#pragma unroll
+    for (int s = 0; s < KS; ++s) wr[ct][s] = *reinterpret_cast<const bf16x8*>(wp + s * 32);
+  }
+  float4 aS[2], aD[2];
+  if constexpr (EPI == EPI_ATT) {
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct) { aS[ct] = ld4(att_src + cb + 8 * q + 4 * ct); aD[ct] = ld4(att_dst + cb + 8 * q + 4 * ct); }
+  }
+  constexpr int ROWS = 1024 / ROWB, PER = TILEB / 1024, CPR = ROWB / 16;      // rows / DMA instructions per tile, chunks per row
+  for (int base = t_lo; base < t_hi; base += TMAX) {
+    const int T = min(TMAX, t_hi - base);
+    // LDS-DMA of tile j (by wave j % 8): 1 KB (ROWS rows) per instruction, source-side swizzle
+    auto dma_tile = [&](int j) {
+      unsigned char* dst = smem + (size_t)j * TILEB;
+#pragma unroll
+      for (int u = 0; u < PER; ++u) {
+        const int r = u * ROWS + lane / CPR, cs = lane % CPR;              // slot (r, cs)
+        const int n = min((base + j) * 16 + r, N - 1);
+        const gatres_bf16* src = X + (size_t)n * K + ((cs ^ (r & 15)) * 8);
+        __builtin_amdgcn_global_load_lds(reinterpret_cast<const float*>(src), reinterpret_cast<float*>(dst + u * 1024), 16, 0, 0);
+      }
+    };
+    uint4 rr[SPW], mr[SPW];
+    auto epi_load = [&](int stage) {                 // this wave's tiles of the stage: j = 8 stage + tg + TG k
+      if constexpr (EPI == EPI_RESID_MASK) {
+#pragma unroll
+        for (int k = 0; k < SPW; ++k) {
+          const int j = 8 * stage + tg + TG * k;
+          const size_t o = (size_t)min((base + min(j, T - 1)) * 16 + i, N - 1) * M + cb + 8 * q;
+          if (resid) rr[k] = *reinterpret_cast<const uint4*>(resid + o);
+          if (relu_ref) mr[k] = *reinterpret_cast<const uint4*>(relu_ref + o);
+        }
+      }
+    };
+    if (wave < T) dma_tile(wave);
+    epi_load(0);
+    const bool second = wave + 8 < T;                // (wave-uniform)
+    if (second) dma_tile(wave + 8);
+    // everything but this wave's second-stage tile has landed (loads return in order)
+    if (second) { if constexpr (PER == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); }
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    static_assert(PER == 4 || PER == 8, "the counted wait above");
+    PSTAMP(1);
+    __builtin_amdgcn_s_barrier();                    // (bare: a fence here would drain the second stage's DMA)
+    PSTAMP(2);
+    for (int stage = 0; stage * 8 < T; ++stage) {
+      if (stage == 1) {
+        epi_load(1);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        PSTAMP(3);
+      }
+#pragma unroll
+      for (int k = 0; k < SPW; ++k) {
+        const int j = 8 * stage + tg + TG * k;
+        if (j >= T) break;
+        const int n = (base + j) * 16 + i;
+        const bool nok = n < N;
+        const unsigned char* xrow = smem + j * TILEB + i * ROWB;
+        bf16x8 xf[KS];
+#pragma unroll
+        for (int s = 0; s < KS; ++s) xf[s] = *reinterpret_cast<const bf16x8*>(xrow + (((4 * s + q) ^ i) * 16));
+        f32x4 acc[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+          acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wr[0][s], xf[s], acc[0], 0, 0, 0);
+          acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wr[1][s], xf[s], acc[1], 0, 0, 0);
+        }
+        if constexpr (EPI == EPI_ATT) {
+          float ps = fmaf(acc[0][3], aS[0].w, fmaf(acc[0][2], aS[0].z, fmaf(acc[0][1], aS[0].y, acc[0][0] * aS[0].x)));
+          float pd = fmaf(acc[0][3], aD[0].w, fmaf(acc[0][2], aD[0].z, fmaf(acc[0][1], aD[0].y, acc[0][0] * aD[0].x)));
+          ps += fmaf(acc[1][3], aS[1].w, fmaf(acc[1][2], aS[1].z, fmaf(acc[1][1], aS[1].y, acc[1][0] * aS[1].x)));
+          pd += fmaf(acc[1][3], aD[1].w, fmaf(acc[1][2], aD[1].z, fmaf(acc[1][1], aD[1].y, acc[1][0] * aD[1].x)));
+          ps += __shfl_xor(ps, 16); ps += __shfl_xor(ps, 32);
+          pd += __shfl_xor(pd, 16); pd += __shfl_xor(pd, 32);
+          if (q == 0) part[(j * 8 + wave) * 16 + i] = make_float2(ps, pd);
+        }
+        float4 o0 = make_float4(acc[0][0], acc[0][1], acc[0][2], acc[0][3]);
+        float4 o1 = make_float4(acc[1][0], acc[1][1], acc[1][2], acc[1][3]);
+        if constexpr (EPI == EPI_RESID_MASK) {
+          auto widen = [](const uint4 u, float4& lo, float4& hi) {
+            lo = make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16),
+                             __uint_as_float(u.y & 0xffff0000u));
+            hi = make_float4(__uint_as_float(u.z << 16), __uint_as_float(u.z & 0xffff0000u), __uint_as_float(u.w << 16),
+                             __uint_as_float(u.w & 0xffff0000u));
+          };
+          if (resid) {
+            float4 ra, rb;
+            widen(rr[k], ra, rb);
+            o0.x += ra.x; o0.y += ra.y; o0.z += ra.z; o0.w += ra.w;
+            o1.x += rb.x; o1.y += rb.y; o1.z += rb.z; o1.w += rb.w;
+          }
+          if (relu_ref) {
+            float4 ra, rb;
+            widen(mr[k], ra, rb);
+            o0.x = ra.x > 0.f ? o0.x : 0.f; o0.y = ra.y > 0.f ? o0.y : 0.f;
+            o0.z = ra.z > 0.f ? o0.z : 0.f; o0.w = ra.w > 0.f ? o0.w : 0.f;
+            o1.x = rb.x > 0.f ? o1.x : 0.f; o1.y = rb.y > 0.f ? o1.y : 0.f;
+            o1.z = rb.z > 0.f ? o1.z : 0.f; o1.w = rb.w > 0.f ? o1.w : 0.f;
+          }
+        }
+        if (nok) {
+          bf16x8 ob;
+          ob[0] = (gatres_bf16)o0.x; ob[1] = (gatres_bf16)o0.y; ob[2] = (gatres_bf16)o0.z; ob[3] = (gatres_bf16)o0.w;
+          ob[4] = (gatres_bf16)o1.x; ob[5] = (gatres_bf16)o1.y; ob[6] = (gatres_bf16)o1.z; ob[7] = (gatres_bf16)o1.w;
+          *reinterpret_cast<bf16x8*>(OUT + (size_t)n * M + cb + 8 * q) = ob;
+        }
+      }
+    }
+    PSTAMP(4);
+    __syncthreads();                       // the partial dots are complete; the x tiles are dead (the next round overwrites them)
+    if constexpr (EPI == EPI_ATT) {
+      for (int idx = threadIdx.x; idx < T * 16 * H; idx += 512) {
+        const int hd = idx % H, r = (idx / H) % 16, j = idx / (16 * H);
+        const int n = (base + j) * 16 + r;
+        const float2* pp = part + (j * 8 + (j % TG) * G + hd * WPH) * 16 + r;
+        float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+        for (int w = 0; w < WPH; ++w) { s0 += pp[w * 16].x; s1 += pp[w * 16].y; }
+        if (n < N) { a_src[n * H + hd] = s0; a_dst[n * H + hd] = s1; }
+      }
+      if (base + TMAX < t_hi) __syncthreads();
+    }
+  }
+  PSTAMP(6);
+}
+
 template <int K, int M, int H, int EPI>
 int launch_proj_bf16(const gatres_bf16* X, const gatres_bf16* Wm, gatres_bf16* OUT, int N, const float* att_src,
                      const float* att_dst, float* a_src, float* a_dst, const gatres_bf16* resid,
                      const gatres_bf16* relu_ref, hipStream_t st) {
+  if constexpr (K % 128 == 0 && (M == 128 || M == 256) && (M / H) % 32 == 0) {
+    // gatres_large's widths: W slices in registers, x tiles streamed through LDS (proj_bf16_stream_kernel)
+    if (!gatres_knobs()->proj_rows && gatres_knobs()->proj_stream) {
+      constexpr int TILEB = 16 * K * 2, G = M / 32, TG = 8 / G;
+      const int ntiles = (N + 15) / 16;
+      int grid = (ntiles + TG - 1) / TG;
+      if (grid > 256) grid = 256;                 // one workgroup per CU, contiguous equal shares of the row tiles
+      constexpr size_t lds = (size_t)16 * TILEB + (EPI == EPI_ATT ? (size_t)16 * 8 * 16 * 8 : 0);
+      static bool attr_set = false;
+      if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&proj_bf16_stream_kernel<K, M, H, EPI>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+          (void)hipGetLastError();
+        attr_set = true;
+      }
+      hipLaunchKernelGGL((proj_bf16_stream_kernel<K, M, H, EPI>), dim3(grid), dim3(512), lds, st, X, Wm, OUT, N, att_src,
+                         att_dst, a_src, a_dst, resid, relu_ref);
+      return gatres_launch_status();
+    }
+  }
   if constexpr (K % 32 == 0 && M % 128 == 0 && M <= 256 && (EPI != EPI_ATT || (M / H) == 128 || (M / H) == 64 || (M / H) == 32)) {
     // wide outputs: 16-row wave tiles walked in passes of 128 columns, 512-thread workgroups, two per CU (proj_bf16_tile_kernel)
     if (!gatres_knobs()->proj_rows) {
@@ -1139,3 +1342,9 @@ extern "C" int gatres_proj_bwd_dw(const float* g_h, const float* x, float* slab_
                                   int64_t slab_stride, int32_t num_nodes, int32_t K, int32_t HC, void* stream) {
   return gatres_t_proj_bwd_dw(g_h, x, slab_W, num_slabs, slab_stride, num_nodes, K, HC, GATRES_DTYPE_F32, stream);
 }
+
+#ifdef PROJ_STAMPS
+extern "C" int gatres_probe_pstamps(unsigned long long* out) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_pstamps), sizeof(unsigned long long) * 512 * 8 * 8);
+}
+#endif

@@ -219,6 +219,11 @@ extern "C" int gatres_model_backward_per_op_part(const gatres_model_t* m, const 
   float* gas = scratch + L.sc_gas;
   float* gh = scratch + L.sc_gh;
   float* go1 = scratch + L.sc_go1;
+  // conv2's own g_h / g_a_src / g_a_dst tables: the parameter-gradient launches of a convolution read them on the side
+  // stream while the chain goes on into the next convolution (which writes the other set)
+  float* gh2 = scratch + L.sc_gh2;
+  float* gas2 = scratch + L.sc_gas2;
+  float* gad2 = scratch + L.sc_gad2;
   float* wt = scratch + L.sc_wt;
   float* slabs = scratch + L.sc_slabs;
 
@@ -241,6 +246,18 @@ extern "C" int gatres_model_backward_per_op_part(const gatres_model_t* m, const 
     RC(gatres_t_lin1_bwd(g_out, xfinal, params + L.p_lin1_w, gp_cur, slabs + L.p_lin1_w, slabs + L.p_lin1_b, S, st, N, nc,
                          L.nb > 0 ? 1 : 0, dt, stream));
   }
+  // Fork / join.  A convolution's partial sums (dW, attention vectors, bias) feed only the optimizer: they are launched on
+  // the library's side stream behind an event of the chain, and the chain waits for them only where it is about to
+  // overwrite what they read -- conv2's before the next block's K3 backward (g_y2, set 2), conv1's before the next block's
+  // dX2 (g_out1, set 1) -- and at the end of the piece.  Inside a stream capture the events become graph edges, and an
+  // edge between two queues costs microseconds: measured on gatres_large, C-Town, bs 128 (hipGraph replay): fp32 13.54 ->
+  // 13.16 ms / step, bf16 5.37 -> 5.85 (its launches are a third as long, and the side launches take the CUs the chain's
+  // next launch needs) -- so the fork is taken for fp32 at nc >= 128 only, unless GATRES_SIDE_STREAM says otherwise.
+  const int want_side = gatres_knobs()->side_stream;
+  gatres_side_t* side = (want_side == 1 || (want_side < 0 && dt == GATRES_DTYPE_F32 && nc >= 128)) ? gatres_side() : nullptr;
+  hipStream_t main_st = gatres_stream(stream);
+  bool pend_a = false, pend_b = false;
+#define HIPRC(call_) do { if ((call_) != hipSuccess) return (int)hipGetLastError(); } while (0)
   for (int b = b_hi - 1; b >= b_lo; --b) {
     const float* base = saved + (int64_t)b * L.s_stride;
     const int64_t po = L.p_block0 + (int64_t)b * L.p_block_stride;
@@ -251,26 +268,45 @@ extern "C" int gatres_model_backward_per_op_part(const gatres_model_t* m, const 
     const void* wt1 = dt == GATRES_DTYPE_BF16 ? (const void*)(wbb + w) : (const void*)(wt + (int64_t)b * 2 * w);
     const void* wt2 = dt == GATRES_DTYPE_BF16 ? (const void*)(wbb + w + w / 2) : (const void*)(wt + (int64_t)b * 2 * w + w);
     // K3 backward: gradient w.r.t. conv2's output
+    if (pend_a) { HIPRC(hipStreamWaitEvent(main_st, side->done_a, 0)); pend_a = false; }
     RC(gatres_t_mean_bwd(g, gp_cur, gy2, nc, dt, stream));
     // conv2 (H = 1, C = nc, K = 2nc); its output has no ReLU
-    RC(gatres_t_gat_aggregate_bwd_dst(g, gy2, base + L.s_h2, base + L.s_al2, base + L.s_as2, base + L.s_ad2, ge, gad, 1,
+    RC(gatres_t_gat_aggregate_bwd_dst(g, gy2, base + L.s_h2, base + L.s_al2, base + L.s_as2, base + L.s_ad2, ge, gad2, 1,
                                       nc, dt, stream));
-    RC(gatres_t_gat_aggregate_bwd_src(g, gy2, base + L.s_al2, ge, gad, pb + L.c2_as, pb + L.c2_ad, gh, gas, 1, nc, dt,
+    RC(gatres_t_gat_aggregate_bwd_src(g, gy2, base + L.s_al2, ge, gad2, pb + L.c2_as, pb + L.c2_ad, gh2, gas2, 1, nc, dt,
                                       stream));
-    RC(conv_partials(gh, base + L.s_o1, sb + L.c2_W, Sw, st, N, 2 * nc, nc, base + L.s_h2, gas, gad, gy2, sb + L.c2_as,
-                     sb + L.c2_ad, sb + L.c2_b, S, 1, nc, dt, stream));
-    RC(gatres_t_proj_bwd_dx(gh, wt2, nullptr, base + L.s_o1, go1, N, 2 * nc, nc, dt, stream));   // ReLU mask of conv1
+    void* pst = stream;
+    if (side) {
+      HIPRC(hipEventRecord(side->fork_a, main_st));
+      HIPRC(hipStreamWaitEvent(side->stream, side->fork_a, 0));
+      pst = side->stream;
+    }
+    RC(conv_partials(gh2, base + L.s_o1, sb + L.c2_W, Sw, st, N, 2 * nc, nc, base + L.s_h2, gas2, gad2, gy2, sb + L.c2_as,
+                     sb + L.c2_ad, sb + L.c2_b, S, 1, nc, dt, pst));
+    if (side) { HIPRC(hipEventRecord(side->done_a, side->stream)); pend_a = true; }
+    if (pend_b) { HIPRC(hipStreamWaitEvent(main_st, side->done_b, 0)); pend_b = false; }
+    RC(gatres_t_proj_bwd_dx(gh2, wt2, nullptr, base + L.s_o1, go1, N, 2 * nc, nc, dt, stream));   // ReLU mask of conv1
     // conv1 (H = 2, C = nc, K = nc)
     RC(gatres_t_gat_aggregate_bwd_dst(g, go1, base + L.s_h1, base + L.s_al1, base + L.s_as1, base + L.s_ad1, ge, gad, 2,
                                       nc, dt, stream));
     RC(gatres_t_gat_aggregate_bwd_src(g, go1, base + L.s_al1, ge, gad, pb + L.c1_as, pb + L.c1_ad, gh, gas, 2, nc, dt,
                                       stream));
+    pst = stream;
+    if (side) {
+      HIPRC(hipEventRecord(side->fork_b, main_st));
+      HIPRC(hipStreamWaitEvent(side->stream, side->fork_b, 0));
+      pst = side->stream;
+    }
     RC(conv_partials(gh, base + L.s_xin, sb + L.c1_W, Sw, st, N, nc, 2 * nc, base + L.s_h1, gas, gad, go1, sb + L.c1_as,
-                     sb + L.c1_ad, sb + L.c1_b, S, 2, nc, dt, stream));
+                     sb + L.c1_ad, sb + L.c1_b, S, 2, nc, dt, pst));
+    if (side) { HIPRC(hipEventRecord(side->done_b, side->stream)); pend_b = true; }
     // d/d xin = conv1 path + residual; masked by the previous block's ReLU (block 0's input is lin0, no ReLU)
     RC(gatres_t_proj_bwd_dx(gh, wt1, gp_cur, b > 0 ? base + L.s_xin : nullptr, gp_nxt, N, nc, 2 * nc, dt, stream));
     float* t = gp_cur; gp_cur = gp_nxt; gp_nxt = t;
   }
+  if (pend_a) HIPRC(hipStreamWaitEvent(main_st, side->done_a, 0));        // join: the piece's slabs are complete
+  if (pend_b) HIPRC(hipStreamWaitEvent(main_st, side->done_b, 0));
+#undef HIPRC
   if (last) {
     RC(gatres_t_lin0_bwd(gp_cur, x, mask, slabs + L.p_lin0_w, slabs + L.p_lin0_b, S, st, N, nc, dt, stream));
     if (g_x) {
