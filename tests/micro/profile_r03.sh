@@ -32,5 +32,9 @@ timeout 900 $B --no-cpu-baseline --model gatres_large --nodes 50000 --pipes 7500
 timeout 900 $B --no-cpu-baseline --model gatres_large --nodes 50000 --pipes 75000 --batch-size 2 --steps 10 --warmup 3 --dtype bf16 2>/dev/null | tail -1 > $O/large_50k_bs2_bf16.json; python3 -c "$short" < $O/large_50k_bs2_bf16.json
 timeout 900 $B --no-cpu-baseline --nodes 50000 --pipes 75000 --batch-size 16 --steps 10 --warmup 3 2>/dev/null | tail -1 > $O/small_50k_bs16.json; python3 -c "$short" < $O/small_50k_bs16.json
 ./tests/micro/lds_dma_probe > $O/lds_dma_probe.txt 2>&1; cat $O/lds_dma_probe.txt
+{ echo "== bf16 projections of gatres_large alone (C-ABI, hipGraph of 12 launches over 12 buffer sets): proj_bf16_tile_kernel (default)"; timeout 120 python3 tests/micro/proj_probe.py 2>/dev/null | tail -4
+  echo "== GATRES_PROJ_STREAM=1: proj_bf16_stream_kernel"; GATRES_PROJ_STREAM=1 timeout 120 python3 tests/micro/proj_probe.py 2>/dev/null | tail -4
+  echo "== GATRES_PROJ_STREAM=1, per-wave stamps inside the kernel (lib/probe_st.so, tests/micro/build_probes.sh); us since the first wave started"; GATRES_PROJ_STREAM=1 timeout 120 python3 tests/micro/proj_probe.py --lib gnn-pressure-estimation_amd/lib/probe_st.so --stamps 2>/dev/null | tail -32; } > $O/proj_probe.txt 2>&1; cat $O/proj_probe.txt
+{ for v in 0 1; do for dt in fp32 bf16; do echo "gatres_large C-Town bs 128 $dt GATRES_SIDE_STREAM=$v"; GATRES_SIDE_STREAM=$v timeout 600 $B --no-cpu-baseline --model gatres_large --batch-size 128 --steps 20 --warmup 5 --dtype $dt 2>/dev/null | tail -1 | python3 -c "$short"; done; done; } > $O/side_stream.txt 2>&1; cat $O/side_stream.txt
 rm -rf $O/kt $O/pmc_fetch $O/pmc_write $O/pmc_sq $O/pmc_inst $O/kt_l16
 ls -la $O

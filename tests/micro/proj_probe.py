@@ -65,7 +65,7 @@ def main():
          N * (256 + 128 + 128 + 128) * 2),
     ]
     if args.stamps:
-        # a library built with -DPROJ_STAMPS (see /tmp probe builds in DESIGN): per-wave wall-clock stamps of the last launch
+        # a library built with -DPROJ_STAMPS (tests/micro/build_probes.sh): per-wave wall-clock stamps of the last launch
         import numpy as np
         for name, f, nbytes in cases:
             for k in range(S):
@@ -75,11 +75,12 @@ def main():
             lib_raw = ctypes.CDLL(os.environ["GATRES_LIB"])
             assert lib_raw.gatres_probe_pstamps(buf) == 0
             t = np.frombuffer(buf, dtype=np.uint64).reshape(512, 8, 8).astype(np.int64)
+            t = t[t[:, 0, 0] > 0]                      # workgroups of the last launch's grid (stamps are zeroed below)
             t0 = t[:, :, 0].min()
             us = lambda v: (v - t0) / 100.0
             print(name)
-            labels = ["start", "issued", "landed", "barrier", "computed", "stores drained", "end"]
-            for k in range(7):
+            labels = ["start", "stage 0 landed", "barrier", "stage 1 barrier", "computed", "-", "end"]
+            for k in (0, 1, 2, 3, 4, 6):
                 v = us(t[:, :, k])
                 print(f"   {labels[k]:16s} min {v.min():6.2f}  mean {v.mean():6.2f}  max {v.max():6.2f} us")
         return
