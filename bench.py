@@ -206,7 +206,7 @@ def pmc_traffic(args):
     MI355X_MICROARCH.md prescribes for wide coalesced reads on gfx950).  Only for the workload they were taken on."""
     if args.model != "gatres_small" or args.batch_size != 32 or args.nodes != 388 or args.per_op or args.shuffle_nodes:
         return None, None
-    for name in ("r02_fused_pmc_raw.json", "r01_fused_pmc_raw.json"):
+    for name in ("r03_fused_pmc_raw.json", "r02_fused_pmc_raw.json", "r01_fused_pmc_raw.json"):
         try:
             with open(os.path.join(ROOT, "profiles", name)) as f:
                 raw = json.load(f)
