@@ -52,6 +52,7 @@ extern "C" __attribute__((visibility("hidden"))) const gatres_knobs_t* gatres_kn
 struct gatres_side_t {
   hipStream_t stream;
   hipEvent_t fork_a, fork_b, done_a, done_b;
+  void* mu;              // std::mutex*: one caller at a time enqueues a fork / join sequence on these events
 };
 extern "C" __attribute__((visibility("hidden"))) gatres_side_t* gatres_side();
 

@@ -86,6 +86,7 @@ extern "C" __attribute__((visibility("hidden"))) gatres_side_t* gatres_side() {
     hipEvent_t* ev[4] = {&s.fork_a, &s.fork_b, &s.done_a, &s.done_b};
     for (int k = 0; k < 4 && ok; ++k) ok = hipEventCreateWithFlags(ev[k], hipEventDisableTiming) == hipSuccess;
     if (!ok) (void)hipGetLastError();
+    s.mu = new std::mutex();
     state[dev] = ok ? 1 : -1;
   }
   return state[dev] == 1 ? &sides[dev] : nullptr;

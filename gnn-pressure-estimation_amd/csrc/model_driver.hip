@@ -5,6 +5,7 @@
 // Block b (GResBlockMeanConv.forward, GraphModels.py:462-468):
 //   xin -> K1(conv1) h1,a1 -> K2(conv1)+bias+ReLU out1 -> K1(conv2) h2,a2 -> K2(conv2)+bias y2
 //       -> K3 mean(y2)+xin, ReLU -> xin of block b+1
+#include <mutex>
 #include "gatres_common.h"
 #include "gatres_layout.h"
 
@@ -256,6 +257,8 @@ extern "C" int gatres_model_backward_per_op_part(const gatres_model_t* m, const 
   const int want_side = gatres_knobs()->side_stream;
   gatres_side_t* side = (want_side == 1 || (want_side < 0 && dt == GATRES_DTYPE_F32 && nc >= 128)) ? gatres_side() : nullptr;
   hipStream_t main_st = gatres_stream(stream);
+  std::unique_lock<std::mutex> side_lock;          // (two host threads enqueueing backward pieces must not interleave on the events)
+  if (side) side_lock = std::unique_lock<std::mutex>(*static_cast<std::mutex*>(side->mu));
   bool pend_a = false, pend_b = false;
 #define HIPRC(call_) do { if ((call_) != hipSuccess) return (int)hipGetLastError(); } while (0)
   for (int b = b_hi - 1; b >= b_lo; --b) {
