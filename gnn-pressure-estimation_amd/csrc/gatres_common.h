@@ -28,6 +28,7 @@ struct gatres_knobs_t {
   int fused_no_halo;          // GATRES_FUSED_NO_HALO: whole-segment kernel, bulk pulls instead of halo lists
   int fused_no_keep;          // GATRES_FUSED_NO_KEEP
   int fused_heartbeat;        // GATRES_FUSED_HEARTBEAT: pace the hand-offs by heartbeat granules even on symmetric plans
+  int fused_no_rounds;        // GATRES_FUSED_NO_ROUNDS: 33 .. 96 segments at the parts that fit the chip at once instead of 8 parts round by round
   int param_grads_no_stream;  // GATRES_PARAM_GRADS_NO_STREAM
   int lin_bwd_wave;           // GATRES_LIN_BWD_WAVE
   int proj_rows;              // GATRES_PROJ_ROWS (0: default)

@@ -54,9 +54,19 @@ static inline int num_slabs_for(int64_t P, int64_t N) {
 // Most workgroups (CUs) one segment may be split over: at most 8, and such that every workgroup of the grid (segments
 // rounded up to a multiple of 8, times the split) is resident at once on the 256 CUs of an MI355X -- the parts of a
 // segment wait for each other, so none may be left undispatched.
+// Batches of 49 .. 96 segments are carried in TWO ROUNDS of at most 48 segments (k_fused_host.hip: launch_fused), at the
+// parts per segment that fit the chip for one round: 8 (49 .. 64 segments), 6 (65 .. 80), 5 (81 .. 96).  0: no rounds.
+static inline int rounds_parts_for(int num_segments) {
+  const int padded = ((num_segments + 7) / 8) * 8;
+  if (padded <= 48 || padded > 96) return 0;
+  const int per = ((padded / 2 + 7) / 8) * 8;
+  const int m = 256 / per;
+  return m > 8 ? 8 : m;
+}
 static inline int split_max_for(int num_segments) {
   const int padded = ((num_segments + 7) / 8) * 8;
   if (padded <= 0 || padded > 256) return 1;
+  if (const int rp = rounds_parts_for(num_segments)) return rp;
   const int m = 256 / padded;
   return m > 8 ? 8 : (m < 1 ? 1 : m);
 }

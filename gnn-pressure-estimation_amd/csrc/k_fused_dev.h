@@ -59,6 +59,8 @@ struct FusedArgs {
   unsigned* flags;          // split segments: 8 flag lines per segment
   int* err;
   int num_segments;
+  int seg0, seg_cnt;        // the segments THIS launch carries: [seg0, seg0 + seg_cnt) -- batches beyond 32 snapshots at 8
+                            // parts go round by round (k_fused_host.hip: launch_fused), everything else is one launch
   int M;                    // workgroups (CUs) per segment
   int safe_sync;            // diagnostic (GATRES_FUSED_SAFE_SYNC=1): always use agent-scope barriers
   int keep_lds;             // window kernel, forward + backward in one launch: ReLU sign masks and own-row g_pre stay in LDS
@@ -1759,8 +1761,8 @@ template <int NC, int THREADS>
 __device__ __forceinline__ void consumer_main(const FusedArgs& a, int cid, float* ldsf) {
   const int C = a.C;
   const int within = cid % (8 * C);
-  const int seg = (cid / (8 * C)) * 8 + (within & 7), c = within >> 3;
-  if (seg >= a.num_segments) return;
+  const int seg = a.seg0 + (cid / (8 * C)) * 8 + (within & 7), c = within >> 3;
+  if (seg >= a.seg0 + a.seg_cnt) return;
   ParamGradArgs pg;
   pg.seg_ptr = a.seg_ptr; pg.saved = a.saved; pg.keep = a.scratch + a.L.sc_keep; pg.slabs = a.slabs;
   pg.part_slabs = a.part_slabs; pg.M = a.M; pg.L = a.L; pg.SL = a.SL;

@@ -201,6 +201,18 @@ static bool window_kernel_fits(const Layout& L, const gatres_graph_t* g, int M, 
 static int fused_split(const Layout& L, const gatres_graph_t* g) {
   const int tiles = (g->max_segment_nodes + 15) / 16;
   const int padded = ((g->num_segments + 7) / 8) * 8;
+  // Rounds: 49 .. 96 segments fit the chip only at 4 .. 2 parts each -- whole-segment tables, where a snapshot costs MORE
+  // than in a batch of 32 (bs 64: 0.99 ms = 64.7 k snapshots/s against 75.5 k at bs 32).  The window kernel is launched twice
+  // instead, each round with half the segments at the parts that fit then (hand-offs only ever cross the parts of ONE
+  // segment; the parameter-gradient launch and the update follow the last round): C-Town, bs 56 / 64 / 72 / 80 / 88 / 96,
+  // ms per step, resident vs rounds: profiles/r03_rounds.txt.  Three rounds of 32 measured slower than the resident choice
+  // (bs 72 .. 96: 1.24 .. 1.29 vs 1.14 .. 1.27).  GATRES_FUSED_NO_ROUNDS=1: the resident choice.
+  if (const int rp = rounds_parts_for(g->num_segments)) {
+    const int per = ((padded / 2 + 7) / 8) * 8;
+    if (L.split_max == rp && tiles >= rp && L.nb > 0 && per * rp <= device_cus() && !gatres_knobs()->fused_split &&
+        !gatres_knobs()->fused_no_rounds && !gatres_knobs()->fused_prefer_consumers && window_kernel_fits(L, g, rp))
+      return rp;
+  }
   int B = L.split_max;
   while (B > 1 && (B > tiles || L.nb == 0 || padded * B > device_cus())) --B;   // (a partitioned / smaller device)
   if (const int v = gatres_knobs()->fused_split) {
@@ -230,12 +242,28 @@ static bool use_window_kernel(const FusedArgs& a, const gatres_graph_t* g) {
   return a.saved && window_kernel_fits(a.L, g, a.M);        // (it writes the saved tables: training launches only)
 }
 
-static int launch_fused(int nc, int threads, const FusedArgs& a, const gatres_graph_t* g, hipStream_t st) {
-  const unsigned grid = (unsigned)(((g->num_segments + 7) / 8) * 8 * (a.M + a.C));
-  if (threads == 1024 && nc <= 32 && use_window_kernel(a, g)) return gatres_fused_launch_window(&a, nc, grid, st);
+static int launch_fused(int nc, int threads, const FusedArgs& a0, const gatres_graph_t* g, hipStream_t st) {
+  const bool window = threads == 1024 && nc <= 32 && use_window_kernel(a0, g);
   const bool cache = !gatres_knobs()->fused_nocache &&
                      cache_fits(nc, threads, g->max_segment_nodes, g->max_segment_edges_gat, g->max_segment_edges_mean);
-  return gatres_fused_launch_whole(&a, nc, threads, cache ? 1 : 0, grid, st);
+  // every workgroup of a split launch must be resident at once: more segments than that go round by round
+  int per_round = g->num_segments;
+  if (a0.M > 1 && ((g->num_segments + 7) / 8) * 8 * (a0.M + a0.C) > device_cus()) {
+    const int padded = ((g->num_segments + 7) / 8) * 8, fit = (device_cus() / a0.M) & ~7;
+    const int rounds = fit > 0 ? (padded + fit - 1) / fit : 0;
+    per_round = rounds > 0 ? (((padded + rounds - 1) / rounds + 7) / 8) * 8 : 0;        // (equal rounds: 72 segments = 40 + 32)
+  }
+  if (per_round <= 0) return GATRES_E_UNSUPPORTED;
+  FusedArgs a = a0;
+  for (int s0 = 0; s0 < g->num_segments; s0 += per_round) {
+    a.seg0 = s0;
+    a.seg_cnt = g->num_segments - s0 < per_round ? g->num_segments - s0 : per_round;
+    const unsigned grid = (unsigned)(((a.seg_cnt + 7) / 8) * 8 * (a.M + a.C));
+    const int rc = window ? gatres_fused_launch_window(&a, nc, grid, st)
+                          : gatres_fused_launch_whole(&a, nc, threads, cache ? 1 : 0, grid, st);
+    if (rc != 0) return rc;
+  }
+  return 0;
 }
 }  // namespace
 
@@ -316,6 +344,7 @@ extern "C" int gatres_fused_run(const gatres_model_t* m, const gatres_graph_t* g
   a.x = x; a.mask = mask; a.y = y; a.out = out; a.g_out = g_out; a.loss_part = loss_part; a.g_x = g_x;
   a.saved = saved; a.scratch = scratch; a.slabs = scratch + a.L.sc_slabs;
   a.num_segments = g->num_segments;
+  a.seg0 = 0; a.seg_cnt = g->num_segments;
   a.M = fused_split(a.L, g);
   a.safe_sync = gatres_knobs()->fused_safe_sync;
   // bits 1 / 2 (diagnostic build only, WRONG results): never-wait exchanges; dX epilogues without their global reads

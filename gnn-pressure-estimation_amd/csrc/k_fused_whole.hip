@@ -13,15 +13,15 @@ __global__ __launch_bounds__(THREADS) void gatres_fused_kernel(const FusedArgs a
   // workgroup id -> (segment, part): ids of one segment are 8 apart (same XCD)
   const int M = a.M;
   {
-    const int F = ((a.num_segments + 7) / 8) * 8 * M;       // per-snapshot workgroups come first, consumers after
+    const int F = ((a.seg_cnt + 7) / 8) * 8 * M;       // per-snapshot workgroups come first, consumers after
     if ((int)blockIdx.x >= F) {
       if constexpr (THREADS == 1024) consumer_main<NC, THREADS>(a, (int)blockIdx.x - F, ldsf);
       return;
     }
   }
   const int within = blockIdx.x % (8 * M);
-  const int seg = (blockIdx.x / (8 * M)) * 8 + (within & 7), part = within >> 3;
-  if (seg >= a.num_segments) return;
+  const int seg = a.seg0 + (blockIdx.x / (8 * M)) * 8 + (within & 7), part = within >> 3;
+  if (seg >= a.seg0 + a.seg_cnt) return;
   const bool split = M > 1;
   const int n0 = a.seg_ptr[seg], n = a.seg_ptr[seg + 1] - n0;
   const int e0 = a.rowptr[n0], eg = a.rowptr[n0 + n] - e0;            // GATConv edges of this segment

@@ -33,6 +33,7 @@ void read_knobs(gatres_knobs_t* k) {
   k->fused_no_halo = env_flag("GATRES_FUSED_NO_HALO");
   k->fused_no_keep = env_flag("GATRES_FUSED_NO_KEEP");
   k->fused_heartbeat = env_flag("GATRES_FUSED_HEARTBEAT");
+  k->fused_no_rounds = env_flag("GATRES_FUSED_NO_ROUNDS");
   k->param_grads_no_stream = env_flag("GATRES_PARAM_GRADS_NO_STREAM");
   k->lin_bwd_wave = env_flag("GATRES_LIN_BWD_WAVE");
   k->proj_rows = (env_int("GATRES_PROJ_ROWS", 0) + 63) & ~63;

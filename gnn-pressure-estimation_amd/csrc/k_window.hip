@@ -27,15 +27,15 @@ __global__ __launch_bounds__(THREADS) void gatres_window_kernel(const FusedArgs 
   const Layout& L = a.L;
   const int M = a.M;
   {
-    const int F = ((a.num_segments + 7) / 8) * 8 * M;
+    const int F = ((a.seg_cnt + 7) / 8) * 8 * M;
     if ((int)blockIdx.x >= F) {
       consumer_main<NC, THREADS>(a, (int)blockIdx.x - F, ldsf);
       return;
     }
   }
   const int within = blockIdx.x % (8 * M);
-  const int seg = (blockIdx.x / (8 * M)) * 8 + (within & 7), part = within >> 3;
-  if (seg >= a.num_segments) return;
+  const int seg = a.seg0 + (blockIdx.x / (8 * M)) * 8 + (within & 7), part = within >> 3;
+  if (seg >= a.seg0 + a.seg_cnt) return;
   const int tid = threadIdx.x;
   // Part tables of the plan (gatres_graph_t.part_tables, built once per topology by gatres_graph_part_tables_host): the
   // part's scalars come from the record's header -- ONE load per wave -- and its LDS tables are copied from the record

@@ -101,6 +101,44 @@ def test_50k_node_graph(pkg, oracle, nb, nc):
     assert torch.isfinite(ga).all() and torch.equal(ga, _flat_grads(model))
 
 
+@pytest.mark.parametrize("bs,parts", [(56, 8), (72, 6), (96, 5)])
+def test_batches_of_49_to_96_snapshots_run_in_two_rounds(pkg, oracle, lib, bs, parts, monkeypatch):
+    """49 .. 96 C-Town snapshots: the window kernel carries the batch in TWO launches (rounds) of at most 48 segments at the
+    parts per snapshot that fit the chip for one round (k_fused_host.hip: fused_split / launch_fused).  Against the resident
+    single launch (GATRES_FUSED_NO_ROUNDS=1: whole-segment tables at 4 .. 2 parts) and the per-op kernels: predictions
+    bit-identical, loss and gradient to rounding; against the oracle: a training step."""
+    nb, nc = 3, 32
+    t1 = pkg.wdn_synth.make_wdn_topology(388, 430, seed=0)
+    ei = pkg.wdn_synth.collate_edge_index(t1, 388, bs).cuda()
+    N = 388 * bs
+    snaps = pkg.wdn_synth.make_snapshots(bs, 388, seed=5)
+    y = pkg.wdn_synth.collate_snapshots(snaps, range(bs))
+    mask = torch.from_numpy(pkg.wdn_synth.generate_batch_mask([388] * bs, 0.95, np.random.RandomState(3)))
+    res = {}
+    for mode in ("rounds", "resident", "per_op"):
+        if mode == "resident":
+            monkeypatch.setenv("GATRES_FUSED_NO_ROUNDS", "1")
+        model, p = build(pkg, oracle, nb, nc, seed=9, fused=(mode != "per_op"))
+        tr = pkg.GATResTrainer(model, ei, N, nodes_per_graph=[388] * bs, use_graph=False, fused=(mode != "per_op"))
+        cus = lib.gatres_fused_cus_per_segment(model._cmodel_ref(), tr.plan.ref()) if mode != "per_op" else 0
+        if mode == "rounds":
+            assert cus == parts and lib.gatres_fused_window_kernel(model._cmodel_ref(), tr.plan.ref()) == 1
+        if mode == "resident":
+            assert cus * ((bs + 7) // 8 * 8) <= 256
+        tr.forward_backward(y.cuda(), y.cuda(), mask.cuda())
+        res[mode] = (tr.out.clone(), tr.loss.clone(), tr.grads.clone())
+        if mode == "rounds":
+            ref = oracle.OracleTrainer(p)
+            l_ref, o_ref = ref.step(y.clone(), y, ei.cpu(), mask)
+            loss = tr.step(y.cuda(), y.cuda(), mask.cuda())
+            assert relerr(tr.out, o_ref) < 1e-5 and relerr(loss, l_ref) < 1e-5
+            assert relerr(model.flat_parameters.detach(), ref.flat("params")) < 1e-5
+        monkeypatch.delenv("GATRES_FUSED_NO_ROUNDS", raising=False)
+    for other in ("resident", "per_op"):
+        assert torch.equal(res["rounds"][0], res[other][0]), other
+        assert relerr(res["rounds"][1], res[other][1]) < 1e-6 and relerr(res["rounds"][2], res[other][2]) < 1e-5, other
+
+
 def test_config5_real_size_25x128_on_two_50k_node_graphs(pkg, oracle, lib):
     """BASELINE config 5 as ONE RANK holds it: gatres_large (25 x 128) on a batch of 2 x 50 000-node / 75 000-pipe graphs,
     per-op kernels, fp32.  The saved activations are 7.9 GB: byte offsets pass 2^32 inside the second graph's half of
