@@ -101,7 +101,7 @@ class GATResTrainer:
             dp.broadcast_params_(params, src=0, group=process_group)      # identical replicas, whatever each rank initialised
         self.reducer = dp.BucketedAllReduce(self.grads, process_group, force=force_collective_path) if self.split else None
         self.blocks_per_bucket = int(blocks_per_bucket)
-        self.use_graph = use_graph
+        self.use_graph = use_graph and not (self.world > 1 and os.environ.get("GATRES_DP_EAGER") == "1")
         self._graphs: "OrderedDict[tuple, torch.cuda.CUDAGraph]" = OrderedDict()
         self._params_ptr = params.data_ptr()
         self._wt_sig = None
@@ -213,8 +213,24 @@ class GATResTrainer:
             torch.cuda.synchronize(self.device)
             rollback()
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
+            try:
+                with torch.cuda.graph(g):
+                    enqueue()
+            except Exception as e:                     # noqa: BLE001
+                # A multi-rank step holds RCCL collectives; if this runtime cannot capture them (every rank fails the
+                # same way: the sequence is identical), run the launch sequence eagerly from here on instead of dying.
+                # Single-rank captures hold only this library's kernels: a failure there is a bug and is raised.
+                if self.world <= 1:
+                    raise
+                import warnings
+                warnings.warn(f"hipGraph capture of the data-parallel step failed ({type(e).__name__}: {e}); "
+                              f"continuing with eager launches")
+                torch.cuda.synchronize(self.device)
+                rollback()
+                self.use_graph = False
+                self._graphs.clear()
                 enqueue()
+                return
             rollback()
             if wt_valid:
                 # the warm-up step left the transposes of ITS updated weights in scratch; the parameters were rolled
