@@ -101,7 +101,12 @@ class GATResTrainer:
             dp.broadcast_params_(params, src=0, group=process_group)      # identical replicas, whatever each rank initialised
         self.reducer = dp.BucketedAllReduce(self.grads, process_group, force=force_collective_path) if self.split else None
         self.blocks_per_bucket = int(blocks_per_bucket)
-        self.use_graph = use_graph and not (self.world > 1 and os.environ.get("GATRES_DP_EAGER") == "1")
+        # Multi-rank steps run as EAGER launch sequences unless GATRES_DP_GRAPH=1: a captured step would hold the RCCL
+        # all-reduce, which has only ever been captured with a one-rank group here (no multi-GPU box is reachable), and
+        # eager costs nothing on this path (one-rank nccl group, gatres_small bs 32: 0.428 ms/step eager vs 0.432 captured;
+        # the step is a handful of native launch sequences, far from host-bound).  One-rank groups (force_collective_path)
+        # keep the capture, so the in-graph form stays tested.
+        self.use_graph = use_graph and (self.world <= 1 or os.environ.get("GATRES_DP_GRAPH") == "1")
         self._graphs: "OrderedDict[tuple, torch.cuda.CUDAGraph]" = OrderedDict()
         self._params_ptr = params.data_ptr()
         self._wt_sig = None
