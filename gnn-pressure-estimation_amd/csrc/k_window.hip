@@ -16,6 +16,14 @@ __device__ __forceinline__ void vec_prefetch(float* dst, const float* __restrict
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   if (wave == THREADS / 64 - 1 && lane * 4 < n) __builtin_amdgcn_global_load_lds(src + lane * 4, dst, 16, 0, 0);
 }
+// A uniform value the compiler must take as new at this point: address arithmetic that depends on it cannot be hoisted above
+// a wave-role branch (the MFMA stages split their waves into tile waves and LDS-DMA waves; hoisted, BOTH roles ran the other's
+// scalar address chains and the v_readlane reloads of the spilled uniforms they need: 45 - 150 per stage of 130 - 300 VALU
+// instructions, profiles/r03_kernel_resource_usage.txt).
+__device__ __forceinline__ int launder_s(int v) {
+  asm volatile("" : "+s"(v));
+  return v;
+}
 __device__ __forceinline__ u16* align16(u16* p) {
   return reinterpret_cast<u16*>((reinterpret_cast<uintptr_t>(p) + 15) & ~(uintptr_t)15);
 }
@@ -37,6 +45,7 @@ __global__ __launch_bounds__(THREADS) void gatres_window_kernel(const FusedArgs 
   const int seg = a.seg0 + (blockIdx.x / (8 * M)) * 8 + (within & 7), part = within >> 3;
   if (seg >= a.seg0 + a.seg_cnt) return;
   const int tid = threadIdx.x;
+  const int wave_u = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   // Part tables of the plan (gatres_graph_t.part_tables, built once per topology by gatres_graph_part_tables_host): the
   // part's scalars come from the record's header -- ONE load per wave -- and its LDS tables are copied from the record
   // by LDS-DMA in the two phase prologues.  Without them (a plan that carries none, or tables for another split) both are
@@ -248,12 +257,18 @@ __global__ __launch_bounds__(THREADS) void gatres_window_kernel(const FusedArgs 
       const float* pb = P + L.p_block0 + (int64_t)b * L.p_block_stride;
       // LDS-DMA rides on the MFMA stages, issued by their tile-less waves: W2 | att | bias of this block while proj1 runs,
       // W1 | att | bias of the next block while proj2 runs
-      w_prefetch<2 * NC, NC, EPI_ATT, THREADS>(wlB, pb + L.c2_W, pb + L.c2_as, pb + L.c2_ad, dw0);
-      vec_prefetch<THREADS>(wlB + B2OFF, pb + L.c2_b, NC);
-      if constexpr (NC == 32)
-        win_proj<NC, 2 * NC, 2, EPI_ATT, 2, PW, THREADS>(rw, xA, wlA, base + SL.h1, 0, hA, base + SL.as1, base + SL.ad1, sa2, sd2,
-                                                     nullptr, nullptr, nullptr, nullptr, xout(xreg, fflag, XL.f1h, XL.f1a));
-      else
+      if (NC != 32 || wave_u >= dw0) {           // (NC == 32: the LDS-DMA waves; their address chains stay in here)
+        const float* pbl = P + L.p_block0 + (int64_t)launder_s(b) * L.p_block_stride;
+        w_prefetch<2 * NC, NC, EPI_ATT, THREADS>(wlB, pbl + L.c2_W, pbl + L.c2_as, pbl + L.c2_ad, dw0);
+        vec_prefetch<THREADS>(wlB + B2OFF, pbl + L.c2_b, NC);
+      }
+      if constexpr (NC == 32) {
+        if (wave_u < PW) {                         // the tile waves
+          float* bl = segbase + (int64_t)launder_s(b) * SL.bstride;
+          win_proj<NC, 2 * NC, 2, EPI_ATT, 2, PW, THREADS>(rw, xA, wlA, bl + SL.h1, 0, hA, bl + SL.as1, bl + SL.ad1, sa2, sd2,
+                                                       nullptr, nullptr, nullptr, nullptr, xout(xreg, fflag, XL.f1h, XL.f1a));
+        }
+      } else
         seg_proj<NC, 2 * NC, 2, EPI_ATT, THREADS, true, true>(rw, xA, 0, pb + L.c1_W, base + SL.h1, 0, hA, 0, pb + L.c1_as,
                                                                pb + L.c1_ad, base + SL.as1, base + SL.ad1, 0, sa2, sd2,
                                                                nullptr, 0, nullptr, 0, wlA);
@@ -285,15 +300,18 @@ __global__ __launch_bounds__(THREADS) void gatres_window_kernel(const FusedArgs 
       }
       lds_barrier();
       STAMP();
-      if (b + 1 < L.nb) {
-        const float* pn = pb + L.p_block_stride;
+      if (b + 1 < L.nb && (NC != 32 || wave_u >= dw0)) {
+        const float* pn = P + L.p_block0 + (int64_t)(launder_s(b) + 1) * L.p_block_stride;
         w_prefetch<NC, 2 * NC, EPI_ATT, THREADS>(wlA, pn + L.c1_W, pn + L.c1_as, pn + L.c1_ad, dw0);
         vec_prefetch<THREADS>(wlA + B1OFF, pn + L.c1_b, 2 * NC);
       }
-      if constexpr (NC == 32)
-        win_proj<2 * NC, NC, 1, EPI_ATT, 2, PW, THREADS>(rw, xB, wlB, base + SL.h2, 0, hB, base + SL.as2, base + SL.ad2, sa1, sd1,
-                                                     nullptr, nullptr, nullptr, nullptr, xout(xreg, fflag, XL.f2h, XL.f2a));
-      else
+      if constexpr (NC == 32) {
+        if (wave_u < PW) {
+          float* bl = segbase + (int64_t)launder_s(b) * SL.bstride;
+          win_proj<2 * NC, NC, 1, EPI_ATT, 2, PW, THREADS>(rw, xB, wlB, bl + SL.h2, 0, hB, bl + SL.as2, bl + SL.ad2, sa1, sd1,
+                                                       nullptr, nullptr, nullptr, nullptr, xout(xreg, fflag, XL.f2h, XL.f2a));
+        }
+      } else
         seg_proj<2 * NC, NC, 1, EPI_ATT, THREADS, true, true>(rw, xB, 0, pb + L.c2_W, base + SL.h2, 0, hB, 0, pb + L.c2_as,
                                                              pb + L.c2_ad, base + SL.as2, base + SL.ad2, 0, sa1, sd1,
                                                              nullptr, 0, nullptr, 0, wlB);
@@ -475,6 +493,8 @@ __global__ __launch_bounds__(THREADS) void gatres_window_kernel(const FusedArgs 
     // per hand-off; in the source-major stage: that stage grows by what dX shrinks), and dedicated loader waves behind
     // bare barriers (the issue itself is what takes the time: the CU accepts ~12 B per cycle).
     auto dma_conv2_early = [&](int blk, int w0) {
+      if (wave_u < w0) return;                   // (the tile waves of the stage: none of the address chains below)
+      blk = launder_s(blk);
       const float* bs = segbase + (int64_t)blk * SL.bstride;
       dma_copy16<THREADS>(hTw, bs + SL.h2 + (size_t)wlo * NC, wr * NC, w0);
       dma_copy4<THREADS>(asTw, bs + SL.as2 + wlo, wr, w0);
@@ -483,6 +503,8 @@ __global__ __launch_bounds__(THREADS) void gatres_window_kernel(const FusedArgs 
       vec_prefetch<THREADS>(wlA + A2OFF, P + L.p_block0 + (int64_t)blk * L.p_block_stride + L.c2_as, 2 * NC);
     };
     auto dma_conv2_late = [&](int blk, int w0) {
+      if (wave_u < w0) return;
+      blk = launder_s(blk);
       const float* bs = segbase + (int64_t)blk * SL.bstride;
       dma_copy4<THREADS>(alTw, bs + SL.al2 + ewlo, weg, w0);
     };
@@ -566,11 +588,15 @@ __global__ __launch_bounds__(THREADS) void gatres_window_kernel(const FusedArgs 
       STAMP();
       // this block's conv1 tables and W1^T stream in while the matrix cores run dX2 (below)
       auto dma_conv1_early = [&]() {
-        w_prefetch<2 * NC, NC, EPI_RESID_MASK, THREADS>(wlB, wt1, nullptr, nullptr, dw0);
-        vec_prefetch<THREADS>(wlB + A1OFF, pb + L.c1_as, 4 * NC);
-        dma_copy16<THREADS>(hTw, base + SL.h1 + (size_t)wlo * 2 * NC, wr * 2 * NC, dw0);
-        dma_copy4<THREADS>(asTw, base + SL.as1 + wlo * 2, wr * 2, dw0);
-        dma_copy4<THREADS>(adTo, base + SL.ad1 + lo * 2, ow * 2, dw0);
+        if (wave_u < dw0) return;
+        const int bl = launder_s(b);
+        const float* bsl = segbase + (int64_t)bl * SL.bstride;
+        w_prefetch<2 * NC, NC, EPI_RESID_MASK, THREADS>(wlB, a.wt + (int64_t)bl * 2 * w, nullptr, nullptr, dw0);
+        vec_prefetch<THREADS>(wlB + A1OFF, P + L.p_block0 + (int64_t)bl * L.p_block_stride + L.c1_as, 4 * NC);
+        dma_copy16<THREADS>(hTw, bsl + SL.h1 + (size_t)wlo * 2 * NC, wr * 2 * NC, dw0);
+        dma_copy4<THREADS>(asTw, bsl + SL.as1 + wlo * 2, wr * 2, dw0);
+        dma_copy4<THREADS>(adTo, bsl + SL.ad1 + lo * 2, ow * 2, dw0);
+        dma_copy4<THREADS>(alTw, bsl + SL.al1 + ewlo * 2, weg * 2, dw0);      // conv1's alpha (its table held conv2's until here)
       };
       seg_bias_finish<NC, THREADS>(red, sb + L.c2_b);
       win_agg_bwd_src<1, NC, THREADS>(rw, tout, trp, teido, tdsto, 0, gy2T, alT2, ge2, gad2, wlA + A2OFF, wlA + A2OFF + NC,
@@ -579,12 +605,12 @@ __global__ __launch_bounds__(THREADS) void gatres_window_kernel(const FusedArgs 
       XSTAMP();
       STAMP();
       dma_conv1_early();
-      dma_copy4<THREADS>(alTw, base + SL.al1 + ewlo * 2, weg * 2, dw0);      // conv1's alpha (its table held conv2's until here)
       if (NC == 32 && a.keep_lds) {              // (the ReLU sign masks of the forward phase are in LDS: no global operand)
         if constexpr (NC == 32)
-          win_proj<NC, 2 * NC, 1, EPI_RESID_MASK, 1, PW, THREADS>(rw, xG2, wlA, RA, 0, nullptr, nullptr, nullptr, nullptr, nullptr,
-                                                              nullptr, nullptr, mo1 + b * ow, nullptr,
-                                                              xout(xrows, (unsigned)XL.b3o, 0u));
+          if (wave_u < PW)
+            win_proj<NC, 2 * NC, 1, EPI_RESID_MASK, 1, PW, THREADS>(rw, xG2, wlA, RA, 0, nullptr, nullptr, nullptr, nullptr,
+                                                                nullptr, nullptr, nullptr, mo1 + launder_s(b) * ow, nullptr,
+                                                                xout(xrows, (unsigned)XL.b3o, 0u));
       } else {
         seg_proj<NC, 2 * NC, 1, EPI_RESID_MASK, THREADS, true, true>(
             rw, xG2, 0, wt2, RA, 0, nullptr, 0, nullptr, nullptr, nullptr, nullptr, 0, nullptr, nullptr, nullptr, 0,
@@ -623,9 +649,12 @@ __global__ __launch_bounds__(THREADS) void gatres_window_kernel(const FusedArgs 
       if (b > 0) { dma_conv2_early(b - 1, dw0); dma_conv2_late(b - 1, dw0); }
       if (NC == 32 && a.keep_lds) {
         if constexpr (NC == 32)
-          win_proj<2 * NC, NC, 1, EPI_RESID_MASK, 1, PW, THREADS>(rw, xG1, wlB, gp_nxt, n0, gpT, nullptr, nullptr, nullptr, nullptr,
-                                                              gkeep, gkeep, nullptr, b > 0 ? mxin + b * ow : nullptr,
-                                                              xout(xrows && b > 0, (unsigned)XL.b1, 0u));
+          if (wave_u < PW) {
+            const int bl = launder_s(b);
+            win_proj<2 * NC, NC, 1, EPI_RESID_MASK, 1, PW, THREADS>(rw, xG1, wlB, gp_nxt, n0, gpT, nullptr, nullptr, nullptr,
+                                                                nullptr, gkeep, gkeep, nullptr, bl > 0 ? mxin + bl * ow : nullptr,
+                                                                xout(xrows && bl > 0, (unsigned)XL.b1, 0u));
+          }
       } else {
         seg_proj<2 * NC, NC, 1, EPI_RESID_MASK, THREADS, true, true>(
             rw, xG1, 0, wt1, gp_nxt, n0, gpT, 0, nullptr, nullptr, nullptr, nullptr, 0, nullptr, nullptr,
