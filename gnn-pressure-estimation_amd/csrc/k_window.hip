@@ -151,6 +151,16 @@ __global__ __launch_bounds__(THREADS) void gatres_window_kernel(const FusedArgs 
   const SegLayout& SL = a.SL;
   float* segbase = a.saved + (int64_t)seg * SL.total;                 // training only: saved is never null here
 
+  // Training launches (forward + loss + backward in one): the loss is formed where lin1 produces the predictions and handed
+  // to lin1's backward through LDS -- the separate loss pass read out / y / mask back from global memory, and lin1 backward
+  // then g_out and the saved final activation: two dependent L2 round trips at the turn of the launch.  Same arithmetic, same
+  // summation order (thread t sums row lo + t, as the stand-alone pass): the same bits.
+  constexpr int LB_R = THREADS / NC;               // row stride of lin1 backward's threads (two rows each at most)
+  const bool fuse_loss = (a.phases & PH_LOSS) && (a.phases & GATRES_PHASE_FORWARD) && (a.phases & GATRES_PHASE_BACKWARD) &&
+                         ow <= 2 * LB_R && ow <= 64 && ow <= THREADS / (NC / 4);
+  float* dml = ldsf + 64;                          // [own row]: masked out - y, then g_out (inside the backward's `red` region)
+  float xk[2] = {0.f, 0.f};                        // final activation of rows lo + rg, lo + rg + LB_R, column c (lin1 backward)
+
   if (a.phases & GATRES_PHASE_FORWARD) {
     // LDS: [hA wr x 2NC | hB wr x NC | sa wr x 2 | sd own x 2 | xA own x NC | xB own x 2NC | W slot A | W slot B] topology
     float* hAw = ldsf;
@@ -360,22 +370,67 @@ __global__ __launch_bounds__(THREADS) void gatres_window_kernel(const FusedArgs 
       const float4 wv = ld4(P + L.p_lin1_w + (tid % G) * 4);
       const float bias = P[L.p_lin1_b];
       const int rounds = (rw.hi - rw.lo + THREADS / G - 1) / (THREADS / G);
+      float cnt = 0.f;
+      if (fuse_loss) {                           // the batch's masked-node count: its loads fly during lin1
+        if ((reinterpret_cast<uintptr_t>(a.mask) & 15) == 0) {
+          const int nv = a.N >> 4;
+          for (int i = tid; i < nv; i += THREADS) {
+            const uint4 v = reinterpret_cast<const uint4*>(a.mask)[i];
+            auto nz = [](unsigned w) { return __popc((((w & 0x7f7f7f7fu) + 0x7f7f7f7fu) | w) & 0x80808080u); };
+            cnt += (float)(nz(v.x) + nz(v.y) + nz(v.z) + nz(v.w));
+          }
+          for (int i = (nv << 4) + tid; i < a.N; i += THREADS) cnt += a.mask[i] ? 1.f : 0.f;
+        } else {
+          for (int i = tid; i < a.N; i += THREADS) cnt += a.mask[i] ? 1.f : 0.f;
+        }
+      }
       for (int it = 0; it < rounds; ++it) {
         int r = rw.lo + it * (THREADS / G) + tid / G;
         const bool valid = r < rw.hi;
         if (!valid) r = rw.hi - 1;
+        const int node = ext_id(a.perm, n0 + r);
+        float yv = 0.f;
+        bool mk = false;
+        if (fuse_loss && valid && (tid % G) == 0) { yv = a.y[node]; mk = a.mask[node] != 0; }
         const float4 xv = ld4(xA + (unsigned)(r * NC + (tid % G) * 4));
         float d = xv.x * wv.x;
         d = fmaf(xv.y, wv.y, d); d = fmaf(xv.z, wv.z, d); d = fmaf(xv.w, wv.w, d);
         for (int off = G >> 1; off > 0; off >>= 1) d += __shfl_xor(d, off);
-        if (valid && (tid % G) == 0) a.out[ext_id(a.perm, n0 + r)] = d + bias;
+        if (valid && (tid % G) == 0) {
+          const float o = d + bias;
+          a.out[node] = o;
+          if (fuse_loss) dml[r - rw.lo] = mk ? o - yv : 0.f;
+        }
+      }
+      if (fuse_loss) {
+        {                                        // lin1 backward's x operand, before the forward's LDS image dies
+          const int c = tid % NC, rg = tid / NC;
+#pragma unroll
+          for (int k = 0; k < 2; ++k) {
+            const int r = rw.lo + rg + k * LB_R;
+            if (r < rw.hi) xk[k] = xA[(unsigned)(r * NC + c)];
+          }
+        }
+        const float Mn = block_sum<THREADS>(cnt, ldsf);            // (its barriers also publish dml)
+        const float dv = tid < ow ? dml[tid] : 0.f;
+        float part_sum = block_sum<THREADS>(tid < ow ? fmaf(dv, dv, 0.f) : 0.f, ldsf);
+        if (tid == 0) {
+          a.loss_part[seg * M + part] = part_sum;
+          if (seg == 0 && part == 0) a.loss_part[a.num_segments * M] = Mn;
+        }
+        const float scale = Mn > 0.f ? 2.f / Mn : 0.f;
+        if (tid < ow) {
+          const float g = dv * scale;
+          a.g_out[ext_id(a.perm, n0 + rw.lo + tid)] = g;
+          dml[tid] = g;
+        }
       }
     }
     __syncthreads();
     STAMP();
   }
 
-  if (a.phases & PH_LOSS) {
+  if ((a.phases & PH_LOSS) && !fuse_loss) {
     float cnt = 0.f;
     for (int i = tid; i < a.N; i += THREADS) cnt += a.mask[i] ? 1.f : 0.f;
     const float Mn = block_sum<THREADS>(cnt, ldsf);
@@ -509,8 +564,36 @@ __global__ __launch_bounds__(THREADS) void gatres_window_kernel(const FusedArgs 
       dma_copy4<THREADS>(alTw, bs + SL.al2 + ewlo, weg, w0);
     };
     if (L.nb > 0) { dma_conv2_early(L.nb - 1, 0); dma_conv2_late(L.nb - 1, 0); }
-    seg_lin1_bwd<NC, THREADS>(rw, n0, a.perm, a.g_out, xfinal, P + L.p_lin1_w, gp_cur, gpT, slab + L.p_lin1_w,
-                              slab + L.p_lin1_b, L.nb > 0 ? 1 : 0, red, gkeep);
+    if (fuse_loss) {                             // seg_lin1_bwd with g_out from LDS (dml) and x from registers (xk)
+      const int c = tid % NC, rg = tid / NC;
+      const float wv = P[L.p_lin1_w + c];
+      float aw = 0.f, ab = 0.f;
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        const int r = rw.lo + rg + k * LB_R;
+        if (r < rw.hi) {
+          const float go = dml[r - rw.lo], xv = xk[k];
+          aw = fmaf(go, xv, aw);
+          ab += go;
+          const float gv = (L.nb > 0 && !(xv > 0.f)) ? 0.f : go * wv;
+          gp_cur[((size_t)n0 + r) * NC + c] = gv;
+          gpT[(size_t)r * NC + c] = gv;
+          if (gkeep) gkeep[(size_t)r * NC + c] = gv;
+        }
+      }
+      __syncthreads();
+      red[tid] = aw; red[THREADS + tid] = ab;
+      __syncthreads();
+      if (rg == 0) {
+        float s0 = 0.f, s1 = 0.f;
+        for (int k = 0; k < LB_R; ++k) { s0 += red[k * NC + c]; s1 += red[THREADS + k * NC + c]; }
+        slab[L.p_lin1_w + c] = s0;
+        if (c == 0) slab[L.p_lin1_b] = s1;
+      }
+    } else {
+      seg_lin1_bwd<NC, THREADS>(rw, n0, a.perm, a.g_out, xfinal, P + L.p_lin1_w, gp_cur, gpT, slab + L.p_lin1_w,
+                                slab + L.p_lin1_b, L.nb > 0 ? 1 : 0, red, gkeep);
+    }
     dma_land(0);
     if (pt) {
       __syncthreads();         // the record's tables and the first block's conv2 tables have landed
