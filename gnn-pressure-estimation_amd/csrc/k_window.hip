@@ -428,6 +428,7 @@ __global__ __launch_bounds__(THREADS) void gatres_window_kernel(const FusedArgs 
     }
     __syncthreads();
     STAMP();
+    if (fuse_loss) STAMP();    // (diagnostic stamp sequence lin0 | lin1 | loss | lin1_bwd | blocks: the loss is inside lin1 here)
   }
 
   if ((a.phases & PH_LOSS) && !fuse_loss) {
