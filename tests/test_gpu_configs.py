@@ -139,6 +139,30 @@ def test_batches_of_49_to_96_snapshots_run_in_two_rounds(pkg, oracle, lib, bs, p
         assert relerr(res["rounds"][1], res[other][1]) < 1e-6 and relerr(res["rounds"][2], res[other][2]) < 1e-5, other
 
 
+@pytest.mark.parametrize("bs", [56, 72, 96])
+def test_module_paths_with_two_round_batches(pkg, bs):
+    """The drop-in nn.Module on batches that go in two rounds: forward-only launches (eval: the whole-segment-table kernel, also
+    round by round) and autograd's separate forward / backward launches against the per-op kernels -- predictions bit for bit,
+    gradients to rounding."""
+    t1 = pkg.wdn_synth.make_wdn_topology(388, 430, seed=0)
+    ei = pkg.wdn_synth.collate_edge_index(t1, 388, bs).cuda()
+    x = torch.randn(388 * bs, 1, generator=torch.Generator().manual_seed(2)).cuda()
+    res = {}
+    for fused in (True, False):
+        torch.manual_seed(1)
+        m = pkg.GATResMeanConv(name="gatres_small", num_blocks=3, nc=32, fused=fused).cuda()
+        m.eval()
+        with torch.no_grad():
+            oe = m(x, ei, None, None).clone()
+        m.train()
+        o = m(x, ei, None, None)
+        o.square().mean().backward()
+        res[fused] = (oe, o.detach().clone(), _flat_grads(m))
+    a, b = res[True], res[False]
+    assert torch.equal(a[0], b[0]) and torch.equal(a[0], a[1]) and torch.equal(a[1], b[1])
+    assert relerr(a[2], b[2]) < 1e-5
+
+
 def test_config5_real_size_25x128_on_two_50k_node_graphs(pkg, oracle, lib):
     """BASELINE config 5 as ONE RANK holds it: gatres_large (25 x 128) on a batch of 2 x 50 000-node / 75 000-pipe graphs,
     per-op kernels, fp32.  The saved activations are 7.9 GB: byte offsets pass 2^32 inside the second graph's half of
