@@ -1147,7 +1147,8 @@ __device__ __forceinline__ void seg_lin1_bwd(Rows rw, int n0, const int* __restr
 template <int NC, int THREADS>
 __device__ __forceinline__ void seg_lin0_bwd(Rows rw, int n0, const int* __restrict__ perm, const float* __restrict__ g, const float* __restrict__ x,
                                              const uint8_t* __restrict__ mask, float* __restrict__ slab_w,
-                                             float* __restrict__ slab_b, float* red) {
+                                             float* __restrict__ slab_b, float* red, const float* g_local = nullptr) {
+  // g_local: the same gradient rows in LDS, indexed by LOCAL row (window kernel: the last dX stage left them there)
   constexpr int R = THREADS / NC;
   const int c = threadIdx.x % NC, rg = threadIdx.x / NC;
   float aw = 0.f, ab = 0.f;
@@ -1155,7 +1156,7 @@ __device__ __forceinline__ void seg_lin0_bwd(Rows rw, int n0, const int* __restr
     const size_t node = (size_t)n0 + r;
     const int en = ext_id(perm, n0 + r);
     const float xv = (mask && mask[en]) ? 0.f : x[en];
-    const float gv = g[node * NC + c];
+    const float gv = g_local ? g_local[(size_t)r * NC + c] : g[node * NC + c];
     aw = fmaf(gv, xv, aw);
     ab += gv;
   }

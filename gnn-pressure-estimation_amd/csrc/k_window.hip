@@ -751,9 +751,14 @@ __global__ __launch_bounds__(THREADS) void gatres_window_kernel(const FusedArgs 
       STAMP();
       float* t = gp_cur; gp_cur = gp_nxt; gp_nxt = t;
     }
-    group_sync<THREADS>(grp);
+    // The parts only meet here for the consumers' sake (the last items are published behind this barrier); without consumer
+    // workgroups nothing of a partner is needed any more: a workgroup barrier that also drains this part's own stores (g_x below
+    // reads gp_cur back) replaces the flag barrier.  a.C is the same for every part: the barrier count per launch stays equal.
+    if (a.C > 0) group_sync<THREADS>(grp);
+    else         __syncthreads();
     publish_items<THREADS>(a, seg, part, 2 * L.nb, grp.local || !pub, !pub);
-    seg_lin0_bwd<NC, THREADS>(rw, n0, a.perm, gp_cur, a.x, a.mask, slab + L.p_lin0_w, slab + L.p_lin0_b, red);
+    // lin0's partial sums: g_pre of the own rows from LDS (the last dX1 left it in gpT as well as in gp_cur)
+    seg_lin0_bwd<NC, THREADS>(rw, n0, a.perm, gp_cur, a.x, a.mask, slab + L.p_lin0_w, slab + L.p_lin0_b, red, gpT);
     if (pub && a.C > 0) {
       group_sync<THREADS>(grp);
       publish_items<THREADS>(a, seg, part, 2 * L.nb + 1, grp.local, true);
