@@ -702,7 +702,7 @@ __global__ __launch_bounds__(THREADS) void gatres_window_kernel(const FusedArgs 
             nullptr);
       }
       dma_land(dw0);                             // the conv1 tables: the destination-major stage is next
-      __syncthreads();
+      lds_barrier();                             // (not __syncthreads(): its vmcnt(0) made the tile waves wait for their granule stores)
       XSTAMP();
       STAMP();
       seg_bias_part<2 * NC, THREADS>(rw, RA, 0, red);
