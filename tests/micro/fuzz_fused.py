@@ -1,7 +1,8 @@
 """Diagnostic fuzzer (not collected by pytest): random batches of random graphs -- directed / undirected edges, degrees
 beyond the slot paths' 6, isolated nodes, self loops, ragged sizes, local and shuffled node orders -- through the fused
 kernels (whichever of window / whole-segment / split the plan selects) against the per-op kernels.
-    python tests/micro/fuzz_fused.py [cases] [seed]         (GATRES_FUSED_SPLIT etc. apply)"""
+    python tests/micro/fuzz_fused.py [cases] [seed] [max segments + 1 = 9] [min segments = 1]     (GATRES_FUSED_SPLIT etc. apply;
+    49 .. 96 segments exercise the two-round launches)"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
@@ -10,6 +11,8 @@ import gnn_pressure_estimation_amd as G
 
 cases = int(sys.argv[1]) if len(sys.argv) > 1 else 30
 rng = np.random.RandomState(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+seg_hi = int(sys.argv[3]) if len(sys.argv) > 3 else 9
+seg_lo = int(sys.argv[4]) if len(sys.argv) > 4 else 1
 
 
 def random_graph(n):
@@ -44,7 +47,7 @@ def relerr(a, b):
 bad = 0
 for case in range(cases):
     nb, nc = int(rng.choice([1, 2, 3])), int(rng.choice([8, 16, 32, 32, 32]))
-    sizes = [int(rng.choice([17, 33, 60, 120, 200, 388, 388, 450])) for _ in range(rng.randint(1, 9))]
+    sizes = [int(rng.choice([17, 33, 60, 120, 200, 388, 388, 450])) for _ in range(rng.randint(seg_lo, seg_hi))]
     tops = [random_graph(n) for n in sizes]
     offs = np.cumsum([0] + sizes)
     ei = torch.cat([t + int(o) for t, o in zip(tops, offs[:-1])], dim=1)
@@ -75,7 +78,7 @@ for case in range(cases):
     plan = mf._plans.get(dei, N)
     lib = G._native.load()
     cus = lib.gatres_fused_cus_per_segment(mf._cmodel_ref(), plan.ref())
-    print(f"case {case:3d} nb {nb} nc {nc:2d} sizes {sizes} segments {plan.num_segments} CUs/segment {cus} windows {plan.windows[3:6]}"
+    print(f"case {case:3d} nb {nb} nc {nc:2d} sizes {sizes if len(sizes) < 10 else str(sizes[:6])[:-1] + ', ...]'} segments {plan.num_segments} CUs/segment {cus} windows {plan.windows[3:6]}"
           f" -> {'ok' if ok else 'FAIL'}{' (hub rows: last-bit forward differences allowed)' if hubs else ''}")
     bad += 0 if ok else 1
 print("failures:", bad, "of", cases)
