@@ -31,7 +31,9 @@ python3 tests/micro/summarize_prof.py stats $O/kt_l16 $O/large_bf16_kernel_stats
 timeout 900 $B --no-cpu-baseline --model gatres_large --nodes 50000 --pipes 75000 --batch-size 2 --steps 10 --warmup 3 2>/dev/null | tail -1 > $O/large_50k_bs2.json; python3 -c "$short" < $O/large_50k_bs2.json
 timeout 900 $B --no-cpu-baseline --model gatres_large --nodes 50000 --pipes 75000 --batch-size 2 --steps 10 --warmup 3 --dtype bf16 2>/dev/null | tail -1 > $O/large_50k_bs2_bf16.json; python3 -c "$short" < $O/large_50k_bs2_bf16.json
 timeout 900 $B --no-cpu-baseline --nodes 50000 --pipes 75000 --batch-size 16 --steps 10 --warmup 3 2>/dev/null | tail -1 > $O/small_50k_bs16.json; python3 -c "$short" < $O/small_50k_bs16.json
+[ -x tests/micro/lds_dma_probe ] || /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 tests/micro/lds_dma_probe.hip -o tests/micro/lds_dma_probe
 ./tests/micro/lds_dma_probe > $O/lds_dma_probe.txt 2>&1; cat $O/lds_dma_probe.txt
+[ -f gnn-pressure-estimation_amd/lib/probe_st.so ] || bash tests/micro/build_probes.sh
 { echo "== bf16 projections of gatres_large alone (C-ABI, hipGraph of 12 launches over 12 buffer sets): proj_bf16_tile_kernel (default)"; timeout 120 python3 tests/micro/proj_probe.py 2>/dev/null | tail -4
   echo "== GATRES_PROJ_STREAM=1: proj_bf16_stream_kernel"; GATRES_PROJ_STREAM=1 timeout 120 python3 tests/micro/proj_probe.py 2>/dev/null | tail -4
   echo "== GATRES_PROJ_STREAM=1, per-wave stamps inside the kernel (lib/probe_st.so, tests/micro/build_probes.sh); us since the first wave started"; GATRES_PROJ_STREAM=1 timeout 120 python3 tests/micro/proj_probe.py --lib gnn-pressure-estimation_amd/lib/probe_st.so --stamps 2>/dev/null | tail -32; } > $O/proj_probe.txt 2>&1; cat $O/proj_probe.txt
