@@ -13,6 +13,7 @@ timeout 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32
 timeout 300 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SMEM SQ_LDS_BANK_CONFLICT SQ_INSTS_VALU_MFMA_MOPS_F32 --output-format csv -d $O/pmc_inst -o i -- $B --steps 20 --warmup 5 --no-cpu-baseline --no-roofline > $O/pmc_inst.log 2>&1
 python3 tests/micro/summarize_prof.py pmc $O/fused_pmc.json gatres_window_kernel $O/pmc_fetch $O/pmc_write $O/pmc_sq $O/pmc_inst; head -50 $O/fused_pmc.json
 python3 tests/micro/summarize_prof.py pmc $O/pgs_pmc.json param_grads_stream_kernel $O/pmc_fetch $O/pmc_write $O/pmc_sq $O/pmc_inst
+[ -f gnn-pressure-estimation_amd/lib/libgatres_hip_diag.so ] || python3 gnn-pressure-estimation_amd/_build.py --diag > /dev/null 2>&1
 GATRES_DIAG_LIB=1 timeout 200 python3 tests/stage_profile.py > $O/stage_times.txt 2>&1; head -22 $O/stage_times.txt
 { for m in 4 6 8; do echo "GATRES_FUSED_SPLIT=$m"; GATRES_FUSED_SPLIT=$m timeout 300 $B --no-cpu-baseline 2>/dev/null | tail -1 | python3 -c "$short"; done
   echo "GATRES_NO_PART_TABLES=1 (prologue tables derived in every launch)"; GATRES_NO_PART_TABLES=1 timeout 300 $B --no-cpu-baseline 2>/dev/null | tail -1 | python3 -c "$short"
