@@ -45,6 +45,20 @@ def _stale(target: str, deps) -> bool:
 DIAG_LIB_PATH = os.path.join(LIB_DIR, "libgatres_hip_diag.so")
 
 
+def source_id() -> str:
+    """Hash of everything the library is compiled from (csrc/*.hip, csrc/*.h, include/gatres.h): the build id that
+    ``gatres_version()`` reports and ``_native.load()`` checks, so a stale or foreign .so is never loaded silently."""
+    import hashlib
+    h = hashlib.sha256()
+    files = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".h")))
+    files.append(os.path.join(REPO_DIR, "include", "gatres.h"))
+    for p in files:
+        h.update(os.path.basename(p).encode())
+        with open(p, "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
 def build_native(force: bool = False, verbose: bool = False, diag: bool = False) -> str:
     """Compile (only what changed) and link; returns the path of the shared library.
 
@@ -62,12 +76,21 @@ def build_native(force: bool = False, verbose: bool = False, diag: bool = False)
     hipcc = _hipcc()
     jobs = []
     objs = []
+    bid = source_id()
+    stamp = os.path.join(obj_dir, "BUILD_ID")
+    try:
+        with open(stamp) as f:
+            same_id = f.read().strip() == bid
+    except OSError:
+        same_id = False
     for s in srcs:
         src = os.path.join(CSRC, s)
         obj = os.path.join(obj_dir, s.replace(".hip", ".o"))
         objs.append(obj)
-        if force or _stale(obj, [src] + headers):
-            jobs.append([hipcc] + _flags() + (["-DGATRES_DIAG_BUILD"] if diag else []) + ["-c", src, "-o", obj])
+        # model_driver.hip carries the build id (gatres_version): recompiled whenever any source changed
+        if force or _stale(obj, [src] + headers) or (s == "model_driver.hip" and not same_id):
+            jobs.append([hipcc] + _flags() + (["-DGATRES_DIAG_BUILD"] if diag else []) +
+                        ([f'-DGATRES_BUILD_ID="{bid}"'] if s == "model_driver.hip" else []) + ["-c", src, "-o", obj])
 
     def run(cmd):
         if verbose:
@@ -83,6 +106,8 @@ def build_native(force: bool = False, verbose: bool = False, diag: bool = False)
             list(ex.map(run, jobs))
     if jobs or force or _stale(lib_path, objs):
         run([hipcc, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", lib_path] + objs)
+    with open(stamp, "w") as f:
+        f.write(bid + "\n")
     return lib_path
 
 

@@ -116,41 +116,87 @@ SIGNATURES = {
     "gatres_fused_run": (C.c_int, [_MP, _GP] + [_P] * 10 + [_I32, _P]),
     "gatres_fused_param_grads": (C.c_int, [_MP, _GP, _P, _P, _P]),
     "gatres_fused_finish": (C.c_int, [_MP, _GP] + [_P] * 4 + [_I32] + [_P] * 4 + [_F64] * 5 + [_F32, _P]),
+    "gatres_fused_finish_hp": (C.c_int, [_MP, _GP] + [_P] * 4 + [_I32] + [_P] * 4 + [_F64] * 5 + [_P, _F32, _P]),
+    "gatres_fused_finish_folds": (C.c_int, [_MP, _GP]),
+    "gatres_fused_param_grads_finish": (C.c_int, [_MP, _GP] + [_P] * 5 + [_I32] + [_P] * 4 + [_F64] * 5 +
+                                        [_P, _F32, _I32, _I32, _P]),
     "gatres_train_step": (C.c_int, [_P, _P]),
     "gatres_version": (C.c_char_p, []),
 }
 
 
+ABI_VERSION = 4                # GATRES_ABI_VERSION of include/gatres.h
+
+
 def diag_build() -> bool:
-    """GATRES_DIAG_LIB=1 selects the diagnostic build of the library (stage stamps, wrong-result switches); GATRES_LIB=<path>
-    any other build (A/B measurements of kernel variants)."""
+    """GATRES_DIAG_LIB=1 selects the diagnostic build of the library (stage stamps, wrong-result switches)."""
     return os.environ.get("GATRES_DIAG_LIB", "") not in ("", "0")
 
 
 def lib_path() -> str:
-    override = os.environ.get("GATRES_LIB")
-    if override:
-        return override
     return _build.DIAG_LIB_PATH if diag_build() else _build.LIB_PATH
 
 
+def _version_of(lib: C.CDLL):
+    """(abi, build id) from gatres_version(): "gatres-gfx950 abi<N> build <id>"."""
+    fn = lib.gatres_version
+    fn.restype, fn.argtypes = C.c_char_p, []
+    words = fn().decode().split()
+    abi = next((int(w[3:]) for w in words if w.startswith("abi") and w[3:].isdigit()), -1)
+    bid = words[words.index("build") + 1] if "build" in words and words.index("build") + 1 < len(words) else ""
+    return abi, bid
+
+
 def load(build_if_missing: bool = True) -> C.CDLL:
-    """dlopen the library (building it first when absent) and attach the C signatures."""
+    """dlopen the in-tree library and attach the C signatures.  The library must have been built from the sources that lie
+    beside it: a missing library, or one whose ABI / build id (``gatres_version()``) differs from ``_build.source_id()``, is
+    (re)built with hipcc first -- or refused when ``build_if_missing`` is False.  Nothing else is ever loaded: there is no
+    path override and no CPU fallback."""
     global _LIB
     if _LIB is not None:
         return _LIB
     path = lib_path()
-    if not os.path.exists(path):
+    want = _build.source_id()
+
+    def stale() -> str:
+        if not os.path.exists(path):
+            return f"{path} is missing"
+        abi, bid = _version_of(C.CDLL(path))
+        if abi != ABI_VERSION or bid != want:
+            return f"{path} is abi{abi} build {bid or '?'}, the sources are abi{ABI_VERSION} build {want}"
+        return ""
+
+    why = stale()
+    if why:
         if not build_if_missing:
-            raise RuntimeError(f"{path} is missing; run `python __graft_entry__.py` (build()) first")
+            raise RuntimeError(f"{why}; run `python __graft_entry__.py` (build()) first")
         _build.build_native(diag=diag_build())
-    lib = C.CDLL(path)
+        # (a process that already mapped the stale file keeps it under the same name: dlopen a fresh copy of the new build)
+        lib = C.CDLL(path) if "missing" in why else _reopen(path)
+        abi, bid = _version_of(lib)
+        if abi != ABI_VERSION or bid != want:
+            raise RuntimeError(f"rebuilt {path} still reports abi{abi} build {bid}; expected abi{ABI_VERSION} build {want}")
+    else:
+        lib = C.CDLL(path)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)     # AttributeError here == the library does not export the header's symbol
         fn.restype = res
         fn.argtypes = args
     _LIB = lib
     return lib
+
+
+def _reopen(path: str) -> C.CDLL:
+    """dlopen caches by path: after a rebuild in the same process, load the new file through a private copy."""
+    import shutil
+    import tempfile
+    fd, tmp = tempfile.mkstemp(suffix=".so", prefix="libgatres_", dir=os.path.dirname(path))
+    os.close(fd)
+    shutil.copyfile(path, tmp)
+    try:
+        return C.CDLL(tmp)
+    finally:
+        os.unlink(tmp)
 
 
 def check(rc: int, what: str) -> None:

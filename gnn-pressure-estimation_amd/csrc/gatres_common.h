@@ -56,6 +56,7 @@ struct gatres_side_t {
   void* mu;              // std::mutex*: one caller at a time enqueues a fork / join sequence on these events
 };
 extern "C" __attribute__((visibility("hidden"))) gatres_side_t* gatres_side();
+extern "C" __attribute__((visibility("hidden"))) gatres_side_t* gatres_side_peek();      // never creates one
 
 static inline int gatres_launch_status() { return (int)hipGetLastError(); }
 static inline hipStream_t gatres_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }

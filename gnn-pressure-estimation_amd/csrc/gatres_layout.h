@@ -30,7 +30,7 @@ struct Layout {
   // fused path, segments split over several CUs: flag lines (8 x 32 words per segment, + one error word at the
   // end) and one partial slab row per (segment, part)
   int split_max;
-  int64_t sc_flags, flag_words, ready_words, sc_part_slabs;
+  int64_t sc_flags, flag_words, ready_words, col_words, sc_part_slabs;    // (col_words: arrival counters of param_grads_finish_kernel)
   int num_slabs;      // node-range slabs of the per-op path
   int slab_rows;      // slabs allocated = max(num_slabs, segments)
   int64_t slab_stride;
@@ -165,8 +165,9 @@ static inline bool make_layout(const gatres_model_t* m, int64_t N, int64_t Eg, i
   L->sc_flags = o;
   L->flag_words = r4((int64_t)((num_segments + 7) / 8) * 8 * 8 * 32 + 32);
   L->ready_words = r4((int64_t)num_segments * 4 * 32);            // consumer hand-off lines, behind the flags
-  L->sc_part_slabs = o + L->flag_words + L->ready_words;
-  if (fused_nodes > 0) o += L->flag_words + L->ready_words;
+  L->col_words = r4(2LL * nb + 8);                                 // one counter per (block, conv) column, behind the ready lines
+  L->sc_part_slabs = o + L->flag_words + L->ready_words + L->col_words;
+  if (fused_nodes > 0) o += L->flag_words + L->ready_words + L->col_words;
   if (L->split_max > 1) o += (int64_t)num_segments * L->split_max * L->slab_stride;
   L->sc_xch = o;
   L->xch_stride = 0;

@@ -1189,13 +1189,21 @@ struct ParamGradArgs {
   unsigned long long* dstamps = nullptr;      // diagnostic (consumer 0 under gatres_fused_set_stamps): steps inside an item
 };
 
+// A slab entry.  AG: the entry is read by ANOTHER workgroup of the same launch (the column's last arriver of
+// param_grads_finish_kernel, k_fused_host.hip): an agent-scope store (sc1: written through, visible from every XCD).
+template <bool AG>
+__device__ __forceinline__ void slab_st(float* p, float v) {
+  if constexpr (AG) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  else *p = v;
+}
+
 // slab[off .. off+cnt) of a segment = sum over its parts' partial rows (fixed order)
-template <int THREADS>
+template <int THREADS, bool AG = false>
 __device__ __forceinline__ void fold_parts(const ParamGradArgs& a, int seg, int64_t off, int cnt) {
   for (int idx = threadIdx.x; idx < cnt; idx += THREADS) {
     float sum = 0.f;
     for (int p = 0; p < a.M; ++p) sum += a.part_slabs[((int64_t)seg * a.M + p) * a.L.slab_stride + off + idx];
-    a.slabs[(int64_t)seg * a.L.slab_stride + off + idx] = sum;
+    slab_st<AG>(a.slabs + (int64_t)seg * a.L.slab_stride + off + idx, sum);
   }
 }
 
@@ -1275,7 +1283,7 @@ struct CiGeom {
 
 // (NBUF chunk buffers: four in the consumers of the window kernel, which own a CU's whole LDS; three in the stand-alone
 //  launch, whose 512-thread workgroups then fit a CU in pairs -- one streams while the other folds its partial blocks)
-template <int NC, int THREADS, int CONV, int NBUF = CI_NBUF>
+template <int NC, int THREADS, int CONV, int NBUF = CI_NBUF, bool AG = false>
 __device__ __forceinline__ void consumer_item_dma(const ParamGradArgs& a, int seg, int b, float* lds) {
   using Gm = CiGeom<NC, CONV>;
   constexpr int DEPTH = NBUF - 1;
@@ -1409,7 +1417,7 @@ __device__ __forceinline__ void consumer_item_dma(const ParamGradArgs& a, int se
 #pragma unroll
       for (int p = 0; p < MAXM; ++p)
         if (p < a.M) sum += bp[p];
-      a.slabs[(int64_t)seg * L.slab_stride + boff] = sum;
+      slab_st<AG>(a.slabs + (int64_t)seg * L.slab_stride + boff, sum);
     }
   }
   lds_barrier_raw();
@@ -1418,7 +1426,7 @@ __device__ __forceinline__ void consumer_item_dma(const ParamGradArgs& a, int se
     float sum = 0.f;
 #pragma unroll
     for (int w = 0; w < CW; ++w) sum += lds[w * (HC * K) + idx];
-    (sb + (CONV == 0 ? L.c1_W : L.c2_W))[idx] = sum;
+    slab_st<AG>(sb + (CONV == 0 ? L.c1_W : L.c2_W) + idx, sum);
   }
   if ((int)threadIdx.x < 4 * K) {
     float sum = 0.f;
@@ -1450,8 +1458,8 @@ __device__ __forceinline__ void consumer_item_dma(const ParamGradArgs& a, int se
       float t0 = 0.f, t1 = 0.f;
 #pragma unroll 4
       for (int g = 0; g < KG; ++g) { t0 += ared[g * HC + c]; t1 += ared[(KG + g) * HC + c]; }
-      (sb + (CONV == 0 ? L.c1_as : L.c2_as))[c] = t0;
-      (sb + (CONV == 0 ? L.c1_ad : L.c2_ad))[c] = t1;
+      slab_st<AG>(sb + (CONV == 0 ? L.c1_as : L.c2_as) + c, t0);
+      slab_st<AG>(sb + (CONV == 0 ? L.c1_ad : L.c2_ad) + c, t1);
     }
   }
   ISTAMP(7);

@@ -21,9 +21,10 @@ __global__ __launch_bounds__(256) void reduce_adam_kernel(const float* __restric
                                                           unsigned long long* __restrict__ step_counter, double lr,
                                                           double b1, double b2, double eps, double wd,
                                                           float grad_scale, float* __restrict__ wt, int nb, int nc,
-                                                          unsigned* __restrict__ status) {
+                                                          unsigned* __restrict__ status, const double* __restrict__ hp) {
   __shared__ float s_step_size, s_bc2_sqrt;
   __shared__ unsigned s_fault;
+  if (hp) { lr = hp[0]; b1 = hp[1]; b2 = hp[2]; eps = hp[3]; wd = hp[4]; }      // (gatres_train_step_t.hparams)
   // status[0]: a split launch of this step gave up waiting for a partner workgroup (its results are poisoned).  The step
   // is then DROPPED: no Adam update, no step count, loss = NaN, gradients = NaN; the last block clears the word and
   // counts the event in status[1], so one transient stall costs one step instead of the whole run.
@@ -116,6 +117,193 @@ __global__ __launch_bounds__(256) void reduce_adam_kernel(const float* __restric
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Parameter gradients of a RANGE of blocks, summed over the segments, in ONE launch: what the data-parallel step of the
+// fused path forms its gradient buckets with (gatres_train_step: GATRES_FLAG_GRADS_ONLY) -- the upper blocks' bucket goes on
+// the wire while the lower blocks' launch runs.
+// A COLUMN is one (block, conv): the S = num_segments items of a column (one workgroup each, param_grads_stream_kernel's
+// items) write the column's range of S slab rows with agent-scope stores (sc1: written through), acknowledged (every wave's
+// s_waitcnt vmcnt(0)) before the item counts itself at the column's counter; the item that ARRIVES LAST reads the rows
+// back with agent-scope loads (never served from its L1 or a stale L2 line: the granule protocol's pair of accesses,
+// k_fused_dev.h), sums them in slab order -- reduce_adam_kernel's association: the same bits, whoever arrives last --,
+// writes grads and, if asked (do_adam: the whole model only), applies Adam to those parameters.  lin0's range rides on
+// column (block 0, conv1), lin1's on (last block, conv2).
+// As a replacement of the single-GPU step's two launches (param_grads_stream_kernel 37.6 us + reduce_adam_kernel 8.7 us
+// inside the captured step) it was measured and is NOT used: 53 us with everything in it (47.7 without Adam) -- the column
+// sums are a serial tail of dependent memory round trips on the workgroups that finish last; a release fence per arriver
+// instead of agent-scope stores 73 us (960 L2 write-back walks); dedicated reducer workgroups behind the items 60 us
+// (a third round of workgroups): profiles/r04_param_grads_finish_probe.txt, tests/micro/pgf_probe.py.
+// A faulted split launch (status[0]) turns grads and loss into NaN and skips the update, as gatres_fused_finish;
+// `final_launch`: this launch holds block 0 (it clears the fault).
+struct FinishArgs {
+  float* grads;
+  const float* loss_part;
+  float* loss;
+  int num_loss, do_adam;
+  float *p, *m, *v;
+  unsigned long long* step_counter;
+  double lr, b1, b2, eps, wd;
+  const double* hp;
+  float grad_scale;
+  float* wt;
+  unsigned* status;
+  unsigned* colcnt;
+  int S, b_lo, b_hi, final_launch;
+};
+
+template <int NC>
+__global__ __launch_bounds__(PGS_THREADS) void param_grads_finish_kernel(const ParamGradArgs a, const FinishArgs f) {
+  __shared__ __attribute__((aligned(16))) float lds[PGS_NBUF * CI_CR * (3 * NC + 4)];
+  __shared__ int s_last;
+  __shared__ float s_step_size, s_bc2_sqrt;
+  __shared__ unsigned s_fault;
+  const Layout& L = a.L;
+  const int S = f.S, tid = threadIdx.x;
+  // segment-major: a segment's items are adjacent workgroups, every column completes with the launch's last segment
+  // (column-major measured 56 us against 53)
+  const int ncol = 2 * (f.b_hi - f.b_lo);
+  const int col = (int)(blockIdx.x % ncol), seg = (int)(blockIdx.x / ncol);
+  const int b = f.b_hi - 1 - (col >> 1), conv = 1 - (col & 1);          // production order: upper blocks first, conv2 before conv1
+  if (f.loss_part && blockIdx.x == 0 && tid < 64) {                      // the loss (as reduce_adam_kernel)
+    float s = 0.f;
+    for (int k = tid; k < f.num_loss; k += 64) s += f.loss_part[k];
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+    const bool flt = f.status && __hip_atomic_load(f.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;
+    if (tid == 0) f.loss[0] = flt ? NAN : s / f.loss_part[f.num_loss];
+  }
+  if (conv == 0) consumer_item_dma<NC, PGS_THREADS, 0, PGS_NBUF, true>(a, seg, b, lds);
+  else           consumer_item_dma<NC, PGS_THREADS, 1, PGS_NBUF, true>(a, seg, b, lds);
+  const bool has_lin0 = b == 0 && conv == 0, has_lin1 = b == L.nb - 1 && conv == 1;
+  if (a.M > 1) {                                                         // lin0 / lin1 partials of a split segment
+    if (has_lin0) fold_parts<PGS_THREADS, true>(a, seg, L.p_lin0_w, 2 * NC);
+    if (has_lin1) fold_parts<PGS_THREADS, true>(a, seg, L.p_lin1_w, NC + 1);
+  }
+  // ---- arrive at the column's counter (no fence: see above)
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  unsigned* cnt = f.colcnt + (2 * b + conv);
+  if (tid == 0) {
+    const unsigned prev = __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    s_last = prev == (unsigned)(S - 1) ? 1 : 0;
+  }
+  __syncthreads();
+  if (!s_last) return;
+  double lr = f.lr, b1 = f.b1, b2 = f.b2, eps = f.eps, wd = f.wd;
+  if (f.hp) { lr = f.hp[0]; b1 = f.hp[1]; b2 = f.hp[2]; eps = f.hp[3]; wd = f.hp[4]; }
+  if (tid == 0) {
+    __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);           // (the next launch starts from zero)
+    s_fault = f.status ? __hip_atomic_load(f.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+    if (f.do_adam) {
+      const unsigned long long t = __hip_atomic_load(f.step_counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1ULL;
+      s_step_size = (float)(lr / (1.0 - gatres_powi(b1, t)));
+      s_bc2_sqrt = (float)sqrt(1.0 - gatres_powi(b2, t));
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");          // (the step count and the fault word are in registers)
+  }
+  __syncthreads();
+  const bool fault = s_fault != 0u;
+  const int64_t po = L.p_block0 + (int64_t)b * L.p_block_stride;
+  const __amdgpu_buffer_rsrc_t slab_rsrc =
+      __builtin_amdgcn_make_buffer_rsrc(a.slabs, 0, (int)((size_t)S * L.slab_stride * 4), 0x00020000);
+  typedef float v4f __attribute__((ext_vector_type(4)));
+  auto slab4 = [&](int srow, int64_t idx) -> float4 {                   // 16 bytes of slab row srow, agent scope (sc1)
+    const v4f v = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(
+        slab_rsrc, (unsigned)(((size_t)srow * L.slab_stride + idx) * 4), 0, 16));
+    return make_float4(v.x, v.y, v.z, v.w);
+  };
+  // one parameter: Adam on the summed gradient (the arithmetic of reduce_adam_kernel, statement for statement)
+  auto update = [&](int64_t idx, float acc, float pv, float mv0, float vv0) {
+    f.grads[idx] = fault ? NAN : acc;
+    if (f.do_adam && !fault) {
+      float gv = acc * f.grad_scale;
+      gv = gv + (float)wd * pv;
+      float mv = mv0;
+      mv = mv + (float)(1.0 - b1) * (gv - mv);
+      const float vv = (float)b2 * vv0 + (float)(1.0 - b2) * gv * gv;
+      const float denom = sqrtf(vv) / s_bc2_sqrt + (float)eps;
+      const float pn = pv + (-s_step_size * mv) / denom;
+      f.p[idx] = pn;
+      f.m[idx] = mv;
+      f.v[idx] = vv;
+      if (f.wt) {               // keep the transposed conv weights of the next backward current (k_misc.hip layout)
+        const long long per = 2LL * NC * NC, o = idx - po;
+        if (o >= 6LL * NC && o < 6LL * NC + per) {                          // W1 [2nc][nc] -> [nc][2nc]
+          const long long e = o - 6LL * NC, row = e / NC, cl = e % NC;
+          f.wt[(long long)b * 2 * per + cl * 2 * NC + row] = pn;
+        } else if (o >= 9LL * NC + per && o < 9LL * NC + 2 * per) {         // W2 [nc][2nc] -> [2nc][nc]
+          const long long e = o - 9LL * NC - per, row = e / (2 * NC), cl = e % (2 * NC);
+          f.wt[(long long)b * 2 * per + per + cl * NC + row] = pn;
+        }
+      }
+    }
+  };
+  // [lo, hi) of the flat vector, lo % 4 == 0: 16 bytes per thread and slab row, twelve rows in flight (sixteen spill at the
+  // 128 VGPRs that two workgroups per CU leave), every element summed in slab order
+  auto finish_range = [&](int64_t lo, int64_t hi) {
+    const int64_t n4 = (hi - lo) >> 2;
+    for (int64_t q = tid; q < n4; q += PGS_THREADS) {
+      const int64_t idx = lo + 4 * q;
+      float4 pv = f4zero(), mv0 = f4zero(), vv0 = f4zero();
+      if (f.do_adam && !fault) { pv = ld4(f.p + idx); mv0 = ld4(f.m + idx); vv0 = ld4(f.v + idx); }
+      float4 acc = f4zero();
+      int s0 = 0;
+      for (; s0 + 12 <= S; s0 += 12) {
+        float4 v12[12];
+#pragma unroll
+        for (int u = 0; u < 12; ++u) v12[u] = slab4(s0 + u, idx);
+#pragma unroll
+        for (int u = 0; u < 12; ++u) { acc.x += v12[u].x; acc.y += v12[u].y; acc.z += v12[u].z; acc.w += v12[u].w; }
+      }
+      for (; s0 + 8 <= S; s0 += 8) {
+        float4 v8[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v8[u] = slab4(s0 + u, idx);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { acc.x += v8[u].x; acc.y += v8[u].y; acc.z += v8[u].z; acc.w += v8[u].w; }
+      }
+      for (; s0 < S; ++s0) {
+        const float4 v1 = slab4(s0, idx);
+        acc.x += v1.x; acc.y += v1.y; acc.z += v1.z; acc.w += v1.w;
+      }
+      update(idx, acc.x, pv.x, mv0.x, vv0.x);
+      update(idx + 1, acc.y, pv.y, mv0.y, vv0.y);
+      update(idx + 2, acc.z, pv.z, mv0.z, vv0.z);
+      update(idx + 3, acc.w, pv.w, mv0.w, vv0.w);
+    }
+    for (int64_t idx = lo + 4 * n4 + tid; idx < hi; idx += PGS_THREADS) {      // (lin1's odd element)
+      float pv = 0.f, mv0 = 0.f, vv0 = 0.f;
+      if (f.do_adam && !fault) { pv = f.p[idx]; mv0 = f.m[idx]; vv0 = f.v[idx]; }
+      float acc = 0.f;
+      for (int s0 = 0; s0 < S; ++s0)
+        acc += __hip_atomic_load(a.slabs + (size_t)s0 * L.slab_stride + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      update(idx, acc, pv, mv0, vv0);
+    }
+  };
+  if (conv == 0) finish_range(po, po + L.c2_as);
+  else           finish_range(po + L.c2_as, po + L.p_block_stride);
+  if (has_lin0) finish_range(L.p_lin0_w, L.p_block0);
+  if (has_lin1) finish_range(L.p_lin1_w, L.P);
+  if (tid == 0) {
+    const unsigned ncols = (unsigned)ncol;
+    if (f.do_adam && !fault) {
+      // counted by the column that finishes last; every column has read the count before it draws
+      const unsigned long long done = atomicAdd(&f.step_counter[1], 1ULL);
+      if (done == (unsigned long long)ncols - 1ULL) {
+        f.step_counter[1] = 0ULL;
+        atomicAdd(&f.step_counter[0], 1ULL);
+      }
+    }
+    if (fault && f.final_launch) {                 // every column of this launch has read status[0] before the last ticket
+      __threadfence();
+      if (atomicAdd(f.status + 2, 1u) == ncols - 1u) {
+        f.status[2] = 0u;
+        f.status[1] += 1u;
+        __hip_atomic_store(f.status, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+  }
+}
+
 // The same bookkeeping after a split launch that no gatres_fused_finish follows (forward / inference launches)
 __global__ __launch_bounds__(64) void fused_status_kernel(unsigned* __restrict__ status) {
   if (threadIdx.x == 0 && __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
@@ -148,6 +336,18 @@ static int serialize_split_launch(hipStream_t st) {
       (void)hipEventDestroy(ev);
     }
     (void)hipGetLastError();                     // (a stream the caller has destroyed meanwhile: nothing left to wait for)
+  }
+  // ... and for what the per-op backward may still have in flight on the library's side stream (its parameter-gradient
+  // launches): they hold CUs a split launch needs resident
+  if (gatres_side_t* side = gatres_side_peek()) {
+    hipStreamCaptureStatus ss = hipStreamCaptureStatusNone;
+    hipEvent_t ev;
+    if (side->stream != st && hipStreamIsCapturing(side->stream, &ss) == hipSuccess && ss == hipStreamCaptureStatusNone &&
+        hipEventCreateWithFlags(&ev, hipEventDisableTiming) == hipSuccess) {
+      if (hipEventRecord(ev, side->stream) == hipSuccess) (void)hipStreamWaitEvent(st, ev, 0);
+      (void)hipEventDestroy(ev);
+    }
+    (void)hipGetLastError();
   }
   g_split_stream[dev] = st;
   g_split_seen[dev] = true;
@@ -299,7 +499,7 @@ extern "C" int gatres_fused_reset_sync(const gatres_model_t* m, const gatres_gra
     const hipError_t e = hipMemsetAsync(scratch + L.sc_xch, 0, (size_t)g->num_segments * L.xch_stride * 4, gatres_stream(stream));
     if (e != hipSuccess) return (int)e;
   }
-  return (int)hipMemsetAsync(scratch + L.sc_flags, 0, (size_t)(L.flag_words + L.ready_words) * 4, gatres_stream(stream));
+  return (int)hipMemsetAsync(scratch + L.sc_flags, 0, (size_t)(L.flag_words + L.ready_words + L.col_words) * 4, gatres_stream(stream));
 }
 
 extern "C" int gatres_fused_window_kernel(const gatres_model_t* m, const gatres_graph_t* g) {
@@ -412,10 +612,71 @@ extern "C" int gatres_fused_param_grads(const gatres_model_t* m, const gatres_gr
   return gatres_launch_status();
 }
 
+// 1 when gatres_fused_param_grads_finish applies: streamed items (nc 16 / 32) in a launch of their own
+static bool finish_folds(const gatres_model_t* m, const gatres_graph_t* g, const Layout& L) {
+  if (!(m->nc == 16 || m->nc == 32) || gatres_knobs()->param_grads_no_stream || L.nb == 0) return false;
+  return fused_consumers(L, g, fused_split(L, g)) == 0;
+}
+
+extern "C" int gatres_fused_finish_folds(const gatres_model_t* m, const gatres_graph_t* g) {
+  Layout L;
+  if (!gatres_fused_supported(m, g) || !make_layout_g(m, g, &L)) return 0;
+  return finish_folds(m, g, L) ? 1 : 0;
+}
+
+extern "C" int gatres_fused_param_grads_finish(const gatres_model_t* m, const gatres_graph_t* g, const float* saved,
+                                               float* scratch, float* grads, const float* loss_part, float* loss,
+                                               int32_t do_adam, float* params, float* exp_avg, float* exp_avg_sq,
+                                               uint64_t* step_counter, double lr, double beta1, double beta2, double eps,
+                                               double weight_decay, const double* hparams, float grad_scale,
+                                               int32_t block_lo, int32_t block_hi, void* stream) {
+  if (!m || !g || !saved || !scratch || !grads) return GATRES_E_BADARG;
+  if (do_adam && (!params || !exp_avg || !exp_avg_sq || !step_counter)) return GATRES_E_BADARG;
+  if ((loss_part == nullptr) != (loss == nullptr)) return GATRES_E_BADARG;
+  if (!gatres_fused_supported(m, g)) return GATRES_E_UNSUPPORTED;
+  ParamGradArgs a;
+  if (!make_layout_g(m, g, &a.L)) return GATRES_E_UNSUPPORTED;
+  if (!finish_folds(m, g, a.L)) return GATRES_E_UNSUPPORTED;
+  if (block_lo < 0 || block_hi > a.L.nb || block_lo >= block_hi) return GATRES_E_BADARG;
+  if (do_adam && (block_lo != 0 || block_hi != a.L.nb)) return GATRES_E_BADARG;      // (the step is counted per launch)
+  a.seg_ptr = g->seg_ptr; a.saved = saved; a.keep = scratch + a.L.sc_keep; a.slabs = scratch + a.L.sc_slabs;
+  a.M = fused_split(a.L, g); a.part_slabs = scratch + a.L.sc_part_slabs;
+  a.SL = make_seg_layout(a.L.nb, a.L.nc, g->max_segment_nodes, g->max_segment_edges_gat);
+  a.wt = scratch + a.L.sc_wt;
+  FinishArgs f;
+  f.grads = grads; f.loss_part = loss_part; f.loss = loss; f.num_loss = g->num_segments * a.M; f.do_adam = do_adam ? 1 : 0;
+  f.p = params; f.m = exp_avg; f.v = exp_avg_sq; f.step_counter = reinterpret_cast<unsigned long long*>(step_counter);
+  f.lr = lr; f.b1 = beta1; f.b2 = beta2; f.eps = eps; f.wd = weight_decay; f.hp = hparams; f.grad_scale = grad_scale;
+  f.wt = do_adam ? scratch + a.L.sc_wt : nullptr;
+  f.status = fused_nodes_of(g) > 0 ? reinterpret_cast<unsigned*>(scratch + a.L.sc_flags + a.L.flag_words - 32) : nullptr;
+  f.colcnt = reinterpret_cast<unsigned*>(scratch + a.L.sc_flags + a.L.flag_words + a.L.ready_words);
+  f.S = g->num_segments; f.b_lo = block_lo; f.b_hi = block_hi; f.final_launch = block_lo == 0 ? 1 : 0;
+  const dim3 grid((unsigned)(2 * (block_hi - block_lo) * g->num_segments));
+  hipStream_t st = gatres_stream(stream);
+  if (m->nc == 16) hipLaunchKernelGGL((param_grads_finish_kernel<16>), grid, dim3(PGS_THREADS), 0, st, a, f);
+  else             hipLaunchKernelGGL((param_grads_finish_kernel<32>), grid, dim3(PGS_THREADS), 0, st, a, f);
+  return gatres_launch_status();
+}
+
+extern "C" int gatres_fused_finish_hp(const gatres_model_t* m, const gatres_graph_t* g, float* scratch, float* grads,
+                                      const float* loss_part, float* loss, int32_t do_adam, float* params,
+                                      float* exp_avg, float* exp_avg_sq, uint64_t* step_counter, double lr, double beta1,
+                                      double beta2, double eps, double weight_decay, const double* hparams,
+                                      float grad_scale, void* stream);
+
 extern "C" int gatres_fused_finish(const gatres_model_t* m, const gatres_graph_t* g, float* scratch, float* grads,
                                    const float* loss_part, float* loss, int32_t do_adam, float* params,
                                    float* exp_avg, float* exp_avg_sq, uint64_t* step_counter, double lr, double beta1,
                                    double beta2, double eps, double weight_decay, float grad_scale, void* stream) {
+  return gatres_fused_finish_hp(m, g, scratch, grads, loss_part, loss, do_adam, params, exp_avg, exp_avg_sq, step_counter,
+                                lr, beta1, beta2, eps, weight_decay, nullptr, grad_scale, stream);
+}
+
+extern "C" int gatres_fused_finish_hp(const gatres_model_t* m, const gatres_graph_t* g, float* scratch, float* grads,
+                                      const float* loss_part, float* loss, int32_t do_adam, float* params,
+                                      float* exp_avg, float* exp_avg_sq, uint64_t* step_counter, double lr, double beta1,
+                                      double beta2, double eps, double weight_decay, const double* hparams,
+                                      float grad_scale, void* stream) {
   if (!m || !g || !scratch || !grads) return GATRES_E_BADARG;
   if (do_adam && (!params || !exp_avg || !exp_avg_sq || !step_counter)) return GATRES_E_BADARG;
   if ((loss_part == nullptr) != (loss == nullptr)) return GATRES_E_BADARG;
@@ -426,7 +687,8 @@ extern "C" int gatres_fused_finish(const gatres_model_t* m, const gatres_graph_t
                      (long long)L.slab_stride, (long long)L.P, grads, loss_part, loss, do_adam, params, exp_avg, exp_avg_sq,
                      reinterpret_cast<unsigned long long*>(step_counter), lr, beta1, beta2, eps, weight_decay,
                      grad_scale, do_adam ? scratch + L.sc_wt : nullptr, L.nb, L.nc,
-                     fused_nodes_of(g) > 0 ? reinterpret_cast<unsigned*>(scratch + L.sc_flags + L.flag_words - 32) : nullptr);
+                     fused_nodes_of(g) > 0 ? reinterpret_cast<unsigned*>(scratch + L.sc_flags + L.flag_words - 32) : nullptr,
+                     hparams);
   return gatres_launch_status();
 }
 

@@ -73,7 +73,7 @@ extern "C" int gatres_knobs_reload(void) {
   return 0;
 }
 
-extern "C" __attribute__((visibility("hidden"))) gatres_side_t* gatres_side() {
+static gatres_side_t* side_of_device(bool create) {
   constexpr int MAXDEV = 64;
   static gatres_side_t sides[MAXDEV];
   static int state[MAXDEV];                // 0: not tried, 1: ready, -1: failed
@@ -81,7 +81,7 @@ extern "C" __attribute__((visibility("hidden"))) gatres_side_t* gatres_side() {
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAXDEV) { (void)hipGetLastError(); return nullptr; }
   std::lock_guard<std::mutex> lk(mu);
-  if (state[dev] == 0) {
+  if (state[dev] == 0 && create) {
     gatres_side_t& s = sides[dev];
     bool ok = hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking) == hipSuccess;
     hipEvent_t* ev[4] = {&s.fork_a, &s.fork_b, &s.done_a, &s.done_b};
@@ -92,6 +92,9 @@ extern "C" __attribute__((visibility("hidden"))) gatres_side_t* gatres_side() {
   }
   return state[dev] == 1 ? &sides[dev] : nullptr;
 }
+extern "C" __attribute__((visibility("hidden"))) gatres_side_t* gatres_side() { return side_of_device(true); }
+// the side stream if one was ever created on this device (never creates one)
+extern "C" __attribute__((visibility("hidden"))) gatres_side_t* gatres_side_peek() { return side_of_device(false); }
 
 namespace {
 
@@ -571,17 +574,23 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
                                                    unsigned long long* __restrict__ step_counter, long long count,
                                                    double lr, double b1, double b2, double eps, double wd,
                                                    float grad_scale, float* __restrict__ wt, int nb, int nc,
-                                                   int drop_marked) {
+                                                   unsigned* __restrict__ drop_count, const double* __restrict__ hp) {
   __shared__ float s_step_size, s_bc2_sqrt;
   __shared__ int s_drop;
   unsigned long long done = 0ULL;
-  // drop_marked (the data-parallel Adam phase only): a fused launch that faulted marks EVERY gradient entry NaN
-  // (gatres_fused_finish) and the all-reduce spreads the mark to all ranks; the step is then dropped on every replica alike
-  // -- no update, no step count.  Everywhere else (gatres_adam_step, FusedAdam) a NaN gradient propagates exactly as in
-  // torch.optim.Adam, which the reference uses (train.py:348).
-  if (threadIdx.x == 0) s_drop = (drop_marked && g[0] != g[0]) ? 1 : 0;
+  if (hp) { lr = hp[0]; b1 = hp[1]; b2 = hp[2]; eps = hp[3]; wd = hp[4]; }      // (gatres_train_step_t.hparams)
+  // drop_count != null (the data-parallel Adam phase of the fused path only): a fused launch that faulted marks EVERY
+  // gradient entry NaN (gatres_fused_finish) and the all-reduce spreads the mark to all ranks; the step is then dropped on
+  // every replica alike -- no update, no step count -- and COUNTED in *drop_count (status word 3: a NaN that a diverging run
+  // puts into g[0] drops steps too, and must not do so silently; GATResTrainer.dropped_steps).  Everywhere else
+  // (gatres_adam_step, FusedAdam) a NaN gradient propagates exactly as in torch.optim.Adam, which the reference uses
+  // (train.py:348).
+  if (threadIdx.x == 0) s_drop = (drop_count && g[0] != g[0]) ? 1 : 0;
   __syncthreads();
-  if (s_drop) return;
+  if (s_drop) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(drop_count, 1u);
+    return;
+  }
   if (threadIdx.x == 0) {
     const unsigned long long t = __hip_atomic_load(step_counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1ULL;
     const double bc1 = 1.0 - gatres_powi(b1, t), bc2 = 1.0 - gatres_powi(b2, t);
@@ -854,22 +863,23 @@ extern "C" int gatres_adam_step(float* params, const float* grads, float* exp_av
   if (!params || !grads || !exp_avg || !exp_avg_sq || !step_counter || count <= 0) return GATRES_E_BADARG;
   hipLaunchKernelGGL(adam_kernel, dim3(adam_blocks(count)), dim3(256), 0, gatres_stream(stream), params,
                      grads, exp_avg, exp_avg_sq, reinterpret_cast<unsigned long long*>(step_counter),
-                     (long long)count, lr, beta1, beta2, eps, weight_decay, grad_scale, (float*)nullptr, 0, 0, 0);
+                     (long long)count, lr, beta1, beta2, eps, weight_decay, grad_scale, (float*)nullptr, 0, 0,
+                     (unsigned*)nullptr, (const double*)nullptr);
   return gatres_launch_status();
 }
 
-// (not part of include/gatres.h: the fused train step's Adam-only phase -- the data-parallel step runs backward |
-//  all-reduce | Adam -- also refreshes scratch's transposed conv weights, so the next backward finds them current.
-//  A step whose gradient carries the fault mark (every entry NaN) is dropped whole: parameters, moments, step count and the
-//  transposed copy stay as they were.)
-extern "C" __attribute__((visibility("hidden"))) int gatres_adam_step_wt(float* params, const float* grads, float* exp_avg, float* exp_avg_sq,
-                                   uint64_t* step_counter, int64_t count, double lr, double beta1, double beta2,
-                                   double eps, double weight_decay, float grad_scale, float* wt, int32_t num_blocks,
-                                   int32_t nc, void* stream) {
-  if (!params || !grads || !exp_avg || !exp_avg_sq || !step_counter || count <= 0 || !wt) return GATRES_E_BADARG;
+// (not part of include/gatres.h) Adam with everything gatres_train_step may ask for: hyper-parameters from a device buffer
+// (hp: double[5] {lr, beta1, beta2, eps, weight_decay}, or null), the fused path's transposed conv weights kept current
+// (wt, or null), fault-marked steps dropped and counted (drop_count, or null).
+extern "C" __attribute__((visibility("hidden"))) int gatres_adam_step_ex(float* params, const float* grads, float* exp_avg,
+                                   float* exp_avg_sq, uint64_t* step_counter, int64_t count, double lr, double beta1,
+                                   double beta2, double eps, double weight_decay, const double* hp, float grad_scale,
+                                   float* wt, int32_t num_blocks, int32_t nc, uint32_t* drop_count, void* stream) {
+  if (!params || !grads || !exp_avg || !exp_avg_sq || !step_counter || count <= 0) return GATRES_E_BADARG;
   hipLaunchKernelGGL(adam_kernel, dim3(adam_blocks(count)), dim3(256), 0, gatres_stream(stream), params,
                      grads, exp_avg, exp_avg_sq, reinterpret_cast<unsigned long long*>(step_counter),
-                     (long long)count, lr, beta1, beta2, eps, weight_decay, grad_scale, wt, (int)num_blocks, (int)nc, 1);
+                     (long long)count, lr, beta1, beta2, eps, weight_decay, grad_scale, wt, (int)num_blocks, (int)nc,
+                     drop_count, hp);
   return gatres_launch_status();
 }
 

@@ -48,7 +48,14 @@ extern "C" int32_t gatres_num_slabs(const gatres_model_t* m, int32_t num_nodes) 
   return make_layout(m, num_nodes, 0, 0, 0, 0, &L) ? L.num_slabs : GATRES_E_UNSUPPORTED;
 }
 
-extern "C" const char* gatres_version(void) { return "gatres-gfx950 abi3"; }
+// "gatres-gfx950 abi<N> build <id>": <id> is the hash of the sources the library was built from (_build.py passes it; the
+// Python loader refuses a library whose id differs from the sources beside it)
+#ifndef GATRES_BUILD_ID
+#define GATRES_BUILD_ID "unknown"
+#endif
+#define GATRES_STR2(x) #x
+#define GATRES_STR(x) GATRES_STR2(x)
+extern "C" const char* gatres_version(void) { return "gatres-gfx950 abi" GATRES_STR(GATRES_ABI_VERSION) " build " GATRES_BUILD_ID; }
 
 extern "C" int gatres_model_forward(const gatres_model_t* m, const gatres_graph_t* g, const float* params,
                                     const float* x, const uint8_t* mask, float* out, float* saved, float* scratch,
@@ -259,7 +266,22 @@ extern "C" int gatres_model_backward_per_op_part(const gatres_model_t* m, const 
   hipStream_t main_st = gatres_stream(stream);
   std::unique_lock<std::mutex> side_lock;          // (two host threads enqueueing backward pieces must not interleave on the events)
   if (side) side_lock = std::unique_lock<std::mutex>(*static_cast<std::mutex*>(side->mu));
-  bool pend_a = false, pend_b = false;
+  // Join on EVERY exit: an error return between a fork and its join would leave the side stream forked -- inside
+  // a stream capture that invalidates the capture with an unrelated error, in eager mode the next call could overwrite
+  // gy2 / gh2 / go1 while the side stream still reads them.  open_*: forked, the done event not recorded yet.
+  struct SideJoin {
+    gatres_side_t* side;
+    hipStream_t main_st;
+    bool pend_a = false, pend_b = false, open_a = false, open_b = false;
+    ~SideJoin() {
+      if (!side) return;
+      if (open_a) { (void)hipEventRecord(side->done_a, side->stream); pend_a = true; }
+      if (open_b) { (void)hipEventRecord(side->done_b, side->stream); pend_b = true; }
+      if (pend_a) (void)hipStreamWaitEvent(main_st, side->done_a, 0);
+      if (pend_b) (void)hipStreamWaitEvent(main_st, side->done_b, 0);
+    }
+  } sj{side, main_st};
+  bool &pend_a = sj.pend_a, &pend_b = sj.pend_b;
 #define HIPRC(call_) do { if ((call_) != hipSuccess) return (int)hipGetLastError(); } while (0)
   for (int b = b_hi - 1; b >= b_lo; --b) {
     const float* base = saved + (int64_t)b * L.s_stride;
@@ -283,10 +305,11 @@ extern "C" int gatres_model_backward_per_op_part(const gatres_model_t* m, const 
       HIPRC(hipEventRecord(side->fork_a, main_st));
       HIPRC(hipStreamWaitEvent(side->stream, side->fork_a, 0));
       pst = side->stream;
+      sj.open_a = true;
     }
     RC(conv_partials(gh2, base + L.s_o1, sb + L.c2_W, Sw, st, N, 2 * nc, nc, base + L.s_h2, gas2, gad2, gy2, sb + L.c2_as,
                      sb + L.c2_ad, sb + L.c2_b, S, 1, nc, dt, pst));
-    if (side) { HIPRC(hipEventRecord(side->done_a, side->stream)); pend_a = true; }
+    if (side) { sj.open_a = false; HIPRC(hipEventRecord(side->done_a, side->stream)); pend_a = true; }
     if (pend_b) { HIPRC(hipStreamWaitEvent(main_st, side->done_b, 0)); pend_b = false; }
     RC(gatres_t_proj_bwd_dx(gh2, wt2, nullptr, base + L.s_o1, go1, N, 2 * nc, nc, dt, stream));   // ReLU mask of conv1
     // conv1 (H = 2, C = nc, K = nc)
@@ -299,16 +322,17 @@ extern "C" int gatres_model_backward_per_op_part(const gatres_model_t* m, const 
       HIPRC(hipEventRecord(side->fork_b, main_st));
       HIPRC(hipStreamWaitEvent(side->stream, side->fork_b, 0));
       pst = side->stream;
+      sj.open_b = true;
     }
     RC(conv_partials(gh, base + L.s_xin, sb + L.c1_W, Sw, st, N, nc, 2 * nc, base + L.s_h1, gas, gad, go1, sb + L.c1_as,
                      sb + L.c1_ad, sb + L.c1_b, S, 2, nc, dt, pst));
-    if (side) { HIPRC(hipEventRecord(side->done_b, side->stream)); pend_b = true; }
+    if (side) { sj.open_b = false; HIPRC(hipEventRecord(side->done_b, side->stream)); pend_b = true; }
     // d/d xin = conv1 path + residual; masked by the previous block's ReLU (block 0's input is lin0, no ReLU)
     RC(gatres_t_proj_bwd_dx(gh, wt1, gp_cur, b > 0 ? base + L.s_xin : nullptr, gp_nxt, N, nc, 2 * nc, dt, stream));
     float* t = gp_cur; gp_cur = gp_nxt; gp_nxt = t;
   }
-  if (pend_a) HIPRC(hipStreamWaitEvent(main_st, side->done_a, 0));        // join: the piece's slabs are complete
-  if (pend_b) HIPRC(hipStreamWaitEvent(main_st, side->done_b, 0));
+  if (pend_a) { HIPRC(hipStreamWaitEvent(main_st, side->done_a, 0)); pend_a = false; }      // join: the piece's slabs are complete
+  if (pend_b) { HIPRC(hipStreamWaitEvent(main_st, side->done_b, 0)); pend_b = false; }
 #undef HIPRC
   if (last) {
     RC(gatres_t_lin0_bwd(gp_cur, x, mask, slabs + L.p_lin0_w, slabs + L.p_lin0_b, S, st, N, nc, dt, stream));

@@ -3,10 +3,26 @@
 #include "gatres_common.h"
 #include "gatres_layout.h"
 
-extern "C" __attribute__((visibility("hidden"))) int gatres_adam_step_wt(float* params, const float* grads, float* exp_avg, float* exp_avg_sq,
-                                   uint64_t* step_counter, int64_t count, double lr, double beta1, double beta2,
-                                   double eps, double weight_decay, float grad_scale, float* wt, int32_t num_blocks,
-                                   int32_t nc, void* stream);
+extern "C" __attribute__((visibility("hidden"))) int gatres_adam_step_ex(float* params, const float* grads, float* exp_avg,
+                                   float* exp_avg_sq, uint64_t* step_counter, int64_t count, double lr, double beta1,
+                                   double beta2, double eps, double weight_decay, const double* hp, float grad_scale,
+                                   float* wt, int32_t num_blocks, int32_t nc, uint32_t* drop_count, void* stream);
+extern "C" int gatres_fused_finish_hp(const gatres_model_t* m, const gatres_graph_t* g, float* scratch, float* grads,
+                                      const float* loss_part, float* loss, int32_t do_adam, float* params,
+                                      float* exp_avg, float* exp_avg_sq, uint64_t* step_counter, double lr, double beta1,
+                                      double beta2, double eps, double weight_decay, const double* hparams,
+                                      float grad_scale, void* stream);
+
+// Parameter gradients, slab sum and (optionally) Adam of the fused path: the parameter-gradient launch followed by
+// gatres_fused_finish.  (The one-launch form, gatres_fused_param_grads_finish, is slower on a single GPU -- 53 us against 38 +
+// 9 inside the captured step, k_fused_host.hip -- and serves the data-parallel step's gradient buckets only.)
+static int fused_grads_and_update(const gatres_train_step_t* ts, const float* loss_part, bool adam, void* stream) {
+  const int rc = gatres_fused_param_grads(&ts->model, ts->graph, ts->saved, ts->scratch, stream);
+  if (rc) return rc;
+  return gatres_fused_finish_hp(&ts->model, ts->graph, ts->scratch, ts->grads, loss_part, loss_part ? ts->loss : nullptr,
+                                adam ? 1 : 0, ts->params, ts->exp_avg, ts->exp_avg_sq, ts->step_counter, ts->lr, ts->beta1,
+                                ts->beta2, ts->eps, ts->weight_decay, ts->hparams, ts->grad_scale, stream);
+}
 
 extern "C" int gatres_train_step(const gatres_train_step_t* ts, void* stream) {
   if (!ts || !ts->graph || !ts->params || !ts->x || !ts->y || !ts->mask || !ts->out || !ts->g_out || !ts->loss ||
@@ -32,16 +48,24 @@ extern "C" int gatres_train_step(const gatres_train_step_t* ts, void* stream) {
       rc = gatres_fused_prepare_backward(&ts->model, ts->graph, ts->params, ts->scratch, stream);
       if (rc) return rc;
     }
+    // GATRES_FLAG_GRADS_DEFERRED: the backward phase stops after the chain (the kept g_h tables are in scratch); the caller
+    // turns them into gradients itself, range by range (gatres_fused_param_grads_finish) -- the data-parallel step starts a
+    // bucket's all-reduce between two such launches.
+    const bool deferred = (ts->flags & GATRES_FLAG_GRADS_DEFERRED) != 0;
+    if (ts->flags & GATRES_FLAG_GRADS_ONLY) {
+      if (!bwd || fwd || adam) return GATRES_E_BADARG;
+      const bool top = ts->block_hi == ts->model.num_blocks;             // (the launch that also writes the loss)
+      return gatres_fused_param_grads_finish(&ts->model, ts->graph, ts->saved, ts->scratch, ts->grads,
+                                             top ? loss_part : nullptr, top ? ts->loss : nullptr, 0, nullptr, nullptr,
+                                             nullptr, nullptr, 0., 0., 0., 0., 0., nullptr, 1.f, ts->block_lo, ts->block_hi,
+                                             stream);
+    }
     if (fwd && bwd) {
       rc = gatres_fused_run(&ts->model, ts->graph, ts->params, ts->x, ts->mask, ts->y, ts->out, ts->g_out, loss_part,
                             nullptr, ts->saved, ts->scratch,
                             GATRES_PHASE_FORWARD | GATRES_PHASE_LOSS | GATRES_PHASE_BACKWARD, stream);
-      if (rc) return rc;
-      rc = gatres_fused_param_grads(&ts->model, ts->graph, ts->saved, ts->scratch, stream);
-      if (rc) return rc;
-      return gatres_fused_finish(&ts->model, ts->graph, ts->scratch, ts->grads, loss_part, ts->loss, adam ? 1 : 0,
-                                 ts->params, ts->exp_avg, ts->exp_avg_sq, ts->step_counter, ts->lr, ts->beta1,
-                                 ts->beta2, ts->eps, ts->weight_decay, ts->grad_scale, stream);
+      if (rc || deferred) return rc;
+      return fused_grads_and_update(ts, loss_part, adam, stream);
     }
     if (fwd) {
       rc = gatres_fused_run(&ts->model, ts->graph, ts->params, ts->x, ts->mask, nullptr, ts->out, nullptr, nullptr,
@@ -53,18 +77,16 @@ extern "C" int gatres_train_step(const gatres_train_step_t* ts, void* stream) {
     if (bwd) {
       rc = gatres_fused_run(&ts->model, ts->graph, ts->params, ts->x, ts->mask, nullptr, nullptr, ts->g_out, nullptr,
                             nullptr, ts->saved, ts->scratch, GATRES_PHASE_BACKWARD, stream);
-      if (rc) return rc;
-      rc = gatres_fused_param_grads(&ts->model, ts->graph, ts->saved, ts->scratch, stream);
-      if (rc) return rc;
-      return gatres_fused_finish(&ts->model, ts->graph, ts->scratch, ts->grads, nullptr, nullptr, adam ? 1 : 0,
-                                 ts->params, ts->exp_avg, ts->exp_avg_sq, ts->step_counter, ts->lr, ts->beta1,
-                                 ts->beta2, ts->eps, ts->weight_decay, ts->grad_scale, stream);
+      if (rc || deferred) return rc;
+      return fused_grads_and_update(ts, nullptr, adam, stream);
     }
-    if (adam)        // (the Adam-only phase of the data-parallel step: keeps scratch's transposed conv weights current too)
-      return gatres_adam_step_wt(ts->params, ts->grads, ts->exp_avg, ts->exp_avg_sq, ts->step_counter,
+    if (adam)        // (the Adam-only phase of the data-parallel step: keeps scratch's transposed conv weights current too;
+                     //  a step whose all-reduced gradient carries a fault mark is dropped and counted in status word 3)
+      return gatres_adam_step_ex(ts->params, ts->grads, ts->exp_avg, ts->exp_avg_sq, ts->step_counter,
                                  gatres_param_count(ts->model.num_blocks, ts->model.nc), ts->lr, ts->beta1, ts->beta2,
-                                 ts->eps, ts->weight_decay, ts->grad_scale, ts->scratch + L.sc_wt, ts->model.num_blocks,
-                                 ts->model.nc, stream);
+                                 ts->eps, ts->weight_decay, ts->hparams, ts->grad_scale, ts->scratch + L.sc_wt,
+                                 ts->model.num_blocks, ts->model.nc,
+                                 reinterpret_cast<uint32_t*>(ts->scratch + L.sc_flags + L.flag_words - 32) + 3, stream);
     return 0;
   }
   if (ts->phases & GATRES_PHASE_FORWARD) {
@@ -82,9 +104,9 @@ extern "C" int gatres_train_step(const gatres_train_step_t* ts, void* stream) {
   }
   if (ts->phases & GATRES_PHASE_ADAM) {
     if (!ts->grads || !ts->exp_avg || !ts->exp_avg_sq || !ts->step_counter) return GATRES_E_BADARG;
-    rc = gatres_adam_step(ts->params, ts->grads, ts->exp_avg, ts->exp_avg_sq, ts->step_counter,
-                          gatres_param_count(ts->model.num_blocks, ts->model.nc), ts->lr, ts->beta1, ts->beta2, ts->eps,
-                          ts->weight_decay, ts->grad_scale, stream);
+    rc = gatres_adam_step_ex(ts->params, ts->grads, ts->exp_avg, ts->exp_avg_sq, ts->step_counter,
+                             gatres_param_count(ts->model.num_blocks, ts->model.nc), ts->lr, ts->beta1, ts->beta2, ts->eps,
+                             ts->weight_decay, ts->hparams, ts->grad_scale, nullptr, 0, 0, nullptr, stream);
     if (rc) return rc;
   }
   return 0;

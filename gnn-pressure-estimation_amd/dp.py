@@ -18,11 +18,16 @@ import torch
 import torch.distributed as dist
 
 
-def shard_graphs(num_graphs: int, rank: int, world: int) -> range:
-    """Contiguous, equal-sized shard of the global batch for `rank`; the ragged tail is dropped so every rank has
-    the same number of graphs (keeps plain gradient averaging exact)."""
+def shard_graphs(num_graphs: int, rank: int, world: int, drop_ragged: bool = False) -> range:
+    """Contiguous, equal-sized shard of the global batch for `rank`.  Every rank must hold the same number of graphs
+    (equal masked-node counts keep plain gradient averaging exact), so a batch that does not divide by `world` is an
+    ERROR unless the caller asks for the ragged tail to be dropped (``drop_ragged=True``: ``num_graphs % world`` graphs
+    are then left out, as a DataLoader's ``drop_last`` would) -- never silently."""
     if world <= 0 or not 0 <= rank < world:
         raise ValueError("bad rank/world")
+    if num_graphs % world and not drop_ragged:
+        raise ValueError(f"a global batch of {num_graphs} graphs does not split evenly over {world} ranks "
+                         f"({num_graphs % world} would be dropped); pad the batch or pass drop_ragged=True")
     per = num_graphs // world
     return range(rank * per, (rank + 1) * per)
 
@@ -55,6 +60,7 @@ class BucketedAllReduce:
         self.active = self.world > 1 or (force and dist.is_available() and dist.is_initialized())
         self._works: List = []
         self.launched: List[Tuple[int, int]] = []          # (lo, hi) of every bucket of the current step, in launch order
+        self.last_buckets: List[Tuple[int, int]] = []
 
     def launch(self, lo: int, hi: int) -> None:
         if not 0 <= lo < hi <= self.flat.numel():
@@ -69,6 +75,7 @@ class BucketedAllReduce:
         self._works.clear()
         covered = sorted(self.launched)
         self.launched = []
+        self.last_buckets = covered                         # (what the step just sent: tests look at it)
         pos = 0
         for lo, hi in covered:              # every entry of the gradient exactly once
             if lo != pos:

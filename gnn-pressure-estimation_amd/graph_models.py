@@ -131,8 +131,7 @@ class _GATResFunction(torch.autograd.Function):
             # kernel even though it writes activations nobody reads -- give it a cached throw-away buffer
             saved = module._eval_saved_for(plan)
         stream = _native.current_stream(x.device)
-        plan.bind(module._cmodel_ref())
-        _native.check(lib.gatres_model_forward(module._cmodel_ref(), plan.ref(), module._flat.data_ptr(), x.data_ptr(),
+        _native.check(lib.gatres_model_forward(module._cmodel_ref(), plan.ref(module._cmodel_ref()), module._flat.data_ptr(), x.data_ptr(),
                                                None, out.data_ptr(), _native.ptr(saved), scratch.data_ptr(), stream),
                       "gatres_model_forward")
         ctx.module, ctx.plan, ctx.saved_acts = module, plan, saved
@@ -154,8 +153,7 @@ class _GATResFunction(torch.autograd.Function):
         g_x = torch.empty_like(x) if ctx.needs_input_grad[3] else None
         scratch = module._scratch_for(plan)
         stream = _native.current_stream(x.device)
-        plan.bind(module._cmodel_ref())
-        _native.check(lib.gatres_model_backward(module._cmodel_ref(), plan.ref(), module._flat.data_ptr(), x.data_ptr(),
+        _native.check(lib.gatres_model_backward(module._cmodel_ref(), plan.ref(module._cmodel_ref()), module._flat.data_ptr(), x.data_ptr(),
                                                 None, g_out.data_ptr(), saved.data_ptr(), scratch.data_ptr(),
                                                 grads.data_ptr(), _native.ptr(g_x), stream), "gatres_model_backward")
         # one C++ call instead of 182 Python slice+view pairs: views of `grads` shaped like the parameters

@@ -94,6 +94,9 @@ class GraphPlan:
         self.device = device
         self._host = host if segments else None          # kept for the part tables (bind)
         self._part_tables: Dict[int, Tuple[torch.Tensor, int]] = {}
+        self._bound: Dict[int, "_native.GatresGraph"] = {}          # workgroups per segment -> struct copy with its part tables
+        import threading
+        self._bind_lock = threading.Lock()
         self.arrays: Dict[str, torch.Tensor] = {k: v.to(device) for k, v in host.items()}
         seg_dev_ptr = None
         if segments:
@@ -109,41 +112,50 @@ class GraphPlan:
                                      perm_dev_ptr,
                                      (C.c_int32 * 7)(*self.windows[21:28]), 0, None, 0, 0)
 
-    def bind(self, cmodel_ref) -> None:
-        """Attach the part tables (``gatres_graph_t.part_tables``) for the split the fused kernels will use with this
+    def bound(self, cmodel_ref) -> "_native.GatresGraph":
+        """The plan struct WITH the part tables (``gatres_graph_t.part_tables``) for the split the fused kernels use with this
         model: built once per (plan, workgroups per segment) on the host by ``gatres_graph_part_tables_host`` and kept on
-        the device.  Without them the window kernel derives the same tables in every launch (GATRES_NO_PART_TABLES=1
-        keeps it that way: the two must agree, tests/test_gpu_model.py)."""
+        the device.  Every split has its OWN immutable copy of the struct (binding used to rewrite the one shared
+        struct on every forward / backward -- a data race for a cached plan used by two modules or threads); ``self.c`` is
+        never modified.  Without tables (GATRES_NO_PART_TABLES=1, unsplit or oversized segments) the window kernel derives
+        the same tables in every launch: the two must agree, tests/test_gpu_model.py."""
         if self._host is None or self.num_segments <= 0 or os.environ.get("GATRES_NO_PART_TABLES"):
-            self.c.part_tables, self.c.part_tables_m, self.c.part_tables_stride = None, 0, 0
-            return
+            return self.c
         lib = _native.load()
-        m = int(lib.gatres_fused_cus_per_segment(cmodel_ref, self.ref()))
+        m = int(lib.gatres_fused_cus_per_segment(cmodel_ref, C.byref(self.c)))
         if m < 2 or m > 8 or self.max_segment_nodes > 65535:
-            self.c.part_tables, self.c.part_tables_m, self.c.part_tables_stride = None, 0, 0
-            return
-        if self.c.part_tables and self.c.part_tables_m == m:
-            return
-        entry = self._part_tables.get(m)
-        if entry is None:
+            return self.c
+        with self._bind_lock:
+            got = self._bound.get(m)
+            if got is not None:
+                return got
             ptrs = [self._host[k].data_ptr() for k in ("rowptr", "col", "t_rowptr", "t_eid", "t_dst", "m_rowptr", "m_col",
                                                        "mt_rowptr", "mt_dst")]
             stride = C.c_int64(0)
             rc = lib.gatres_graph_part_tables_host(*ptrs, self.segment_ptr_host.data_ptr(), self.num_segments, m, None, 0,
                                                    C.byref(stride))
             if rc != 0:                  # (segments beyond the 16-bit tables: the kernels do not take them either)
-                self.c.part_tables, self.c.part_tables_m, self.c.part_tables_stride = None, 0, 0
-                return
+                self._bound[m] = self.c
+                return self.c
             words = torch.zeros(self.num_segments * m * int(stride.value), dtype=torch.int32)
             _native.check(lib.gatres_graph_part_tables_host(*ptrs, self.segment_ptr_host.data_ptr(), self.num_segments, m,
                                                             words.data_ptr(), int(stride.value), C.byref(stride)),
                           "gatres_graph_part_tables_host")
-            entry = (words.to(self.device), int(stride.value))
-            self._part_tables[m] = entry
-        self.c.part_tables, self.c.part_tables_m, self.c.part_tables_stride = entry[0].data_ptr(), m, entry[1]
+            dev = words.to(self.device)
+            self._part_tables[m] = (dev, int(stride.value))
+            c = _native.GatresGraph.from_buffer_copy(self.c)
+            c.part_tables, c.part_tables_m, c.part_tables_stride = dev.data_ptr(), m, int(stride.value)
+            self._bound[m] = c
+            return c
 
-    def ref(self):
-        return C.byref(self.c)
+    def bind(self, cmodel_ref) -> None:
+        """Build (once) the part tables this model's split needs; ``ref(cmodel_ref)`` then hands out the struct that has them."""
+        self.bound(cmodel_ref)
+
+    def ref(self, cmodel_ref=None):
+        """``gatres_graph_t*`` for a C call: the bare plan, or -- given the model -- the copy that carries the part tables
+        of that model's split."""
+        return C.byref(self.c if cmodel_ref is None else self.bound(cmodel_ref))
 
     def window_rows(self, parts: int) -> int:
         """Rows of the largest part window when a segment is carried by ``parts`` (2 .. 8) workgroups; 0 = unknown."""

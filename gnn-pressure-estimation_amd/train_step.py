@@ -23,6 +23,7 @@ from .graph_plan import GraphPlan
 
 PHASE_MASK, PHASE_FORWARD, PHASE_BACKWARD, PHASE_ADAM = 1, 2, 4, 8
 PART_FIRST, PART_LAST, PART_REDUCE = 1, 2, 4
+FLAG_PER_OP, FLAG_WT_VALID, FLAG_GRADS_DEFERRED, FLAG_GRADS_ONLY = 1, 2, 4, 8
 MAX_CACHED_GRAPHS = 8
 
 
@@ -36,7 +37,8 @@ class _TrainStepC(C.Structure):
                 ("out", C.c_void_p), ("g_out", C.c_void_p), ("loss", C.c_void_p), ("saved", C.c_void_p),
                 ("scratch", C.c_void_p),
                 ("lr", C.c_double), ("beta1", C.c_double), ("beta2", C.c_double), ("eps", C.c_double),
-                ("weight_decay", C.c_double), ("grad_scale", C.c_float), ("flags", C.c_int32)]
+                ("weight_decay", C.c_double), ("grad_scale", C.c_float), ("flags", C.c_int32),
+                ("hparams", C.c_void_p), ("block_lo", C.c_int32), ("block_hi", C.c_int32)]
 
 
 class GATResTrainer:
@@ -60,20 +62,25 @@ class GATResTrainer:
         self.device = dev
         self.plan: GraphPlan = GraphPlan(edge_index, num_nodes, device=dev, segments=fused)
         self.fused = bool(fused and self.lib.gatres_fused_supported(model._cmodel_ref(), self.plan.ref()))
-        if self.fused:
-            self.plan.bind(model._cmodel_ref())
+        # the plan struct this trainer's launches take: with the part tables of this model's split on the fused path
+        self._gstruct = self.plan.bound(model._cmodel_ref()) if self.fused else self.plan.c
         N = num_nodes
         self.N = N
         self.P = params.numel()
         f32 = dict(dtype=torch.float32, device=dev)
         self.grads = torch.zeros(self.P, **f32)
+        self.hparams = dict(lr=lr, weight_decay=weight_decay, beta1=betas[0], beta2=betas[1], eps=eps)
         if _share_state_with is not None:            # a sibling trainer for another batch size: ONE optimizer state
             self.exp_avg, self.exp_avg_sq = _share_state_with.exp_avg, _share_state_with.exp_avg_sq
             self.step_counter = _share_state_with.step_counter
+            self.hp = _share_state_with.hp
         else:
             self.exp_avg = torch.zeros(self.P, **f32)
             self.exp_avg_sq = torch.zeros(self.P, **f32)
             self.step_counter = torch.zeros(2, dtype=torch.int64, device=dev)
+            # the hyper-parameters the update kernels read (gatres_train_step_t.hparams): a captured step follows
+            # set_lr() without being captured again
+            self.hp = torch.tensor(self._hp_list(), dtype=torch.float64, device=dev)
         self.x = torch.zeros(N, **f32)
         # targets_are_inputs: the reference's snapshots have data.y == data.x until the loop masks x (train.py:162-166),
         # and the masking happens inside the kernels here (x itself is never overwritten): one buffer serves both
@@ -87,7 +94,6 @@ class GATResTrainer:
         self.scratch = model._scratch_for(self.plan)
         self.node_ptr = self.plan.node_ptr_for(nodes_per_graph) if nodes_per_graph is not None else None
         self.num_graphs = len(nodes_per_graph) if nodes_per_graph is not None else 0
-        self.hparams = dict(lr=lr, weight_decay=weight_decay, beta1=betas[0], beta2=betas[1], eps=eps)
         self.pg = process_group
         self.world, self.rank = 1, 0
         if process_group is not None or (torch.distributed.is_available() and torch.distributed.is_initialized()):
@@ -101,6 +107,7 @@ class GATResTrainer:
             dp.broadcast_params_(params, src=0, group=process_group)      # identical replicas, whatever each rank initialised
         self.reducer = dp.BucketedAllReduce(self.grads, process_group, force=force_collective_path) if self.split else None
         self.blocks_per_bucket = int(blocks_per_bucket)
+        self.fused_buckets = 2                       # gradient buckets of the fused path's data-parallel step (1: one piece)
         # Multi-rank steps run as EAGER launch sequences unless GATRES_DP_GRAPH=1: a captured step would hold the RCCL
         # all-reduce, which has only ever been captured with a one-rank group here (no multi-GPU box is reachable), and
         # eager costs nothing on this path (one-rank nccl group, gatres_small bs 32: 0.428 ms/step eager vs 0.432 captured;
@@ -112,23 +119,36 @@ class GATResTrainer:
         self._wt_sig = None
         self._siblings: Dict[int, "GATResTrainer"] = {}
         off = self.lib.gatres_fused_status_offset(model._cmodel_ref(), self.plan.ref()) if self.fused else -1
-        self._status = self.scratch[off:off + 3].view(torch.int32) if off >= 0 else None
+        self._status = self.scratch[off:off + 4].view(torch.int32) if off >= 0 else None
+        # the fused path's parameter gradients can be formed range by range (a bucket's all-reduce starts in between)
+        self._ranges = bool(self.fused and self.lib.gatres_fused_finish_folds(model._cmodel_ref(), self.plan.ref()))
 
     # ------------------------------------------------------------------------------------------
-    def _desc(self, phases: int, device_mask: bool, wt_valid: bool = False) -> _TrainStepC:
+    def _hp_list(self):
+        h = self.hparams
+        return [h["lr"], h["beta1"], h["beta2"], h["eps"], h["weight_decay"]]
+
+    def _push_hparams(self) -> None:
+        """Host values -> the device buffer (one small stream-ordered copy; never inside a capture)."""
+        self.hp.copy_(torch.tensor(self._hp_list(), dtype=torch.float64), non_blocking=False)
+
+    def _desc(self, phases: int, device_mask: bool, wt_valid: bool = False, flags: int = 0, block_lo: int = 0,
+              block_hi: int = 0) -> _TrainStepC:
         m = self.model
         params = m.flat_parameters
         if params.data_ptr() != self._params_ptr:
             raise RuntimeError("the model's parameter storage moved (e.g. .to()/deepcopy); build a new GATResTrainer")
         h = self.hparams
         return _TrainStepC(
-            _native.GatresModel(m.num_blocks, m.nc, m._cmodel.act_dtype, 0), C.pointer(self.plan.c), params.data_ptr(), self.grads.data_ptr(),
+            _native.GatresModel(m.num_blocks, m.nc, m._cmodel.act_dtype, 0), C.pointer(self._gstruct), params.data_ptr(), self.grads.data_ptr(),
             self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr(), self.step_counter.data_ptr(), self.x.data_ptr(),
             self.y.data_ptr(), self.mask.data_ptr(),
             self.node_ptr.data_ptr() if (device_mask and self.node_ptr is not None) else None,
             self.num_graphs, phases, self.mask_rate, self.seed, self.out.data_ptr(), self.g_out.data_ptr(),
             self.loss.data_ptr(), self.saved.data_ptr(), self.scratch.data_ptr(), h["lr"], h["beta1"], h["beta2"],
-            h["eps"], h["weight_decay"], 1.0 / self.world, (0 if self.fused else 1) | (2 if wt_valid else 0))
+            h["eps"], h["weight_decay"], 1.0 / self.world,
+            (0 if self.fused else FLAG_PER_OP) | (FLAG_WT_VALID if wt_valid else 0) | flags, self.hp.data_ptr(),
+            block_lo, block_hi)
 
     def _count_native_update(self) -> None:
         """A native kernel (fused Adam pass, Adam-only phase) just changed the parameters without touching torch's
@@ -156,24 +176,40 @@ class GATResTrainer:
         self._wt_sig = None
 
     def set_lr(self, lr: float) -> None:
-        """Learning-rate schedules (the reference runs ReduceLROnPlateau, train.py:349-350,510).  Hyper-parameters are
-        kernel arguments baked into a captured hipGraph, so the graph cache is keyed by them: a new value captures a
-        new graph (milliseconds, once per distinct value), an old value finds its graph again."""
-        self.hparams["lr"] = float(lr)
+        """Learning-rate schedules (the reference runs ReduceLROnPlateau, train.py:349-350,510).  The update kernels read
+        the hyper-parameters from a device buffer (``gatres_train_step_t.hparams``), so the captured step is NOT captured
+        again: the new value is one 40-byte copy in stream order."""
+        self.set_hparams(lr=lr)
 
     def set_hparams(self, **kw) -> None:
+        changed = False
         for k, v in kw.items():
             if k == "mask_rate":
                 self.mask_rate = float(v)
             elif k in self.hparams:
+                changed = changed or self.hparams[k] != float(v)
                 self.hparams[k] = float(v)
             else:
                 raise KeyError(k)
+        if changed:
+            self._push_hparams()
+            for t in self._siblings.values():          # (they share the buffer; keep their host copies in step)
+                t.hparams = dict(self.hparams)
 
     def _graph_key(self, what, device_mask: bool, wt_valid: bool) -> tuple:
-        h = self.hparams
-        return (what, device_mask, wt_valid, h["lr"], h["weight_decay"], h["beta1"], h["beta2"], h["eps"], self.mask_rate,
-                self.seed, self.world)
+        # (no hyper-parameter in here: the kernels read them from self.hp)
+        return (what, device_mask, wt_valid, self.mask_rate, self.seed, self.world)
+
+    @property
+    def num_captured_graphs(self) -> int:
+        return len(self._graphs)
+
+    @property
+    def dropped_steps(self) -> int:
+        """Data-parallel steps whose update was skipped because the all-reduced gradient carried a fault mark -- the mark is
+        "entry 0 is NaN", so a diverging run that puts a NaN there shows up here too (it would otherwise freeze silently:
+        ADVICE r3).  Synchronises."""
+        return int(self._status[3].item()) if self._status is not None else 0
 
     @property
     def fault_count(self) -> int:
@@ -181,8 +217,9 @@ class GATResTrainer:
         NaN, no update).  Synchronises."""
         return int(self._status[1].item()) if self._status is not None else 0
 
-    def _enqueue(self, phases: int, device_mask: bool, wt_valid: bool = False) -> None:
-        ts = self._desc(phases, device_mask, wt_valid)
+    def _enqueue(self, phases: int, device_mask: bool, wt_valid: bool = False, flags: int = 0, block_lo: int = 0,
+                 block_hi: int = 0) -> None:
+        ts = self._desc(phases, device_mask, wt_valid, flags, block_lo, block_hi)
         _native.check(self.lib.gatres_train_step(C.byref(ts), _native.current_stream(self.device)),
                       "gatres_train_step")
 
@@ -230,8 +267,19 @@ class GATResTrainer:
                 import warnings
                 warnings.warn(f"hipGraph capture of the data-parallel step failed ({type(e).__name__}: {e}); "
                               f"continuing with eager launches")
+                try:                                   # (a failed capture may leave the stream in capture mode: end it)
+                    if torch.cuda.is_current_stream_capturing():
+                        g.capture_end()
+                except Exception:                      # noqa: BLE001
+                    pass
                 torch.cuda.synchronize(self.device)
                 rollback()
+                if wt_valid:
+                    # the warm-up step left the transposes of ITS updated weights in scratch and the parameters were
+                    # rolled back: re-derive them, or this eager step's backward would use W^T of other weights
+                    _native.check(self.lib.gatres_fused_prepare_backward(
+                        self.model._cmodel_ref(), C.byref(self._gstruct), self.model.flat_parameters.data_ptr(),
+                        self.scratch.data_ptr(), _native.current_stream(self.device)), "gatres_fused_prepare_backward")
                 self.use_graph = False
                 self._graphs.clear()
                 enqueue()
@@ -241,7 +289,7 @@ class GATResTrainer:
                 # the warm-up step left the transposes of ITS updated weights in scratch; the parameters were rolled
                 # back, so make the promise this graph relies on true again
                 _native.check(self.lib.gatres_fused_prepare_backward(
-                    self.model._cmodel_ref(), self.plan.ref(), self.model.flat_parameters.data_ptr(),
+                    self.model._cmodel_ref(), C.byref(self._gstruct), self.model.flat_parameters.data_ptr(),
                     self.scratch.data_ptr(), _native.current_stream(self.device)), "gatres_fused_prepare_backward")
             self._graphs[key] = g
             while len(self._graphs) > MAX_CACHED_GRAPHS:
@@ -261,10 +309,29 @@ class GATResTrainer:
         path (gatres_large, large graphs): forward, then one piece per ``blocks_per_bucket`` blocks in reverse order,
         each ending with the slab reduction of exactly its parameters."""
         if self.fused:
-            def whole():
-                self._enqueue((0 if premasked else PHASE_MASK) | PHASE_FORWARD | PHASE_BACKWARD, device_mask, wt_valid)
-                return 0, self.P
-            return [whole]
+            m = self.model
+            head = (0 if premasked else PHASE_MASK) | PHASE_FORWARD | PHASE_BACKWARD
+            if not self._ranges or m.num_blocks < 2 or self.fused_buckets < 2:
+                def whole():
+                    self._enqueue(head, device_mask, wt_valid)
+                    return 0, self.P
+                return [whole]
+            # Two pieces: the backward chain + the parameter gradients of the UPPER blocks (whose bucket closes the flat
+            # vector: it carries lin1), then the lower blocks (+ lin0).  The first bucket's all-reduce runs on the process
+            # group's stream while the second launch forms the rest of the gradient (SURVEY 8(e): "a single bucket launched
+            # after the last K1b and hidden behind ..."): 130 KB on the wire under ~19 us of kernel.
+            k = m.num_blocks // 2
+            cut = 2 * m.nc + k * (9 * m.nc + 4 * m.nc * m.nc)
+
+            def upper():
+                self._enqueue(head, device_mask, wt_valid, flags=FLAG_GRADS_DEFERRED)
+                self._enqueue(PHASE_BACKWARD, device_mask, flags=FLAG_GRADS_ONLY, block_lo=k, block_hi=m.num_blocks)
+                return cut, self.P
+
+            def lower():
+                self._enqueue(PHASE_BACKWARD, device_mask, flags=FLAG_GRADS_ONLY, block_lo=0, block_hi=k)
+                return 0, cut
+            return [upper, lower]
         m = self.model
         pieces = []
         for k, (b_hi, b_lo, lo, hi) in enumerate(dp.block_buckets(m.num_blocks, m.nc, self.blocks_per_bucket)):
@@ -273,7 +340,7 @@ class GATResTrainer:
                     self._enqueue((0 if premasked else PHASE_MASK) | PHASE_FORWARD, device_mask)
                 flags = PART_REDUCE | (PART_FIRST if b_hi == m.num_blocks else 0) | (PART_LAST if b_lo == 0 else 0)
                 _native.check(self.lib.gatres_model_backward_per_op_part(
-                    m._cmodel_ref(), self.plan.ref(), m.flat_parameters.data_ptr(), self.x.data_ptr(),
+                    m._cmodel_ref(), C.byref(self._gstruct), m.flat_parameters.data_ptr(), self.x.data_ptr(),
                     self.mask.data_ptr(), self.g_out.data_ptr(), self.saved.data_ptr(), self.scratch.data_ptr(),
                     self.grads.data_ptr(), None, b_hi, b_lo, flags, _native.current_stream(self.device)),
                     "gatres_model_backward_per_op_part")

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define GATRES_ABI_VERSION 3
+#define GATRES_ABI_VERSION 4
 
 #define GATRES_E_BADARG      (-1)  /* null pointer, negative size, misaligned pointer            */
 #define GATRES_E_UNSUPPORTED (-2)  /* width not supported by the gfx950 kernels                  */
@@ -455,6 +455,25 @@ int gatres_fused_finish(const gatres_model_t* m, const gatres_graph_t* g, float*
                         const float* loss_part, float* loss, int32_t do_adam, float* params, float* exp_avg,
                         float* exp_avg_sq, uint64_t* step_counter, double lr, double beta1, double beta2,
                         double eps, double weight_decay, float grad_scale, void* stream);
+/* The same with the hyper-parameters read from `hparams` (device double[5] {lr, beta1, beta2, eps, weight_decay}) when it
+ * is not NULL. */
+int gatres_fused_finish_hp(const gatres_model_t* m, const gatres_graph_t* g, float* scratch, float* grads,
+                           const float* loss_part, float* loss, int32_t do_adam, float* params, float* exp_avg,
+                           float* exp_avg_sq, uint64_t* step_counter, double lr, double beta1, double beta2,
+                           double eps, double weight_decay, const double* hparams, float grad_scale, void* stream);
+/* gatres_fused_param_grads + gatres_fused_finish as ONE launch, for blocks [block_lo, block_hi) of the model (the whole
+ * model: 0, num_blocks): every (block, conv) column's last workgroup sums the column's slab rows, writes grads and (do_adam)
+ * applies Adam to those parameters; lin0's gradient rides on block 0, lin1's on the last block, so the ranges
+ * [0, p(block_hi)) ... tile the flat vector like gatres_model_backward_per_op_part's.  do_adam needs the whole model in one
+ * call.  Returns GATRES_E_UNSUPPORTED where the two-launch form has to be used (nc other than 16 / 32, or parameter
+ * gradients formed on consumer workgroups of the backward launch: batches that leave CUs free). */
+/* 1 if gatres_fused_param_grads_finish applies to this model / plan (else it returns GATRES_E_UNSUPPORTED). */
+int gatres_fused_finish_folds(const gatres_model_t* m, const gatres_graph_t* g);
+int gatres_fused_param_grads_finish(const gatres_model_t* m, const gatres_graph_t* g, const float* saved, float* scratch,
+                                    float* grads, const float* loss_part, float* loss, int32_t do_adam, float* params,
+                                    float* exp_avg, float* exp_avg_sq, uint64_t* step_counter, double lr, double beta1,
+                                    double beta2, double eps, double weight_decay, const double* hparams,
+                                    float grad_scale, int32_t block_lo, int32_t block_hi, void* stream);
 
 /* --------------------------------------------------------------------------------------------------------
  * One reference training iteration (train.py:159-190) enqueued natively:
@@ -495,8 +514,20 @@ typedef struct gatres_train_step {
   double lr, beta1, beta2, eps, weight_decay;
   float grad_scale;                /* multiplies grads inside Adam (1/world_size)        */
   int32_t flags;                   /* GATRES_FLAG_PER_OP: force the per-op kernels       */
+  const double* hparams;           /* device double[5] {lr, beta1, beta2, eps, weight_decay}, or NULL.  When set, the update
+                                    * kernels read the hyper-parameters from it INSTEAD of the five host values above, so a
+                                    * captured step follows a learning-rate schedule (train.py:349-350,510) without being
+                                    * captured again                                                                     */
+  int32_t block_lo, block_hi;      /* GATRES_FLAG_GRADS_ONLY: the blocks whose parameter gradients this call forms       */
 } gatres_train_step_t;
 #define GATRES_FLAG_PER_OP 1
+/* Fused path, PHASE_BACKWARD: stop after the backward chain; the caller forms the parameter gradients itself, range by
+ * range, with gatres_fused_param_grads_finish (the data-parallel step: a bucket's all-reduce starts between two ranges). */
+#define GATRES_FLAG_GRADS_DEFERRED 4
+/* Fused path, PHASE_BACKWARD: ONLY the parameter gradients of blocks [block_lo, block_hi) from the kept tables of a
+ * GRADS_DEFERRED backward (gatres_fused_param_grads_finish, no Adam; the launch that holds the last block also writes the
+ * loss).  Needs gatres_fused_finish_folds(). */
+#define GATRES_FLAG_GRADS_ONLY 8
 /* The transposed conv weights in `scratch` already match `params`: true right after a fused PHASE_ADAM step on the
  * same scratch (its Adam pass rewrites them) as long as nobody else has touched the parameters; skips the transposes. */
 #define GATRES_FLAG_WT_VALID 2

@@ -128,7 +128,9 @@ def test_two_rank_training_equals_global_batch(pkg, oracle, tmp_path):
 
 def test_shard_assignment(pkg):
     assert [list(pkg.dp.shard_graphs(256, r, 8))[:2] for r in (0, 7)] == [[0, 1], [224, 225]]
-    assert len(pkg.dp.shard_graphs(35, 3, 4)) == 8                       # ragged tail dropped: equal shards
+    with pytest.raises(ValueError, match="does not split evenly"):       # never silently
+        pkg.dp.shard_graphs(35, 3, 4)
+    assert len(pkg.dp.shard_graphs(35, 3, 4, drop_ragged=True)) == 8     # ragged tail dropped on request: equal shards
     with pytest.raises(ValueError):
         pkg.dp.shard_graphs(8, 2, 2)
 

@@ -1,0 +1,216 @@
+"""The benchmarked path itself, pinned: BASELINE config 2 -- gatres_small (15 x 32), C-Town-sized
+snapshots, batch_size 32, fp32 -- through ``GATResTrainer.step`` with hipGraph replay, 8 CUs per snapshot and the folded
+parameter-gradient / update launch, against the oracle's training loop (train.py:159-190) under identical host masks.
+Also here: the pieces of the step that round 4 changed -- hyper-parameters in a device buffer, the one-launch parameter
+gradients + slab sum + Adam against the two-launch form, the fused path's two gradient buckets, counted dropped steps.
+
+The checker is the oracle (parity unpinned: never held to PyG output)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+from test_gpu_model import build, note, relerr
+
+pytestmark = pytest.mark.gpu
+NB, NC, BS, NODES, PIPES = 15, 32, 32, 388, 430
+
+
+def _trainer(pkg, oracle, seed=3, bs=BS, **kw):
+    model, p = build(pkg, oracle, NB, NC, seed=seed)
+    ei = pkg.wdn_synth.collate_edge_index(pkg.wdn_synth.make_wdn_topology(NODES, PIPES, seed=0), NODES, bs)
+    tr = pkg.GATResTrainer(model, ei.cuda(), NODES * bs, nodes_per_graph=[NODES] * bs, **kw)
+    return model, p, tr, ei
+
+
+def test_headline_config_training_steps_vs_oracle(pkg, oracle, lib):
+    model, p, tr, ei = _trainer(pkg, oracle, use_graph=True)
+    # the configuration the bench line reports: window kernel at 8 CUs per snapshot, the parameter gradients as a launch of
+    # their own (no consumer workgroups at bs 32) that also carries the slab sum and Adam
+    assert tr.fused and tr.use_graph
+    assert lib.gatres_fused_cus_per_segment(model._cmodel_ref(), tr.plan.ref()) == 8
+    assert lib.gatres_fused_window_kernel(model._cmodel_ref(), tr.plan.ref()) == 1
+    assert lib.gatres_fused_finish_folds(model._cmodel_ref(), tr.plan.ref()) == 1
+    ref = oracle.OracleTrainer(p)
+    snaps = pkg.wdn_synth.make_snapshots(3 * BS, NODES, seed=6)
+    rng = np.random.RandomState(1)
+    errs = []
+    for it in range(3):
+        y = pkg.wdn_synth.collate_snapshots(snaps, range(it * BS, (it + 1) * BS))
+        mask = torch.from_numpy(pkg.wdn_synth.generate_batch_mask([NODES] * BS, 0.95, rng))
+        if it == 0:
+            # fp64 arbiter for the step-0 gradient (as test_forward_backward_parity): a tensor may be off the fp64 gradient by
+            # twice what the fp32 oracle itself is off, or by the noise floor of its own / the whole gradient's scale
+            xin = y.double().clone()
+            xin[mask] = 0
+
+            def grads64(params64):
+                l = {k: v.clone().requires_grad_(True) for k, v in params64.items()}
+                o = oracle.gatres_forward(l, xin, ei, num_blocks=NB)
+                torch.nn.functional.mse_loss(o[mask], y.double()[mask]).backward()
+                return {k: v.grad for k, v in l.items()}
+
+            p64 = {k: v.double() for k, v in p.items()}
+            g64 = grads64(p64)
+        l_ref, o_ref = ref.step(y.clone(), y, ei, mask)
+        loss = tr.step(y.cuda(), y.cuda(), mask.cuda())
+        e_out, e_loss = relerr(tr.out, o_ref), relerr(loss, l_ref)
+        errs.append((e_out, e_loss))
+        assert e_out < 1e-5 and e_loss < 1e-5, (it, e_out, e_loss)
+        if it == 0:
+            g_hip = tr.grads.detach().cpu().double()
+            e_flat = relerr(tr.grads, ref.flat("grads"))
+            assert e_flat < 1e-4, e_flat
+            def judge(gref):
+                gscale = max(float(v.abs().max()) for v in gref.values())
+                off, bad, worst = 0, [], 0.0
+                for k, v in ref.params.items():
+                    n = v.numel()
+                    e_hip = float((g_hip[off:off + n] - gref[k].reshape(-1)).abs().max())
+                    e_ref = float((v.grad.double().reshape(-1) - gref[k].reshape(-1)).abs().max())
+                    floor = max(1e-5 * float(gref[k].abs().max()), 2e-6 * gscale)
+                    if e_hip > max(2 * e_ref, floor):
+                        bad.append((k, e_hip, e_ref, floor))
+                    worst = max(worst, e_hip / gscale)
+                    off += n
+                return bad, worst
+
+            bad, worst = judge(g64)
+            branch, bad0 = 0, bad
+            # The network is piecewise linear: a pre-activation within fp32 round-off of a ReLU / LeakyReLU kink makes the
+            # gradient BIMODAL, and the kernels (fused and per-op alike: tests/micro/grad_err_probe.py) may stand on the other
+            # side of it than the fp32 oracle does -- at this very point one conv1 output of block 8 does, and row 12 of its
+            # weight gradient differs by 5.6e-5 (4.3e-5 allowed).  Such a tensor is excused ONLY by a demonstrated kink: an
+            # fp64 gradient at parameters perturbed by 1e-7 (relative) that (i) jumps on that tensor by more than the
+            # tolerance floor against the unperturbed fp64 gradient and (ii) agrees with the kernels' gradient within the
+            # usual tolerance on EVERY tensor.
+            gen = torch.Generator().manual_seed(1234)
+            while bad and branch < 12:
+                branch += 1
+                pert = {k: v * (1 + 1e-7 * torch.randn(v.shape, generator=gen, dtype=torch.float64)) for k, v in p64.items()}
+                gb = grads64(pert)
+                bad, worst_b = judge(gb)
+                if not bad:
+                    for k, _, _, floor in bad0:
+                        jump = float((gb[k] - g64[k]).abs().max())
+                        assert jump > floor, (k, jump, floor, "the excuse must be a kink the fp64 oracle itself shows")
+                    worst = worst_b
+            assert not bad, (bad[:3], bad0[:3], branch)
+            note("headline config (15x32, bs 32, hipGraph, 8 CUs/snapshot, folded update) step 0: flat grad vs oracle32 / "
+                 "worst tensor error over |g|max vs fp64 / fp64 kink branch used (0 = none)", [e_flat, worst, branch])
+    assert tr.optimizer_step == 3 and tr.fault_count == 0
+    assert tr.num_captured_graphs <= 2          # (one before / one after scratch's transposed weights became current)
+    diff = (model.flat_parameters.detach().cpu().double() - ref.flat("params").double()).abs()
+    note("headline config, 3 steps: worst out / loss error vs oracle, max |dp|, fraction of params off by > 1e-5",
+         [max(e[0] for e in errs), max(e[1] for e in errs), float(diff.max()), float((diff > 1e-5).double().mean())])
+    assert float(diff.max()) <= 3 * 5e-4 * 1.01 and float((diff > 1e-5).double().mean()) < 0.01
+
+
+def test_set_lr_follows_a_schedule_without_recapture(pkg, oracle):
+    """ReduceLROnPlateau (train.py:349-350,510): three learning rates, ONE family of captured graphs -- the update kernels
+    read the hyper-parameters from the trainer's device buffer -- and every step bit-identical to eager launches."""
+    model, p, tr, ei = _trainer(pkg, oracle, use_graph=True)
+    twin, _, tr2, _ = _trainer(pkg, oracle, use_graph=False)
+    y = pkg.wdn_synth.make_snapshots(BS, NODES, seed=9).reshape(-1).cuda()
+    mask = torch.from_numpy(pkg.wdn_synth.generate_batch_mask([NODES] * BS, 0.95, np.random.RandomState(3))).cuda()
+    seen = []
+    for lr in (5e-4, 5e-4, 1e-4, 2.5e-5, 2.5e-5, 5e-4):
+        tr.set_lr(lr); tr2.set_lr(lr)
+        tr.step(y, y, mask); tr2.step(y, y, mask)
+        assert torch.equal(model.flat_parameters, twin.flat_parameters), lr
+        seen.append(tr.num_captured_graphs)
+    assert seen[-1] == seen[1] <= 2, seen                      # nothing was captured for the later learning rates
+    # ... and the value really is used: the same step at lr / 10 moves the parameters a tenth as far
+    before = model.flat_parameters.clone()
+    tr.set_lr(5e-5); tr.step(y, y, mask)
+    d_small = (model.flat_parameters - before).abs().max()
+    model.flat_parameters.copy_(before); tr.invalidate_weights()
+    assert float(d_small) < 5e-5 * 1.01 * 3
+
+
+def test_folded_update_equals_the_two_launch_form(pkg, oracle, lib):
+    """param_grads_finish_kernel (parameter gradients + slab sum + Adam in one launch, the column's last workgroup doing the
+    sum) against gatres_fused_param_grads + gatres_fused_finish: gradients, parameters, moments and the transposed weights
+    bit for bit, three steps in a row, and again range by range without Adam."""
+    from gnn_pressure_estimation_amd import train_step as TS
+    y = pkg.wdn_synth.make_snapshots(BS, NODES, seed=11).reshape(-1).cuda()
+    mask = torch.from_numpy(pkg.wdn_synth.generate_batch_mask([NODES] * BS, 0.95, np.random.RandomState(5))).cuda()
+    runs = []
+    for folded in (True, False):
+        model, p, tr, ei = _trainer(pkg, oracle, use_graph=False)
+        st = pkg._native.current_stream(tr.device)
+        m, g = model._cmodel_ref(), tr.plan.ref(model._cmodel_ref())
+        h = tr.hparams
+        hist = []
+        for it in range(3):
+            tr.load_batch(y, y, mask)
+            tr._enqueue(TS.PHASE_FORWARD | TS.PHASE_BACKWARD, False, flags=TS.FLAG_GRADS_DEFERRED)
+            tail = (1, model.flat_parameters.data_ptr(), tr.exp_avg.data_ptr(), tr.exp_avg_sq.data_ptr(),
+                    tr.step_counter.data_ptr(), h["lr"], h["beta1"], h["beta2"], h["eps"], h["weight_decay"])
+            if folded:
+                pkg._native.check(lib.gatres_fused_param_grads_finish(m, g, tr.saved.data_ptr(), tr.scratch.data_ptr(),
+                                                                      tr.grads.data_ptr(), None, None, *tail, None, 1.0, 0, NB,
+                                                                      st), "folded")
+            else:
+                pkg._native.check(lib.gatres_fused_param_grads(m, g, tr.saved.data_ptr(), tr.scratch.data_ptr(), st), "pg")
+                pkg._native.check(lib.gatres_fused_finish(m, g, tr.scratch.data_ptr(), tr.grads.data_ptr(), None, None, *tail,
+                                                          1.0, st), "finish")
+            torch.cuda.synchronize()
+            hist.append((tr.grads.clone(), model.flat_parameters.clone(), tr.exp_avg.clone(), tr.exp_avg_sq.clone()))
+        assert tr.optimizer_step == 3
+        runs.append(hist)
+    for it in range(3):
+        for a, b, what in zip(runs[0][it], runs[1][it], ("grads", "params", "exp_avg", "exp_avg_sq")):
+            assert torch.equal(a, b), (it, what, float((a - b).abs().max()))
+    # range by range (the data-parallel step's two buckets), no Adam: the same gradient
+    model, p, tr, ei = _trainer(pkg, oracle, use_graph=False)
+    tr.load_batch(y, y, mask)
+    tr._enqueue(TS.PHASE_FORWARD | TS.PHASE_BACKWARD, False, flags=TS.FLAG_GRADS_DEFERRED)
+    tr.grads.fill_(float("nan"))
+    tr._enqueue(TS.PHASE_BACKWARD, False, flags=TS.FLAG_GRADS_ONLY, block_lo=7, block_hi=NB)
+    tr._enqueue(TS.PHASE_BACKWARD, False, flags=TS.FLAG_GRADS_ONLY, block_lo=0, block_hi=7)
+    torch.cuda.synchronize()
+    assert torch.equal(tr.grads, runs[0][0][0])
+    assert tr.optimizer_step == 0 and torch.isfinite(tr.loss).all()
+
+
+def test_fused_data_parallel_step_has_two_buckets_and_equals_the_plain_step(pkg, oracle):
+    """SURVEY 8(e) / VERDICT r3 item 3: on the fused path the gradient leaves in TWO buckets -- the upper blocks' (with
+    lin1) while the lower blocks' launch runs -- and the sequence [chain | grads hi | all-reduce hi || grads lo | all-reduce
+    lo | Adam] gives exactly the single-call step at world size 1 (eager and captured)."""
+    snaps = pkg.wdn_synth.make_snapshots(3 * BS, NODES, seed=8).cuda()
+    for use_graph in (False, True):
+        res = []
+        for split in (False, True):
+            model, p, tr, ei = _trainer(pkg, oracle, seed=2, use_graph=use_graph, force_collective_path=split)
+            tr.seed = 77
+            assert tr.split == split
+            losses = []
+            for it in range(3):
+                y = snaps[it * BS:(it + 1) * BS].reshape(-1)
+                losses.append(float(tr.step(y, y)))
+                if split:
+                    cut = 2 * NC + (NB // 2) * (9 * NC + 4 * NC * NC)
+                    assert tr.reducer.last_buckets == [(0, cut), (cut, tr.P)], tr.reducer.last_buckets
+            res.append((losses, model.flat_parameters.clone(), tr.mask.clone(), tr.grads.clone()))
+        assert res[0][0] == res[1][0], use_graph
+        assert torch.equal(res[0][1], res[1][1]) and torch.equal(res[0][2], res[1][2]) and torch.equal(res[0][3], res[1][3])
+
+
+def test_dropped_data_parallel_steps_are_counted(pkg, oracle):
+    """the data-parallel Adam phase drops a step whose gradient carries the fault mark (entry 0 is NaN) -- a
+    diverging run that puts a NaN there is dropped too, and that must be visible: ``dropped_steps`` counts it."""
+    from gnn_pressure_estimation_amd import train_step as TS
+    model, p, tr, ei = _trainer(pkg, oracle, bs=2, use_graph=False, force_collective_path=True)
+    y = pkg.wdn_synth.make_snapshots(2, NODES, seed=2).reshape(-1).cuda()
+    tr.step(y, y)
+    assert tr.dropped_steps == 0 and tr.optimizer_step == 1
+    before = model.flat_parameters.clone()
+    tr.grads[0] = float("nan")
+    tr._enqueue(TS.PHASE_ADAM, True)
+    torch.cuda.synchronize()
+    assert tr.dropped_steps == 1 and tr.optimizer_step == 1
+    assert torch.equal(model.flat_parameters, before)
+    tr.step(y, y)                                               # the next step is a normal one again
+    assert tr.dropped_steps == 1 and tr.optimizer_step == 2 and torch.isfinite(tr.loss).all()

@@ -599,7 +599,7 @@ def test_part_tables_equal_in_kernel_derivation(pkg, oracle, directed, monkeypat
             monkeypatch.setenv("GATRES_NO_PART_TABLES", "1")
         model, _ = build(pkg, oracle, nb, nc, seed=3, fused=True)
         tr = pkg.GATResTrainer(model, ei.cuda(), N, nodes_per_graph=[388] * bs, use_graph=False)
-        assert bool(tr.plan.c.part_tables) == (not no_tables)
+        assert bool(tr._gstruct.part_tables) == (not no_tables) and not tr.plan.c.part_tables      # (the shared struct is never rewritten)
         assert (tr.plan.flags & 1) == (0 if directed else 1)
         lib = pkg._native.load()
         assert lib.gatres_fused_window_kernel(model._cmodel_ref(), tr.plan.ref()) == 1

@@ -112,16 +112,39 @@ def _single_main(out_dir, case):
                os.path.join(out_dir, "single.pt"))
 
 
+def _free_port():
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _run_all(procs, timeout=600):
+    """Start, join, and NEVER leave a child behind (a rank that hangs would keep spinning on the GPU after the test)."""
+    try:
+        for p in procs:
+            p.start()
+        for p in procs:
+            p.join(timeout)
+        codes = [p.exitcode for p in procs]
+        assert all(c == 0 for c in codes), f"rank processes failed or timed out (exit codes {codes})"
+    finally:
+        for p in procs:
+            if p.is_alive():
+                p.terminate()
+                p.join(10)
+                if p.is_alive():
+                    p.kill()
+                    p.join(10)
+
+
 @pytest.mark.parametrize("case", ["fused", "per_op"])
 def test_trainer_at_world_size_two_on_one_gpu(case, tmp_path, fork_ctx):
-    world, port = 2, 29600 + (os.getpid() * 7 + len(case)) % 2000
-    procs = [fork_ctx.Process(target=_rank_main, args=(r, world, port, str(tmp_path), case)) for r in range(world)]
-    procs.append(fork_ctx.Process(target=_single_main, args=(str(tmp_path), case)))
-    for p in procs:
-        p.start()
-    for p in procs:
-        p.join(600)
-        assert p.exitcode == 0, f"a rank process failed (exit code {p.exitcode})"
+    world, port = 2, _free_port()
+    # The single-process reference runs BEFORE the two ranks, not beside them: the split launches spin-wait for their
+    # partners and need their whole grid resident (three processes at once needed 240 of the 256 CUs: ADVICE r3).
+    _run_all([fork_ctx.Process(target=_single_main, args=(str(tmp_path), case))])
+    _run_all([fork_ctx.Process(target=_rank_main, args=(r, world, port, str(tmp_path), case)) for r in range(world)])
     r0, r1 = torch.load(tmp_path / "r0.pt"), torch.load(tmp_path / "r1.pt")
     one = torch.load(tmp_path / "single.pt")
     assert not torch.equal(r0["mine"], r1["mine"])                                   # the ranks were initialised differently
