@@ -186,6 +186,23 @@ def load(build_if_missing: bool = True) -> C.CDLL:
     return lib
 
 
+def load_unchecked(path: str) -> C.CDLL:
+    """DIAGNOSTIC TOOLS ONLY (tests/micro/*.py): make an arbitrary build of the library the process's library -- an older
+    build for an A/B measurement, a probe build with in-kernel stamps.  No ABI / build-id check; must be called before
+    anything else loads the library.  The product never calls this and no environment variable leads here."""
+    global _LIB
+    if _LIB is not None:
+        raise RuntimeError("the library is already loaded")
+    lib = C.CDLL(os.path.abspath(path))
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name, None)
+        if fn is not None:
+            fn.restype = res
+            fn.argtypes = args
+    _LIB = lib
+    return lib
+
+
 def _reopen(path: str) -> C.CDLL:
     """dlopen caches by path: after a rebuild in the same process, load the new file through a private copy."""
     import shutil

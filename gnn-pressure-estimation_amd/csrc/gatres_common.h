@@ -10,39 +10,51 @@
 #define GATRES_SOFTMAX_EPS 1e-16f    // torch_geometric.utils.softmax: out_sum + 1e-16
 #define GATRES_WAVE 64
 
-// Tuning / fallback switches of the library, read from the environment ONCE (first use) -- never on a launch path.  A
-// process that changes the environment afterwards (the tests do) calls gatres_knobs_reload().  Switches that produce WRONG
-// results exist only in the diagnostic build (GATRES_DIAG_BUILD).
+// The DIAGNOSTIC build of the library (-DGATRES_DIAG_BUILD: _build.build_native(diag=True) -> lib/libgatres_hip_diag.so,
+// loaded when GATRES_DIAG_LIB=1) carries stage stamps, the switches that produce WRONG results and every switch that selects
+// a measured-and-lost alternative; the product build carries none of them.
+#ifdef GATRES_DIAG_BUILD
+#define GATRES_DIAG 1
+#else
+#define GATRES_DIAG 0
+#endif
+
+// Switches of the library, read from the environment ONCE (first use) -- never on a launch path.  A process that changes
+// the environment afterwards (the tests do) calls gatres_knobs_reload().
+// PRODUCT switches (ten; each one selects a path that some plan / model takes on its own, so each has a test that forces
+// it -- tests named in DESIGN.md section 8):
 struct gatres_knobs_t {
-  int agg_lane_features;      // GATRES_AGG_LANE_FEATURES = 4 | 8 (0: automatic)
+  int fused_split;            // GATRES_FUSED_SPLIT = 1 .. 8: workgroups per snapshot (0: automatic)
+  int fused_safe_sync;        // GATRES_FUSED_SAFE_SYNC: always agent-scope hand-offs (what parts on different XCDs get)
+  int fused_no_halo;          // GATRES_FUSED_NO_HALO: whole-segment kernel, bulk pulls (what an overflowing halo list gets)
+  int fused_no_consumers;     // GATRES_FUSED_NO_CONSUMERS: parameter gradients as a launch of their own (what a full chip gets)
+  int fused_no_rounds;        // GATRES_FUSED_NO_ROUNDS: 49 .. 96 segments resident at fewer parts instead of two rounds
+  int agg_lane_features;      // GATRES_AGG_LANE_FEATURES = 4 | 8 (0: automatic -- 8 for rows of 64 features and more)
+  int lin_bwd_wave;           // GATRES_LIN_BWD_WAVE: lin0 / lin1 backward, one wave per slab (what odd widths get)
+  int no_proj_lds;            // GATRES_NO_PROJ_LDS: fp32 projections without the LDS copy of W (what small batches get)
+  int dw_1d;                  // GATRES_DW_1D: bf16 weight gradients, one matrix per workgroup (what narrow models get)
+  int side_stream;            // GATRES_SIDE_STREAM = 0 | 1: the per-op backward's parameter-gradient launches never / always on
+                              // the library's side stream (-1, unset: where it was measured faster -- fp32, nc >= 128)
+  // DIAGNOSTIC build only (fixed at the defaults in the product build): measured-and-lost alternatives, tuning sweeps and the
+  // switches that give WRONG results
   int agg_wide_offsets;       // GATRES_AGG_WIDE_OFFSETS
   int fused_threads;          // GATRES_FUSED_THREADS = 512 (default 1024)
   int fused_no_window;        // GATRES_FUSED_NO_WINDOW
-  int fused_split;            // GATRES_FUSED_SPLIT = 1 .. 8 (0: automatic)
   int fused_prefer_consumers; // GATRES_FUSED_PREFER_CONSUMERS
-  int fused_no_consumers;     // GATRES_FUSED_NO_CONSUMERS
   int fused_consumers_cap;    // GATRES_FUSED_CONSUMERS (default 2, at most 4)
   int fused_nocache;          // GATRES_FUSED_NOCACHE
-  int fused_wide;             // GATRES_FUSED_WIDE (diagnostic build only: nc > 32 on the per-snapshot kernels)
-  int fused_safe_sync;        // GATRES_FUSED_SAFE_SYNC: always agent-scope hand-offs (slower, never wrong)
-  int fused_no_halo;          // GATRES_FUSED_NO_HALO: whole-segment kernel, bulk pulls instead of halo lists
+  int fused_wide;             // GATRES_FUSED_WIDE (nc > 32 on the per-snapshot kernels)
   int fused_no_keep;          // GATRES_FUSED_NO_KEEP
   int fused_heartbeat;        // GATRES_FUSED_HEARTBEAT: pace the hand-offs by heartbeat granules even on symmetric plans
-  int fused_no_rounds;        // GATRES_FUSED_NO_ROUNDS: 33 .. 96 segments at the parts that fit the chip at once instead of 8 parts round by round
   int param_grads_no_stream;  // GATRES_PARAM_GRADS_NO_STREAM
-  int lin_bwd_wave;           // GATRES_LIN_BWD_WAVE
   int proj_rows;              // GATRES_PROJ_ROWS (0: default)
-  int proj_stream;            // GATRES_PROJ_STREAM=1: bf16 projections of gatres_large by proj_bf16_stream_kernel (measured, not the default)
-  int no_proj_lds;            // GATRES_NO_PROJ_LDS
-  int dw_1d;                  // GATRES_DW_1D
+  int proj_stream;            // GATRES_PROJ_STREAM=1: bf16 projections of gatres_large by proj_bf16_stream_kernel
   int dw_fp32;                // GATRES_DW_FP32
   int no_co_launch;           // GATRES_NO_CO_LAUNCH
   int co_launch_always;       // GATRES_CO_LAUNCH_ALWAYS
   int dw_slab_rows;           // GATRES_DW_SLAB_ROWS (0: default)
-  int side_stream;            // GATRES_SIDE_STREAM = 0 | 1: the per-op backward's parameter-gradient launches never / always on the
-                              // library's side stream (-1, unset: where it was measured faster -- fp32, nc >= 128)
-  int xch_nowait;             // diagnostic build only, WRONG results: GATRES_XCH_NOWAIT
-  int diag_nomask;            // diagnostic build only, WRONG results: GATRES_DIAG_NOMASK
+  int xch_nowait;             // WRONG results: GATRES_XCH_NOWAIT
+  int diag_nomask;            // WRONG results: GATRES_DIAG_NOMASK
 };
 extern "C" __attribute__((visibility("hidden"))) const gatres_knobs_t* gatres_knobs();
 

@@ -84,8 +84,7 @@ enum { PH_LOSS = 16 };
 // Stage stamps and the knobs that produce WRONG results (never-wait exchanges, unmasked dX epilogues) exist only in the
 // diagnostic build of the library (-DGATRES_DIAG_BUILD: _build.build_native(diag=True) -> lib/libgatres_hip_diag.so,
 // loaded when GATRES_DIAG_LIB=1); the product build carries neither the code nor the registers they cost.
-#ifdef GATRES_DIAG_BUILD
-#define GATRES_DIAG 1
+#if GATRES_DIAG
 #define STAMPS_PTR (a.stamps)
 #define STAMP()                                                                                  \
   do {                                                                                           \
@@ -93,7 +92,6 @@ enum { PH_LOSS = 16 };
       a.stamps[stamp_i++] = wall_clock64();                                                      \
   } while (0)
 #else
-#define GATRES_DIAG 0
 #define STAMPS_PTR (static_cast<unsigned long long*>(nullptr))
 #define STAMP() do {} while (0)
 #endif

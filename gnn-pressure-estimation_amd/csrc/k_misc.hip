@@ -19,38 +19,42 @@ std::mutex g_knobs_mu;
 int env_flag(const char* n) { const char* e = getenv(n); return (e && *e && !(e[0] == '0' && !e[1])) ? 1 : 0; }
 int env_int(const char* n, int dflt) { const char* e = getenv(n); return (e && *e) ? atoi(e) : dflt; }
 void read_knobs(gatres_knobs_t* k) {
+  // product switches
+  k->fused_split = env_int("GATRES_FUSED_SPLIT", 0);
+  k->fused_safe_sync = env_flag("GATRES_FUSED_SAFE_SYNC");
+  k->fused_no_halo = env_flag("GATRES_FUSED_NO_HALO");
+  k->fused_no_consumers = env_flag("GATRES_FUSED_NO_CONSUMERS");
+  k->fused_no_rounds = env_flag("GATRES_FUSED_NO_ROUNDS");
   const int lf = env_int("GATRES_AGG_LANE_FEATURES", 0);
   k->agg_lane_features = (lf == 4 || lf == 8) ? lf : 0;
+  k->lin_bwd_wave = env_flag("GATRES_LIN_BWD_WAVE");
+  k->no_proj_lds = env_flag("GATRES_NO_PROJ_LDS");
+  k->dw_1d = env_flag("GATRES_DW_1D");
+  k->side_stream = env_int("GATRES_SIDE_STREAM", -1);
+  // diagnostic build only
+  k->agg_wide_offsets = 0; k->fused_threads = 1024; k->fused_no_window = 0; k->fused_prefer_consumers = 0;
+  k->fused_consumers_cap = 2; k->fused_nocache = 0; k->fused_wide = 0; k->fused_no_keep = 0; k->fused_heartbeat = 0;
+  k->param_grads_no_stream = 0; k->proj_rows = 0; k->proj_stream = 0; k->dw_fp32 = 0; k->no_co_launch = 0;
+  k->co_launch_always = 0; k->dw_slab_rows = 0; k->xch_nowait = 0; k->diag_nomask = 0;
+#ifdef GATRES_DIAG_BUILD
   k->agg_wide_offsets = env_flag("GATRES_AGG_WIDE_OFFSETS");
   k->fused_threads = env_int("GATRES_FUSED_THREADS", 1024) == 512 ? 512 : 1024;
   k->fused_no_window = env_flag("GATRES_FUSED_NO_WINDOW");
-  k->fused_split = env_int("GATRES_FUSED_SPLIT", 0);
   k->fused_prefer_consumers = env_flag("GATRES_FUSED_PREFER_CONSUMERS");
-  k->fused_no_consumers = env_flag("GATRES_FUSED_NO_CONSUMERS");
   { const int c = env_int("GATRES_FUSED_CONSUMERS", 2); k->fused_consumers_cap = c < 4 ? c : 4; }
   k->fused_nocache = env_flag("GATRES_FUSED_NOCACHE");
-  k->fused_safe_sync = env_flag("GATRES_FUSED_SAFE_SYNC");
-  k->fused_no_halo = env_flag("GATRES_FUSED_NO_HALO");
+  k->fused_wide = env_flag("GATRES_FUSED_WIDE");
   k->fused_no_keep = env_flag("GATRES_FUSED_NO_KEEP");
   k->fused_heartbeat = env_flag("GATRES_FUSED_HEARTBEAT");
-  k->fused_no_rounds = env_flag("GATRES_FUSED_NO_ROUNDS");
   k->param_grads_no_stream = env_flag("GATRES_PARAM_GRADS_NO_STREAM");
-  k->lin_bwd_wave = env_flag("GATRES_LIN_BWD_WAVE");
   k->proj_rows = (env_int("GATRES_PROJ_ROWS", 0) + 63) & ~63;
   k->proj_stream = env_flag("GATRES_PROJ_STREAM");
-  k->no_proj_lds = env_flag("GATRES_NO_PROJ_LDS");
-  k->dw_1d = env_flag("GATRES_DW_1D");
   k->dw_fp32 = env_flag("GATRES_DW_FP32");
   k->no_co_launch = env_flag("GATRES_NO_CO_LAUNCH");
   k->co_launch_always = env_flag("GATRES_CO_LAUNCH_ALWAYS");
   k->dw_slab_rows = env_int("GATRES_DW_SLAB_ROWS", 0);
-  k->side_stream = env_int("GATRES_SIDE_STREAM", -1);
-#ifdef GATRES_DIAG_BUILD
-  k->fused_wide = env_flag("GATRES_FUSED_WIDE");
   k->xch_nowait = env_flag("GATRES_XCH_NOWAIT");
   k->diag_nomask = env_flag("GATRES_DIAG_NOMASK");
-#else
-  k->fused_wide = 0; k->xch_nowait = 0; k->diag_nomask = 0;
 #endif
 }
 }  // namespace

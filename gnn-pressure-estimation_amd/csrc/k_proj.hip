@@ -680,6 +680,8 @@ __global__ __launch_bounds__(512, 4) void proj_bf16_tile_kernel(const gatres_bf1
   }
 }
 
+#if GATRES_DIAG      // (measured, not faster than proj_bf16_tile_kernel: DESIGN.md section 3.3; kept as the measured alternative)
+
 #ifdef PROJ_STAMPS
 __device__ unsigned long long g_pstamps[512 * 8 * 8];
 #define PSTAMP(k) do { if (lane == 0) g_pstamps[(blockIdx.x * 8 + wave) * 8 + (k)] = wall_clock64(); } while (0)
@@ -860,11 +862,14 @@ __global__ __launch_bounds__(512, 2) void proj_bf16_stream_kernel(const gatres_b
   PSTAMP(6);
 }
 
+#endif      // GATRES_DIAG
+
 template <int K, int M, int H, int EPI>
 int launch_proj_bf16(const gatres_bf16* X, const gatres_bf16* Wm, gatres_bf16* OUT, int N, const float* att_src,
                      const float* att_dst, float* a_src, float* a_dst, const gatres_bf16* resid,
                      const gatres_bf16* relu_ref, hipStream_t st) {
   if constexpr (K % 128 == 0 && (M == 128 || M == 256) && (M / H) % 32 == 0) {
+#if GATRES_DIAG
     // gatres_large's widths: W slices in registers, x tiles streamed through LDS (proj_bf16_stream_kernel)
     if (!gatres_knobs()->proj_rows && gatres_knobs()->proj_stream) {
       constexpr int TILEB = 16 * K * 2, G = M / 32, TG = 8 / G;
@@ -883,6 +888,7 @@ int launch_proj_bf16(const gatres_bf16* X, const gatres_bf16* Wm, gatres_bf16* O
                          att_dst, a_src, a_dst, resid, relu_ref);
       return gatres_launch_status();
     }
+#endif
   }
   if constexpr (K % 32 == 0 && M % 128 == 0 && M <= 256 && (EPI != EPI_ATT || (M / H) == 128 || (M / H) == 64 || (M / H) == 32)) {
     // wide outputs: 16-row wave tiles walked in passes of 128 columns, 512-thread workgroups, two per CU (proj_bf16_tile_kernel)

@@ -114,7 +114,10 @@ def rel(a, b):
     return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-30))
 
 
-def replay(path, reference_root, tol):
+def replay(path, reference_root, tol, out_dir=None, versions=None):
+    """``out_dir``: where ``<fixture>.pyg.npz`` goes (default: beside the fixture); ``versions``: (torch_geometric version
+    string) when the model does not come from an installed torch_geometric -- the CPU suite's self-test of this script runs
+    it over a stand-in module (tests/test_host_logic.py)."""
     d = np.load(path)
     nb, nc = int(d["num_blocks"]), int(d["nc"])
     model = load_reference_model(reference_root, nb, nc)
@@ -133,28 +136,32 @@ def replay(path, reference_root, tol):
     grads = flat_from(model, nb, nc, grads=True)
     opt.step()
     after = flat_from(model, nb, nc)
-    import torch_geometric
-    errs = {"out": rel(out.detach().numpy(), d["out"]), "loss": rel(float(loss), float(d["loss"])),
+    if versions is None:
+        import torch_geometric
+        versions = str(torch_geometric.__version__)
+    errs = {"out": rel(out.detach().numpy(), d["out"]), "loss": rel(float(loss.detach()), float(d["loss"])),
             "grads": rel(grads, d["grads"]), "params_after_abs": float(np.abs(after - d["params_after"]).max())}
-    np.savez_compressed(path[:-4] + ".pyg.npz", out=out.detach().numpy(), loss=np.float32(float(loss)), grads=grads,
+    target = os.path.join(out_dir, os.path.basename(path)[:-4] + ".pyg.npz") if out_dir else path[:-4] + ".pyg.npz"
+    np.savez_compressed(target, out=out.detach().numpy(), loss=np.float32(float(loss.detach())), grads=grads,
                         params_after=after, torch_version=str(torch.__version__),
-                        torch_geometric_version=str(torch_geometric.__version__))
+                        torch_geometric_version=versions)
     ok = errs["out"] < tol and errs["loss"] < tol and errs["grads"] < 10 * tol and errs["params_after_abs"] < 1e-5
-    print(f"{os.path.basename(path)}: PyG {torch_geometric.__version__} vs oracle: out {errs['out']:.2e}  loss {errs['loss']:.2e}  "
+    print(f"{os.path.basename(path)}: PyG {versions} vs oracle: out {errs['out']:.2e}  loss {errs['loss']:.2e}  "
           f"grads {errs['grads']:.2e}  |params_after| {errs['params_after_abs']:.2e}  ->  {'OK' if ok else 'MISMATCH'}")
     return ok
 
 
-def main():
+def main(argv=None):
     ap = argparse.ArgumentParser(description=__doc__.split("\n\n")[0])
     ap.add_argument("--reference", default="/root/reference", help="root of the DiTEC-project/gnn-pressure-estimation checkout")
     ap.add_argument("--tol", type=float, default=1e-5, help="relative tolerance on predictions / loss (north star: 1e-5)")
     ap.add_argument("--fixtures", nargs="*", default=None)
-    args = ap.parse_args()
+    ap.add_argument("--out-dir", default=None, help="write the *.pyg.npz files here instead of beside the fixtures")
+    args = ap.parse_args(argv)
     torch.manual_seed(0)
     paths = args.fixtures or sorted(os.path.join(HERE, f) for f in os.listdir(HERE)
                                     if f.endswith(".npz") and not f.endswith(".pyg.npz") and "wdn" not in f)
-    ok = all([replay(p, args.reference, args.tol) for p in paths])
+    ok = all([replay(p, args.reference, args.tol, out_dir=args.out_dir) for p in paths])
     sys.exit(0 if ok else 1)
 
 

@@ -1,6 +1,6 @@
 """Hub rows in the per-op sparse kernels: times the five k_aggregate.hip kernels on a graph with a heavy-tailed degree
 distribution (a few nodes with hundreds to thousands of incident edges) and on a uniform graph of the same size.
-GATRES_LIB=<path> loads another build of the library (A/B against the pre-hub-path kernels).
+--lib <path> loads another build of the library (A/B against the pre-hub-path kernels; _native.load_unchecked).
     python tests/micro/hub_bench.py [--nodes 50000] [--edges 400000] [--hubs 32] [--hub-degree 1500]"""
 import argparse
 import json
@@ -12,8 +12,9 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import gnn_pressure_estimation_amd as G                      # noqa: E402
 
-if os.environ.get("GATRES_LIB"):
-    G._build.LIB_PATH = os.path.abspath(os.environ["GATRES_LIB"])
+if "--lib" in sys.argv:
+    G._native.load_unchecked(sys.argv[sys.argv.index("--lib") + 1])
+    del sys.argv[sys.argv.index("--lib"):sys.argv.index("--lib") + 2]
 from tests import hipops as ops                               # noqa: E402
 
 

@@ -297,3 +297,25 @@ def test_wide_projection_on_many_rows_matches_the_tile_kernel(ops, K, H, C, monk
     assert float((h1.double() - h64).abs().max() / h64.abs().max()) < 1e-6
     s64 = (h64.view(n, H, C) * a_s.double().view(1, H, C)).sum(-1)
     assert float((s1.double() - s64).abs().max() / s64.abs().max()) < 1e-5
+
+
+def test_side_stream_fork_join_gives_the_same_gradients(pkg, oracle, monkeypatch):
+    """GATRES_SIDE_STREAM (product switch): the per-op backward's parameter-gradient launches on the library's side stream
+    (fork / join through events; the default for fp32 at nc >= 128) or on the caller's stream -- the same launches, the same
+    bits, also across repeated calls (the join guard must leave no launch of one call running into the next)."""
+    from test_gpu_model import build
+    x, y, ei, mask = pkg.wdn_synth.make_batch(3, 120, 140)
+    res = []
+    for v in ("0", "1"):
+        monkeypatch.setenv("GATRES_SIDE_STREAM", v)
+        model, _ = build(pkg, oracle, 3, 32, seed=5, fused=False)
+        gs = []
+        for rep in range(3):
+            model.zero_grad()
+            out = model(x.cuda(), ei.cuda())
+            out.backward(torch.ones_like(out) * (rep + 1))
+            gs.append(torch.cat([q.grad.reshape(-1) for q in model.parameters()]).clone())
+        torch.cuda.synchronize()
+        res.append(gs)
+    for a, b in zip(*res):
+        assert torch.isfinite(a).all() and torch.equal(a, b)

@@ -311,3 +311,97 @@ def test_oracle_matches_pyg_replay(oracle, name):
     rel = lambda a, b: float(np.abs(a - b).max() / np.abs(b).max())
     assert rel(d["out"], r["out"]) < 1e-5 and abs(float(d["loss"]) - float(r["loss"])) < 1e-5 * abs(float(r["loss"]))
     assert rel(d["grads"], r["grads"]) < 1e-4
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# tests/golden/replay_pyg.py is the one committed way to pin the oracle against PyG; it has never run where PyG exists.
+# So that it is known to WORK the day somebody has torch_geometric: its argument parsing, its state_dict mapping for both
+# PyG spellings and its whole replay loop run here over stand-in modules that have PyG's parameter names.
+# ---------------------------------------------------------------------------------------------------------------------
+def _replay_module():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("replay_pyg", os.path.join(GOLDEN, "replay_pyg.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+class _StandInConv(torch.nn.Module):
+    """Parameter names of torch_geometric.nn.GATConv: ``lin_src`` + ``lin_dst`` registered as the SAME Linear (PyG 2.3 / 2.4,
+    int in_channels) or a single ``lin`` (PyG >= 2.5)."""
+
+    def __init__(self, cin, heads, c, concat, spelling):
+        super().__init__()
+        lin = torch.nn.Linear(cin, heads * c, bias=False)
+        if spelling == "lin_src":
+            self.lin_src = lin
+            self.lin_dst = lin
+        else:
+            self.lin = lin
+        self.att_src = torch.nn.Parameter(torch.zeros(1, heads, c))
+        self.att_dst = torch.nn.Parameter(torch.zeros(1, heads, c))
+        self.bias = torch.nn.Parameter(torch.zeros(heads * c if concat else c))
+
+
+class _StandInBlock(torch.nn.Module):
+    def __init__(self, nc, spelling):
+        super().__init__()
+        self.conv1 = _StandInConv(nc, 2, nc, True, spelling)
+        self.conv2 = _StandInConv(2 * nc, 1, nc, False, spelling)
+
+
+class _StandInGATRes(torch.nn.Module):
+    """The reference module's parameter tree (GraphModels.py:472-484) over the ORACLE's arithmetic: what replay_pyg.py
+    would get from the reference, minus torch_geometric."""
+
+    def __init__(self, oracle, nb, nc, spelling):
+        super().__init__()
+        self.oracle, self.nb = oracle, nb
+        self.lin0 = torch.nn.Linear(1, nc)
+        self.blocks = torch.nn.ModuleList([_StandInBlock(nc, spelling) for _ in range(nb)])
+        self.lin1 = torch.nn.Linear(nc, 1)
+
+    def forward(self, x, edge_index, batch=None, edge_attr=None):
+        named = dict(self.named_parameters())
+        p = {}
+        for key in self.oracle.param_shapes(self.nb, self.lin0.out_features):
+            k = key
+            if k not in named:
+                k = key.replace("lin_src.weight", "lin.weight")
+            p[key] = named[k]
+        return self.oracle.gatres_forward(p, x, edge_index, num_blocks=self.nb)
+
+
+@pytest.mark.parametrize("spelling", ["lin_src", "lin"])
+def test_replay_pyg_script_runs_over_a_stand_in_module(oracle, spelling, tmp_path, monkeypatch, capsys):
+    R = _replay_module()
+    with pytest.raises(SystemExit) as e:                                  # argument parsing
+        R.main(["--help"])
+    assert e.value.code == 0 and "--reference" in capsys.readouterr().out
+    fixture = os.path.join(GOLDEN, "tiny_nb2_nc8.npz")
+    d = np.load(fixture)
+    nb, nc = int(d["num_blocks"]), int(d["nc"])
+    # state_dict mapping, both PyG spellings: every key of the module is filled, the flat vector comes back unchanged
+    model = _StandInGATRes(oracle, nb, nc, spelling)
+    keys = set(model.state_dict())
+    assert (f"blocks.0.conv1.{spelling}.weight" in keys) and (("blocks.0.conv1.lin_dst.weight" in keys) == (spelling == "lin_src"))
+    R.fill_state_dict(model, d["params"], nb, nc)
+    assert np.array_equal(R.flat_from(model, nb, nc), d["params"])
+    if spelling == "lin_src":
+        assert model.blocks[0].conv1.lin_src.weight is model.blocks[0].conv1.lin_dst.weight
+    # the whole replay (train.py:159-190 on the fixture's batch), with the stand-in where the reference import would be
+    monkeypatch.setattr(R, "load_reference_model", lambda root, nb_, nc_: _StandInGATRes(oracle, nb_, nc_, spelling))
+    assert R.replay(fixture, "/nonexistent", 1e-5, out_dir=str(tmp_path), versions="stand-in") is True
+    r = np.load(tmp_path / "tiny_nb2_nc8.pyg.npz")
+    assert str(r["torch_geometric_version"]) == "stand-in"
+    for k in ("out", "grads", "params_after"):
+        assert r[k].shape == d[k].shape
+    assert float(np.abs(r["out"] - d["out"]).max()) < 1e-6 and float(np.abs(r["grads"] - d["grads"]).max()) < 1e-5 * float(np.abs(d["grads"]).max()) + 1e-9
+    # a reference checkout without torch_geometric: the script must say so, not crash
+    monkeypatch.undo()
+    R2 = _replay_module()
+    try:
+        import torch_geometric  # noqa: F401
+    except ImportError:
+        with pytest.raises(SystemExit, match="torch_geometric is not installed"):
+            R2.load_reference_model("/nonexistent", nb, nc)
