@@ -54,7 +54,6 @@ SIGNATURES = {
     "gatres_graph_segments_host": (C.c_int, [_P, _I64, _I64, _I32, _P] + [C.POINTER(_I32)] * 4),
     "gatres_graph_windows_host": (C.c_int, [_P, _I64, _I64, _P, _I32, _P]),
     "gatres_graph_reorder_host": (C.c_int, [_P, _I64, _I64, _P, _I32, _P]),
-    "gatres_graph_refine_parts_host": (C.c_int, [_P, _I64, _I64, _P, _I32, _I32, _P]),
     "gatres_lz4_decompress_host": (_I64, [_P, _I64, _P, _I64]),
     "gatres_edge_index_hash": (C.c_int, [_P, _I64, _P, _P]),
     "gatres_permute_f32": (C.c_int, [_P, _P, _P, _I32, _I32, _P]),
