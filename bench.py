@@ -67,6 +67,9 @@ def parse():
     ap.add_argument("--drop-in", action="store_true",
                     help="time the reference loop body verbatim (train.py:160-188): nn.Module forward, loss.backward(), "
                          "torch.optim.Adam, host-side numpy mask, a fresh edge_index tensor every batch")
+    ap.add_argument("--copy-batches", action="store_true",
+                    help="stage every batch into the trainer's buffer (GATResTrainer.step(x, y): one more launch per step) "
+                         "instead of training on the resident batches in place (bind_batches / step_bound)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--no-roofline", action="store_true")
@@ -495,15 +498,19 @@ def main():
     if args.host_batches:
         batches = [b.cpu().pin_memory() for b in batches]
         trainer.prefetch_batch(batches[0])
+    elif not args.copy_batches:
+        trainer.bind_batches(batches)               # the captured step reads the resident batches in place (no staging copy)
 
     def one_step(i):
         if args.host_batches:                       # batch i was prefetched during step i - 1; start fetching i + 1
             trainer.commit_batch()
             trainer.prefetch_batch(batches[(i + 1) % nbatches])
             trainer.run_step(device_mask=True)
-        else:                                       # device-resident batch: the reference-shaped call (train.py:159-190)
-            b = batches[i % nbatches]
+        elif args.copy_batches:                     # device-resident batch through the reference-shaped call (train.py:159-190):
+            b = batches[i % nbatches]               # staged into the trainer's own buffer by one extra launch
             trainer.step(b, b)
+        else:
+            trainer.step_bound(i % nbatches)
 
     def fence():
         torch.cuda.synchronize(device)
@@ -557,7 +564,8 @@ def main():
                                f"{'RCCL all-reduce -> ' if trainer.split else ''}Adam), "
                                f"{'per-op kernels' if not trainer.fused else f'fused per-snapshot kernel ({cus} CUs per snapshot, ' + ('row-window' if window else 'whole-segment') + ' tables)'}, "
                                f"{'eager launches' if args.no_graph else 'hipGraph replay'}"
-                               f"{', batches from SnapshotStore.fit_epoch' if store is not None else ''}",
+                               f"{', batches from SnapshotStore.fit_epoch' if store is not None else ''}"
+                               f"{', batches staged by copy' if args.copy_batches else ''}",
                    "global_batch": world * args.batch_size, "parallelism": f"dp{world}",
                    "plan_relabelled": trainer.plan.perm_host is not None, "row_window": trainer.plan.window_rows(cus) if cus >= 2 else None,
                    "dropped_steps": trainer.fault_count + trainer.dropped_steps, "final_loss": loss},

@@ -116,7 +116,7 @@ SIGNATURES = {
     "gatres_fused_run": (C.c_int, [_MP, _GP] + [_P] * 10 + [_I32, _P]),
     "gatres_fused_param_grads": (C.c_int, [_MP, _GP, _P, _P, _P]),
     "gatres_fused_finish": (C.c_int, [_MP, _GP] + [_P] * 4 + [_I32] + [_P] * 4 + [_F64] * 5 + [_F32, _P]),
-    "gatres_fused_finish_hp": (C.c_int, [_MP, _GP] + [_P] * 4 + [_I32] + [_P] * 4 + [_F64] * 5 + [_P, _F32, _P]),
+    "gatres_fused_finish_hp": (C.c_int, [_MP, _GP] + [_P] * 4 + [_I32] + [_P] * 4 + [_F64] * 5 + [_P, _F32, _P, _I32, _F64, _U64, _P, _P]),
     "gatres_fused_finish_folds": (C.c_int, [_MP, _GP]),
     "gatres_fused_param_grads_finish": (C.c_int, [_MP, _GP] + [_P] * 5 + [_I32] + [_P] * 4 + [_F64] * 5 +
                                         [_P, _F32, _I32, _I32, _P]),

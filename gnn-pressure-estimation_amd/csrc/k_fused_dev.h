@@ -1184,6 +1184,11 @@ struct ParamGradArgs {
   Layout L;
   SegLayout SL;
   const float* wt = nullptr;                  // (consumer_item_dma: the transposed conv weights, gatres_fused_prepare_backward)
+  // param_grads_stream_kernel, training step: workgroup 0 copies the optimizer's step count and the split launches' fault word
+  // into snap[0..1] -- stable words for the sampling tail of the update launch that follows (reduce_adam_kernel)
+  const unsigned long long* step_counter = nullptr;
+  const unsigned* status = nullptr;
+  unsigned long long* snap = nullptr;
   unsigned long long* dstamps = nullptr;      // diagnostic (consumer 0 under gatres_fused_set_stamps): steps inside an item
 };
 
@@ -1472,6 +1477,10 @@ template <int NC>
 __global__ __launch_bounds__(PGS_THREADS) void param_grads_stream_kernel(const ParamGradArgs a) {
   __shared__ __attribute__((aligned(16))) float lds[PGS_NBUF * CI_CR * (3 * NC + 4)];
   const int conv = blockIdx.x & 1, b = (blockIdx.x >> 1) % a.L.nb, seg = (blockIdx.x >> 1) / a.L.nb;
+  if (a.snap && blockIdx.x == 0 && threadIdx.x == 0) {
+    a.snap[0] = a.step_counter ? __hip_atomic_load(a.step_counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ULL;
+    a.snap[1] = a.status ? (unsigned long long)__hip_atomic_load(a.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ULL;
+  }
   if (conv == 0) consumer_item_dma<NC, PGS_THREADS, 0, PGS_NBUF>(a, seg, b, lds);
   else           consumer_item_dma<NC, PGS_THREADS, 1, PGS_NBUF>(a, seg, b, lds);
   if (a.M > 1 && b == 0 && conv == 0) {

@@ -1,6 +1,7 @@
 // Host side of the fused per-snapshot path: launch geometry, the deferred parameter-gradient launch, the slab reduction +
 // Adam launch, and the C-ABI entry points (include/gatres.h: gatres_fused_*).
 #include "k_fused_dev.h"
+#include "k_mask.h"
 
 // the kernels live in translation units of their own (k_window.hip, k_fused_whole.hip); args: const FusedArgs*
 extern "C" __attribute__((visibility("hidden"))) int gatres_fused_launch_window(const void* args, int nc, unsigned grid, void* stream);
@@ -21,26 +22,49 @@ __global__ __launch_bounds__(256) void reduce_adam_kernel(const float* __restric
                                                           unsigned long long* __restrict__ step_counter, double lr,
                                                           double b1, double b2, double eps, double wd,
                                                           float grad_scale, float* __restrict__ wt, int nb, int nc,
-                                                          unsigned* __restrict__ status, const double* __restrict__ hp) {
+                                                          unsigned* __restrict__ status, const double* __restrict__ hp,
+                                                          const int* __restrict__ mask_node_ptr, double mask_rate,
+                                                          unsigned long long mask_seed, uint8_t* __restrict__ mask_next,
+                                                          const unsigned long long* __restrict__ mask_snap, int use_snap,
+                                                          int reduce_blocks) {
   __shared__ float s_step_size, s_bc2_sqrt;
   __shared__ unsigned s_fault;
+  // The device mask of the NEXT step (utils/auxil.py:166-182), sampled by the workgroups behind the reduction's: the
+  // sampler's own launch (5.9 us + a launch boundary per step) disappears from the captured step.  Its key uses the step
+  // count this update leaves behind -- exactly what gatres_mask_generate would read at the start of the next step: the
+  // count and the fault word as the parameter-gradient launch in front of this one snapshotted them (mask_snap: this
+  // launch changes both, and 512 more tickets on the one counter address would cost 10 us).
+  if (mask_next && (int)blockIdx.x >= reduce_blocks) {
+    const int mb = (int)blockIdx.x - reduce_blocks;
+    const unsigned long long next_step = mask_snap[1] == 0ULL ? mask_snap[0] + 1ULL : mask_snap[0];      // (a dropped step: unchanged)
+    mask_sample_graph<256, MASK_WGS_UPDATE>(mask_node_ptr, mask_rate, mask_seed, next_step, mask_next, mb / MASK_WGS_UPDATE,
+                                            mb % MASK_WGS_UPDATE);
+    return;
+  }
   if (hp) { lr = hp[0]; b1 = hp[1]; b2 = hp[2]; eps = hp[3]; wd = hp[4]; }      // (gatres_train_step_t.hparams)
   // status[0]: a split launch of this step gave up waiting for a partner workgroup (its results are poisoned).  The step
   // is then DROPPED: no Adam update, no step count, loss = NaN, gradients = NaN; the last block clears the word and
   // counts the event in status[1], so one transient stall costs one step instead of the whole run.
-  if (threadIdx.x == 0) s_fault = status ? __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+  // snap: the parameter-gradient launch in front of this one left the step count and the fault word in mask_snap (the training
+  // step's sequence, gatres_train_step).  Every block then reads THOSE -- stable words -- and block 0 alone counts the step:
+  // no tickets (258 read-modify-writes on one address serialise in the L2 at ~20 ns each: 5 of this launch's 8 us).
+  const bool snap = use_snap != 0;
+  if (threadIdx.x == 0)
+    s_fault = snap ? (unsigned)mask_snap[1] : (status ? __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u);
   if (do_adam && threadIdx.x == 0) {
-    const unsigned long long t = __hip_atomic_load(step_counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1ULL;
+    const unsigned long long t =
+        (snap ? mask_snap[0] : __hip_atomic_load(step_counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) + 1ULL;
     s_step_size = (float)(lr / (1.0 - gatres_powi(b1, t)));
     s_bc2_sqrt = (float)sqrt(1.0 - gatres_powi(b2, t));
+    if (snap && s_fault == 0u && blockIdx.x == 0) step_counter[0] = t;      // (nobody reads the counter in this launch)
     // The step is counted once every block has READ the counter: a ticket drawn right after this block's read (its value is
     // in a register: the wait below), the last ticket increments.  Nothing orders the count behind the parameter stores --
     // the next launch is -- so no fence: the ticket used to follow the block's stores behind a __threadfence(), an L2
     // write-back + invalidate of ~3.5 us at the end of every block of a 14-us launch.
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    if (s_fault == 0u) {
+    if (!snap) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    if (!snap && s_fault == 0u) {
       const unsigned long long done = atomicAdd(&step_counter[1], 1ULL);
-      if (done == (unsigned long long)gridDim.x - 1ULL) {
+      if (done == (unsigned long long)reduce_blocks - 1ULL) {
         step_counter[1] = 0ULL;
         atomicAdd(&step_counter[0], 1ULL);
       }
@@ -58,7 +82,7 @@ __global__ __launch_bounds__(256) void reduce_adam_kernel(const float* __restric
   const bool fault = s_fault != 0u;
   if (fault && loss && blockIdx.x == 0 && threadIdx.x == 0) loss[0] = NAN;
   const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
-  if (idx < count) {
+  if (idx < count && (int)blockIdx.x < reduce_blocks) {
     float acc = 0.f;
     int s0 = 0;
     // the parameter and its moments are requested together with the first slab rows: one memory round trip for a
@@ -107,9 +131,13 @@ __global__ __launch_bounds__(256) void reduce_adam_kernel(const float* __restric
       }
     }
   }
-  if (fault && threadIdx.x == 0) {               // every block has read status[0] before the last ticket is drawn
+  if (fault && snap && blockIdx.x == 0 && threadIdx.x == 0) {      // (the other blocks read the snapshot, not the word)
+    status[1] += 1u;
+    __hip_atomic_store(status, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  if (fault && !snap && threadIdx.x == 0) {      // every block has read status[0] before the last ticket is drawn
     __threadfence();
-    if (atomicAdd(status + 2, 1u) == gridDim.x - 1u) {
+    if (atomicAdd(status + 2, 1u) == (unsigned)reduce_blocks - 1u) {
       status[2] = 0u;
       status[1] += 1u;
       __hip_atomic_store(status, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -581,8 +609,18 @@ extern "C" int64_t gatres_fused_status_offset(const gatres_model_t* m, const gat
   return L.sc_flags + L.flag_words - 32;
 }
 
+extern "C" __attribute__((visibility("hidden"))) int gatres_fused_param_grads_ex(const gatres_model_t* m, const gatres_graph_t* g,
+                                                                                 const float* saved, float* scratch,
+                                                                                 const uint64_t* step_counter, void* stream);
 extern "C" int gatres_fused_param_grads(const gatres_model_t* m, const gatres_graph_t* g, const float* saved,
                                         float* scratch, void* stream) {
+  return gatres_fused_param_grads_ex(m, g, saved, scratch, nullptr, stream);
+}
+// step_counter != null (gatres_train_step): the launch also snapshots the step count and the fault word for the update
+// launch's sampling tail (status words 8 .. 11).  Returns 1 instead of 0 when it did (the caller may then ask for mask_next).
+extern "C" __attribute__((visibility("hidden"))) int gatres_fused_param_grads_ex(const gatres_model_t* m, const gatres_graph_t* g,
+                                                                                 const float* saved, float* scratch,
+                                                                                 const uint64_t* step_counter, void* stream) {
   if (!m || !g || !saved || !scratch) return GATRES_E_BADARG;
   if (!gatres_fused_supported(m, g)) return GATRES_E_UNSUPPORTED;
   ParamGradArgs a;
@@ -596,9 +634,16 @@ extern "C" int gatres_fused_param_grads(const gatres_model_t* m, const gatres_gr
   const dim3 grid((unsigned)(2 * a.L.nb * g->num_segments));
   hipStream_t st = gatres_stream(stream);
   if ((m->nc == 16 || m->nc == 32) && !gatres_knobs()->param_grads_no_stream) {
+    if (step_counter) {
+      unsigned* status = reinterpret_cast<unsigned*>(scratch + a.L.sc_flags + a.L.flag_words - 32);
+      a.step_counter = reinterpret_cast<const unsigned long long*>(step_counter);
+      a.status = fused_nodes_of(g) > 0 ? status : nullptr;
+      a.snap = reinterpret_cast<unsigned long long*>(status + 8);
+    }
     if (m->nc == 16) hipLaunchKernelGGL((param_grads_stream_kernel<16>), grid, dim3(PGS_THREADS), 0, st, a);
     else             hipLaunchKernelGGL((param_grads_stream_kernel<32>), grid, dim3(PGS_THREADS), 0, st, a);
-    return gatres_launch_status();
+    const int rc = gatres_launch_status();
+    return rc ? rc : (step_counter ? 1 : 0);
   }
   switch (m->nc) {
     case 4: hipLaunchKernelGGL((param_grads_kernel<4, 256>), grid, dim3(256), 0, st, a); break;
@@ -662,33 +707,62 @@ extern "C" int gatres_fused_finish_hp(const gatres_model_t* m, const gatres_grap
                                       const float* loss_part, float* loss, int32_t do_adam, float* params,
                                       float* exp_avg, float* exp_avg_sq, uint64_t* step_counter, double lr, double beta1,
                                       double beta2, double eps, double weight_decay, const double* hparams,
-                                      float grad_scale, void* stream);
+                                      float grad_scale, const int32_t* mask_node_ptr, int32_t mask_graphs, double mask_rate,
+                                      uint64_t mask_seed, uint8_t* mask_next, void* stream);
+
+extern "C" __attribute__((visibility("hidden"))) int gatres_fused_finish_ex(
+    const gatres_model_t* m, const gatres_graph_t* g, float* scratch, float* grads, const float* loss_part, float* loss,
+    int32_t do_adam, float* params, float* exp_avg, float* exp_avg_sq, uint64_t* step_counter, double lr, double beta1,
+    double beta2, double eps, double weight_decay, const double* hparams, float grad_scale, const int32_t* mask_node_ptr,
+    int32_t mask_graphs, double mask_rate, uint64_t mask_seed, uint8_t* mask_next, int32_t use_snap, void* stream);
 
 extern "C" int gatres_fused_finish(const gatres_model_t* m, const gatres_graph_t* g, float* scratch, float* grads,
                                    const float* loss_part, float* loss, int32_t do_adam, float* params,
                                    float* exp_avg, float* exp_avg_sq, uint64_t* step_counter, double lr, double beta1,
                                    double beta2, double eps, double weight_decay, float grad_scale, void* stream) {
   return gatres_fused_finish_hp(m, g, scratch, grads, loss_part, loss, do_adam, params, exp_avg, exp_avg_sq, step_counter,
-                                lr, beta1, beta2, eps, weight_decay, nullptr, grad_scale, stream);
+                                lr, beta1, beta2, eps, weight_decay, nullptr, grad_scale, nullptr, 0, 0.0, 0, nullptr, stream);
 }
 
 extern "C" int gatres_fused_finish_hp(const gatres_model_t* m, const gatres_graph_t* g, float* scratch, float* grads,
                                       const float* loss_part, float* loss, int32_t do_adam, float* params,
                                       float* exp_avg, float* exp_avg_sq, uint64_t* step_counter, double lr, double beta1,
                                       double beta2, double eps, double weight_decay, const double* hparams,
-                                      float grad_scale, void* stream) {
+                                      float grad_scale, const int32_t* mask_node_ptr, int32_t mask_graphs, double mask_rate,
+                                      uint64_t mask_seed, uint8_t* mask_next, void* stream) {
+  // (mask_next through the public entry: the caller vouches that gatres_fused_param_grads ran under gatres_train_step's
+  //  sequence -- the snapshot it reads is only written there; without one the sampling tail is refused)
+  if (mask_next) return GATRES_E_UNSUPPORTED;
+  return gatres_fused_finish_ex(m, g, scratch, grads, loss_part, loss, do_adam, params, exp_avg, exp_avg_sq, step_counter, lr,
+                                beta1, beta2, eps, weight_decay, hparams, grad_scale, mask_node_ptr, mask_graphs, mask_rate,
+                                mask_seed, mask_next, 0, stream);
+}
+
+// (not part of include/gatres.h) use_snap: the parameter-gradient launch in front of this one (gatres_fused_param_grads_ex)
+// left the step count / fault word snapshot: the update reads those instead of drawing tickets, and may sample the next mask
+extern "C" __attribute__((visibility("hidden"))) int gatres_fused_finish_ex(
+    const gatres_model_t* m, const gatres_graph_t* g, float* scratch, float* grads, const float* loss_part, float* loss,
+    int32_t do_adam, float* params, float* exp_avg, float* exp_avg_sq, uint64_t* step_counter, double lr, double beta1,
+    double beta2, double eps, double weight_decay, const double* hparams, float grad_scale, const int32_t* mask_node_ptr,
+    int32_t mask_graphs, double mask_rate, uint64_t mask_seed, uint8_t* mask_next, int32_t use_snap, void* stream) {
   if (!m || !g || !scratch || !grads) return GATRES_E_BADARG;
+  if (mask_next && !use_snap) return GATRES_E_BADARG;
+  if (mask_next && (!do_adam || !mask_node_ptr || mask_graphs <= 0 || !(mask_rate >= 0.0 && mask_rate <= 1.0))) return GATRES_E_BADARG;
   if (do_adam && (!params || !exp_avg || !exp_avg_sq || !step_counter)) return GATRES_E_BADARG;
   if ((loss_part == nullptr) != (loss == nullptr)) return GATRES_E_BADARG;
   Layout L;
   if (!make_layout_g(m, g, &L)) return GATRES_E_UNSUPPORTED;
-  hipLaunchKernelGGL(reduce_adam_kernel, dim3((unsigned)((L.P + 255) / 256)), dim3(256), 0, gatres_stream(stream),
+  const int reduce_blocks = (int)((L.P + 255) / 256);
+  hipLaunchKernelGGL(reduce_adam_kernel, dim3((unsigned)(reduce_blocks + (mask_next ? mask_graphs * MASK_WGS_UPDATE : 0))), dim3(256), 0,
+                     gatres_stream(stream),
                      scratch + L.sc_slabs, g->num_segments, g->num_segments * fused_split(L, g),
                      (long long)L.slab_stride, (long long)L.P, grads, loss_part, loss, do_adam, params, exp_avg, exp_avg_sq,
                      reinterpret_cast<unsigned long long*>(step_counter), lr, beta1, beta2, eps, weight_decay,
                      grad_scale, do_adam ? scratch + L.sc_wt : nullptr, L.nb, L.nc,
                      fused_nodes_of(g) > 0 ? reinterpret_cast<unsigned*>(scratch + L.sc_flags + L.flag_words - 32) : nullptr,
-                     hparams);
+                     hparams, mask_node_ptr, mask_rate, (unsigned long long)mask_seed, mask_next,
+                     reinterpret_cast<const unsigned long long*>(scratch + L.sc_flags + L.flag_words - 32 + 8),
+                     (use_snap && do_adam) ? 1 : 0, reduce_blocks);
   return gatres_launch_status();
 }
 

@@ -7,6 +7,7 @@
 // bitwise reproducible.
 #include "gatres_common.h"
 #include "k_conv_grads.h"
+#include "k_mask.h"
 
 // ---------------------------------------------------------------------------------------------------- environment knobs
 #include <atomic>
@@ -422,11 +423,7 @@ __global__ __launch_bounds__(256) void gather_u8_kernel(const uint8_t* __restric
 }
 
 // ------------------------------------------------------------------------------------------ edge_index hash
-__device__ __forceinline__ uint64_t mix64(uint64_t z) {
-  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
-  z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
-  return z ^ (z >> 31);
-}
+
 
 __global__ __launch_bounds__(256) void edge_hash_kernel(const int64_t* __restrict__ ei, long long E,
                                                         unsigned long long* __restrict__ out) {
@@ -440,17 +437,9 @@ __global__ __launch_bounds__(256) void edge_hash_kernel(const int64_t* __restric
   if ((threadIdx.x & 63) == 0 && v) atomicAdd(out, v);      // integer add: order-independent
 }
 
-// ---------------------------------------------------------------------------------- device mask sampler
-// One workgroup per graph.  Every node gets a unique 64-bit key (hash32(seed, step, node) << 32 | local id);
-// the k = int(n*rate) smallest keys are masked: an exactly-k uniform subset without replacement, the same
-// distribution as np.random.choice(n, k, replace=False) in utils/auxil.py:154-157.  The k-th key is found by an
-// 8-pass byte-wise radix select in LDS.
-__device__ __forceinline__ uint64_t mask_key(uint64_t seed, uint64_t step, int gnode, int local) {
-  const uint64_t z = mix64(seed + 0x9E3779B97F4A7C15ULL * (step + 1) + 0xBF58476D1CE4E5B9ULL * (uint64_t)(gnode + 1));
-  return ((z >> 32) << 32) | (uint32_t)local;
-}
-
-constexpr int MASK_WGS = 4;
+// ---------------------------------------------------------------------------------- device mask sampler (k_mask.h)
+// One launch: MASK_WGS workgroups per graph; the batch copy -- or its collation from the snapshot matrix -- rides on it
+// (gatres_stage_batch_mask / gatres_stage_rows_mask: grid-stride, before the sampling: its stores drain while the keys are ranked)
 __global__ __launch_bounds__(1024) void mask_generate_kernel(const int* __restrict__ node_ptr, double rate,
                                                              uint64_t seed, const uint64_t* __restrict__ step_counter,
                                                              uint8_t* __restrict__ mask,
@@ -458,8 +447,6 @@ __global__ __launch_bounds__(1024) void mask_generate_kernel(const int* __restri
                                                              float* __restrict__ x_dst, float* __restrict__ y_dst,
                                                              long long num_nodes, const long long* __restrict__ rows,
                                                              int rows_npg) {
-  // gatres_stage_batch_mask / gatres_stage_rows_mask: the batch copy -- or its collation from the snapshot matrix -- rides
-  // on the sampler's launch (grid-stride, before the sampling: its stores drain while the keys are ranked)
   if (x_src && x_src != x_dst) {
     for (long long v = (long long)blockIdx.x * 1024 + threadIdx.x; v < num_nodes; v += (long long)gridDim.x * 1024) {
       const long long u = rows ? rows[v / rows_npg] * rows_npg + v % rows_npg : v;
@@ -467,64 +454,8 @@ __global__ __launch_bounds__(1024) void mask_generate_kernel(const int* __restri
       if (y_src && y_dst) y_dst[v] = y_src[u];
     }
   }
-  constexpr int SMALL = 2048, T = 1024;            // graphs up to SMALL nodes: all-pairs rank in LDS (~2 us for C-Town)
-  __shared__ uint64_t s_keys[SMALL];
-  __shared__ int s_rank[SMALL];
-  __shared__ int hist[256];
-  __shared__ uint64_t s_prefix;
-  __shared__ int s_k;
-  // MASK_WGS workgroups per graph: each ranks one slice of the graph's nodes (the all-pairs compare is ALU work)
-  const int g = blockIdx.x / MASK_WGS, wq = blockIdx.x % MASK_WGS, tid = threadIdx.x;
-  const int n0 = node_ptr[g], n = node_ptr[g + 1] - n0;
-  const uint64_t step = step_counter ? step_counter[0] : 0;
-  const int k = (int)((double)n * rate);          // Python: int(num_nodes * masking_rate)
-  if (k <= 0) {
-    if (wq == 0)
-      for (int v = tid; v < n; v += T) mask[n0 + v] = 0;
-    return;
-  }
-  if (n > SMALL && wq != 0) return;               // the radix-select path runs in one workgroup
-  if (n <= SMALL) {
-    // keys are unique, so "masked" == "fewer than k keys are smaller than mine".  The n x n comparisons are spread
-    // over all threads: Q threads per node, each ranks the node against one slice of the keys.
-    for (int v = tid; v < n; v += T) { s_keys[v] = mask_key(seed, step, n0 + v, v); s_rank[v] = 0; }
-    __syncthreads();
-    const int Q = min(16, max(1, (n + 63) / 64));   // slices of ~64 keys: 7 for C-Town's 388 nodes
-    const int slice = (n + Q - 1) / Q;
-    const int per = (n + MASK_WGS - 1) / MASK_WGS, vlo = wq * per, vhi = min(n, vlo + per);
-    for (int w = tid; w < (vhi - vlo) * Q; w += T) {
-      const int v = vlo + w / Q, q = w % Q;
-      const uint64_t mine = s_keys[v];
-      const int ub = q * slice, ue = min(n, ub + slice);
-      int rank = 0;
-      for (int u = ub; u < ue; ++u) rank += s_keys[u] < mine ? 1 : 0;
-      if (Q == 1) s_rank[v] = rank; else atomicAdd(&s_rank[v], rank);
-    }
-    __syncthreads();
-    for (int v = vlo + tid; v < vhi; v += T) mask[n0 + v] = s_rank[v] < k ? 1 : 0;
-    return;
-  }
-  if (tid == 0) { s_prefix = 0; s_k = k; }
-  for (int pass = 7; pass >= 0; --pass) {
-    if (tid < 256) hist[tid] = 0;
-    __syncthreads();
-    const uint64_t prefix = s_prefix;
-    for (int v = tid; v < n; v += T) {
-      const uint64_t key = mask_key(seed, step, n0 + v, v);
-      const bool match = (pass == 7) || ((key >> (8 * (pass + 1))) == prefix);
-      if (match) atomicAdd(&hist[(int)((key >> (8 * pass)) & 255)], 1);
-    }
-    __syncthreads();
-    if (tid == 0) {
-      int kk = s_k, b = 0;
-      while (b < 255 && kk > hist[b]) { kk -= hist[b]; ++b; }
-      s_k = kk;
-      s_prefix = (prefix << 8) | (uint64_t)b;
-    }
-    __syncthreads();
-  }
-  const uint64_t kth = s_prefix;
-  for (int v = tid; v < n; v += T) mask[n0 + v] = mask_key(seed, step, n0 + v, v) <= kth ? 1 : 0;
+  mask_sample_graph<1024, MASK_WGS>(node_ptr, rate, seed, step_counter ? step_counter[0] : 0, mask, blockIdx.x / MASK_WGS,
+                          blockIdx.x % MASK_WGS);
 }
 
 // ------------------------------------------------------------------------------------------- masked MSE

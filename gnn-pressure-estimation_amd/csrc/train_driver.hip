@@ -7,21 +7,33 @@ extern "C" __attribute__((visibility("hidden"))) int gatres_adam_step_ex(float* 
                                    float* exp_avg_sq, uint64_t* step_counter, int64_t count, double lr, double beta1,
                                    double beta2, double eps, double weight_decay, const double* hp, float grad_scale,
                                    float* wt, int32_t num_blocks, int32_t nc, uint32_t* drop_count, void* stream);
-extern "C" int gatres_fused_finish_hp(const gatres_model_t* m, const gatres_graph_t* g, float* scratch, float* grads,
-                                      const float* loss_part, float* loss, int32_t do_adam, float* params,
-                                      float* exp_avg, float* exp_avg_sq, uint64_t* step_counter, double lr, double beta1,
-                                      double beta2, double eps, double weight_decay, const double* hparams,
-                                      float grad_scale, void* stream);
 
 // Parameter gradients, slab sum and (optionally) Adam of the fused path: the parameter-gradient launch followed by
 // gatres_fused_finish.  (The one-launch form, gatres_fused_param_grads_finish, is slower on a single GPU -- 53 us against 38 +
 // 9 inside the captured step, k_fused_host.hip -- and serves the data-parallel step's gradient buckets only.)
+extern "C" __attribute__((visibility("hidden"))) int gatres_fused_param_grads_ex(const gatres_model_t* m, const gatres_graph_t* g,
+                                                                                 const float* saved, float* scratch,
+                                                                                 const uint64_t* step_counter, void* stream);
+extern "C" __attribute__((visibility("hidden"))) int gatres_fused_finish_ex(
+    const gatres_model_t* m, const gatres_graph_t* g, float* scratch, float* grads, const float* loss_part, float* loss,
+    int32_t do_adam, float* params, float* exp_avg, float* exp_avg_sq, uint64_t* step_counter, double lr, double beta1,
+    double beta2, double eps, double weight_decay, const double* hparams, float grad_scale, const int32_t* mask_node_ptr,
+    int32_t mask_graphs, double mask_rate, uint64_t mask_seed, uint8_t* mask_next, int32_t use_snap, void* stream);
 static int fused_grads_and_update(const gatres_train_step_t* ts, const float* loss_part, bool adam, void* stream) {
-  const int rc = gatres_fused_param_grads(&ts->model, ts->graph, ts->saved, ts->scratch, stream);
-  if (rc) return rc;
-  return gatres_fused_finish_hp(&ts->model, ts->graph, ts->scratch, ts->grads, loss_part, loss_part ? ts->loss : nullptr,
+  const bool want_next = adam && (ts->flags & GATRES_FLAG_MASK_NEXT) && ts->node_ptr && ts->num_graphs > 0 && ts->mask_next &&
+                         ts->mask_next != ts->mask;
+  const int rc = gatres_fused_param_grads_ex(&ts->model, ts->graph, ts->saved, ts->scratch,
+                                             adam ? ts->step_counter : nullptr, stream);
+  if (rc < 0 || rc > 1) return rc;
+  // (rc == 1: the launch left the step count / fault word snapshot the sampling tail of the update launch reads; batches
+  //  that leave CUs free form their parameter gradients on consumer workgroups instead -- no snapshot, no sampling ahead:
+  //  the caller finds mask_next untouched... so it must not rely on it: GATResTrainer asks gatres_fused_finish_folds first)
+  const bool mask_next = want_next && rc == 1;
+  return gatres_fused_finish_ex(&ts->model, ts->graph, ts->scratch, ts->grads, loss_part, loss_part ? ts->loss : nullptr,
                                 adam ? 1 : 0, ts->params, ts->exp_avg, ts->exp_avg_sq, ts->step_counter, ts->lr, ts->beta1,
-                                ts->beta2, ts->eps, ts->weight_decay, ts->hparams, ts->grad_scale, stream);
+                                ts->beta2, ts->eps, ts->weight_decay, ts->hparams, ts->grad_scale,
+                                mask_next ? ts->node_ptr : nullptr, ts->num_graphs, ts->mask_rate, ts->seed,
+                                mask_next ? ts->mask_next : nullptr, rc == 1 ? 1 : 0, stream);
 }
 
 extern "C" int gatres_train_step(const gatres_train_step_t* ts, void* stream) {

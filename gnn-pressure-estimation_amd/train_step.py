@@ -23,8 +23,8 @@ from .graph_plan import GraphPlan
 
 PHASE_MASK, PHASE_FORWARD, PHASE_BACKWARD, PHASE_ADAM = 1, 2, 4, 8
 PART_FIRST, PART_LAST, PART_REDUCE = 1, 2, 4
-FLAG_PER_OP, FLAG_WT_VALID, FLAG_GRADS_DEFERRED, FLAG_GRADS_ONLY = 1, 2, 4, 8
-MAX_CACHED_GRAPHS = 8
+FLAG_PER_OP, FLAG_WT_VALID, FLAG_GRADS_DEFERRED, FLAG_GRADS_ONLY, FLAG_MASK_NEXT = 1, 2, 4, 8, 16
+MAX_CACHED_GRAPHS = 40          # (bound batches: one captured step per batch buffer and transposed-weights state)
 
 
 class _TrainStepC(C.Structure):
@@ -38,7 +38,7 @@ class _TrainStepC(C.Structure):
                 ("scratch", C.c_void_p),
                 ("lr", C.c_double), ("beta1", C.c_double), ("beta2", C.c_double), ("eps", C.c_double),
                 ("weight_decay", C.c_double), ("grad_scale", C.c_float), ("flags", C.c_int32),
-                ("hparams", C.c_void_p), ("block_lo", C.c_int32), ("block_hi", C.c_int32)]
+                ("hparams", C.c_void_p), ("block_lo", C.c_int32), ("block_hi", C.c_int32), ("mask_next", C.c_void_p)]
 
 
 class GATResTrainer:
@@ -86,7 +86,8 @@ class GATResTrainer:
         # and the masking happens inside the kernels here (x itself is never overwritten): one buffer serves both
         self.targets_are_inputs = bool(targets_are_inputs)
         self.y = self.x if self.targets_are_inputs else torch.zeros(N, **f32)
-        self.mask = torch.zeros(N, dtype=torch.uint8, device=dev)
+        self.mask = torch.zeros(N, dtype=torch.uint8, device=dev)         # the mask of the step that ran last / is staged
+        self._mask_spare = torch.zeros(N, dtype=torch.uint8, device=dev)  # where the update launch samples the NEXT step's mask
         self.out = torch.zeros(N, **f32)
         self.g_out = torch.zeros(N, **f32)
         self.loss = torch.zeros(1, **f32)
@@ -120,6 +121,16 @@ class GATResTrainer:
         self._siblings: Dict[int, "GATResTrainer"] = {}
         off = self.lib.gatres_fused_status_offset(model._cmodel_ref(), self.plan.ref()) if self.fused else -1
         self._status = self.scratch[off:off + 4].view(torch.int32) if off >= 0 else None
+        # Single-GPU fused step: the update launch samples the NEXT step's device mask into the spare buffer
+        # (GATRES_FLAG_MASK_NEXT); a step that finds it still valid swaps the buffers and leaves the sampler's launch out.
+        # self.mask always is the mask of the step that ran last.  _mask_sig: what the spare buffer's mask was sampled for.
+        # (only where the parameter gradients are a launch of their own: it leaves the step count / fault snapshot the
+        #  sampling tail reads -- batches that leave CUs free use consumer workgroups and keep the sampler's own launch)
+        self._mask_next = bool(self.fused and not self.split and self.node_ptr is not None
+                               and self.lib.gatres_fused_finish_folds(model._cmodel_ref(), self.plan.ref())
+                               and not os.environ.get("GATRES_NO_MASK_NEXT"))
+        self._mask_sig = None
+        self._bound: list = []                      # bind_batches(): (x, y) tensors the captured steps read directly
         # the fused path's parameter gradients can be formed range by range (a bucket's all-reduce starts in between)
         self._ranges = bool(self.fused and self.lib.gatres_fused_finish_folds(model._cmodel_ref(), self.plan.ref()))
 
@@ -133,22 +144,23 @@ class GATResTrainer:
         self.hp.copy_(torch.tensor(self._hp_list(), dtype=torch.float64), non_blocking=False)
 
     def _desc(self, phases: int, device_mask: bool, wt_valid: bool = False, flags: int = 0, block_lo: int = 0,
-              block_hi: int = 0) -> _TrainStepC:
+              block_hi: int = 0, batch=None) -> _TrainStepC:
         m = self.model
+        bx, by = (self.x, self.y) if batch is None else batch
         params = m.flat_parameters
         if params.data_ptr() != self._params_ptr:
             raise RuntimeError("the model's parameter storage moved (e.g. .to()/deepcopy); build a new GATResTrainer")
         h = self.hparams
         return _TrainStepC(
             _native.GatresModel(m.num_blocks, m.nc, m._cmodel.act_dtype, 0), C.pointer(self._gstruct), params.data_ptr(), self.grads.data_ptr(),
-            self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr(), self.step_counter.data_ptr(), self.x.data_ptr(),
-            self.y.data_ptr(), self.mask.data_ptr(),
+            self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr(), self.step_counter.data_ptr(), bx.data_ptr(),
+            by.data_ptr(), self.mask.data_ptr(),
             self.node_ptr.data_ptr() if (device_mask and self.node_ptr is not None) else None,
             self.num_graphs, phases, self.mask_rate, self.seed, self.out.data_ptr(), self.g_out.data_ptr(),
             self.loss.data_ptr(), self.saved.data_ptr(), self.scratch.data_ptr(), h["lr"], h["beta1"], h["beta2"],
             h["eps"], h["weight_decay"], 1.0 / self.world,
             (0 if self.fused else FLAG_PER_OP) | (FLAG_WT_VALID if wt_valid else 0) | flags, self.hp.data_ptr(),
-            block_lo, block_hi)
+            block_lo, block_hi, self._mask_spare.data_ptr())
 
     def _count_native_update(self) -> None:
         """A native kernel (fused Adam pass, Adam-only phase) just changed the parameters without touching torch's
@@ -197,8 +209,18 @@ class GATResTrainer:
                 t.hparams = dict(self.hparams)
 
     def _graph_key(self, what, device_mask: bool, wt_valid: bool) -> tuple:
-        # (no hyper-parameter in here: the kernels read them from self.hp)
-        return (what, device_mask, wt_valid, self.mask_rate, self.seed, self.world)
+        # (no hyper-parameter in here: the kernels read them from self.hp; which of the two mask buffers is current is)
+        return (what, device_mask, wt_valid, self.mask_rate, self.seed, self.world, self.mask.data_ptr())
+
+    def _take_mask_ahead(self) -> bool:
+        """If the previous step's update launch sampled THIS step's mask and nothing has moved since, make that buffer the
+        current one (True); else the caller samples / stages a mask into self.mask as before."""
+        if self._mask_next and self._mask_sig is not None and self._mask_sig == self._mask_key():
+            self.mask, self._mask_spare = self._mask_spare, self.mask
+            self._mask_sig = None
+            return True
+        self._mask_sig = None
+        return False
 
     @property
     def num_captured_graphs(self) -> int:
@@ -218,23 +240,35 @@ class GATResTrainer:
         return int(self._status[1].item()) if self._status is not None else 0
 
     def _enqueue(self, phases: int, device_mask: bool, wt_valid: bool = False, flags: int = 0, block_lo: int = 0,
-                 block_hi: int = 0) -> None:
-        ts = self._desc(phases, device_mask, wt_valid, flags, block_lo, block_hi)
+                 block_hi: int = 0, batch=None) -> None:
+        ts = self._desc(phases, device_mask, wt_valid, flags, block_lo, block_hi, batch)
         _native.check(self.lib.gatres_train_step(C.byref(ts), _native.current_stream(self.device)),
                       "gatres_train_step")
 
-    def _run(self, phases: int, device_mask: bool) -> None:
+    def _mask_key(self):
+        """What a mask sampled by the update launch is valid for: the optimizer state as this trainer left it (a sibling's or a
+        FusedAdam step moves the shared step count: the sampler's key would differ) and the sampler's own settings."""
+        return (getattr(self.model, "_native_updates", 0), self.mask_rate, self.seed)
+
+    def _run(self, phases: int, device_mask: bool, batch=None, slot=None) -> None:
         full = PHASE_BACKWARD | PHASE_ADAM
         wt_valid = self.fused and (phases & PHASE_BACKWARD) != 0 and self._wt_current()
+        flags = 0
+        mask_next = self._mask_next and device_mask and (phases & (PHASE_FORWARD | full)) == (PHASE_FORWARD | full)
+        if mask_next:
+            flags |= FLAG_MASK_NEXT
+            if (phases & PHASE_MASK) and self._take_mask_ahead():
+                phases &= ~PHASE_MASK            # the previous step's update launch has sampled this step's mask already
         try:
-            self._replay(self._graph_key(phases, device_mask, wt_valid),
-                         lambda: self._enqueue(phases, device_mask, wt_valid), wt_valid)
+            self._replay(self._graph_key((phases, flags, slot), device_mask, wt_valid),
+                         lambda: self._enqueue(phases, device_mask, wt_valid, flags=flags, batch=batch), wt_valid)
         finally:
             if phases & PHASE_ADAM:
                 self._count_native_update()
             # a fused backward + Adam step leaves the transposed weights of the NEW parameters in (this trainer's) scratch
             if self.fused and (phases & full) == full:
                 self._wt_sig = self._param_signature()
+            self._mask_sig = self._mask_key() if mask_next else None
 
     def _replay(self, key: tuple, enqueue: Callable[[], None], wt_valid: bool = False) -> None:
         """Run ``enqueue`` -- eagerly, or captured once into a hipGraph (cached by ``key``) and replayed."""
@@ -245,11 +279,12 @@ class GATResTrainer:
         if g is None:
             # warm-up launch outside capture (module load, lazy init, RCCL communicator), then capture the same sequence
             state = (self.step_counter.clone(), self.model.flat_parameters.clone(), self.exp_avg.clone(),
-                     self.exp_avg_sq.clone())
+                     self.exp_avg_sq.clone(), self.mask.clone())
 
             def rollback():
                 self.step_counter.copy_(state[0]); self.model.flat_parameters.copy_(state[1])
                 self.exp_avg.copy_(state[2]); self.exp_avg_sq.copy_(state[3])
+                self.mask.copy_(state[4])        # (a warm-up that ran the sampler's launch re-sampled it: same bits; kept simple)
 
             enqueue()
             torch.cuda.synchronize(self.device)
@@ -368,6 +403,7 @@ class GATResTrainer:
             self.y.copy_(y.reshape(-1), non_blocking=True)
         if mask is not None:
             self.mask.copy_(mask.reshape(-1).to(torch.uint8), non_blocking=True)
+            self._mask_sig = None                # (the caller's mask replaced whatever the update launch had sampled)
 
     def prefetch_batch(self, x: torch.Tensor, y: Optional[torch.Tensor] = None) -> None:
         """Start copying the NEXT batch (typically pinned host memory) into a staging buffer on a side stream, so the
@@ -425,6 +461,10 @@ class GATResTrainer:
         for t in (x, y):
             if not (t.is_cuda and t.device == self.x.device and t.dtype == torch.float32 and t.numel() == n and t.is_contiguous()):
                 return False
+        # (a mask the previous update launch may have sampled ahead is NOT used here: the batch needs a staging launch anyway,
+        #  and copy + sampling in one launch is cheaper than a copy launch of its own -- measured 0.4204 vs 0.4237 ms/step;
+        #  step_bound() / run_step() are the paths without a staging launch)
+        self._mask_sig = None
         ys = None if self.targets_are_inputs else y
         _native.check(self.lib.gatres_stage_batch_mask(
             x.data_ptr(), None if ys is None else ys.data_ptr(), self.x.data_ptr(), None if ys is None else self.y.data_ptr(), n,
@@ -451,7 +491,7 @@ class GATResTrainer:
         if self.split:
             self._run_split(True, premasked=True)
         else:
-            self._run(PHASE_FORWARD | PHASE_BACKWARD | PHASE_ADAM, True)
+            self._run_premasked(ahead=False)
         return True
 
     def step(self, x: torch.Tensor, y: torch.Tensor, mask: Optional[torch.Tensor] = None) -> torch.Tensor:
@@ -460,10 +500,59 @@ class GATResTrainer:
             if self.split:
                 self._run_split(True, premasked=True)
             else:
-                self._run(PHASE_FORWARD | PHASE_BACKWARD | PHASE_ADAM, True)
+                self._run_premasked(ahead=False)
             return self.loss
         self.load_batch(x, y, mask)
         self.run_step(device_mask=mask is None)
+        return self.loss
+
+    def _run_premasked(self, batch=None, slot=None, ahead: bool = True) -> None:
+        """The single-GPU step on a mask that is already in self.mask (staged with the batch, or sampled by the previous
+        step's update launch).  ahead=False: the caller samples every step's mask itself (the store's row collation)."""
+        full = PHASE_FORWARD | PHASE_BACKWARD | PHASE_ADAM
+        wt_valid = self.fused and self._wt_current()
+        ahead = ahead and self._mask_next
+        flags = FLAG_MASK_NEXT if ahead else 0
+        try:
+            self._replay(self._graph_key((full, flags, slot), True, wt_valid),
+                         lambda: self._enqueue(full, True, wt_valid, flags=flags, batch=batch), wt_valid)
+        finally:
+            self._count_native_update()
+            if self.fused:
+                self._wt_sig = self._param_signature()
+            self._mask_sig = self._mask_key() if ahead else None
+
+    # ---- bound batches: the captured step reads the caller's buffers, nothing is copied -------------------------------------
+    def bind_batches(self, xs, ys=None) -> int:
+        """Register device-resident batches (flat fp32 ``[N]`` tensors; ``ys`` defaults to ``xs``: y == x before masking,
+        train.py:162-166) that ``step_bound(i)`` then trains on IN PLACE: the kernels mask x on the fly and never write it,
+        so no staging copy is needed -- one captured step per buffer.  The trainer keeps the tensors alive; do not resize
+        them.  Returns the number of bound batches."""
+        ys = xs if ys is None else ys
+        bound = []
+        for x, y in zip(xs, ys):
+            for t in (x, y):
+                _native.require_gpu_tensor(t, "a bound batch")
+                if t.numel() != self.N or t.device != self.x.device:
+                    raise ValueError(f"a bound batch must hold {self.N} values on {self.x.device}")
+            bound.append((x.reshape(-1), y.reshape(-1)))
+        if self._graphs:                              # (captured steps of the previous binding read other buffers)
+            torch.cuda.synchronize(self.device)
+            self._graphs.clear()
+        self._bound = bound
+        return len(bound)
+
+    def step_bound(self, i: int) -> torch.Tensor:
+        """One optimisation step (train.py:159-190) on bound batch ``i`` with a device-sampled mask.  On the single-GPU fused
+        path this is three launches -- the per-snapshot kernel, the parameter gradients, the update (which also samples the
+        next step's mask) -- replayed from one hipGraph; the first step (and any step after the optimizer state moved under
+        the trainer) runs the sampler's launch first."""
+        x, y = self._bound[i]
+        if self.node_ptr is None:
+            raise ValueError("device mask sampling needs nodes_per_graph at construction")
+        if self.split:                     # (data-parallel step: staged like any other batch)
+            return self.step(x, y)
+        self._run(PHASE_MASK | PHASE_FORWARD | PHASE_BACKWARD | PHASE_ADAM, True, batch=(x, y), slot=i)
         return self.loss
 
     def forward_backward(self, x: torch.Tensor, y: torch.Tensor, mask: torch.Tensor) -> torch.Tensor:

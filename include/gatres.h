@@ -460,7 +460,13 @@ int gatres_fused_finish(const gatres_model_t* m, const gatres_graph_t* g, float*
 int gatres_fused_finish_hp(const gatres_model_t* m, const gatres_graph_t* g, float* scratch, float* grads,
                            const float* loss_part, float* loss, int32_t do_adam, float* params, float* exp_avg,
                            float* exp_avg_sq, uint64_t* step_counter, double lr, double beta1, double beta2,
-                           double eps, double weight_decay, const double* hparams, float grad_scale, void* stream);
+                           double eps, double weight_decay, const double* hparams, float grad_scale,
+                           const int32_t* mask_node_ptr, int32_t mask_graphs, double mask_rate, uint64_t mask_seed,
+                           uint8_t* mask_next, void* stream);
+/* mask_* : reserved for gatres_train_step's own sequence (GATRES_FLAG_MASK_NEXT: extra workgroups of the update launch sample
+ * the device mask of the NEXT step -- what gatres_mask_generate would produce when called after this update); through this
+ * entry point pass NULL / 0 (a non-NULL mask_next is refused with GATRES_E_UNSUPPORTED: the sampling tail reads a snapshot
+ * that only the train step's parameter-gradient launch writes). */
 /* gatres_fused_param_grads + gatres_fused_finish as ONE launch, for blocks [block_lo, block_hi) of the model (the whole
  * model: 0, num_blocks): every (block, conv) column's last workgroup sums the column's slab rows, writes grads and (do_adam)
  * applies Adam to those parameters; lin0's gradient rides on block 0, lin1's on the last block, so the ranges
@@ -519,6 +525,8 @@ typedef struct gatres_train_step {
                                     * captured step follows a learning-rate schedule (train.py:349-350,510) without being
                                     * captured again                                                                     */
   int32_t block_lo, block_hi;      /* GATRES_FLAG_GRADS_ONLY: the blocks whose parameter gradients this call forms       */
+  uint8_t* mask_next;              /* GATRES_FLAG_MASK_NEXT: [N] where the update launch leaves the NEXT step's mask (another
+                                    * buffer than `mask`, which keeps the mask this step used); NULL: no sampling ahead     */
 } gatres_train_step_t;
 #define GATRES_FLAG_PER_OP 1
 /* Fused path, PHASE_BACKWARD: stop after the backward chain; the caller forms the parameter gradients itself, range by
@@ -528,6 +536,10 @@ typedef struct gatres_train_step {
  * GRADS_DEFERRED backward (gatres_fused_param_grads_finish, no Adam; the launch that holds the last block also writes the
  * loss).  Needs gatres_fused_finish_folds(). */
 #define GATRES_FLAG_GRADS_ONLY 8
+/* Fused path, PHASE_ADAM in the same call as PHASE_BACKWARD, node_ptr and mask_next given: the update launch also samples
+ * the mask of the NEXT step into `mask_next` (gatres_fused_finish_hp), so the next call -- with that buffer as its `mask` --
+ * may leave PHASE_MASK out. */
+#define GATRES_FLAG_MASK_NEXT 16
 /* The transposed conv weights in `scratch` already match `params`: true right after a fused PHASE_ADAM step on the
  * same scratch (its Adam pass rewrites them) as long as nobody else has touched the parameters; skips the transposes. */
 #define GATRES_FLAG_WT_VALID 2
