@@ -97,7 +97,7 @@ def test_headline_config_training_steps_vs_oracle(pkg, oracle, lib):
                         assert jump > floor, (k, jump, floor, "the excuse must be a kink the fp64 oracle itself shows")
                     worst = worst_b
             assert not bad, (bad[:3], bad0[:3], branch)
-            note("headline config (15x32, bs 32, hipGraph, 8 CUs/snapshot, folded update) step 0: flat grad vs oracle32 / "
+            note("headline config (15x32, bs 32, hipGraph, 8 CUs/snapshot, parameter gradients as their own launch) step 0: flat grad vs oracle32 / "
                  "worst tensor error over |g|max vs fp64 / fp64 kink branch used (0 = none)", [e_flat, worst, branch])
     assert tr.optimizer_step == 3 and tr.fault_count == 0
     assert tr.num_captured_graphs <= 2          # (one before / one after scratch's transposed weights became current)
