@@ -24,6 +24,21 @@ __device__ __forceinline__ int launder_s(int v) {
   asm volatile("" : "+s"(v));
   return v;
 }
+
+// The kernel's arguments, re-read where they are used.  Layout / SegLayout / XchLayout hold ~60 offsets that the 15-block
+// loops need a few at a time; read once at the top they are all live across both loops, which is most of what hipcc spills
+// to VGPR lanes (a v_readlane per use, on the VALU port the stages are bound by).  A stage that opens with FRESH_ARGS()
+// reads its offsets through a pointer to the kernarg segment that the compiler cannot see through (empty asm): scalar loads
+// from the constant cache, dead again when the stage ends.
+typedef const __attribute__((address_space(4))) FusedArgs* KArgs;
+__device__ __forceinline__ KArgs kargs_fresh() {
+  KArgs p = (KArgs)__builtin_amdgcn_kernarg_segment_ptr();
+  asm volatile("" : "+s"(p));
+  return p;
+}
+#define FRESH_ARGS()                                                                                          \
+  const KArgs ka_ = kargs_fresh();                                                                            \
+  [[maybe_unused]] const auto& L = ka_->L; [[maybe_unused]] const auto& SL = ka_->SL; [[maybe_unused]] const auto& XL = ka_->XL
 __device__ __forceinline__ u16* align16(u16* p) {
   return reinterpret_cast<u16*>((reinterpret_cast<uintptr_t>(p) + 15) & ~(uintptr_t)15);
 }
@@ -261,109 +276,137 @@ __global__ __launch_bounds__(THREADS) void gatres_window_kernel(const FusedArgs 
       return x;
     };
     STAMP();
-    for (int b = 0; b < L.nb; ++b) {
-      float* base = segbase + (int64_t)b * SL.bstride;
-      float* xnext = segbase + (int64_t)(b + 1) * SL.bstride + SL.xin;
-      const float* pb = P + L.p_block0 + (int64_t)b * L.p_block_stride;
-      // LDS-DMA rides on the MFMA stages, issued by their tile-less waves: W2 | att | bias of this block while proj1 runs,
-      // W1 | att | bias of the next block while proj2 runs
-      if (NC != 32 || wave_u >= dw0) {           // (NC == 32: the LDS-DMA waves; their address chains stay in here)
-        const float* pbl = P + L.p_block0 + (int64_t)launder_s(b) * L.p_block_stride;
-        w_prefetch<2 * NC, NC, EPI_ATT, THREADS>(wlB, pbl + L.c2_W, pbl + L.c2_as, pbl + L.c2_ad, dw0);
-        vec_prefetch<THREADS>(wlB + B2OFF, pbl + L.c2_b, NC);
-      }
-      if constexpr (NC == 32) {
-        if (wave_u < PW) {                         // the tile waves
-          float* bl = segbase + (int64_t)launder_s(b) * SL.bstride;
-          win_proj<NC, 2 * NC, 2, EPI_ATT, 2, PW, THREADS>(rw, xA, wlA, bl + SL.h1, 0, hA, bl + SL.as1, bl + SL.ad1, sa2, sd2,
-                                                       nullptr, nullptr, nullptr, nullptr, xout(xreg, fflag, XL.f1h, XL.f1a));
+    const int nb = L.nb;
+    for (int b = 0; b < nb; ++b) {
+      // (per stage: FRESH_ARGS() re-reads the offsets it needs; base / pb are formed where they are used)
+      {
+        FRESH_ARGS();
+        [[maybe_unused]] const float* pb = P + L.p_block0 + (int64_t)launder_s(b) * L.p_block_stride;
+        [[maybe_unused]] float* base = segbase + (int64_t)launder_s(b) * SL.bstride;
+        // LDS-DMA rides on the MFMA stages, issued by their tile-less waves: W2 | att | bias of this block while proj1 runs,
+        // W1 | att | bias of the next block while proj2 runs
+        if (NC != 32 || wave_u >= dw0) {           // (NC == 32: the LDS-DMA waves; their address chains stay in here)
+          w_prefetch<2 * NC, NC, EPI_ATT, THREADS>(wlB, pb + L.c2_W, pb + L.c2_as, pb + L.c2_ad, dw0);
+          vec_prefetch<THREADS>(wlB + B2OFF, pb + L.c2_b, NC);
         }
-      } else
-        seg_proj<NC, 2 * NC, 2, EPI_ATT, THREADS, true, true>(rw, xA, 0, pb + L.c1_W, base + SL.h1, 0, hA, 0, pb + L.c1_as,
-                                                               pb + L.c1_ad, base + SL.as1, base + SL.ad1, 0, sa2, sd2,
-                                                               nullptr, 0, nullptr, 0, wlA);
-      dma_land(dw0);
-      lds_barrier();                                      // own rows of h1 / a_src are in LDS; the saved copies drain meanwhile
-      ++xc.ep;                                    // exchange F1: the gathers below read h1 / a_src of neighbour rows
-      if (!xreg) xch_export2<2 * NC, 2, THREADS>(xc, xbuf, elist, ecnt, hA, (unsigned)XL.f1h, elist, ecnt, sa2, (unsigned)XL.f1a);
-      xch_import2<2 * NC, 2, THREADS>(xc, xbuf, hlist, hcnt, (unsigned)XL.f1h, hA, hlist, hcnt, (unsigned)XL.f1a, sa2);
-      xch_after<THREADS>(xc, pace, drain);
-      lds_barrier();
-      STAMP();
-      // K2 conv1: alpha -> HBM, the gather's o1 -> HBM + the x buffer of proj2
-      if (__builtin_expect(2 * oeg <= wr * NC, 1)) {
         if constexpr (NC == 32) {
-          win_fwd_agg<true, 2, NC, THREADS>(rw, nbin, rp, colo, hA, sa2, sd2, base + SL.al1, elo, hBw, wlA + B1OFF,
-                                            base + SL.o1, 0, xB, mo1 ? mo1 + b * ow : nullptr, xout(false, fflag, 0, 0));
-        } else {
-          win_softmax<2, THREADS>(rw, nbin, rp, colo, sa2, sd2, base + SL.al1, elo, hBw);
-          lds_barrier();
-          win_gather<true, 2, NC, THREADS>(rw, nbin, rp, colo, hA, hBw, wlA + B1OFF, base + SL.o1, 0, xB,
-                                           mo1 ? mo1 + b * ow : nullptr);
-        }
-      } else {
-        dma_land(dw0);                            // (every wave reads LDS below)
-        seg_softmax<2, false, THREADS>(rw, rp, colo, sa2, sd2, 0, base + SL.al1, elo, nullptr);
-        __syncthreads();
-        seg_gather<true, 2, NC, THREADS, 1>(rw, rp, colo, hA, 0, base + SL.al1, elo, pb + L.c1_b, base + SL.o1, 0, xB, 0,
+          if (wave_u < PW) {                         // the tile waves
+            win_proj<NC, 2 * NC, 2, EPI_ATT, 2, PW, THREADS>(rw, xA, wlA, base + SL.h1, 0, hA, base + SL.as1, base + SL.ad1, sa2,
+                                                         sd2, nullptr, nullptr, nullptr, nullptr, xout(xreg, fflag, XL.f1h, XL.f1a));
+          }
+        } else
+          seg_proj<NC, 2 * NC, 2, EPI_ATT, THREADS, true, true>(rw, xA, 0, pb + L.c1_W, base + SL.h1, 0, hA, 0, pb + L.c1_as,
+                                                                 pb + L.c1_ad, base + SL.as1, base + SL.ad1, 0, sa2, sd2,
+                                                                 nullptr, 0, nullptr, 0, wlA);
+        dma_land(dw0);
+        lds_barrier();                                      // own rows of h1 / a_src are in LDS; the saved copies drain meanwhile
+      }
+      {
+        FRESH_ARGS();
+        ++xc.ep;                                    // exchange F1: the gathers below read h1 / a_src of neighbour rows
+        if (!xreg) xch_export2<2 * NC, 2, THREADS>(xc, xbuf, elist, ecnt, hA, (unsigned)XL.f1h, elist, ecnt, sa2, (unsigned)XL.f1a);
+        xch_import2<2 * NC, 2, THREADS>(xc, xbuf, hlist, hcnt, (unsigned)XL.f1h, hA, hlist, hcnt, (unsigned)XL.f1a, sa2);
+        xch_after<THREADS>(xc, pace, drain);
+        lds_barrier();
+        STAMP();
+      }
+      {
+        FRESH_ARGS();
+        [[maybe_unused]] const float* pb = P + L.p_block0 + (int64_t)launder_s(b) * L.p_block_stride;
+        float* base = segbase + (int64_t)launder_s(b) * SL.bstride;
+        // K2 conv1: alpha -> HBM, the gather's o1 -> HBM + the x buffer of proj2
+        if (__builtin_expect(2 * oeg <= wr * NC, 1)) {
+          if constexpr (NC == 32) {
+            win_fwd_agg<true, 2, NC, THREADS>(rw, nbin, rp, colo, hA, sa2, sd2, base + SL.al1, elo, hBw, wlA + B1OFF,
+                                              base + SL.o1, 0, xB, mo1 ? mo1 + b * ow : nullptr, xout(false, fflag, 0, 0));
+          } else {
+            win_softmax<2, THREADS>(rw, nbin, rp, colo, sa2, sd2, base + SL.al1, elo, hBw);
+            lds_barrier();
+            win_gather<true, 2, NC, THREADS>(rw, nbin, rp, colo, hA, hBw, wlA + B1OFF, base + SL.o1, 0, xB,
                                              mo1 ? mo1 + b * ow : nullptr);
-      }
-      lds_barrier();
-      STAMP();
-      if (b + 1 < L.nb && (NC != 32 || wave_u >= dw0)) {
-        const float* pn = P + L.p_block0 + (int64_t)(launder_s(b) + 1) * L.p_block_stride;
-        w_prefetch<NC, 2 * NC, EPI_ATT, THREADS>(wlA, pn + L.c1_W, pn + L.c1_as, pn + L.c1_ad, dw0);
-        vec_prefetch<THREADS>(wlA + B1OFF, pn + L.c1_b, 2 * NC);
-      }
-      if constexpr (NC == 32) {
-        if (wave_u < PW) {
-          float* bl = segbase + (int64_t)launder_s(b) * SL.bstride;
-          win_proj<2 * NC, NC, 1, EPI_ATT, 2, PW, THREADS>(rw, xB, wlB, bl + SL.h2, 0, hB, bl + SL.as2, bl + SL.ad2, sa1, sd1,
-                                                       nullptr, nullptr, nullptr, nullptr, xout(xreg, fflag, XL.f2h, XL.f2a));
+          }
+        } else {
+          dma_land(dw0);                            // (every wave reads LDS below)
+          seg_softmax<2, false, THREADS>(rw, rp, colo, sa2, sd2, 0, base + SL.al1, elo, nullptr);
+          __syncthreads();
+          seg_gather<true, 2, NC, THREADS, 1>(rw, rp, colo, hA, 0, base + SL.al1, elo, pb + L.c1_b, base + SL.o1, 0, xB, 0,
+                                               mo1 ? mo1 + b * ow : nullptr);
         }
-      } else
-        seg_proj<2 * NC, NC, 1, EPI_ATT, THREADS, true, true>(rw, xB, 0, pb + L.c2_W, base + SL.h2, 0, hB, 0, pb + L.c2_as,
-                                                             pb + L.c2_ad, base + SL.as2, base + SL.ad2, 0, sa1, sd1,
-                                                             nullptr, 0, nullptr, 0, wlB);
-      dma_land(dw0);
-      lds_barrier();
-      ++xc.ep;                                    // exchange F2
-      if (!xreg) xch_export2<NC, 1, THREADS>(xc, xbuf, elist, ecnt, hB, (unsigned)XL.f2h, elist, ecnt, sa1, (unsigned)XL.f2a);
-      xch_import2<NC, 1, THREADS>(xc, xbuf, hlist, hcnt, (unsigned)XL.f2h, hB, hlist, hcnt, (unsigned)XL.f2a, sa1);
-      xch_after<THREADS>(xc, pace, drain);
-      lds_barrier();
-      STAMP();
+        lds_barrier();
+        STAMP();
+      }
+      {
+        FRESH_ARGS();
+        [[maybe_unused]] const float* pb = P + L.p_block0 + (int64_t)launder_s(b) * L.p_block_stride;
+        [[maybe_unused]] float* base = segbase + (int64_t)launder_s(b) * SL.bstride;
+        if (b + 1 < nb && (NC != 32 || wave_u >= dw0)) {
+          const float* pn = pb + L.p_block_stride;
+          w_prefetch<NC, 2 * NC, EPI_ATT, THREADS>(wlA, pn + L.c1_W, pn + L.c1_as, pn + L.c1_ad, dw0);
+          vec_prefetch<THREADS>(wlA + B1OFF, pn + L.c1_b, 2 * NC);
+        }
+        if constexpr (NC == 32) {
+          if (wave_u < PW) {
+            win_proj<2 * NC, NC, 1, EPI_ATT, 2, PW, THREADS>(rw, xB, wlB, base + SL.h2, 0, hB, base + SL.as2, base + SL.ad2, sa1,
+                                                         sd1, nullptr, nullptr, nullptr, nullptr, xout(xreg, fflag, XL.f2h, XL.f2a));
+          }
+        } else
+          seg_proj<2 * NC, NC, 1, EPI_ATT, THREADS, true, true>(rw, xB, 0, pb + L.c2_W, base + SL.h2, 0, hB, 0, pb + L.c2_as,
+                                                               pb + L.c2_ad, base + SL.as2, base + SL.ad2, 0, sa1, sd1,
+                                                               nullptr, 0, nullptr, 0, wlB);
+        dma_land(dw0);
+        lds_barrier();
+      }
+      {
+        FRESH_ARGS();
+        ++xc.ep;                                    // exchange F2
+        if (!xreg) xch_export2<NC, 1, THREADS>(xc, xbuf, elist, ecnt, hB, (unsigned)XL.f2h, elist, ecnt, sa1, (unsigned)XL.f2a);
+        xch_import2<NC, 1, THREADS>(xc, xbuf, hlist, hcnt, (unsigned)XL.f2h, hB, hlist, hcnt, (unsigned)XL.f2a, sa1);
+        xch_after<THREADS>(xc, pace, drain);
+        lds_barrier();
+        STAMP();
+      }
       // K2 conv2: y2 in the lower half of the h1 window (its upper half: the alpha table of rows beyond the slot path)
       float* y2T = hAw - wlo * NC;
-      if (__builtin_expect(oeg <= wr * NC, 1)) {
-        float* al2L = hAw + (size_t)wr * NC;
-        if constexpr (NC == 32) {
-          win_fwd_agg<false, 1, NC, THREADS>(rw, nbin, rp, colo, hB, sa1, sd1, base + SL.al2, elo, al2L, wlB + B2OFF, y2T,
-                                             0, nullptr, nullptr, xout(xreg, fflag, XL.f3, 0));
+      {
+        FRESH_ARGS();
+        [[maybe_unused]] const float* pb = P + L.p_block0 + (int64_t)launder_s(b) * L.p_block_stride;
+        float* base = segbase + (int64_t)launder_s(b) * SL.bstride;
+        if (__builtin_expect(oeg <= wr * NC, 1)) {
+          float* al2L = hAw + (size_t)wr * NC;
+          if constexpr (NC == 32) {
+            win_fwd_agg<false, 1, NC, THREADS>(rw, nbin, rp, colo, hB, sa1, sd1, base + SL.al2, elo, al2L, wlB + B2OFF, y2T,
+                                               0, nullptr, nullptr, xout(xreg, fflag, XL.f3, 0));
+          } else {
+            win_softmax<1, THREADS>(rw, nbin, rp, colo, sa1, sd1, base + SL.al2, elo, al2L);
+            lds_barrier();
+            win_gather<false, 1, NC, THREADS>(rw, nbin, rp, colo, hB, al2L, wlB + B2OFF, y2T, 0, nullptr, nullptr);
+          }
         } else {
-          win_softmax<1, THREADS>(rw, nbin, rp, colo, sa1, sd1, base + SL.al2, elo, al2L);
-          lds_barrier();
-          win_gather<false, 1, NC, THREADS>(rw, nbin, rp, colo, hB, al2L, wlB + B2OFF, y2T, 0, nullptr, nullptr);
+          dma_land(dw0);
+          seg_softmax<1, false, THREADS>(rw, rp, colo, sa1, sd1, 0, base + SL.al2, elo, nullptr);
+          __syncthreads();
+          seg_gather<false, 1, NC, THREADS, 1>(rw, rp, colo, hB, 0, base + SL.al2, elo, pb + L.c2_b, y2T, 0);
         }
-      } else {
-        dma_land(dw0);
-        seg_softmax<1, false, THREADS>(rw, rp, colo, sa1, sd1, 0, base + SL.al2, elo, nullptr);
-        __syncthreads();
-        seg_gather<false, 1, NC, THREADS, 1>(rw, rp, colo, hB, 0, base + SL.al2, elo, pb + L.c2_b, y2T, 0);
+        lds_barrier();
       }
-      lds_barrier();
-      ++xc.ep;                                    // exchange F3: K3 averages y2 over neighbour rows
-      if (!(xreg && oeg <= wr * NC)) xch_export2<NC, 0, THREADS>(xc, xbuf, elist, ecnt, y2T, (unsigned)XL.f3, elist, 0, y2T, 0u);
-      xch_import2<NC, 0, THREADS>(xc, xbuf, hlist, hcnt, (unsigned)XL.f3, y2T, hlist, 0, 0u, y2T);
-      xch_after<THREADS>(xc, pace, drain);
-      lds_barrier();
-      STAMP();
-      // K3: residual from the x buffer, result back into it (and to HBM: saved xin of the next block)
-      win_mean_fwd<NC, THREADS>(rw, mbin, mrp, mcolo, y2T, xA, xnext, xA,
-                                     (mxin && b + 1 < L.nb) ? mxin + (b + 1) * ow : nullptr);
-      lds_barrier();
-      STAMP();
-      xcur = xnext;
+      {
+        FRESH_ARGS();
+        ++xc.ep;                                    // exchange F3: K3 averages y2 over neighbour rows
+        if (!(xreg && oeg <= wr * NC)) xch_export2<NC, 0, THREADS>(xc, xbuf, elist, ecnt, y2T, (unsigned)XL.f3, elist, 0, y2T, 0u);
+        xch_import2<NC, 0, THREADS>(xc, xbuf, hlist, hcnt, (unsigned)XL.f3, y2T, hlist, 0, 0u, y2T);
+        xch_after<THREADS>(xc, pace, drain);
+        lds_barrier();
+        STAMP();
+      }
+      {
+        FRESH_ARGS();
+        // K3: residual from the x buffer, result back into it (and to HBM: saved xin of the next block)
+        float* xnext = segbase + (int64_t)(launder_s(b) + 1) * SL.bstride + SL.xin;
+        win_mean_fwd<NC, THREADS>(rw, mbin, mrp, mcolo, y2T, xA, xnext, xA,
+                                       (mxin && b + 1 < nb) ? mxin + (b + 1) * ow : nullptr);
+        lds_barrier();
+        STAMP();
+      }
     }
     {  // lin1
       constexpr int G = NC / 4;
@@ -550,6 +593,7 @@ __global__ __launch_bounds__(THREADS) void gatres_window_kernel(const FusedArgs 
     // bare barriers (the issue itself is what takes the time: the CU accepts ~12 B per cycle).
     auto dma_conv2_early = [&](int blk, int w0) {
       if (wave_u < w0) return;                   // (the tile waves of the stage: none of the address chains below)
+      FRESH_ARGS();
       blk = launder_s(blk);
       const float* bs = segbase + (int64_t)blk * SL.bstride;
       dma_copy16<THREADS>(hTw, bs + SL.h2 + (size_t)wlo * NC, wr * NC, w0);
@@ -560,6 +604,7 @@ __global__ __launch_bounds__(THREADS) void gatres_window_kernel(const FusedArgs 
     };
     auto dma_conv2_late = [&](int blk, int w0) {
       if (wave_u < w0) return;
+      FRESH_ARGS();
       blk = launder_s(blk);
       const float* bs = segbase + (int64_t)blk * SL.bstride;
       dma_copy4<THREADS>(alTw, bs + SL.al2 + ewlo, weg, w0);
@@ -627,52 +672,55 @@ __global__ __launch_bounds__(THREADS) void gatres_window_kernel(const FusedArgs 
       return o;
     };
     STAMP();
-    for (int b = L.nb - 1; b >= 0; --b) {
-      const float* base = segbase + (int64_t)b * SL.bstride;
-      const int64_t po = L.p_block0 + (int64_t)b * L.p_block_stride;
-      const float* pb = P + po;
-      float* sb = slab + po;
-      const float* wt1 = a.wt + (int64_t)b * 2 * w;
-      const float* wt2 = wt1 + w;
-      [[maybe_unused]] const bool xs_on = STAMPS_PTR && a.stamp_cap >= 4096 && seg == 0 && b == L.nb / 2;
+    const int nb = L.nb;
+    for (int b = nb - 1; b >= 0; --b) {
+      // (per stage: FRESH_ARGS() re-reads the offsets it needs; keep / sb / base are formed where they are used)
+      [[maybe_unused]] const bool xs_on = STAMPS_PTR && a.stamp_cap >= 4096 && seg == 0 && b == nb / 2;
       [[maybe_unused]] int xs_i = 0;
       XSTAMP();
       lds_barrier();                                     // own rows of g_pre are in LDS (lin1 backward / the previous dX1)
       XSTAMP();
-      ++xc.ep;                                   // exchange B1: K3 backward gathers g_pre of neighbour rows
-      if (!xrows || b == L.nb - 1)               // (else the previous block's dX1 stored them)
-        xch_export2<NC, 0, THREADS>(xc, xbuf, erow, ercnt, gpT, (unsigned)XL.b1, erow, 0, gpT, 0u);
-      XSTAMP();
-      xch_import2<NC, 0, THREADS>(xc, xbuf, hrow, hrcnt, (unsigned)XL.b1, gpT, hrow, 0, 0u, gpT);
-      XSTAMP();
-      xch_after<THREADS>(xc, pace, drain);
-      XSTAMP();
-      lds_barrier();
-      XSTAMP();
-      publish_items<THREADS>(a, seg, part, 2 * (L.nb - 1 - b), grp.local, false);      // the blocks above are kept
+      {
+        FRESH_ARGS();
+        ++xc.ep;                                   // exchange B1: K3 backward gathers g_pre of neighbour rows
+        if (!xrows || b == nb - 1)                 // (else the previous block's dX1 stored them)
+          xch_export2<NC, 0, THREADS>(xc, xbuf, erow, ercnt, gpT, (unsigned)XL.b1, erow, 0, gpT, 0u);
+        XSTAMP();
+        xch_import2<NC, 0, THREADS>(xc, xbuf, hrow, hrcnt, (unsigned)XL.b1, gpT, hrow, 0, 0u, gpT);
+        XSTAMP();
+        xch_after<THREADS>(xc, pace, drain);
+        XSTAMP();
+        lds_barrier();
+        XSTAMP();
+      }
+      publish_items<THREADS>(a, seg, part, 2 * (nb - 1 - b), grp.local, false);      // the blocks above are kept
       // K3 backward, conv2's edge dots and softmax backward: one stage (win_bwd_dst)
       STAMP();
-      float* keep = sc + L.sc_keep + (int64_t)b * L.keep_stride;
-      float* gh = keep + L.k_gh1;
-      float* gh2 = keep + L.k_gh2;
-      win_bwd_dst<true, 1, NC, THREADS>(rw, nbin, rp, colo, gy2T, hT2, alT2 + elo, asT2, adT2, ge2 + elo, gad2, mout, mrp,
-                                             mtrp, mtdsto, gpT, xout(xedge, (unsigned)XL.b2y, (unsigned)XL.b2e), elo);
-      lds_barrier();
-      XSTAMP();
-      seg_bias_part<NC, THREADS>(rw, gy2T, 0, red);  // (own rows of g_y2: the sweep below only writes halo rows)
-      ++xc.ep;                                   // exchange B2: the source-major stage reads g_y2 / g_e of neighbour rows
-      if (!xedge) xch_export2<NC, 1, THREADS>(xc, xbuf, erow, ercnt, gy2T, (unsigned)XL.b2y, eedge, eecnt, ge2, (unsigned)XL.b2e);
-      XSTAMP();
-      xch_import2<NC, 1, THREADS>(xc, xbuf, hrow, hrcnt, (unsigned)XL.b2y, gy2T, hedge, hecnt, (unsigned)XL.b2e, ge2);
-      XSTAMP();
-      xch_after<THREADS>(xc, pace, drain);
-      XSTAMP();
-      lds_barrier();
-      XSTAMP();
-      STAMP();
+      {
+        FRESH_ARGS();
+        win_bwd_dst<true, 1, NC, THREADS>(rw, nbin, rp, colo, gy2T, hT2, alT2 + elo, asT2, adT2, ge2 + elo, gad2, mout, mrp,
+                                               mtrp, mtdsto, gpT, xout(xedge, (unsigned)XL.b2y, (unsigned)XL.b2e), elo);
+        lds_barrier();
+        XSTAMP();
+      }
+      {
+        FRESH_ARGS();
+        seg_bias_part<NC, THREADS>(rw, gy2T, 0, red);  // (own rows of g_y2: the sweep below only writes halo rows)
+        ++xc.ep;                                   // exchange B2: the source-major stage reads g_y2 / g_e of neighbour rows
+        if (!xedge) xch_export2<NC, 1, THREADS>(xc, xbuf, erow, ercnt, gy2T, (unsigned)XL.b2y, eedge, eecnt, ge2, (unsigned)XL.b2e);
+        XSTAMP();
+        xch_import2<NC, 1, THREADS>(xc, xbuf, hrow, hrcnt, (unsigned)XL.b2y, gy2T, hedge, hecnt, (unsigned)XL.b2e, ge2);
+        XSTAMP();
+        xch_after<THREADS>(xc, pace, drain);
+        XSTAMP();
+        lds_barrier();
+        XSTAMP();
+        STAMP();
+      }
       // this block's conv1 tables and W1^T stream in while the matrix cores run dX2 (below)
       auto dma_conv1_early = [&]() {
         if (wave_u < dw0) return;
+        FRESH_ARGS();
         const int bl = launder_s(b);
         const float* bsl = segbase + (int64_t)bl * SL.bstride;
         w_prefetch<2 * NC, NC, EPI_RESID_MASK, THREADS>(wlB, a.wt + (int64_t)bl * 2 * w, nullptr, nullptr, dw0);
@@ -682,20 +730,30 @@ __global__ __launch_bounds__(THREADS) void gatres_window_kernel(const FusedArgs 
         dma_copy4<THREADS>(adTo, bsl + SL.ad1 + lo * 2, ow * 2, dw0);
         dma_copy4<THREADS>(alTw, bsl + SL.al1 + ewlo * 2, weg * 2, dw0);      // conv1's alpha (its table held conv2's until here)
       };
-      seg_bias_finish<NC, THREADS>(red, sb + L.c2_b);
-      win_agg_bwd_src<1, NC, THREADS>(rw, tout, trp, teido, tdsto, 0, gy2T, alT2, ge2, gad2, wlA + A2OFF, wlA + A2OFF + NC,
-                                           gh2, n0, keep + L.k_gas2, keep + L.k_gad2, xG2);
-      lds_barrier();                   // g_y2 (RA) and the conv2 tables are dead
-      XSTAMP();
-      STAMP();
+      {
+        FRESH_ARGS();
+        float* sb = slab + L.p_block0 + (int64_t)launder_s(b) * L.p_block_stride;
+        float* keep = sc + L.sc_keep + (int64_t)launder_s(b) * L.keep_stride;
+        seg_bias_finish<NC, THREADS>(red, sb + L.c2_b);
+        win_agg_bwd_src<1, NC, THREADS>(rw, tout, trp, teido, tdsto, 0, gy2T, alT2, ge2, gad2, wlA + A2OFF, wlA + A2OFF + NC,
+                                             keep + L.k_gh2, n0, keep + L.k_gas2, keep + L.k_gad2, xG2);
+        lds_barrier();                   // g_y2 (RA) and the conv2 tables are dead
+        XSTAMP();
+        STAMP();
+      }
       dma_conv1_early();
       if (NC == 32 && a.keep_lds) {              // (the ReLU sign masks of the forward phase are in LDS: no global operand)
         if constexpr (NC == 32)
-          if (wave_u < PW)
+          if (wave_u < PW) {
+            FRESH_ARGS();
             win_proj<NC, 2 * NC, 1, EPI_RESID_MASK, 1, PW, THREADS>(rw, xG2, wlA, RA, 0, nullptr, nullptr, nullptr, nullptr,
                                                                 nullptr, nullptr, nullptr, mo1 + launder_s(b) * ow, nullptr,
                                                                 xout(xrows, (unsigned)XL.b3o, 0u));
+          }
       } else {
+        FRESH_ARGS();
+        const float* base = segbase + (int64_t)launder_s(b) * SL.bstride;
+        const float* wt2 = a.wt + (int64_t)launder_s(b) * 2 * w + w;
         seg_proj<NC, 2 * NC, 1, EPI_RESID_MASK, THREADS, true, true>(
             rw, xG2, 0, wt2, RA, 0, nullptr, 0, nullptr, nullptr, nullptr, nullptr, 0, nullptr, nullptr, nullptr, 0,
             (GATRES_DIAG && (a.no_halo & 4)) ? nullptr : base + SL.o1, 0, wlA, nullptr, nullptr, mo1 ? mo1 + b * ow : nullptr,
@@ -705,41 +763,56 @@ __global__ __launch_bounds__(THREADS) void gatres_window_kernel(const FusedArgs 
       lds_barrier();                             // (not __syncthreads(): its vmcnt(0) made the tile waves wait for their granule stores)
       XSTAMP();
       STAMP();
-      seg_bias_part<2 * NC, THREADS>(rw, RA, 0, red);
-      win_bwd_dst<false, 2, NC, THREADS>(rw, nbin, rp, colo, RA, hT1, alT1 + elo * 2, asT1, adT1, ge1 + elo * 2, gad1,
-                                              nullptr, nullptr, nullptr, nullptr, nullptr,
-                                              xout(xedge, 0u, (unsigned)XL.b3e), elo);
-      lds_barrier();
-      XSTAMP();
-      ++xc.ep;                                   // exchange B3
-      if (!xrows || !xedge)
-        xch_export2<2 * NC, 2, THREADS>(xc, xbuf, erow, xrows ? 0 : ercnt, RA, (unsigned)XL.b3o, eedge, xedge ? 0 : eecnt, ge1,
-                                        (unsigned)XL.b3e);
-      XSTAMP();
-      xch_import2<2 * NC, 2, THREADS>(xc, xbuf, hrow, hrcnt, (unsigned)XL.b3o, RA, hedge, hecnt, (unsigned)XL.b3e, ge1);
-      XSTAMP();
-      xch_after<THREADS>(xc, pace, drain);
-      XSTAMP();
-      lds_barrier();
-      XSTAMP();
-      publish_items<THREADS>(a, seg, part, 2 * (L.nb - 1 - b) + 1, grp.local, false);      // conv2 tables complete
+      {
+        FRESH_ARGS();
+        seg_bias_part<2 * NC, THREADS>(rw, RA, 0, red);
+        win_bwd_dst<false, 2, NC, THREADS>(rw, nbin, rp, colo, RA, hT1, alT1 + elo * 2, asT1, adT1, ge1 + elo * 2, gad1,
+                                                nullptr, nullptr, nullptr, nullptr, nullptr,
+                                                xout(xedge, 0u, (unsigned)XL.b3e), elo);
+        lds_barrier();
+        XSTAMP();
+      }
+      {
+        FRESH_ARGS();
+        ++xc.ep;                                   // exchange B3
+        if (!xrows || !xedge)
+          xch_export2<2 * NC, 2, THREADS>(xc, xbuf, erow, xrows ? 0 : ercnt, RA, (unsigned)XL.b3o, eedge, xedge ? 0 : eecnt, ge1,
+                                          (unsigned)XL.b3e);
+        XSTAMP();
+        xch_import2<2 * NC, 2, THREADS>(xc, xbuf, hrow, hrcnt, (unsigned)XL.b3o, RA, hedge, hecnt, (unsigned)XL.b3e, ge1);
+        XSTAMP();
+        xch_after<THREADS>(xc, pace, drain);
+        XSTAMP();
+        lds_barrier();
+        XSTAMP();
+      }
+      publish_items<THREADS>(a, seg, part, 2 * (nb - 1 - b) + 1, grp.local, false);      // conv2 tables complete
       STAMP();
-      seg_bias_finish<2 * NC, THREADS>(red, sb + L.c1_b);
-      win_agg_bwd_src<2, NC, THREADS>(rw, tout, trp, teido, tdsto, 0, RA, alT1, ge1, gad1, wlB + A1OFF, wlB + A1OFF + 2 * NC,
-                                           gh, n0, keep + L.k_gas1, keep + L.k_gad1, xG1);
-      lds_barrier();
-      XSTAMP();
-      STAMP();
+      {
+        FRESH_ARGS();
+        float* sb = slab + L.p_block0 + (int64_t)launder_s(b) * L.p_block_stride;
+        float* keep = sc + L.sc_keep + (int64_t)launder_s(b) * L.keep_stride;
+        seg_bias_finish<2 * NC, THREADS>(red, sb + L.c1_b);
+        win_agg_bwd_src<2, NC, THREADS>(rw, tout, trp, teido, tdsto, 0, RA, alT1, ge1, gad1, wlB + A1OFF, wlB + A1OFF + 2 * NC,
+                                             keep + L.k_gh1, n0, keep + L.k_gas1, keep + L.k_gad1, xG1);
+        lds_barrier();
+        XSTAMP();
+        STAMP();
+      }
       if (b > 0) { dma_conv2_early(b - 1, dw0); dma_conv2_late(b - 1, dw0); }
       if (NC == 32 && a.keep_lds) {
         if constexpr (NC == 32)
           if (wave_u < PW) {
+            FRESH_ARGS();
             const int bl = launder_s(b);
             win_proj<2 * NC, NC, 1, EPI_RESID_MASK, 1, PW, THREADS>(rw, xG1, wlB, gp_nxt, n0, gpT, nullptr, nullptr, nullptr,
                                                                 nullptr, gkeep, gkeep, nullptr, bl > 0 ? mxin + bl * ow : nullptr,
                                                                 xout(xrows && bl > 0, (unsigned)XL.b1, 0u));
           }
       } else {
+        FRESH_ARGS();
+        const float* base = segbase + (int64_t)launder_s(b) * SL.bstride;
+        const float* wt1 = a.wt + (int64_t)launder_s(b) * 2 * w;
         seg_proj<2 * NC, NC, 1, EPI_RESID_MASK, THREADS, true, true>(
             rw, xG1, 0, wt1, gp_nxt, n0, gpT, 0, nullptr, nullptr, nullptr, nullptr, 0, nullptr, nullptr,
             (GATRES_DIAG && (a.no_halo & 4)) ? nullptr : gp_cur, n0,

@@ -669,6 +669,16 @@ __device__ __forceinline__ void win_fwd_agg(Rows rw, const u16* nb, const u16* r
     lds_rd128_32(a_nb + (unsigned)(r - rw.lo) * 16u, a_ad + (unsigned)(r * H) * 4u, w, adst);
     const NbrIn d = unpack_in(w);
     float4 acc = f4zero();
+#ifdef GATRES_VALU_PROBE      // experiment builds only (profiles/r04_valu_probe.txt): N extra VALU instructions per lane and call
+#ifdef GATRES_VALU_PROBE_H
+    if constexpr (H == GATRES_VALU_PROBE_H)
+#endif
+#ifdef GATRES_VALU_PROBE_ILP
+    asm volatile(".rept " GATRES_VALU_PROBE "\n\tv_mov_b32 %0, %0\n\tv_mov_b32 %1, %1\n\t.endr" : "+v"(acc.x), "+v"(acc.y));
+#else
+    asm volatile(".rept " GATRES_VALU_PROBE "\n\tv_mov_b32 %0, %0\n\t.endr" : "+v"(acc.x));
+#endif
+#endif
     if (__builtin_expect(wave_has_hub(d.deg), 0)) {
       // edge at a time: the head's first lane forms the coefficients (seg_softmax's loops), through the LDS table
       const int beg = rp[r], end = rp[r + 1];
