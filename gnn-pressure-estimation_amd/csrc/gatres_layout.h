@@ -3,6 +3,7 @@
 #include "gatres_common.h"
 
 static inline __host__ __device__ int64_t r4(int64_t v) { return (v + 3) & ~(int64_t)3; }
+#define GATRES_UREC_WORDS 128      // window kernel: words of one workgroup's geometry record (forward half | backward half)
 
 struct Layout {
   int nb, nc;
@@ -24,6 +25,7 @@ struct Layout {
   // window kernel, split segments: tagged 8-byte granules {value, epoch} through which the parts of a segment hand each
   // other the rows / edge values their neighbours need (k_fused.hip: xch_*), one region per segment
   int64_t sc_xch, xch_stride;        // in floats (a granule = 2 floats)
+  int64_t sc_urec;                   // window kernel: GATRES_UREC_WORDS words per workgroup
   // fused path only: every block keeps its g_h / g_alpha tables until the deferred parameter-gradient launch
   // (k_fused.hip: param_grads_kernel) has consumed them.  Block-major, global node index.
   int64_t sc_keep, keep_stride, k_gh1, k_gh2, k_gas1, k_gad1, k_gas2, k_gad2;
@@ -176,6 +178,10 @@ static inline bool make_layout(const gatres_model_t* m, int64_t N, int64_t Eg, i
     L->xch_stride = 2 * X.total;
     o += (int64_t)num_segments * L->xch_stride;
   }
+  // window kernel: one record of per-part geometry (LDS table offsets, counts) per workgroup, written by the workgroup's
+  // prologue and re-read per stage through the constant cache (k_window.hip: FwdRec / BwdRec)
+  L->sc_urec = o;
+  if (L->xch_stride > 0) o += (int64_t)((num_segments + 7) / 8) * 8 * 8 * GATRES_UREC_WORDS;
   L->sc_wb = o;    o += r4((int64_t)nb * 4 * nc * nc);        // nb * 4 matrices * 2nc^2 bf16 = nb * 4 nc^2 floats
   L->sc_px = o;    o += r4(N);
   L->sc_pmask = o; o += r4((N + 3) / 4);

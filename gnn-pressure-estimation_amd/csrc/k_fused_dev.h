@@ -71,6 +71,7 @@ struct FusedArgs {
   int ptab_m, ptab_stride;
   unsigned* ready;          // [segment][4] lines: items published by the segment's part 0 for each consumer
   unsigned long long* xch;  // window kernel: granule exchange regions, one per segment (Layout::sc_xch)
+  int* urec;                // window kernel: GATRES_UREC_WORDS words per workgroup (Layout::sc_urec), written by its prologue
   XchLayout XL;
   Layout L;
   SegLayout SL;             // segment-major saved activations (training)

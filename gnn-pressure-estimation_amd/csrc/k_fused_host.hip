@@ -588,6 +588,7 @@ extern "C" int gatres_fused_run(const gatres_model_t* m, const gatres_graph_t* g
   a.part_slabs = scratch + a.L.sc_part_slabs;
   a.SL = make_seg_layout(a.L.nb, a.L.nc, g->max_segment_nodes, g->max_segment_edges_gat);
   a.xch = reinterpret_cast<unsigned long long*>(scratch + a.L.sc_xch);
+  a.urec = reinterpret_cast<int*>(scratch + a.L.sc_urec);
   a.XL = make_xch_layout(a.L.nc, g->max_segment_nodes, g->max_segment_edges_gat);
   a.stamps = g_stamps; a.stamp_cap = g_stamp_cap;
   a.phases = (phases & (GATRES_PHASE_FORWARD | GATRES_PHASE_BACKWARD)) | ((phases & GATRES_PHASE_LOSS) ? PH_LOSS : 0);

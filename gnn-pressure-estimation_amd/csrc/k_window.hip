@@ -1,5 +1,6 @@
 // Window form of the fused per-snapshot kernel: the headline path (gatres_small, 8 parts per snapshot).
 // Device code and commentary: k_fused_dev.h.
+#include <climits>
 #include "k_window_stages.h"
 
 namespace {
@@ -39,6 +40,57 @@ __device__ __forceinline__ KArgs kargs_fresh() {
 #define FRESH_ARGS()                                                                                          \
   const KArgs ka_ = kargs_fresh();                                                                            \
   [[maybe_unused]] const auto& L = ka_->L; [[maybe_unused]] const auto& SL = ka_->SL; [[maybe_unused]] const auto& XL = ka_->XL
+
+// The part's geometry, re-read where it is used.  The two phase prologues carve LDS into ~25 / ~45 tables whose addresses (and
+// the part's row / edge ranges and list lengths) every stage of the block loops needs a handful of; held in SGPRs across the
+// loops they were the rest of the spill reloads.  The prologue now writes them into this workgroup's record (FusedArgs::urec,
+// GATRES_UREC_WORDS words: forward half | backward half) and a stage reads its fields back by scalar loads (FRESH_FWD /
+// FRESH_BWD: same laundered-pointer idiom as FRESH_ARGS).  LDS addresses are byte offsets from the start of the LDS array
+// (shifted views may be negative); NO_TABLE = the table does not exist in this launch (null pointer).
+struct FwdRec {
+  int lo, hi, ow, wr, oeg, elo, hcnt, ecnt;
+  int xA, xB, wlA, wlB, hA, hB, hBw, y2T, al2L, sa2, sa1, sd2, sd1, fflag, hlist, elist, nbin, mbin, rp, colo, mrp, mcolo, mo1, mxin;
+};
+struct BwdRec {
+  int lo, hi, ow, wr, wlo, elo, ewlo, weg, n0, hrcnt, hecnt, ercnt, eecnt;
+  int RA, gpT, gy2T, ge2, ge1, gad2, gad1, hTw, hT2, hT1, asTw, asT2, asT1, adTo, adT2, adT1, alTw, alT2, alT1, xG2, xG1, gkeep,
+      wlA, wlB, rp, colo, trp, teido, tdsto, mrp, mtrp, mtdsto, nbin, tout, mout, hrow, hedge, erow, eedge, bflag, mo1, mxin;
+};
+static_assert(sizeof(FwdRec) <= 4 * (GATRES_UREC_WORDS / 2) && sizeof(BwdRec) <= 4 * (GATRES_UREC_WORDS / 2), "record halves");
+constexpr int NO_TABLE = INT_MIN;
+template <class R>
+__device__ __forceinline__ const __attribute__((address_space(4))) R* rec_fresh(const int* words) {
+  auto p = (const __attribute__((address_space(4))) R*)(unsigned long long)words;
+  asm volatile("" : "+s"(p));
+  return p;
+}
+// after the prologue's stores and the barrier behind them: no stale line of the record in the scalar cache
+__device__ __forceinline__ void rec_published() { asm volatile("s_dcache_inv\n\ts_waitcnt lgkmcnt(0)" ::: "memory"); }
+#define FRESH_FWD() const auto rf_ = rec_fresh<FwdRec>(myrec)
+#define FRESH_BWD() const auto rb_ = rec_fresh<BwdRec>(myrec + GATRES_UREC_WORDS / 2)
+#define LDS_TABLE(T, base, off) (reinterpret_cast<T*>((base) + (off)))
+// A stage declares what it needs as a field list  LIST(T_, N_, I_)  = T_(type, table) ... N_(type, nullable table) ...
+// I_(int field) ...  and opens with  REC_LOADS(LIST); REC_PINS(LIST, ...); REC_DEFS(LIST);  -- scalar loads of the fields,
+// then the tables as pointers and the ints under their own names.  hipcc sinks every load to its first use, behind whatever
+// VALU / SALU work of the stage's opening does not need it: that hides the scalar-cache round trip.  REC_PINS is an
+// experiment switch (-DGATRES_REC_PINS): one empty asm that names every loaded value, so that all loads are issued and
+// waited for at the stage's opening -- measured + 12 us per step (0.4154 - 0.4188 vs 0.4042 - 0.4062 ms, same box), and in
+// front of the previous stage's closing barrier 0.4172 - 0.4182; one asm per value (a wait each: scalar loads return out of
+// order) 0.4427.  profiles/r04_valu_probe.txt.
+#define REC_LOAD_T(T, n) const int o_##n = RECP->n;
+#define REC_LOAD_I(n) const int o_##n = RECP->n;
+#define REC_PIN_T(T, n) , "s"(o_##n)
+#define REC_PIN_I(n) , "s"(o_##n)
+#define REC_DEF_T(T, n) [[maybe_unused]] T* n = LDS_TABLE(T, lds_raw, o_##n);
+#define REC_DEF_N(T, n) [[maybe_unused]] T* n = o_##n == NO_TABLE ? nullptr : LDS_TABLE(T, lds_raw, o_##n);
+#define REC_DEF_I(n) [[maybe_unused]] const int n = o_##n;
+#define REC_LOADS(LIST) LIST(REC_LOAD_T, REC_LOAD_T, REC_LOAD_I)
+#ifdef GATRES_REC_PINS
+#define REC_PINS(LIST, ...) asm volatile("" ::"s"(0) LIST(REC_PIN_T, REC_PIN_T, REC_PIN_I) __VA_ARGS__)
+#else
+#define REC_PINS(LIST, ...) do {} while (0)
+#endif
+#define REC_DEFS(LIST) LIST(REC_DEF_T, REC_DEF_N, REC_DEF_I) [[maybe_unused]] const Rows rw = {lo, hi}
 __device__ __forceinline__ u16* align16(u16* p) {
   return reinterpret_cast<u16*>((reinterpret_cast<uintptr_t>(p) + 15) & ~(uintptr_t)15);
 }
@@ -176,7 +228,12 @@ __global__ __launch_bounds__(THREADS) void gatres_window_kernel(const FusedArgs 
   float* dml = ldsf + 64;                          // [own row]: masked out - y, then g_out (inside the backward's `red` region)
   float xk[2] = {0.f, 0.f};                        // final activation of rows lo + rg, lo + rg + LB_R, column c (lin1 backward)
 
+  int* const myrec = a.urec + (size_t)blockIdx.x * GATRES_UREC_WORDS;
+  auto lds_off = [&](const void* p) { return (int)(reinterpret_cast<const unsigned char*>(p) - lds_raw); };
+
   if (a.phases & GATRES_PHASE_FORWARD) {
+    constexpr bool xreg = NC == 32;
+    {  // ---- prologue: LDS carve-up, the part's tables, lin0; the geometry goes into the record
     // LDS: [hA wr x 2NC | hB wr x NC | sa wr x 2 | sd own x 2 | xA own x NC | xB own x 2NC | W slot A | W slot B] topology
     float* hAw = ldsf;
     float* hBw = hAw + (size_t)wr * 2 * NC;
@@ -203,7 +260,6 @@ __global__ __launch_bounds__(THREADS) void gatres_window_kernel(const FusedArgs 
     unsigned char* fflag_o = lds_top - ((ow + 15) & ~15);
     const int hcap = max(0, (int)((fflag_o - reinterpret_cast<unsigned char*>(hlist)) / 4)) & ~1;
     u16* elist = hlist + hcap;           // export list: own rows some partner's row has an in-edge from
-    const bool xreg = NC == 32;
     const unsigned char* fflag = fflag_o - lo;
     // index-shifted views: absolute local row / relative own-edge indices work unchanged in the stage functions
     float* hA = hAw - wlo * 2 * NC;
@@ -265,10 +321,25 @@ __global__ __launch_bounds__(THREADS) void gatres_window_kernel(const FusedArgs 
         hcnt = min(hcnt, hcap); ecnt = min(ecnt, hcap);
       }
     }
-    if (xreg) {
+    if (xreg)
       for (int k = tid; k < ecnt; k += THREADS) fflag_o[(int)elist[k] - lo] = 1;
-      __syncthreads();
+    if (tid == 0) {
+      FwdRec r;
+      r.lo = rw.lo; r.hi = rw.hi; r.ow = ow; r.wr = wr; r.oeg = oeg; r.elo = elo; r.hcnt = hcnt; r.ecnt = ecnt;
+      r.xA = lds_off(xA); r.xB = lds_off(xB); r.wlA = lds_off(wlA); r.wlB = lds_off(wlB); r.hA = lds_off(hA); r.hB = lds_off(hB);
+      r.hBw = lds_off(hBw); r.y2T = lds_off(hAw - wlo * NC); r.al2L = lds_off(hAw + (size_t)wr * NC);
+      r.sa2 = lds_off(sa2); r.sa1 = lds_off(sa1); r.sd2 = lds_off(sd2); r.sd1 = lds_off(sd1); r.fflag = lds_off(fflag);
+      r.hlist = lds_off(hlist); r.elist = lds_off(elist); r.nbin = lds_off(nbin); r.mbin = lds_off(mbin);
+      r.rp = lds_off(rp); r.colo = lds_off(colo); r.mrp = lds_off(mrp); r.mcolo = lds_off(mcolo);
+      r.mo1 = mo1 ? lds_off(mo1) : NO_TABLE; r.mxin = mxin ? lds_off(mxin) : NO_TABLE;
+      const int* src = reinterpret_cast<const int*>(&r);
+#pragma unroll
+      for (int k = 0; k < (int)(sizeof(FwdRec) / 4); ++k)
+        __hip_atomic_store(myrec + k, src[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
+    }  // ---- (end of the prologue's scope: the block loop below sees the record only)
+    __syncthreads();           // export flags and the record are published
+    rec_published();
     auto xout = [&](bool on, const unsigned char* flag, long long t_rows, long long t_small) {
       XOut x;
       x.xb = xbuf; x.ep = xc.ep + 1u; x.local = xc.local; x.on = on; x.flag = flag;
@@ -276,13 +347,20 @@ __global__ __launch_bounds__(THREADS) void gatres_window_kernel(const FusedArgs 
       return x;
     };
     STAMP();
+#define RECP rf_
     const int nb = L.nb;
     for (int b = 0; b < nb; ++b) {
-      // (per stage: FRESH_ARGS() re-reads the offsets it needs; base / pb are formed where they are used)
+      // (per stage: FRESH_ARGS() / FRESH_FWD() re-read the offsets and tables the stage needs; base / pb are formed where
+      // they are used)
       {
-        FRESH_ARGS();
+        FRESH_ARGS(); FRESH_FWD();
+#define LIST_(T_, N_, I_) I_(lo) I_(hi) T_(float, xA) T_(float, wlA) T_(float, wlB) T_(float, hA) T_(float, sa2) T_(float, sd2) T_(const unsigned char, fflag)
+        REC_LOADS(LIST_);
         [[maybe_unused]] const float* pb = P + L.p_block0 + (int64_t)launder_s(b) * L.p_block_stride;
         [[maybe_unused]] float* base = segbase + (int64_t)launder_s(b) * SL.bstride;
+        REC_PINS(LIST_, , "s"(pb), "s"(base));
+        REC_DEFS(LIST_);
+#undef LIST_
         // LDS-DMA rides on the MFMA stages, issued by their tile-less waves: W2 | att | bias of this block while proj1 runs,
         // W1 | att | bias of the next block while proj2 runs
         if (NC != 32 || wave_u >= dw0) {           // (NC == 32: the LDS-DMA waves; their address chains stay in here)
@@ -302,7 +380,12 @@ __global__ __launch_bounds__(THREADS) void gatres_window_kernel(const FusedArgs 
         lds_barrier();                                      // own rows of h1 / a_src are in LDS; the saved copies drain meanwhile
       }
       {
-        FRESH_ARGS();
+        FRESH_ARGS(); FRESH_FWD();
+#define LIST_(T_, N_, I_) I_(lo) I_(hi) T_(float, hA) T_(float, sa2) T_(const u16, hlist) T_(const u16, elist) I_(hcnt) I_(ecnt)
+        REC_LOADS(LIST_);
+        REC_PINS(LIST_);
+        REC_DEFS(LIST_);
+#undef LIST_
         ++xc.ep;                                    // exchange F1: the gathers below read h1 / a_src of neighbour rows
         if (!xreg) xch_export2<2 * NC, 2, THREADS>(xc, xbuf, elist, ecnt, hA, (unsigned)XL.f1h, elist, ecnt, sa2, (unsigned)XL.f1a);
         xch_import2<2 * NC, 2, THREADS>(xc, xbuf, hlist, hcnt, (unsigned)XL.f1h, hA, hlist, hcnt, (unsigned)XL.f1a, sa2);
@@ -311,9 +394,14 @@ __global__ __launch_bounds__(THREADS) void gatres_window_kernel(const FusedArgs 
         STAMP();
       }
       {
-        FRESH_ARGS();
+        FRESH_ARGS(); FRESH_FWD();
+#define LIST_(T_, N_, I_) I_(lo) I_(hi) T_(const u16, nbin) T_(const u16, rp) T_(const u16, colo) T_(float, hA) T_(float, sa2) T_(float, sd2) T_(float, hBw) T_(float, wlA) T_(float, xB) T_(const unsigned char, fflag) N_(unsigned long long, mo1) I_(ow) I_(oeg) I_(wr) I_(elo)
+        REC_LOADS(LIST_);
         [[maybe_unused]] const float* pb = P + L.p_block0 + (int64_t)launder_s(b) * L.p_block_stride;
-        float* base = segbase + (int64_t)launder_s(b) * SL.bstride;
+        [[maybe_unused]] float* base = segbase + (int64_t)launder_s(b) * SL.bstride;
+        REC_PINS(LIST_, , "s"(pb), "s"(base));
+        REC_DEFS(LIST_);
+#undef LIST_
         // K2 conv1: alpha -> HBM, the gather's o1 -> HBM + the x buffer of proj2
         if (__builtin_expect(2 * oeg <= wr * NC, 1)) {
           if constexpr (NC == 32) {
@@ -336,9 +424,14 @@ __global__ __launch_bounds__(THREADS) void gatres_window_kernel(const FusedArgs 
         STAMP();
       }
       {
-        FRESH_ARGS();
+        FRESH_ARGS(); FRESH_FWD();
+#define LIST_(T_, N_, I_) I_(lo) I_(hi) T_(float, xB) T_(float, wlA) T_(float, wlB) T_(float, hB) T_(float, sa1) T_(float, sd1) T_(const unsigned char, fflag)
+        REC_LOADS(LIST_);
         [[maybe_unused]] const float* pb = P + L.p_block0 + (int64_t)launder_s(b) * L.p_block_stride;
         [[maybe_unused]] float* base = segbase + (int64_t)launder_s(b) * SL.bstride;
+        REC_PINS(LIST_, , "s"(pb), "s"(base));
+        REC_DEFS(LIST_);
+#undef LIST_
         if (b + 1 < nb && (NC != 32 || wave_u >= dw0)) {
           const float* pn = pb + L.p_block_stride;
           w_prefetch<NC, 2 * NC, EPI_ATT, THREADS>(wlA, pn + L.c1_W, pn + L.c1_as, pn + L.c1_ad, dw0);
@@ -357,7 +450,12 @@ __global__ __launch_bounds__(THREADS) void gatres_window_kernel(const FusedArgs 
         lds_barrier();
       }
       {
-        FRESH_ARGS();
+        FRESH_ARGS(); FRESH_FWD();
+#define LIST_(T_, N_, I_) I_(lo) I_(hi) T_(float, hB) T_(float, sa1) T_(const u16, hlist) T_(const u16, elist) I_(hcnt) I_(ecnt)
+        REC_LOADS(LIST_);
+        REC_PINS(LIST_);
+        REC_DEFS(LIST_);
+#undef LIST_
         ++xc.ep;                                    // exchange F2
         if (!xreg) xch_export2<NC, 1, THREADS>(xc, xbuf, elist, ecnt, hB, (unsigned)XL.f2h, elist, ecnt, sa1, (unsigned)XL.f2a);
         xch_import2<NC, 1, THREADS>(xc, xbuf, hlist, hcnt, (unsigned)XL.f2h, hB, hlist, hcnt, (unsigned)XL.f2a, sa1);
@@ -366,13 +464,16 @@ __global__ __launch_bounds__(THREADS) void gatres_window_kernel(const FusedArgs 
         STAMP();
       }
       // K2 conv2: y2 in the lower half of the h1 window (its upper half: the alpha table of rows beyond the slot path)
-      float* y2T = hAw - wlo * NC;
       {
-        FRESH_ARGS();
+        FRESH_ARGS(); FRESH_FWD();
+#define LIST_(T_, N_, I_) I_(lo) I_(hi) T_(const u16, nbin) T_(const u16, rp) T_(const u16, colo) T_(float, hB) T_(float, sa1) T_(float, sd1) T_(float, wlB) T_(float, y2T) T_(float, al2L) T_(const unsigned char, fflag) I_(oeg) I_(wr) I_(elo)
+        REC_LOADS(LIST_);
         [[maybe_unused]] const float* pb = P + L.p_block0 + (int64_t)launder_s(b) * L.p_block_stride;
-        float* base = segbase + (int64_t)launder_s(b) * SL.bstride;
+        [[maybe_unused]] float* base = segbase + (int64_t)launder_s(b) * SL.bstride;
+        REC_PINS(LIST_, , "s"(pb), "s"(base));
+        REC_DEFS(LIST_);
+#undef LIST_
         if (__builtin_expect(oeg <= wr * NC, 1)) {
-          float* al2L = hAw + (size_t)wr * NC;
           if constexpr (NC == 32) {
             win_fwd_agg<false, 1, NC, THREADS>(rw, nbin, rp, colo, hB, sa1, sd1, base + SL.al2, elo, al2L, wlB + B2OFF, y2T,
                                                0, nullptr, nullptr, xout(xreg, fflag, XL.f3, 0));
@@ -390,7 +491,12 @@ __global__ __launch_bounds__(THREADS) void gatres_window_kernel(const FusedArgs 
         lds_barrier();
       }
       {
-        FRESH_ARGS();
+        FRESH_ARGS(); FRESH_FWD();
+#define LIST_(T_, N_, I_) I_(lo) I_(hi) T_(float, y2T) T_(const u16, hlist) T_(const u16, elist) I_(hcnt) I_(ecnt) I_(oeg) I_(wr)
+        REC_LOADS(LIST_);
+        REC_PINS(LIST_);
+        REC_DEFS(LIST_);
+#undef LIST_
         ++xc.ep;                                    // exchange F3: K3 averages y2 over neighbour rows
         if (!(xreg && oeg <= wr * NC)) xch_export2<NC, 0, THREADS>(xc, xbuf, elist, ecnt, y2T, (unsigned)XL.f3, elist, 0, y2T, 0u);
         xch_import2<NC, 0, THREADS>(xc, xbuf, hlist, hcnt, (unsigned)XL.f3, y2T, hlist, 0, 0u, y2T);
@@ -399,7 +505,12 @@ __global__ __launch_bounds__(THREADS) void gatres_window_kernel(const FusedArgs 
         STAMP();
       }
       {
-        FRESH_ARGS();
+        FRESH_ARGS(); FRESH_FWD();
+#define LIST_(T_, N_, I_) I_(lo) I_(hi) T_(const u16, mbin) T_(const u16, mrp) T_(const u16, mcolo) T_(float, y2T) T_(float, xA) N_(unsigned, mxin) I_(ow)
+        REC_LOADS(LIST_);
+        REC_PINS(LIST_);
+        REC_DEFS(LIST_);
+#undef LIST_
         // K3: residual from the x buffer, result back into it (and to HBM: saved xin of the next block)
         float* xnext = segbase + (int64_t)(launder_s(b) + 1) * SL.bstride + SL.xin;
         win_mean_fwd<NC, THREADS>(rw, mbin, mrp, mcolo, y2T, xA, xnext, xA,
@@ -408,6 +519,11 @@ __global__ __launch_bounds__(THREADS) void gatres_window_kernel(const FusedArgs 
         STAMP();
       }
     }
+    FRESH_FWD();
+#define LIST_(T_, N_, I_) I_(lo) I_(hi) T_(float, xA)
+    REC_LOADS(LIST_);
+    REC_DEFS(LIST_);
+#undef LIST_
     {  // lin1
       constexpr int G = NC / 4;
       const float4 wv = ld4(P + L.p_lin1_w + (tid % G) * 4);
@@ -501,9 +617,18 @@ __global__ __launch_bounds__(THREADS) void gatres_window_kernel(const FusedArgs 
   }
 
   if (a.phases & GATRES_PHASE_BACKWARD) {
+    float* const red = ldsf;
+    constexpr bool xedge = NC == 32;                 // win_bwd_dst stores the exported g_e granules itself
+    const bool xrows = xedge && a.keep_lds;          // ... and so do the dX stages (win_proj) with their rows
+    constexpr bool pub = true;           // (the window kernel only runs split segments)
+    constexpr int64_t w = 2LL * NC * NC;
+    float* gp_cur = sc + L.sc_gpa;
+    float* gp_nxt = sc + L.sc_gpb;
+    float* const slab = pub ? a.part_slabs + ((int64_t)seg * M + part) * L.slab_stride
+                            : a.slabs + (int64_t)seg * L.slab_stride;
+    {  // ---- prologue: LDS carve-up, the part's tables, lin1 backward; the geometry goes into the record
     // LDS: red | RA wr x 2NC | ge weg x 2 | gad own x 2 | hT wr x 2NC | asT wr x 2 | adT own x 2 | alT weg x 2 |
     //      xG own x 2NC | W slot A | W slot B | topology | halo lists
-    float* red = ldsf;
     float* RAw = red + 3 * THREADS;
     float* gew = RAw + (size_t)wr * 2 * NC;
     float* gado = gew + 2 * (size_t)even(weg);
@@ -537,8 +662,6 @@ __global__ __launch_bounds__(THREADS) void gatres_window_kernel(const FusedArgs 
     u16* erow = hedge + hcap;            // export lists: own rows with an in-edge from a partner's row, and those in-edges
     u16* eedge = erow + hcap;
     __syncthreads();           // forward's LDS contents are dead from here
-    constexpr bool xedge = NC == 32;                 // win_bwd_dst stores the exported g_e granules itself
-    const bool xrows = xedge && a.keep_lds;          // ... and so do the dX stages (win_proj) with their rows
     const unsigned char* bflag = bflag_o - lo;
     for (int k = tid; k < ((ow + 15) & ~15) / 4; k += THREADS) reinterpret_cast<unsigned*>(bflag_o)[k] = 0u;
     int hrcnt = 0, hecnt = 0, ercnt = 0, eecnt = 0;      // import rows / import edges / export rows / export edges
@@ -578,12 +701,6 @@ __global__ __launch_bounds__(THREADS) void gatres_window_kernel(const FusedArgs 
     float* xG2 = xGo - lo * NC;   float* xG1 = xGo - lo * 2 * NC;
     float* gkeep = a.keep_lds ? gko - lo * NC : nullptr;
 
-    float* gp_cur = sc + L.sc_gpa;
-    float* gp_nxt = sc + L.sc_gpb;
-    constexpr bool pub = true;           // (the window kernel only runs split segments)
-    float* slab = pub ? a.part_slabs + ((int64_t)seg * M + part) * L.slab_stride
-                      : a.slabs + (int64_t)seg * L.slab_stride;
-    const int64_t w = 2LL * NC * NC;
     const float* xfinal = segbase + (int64_t)L.nb * SL.bstride + SL.xin;
     // LDS-DMA of the saved tables (independent of the backward chain) rides on the dX stages, issued by their tile-less
     // waves, which wait for it to land before the stage's closing barrier.  Every CU streams at the same moments, so a
@@ -665,23 +782,81 @@ __global__ __launch_bounds__(THREADS) void gatres_window_kernel(const FusedArgs 
         hrcnt = hecnt = min(hrcnt, hcap); ercnt = min(ercnt, hcap); eecnt = min(eecnt, hcap);
       }
     }
-    for (int k = tid; k < ercnt; k += THREADS) bflag_o[(int)erow[k] - lo] = 1;      // (the top-of-loop barrier publishes them)
-    auto xout = [&](bool on, unsigned t_rows, unsigned t_small) {      // values of the hand-off that follows
+    for (int k = tid; k < ercnt; k += THREADS) bflag_o[(int)erow[k] - lo] = 1;
+    if (tid == 0) {
+      BwdRec r;
+      r.lo = rw.lo; r.hi = rw.hi; r.ow = ow; r.wr = wr; r.wlo = wlo; r.elo = elo; r.ewlo = ewlo; r.weg = weg; r.n0 = n0;
+      r.hrcnt = hrcnt; r.hecnt = hecnt; r.ercnt = ercnt; r.eecnt = eecnt;
+      r.RA = lds_off(RA); r.gpT = lds_off(gpT); r.gy2T = lds_off(gy2T); r.ge2 = lds_off(ge2); r.ge1 = lds_off(ge1);
+      r.gad2 = lds_off(gad2); r.gad1 = lds_off(gad1); r.hTw = lds_off(hTw); r.hT2 = lds_off(hT2); r.hT1 = lds_off(hT1);
+      r.asTw = lds_off(asTw); r.asT2 = lds_off(asT2); r.asT1 = lds_off(asT1); r.adTo = lds_off(adTo); r.adT2 = lds_off(adT2);
+      r.adT1 = lds_off(adT1); r.alTw = lds_off(alTw); r.alT2 = lds_off(alT2); r.alT1 = lds_off(alT1); r.xG2 = lds_off(xG2);
+      r.xG1 = lds_off(xG1); r.gkeep = gkeep ? lds_off(gkeep) : NO_TABLE; r.wlA = lds_off(wlA); r.wlB = lds_off(wlB);
+      r.rp = lds_off(rp); r.colo = lds_off(colo); r.trp = lds_off(trp); r.teido = lds_off(teido); r.tdsto = lds_off(tdsto);
+      r.mrp = lds_off(mrp); r.mtrp = lds_off(mtrp); r.mtdsto = lds_off(mtdsto); r.nbin = lds_off(nbin); r.tout = lds_off(tout);
+      r.mout = lds_off(mout); r.hrow = lds_off(hrow); r.hedge = lds_off(hedge); r.erow = lds_off(erow); r.eedge = lds_off(eedge);
+      r.bflag = lds_off(bflag); r.mo1 = mo1 ? lds_off(mo1) : NO_TABLE; r.mxin = mxin ? lds_off(mxin) : NO_TABLE;
+      const int* src = reinterpret_cast<const int*>(&r);
+#pragma unroll
+      for (int k = 0; k < (int)(sizeof(BwdRec) / 4); ++k)
+        __hip_atomic_store(myrec + GATRES_UREC_WORDS / 2 + k, src[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    }  // ---- (end of the prologue's scope: the block loop below sees the record only)
+    __syncthreads();           // export flags and the record are published
+    rec_published();
+#undef RECP
+#define RECP rb_
+    auto xout = [&](bool on, const unsigned char* bflag, unsigned t_rows, unsigned t_small) {      // values of the hand-off that follows
       XOut o;
       o.xb = xbuf; o.ep = xc.ep + 1u; o.local = xc.local; o.on = on; o.flag = bflag; o.t_rows = t_rows; o.t_small = t_small;
       return o;
     };
+    // LDS-DMA of the saved tables inside the loop (the prologue above issued the first block's with its own pointers)
+    auto dma_conv2_early = [&](int blk, int w0) {
+      if (wave_u < w0) return;                   // (the tile waves of the stage: none of the address chains below)
+      FRESH_ARGS(); FRESH_BWD();
+#define LIST_(T_, N_, I_) I_(lo) I_(hi) T_(float, hTw) T_(float, asTw) T_(float, adTo) T_(float, wlA) I_(wlo) I_(wr) I_(ow)
+      REC_LOADS(LIST_);
+      REC_PINS(LIST_);
+      REC_DEFS(LIST_);
+#undef LIST_
+      blk = launder_s(blk);
+      const float* bs = segbase + (int64_t)blk * SL.bstride;
+      dma_copy16<THREADS>(hTw, bs + SL.h2 + (size_t)wlo * NC, wr * NC, w0);
+      dma_copy4<THREADS>(asTw, bs + SL.as2 + wlo, wr, w0);
+      dma_copy4<THREADS>(adTo, bs + SL.ad2 + lo, ow, w0);
+      w_prefetch<NC, 2 * NC, EPI_RESID_MASK, THREADS>(wlA, a.wt + (int64_t)blk * 2 * w + w, nullptr, nullptr, w0);
+      vec_prefetch<THREADS>(wlA + A2OFF, P + L.p_block0 + (int64_t)blk * L.p_block_stride + L.c2_as, 2 * NC);
+    };
+    auto dma_conv2_late = [&](int blk, int w0) {
+      if (wave_u < w0) return;
+      FRESH_ARGS(); FRESH_BWD();
+#define LIST_(T_, N_, I_) I_(lo) I_(hi) T_(float, alTw) I_(ewlo) I_(weg)
+      REC_LOADS(LIST_);
+      REC_PINS(LIST_);
+      REC_DEFS(LIST_);
+#undef LIST_
+      blk = launder_s(blk);
+      const float* bs = segbase + (int64_t)blk * SL.bstride;
+      dma_copy4<THREADS>(alTw, bs + SL.al2 + ewlo, weg, w0);
+    };
     STAMP();
     const int nb = L.nb;
     for (int b = nb - 1; b >= 0; --b) {
-      // (per stage: FRESH_ARGS() re-reads the offsets it needs; keep / sb / base are formed where they are used)
+      // (per stage: FRESH_ARGS() / FRESH_BWD() re-read the offsets and tables the stage needs; keep / sb / base are formed
+      // where they are used)
       [[maybe_unused]] const bool xs_on = STAMPS_PTR && a.stamp_cap >= 4096 && seg == 0 && b == nb / 2;
       [[maybe_unused]] int xs_i = 0;
       XSTAMP();
       lds_barrier();                                     // own rows of g_pre are in LDS (lin1 backward / the previous dX1)
       XSTAMP();
       {
-        FRESH_ARGS();
+        FRESH_ARGS(); FRESH_BWD();
+#define LIST_(T_, N_, I_) I_(lo) I_(hi) T_(float, gpT) T_(const u16, erow) T_(const u16, hrow) I_(ercnt) I_(hrcnt)
+        REC_LOADS(LIST_);
+        REC_PINS(LIST_);
+        REC_DEFS(LIST_);
+#undef LIST_
         ++xc.ep;                                   // exchange B1: K3 backward gathers g_pre of neighbour rows
         if (!xrows || b == nb - 1)                 // (else the previous block's dX1 stored them)
           xch_export2<NC, 0, THREADS>(xc, xbuf, erow, ercnt, gpT, (unsigned)XL.b1, erow, 0, gpT, 0u);
@@ -697,14 +872,24 @@ __global__ __launch_bounds__(THREADS) void gatres_window_kernel(const FusedArgs 
       // K3 backward, conv2's edge dots and softmax backward: one stage (win_bwd_dst)
       STAMP();
       {
-        FRESH_ARGS();
+        FRESH_ARGS(); FRESH_BWD();
+#define LIST_(T_, N_, I_) I_(lo) I_(hi) T_(const u16, nbin) T_(const u16, rp) T_(const u16, colo) T_(float, gy2T) T_(float, hT2) T_(float, alT2) T_(float, asT2) T_(float, adT2) T_(float, ge2) T_(float, gad2) T_(const u16, mout) T_(const u16, mrp) T_(const u16, mtrp) T_(const u16, mtdsto) T_(float, gpT) T_(const unsigned char, bflag) I_(elo)
+        REC_LOADS(LIST_);
+        REC_PINS(LIST_);
+        REC_DEFS(LIST_);
+#undef LIST_
         win_bwd_dst<true, 1, NC, THREADS>(rw, nbin, rp, colo, gy2T, hT2, alT2 + elo, asT2, adT2, ge2 + elo, gad2, mout, mrp,
-                                               mtrp, mtdsto, gpT, xout(xedge, (unsigned)XL.b2y, (unsigned)XL.b2e), elo);
+                                               mtrp, mtdsto, gpT, xout(xedge, bflag, (unsigned)XL.b2y, (unsigned)XL.b2e), elo);
         lds_barrier();
         XSTAMP();
       }
       {
-        FRESH_ARGS();
+        FRESH_ARGS(); FRESH_BWD();
+#define LIST_(T_, N_, I_) I_(lo) I_(hi) T_(float, gy2T) T_(float, ge2) T_(const u16, erow) T_(const u16, eedge) T_(const u16, hrow) T_(const u16, hedge) I_(ercnt) I_(eecnt) I_(hrcnt) I_(hecnt)
+        REC_LOADS(LIST_);
+        REC_PINS(LIST_);
+        REC_DEFS(LIST_);
+#undef LIST_
         seg_bias_part<NC, THREADS>(rw, gy2T, 0, red);  // (own rows of g_y2: the sweep below only writes halo rows)
         ++xc.ep;                                   // exchange B2: the source-major stage reads g_y2 / g_e of neighbour rows
         if (!xedge) xch_export2<NC, 1, THREADS>(xc, xbuf, erow, ercnt, gy2T, (unsigned)XL.b2y, eedge, eecnt, ge2, (unsigned)XL.b2e);
@@ -720,7 +905,12 @@ __global__ __launch_bounds__(THREADS) void gatres_window_kernel(const FusedArgs 
       // this block's conv1 tables and W1^T stream in while the matrix cores run dX2 (below)
       auto dma_conv1_early = [&]() {
         if (wave_u < dw0) return;
-        FRESH_ARGS();
+        FRESH_ARGS(); FRESH_BWD();
+#define LIST_(T_, N_, I_) I_(lo) I_(hi) T_(float, wlB) T_(float, hTw) T_(float, asTw) T_(float, adTo) T_(float, alTw) I_(wlo) I_(wr) I_(ow) I_(ewlo) I_(weg)
+        REC_LOADS(LIST_);
+        REC_PINS(LIST_);
+        REC_DEFS(LIST_);
+#undef LIST_
         const int bl = launder_s(b);
         const float* bsl = segbase + (int64_t)bl * SL.bstride;
         w_prefetch<2 * NC, NC, EPI_RESID_MASK, THREADS>(wlB, a.wt + (int64_t)bl * 2 * w, nullptr, nullptr, dw0);
@@ -731,9 +921,14 @@ __global__ __launch_bounds__(THREADS) void gatres_window_kernel(const FusedArgs 
         dma_copy4<THREADS>(alTw, bsl + SL.al1 + ewlo * 2, weg * 2, dw0);      // conv1's alpha (its table held conv2's until here)
       };
       {
-        FRESH_ARGS();
-        float* sb = slab + L.p_block0 + (int64_t)launder_s(b) * L.p_block_stride;
-        float* keep = sc + L.sc_keep + (int64_t)launder_s(b) * L.keep_stride;
+        FRESH_ARGS(); FRESH_BWD();
+#define LIST_(T_, N_, I_) I_(lo) I_(hi) T_(const u16, tout) T_(const u16, trp) T_(const u16, teido) T_(const u16, tdsto) T_(float, gy2T) T_(float, alT2) T_(float, ge2) T_(float, gad2) T_(float, wlA) T_(float, xG2) I_(n0)
+        REC_LOADS(LIST_);
+        [[maybe_unused]] float* sb = slab + L.p_block0 + (int64_t)launder_s(b) * L.p_block_stride;
+        [[maybe_unused]] float* keep = sc + L.sc_keep + (int64_t)launder_s(b) * L.keep_stride;
+        REC_PINS(LIST_, , "s"(sb), "s"(keep));
+        REC_DEFS(LIST_);
+#undef LIST_
         seg_bias_finish<NC, THREADS>(red, sb + L.c2_b);
         win_agg_bwd_src<1, NC, THREADS>(rw, tout, trp, teido, tdsto, 0, gy2T, alT2, ge2, gad2, wlA + A2OFF, wlA + A2OFF + NC,
                                              keep + L.k_gh2, n0, keep + L.k_gas2, keep + L.k_gad2, xG2);
@@ -745,13 +940,23 @@ __global__ __launch_bounds__(THREADS) void gatres_window_kernel(const FusedArgs 
       if (NC == 32 && a.keep_lds) {              // (the ReLU sign masks of the forward phase are in LDS: no global operand)
         if constexpr (NC == 32)
           if (wave_u < PW) {
-            FRESH_ARGS();
+            FRESH_ARGS(); FRESH_BWD();
+#define LIST_(T_, N_, I_) I_(lo) I_(hi) I_(ow) T_(float, xG2) T_(float, wlA) T_(float, RA) T_(const unsigned char, bflag) T_(const unsigned long long, mo1)
+            REC_LOADS(LIST_);
+            REC_PINS(LIST_);
+            REC_DEFS(LIST_);
+#undef LIST_
             win_proj<NC, 2 * NC, 1, EPI_RESID_MASK, 1, PW, THREADS>(rw, xG2, wlA, RA, 0, nullptr, nullptr, nullptr, nullptr,
                                                                 nullptr, nullptr, nullptr, mo1 + launder_s(b) * ow, nullptr,
-                                                                xout(xrows, (unsigned)XL.b3o, 0u));
+                                                                xout(xrows, bflag, (unsigned)XL.b3o, 0u));
           }
       } else {
-        FRESH_ARGS();
+        FRESH_ARGS(); FRESH_BWD();
+#define LIST_(T_, N_, I_) I_(lo) I_(hi) I_(ow) T_(float, xG2) T_(float, wlA) T_(float, RA) N_(const unsigned long long, mo1)
+        REC_LOADS(LIST_);
+        REC_PINS(LIST_);
+        REC_DEFS(LIST_);
+#undef LIST_
         const float* base = segbase + (int64_t)launder_s(b) * SL.bstride;
         const float* wt2 = a.wt + (int64_t)launder_s(b) * 2 * w + w;
         seg_proj<NC, 2 * NC, 1, EPI_RESID_MASK, THREADS, true, true>(
@@ -764,16 +969,26 @@ __global__ __launch_bounds__(THREADS) void gatres_window_kernel(const FusedArgs 
       XSTAMP();
       STAMP();
       {
-        FRESH_ARGS();
+        FRESH_ARGS(); FRESH_BWD();
+#define LIST_(T_, N_, I_) I_(lo) I_(hi) T_(const u16, nbin) T_(const u16, rp) T_(const u16, colo) T_(float, RA) T_(float, hT1) T_(float, alT1) T_(float, asT1) T_(float, adT1) T_(float, ge1) T_(float, gad1) T_(const unsigned char, bflag) I_(elo)
+        REC_LOADS(LIST_);
+        REC_PINS(LIST_);
+        REC_DEFS(LIST_);
+#undef LIST_
         seg_bias_part<2 * NC, THREADS>(rw, RA, 0, red);
         win_bwd_dst<false, 2, NC, THREADS>(rw, nbin, rp, colo, RA, hT1, alT1 + elo * 2, asT1, adT1, ge1 + elo * 2, gad1,
                                                 nullptr, nullptr, nullptr, nullptr, nullptr,
-                                                xout(xedge, 0u, (unsigned)XL.b3e), elo);
+                                                xout(xedge, bflag, 0u, (unsigned)XL.b3e), elo);
         lds_barrier();
         XSTAMP();
       }
       {
-        FRESH_ARGS();
+        FRESH_ARGS(); FRESH_BWD();
+#define LIST_(T_, N_, I_) I_(lo) I_(hi) T_(float, RA) T_(float, ge1) T_(const u16, erow) T_(const u16, eedge) T_(const u16, hrow) T_(const u16, hedge) I_(ercnt) I_(eecnt) I_(hrcnt) I_(hecnt)
+        REC_LOADS(LIST_);
+        REC_PINS(LIST_);
+        REC_DEFS(LIST_);
+#undef LIST_
         ++xc.ep;                                   // exchange B3
         if (!xrows || !xedge)
           xch_export2<2 * NC, 2, THREADS>(xc, xbuf, erow, xrows ? 0 : ercnt, RA, (unsigned)XL.b3o, eedge, xedge ? 0 : eecnt, ge1,
@@ -789,9 +1004,14 @@ __global__ __launch_bounds__(THREADS) void gatres_window_kernel(const FusedArgs 
       publish_items<THREADS>(a, seg, part, 2 * (nb - 1 - b) + 1, grp.local, false);      // conv2 tables complete
       STAMP();
       {
-        FRESH_ARGS();
-        float* sb = slab + L.p_block0 + (int64_t)launder_s(b) * L.p_block_stride;
-        float* keep = sc + L.sc_keep + (int64_t)launder_s(b) * L.keep_stride;
+        FRESH_ARGS(); FRESH_BWD();
+#define LIST_(T_, N_, I_) I_(lo) I_(hi) T_(const u16, tout) T_(const u16, trp) T_(const u16, teido) T_(const u16, tdsto) T_(float, RA) T_(float, alT1) T_(float, ge1) T_(float, gad1) T_(float, wlB) T_(float, xG1) I_(n0)
+        REC_LOADS(LIST_);
+        [[maybe_unused]] float* sb = slab + L.p_block0 + (int64_t)launder_s(b) * L.p_block_stride;
+        [[maybe_unused]] float* keep = sc + L.sc_keep + (int64_t)launder_s(b) * L.keep_stride;
+        REC_PINS(LIST_, , "s"(sb), "s"(keep));
+        REC_DEFS(LIST_);
+#undef LIST_
         seg_bias_finish<2 * NC, THREADS>(red, sb + L.c1_b);
         win_agg_bwd_src<2, NC, THREADS>(rw, tout, trp, teido, tdsto, 0, RA, alT1, ge1, gad1, wlB + A1OFF, wlB + A1OFF + 2 * NC,
                                              keep + L.k_gh1, n0, keep + L.k_gas1, keep + L.k_gad1, xG1);
@@ -803,14 +1023,24 @@ __global__ __launch_bounds__(THREADS) void gatres_window_kernel(const FusedArgs 
       if (NC == 32 && a.keep_lds) {
         if constexpr (NC == 32)
           if (wave_u < PW) {
-            FRESH_ARGS();
+            FRESH_ARGS(); FRESH_BWD();
+#define LIST_(T_, N_, I_) I_(lo) I_(hi) I_(ow) I_(n0) T_(float, xG1) T_(float, wlB) T_(float, gpT) T_(const unsigned char, bflag) T_(float, gkeep) T_(const unsigned, mxin)
+            REC_LOADS(LIST_);
+            REC_PINS(LIST_);
+            REC_DEFS(LIST_);
+#undef LIST_
             const int bl = launder_s(b);
             win_proj<2 * NC, NC, 1, EPI_RESID_MASK, 1, PW, THREADS>(rw, xG1, wlB, gp_nxt, n0, gpT, nullptr, nullptr, nullptr,
                                                                 nullptr, gkeep, gkeep, nullptr, bl > 0 ? mxin + bl * ow : nullptr,
-                                                                xout(xrows && bl > 0, (unsigned)XL.b1, 0u));
+                                                                xout(xrows && bl > 0, bflag, (unsigned)XL.b1, 0u));
           }
       } else {
-        FRESH_ARGS();
+        FRESH_ARGS(); FRESH_BWD();
+#define LIST_(T_, N_, I_) I_(lo) I_(hi) I_(ow) I_(n0) T_(float, xG1) T_(float, wlB) T_(float, gpT) N_(float, gkeep) N_(const unsigned, mxin)
+        REC_LOADS(LIST_);
+        REC_PINS(LIST_);
+        REC_DEFS(LIST_);
+#undef LIST_
         const float* base = segbase + (int64_t)launder_s(b) * SL.bstride;
         const float* wt1 = a.wt + (int64_t)launder_s(b) * 2 * w;
         seg_proj<2 * NC, NC, 1, EPI_RESID_MASK, THREADS, true, true>(
@@ -824,6 +1054,12 @@ __global__ __launch_bounds__(THREADS) void gatres_window_kernel(const FusedArgs 
       STAMP();
       float* t = gp_cur; gp_cur = gp_nxt; gp_nxt = t;
     }
+    FRESH_ARGS(); FRESH_BWD();
+#define LIST_(T_, N_, I_) I_(lo) I_(hi) T_(float, gpT) I_(n0)
+    REC_LOADS(LIST_);
+    REC_PINS(LIST_);
+    REC_DEFS(LIST_);
+#undef LIST_
     // The parts only meet here for the consumers' sake (the last items are published behind this barrier); without consumer
     // workgroups nothing of a partner is needed any more: a workgroup barrier that also drains this part's own stores (g_x below
     // reads gp_cur back) replaces the flag barrier.  a.C is the same for every part: the barrier count per launch stays equal.
