@@ -95,6 +95,19 @@ __device__ __forceinline__ u16* align16(u16* p) {
   return reinterpret_cast<u16*>((reinterpret_cast<uintptr_t>(p) + 15) & ~(uintptr_t)15);
 }
 
+// g_pre of the own rows (LDS [row][NC], shifted view) -> g_pre / max(in-degree in SimpleConv's graph, 1): the operand K3
+// backward gathers (win_bwd_dst<MEAN, PRE>).  The dX1 stage of the kept-in-LDS form stores it that way itself (win_proj:
+// cnt_rp); this pass serves lin1 backward's rows and the launches that run dX1 through seg_proj.
+template <int NC, int THREADS>
+__device__ __forceinline__ void scale_g_pre(float* gpT, const u16* mrp, int lo, int ow) {
+  for (int idx = threadIdx.x; idx < ow * NC; idx += THREADS) {
+    const int r = lo + idx / NC;
+    const float cnt = (float)max((int)mrp[r + 1] - (int)mrp[r], 1);
+    float* p = gpT + (size_t)r * NC + idx % NC;
+    *p = *p / cnt;
+  }
+}
+
 template <int NC, int THREADS>
 __global__ __launch_bounds__(THREADS) void gatres_window_kernel(const FusedArgs a) {
   __shared__ __attribute__((aligned(16))) unsigned char lds_raw[LDS_BYTES];
@@ -783,6 +796,7 @@ __global__ __launch_bounds__(THREADS) void gatres_window_kernel(const FusedArgs 
       }
     }
     for (int k = tid; k < ercnt; k += THREADS) bflag_o[(int)erow[k] - lo] = 1;
+    if constexpr (NC == 32) scale_g_pre<NC, THREADS>(gpT, mrp, lo, ow);      // (lin1 backward's rows; the tables have landed)
     if (tid == 0) {
       BwdRec r;
       r.lo = rw.lo; r.hi = rw.hi; r.ow = ow; r.wr = wr; r.wlo = wlo; r.elo = elo; r.ewlo = ewlo; r.weg = weg; r.n0 = n0;
@@ -878,7 +892,7 @@ __global__ __launch_bounds__(THREADS) void gatres_window_kernel(const FusedArgs 
         REC_PINS(LIST_);
         REC_DEFS(LIST_);
 #undef LIST_
-        win_bwd_dst<true, 1, NC, THREADS>(rw, nbin, rp, colo, gy2T, hT2, alT2 + elo, asT2, adT2, ge2 + elo, gad2, mout, mrp,
+        win_bwd_dst<true, 1, NC, THREADS, NC == 32>(rw, nbin, rp, colo, gy2T, hT2, alT2 + elo, asT2, adT2, ge2 + elo, gad2, mout, mrp,
                                                mtrp, mtdsto, gpT, xout(xedge, bflag, (unsigned)XL.b2y, (unsigned)XL.b2e), elo);
         lds_barrier();
         XSTAMP();
@@ -1024,7 +1038,7 @@ __global__ __launch_bounds__(THREADS) void gatres_window_kernel(const FusedArgs 
         if constexpr (NC == 32)
           if (wave_u < PW) {
             FRESH_ARGS(); FRESH_BWD();
-#define LIST_(T_, N_, I_) I_(lo) I_(hi) I_(ow) I_(n0) T_(float, xG1) T_(float, wlB) T_(float, gpT) T_(const unsigned char, bflag) T_(float, gkeep) T_(const unsigned, mxin)
+#define LIST_(T_, N_, I_) I_(lo) I_(hi) I_(ow) I_(n0) T_(float, xG1) T_(float, wlB) T_(float, gpT) T_(const unsigned char, bflag) T_(float, gkeep) T_(const unsigned, mxin) T_(const u16, mrp)
             REC_LOADS(LIST_);
             REC_PINS(LIST_);
             REC_DEFS(LIST_);
@@ -1032,11 +1046,11 @@ __global__ __launch_bounds__(THREADS) void gatres_window_kernel(const FusedArgs 
             const int bl = launder_s(b);
             win_proj<2 * NC, NC, 1, EPI_RESID_MASK, 1, PW, THREADS>(rw, xG1, wlB, gp_nxt, n0, gpT, nullptr, nullptr, nullptr,
                                                                 nullptr, gkeep, gkeep, nullptr, bl > 0 ? mxin + bl * ow : nullptr,
-                                                                xout(xrows && bl > 0, bflag, (unsigned)XL.b1, 0u));
+                                                                xout(xrows && bl > 0, bflag, (unsigned)XL.b1, 0u), mrp);
           }
       } else {
         FRESH_ARGS(); FRESH_BWD();
-#define LIST_(T_, N_, I_) I_(lo) I_(hi) I_(ow) I_(n0) T_(float, xG1) T_(float, wlB) T_(float, gpT) N_(float, gkeep) N_(const unsigned, mxin)
+#define LIST_(T_, N_, I_) I_(lo) I_(hi) I_(ow) I_(n0) T_(float, xG1) T_(float, wlB) T_(float, gpT) N_(float, gkeep) N_(const unsigned, mxin) T_(const u16, mrp)
         REC_LOADS(LIST_);
         REC_PINS(LIST_);
         REC_DEFS(LIST_);
@@ -1048,6 +1062,10 @@ __global__ __launch_bounds__(THREADS) void gatres_window_kernel(const FusedArgs 
             (GATRES_DIAG && (a.no_halo & 4)) ? nullptr : gp_cur, n0,
             (b > 0 && !(GATRES_DIAG && (a.no_halo & 4))) ? base + SL.xin : nullptr, 0, wlB, gkeep, gkeep, nullptr,
             (mxin && b > 0) ? mxin + b * ow : nullptr);
+        if constexpr (NC == 32) {                  // (rare path) g_pre in LDS as K3 backward gathers it: see scale_g_pre
+          __syncthreads();
+          scale_g_pre<NC, THREADS>(gpT, mrp, lo, ow);
+        }
       }
       dma_land(dw0);
       XSTAMP();
@@ -1055,7 +1073,7 @@ __global__ __launch_bounds__(THREADS) void gatres_window_kernel(const FusedArgs 
       float* t = gp_cur; gp_cur = gp_nxt; gp_nxt = t;
     }
     FRESH_ARGS(); FRESH_BWD();
-#define LIST_(T_, N_, I_) I_(lo) I_(hi) T_(float, gpT) I_(n0)
+#define LIST_(T_, N_, I_) I_(lo) I_(hi) N_(float, gkeep) T_(float, gpT) I_(n0)
     REC_LOADS(LIST_);
     REC_PINS(LIST_);
     REC_DEFS(LIST_);
@@ -1066,8 +1084,10 @@ __global__ __launch_bounds__(THREADS) void gatres_window_kernel(const FusedArgs 
     if (a.C > 0) group_sync<THREADS>(grp);
     else         __syncthreads();
     publish_items<THREADS>(a, seg, part, 2 * L.nb, grp.local || !pub, !pub);
-    // lin0's partial sums: g_pre of the own rows from LDS (the last dX1 left it in gpT as well as in gp_cur)
-    seg_lin0_bwd<NC, THREADS>(rw, n0, a.perm, gp_cur, a.x, a.mask, slab + L.p_lin0_w, slab + L.p_lin0_b, red, gpT);
+    // lin0's partial sums: g_pre of the own rows from LDS when the launch keeps them there (gkeep; gpT holds them divided by
+    // the in-degrees for NC == 32), else from gp_cur
+    seg_lin0_bwd<NC, THREADS>(rw, n0, a.perm, gp_cur, a.x, a.mask, slab + L.p_lin0_w, slab + L.p_lin0_b, red,
+                              NC == 32 ? gkeep : gpT);
     if (pub && a.C > 0) {
       group_sync<THREADS>(grp);
       publish_items<THREADS>(a, seg, part, 2 * L.nb + 1, grp.local, true);

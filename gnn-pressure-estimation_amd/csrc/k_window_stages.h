@@ -335,7 +335,11 @@ __device__ __forceinline__ void xout_store1(const XOut& x, unsigned granule, con
 template <int K, int M, int H, int EPI, int NTG, int MW, int THREADS>
 __device__ __forceinline__ void win_proj(Rows rw, const float* X, const float* wl, float* OUT, int ob, float* OUT2,
                                          float* as_g, float* ad_g, float* as_l, float* ad_l, const float* resid_l,
-                                         float* OUT3, const unsigned long long* m64, const unsigned* m32, const XOut& xo) {
+                                         float* OUT3, const unsigned long long* m64, const unsigned* m32, const XOut& xo,
+                                         const u16* cnt_rp = nullptr) {
+  // cnt_rp (dX1 only): SimpleConv's in-edge rowptr (LDS, shifted view).  OUT2 and the exported granules then carry
+  // o / max(indeg(r), 1) -- the form K3 backward gathers (win_bwd_dst<MEAN, PRE>): ONE division per element where it is
+  // produced instead of one per out-edge where it is consumed (the same operands: the same bits).
   static_assert(K % 16 == 0 && M % 16 == 0, "whole tiles");
   constexpr int KQ = K / 4, NT = M / 16, GROUPS = NT / NTG, KP = K + 4;
   static_assert(MW >= 1 && MW <= THREADS / 64, "waves that carry work units");
@@ -354,6 +358,8 @@ __device__ __forceinline__ void win_proj(Rows rw, const float* X, const float* w
     const int r = t0 * 16 + i;
     const bool rok = r < rw.hi;
     const bool xrow = xo.on && rok && xo.flag[min(r, rw.hi - 1)] != 0;      // (read now: the wait falls behind the MFMA chain)
+    float rcnt = 1.f;
+    if (cnt_rp) { const int rr = min(r, rw.hi - 1); rcnt = (float)max((int)cnt_rp[rr + 1] - (int)cnt_rp[rr], 1); }
     unsigned ad[XR + WR];
     f32x4 fr[XR + WR];
 #pragma unroll
@@ -428,9 +434,11 @@ __device__ __forceinline__ void win_proj(Rows rw, const float* X, const float* w
           }
         }
         st4(OUT + (unsigned)((ob + r) * M + mb), o);
-        if (OUT2) st4(OUT2 + (unsigned)(r * M + mb), o);
+        float4 os = o;
+        if (cnt_rp) { os.x = o.x / rcnt; os.y = o.y / rcnt; os.z = o.z / rcnt; os.w = o.w / rcnt; }
+        if (OUT2) st4(OUT2 + (unsigned)(r * M + mb), os);
         if (OUT3) st4(OUT3 + (unsigned)(r * M + mb), o);
-        if (xrow) xout_store4(xo, xo.t_rows + (unsigned)(r * M + mb), o);
+        if (xrow) xout_store4(xo, xo.t_rows + (unsigned)(r * M + mb), os);
       }
     }
   }
@@ -954,7 +962,7 @@ __device__ __forceinline__ void win_softmax_bwd(Rows rw, const u16* nb, const u1
 // MEAN (conv2 only, H == 1): the stage starts with K3 backward (win_mean_bwd) for the same row -- its result g_y2[r] is
 // the g_out operand of the edge dots, held by the same lanes -- so  B1 exchange -> [K3 bwd, edge dots, softmax bwd] -> B2
 // exchange  is ONE stage.  g_out_rw: [row][HC] over the window (shifted view): read (MEAN = false) or written (MEAN).
-template <bool MEAN, int H, int C, int THREADS>
+template <bool MEAN, int H, int C, int THREADS, bool PRE = false>
 __device__ __forceinline__ void win_bwd_dst(Rows rw, const u16* nb, const u16* rp, const u16* col, float* g_out_rw,
                                             const float* h, const float* alpha, const float* a_src, const float* a_dst,
                                             float* g_e, float* g_a_dst,
@@ -993,10 +1001,13 @@ __device__ __forceinline__ void win_bwd_dst(Rows rw, const u16* nb, const u16* r
         const int beg = mtrp[r], end = mtrp[r + 1];
         for (int t = beg; t < end; ++t) {
           const int ii = mtdst[t];
-          const float cnt = (float)max((int)mrp[ii + 1] - (int)mrp[ii], 1);
+          [[maybe_unused]] const float cnt = (float)max((int)mrp[ii + 1] - (int)mrp[ii], 1);
           const float4 v = ld4(g_pre + (unsigned)(ii * C + c0));
-          acc.x = acc.x + v.x / cnt; acc.y = acc.y + v.y / cnt;
-          acc.z = acc.z + v.z / cnt; acc.w = acc.w + v.w / cnt;
+          if constexpr (PRE) { add4(acc, v); }
+          else {
+            acc.x = acc.x + v.x / cnt; acc.y = acc.y + v.y / cnt;
+            acc.z = acc.z + v.z / cnt; acc.w = acc.w + v.w / cnt;
+          }
         }
       } else {
         const unsigned a_g = lds_addr(g_pre) + (unsigned)c0 * 4u;
@@ -1008,9 +1019,14 @@ __device__ __forceinline__ void win_bwd_dst(Rows rw, const u16* nb, const u16* r
 #pragma unroll
         for (int k = 0; k < MAXD; ++k) {
           const float w1 = k < od.deg ? 1.f : 0.f;                      // x + 0 * q == x exactly
-          const float cnt = (float)od.x[k];
-          acc.x = fmaf(w1, v[k][0] / cnt, acc.x); acc.y = fmaf(w1, v[k][1] / cnt, acc.y);
-          acc.z = fmaf(w1, v[k][2] / cnt, acc.z); acc.w = fmaf(w1, v[k][3] / cnt, acc.w);
+          if constexpr (PRE) {                                          // g_pre holds g / max(indeg, 1): win_proj's cnt_rp
+            acc.x = fmaf(w1, v[k][0], acc.x); acc.y = fmaf(w1, v[k][1], acc.y);
+            acc.z = fmaf(w1, v[k][2], acc.z); acc.w = fmaf(w1, v[k][3], acc.w);
+          } else {
+            const float cnt = (float)od.x[k];
+            acc.x = fmaf(w1, v[k][0] / cnt, acc.x); acc.y = fmaf(w1, v[k][1] / cnt, acc.y);
+            acc.z = fmaf(w1, v[k][2] / cnt, acc.z); acc.w = fmaf(w1, v[k][3] / cnt, acc.w);
+          }
         }
       }
       go = acc;
