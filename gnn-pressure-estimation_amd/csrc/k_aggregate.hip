@@ -208,7 +208,59 @@ __global__ __launch_bounds__(256, W == 16 ? 3 : W == 8 ? 5 : 8) void gat_aggrega
       }
     }
     };
-    if (__ballot(deg > 4) == 0ULL) slots(std::integral_constant<int, 4>{});
+    // The same, one edge slot per LANE of the head's lane group (heads of 8 or 16 lanes: 64 / 128 features at 8 per lane):
+    // a lane forms its slot's logit, ONE exp and ONE divide; the maximum runs over the group by DPP (exact in any order),
+    // the exponentials and then the coefficients go round the group by ds_swizzle, and every lane adds them up in CSR
+    // order -- bit for bit the sums of the form above, at a sixth of its exp / divide work (k_window_stages.h: win_fwd_agg).
+    auto slots_lane = [&](auto KC, auto LHC) {
+      constexpr int MAXD = decltype(KC)::value, LH = decltype(LHC)::value;
+      const int kk = (c0 >> LGW) & (LH - 1);                      // this lane's place in its head's lane group = its slot
+      int jj[MAXD];
+#pragma unroll
+      for (int k = 0; k < MAXD; ++k) jj[k] = ival(col, beg + min(k, deg - 1));
+      const int jm = ival(col, beg + min(min(kk, MAXD - 1), deg - 1));
+      gatres_rowv<W> v[MAXD];
+#pragma unroll
+      for (int k = 0; k < MAXD; ++k) v[k] = rowldv(h, jj[k], c0);
+      const float sv = gatres_leaky(hval(a_src, jm, hd) + adst);
+      const float so = kk < deg ? sv : -INFINITY;                 // (deg <= MAXD: slots beyond it are padding)
+      float m = so;
+      m = fmaxf(m, gatres_dpp<0xB1>(m));                          // quad_perm [1,0,3,2]
+      m = fmaxf(m, gatres_dpp<0x4E>(m));                          // quad_perm [2,3,0,1]
+      m = fmaxf(m, gatres_dpp<0x141>(m));                         // row_half_mirror
+      if constexpr (LH == 16) m = fmaxf(m, gatres_dpp<0x140>(m)); // row_mirror
+      const float ex = expf(so - m);                              // exp(-inf) = 0 on padding slots
+      auto bcast = [&](float x, auto K) {                         // lane K of the lane group (32-lane swizzle: and | or << 5)
+        constexpr int pat = (0x1f & ~(LH - 1)) | (decltype(K)::value << 5);
+        return __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(x), pat));
+      };
+      float e[MAXD];
+      e[0] = bcast(ex, std::integral_constant<int, 0>{}); e[1] = bcast(ex, std::integral_constant<int, 1>{});
+      e[2] = bcast(ex, std::integral_constant<int, 2>{}); e[3] = bcast(ex, std::integral_constant<int, 3>{});
+      if constexpr (MAXD > 4) { e[4] = bcast(ex, std::integral_constant<int, 4>{}); e[5] = bcast(ex, std::integral_constant<int, 5>{}); }
+      float Z = 0.f;
+#pragma unroll
+      for (int k = 0; k < MAXD; ++k) Z = Z + e[k];
+      Z = Z + GATRES_SOFTMAX_EPS;
+      const float alm = ex / Z;
+      if (valid && kk < deg) *hptr(alpha, (beg + kk), hd) = alm;
+      float al[MAXD];
+      al[0] = bcast(alm, std::integral_constant<int, 0>{}); al[1] = bcast(alm, std::integral_constant<int, 1>{});
+      al[2] = bcast(alm, std::integral_constant<int, 2>{}); al[3] = bcast(alm, std::integral_constant<int, 3>{});
+      if constexpr (MAXD > 4) { al[4] = bcast(alm, std::integral_constant<int, 4>{}); al[5] = bcast(alm, std::integral_constant<int, 5>{}); }
+#pragma unroll
+      for (int k = 0; k < MAXD; ++k)
+        if (k < deg) axpyv(acc, al[k], v[k]);
+    };
+    const int lgLH = gm.lgC - LGW;
+    const bool few = __ballot(deg > 4) == 0ULL;
+    if (lgLH == 4) {
+      if (few) slots_lane(std::integral_constant<int, 4>{}, std::integral_constant<int, 16>{});
+      else slots_lane(std::integral_constant<int, MAXD>{}, std::integral_constant<int, 16>{});
+    } else if (lgLH == 3) {
+      if (few) slots_lane(std::integral_constant<int, 4>{}, std::integral_constant<int, 8>{});
+      else slots_lane(std::integral_constant<int, MAXD>{}, std::integral_constant<int, 8>{});
+    } else if (few) slots(std::integral_constant<int, 4>{});
     else slots(std::integral_constant<int, MAXD>{});
   } else {                                     // up to HUB_MIN_DEGREE in-edges: the row's own lanes, edge after edge
   float m = -INFINITY;
@@ -604,11 +656,23 @@ __global__ __launch_bounds__(256, W == 16 ? 5 : 8) void mean_bwd_kernel(
   const int c0 = (tid & (G - 1)) * W;
   const int beg = ival(mt_rowptr, row), end0 = ival(mt_rowptr, row + 1);
   gatres_rowv<W> acc = rowv_zero<W>();
+  // fp32 storage: g / cnt per element, the reference's arithmetic bit for bit.  bf16 storage: ONE division per edge and a
+  // multiply per element -- the product differs from the quotient by at most an fp32 ulp, far below the bf16 rounding of the
+  // stored sum, and the kernel's VALU work per edge drops from 10 W to 10 + W instructions.
   auto add_div = [&](gatres_rowv<W>& a, const gatres_rowv<W>& v, float cnt) {
+    if constexpr (sizeof(T) == 2) {
+      const float inv = 1.f / cnt;
 #pragma unroll
-    for (int q = 0; q < Q; ++q) {
-      a.v[q].x = a.v[q].x + v.v[q].x / cnt; a.v[q].y = a.v[q].y + v.v[q].y / cnt;
-      a.v[q].z = a.v[q].z + v.v[q].z / cnt; a.v[q].w = a.v[q].w + v.v[q].w / cnt;
+      for (int q = 0; q < Q; ++q) {
+        a.v[q].x = a.v[q].x + v.v[q].x * inv; a.v[q].y = a.v[q].y + v.v[q].y * inv;
+        a.v[q].z = a.v[q].z + v.v[q].z * inv; a.v[q].w = a.v[q].w + v.v[q].w * inv;
+      }
+    } else {
+#pragma unroll
+      for (int q = 0; q < Q; ++q) {
+        a.v[q].x = a.v[q].x + v.v[q].x / cnt; a.v[q].y = a.v[q].y + v.v[q].y / cnt;
+        a.v[q].z = a.v[q].z + v.v[q].z / cnt; a.v[q].w = a.v[q].w + v.v[q].w / cnt;
+      }
     }
   };
   const bool hub = valid && end0 - beg > HUB_MIN_DEGREE;                    // hub sources: whole wave + LDS-staged partial sums
