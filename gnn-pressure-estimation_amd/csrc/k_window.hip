@@ -887,11 +887,22 @@ __global__ __launch_bounds__(THREADS) void gatres_window_kernel(const FusedArgs 
       STAMP();
       {
         FRESH_ARGS(); FRESH_BWD();
-#define LIST_(T_, N_, I_) I_(lo) I_(hi) T_(const u16, nbin) T_(const u16, rp) T_(const u16, colo) T_(float, gy2T) T_(float, hT2) T_(float, alT2) T_(float, asT2) T_(float, adT2) T_(float, ge2) T_(float, gad2) T_(const u16, mout) T_(const u16, mrp) T_(const u16, mtrp) T_(const u16, mtdsto) T_(float, gpT) T_(const unsigned char, bflag) I_(elo)
+#define LIST_(T_, N_, I_) I_(lo) I_(hi) T_(const u16, nbin) T_(const u16, rp) T_(const u16, colo) T_(float, gy2T) T_(float, hT2) T_(float, alT2) T_(float, asT2) T_(float, adT2) T_(float, ge2) T_(float, gad2) T_(const u16, mout) T_(const u16, mrp) T_(const u16, mtrp) T_(const u16, mtdsto) T_(float, gpT) T_(const unsigned char, bflag) I_(elo) I_(ow)
         REC_LOADS(LIST_);
         REC_PINS(LIST_);
         REC_DEFS(LIST_);
 #undef LIST_
+        // Early import of exchange B2: at eight lanes per row a part of up to 64 rows sits on waves 0 .. 7; the other eight run
+        // B2's sweep DURING this stage (its halo rows of g_y2 / g_e are not touched by the stage; the partners store their
+        // g_y2 granules at the start of their own stage), so the hand-off behind the closing barrier has no sweep of its own:
+        // 0.3923 - 0.3936 -> 0.3871 - 0.3903 ms/step.  The same for F3 (behind conv2's aggregation) gave nothing and for B3
+        // (three idle waves behind conv1's destination-major stage) cost 8 us: profiles/r04_valu_probe.txt.
+        if (NC == 32 && ow <= 64 && wave_u >= 8) {
+          const auto rb2_ = rec_fresh<BwdRec>(myrec + GATRES_UREC_WORDS / 2);
+          xch_import2_by<NC, 1, 512, THREADS - 512>(xc, xc.ep + 1u, xbuf, LDS_TABLE(const u16, lds_raw, rb2_->hrow), rb2_->hrcnt,
+                                                     (unsigned)XL.b2y, gy2T, LDS_TABLE(const u16, lds_raw, rb2_->hedge),
+                                                     rb2_->hecnt, (unsigned)XL.b2e, ge2);
+        } else
         win_bwd_dst<true, 1, NC, THREADS, NC == 32>(rw, nbin, rp, colo, gy2T, hT2, alT2 + elo, asT2, adT2, ge2 + elo, gad2, mout, mrp,
                                                mtrp, mtdsto, gpT, xout(xedge, bflag, (unsigned)XL.b2y, (unsigned)XL.b2e), elo);
         lds_barrier();
@@ -899,7 +910,7 @@ __global__ __launch_bounds__(THREADS) void gatres_window_kernel(const FusedArgs 
       }
       {
         FRESH_ARGS(); FRESH_BWD();
-#define LIST_(T_, N_, I_) I_(lo) I_(hi) T_(float, gy2T) T_(float, ge2) T_(const u16, erow) T_(const u16, eedge) T_(const u16, hrow) T_(const u16, hedge) I_(ercnt) I_(eecnt) I_(hrcnt) I_(hecnt)
+#define LIST_(T_, N_, I_) I_(lo) I_(hi) T_(float, gy2T) T_(float, ge2) T_(const u16, erow) T_(const u16, eedge) T_(const u16, hrow) T_(const u16, hedge) I_(ercnt) I_(eecnt) I_(hrcnt) I_(hecnt) I_(ow)
         REC_LOADS(LIST_);
         REC_PINS(LIST_);
         REC_DEFS(LIST_);
@@ -908,6 +919,7 @@ __global__ __launch_bounds__(THREADS) void gatres_window_kernel(const FusedArgs 
         ++xc.ep;                                   // exchange B2: the source-major stage reads g_y2 / g_e of neighbour rows
         if (!xedge) xch_export2<NC, 1, THREADS>(xc, xbuf, erow, ercnt, gy2T, (unsigned)XL.b2y, eedge, eecnt, ge2, (unsigned)XL.b2e);
         XSTAMP();
+        if (NC != 32 || ow > 64)                   // (else the stage before ran the sweep on its idle waves)
         xch_import2<NC, 1, THREADS>(xc, xbuf, hrow, hrcnt, (unsigned)XL.b2y, gy2T, hedge, hecnt, (unsigned)XL.b2e, ge2);
         XSTAMP();
         xch_after<THREADS>(xc, pace, drain);

@@ -259,6 +259,55 @@ __device__ __forceinline__ void xch_import2(Xch& x, const XchBuf& xb, const u16*
   }
 }
 
+// The same sweep run by the waves [T0 / 64, (T0 + NT) / 64) only, for the epoch `ep` -- DURING the stage that precedes the
+// hand-off, by waves that hold no rows in it (early import): what the partners store early in their own stage is then in LDS
+// when the stage's closing barrier falls, and the hand-off behind it has no sweep of its own.
+template <int W1, int W2, int T0, int NT>
+__device__ __forceinline__ void xch_import2_by(Xch& x, unsigned ep, const XchBuf& xb, const u16* l1, int c1, unsigned t1, float* d1,
+                                               const u16* l2, int c2, unsigned t2, float* d2) {
+  constexpr int P1 = XchGeom<W1>::P, P2 = XchGeom<W2>::P, E1 = XchGeom<W1>::E, E2 = XchGeom<W2>::E;
+  constexpr int U = 2;
+  const int tid = stage_tid() - T0;
+  if (tid < 0 || tid >= NT) return;
+  const int n1 = c1 * P1, total = n1 + c2 * P2;
+  for (int base = 0; base < total; base += U * NT) {
+    if (base + (tid & ~63) >= total) continue;                             // nothing left for this wave
+    int o[U];
+    bool valid[U], two[U], first[U];
+    unsigned off[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int k = base + u * NT + tid;
+      valid[u] = k < total;
+      first[u] = k < n1;
+      const int kk = first[u] ? k : k - n1;
+      if (!valid[u])     { o[u] = 0; two[u] = false; off[u] = 0; }
+      else if (first[u]) { o[u] = (int)l1[kk / P1] * W1 + E1 * (kk % P1); two[u] = E1 == 2; off[u] = (t1 + (unsigned)o[u]) * 8u; }
+      else               { o[u] = (int)l2[kk / (P2 ? P2 : 1)] * W2 + E2 * (kk % (P2 ? P2 : 1)); two[u] = E2 == 2; off[u] = (t2 + (unsigned)o[u]) * 8u; }
+    }
+    v4u v[U];
+    int spin = 0;
+    for (;;) {
+      bool ok = true;
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+        if (valid[u]) v[u] = __builtin_amdgcn_raw_buffer_load_b128(xb.r, off[u], 0, 16);
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+        ok = ok && (!valid[u] || (v[u].y == ep && (!two[u] || v[u].w == ep)));
+      if (__all(ok || x.dead)) break;
+      if (++spin > SPIN_LIMIT) { *x.err = 1; x.dead = true; }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+      if (valid[u]) {
+        float* d = first[u] ? d1 : d2;
+        d[o[u]] = __uint_as_float(v[u].x);
+        if (two[u]) d[o[u] + 1] = __uint_as_float(v[u].z);
+      }
+  }
+}
+
 // After a part's sweep.  pace: announce "exchange ep is behind me" and wait until every other part has announced exchange
 // ep - 1 (k_fused_dev.h: xch_heartbeat) -- needed only when the plan cannot promise that partners owe each other rows in
 // both directions (GATRES_GRAPH_SYMMETRIC: then a part cannot reach the exchange that rewrites a cell before the cell's
