@@ -221,8 +221,8 @@ def pmc_traffic(args, us_main, us_second):
     FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for wide coalesced reads on gfx950), plus the wait counters of the
     dominant kernel.  Only for the workload they were taken on, and only while the kernels still are the kernels that were
     counted: the file records each kernel's average duration in the profiled run, and a file whose figures differ from
-    this run's live HIP-event durations by more than 5 % is REFUSED (traffic = null, the reason in traffic_source) -- no
-    falling back to another round's file."""
+    this run's live HIP-event durations by more than 5 % (dominant kernel; 10 % for the second launch, see below) is REFUSED
+    (traffic = null, the reason in traffic_source) -- no falling back to another round's file."""
     if args.model != "gatres_small" or args.batch_size != 32 or args.nodes != 388 or args.per_op or args.shuffle_nodes:
         return None, "no counter passes were taken for this workload", None
     path = os.path.join(ROOT, "profiles", PMC_FILE)
@@ -232,12 +232,16 @@ def pmc_traffic(args, us_main, us_second):
         rec = [raw["kernel_avg_us"], (raw.get("second_kernel") or {}).get("kernel_avg_us")]
     except Exception as e:      # noqa: BLE001
         return None, f"profiles/{PMC_FILE} unusable ({type(e).__name__}: {e})", None
-    for what, live, was in (("dominant kernel", us_main, rec[0]), ("parameter-gradient launch", us_second, rec[1])):
+    # (the second launch is timed back to back here, 36.8 - 37.3 us, and inside the step by rocprof, 38.7 - 39.4 us with the
+    # window kernel's tables freshly evicted from L2: the same kernel reads 4 - 7 % apart between the two set-ups, so its
+    # band is 10 %; the dominant kernel, which carries 3/4 of the traffic, stays at 5 %)
+    for what, live, was, tol in (("dominant kernel", us_main, rec[0], 0.05),
+                                 ("parameter-gradient launch", us_second, rec[1], 0.10)):
         if live is None or was is None:
             continue
-        if abs(live - was) > 0.05 * was:
+        if abs(live - was) > tol * was:
             return None, (f"profiles/{PMC_FILE} REFUSED: its {what} averaged {was:.1f} us in the profiled run, this run "
-                          f"measures {live:.1f} us (> 5 % apart): the counters describe other kernels; rerun "
+                          f"measures {live:.1f} us (> {int(tol * 100)} % apart): the counters describe other kernels; rerun "
                           f"tests/micro/profile_r04.sh"), None
     val = int((2.0 * raw["FETCH_SIZE"]["mean_counter_value_KB"] + raw["WRITE_SIZE"]["mean_counter_value_KB"]) * 1024)
     sk = raw.get("second_kernel")
@@ -246,7 +250,7 @@ def pmc_traffic(args, us_main, us_second):
     src = (f"profiles/{PMC_FILE}: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, 2 x FETCH + WRITE "
            f"per launch{' (window kernel + parameter-gradient launch)' if sk else ''}; a committed constant, NOT measured in "
            f"this run; accepted because the recorded kernel durations ({rec[0]:.1f}"
-           f"{'' if rec[1] is None else ' + %.1f' % rec[1]} us) agree with this run's within 5 %")
+           f"{'' if rec[1] is None else ' + %.1f' % rec[1]} us) agree with this run's within 5 % (dominant kernel) / 10 % (second launch)")
     return val, src, raw.get("wait")
 
 
