@@ -1113,6 +1113,51 @@ __device__ __forceinline__ void win_bwd_dst(Rows rw, const u16* nb, const u16* r
       }
       continue;
     }
+    if constexpr (LH == 8) {
+      // One edge slot per lane of the head's eight lanes for everything that is per EDGE (win_fwd_agg's scheme): lane j reads
+      // alpha_j and a_src of its slot's source (2 LDS reads instead of 12), the coefficients go round the group for S, lane j
+      // forms g_s / g_e of its slot and stores it (table + exported granule), the g_e go round once more for g_a_dst in CSR
+      // order.  Same operands, same order: the same bits; ~45 VALU instructions per lane less.
+      const int j = tid % LH;
+      const int jj = min(j, MAXD - 1);
+      const int nj = d.n[0] * (jj == 0) + d.n[1] * (jj == 1) + d.n[2] * (jj == 2) + d.n[3] * (jj == 3) + d.n[4] * (jj == 4) +
+                     d.n[5] * (jj == 5);
+      unsigned av[MAXD];
+#pragma unroll
+      for (int k = 0; k < MAXD; ++k) av[k] = a_h + (unsigned)(d.n[k] * HC) * 4u;
+      const unsigned aaj = a_al + (unsigned)((d.beg + min(jj, d.deg - 1)) * H) * 4u, asj = a_as + (unsigned)(nj * H) * 4u;
+      f32x4 hv[MAXD];
+      float alj, rawj;
+      asm volatile(
+          "ds_read_b128 %0, %8\n\tds_read_b128 %1, %9\n\tds_read_b128 %2, %10\n\t"
+          "ds_read_b128 %3, %11\n\tds_read_b128 %4, %12\n\tds_read_b128 %5, %13\n\t"
+          "ds_read_b32 %6, %14\n\tds_read_b32 %7, %15\n\ts_waitcnt lgkmcnt(0)"
+          : "=&v"(hv[0]), "=&v"(hv[1]), "=&v"(hv[2]), "=&v"(hv[3]), "=&v"(hv[4]), "=&v"(hv[5]), "=&v"(alj), "=&v"(rawj)
+          : "v"(av[0]), "v"(av[1]), "v"(av[2]), "v"(av[3]), "v"(av[4]), "v"(av[5]), "v"(aaj), "v"(asj)
+          : "memory");
+      const float al_m = j < d.deg ? alj : 0.f;                            // padding slots weigh nothing
+      float al[MAXD], ga[MAXD];
+      al[0] = group8_bcast<0>(al_m); al[1] = group8_bcast<1>(al_m); al[2] = group8_bcast<2>(al_m);
+      al[3] = group8_bcast<3>(al_m); al[4] = group8_bcast<4>(al_m); al[5] = group8_bcast<5>(al_m);
+      float S = 0.f, gad = 0.f, ga_m = 0.f;
+#pragma unroll
+      for (int k = 0; k < MAXD; ++k) {
+        ga[k] = gatres_head_reduce<LH>(gatres_head_dot4(go, as_f4(hv[k])));
+        S = fmaf(al[k], ga[k], S);
+        ga_m = j == k ? ga[k] : ga_m;
+      }
+      const float gs = al_m * (ga_m - S);
+      const float ge_m = (rawj + adst) > 0.f ? gs : gs * GATRES_NEG_SLOPE;
+      if (valid && j < d.deg) {
+        g_e[(unsigned)((d.beg + j) * H + hd)] = ge_m;
+        // the owner of the edge's SOURCE row needs g_e in its source-major stage
+        if (xo.on && (nj < rw.lo || nj >= rw.hi)) xout_store1(xo, xo.t_small + (unsigned)((eabs + d.beg + j) * H + hd), ge_m);
+      }
+      gad = gad + group8_bcast<0>(ge_m); gad = gad + group8_bcast<1>(ge_m); gad = gad + group8_bcast<2>(ge_m);
+      gad = gad + group8_bcast<3>(ge_m); gad = gad + group8_bcast<4>(ge_m); gad = gad + group8_bcast<5>(ge_m);
+      if (leader) g_a_dst[(unsigned)(r * H + hd)] = gad;
+      continue;
+    }
     unsigned av[MAXD], aa[MAXD], as[MAXD];
 #pragma unroll
     for (int k = 0; k < MAXD; ++k) {
@@ -1184,6 +1229,34 @@ __device__ __forceinline__ void win_agg_bwd_src(Rows rw, const u16* to, const u1
         gatres_axpy4(acc, alpha[(unsigned)(e * H + hd)], ld4(g_out + (unsigned)(ii * HC + c0)));
       }
     } else {
+      if constexpr (C == 32) {
+        // one out-edge slot per lane of the head's eight lanes for the per-EDGE operands (win_bwd_dst's scheme): lane j reads
+        // alpha and g_e of its slot's edge (2 LDS reads instead of 12) and the two go round the group, masked at the source
+        const int j = tid % (C / 4);
+        const int jj = min(j, MAXD - 1);
+        const int xj = d.x[0] * (jj == 0) + d.x[1] * (jj == 1) + d.x[2] * (jj == 2) + d.x[3] * (jj == 3) + d.x[4] * (jj == 4) +
+                       d.x[5] * (jj == 5);
+        unsigned av[MAXD];
+#pragma unroll
+        for (int k = 0; k < MAXD; ++k) av[k] = a_go + (unsigned)(d.d[k] * HC) * 4u;
+        f32x4 v[MAXD];
+        float alj, gej;
+        asm volatile(
+            "ds_read_b128 %0, %8\n\tds_read_b128 %1, %9\n\tds_read_b128 %2, %10\n\t"
+            "ds_read_b128 %3, %11\n\tds_read_b128 %4, %12\n\tds_read_b128 %5, %13\n\t"
+            "ds_read_b32 %6, %14\n\tds_read_b32 %7, %15\n\ts_waitcnt lgkmcnt(0)"
+            : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]), "=&v"(v[4]), "=&v"(v[5]), "=&v"(alj), "=&v"(gej)
+            : "v"(av[0]), "v"(av[1]), "v"(av[2]), "v"(av[3]), "v"(av[4]), "v"(av[5]), "v"(a_al + (unsigned)(xj * H) * 4u),
+              "v"(a_ge + (unsigned)(xj * H) * 4u)
+            : "memory");
+        const bool okj = j < d.deg;
+        const float al_m = okj ? alj : 0.f, ge_m = okj ? gej : 0.f;
+        gas = gas + group8_bcast<0>(ge_m); gas = gas + group8_bcast<1>(ge_m); gas = gas + group8_bcast<2>(ge_m);
+        gas = gas + group8_bcast<3>(ge_m); gas = gas + group8_bcast<4>(ge_m); gas = gas + group8_bcast<5>(ge_m);
+        gatres_axpy4(acc, group8_bcast<0>(al_m), as_f4(v[0])); gatres_axpy4(acc, group8_bcast<1>(al_m), as_f4(v[1]));
+        gatres_axpy4(acc, group8_bcast<2>(al_m), as_f4(v[2])); gatres_axpy4(acc, group8_bcast<3>(al_m), as_f4(v[3]));
+        gatres_axpy4(acc, group8_bcast<4>(al_m), as_f4(v[4])); gatres_axpy4(acc, group8_bcast<5>(al_m), as_f4(v[5]));
+      } else {
       unsigned av[MAXD], aa[MAXD], ag[MAXD];
 #pragma unroll
       for (int k = 0; k < MAXD; ++k) {
@@ -1199,6 +1272,7 @@ __device__ __forceinline__ void win_agg_bwd_src(Rows rw, const u16* to, const u1
         const bool ok = k < d.deg;
         gas = gas + (ok ? ge[k] : 0.f);
         gatres_axpy4(acc, ok ? al[k] : 0.f, as_f4(v[k]));
+      }
       }
     }
     const bool leader = valid && (c0 % C) == 0;
