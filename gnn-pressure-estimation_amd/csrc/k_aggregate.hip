@@ -755,7 +755,29 @@ __global__ __launch_bounds__(256, W == 16 ? 5 : 8) void mean_bwd_kernel(
       if ((lane >> lgG) == (owner >> lgG)) acc = sum;
     }
   }
-  const int end = hub ? beg : end0;            // (the slot form of the other kernels measured slower here: 13.6 vs 12.8 us)
+  int end = hub ? beg : end0;
+  // bf16 storage (one reciprocal per edge, light arithmetic): rows of up to four out-edges issue every load of the row together --
+  // one dependent round trip mt_dst -> {m_rowptr x 2, g_pre row} instead of one per edge -- and sum in edge order: the same
+  // bits as the loop.  (With fp32's per-element divisions the slot form measured slower: 13.6 vs 12.8 us; it keeps the loop.)
+  if constexpr (sizeof(T) == 2) {
+    if (__ballot(end - beg > 4) == 0ULL) {
+      const int deg = end - beg;
+      int ii[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) ii[k] = k < deg ? ival(mt_dst, beg + k) : row;        // (padding: a valid row, masked out below)
+      gatres_rowv<W> gv[4];
+      int c0r[4], c1r[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        gv[k] = rowldv(g_pre, ii[k], c0);
+        c0r[k] = ival(m_rowptr, ii[k]); c1r[k] = ival(m_rowptr, ii[k] + 1);
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        if (k < deg) add_div(acc, gv[k], (float)max(c1r[k] - c0r[k], 1));
+      end = beg;
+    }
+  }
   for (int t = beg; t < end; ++t) {
     const int i = ival(mt_dst, t);
     const float cnt = (float)max(ival(m_rowptr, i + 1) - ival(m_rowptr, i), 1);
