@@ -1101,6 +1101,39 @@ __device__ __forceinline__ void seg_bias_part(Rows rw, const float* g_out, int g
   }
   red[threadIdx.x] = ab;
 }
+// The same partials (thread t's of seg_bias_part for every t in [0, THREADS)) formed by the threads [T0, T0 + NT) only --
+// by waves that hold no rows in the sparse stage they ride on -- and the finish by the HC threads from T0 on.
+template <int HC, int THREADS, int T0, int NT>
+__device__ __forceinline__ void seg_bias_part_by(Rows rw, const float* g_out, int gb, float* red) {
+  constexpr int R = THREADS / HC;
+  const int t0 = (int)threadIdx.x - T0;
+  if (t0 < 0 || t0 >= NT) return;
+  for (int idx = t0; idx < THREADS; idx += NT) {
+    const int c = idx % HC, rg = idx / HC;
+    float ab = 0.f;
+    for (int r0 = rw.lo + rg; r0 < rw.hi; r0 += 4 * R) {
+      float go[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int r = r0 + k * R;
+        go[k] = r < rw.hi ? g_out[(unsigned)((gb + (r < rw.hi ? r : rw.lo)) * HC + c)] : 0.f;
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) ab += go[k];
+    }
+    red[idx] = ab;
+  }
+}
+template <int HC, int THREADS, int T0>
+__device__ __forceinline__ void seg_bias_finish_by(const float* red, float* __restrict__ slab_b) {
+  constexpr int R = THREADS / HC;
+  const int t = (int)threadIdx.x - T0;
+  if (t >= 0 && t < HC) {
+    float s = 0.f;
+    for (int k = 0; k < R; ++k) s += red[k * HC + t];
+    slab_b[t] = s;
+  }
+}
 template <int HC, int THREADS>
 __device__ __forceinline__ void seg_bias_finish(const float* red, float* __restrict__ slab_b) {
   constexpr int R = THREADS / HC;

@@ -862,6 +862,11 @@ __global__ __launch_bounds__(THREADS) void gatres_window_kernel(const FusedArgs 
       [[maybe_unused]] const bool xs_on = STAMPS_PTR && a.stamp_cap >= 4096 && seg == 0 && b == nb / 2;
       [[maybe_unused]] int xs_i = 0;
       XSTAMP();
+      // (no barrier in front of exchange B1's sweep when nothing exports here: the sweep writes halo rows only, which the dX1
+      // stage still running on slower waves does not touch -- a wave sweeps its share as soon as it arrives, and the LDS-DMA
+      // waves' landing wait overlaps with it; the same in front of B3's sweep.  Measured: 0.3728 - 0.3746 -> 0.3691 - 0.3695
+      // ms/step; the three forward hand-offs the same way gained nothing and keep theirs.)
+      if (NC != 32 || !xrows || b == nb - 1)             // (an export pass reads rows other waves wrote)
       lds_barrier();                                     // own rows of g_pre are in LDS (lin1 backward / the previous dX1)
       XSTAMP();
       {
@@ -915,7 +920,8 @@ __global__ __launch_bounds__(THREADS) void gatres_window_kernel(const FusedArgs 
         REC_PINS(LIST_);
         REC_DEFS(LIST_);
 #undef LIST_
-        seg_bias_part<NC, THREADS>(rw, gy2T, 0, red);  // (own rows of g_y2: the sweep below only writes halo rows)
+        const bool lean = NC == 32 && ow <= 64;    // (the sweep ran in the stage before; the bias partials ride on the stage after)
+        if (!lean) seg_bias_part<NC, THREADS>(rw, gy2T, 0, red);  // (own rows of g_y2: the sweep below only writes halo rows)
         ++xc.ep;                                   // exchange B2: the source-major stage reads g_y2 / g_e of neighbour rows
         if (!xedge) xch_export2<NC, 1, THREADS>(xc, xbuf, erow, ercnt, gy2T, (unsigned)XL.b2y, eedge, eecnt, ge2, (unsigned)XL.b2e);
         XSTAMP();
@@ -924,7 +930,7 @@ __global__ __launch_bounds__(THREADS) void gatres_window_kernel(const FusedArgs 
         XSTAMP();
         xch_after<THREADS>(xc, pace, drain);
         XSTAMP();
-        lds_barrier();
+        if (!lean) lds_barrier();                  // (lean: nothing between the two stages touches LDS)
         XSTAMP();
         STAMP();
       }
@@ -948,17 +954,21 @@ __global__ __launch_bounds__(THREADS) void gatres_window_kernel(const FusedArgs 
       };
       {
         FRESH_ARGS(); FRESH_BWD();
-#define LIST_(T_, N_, I_) I_(lo) I_(hi) T_(const u16, tout) T_(const u16, trp) T_(const u16, teido) T_(const u16, tdsto) T_(float, gy2T) T_(float, alT2) T_(float, ge2) T_(float, gad2) T_(float, wlA) T_(float, xG2) I_(n0)
+#define LIST_(T_, N_, I_) I_(lo) I_(hi) T_(const u16, tout) T_(const u16, trp) T_(const u16, teido) T_(const u16, tdsto) T_(float, gy2T) T_(float, alT2) T_(float, ge2) T_(float, gad2) T_(float, wlA) T_(float, xG2) I_(n0) I_(ow)
         REC_LOADS(LIST_);
         [[maybe_unused]] float* sb = slab + L.p_block0 + (int64_t)launder_s(b) * L.p_block_stride;
         [[maybe_unused]] float* keep = sc + L.sc_keep + (int64_t)launder_s(b) * L.keep_stride;
         REC_PINS(LIST_, , "s"(sb), "s"(keep));
         REC_DEFS(LIST_);
 #undef LIST_
-        seg_bias_finish<NC, THREADS>(red, sb + L.c2_b);
+        const bool lean = NC == 32 && ow <= 64;    // rows on waves 0 .. 7: the other eight form conv2's bias partials meanwhile
+        if (!lean) seg_bias_finish<NC, THREADS>(red, sb + L.c2_b);
+        if (lean && wave_u >= 8) seg_bias_part_by<NC, THREADS, 512, THREADS - 512>(rw, gy2T, 0, red);
+        else
         win_agg_bwd_src<1, NC, THREADS>(rw, tout, trp, teido, tdsto, 0, gy2T, alT2, ge2, gad2, wlA + A2OFF, wlA + A2OFF + NC,
                                              keep + L.k_gh2, n0, keep + L.k_gas2, keep + L.k_gad2, xG2);
         lds_barrier();                   // g_y2 (RA) and the conv2 tables are dead
+        if (lean) seg_bias_finish_by<NC, THREADS, THREADS - 64>(red, sb + L.c2_b);      // (the last wave: `red` rests until dst1)
         XSTAMP();
         STAMP();
       }
@@ -1005,7 +1015,7 @@ __global__ __launch_bounds__(THREADS) void gatres_window_kernel(const FusedArgs 
         win_bwd_dst<false, 2, NC, THREADS>(rw, nbin, rp, colo, RA, hT1, alT1 + elo * 2, asT1, adT1, ge1 + elo * 2, gad1,
                                                 nullptr, nullptr, nullptr, nullptr, nullptr,
                                                 xout(xedge, bflag, 0u, (unsigned)XL.b3e), elo);
-        lds_barrier();
+        if (NC != 32 || !xrows) lds_barrier();     // (else B3's sweep starts without one: see the top of the loop)
         XSTAMP();
       }
       {
