@@ -218,7 +218,10 @@ template <int W1, int W2, int THREADS>
 __device__ __forceinline__ void xch_import2(Xch& x, const XchBuf& xb, const u16* l1, int c1, unsigned t1, float* d1,
                                             const u16* l2, int c2, unsigned t2, float* d2) {
   constexpr int P1 = XchGeom<W1>::P, P2 = XchGeom<W2>::P, E1 = XchGeom<W1>::E, E2 = XchGeom<W2>::E;
-  constexpr int U = 2;
+  // ONE granule access per lane and trip: the hand-off lists of a part fit one trip of the workgroup's threads (C-Town, 8 parts:
+  // 320 - 700 accesses), and a second, always-empty access per lane cost 13 us per step in index arithmetic and predication
+  // (0.3555 - 0.3565 vs 0.3678 - 0.3709 ms/step); longer lists take more trips.
+  constexpr int U = 1;
   const int tid = stage_tid();
   const int n1 = c1 * P1, total = n1 + c2 * P2;
   for (int base = 0; base < total; base += U * THREADS) {
@@ -266,7 +269,7 @@ template <int W1, int W2, int T0, int NT>
 __device__ __forceinline__ void xch_import2_by(Xch& x, unsigned ep, const XchBuf& xb, const u16* l1, int c1, unsigned t1, float* d1,
                                                const u16* l2, int c2, unsigned t2, float* d2) {
   constexpr int P1 = XchGeom<W1>::P, P2 = XchGeom<W2>::P, E1 = XchGeom<W1>::E, E2 = XchGeom<W2>::E;
-  constexpr int U = 2;
+  constexpr int U = 1;                         // (see xch_import2)
   const int tid = stage_tid() - T0;
   if (tid < 0 || tid >= NT) return;
   const int n1 = c1 * P1, total = n1 + c2 * P2;
