@@ -250,6 +250,7 @@ __device__ __forceinline__ void xch_import2(Xch& x, const XchBuf& xb, const u16*
       for (int u = 0; u < U; ++u)
         ok = ok && (!valid[u] || (v[u].y == x.ep && (!two[u] || v[u].w == x.ep)));
       if (__all(ok || x.dead)) break;
+      __builtin_amdgcn_s_sleep(1);                 // (a failed poll: 64 cycles before the next one -- 0.8 us per step less L2 pressure)
       if (++spin > SPIN_LIMIT) { *x.err = 1; x.dead = true; }
     }
 #pragma unroll
@@ -299,6 +300,7 @@ __device__ __forceinline__ void xch_import2_by(Xch& x, unsigned ep, const XchBuf
       for (int u = 0; u < U; ++u)
         ok = ok && (!valid[u] || (v[u].y == ep && (!two[u] || v[u].w == ep)));
       if (__all(ok || x.dead)) break;
+      __builtin_amdgcn_s_sleep(1);                 // (a failed poll: 64 cycles before the next one -- 0.8 us per step less L2 pressure)
       if (++spin > SPIN_LIMIT) { *x.err = 1; x.dead = true; }
     }
 #pragma unroll
