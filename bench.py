@@ -212,12 +212,12 @@ def survey_bytes_per_snapshot(nb, nc, n_g, e_g, s):
 SURVEY_STATED_BYTES = {("gatres_small", 388, 860, "fp32"): 50.6e6, ("gatres_large", 388, 860, "bf16"): 163e6}
 
 
-PMC_FILE = "r04_fused_pmc_raw.json"      # written by tests/micro/profile_r04.sh from the round's own counter passes
+PMC_FILE = "r05_fused_pmc_raw.json"      # written by tests/micro/profile_r05.sh from the round's own counter passes
 
 
 def pmc_traffic(args, us_main, us_second):
     """HBM-side bytes per step of the two heavy launches from the committed rocprofv3 --pmc passes of THIS round
-    (profiles/r04_fused_pmc_raw.json: FETCH_SIZE and WRITE_SIZE collected in separate runs of this script, KB per launch;
+    (profiles/r05_fused_pmc_raw.json: FETCH_SIZE and WRITE_SIZE collected in separate runs of this script, KB per launch;
     FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for wide coalesced reads on gfx950), plus the wait counters of the
     dominant kernel.  Only for the workload they were taken on, and only while the kernels still are the kernels that were
     counted: the file records each kernel's average duration in the profiled run, and a file whose figures differ from
@@ -242,7 +242,7 @@ def pmc_traffic(args, us_main, us_second):
         if abs(live - was) > tol * was:
             return None, (f"profiles/{PMC_FILE} REFUSED: its {what} averaged {was:.1f} us in the profiled run, this run "
                           f"measures {live:.1f} us (> {int(tol * 100)} % apart): the counters describe other kernels; rerun "
-                          f"tests/micro/profile_r04.sh"), None
+                          f"tests/micro/profile_r05.sh"), None
     val = int((2.0 * raw["FETCH_SIZE"]["mean_counter_value_KB"] + raw["WRITE_SIZE"]["mean_counter_value_KB"]) * 1024)
     sk = raw.get("second_kernel")
     if sk:           # the parameter gradients (+ update) run as a launch of their own: both launches, like counted_us
@@ -303,9 +303,40 @@ def time_kernels(rows, device, reps=200):
         e1.record(torch.cuda.current_stream(device))
         e1.synchronize()
         us = e0.elapsed_time(e1) * 1e3 / reps
-        out.append(dict(kernel=name, calls_per_step=calls, avg_us=us, algorithmic_bytes=nbytes,
-                        gbs=nbytes / us * 1e-3))
+        gbs = nbytes / us * 1e-3
+        # `gbs` prices ALGORITHMIC bytes (every gathered neighbour row at full width, no cache credit): for the sparse kernels
+        # most of those bytes are served by L2, so the figure is an L2-SIDE rate and can exceed the HBM peak; it is not a
+        # roofline fraction.  The HBM-side rate of the same kernels (FETCH_SIZE / WRITE_SIZE counters) is attached to the line
+        # as `hbm_side_rates` where a counter file of this round exists for the workload.
+        out.append(dict(kernel=name, calls_per_step=calls, avg_us=us, algorithmic_bytes=nbytes, gbs=gbs,
+                        gbs_kind="L2-side (algorithmic bytes, gathers at full row width, no cache credit)",
+                        exceeds_hbm_peak=bool(gbs > HBM_PEAK_GBS)))
     return out
+
+
+PEROP_PMC_FILES = {("gatres_large", 128, 388, "bf16"): "r05_large_ctown_bs128_bf16_pmc.json"}
+
+
+def hbm_side_rates(args):
+    """Counter-based HBM-side traffic of the per-op kernels ((2 x FETCH_SIZE + WRITE_SIZE) x 1024 bytes per launch, separate
+    rocprofv3 --pmc passes of this command, tests/micro/profile_r05.sh) over their rocprof average durations: what HBM (or
+    the Infinity Cache in front of it) physically moved, per kernel symbol -- beside the L2-side `gbs` of the kernel table."""
+    name = PEROP_PMC_FILES.get((args.model, args.batch_size, args.nodes, args.dtype))
+    if name is None:
+        return None
+    try:
+        with open(os.path.join(ROOT, "profiles", name)) as f:
+            raw = json.load(f)
+        out = {}
+        for sym, c in raw["mean_per_launch"].items():
+            if "FETCH_SIZE" in c and "WRITE_SIZE" in c and c.get("avg_us"):
+                nbytes = (2.0 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0
+                out[sym] = {"hbm_bytes_per_launch": int(nbytes), "avg_us": c["avg_us"],
+                            "hbm_gbs": round(nbytes / c["avg_us"] * 1e-3, 1),
+                            "hbm_frac_of_peak": round(nbytes / c["avg_us"] * 1e-3 / HBM_PEAK_GBS, 4)}
+        return {"source": f"profiles/{name} (a committed constant of this round, NOT measured in this run)", "kernels": out}
+    except Exception as e:      # noqa: BLE001
+        return {"source": f"profiles/{name} unusable ({type(e).__name__}: {e})", "kernels": {}}
 
 
 def in_run_parity(args, nb, nc, device):
@@ -542,12 +573,27 @@ def main():
     log(f"model/trainer ready on {device}; warm-up {args.warmup} steps")
     for i in range(args.warmup):
         one_step(i)
+    # Every hipGraph the timed steps replay exists BEFORE the first timed block, whatever --warmup is: bind_batches() captured
+    # the steady-state step of every (batch, mask buffer) pair (GATResTrainer.precapture_bound).  Checked, not assumed: the
+    # number of captured graphs must not move across the timed blocks (block 1 used to hold four captures).
+    graphs_before = trainer.num_captured_graphs
     times = [timed_block(args.steps) for _ in range(max(1, args.repeats))]
+    graphs_after = trainer.num_captured_graphs
+    bound_path = not (args.host_batches or args.copy_batches or store is not None or args.no_graph)
+    if bound_path and graphs_after != graphs_before:
+        raise SystemExit(f"bench.py: {graphs_after - graphs_before} hipGraph capture(s) happened INSIDE the timed region "
+                         f"({graphs_before} -> {graphs_after} graphs): the measurement is invalid")
     dt = statistics.median(times)
     loss = float(trainer.loss.item())
     log(f"timed {len(times)} x {args.steps} steps: median {dt:.4f}s (min {min(times):.4f}, max {max(times):.4f}), loss {loss:.5f}")
     if not (loss == loss) or loss > 1e6:
         raise SystemExit(f"training diverged (loss={loss}; dropped steps: {trainer.fault_count})")
+    dropped = trainer.fault_count + trainer.dropped_steps
+    if dropped > 0:
+        # a dropped step did no work: a rate that counts it would be inflated.  The per-snapshot kernel needs its whole grid
+        # co-resident (one workgroup per CU); on a shared / partitioned / CU-masked device partners time out instead.
+        raise SystemExit(f"bench.py: {dropped} training step(s) were DROPPED (a split launch gave up waiting for a partner "
+                         f"workgroup: is the GPU shared?): refusing to report a rate")
 
     lib = G._native.load()
     cus = lib.gatres_fused_cus_per_segment(model._cmodel_ref(), trainer.plan.ref()) if trainer.fused else 0
@@ -572,7 +618,8 @@ def main():
                                f"{', batches staged by copy' if args.copy_batches else ''}",
                    "global_batch": world * args.batch_size, "parallelism": f"dp{world}",
                    "plan_relabelled": trainer.plan.perm_host is not None, "row_window": trainer.plan.window_rows(cus) if cus >= 2 else None,
-                   "dropped_steps": trainer.fault_count + trainer.dropped_steps, "final_loss": loss},
+                   "dropped_steps": dropped, "final_loss": loss,
+                   "captured_graphs": graphs_after, "captures_in_timed_region": graphs_after - graphs_before},
     }
     if DIST_BACKEND != "nccl" or SHARE_GPU:
         result["config"]["test_overrides"] = {"backend": DIST_BACKEND, "ranks_share_gpu": SHARE_GPU}
@@ -632,13 +679,24 @@ def main():
             for r in rows:
                 r["step_share_us"] = r["avg_us"] * r["calls_per_step"]
             dom = max(rows, key=lambda r: r["step_share_us"])
-            result["roofline"] = {"bound": "hbm", "kernel": dom["kernel"], "achieved": dom["gbs"],
-                                  "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": dom["gbs"] / HBM_PEAK_GBS,
+            # Per-op configurations: the step is some hundred launches, so the ONE roofline figure is SURVEY 8(d)'s algorithmic
+            # bytes per snapshot x batch over the whole STEP time (`frac` == `frac_of_step_time`).  The per-kernel `gbs` of the
+            # kernel table are L2-side rates (see time_kernels) and are not roofline fractions.
+            step_us = dt / args.steps * 1e6
+            ach = unit_bytes * args.batch_size / step_us * 1e-3
+            result["roofline"] = {"bound": "hbm", "kernel": f"whole step ({sum(r['calls_per_step'] for r in rows)} launches of the "
+                                                            f"kernel table + slab reductions); largest share: {dom['kernel']}",
+                                  "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                                   "traffic": None, "traffic_source": None, "avg_launch_us": dom["avg_us"],
-                                  "algorithmic_bytes_per_launch": dom["algorithmic_bytes"],
+                                  "counted_us": step_us,
+                                  "algorithmic_bytes_per_launch": unit_bytes * args.batch_size,
                                   "algorithmic_bytes_per_snapshot": unit_bytes, "survey_formula": sb,
-                                  "frac_of_step_time": unit_bytes * args.batch_size / (dt / args.steps * 1e6) * 1e-3 / HBM_PEAK_GBS}
+                                  "frac_of_step_time": ach / HBM_PEAK_GBS,
+                                  "dominant_kernel": {k: dom[k] for k in ("kernel", "avg_us", "calls_per_step", "gbs", "gbs_kind")}}
             result["kernels"] = [{k: (round(v, 3) if isinstance(v, float) else v) for k, v in r.items()} for r in rows]
+            hs = hbm_side_rates(args)
+            if hs is not None:
+                result["hbm_side_rates"] = hs
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result["parity"] = in_run_parity(args, nb, nc, device)
         log(f"in-run parity vs the oracle: {result['parity']['out_rel']:.2e} (out) {result['parity']['loss_rel']:.2e} (loss) "

@@ -170,9 +170,21 @@ def load(build_if_missing: bool = True) -> C.CDLL:
     if why:
         if not build_if_missing:
             raise RuntimeError(f"{why}; run `python __graft_entry__.py` (build()) first")
-        _build.build_native(diag=diag_build())
+        # One builder at a time: under torchrun every rank finds the stale library at the same moment, and N hipcc runs into the
+        # same build/ and lib/ paths would mix objects.  The first rank to take the lock builds; the others wait and
+        # find a current library when they get it.
+        import fcntl
+        os.makedirs(_build.LIB_DIR, exist_ok=True)
+        with open(os.path.join(_build.LIB_DIR, ".build.lock"), "w") as lock:
+            fcntl.flock(lock, fcntl.LOCK_EX)
+            try:
+                was_missing = "missing" in why
+                if stale():
+                    _build.build_native(diag=diag_build())
+            finally:
+                fcntl.flock(lock, fcntl.LOCK_UN)
         # (a process that already mapped the stale file keeps it under the same name: dlopen a fresh copy of the new build)
-        lib = C.CDLL(path) if "missing" in why else _reopen(path)
+        lib = C.CDLL(path) if was_missing else _reopen(path)
         abi, bid = _version_of(lib)
         if abi != ABI_VERSION or bid != want:
             raise RuntimeError(f"rebuilt {path} still reports abi{abi} build {bid}; expected abi{ABI_VERSION} build {want}")

@@ -509,10 +509,24 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
                                                    unsigned long long* __restrict__ step_counter, long long count,
                                                    double lr, double b1, double b2, double eps, double wd,
                                                    float grad_scale, float* __restrict__ wt, int nb, int nc,
-                                                   unsigned* __restrict__ drop_count, const double* __restrict__ hp) {
+                                                   unsigned* __restrict__ drop_count, const double* __restrict__ hp,
+                                                   const int* __restrict__ mask_node_ptr, double mask_rate,
+                                                   unsigned long long mask_seed, uint8_t* __restrict__ mask_next,
+                                                   const unsigned long long* __restrict__ mask_snap, int update_blocks) {
   __shared__ float s_step_size, s_bc2_sqrt;
   __shared__ int s_drop;
   unsigned long long done = 0ULL;
+  // The device mask of the NEXT step, sampled by the workgroups behind the update's (the data-parallel step's Adam phase; the
+  // single-GPU step does the same in reduce_adam_kernel, k_fused_host.hip).  Its key uses the step count this update leaves
+  // behind: the count as the parameter-gradient launch of this step snapshotted it (mask_snap[0]: nothing has moved it since;
+  // the update blocks increment it at their very end), + 1 unless the step is dropped (the all-reduced gradient's fault mark).
+  if (mask_next && (int)blockIdx.x >= update_blocks) {
+    const int mb = (int)blockIdx.x - update_blocks;
+    const bool dropped = drop_count && g[0] != g[0];
+    mask_sample_graph<256, MASK_WGS_UPDATE>(mask_node_ptr, mask_rate, mask_seed, mask_snap[0] + (dropped ? 0ULL : 1ULL),
+                                            mask_next, mb / MASK_WGS_UPDATE, mb % MASK_WGS_UPDATE);
+    return;
+  }
   if (hp) { lr = hp[0]; b1 = hp[1]; b2 = hp[2]; eps = hp[3]; wd = hp[4]; }      // (gatres_train_step_t.hparams)
   // drop_count != null (the data-parallel Adam phase of the fused path only): a fused launch that faulted marks EVERY
   // gradient entry NaN (gatres_fused_finish) and the all-reduce spreads the mark to all ranks; the step is then dropped on
@@ -539,7 +553,7 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
   __syncthreads();
   // Grid-stride: the launch has at most ADAM_MAX_BLOCKS blocks.  One block per 256 parameters meant 6.6 k tickets on ONE
   // address for gatres_large -- they serialise in the L2 at ~20 ns each and were the whole 146 us of the launch.
-  for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < count; idx += (long long)gridDim.x * 256) {
+  for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < count; idx += (long long)update_blocks * 256) {
   {
     const float pv = p[idx];
     float gv = g[idx] * grad_scale;
@@ -567,7 +581,7 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
     }
   }
   }
-  if (threadIdx.x == 0 && done == (unsigned long long)gridDim.x - 1ULL) {
+  if (threadIdx.x == 0 && done == (unsigned long long)update_blocks - 1ULL) {
     step_counter[1] = 0ULL;
     atomicAdd(&step_counter[0], 1ULL);
   }
@@ -799,22 +813,30 @@ extern "C" int gatres_adam_step(float* params, const float* grads, float* exp_av
   hipLaunchKernelGGL(adam_kernel, dim3(adam_blocks(count)), dim3(256), 0, gatres_stream(stream), params,
                      grads, exp_avg, exp_avg_sq, reinterpret_cast<unsigned long long*>(step_counter),
                      (long long)count, lr, beta1, beta2, eps, weight_decay, grad_scale, (float*)nullptr, 0, 0,
-                     (unsigned*)nullptr, (const double*)nullptr);
+                     (unsigned*)nullptr, (const double*)nullptr, (const int*)nullptr, 0., 0ULL, (uint8_t*)nullptr,
+                     (const unsigned long long*)nullptr, (int)adam_blocks(count));
   return gatres_launch_status();
 }
 
 // (not part of include/gatres.h) Adam with everything gatres_train_step may ask for: hyper-parameters from a device buffer
 // (hp: double[5] {lr, beta1, beta2, eps, weight_decay}, or null), the fused path's transposed conv weights kept current
-// (wt, or null), fault-marked steps dropped and counted (drop_count, or null).
+// (wt, or null), fault-marked steps dropped and counted (drop_count, or null), the next step's device mask sampled by extra
+// workgroups (mask_next, or null; mask_snap: {step count before this update, -}, stable during the launch).
 extern "C" __attribute__((visibility("hidden"))) int gatres_adam_step_ex(float* params, const float* grads, float* exp_avg,
                                    float* exp_avg_sq, uint64_t* step_counter, int64_t count, double lr, double beta1,
                                    double beta2, double eps, double weight_decay, const double* hp, float grad_scale,
-                                   float* wt, int32_t num_blocks, int32_t nc, uint32_t* drop_count, void* stream) {
+                                   float* wt, int32_t num_blocks, int32_t nc, uint32_t* drop_count,
+                                   const int32_t* mask_node_ptr, int32_t mask_graphs, double mask_rate, uint64_t mask_seed,
+                                   uint8_t* mask_next, const uint64_t* mask_snap, void* stream) {
   if (!params || !grads || !exp_avg || !exp_avg_sq || !step_counter || count <= 0) return GATRES_E_BADARG;
-  hipLaunchKernelGGL(adam_kernel, dim3(adam_blocks(count)), dim3(256), 0, gatres_stream(stream), params,
+  const bool sample = mask_next && mask_node_ptr && mask_snap && mask_graphs > 0;
+  const unsigned ub = adam_blocks(count);
+  hipLaunchKernelGGL(adam_kernel, dim3(ub + (sample ? (unsigned)mask_graphs * MASK_WGS_UPDATE : 0u)), dim3(256), 0,
+                     gatres_stream(stream), params,
                      grads, exp_avg, exp_avg_sq, reinterpret_cast<unsigned long long*>(step_counter),
                      (long long)count, lr, beta1, beta2, eps, weight_decay, grad_scale, wt, (int)num_blocks, (int)nc,
-                     drop_count, hp);
+                     drop_count, hp, sample ? mask_node_ptr : nullptr, mask_rate, (unsigned long long)mask_seed,
+                     sample ? mask_next : nullptr, reinterpret_cast<const unsigned long long*>(mask_snap), (int)ub);
   return gatres_launch_status();
 }
 

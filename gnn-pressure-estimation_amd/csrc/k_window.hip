@@ -349,6 +349,9 @@ __global__ __launch_bounds__(THREADS) void gatres_window_kernel(const FusedArgs 
 #pragma unroll
       for (int k = 0; k < (int)(sizeof(FwdRec) / 4); ++k)
         __hip_atomic_store(myrec + k, src[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      // the barrier below is `s_waitcnt lgkmcnt(0); s_barrier` on gfx950 -- no vmcnt: drain the record's stores here, or the
+      // other waves' scalar loads (rec_published) may still find the previous launch's record in L2
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     }  // ---- (end of the prologue's scope: the block loop below sees the record only)
     __syncthreads();           // export flags and the record are published
@@ -814,6 +817,7 @@ __global__ __launch_bounds__(THREADS) void gatres_window_kernel(const FusedArgs 
 #pragma unroll
       for (int k = 0; k < (int)(sizeof(BwdRec) / 4); ++k)
         __hip_atomic_store(myrec + GATRES_UREC_WORDS / 2 + k, src[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (as in the forward prologue: the barrier does not drain stores)
     }
     }  // ---- (end of the prologue's scope: the block loop below sees the record only)
     __syncthreads();           // export flags and the record are published

@@ -24,7 +24,7 @@ from .graph_plan import GraphPlan
 PHASE_MASK, PHASE_FORWARD, PHASE_BACKWARD, PHASE_ADAM = 1, 2, 4, 8
 PART_FIRST, PART_LAST, PART_REDUCE = 1, 2, 4
 FLAG_PER_OP, FLAG_WT_VALID, FLAG_GRADS_DEFERRED, FLAG_GRADS_ONLY, FLAG_MASK_NEXT = 1, 2, 4, 8, 16
-MAX_CACHED_GRAPHS = 40          # (bound batches: one captured step per batch buffer and transposed-weights state)
+MAX_CACHED_GRAPHS = 40          # floor of the captured-step cache; bind_batches() sizes it from the number of bound batches
 
 
 class _TrainStepC(C.Structure):
@@ -74,6 +74,10 @@ class GATResTrainer:
             self.exp_avg, self.exp_avg_sq = _share_state_with.exp_avg, _share_state_with.exp_avg_sq
             self.step_counter = _share_state_with.step_counter
             self.hp = _share_state_with.hp
+            # ... and ONE host copy of the hyper-parameters beside the one device buffer: set_hparams() on either trainer
+            # is seen by both (a sibling's set_lr left the parent's host copy stale, and the parent's next
+            # set_hparams(weight_decay=...) pushed the old lr back)
+            self.hparams = _share_state_with.hparams
         else:
             self.exp_avg = torch.zeros(self.P, **f32)
             self.exp_avg_sq = torch.zeros(self.P, **f32)
@@ -108,7 +112,12 @@ class GATResTrainer:
             dp.broadcast_params_(params, src=0, group=process_group)      # identical replicas, whatever each rank initialised
         self.reducer = dp.BucketedAllReduce(self.grads, process_group, force=force_collective_path) if self.split else None
         self.blocks_per_bucket = int(blocks_per_bucket)
-        self.fused_buckets = 2                       # gradient buckets of the fused path's data-parallel step (1: one piece)
+        # Gradient buckets of the fused path's data-parallel step.  1 (default): the single-GPU step's own launches (window
+        # kernel, parameter gradients, slab sum) + ONE all-reduce of the flat gradient + the Adam launch.  2: the backward chain,
+        # then the parameter gradients of the upper and of the lower blocks as range launches, the first bucket on the wire
+        # under the second launch (DESIGN.md section 5 has the measured cost of either form on one GPU).
+        self.fused_buckets = 1
+        self._max_graphs = MAX_CACHED_GRAPHS
         # Multi-rank steps run as EAGER launch sequences unless GATRES_DP_GRAPH=1: a captured step would hold the RCCL
         # all-reduce, which has only ever been captured with a one-rank group here (no multi-GPU box is reachable), and
         # eager costs nothing on this path (one-rank nccl group, gatres_small bs 32: 0.428 ms/step eager vs 0.432 captured;
@@ -126,13 +135,48 @@ class GATResTrainer:
         # self.mask always is the mask of the step that ran last.  _mask_sig: what the spare buffer's mask was sampled for.
         # (only where the parameter gradients are a launch of their own: it leaves the step count / fault snapshot the
         #  sampling tail reads -- batches that leave CUs free use consumer workgroups and keep the sampler's own launch)
-        self._mask_next = bool(self.fused and not self.split and self.node_ptr is not None
+        # (the data-parallel step -- one gradient bucket -- does the same from its Adam launch, gatres_adam_step_ex)
+        self._mask_next = bool(self.fused and self.node_ptr is not None
                                and self.lib.gatres_fused_finish_folds(model._cmodel_ref(), self.plan.ref())
                                and not os.environ.get("GATRES_NO_MASK_NEXT"))
         self._mask_sig = None
         self._bound: list = []                      # bind_batches(): (x, y) tensors the captured steps read directly
         # the fused path's parameter gradients can be formed range by range (a bucket's all-reduce starts in between)
         self._ranges = bool(self.fused and self.lib.gatres_fused_finish_folds(model._cmodel_ref(), self.plan.ref()))
+        self._faults_seen = 0
+        self._warn_if_the_chip_is_not_ours()
+
+    def _warn_if_the_chip_is_not_ours(self) -> None:
+        """A split launch (several workgroups per snapshot, spin-waiting on each other's granules) needs EVERY workgroup of
+        its grid resident at once, one per CU.  The native library sizes the split from the device's CU count; what it cannot
+        see is a CU mask or other work on the device.  A partner that never gets a CU costs a DROPPED step (counted in
+        ``fault_count``), never a wrong one -- but a trainer that silently skips updates is not what anyone wants: say so at
+        construction, and let ``check_no_dropped_steps()`` (called by ``fit_epoch`` and by bench.py) turn drops into an error."""
+        if not self.fused:
+            return
+        cus = int(self.lib.gatres_fused_cus_per_segment(self.model._cmodel_ref(), self.plan.ref()))
+        if cus < 2:
+            return
+        need = ((self.plan.num_segments + 7) // 8) * 8 * cus
+        have = int(torch.cuda.get_device_properties(self.device).multi_processor_count)
+        masked = [k for k in ("HSA_CU_MASK", "ROC_GLOBAL_CU_MASK") if os.environ.get(k)]
+        if need > have or masked:
+            import warnings
+            warnings.warn(f"GATResTrainer: the per-snapshot kernel launches {need} co-resident workgroups (one per CU, {cus} per "
+                          f"snapshot) on a device that reports {have} CUs"
+                          + (f" under {', '.join(masked)}" if masked else "") +
+                          "; workgroups that cannot be resident together time out and the step is DROPPED (fault_count). "
+                          "Set GATRES_FUSED_SPLIT to fewer parts per snapshot or use fused=False.", RuntimeWarning, stacklevel=3)
+
+    def check_no_dropped_steps(self) -> None:
+        """Raise if any step was dropped since the last call (a split launch that timed out waiting for a partner workgroup,
+        or a data-parallel step whose all-reduced gradient carried a fault mark).  Synchronises."""
+        n = self.fault_count + self.dropped_steps
+        new, self._faults_seen = n - self._faults_seen, n
+        if new > 0:
+            raise RuntimeError(f"{new} training step(s) were DROPPED (no update): a workgroup of the per-snapshot kernel was not "
+                               f"co-resident with its partners (is the GPU shared, partitioned or CU-masked?) or a replica "
+                               f"faulted; fault_count={self.fault_count}, dropped_steps={self.dropped_steps}")
 
     # ------------------------------------------------------------------------------------------
     def _hp_list(self):
@@ -204,9 +248,7 @@ class GATResTrainer:
             else:
                 raise KeyError(k)
         if changed:
-            self._push_hparams()
-            for t in self._siblings.values():          # (they share the buffer; keep their host copies in step)
-                t.hparams = dict(self.hparams)
+            self._push_hparams()                       # (siblings share both the dict and the device buffer)
 
     def _graph_key(self, what, device_mask: bool, wt_valid: bool) -> tuple:
         # (no hyper-parameter in here: the kernels read them from self.hp; which of the two mask buffers is current is)
@@ -327,7 +369,7 @@ class GATResTrainer:
                     self.model._cmodel_ref(), C.byref(self._gstruct), self.model.flat_parameters.data_ptr(),
                     self.scratch.data_ptr(), _native.current_stream(self.device)), "gatres_fused_prepare_backward")
             self._graphs[key] = g
-            while len(self._graphs) > MAX_CACHED_GRAPHS:
+            while len(self._graphs) > self._max_graphs:
                 torch.cuda.synchronize(self.device)      # (its last replay may still be in flight on the stream)
                 self._graphs.popitem(last=False)
         else:
@@ -338,7 +380,11 @@ class GATResTrainer:
         g.replay()
 
     # ---- the multi-rank step: backward pieces | bucketed all-reduce | Adam, as ONE launch sequence / hipGraph ---------
-    def _backward_pieces(self, device_mask: bool, wt_valid: bool, premasked: bool = False):
+    def _one_piece(self) -> bool:
+        """The fused data-parallel step as ONE gradient bucket (the single-GPU step's own launches in front of the all-reduce)."""
+        return self.fused and (not self._ranges or self.model.num_blocks < 2 or self.fused_buckets < 2)
+
+    def _backward_pieces(self, device_mask: bool, wt_valid: bool, premasked: bool = False, batch=None, flags: int = 0):
         """Pieces for ``dp.run_data_parallel_step``.  Fused path (gatres_small): one piece -- mask, forward, loss and the
         whole backward are a single launch whose gradient exists only after the slab reduction that ends it.  Per-op
         path (gatres_large, large graphs): forward, then one piece per ``blocks_per_bucket`` blocks in reverse order,
@@ -346,9 +392,11 @@ class GATResTrainer:
         if self.fused:
             m = self.model
             head = (0 if premasked else PHASE_MASK) | PHASE_FORWARD | PHASE_BACKWARD
-            if not self._ranges or m.num_blocks < 2 or self.fused_buckets < 2:
+            if self._one_piece():
+                # (flags: GATRES_FLAG_MASK_NEXT makes the parameter-gradient launch leave the step-count snapshot that the
+                #  Adam launch's sampling tail reads)
                 def whole():
-                    self._enqueue(head, device_mask, wt_valid)
+                    self._enqueue(head, device_mask, wt_valid, flags=flags, batch=batch)
                     return 0, self.P
                 return [whole]
             # Two pieces: the backward chain + the parameter gradients of the UPPER blocks (whose bucket closes the flat
@@ -359,7 +407,7 @@ class GATResTrainer:
             cut = 2 * m.nc + k * (9 * m.nc + 4 * m.nc * m.nc)
 
             def upper():
-                self._enqueue(head, device_mask, wt_valid, flags=FLAG_GRADS_DEFERRED)
+                self._enqueue(head, device_mask, wt_valid, flags=FLAG_GRADS_DEFERRED, batch=batch)
                 self._enqueue(PHASE_BACKWARD, device_mask, flags=FLAG_GRADS_ONLY, block_lo=k, block_hi=m.num_blocks)
                 return cut, self.P
 
@@ -369,13 +417,14 @@ class GATResTrainer:
             return [upper, lower]
         m = self.model
         pieces = []
+        bx = self.x if batch is None else batch[0]
         for k, (b_hi, b_lo, lo, hi) in enumerate(dp.block_buckets(m.num_blocks, m.nc, self.blocks_per_bucket)):
             def piece(k=k, b_hi=b_hi, b_lo=b_lo, lo=lo, hi=hi):
                 if k == 0:
-                    self._enqueue((0 if premasked else PHASE_MASK) | PHASE_FORWARD, device_mask)
+                    self._enqueue((0 if premasked else PHASE_MASK) | PHASE_FORWARD, device_mask, batch=batch)
                 flags = PART_REDUCE | (PART_FIRST if b_hi == m.num_blocks else 0) | (PART_LAST if b_lo == 0 else 0)
                 _native.check(self.lib.gatres_model_backward_per_op_part(
-                    m._cmodel_ref(), C.byref(self._gstruct), m.flat_parameters.data_ptr(), self.x.data_ptr(),
+                    m._cmodel_ref(), C.byref(self._gstruct), m.flat_parameters.data_ptr(), bx.data_ptr(),
                     self.mask.data_ptr(), self.g_out.data_ptr(), self.saved.data_ptr(), self.scratch.data_ptr(),
                     self.grads.data_ptr(), None, b_hi, b_lo, flags, _native.current_stream(self.device)),
                     "gatres_model_backward_per_op_part")
@@ -383,17 +432,29 @@ class GATResTrainer:
             pieces.append(piece)
         return pieces
 
-    def _run_split(self, device_mask: bool, premasked: bool = False) -> None:
+    def _run_split(self, device_mask: bool, premasked: bool = False, batch=None, slot=None, ahead: bool = True) -> None:
+        """The data-parallel step: backward pieces | bucketed all-reduce | Adam.  With one gradient bucket on the fused path
+        this is the single-GPU step's launch sequence with the slab sum and the update as two launches around ONE all-reduce:
+        the batch is read in place (``batch``), and the Adam launch samples the next step's mask (``ahead``) exactly as the
+        single-GPU update launch does.  ahead=False: the caller samples every step's mask itself (staged batches)."""
         # (fused path: the Adam-only phase refreshes scratch's transposed conv weights like the fused Adam pass does)
         wt_valid = self.fused and self._wt_current()
+        ahead = bool(ahead and self._mask_next and device_mask and self._one_piece())
+        if ahead and not premasked and self._take_mask_ahead():
+            premasked = True                       # the previous step's Adam launch has sampled this step's mask already
+        elif not ahead:
+            self._mask_sig = None
+        flags = FLAG_MASK_NEXT if ahead else 0
         try:
-            self._replay(self._graph_key("split-premasked" if premasked else "split", device_mask, wt_valid),
-                         lambda: dp.run_data_parallel_step(self._backward_pieces(device_mask, wt_valid, premasked), self.reducer,
-                                                           lambda: self._enqueue(PHASE_ADAM, device_mask)), wt_valid)
+            self._replay(self._graph_key(("split", premasked, flags, slot), device_mask, wt_valid),
+                         lambda: dp.run_data_parallel_step(
+                             self._backward_pieces(device_mask, wt_valid, premasked, batch, flags), self.reducer,
+                             lambda: self._enqueue(PHASE_ADAM, device_mask, flags=flags)), wt_valid)
         finally:
             self._count_native_update()
             if self.fused:
                 self._wt_sig = self._param_signature()
+            self._mask_sig = self._mask_key() if ahead else None
 
     # ------------------------------------------------------------------------------------------
     def load_batch(self, x: torch.Tensor, y: torch.Tensor, mask: Optional[torch.Tensor] = None) -> None:
@@ -489,7 +550,7 @@ class GATResTrainer:
             self.node_ptr.data_ptr(), self.num_graphs, self.mask_rate, self.seed, self.step_counter.data_ptr(),
             self.mask.data_ptr(), _native.current_stream(self.device)), "gatres_stage_rows_mask")
         if self.split:
-            self._run_split(True, premasked=True)
+            self._run_split(True, premasked=True, ahead=False)
         else:
             self._run_premasked(ahead=False)
         return True
@@ -498,7 +559,7 @@ class GATResTrainer:
         """Reference-shaped call: one iteration of train.py:159-190.  Returns the (device) loss tensor."""
         if mask is None and self._stage_with_mask(x, y):                        # (the mask of this step is in place)
             if self.split:
-                self._run_split(True, premasked=True)
+                self._run_split(True, premasked=True, ahead=False)
             else:
                 self._run_premasked(ahead=False)
             return self.loss
@@ -523,11 +584,12 @@ class GATResTrainer:
             self._mask_sig = self._mask_key() if ahead else None
 
     # ---- bound batches: the captured step reads the caller's buffers, nothing is copied -------------------------------------
-    def bind_batches(self, xs, ys=None) -> int:
+    def bind_batches(self, xs, ys=None, precapture: bool = True) -> int:
         """Register device-resident batches (flat fp32 ``[N]`` tensors; ``ys`` defaults to ``xs``: y == x before masking,
         train.py:162-166) that ``step_bound(i)`` then trains on IN PLACE: the kernels mask x on the fly and never write it,
-        so no staging copy is needed -- one captured step per buffer.  The trainer keeps the tensors alive; do not resize
-        them.  Returns the number of bound batches."""
+        so no staging copy is needed -- one captured step per buffer and mask-buffer orientation.  ``precapture``: capture
+        every one of those steps NOW (``precapture_bound()``), so that no ``step_bound`` call ever pays for a capture.  The
+        trainer keeps the tensors alive; do not resize them.  Returns the number of bound batches."""
         ys = xs if ys is None else ys
         bound = []
         for x, y in zip(xs, ys):
@@ -540,7 +602,64 @@ class GATResTrainer:
             torch.cuda.synchronize(self.device)
             self._graphs.clear()
         self._bound = bound
+        # two captured steps per bound batch (the two mask buffers take turns) + the first-step variants + whatever else this
+        # trainer replays: the cache must hold them all, or FIFO eviction makes every step pay for a capture
+        self._max_graphs = max(MAX_CACHED_GRAPHS, 2 * len(bound) + 16)
+        if precapture:
+            self.precapture_bound()
         return len(bound)
+
+    def precapture_bound(self) -> int:
+        """Capture the steady-state step of every (bound batch, mask-buffer orientation) pair by RUNNING steps, then put the
+        training state back exactly where it was (parameters, Adam moments, step count) -- with the transposed weights current
+        and the first step's mask sampled ahead, so that the first real ``step_bound`` call already replays a steady-state
+        graph.  Nothing is captured inside a caller's timed region afterwards (bench.py's first timed block held
+        four captures).  Under data parallelism every rank runs the same number of steps (the collectives match).  Returns the
+        number of captured graphs."""
+        if not (self.use_graph and self._bound and self.node_ptr is not None):
+            return len(self._graphs)
+        dev = self.device
+        torch.cuda.synchronize(dev)
+        keep = [t.clone() for t in (self.step_counter, self.model.flat_parameters, self.exp_avg, self.exp_avg_sq, self.loss)]
+        n = len(self._bound)
+        # (mask-ahead: the two mask buffers take turns, so a batch has two steady-state graphs; without it, one)
+        ahead_ok = self._mask_next and (not self.split or self._one_piece())
+        ptrs = (self.mask.data_ptr(), self._mask_spare.data_ptr()) if ahead_ok else (None,)
+        need = {(i, p) for i in range(n) for p in ptrs}
+        steps = 0
+        while need and steps < 4 * n + 8:
+            # the step about to run is a steady-state one iff the weights' transposes are current and (mask-ahead) a mask was
+            # sampled ahead; it then trains with the (current) spare buffer as its mask
+            steady = (not self.fused) or self._wt_current()
+            ptr = None
+            if ahead_ok:
+                steady = steady and self._mask_sig is not None and self._mask_sig == self._mask_key()
+                ptr = self._mask_spare.data_ptr() if steady else None
+            i = next((j for j in range(n) if (j, ptr) in need), 0)
+            self.step_bound(i)
+            if steady:
+                need.discard((i, ptr))
+            steps += 1
+        torch.cuda.synchronize(dev)
+        for dst, src in zip((self.step_counter, self.model.flat_parameters, self.exp_avg, self.exp_avg_sq, self.loss), keep):
+            dst.copy_(src)
+        self._mask_sig = None
+        if self.fused:
+            # scratch holds the transposes of the LAST pre-capture step's weights: re-derive them for the restored parameters
+            _native.check(self.lib.gatres_fused_prepare_backward(
+                self.model._cmodel_ref(), C.byref(self._gstruct), self.model.flat_parameters.data_ptr(),
+                self.scratch.data_ptr(), _native.current_stream(dev)), "gatres_fused_prepare_backward")
+            self._count_native_update()                # (siblings / other trainers of this model: their copies are stale too)
+            self._wt_sig = self._param_signature()
+        if ahead_ok:
+            # the first step's mask, sampled where the previous step's update launch would have left it (same key: same bits)
+            _native.check(self.lib.gatres_mask_generate(
+                self.node_ptr.data_ptr(), self.num_graphs, self.mask_rate, self.seed, self.step_counter.data_ptr(),
+                self._mask_spare.data_ptr(), _native.current_stream(dev)), "gatres_mask_generate")
+            self._mask_sig = self._mask_key()
+        torch.cuda.synchronize(dev)
+        self._faults_seen = self.fault_count + self.dropped_steps
+        return len(self._graphs)
 
     def step_bound(self, i: int) -> torch.Tensor:
         """One optimisation step (train.py:159-190) on bound batch ``i`` with a device-sampled mask.  On the single-GPU fused
@@ -550,8 +669,9 @@ class GATResTrainer:
         x, y = self._bound[i]
         if self.node_ptr is None:
             raise ValueError("device mask sampling needs nodes_per_graph at construction")
-        if self.split:                     # (data-parallel step: staged like any other batch)
-            return self.step(x, y)
+        if self.split:                     # (data-parallel step: the same launches around the all-reduce, batch read in place)
+            self._run_split(True, batch=(x, y), slot=i)
+            return self.loss
         self._run(PHASE_MASK | PHASE_FORWARD | PHASE_BACKWARD | PHASE_ADAM, True, batch=(x, y), slot=i)
         return self.loss
 
@@ -581,7 +701,7 @@ class GATResTrainer:
                               _share_state_with=self)
             t.seed = self.seed
             self._siblings[num_graphs] = t
-        t.hparams, t.mask_rate = dict(self.hparams), self.mask_rate
+        t.mask_rate = self.mask_rate
         return t
 
     def fit_epoch(self, store, batch_size: Optional[int] = None, shuffle: bool = True, drop_last: bool = False,

@@ -185,6 +185,7 @@ def test_fused_data_parallel_step_has_two_buckets_and_equals_the_plain_step(pkg,
         for split in (False, True):
             model, p, tr, ei = _trainer(pkg, oracle, seed=2, use_graph=use_graph, force_collective_path=split)
             tr.seed = 77
+            tr.fused_buckets = 2                 # (the default is ONE bucket since round 5: the test below)
             assert tr.split == split
             losses = []
             for it in range(3):
@@ -264,3 +265,122 @@ def test_mask_sampled_by_the_update_launch_equals_the_samplers_own_launch(pkg, o
         assert torch.equal(a[0], b[0]), f"mask of step {k}"
         assert a[1] == b[1], f"loss of step {k}"
         assert torch.equal(a[2], b[2]), f"parameters after step {k}"
+
+
+def test_data_parallel_step_is_the_single_gpu_step_around_one_all_reduce(pkg, oracle):
+    """Round 5: the multi-rank step of the fused path is the single-GPU step's own launches -- window
+    kernel, parameter gradients, slab sum -- then ONE all-reduce of the flat gradient and the Adam launch, which samples the
+    next step's mask exactly as the single-GPU update launch does; bound batches are read in place.  At world size 1 the
+    sequence gives the plain step bit for bit (masks, losses, parameters), eager and captured, and from the second step on it
+    holds no sampler launch."""
+    from gnn_pressure_estimation_amd import train_step as TS
+    snaps = pkg.wdn_synth.make_snapshots(3 * BS, NODES, seed=18).cuda()
+    batches = [snaps[i * BS:(i + 1) * BS].reshape(-1).contiguous() for i in range(3)]
+    for use_graph in (False, True):
+        res = []
+        for split in (False, True):
+            model, p, tr, ei = _trainer(pkg, oracle, seed=4, use_graph=use_graph, force_collective_path=split)
+            tr.seed = 55
+            assert tr.split == split and tr.fused_buckets == 1 and tr._mask_next
+            tr.bind_batches(batches)
+            hist = []
+            for it in range(7):
+                loss = float(tr.step_bound(it % 3))
+                hist.append((loss, tr.mask.clone(), model.flat_parameters.clone()))
+                if split:
+                    assert tr.reducer.last_buckets == [(0, tr.P)], tr.reducer.last_buckets
+                    assert tr._mask_sig is not None            # the Adam launch sampled the next step's mask
+            if split and use_graph:
+                keys = [k[0] for k in tr._graphs if isinstance(k[0], tuple) and k[0][0] == "split"]
+                # one first-step graph (it still runs the sampler's launch), then premasked steady-state graphs only:
+                # two per bound batch (the mask buffers take turns)
+                assert sum(1 for k in keys if not k[1]) <= 1 and sum(1 for k in keys if k[1] and k[2] & TS.FLAG_MASK_NEXT) == 6, keys
+            assert tr.optimizer_step == 7 and tr.fault_count == 0 and tr.dropped_steps == 0
+            res.append(hist)
+        for k, (a, b) in enumerate(zip(*res)):
+            assert a[0] == b[0], (use_graph, k)
+            assert torch.equal(a[1], b[1]) and torch.equal(a[2], b[2]), (use_graph, k)
+
+
+def test_bound_steps_are_captured_at_bind_time(pkg, oracle):
+    """Round 5: ``bind_batches`` captures the steady-state step of every (batch, mask buffer) pair by
+    running steps and rolling the training state back, so no ``step_bound`` call ever holds a capture -- whatever the order
+    of the batches -- and the run is bit-identical to one whose graphs are captured lazily."""
+    snaps = pkg.wdn_synth.make_snapshots(4 * BS, NODES, seed=41).cuda()
+    batches = [snaps[i * BS:(i + 1) * BS].reshape(-1).contiguous() for i in range(4)]
+    order = [0, 1, 2, 3, 0, 0, 1, 3, 2, 2, 1]                 # (both mask buffers meet every batch)
+    runs = []
+    for pre in (True, False):
+        model, p, tr, ei = _trainer(pkg, oracle, seed=6, use_graph=True)
+        before = model.flat_parameters.clone()
+        tr.bind_batches(batches, precapture=pre)
+        if pre:
+            assert tr.num_captured_graphs >= 2 * len(batches)
+            assert torch.equal(model.flat_parameters, before) and tr.optimizer_step == 0
+            assert float(tr.exp_avg.abs().max()) == 0.0 and float(tr.exp_avg_sq.abs().max()) == 0.0
+        n0 = tr.num_captured_graphs
+        hist = []
+        for i in order:
+            hist.append((float(tr.step_bound(i)), tr.mask.clone(), model.flat_parameters.clone()))
+        if pre:
+            assert tr.num_captured_graphs == n0, (n0, tr.num_captured_graphs)      # nothing was captured by a step
+        assert tr.optimizer_step == len(order) and tr.fault_count == 0
+        tr.check_no_dropped_steps()
+        runs.append(hist)
+    for k, (a, b) in enumerate(zip(*runs)):
+        assert a[0] == b[0] and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2]), k
+
+
+def test_alternating_launch_kinds_on_one_scratch_buffer(pkg, oracle):
+    """the window kernel's prologue publishes the part's geometry record to the other waves through L2
+    (tid 0 stores, barrier, scalar loads).  A forward-only launch, a training launch and a backward-only launch write
+    DIFFERENT records into the same words (the ReLU-mask tables exist only in training launches), so a stale record shows as
+    wrong LDS offsets.  Alternate the three kinds on ONE freshly zeroed scratch buffer, starting with the first launch ever
+    into it, and hold every result to kernels that do not share that state."""
+    bs = BS
+    x, y, ei, mask = pkg.wdn_synth.make_batch(bs, NODES, PIPES)
+    dx, dy, dei, dmask = x.cuda(), y.cuda(), ei.cuda(), mask.cuda()
+    mf, p = build(pkg, oracle, NB, NC, seed=9, fused=True)
+    mp, _ = build(pkg, oracle, NB, NC, seed=9, fused=False)            # per-op kernels: no record, no LDS windows
+    with torch.no_grad():
+        first = mf(dx.reshape(-1, 1), dei)                             # the FIRST launch into this scratch: forward-only
+        assert torch.equal(first, mp(dx.reshape(-1, 1), dei))
+    tr = pkg.GATResTrainer(mf, dei, NODES * bs, nodes_per_graph=[NODES] * bs, use_graph=False)
+    ref_model, _ = build(pkg, oracle, NB, NC, seed=9, fused=True)      # a trainer that only ever runs training launches
+    ref = pkg.GATResTrainer(ref_model, dei, NODES * bs, nodes_per_graph=[NODES] * bs, use_graph=False)
+    assert tr.scratch.data_ptr() == mf._scratch_for(tr.plan).data_ptr()
+    for it in range(3):
+        la, lb = float(tr.step(dx, dy, dmask)), float(ref.step(dx, dy, dmask))          # training launch
+        assert la == lb and torch.equal(mf.flat_parameters, ref_model.flat_parameters), it
+        load = {k: v.detach().clone() for k, v in mf.state_dict().items()}
+        mp.load_state_dict(load)
+        with torch.no_grad():                                          # forward-only launch (other record: no mask tables)
+            assert torch.equal(mf(dx.reshape(-1, 1), dei), mp(dx.reshape(-1, 1), dei)), it
+        xin = dx.clone().reshape(-1, 1); xin[dmask.bool()] = 0
+        of = mf(xin, dei)                                              # forward with saved activations, then a
+        op = mp(xin, dei)                                              # backward-only launch
+        assert torch.equal(of, op), it
+        g = torch.randn(of.shape, generator=torch.Generator().manual_seed(it)).cuda()
+        mf.zero_grad(); mp.zero_grad()
+        of.backward(g); op.backward(g)
+        gf = torch.cat([q.grad.reshape(-1) for q in mf.parameters()])
+        gp = torch.cat([q.grad.reshape(-1) for q in mp.parameters()])
+        assert relerr(gf, gp) < 2e-5, (it, relerr(gf, gp))
+    assert tr.fault_count == 0
+
+
+def test_mask_next_is_refused_where_it_cannot_be_honoured(pkg, oracle, monkeypatch):
+    """GATRES_FLAG_MASK_NEXT on a configuration whose parameter gradients run on consumer workgroups (no step-count
+    snapshot for the sampling tail) used to be dropped silently; it is an error now, raised before anything is enqueued."""
+    from gnn_pressure_estimation_amd import train_step as TS
+    model, p, tr, ei = _trainer(pkg, oracle, bs=8, use_graph=False)      # bs 8: CUs are left, consumers form the gradients
+    if tr._mask_next:
+        pytest.skip("this configuration folds the update: nothing to refuse")
+    y = pkg.wdn_synth.make_snapshots(8, NODES, seed=2).reshape(-1).cuda()
+    tr.load_batch(y, y)
+    before = tr.optimizer_step
+    with pytest.raises(RuntimeError):
+        tr._enqueue(TS.PHASE_MASK | TS.PHASE_FORWARD | TS.PHASE_BACKWARD | TS.PHASE_ADAM, True, flags=TS.FLAG_MASK_NEXT)
+    torch.cuda.synchronize()
+    assert tr.optimizer_step == before
+    assert float(tr.step(y, y)) == float(tr.loss)                        # the trainer itself never asks for it here
