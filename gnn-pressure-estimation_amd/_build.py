@@ -18,7 +18,7 @@ OBJ_DIR = os.path.join(PKG_DIR, "build")
 LIB_PATH = os.path.join(LIB_DIR, "libgatres_hip.so")
 ARCH = "gfx950"
 
-SOURCES = ["k_window.hip", "k_fused_whole.hip", "k_fused_host.hip", "k_aggregate.hip", "k_proj.hip", "k_misc.hip", "graph_plan.hip",
+SOURCES = ["k_window.hip", "k_fused_whole.hip", "k_fused_host.hip", "k_aggregate.hip", "k_proj.hip", "k_misc.hip", "k_blocked.hip", "graph_plan.hip",
            "model_driver.hip", "train_driver.hip"]
 
 

@@ -97,6 +97,10 @@ SIGNATURES = {
     "gatres_t_proj_attn_fwd": (C.c_int, [_P] * 7 + [C.c_int] * 5 + [_P]),
     "gatres_t_proj_bwd_dx": (C.c_int, [_P] * 5 + [C.c_int] * 4 + [_P]),
     "gatres_t_proj_bwd_dw": (C.c_int, [_P] * 3 + [C.c_int, _I64, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
+    "gatres_blocked_supported": (C.c_int, [_MP, _GP]),
+    "gatres_bf16_agg_proj_fwd": (C.c_int, [_GP] + [_P] * 12 + [_I32, _P]),
+    "gatres_bf16_mean_proj_fwd": (C.c_int, [_GP] + [_P] * 9 + [_I32, _P]),
+    "gatres_bf16_src_dx_bwd": (C.c_int, [_GP] + [_P] * 12 + [_I32, _I32, _P]),
     "gatres_param_count": (_I64, [_I32, _I32]),
     "gatres_saved_floats": (_I64, [_MP, _GP]),
     "gatres_scratch_floats": (_I64, [_MP, _GP]),
@@ -125,7 +129,7 @@ SIGNATURES = {
 }
 
 
-ABI_VERSION = 4                # GATRES_ABI_VERSION of include/gatres.h
+ABI_VERSION = 5                # GATRES_ABI_VERSION of include/gatres.h
 
 
 def diag_build() -> bool:

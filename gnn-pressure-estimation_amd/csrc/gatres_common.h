@@ -21,7 +21,7 @@
 
 // Switches of the library, read from the environment ONCE (first use) -- never on a launch path.  A process that changes
 // the environment afterwards (the tests do) calls gatres_knobs_reload().
-// PRODUCT switches (ten; each one selects a path that some plan / model takes on its own, so each has a test that forces
+// PRODUCT switches (eleven; each one selects a path that some plan / model takes on its own, so each has a test that forces
 // it -- tests named in DESIGN.md section 8):
 struct gatres_knobs_t {
   int fused_split;            // GATRES_FUSED_SPLIT = 1 .. 8: workgroups per snapshot (0: automatic)
@@ -35,6 +35,9 @@ struct gatres_knobs_t {
   int dw_1d;                  // GATRES_DW_1D: bf16 weight gradients, one matrix per workgroup (what narrow models get)
   int side_stream;            // GATRES_SIDE_STREAM = 0 | 1: the per-op backward's parameter-gradient launches never / always on
                               // the library's side stream (-1, unset: where it was measured faster -- fp32, nc >= 128)
+  int blocked;                // GATRES_BLOCKED: wide bf16 models (nc = 128) take the blocked launches of k_blocked.hip (a sparse
+                              // stage + the projection behind it as one kernel) where the plan allows; default off: bit-identical
+                              // to the per-op pairs, measured 5 - 20 % slower than them (profiles/r05_blocked_probe.txt)
   // DIAGNOSTIC build only (fixed at the defaults in the product build): measured-and-lost alternatives, tuning sweeps and the
   // switches that give WRONG results
   int agg_wide_offsets;       // GATRES_AGG_WIDE_OFFSETS

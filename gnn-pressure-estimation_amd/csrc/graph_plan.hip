@@ -76,16 +76,23 @@ extern "C" int gatres_graph_flags_host(const int64_t* ei, int64_t E, int64_t N, 
   if ((!ei && E > 0) || !flags_out || E < 0 || N <= 0) return GATRES_E_BADARG;
   std::vector<uint64_t> key;
   key.reserve((size_t)E);
+  std::vector<int32_t> indeg((size_t)N, 0), outdeg((size_t)N, 0);
   for (int64_t e = 0; e < E; ++e) {
     const int64_t s = ei[e], d = ei[E + e];
     if (s < 0 || s >= N || d < 0 || d >= N) return GATRES_E_GRAPH;
     if (s != d) key.push_back(((uint64_t)s << 32) | (uint64_t)d);
+    ++indeg[(size_t)d]; ++outdeg[(size_t)s];
   }
+  // every row of every CSR of the plan (GATConv: the edges without self loops + one; SimpleConv: all of them; and the
+  // transposes) has at most 32 entries: the blocked kernels' rows are walked by their own lane group (k_blocked.hip)
+  int32_t most = 0;
+  for (int64_t i = 0; i < N; ++i) most = std::max(most, std::max(indeg[(size_t)i], outdeg[(size_t)i]));
+  const bool le32 = most + 1 <= 32;
   std::sort(key.begin(), key.end());
   bool sym = true;
   for (size_t i = 0; i < key.size() && sym; ++i)
     sym = std::binary_search(key.begin(), key.end(), (key[i] << 32) | (key[i] >> 32));
-  *flags_out = sym ? GATRES_GRAPH_SYMMETRIC : 0;
+  *flags_out = (sym ? GATRES_GRAPH_SYMMETRIC : 0) | (le32 ? GATRES_GRAPH_DEG_LE32 : 0);
   return 0;
 }
 

@@ -32,6 +32,7 @@ void read_knobs(gatres_knobs_t* k) {
   k->no_proj_lds = env_flag("GATRES_NO_PROJ_LDS");
   k->dw_1d = env_flag("GATRES_DW_1D");
   k->side_stream = env_int("GATRES_SIDE_STREAM", -1);
+  k->blocked = env_flag("GATRES_BLOCKED");
   // diagnostic build only
   k->agg_wide_offsets = 0; k->fused_threads = 1024; k->fused_no_window = 0; k->fused_prefer_consumers = 0;
   k->fused_consumers_cap = 2; k->fused_nocache = 0; k->fused_wide = 0; k->fused_no_keep = 0; k->fused_heartbeat = 0;

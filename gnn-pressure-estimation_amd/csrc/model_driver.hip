@@ -97,6 +97,10 @@ extern "C" int gatres_model_forward_per_op(const gatres_model_t* m, const gatres
   const int64_t w = 2LL * nc * nc;
   if (dt == GATRES_DTYPE_BF16) RC(gatres_convert_conv_weights_bf16(params, scratch + L.sc_wb, L.nb, nc, stream));
   RC(gatres_t_lin0_fwd(x, mask, params + L.p_lin0_w, params + L.p_lin0_b, xcur, N, nc, dt, stream));
+  // Blocked launches (k_blocked.hip; bf16, nc = 128, training -- `saved` -- only): conv1's aggregation carries conv2's
+  // projection, K3 carries the next block's conv1 projection: 3 launches per block instead of 5.
+  const bool blocked = saved && gatres_blocked_supported(m, g);
+  bool have_proj1 = false;            // (the previous block's K3 launch has projected this block's conv1 already)
   for (int b = 0; b < L.nb; ++b) {
     float* base = saved ? saved + (int64_t)b * L.s_stride : scratch + L.sc_ev;
     float* xnext = saved ? saved + (int64_t)(b + 1) * L.s_stride + L.s_xin : (xcur == xa ? xb : xa);
@@ -105,15 +109,31 @@ extern "C" int gatres_model_forward_per_op(const gatres_model_t* m, const gatres
     const float* wbb = scratch + L.sc_wb + (int64_t)b * 2 * w;
     const void* W1 = dt == GATRES_DTYPE_BF16 ? (const void*)wbb : (const void*)(pb + L.c1_W);
     const void* W2 = dt == GATRES_DTYPE_BF16 ? (const void*)(wbb + w / 2) : (const void*)(pb + L.c2_W);
-    RC(gatres_t_proj_attn_fwd(xcur, W1, pb + L.c1_as, pb + L.c1_ad, base + L.s_h1, base + L.s_as1, base + L.s_ad1, N, nc,
-                              2, nc, dt, stream));
-    RC(gatres_t_gat_aggregate_fwd(g, base + L.s_h1, base + L.s_as1, base + L.s_ad1, pb + L.c1_b, base + L.s_o1,
-                                  base + L.s_al1, 2, nc, 1, dt, stream));
-    RC(gatres_t_proj_attn_fwd(base + L.s_o1, W2, pb + L.c2_as, pb + L.c2_ad, base + L.s_h2, base + L.s_as2,
-                              base + L.s_ad2, N, 2 * nc, 1, nc, dt, stream));
+    if (!have_proj1)
+      RC(gatres_t_proj_attn_fwd(xcur, W1, pb + L.c1_as, pb + L.c1_ad, base + L.s_h1, base + L.s_as1, base + L.s_ad1, N, nc,
+                                2, nc, dt, stream));
+    if (blocked) {
+      RC(gatres_bf16_agg_proj_fwd(g, base + L.s_h1, base + L.s_as1, base + L.s_ad1, pb + L.c1_b, base + L.s_o1,
+                                  base + L.s_al1, W2, pb + L.c2_as, pb + L.c2_ad, base + L.s_h2, base + L.s_as2,
+                                  base + L.s_ad2, nc, stream));
+    } else {
+      RC(gatres_t_gat_aggregate_fwd(g, base + L.s_h1, base + L.s_as1, base + L.s_ad1, pb + L.c1_b, base + L.s_o1,
+                                    base + L.s_al1, 2, nc, 1, dt, stream));
+      RC(gatres_t_proj_attn_fwd(base + L.s_o1, W2, pb + L.c2_as, pb + L.c2_ad, base + L.s_h2, base + L.s_as2,
+                                base + L.s_ad2, N, 2 * nc, 1, nc, dt, stream));
+    }
     RC(gatres_t_gat_aggregate_fwd(g, base + L.s_h2, base + L.s_as2, base + L.s_ad2, pb + L.c2_b, y2, base + L.s_al2, 1,
                                   nc, 0, dt, stream));
-    RC(gatres_t_mean_residual_relu_fwd(g, y2, xcur, xnext, nc, dt, stream));
+    if (blocked && b + 1 < L.nb) {
+      float* nbase = saved + (int64_t)(b + 1) * L.s_stride;
+      const float* pn = pb + L.p_block_stride;
+      RC(gatres_bf16_mean_proj_fwd(g, y2, xcur, xnext, wbb + 2 * w, pn + L.c1_as, pn + L.c1_ad, nbase + L.s_h1,
+                                   nbase + L.s_as1, nbase + L.s_ad1, nc, stream));
+      have_proj1 = true;
+    } else {
+      RC(gatres_t_mean_residual_relu_fwd(g, y2, xcur, xnext, nc, dt, stream));
+      have_proj1 = false;
+    }
     xcur = xnext;
   }
   RC(gatres_t_lin1_fwd(xcur, params + L.p_lin1_w, params + L.p_lin1_b, out, N, nc, dt, stream));
@@ -264,6 +284,7 @@ extern "C" int gatres_model_backward_per_op_part(const gatres_model_t* m, const 
   const int want_side = gatres_knobs()->side_stream;
   gatres_side_t* side = (want_side == 1 || (want_side < 0 && dt == GATRES_DTYPE_F32 && nc >= 128)) ? gatres_side() : nullptr;
   hipStream_t main_st = gatres_stream(stream);
+  const bool blocked = gatres_blocked_supported(m, g) != 0;
   std::unique_lock<std::mutex> side_lock;          // (two host threads enqueueing backward pieces must not interleave on the events)
   if (side) side_lock = std::unique_lock<std::mutex>(*static_cast<std::mutex*>(side->mu));
   // Join on EVERY exit: an error return between a fork and its join would leave the side stream forked -- inside
@@ -298,6 +319,14 @@ extern "C" int gatres_model_backward_per_op_part(const gatres_model_t* m, const 
     // conv2 (H = 1, C = nc, K = 2nc); its output has no ReLU
     RC(gatres_t_gat_aggregate_bwd_dst(g, gy2, base + L.s_h2, base + L.s_al2, base + L.s_as2, base + L.s_ad2, ge, gad2, 1,
                                       nc, dt, stream));
+    // Blocked launches (k_blocked.hip): the source-major pass carries the input gradient -- the weight-gradient launch that
+    // reads g_h then follows the pair instead of standing between them (not on the side stream: it now reads what the chain's
+    // next launch has not overwritten yet either way, but the fork is an fp32 choice and these kernels are bf16).
+    if (blocked) {
+      if (pend_b) { HIPRC(hipStreamWaitEvent(main_st, side->done_b, 0)); pend_b = false; }
+      RC(gatres_bf16_src_dx_bwd(g, gy2, base + L.s_al2, ge, gad2, pb + L.c2_as, pb + L.c2_ad, gh2, gas2, wt2, nullptr,
+                                base + L.s_o1, go1, 1, nc, stream));
+    } else
     RC(gatres_t_gat_aggregate_bwd_src(g, gy2, base + L.s_al2, ge, gad2, pb + L.c2_as, pb + L.c2_ad, gh2, gas2, 1, nc, dt,
                                       stream));
     void* pst = stream;
@@ -310,11 +339,18 @@ extern "C" int gatres_model_backward_per_op_part(const gatres_model_t* m, const 
     RC(conv_partials(gh2, base + L.s_o1, sb + L.c2_W, Sw, st, N, 2 * nc, nc, base + L.s_h2, gas2, gad2, gy2, sb + L.c2_as,
                      sb + L.c2_ad, sb + L.c2_b, S, 1, nc, dt, pst));
     if (side) { sj.open_a = false; HIPRC(hipEventRecord(side->done_a, side->stream)); pend_a = true; }
-    if (pend_b) { HIPRC(hipStreamWaitEvent(main_st, side->done_b, 0)); pend_b = false; }
-    RC(gatres_t_proj_bwd_dx(gh2, wt2, nullptr, base + L.s_o1, go1, N, 2 * nc, nc, dt, stream));   // ReLU mask of conv1
+    if (!blocked) {
+      if (pend_b) { HIPRC(hipStreamWaitEvent(main_st, side->done_b, 0)); pend_b = false; }
+      RC(gatres_t_proj_bwd_dx(gh2, wt2, nullptr, base + L.s_o1, go1, N, 2 * nc, nc, dt, stream));   // ReLU mask of conv1
+    }
     // conv1 (H = 2, C = nc, K = nc)
     RC(gatres_t_gat_aggregate_bwd_dst(g, go1, base + L.s_h1, base + L.s_al1, base + L.s_as1, base + L.s_ad1, ge, gad, 2,
                                       nc, dt, stream));
+    // d/d xin = conv1 path + residual; masked by the previous block's ReLU (block 0's input is lin0, no ReLU)
+    if (blocked)
+      RC(gatres_bf16_src_dx_bwd(g, go1, base + L.s_al1, ge, gad, pb + L.c1_as, pb + L.c1_ad, gh, gas, wt1, gp_cur,
+                                b > 0 ? base + L.s_xin : nullptr, gp_nxt, 2, nc, stream));
+    else
     RC(gatres_t_gat_aggregate_bwd_src(g, go1, base + L.s_al1, ge, gad, pb + L.c1_as, pb + L.c1_ad, gh, gas, 2, nc, dt,
                                       stream));
     pst = stream;
@@ -327,8 +363,8 @@ extern "C" int gatres_model_backward_per_op_part(const gatres_model_t* m, const 
     RC(conv_partials(gh, base + L.s_xin, sb + L.c1_W, Sw, st, N, nc, 2 * nc, base + L.s_h1, gas, gad, go1, sb + L.c1_as,
                      sb + L.c1_ad, sb + L.c1_b, S, 2, nc, dt, pst));
     if (side) { sj.open_b = false; HIPRC(hipEventRecord(side->done_b, side->stream)); pend_b = true; }
-    // d/d xin = conv1 path + residual; masked by the previous block's ReLU (block 0's input is lin0, no ReLU)
-    RC(gatres_t_proj_bwd_dx(gh, wt1, gp_cur, b > 0 ? base + L.s_xin : nullptr, gp_nxt, N, nc, 2 * nc, dt, stream));
+    if (!blocked)
+      RC(gatres_t_proj_bwd_dx(gh, wt1, gp_cur, b > 0 ? base + L.s_xin : nullptr, gp_nxt, N, nc, 2 * nc, dt, stream));
     float* t = gp_cur; gp_cur = gp_nxt; gp_nxt = t;
   }
   if (pend_a) { HIPRC(hipStreamWaitEvent(main_st, side->done_a, 0)); pend_a = false; }      // join: the piece's slabs are complete

@@ -157,8 +157,11 @@ class GATResTrainer:
         cus = int(self.lib.gatres_fused_cus_per_segment(self.model._cmodel_ref(), self.plan.ref()))
         if cus < 2:
             return
-        need = ((self.plan.num_segments + 7) // 8) * 8 * cus
+        padded = ((self.plan.num_segments + 7) // 8) * 8
+        need = padded * cus
         have = int(torch.cuda.get_device_properties(self.device).multi_processor_count)
+        if need > have and ((padded // 2 + 7) // 8) * 8 * cus <= have:
+            need = ((padded // 2 + 7) // 8) * 8 * cus       # (batches of 49 - 96 snapshots go in two rounds of half the segments)
         masked = [k for k in ("HSA_CU_MASK", "ROC_GLOBAL_CU_MASK") if os.environ.get(k)]
         if need > have or masked:
             import warnings

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define GATRES_ABI_VERSION 4
+#define GATRES_ABI_VERSION 5
 
 #define GATRES_E_BADARG      (-1)  /* null pointer, negative size, misaligned pointer            */
 #define GATRES_E_UNSUPPORTED (-2)  /* width not supported by the gfx950 kernels                  */
@@ -109,6 +109,12 @@ enum {
                                     * pgu.from_networkx gives for an undirected water network (utils/DataLoader.py:29).  The parts
                                     * of a split segment then owe each other halo rows in BOTH directions at every hand-off,
                                     * which paces them without the heartbeat granules (k_fused_dev.h: xch_heartbeat). */
+
+#define GATRES_GRAPH_DEG_LE32 2    /* no node has more than 31 edges into it or out of it in edge_index: every row of the
+                                    * plan's CSRs (GATConv's with its self loop, SimpleConv's, their transposes) has at most
+                                    * 32 entries.  The blocked kernels (gatres_bf16_*_proj / _src_dx) walk a row with its own
+                                    * lane group and are only taken for such plans; others keep the per-op kernels, whose hub
+                                    * rows are reduced by whole waves. */
 
 /* Host-side plan builder (runs on the CPU, once per topology).  edge_index_host: int64 [2, E] row-major as
  * torch stores it.  Step 1: count -> E'.  Step 2: fill caller-allocated HOST arrays sized from that count. */
@@ -360,6 +366,31 @@ typedef struct gatres_model {
   int32_t act_dtype;
   int32_t reserved;
 } gatres_model_t;
+
+/* --------------------------------------------------------------------------------------------------------
+ * Blocked kernels (round 5; k_blocked.hip): a SPARSE stage and the dense projection that consumes its output
+ * as ONE launch -- bf16 storage, nc = 128 (gatres_large: ConfigModels.py:22-32; block GraphModels.py:462-468),
+ * plans flagged GATRES_GRAPH_DEG_LE32.  A 512-thread workgroup aggregates a block of 32 rows (the arithmetic
+ * of the gatres_t_* sparse kernels, statement for statement), stores them (later launches read them) and runs
+ * them through the matrix cores from LDS against W fragments held in registers.  Each call gives what the two
+ * per-op calls it replaces give (the next convolution's attention logits are summed in another order).
+ *   gatres_blocked_supported   1 when gatres_model_forward/backward_per_op take these kernels for (m, g)
+ *   gatres_bf16_agg_proj_fwd   = gatres_t_gat_aggregate_fwd(H = 2, ReLU) + gatres_t_proj_attn_fwd(K = 2nc, H = 1)
+ *   gatres_bf16_mean_proj_fwd  = gatres_t_mean_residual_relu_fwd + gatres_t_proj_attn_fwd(K = nc, H = 2)
+ *   gatres_bf16_src_dx_bwd     = gatres_t_gat_aggregate_bwd_src(H) + gatres_t_proj_bwd_dx
+ * W_next / Wt: bf16 [M, K] row-major as gatres_convert_conv_weights_bf16 leaves them. */
+int gatres_blocked_supported(const gatres_model_t* m, const gatres_graph_t* g);
+int gatres_bf16_agg_proj_fwd(const gatres_graph_t* g, const void* h, const float* a_src, const float* a_dst,
+                             const float* bias, void* o, float* alpha, const void* W_next, const float* att_src_next,
+                             const float* att_dst_next, void* h_next, float* a_src_next, float* a_dst_next, int32_t nc,
+                             void* stream);
+int gatres_bf16_mean_proj_fwd(const gatres_graph_t* g, const void* y, const void* x0, void* x_next, const void* W_next,
+                              const float* att_src_next, const float* att_dst_next, void* h_next, float* a_src_next,
+                              float* a_dst_next, int32_t nc, void* stream);
+int gatres_bf16_src_dx_bwd(const gatres_graph_t* g, const void* g_out, const float* alpha, const float* g_e,
+                           const float* g_a_dst, const float* att_src, const float* att_dst, void* g_h, float* g_a_src,
+                           const void* Wt, const void* resid, const void* relu_ref, void* g_x, int32_t H, int32_t nc,
+                           void* stream);
 
 int64_t gatres_param_count(int32_t num_blocks, int32_t nc);
 /* floats of forward state kept for backward / of scratch needed by forward+backward / slabs used. */

@@ -239,3 +239,105 @@ def test_bf16_gatres_large_full_batch_128(pkg, oracle):
     d = (model.flat_parameters - before).abs()
     assert torch.isfinite(tr.grads).all() and 0 < float(d.max()) <= 5e-4 * 1.01
 
+
+
+# ---------------------------------------------------------------------------------------------- blocked kernels (round 5)
+def _plan_for(pkg, bs, nodes=388, pipes=430, seed=0):
+    ei = pkg.wdn_synth.collate_edge_index(pkg.wdn_synth.make_wdn_topology(nodes, pipes, seed=seed), nodes, bs).cuda()
+    return pkg.GraphPlan(ei, nodes * bs, device=ei.device, segments=False), ei
+
+
+@pytest.mark.parametrize("bs,nodes,pipes", [(5, 388, 430), (1, 131, 150)])
+def test_blocked_kernels_equal_the_per_op_pairs(pkg, lib, bs, nodes, pipes):
+    """k_blocked.hip: one launch = a sparse stage + the projection that consumes it.  Against the two per-op launches it
+    replaces, on the same operands, EVERY output bit for bit: the sparse stage's (o1 / x_next / g_h, alpha, g_a_src: the same
+    slot arithmetic), the projected rows (the same bf16 operands, the same k order on the matrix cores) and the next
+    convolution's attention logits (summed from the fp32 accumulators in the projection kernel's association).  Ragged row
+    counts: the last 16-row tile and the last 32-row phase of a workgroup's share are partial."""
+    nc = 128
+    plan, ei = _plan_for(pkg, bs, nodes, pipes)
+    assert plan.flags & 2, "the synthetic WDN topology has low degrees: GATRES_GRAPH_DEG_LE32"
+    N, Eg = plan.num_nodes, plan.num_edges_gat
+    gp = plan.ref()
+    g = torch.Generator().manual_seed(bs * 1000 + nodes)
+    rn = lambda *s: torch.randn(*s, generator=g).cuda()
+    bf = lambda *s: rn(*s).bfloat16()
+    st = lambda: pkg._native.current_stream(ei.device)
+    chk = pkg._native.check
+    # ---- conv1 aggregation (H = 2, ReLU) -> conv2 projection (K = 256 -> M = 128, H = 1)
+    h1, a_s, a_d, bias = bf(N, 256), rn(N, 2), rn(N, 2), rn(256)
+    W2 = (rn(128, 256) / 16).bfloat16()
+    att_s, att_d = rn(128), rn(128)
+    o_a, al_a = torch.empty(N, 256, dtype=torch.bfloat16, device="cuda"), torch.zeros(Eg, 2, device="cuda")
+    h2_a, as_a, ad_a = torch.empty(N, 128, dtype=torch.bfloat16, device="cuda"), torch.empty(N, device="cuda"), torch.empty(N, device="cuda")
+    chk(lib.gatres_t_gat_aggregate_fwd(gp, h1.data_ptr(), a_s.data_ptr(), a_d.data_ptr(), bias.data_ptr(), o_a.data_ptr(),
+                                       al_a.data_ptr(), 2, nc, 1, BF16, st()), "agg")
+    chk(lib.gatres_t_proj_attn_fwd(o_a.data_ptr(), W2.data_ptr(), att_s.data_ptr(), att_d.data_ptr(), h2_a.data_ptr(),
+                                   as_a.data_ptr(), ad_a.data_ptr(), N, 256, 1, nc, BF16, st()), "proj")
+    o_b, al_b = torch.zeros_like(o_a), torch.zeros_like(al_a)
+    h2_b, as_b, ad_b = torch.zeros_like(h2_a), torch.zeros_like(as_a), torch.zeros_like(ad_a)
+    chk(lib.gatres_bf16_agg_proj_fwd(gp, h1.data_ptr(), a_s.data_ptr(), a_d.data_ptr(), bias.data_ptr(), o_b.data_ptr(),
+                                     al_b.data_ptr(), W2.data_ptr(), att_s.data_ptr(), att_d.data_ptr(), h2_b.data_ptr(),
+                                     as_b.data_ptr(), ad_b.data_ptr(), nc, st()), "agg_proj")
+    torch.cuda.synchronize()
+    assert torch.equal(o_a, o_b) and torch.equal(al_a, al_b)
+    assert torch.equal(h2_a, h2_b)
+    assert torch.equal(as_b, as_a) and torch.equal(ad_b, ad_a)
+    # ---- K3 (mean + residual + ReLU) -> the next block's conv1 projection (K = 128 -> M = 256, H = 2)
+    y2, x0 = bf(N, 128), bf(N, 128)
+    W1 = (rn(256, 128) / 11).bfloat16()
+    att_s1, att_d1 = rn(256), rn(256)
+    xn_a = torch.empty(N, 128, dtype=torch.bfloat16, device="cuda")
+    h1_a, as1_a, ad1_a = torch.empty(N, 256, dtype=torch.bfloat16, device="cuda"), torch.empty(N, 2, device="cuda"), torch.empty(N, 2, device="cuda")
+    chk(lib.gatres_t_mean_residual_relu_fwd(gp, y2.data_ptr(), x0.data_ptr(), xn_a.data_ptr(), nc, BF16, st()), "mean")
+    chk(lib.gatres_t_proj_attn_fwd(xn_a.data_ptr(), W1.data_ptr(), att_s1.data_ptr(), att_d1.data_ptr(), h1_a.data_ptr(),
+                                   as1_a.data_ptr(), ad1_a.data_ptr(), N, 128, 2, nc, BF16, st()), "proj1")
+    xn_b, h1_b, as1_b, ad1_b = torch.zeros_like(xn_a), torch.zeros_like(h1_a), torch.zeros_like(as1_a), torch.zeros_like(ad1_a)
+    chk(lib.gatres_bf16_mean_proj_fwd(gp, y2.data_ptr(), x0.data_ptr(), xn_b.data_ptr(), W1.data_ptr(), att_s1.data_ptr(),
+                                      att_d1.data_ptr(), h1_b.data_ptr(), as1_b.data_ptr(), ad1_b.data_ptr(), nc, st()),
+        "mean_proj")
+    torch.cuda.synchronize()
+    assert torch.equal(xn_a, xn_b) and torch.equal(h1_a, h1_b)
+    assert torch.equal(as1_b, as1_a) and torch.equal(ad1_b, ad1_a)
+    # ---- source-major backward -> input gradient, both convolutions
+    for H, K, M in ((1, 128, 256), (2, 256, 128)):
+        g_out, alpha = bf(N, K), torch.rand(Eg, H, generator=g).cuda()
+        g_e, g_ad = rn(Eg, H), rn(N, H)
+        att_s2, att_d2 = rn(K), rn(K)
+        Wt = (rn(M, K) / 13).bfloat16()
+        resid = bf(N, M) if H == 2 else None
+        ref_act = bf(N, M)
+        gh_a, gas_a, gx_a = torch.empty(N, K, dtype=torch.bfloat16, device="cuda"), torch.empty(N, H, device="cuda"), torch.empty(N, M, dtype=torch.bfloat16, device="cuda")
+        chk(lib.gatres_t_gat_aggregate_bwd_src(gp, g_out.data_ptr(), alpha.data_ptr(), g_e.data_ptr(), g_ad.data_ptr(),
+                                               att_s2.data_ptr(), att_d2.data_ptr(), gh_a.data_ptr(), gas_a.data_ptr(), H, nc,
+                                               BF16, st()), "src")
+        chk(lib.gatres_t_proj_bwd_dx(gh_a.data_ptr(), Wt.data_ptr(), pkg._native.ptr(resid), ref_act.data_ptr(), gx_a.data_ptr(),
+                                     N, M, K, BF16, st()), "dx")
+        gh_b, gas_b, gx_b = torch.zeros_like(gh_a), torch.zeros_like(gas_a), torch.zeros_like(gx_a)
+        chk(lib.gatres_bf16_src_dx_bwd(gp, g_out.data_ptr(), alpha.data_ptr(), g_e.data_ptr(), g_ad.data_ptr(), att_s2.data_ptr(),
+                                       att_d2.data_ptr(), gh_b.data_ptr(), gas_b.data_ptr(), Wt.data_ptr(), pkg._native.ptr(resid),
+                                       ref_act.data_ptr(), gx_b.data_ptr(), H, nc, st()), "src_dx")
+        torch.cuda.synchronize()
+        assert torch.equal(gh_a, gh_b) and torch.equal(gas_a, gas_b), H
+        assert torch.equal(gx_a, gx_b), H
+
+
+def test_blocked_model_equals_the_per_op_model(pkg, oracle, monkeypatch):
+    """gatres_large-shaped training steps (bf16, nc = 128) with the blocked launches (GATRES_BLOCKED=1) and without (the
+    default): the same predictions, losses, gradients and parameters, bit for bit."""
+    nb, nc, bs = 4, 128, 6
+    x, y, ei, mask = ctown_batch(pkg, bs)
+    res = []
+    for off in (True, False):
+        if off:
+            monkeypatch.delenv("GATRES_BLOCKED", raising=False)
+        else:
+            monkeypatch.setenv("GATRES_BLOCKED", "1")
+        model, p = build(pkg, oracle, nb, nc, seed=11)
+        model.set_compute_dtype("bf16")
+        tr = pkg.GATResTrainer(model, ei.cuda(), x.shape[0], nodes_per_graph=[388] * bs, use_graph=False, fused=False)
+        assert bool(pkg._native.load().gatres_blocked_supported(model._cmodel_ref(), tr.plan.ref())) == (not off)
+        losses = [float(tr.step(x.cuda(), y.cuda(), mask.cuda())) for _ in range(2)]
+        res.append((tr.out.clone(), losses, tr.grads.clone(), model.flat_parameters.clone()))
+    assert res[0][1] == res[1][1], (res[0][1], res[1][1])
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][2], res[1][2]) and torch.equal(res[0][3], res[1][3])

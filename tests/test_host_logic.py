@@ -223,10 +223,16 @@ def test_graph_flags_symmetric(pkg, lib):
         assert lib.gatres_graph_flags_host(ei.data_ptr(), ei.shape[1], 60, C.byref(f)) == 0
         return f.value
 
-    assert flags(t) == 1
-    assert flags(torch.cat([t, t[:, :5], torch.tensor([[3, 7], [3, 7]])], dim=1)) == 1       # duplicates + self loops
-    assert flags(t[:, 1:]) == 0                                                            # one direction missing
-    assert flags(t[:, t[0] < t[1]]) == 0
+    SYM, LE32 = 1, 2          # GATRES_GRAPH_SYMMETRIC, GATRES_GRAPH_DEG_LE32 (every water network has low degrees)
+    assert flags(t) == SYM | LE32
+    assert flags(torch.cat([t, t[:, :5], torch.tensor([[3, 7], [3, 7]])], dim=1)) == SYM | LE32       # duplicates + self loops
+    assert flags(t[:, 1:]) == LE32                                                         # one direction missing
+    assert flags(t[:, t[0] < t[1]]) == LE32
+    # GATRES_GRAPH_DEG_LE32: no node with more than 31 edges into or out of it (a row of 32 with GATConv's self loop)
+    hub = torch.stack([torch.arange(1, 33), torch.zeros(32, dtype=torch.long)])                # 32 edges INTO node 0
+    assert flags(torch.cat([t, hub], dim=1)) & LE32 == 0
+    assert flags(torch.cat([t, hub.flip(0)], dim=1)) & LE32 == 0                               # ... and OUT of it
+    assert flags(torch.cat([t[:, t[1] != 0][:, :0], hub[:, :31]], dim=1)) & LE32 == LE32      # 31: still a slot / loop row
 
 
 @pytest.mark.parametrize("m", [2, 4, 8])
