@@ -80,6 +80,9 @@ def parse():
     ap.add_argument("--from-store", action="store_true",
                     help="batches come from a device-resident SnapshotStore through GATResTrainer.fit_epoch (shuffled row "
                          "gathers; the epoch loop of train.py:159-198) instead of pre-collated rotating batches")
+    ap.add_argument("--graph-steps", type=int, default=20,
+                    help="steps per hipGraph launch on the bound-batch path (GATResTrainer.steps_bound): every step is the full "
+                         "iteration, consecutive steps share one graph launch; 1 = one launch per step")
     ap.add_argument("--dtype", default="fp32", choices=["fp32", "bf16"],
                     help="storage / MFMA type of the projections (bf16: gatres_large per-op path, BASELINE config 3)")
     return ap.parse_args()
@@ -533,8 +536,16 @@ def main():
     if args.host_batches:
         batches = [b.cpu().pin_memory() for b in batches]
         trainer.prefetch_batch(batches[0])
-    elif not args.copy_batches:
-        trainer.bind_batches(batches)               # the captured step reads the resident batches in place (no staging copy)
+    G_ = max(1, args.graph_steps)
+
+    def chunks(k):                                  # the bound-batch indices of k consecutive steps, G_ per graph launch
+        return [tuple((i0 + j) % nbatches for j in range(min(G_, k - i0))) for i0 in range(0, k, G_)]
+
+    if not (args.host_batches or args.copy_batches):
+        # the captured steps read the resident batches in place (no staging copy); every graph the run will replay -- single
+        # steps and the multi-step sequences of the warm-up and of a timed block -- is captured here, before any timing
+        seqs = sorted({c for c in chunks(args.steps) + chunks(args.warmup) if len(c) > 1})
+        trainer.bind_batches(batches, sequences=seqs)
 
     def one_step(i):
         if args.host_batches:                       # batch i was prefetched during step i - 1; start fetching i + 1
@@ -546,6 +557,16 @@ def main():
             trainer.step(b, b)
         else:
             trainer.step_bound(i % nbatches)
+
+    bound_path = not (args.host_batches or args.copy_batches or args.from_store)
+
+    def run_steps(k):
+        if bound_path and G_ > 1:
+            for c in chunks(k):
+                trainer.steps_bound(c) if len(c) > 1 else trainer.step_bound(c[0])
+        else:
+            for i in range(k):
+                one_step(i)
 
     def fence():
         torch.cuda.synchronize(device)
@@ -560,8 +581,7 @@ def main():
         if store is not None:
             trainer.fit_epoch(store, args.batch_size, shuffle=True)
         else:
-            for i in range(k):
-                one_step(i)
+            run_steps(k)
         fence()
         dt = time.perf_counter() - t0
         if world > 1:
@@ -571,16 +591,14 @@ def main():
         return dt
 
     log(f"model/trainer ready on {device}; warm-up {args.warmup} steps")
-    for i in range(args.warmup):
-        one_step(i)
+    run_steps(args.warmup)
     # Every hipGraph the timed steps replay exists BEFORE the first timed block, whatever --warmup is: bind_batches() captured
     # the steady-state step of every (batch, mask buffer) pair (GATResTrainer.precapture_bound).  Checked, not assumed: the
     # number of captured graphs must not move across the timed blocks (block 1 used to hold four captures).
     graphs_before = trainer.num_captured_graphs
     times = [timed_block(args.steps) for _ in range(max(1, args.repeats))]
     graphs_after = trainer.num_captured_graphs
-    bound_path = not (args.host_batches or args.copy_batches or store is not None or args.no_graph)
-    if bound_path and graphs_after != graphs_before:
+    if bound_path and not args.no_graph and graphs_after != graphs_before:
         raise SystemExit(f"bench.py: {graphs_after - graphs_before} hipGraph capture(s) happened INSIDE the timed region "
                          f"({graphs_before} -> {graphs_after} graphs): the measurement is invalid")
     dt = statistics.median(times)
@@ -613,7 +631,7 @@ def main():
                                f"full training step (device mask 0.95 -> fwd -> masked MSE -> bwd -> "
                                f"{'RCCL all-reduce -> ' if trainer.split else ''}Adam), "
                                f"{'per-op kernels' if not trainer.fused else f'fused per-snapshot kernel ({cus} CUs per snapshot, ' + ('row-window' if window else 'whole-segment') + ' tables)'}, "
-                               f"{'eager launches' if args.no_graph else 'hipGraph replay'}"
+                               f"{'eager launches' if args.no_graph else 'hipGraph replay' + (f' ({G_} steps per graph launch)' if bound_path and G_ > 1 else '')}"
                                f"{', batches from SnapshotStore.fit_epoch' if store is not None else ''}"
                                f"{', batches staged by copy' if args.copy_batches else ''}",
                    "global_batch": world * args.batch_size, "parallelism": f"dp{world}",

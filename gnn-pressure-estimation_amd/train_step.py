@@ -191,9 +191,10 @@ class GATResTrainer:
         self.hp.copy_(torch.tensor(self._hp_list(), dtype=torch.float64), non_blocking=False)
 
     def _desc(self, phases: int, device_mask: bool, wt_valid: bool = False, flags: int = 0, block_lo: int = 0,
-              block_hi: int = 0, batch=None) -> _TrainStepC:
+              block_hi: int = 0, batch=None, masks=None) -> _TrainStepC:
         m = self.model
         bx, by = (self.x, self.y) if batch is None else batch
+        mask, mask_next = (self.mask, self._mask_spare) if masks is None else masks
         params = m.flat_parameters
         if params.data_ptr() != self._params_ptr:
             raise RuntimeError("the model's parameter storage moved (e.g. .to()/deepcopy); build a new GATResTrainer")
@@ -201,13 +202,13 @@ class GATResTrainer:
         return _TrainStepC(
             _native.GatresModel(m.num_blocks, m.nc, m._cmodel.act_dtype, 0), C.pointer(self._gstruct), params.data_ptr(), self.grads.data_ptr(),
             self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr(), self.step_counter.data_ptr(), bx.data_ptr(),
-            by.data_ptr(), self.mask.data_ptr(),
+            by.data_ptr(), mask.data_ptr(),
             self.node_ptr.data_ptr() if (device_mask and self.node_ptr is not None) else None,
             self.num_graphs, phases, self.mask_rate, self.seed, self.out.data_ptr(), self.g_out.data_ptr(),
             self.loss.data_ptr(), self.saved.data_ptr(), self.scratch.data_ptr(), h["lr"], h["beta1"], h["beta2"],
             h["eps"], h["weight_decay"], 1.0 / self.world,
             (0 if self.fused else FLAG_PER_OP) | (FLAG_WT_VALID if wt_valid else 0) | flags, self.hp.data_ptr(),
-            block_lo, block_hi, self._mask_spare.data_ptr())
+            block_lo, block_hi, mask_next.data_ptr())
 
     def _count_native_update(self) -> None:
         """A native kernel (fused Adam pass, Adam-only phase) just changed the parameters without touching torch's
@@ -285,8 +286,8 @@ class GATResTrainer:
         return int(self._status[1].item()) if self._status is not None else 0
 
     def _enqueue(self, phases: int, device_mask: bool, wt_valid: bool = False, flags: int = 0, block_lo: int = 0,
-                 block_hi: int = 0, batch=None) -> None:
-        ts = self._desc(phases, device_mask, wt_valid, flags, block_lo, block_hi, batch)
+                 block_hi: int = 0, batch=None, masks=None) -> None:
+        ts = self._desc(phases, device_mask, wt_valid, flags, block_lo, block_hi, batch, masks)
         _native.check(self.lib.gatres_train_step(C.byref(ts), _native.current_stream(self.device)),
                       "gatres_train_step")
 
@@ -324,12 +325,13 @@ class GATResTrainer:
         if g is None:
             # warm-up launch outside capture (module load, lazy init, RCCL communicator), then capture the same sequence
             state = (self.step_counter.clone(), self.model.flat_parameters.clone(), self.exp_avg.clone(),
-                     self.exp_avg_sq.clone(), self.mask.clone())
+                     self.exp_avg_sq.clone(), self.mask.clone(), self._mask_spare.clone())
 
             def rollback():
                 self.step_counter.copy_(state[0]); self.model.flat_parameters.copy_(state[1])
                 self.exp_avg.copy_(state[2]); self.exp_avg_sq.copy_(state[3])
                 self.mask.copy_(state[4])        # (a warm-up that ran the sampler's launch re-sampled it: same bits; kept simple)
+                self._mask_spare.copy_(state[5])  # (a multi-step sequence samples into BOTH buffers, two steps ahead of the rollback)
 
             enqueue()
             torch.cuda.synchronize(self.device)
@@ -587,7 +589,7 @@ class GATResTrainer:
             self._mask_sig = self._mask_key() if ahead else None
 
     # ---- bound batches: the captured step reads the caller's buffers, nothing is copied -------------------------------------
-    def bind_batches(self, xs, ys=None, precapture: bool = True) -> int:
+    def bind_batches(self, xs, ys=None, precapture: bool = True, sequences=()) -> int:
         """Register device-resident batches (flat fp32 ``[N]`` tensors; ``ys`` defaults to ``xs``: y == x before masking,
         train.py:162-166) that ``step_bound(i)`` then trains on IN PLACE: the kernels mask x on the fly and never write it,
         so no staging copy is needed -- one captured step per buffer and mask-buffer orientation.  ``precapture``: capture
@@ -607,18 +609,19 @@ class GATResTrainer:
         self._bound = bound
         # two captured steps per bound batch (the two mask buffers take turns) + the first-step variants + whatever else this
         # trainer replays: the cache must hold them all, or FIFO eviction makes every step pay for a capture
-        self._max_graphs = max(MAX_CACHED_GRAPHS, 2 * len(bound) + 16)
+        self._max_graphs = max(MAX_CACHED_GRAPHS, 2 * len(bound) + 16 + 2 * len(tuple(sequences)))
         if precapture:
-            self.precapture_bound()
+            self.precapture_bound(sequences)
         return len(bound)
 
-    def precapture_bound(self) -> int:
+    def precapture_bound(self, sequences=()) -> int:
         """Capture the steady-state step of every (bound batch, mask-buffer orientation) pair by RUNNING steps, then put the
         training state back exactly where it was (parameters, Adam moments, step count) -- with the transposed weights current
         and the first step's mask sampled ahead, so that the first real ``step_bound`` call already replays a steady-state
         graph.  Nothing is captured inside a caller's timed region afterwards (bench.py's first timed block held
-        four captures).  Under data parallelism every rank runs the same number of steps (the collectives match).  Returns the
-        number of captured graphs."""
+        four captures).  ``sequences``: tuples of bound-batch indices that the caller will run through ``steps_bound`` -- each is
+        captured too, under both orientations of the mask buffers.  Under data parallelism every rank runs the same number of
+        steps (the collectives match).  Returns the number of captured graphs."""
         if not (self.use_graph and self._bound and self.node_ptr is not None):
             return len(self._graphs)
         dev = self.device
@@ -643,6 +646,22 @@ class GATResTrainer:
             if steady:
                 need.discard((i, ptr))
             steps += 1
+        # multi-step sequences (steps_bound): each one under both start orientations of the mask buffers
+        for seq in sequences:
+            seq = tuple(int(i) for i in seq)
+            if len(seq) < 2 or not ahead_ok or self.split:
+                continue
+            seen = set()
+            for _ in range(4):
+                if len(seen) == 2:
+                    break
+                start = self._mask_spare.data_ptr()
+                if start in seen:
+                    self.step_bound(seq[0])            # (flip the orientation)
+                    continue
+                self.steps_bound(seq)
+                seen.add(start)
+        self._max_graphs = max(self._max_graphs, len(self._graphs) + 16)
         torch.cuda.synchronize(dev)
         for dst, src in zip((self.step_counter, self.model.flat_parameters, self.exp_avg, self.exp_avg_sq, self.loss), keep):
             dst.copy_(src)
@@ -676,6 +695,40 @@ class GATResTrainer:
             self._run_split(True, batch=(x, y), slot=i)
             return self.loss
         self._run(PHASE_MASK | PHASE_FORWARD | PHASE_BACKWARD | PHASE_ADAM, True, batch=(x, y), slot=i)
+        return self.loss
+
+    def steps_bound(self, indices) -> torch.Tensor:
+        """``step_bound(i)`` for every i of ``indices``, in order -- as ONE captured launch sequence when the trainer is in its
+        steady state (single GPU, fused path, transposed weights current, the first mask sampled ahead): 3 k kernels in one
+        hipGraph, so the ~8 us between two graph launches are paid once per k steps instead of once per step.  The two mask
+        buffers take turns inside the sequence exactly as they do between ``step_bound`` calls (step j trains on the mask the
+        update launch of step j - 1 sampled), so the results are those of the single calls bit for bit.  Anything else (first
+        step, data-parallel trainer, eager launches) falls back to the single calls.  Returns the last step's loss tensor."""
+        idx = tuple(int(i) for i in indices)
+        steady = (len(idx) > 1 and self.use_graph and self.fused and not self.split and self._mask_next and self._wt_current()
+                  and self._mask_sig is not None and self._mask_sig == self._mask_key() and self.node_ptr is not None)
+        if not steady:
+            for i in idx:
+                self.step_bound(i)
+            return self.loss
+        full = PHASE_FORWARD | PHASE_BACKWARD | PHASE_ADAM
+        m0, m1 = self._mask_spare, self.mask          # step 0 trains on the mask sampled ahead and samples step 1's into the other
+
+        def enqueue():
+            a, b = m0, m1
+            for i in idx:
+                self._enqueue(full, True, True, flags=FLAG_MASK_NEXT, batch=self._bound[i], masks=(a, b))
+                a, b = b, a
+
+        try:
+            self._replay(("seq", idx, self.mask_rate, self.seed, self.world, m0.data_ptr()), enqueue, True)
+        finally:
+            for _ in idx:
+                self._count_native_update()
+            self._wt_sig = self._param_signature()
+            if len(idx) % 2:                           # an odd number of steps leaves the buffers swapped
+                self.mask, self._mask_spare = self._mask_spare, self.mask
+            self._mask_sig = self._mask_key()          # (the last update launch sampled the next step's mask into the spare buffer)
         return self.loss
 
     def forward_backward(self, x: torch.Tensor, y: torch.Tensor, mask: torch.Tensor) -> torch.Tensor:

@@ -384,3 +384,35 @@ def test_mask_next_is_refused_where_it_cannot_be_honoured(pkg, oracle, monkeypat
     torch.cuda.synchronize()
     assert tr.optimizer_step == before
     assert float(tr.step(y, y)) == float(tr.loss)                        # the trainer itself never asks for it here
+
+
+def test_multi_step_sequences_equal_single_steps(pkg, oracle):
+    """Round 5: ``steps_bound(indices)`` replays k full training steps as ONE hipGraph launch (the ~8 us between two graph
+    launches are paid once per k steps).  Masks, losses and parameters after every sequence equal those of the single
+    ``step_bound`` calls bit for bit -- even and odd lengths (an odd one leaves the two mask buffers swapped), sequences captured
+    at bind time and lazily, a change of the mask rate in between."""
+    snaps = pkg.wdn_synth.make_snapshots(4 * BS, NODES, seed=51).cuda()
+    batches = [snaps[i * BS:(i + 1) * BS].reshape(-1).contiguous() for i in range(4)]
+    plan = [(0, 1, 2, 3), (0, 1, 2), (3, 0), (1, 2, 3, 0, 1), (2,), (3, 0, 1, 2)]
+    runs = []
+    for seq_mode in (False, True):
+        model, p, tr, ei = _trainer(pkg, oracle, seed=7, use_graph=True)
+        tr.bind_batches(batches, sequences=[(0, 1, 2, 3), (0, 1, 2)] if seq_mode else ())
+        n0 = tr.num_captured_graphs
+        hist = []
+        for k, seq in enumerate(plan):
+            if k == 4:
+                tr.set_hparams(mask_rate=0.5)
+            if seq_mode:
+                tr.steps_bound(seq)
+            else:
+                for i in seq:
+                    tr.step_bound(i)
+            hist.append((float(tr.loss), tr.mask.clone(), model.flat_parameters.clone(), tr.optimizer_step))
+            if seq_mode and k == 1:
+                assert tr.num_captured_graphs == n0          # both sequences so far were captured at bind time
+        assert tr.fault_count == 0
+        runs.append(hist)
+    for k, (a, b) in enumerate(zip(*runs)):
+        assert a[3] == b[3] and a[0] == b[0], (k, a[0], b[0])
+        assert torch.equal(a[1], b[1]) and torch.equal(a[2], b[2]), k
