@@ -5,16 +5,18 @@
 // them is mostly its own latency chain: ~3 us from the graph node's start to the first instruction, 4 - 7 us until the first
 // MFMA of a projection (every workgroup staging W), the matrix work itself 2 - 3 us (DESIGN.md section 3.3,
 // profiles/r03_proj_probe.txt).  The projections' inputs are exactly the row blocks the sparse kernels in front of them
-// produce, so here a 512-thread workgroup
-//   1. aggregates a block of 32 destination (or source) rows with the sparse kernels' own slot arithmetic (k_aggregate.hip:
-//      same operands, same order -- the same bits), writes them to HBM (later launches need them: weight gradients, ReLU
-//      masks) AND into an LDS tile,
-//   2. runs the block through the matrix cores against a slice of W that its waves hold in REGISTERS for the whole launch
-//      (32 VGPRs per wave: loaded once, in the shadow of the first block's gathers; no LDS copy of W, so two workgroups share
-//      a CU and their phases interleave), k steps in the projection kernels' order,
-//   3. passes the result through an fp32 LDS tile so that every row leaves in 16-byte pieces; the next convolution's attention
-//      logits are summed from that tile in proj_bf16_tile_kernel's association: a blocked launch gives the BITS of the two
-//      per-op launches it replaces.
+// produce, so here ONE 1024-thread workgroup per CU
+//   1. aggregates a block of 64 / 128 destination (or source) rows with the sparse kernels' own slot arithmetic (k_aggregate.hip:
+//      same operands, same order -- the same bits), two row sets per wave in flight together, the next block's row pointers and
+//      neighbour ids requested one block ahead; the rows go to HBM (later launches need them: weight gradients, ReLU masks) AND
+//      into a double-buffered LDS tile,
+//   2. runs the block through the matrix cores with proj_bf16_tile_kernel's own inner loop (W staged once per launch in that
+//      kernel's LDS image, the B fragments from the LDS tile): the same accumulator-to-feature map, logits and epilogue, so a
+//      blocked launch gives the BITS of the two per-op launches it replaces.
+// MEASURED (profiles/r05_blocked_probe.txt): bit-identical, and 5 - 15 % SLOWER than the per-op pairs in four forms of this
+// kernel -- a CU holds ~200 rows of a C-Town batch of 128, a launch is a chain of memory round trips either way, and fusing
+// puts the sparse chain and the dense chain of a row block in series inside one workgroup where the per-op kernels run 20
+// independent waves per CU.  The per-op drivers therefore take these kernels only on request (GATRES_BLOCKED=1).
 // Three sparse stages x two shapes:
 //   agg_proj   GATConv aggregation (softmax, weighted sum, bias, ReLU)  -> next GATConv's projection + logits  (conv1 -> conv2)
 //   mean_proj  SimpleConv mean + residual + ReLU                        -> next block's conv1 projection + logits
@@ -30,17 +32,6 @@ typedef gatres_bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef gatres_bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-#ifdef BK_STAMPS       // (probe build: in-kernel time stamps of one workgroup's wave 0, tests/micro/blocked_probe.py --stamps)
-__device__ unsigned long long g_bk_stamps[4096];
-__device__ __forceinline__ unsigned long long bk_time(float dep) {
-  unsigned long long t;
-  asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) : "v"(dep) : "memory");
-  return t;
-}
-#define BKSTAMP(k, dep) do { if (stamp_on) g_bk_stamps[stamp_base + (k)] = bk_time(dep); } while (0)
-#else
-#define BKSTAMP(k, dep) do {} while (0)
-#endif
 enum { BK_GAT_FWD = 0, BK_MEAN_FWD = 1, BK_GAT_BWD_SRC = 2 };
 enum { BE_ATT = 0, BE_RESID_MASK = 1 };
 
@@ -352,31 +343,25 @@ __device__ __forceinline__ Row8 bk_gat_bwd_src(const BlockedArgs& a, const IdxSr
 }
 
 // ---------------------------------------------------------------------------------------------- the kernel
-// 512 threads = 8 waves, two workgroups per CU.  K / 8 lanes per row, so a wave gathers RW = 2 (K = 256) or 4 (K = 128) rows at
-// a time and a PHASE is the 8 RW = 16 or 32 rows of one such pass: RT = 1 or 2 row tiles of 16.  MFMA work of a phase: RT row
-// tiles x M / 16 column tiles; wave w owns CTW = M / 128 column tiles for every row tile -- its W fragments (CTW x K / 32 x 16
-// bytes per lane = 32 VGPRs) stay in registers from the start of the launch.  A workgroup takes a contiguous share of the phases
-// (XCD-contiguous: neighbour rows lie near their own).
-//
-// A workgroup's life is a CHAIN of phases, and what a phase costs is latency, not throughput (a CU has ~200 rows per launch):
-//   * three levels of loads are in flight at the top of a phase -- this phase's neighbour rows, the next phase's neighbour ids,
-//     the row pointers of the phase after that -- so a phase waits for ONE memory round trip (it was three);
-//   * ONE barrier per phase: the LDS row tile and the logit partials are double-buffered, so the tile a phase writes is the
-//     one its slowest reader left two barriers ago;
-//   * the B operands of a phase's whole k loop are read from LDS in one batch in front of the MFMA chain;
-//   * results leave from the accumulators (no output tile): with M = 256 the A operand's rows are permuted so that a lane's two
-//     column tiles hold 8 CONSECUTIVE features -- feature 32 w + 8 q + 4 c + r for wave w, lane group q, tile c, register r --
-//     one 16-byte store per lane and row, 64 contiguous bytes per row and wave (proj_bf16_tile_kernel's map); M = 128: 8 bytes;
-//   * the next convolution's attention logits in proj_bf16_tile_kernel's association (so a blocked launch gives the bits of
-//     the per-op pair): every lane leaves its 4-term fma dots in LDS, and one phase LATER (behind that phase's barrier) a
-//     thread per (row, head, quarter) adds a quarter's eight dots in that kernel's order, the quarters as (q0 + q1) + (q2 + q3).
+// ONE 1024-thread workgroup per CU.  LDS: W [M][K + 8] bf16 in proj_bf16_tile_kernel's permuted layout (staged once), the
+// next convolution's attention vectors, and a DOUBLE-BUFFERED tile of the phase's rows.
+// Sparse stage: K / 8 lanes per row, RW = 64 / (K / 8) rows per wave at a time; a wave gathers TWO such row sets per phase with
+// the loads of both in flight together (a CU holds ~200 rows of a C-Town batch of 128: what a phase costs is one memory round
+// trip, so rows per round trip is what counts), 16 waves -> a PHASE is 64 (K = 256) or 128 (K = 128) rows = RT = 4 or 8 row tiles.
+// The next phase's row pointers are requested behind this phase's row loads, its neighbour ids behind this phase's arithmetic.
+// Dense stage (behind ONE barrier per phase): wave w < RT takes row tile w through proj_bf16_tile_kernel's own inner loop --
+// B fragments from the LDS tile instead of HBM, passes of 128 columns, the same accumulator-to-feature map, logits and
+// epilogue -- so a blocked launch gives the BITS of the per-op pair; the other waves go on to the next phase's rows (the tile a
+// phase writes is the one whose readers passed the barrier in between).
 template <int KIND, int K, int M, int HIN, bool RELU, int EPI, int HOUT>
-__global__ __launch_bounds__(512, 4) void blocked_kernel(const BlockedArgs a) {
-  constexpr int KS = K / 32, KP = K + 8, LPR = K / 8, RW = 64 / LPR, ROWS = 8 * RW, RT = ROWS / 16, CTW = M / 128, NE = 32 * CTW;
+__global__ __launch_bounds__(1024) void blocked_kernel(const BlockedArgs a) {
+  constexpr int KS = K / 32, KP = K + 8, LPR = K / 8, RW = 64 / LPR, SETROWS = 16 * RW, ROWS = 2 * SETROWS, RT = ROWS / 16;
+  constexpr int WC = 128, C = M / HOUT;
   static_assert((K == 128 || K == 256) && (M == 128 || M == 256), "gatres_large shapes");
-  static_assert(EPI != BE_ATT || M / HOUT == 128, "heads of 128 columns");
-  __shared__ __attribute__((aligned(16))) gatres_bf16 xt[2][ROWS * KP];            // a phase's rows (MFMA B operand), double-buffered
-  __shared__ float dl[EPI == BE_ATT ? 2 : 1][2][EPI == BE_ATT ? ROWS * NE : 1];    // BE_ATT: [buffer][src | dst][row][dot]
+  static_assert(EPI != BE_ATT || C == 128, "a pass of 128 columns is one head");
+  __shared__ __attribute__((aligned(16))) gatres_bf16 wl[M * KP];
+  __shared__ __attribute__((aligned(16))) gatres_bf16 xt[2][ROWS * KP];
+  __shared__ __attribute__((aligned(16))) float attl[2 * M];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int i = lane & 15, q = lane >> 4;
   const int N = a.N, nph = (N + ROWS - 1) / ROWS;
@@ -384,7 +369,7 @@ __global__ __launch_bounds__(512, 4) void blocked_kernel(const BlockedArgs a) {
   const int p_lo = (int)((long long)nph * wb / gridDim.x), p_hi = (int)((long long)nph * (wb + 1) / gridDim.x);
   if (p_lo >= p_hi) return;
   const int lr = lane & (LPR - 1);
-  const int rr = wave * RW + lane / LPR;                  // this lane's row within a phase
+  const int rr0 = wave * RW + lane / LPR, rr1 = SETROWS + rr0;          // this lane's two rows within a phase
   using Idx = std::conditional_t<KIND == BK_GAT_FWD, IdxGat, std::conditional_t<KIND == BK_MEAN_FWD, IdxMean, IdxSrc>>;
   auto idx1 = [&](int row, Idx& x) {
     if constexpr (KIND == BK_GAT_FWD) bk_idx1_gat<K, HIN>(a, row, lr, x);
@@ -396,168 +381,146 @@ __global__ __launch_bounds__(512, 4) void blocked_kernel(const BlockedArgs a) {
     else if constexpr (KIND == BK_MEAN_FWD) bk_idx2_mean(a, row, x);
     else bk_idx2_src(a, row, x);
   };
-  auto row_of = [&](int ph) { return min(min(ph, p_hi - 1) * ROWS + rr, N - 1); };
-  Idx cur, nxt, nn;
-  idx1(row_of(p_lo), cur);
-  idx1(row_of(p_lo + 1), nxt);
-  // W fragments: A operand of v_mfma_f32_16x16x32_bf16 -- lane (i, q) holds row i of the column tile, k chunk q of step s.
-  // Row m of tile c is W's row for the feature the accumulators of (tile c, m) stand for (see the header).
-  bf16x8 wreg[CTW][KS];
+  auto row_of = [&](int ph, int rr) { return min(min(ph, p_hi - 1) * ROWS + rr, N - 1); };
+  Idx c0, c1, n0, n1;
+  idx1(row_of(p_lo, rr0), c0);
+  idx1(row_of(p_lo, rr1), c1);
+  {
+    // W -> LDS, proj_bf16_tile_kernel's image: LDS row l = 128 p + 16 t + a holds W row 128 p + 32 (t >> 1) + 8 (a >> 2) +
+    // 4 (t & 1) + (a & 3); four 16-byte loads in flight per thread, then their LDS stores
+    constexpr int CH = M * (K / 8), PER = CH / 1024;
+    static_assert(CH % 1024 == 0 && PER <= 8, "W chunks per thread");
+    uint4 v[PER];
 #pragma unroll
-  for (int c = 0; c < CTW; ++c) {
-    const int wrow = CTW == 2 ? 32 * wave + 8 * (i >> 2) + 4 * c + (i & 3) : 16 * wave + i;
+    for (int u = 0; u < PER; ++u) {
+      const int idx = threadIdx.x + 1024 * u;
+      const int l = idx / (K / 8), k8 = (idx % (K / 8)) * 8;
+      const int lw = l % WC, t = lw >> 4, aa = lw & 15;
+      const int m = (l / WC) * WC + 32 * (t >> 1) + 8 * (aa >> 2) + 4 * (t & 1) + (aa & 3);
+      v[u] = *reinterpret_cast<const uint4*>(a.W + (size_t)m * K + k8);
+    }
 #pragma unroll
-    for (int s = 0; s < KS; ++s) wreg[c][s] = *reinterpret_cast<const bf16x8*>(a.W + (size_t)wrow * K + s * 32 + q * 8);
-  }
-  idx2(row_of(p_lo), cur);
-#ifdef BK_STAMPS
-  const bool stamp_on = (wb == 0 || wb == 100) && threadIdx.x == 0;
-  int stamp_base = (wb == 0 ? 0 : 2048);
-  if (stamp_on) g_bk_stamps[stamp_base + 1000] = bk_time(0.f);
-#endif
-  // the attention logits of the phase BEFORE `ph` (rows from prow0), from the dots that phase left in dl[pb]
-  auto logits_of = [&](int prow0, int pb) {
+    for (int u = 0; u < PER; ++u) {
+      const int idx = threadIdx.x + 1024 * u;
+      const int l = idx / (K / 8), k8 = (idx % (K / 8)) * 8;
+      *reinterpret_cast<uint4*>(wl + l * KP + k8) = v[u];
+    }
     if constexpr (EPI == BE_ATT) {
-      if ((int)threadIdx.x < ROWS * HOUT * 4) {
-        const int qq = (int)threadIdx.x & 3, hd = ((int)threadIdx.x >> 2) % HOUT, lrr = (int)threadIdx.x / (4 * HOUT);
-        const int lrow = prow0 + lrr;
-        float ps = 0.f, pd = 0.f;
-#pragma unroll
-        for (int tt = 0; tt < 8; ++tt) {
-          const int jb = tt >> 1, hh = tt & 1;
-          // the dot of features 128 hd + 32 jb + 8 qq + 4 hh + [0, 4): which (wave, lane group, tile) formed it
-          const int e = CTW == 2 ? ((hd * 4 + jb) * 4 + qq) * 2 + hh : (2 * jb + (qq >> 1)) * 4 + 2 * (qq & 1) + hh;
-          ps += dl[pb][0][lrr * NE + e];
-          pd += dl[pb][1][lrr * NE + e];
-        }
-        ps += __shfl_xor(ps, 1); ps += __shfl_xor(ps, 2);
-        pd += __shfl_xor(pd, 1); pd += __shfl_xor(pd, 2);
-        if (qq == 0 && lrow < N) { a.a_src_out[lrow * HOUT + hd] = ps; a.a_dst_out[lrow * HOUT + hd] = pd; }
+      if ((int)threadIdx.x < 2 * (M / 4)) {
+        const int which = (int)threadIdx.x / (M / 4), c4 = ((int)threadIdx.x % (M / 4)) * 4;
+        st4(attl + which * M + c4, ld4((which ? a.att_d_out : a.att_s_out) + c4));
       }
     }
-  };
+  }
+  idx2(row_of(p_lo, rr0), c0);
+  idx2(row_of(p_lo, rr1), c1);
+  const float* attS = attl;
+  const float* attD = attl + M;
   for (int ph = p_lo; ph < p_hi; ++ph) {
     const int row0 = ph * ROWS, buf = (ph - p_lo) & 1;
     gatres_bf16* xtb = xt[buf];
-    // ---- sparse stage: this phase's rows -> HBM and the LDS tile; behind the issue of their loads, the next phase's
-    // neighbour ids and the row pointers of the phase after it
-    const int row = row_of(ph), nrow1 = row_of(ph + 1), nrow2 = row_of(ph + 2);
-    const bool valid = row0 + rr < N;
-    auto after_issue = [&] { idx2(nrow1, nxt); idx1(nrow2, nn); };
-    BKSTAMP(0, 0.f);
-    Row8 o;
+    // ---- sparse stage: both row sets of the phase -> HBM and the LDS tile
+    const int r0 = row_of(ph, rr0), r1 = row_of(ph, rr1), nr0 = row_of(ph + 1, rr0), nr1 = row_of(ph + 1, rr1);
+    const bool valid0 = row0 + rr0 < N, valid1 = row0 + rr1 < N;
+    Row8 o0, o1;
 #ifdef BK_PROBE_NO_GATHER            // (probe build, WRONG results: what a launch costs without its sparse stage)
-    o = row8_zero(); o.lo.x = (float)row; (void)after_issue; nn = nxt;
+    o0 = row8_zero(); o0.lo.x = (float)r0; o1 = o0; n0 = c0; n1 = c1;
 #else
-    if constexpr (KIND == BK_GAT_FWD) o = bk_gat_fwd<K, HIN, RELU>(a, cur, valid, lr, after_issue);
-    else if constexpr (KIND == BK_MEAN_FWD) o = bk_mean_fwd<K>(a, cur, row, lr, after_issue);
-    else o = bk_gat_bwd_src<K, HIN>(a, cur, row, valid, lr, after_issue);
+    {
+      auto last = [&] { idx1(nr0, n0); idx1(nr1, n1); };          // (behind the issue of BOTH sets' row loads)
+      auto second = [&] {
+        if constexpr (KIND == BK_GAT_FWD) o1 = bk_gat_fwd<K, HIN, RELU>(a, c1, valid1, lr, last);
+        else if constexpr (KIND == BK_MEAN_FWD) o1 = bk_mean_fwd<K>(a, c1, r1, lr, last);
+        else o1 = bk_gat_bwd_src<K, HIN>(a, c1, r1, valid1, lr, last);
+      };
+      if constexpr (KIND == BK_GAT_FWD) o0 = bk_gat_fwd<K, HIN, RELU>(a, c0, valid0, lr, second);
+      else if constexpr (KIND == BK_MEAN_FWD) o0 = bk_mean_fwd<K>(a, c0, r0, lr, second);
+      else o0 = bk_gat_bwd_src<K, HIN>(a, c0, r0, valid0, lr, second);
+    }
+    idx2(nr0, n0);
+    idx2(nr1, n1);
 #endif
-    BKSTAMP(1, o.lo.x + o.hi.w);
-    const bf16x8 ob = pack8(o);
-    if (valid) *reinterpret_cast<bf16x8*>(a.mid + (size_t)row * K + lr * 8) = ob;
-    *reinterpret_cast<bf16x8*>(xtb + rr * KP + lr * 8) = ob;         // (rows beyond N: a copy of the last row, never stored)
-    cur = nxt; nxt = nn;
+    {
+      const bf16x8 b0 = pack8(o0), b1 = pack8(o1);
+      if (valid0) *reinterpret_cast<bf16x8*>(a.mid + (size_t)r0 * K + lr * 8) = b0;
+      if (valid1) *reinterpret_cast<bf16x8*>(a.mid + (size_t)r1 * K + lr * 8) = b1;
+      *reinterpret_cast<bf16x8*>(xtb + rr0 * KP + lr * 8) = b0;       // (rows beyond N: a copy of the last row, never stored)
+      *reinterpret_cast<bf16x8*>(xtb + rr1 * KP + lr * 8) = b1;
+    }
+    c0 = n0; c1 = n1;
 #ifdef BK_PROBE_NO_DENSE             // (probe build, WRONG results: the sparse stage alone, phase after phase)
     continue;
 #endif
-    // the epilogue's operands (8 or 16 bytes per lane and row tile), requested in front of the barrier
-    const int fb = CTW == 2 ? 32 * wave + 8 * q : 16 * wave + 4 * q;          // this lane's first feature
-    uint4 rraw[RT], mraw[RT];
-    if constexpr (EPI == BE_RESID_MASK) {
-#pragma unroll
-      for (int rt = 0; rt < RT; ++rt) {
-        const size_t off = (size_t)min(row0 + rt * 16 + i, N - 1) * M + fb;
-        rraw[rt] = make_uint4(0u, 0u, 0u, 0u); mraw[rt] = make_uint4(0u, 0u, 0u, 0u);
-        if constexpr (CTW == 2) {
-          if (a.resid) rraw[rt] = ld_raw8(a.resid + off);
-          if (a.relu_ref) mraw[rt] = ld_raw8(a.relu_ref + off);
-        } else {
-          if (a.resid) { const uint2 u = *reinterpret_cast<const uint2*>(a.resid + off); rraw[rt].x = u.x; rraw[rt].y = u.y; }
-          if (a.relu_ref) { const uint2 u = *reinterpret_cast<const uint2*>(a.relu_ref + off); mraw[rt].x = u.x; mraw[rt].y = u.y; }
-        }
-      }
-    }
-    BKSTAMP(2, 0.f);
     __syncthreads();
-    BKSTAMP(3, 0.f);
-    if (ph > p_lo) logits_of(row0 - ROWS, buf ^ 1);
-    BKSTAMP(4, 0.f);
-    // ---- dense stage: every B fragment of the phase in one batch, then the MFMA chains
-    bf16x8 xf[RT][KS];
+    // ---- dense stage: proj_bf16_tile_kernel's inner loop.  A work ITEM is (row tile, chunk of NTW column tiles): NTW = 8 -- one
+    // head, so the logits reduce inside the wave -- for the projections with logits, 4 for the input gradients (their epilogue
+    // holds a residual and a ReLU-reference row piece per pair of tiles: half the registers); items go round the 16 waves.
+    constexpr int NTW = EPI == BE_ATT ? 8 : 4, CHUNKS = M / (16 * NTW), ITEMS = RT * CHUNKS;
+    for (int it = wave; it < ITEMS; it += 16) {
+      const int rt = it / CHUNKS, tb = (it % CHUNKS) * NTW;            // first column tile of the chunk
+      const int n = row0 + rt * 16 + i;
+      const bool nok = n < N;
+      bf16x8 xf[KS];
 #pragma unroll
-    for (int rt = 0; rt < RT; ++rt)
-#pragma unroll
-      for (int s = 0; s < KS; ++s) xf[rt][s] = *reinterpret_cast<const bf16x8*>(xtb + (rt * 16 + i) * KP + s * 32 + q * 8);
-    f32x4 acc[RT][CTW];
-#pragma unroll
-    for (int rt = 0; rt < RT; ++rt)
-#pragma unroll
-      for (int c = 0; c < CTW; ++c) acc[rt][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int s = 0; s < KS; ++s)
-#pragma unroll
-      for (int rt = 0; rt < RT; ++rt)
-#pragma unroll
-        for (int c = 0; c < CTW; ++c) acc[rt][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wreg[c][s], xf[rt][s], acc[rt][c], 0, 0, 0);
-    // acc[rt][c][r] = output feature fb + 4 c + r of row rt 16 + i
-    BKSTAMP(5, acc[0][0][0] + acc[RT - 1][CTW - 1][3]);
-#pragma unroll
-    for (int rt = 0; rt < RT; ++rt) {
-      const int orow = row0 + rt * 16 + i;
-      if constexpr (EPI == BE_ATT) {
-#pragma unroll
-        for (int c = 0; c < CTW; ++c) {
-          const float4 as = ld4(a.att_s_out + fb + 4 * c), ad = ld4(a.att_d_out + fb + 4 * c);
-          const int e = CTW == 2 ? (wave * 4 + q) * 2 + c : wave * 4 + q;
-          dl[buf][0][(rt * 16 + i) * NE + e] = fmaf(acc[rt][c][3], as.w, fmaf(acc[rt][c][2], as.z, fmaf(acc[rt][c][1], as.y, acc[rt][c][0] * as.x)));
-          dl[buf][1][(rt * 16 + i) * NE + e] = fmaf(acc[rt][c][3], ad.w, fmaf(acc[rt][c][2], ad.z, fmaf(acc[rt][c][1], ad.y, acc[rt][c][0] * ad.x)));
-        }
-      }
-      float4 o4[CTW];
-#pragma unroll
-      for (int c = 0; c < CTW; ++c) o4[c] = make_float4(acc[rt][c][0], acc[rt][c][1], acc[rt][c][2], acc[rt][c][3]);
+      for (int s = 0; s < KS; ++s) xf[s] = *reinterpret_cast<const bf16x8*>(xtb + (rt * 16 + i) * KP + s * 32 + q * 8);
+      const size_t rowo = (size_t)min(n, N - 1) * M + 16 * tb + q * 8;
+      const gatres_bf16* wbase = wl + (size_t)(16 * tb + i) * KP + q * 8;
+      uint4 rraw[EPI == BE_RESID_MASK ? NTW / 2 : 1], mraw[EPI == BE_RESID_MASK ? NTW / 2 : 1];
       if constexpr (EPI == BE_RESID_MASK) {
-        if (a.resid) {
-          add4(o4[0], widen_lo(rraw[rt]));
-          if constexpr (CTW == 2) add4(o4[1], widen_hi(rraw[rt]));
-        }
-        if (a.relu_ref) {
-          const float4 ra = widen_lo(mraw[rt]);
-          o4[0].x = ra.x > 0.f ? o4[0].x : 0.f; o4[0].y = ra.y > 0.f ? o4[0].y : 0.f;
-          o4[0].z = ra.z > 0.f ? o4[0].z : 0.f; o4[0].w = ra.w > 0.f ? o4[0].w : 0.f;
-          if constexpr (CTW == 2) {
-            const float4 rb = widen_hi(mraw[rt]);
-            o4[1].x = rb.x > 0.f ? o4[1].x : 0.f; o4[1].y = rb.y > 0.f ? o4[1].y : 0.f;
-            o4[1].z = rb.z > 0.f ? o4[1].z : 0.f; o4[1].w = rb.w > 0.f ? o4[1].w : 0.f;
-          }
+#pragma unroll
+        for (int t = 0; t < NTW; t += 2) {
+          if (a.resid) rraw[t / 2] = *reinterpret_cast<const uint4*>(a.resid + rowo + 16 * t);
+          if (a.relu_ref) mraw[t / 2] = *reinterpret_cast<const uint4*>(a.relu_ref + rowo + 16 * t);
         }
       }
-      if (orow < N) {
-        if constexpr (CTW == 2) {
-          Row8 ov; ov.lo = o4[0]; ov.hi = o4[1];
-          *reinterpret_cast<bf16x8*>(a.out + (size_t)orow * M + fb) = pack8(ov);
-        } else {
-          bf16x4 b4;
-          b4[0] = (gatres_bf16)o4[0].x; b4[1] = (gatres_bf16)o4[0].y; b4[2] = (gatres_bf16)o4[0].z; b4[3] = (gatres_bf16)o4[0].w;
-          *reinterpret_cast<bf16x4*>(a.out + (size_t)orow * M + fb) = b4;
+      f32x4 acc[NTW];
+#pragma unroll
+      for (int t = 0; t < NTW; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int s = 0; s < KS; ++s) {
+        bf16x8 wf[NTW];
+#pragma unroll
+        for (int t = 0; t < NTW; ++t) wf[t] = *reinterpret_cast<const bf16x8*>(wbase + (size_t)(t * 16) * KP + s * 32);
+#pragma unroll
+        for (int t = 0; t < NTW; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[t], xf[s], acc[t], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      // acc[t][reg] = output feature 16 (tb + t - ((tb + t) & 1)) + 8 q + 4 ((tb + t) & 1) + reg of row n  (tb is even)
+      if constexpr (EPI == BE_ATT) {
+        const int hd = tb / 8;                           // (a chunk is one head)
+        float ps = 0.f, pd = 0.f;
+#pragma unroll
+        for (int t = 0; t < NTW; ++t) {
+          const int mb = 16 * tb + 32 * (t >> 1) + 8 * q + 4 * (t & 1);
+          const float4 as = ld4(attS + mb), ad = ld4(attD + mb);
+          ps += fmaf(acc[t][3], as.w, fmaf(acc[t][2], as.z, fmaf(acc[t][1], as.y, acc[t][0] * as.x)));
+          pd += fmaf(acc[t][3], ad.w, fmaf(acc[t][2], ad.z, fmaf(acc[t][1], ad.y, acc[t][0] * ad.x)));
+        }
+        ps += __shfl_xor(ps, 16); ps += __shfl_xor(ps, 32);
+        pd += __shfl_xor(pd, 16); pd += __shfl_xor(pd, 32);
+        if (q == 0 && nok) { a.a_src_out[n * HOUT + hd] = ps; a.a_dst_out[n * HOUT + hd] = pd; }
+      }
+      if (nok) {
+#pragma unroll
+        for (int t = 0; t < NTW; t += 2) {
+          Row8 ov;
+          ov.lo = make_float4(acc[t][0], acc[t][1], acc[t][2], acc[t][3]);
+          ov.hi = make_float4(acc[t + 1][0], acc[t + 1][1], acc[t + 1][2], acc[t + 1][3]);
+          if constexpr (EPI == BE_RESID_MASK) {
+            if (a.resid) { add4(ov.lo, widen_lo(rraw[t / 2])); add4(ov.hi, widen_hi(rraw[t / 2])); }
+            if (a.relu_ref) {
+              const float4 ra = widen_lo(mraw[t / 2]), rb = widen_hi(mraw[t / 2]);
+              ov.lo.x = ra.x > 0.f ? ov.lo.x : 0.f; ov.lo.y = ra.y > 0.f ? ov.lo.y : 0.f;
+              ov.lo.z = ra.z > 0.f ? ov.lo.z : 0.f; ov.lo.w = ra.w > 0.f ? ov.lo.w : 0.f;
+              ov.hi.x = rb.x > 0.f ? ov.hi.x : 0.f; ov.hi.y = rb.y > 0.f ? ov.hi.y : 0.f;
+              ov.hi.z = rb.z > 0.f ? ov.hi.z : 0.f; ov.hi.w = rb.w > 0.f ? ov.hi.w : 0.f;
+            }
+          }
+          *reinterpret_cast<bf16x8*>(a.out + (size_t)n * M + 16 * (tb + t) + q * 8) = pack8(ov);
         }
       }
     }
-    BKSTAMP(6, 0.f);
-#ifdef BK_STAMPS
-    stamp_base += 8;
-#endif
   }
-#ifdef BK_STAMPS
-  if (stamp_on) g_bk_stamps[(wb == 0 ? 0 : 2048) + 1001] = bk_time(0.f);
-#endif
-#ifndef BK_PROBE_NO_DENSE
-  if constexpr (EPI == BE_ATT) {
-    __syncthreads();                                      // the last phase's dots
-    logits_of((p_hi - 1) * ROWS, (p_hi - 1 - p_lo) & 1);
-  }
-#endif
 }
 
 static inline bool blocked_shape_ok(const gatres_graph_t* g, int nc) {
@@ -569,8 +532,8 @@ static inline unsigned blocked_grid(int N) {
   int dev = 0, cus = 0;
   if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
     cus = 256;
-  const int phases = (N + 31) / 32, want = 2 * cus;            // two workgroups per CU; never more workgroups than 32-row phases
-  return (unsigned)(phases < want ? phases : want);
+  const int phases = (N + 127) / 128;                          // one workgroup per CU; never more workgroups than 128-row phases
+  return (unsigned)(phases < cus ? phases : cus);
 }
 
 }  // namespace
@@ -595,7 +558,7 @@ extern "C" int gatres_bf16_agg_proj_fwd(const gatres_graph_t* g, const void* h, 
   a.rowptr = g->rowptr; a.col = g->col; a.src = (const gatres_bf16*)h; a.a_src = a_src; a.a_dst = a_dst; a.bias = bias;
   a.alpha = alpha; a.mid = (gatres_bf16*)o; a.W = (const gatres_bf16*)W_next; a.out = (gatres_bf16*)h_next;
   a.att_s_out = att_src_next; a.att_d_out = att_dst_next; a.a_src_out = a_src_next; a.a_dst_out = a_dst_next; a.N = g->num_nodes;
-  hipLaunchKernelGGL((blocked_kernel<BK_GAT_FWD, 256, 128, 2, true, BE_ATT, 1>), dim3(blocked_grid(a.N)), dim3(512), 0,
+  hipLaunchKernelGGL((blocked_kernel<BK_GAT_FWD, 256, 128, 2, true, BE_ATT, 1>), dim3(blocked_grid(a.N)), dim3(1024), 0,
                      gatres_stream(stream), a);
   return gatres_launch_status();
 }
@@ -614,7 +577,7 @@ extern "C" int gatres_bf16_mean_proj_fwd(const gatres_graph_t* g, const void* y,
   a.rowptr = g->m_rowptr; a.col = g->m_col; a.src = (const gatres_bf16*)y; a.x0 = (const gatres_bf16*)x0;
   a.mid = (gatres_bf16*)x_next; a.W = (const gatres_bf16*)W_next; a.out = (gatres_bf16*)h_next;
   a.att_s_out = att_src_next; a.att_d_out = att_dst_next; a.a_src_out = a_src_next; a.a_dst_out = a_dst_next; a.N = g->num_nodes;
-  hipLaunchKernelGGL((blocked_kernel<BK_MEAN_FWD, 128, 256, 1, false, BE_ATT, 2>), dim3(blocked_grid(a.N)), dim3(512), 0,
+  hipLaunchKernelGGL((blocked_kernel<BK_MEAN_FWD, 128, 256, 1, false, BE_ATT, 2>), dim3(blocked_grid(a.N)), dim3(1024), 0,
                      gatres_stream(stream), a);
   return gatres_launch_status();
 }
@@ -637,16 +600,10 @@ extern "C" int gatres_bf16_src_dx_bwd(const gatres_graph_t* g, const void* g_out
   a.W = (const gatres_bf16*)Wt; a.out = (gatres_bf16*)g_x; a.resid = (const gatres_bf16*)resid;
   a.relu_ref = (const gatres_bf16*)relu_ref; a.N = g->num_nodes;
   if (H == 1)
-    hipLaunchKernelGGL((blocked_kernel<BK_GAT_BWD_SRC, 128, 256, 1, false, BE_RESID_MASK, 1>), dim3(blocked_grid(a.N)), dim3(512), 0,
+    hipLaunchKernelGGL((blocked_kernel<BK_GAT_BWD_SRC, 128, 256, 1, false, BE_RESID_MASK, 1>), dim3(blocked_grid(a.N)), dim3(1024), 0,
                        gatres_stream(stream), a);
   else
-    hipLaunchKernelGGL((blocked_kernel<BK_GAT_BWD_SRC, 256, 128, 2, false, BE_RESID_MASK, 1>), dim3(blocked_grid(a.N)), dim3(512), 0,
+    hipLaunchKernelGGL((blocked_kernel<BK_GAT_BWD_SRC, 256, 128, 2, false, BE_RESID_MASK, 1>), dim3(blocked_grid(a.N)), dim3(1024), 0,
                        gatres_stream(stream), a);
   return gatres_launch_status();
 }
-
-#ifdef BK_STAMPS
-extern "C" int gatres_probe_bk_stamps(unsigned long long* out_host) {
-  return (int)hipMemcpyFromSymbol(out_host, HIP_SYMBOL(g_bk_stamps), sizeof(unsigned long long) * 4096);
-}
-#endif

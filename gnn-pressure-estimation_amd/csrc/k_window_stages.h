@@ -417,7 +417,11 @@ __device__ __forceinline__ void win_proj(Rows rw, const float* X, const float* w
     unsigned ad[XR + WR];
     f32x4 fr[XR + WR];
 #pragma unroll
+#ifdef GATRES_PROBE_XPAD      // (timing probe, WRONG results: the x operand read as if its rows were K + 4 floats apart -- no bank conflicts)
+    for (int s = 0; s < XR; ++s) ad[s] = a_x + (unsigned)((min(r, rw.hi - 1) - rw.lo) * (K + 4) + rw.lo * K + 4 * s) * 4u;
+#else
     for (int s = 0; s < XR; ++s) ad[s] = a_x + (unsigned)(min(r, rw.hi - 1) * K + 4 * s) * 4u;
+#endif
 #pragma unroll
     for (int tt = 0; tt < NTG; ++tt)
 #pragma unroll

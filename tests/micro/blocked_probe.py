@@ -71,28 +71,3 @@ for name, pf, bfn in (("agg1 + proj2", pair_agg, blk_agg), ("mean + proj1", pair
     tp = timeit([lambda d=d: pf(d) for d in sets])
     tb = timeit([lambda d=d: bfn(d) for d in sets])
     print(f"{name:14s}  per-op pair {tp:7.2f} us   blocked {tb:7.2f} us   ({(tp - tb):+6.2f})")
-
-if "--stamps" in sys.argv:               # lib/probe_bk_st.so: per-phase timeline of workgroup 0 / 100, wave 0 (10-ns clock)
-    import ctypes as C, numpy as np
-    raw = C.CDLL(sys.argv[sys.argv.index("--lib") + 1])
-    names = ["top", "rows arrived + arithmetic", "stores + LDS tile", "barrier", "logits of prev", "LDS reads + MFMA", "epilogue + stores"]
-    for name, bfn in (("agg1 + proj2", blk_agg), ("mean + proj1", blk_mean), ("src2 + dx2", blk_src2), ("src1 + dx1", blk_src1)):
-        for _ in range(3):
-            bfn(sets[0])
-        torch.cuda.synchronize()
-        buf = (C.c_ulonglong * 4096)()
-        raw.gatres_probe_bk_stamps(buf)
-        st_ = np.array(buf[:], dtype=np.int64)
-        for base in (0, 2048):
-            t_start, t_end = st_[base + 1000], st_[base + 1001]
-            rows_ = []
-            k = 0
-            while k < 100 and st_[base + 8 * k] >= t_start and st_[base + 8 * k + 6] <= t_end and st_[base + 8 * k] > 0:
-                rows_.append(st_[base + 8 * k: base + 8 * k + 7]); k += 1
-            if not rows_:
-                continue
-            arr = np.array(rows_)
-            seg = np.diff(arr, axis=1) / 100.0
-            print(f"{name} wg {0 if base == 0 else 100}: {len(rows_)} phases, kernel body {(t_end - t_start) / 100.0:.2f} us; prologue {(arr[0, 0] - t_start) / 100.0:.2f} us")
-            for kk, nm in enumerate(names[1:]):
-                print(f"    {nm:28s} mean {seg[:, kk].mean():6.2f} us   per phase: " + " ".join(f"{v:5.2f}" for v in seg[:, kk]))
