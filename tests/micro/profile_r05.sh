@@ -25,11 +25,14 @@ timeout 300 $B --no-cpu-baseline --from-store 2>/dev/null | tail -1 > $O/from_st
 timeout 300 $B --no-cpu-baseline --host-batches 2>/dev/null | tail -1 > $O/host_batches.json; python3 -c "$short" < $O/host_batches.json
 timeout 300 $B --no-cpu-baseline --per-op 2>/dev/null | tail -1 > $O/per_op.json; python3 -c "$short" < $O/per_op.json
 timeout 300 $B --no-cpu-baseline --no-roofline --force-collective-path 2>/dev/null | tail -1 > $O/collective_path_1rank.json; python3 -c "$short" < $O/collective_path_1rank.json
+timeout 300 $B --no-cpu-baseline --no-roofline --graph-steps 1 2>/dev/null | tail -1 > $O/one_step_per_graph.json; python3 -c "$short" < $O/one_step_per_graph.json
+timeout 200 python3 tests/micro/slab_reduce_probe.py > $O/slab_reduce_probe.txt 2>&1; cat $O/slab_reduce_probe.txt
 # ---- the launcher path: 2 ranks on this one GPU (test overrides: gloo, shared device)
 GATRES_DIST_BACKEND=gloo GATRES_BENCH_SHARE_GPU=1 timeout 600 $B --gpus 2 --batch-size 8 --steps 50 --warmup 5 --no-cpu-baseline --no-roofline 2>/dev/null | tail -1 > $O/launcher_2ranks_one_gpu.json; python3 -c "$short" < $O/launcher_2ranks_one_gpu.json
 # ---- config 3 (gatres_large, C-Town, bs 128, bf16): bench line, kernel stats, counters incl. MFMA utilisation
-timeout 600 $B --no-cpu-baseline --model gatres_large --batch-size 128 --steps 50 --warmup 10 --dtype bf16 2>/dev/null | tail -1 > $O/large_bf16.json; python3 -c "$short" < $O/large_bf16.json
 timeout 600 $B --no-cpu-baseline --model gatres_large --batch-size 128 --steps 20 --warmup 5 2>/dev/null | tail -1 > $O/large_fp32.json; python3 -c "$short" < $O/large_fp32.json
+GATRES_BLOCKED=1 timeout 600 $B --no-cpu-baseline --no-roofline --model gatres_large --batch-size 128 --steps 50 --warmup 10 --dtype bf16 2>/dev/null | tail -1 > $O/large_bf16_blocked.json; python3 -c "$short" < $O/large_bf16_blocked.json
+timeout 200 python3 tests/micro/blocked_probe.py > $O/blocked_probe.txt 2>&1; tail -4 $O/blocked_probe.txt
 L="$B --model gatres_large --batch-size 128 --steps 4 --warmup 2 --dtype bf16 --no-cpu-baseline --no-roofline"
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_l16 -o kt -- $B --model gatres_large --batch-size 128 --steps 10 --warmup 3 --dtype bf16 --no-cpu-baseline --no-roofline > $O/kt_l16.log 2>&1
 python3 tests/micro/summarize_prof.py stats $O/kt_l16 $O/large_bf16_kernel_stats.csv
@@ -38,6 +41,8 @@ timeout 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/lc -o s -- $L >
 timeout 300 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_BF16 GRBM_GUI_ACTIVE --output-format csv -d $O/la -o s -- $L > $O/la.log 2>&1
 timeout 300 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_VALU_MFMA_MOPS_F32 --output-format csv -d $O/ld -o s -- $L > $O/ld.log 2>&1
 python3 tests/micro/collect_r05.py large_pmc $O
+# (the bench line of config 3 AFTER its counter file exists: it attaches the HBM-side rates of the per-op kernels from it)
+timeout 600 $B --no-cpu-baseline --model gatres_large --batch-size 128 --steps 50 --warmup 10 --dtype bf16 2>/dev/null | tail -1 > $O/large_bf16.json; python3 -c "$short" < $O/large_bf16.json
 timeout 900 $B --no-cpu-baseline --model gatres_large --nodes 50000 --pipes 75000 --batch-size 2 --steps 10 --warmup 3 --dtype bf16 2>/dev/null | tail -1 > $O/large_50k_bs2_bf16.json; python3 -c "$short" < $O/large_50k_bs2_bf16.json
 timeout 900 $B --no-cpu-baseline --nodes 50000 --pipes 75000 --batch-size 16 --steps 10 --warmup 3 2>/dev/null | tail -1 > $O/small_50k_bs16.json; python3 -c "$short" < $O/small_50k_bs16.json
 rm -rf $O/kt $O/pmc_fetch $O/pmc_write $O/pmc_sq $O/pmc_inst $O/kt_l16 $O/la $O/lb $O/lc $O/ld

@@ -554,9 +554,19 @@ def test_golden_vectors(pkg, name, fused):
     assert relerr(tr.out, torch.from_numpy(d["out"])) < 1e-5
     assert relerr(loss, torch.tensor(float(d["loss"]))) < 1e-5
     assert relerr(tr.grads, torch.from_numpy(d["grads"])) < 1e-5
-    assert float((model.flat_parameters.cpu() - torch.from_numpy(d["params_after"])).abs().max()) <= 2 * 5e-4
-    frac = float(((model.flat_parameters.cpu() - torch.from_numpy(d["params_after"])).abs() > 1e-5).double().mean())
-    assert frac < 0.01
+    # Parameters after the first Adam step, entry by entry (the old bound -- 1e-3 on up to 1 % of the entries --
+    # pinned little).  The first update is lr * g / (|g| + eps): its derivative in g is at most 1 / (|g| + eps), so an entry
+    # whose gradient differs from the fixture's by dg may differ by lr * dg / (|g| + eps) (x 2 for the curvature near g = 0)
+    # plus fp32 round-off of the parameter itself -- and by nothing else.
+    # (g here is the gradient Adam sees: the loss gradient + weight_decay * p, train.py:348)
+    lr, eps, wd = 5e-4, 1e-8, 6e-6
+    g_gold, g_hip = torch.from_numpy(d["grads"]).double(), tr.grads.detach().cpu().double()
+    p_gold, p_hip = torch.from_numpy(d["params_after"]).double(), model.flat_parameters.detach().cpu().double()
+    g_eff = g_gold + wd * torch.from_numpy(d["params"]).double()
+    allow = 2 * lr * (g_hip - g_gold).abs() / (g_eff.abs() + eps) + 4e-7 * (1 + p_gold.abs())
+    worst = float(((p_hip - p_gold).abs() - allow).max())
+    assert worst <= 0, worst
+    assert float((p_hip - p_gold).abs().max()) <= 2 * lr
 
 
 def test_collective_path_equals_single_call(pkg, oracle):
