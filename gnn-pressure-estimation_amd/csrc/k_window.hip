@@ -392,7 +392,9 @@ __global__ __launch_bounds__(THREADS) void gatres_window_kernel(const FusedArgs 
           seg_proj<NC, 2 * NC, 2, EPI_ATT, THREADS, true, true>(rw, xA, 0, pb + L.c1_W, base + SL.h1, 0, hA, 0, pb + L.c1_as,
                                                                  pb + L.c1_ad, base + SL.as1, base + SL.ad1, 0, sa2, sd2,
                                                                  nullptr, 0, nullptr, 0, wlA);
+#ifndef GATRES_PROBE_NO_FWD_LAND      // (timing probe, WRONG results: the forward's projection stages without the landing wait of the next W)
         dma_land(dw0);
+#endif
         lds_barrier();                                      // own rows of h1 / a_src are in LDS; the saved copies drain meanwhile
       }
       {
@@ -462,7 +464,9 @@ __global__ __launch_bounds__(THREADS) void gatres_window_kernel(const FusedArgs 
           seg_proj<2 * NC, NC, 1, EPI_ATT, THREADS, true, true>(rw, xB, 0, pb + L.c2_W, base + SL.h2, 0, hB, 0, pb + L.c2_as,
                                                                pb + L.c2_ad, base + SL.as2, base + SL.ad2, 0, sa1, sd1,
                                                                nullptr, 0, nullptr, 0, wlB);
+#ifndef GATRES_PROBE_NO_FWD_LAND
         dma_land(dw0);
+#endif
         lds_barrier();
       }
       {
@@ -976,7 +980,9 @@ __global__ __launch_bounds__(THREADS) void gatres_window_kernel(const FusedArgs 
         XSTAMP();
         STAMP();
       }
+#ifndef GATRES_PROBE_NO_BWD_DMA       // (timing probe, WRONG results: the backward's block loop without its LDS-DMA of saved tables)
       dma_conv1_early();
+#endif
       if (NC == 32 && a.keep_lds) {              // (the ReLU sign masks of the forward phase are in LDS: no global operand)
         if constexpr (NC == 32)
           if (wave_u < PW) {
@@ -1004,7 +1010,9 @@ __global__ __launch_bounds__(THREADS) void gatres_window_kernel(const FusedArgs 
             (GATRES_DIAG && (a.no_halo & 4)) ? nullptr : base + SL.o1, 0, wlA, nullptr, nullptr, mo1 ? mo1 + b * ow : nullptr,
             nullptr);
       }
+#ifndef GATRES_PROBE_NO_BWD_LAND      // (timing probe, WRONG results: the backward's dX stages without their LDS-DMA landing waits)
       dma_land(dw0);                             // the conv1 tables: the destination-major stage is next
+#endif
       lds_barrier();                             // (not __syncthreads(): its vmcnt(0) made the tile waves wait for their granule stores)
       XSTAMP();
       STAMP();
@@ -1059,7 +1067,9 @@ __global__ __launch_bounds__(THREADS) void gatres_window_kernel(const FusedArgs 
         XSTAMP();
         STAMP();
       }
+#ifndef GATRES_PROBE_NO_BWD_DMA
       if (b > 0) { dma_conv2_early(b - 1, dw0); dma_conv2_late(b - 1, dw0); }
+#endif
       if (NC == 32 && a.keep_lds) {
         if constexpr (NC == 32)
           if (wave_u < PW) {
@@ -1093,7 +1103,9 @@ __global__ __launch_bounds__(THREADS) void gatres_window_kernel(const FusedArgs 
           scale_g_pre<NC, THREADS>(gpT, mrp, lo, ow);
         }
       }
+#ifndef GATRES_PROBE_NO_BWD_LAND
       dma_land(dw0);
+#endif
       XSTAMP();
       STAMP();
       float* t = gp_cur; gp_cur = gp_nxt; gp_nxt = t;
