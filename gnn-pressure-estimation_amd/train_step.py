@@ -796,4 +796,10 @@ class GATResTrainer:
             seen += ng
         if seen == 0:
             raise ValueError("the store yielded no batch")
-        return float(total.item()) / seen, {k: v / seen for k, v in sums.items()}
+        mean_loss = float(total.item()) / seen
+        # a dropped step (a split launch whose workgroups were not co-resident) trained on nothing: an epoch that contains one
+        # is an error, not a slightly smaller epoch
+        self.check_no_dropped_steps()
+        for t in self._siblings.values():
+            t.check_no_dropped_steps()
+        return mean_loss, {k: v / seen for k, v in sums.items()}

@@ -289,6 +289,9 @@ def test_transient_fault_drops_one_step_only(pkg, oracle, use_graph):
     assert torch.equal(model.flat_parameters, before[0]) and torch.equal(tr.exp_avg, before[1])
     assert torch.equal(tr.exp_avg_sq, before[2]) and tr.optimizer_step == before[3]
     assert int(tr._status[0]) == 0 and tr.fault_count == 1
+    with pytest.raises(RuntimeError, match="DROPPED"):       # (round 5: drops are an error for whoever asks -- fit_epoch, bench.py)
+        tr.check_no_dropped_steps()
+    tr.check_no_dropped_steps()                              # ... reported once
     loss2 = tr.step(y, y, mask)
     twin, _, tr2, *_ = _small_setup(pkg, oracle, use_graph=False)
     for _ in range(3):
