@@ -14,9 +14,9 @@
 //      kernel's LDS image, the B fragments from the LDS tile): the same accumulator-to-feature map, logits and epilogue, so a
 //      blocked launch gives the BITS of the two per-op launches it replaces.
 // MEASURED (profiles/r05_blocked_probe.txt): bit-identical, and 5 - 15 % SLOWER than the per-op pairs in four forms of this
-// kernel -- a CU holds ~200 rows of a C-Town batch of 128, a launch is a chain of memory round trips either way, and fusing
-// puts the sparse chain and the dense chain of a row block in series inside one workgroup where the per-op kernels run 20
-// independent waves per CU.  The per-op drivers therefore take these kernels only on request (GATRES_BLOCKED=1).
+// kernel, at 194, 390 and 780 rows per CU alike -- a launch is a chain of memory round trips either way, and fusing puts the
+// sparse chain and the dense chain of a row block in series inside one workgroup where the per-op kernels run 20 independent
+// waves per CU.  The per-op drivers therefore take these kernels only on request (GATRES_BLOCKED=1).
 // Three sparse stages x two shapes:
 //   agg_proj   GATConv aggregation (softmax, weighted sum, bias, ReLU)  -> next GATConv's projection + logits  (conv1 -> conv2)
 //   mean_proj  SimpleConv mean + residual + ReLU                        -> next block's conv1 projection + logits
