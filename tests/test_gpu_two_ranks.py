@@ -1,4 +1,4 @@
-"""The REAL trainer at world size 2 on the one GPU a test box has: two fresh processes on cuda:0, gloo backend (device
+"""The REAL trainer at world size 2 (and 4: round 5) on the one GPU a test box has: fresh processes on cuda:0, gloo backend (device
 tensors are allowed: ProcessGroupGloo stages them through the host), eager launches (no hipGraph: gloo cannot be captured).
 
 This is the only multi-rank execution of ``GATResTrainer`` reachable without a multi-GPU node (hardware scaling itself
@@ -25,9 +25,13 @@ CASES = {"fused": dict(nb=4, nc=32, per_rank=4, fused=True),           # 8 parts
          "per_op": dict(nb=3, nc=128, per_rank=2, fused=False)}        # gatres_large's path: one gradient bucket per block
 
 
-def _data(G, case):
+def _per_rank(case, world):
+    return CASES[case]["per_rank"] if world == 2 else 2          # world 4: 2 snapshots per rank (4 x (16 + 4) workgroups resident)
+
+
+def _data(G, case, world=2):
     c = CASES[case]
-    B = 2 * c["per_rank"]
+    B = world * _per_rank(case, world)
     one = G.wdn_synth.make_wdn_topology(NODES, PIPES)
     snaps = [G.wdn_synth.make_snapshots(B, NODES, seed=21 + s) for s in range(STEPS)]
     masks = [torch.from_numpy(G.wdn_synth.generate_batch_mask([NODES] * B, 0.95, np.random.RandomState(7 + s)))
@@ -57,7 +61,7 @@ def _rank_main(rank, world, port, out_dir, case):
         from oracle import gatres_oracle as O
         c = CASES[case]
         torch.cuda.set_device(0)
-        one, snaps, masks, B = _data(G, case)
+        one, snaps, masks, B = _data(G, case, world)
         rows = G.dp.shard_graphs(B, rank, world)
         per = len(rows)
         ei = G.wdn_synth.collate_edge_index(one, NODES, per).cuda()
@@ -65,7 +69,7 @@ def _rank_main(rank, world, port, out_dir, case):
         mine = model.flat_parameters.clone()
         tr = G.GATResTrainer(model, ei, NODES * per, nodes_per_graph=[NODES] * per, seed=5, use_graph=False,
                              fused=c["fused"], blocks_per_bucket=1)
-        assert tr.world == 2 and tr.rank == rank and tr.split and tr.reducer.active and tr.fused == c["fused"]
+        assert tr.world == world and tr.rank == rank and tr.split and tr.reducer.active and tr.fused == c["fused"]
         after_bcast = model.flat_parameters.clone()
         grads0, losses = None, []
         for s in range(STEPS):
@@ -91,13 +95,13 @@ def _rank_main(rank, world, port, out_dir, case):
         dist.destroy_process_group()
 
 
-def _single_main(out_dir, case):
-    """ONE process on the global batch: the same data, the two shards' masks side by side."""
+def _single_main(out_dir, case, world=2):
+    """ONE process on the global batch: the same data, the shards' masks side by side."""
     sys.path.insert(0, ROOT)
     import gnn_pressure_estimation_amd as G
     from oracle import gatres_oracle as O
     c = CASES[case]
-    one, snaps, masks, B = _data(G, case)
+    one, snaps, masks, B = _data(G, case, world)
     ei = G.wdn_synth.collate_edge_index(one, NODES, B).cuda()
     model = _build(G, O, c, seed=1)
     tr = G.GATResTrainer(model, ei, NODES * B, nodes_per_graph=[NODES] * B, seed=5, use_graph=False, fused=c["fused"])
@@ -138,27 +142,31 @@ def _run_all(procs, timeout=600):
                     p.join(10)
 
 
-@pytest.mark.parametrize("case", ["fused", "per_op"])
-def test_trainer_at_world_size_two_on_one_gpu(case, tmp_path, fork_ctx):
-    world, port = 2, _free_port()
-    # The single-process reference runs BEFORE the two ranks, not beside them: the split launches spin-wait for their
+@pytest.mark.parametrize("case,world", [("fused", 2), ("per_op", 2), ("fused", 4)])
+def test_trainer_at_world_size_two_and_four_on_one_gpu(case, world, tmp_path, fork_ctx):
+    port = _free_port()
+    # The single-process reference runs BEFORE the ranks, not beside them: the split launches spin-wait for their
     # partners and need their whole grid resident (three processes at once needed 240 of the 256 CUs: ADVICE r3).
-    _run_all([fork_ctx.Process(target=_single_main, args=(str(tmp_path), case))])
+    _run_all([fork_ctx.Process(target=_single_main, args=(str(tmp_path), case, world))])
     _run_all([fork_ctx.Process(target=_rank_main, args=(r, world, port, str(tmp_path), case)) for r in range(world)])
-    r0, r1 = torch.load(tmp_path / "r0.pt"), torch.load(tmp_path / "r1.pt")
+    rk = [torch.load(tmp_path / f"r{r}.pt") for r in range(world)]
+    r0 = rk[0]
     one = torch.load(tmp_path / "single.pt")
-    assert not torch.equal(r0["mine"], r1["mine"])                                   # the ranks were initialised differently
-    assert torch.equal(r0["after_bcast"], r0["mine"]) and torch.equal(r1["after_bcast"], r0["mine"])      # rank-0 broadcast
-    assert r0["faults"] == 0 and r1["faults"] == 0 and r0["steps"] == STEPS + 1
-    assert torch.equal(r0["grads0"], r1["grads0"])                                   # every rank holds the same summed gradient
-    assert torch.equal(r0["params"], r1["params"])                                   # replicas bit-identical after 3 updates
-    assert not torch.equal(r0["device_mask"], r1["device_mask"])                     # distinct masks per rank ...
+    assert not torch.equal(r0["mine"], rk[1]["mine"])                                # the ranks were initialised differently
+    for r in rk:
+        assert torch.equal(r["after_bcast"], r0["mine"])                             # rank-0 broadcast
+        assert r["faults"] == 0 and r["steps"] == STEPS + 1
+        assert torch.equal(r["grads0"], r0["grads0"])                                # every rank holds the same summed gradient
+        assert torch.equal(r["params"], r0["params"])                                # replicas bit-identical after 3 updates
     per = r0["device_mask"].numel() // NODES
-    assert int(r0["device_mask"].sum()) == per * 368 and int(r1["device_mask"].sum()) == per * 368      # ... of exactly int(388 * 0.95)
+    for a in range(world):
+        assert int(rk[a]["device_mask"].sum()) == per * 368                          # exactly int(388 * 0.95) per graph ...
+        for b in range(a + 1, world):
+            assert not torch.equal(rk[a]["device_mask"], rk[b]["device_mask"])       # ... and distinct masks per rank
     # == one process on the global batch: equal masked counts per graph, so the mean of the rank gradients (grad_scale =
-    # 1 / 2 inside Adam) is the gradient of the global-batch loss; fp32 reassociation across slabs / ranks only
+    # 1 / world inside Adam) is the gradient of the global-batch loss; fp32 reassociation across slabs / ranks only
     g = one["grads0"]
-    assert float((r0["grads0"] * 0.5 - g).abs().max() / g.abs().max()) < 2e-5
+    assert float((r0["grads0"] / world - g).abs().max() / g.abs().max()) < 2e-5
     for a, b in zip(r0["losses"], one["losses"]):
         assert abs(a - b) < 1e-5 * abs(b)
     assert float((r0["params"] - one["params"]).abs().max()) < 2e-5                  # a few ulp of lr-sized updates over 3 steps
