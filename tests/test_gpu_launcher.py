@@ -1,4 +1,4 @@
-"""`bench.py --gpus 2` END TO END on the one GPU a test box has: the launcher path the driver uses for its
+"""`bench.py --gpus 2` (and `--gpus 4`) END TO END on the one GPU a test box has: the launcher path the driver uses for its
 scaling runs -- self_launch (a child ``torch.distributed.run``, started before anything touches the GPU), rank / local-rank
 wiring, distinct per-rank seeds with a rank-0 broadcast, the barrier + MAX-over-ranks timing, one JSON line from rank 0 --
 had never executed anywhere.  Two TEST-ONLY overrides make it runnable here: GATRES_DIST_BACKEND=gloo (RCCL wants one GPU
@@ -46,22 +46,23 @@ def _launch(fork_ctx, tmp_path, argv, env_extra):
     return line
 
 
-@pytest.mark.parametrize("model_args,workload", [
-    (["--batch-size", "8"], "gatres_small"),                                        # fused path: two gradient buckets
-    (["--model", "gatres_large", "--batch-size", "2", "--dtype", "bf16"], "gatres_large"),     # per-op path: a bucket per block group
-], ids=["gatres_small_fused", "gatres_large_per_op"])
-def test_bench_gpus_2_runs_end_to_end_on_one_gpu(fork_ctx, tmp_path, model_args, workload):
+@pytest.mark.parametrize("gpus,model_args,workload", [
+    (2, ["--batch-size", "8"], "gatres_small"),                                     # fused path: the single-GPU launches around one all-reduce
+    (2, ["--model", "gatres_large", "--batch-size", "2", "--dtype", "bf16"], "gatres_large"),  # per-op path: a bucket per block group
+    (4, ["--batch-size", "4"], "gatres_small"),                                     # four ranks (round 5): 4 x 40 workgroups resident
+], ids=["gatres_small_fused", "gatres_large_per_op", "gatres_small_fused_4_ranks"])
+def test_bench_gpus_n_runs_end_to_end_on_one_gpu(fork_ctx, tmp_path, gpus, model_args, workload):
     line = _launch(fork_ctx, tmp_path,
-                   ["--gpus", "2", "--steps", "4", "--warmup", "2", "--repeats", "2", "--no-cpu-baseline", "--no-roofline"]
+                   ["--gpus", str(gpus), "--steps", "4", "--warmup", "2", "--repeats", "2", "--no-cpu-baseline", "--no-roofline"]
                    + model_args,
                    {"GATRES_DIST_BACKEND": "gloo", "GATRES_BENCH_SHARE_GPU": "1", "HSA_ENABLE_IPC_MODE_LEGACY": "0"})
     bs = int(model_args[model_args.index("--batch-size") + 1])
-    assert line["n_gpus"] == 2 and line["steps"] == 4 and line["warmup"] == 2 and line["scaling"] == "weak"
+    assert line["n_gpus"] == gpus and line["steps"] == 4 and line["warmup"] == 2 and line["scaling"] == "weak"
     assert line["metric"] == "train snapshots/sec" and line["value"] > 0 and line["higher_is_better"] is True
-    assert abs(line["value"] - 2 * bs * 4 / (line["ms_per_step"] * 4e-3)) < 1e-6 * line["value"]      # whole-job aggregate
+    assert abs(line["value"] - gpus * bs * 4 / (line["ms_per_step"] * 4e-3)) < 1e-6 * line["value"]      # whole-job aggregate
     cfg = line["config"]
     assert workload in cfg["workload"] and "RCCL all-reduce" in cfg["workload"]      # the multi-rank sequence ran
-    assert cfg["global_batch"] == 2 * bs and cfg["parallelism"] == "dp2" and cfg["dropped_steps"] == 0
+    assert cfg["global_batch"] == gpus * bs and cfg["parallelism"] == f"dp{gpus}" and cfg["dropped_steps"] == 0
     assert cfg["test_overrides"] == {"backend": "gloo", "ranks_share_gpu": True}
     assert cfg["final_loss"] == cfg["final_loss"] and cfg["final_loss"] < 1e3
 
