@@ -1510,7 +1510,21 @@ constexpr int PGS_THREADS = 512, PGS_NBUF = 3;
 template <int NC>
 __global__ __launch_bounds__(PGS_THREADS) void param_grads_stream_kernel(const ParamGradArgs a) {
   __shared__ __attribute__((aligned(16))) float lds[PGS_NBUF * CI_CR * (3 * NC + 4)];
-  const int conv = blockIdx.x & 1, b = (blockIdx.x >> 1) % a.L.nb, seg = (blockIdx.x >> 1) / a.L.nb;
+  // Item of this workgroup.  The kept g_h tables an item reads were written by the window kernel's parts of its segment -- on
+  // XCD (segment % 8), their ids being 8 apart -- and the LAST blocks the backward chain walked (b = 0, 1, ...) were written
+  // last: with a whole number of segments per XCD the item goes to a workgroup of THAT XCD (round-robin dispatch: id % 8) and
+  // the items are dealt block-major from b = 0, so the first wave of items finds its freshest tables still in its XCD's L2
+  // (4 MB hold the kept tables of four to five blocks of an XCD's four snapshots).  Speed only: any map is a bijection.
+  int conv = blockIdx.x & 1, b = (blockIdx.x >> 1) % a.L.nb, seg = (blockIdx.x >> 1) / a.L.nb;
+#ifndef GATRES_PROBE_PG_OLD_MAP
+  {
+    const int S = (int)(gridDim.x / (2 * a.L.nb));
+    if ((S & 7) == 0) {
+      const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3, per = (S >> 3) * 2;       // (segment, conv) pairs of one XCD
+      b = j / per; conv = (j % per) & 1; seg = ((j % per) >> 1) * 8 + xcd;
+    }
+  }
+#endif
   if (a.snap && blockIdx.x == 0 && threadIdx.x == 0) {
     a.snap[0] = a.step_counter ? __hip_atomic_load(a.step_counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ULL;
     a.snap[1] = a.status ? (unsigned long long)__hip_atomic_load(a.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ULL;
