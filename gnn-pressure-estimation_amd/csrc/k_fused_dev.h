@@ -1537,6 +1537,223 @@ __global__ __launch_bounds__(PGS_THREADS) void param_grads_stream_kernel(const P
   }
 }
 
+// ---- items streamed through REGISTERS (round 5; the stand-alone launch for nc 16 / 32).  The LDS-DMA form above keeps two
+// 64-row chunks in flight per workgroup and paces its waves by one barrier per chunk; its launch moves 161 MB at 4.2 TB/s with the
+// matrix pipe 42 % busy -- neither bound.  Here an item is one 256-thread workgroup whose four waves take the item's 4-row steps
+// round-robin (wave w: steps w, w + 4, ...), every lane loads its MFMA operands straight from the tables (the permuted operand map
+// of seg_dw_blk: 16 / 8 bytes of contiguous features per lane, a wave-load covers four whole rows) into a ring of P register
+// slots -- P steps in flight per wave, no barrier, no LDS until the four partial blocks meet -- and ALL 960 items of a bs-32 step
+// are resident at once (35 KB of LDS and 16 waves for the four workgroups of a CU).  T = [g_a_src | g_a_dst]^T x (the attention-
+// vector gradients without reading h, see above) is formed on the VALU beside the matrix pipe: 2H x VK fused multiply-adds per lane
+// and step, the four row phases of a wave summed by two shuffles at the end.  Every sum has a fixed order: deterministic.
+constexpr int PGR_THREADS = 256;
+#define PGR_LDS_FLOATS(NC) ((PGR_THREADS / 64) * 2 * (NC) * (NC) + (PGR_THREADS / 64 + 1) * 4 * (NC))
+#ifndef PGR_SLOTS
+#define PGR_SLOTS 6
+#endif
+// a lane's operand fragment of W consecutive floats as ONE register tuple; requested by hand-written global_load (the compiler
+// does not count these: pgr_wait names the tuples it makes valid, so no use can move in front of the wait)
+template <int W> struct PgrVec;
+template <> struct PgrVec<1> { typedef float type; };
+template <> struct PgrVec<2> { typedef float type __attribute__((ext_vector_type(2))); };
+template <> struct PgrVec<4> { typedef float type __attribute__((ext_vector_type(4))); };
+template <int W>
+__device__ __forceinline__ void pgr_load(typename PgrVec<W>::type& d, const float* p) {
+  if constexpr (W == 4)      asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(d) : "v"(p) : "memory");
+  else if constexpr (W == 2) asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(d) : "v"(p) : "memory");
+  else                       asm volatile("global_load_dword %0, %1, off" : "=v"(d) : "v"(p) : "memory");
+}
+template <int W>
+__device__ __forceinline__ float pgr_at(const typename PgrVec<W>::type& v, int k) {
+  if constexpr (W == 1) return v;
+  else return v[k];
+}
+template <int N, class A, class B, class C, class D>
+__device__ __forceinline__ void pgr_wait(A& a, B& b, C& c, D& d) {
+  asm volatile("s_waitcnt vmcnt(%4)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "n"(N) : "memory");
+}
+// (AG: slab entries by agent-scope stores, for param_grads_finish_kernel's last arriver)
+template <int NC, int CONV, bool AG = false>
+__device__ __forceinline__ void param_grads_item_reg(const ParamGradArgs& a, int seg, int b, float* lds) {
+  using Gm = CiGeom<NC, CONV>;
+  constexpr int HC = Gm::HC, K = Gm::K, H = Gm::H, P = PGR_SLOTS;
+  constexpr int NW = PGR_THREADS / 64, VC = HC / 16, VK = K / 16;
+  static_assert(4 * (P - 1) < 64, "vmcnt");
+  const Layout& L = a.L;
+  const SegLayout& SL = a.SL;
+  const int n0 = uni(a.seg_ptr[seg]), n = uni(a.seg_ptr[seg + 1]) - n0;
+  const float* base = a.saved + (int64_t)seg * SL.total + (int64_t)b * SL.bstride;
+  const float* keep = a.keep + (int64_t)b * L.keep_stride;
+  const int64_t po = L.p_block0 + (int64_t)b * L.p_block_stride;
+  float* sb = a.slabs + (int64_t)seg * L.slab_stride + po;
+  const float* gG = keep + (CONV == 0 ? L.k_gh1 : L.k_gh2) + (int64_t)n0 * HC;      // [n][HC]
+  const float* gX = base + (CONV == 0 ? SL.xin : SL.o1);                              // [n][K]
+  const float* gS = keep + (CONV == 0 ? L.k_gas1 : L.k_gas2) + (int64_t)n0 * H;      // [n][H]
+  const float* gD = keep + (CONV == 0 ? L.k_gad1 : L.k_gad2) + (int64_t)n0 * H;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int i = lane & 15, q = lane >> 4;
+  const int steps = (n + 3) >> 2;
+  const int cnt = steps > wave ? (steps - wave + NW - 1) / NW : 0;                    // this wave's steps (wave-uniform)
+  float* part = lds;                                  // [NW][HC * K]
+  float* tpart = lds + NW * HC * K;                   // [NW][2H][K]
+  float* tsum = tpart + NW * 2 * H * K;               // [2H][K]
+
+  f32x4 acc[VC][VK];
+  float accT[2 * H][VK];
+#pragma unroll
+  for (int y = 0; y < VK; ++y) {
+#pragma unroll
+    for (int x = 0; x < VC; ++x) acc[x][y] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < 2 * H; ++j) accT[j][y] = 0.f;
+  }
+  typename PgrVec<VC>::type gv[P];
+  typename PgrVec<VK>::type xv[P];
+  typename PgrVec<H>::type sv[P], dv[P];
+  // step t of this wave = rows 4 (wave + t NW) + q; a row beyond the segment reads the last row and counts as zero.  EVERY slot
+  // is re-requested unconditionally, four instructions each (steps beyond the wave's last re-read its last step: cache hits),
+  // so "slot j has landed" is always "at most the 4 (P - 1) younger requests are outstanding"
+  const int last = max(cnt - 1, 0);
+#define PGR_LOAD(slot, t)                                                                        \
+  do {                                                                                           \
+    const int r_ = min(4 * (wave + min((t), last) * NW) + q, n - 1);                             \
+    pgr_load<VC>(gv[slot], gG + (unsigned)(r_ * HC + VC * i));                                   \
+    pgr_load<VK>(xv[slot], gX + (unsigned)(r_ * K + VK * i));                                    \
+    pgr_load<H>(sv[slot], gS + (unsigned)(r_ * H));                                              \
+    pgr_load<H>(dv[slot], gD + (unsigned)(r_ * H));                                              \
+  } while (0)
+#pragma unroll
+  for (int j = 0; j < P; ++j) PGR_LOAD(j, j);
+  for (int t0 = 0; t0 < cnt; t0 += P) {
+#pragma unroll
+    for (int j = 0; j < P; ++j) {
+      const int t = t0 + j;
+      pgr_wait<4 * (P - 1)>(gv[j], xv[j], sv[j], dv[j]);
+      if (t < cnt) {                                                                    // (wave-uniform)
+        const bool ok = 4 * (wave + t * NW) + q < n;
+        float ae[2 * H], af[VC], bf[VK];
+#pragma unroll
+        for (int x = 0; x < VC; ++x) af[x] = ok ? pgr_at<VC>(gv[j], x) : 0.f;
+#pragma unroll
+        for (int y = 0; y < VK; ++y) bf[y] = pgr_at<VK>(xv[j], y);
+#pragma unroll
+        for (int k = 0; k < H; ++k) { ae[k] = ok ? pgr_at<H>(sv[j], k) : 0.f; ae[H + k] = ok ? pgr_at<H>(dv[j], k) : 0.f; }
+#pragma unroll
+        for (int y = 0; y < VK; ++y) {
+#pragma unroll
+          for (int x = 0; x < VC; ++x) acc[x][y] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[x], bf[y], acc[x][y], 0, 0, 0);
+#pragma unroll
+          for (int k = 0; k < 2 * H; ++k) accT[k][y] = fmaf(ae[k], bf[y], accT[k][y]);
+        }
+      }
+      PGR_LOAD(j, t + P);
+    }
+  }
+#undef PGR_LOAD
+  // the re-requests behind the last step: nothing reads them, but their registers stay named until they have landed (to the
+  // compiler an unused asm output is a free register at once)
+#pragma unroll
+  for (int j = 0; j < P; ++j) pgr_wait<0>(gv[j], xv[j], sv[j], dv[j]);
+  // operands of the epilogue, requested before the partial blocks meet: the bias partials of a split segment and this thread's
+  // share of W^T (the scratch copy the dX stages use, L2-resident)
+  constexpr int MAXM = 8;
+  float bp[MAXM];
+  const bool folds = a.M > 1 && (int)threadIdx.x < HC;
+  const int64_t boff = po + (CONV == 0 ? L.c1_b : L.c2_b) + threadIdx.x;
+#pragma unroll
+  for (int p = 0; p < MAXM; ++p)
+    bp[p] = (folds && p < a.M) ? a.part_slabs[((int64_t)seg * a.M + p) * L.slab_stride + boff] : 0.f;
+  constexpr int KG = PGR_THREADS / HC, KPT = (K + KG - 1) / KG;
+  const int c = threadIdx.x % HC, kg = threadIdx.x / HC, hd = c / (HC / H);
+  float wv[KPT];
+  {
+    const float* Wt = a.wt + ((int64_t)b * 2 + CONV) * (2LL * NC * NC) + c;
+#pragma unroll
+    for (int j = 0; j < KPT; ++j) wv[j] = (kg + j * KG < K) ? Wt[(kg + j * KG) * HC] : 0.f;
+  }
+  float* mine = part + wave * (HC * K);
+#pragma unroll
+  for (int x = 0; x < VC; ++x)
+#pragma unroll
+    for (int y = 0; y < VK; ++y)
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) mine[(VC * (4 * q + rr) + x) * K + VK * i + y] = acc[x][y][rr];
+#pragma unroll
+  for (int k = 0; k < 2 * H; ++k)
+#pragma unroll
+    for (int y = 0; y < VK; ++y) {
+      float v = accT[k][y];
+      v += __shfl_xor(v, 16);
+      v += __shfl_xor(v, 32);
+      if (q == 0) tpart[(wave * 2 * H + k) * K + VK * i + y] = v;
+    }
+  if (folds) {
+    float sum = 0.f;
+#pragma unroll
+    for (int p = 0; p < MAXM; ++p)
+      if (p < a.M) sum += bp[p];
+    slab_st<AG>(a.slabs + (int64_t)seg * L.slab_stride + boff, sum);
+  }
+  lds_barrier_raw();
+  for (int idx = threadIdx.x; idx < HC * K; idx += PGR_THREADS) {
+    float sum = 0.f;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) sum += part[w * (HC * K) + idx];
+    slab_st<AG>(sb + (CONV == 0 ? L.c1_W : L.c2_W) + idx, sum);
+  }
+  if ((int)threadIdx.x < 2 * H * K) {
+    float sum = 0.f;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) sum += tpart[w * 2 * H * K + threadIdx.x];
+    tsum[threadIdx.x] = sum;
+  }
+  lds_barrier_raw();
+  {
+    // g_att[c] = sum_k W^T[k][c] T[hd(c)][k]: thread (c, kg) takes k = kg, kg + KG, ...; the KG partial sums meet in LDS
+    float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+    for (int j = 0; j < KPT; ++j) {
+      const int k = min(kg + j * KG, K - 1);
+      s0 = fmaf(wv[j], tsum[hd * K + k], s0);
+      s1 = fmaf(wv[j], tsum[(H + hd) * K + k], s1);
+    }
+    float* ared = part;                                            // (the partial blocks are folded: reuse)  [2][KG][HC]
+    ared[kg * HC + c] = s0; ared[(KG + kg) * HC + c] = s1;
+    lds_barrier_raw();
+    if ((int)threadIdx.x < HC) {
+      float t0 = 0.f, t1 = 0.f;
+#pragma unroll 4
+      for (int g = 0; g < KG; ++g) { t0 += ared[g * HC + c]; t1 += ared[(KG + g) * HC + c]; }
+      slab_st<AG>(sb + (CONV == 0 ? L.c1_as : L.c2_as) + c, t0);
+      slab_st<AG>(sb + (CONV == 0 ? L.c1_ad : L.c2_ad) + c, t1);
+    }
+  }
+}
+
+template <int NC>
+__global__ __launch_bounds__(PGR_THREADS) void param_grads_reg_kernel(const ParamGradArgs a) {
+  __shared__ __attribute__((aligned(16))) float lds[PGR_LDS_FLOATS(NC)];
+  // item of this workgroup: on the XCD whose window-kernel parts wrote its kept tables (param_grads_stream_kernel's map)
+  int conv = blockIdx.x & 1, b = (blockIdx.x >> 1) % a.L.nb, seg = (blockIdx.x >> 1) / a.L.nb;
+  {
+    const int S = (int)(gridDim.x / (2 * a.L.nb));
+    if ((S & 7) == 0) {
+      const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3, per = (S >> 3) * 2;       // (segment, conv) pairs of one XCD
+      b = j / per; conv = (j % per) & 1; seg = ((j % per) >> 1) * 8 + xcd;
+    }
+  }
+  if (a.snap && blockIdx.x == 0 && threadIdx.x == 0) {
+    a.snap[0] = a.step_counter ? __hip_atomic_load(a.step_counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ULL;
+    a.snap[1] = a.status ? (unsigned long long)__hip_atomic_load(a.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ULL;
+  }
+  if (conv == 0) param_grads_item_reg<NC, 0>(a, seg, b, lds);
+  else           param_grads_item_reg<NC, 1>(a, seg, b, lds);
+  if (a.M > 1 && b == 0 && conv == 0) {
+    fold_parts<PGR_THREADS>(a, seg, a.L.p_lin0_w, 2 * NC);
+    fold_parts<PGR_THREADS>(a, seg, a.L.p_lin1_w, NC + 1);
+  }
+}
+
 // ------------------------------------------------------------------------------------------ split segments
 // One segment may be carried by M workgroups on M CUs (M a power of two, chosen by the host so that every workgroup
 // of the grid is resident at once).  Part p owns a 16-aligned row window; the dense stages touch own rows only, the

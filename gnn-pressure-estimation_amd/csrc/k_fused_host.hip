@@ -180,8 +180,8 @@ struct FinishArgs {
 };
 
 template <int NC>
-__global__ __launch_bounds__(PGS_THREADS) void param_grads_finish_kernel(const ParamGradArgs a, const FinishArgs f) {
-  __shared__ __attribute__((aligned(16))) float lds[PGS_NBUF * CI_CR * (3 * NC + 4)];
+__global__ __launch_bounds__(PGR_THREADS) void param_grads_finish_kernel(const ParamGradArgs a, const FinishArgs f) {
+  __shared__ __attribute__((aligned(16))) float lds[PGR_LDS_FLOATS(NC)];
   __shared__ int s_last;
   __shared__ float s_step_size, s_bc2_sqrt;
   __shared__ unsigned s_fault;
@@ -199,12 +199,12 @@ __global__ __launch_bounds__(PGS_THREADS) void param_grads_finish_kernel(const P
     const bool flt = f.status && __hip_atomic_load(f.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;
     if (tid == 0) f.loss[0] = flt ? NAN : s / f.loss_part[f.num_loss];
   }
-  if (conv == 0) consumer_item_dma<NC, PGS_THREADS, 0, PGS_NBUF, true>(a, seg, b, lds);
-  else           consumer_item_dma<NC, PGS_THREADS, 1, PGS_NBUF, true>(a, seg, b, lds);
+  if (conv == 0) param_grads_item_reg<NC, 0, true>(a, seg, b, lds);
+  else           param_grads_item_reg<NC, 1, true>(a, seg, b, lds);
   const bool has_lin0 = b == 0 && conv == 0, has_lin1 = b == L.nb - 1 && conv == 1;
   if (a.M > 1) {                                                         // lin0 / lin1 partials of a split segment
-    if (has_lin0) fold_parts<PGS_THREADS, true>(a, seg, L.p_lin0_w, 2 * NC);
-    if (has_lin1) fold_parts<PGS_THREADS, true>(a, seg, L.p_lin1_w, NC + 1);
+    if (has_lin0) fold_parts<PGR_THREADS, true>(a, seg, L.p_lin0_w, 2 * NC);
+    if (has_lin1) fold_parts<PGR_THREADS, true>(a, seg, L.p_lin1_w, NC + 1);
   }
   // ---- arrive at the column's counter (no fence: see above)
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -269,7 +269,7 @@ __global__ __launch_bounds__(PGS_THREADS) void param_grads_finish_kernel(const P
   // 128 VGPRs that two workgroups per CU leave), every element summed in slab order
   auto finish_range = [&](int64_t lo, int64_t hi) {
     const int64_t n4 = (hi - lo) >> 2;
-    for (int64_t q = tid; q < n4; q += PGS_THREADS) {
+    for (int64_t q = tid; q < n4; q += PGR_THREADS) {
       const int64_t idx = lo + 4 * q;
       float4 pv = f4zero(), mv0 = f4zero(), vv0 = f4zero();
       if (f.do_adam && !fault) { pv = ld4(f.p + idx); mv0 = ld4(f.m + idx); vv0 = ld4(f.v + idx); }
@@ -298,7 +298,7 @@ __global__ __launch_bounds__(PGS_THREADS) void param_grads_finish_kernel(const P
       update(idx + 2, acc.z, pv.z, mv0.z, vv0.z);
       update(idx + 3, acc.w, pv.w, mv0.w, vv0.w);
     }
-    for (int64_t idx = lo + 4 * n4 + tid; idx < hi; idx += PGS_THREADS) {      // (lin1's odd element)
+    for (int64_t idx = lo + 4 * n4 + tid; idx < hi; idx += PGR_THREADS) {      // (lin1's odd element)
       float pv = 0.f, mv0 = 0.f, vv0 = 0.f;
       if (f.do_adam && !fault) { pv = f.p[idx]; mv0 = f.m[idx]; vv0 = f.v[idx]; }
       float acc = 0.f;
@@ -641,8 +641,13 @@ extern "C" __attribute__((visibility("hidden"))) int gatres_fused_param_grads_ex
       a.status = fused_nodes_of(g) > 0 ? status : nullptr;
       a.snap = reinterpret_cast<unsigned long long*>(status + 8);
     }
+#ifdef GATRES_PROBE_PG_DMA
     if (m->nc == 16) hipLaunchKernelGGL((param_grads_stream_kernel<16>), grid, dim3(PGS_THREADS), 0, st, a);
     else             hipLaunchKernelGGL((param_grads_stream_kernel<32>), grid, dim3(PGS_THREADS), 0, st, a);
+#else
+    if (m->nc == 16) hipLaunchKernelGGL((param_grads_reg_kernel<16>), grid, dim3(PGR_THREADS), 0, st, a);
+    else             hipLaunchKernelGGL((param_grads_reg_kernel<32>), grid, dim3(PGR_THREADS), 0, st, a);
+#endif
     const int rc = gatres_launch_status();
     return rc ? rc : (step_counter ? 1 : 0);
   }
@@ -699,8 +704,8 @@ extern "C" int gatres_fused_param_grads_finish(const gatres_model_t* m, const ga
   f.S = g->num_segments; f.b_lo = block_lo; f.b_hi = block_hi; f.final_launch = block_lo == 0 ? 1 : 0;
   const dim3 grid((unsigned)(2 * (block_hi - block_lo) * g->num_segments));
   hipStream_t st = gatres_stream(stream);
-  if (m->nc == 16) hipLaunchKernelGGL((param_grads_finish_kernel<16>), grid, dim3(PGS_THREADS), 0, st, a, f);
-  else             hipLaunchKernelGGL((param_grads_finish_kernel<32>), grid, dim3(PGS_THREADS), 0, st, a, f);
+  if (m->nc == 16) hipLaunchKernelGGL((param_grads_finish_kernel<16>), grid, dim3(PGR_THREADS), 0, st, a, f);
+  else             hipLaunchKernelGGL((param_grads_finish_kernel<32>), grid, dim3(PGR_THREADS), 0, st, a, f);
   return gatres_launch_status();
 }
 
