@@ -1549,7 +1549,7 @@ __global__ __launch_bounds__(PGS_THREADS) void param_grads_stream_kernel(const P
 constexpr int PGR_THREADS = 256;
 #define PGR_LDS_FLOATS(NC) ((PGR_THREADS / 64) * 2 * (NC) * (NC) + (PGR_THREADS / 64 + 1) * 4 * (NC))
 #ifndef PGR_SLOTS
-#define PGR_SLOTS 6
+#define PGR_SLOTS 4          // steps in flight per wave (3 .. 6 measure the same; 7 and non-temporal loads are slower)
 #endif
 // a lane's operand fragment of W consecutive floats as ONE register tuple; requested by hand-written global_load (the compiler
 // does not count these: pgr_wait names the tuples it makes valid, so no use can move in front of the wait)
@@ -1559,9 +1559,18 @@ template <> struct PgrVec<2> { typedef float type __attribute__((ext_vector_type
 template <> struct PgrVec<4> { typedef float type __attribute__((ext_vector_type(4))); };
 template <int W>
 __device__ __forceinline__ void pgr_load(typename PgrVec<W>::type& d, const float* p) {
-  if constexpr (W == 4)      asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(d) : "v"(p) : "memory");
-  else if constexpr (W == 2) asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(d) : "v"(p) : "memory");
-  else                       asm volatile("global_load_dword %0, %1, off" : "=v"(d) : "v"(p) : "memory");
+#ifdef PGR_PROBE_NOLOAD
+  asm volatile("" : "=v"(d) : "v"(p));
+  return;
+#endif
+#ifdef PGR_NT
+#define PGR_MOD " nt"
+#else
+#define PGR_MOD ""
+#endif
+  if constexpr (W == 4)      asm volatile("global_load_dwordx4 %0, %1, off" PGR_MOD : "=v"(d) : "v"(p) : "memory");
+  else if constexpr (W == 2) asm volatile("global_load_dwordx2 %0, %1, off" PGR_MOD : "=v"(d) : "v"(p) : "memory");
+  else                       asm volatile("global_load_dword %0, %1, off" PGR_MOD : "=v"(d) : "v"(p) : "memory");
 }
 template <int W>
 __device__ __forceinline__ float pgr_at(const typename PgrVec<W>::type& v, int k) {
@@ -1629,7 +1638,11 @@ __device__ __forceinline__ void param_grads_item_reg(const ParamGradArgs& a, int
     for (int j = 0; j < P; ++j) {
       const int t = t0 + j;
       pgr_wait<4 * (P - 1)>(gv[j], xv[j], sv[j], dv[j]);
+#ifdef PGR_PROBE_NOMFMA
+      if (t < cnt && n < 0) {
+#else
       if (t < cnt) {                                                                    // (wave-uniform)
+#endif
         const bool ok = 4 * (wave + t * NW) + q < n;
         float ae[2 * H], af[VC], bf[VK];
 #pragma unroll
@@ -1654,6 +1667,9 @@ __device__ __forceinline__ void param_grads_item_reg(const ParamGradArgs& a, int
   // compiler an unused asm output is a free register at once)
 #pragma unroll
   for (int j = 0; j < P; ++j) pgr_wait<0>(gv[j], xv[j], sv[j], dv[j]);
+#ifdef PGR_PROBE_NOEPI
+  if (n > 0) { if (acc[0][0][0] == 12345.f && accT[0][0] == 1.f) sb[0] = 1.f; return; }
+#endif
   // operands of the epilogue, requested before the partial blocks meet: the bias partials of a split segment and this thread's
   // share of W^T (the scratch copy the dX stages use, L2-resident)
   constexpr int MAXM = 8;
@@ -1663,13 +1679,16 @@ __device__ __forceinline__ void param_grads_item_reg(const ParamGradArgs& a, int
 #pragma unroll
   for (int p = 0; p < MAXM; ++p)
     bp[p] = (folds && p < a.M) ? a.part_slabs[((int64_t)seg * a.M + p) * L.slab_stride + boff] : 0.f;
-  constexpr int KG = PGR_THREADS / HC, KPT = (K + KG - 1) / KG;
-  const int c = threadIdx.x % HC, kg = threadIdx.x / HC, hd = c / (HC / H);
+  // g_att[c] = sum_k W^T[k][c] T[hd(c)][k]: wave w takes the columns [CPW w, CPW (w + 1)), lane (cl, kg) the k = kg, kg + KGW, ...
+  // of column CPW w + cl; the KGW partial sums of a column meet by shuffles inside the wave (no LDS, no barrier)
+  constexpr int CPW = HC / NW, KGW = 64 / CPW, KPT = K / KGW;
+  static_assert(HC % NW == 0 && 64 % CPW == 0 && K % KGW == 0 && CPW >= 1, "attention-vector columns per wave");
+  const int c = CPW * wave + lane % CPW, kg = lane / CPW, hd = c / (HC / H);
   float wv[KPT];
   {
     const float* Wt = a.wt + ((int64_t)b * 2 + CONV) * (2LL * NC * NC) + c;
 #pragma unroll
-    for (int j = 0; j < KPT; ++j) wv[j] = (kg + j * KG < K) ? Wt[(kg + j * KG) * HC] : 0.f;
+    for (int j = 0; j < KPT; ++j) wv[j] = Wt[(kg + j * KGW) * HC];
   }
   float* mine = part + wave * (HC * K);
 #pragma unroll
@@ -1695,11 +1714,27 @@ __device__ __forceinline__ void param_grads_item_reg(const ParamGradArgs& a, int
     slab_st<AG>(a.slabs + (int64_t)seg * L.slab_stride + boff, sum);
   }
   lds_barrier_raw();
-  for (int idx = threadIdx.x; idx < HC * K; idx += PGR_THREADS) {
-    float sum = 0.f;
+  static_assert(HC * K % (4 * PGR_THREADS) == 0 || HC * K == 2 * PGR_THREADS, "fold: 16 bytes per thread and trip");
+  if constexpr (HC * K % (4 * PGR_THREADS) == 0) {
 #pragma unroll
-    for (int w = 0; w < NW; ++w) sum += part[w * (HC * K) + idx];
-    slab_st<AG>(sb + (CONV == 0 ? L.c1_W : L.c2_W) + idx, sum);
+    for (int idx = 4 * (int)threadIdx.x; idx < HC * K; idx += 4 * PGR_THREADS) {
+      float4 sum = ld4(part + idx);
+#pragma unroll
+      for (int w = 1; w < NW; ++w) {
+        const float4 v = ld4(part + w * (HC * K) + idx);
+        sum.x += v.x; sum.y += v.y; sum.z += v.z; sum.w += v.w;
+      }
+      float* dst = sb + (CONV == 0 ? L.c1_W : L.c2_W) + idx;
+      if constexpr (AG) { slab_st<AG>(dst, sum.x); slab_st<AG>(dst + 1, sum.y); slab_st<AG>(dst + 2, sum.z); slab_st<AG>(dst + 3, sum.w); }
+      else st4(dst, sum);
+    }
+  } else {
+    for (int idx = threadIdx.x; idx < HC * K; idx += PGR_THREADS) {
+      float sum = 0.f;
+#pragma unroll
+      for (int w = 0; w < NW; ++w) sum += part[w * (HC * K) + idx];
+      slab_st<AG>(sb + (CONV == 0 ? L.c1_W : L.c2_W) + idx, sum);
+    }
   }
   if ((int)threadIdx.x < 2 * H * K) {
     float sum = 0.f;
@@ -1709,23 +1744,18 @@ __device__ __forceinline__ void param_grads_item_reg(const ParamGradArgs& a, int
   }
   lds_barrier_raw();
   {
-    // g_att[c] = sum_k W^T[k][c] T[hd(c)][k]: thread (c, kg) takes k = kg, kg + KG, ...; the KG partial sums meet in LDS
     float s0 = 0.f, s1 = 0.f;
 #pragma unroll
     for (int j = 0; j < KPT; ++j) {
-      const int k = min(kg + j * KG, K - 1);
+      const int k = kg + j * KGW;
       s0 = fmaf(wv[j], tsum[hd * K + k], s0);
       s1 = fmaf(wv[j], tsum[(H + hd) * K + k], s1);
     }
-    float* ared = part;                                            // (the partial blocks are folded: reuse)  [2][KG][HC]
-    ared[kg * HC + c] = s0; ared[(KG + kg) * HC + c] = s1;
-    lds_barrier_raw();
-    if ((int)threadIdx.x < HC) {
-      float t0 = 0.f, t1 = 0.f;
-#pragma unroll 4
-      for (int g = 0; g < KG; ++g) { t0 += ared[g * HC + c]; t1 += ared[(KG + g) * HC + c]; }
-      slab_st<AG>(sb + (CONV == 0 ? L.c1_as : L.c2_as) + c, t0);
-      slab_st<AG>(sb + (CONV == 0 ? L.c1_ad : L.c2_ad) + c, t1);
+#pragma unroll
+    for (int off = CPW; off < 64; off <<= 1) { s0 += __shfl_xor(s0, off); s1 += __shfl_xor(s1, off); }
+    if (kg == 0) {
+      slab_st<AG>(sb + (CONV == 0 ? L.c1_as : L.c2_as) + c, s0);
+      slab_st<AG>(sb + (CONV == 0 ? L.c1_ad : L.c2_ad) + c, s1);
     }
   }
 }
@@ -1746,6 +1776,9 @@ __global__ __launch_bounds__(PGR_THREADS) void param_grads_reg_kernel(const Para
     a.snap[0] = a.step_counter ? __hip_atomic_load(a.step_counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ULL;
     a.snap[1] = a.status ? (unsigned long long)__hip_atomic_load(a.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ULL;
   }
+#ifdef PGR_PROBE_EMPTY
+  if (a.M > 0) return;
+#endif
   if (conv == 0) param_grads_item_reg<NC, 0>(a, seg, b, lds);
   else           param_grads_item_reg<NC, 1>(a, seg, b, lds);
   if (a.M > 1 && b == 0 && conv == 0) {
