@@ -694,7 +694,7 @@ def main():
                                                         "note": "round-1 accounting (slab partials, index reads, per-op "
                                                                 "intermediates): fatter than SURVEY 8(d); kept for comparison only"},
                                   "second_kernel": None if inline_pg else
-                                  {"kernel": "param_grads_stream_kernel (deferred dW / att gradients)",
+                                  {"kernel": "param_grads_reg_kernel (deferred dW / att gradients)",
                                    "avg_launch_us": us_pg, "algorithmic_bytes_per_launch": nbytes_pg,
                                    "achieved": nbytes_pg / us_pg * 1e-3}}
         else:

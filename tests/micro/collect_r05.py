@@ -39,7 +39,7 @@ def pmc_raw(d):
     wc, wa = main["SQ_WAVE_CYCLES"]["mean_per_launch"], main["SQ_WAIT_ANY"]["mean_per_launch"]
     out = {
         "kernel": "gatres_window_kernel<32,1024>, bs=32, 8 CUs per snapshot (256 workgroups); second_kernel: "
-                  "param_grads_stream_kernel<32> (960 workgroups x 512 threads, the deferred parameter gradients)",
+                  "param_grads_reg_kernel<32> (960 workgroups x 256 threads, the deferred parameter gradients)",
         "command": "rocprofv3 --pmc FETCH_SIZE --output-format csv -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline "
                    "--no-roofline (and the same with --pmc WRITE_SIZE / the SQ sets: separate passes, tests/micro/profile_r05.sh)",
         "units": "rocprofv3 reports FETCH_SIZE / WRITE_SIZE in KB; FETCH_SIZE counts 64 B per 128-B request on gfx950 "
@@ -47,7 +47,7 @@ def pmc_raw(d):
         "kernel_avg_us": kernel_avg_us(stats, "gatres_window_kernel"),
         "kernel_avg_us_source": "rocprofv3 --kernel-trace --stats of the same session (profiles/r05_fused_kernel_stats.csv)",
         "FETCH_SIZE": kb(main, "FETCH_SIZE"), "WRITE_SIZE": kb(main, "WRITE_SIZE"),
-        "second_kernel": {"kernel_avg_us": kernel_avg_us(stats, "param_grads_stream_kernel"),
+        "second_kernel": {"kernel_avg_us": kernel_avg_us(stats, "param_grads_reg_kernel"),
                           "FETCH_SIZE": kb(pg, "FETCH_SIZE"), "WRITE_SIZE": kb(pg, "WRITE_SIZE"),
                           "hbm_side_bytes_per_launch": b(pg)},
         "hbm_side_bytes_per_launch": b(main), "hbm_side_bytes_both_launches": b(main) + b(pg),

@@ -14,7 +14,7 @@ timeout 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -o w 
 timeout 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $O/pmc_sq -o s -- $B $P > $O/pmc_sq.log 2>&1
 timeout 300 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SMEM SQ_LDS_BANK_CONFLICT SQ_INSTS_VALU_MFMA_MOPS_F32 --output-format csv -d $O/pmc_inst -o i -- $B $P > $O/pmc_inst.log 2>&1
 python3 tests/micro/summarize_prof.py pmc $O/fused_pmc.json gatres_window_kernel $O/pmc_fetch $O/pmc_write $O/pmc_sq $O/pmc_inst
-python3 tests/micro/summarize_prof.py pmc $O/param_grads_pmc.json param_grads_stream_kernel $O/pmc_fetch $O/pmc_write $O/pmc_sq $O/pmc_inst
+python3 tests/micro/summarize_prof.py pmc $O/param_grads_pmc.json param_grads_reg_kernel $O/pmc_fetch $O/pmc_write $O/pmc_sq $O/pmc_inst
 python3 tests/micro/collect_r05.py pmc_raw $O      # -> $O/fused_pmc_raw.json AND profiles/r05_fused_pmc_raw.json (bench.py reads that one)
 timeout 600 $B 2>$O/bench.err | tail -1 > $O/bench_n1.json; python3 -c "$short" < $O/bench_n1.json
 [ -f gnn-pressure-estimation_amd/lib/libgatres_hip_diag.so ] || python3 gnn-pressure-estimation_amd/_build.py --diag > /dev/null 2>&1
