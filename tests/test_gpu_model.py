@@ -493,6 +493,39 @@ def test_fused_equals_per_op_bitwise_forward(pkg, oracle):
         assert relerr(gf, gp) < 2e-5, (nb, nc, nodes, relerr(gf, gp))
 
 
+@pytest.mark.parametrize("nc", [16, 32])
+def test_parameter_gradient_items_on_segments_of_any_size(pkg, oracle, nc, monkeypatch):
+    """The register-streamed parameter-gradient items (param_grads_reg_kernel: a wave takes 4-row steps round-robin, the
+    last step of a segment may hold 1 .. 3 rows, a wave may hold no step at all) on graphs whose node counts are NOT
+    multiples of four -- 37, 201, 390 and a 6-node graph that leaves two of an item's four waves without rows -- in the
+    stand-alone launch (GATRES_FUSED_NO_CONSUMERS), against the per-op path and the oracle over three training steps."""
+    monkeypatch.setenv("GATRES_FUSED_NO_CONSUMERS", "1")
+    nb = 3
+    sizes = [(390, 433), (37, 41), (201, 230), (6, 5)]
+    tops = [pkg.wdn_synth.make_wdn_topology(n, e, seed=11 + i) for i, (n, e) in enumerate(sizes)]
+    offs = np.cumsum([0] + [n for n, _ in sizes])
+    ei = torch.cat([t + int(o) for t, o in zip(tops, offs[:-1])], dim=1)
+    N = int(offs[-1])
+    npg = [n for n, _ in sizes]
+    y = torch.randn(N, 1, generator=torch.Generator().manual_seed(14))
+    mask = torch.from_numpy(pkg.wdn_synth.generate_batch_mask(npg, 0.95, np.random.RandomState(12)))
+    mf, p = build(pkg, oracle, nb, nc, seed=43, fused=True)
+    mp, _ = build(pkg, oracle, nb, nc, seed=43, fused=False)
+    tf = pkg.GATResTrainer(mf, ei.cuda(), N, nodes_per_graph=npg, use_graph=False, fused=True)
+    tp = pkg.GATResTrainer(mp, ei.cuda(), N, nodes_per_graph=npg, use_graph=False, fused=False)
+    ref = oracle.OracleTrainer(p)
+    for it in range(3):
+        l_ref, o_ref = ref.step(y.clone(), y, ei, mask)
+        lf = tf.step(y.cuda(), y.cuda(), mask.cuda())
+        lp = tp.step(y.cuda(), y.cuda(), mask.cuda())
+        if it == 0:
+            assert torch.equal(tf.out, tp.out)
+        assert relerr(tf.out, o_ref) < 2e-5 and relerr(lf, l_ref) < 2e-5 and relerr(lf, lp) < 1e-6
+        e_pp, e_or = relerr(tf.grads, tp.grads), relerr(tf.grads, ref.flat("grads"))
+        assert torch.isfinite(tf.grads).all() and e_pp < 2e-5 and e_or < 1e-4, (it, e_pp, e_or)
+    note(f"param_grad_items_any_size_nc{nc}", {"grads_vs_per_op": e_pp, "grads_vs_oracle": e_or})
+
+
 @pytest.mark.parametrize("split,mode", [(1, ""), (2, ""), (4, ""), (8, ""), (3, ""), (7, ""), (4, "GATRES_FUSED_NO_HALO"),
                                         (4, "GATRES_FUSED_SAFE_SYNC"), (2, "GATRES_FUSED_NO_CONSUMERS")])
 def test_fused_split_over_cus_matches_per_op(pkg, oracle, split, mode, monkeypatch):
