@@ -47,3 +47,5 @@ timeout 900 $B --no-cpu-baseline --model gatres_large --nodes 50000 --pipes 7500
 timeout 900 $B --no-cpu-baseline --nodes 50000 --pipes 75000 --batch-size 16 --steps 10 --warmup 3 2>/dev/null | tail -1 > $O/small_50k_bs16.json; python3 -c "$short" < $O/small_50k_bs16.json
 rm -rf $O/kt $O/pmc_fetch $O/pmc_write $O/pmc_sq $O/pmc_inst $O/kt_l16 $O/la $O/lb $O/lc $O/ld
 ls -la $O
+# ---- the bench line at the driver's protocol (BENCH_rNN.json: python3 bench.py --gpus 1 --steps 20 --warmup 5)
+timeout 600 $B --gpus 1 --steps 20 --warmup 5 2>/dev/null | tail -1 > $O/bench_driver_protocol.json; python3 -c "$short" < $O/bench_driver_protocol.json
