@@ -1568,9 +1568,11 @@ __device__ __forceinline__ void pgr_load(typename PgrVec<W>::type& d, const floa
 #else
 #define PGR_MOD ""
 #endif
-  if constexpr (W == 4)      asm volatile("global_load_dwordx4 %0, %1, off" PGR_MOD : "=v"(d) : "v"(p) : "memory");
-  else if constexpr (W == 2) asm volatile("global_load_dwordx2 %0, %1, off" PGR_MOD : "=v"(d) : "v"(p) : "memory");
-  else                       asm volatile("global_load_dword %0, %1, off" PGR_MOD : "=v"(d) : "v"(p) : "memory");
+  // "+v": the request lands in the registers the slot already occupies -- the ring stays in place, the compiler cannot rename
+  // a slot between its request and its wait, and the tuple is never a free register while a load is in flight
+  if constexpr (W == 4)      asm volatile("global_load_dwordx4 %0, %1, off" PGR_MOD : "+v"(d) : "v"(p) : "memory");
+  else if constexpr (W == 2) asm volatile("global_load_dwordx2 %0, %1, off" PGR_MOD : "+v"(d) : "v"(p) : "memory");
+  else                       asm volatile("global_load_dword %0, %1, off" PGR_MOD : "+v"(d) : "v"(p) : "memory");
 }
 template <int W>
 __device__ __forceinline__ float pgr_at(const typename PgrVec<W>::type& v, int k) {
@@ -1616,9 +1618,9 @@ __device__ __forceinline__ void param_grads_item_reg(const ParamGradArgs& a, int
 #pragma unroll
     for (int j = 0; j < 2 * H; ++j) accT[j][y] = 0.f;
   }
-  typename PgrVec<VC>::type gv[P];
-  typename PgrVec<VK>::type xv[P];
-  typename PgrVec<H>::type sv[P], dv[P];
+  typename PgrVec<VC>::type gv[P] = {};
+  typename PgrVec<VK>::type xv[P] = {};
+  typename PgrVec<H>::type sv[P] = {}, dv[P] = {};
   // step t of this wave = rows 4 (wave + t NW) + q; a row beyond the segment reads the last row and counts as zero.  EVERY slot
   // is re-requested unconditionally, four instructions each (steps beyond the wave's last re-read its last step: cache hits),
   // so "slot j has landed" is always "at most the 4 (P - 1) younger requests are outstanding"
