@@ -1627,7 +1627,7 @@ __device__ __forceinline__ void param_grads_item_reg(const ParamGradArgs& a, int
   const int last = max(cnt - 1, 0);
 #define PGR_LOAD(slot, t)                                                                        \
   do {                                                                                           \
-    const int r_ = min(4 * (wave + min((t), last) * NW) + q, n - 1);                             \
+    const int r_ = max(min(4 * (wave + min((t), last) * NW) + q, n - 1), 0);                     \
     pgr_load<VC>(gv[slot], gG + (unsigned)(r_ * HC + VC * i));                                   \
     pgr_load<VK>(xv[slot], gX + (unsigned)(r_ * K + VK * i));                                    \
     pgr_load<H>(sv[slot], gS + (unsigned)(r_ * H));                                              \
