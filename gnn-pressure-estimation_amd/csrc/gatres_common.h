@@ -27,7 +27,7 @@ struct gatres_knobs_t {
   int fused_split;            // GATRES_FUSED_SPLIT = 1 .. 8: workgroups per snapshot (0: automatic)
   int fused_safe_sync;        // GATRES_FUSED_SAFE_SYNC: always agent-scope hand-offs (what parts on different XCDs get)
   int fused_no_halo;          // GATRES_FUSED_NO_HALO: whole-segment kernel, bulk pulls (what an overflowing halo list gets)
-  int fused_no_consumers;     // GATRES_FUSED_NO_CONSUMERS: parameter gradients as a launch of their own (what a full chip gets)
+  int fused_no_consumers;     // 1 unless GATRES_FUSED_WITH_CONSUMERS=1: parameter gradients as a launch of their own (the default)
   int fused_no_rounds;        // GATRES_FUSED_NO_ROUNDS: 49 .. 96 segments resident at fewer parts instead of two rounds
   int agg_lane_features;      // GATRES_AGG_LANE_FEATURES = 4 | 8 (0: automatic -- 8 for rows of 64 features and more)
   int lin_bwd_wave;           // GATRES_LIN_BWD_WAVE: lin0 / lin1 backward, one wave per slab (what odd widths get)

@@ -24,7 +24,10 @@ void read_knobs(gatres_knobs_t* k) {
   k->fused_split = env_int("GATRES_FUSED_SPLIT", 0);
   k->fused_safe_sync = env_flag("GATRES_FUSED_SAFE_SYNC");
   k->fused_no_halo = env_flag("GATRES_FUSED_NO_HALO");
-  k->fused_no_consumers = env_flag("GATRES_FUSED_NO_CONSUMERS");
+  // consumer workgroups on a launch's spare CUs are opt-in since round 5: the stand-alone parameter-gradient launch
+  // (param_grads_reg_kernel) is faster at every batch size that leaves CUs free (bs 8 / 16 / 24: 0.317 / 0.322 / 0.328 against
+  // 0.347 / 0.349 / 0.352 ms/step), and it lets the update launch sample the next mask
+  k->fused_no_consumers = env_flag("GATRES_FUSED_WITH_CONSUMERS") ? 0 : 1;
   k->fused_no_rounds = env_flag("GATRES_FUSED_NO_ROUNDS");
   const int lf = env_int("GATRES_AGG_LANE_FEATURES", 0);
   k->agg_lane_features = (lf == 4 || lf == 8) ? lf : 0;

@@ -373,6 +373,7 @@ def test_mask_next_is_refused_where_it_cannot_be_honoured(pkg, oracle, monkeypat
     """GATRES_FLAG_MASK_NEXT on a configuration whose parameter gradients run on consumer workgroups (no step-count
     snapshot for the sampling tail) used to be dropped silently; it is an error now, raised before anything is enqueued."""
     from gnn_pressure_estimation_amd import train_step as TS
+    monkeypatch.setenv("GATRES_FUSED_WITH_CONSUMERS", "1")              # (opt-in since round 5: the stand-alone launch is the default)
     model, p, tr, ei = _trainer(pkg, oracle, bs=8, use_graph=False)      # bs 8: CUs are left, consumers form the gradients
     if tr._mask_next:
         pytest.skip("this configuration folds the update: nothing to refuse")

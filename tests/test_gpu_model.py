@@ -498,8 +498,7 @@ def test_parameter_gradient_items_on_segments_of_any_size(pkg, oracle, nc, monke
     """The register-streamed parameter-gradient items (param_grads_reg_kernel: a wave takes 4-row steps round-robin, the
     last step of a segment may hold 1 .. 3 rows, a wave may hold no step at all) on graphs whose node counts are NOT
     multiples of four -- 37, 201, 390 and a 6-node graph that leaves two of an item's four waves without rows -- in the
-    stand-alone launch (GATRES_FUSED_NO_CONSUMERS), against the per-op path and the oracle over three training steps."""
-    monkeypatch.setenv("GATRES_FUSED_NO_CONSUMERS", "1")
+    stand-alone launch (the default since round 5), against the per-op path and the oracle over three training steps."""
     nb = 3
     sizes = [(390, 433), (37, 41), (201, 230), (6, 5)]
     tops = [pkg.wdn_synth.make_wdn_topology(n, e, seed=11 + i) for i, (n, e) in enumerate(sizes)]
@@ -527,7 +526,8 @@ def test_parameter_gradient_items_on_segments_of_any_size(pkg, oracle, nc, monke
 
 
 @pytest.mark.parametrize("split,mode", [(1, ""), (2, ""), (4, ""), (8, ""), (3, ""), (7, ""), (4, "GATRES_FUSED_NO_HALO"),
-                                        (4, "GATRES_FUSED_SAFE_SYNC"), (2, "GATRES_FUSED_NO_CONSUMERS")])
+                                        (4, "GATRES_FUSED_SAFE_SYNC"), (2, "GATRES_FUSED_WITH_CONSUMERS"),
+                                        (4, "GATRES_FUSED_WITH_CONSUMERS")])
 def test_fused_split_over_cus_matches_per_op(pkg, oracle, split, mode, monkeypatch):
     """One snapshot carried by 1 / 2 / 4 / 8 workgroups (row windows + flag barriers + halo pulls): predictions stay
     bit-identical to the per-op kernels, gradients agree up to the slab partition.  The batch is ragged (a 388-node
@@ -535,7 +535,7 @@ def test_fused_split_over_cus_matches_per_op(pkg, oracle, split, mode, monkeypat
     neighbours are halo rows) and the launches are repeated so that the persistent barrier epochs are exercised."""
     monkeypatch.setenv("GATRES_FUSED_SPLIT", str(split))
     monkeypatch.setenv("GATRES_REORDER", "0")          # keep the shuffled ids: this test is about large halos
-    if mode:                 # the fallbacks: bulk pulls, agent-scope barriers, parameter gradients in a second launch
+    if mode:                 # the fallbacks: bulk pulls, agent-scope barriers; parameter gradients on consumer workgroups of the launch
         monkeypatch.setenv(mode, "1")
     nb, nc = 4, 32
     t_big = pkg.wdn_synth.make_wdn_topology(388, 430, seed=0)
