@@ -594,6 +594,8 @@ def main():
 
     log(f"model/trainer ready on {device}; warm-up {args.warmup} steps")
     run_steps(args.warmup)
+    if store is not None:
+        trainer.fit_epoch(store, args.batch_size, shuffle=True)      # (untimed: captures the epoch's k-step sequence, steps_rows)
     # Every hipGraph the timed steps replay exists BEFORE the first timed block, whatever --warmup is: bind_batches() captured
     # the steady-state step of every (batch, mask buffer) pair (GATResTrainer.precapture_bound).  Checked, not assumed: the
     # number of captured graphs must not move across the timed blocks (block 1 used to hold four captures).

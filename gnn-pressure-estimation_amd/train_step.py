@@ -316,8 +316,9 @@ class GATResTrainer:
                 self._wt_sig = self._param_signature()
             self._mask_sig = self._mask_key() if mask_next else None
 
-    def _replay(self, key: tuple, enqueue: Callable[[], None], wt_valid: bool = False) -> None:
-        """Run ``enqueue`` -- eagerly, or captured once into a hipGraph (cached by ``key``) and replayed."""
+    def _replay(self, key: tuple, enqueue: Callable[[], None], wt_valid: bool = False, extra_state=()) -> None:
+        """Run ``enqueue`` -- eagerly, or captured once into a hipGraph (cached by ``key``) and replayed.  ``extra_state``:
+        tensors the sequence also writes (an epoch's loss accumulator), put back with the optimizer state after the warm-up."""
         if not self.use_graph:
             enqueue()
             return
@@ -326,12 +327,15 @@ class GATResTrainer:
             # warm-up launch outside capture (module load, lazy init, RCCL communicator), then capture the same sequence
             state = (self.step_counter.clone(), self.model.flat_parameters.clone(), self.exp_avg.clone(),
                      self.exp_avg_sq.clone(), self.mask.clone(), self._mask_spare.clone())
+            extra = [(t, t.clone()) for t in extra_state]
 
             def rollback():
                 self.step_counter.copy_(state[0]); self.model.flat_parameters.copy_(state[1])
                 self.exp_avg.copy_(state[2]); self.exp_avg_sq.copy_(state[3])
                 self.mask.copy_(state[4])        # (a warm-up that ran the sampler's launch re-sampled it: same bits; kept simple)
                 self._mask_spare.copy_(state[5])  # (a multi-step sequence samples into BOTH buffers, two steps ahead of the rollback)
+                for t, saved in extra:
+                    t.copy_(saved)
 
             enqueue()
             torch.cuda.synchronize(self.device)
@@ -560,6 +564,51 @@ class GATResTrainer:
             self._run_premasked(ahead=False)
         return True
 
+    def _rows_path_ok(self, data: torch.Tensor) -> bool:
+        npg = self.N // max(self.num_graphs, 1)
+        return (self.node_ptr is not None and not os.environ.get("GATRES_NO_STAGE_MASK") and data.is_cuda
+                and data.device == self.x.device and data.dtype == torch.float32 and data.dim() == 2
+                and data.shape[1] == npg and data.is_contiguous())
+
+    def steps_rows(self, data: torch.Tensor, rows: torch.Tensor, total: Optional[torch.Tensor] = None) -> bool:
+        """``step_rows`` for k consecutive batches -- ``rows`` is a device int64 ``[k * num_graphs]`` slice of an epoch's
+        snapshot order -- as ONE captured launch sequence (k x [collation + mask sampler, window kernel, parameter gradients,
+        update] and, if ``total`` is given, k x ``total += loss * num_graphs``): an epoch then pays the host's per-step work and
+        the gap between two graph launches once per k steps.  The rows are copied into a window buffer the captured kernels read
+        (5 KB per 20 steps); every launch, and so every bit of the result, is the single calls'.  Steady state only (single GPU,
+        fused path, hipGraph replay, transposed weights current); returns False (nothing done) otherwise."""
+        bs = self.num_graphs
+        k = rows.numel() // max(bs, 1)
+        if not (k > 1 and rows.numel() == k * bs and self.use_graph and self.fused and not self.split and self._rows_path_ok(data)
+                and rows.is_cuda and rows.dtype == torch.int64 and self._wt_current()):
+            return False
+        win = getattr(self, "_rows_win", None)
+        if win is None or win.numel() < k * bs:
+            win = self._rows_win = torch.zeros(k * bs, dtype=torch.int64, device=self.device)
+        win[:k * bs].copy_(rows)
+        npg = self.N // bs
+        full = PHASE_FORWARD | PHASE_BACKWARD | PHASE_ADAM
+
+        def enqueue():
+            for i in range(k):
+                _native.check(self.lib.gatres_stage_rows_mask(
+                    data.data_ptr(), win.data_ptr() + 8 * i * bs, npg, self.x.data_ptr(),
+                    None if self.targets_are_inputs else self.y.data_ptr(), self.node_ptr.data_ptr(), bs, self.mask_rate, self.seed,
+                    self.step_counter.data_ptr(), self.mask.data_ptr(), _native.current_stream(self.device)), "gatres_stage_rows_mask")
+                self._enqueue(full, True, True, flags=0)
+                if total is not None:
+                    total.add_(self.loss, alpha=float(bs))
+
+        try:
+            self._replay(("rowseq", k, data.data_ptr(), win.data_ptr(), None if total is None else total.data_ptr(),
+                          self.mask_rate, self.seed, self.world), enqueue, True, extra_state=() if total is None else (total,))
+        finally:
+            for _ in range(k):
+                self._count_native_update()
+            self._wt_sig = self._param_signature()
+            self._mask_sig = None
+        return True
+
     def step(self, x: torch.Tensor, y: torch.Tensor, mask: Optional[torch.Tensor] = None) -> torch.Tensor:
         """Reference-shaped call: one iteration of train.py:159-190.  Returns the (device) loss tensor."""
         if mask is None and self._stage_with_mask(x, y):                        # (the mask of this step is in place)
@@ -776,12 +825,44 @@ class GATResTrainer:
             raise ValueError(f"this trainer was built for batches of {self.num_graphs} graphs x {self.N // max(self.num_graphs, 1)} nodes")
         if self.world > 1:
             drop_last = True                 # equal graph counts on every rank keep plain gradient averaging exact
-        total = torch.zeros(1, dtype=torch.float32, device=self.device)
+        total = getattr(self, "_epoch_total", None)
+        if total is None:
+            total = self._epoch_total = torch.zeros(1, dtype=torch.float32, device=self.device)   # (persistent: captured sequences add to it)
+        total.zero_()
         sums = {k: 0.0 for k in (metric_fn_dict or {})}
         seen = 0
         # the epoch's snapshot order goes to the device ONCE; a batch is a slice of it, collated inside the mask sampler's
-        # launch (step_rows) -- the reference collates on the host and copies every iteration (train.py:302-303)
+        # launch (step_rows) -- the reference collates on the host and copies every iteration (train.py:302-303).  Runs of
+        # `epoch_graph_steps` full batches go through ONE captured sequence each (steps_rows); what is left -- the first step
+        # of a run whose transposed weights are not current, the epoch's last few batches, the ragged one -- goes step by step.
+        kseq = int(getattr(self, "epoch_graph_steps", 20))
+        pending = []                                     # full batches waiting for a sequence
+
+        def flush(n_keep: int = 0):
+            nonlocal seen
+            while len(pending) > n_keep:
+                rows_one = pending.pop(0)
+                if not self.step_rows(store.data, rows_one):
+                    x = store.batch(rows_one)
+                    self.load_batch(x, x)
+                    self.run_step(device_mask=True)
+                total.add_(self.loss, alpha=float(bs))
+                seen += bs
+
         for rows, edge_index, ng in store.row_batches(bs, shuffle=shuffle, drop_last=drop_last, generator=generator):
+            if ng == bs and not metric_fn_dict and kseq > 1:
+                pending.append(rows)
+                if len(pending) == kseq:
+                    # (row_batches yields consecutive slices of ONE order tensor: the run is its slice too)
+                    run = torch.cat(pending) if pending[0].data_ptr() + 8 * bs * (kseq - 1) != pending[-1].data_ptr() else \
+                        torch.as_strided(pending[0], (kseq * bs,), (1,))
+                    if self.steps_rows(store.data, run, total):
+                        seen += kseq * bs
+                        pending.clear()
+                    else:
+                        flush(n_keep=kseq - 1)           # one step by itself (it makes the weights current), then try again
+                continue
+            flush()
             tr = self if ng == bs else self._sibling(ng, npg, edge_index)
             if not tr.step_rows(store.data, rows):
                 x = store.batch(rows)
@@ -794,6 +875,7 @@ class GATResTrainer:
                 for k, fn in metric_fn_dict.items():
                     sums[k] += float(fn(p, t)) * ng
             seen += ng
+        flush()
         if seen == 0:
             raise ValueError("the store yielded no batch")
         mean_loss = float(total.item()) / seen
