@@ -117,6 +117,7 @@ class GATResTrainer:
         # then the parameter gradients of the upper and of the lower blocks as range launches, the first bucket on the wire
         # under the second launch (DESIGN.md section 5 has the measured cost of either form on one GPU).
         self.fused_buckets = 1
+        self.epoch_graph_steps = 20          # fit_epoch: full batches per captured launch sequence (steps_rows); 1 = step by step
         self._max_graphs = MAX_CACHED_GRAPHS
         # Multi-rank steps run as EAGER launch sequences unless GATRES_DP_GRAPH=1: a captured step would hold the RCCL
         # all-reduce, which has only ever been captured with a one-rank group here (no multi-GPU box is reachable), and
@@ -835,7 +836,7 @@ class GATResTrainer:
         # launch (step_rows) -- the reference collates on the host and copies every iteration (train.py:302-303).  Runs of
         # `epoch_graph_steps` full batches go through ONE captured sequence each (steps_rows); what is left -- the first step
         # of a run whose transposed weights are not current, the epoch's last few batches, the ragged one -- goes step by step.
-        kseq = int(getattr(self, "epoch_graph_steps", 20))
+        kseq = int(self.epoch_graph_steps)
         pending = []                                     # full batches waiting for a sequence
 
         def flush(n_keep: int = 0):
