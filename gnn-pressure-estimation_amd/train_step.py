@@ -192,7 +192,7 @@ class GATResTrainer:
         self.hp.copy_(torch.tensor(self._hp_list(), dtype=torch.float64), non_blocking=False)
 
     def _desc(self, phases: int, device_mask: bool, wt_valid: bool = False, flags: int = 0, block_lo: int = 0,
-              block_hi: int = 0, batch=None, masks=None) -> _TrainStepC:
+              block_hi: int = 0, batch=None, masks=None, loss=None) -> _TrainStepC:
         m = self.model
         bx, by = (self.x, self.y) if batch is None else batch
         mask, mask_next = (self.mask, self._mask_spare) if masks is None else masks
@@ -206,7 +206,7 @@ class GATResTrainer:
             by.data_ptr(), mask.data_ptr(),
             self.node_ptr.data_ptr() if (device_mask and self.node_ptr is not None) else None,
             self.num_graphs, phases, self.mask_rate, self.seed, self.out.data_ptr(), self.g_out.data_ptr(),
-            self.loss.data_ptr(), self.saved.data_ptr(), self.scratch.data_ptr(), h["lr"], h["beta1"], h["beta2"],
+            (self.loss if loss is None else loss).data_ptr(), self.saved.data_ptr(), self.scratch.data_ptr(), h["lr"], h["beta1"], h["beta2"],
             h["eps"], h["weight_decay"], 1.0 / self.world,
             (0 if self.fused else FLAG_PER_OP) | (FLAG_WT_VALID if wt_valid else 0) | flags, self.hp.data_ptr(),
             block_lo, block_hi, mask_next.data_ptr())
@@ -287,8 +287,8 @@ class GATResTrainer:
         return int(self._status[1].item()) if self._status is not None else 0
 
     def _enqueue(self, phases: int, device_mask: bool, wt_valid: bool = False, flags: int = 0, block_lo: int = 0,
-                 block_hi: int = 0, batch=None, masks=None) -> None:
-        ts = self._desc(phases, device_mask, wt_valid, flags, block_lo, block_hi, batch, masks)
+                 block_hi: int = 0, batch=None, masks=None, loss=None) -> None:
+        ts = self._desc(phases, device_mask, wt_valid, flags, block_lo, block_hi, batch, masks, loss)
         _native.check(self.lib.gatres_train_step(C.byref(ts), _native.current_stream(self.device)),
                       "gatres_train_step")
 
@@ -317,9 +317,8 @@ class GATResTrainer:
                 self._wt_sig = self._param_signature()
             self._mask_sig = self._mask_key() if mask_next else None
 
-    def _replay(self, key: tuple, enqueue: Callable[[], None], wt_valid: bool = False, extra_state=()) -> None:
-        """Run ``enqueue`` -- eagerly, or captured once into a hipGraph (cached by ``key``) and replayed.  ``extra_state``:
-        tensors the sequence also writes (an epoch's loss accumulator), put back with the optimizer state after the warm-up."""
+    def _replay(self, key: tuple, enqueue: Callable[[], None], wt_valid: bool = False) -> None:
+        """Run ``enqueue`` -- eagerly, or captured once into a hipGraph (cached by ``key``) and replayed."""
         if not self.use_graph:
             enqueue()
             return
@@ -328,15 +327,12 @@ class GATResTrainer:
             # warm-up launch outside capture (module load, lazy init, RCCL communicator), then capture the same sequence
             state = (self.step_counter.clone(), self.model.flat_parameters.clone(), self.exp_avg.clone(),
                      self.exp_avg_sq.clone(), self.mask.clone(), self._mask_spare.clone())
-            extra = [(t, t.clone()) for t in extra_state]
 
             def rollback():
                 self.step_counter.copy_(state[0]); self.model.flat_parameters.copy_(state[1])
                 self.exp_avg.copy_(state[2]); self.exp_avg_sq.copy_(state[3])
                 self.mask.copy_(state[4])        # (a warm-up that ran the sampler's launch re-sampled it: same bits; kept simple)
                 self._mask_spare.copy_(state[5])  # (a multi-step sequence samples into BOTH buffers, two steps ahead of the rollback)
-                for t, saved in extra:
-                    t.copy_(saved)
 
             enqueue()
             torch.cuda.synchronize(self.device)
@@ -574,10 +570,12 @@ class GATResTrainer:
     def steps_rows(self, data: torch.Tensor, rows: torch.Tensor, total: Optional[torch.Tensor] = None) -> bool:
         """``step_rows`` for k consecutive batches -- ``rows`` is a device int64 ``[k * num_graphs]`` slice of an epoch's
         snapshot order -- as ONE captured launch sequence (k x [collation + mask sampler, window kernel, parameter gradients,
-        update] and, if ``total`` is given, k x ``total += loss * num_graphs``): an epoch then pays the host's per-step work and
-        the gap between two graph launches once per k steps.  The rows are copied into a window buffer the captured kernels read
-        (5 KB per 20 steps); every launch, and so every bit of the result, is the single calls'.  Steady state only (single GPU,
-        fused path, hipGraph replay, transposed weights current); returns False (nothing done) otherwise."""
+        update]): an epoch then pays the host's per-step work and the gap between two graph launches once per k steps.  The
+        rows are copied into a window buffer the captured kernels read (5 KB per 20 steps) and step i's update launch writes
+        its loss into entry i of a k-vector; every launch, and so every bit of the result, is the single calls'.  ``total``
+        (float64 ``[1]``): += sum of the k losses x num_graphs -- in double, where a sum of fp32 losses is exact, so it does not
+        matter that the k terms are added at once.  Steady state only (single GPU, fused path, hipGraph replay, transposed
+        weights current); returns False (nothing done) otherwise."""
         bs = self.num_graphs
         k = rows.numel() // max(bs, 1)
         if not (k > 1 and rows.numel() == k * bs and self.use_graph and self.fused and not self.split and self._rows_path_ok(data)
@@ -586,7 +584,9 @@ class GATResTrainer:
         win = getattr(self, "_rows_win", None)
         if win is None or win.numel() < k * bs:
             win = self._rows_win = torch.zeros(k * bs, dtype=torch.int64, device=self.device)
+            self._loss_seq = torch.zeros(k, dtype=torch.float32, device=self.device)
         win[:k * bs].copy_(rows)
+        lseq = self._loss_seq
         npg = self.N // bs
         full = PHASE_FORWARD | PHASE_BACKWARD | PHASE_ADAM
 
@@ -596,18 +596,19 @@ class GATResTrainer:
                     data.data_ptr(), win.data_ptr() + 8 * i * bs, npg, self.x.data_ptr(),
                     None if self.targets_are_inputs else self.y.data_ptr(), self.node_ptr.data_ptr(), bs, self.mask_rate, self.seed,
                     self.step_counter.data_ptr(), self.mask.data_ptr(), _native.current_stream(self.device)), "gatres_stage_rows_mask")
-                self._enqueue(full, True, True, flags=0)
-                if total is not None:
-                    total.add_(self.loss, alpha=float(bs))
+                self._enqueue(full, True, True, flags=0, loss=lseq[i:i + 1])
 
         try:
-            self._replay(("rowseq", k, data.data_ptr(), win.data_ptr(), None if total is None else total.data_ptr(),
-                          self.mask_rate, self.seed, self.world), enqueue, True, extra_state=() if total is None else (total,))
+            self._replay(("rowseq", k, data.data_ptr(), win.data_ptr(), lseq.data_ptr(), self.mask_rate, self.seed, self.world),
+                         enqueue, True)
         finally:
             for _ in range(k):
                 self._count_native_update()
             self._wt_sig = self._param_signature()
             self._mask_sig = None
+        self.loss.copy_(lseq[k - 1:k])                   # (the loss of the step that ran last, as after single steps)
+        if total is not None:
+            total.add_(lseq[:k].double().sum(), alpha=float(bs))
         return True
 
     def step(self, x: torch.Tensor, y: torch.Tensor, mask: Optional[torch.Tensor] = None) -> torch.Tensor:
@@ -826,10 +827,9 @@ class GATResTrainer:
             raise ValueError(f"this trainer was built for batches of {self.num_graphs} graphs x {self.N // max(self.num_graphs, 1)} nodes")
         if self.world > 1:
             drop_last = True                 # equal graph counts on every rank keep plain gradient averaging exact
-        total = getattr(self, "_epoch_total", None)
-        if total is None:
-            total = self._epoch_total = torch.zeros(1, dtype=torch.float32, device=self.device)   # (persistent: captured sequences add to it)
-        total.zero_()
+        # the epoch's loss sum in DOUBLE (train.py:196 accumulates Python floats): a sum of fp32 losses is exact there, so a
+        # sequence's k losses added at once and the same losses added one by one give the same bits
+        total = torch.zeros(1, dtype=torch.float64, device=self.device)
         sums = {k: 0.0 for k in (metric_fn_dict or {})}
         seen = 0
         # the epoch's snapshot order goes to the device ONCE; a batch is a slice of it, collated inside the mask sampler's
@@ -847,7 +847,7 @@ class GATResTrainer:
                     x = store.batch(rows_one)
                     self.load_batch(x, x)
                     self.run_step(device_mask=True)
-                total.add_(self.loss, alpha=float(bs))
+                total.add_(self.loss.double(), alpha=float(bs))
                 seen += bs
 
         for rows, edge_index, ng in store.row_batches(bs, shuffle=shuffle, drop_last=drop_last, generator=generator):
@@ -869,7 +869,7 @@ class GATResTrainer:
                 x = store.batch(rows)
                 tr.load_batch(x, x)
                 tr.run_step(device_mask=True)
-            total.add_(tr.loss, alpha=float(ng))
+            total.add_(tr.loss.double(), alpha=float(ng))
             if metric_fn_dict:
                 m = tr.mask.bool()
                 p, t = store.descale(tr.out[m]), store.descale(tr.x[m])
