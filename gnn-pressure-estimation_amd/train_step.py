@@ -837,6 +837,8 @@ class GATResTrainer:
         # `epoch_graph_steps` full batches go through ONE captured sequence each (steps_rows); what is left -- the first step
         # of a run whose transposed weights are not current, the epoch's last few batches, the ragged one -- goes step by step.
         kseq = int(self.epoch_graph_steps)
+        if not (self.use_graph and self.fused and not self.split and self._rows_path_ok(store.data)):
+            kseq = 1                                     # (eager / data-parallel / per-op trainers: step by step)
         pending = []                                     # full batches waiting for a sequence
 
         def flush(n_keep: int = 0):
