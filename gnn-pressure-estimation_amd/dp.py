@@ -62,12 +62,19 @@ class BucketedAllReduce:
         self.launched: List[Tuple[int, int]] = []          # (lo, hi) of every bucket of the current step, in launch order
         self.last_buckets: List[Tuple[int, int]] = []
 
-    def launch(self, lo: int, hi: int) -> None:
+    def launch(self, lo: int, hi: int, alone: bool = False) -> None:
+        """``alone``: this bucket is the step's only one (the fused path's flat gradient) -- nothing can overlap it, so it goes
+        as a SYNCHRONOUS collective: ordered on the caller's stream by the backend itself, without the event hand-over to the
+        process group's stream and back that an asynchronous one costs (measured at world size 1, eager launches, RCCL:
+        0.3695 -> 0.3527 ms/step)."""
         if not 0 <= lo < hi <= self.flat.numel():
             raise ValueError(f"bad bucket [{lo}, {hi})")
         self.launched.append((lo, hi))
         if self.active:
-            self._works.append(dist.all_reduce(self.flat[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+            if alone and not self._works:
+                dist.all_reduce(self.flat[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=False)
+            else:
+                self._works.append(dist.all_reduce(self.flat[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
     def wait_all(self) -> None:
         for w in self._works:
@@ -92,9 +99,10 @@ def run_data_parallel_step(pieces: Iterable[Callable[[], Tuple[int, int]]], redu
     (for gatres_large: one bucket per group of blocks, in reverse block order; for the single fused launch of
     gatres_small there is one piece -- its gradient only exists after the slab reduction that ends the launch
     sequence).  ``update`` (Adam with grad_scale = 1/world) runs after every bucket has arrived."""
+    pieces = list(pieces)
     for piece in pieces:
         lo, hi = piece()
-        reducer.launch(lo, hi)
+        reducer.launch(lo, hi, alone=len(pieces) == 1)
     reducer.wait_all()
     update()
 
