@@ -69,13 +69,20 @@ class SnapshotStore:
                 break
             yield self.batch(rows), self.edge_index(int(rows.numel())), int(rows.numel())
 
+    def epoch_order(self, shuffle: bool = True, generator: Optional[torch.Generator] = None) -> torch.Tensor:
+        """The epoch's snapshot order as a DEVICE int64 vector (one upload per epoch)."""
+        order = torch.randperm(self.num_snapshots, generator=generator) if shuffle else torch.arange(self.num_snapshots)
+        return order.to(self.device)
+
     def row_batches(self, batch_size: int, shuffle: bool = True, drop_last: bool = False,
-                    generator: Optional[torch.Generator] = None) -> Iterator[Tuple[torch.Tensor, torch.Tensor, int]]:
+                    generator: Optional[torch.Generator] = None, order: Optional[torch.Tensor] = None,
+                    first: int = 0) -> Iterator[Tuple[torch.Tensor, torch.Tensor, int]]:
         """Yields ``(rows, edge_index, num_graphs)``: ``rows`` is a DEVICE int64 slice of the epoch's snapshot order
-        (uploaded once per epoch), for consumers that collate on the device themselves (``GATResTrainer.step_rows``)."""
-        order = (torch.randperm(self.num_snapshots, generator=generator) if shuffle
-                 else torch.arange(self.num_snapshots)).to(self.device)
-        for s in range(0, self.num_snapshots, batch_size):
+        (uploaded once per epoch; ``order``: use this one, ``epoch_order()``'s), for consumers that collate on the device
+        themselves (``GATResTrainer.step_rows``).  ``first``: start at that batch."""
+        if order is None:
+            order = self.epoch_order(shuffle, generator)
+        for s in range(first * batch_size, self.num_snapshots, batch_size):
             rows = order[s:s + batch_size]
             if drop_last and rows.numel() < batch_size:
                 break

@@ -117,7 +117,8 @@ class GATResTrainer:
         # then the parameter gradients of the upper and of the lower blocks as range launches, the first bucket on the wire
         # under the second launch (DESIGN.md section 5 has the measured cost of either form on one GPU).
         self.fused_buckets = 1
-        self.epoch_graph_steps = 20          # fit_epoch: full batches per captured launch sequence (steps_rows); 1 = step by step
+        self.epoch_graph_steps = 20          # fit_epoch: full batches per captured launch sequence; 1 = step by step
+        self.epoch_copy_limit_bytes = 16 << 30   # fit_epoch trains on a shuffled device copy of the store up to this size (else: steps_rows)
         self._max_graphs = MAX_CACHED_GRAPHS
         # Multi-rank steps run as EAGER launch sequences unless GATRES_DP_GRAPH=1: a captured step would hold the RCCL
         # all-reduce, which has only ever been captured with a one-rank group here (no multi-GPU box is reachable), and
@@ -748,31 +749,41 @@ class GATResTrainer:
         self._run(PHASE_MASK | PHASE_FORWARD | PHASE_BACKWARD | PHASE_ADAM, True, batch=(x, y), slot=i)
         return self.loss
 
-    def steps_bound(self, indices) -> torch.Tensor:
+    def steps_bound(self, indices, bound=None, losses: Optional[torch.Tensor] = None) -> torch.Tensor:
         """``step_bound(i)`` for every i of ``indices``, in order -- as ONE captured launch sequence when the trainer is in its
         steady state (single GPU, fused path, transposed weights current, the first mask sampled ahead): 3 k kernels in one
         hipGraph, so the ~8 us between two graph launches are paid once per k steps instead of once per step.  The two mask
         buffers take turns inside the sequence exactly as they do between ``step_bound`` calls (step j trains on the mask the
         update launch of step j - 1 sampled), so the results are those of the single calls bit for bit.  Anything else (first
-        step, data-parallel trainer, eager launches) falls back to the single calls.  Returns the last step's loss tensor."""
+        step, data-parallel trainer, eager launches) falls back to the single calls.  ``bound``: another list of resident
+        ``(x, y)`` batches than the one ``bind_batches`` registered (``fit_epoch``'s epoch buffer); ``losses``: a float32 vector
+        whose entry j receives step j's loss.  Returns the last step's loss tensor."""
         idx = tuple(int(i) for i in indices)
+        bnd = self._bound if bound is None else bound
         steady = (len(idx) > 1 and self.use_graph and self.fused and not self.split and self._mask_next and self._wt_current()
                   and self._mask_sig is not None and self._mask_sig == self._mask_key() and self.node_ptr is not None)
         if not steady:
-            for i in idx:
-                self.step_bound(i)
+            for j, i in enumerate(idx):
+                if bound is None:
+                    self.step_bound(i)
+                else:
+                    self._step_on(bnd[i], ("epoch", i))
+                if losses is not None:
+                    losses[j:j + 1].copy_(self.loss)
             return self.loss
         full = PHASE_FORWARD | PHASE_BACKWARD | PHASE_ADAM
         m0, m1 = self._mask_spare, self.mask          # step 0 trains on the mask sampled ahead and samples step 1's into the other
 
         def enqueue():
             a, b = m0, m1
-            for i in idx:
-                self._enqueue(full, True, True, flags=FLAG_MASK_NEXT, batch=self._bound[i], masks=(a, b))
+            for j, i in enumerate(idx):
+                self._enqueue(full, True, True, flags=FLAG_MASK_NEXT, batch=bnd[i], masks=(a, b),
+                              loss=None if losses is None else losses[j:j + 1])
                 a, b = b, a
 
         try:
-            self._replay(("seq", idx, self.mask_rate, self.seed, self.world, m0.data_ptr()), enqueue, True)
+            self._replay(("seq", idx, self.mask_rate, self.seed, self.world, m0.data_ptr(), bnd[idx[0]][0].data_ptr(),
+                          None if losses is None else losses.data_ptr()), enqueue, True)
         finally:
             for _ in idx:
                 self._count_native_update()
@@ -780,6 +791,18 @@ class GATResTrainer:
             if len(idx) % 2:                           # an odd number of steps leaves the buffers swapped
                 self.mask, self._mask_spare = self._mask_spare, self.mask
             self._mask_sig = self._mask_key()          # (the last update launch sampled the next step's mask into the spare buffer)
+        if losses is not None:
+            self.loss.copy_(losses[len(idx) - 1:len(idx)])
+        return self.loss
+
+    def _step_on(self, batch, slot) -> torch.Tensor:
+        """``step_bound`` on a resident ``(x, y)`` batch that is not in the bound list (``slot`` names it in the graph cache)."""
+        if self.node_ptr is None:
+            raise ValueError("device mask sampling needs nodes_per_graph at construction")
+        if self.split:
+            self._run_split(True, batch=batch, slot=slot)
+        else:
+            self._run(PHASE_MASK | PHASE_FORWARD | PHASE_BACKWARD | PHASE_ADAM, True, batch=batch, slot=slot)
         return self.loss
 
     def forward_backward(self, x: torch.Tensor, y: torch.Tensor, mask: torch.Tensor) -> torch.Tensor:
@@ -793,6 +816,30 @@ class GATResTrainer:
         return int(self.step_counter[0].item())
 
     # ---- epoch-level loop (train.py:112-202) ---------------------------------------------------------------------------
+    def _epoch_in_place(self, store, order: torch.Tensor, nfull: int, kseq: int, total: torch.Tensor) -> None:
+        bs, npg = self.num_graphs, store.nodes_per_graph
+        buf = getattr(self, "_epoch_buf", None)
+        if buf is None or tuple(buf.shape) != (nfull * bs, npg):
+            buf = self._epoch_buf = torch.empty(nfull * bs, npg, dtype=torch.float32, device=self.device)
+            views = [buf[j * bs:(j + 1) * bs].reshape(-1) for j in range(nfull)]
+            self._epoch_bound = [(v, v) for v in views]            # (x is also y: train.py:162-166)
+            self._epoch_losses = torch.zeros(max(kseq, 2), dtype=torch.float32, device=self.device)
+            # sequences of k (one graph per run of the epoch and mask orientation), single steps where a run starts or ends
+            self._max_graphs = max(self._max_graphs, MAX_CACHED_GRAPHS + 2 * (nfull // kseq + 1) + 2 * kseq + 8)
+        torch.index_select(store.data, 0, order[:nfull * bs], out=buf)
+        eb, lseq = self._epoch_bound, self._epoch_losses
+        j = 0
+        while j < nfull:
+            steady = (self._wt_current() and self._mask_sig is not None and self._mask_sig == self._mask_key())
+            k = min(kseq, nfull - j) if steady else 1
+            if k > 1:
+                self.steps_bound(range(j, j + k), bound=eb, losses=lseq)
+                total.add_(lseq[:k].double().sum(), alpha=float(bs))
+            else:
+                self._step_on(eb[j], ("epoch", j))
+                total.add_(self.loss.double(), alpha=float(bs))
+            j += k
+
     def _sibling(self, num_graphs: int, nodes_per_graph: int, edge_index: torch.Tensor) -> "GATResTrainer":
         """Trainer for another batch size of the same dataset (the ragged last batch of an epoch): its own plan and
         buffers, the SAME model, Adam moments and step counter."""
@@ -839,6 +886,16 @@ class GATResTrainer:
         kseq = int(self.epoch_graph_steps)
         if not (self.use_graph and self.fused and not self.split and self._rows_path_ok(store.data)):
             kseq = 1                                     # (eager / data-parallel / per-op trainers: step by step)
+        order = store.epoch_order(shuffle=shuffle, generator=generator)
+        first = 0                                        # batches [0, first) are done by the in-place path below
+        nfull = store.num_snapshots // bs
+        if (kseq > 1 and not metric_fn_dict and nfull >= 2 and self._mask_next and self.node_ptr is not None
+                and 4 * nfull * bs * npg <= int(self.epoch_copy_limit_bytes)):
+            # The epoch's full batches as ONE device gather into a persistent buffer (the shuffled store: S x N_g floats), then
+            # trained IN PLACE, k per captured launch sequence, with the mask sampled ahead by the update launches -- the
+            # bound-batch step of bench.py, three launches and nothing else: no collation launch, no per-step host work.
+            self._epoch_in_place(store, order, nfull, kseq, total)
+            first, seen = nfull, nfull * bs
         pending = []                                     # full batches waiting for a sequence
 
         def flush(n_keep: int = 0):
@@ -852,7 +909,7 @@ class GATResTrainer:
                 total.add_(self.loss.double(), alpha=float(bs))
                 seen += bs
 
-        for rows, edge_index, ng in store.row_batches(bs, shuffle=shuffle, drop_last=drop_last, generator=generator):
+        for rows, edge_index, ng in store.row_batches(bs, drop_last=drop_last, order=order, first=first):
             if ng == bs and not metric_fn_dict and kseq > 1:
                 pending.append(rows)
                 if len(pending) == kseq:

@@ -432,29 +432,35 @@ def test_snapshot_store_collation_on_device_and_fit_epoch(pkg, oracle):
 
 
 def test_fit_epoch_sequences_equal_single_steps(pkg, oracle):
-    """Round 5: fit_epoch sends runs of `epoch_graph_steps` full batches through ONE captured launch sequence each
-    (GATResTrainer.steps_rows: k x [collation + mask sampler, window kernel, parameter gradients, update, total += loss]).
-    Two epochs over 23 snapshots in batches of 2 -- the first step by itself (its transposed weights are not current), two
-    sequences of 4, two single steps, a ragged batch of 1 on the sibling trainer; the second epoch replays the captured
-    sequence -- must equal, bit for bit, the same epochs stepped one batch at a time: mean losses, masks, parameters, moments,
-    step count."""
+    """Round 5: fit_epoch trains an epoch's full batches IN PLACE on a shuffled device copy of the store (one gather per epoch),
+    `epoch_graph_steps` per captured launch sequence with the mask sampled ahead by the update launches
+    (``steps_bound(bound=..., losses=...)``); a store beyond ``epoch_copy_limit_bytes`` goes through ``steps_rows`` instead
+    (k x [collation + mask sampler, the step's three launches] per sequence).  Two epochs over 23 snapshots in batches of 2 --
+    11 full batches (the first by itself: its transposed weights are not current; sequences of 4; what is left by itself or as
+    a shorter sequence) and a ragged batch of 1 on the sibling trainer; the second epoch replays the captured sequences -- must
+    equal, bit for bit, the same epochs stepped one batch at a time through the collation launch: mean losses, masks,
+    parameters, moments, step count."""
     one = pkg.wdn_synth.make_wdn_topology()
     raw = pkg.wdn_synth.make_snapshots(23, 388, seed=13) * 6 + 35
     st = pkg.SnapshotStore(raw, one, device="cuda")
     nb, nc, bs = 3, 32, 2
     res = []
-    for kseq in (4, 1):
+    for kseq, limit, kind in ((4, None, "seq"), (4, 0, "rowseq"), (1, 0, None)):
         model, _ = build(pkg, oracle, nb, nc, seed=18)
         tr = pkg.GATResTrainer(model, st.edge_index(bs), 388 * bs, nodes_per_graph=[388] * bs, seed=9, targets_are_inputs=True)
         tr.epoch_graph_steps = kseq
+        if limit is not None:
+            tr.epoch_copy_limit_bytes = limit
         losses = [tr.fit_epoch(st, bs, shuffle=True, generator=torch.Generator().manual_seed(31 + ep))[0] for ep in range(2)]
         assert tr.optimizer_step == 24 and tr.dropped_steps == 0
-        if kseq > 1:
-            assert any(k[0] == "rowseq" for k in tr._graphs), "the sequence path was not taken"
+        taken = {k[0] for k in tr._graphs if isinstance(k[0], str)}
+        assert kind is None or kind in taken, (kind, taken)
+        assert kind == "seq" or "seq" not in taken
         res.append((losses, model.flat_parameters.clone(), tr.exp_avg.clone(), tr.exp_avg_sq.clone(), tr.mask.clone()))
-    assert res[0][0] == res[1][0], (res[0][0], res[1][0])
-    for a, b in zip(res[0][1:], res[1][1:]):
-        assert torch.equal(a, b)
+    for other in res[1:]:
+        assert res[0][0] == other[0], (res[0][0], other[0])
+        for a, b in zip(res[0][1:], other[1:]):
+            assert torch.equal(a, b)
 
 
 @pytest.mark.parametrize("use_graph", [False, True])
