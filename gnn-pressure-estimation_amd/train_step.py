@@ -767,7 +767,7 @@ class GATResTrainer:
                 if bound is None:
                     self.step_bound(i)
                 else:
-                    self._step_on(bnd[i], ("epoch", i))
+                    self._step_on(bnd[i], ("at", bnd[i][0].data_ptr(), bnd[i][1].data_ptr()))
                 if losses is not None:
                     losses[j:j + 1].copy_(self.loss)
             return self.loss
@@ -796,7 +796,8 @@ class GATResTrainer:
         return self.loss
 
     def _step_on(self, batch, slot) -> torch.Tensor:
-        """``step_bound`` on a resident ``(x, y)`` batch that is not in the bound list (``slot`` names it in the graph cache)."""
+        """``step_bound`` on a resident ``(x, y)`` batch that is not in the bound list (``slot`` names it in the graph cache: use
+        the buffers' addresses)."""
         if self.node_ptr is None:
             raise ValueError("device mask sampling needs nodes_per_graph at construction")
         if self.split:
@@ -836,7 +837,7 @@ class GATResTrainer:
                 self.steps_bound(range(j, j + k), bound=eb, losses=lseq)
                 total.add_(lseq[:k].double().sum(), alpha=float(bs))
             else:
-                self._step_on(eb[j], ("epoch", j))
+                self._step_on(eb[j], ("at", eb[j][0].data_ptr(), eb[j][1].data_ptr()))   # (the slot names the buffers: a re-allocated epoch buffer never meets a stale graph)
                 total.add_(self.loss.double(), alpha=float(bs))
             j += k
 
