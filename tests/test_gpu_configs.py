@@ -443,6 +443,7 @@ def test_fit_epoch_sequences_equal_single_steps(pkg, oracle):
     one = pkg.wdn_synth.make_wdn_topology()
     raw = pkg.wdn_synth.make_snapshots(23, 388, seed=13) * 6 + 35
     st = pkg.SnapshotStore(raw, one, device="cuda")
+    st2 = pkg.SnapshotStore(pkg.wdn_synth.make_snapshots(17, 388, seed=14) * 6 + 35, one, device="cuda")
     nb, nc, bs = 3, 32, 2
     res = []
     for kseq, limit, kind in ((4, None, "seq"), (4, 0, "rowseq"), (1, 0, None)):
@@ -453,6 +454,9 @@ def test_fit_epoch_sequences_equal_single_steps(pkg, oracle):
             tr.epoch_copy_limit_bytes = limit
         losses = [tr.fit_epoch(st, bs, shuffle=True, generator=torch.Generator().manual_seed(31 + ep))[0] for ep in range(2)]
         assert tr.optimizer_step == 24 and tr.dropped_steps == 0
+        # a third epoch over a store of another size: the epoch buffer is re-allocated, no graph of the old one may be replayed
+        losses.append(tr.fit_epoch(st2, bs, shuffle=True, generator=torch.Generator().manual_seed(40))[0])
+        assert tr.optimizer_step == 24 + 9
         taken = {k[0] for k in tr._graphs if isinstance(k[0], str)}
         assert kind is None or kind in taken, (kind, taken)
         assert kind == "seq" or "seq" not in taken
