@@ -551,9 +551,8 @@ def main():
 
     def one_step(i):
         if args.host_batches:                       # batch i was prefetched during step i - 1; start fetching i + 1
-            trainer.commit_batch()
+            trainer.step_prefetched()               # (trains on the staging slot in place: no device copy, mask sampled ahead)
             trainer.prefetch_batch(batches[(i + 1) % nbatches])
-            trainer.run_step(device_mask=True)
         elif args.copy_batches:                     # device-resident batch through the reference-shaped call (train.py:159-190):
             b = batches[i % nbatches]               # staged into the trainer's own buffer by one extra launch
             trainer.step(b, b)

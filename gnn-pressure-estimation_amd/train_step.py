@@ -510,6 +510,21 @@ class GATResTrainer:
         self._free[k].record(cur)
         self._slot_out = 1 - k
 
+    def step_prefetched(self) -> torch.Tensor:
+        """One optimisation step (device-sampled mask) on the prefetched batch IN PLACE: the kernels read the staging slot the
+        side stream filled -- they never write x -- so there is no device copy and, with the mask sampled ahead by the previous
+        update launch, no sampler launch either: the bound-batch step's three launches, the PCIe transfer of the next batch
+        under them.  ``commit_batch()`` + ``run_step()`` is the same step through the static buffers (two launches more)."""
+        k = self._slot_out
+        cur = torch.cuda.current_stream(self.device)
+        cur.wait_event(self._ready[k])
+        sx, sy = self._stage[k]
+        batch = (sx, sx if sy is None else sy)
+        self._step_on(batch, ("at", batch[0].data_ptr(), batch[1].data_ptr()))
+        self._free[k].record(cur)                  # (the slot may be refilled once this step has read it)
+        self._slot_out = 1 - k
+        return self.loss
+
     def run_step(self, device_mask: bool = True) -> None:
         """One optimisation step on the staged batch.  Nothing is synchronised; read ``self.loss`` afterwards."""
         if device_mask and self.node_ptr is None:

@@ -373,20 +373,26 @@ def test_targets_are_inputs_alias(pkg, oracle):
 
 def test_prefetched_host_batches_match_direct_loading(pkg, oracle):
     """prefetch_batch (side-stream H2D into a staging slot) + commit_batch give the same training trajectory as
-    load_batch, including the two-slot rotation."""
+    load_batch, including the two-slot rotation -- and so does step_prefetched(), which trains on the staging slot in place."""
     nb, nc, bs = 2, 32, 2
     ei = pkg.wdn_synth.collate_edge_index(pkg.wdn_synth.make_wdn_topology(), 388, bs).cuda()
     snaps = pkg.wdn_synth.make_snapshots(5 * bs, 388, seed=15)
     host = [pkg.wdn_synth.collate_snapshots(snaps, range(i * bs, (i + 1) * bs)).reshape(-1).pin_memory() for i in range(5)]
     losses = []
-    for mode in ("direct", "prefetch"):
+    for mode in ("direct", "prefetch", "in_place"):
         model, _ = build(pkg, oracle, nb, nc, seed=19)
         tr = pkg.GATResTrainer(model, ei, 388 * bs, nodes_per_graph=[388] * bs, use_graph=True, seed=3,
                                targets_are_inputs=True)
         out = []
-        if mode == "prefetch":
+        if mode != "direct":
             tr.prefetch_batch(host[0])
         for i in range(5):
+            if mode == "in_place":                     # (round 5: the step reads the staging slot itself, mask sampled ahead)
+                tr.step_prefetched()
+                if i + 1 < 5:
+                    tr.prefetch_batch(host[i + 1])
+                out.append(float(tr.loss.item()))
+                continue
             if mode == "prefetch":
                 tr.commit_batch()
                 if i + 1 < 5:
@@ -396,7 +402,7 @@ def test_prefetched_host_batches_match_direct_loading(pkg, oracle):
             tr.run_step(device_mask=True)
             out.append(float(tr.loss.item()))
         losses.append(out)
-    assert losses[0] == losses[1], losses
+    assert losses[0] == losses[1] == losses[2], losses
 
 
 def test_reset_sync_recovers_a_corrupted_barrier_state(pkg, oracle):
