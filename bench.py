@@ -64,6 +64,10 @@ def parse():
                          "rate for DESIGN.md; never the headline value)")
     ap.add_argument("--fused-adam", action="store_true",
                     help="with --drop-in: FusedAdam (one native launch) instead of torch.optim.Adam")
+    ap.add_argument("--eval", action="store_true",
+                    help="inference line instead of the training step: forward-only through the drop-in module under the "
+                         "reference's Timer protocol (utils/timer.py:22-66: 10 warm-up calls, one event pair + synchronize per "
+                         "call), test_time (ms/graph) and test_throughput (graphs/s) as evaluation.py:346-347 computes them")
     ap.add_argument("--drop-in", action="store_true",
                     help="time the reference loop body verbatim (train.py:160-188): nn.Module forward, loss.backward(), "
                          "torch.optim.Adam, host-side numpy mask, a fresh edge_index tensor every batch")
@@ -200,12 +204,15 @@ def survey_bytes_per_snapshot(nb, nc, n_g, e_g, s):
         fwd_a = 4 * (N + 1) + 4 * Ep + Ep * H * s + N * H * s + Ep * HC * s + N * D * s + Ep * H * s
         bwd_a = 12 * Ep + 8 * (N + 1) + Ep * HC * s + Ep * D * s + 3 * Ep * H * s + N * D * s + N * HC * s + 2 * N * H * s
         bwd_p = 2 * (N * HC * s + N * F * s) + 2 * F * HC * s
-        return fwd_p + fwd_a + bwd_a + bwd_p
+        return fwd_p + fwd_a + bwd_a + bwd_p, fwd_p + fwd_a
 
-    conv1, conv2 = gatconv(nc, 2, nc, True), gatconv(2 * nc, 1, nc, False)
-    mean = 2 * (4 * (N + 1) + 4 * E + E * nc * s + 2 * N * nc * s)
+    (conv1, conv1_f), (conv2, conv2_f) = gatconv(nc, 2, nc, True), gatconv(2 * nc, 1, nc, False)
+    mean_f = 4 * (N + 1) + 4 * E + E * nc * s + 2 * N * nc * s
+    mean = 2 * mean_f
     lin = 6 * (N * s + N * nc * s)
+    lin_f = 2 * (N * s + N * nc * s)                 # (lin0 reads x, writes [N, nc]; lin1 reads [N, nc], writes out)
     return dict(total=nb * (conv1 + conv2 + mean) + lin, conv1=conv1, conv2=conv2, mean_conv=mean, lin0_lin1=lin,
+                forward=nb * (conv1_f + conv2_f + mean_f) + lin_f,
                 inputs=dict(num_blocks=nb, nc=nc, N=N, E=E, E_prime=Ep, bytes_per_element=s, index_bytes=4))
 
 
@@ -479,6 +486,50 @@ def drop_in_loop(args, G, model, topo, device, nb, nc):
                                  "final_loss": last}}))
 
 
+def eval_loop(args, G, model, topo, device, nb, nc):
+    """The reference's inference measurement (evaluation.py:298,324-347) on the drop-in module: every batch is one call of
+    ``Timer.auto_measure(model)(x1, edge_index, None, None)`` under ``torch.no_grad()`` -- 10 untimed warm-up calls, then one
+    event pair and a synchronize per call -- and the two figures the reference reports, ``test_time`` (mean milliseconds per
+    graph) and ``test_throughput`` (graphs per second), from the Timer's own formulas.  Roofline: the FORWARD share of
+    SURVEY.md 8(d)'s bytes per snapshot over the mean event-pair duration of a call."""
+    import numpy as np
+    bs, npg = args.batch_size, args.nodes
+    model.eval()
+    ei = G.wdn_synth.collate_edge_index(topo, npg, bs).to(device)
+    snaps = G.wdn_synth.make_snapshots(8 * bs, npg, seed=100)
+    rng = np.random.RandomState(0)
+    timer = G.evaluation.Timer()
+    n_batches = max(args.steps, 1)
+    t0 = time.perf_counter()
+    with torch.no_grad():
+        for i in range(n_batches):
+            y = G.wdn_synth.collate_snapshots(snaps, range((i % 8) * bs, (i % 8 + 1) * bs)).to(device)
+            mask = G.wdn_synth.generate_batch_mask([npg] * bs, 0.95, rng)                 # evaluation.py:312-317
+            x1 = y.clone()
+            x1[mask] = 0
+            out = timer.auto_measure(model, bs, 10)(x1, ei, None, None)                   # evaluation.py:321-323
+    wall = time.perf_counter() - t0
+    n_graphs = n_batches * bs
+    ms_graph, thr = timer.compute_time(n_graphs), timer.compute_throughput(n_graphs)
+    ms_call = float(np.mean(timer.timings))
+    sb = survey_bytes_per_snapshot(nb, nc, npg, 2 * args.pipes, 2 if args.dtype == "bf16" else 4)
+    ach = sb["forward"] * bs / (ms_call * 1e-3) * 1e-9
+    assert bool(torch.isfinite(out).all())
+    print(json.dumps({"metric": "test_throughput (evaluation.py:347)", "value": thr, "unit": "graphs/s", "n_gpus": 1,
+                      "steps": n_batches, "warmup": 10, "ms_per_step": ms_call, "higher_is_better": True, "scaling": "weak",
+                      "vs_baseline": None, "dtype": "bf16" if args.dtype == "bf16" else "f32", "data": "synthetic",
+                      "test_time_ms_per_graph": ms_graph,
+                      "ms_per_call": {"mean": ms_call, "min": float(np.min(timer.timings)), "max": float(np.max(timer.timings))},
+                      "wall_graphs_per_s_incl_host": n_graphs / wall,
+                      "config": {"workload": f"{args.model} ({nb} blocks, nc={nc}), forward only, drop-in nn.Module under "
+                                             f"torch.no_grad(), {npg}-node WDN, batch_size={bs}, {args.dtype}; Timer protocol of "
+                                             f"utils/timer.py:22-66 (10 warm-up calls, one event pair + synchronize per call)"},
+                      "roofline": {"bound": "hbm", "kernel": "forward launch(es) of one model call",
+                                   "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                                   "traffic": None, "algorithmic_bytes_per_snapshot": sb["forward"],
+                                   "bytes_per_snapshot_source": "forward terms of the SURVEY.md 8(d) formula"}}))
+
+
 def main():
     args = parse()
     nb, nc = MODELS[args.model]
@@ -521,12 +572,14 @@ def main():
         g = torch.Generator().manual_seed(12345)
         topo = torch.randperm(args.nodes, generator=g)[topo]
     ei = G.wdn_synth.collate_edge_index(topo, args.nodes, args.batch_size).to(device)
+    if args.drop_in:
+        return drop_in_loop(args, G, model, topo, device, nb, nc)
+    if args.eval:
+        return eval_loop(args, G, model, topo, device, nb, nc)
     trainer = G.GATResTrainer(model, ei, N, nodes_per_graph=[args.nodes] * args.batch_size, seed=1000,
                               use_graph=not args.no_graph, fused=not args.per_op,
                               force_collective_path=args.force_collective_path,
                               targets_are_inputs=True)        # synthetic snapshots: y is x before masking
-    if args.drop_in:
-        return drop_in_loop(args, G, model, topo, device, nb, nc)
     nbatches = 8
     snaps = G.wdn_synth.make_snapshots(nbatches * args.batch_size, args.nodes, seed=100 + rank).to(device)
     batches = [snaps[i * args.batch_size:(i + 1) * args.batch_size].reshape(-1).contiguous() for i in range(nbatches)]

@@ -183,12 +183,22 @@ def load(build_if_missing: bool = True) -> C.CDLL:
             fcntl.flock(lock, fcntl.LOCK_EX)
             try:
                 was_missing = "missing" in why
-                if stale():
+                # Is the file on disk current NOW (another rank may have rebuilt it while this one waited)?  Not through
+                # C.CDLL(path): a process that already mapped the stale file gets glibc's cached handle back and would rebuild
+                # again.  The build stamp beside the objects is what build_native wrote for the file it linked.
+                stamp = os.path.join(_build.OBJ_DIR + ("_diag" if diag_build() else ""), "BUILD_ID")
+                try:
+                    with open(stamp) as f:
+                        on_disk = f.read().strip()
+                except OSError:
+                    on_disk = ""
+                if not os.path.exists(path) or on_disk != want:
                     _build.build_native(diag=diag_build())
+                # (a process that already mapped the stale file keeps it under the same name: dlopen a fresh copy of the new
+                #  build -- copied while the lock is held, so no other rank relinks the file under the copy)
+                lib = C.CDLL(path) if was_missing else _reopen(path)
             finally:
                 fcntl.flock(lock, fcntl.LOCK_UN)
-        # (a process that already mapped the stale file keeps it under the same name: dlopen a fresh copy of the new build)
-        lib = C.CDLL(path) if was_missing else _reopen(path)
         abi, bid = _version_of(lib)
         if abi != ABI_VERSION or bid != want:
             raise RuntimeError(f"rebuilt {path} still reports abi{abi} build {bid}; expected abi{ABI_VERSION} build {want}")

@@ -38,6 +38,9 @@ struct gatres_knobs_t {
   int blocked;                // GATRES_BLOCKED: wide bf16 models (nc = 128) take the blocked launches of k_blocked.hip (a sparse
                               // stage + the projection behind it as one kernel) where the plan allows; default off: bit-identical
                               // to the per-op pairs, measured 5 - 20 % slower than them (profiles/r05_blocked_probe.txt)
+  int window_runtime_phases;  // GATRES_WINDOW_RUNTIME_PHASES: the window kernel reads its phases at run time (one register allocation
+                              // for forward and backward) instead of taking the per-phase instantiations
+  int window_ph_mask;         // GATRES_WINDOW_PH_MASK (default all ones): which compile-time facts a launch may use (k_window.hip)
   // DIAGNOSTIC build only (fixed at the defaults in the product build): measured-and-lost alternatives, tuning sweeps and the
   // switches that give WRONG results
   int agg_wide_offsets;       // GATRES_AGG_WIDE_OFFSETS

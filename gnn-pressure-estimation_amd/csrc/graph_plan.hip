@@ -87,12 +87,12 @@ extern "C" int gatres_graph_flags_host(const int64_t* ei, int64_t E, int64_t N, 
   // transposes) has at most 32 entries: the blocked kernels' rows are walked by their own lane group (k_blocked.hip)
   int32_t most = 0;
   for (int64_t i = 0; i < N; ++i) most = std::max(most, std::max(indeg[(size_t)i], outdeg[(size_t)i]));
-  const bool le32 = most + 1 <= 32;
+  const bool le32 = most + 1 <= 32, le6 = most + 1 <= 6;
   std::sort(key.begin(), key.end());
   bool sym = true;
   for (size_t i = 0; i < key.size() && sym; ++i)
     sym = std::binary_search(key.begin(), key.end(), (key[i] << 32) | (key[i] >> 32));
-  *flags_out = (sym ? GATRES_GRAPH_SYMMETRIC : 0) | (le32 ? GATRES_GRAPH_DEG_LE32 : 0);
+  *flags_out = (sym ? GATRES_GRAPH_SYMMETRIC : 0) | (le32 ? GATRES_GRAPH_DEG_LE32 : 0) | (le6 ? GATRES_GRAPH_DEG_LE6 : 0);
   return 0;
 }
 

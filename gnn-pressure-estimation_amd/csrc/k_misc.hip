@@ -36,9 +36,12 @@ void read_knobs(gatres_knobs_t* k) {
   k->dw_1d = env_flag("GATRES_DW_1D");
   k->side_stream = env_int("GATRES_SIDE_STREAM", -1);
   k->blocked = env_flag("GATRES_BLOCKED");
+  k->window_runtime_phases = env_flag("GATRES_WINDOW_RUNTIME_PHASES");
+  k->window_ph_mask = env_int("GATRES_WINDOW_PH_MASK", 0xffff);
+  k->fused_no_keep = env_flag("GATRES_FUSED_NO_KEEP");
   // diagnostic build only
   k->agg_wide_offsets = 0; k->fused_threads = 1024; k->fused_no_window = 0; k->fused_prefer_consumers = 0;
-  k->fused_consumers_cap = 2; k->fused_nocache = 0; k->fused_wide = 0; k->fused_no_keep = 0; k->fused_heartbeat = 0;
+  k->fused_consumers_cap = 2; k->fused_nocache = 0; k->fused_wide = 0; k->fused_heartbeat = 0;
   k->param_grads_no_stream = 0; k->proj_rows = 0; k->proj_stream = 0; k->dw_fp32 = 0; k->no_co_launch = 0;
   k->co_launch_always = 0; k->dw_slab_rows = 0; k->xch_nowait = 0; k->diag_nomask = 0;
 #ifdef GATRES_DIAG_BUILD
@@ -49,7 +52,6 @@ void read_knobs(gatres_knobs_t* k) {
   { const int c = env_int("GATRES_FUSED_CONSUMERS", 2); k->fused_consumers_cap = c < 4 ? c : 4; }
   k->fused_nocache = env_flag("GATRES_FUSED_NOCACHE");
   k->fused_wide = env_flag("GATRES_FUSED_WIDE");
-  k->fused_no_keep = env_flag("GATRES_FUSED_NO_KEEP");
   k->fused_heartbeat = env_flag("GATRES_FUSED_HEARTBEAT");
   k->param_grads_no_stream = env_flag("GATRES_PARAM_GRADS_NO_STREAM");
   k->proj_rows = (env_int("GATRES_PROJ_ROWS", 0) + 63) & ~63;

@@ -108,13 +108,28 @@ __device__ __forceinline__ void scale_g_pre(float* gpT, const u16* mrp, int lo, 
   }
 }
 
-template <int NC, int THREADS>
+template <int NC, int THREADS, int PH = -1>
 __global__ __launch_bounds__(THREADS) void gatres_window_kernel(const FusedArgs a) {
+  // PH >= 0: the launch's phases and whether it keeps the ReLU sign masks in LDS are compile-time facts (separate register
+  // allocations for the forward-only, backward-only and training instantiations); PH < 0: read from the arguments
+  const int ph_ = PH < 0 ? a.phases : (PH & 0xff);
+  const bool keep_ = PH < 0 ? a.keep_lds != 0 : (PH & 0x100) != 0;
+  // PH & 0x200: a symmetric plan (no pacing granules) and no consumer workgroups in this launch (the common case: undirected
+  // water networks, the parameter gradients as a launch of their own) -- the hand-offs' pace / drain paths are not compiled
+  constexpr bool LEAN = PH >= 0 && (PH & 0x200) != 0;
+  const int nC_ = LEAN ? 0 : a.C;
+  // PH & 0x400: no row of any CSR of the plan has more than MAXD entries (GATRES_GRAPH_DEG_LE6): the stages' edge-at-a-time
+  // paths and the alpha-table fallbacks are not compiled.  PH & 0x800: the plan carries this split's part tables (a record
+  // that fails its magic check faults the launch instead of falling back to the in-kernel derivation).  PH & 0x1000: no part
+  // owns more than 64 rows (the host knows from the largest segment and the split).
+  constexpr bool NOHUB = PH >= 0 && (PH & 0x400) != 0;
+  constexpr bool PTAB = PH >= 0 && (PH & 0x800) != 0;
+  constexpr bool OW64 = PH >= 0 && (PH & 0x1000) != 0;
   __shared__ __attribute__((aligned(16))) unsigned char lds_raw[LDS_BYTES];
   float* ldsf = reinterpret_cast<float*>(lds_raw);
   const Layout& L = a.L;
   const int M = a.M;
-  {
+  if constexpr (!LEAN) {
     const int F = ((a.seg_cnt + 7) / 8) * 8 * M;
     if ((int)blockIdx.x >= F) {
       consumer_main<NC, THREADS>(a, (int)blockIdx.x - F, ldsf);
@@ -130,19 +145,20 @@ __global__ __launch_bounds__(THREADS) void gatres_window_kernel(const FusedArgs 
   // part's scalars come from the record's header -- ONE load per wave -- and its LDS tables are copied from the record
   // by LDS-DMA in the two phase prologues.  Without them (a plan that carries none, or tables for another split) both are
   // derived from the CSR arrays as in round 2: four barrier-separated passes with LDS atomics per phase.
-  const int* pt = (a.ptab && a.ptab_m == M) ? a.ptab + ((size_t)seg * M + part) * (size_t)a.ptab_stride : nullptr;
+  const int* pt = (PTAB || (a.ptab && a.ptab_m == M)) ? a.ptab + ((size_t)seg * M + part) * (size_t)a.ptab_stride : nullptr;
   int hv = 0;
-  if (pt) hv = pt[min((int)(threadIdx.x & 63), GATRES_PT_HEADER - 1)];
+  if (PTAB || pt) hv = pt[min((int)(threadIdx.x & 63), GATRES_PT_HEADER - 1)];
   auto H = [&](int field) { return __builtin_amdgcn_readlane(hv, field); };
   int n0, n, e0, em0, t0, mt0;
   Rows rw;
-  if (pt) {
+  if (PTAB || pt) {
     if (H(GATRES_PT_MAGIC) != GATRES_PT_MAGIC_VALUE || H(GATRES_PT_M) != M) {       // (not this plan's tables)
       if (tid == 0) *a.err = 1;
+      if constexpr (PTAB) return;              // (the partners' sweeps time out: the step is dropped, gatres_fused_finish)
       pt = nullptr;
     }
   }
-  if (pt) {
+  if (PTAB || pt) {
     n0 = H(GATRES_PT_N0); n = H(GATRES_PT_N); e0 = H(GATRES_PT_E0); em0 = H(GATRES_PT_EM0); t0 = H(GATRES_PT_T0);
     mt0 = H(GATRES_PT_MT0); rw.lo = H(GATRES_PT_LO); rw.hi = H(GATRES_PT_HI);
   } else {
@@ -153,6 +169,7 @@ __global__ __launch_bounds__(THREADS) void gatres_window_kernel(const FusedArgs 
     rw.hi = min(n, 16 * (int)((long long)tiles * (part + 1) / M));
   }
   const int lo = rw.lo, ow = rw.hi - rw.lo;
+  const bool ow64 = OW64 || ow <= 64;
   Group grp;
   grp.flags = a.flags + (size_t)seg * 8 * FLAG_STRIDE; grp.M = M; grp.part = part; grp.err = a.err;
   group_init<THREADS>(grp);
@@ -169,7 +186,7 @@ __global__ __launch_bounds__(THREADS) void gatres_window_kernel(const FusedArgs 
   const XchBuf xbuf = xch_buffer(xc.base, XL.total);
   // pacing of the hand-offs by heartbeat granules: only when the plan does not promise two-sided halos; store drain at
   // every hand-off: only when consumer workgroups read this part's tables in the same launch (xch_after)
-  const bool pace = !a.sym, drain = a.C > 0;
+  const bool pace = LEAN ? false : !a.sym, drain = nC_ > 0;
   // first wave that issues LDS-DMA inside MFMA stages: the waves below it own a 16-row tile there (dma_copy16)
   constexpr int PW = 8;                    // waves that carry the work units of an MFMA stage (win_proj); NC == 32
   const int dw0 = NC == 32 ? PW : min((ow + 15) >> 4, THREADS / 64 - 4);
@@ -183,10 +200,10 @@ __global__ __launch_bounds__(THREADS) void gatres_window_kernel(const FusedArgs 
   static_assert(B1OFF + 2 * NC <= WLB && B2OFF + NC <= WLB && A2OFF + 2 * NC <= WLB && A1OFF + 4 * NC <= WLB, "W slot tails");
   const float* P = a.params;
   float* sc = a.scratch;
-  // a.keep_lds: the top of LDS carries the ReLU sign masks from the forward to the backward phase of this launch
-  unsigned char* lds_top = lds_raw + LDS_BYTES - (a.keep_lds ? win_keep_bytes(L.nb, ow) : 0);
-  unsigned long long* mo1 = a.keep_lds ? reinterpret_cast<unsigned long long*>(lds_top) - lo : nullptr;   // [b * ow + row]
-  unsigned* mxin = a.keep_lds ? reinterpret_cast<unsigned*>(lds_top + 8LL * L.nb * ow) - lo : nullptr;
+  // keep_: the top of LDS carries the ReLU sign masks from the forward to the backward phase of this launch
+  unsigned char* lds_top = lds_raw + LDS_BYTES - (keep_ ? win_keep_bytes(L.nb, ow) : 0);
+  unsigned long long* mo1 = keep_ ? reinterpret_cast<unsigned long long*>(lds_top) - lo : nullptr;   // [b * ow + row]
+  unsigned* mxin = keep_ ? reinterpret_cast<unsigned*>(lds_top + 8LL * L.nb * ow) - lo : nullptr;
   [[maybe_unused]] int stamp_i = 0;
   STAMP();
   if (STAMPS_PTR && blockIdx.x == 0 && threadIdx.x == 0) STAMPS_PTR[a.stamp_cap] = clock64();
@@ -194,7 +211,7 @@ __global__ __launch_bounds__(THREADS) void gatres_window_kernel(const FusedArgs 
   // ---- the window: own rows and every row adjacent to them (in- and out-neighbours), as one contiguous range; edge ranges
   // (local ids = position - e0): own in-edges [elo, elo + oeg), window in-edges [ewlo, ewlo + weg), ...
   int wlo, whi, elo, oeg, ewlo, weg, melo, oem, tlo, otg, mtlo, otm;
-  if (pt) {
+  if (PTAB || pt) {
     wlo = H(GATRES_PT_WLO); whi = H(GATRES_PT_WHI); elo = H(GATRES_PT_ELO); oeg = H(GATRES_PT_OEG); ewlo = H(GATRES_PT_EWLO);
     weg = H(GATRES_PT_WEG); melo = H(GATRES_PT_MELO); oem = H(GATRES_PT_OEM); tlo = H(GATRES_PT_TLO); otg = H(GATRES_PT_OTG);
     mtlo = H(GATRES_PT_MTLO); otm = H(GATRES_PT_OTM);
@@ -236,15 +253,15 @@ __global__ __launch_bounds__(THREADS) void gatres_window_kernel(const FusedArgs 
   // then g_out and the saved final activation: two dependent L2 round trips at the turn of the launch.  Same arithmetic, same
   // summation order (thread t sums row lo + t, as the stand-alone pass): the same bits.
   constexpr int LB_R = THREADS / NC;               // row stride of lin1 backward's threads (two rows each at most)
-  const bool fuse_loss = (a.phases & PH_LOSS) && (a.phases & GATRES_PHASE_FORWARD) && (a.phases & GATRES_PHASE_BACKWARD) &&
-                         ow <= 2 * LB_R && ow <= 64 && ow <= THREADS / (NC / 4);
+  const bool fuse_loss = (ph_ & PH_LOSS) && (ph_ & GATRES_PHASE_FORWARD) && (ph_ & GATRES_PHASE_BACKWARD) &&
+                         (OW64 || ow <= 2 * LB_R) && ow64 && (OW64 || ow <= THREADS / (NC / 4));
   float* dml = ldsf + 64;                          // [own row]: masked out - y, then g_out (inside the backward's `red` region)
   float xk[2] = {0.f, 0.f};                        // final activation of rows lo + rg, lo + rg + LB_R, column c (lin1 backward)
 
   int* const myrec = a.urec + (size_t)blockIdx.x * GATRES_UREC_WORDS;
   auto lds_off = [&](const void* p) { return (int)(reinterpret_cast<const unsigned char*>(p) - lds_raw); };
 
-  if (a.phases & GATRES_PHASE_FORWARD) {
+  if (ph_ & GATRES_PHASE_FORWARD) {
     constexpr bool xreg = NC == 32;
     {  // ---- prologue: LDS carve-up, the part's tables, lin0; the geometry goes into the record
     // LDS: [hA wr x 2NC | hB wr x NC | sa wr x 2 | sd own x 2 | xA own x NC | xB own x 2NC | W slot A | W slot B] topology
@@ -283,7 +300,7 @@ __global__ __launch_bounds__(THREADS) void gatres_window_kernel(const FusedArgs 
     float* xB = xBo - lo * 2 * NC;
     const u16* rp = rpo - lo;  const u16* mrp = mrpo - lo;
     int hcnt = 0, ecnt = 0;
-    if (pt) {
+    if (PTAB || pt) {
       // the record's forward image is this LDS range, verbatim; the two hand-off lists follow it in the record
       hcnt = H(GATRES_PT_F_HCNT); ecnt = H(GATRES_PT_F_ECNT);
       if (H(GATRES_PT_F_IMG_WORDS) * 2 != (int)(f_img_end - rpo) || hcnt > hcap || ecnt > hcap) {
@@ -324,7 +341,7 @@ __global__ __launch_bounds__(THREADS) void gatres_window_kernel(const FusedArgs 
     }
     dma_land(0);
     __syncthreads();
-    if (!pt) {
+    if (!PTAB && !pt) {
       build_nbr_in<THREADS>(rw, rp, colo, oeg, false, nbin);
       build_nbr_in<THREADS>(rw, mrp, mcolo, oem, true, mbin);
       hcnt = uni(build_halo<THREADS>(rp, colo, nullptr, rw, hlist, nullptr, hcap, hcounter));
@@ -421,9 +438,9 @@ __global__ __launch_bounds__(THREADS) void gatres_window_kernel(const FusedArgs 
         REC_DEFS(LIST_);
 #undef LIST_
         // K2 conv1: alpha -> HBM, the gather's o1 -> HBM + the x buffer of proj2
-        if (__builtin_expect(2 * oeg <= wr * NC, 1)) {
+        if (NOHUB || __builtin_expect(2 * oeg <= wr * NC, 1)) {
           if constexpr (NC == 32) {
-            win_fwd_agg<true, 2, NC, THREADS>(rw, nbin, rp, colo, hA, sa2, sd2, base + SL.al1, elo, hBw, wlA + B1OFF,
+            win_fwd_agg<true, 2, NC, THREADS, NOHUB>(rw, nbin, rp, colo, hA, sa2, sd2, base + SL.al1, elo, hBw, wlA + B1OFF,
                                               base + SL.o1, 0, xB, mo1 ? mo1 + b * ow : nullptr, xout(false, fflag, 0, 0));
           } else {
             win_softmax<2, THREADS>(rw, nbin, rp, colo, sa2, sd2, base + SL.al1, elo, hBw);
@@ -493,9 +510,9 @@ __global__ __launch_bounds__(THREADS) void gatres_window_kernel(const FusedArgs 
         REC_PINS(LIST_, , "s"(pb), "s"(base));
         REC_DEFS(LIST_);
 #undef LIST_
-        if (__builtin_expect(oeg <= wr * NC, 1)) {
+        if (NOHUB || __builtin_expect(oeg <= wr * NC, 1)) {
           if constexpr (NC == 32) {
-            win_fwd_agg<false, 1, NC, THREADS>(rw, nbin, rp, colo, hB, sa1, sd1, base + SL.al2, elo, al2L, wlB + B2OFF, y2T,
+            win_fwd_agg<false, 1, NC, THREADS, NOHUB>(rw, nbin, rp, colo, hB, sa1, sd1, base + SL.al2, elo, al2L, wlB + B2OFF, y2T,
                                                0, nullptr, nullptr, xout(xreg, fflag, XL.f3, 0));
           } else {
             win_softmax<1, THREADS>(rw, nbin, rp, colo, sa1, sd1, base + SL.al2, elo, al2L);
@@ -533,7 +550,7 @@ __global__ __launch_bounds__(THREADS) void gatres_window_kernel(const FusedArgs 
 #undef LIST_
         // K3: residual from the x buffer, result back into it (and to HBM: saved xin of the next block)
         float* xnext = segbase + (int64_t)(launder_s(b) + 1) * SL.bstride + SL.xin;
-        win_mean_fwd<NC, THREADS>(rw, mbin, mrp, mcolo, y2T, xA, xnext, xA,
+        win_mean_fwd<NC, THREADS, NOHUB>(rw, mbin, mrp, mcolo, y2T, xA, xnext, xA,
                                        (mxin && b + 1 < nb) ? mxin + (b + 1) * ow : nullptr);
         lds_barrier();
         STAMP();
@@ -610,7 +627,7 @@ __global__ __launch_bounds__(THREADS) void gatres_window_kernel(const FusedArgs 
     if (fuse_loss) STAMP();    // (diagnostic stamp sequence lin0 | lin1 | loss | lin1_bwd | blocks: the loss is inside lin1 here)
   }
 
-  if ((a.phases & PH_LOSS) && !fuse_loss) {
+  if ((ph_ & PH_LOSS) && !fuse_loss) {
     float cnt = 0.f;
     for (int i = tid; i < a.N; i += THREADS) cnt += a.mask[i] ? 1.f : 0.f;
     const float Mn = block_sum<THREADS>(cnt, ldsf);
@@ -636,10 +653,10 @@ __global__ __launch_bounds__(THREADS) void gatres_window_kernel(const FusedArgs 
     STAMP();
   }
 
-  if (a.phases & GATRES_PHASE_BACKWARD) {
+  if (ph_ & GATRES_PHASE_BACKWARD) {
     float* const red = ldsf;
     constexpr bool xedge = NC == 32;                 // win_bwd_dst stores the exported g_e granules itself
-    const bool xrows = xedge && a.keep_lds;          // ... and so do the dX stages (win_proj) with their rows
+    const bool xrows = xedge && keep_;          // ... and so do the dX stages (win_proj) with their rows
     constexpr bool pub = true;           // (the window kernel only runs split segments)
     constexpr int64_t w = 2LL * NC * NC;
     float* gp_cur = sc + L.sc_gpa;
@@ -657,8 +674,8 @@ __global__ __launch_bounds__(THREADS) void gatres_window_kernel(const FusedArgs 
     float* adTo = asTw + (size_t)((wr * 2 + 3) & ~3);
     float* alTw = adTo + (size_t)((ow * 2 + 3) & ~3);
     float* xGo = alTw + 2 * (size_t)even(weg);
-    float* gko = xGo + (size_t)ow * 2 * NC;                              // a.keep_lds: g_pre of the own rows (dX1's residual term)
-    float* wlA = reinterpret_cast<float*>(lds_raw + ((reinterpret_cast<unsigned char*>(gko + (a.keep_lds ? (size_t)ow * NC : 0)) - lds_raw + 15) & ~15));
+    float* gko = xGo + (size_t)ow * 2 * NC;                              // keep_: g_pre of the own rows (dX1's residual term)
+    float* wlA = reinterpret_cast<float*>(lds_raw + ((reinterpret_cast<unsigned char*>(gko + (keep_ ? (size_t)ow * NC : 0)) - lds_raw + 15) & ~15));
     float* wlB = wlA + WLB;
     u16* tp = reinterpret_cast<u16*>(wlB + WLB);
     u16* rpo = tp;             tp += even(ow + 1);
@@ -685,7 +702,7 @@ __global__ __launch_bounds__(THREADS) void gatres_window_kernel(const FusedArgs 
     const unsigned char* bflag = bflag_o - lo;
     for (int k = tid; k < ((ow + 15) & ~15) / 4; k += THREADS) reinterpret_cast<unsigned*>(bflag_o)[k] = 0u;
     int hrcnt = 0, hecnt = 0, ercnt = 0, eecnt = 0;      // import rows / import edges / export rows / export edges
-    if (pt) {
+    if (PTAB || pt) {
       hrcnt = H(GATRES_PT_B_HRCNT); hecnt = H(GATRES_PT_B_HECNT); ercnt = H(GATRES_PT_B_ERCNT); eecnt = H(GATRES_PT_B_EECNT);
       if (H(GATRES_PT_B_IMG_WORDS) * 2 != (int)(b_img_end - rpo) || hrcnt > hcap || hecnt > hcap || ercnt > hcap || eecnt > hcap) {
         if (tid == 0) *a.err = 1;
@@ -719,7 +736,7 @@ __global__ __launch_bounds__(THREADS) void gatres_window_kernel(const FusedArgs 
     float* adT2 = adTo - lo;      float* adT1 = adTo - lo * 2;
     float* alT2 = alTw - ewlo;    float* alT1 = alTw - ewlo * 2;
     float* xG2 = xGo - lo * NC;   float* xG1 = xGo - lo * 2 * NC;
-    float* gkeep = a.keep_lds ? gko - lo * NC : nullptr;
+    float* gkeep = keep_ ? gko - lo * NC : nullptr;
 
     const float* xfinal = segbase + (int64_t)L.nb * SL.bstride + SL.xin;
     // LDS-DMA of the saved tables (independent of the backward chain) rides on the dX stages, issued by their tile-less
@@ -778,7 +795,7 @@ __global__ __launch_bounds__(THREADS) void gatres_window_kernel(const FusedArgs 
                                 slab + L.p_lin1_b, L.nb > 0 ? 1 : 0, red, gkeep);
     }
     dma_land(0);
-    if (pt) {
+    if (PTAB || pt) {
       __syncthreads();         // the record's tables and the first block's conv2 tables have landed
     } else {
       build_nbr_in<THREADS>(rw, rp, colo, oeg, false, nbin);
@@ -895,7 +912,7 @@ __global__ __launch_bounds__(THREADS) void gatres_window_kernel(const FusedArgs 
         lds_barrier();
         XSTAMP();
       }
-      publish_items<THREADS>(a, seg, part, 2 * (nb - 1 - b), grp.local, false);      // the blocks above are kept
+      if constexpr (!LEAN) publish_items<THREADS>(a, seg, part, 2 * (nb - 1 - b), grp.local, false);      // the blocks above are kept
       // K3 backward, conv2's edge dots and softmax backward: one stage (win_bwd_dst)
       STAMP();
       {
@@ -910,13 +927,13 @@ __global__ __launch_bounds__(THREADS) void gatres_window_kernel(const FusedArgs 
         // g_y2 granules at the start of their own stage), so the hand-off behind the closing barrier has no sweep of its own:
         // 0.3923 - 0.3936 -> 0.3871 - 0.3903 ms/step.  The same for F3 (behind conv2's aggregation) gave nothing and for B3
         // (three idle waves behind conv1's destination-major stage) cost 8 us: profiles/r04_valu_probe.txt.
-        if (NC == 32 && ow <= 64 && wave_u >= 8) {
+        if (NC == 32 && ow64 && wave_u >= 8) {
           const auto rb2_ = rec_fresh<BwdRec>(myrec + GATRES_UREC_WORDS / 2);
           xch_import2_by<NC, 1, 512, THREADS - 512>(xc, xc.ep + 1u, xbuf, LDS_TABLE(const u16, lds_raw, rb2_->hrow), rb2_->hrcnt,
                                                      (unsigned)XL.b2y, gy2T, LDS_TABLE(const u16, lds_raw, rb2_->hedge),
                                                      rb2_->hecnt, (unsigned)XL.b2e, ge2);
         } else
-        win_bwd_dst<true, 1, NC, THREADS, NC == 32>(rw, nbin, rp, colo, gy2T, hT2, alT2 + elo, asT2, adT2, ge2 + elo, gad2, mout, mrp,
+        win_bwd_dst<true, 1, NC, THREADS, NC == 32, NOHUB>(rw, nbin, rp, colo, gy2T, hT2, alT2 + elo, asT2, adT2, ge2 + elo, gad2, mout, mrp,
                                                mtrp, mtdsto, gpT, xout(xedge, bflag, (unsigned)XL.b2y, (unsigned)XL.b2e), elo);
         lds_barrier();
         XSTAMP();
@@ -928,12 +945,12 @@ __global__ __launch_bounds__(THREADS) void gatres_window_kernel(const FusedArgs 
         REC_PINS(LIST_);
         REC_DEFS(LIST_);
 #undef LIST_
-        const bool lean = NC == 32 && ow <= 64;    // (the sweep ran in the stage before; the bias partials ride on the stage after)
+        const bool lean = NC == 32 && ow64;    // (the sweep ran in the stage before; the bias partials ride on the stage after)
         if (!lean) seg_bias_part<NC, THREADS>(rw, gy2T, 0, red);  // (own rows of g_y2: the sweep below only writes halo rows)
         ++xc.ep;                                   // exchange B2: the source-major stage reads g_y2 / g_e of neighbour rows
         if (!xedge) xch_export2<NC, 1, THREADS>(xc, xbuf, erow, ercnt, gy2T, (unsigned)XL.b2y, eedge, eecnt, ge2, (unsigned)XL.b2e);
         XSTAMP();
-        if (NC != 32 || ow > 64)                   // (else the stage before ran the sweep on its idle waves)
+        if (NC != 32 || !ow64)                   // (else the stage before ran the sweep on its idle waves)
         xch_import2<NC, 1, THREADS>(xc, xbuf, hrow, hrcnt, (unsigned)XL.b2y, gy2T, hedge, hecnt, (unsigned)XL.b2e, ge2);
         XSTAMP();
         xch_after<THREADS>(xc, pace, drain);
@@ -969,11 +986,11 @@ __global__ __launch_bounds__(THREADS) void gatres_window_kernel(const FusedArgs 
         REC_PINS(LIST_, , "s"(sb), "s"(keep));
         REC_DEFS(LIST_);
 #undef LIST_
-        const bool lean = NC == 32 && ow <= 64;    // rows on waves 0 .. 7: the other eight form conv2's bias partials meanwhile
+        const bool lean = NC == 32 && ow64;    // rows on waves 0 .. 7: the other eight form conv2's bias partials meanwhile
         if (!lean) seg_bias_finish<NC, THREADS>(red, sb + L.c2_b);
         if (lean && wave_u >= 8) seg_bias_part_by<NC, THREADS, 512, THREADS - 512>(rw, gy2T, 0, red);
         else
-        win_agg_bwd_src<1, NC, THREADS>(rw, tout, trp, teido, tdsto, 0, gy2T, alT2, ge2, gad2, wlA + A2OFF, wlA + A2OFF + NC,
+        win_agg_bwd_src<1, NC, THREADS, NOHUB>(rw, tout, trp, teido, tdsto, 0, gy2T, alT2, ge2, gad2, wlA + A2OFF, wlA + A2OFF + NC,
                                              keep + L.k_gh2, n0, keep + L.k_gas2, keep + L.k_gad2, xG2);
         lds_barrier();                   // g_y2 (RA) and the conv2 tables are dead
         if (lean) seg_bias_finish_by<NC, THREADS, THREADS - 64>(red, sb + L.c2_b);      // (the last wave: `red` rests until dst1)
@@ -983,7 +1000,7 @@ __global__ __launch_bounds__(THREADS) void gatres_window_kernel(const FusedArgs 
 #ifndef GATRES_PROBE_NO_BWD_DMA       // (timing probe, WRONG results: the backward's block loop without its LDS-DMA of saved tables)
       dma_conv1_early();
 #endif
-      if (NC == 32 && a.keep_lds) {              // (the ReLU sign masks of the forward phase are in LDS: no global operand)
+      if (NC == 32 && keep_) {              // (the ReLU sign masks of the forward phase are in LDS: no global operand)
         if constexpr (NC == 32)
           if (wave_u < PW) {
             FRESH_ARGS(); FRESH_BWD();
@@ -1024,7 +1041,7 @@ __global__ __launch_bounds__(THREADS) void gatres_window_kernel(const FusedArgs 
         REC_DEFS(LIST_);
 #undef LIST_
         seg_bias_part<2 * NC, THREADS>(rw, RA, 0, red);
-        win_bwd_dst<false, 2, NC, THREADS>(rw, nbin, rp, colo, RA, hT1, alT1 + elo * 2, asT1, adT1, ge1 + elo * 2, gad1,
+        win_bwd_dst<false, 2, NC, THREADS, false, NOHUB>(rw, nbin, rp, colo, RA, hT1, alT1 + elo * 2, asT1, adT1, ge1 + elo * 2, gad1,
                                                 nullptr, nullptr, nullptr, nullptr, nullptr,
                                                 xout(xedge, bflag, 0u, (unsigned)XL.b3e), elo);
         if (NC != 32 || !xrows) lds_barrier();     // (else B3's sweep starts without one: see the top of the loop)
@@ -1049,7 +1066,7 @@ __global__ __launch_bounds__(THREADS) void gatres_window_kernel(const FusedArgs 
         lds_barrier();
         XSTAMP();
       }
-      publish_items<THREADS>(a, seg, part, 2 * (nb - 1 - b) + 1, grp.local, false);      // conv2 tables complete
+      if constexpr (!LEAN) publish_items<THREADS>(a, seg, part, 2 * (nb - 1 - b) + 1, grp.local, false);      // conv2 tables complete
       STAMP();
       {
         FRESH_ARGS(); FRESH_BWD();
@@ -1061,7 +1078,7 @@ __global__ __launch_bounds__(THREADS) void gatres_window_kernel(const FusedArgs 
         REC_DEFS(LIST_);
 #undef LIST_
         seg_bias_finish<2 * NC, THREADS>(red, sb + L.c1_b);
-        win_agg_bwd_src<2, NC, THREADS>(rw, tout, trp, teido, tdsto, 0, RA, alT1, ge1, gad1, wlB + A1OFF, wlB + A1OFF + 2 * NC,
+        win_agg_bwd_src<2, NC, THREADS, NOHUB>(rw, tout, trp, teido, tdsto, 0, RA, alT1, ge1, gad1, wlB + A1OFF, wlB + A1OFF + 2 * NC,
                                              keep + L.k_gh1, n0, keep + L.k_gas1, keep + L.k_gad1, xG1);
         lds_barrier();
         XSTAMP();
@@ -1070,7 +1087,7 @@ __global__ __launch_bounds__(THREADS) void gatres_window_kernel(const FusedArgs 
 #ifndef GATRES_PROBE_NO_BWD_DMA
       if (b > 0) { dma_conv2_early(b - 1, dw0); dma_conv2_late(b - 1, dw0); }
 #endif
-      if (NC == 32 && a.keep_lds) {
+      if (NC == 32 && keep_) {
         if constexpr (NC == 32)
           if (wave_u < PW) {
             FRESH_ARGS(); FRESH_BWD();
@@ -1119,14 +1136,14 @@ __global__ __launch_bounds__(THREADS) void gatres_window_kernel(const FusedArgs 
     // The parts only meet here for the consumers' sake (the last items are published behind this barrier); without consumer
     // workgroups nothing of a partner is needed any more: a workgroup barrier that also drains this part's own stores (g_x below
     // reads gp_cur back) replaces the flag barrier.  a.C is the same for every part: the barrier count per launch stays equal.
-    if (a.C > 0) group_sync<THREADS>(grp);
+    if (nC_ > 0) group_sync<THREADS>(grp);
     else         __syncthreads();
-    publish_items<THREADS>(a, seg, part, 2 * L.nb, grp.local || !pub, !pub);
+    if constexpr (!LEAN) publish_items<THREADS>(a, seg, part, 2 * L.nb, grp.local || !pub, !pub);
     // lin0's partial sums: g_pre of the own rows from LDS when the launch keeps them there (gkeep; gpT holds them divided by
     // the in-degrees for NC == 32), else from gp_cur
     seg_lin0_bwd<NC, THREADS>(rw, n0, a.perm, gp_cur, a.x, a.mask, slab + L.p_lin0_w, slab + L.p_lin0_b, red,
                               NC == 32 ? gkeep : gpT);
-    if (pub && a.C > 0) {
+    if (pub && nC_ > 0) {
       group_sync<THREADS>(grp);
       publish_items<THREADS>(a, seg, part, 2 * L.nb + 1, grp.local, true);
     }
@@ -1148,8 +1165,8 @@ __global__ __launch_bounds__(THREADS) void gatres_window_kernel(const FusedArgs 
   }
   if (tid == 0) __hip_atomic_store(grp.flags + part * FLAG_STRIDE + 2, xc.ep, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   if (M > 1 && tid == 0 && *a.err) {
-    if ((a.phases & GATRES_PHASE_FORWARD) && a.out) a.out[n0] = NAN;
-    if (a.phases & GATRES_PHASE_BACKWARD) a.slabs[(int64_t)seg * L.slab_stride + L.p_lin1_b] = NAN;
+    if ((ph_ & GATRES_PHASE_FORWARD) && a.out) a.out[n0] = NAN;
+    if (ph_ & GATRES_PHASE_BACKWARD) a.slabs[(int64_t)seg * L.slab_stride + L.p_lin1_b] = NAN;
   }
   if (STAMPS_PTR && blockIdx.x == 0 && threadIdx.x == 0) {
     STAMPS_PTR[a.stamp_cap + 1] = clock64();
@@ -1166,7 +1183,28 @@ extern "C" __attribute__((visibility("hidden"))) int gatres_fused_launch_window(
     case 4: hipLaunchKernelGGL((gatres_window_kernel<4, 1024>), dim3(grid), dim3(1024), 0, st, a); break;
     case 8: hipLaunchKernelGGL((gatres_window_kernel<8, 1024>), dim3(grid), dim3(1024), 0, st, a); break;
     case 16: hipLaunchKernelGGL((gatres_window_kernel<16, 1024>), dim3(grid), dim3(1024), 0, st, a); break;
-    case 32: hipLaunchKernelGGL((gatres_window_kernel<32, 1024>), dim3(grid), dim3(1024), 0, st, a); break;
+    case 32: {
+      // the launch's compile-time facts (gatres_window_kernel): phases | 0x100 keep-in-LDS | 0x200 symmetric plan, no consumer
+      // workgroups | 0x400 rows of at most MAXD entries | 0x800 part tables | 0x1000 parts of at most 64 rows
+      const int facts = ((a.sym && a.C == 0) ? 0x200 : 0) | (a.facts & 0x1400) | ((a.ptab && a.ptab_m == a.M) ? 0x800 : 0);
+      const int key = a.phases | (a.keep_lds ? 0x100 : 0) | (facts & gatres_knobs()->window_ph_mask);
+      if (!gatres_knobs()->window_runtime_phases && !GATRES_DIAG) {
+        switch (key) {
+          case 0x1f16: hipLaunchKernelGGL((gatres_window_kernel<32, 1024, 0x1f16>), dim3(grid), dim3(1024), 0, st, a); return gatres_launch_status();
+          case 0x0f16: hipLaunchKernelGGL((gatres_window_kernel<32, 1024, 0x0f16>), dim3(grid), dim3(1024), 0, st, a); return gatres_launch_status();
+          case 0x0716: hipLaunchKernelGGL((gatres_window_kernel<32, 1024, 0x0716>), dim3(grid), dim3(1024), 0, st, a); return gatres_launch_status();
+          case 0x0316: hipLaunchKernelGGL((gatres_window_kernel<32, 1024, 0x0316>), dim3(grid), dim3(1024), 0, st, a); return gatres_launch_status();
+          case 0x1e02: hipLaunchKernelGGL((gatres_window_kernel<32, 1024, 0x1e02>), dim3(grid), dim3(1024), 0, st, a); return gatres_launch_status();
+          case 0x1e04: hipLaunchKernelGGL((gatres_window_kernel<32, 1024, 0x1e04>), dim3(grid), dim3(1024), 0, st, a); return gatres_launch_status();
+          case 0x116: hipLaunchKernelGGL((gatres_window_kernel<32, 1024, 0x116>), dim3(grid), dim3(1024), 0, st, a); return gatres_launch_status();
+          case 0x002: hipLaunchKernelGGL((gatres_window_kernel<32, 1024, 0x002>), dim3(grid), dim3(1024), 0, st, a); return gatres_launch_status();
+          case 0x004: hipLaunchKernelGGL((gatres_window_kernel<32, 1024, 0x004>), dim3(grid), dim3(1024), 0, st, a); return gatres_launch_status();
+          default: break;
+        }
+      }
+      hipLaunchKernelGGL((gatres_window_kernel<32, 1024>), dim3(grid), dim3(1024), 0, st, a);
+      break;
+    }
     default: return GATRES_E_UNSUPPORTED;
   }
   return gatres_launch_status();

@@ -577,6 +577,12 @@ __device__ __forceinline__ void build_nbr_out(Rows rw, const u16* trp, const u16
 
 // does any lane of this wave hold a row with more than MAXD edges?  (wave-uniform)
 __device__ __forceinline__ bool wave_has_hub(int deg) { return __ballot(deg > MAXD) != 0ull; }
+// NH: the plan promises that no row of any CSR has more than MAXD entries (GATRES_GRAPH_DEG_LE6) -- the edge-at-a-time
+// paths of the stages are not compiled
+template <bool NH> __device__ __forceinline__ bool wave_has_hub_t(int deg) {
+  if constexpr (NH) return false;
+  else return wave_has_hub(deg);
+}
 
 // ---------------------------------------------------------------------------------------------- forward stages
 // K2 forward, sub-stage A (seg_softmax): one thread per (row, head).
@@ -711,7 +717,7 @@ __device__ __forceinline__ void win_gather(Rows rw, const u16* nb, const u16* rp
 template <int K> __device__ __forceinline__ float group8_bcast(float v) {
   return __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(v), 0x18 | (K << 5)));      // lane (l & 0x18) | K
 }
-template <bool RELU, int H, int C, int THREADS>
+template <bool RELU, int H, int C, int THREADS, bool NH = false>
 __device__ __forceinline__ void win_fwd_agg(Rows rw, const u16* nb, const u16* rp, const u16* col, const float* hsrc,
                                             const float* asrc, const float* adst_t, float* __restrict__ alpha_g, int eb,
                                             float* alpha_l, const float* bias, float* out, int ob, float* out_pub,
@@ -745,7 +751,7 @@ __device__ __forceinline__ void win_fwd_agg(Rows rw, const u16* nb, const u16* r
     asm volatile(".rept " GATRES_VALU_PROBE "\n\tv_mov_b32 %0, %0\n\t.endr" : "+v"(acc.x));
 #endif
 #endif
-    if (__builtin_expect(wave_has_hub(d.deg), 0)) {
+    if (__builtin_expect(wave_has_hub_t<NH>(d.deg), 0)) {
       // edge at a time: the head's first lane forms the coefficients (seg_softmax's loops), through the LDS table
       const int beg = rp[r], end = rp[r + 1];
       if (c0 % C == 0) {
@@ -822,7 +828,7 @@ __device__ __forceinline__ void win_fwd_agg(Rows rw, const u16* nb, const u16* r
 }
 
 // K3 forward (seg_mean_fwd): out = relu(mean_{j->r} y[j] + x0[r]).
-template <int C, int THREADS>
+template <int C, int THREADS, bool NH = false>
 __device__ __forceinline__ void win_mean_fwd(Rows rw, const u16* mb, const u16* mrp, const u16* mcol, const float* y,
                                              const float* x0, float* out, float* out2, unsigned* mask32) {
   const int tid = stage_tid();
@@ -839,7 +845,7 @@ __device__ __forceinline__ void win_mean_fwd(Rows rw, const u16* mb, const u16* 
     const NbrIn d = unpack_in(w);
     const float4 rr = as_f4(xr);
     float4 acc = f4zero();
-    if (__builtin_expect(wave_has_hub(d.deg), 0)) {
+    if (__builtin_expect(wave_has_hub_t<NH>(d.deg), 0)) {
       const int beg = mrp[r], end = mrp[r + 1];
       for (int e = beg; e < end; ++e) add4(acc, ld4(y + (unsigned)((int)mcol[e] * C + c0)));
     } else {
@@ -1020,7 +1026,7 @@ __device__ __forceinline__ void win_softmax_bwd(Rows rw, const u16* nb, const u1
 // MEAN (conv2 only, H == 1): the stage starts with K3 backward (win_mean_bwd) for the same row -- its result g_y2[r] is
 // the g_out operand of the edge dots, held by the same lanes -- so  B1 exchange -> [K3 bwd, edge dots, softmax bwd] -> B2
 // exchange  is ONE stage.  g_out_rw: [row][HC] over the window (shifted view): read (MEAN = false) or written (MEAN).
-template <bool MEAN, int H, int C, int THREADS, bool PRE = false>
+template <bool MEAN, int H, int C, int THREADS, bool PRE = false, bool NH = false>
 __device__ __forceinline__ void win_bwd_dst(Rows rw, const u16* nb, const u16* rp, const u16* col, float* g_out_rw,
                                             const float* h, const float* alpha, const float* a_src, const float* a_dst,
                                             float* g_e, float* g_a_dst,
@@ -1055,7 +1061,7 @@ __device__ __forceinline__ void win_bwd_dst(Rows rw, const u16* nb, const u16* r
       const NbrOut od = unpack_out(wa, wb);
       d = unpack_in(w);
       float4 acc = f4zero();
-      if (__builtin_expect(wave_has_hub(od.deg), 0)) {
+      if (__builtin_expect(wave_has_hub_t<NH>(od.deg), 0)) {
         const int beg = mtrp[r], end = mtrp[r + 1];
         for (int t = beg; t < end; ++t) {
           const int ii = mtdst[t];
@@ -1099,7 +1105,7 @@ __device__ __forceinline__ void win_bwd_dst(Rows rw, const u16* nb, const u16* r
       d = unpack_in(w);
       go = as_f4(gw);
     }
-    if (__builtin_expect(wave_has_hub(d.deg), 0)) {
+    if (__builtin_expect(wave_has_hub_t<NH>(d.deg), 0)) {
       // edge at a time: the dots of the row through LDS (written and read by lanes of this wave, in program order)
       const int beg = rp[r], end = rp[r + 1];
       for (int e = beg; e < end; ++e) {
@@ -1204,7 +1210,7 @@ __device__ __forceinline__ void win_bwd_dst(Rows rw, const u16* nb, const u16* r
 //   to: out-edge descriptors (x_k = window-relative edge id); g_out: [row][HC] over the window; alpha / g_e: LDS [e][H]
 //   over the WINDOW's edges; g_a_dst: [row][H] own rows; g_h: global (kept for the deferred parameter gradients, row
 //   hb + r); g_h2: LDS x operand of the dX stage.
-template <int H, int C, int THREADS>
+template <int H, int C, int THREADS, bool NH = false>
 __device__ __forceinline__ void win_agg_bwd_src(Rows rw, const u16* to, const u16* trp, const u16* teid, const u16* tdst,
                                                 int eid_sub, const float* g_out, const float* alpha, const float* g_e,
                                                 const float* g_a_dst, const float* att_src, const float* att_dst,
@@ -1230,7 +1236,7 @@ __device__ __forceinline__ void win_agg_bwd_src(Rows rw, const u16* to, const u1
     const NbrOut d = unpack_out(wa, wb);
     float4 acc = f4zero();
     float gas = 0.f;
-    if (__builtin_expect(wave_has_hub(d.deg), 0)) {
+    if (__builtin_expect(wave_has_hub_t<NH>(d.deg), 0)) {
       const int beg = trp[r], end = trp[r + 1];
       for (int t = beg; t < end; ++t) {
         const int e = (int)teid[t] - eid_sub, ii = tdst[t];

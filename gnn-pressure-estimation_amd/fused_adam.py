@@ -40,6 +40,9 @@ class FusedAdam(torch.optim.Optimizer):
         """(pointer, keep-alive) of the gradients as one contiguous fp32 buffer, or None if a gradient is missing.
         loss.backward() of the module hands them out as views of a single allocation in parameter order: then no copy
         is needed, only the base pointer."""
+        fg = self.model.flat_grad()          # (gradients delivered in place by the module's backward: one identity check each)
+        if fg is not None:
+            return fg.data_ptr(), fg
         g0 = params[0].grad
         if g0 is None:
             return None

@@ -694,45 +694,50 @@ class GATResTrainer:
         dev = self.device
         torch.cuda.synchronize(dev)
         keep = [t.clone() for t in (self.step_counter, self.model.flat_parameters, self.exp_avg, self.exp_avg_sq, self.loss)]
-        n = len(self._bound)
-        # (mask-ahead: the two mask buffers take turns, so a batch has two steady-state graphs; without it, one)
-        ahead_ok = self._mask_next and (not self.split or self._one_piece())
-        ptrs = (self.mask.data_ptr(), self._mask_spare.data_ptr()) if ahead_ok else (None,)
-        need = {(i, p) for i in range(n) for p in ptrs}
-        steps = 0
-        while need and steps < 4 * n + 8:
-            # the step about to run is a steady-state one iff the weights' transposes are current and (mask-ahead) a mask was
-            # sampled ahead; it then trains with the (current) spare buffer as its mask
-            steady = (not self.fused) or self._wt_current()
-            ptr = None
-            if ahead_ok:
-                steady = steady and self._mask_sig is not None and self._mask_sig == self._mask_key()
-                ptr = self._mask_spare.data_ptr() if steady else None
-            i = next((j for j in range(n) if (j, ptr) in need), 0)
-            self.step_bound(i)
-            if steady:
-                need.discard((i, ptr))
-            steps += 1
-        # multi-step sequences (steps_bound): each one under both start orientations of the mask buffers
-        for seq in sequences:
-            seq = tuple(int(i) for i in seq)
-            if len(seq) < 2 or not ahead_ok or self.split:
-                continue
-            seen = set()
-            for _ in range(4):
-                if len(seen) == 2:
-                    break
-                start = self._mask_spare.data_ptr()
-                if start in seen:
-                    self.step_bound(seq[0])            # (flip the orientation)
+        try:
+            n = len(self._bound)
+            # (mask-ahead: the two mask buffers take turns, so a batch has two steady-state graphs; without it, one)
+            ahead_ok = self._mask_next and (not self.split or self._one_piece())
+            ptrs = (self.mask.data_ptr(), self._mask_spare.data_ptr()) if ahead_ok else (None,)
+            need = {(i, p) for i in range(n) for p in ptrs}
+            steps = 0
+            while need and steps < 4 * n + 8:
+                # the step about to run is a steady-state one iff the weights' transposes are current and (mask-ahead) a mask was
+                # sampled ahead; it then trains with the (current) spare buffer as its mask
+                steady = (not self.fused) or self._wt_current()
+                ptr = None
+                if ahead_ok:
+                    steady = steady and self._mask_sig is not None and self._mask_sig == self._mask_key()
+                    ptr = self._mask_spare.data_ptr() if steady else None
+                i = next((j for j in range(n) if (j, ptr) in need), 0)
+                self.step_bound(i)
+                if steady:
+                    need.discard((i, ptr))
+                steps += 1
+            # multi-step sequences (steps_bound): each one under both start orientations of the mask buffers
+            for seq in sequences:
+                seq = tuple(int(i) for i in seq)
+                if len(seq) < 2 or not ahead_ok or self.split:
                     continue
-                self.steps_bound(seq)
-                seen.add(start)
-        self._max_graphs = max(self._max_graphs, len(self._graphs) + 16)
-        torch.cuda.synchronize(dev)
-        for dst, src in zip((self.step_counter, self.model.flat_parameters, self.exp_avg, self.exp_avg_sq, self.loss), keep):
-            dst.copy_(src)
-        self._mask_sig = None
+                seen = set()
+                for _ in range(4):
+                    if len(seen) == 2:
+                        break
+                    start = self._mask_spare.data_ptr()
+                    if start in seen:
+                        self.step_bound(seq[0])            # (flip the orientation)
+                        continue
+                    self.steps_bound(seq)
+                    seen.add(start)
+            self._max_graphs = max(self._max_graphs, len(self._graphs) + 16)
+        finally:
+            # whatever happened above (a capture or a launch may raise midway): the caller's model, moments and step count
+            # come back, and neither the sampled-ahead mask nor scratch's transposed weights is taken for current
+            torch.cuda.synchronize(dev)
+            for dst, src in zip((self.step_counter, self.model.flat_parameters, self.exp_avg, self.exp_avg_sq, self.loss), keep):
+                dst.copy_(src)
+            self._mask_sig = None
+            self._wt_sig = None
         if self.fused:
             # scratch holds the transposes of the LAST pre-capture step's weights: re-derive them for the restored parameters
             _native.check(self.lib.gatres_fused_prepare_backward(
@@ -775,6 +780,8 @@ class GATResTrainer:
         whose entry j receives step j's loss.  Returns the last step's loss tensor."""
         idx = tuple(int(i) for i in indices)
         bnd = self._bound if bound is None else bound
+        if losses is not None and losses.numel() < len(idx):
+            raise ValueError(f"`losses` holds {losses.numel()} entries for {len(idx)} steps")
         steady = (len(idx) > 1 and self.use_graph and self.fused and not self.split and self._mask_next and self._wt_current()
                   and self._mask_sig is not None and self._mask_sig == self._mask_key() and self.node_ptr is not None)
         if not steady:
@@ -799,13 +806,19 @@ class GATResTrainer:
         try:
             self._replay(("seq", idx, self.mask_rate, self.seed, self.world, m0.data_ptr(), bnd[idx[0]][0].data_ptr(),
                           None if losses is None else losses.data_ptr()), enqueue, True)
-        finally:
-            for _ in idx:
-                self._count_native_update()
-            self._wt_sig = self._param_signature()
-            if len(idx) % 2:                           # an odd number of steps leaves the buffers swapped
-                self.mask, self._mask_spare = self._mask_spare, self.mask
-            self._mask_sig = self._mask_key()          # (the last update launch sampled the next step's mask into the spare buffer)
+        except BaseException:
+            # an unknown number of the sequence's steps ran: nothing about the mask buffers or the transposed weights can be
+            # relied on -- the next step samples its own mask and re-derives the transposes
+            self._count_native_update()
+            self._mask_sig = None
+            self._wt_sig = None
+            raise
+        for _ in idx:
+            self._count_native_update()
+        self._wt_sig = self._param_signature()
+        if len(idx) % 2:                               # an odd number of steps leaves the buffers swapped
+            self.mask, self._mask_spare = self._mask_spare, self.mask
+        self._mask_sig = self._mask_key()              # (the last update launch sampled the next step's mask into the spare buffer)
         if losses is not None:
             self.loss.copy_(losses[len(idx) - 1:len(idx)])
         return self.loss
@@ -836,9 +849,15 @@ class GATResTrainer:
         bs, npg = self.num_graphs, store.nodes_per_graph
         buf = getattr(self, "_epoch_buf", None)
         if buf is None or tuple(buf.shape) != (nfull * bs, npg):
+            if buf is not None:
+                self.release_epoch_buffer()
             buf = self._epoch_buf = torch.empty(nfull * bs, npg, dtype=torch.float32, device=self.device)
             views = [buf[j * bs:(j + 1) * bs].reshape(-1) for j in range(nfull)]
             self._epoch_bound = [(v, v) for v in views]            # (x is also y: train.py:162-166)
+            self._epoch_losses = None
+        if getattr(self, "_epoch_losses", None) is None or self._epoch_losses.numel() < max(kseq, 2):
+            # (also when epoch_graph_steps was raised between two epochs on the same store: a step's loss slot must exist --
+            #  ADVICE r5; the losses pointer is part of the sequences' graph key, so no stale graph meets the new vector)
             self._epoch_losses = torch.zeros(max(kseq, 2), dtype=torch.float32, device=self.device)
             # sequences of k (one graph per run of the epoch and mask orientation), single steps where a run starts or ends
             self._max_graphs = max(self._max_graphs, MAX_CACHED_GRAPHS + 2 * (nfull // kseq + 1) + 2 * kseq + 8)
@@ -855,6 +874,28 @@ class GATResTrainer:
                 self._step_on(eb[j], ("at", eb[j][0].data_ptr(), eb[j][1].data_ptr()))   # (the slot names the buffers: a re-allocated epoch buffer never meets a stale graph)
                 total.add_(self.loss.double(), alpha=float(bs))
             j += k
+
+    def _epoch_copy_fits(self, rows: int, npg: int) -> bool:
+        """May ``fit_epoch`` keep a device copy of the epoch's shuffled batches (``rows`` x ``npg`` floats: as large as the store
+        itself, i.e. the store's footprint doubles)?  Yes if it already exists, or if it is within ``epoch_copy_limit_bytes``
+        AND leaves a quarter of the device's free memory untouched; otherwise the epoch goes through the row-gather steps
+        (``steps_rows``), which need no copy."""
+        buf = getattr(self, "_epoch_buf", None)
+        if buf is not None and tuple(buf.shape) == (rows, npg):
+            return True
+        need = 4 * rows * npg
+        if need > int(self.epoch_copy_limit_bytes):
+            return False
+        held = 0 if buf is None else buf.numel() * 4          # (a buffer of another shape is released first)
+        free, _ = torch.cuda.mem_get_info(self.device)
+        return need <= 0.75 * (free + held)
+
+    def release_epoch_buffer(self) -> None:
+        """Free ``fit_epoch``'s device copy of the epoch (and the graphs captured on it)."""
+        if getattr(self, "_epoch_buf", None) is not None:
+            torch.cuda.synchronize(self.device)
+            self._graphs.clear()
+            self._epoch_buf = self._epoch_bound = self._epoch_losses = None
 
     def _sibling(self, num_graphs: int, nodes_per_graph: int, edge_index: torch.Tensor) -> "GATResTrainer":
         """Trainer for another batch size of the same dataset (the ragged last batch of an epoch): its own plan and
@@ -906,7 +947,7 @@ class GATResTrainer:
         first = 0                                        # batches [0, first) are done by the in-place path below
         nfull = store.num_snapshots // bs
         if (kseq > 1 and not metric_fn_dict and nfull >= 2 and self._mask_next and self.node_ptr is not None
-                and 4 * nfull * bs * npg <= int(self.epoch_copy_limit_bytes)):
+                and self._epoch_copy_fits(nfull * bs, npg)):
             # The epoch's full batches as ONE device gather into a persistent buffer (the shuffled store: S x N_g floats), then
             # trained IN PLACE, k per captured launch sequence, with the mask sampled ahead by the update launches -- the
             # bound-batch step of bench.py, three launches and nothing else: no collation launch, no per-step host work.

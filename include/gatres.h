@@ -116,6 +116,10 @@ enum {
                                     * lane group and are only taken for such plans; others keep the per-op kernels, whose hub
                                     * rows are reduced by whole waves. */
 
+#define GATRES_GRAPH_DEG_LE6 4     /* no node has more than 5 edges into it or out of it in edge_index: every row of the plan's
+                                    * CSRs has at most 6 entries (the per-snapshot kernels' slot width, MAXD).  The window kernel
+                                    * then runs an instantiation without the edge-at-a-time paths of its stages (k_window.hip). */
+
 /* Host-side plan builder (runs on the CPU, once per topology).  edge_index_host: int64 [2, E] row-major as
  * torch stores it.  Step 1: count -> E'.  Step 2: fill caller-allocated HOST arrays sized from that count. */
 int gatres_graph_count_host(const int64_t* edge_index_host, int64_t num_edges, int64_t num_nodes,

@@ -202,6 +202,84 @@ def test_drop_in_training_loop_with_torch_adam(pkg, oracle):
     assert e < 1e-4
 
 
+def test_parameter_gradients_delivered_in_place_equal_autograds(pkg, oracle):
+    """``direct_param_grads`` (the default): loss.backward() writes the flat gradient into persistent ``.grad`` views and no
+    AccumulateGrad node runs.  Held bit for bit to the gradients the same module delivers THROUGH autograd
+    (``direct_param_grads = False``) under every state the ``.grad`` fields can be in: None (``zero_grad()``), the module's
+    own views (``zero_grad(set_to_none=False)``, accumulation over two backwards), a mixture with foreign tensors; a tensor
+    hook switches the path off by itself; the previous backward's gradients survive the next one."""
+    nb, nc, bs = 3, 32, 2
+    ei = pkg.wdn_synth.collate_edge_index(pkg.wdn_synth.make_wdn_topology(), 388, bs).cuda()
+    snaps = pkg.wdn_synth.make_snapshots(4, 388, seed=21)
+    ya = pkg.wdn_synth.collate_snapshots(snaps, range(0, bs)).cuda()
+    yb = pkg.wdn_synth.collate_snapshots(snaps, range(bs, 2 * bs)).cuda()
+    md, _ = build(pkg, oracle, nb, nc, seed=61)
+    ma, _ = build(pkg, oracle, nb, nc, seed=61)
+    ma.direct_param_grads = False
+    assert md.direct_param_grads
+
+    def bwd(model, y):
+        out = model(y, ei)
+        (out * out).mean().backward()
+        return out
+
+    def flat(model):
+        return torch.cat([p.grad.reshape(-1) for p in model.parameters()])
+
+    # 1. every .grad None
+    o1, o2 = bwd(md, ya), bwd(ma, ya)
+    assert o1.grad_fn is not None and torch.equal(o1, o2)
+    assert torch.equal(flat(md), flat(ma))
+    fg = md.flat_grad()
+    assert fg is not None and torch.equal(fg, flat(ma)) and ma.flat_grad() is None
+    assert all(p.grad.shape == p.shape and p.grad.is_contiguous() for p in md.parameters())
+    held = [p.grad for p in md.parameters()]
+    held_vals = flat(md).clone()
+    # 2. zero_grad() (set_to_none=True), another batch: fresh views; the gradients held from step 1 are intact
+    md.zero_grad(); ma.zero_grad()
+    assert md.flat_grad() is None
+    bwd(md, yb); bwd(ma, yb)
+    assert torch.equal(flat(md), flat(ma))
+    assert torch.equal(torch.cat([g.reshape(-1) for g in held]), held_vals)
+    # 3. accumulation on top of the module's own views
+    bwd(md, ya); bwd(ma, ya)
+    assert torch.equal(flat(md), flat(ma)) and md.flat_grad() is not None
+    # 4. zero_grad(set_to_none=False): zeros in place, then accumulate
+    md.zero_grad(set_to_none=False); ma.zero_grad(set_to_none=False)
+    assert float(flat(md).abs().max()) == 0.0
+    bwd(md, yb); bwd(ma, yb)
+    assert torch.equal(flat(md), flat(ma))
+    # 5. a mixture: one gradient replaced by a foreign tensor, one set to None
+    for model in (md, ma):
+        model.lin0.weight.grad = model.lin0.weight.grad.clone()
+        model.lin1.bias.grad = None
+    bwd(md, ya); bwd(ma, ya)
+    assert torch.equal(flat(md), flat(ma)) and md.flat_grad() is None
+    # 6. torch.optim.Adam and FusedAdam take the views
+    md.zero_grad(); ma.zero_grad()
+    od = torch.optim.Adam(md.parameters(), lr=5e-4, weight_decay=6e-6)
+    oa = torch.optim.Adam(ma.parameters(), lr=5e-4, weight_decay=6e-6)
+    for y in (ya, yb, ya):
+        for model, opt in ((md, od), (ma, oa)):
+            opt.zero_grad()
+            bwd(model, y)
+            opt.step()
+    assert torch.equal(md.flat_parameters, ma.flat_parameters)
+    # 7. a tensor hook: the gradient must pass through autograd, and does
+    seen = []
+    h = md.lin1.weight.register_hook(lambda g: seen.append(float(g.abs().sum())) or g * 2.0)
+    md.zero_grad(); ma.zero_grad()
+    bwd(md, ya); bwd(ma, ya)
+    assert len(seen) == 1 and torch.equal(md.lin1.weight.grad, 2.0 * ma.lin1.weight.grad)
+    assert torch.equal(md.lin0.weight.grad, ma.lin0.weight.grad)
+    h.remove()
+    # 8. torch.autograd.grad needs the autograd path: documented switch
+    md.direct_param_grads = False
+    gs = torch.autograd.grad((md(ya, ei) ** 2).mean(), list(md.parameters()))
+    ma.zero_grad(); bwd(ma, ya)
+    assert torch.equal(torch.cat([g.reshape(-1) for g in gs]), flat(ma))
+
+
 @pytest.mark.parametrize("fused", [True, False], ids=["fused", "per_op"])
 @pytest.mark.parametrize("use_graph", [False, True])
 def test_native_train_step_matches_oracle(pkg, oracle, use_graph, fused):
