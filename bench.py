@@ -59,11 +59,19 @@ def parse():
     ap.add_argument("--per-op", action="store_true", help="one launch per stage instead of the fused per-snapshot kernel")
     ap.add_argument("--force-collective-path", action="store_true",
                     help="run the multi-GPU sequence (backward | RCCL all-reduce | Adam) even at world size 1")
+    ap.add_argument("--fused-buckets", type=int, default=1, choices=[1, 2],
+                    help="data-parallel step of the fused path: 1 = the single-GPU step's launches + ONE all-reduce of the flat "
+                         "gradient + the Adam launch; 2 = the parameter gradients as two range launches, the upper blocks' bucket "
+                         "on the wire under the lower blocks' launch (GATResTrainer.fused_buckets)")
     ap.add_argument("--host-batches", action="store_true",
                     help="batches start in pinned host memory: the timed step includes the H2D copy (PCIe-inclusive "
                          "rate for DESIGN.md; never the headline value)")
     ap.add_argument("--fused-adam", action="store_true",
                     help="with --drop-in: FusedAdam (one native launch) instead of torch.optim.Adam")
+    ap.add_argument("--flat-adam", action="store_true",
+                    help="with --drop-in: torch.optim.Adam(model.optimizer_parameters()) -- torch's own Adam on ONE flat leaf "
+                         "parameter instead of the 124 named tensors (the optimizer line of train.py:348 changes, the loop body "
+                         "does not)")
     ap.add_argument("--eval", action="store_true",
                     help="inference line instead of the training step: forward-only through the drop-in module under the "
                          "reference's Timer protocol (utils/timer.py:22-66: 10 warm-up calls, one event pair + synchronize per "
@@ -448,6 +456,8 @@ def drop_in_loop(args, G, model, topo, device, nb, nc):
     import numpy as np
     if args.fused_adam:
         opt = G.FusedAdam(model, lr=5e-4, weight_decay=6e-6)
+    elif args.flat_adam:
+        opt = torch.optim.Adam(model.optimizer_parameters(), lr=5e-4, weight_decay=6e-6)
     else:
         opt = torch.optim.Adam(model.parameters(), lr=5e-4, weight_decay=6e-6)
     crit = torch.nn.MSELoss()
@@ -481,7 +491,7 @@ def drop_in_loop(args, G, model, topo, device, nb, nc):
                       "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
                       "data": "synthetic",
                       "config": {"workload": f"{args.model}, drop-in nn.Module + "
-                                             f"{'FusedAdam' if args.fused_adam else 'torch.optim.Adam'} + host numpy mask, "
+                                             f"{'FusedAdam' if args.fused_adam else 'torch.optim.Adam on the flat parameter' if args.flat_adam else 'torch.optim.Adam'} + host numpy mask, "
                                              f"reference loop body verbatim (train.py:160-190), batch_size={bs}",
                                  "final_loss": last}}))
 
@@ -510,15 +520,24 @@ def eval_loop(args, G, model, topo, device, nb, nc):
             out = timer.auto_measure(model, bs, 10)(x1, ei, None, None)                   # evaluation.py:321-323
     wall = time.perf_counter() - t0
     n_graphs = n_batches * bs
+    # The reference's two figures, by its own formulas (utils/timer.py:43-66).  Both carry a quirk of that file: compute_time
+    # divides the sum of (batch time x graphs in the batch) by the NUMBER OF GRAPHS, which is the mean time of a BATCH, and
+    # compute_throughput divides (batches x batch size) by that mean batch time in seconds -- N times the rate at which graphs
+    # are processed.  They are reported as the reference would print them; `value` is the plain rate: graphs / summed call time.
     ms_graph, thr = timer.compute_time(n_graphs), timer.compute_throughput(n_graphs)
     ms_call = float(np.mean(timer.timings))
+    rate = n_graphs / (float(np.sum(timer.timings)) * 1e-3)
     sb = survey_bytes_per_snapshot(nb, nc, npg, 2 * args.pipes, 2 if args.dtype == "bf16" else 4)
     ach = sb["forward"] * bs / (ms_call * 1e-3) * 1e-9
     assert bool(torch.isfinite(out).all())
-    print(json.dumps({"metric": "test_throughput (evaluation.py:347)", "value": thr, "unit": "graphs/s", "n_gpus": 1,
+    print(json.dumps({"metric": "inference graphs/sec (forward only, Timer protocol)", "value": rate, "unit": "graphs/s", "n_gpus": 1,
                       "steps": n_batches, "warmup": 10, "ms_per_step": ms_call, "higher_is_better": True, "scaling": "weak",
                       "vs_baseline": None, "dtype": "bf16" if args.dtype == "bf16" else "f32", "data": "synthetic",
-                      "test_time_ms_per_graph": ms_graph,
+                      "reference_figures": {"test_time (evaluation.py:346, timer.py:43-51)": ms_graph,
+                                            "test_throughput (evaluation.py:347, timer.py:53-66)": thr,
+                                            "note": "as the reference computes them: test_time is the mean milliseconds of a BATCH "
+                                                    "(weighted by graph count), test_throughput is batches x batch_size / that time"},
+                      "ms_per_graph": ms_call / bs,
                       "ms_per_call": {"mean": ms_call, "min": float(np.min(timer.timings)), "max": float(np.max(timer.timings))},
                       "wall_graphs_per_s_incl_host": n_graphs / wall,
                       "config": {"workload": f"{args.model} ({nb} blocks, nc={nc}), forward only, drop-in nn.Module under "
@@ -580,6 +599,7 @@ def main():
                               use_graph=not args.no_graph, fused=not args.per_op,
                               force_collective_path=args.force_collective_path,
                               targets_are_inputs=True)        # synthetic snapshots: y is x before masking
+    trainer.fused_buckets = args.fused_buckets
     nbatches = 8
     snaps = G.wdn_synth.make_snapshots(nbatches * args.batch_size, args.nodes, seed=100 + rank).to(device)
     batches = [snaps[i * args.batch_size:(i + 1) * args.batch_size].reshape(-1).contiguous() for i in range(nbatches)]
@@ -658,6 +678,23 @@ def main():
         raise SystemExit(f"bench.py: {graphs_after - graphs_before} hipGraph capture(s) happened INSIDE the timed region "
                          f"({graphs_before} -> {graphs_after} graphs): the measurement is invalid")
     dt = statistics.median(times)
+    coll = None
+    if trainer.split and trainer.reducer is not None and trainer.reducer.active and trainer._one_piece():
+        # what the all-reduce itself takes: 20 more steps as EAGER launches with an event pair around the collective (events
+        # inside a captured step cannot be read); untimed, after the timed blocks
+        was = trainer.use_graph
+        trainer.use_graph = False
+        trainer.reducer.time_collective = True
+        for i in range(20):
+            trainer.step_bound(i % nbatches) if bound_path else one_step(i)
+        ms = trainer.reducer.collective_ms()
+        trainer.reducer.time_collective = False
+        trainer.use_graph = was
+        if ms:
+            coll = {"all_reduce_us_mean": 1e3 * sum(ms) / len(ms), "all_reduce_us_min": 1e3 * min(ms), "all_reduce_us_max": 1e3 * max(ms),
+                    "samples": len(ms), "bytes": 4 * trainer.P,
+                    "how": "event pair on the launch stream around the synchronous all-reduce of the flat gradient, eager steps "
+                           "after the timed blocks (rank 0)"}
     loss = float(trainer.loss.item())
     log(f"timed {len(times)} x {args.steps} steps: median {dt:.4f}s (min {min(times):.4f}, max {max(times):.4f}), loss {loss:.5f}")
     # GATRES_BENCH_TIMING_ONLY=1: probe builds of the library that give WRONG results on purpose (tests/micro/ab_libs.sh); the line
@@ -695,6 +732,7 @@ def main():
                                f"{', batches staged by copy' if args.copy_batches else ''}",
                    "global_batch": world * args.batch_size, "parallelism": f"dp{world}",
                    "plan_relabelled": trainer.plan.perm_host is not None, "row_window": trainer.plan.window_rows(cus) if cus >= 2 else None,
+                   "fused_buckets": trainer.fused_buckets if trainer.split else None, "collective": coll,
                    "dropped_steps": dropped, "final_loss": loss,
                    "captured_graphs": graphs_after, "captures_in_timed_region": graphs_after - graphs_before},
     }
@@ -809,8 +847,9 @@ def main():
             pass
         sys.stdout.flush()
         print(json.dumps(result), flush=True)
-        if world > 1 or args.force_collective_path:
-            os._exit(0)           # (nothing may follow the JSON line: skip exit handlers that print, e.g. RCCL's)
+        if (world > 1 or args.force_collective_path) and not os.environ.get("GATRES_BENCH_NO_HARD_EXIT"):
+            os._exit(0)           # (nothing may follow the JSON line: skip exit handlers that print, e.g. RCCL's; a profiler
+                                  #  that writes its files at exit needs GATRES_BENCH_NO_HARD_EXIT=1)
 
 
 if __name__ == "__main__":

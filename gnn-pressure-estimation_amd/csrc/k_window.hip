@@ -1188,7 +1188,7 @@ extern "C" __attribute__((visibility("hidden"))) int gatres_fused_launch_window(
       // workgroups | 0x400 rows of at most MAXD entries | 0x800 part tables | 0x1000 parts of at most 64 rows
       const int facts = ((a.sym && a.C == 0) ? 0x200 : 0) | (a.facts & 0x1400) | ((a.ptab && a.ptab_m == a.M) ? 0x800 : 0);
       const int key = a.phases | (a.keep_lds ? 0x100 : 0) | (facts & gatres_knobs()->window_ph_mask);
-      if (!gatres_knobs()->window_runtime_phases && !GATRES_DIAG) {
+      if (!gatres_knobs()->window_runtime_phases) {
         switch (key) {
           case 0x1f16: hipLaunchKernelGGL((gatres_window_kernel<32, 1024, 0x1f16>), dim3(grid), dim3(1024), 0, st, a); return gatres_launch_status();
           case 0x0f16: hipLaunchKernelGGL((gatres_window_kernel<32, 1024, 0x0f16>), dim3(grid), dim3(1024), 0, st, a); return gatres_launch_status();

@@ -61,6 +61,11 @@ class BucketedAllReduce:
         self._works: List = []
         self.launched: List[Tuple[int, int]] = []          # (lo, hi) of every bucket of the current step, in launch order
         self.last_buckets: List[Tuple[int, int]] = []
+        # time_collective: an event pair on the caller's stream around every SYNCHRONOUS collective (eager launches only: events
+        # inside a capture cannot be read) -- ``collective_ms()`` then tells what the all-reduce itself took, so that a scaling
+        # loss can be attributed (bench.py prints it at N > 1)
+        self.time_collective = False
+        self._pairs: List = []
 
     def launch(self, lo: int, hi: int, alone: bool = False) -> None:
         """``alone``: this bucket is the step's only one (the fused path's flat gradient) -- nothing can overlap it, so it goes
@@ -72,9 +77,25 @@ class BucketedAllReduce:
         self.launched.append((lo, hi))
         if self.active:
             if alone and not self._works:
+                timed = self.time_collective and self.flat.is_cuda and not torch.cuda.is_current_stream_capturing()
+                if timed:
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
                 dist.all_reduce(self.flat[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=False)
+                if timed:
+                    e1.record()
+                    self._pairs.append((e0, e1))
             else:
                 self._works.append(dist.all_reduce(self.flat[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+
+    def collective_ms(self) -> List[float]:
+        """Durations (ms) of the collectives timed since the last call (synchronises the device)."""
+        if not self._pairs:
+            return []
+        torch.cuda.synchronize(self.flat.device)
+        out = [a.elapsed_time(b) for a, b in self._pairs]
+        self._pairs = []
+        return out
 
     def wait_all(self) -> None:
         for w in self._works:

@@ -129,21 +129,7 @@ class _GATResFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, module: "GATResMeanConv", plan: GraphPlan, needs_grad: bool, direct: bool, x: Tensor,
                 *params: Tensor) -> Tensor:
-        lib = _native.load()
-        N = plan.num_nodes
-        out = torch.empty((N, 1), dtype=torch.float32, device=x.device)
-        scratch = module._scratch_for(plan)
-        saved = None
-        if needs_grad:
-            saved = torch.empty(module._saved_floats(plan), dtype=torch.float32, device=x.device)
-        elif lib.gatres_fused_window_kernel(module._cmodel_ref(), plan.ref()):
-            # inference: the window kernel (taken only with a `saved` buffer) is ~17 % faster than the whole-segment-table
-            # kernel even though it writes activations nobody reads -- give it a cached throw-away buffer
-            saved = module._eval_saved_for(plan)
-        stream = _native.current_stream(x.device)
-        _native.check(lib.gatres_model_forward(module._cmodel_ref(), plan.ref(module._cmodel_ref()), module._flat.data_ptr(), x.data_ptr(),
-                                               None, out.data_ptr(), _native.ptr(saved), scratch.data_ptr(), stream),
-                      "gatres_model_forward")
+        out, saved = module._run_forward(plan, x, needs_grad)
         ctx.module, ctx.plan, ctx.saved_acts, ctx.direct = module, plan, saved, direct
         ctx.save_for_backward(x)
         ctx.params_like = params
@@ -164,10 +150,10 @@ class _GATResFunction(torch.autograd.Function):
         else:
             grads = torch.empty(module._flat.numel(), dtype=torch.float32, device=x.device)
         g_x = torch.empty_like(x) if ctx.needs_input_grad[4] else None
-        scratch = module._scratch_for(plan)
+        st = module._call_state(plan)
         stream = _native.current_stream(x.device)
-        _native.check(lib.gatres_model_backward(module._cmodel_ref(), plan.ref(module._cmodel_ref()), module._flat.data_ptr(), x.data_ptr(),
-                                                None, g_out.data_ptr(), saved.data_ptr(), scratch.data_ptr(),
+        _native.check(lib.gatres_model_backward(st["mref"], st["gref"], module._flat.data_ptr(), x.data_ptr(),
+                                                None, g_out.data_ptr(), saved.data_ptr(), st["scratch"].data_ptr(),
                                                 grads.data_ptr(), _native.ptr(g_x), stream), "gatres_model_backward")
         if ctx.direct:
             module._grad_deliver(slot)
@@ -203,6 +189,7 @@ class GATResMeanConv(nn.Module):
         self.direct_param_grads = True
         self._plans = PlanCache(segments=fused)
         self._scratch = {}
+        self._call_states = {}
         self._cmodel = _native.GatresModel(num_blocks, nc)
         self._flatten_parameters()
 
@@ -210,7 +197,7 @@ class GATResMeanConv(nn.Module):
     def __getstate__(self):
         state = self.__dict__.copy()
         for k in ("_plans", "_scratch", "_cmodel", "_flat", "_param_table", "_param_list", "_grad_bufs", "_grad_views",
-                  "_grad_cur"):
+                  "_grad_cur", "_call_states", "_flat_param"):
             state.pop(k, None)
         state["_act_dtype"] = int(self._cmodel.act_dtype)
         return state
@@ -220,6 +207,7 @@ class GATResMeanConv(nn.Module):
         self._flat = None
         self._plans = PlanCache(segments=getattr(self, 'fused', True))
         self._scratch = {}
+        self._call_states = {}
         self._cmodel = _native.GatresModel(self.num_blocks, self.nc, int(getattr(self, "_act_dtype", 0)), 0)
         self._flatten_parameters()
 
@@ -243,6 +231,7 @@ class GATResMeanConv(nn.Module):
                 off += n
         self._flat = flat
         self._scratch = {}
+        self._call_states = {}
         # (owner dict, name, parameter, byte offset) of every parameter in state_dict order: Module.parameters() walks
         # the whole module tree (0.4 ms for 182 parameters), too slow to repeat in every forward
         table = []
@@ -261,6 +250,7 @@ class GATResMeanConv(nn.Module):
         self._grad_bufs = None          # (two flat gradient buffers and the parameters' views of them: _grad_target)
         self._grad_views = None
         self._grad_cur = None
+        object.__setattr__(self, "_flat_param", None)      # (optimizer_parameters(): rebuilt over the new flat vector on demand)
 
     # ---- gradients delivered in place (direct_param_grads) ------------------------------------------------------
     def _grad_target(self):
@@ -278,6 +268,12 @@ class GATResMeanConv(nn.Module):
                     off += n
                 self._grad_views.append(views)
             self._grad_cur = None
+        fp = self._flat_param
+        if fp is not None:
+            # flat mode (optimizer_parameters()): ONE gradient buffer, slot 0, which ``flat_parameter.grad`` and the
+            # per-parameter ``.grad`` views stay attached to; slot 1 is the temporary of an accumulating backward
+            slot = 0 if fp.grad is None else 1
+            return self._grad_bufs[slot], slot
         slot = 0 if self._grad_cur is None else 1 - self._grad_cur
         return self._grad_bufs[slot], slot
 
@@ -285,6 +281,21 @@ class GATResMeanConv(nn.Module):
         """What AccumulateGrad does, for all parameters at once: every ``.grad`` is None (``zero_grad()``) -> the views of
         the buffer just written become the gradients; every ``.grad`` still is the view this module attached last time
         (``zero_grad(set_to_none=False)``, gradient accumulation) -> one flat ``add_``; anything else -> per parameter."""
+        fp = self._flat_param
+        if fp is not None:
+            if slot == 0:                           # flat_parameter.grad was None: the buffer just written IS the gradient
+                fp.grad = self._grad_bufs[0]
+                if self._grad_cur != 0:             # (the per-parameter views: attached once, they stay)
+                    for p, v in zip(self._param_list, self._grad_views[0]):
+                        p.grad = v
+                    self._grad_cur = 0
+            else:
+                g = fp.grad
+                if g is not self._grad_bufs[0]:     # (a foreign gradient tensor on the flat parameter)
+                    g.add_(self._grad_bufs[1])
+                else:
+                    self._grad_bufs[0].add_(self._grad_bufs[1])
+            return
         params, new = self._param_list, self._grad_views[slot]
         cur = self._grad_views[self._grad_cur] if self._grad_cur is not None else None
         n_none = n_ours = 0
@@ -308,9 +319,44 @@ class GATResMeanConv(nn.Module):
                     else:
                         p.grad.add_(v)
 
+    def optimizer_parameters(self) -> List[nn.Parameter]:
+        """``[flat_parameter]``: ONE leaf ``nn.Parameter`` over the flat vector every named parameter is a view of -- for
+        ``torch.optim.Adam(model.optimizer_parameters(), ...)`` in place of ``model.parameters()`` (train.py:348).  Adam is
+        element-wise, so the update is the 124-tensor one bit for bit, while the optimizer's per-tensor host work (0.9 ms per
+        step for gatres_small) is paid once.  From this call on the module is in FLAT MODE: ``loss.backward()`` delivers the
+        gradient as ``flat_parameter.grad`` (the named parameters' ``.grad`` are views of the same buffer, for inspection);
+        what ``zero_grad()`` / accumulation see is the flat parameter's ``.grad`` alone.  ``state_dict()`` is unchanged (the
+        flat parameter is not registered); an optimizer ``state_dict`` then holds one tensor, not the reference's 124."""
+        if self._flat_param is None:
+            if not self._flat_is_current():
+                self._flatten_parameters()
+            fp = nn.Parameter(self._flat, requires_grad=True)
+            if fp.data_ptr() != self._flat.data_ptr():
+                raise RuntimeError("flat parameter does not alias the flat vector")
+            object.__setattr__(self, "_flat_param", fp)          # (not registered: state_dict / parameters() stay the reference's)
+            self._grad_cur = None
+        return [self._flat_param]
+
+    @property
+    def flat_parameter(self) -> Optional[nn.Parameter]:
+        return self._flat_param
+
+    def zero_grad(self, set_to_none: bool = True) -> None:
+        super().zero_grad(set_to_none)
+        fp = self._flat_param
+        if fp is not None:                                   # (flat mode: the flat parameter's gradient is THE gradient)
+            if set_to_none:
+                fp.grad = None
+                self._grad_cur = None                        # (the named parameters' views were just detached: re-attach)
+            elif fp.grad is not None:
+                fp.grad.zero_()
+
     def flat_grad(self) -> Optional[Tensor]:
         """The flat fp32 buffer all parameter gradients currently are views of (state_dict order), or None when they are
         not (no backward yet, ``zero_grad()`` since, or gradients that came another way)."""
+        fp = self._flat_param
+        if fp is not None:
+            return fp.grad if fp.grad is self._grad_bufs[0] else None
         if self._grad_cur is None:
             return None
         cur = self._grad_views[self._grad_cur]
@@ -321,6 +367,8 @@ class GATResMeanConv(nn.Module):
 
     def _direct_ok(self, params) -> bool:
         if not self.direct_param_grads:
+            if self._flat_param is not None:
+                raise RuntimeError("flat mode (optimizer_parameters()) needs direct_param_grads")
             return False
         for p in params:
             if not p.requires_grad or p._backward_hooks or getattr(p, "_post_accumulate_grad_hooks", None):
@@ -367,6 +415,7 @@ class GATResMeanConv(nn.Module):
             raise ValueError("bf16 projections need nc >= 32 (a 32-deep MFMA reduction)")
         self._cmodel.act_dtype = code
         self._plans.clear()
+        self._call_states = {}
         return self
 
     @property
@@ -415,8 +464,43 @@ class GATResMeanConv(nn.Module):
             self._remember(key, buf)
         return buf
 
+    def _call_state(self, plan: GraphPlan) -> dict:
+        """What a forward / backward call of this model on ``plan`` needs besides the tensors, looked up ONCE per (plan, model
+        configuration): the plan struct with this model's part tables (``GraphPlan.bound`` asks the library for the split on
+        every call), whether inference takes the window kernel, the scratch buffer.  The reference's evaluation times every
+        call with an event pair (utils/timer.py:22-41): what the host spends between the two records is part of the figure."""
+        key = (id(plan), int(self._cmodel.act_dtype), bool(self.fused))
+        st = self._call_states.get(key)
+        if st is None or st["plan"] is not plan:
+            lib = _native.load()
+            st = {"plan": plan, "gref": plan.ref(self._cmodel_ref()), "mref": self._cmodel_ref(),
+                  "window": bool(lib.gatres_fused_window_kernel(self._cmodel_ref(), plan.ref())),
+                  "saved_floats": self._saved_floats(plan)}
+            if len(self._call_states) >= 8:
+                self._call_states.clear()
+            self._call_states[key] = st
+        st["scratch"] = self._scratch_for(plan)      # (through the LRU every time: one scratch buffer per plan, whoever asks)
+        return st
+
     def plan_for(self, edge_index: Tensor, num_nodes: int) -> GraphPlan:
         return self._plans.get(edge_index, num_nodes)
+
+    def _run_forward(self, plan: GraphPlan, x: Tensor, keep: bool):
+        """The native forward: (out, saved activations or None).  ``keep``: a backward will follow."""
+        lib = _native.load()
+        st = self._call_state(plan)
+        out = torch.empty((plan.num_nodes, 1), dtype=torch.float32, device=x.device)
+        saved = None
+        if keep:
+            saved = torch.empty(st["saved_floats"], dtype=torch.float32, device=x.device)
+        elif st["window"]:
+            # inference: the window kernel (taken only with a `saved` buffer) is ~17 % faster than the whole-segment-table
+            # kernel even though it writes activations nobody reads -- give it a cached throw-away buffer
+            saved = self._eval_saved_for(plan)
+        _native.check(lib.gatres_model_forward(st["mref"], st["gref"], self._flat.data_ptr(), x.data_ptr(), None,
+                                               out.data_ptr(), _native.ptr(saved), st["scratch"].data_ptr(),
+                                               _native.current_stream(x.device)), "gatres_model_forward")
+        return out, saved
 
     # ---- reference surface -----------------------------------------------------------------
     def forward(self, x: Tensor, edge_index: Tensor, batch: Optional[Tensor] = None,
@@ -435,6 +519,11 @@ class GATResMeanConv(nn.Module):
         params = self._param_list
         # grad mode is switched off inside Function.forward, so decide here whether activations must be kept
         needs_grad = torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in params))
-        if needs_grad and self._direct_ok(params):
+        if not needs_grad:
+            return self._run_forward(plan, x, False)[0]          # inference (evaluation.py:298,324-326): no autograd node at all
+        if self._direct_ok(params):
             return _GATResFunction.apply(self, plan, True, True, x, params[0])      # (params[0]: the anchor)
-        return _GATResFunction.apply(self, plan, needs_grad, False, x, *params)
+        if self._flat_param is not None:
+            raise RuntimeError("flat mode (optimizer_parameters()) delivers gradients in place: it cannot be combined with "
+                               "tensor hooks on, or frozen, named parameters")
+        return _GATResFunction.apply(self, plan, True, False, x, *params)

@@ -417,3 +417,48 @@ def test_multi_step_sequences_equal_single_steps(pkg, oracle):
     for k, (a, b) in enumerate(zip(*runs)):
         assert a[3] == b[3] and a[0] == b[0], (k, a[0], b[0])
         assert torch.equal(a[1], b[1]) and torch.equal(a[2], b[2]), k
+
+
+def test_window_kernel_instantiations_are_bit_identical(pkg, oracle, lib, monkeypatch):
+    """Round 6: a launch of the window kernel takes the instantiation that has everything the host knows about it as
+    template arguments (k_window.hip: phases, keep-in-LDS, symmetric plan without consumer workgroups, rows of at most six
+    entries, part tables, parts of at most 64 rows).  Every one of them -- down to the run-time-phases kernel of round 5 -- runs
+    the same stage functions on the same operands: predictions, loss, the flat gradient and the parameters after two Adam
+    steps must agree BIT FOR BIT, for the training launch, the forward-only launch (evaluation) and the nn.Module's
+    forward + backward launches.  Plans that lack a fact (a directed graph, a hub row) take the slower instantiation by
+    themselves: their parity tests are test_gpu_model.py's edge cases."""
+    bs = 8
+    ei = pkg.wdn_synth.collate_edge_index(pkg.wdn_synth.make_wdn_topology(NODES, PIPES, seed=0), NODES, bs).cuda()
+    y = pkg.wdn_synth.collate_snapshots(pkg.wdn_synth.make_snapshots(bs, NODES, seed=9), range(bs)).cuda()
+    mask = torch.from_numpy(pkg.wdn_synth.generate_batch_mask([NODES] * bs, 0.95, np.random.RandomState(4))).cuda()
+    plan_flags = None
+
+    def run(env):
+        nonlocal plan_flags
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        model, _ = build(pkg, oracle, NB, NC, seed=13)
+        tr = pkg.GATResTrainer(model, ei, NODES * bs, nodes_per_graph=[NODES] * bs, use_graph=False)
+        assert lib.gatres_fused_window_kernel(model._cmodel_ref(), tr.plan.ref()) == 1
+        plan_flags = tr.plan.flags
+        out = {}
+        tr.step(y, y, mask)
+        out["pred"], out["loss"], out["grads"] = tr.out.clone(), tr.loss.clone(), tr.grads.clone()
+        tr.step(y, y, mask)
+        out["params"] = model.flat_parameters.clone()
+        with torch.no_grad():
+            out["eval"] = model(y.reshape(-1, 1), ei).clone()                      # forward-only launch
+        model.zero_grad()
+        o = model(y.reshape(-1, 1), ei)                                            # the module's forward + backward launches
+        (o * o).mean().backward()
+        out["module_out"], out["module_grads"] = o.detach().clone(), model.flat_grad().clone()
+        for k in env:
+            monkeypatch.delenv(k)
+        return out
+
+    ref = run({"GATRES_WINDOW_RUNTIME_PHASES": "1"})
+    assert plan_flags & 1 and plan_flags & 4, "the synthetic WDN is symmetric with rows of at most six entries"
+    for m in ("65535", "4095", "2047", "1023", "511"):
+        got = run({"GATRES_WINDOW_PH_MASK": m})
+        for k, v in ref.items():
+            assert torch.equal(v, got[k]), (m, k)

@@ -743,3 +743,42 @@ def test_part_tables_equal_in_kernel_derivation(pkg, oracle, directed, monkeypat
         for u, v in zip(a, b):
             assert torch.isfinite(u).all() and torch.equal(u, v)
 
+
+
+def test_flat_parameter_mode_equals_per_tensor_adam(pkg, oracle):
+    """``torch.optim.Adam(model.optimizer_parameters())``: ONE leaf parameter over the flat vector instead of the 124 named
+    tensors (the optimizer line of train.py:348).  Adam is element-wise, so four steps of the reference loop body give the
+    SAME BITS as ``torch.optim.Adam(model.parameters())`` on a twin; ``zero_grad`` both ways, accumulation over two backwards,
+    ``model.zero_grad()``, and the named parameters' ``.grad`` views are covered; ``state_dict`` keeps the reference's keys."""
+    nb, nc, bs = 3, 32, 2
+    ei = pkg.wdn_synth.collate_edge_index(pkg.wdn_synth.make_wdn_topology(), 388, bs).cuda()
+    snaps = pkg.wdn_synth.make_snapshots(8, 388, seed=31)
+    mf, _ = build(pkg, oracle, nb, nc, seed=71)
+    mt, _ = build(pkg, oracle, nb, nc, seed=71)
+    keys = list(mf.state_dict().keys())
+    of = torch.optim.Adam(mf.optimizer_parameters(), lr=5e-4, weight_decay=6e-6)
+    ot = torch.optim.Adam(mt.parameters(), lr=5e-4, weight_decay=6e-6)
+    assert len(of.param_groups[0]["params"]) == 1 and list(mf.state_dict().keys()) == keys
+    assert len(list(mf.parameters())) == len(list(mt.parameters()))
+    rng = np.random.RandomState(5)
+    for it in range(4):
+        y = pkg.wdn_synth.collate_snapshots(snaps, range(it * bs, (it + 1) * bs)).cuda()
+        m = torch.from_numpy(pkg.wdn_synth.generate_batch_mask([388] * bs, 0.95, rng)).cuda()
+        x = y.clone(); x[m] = 0
+        for model, opt in ((mf, of), (mt, ot)):
+            if it == 2:
+                opt.zero_grad(set_to_none=False)
+            elif it == 3:
+                model.zero_grad()
+            else:
+                opt.zero_grad()
+            loss = torch.nn.functional.mse_loss(model(x, ei)[m], y[m])
+            loss.backward()
+            if it == 1:                                  # accumulate a second backward on top
+                torch.nn.functional.mse_loss(model(x, ei)[m], y[m]).backward()
+            opt.step()
+        gt = torch.cat([p.grad.reshape(-1) for p in mt.parameters()])
+        assert torch.equal(mf.flat_parameter.grad, gt), it
+        assert torch.equal(torch.cat([p.grad.reshape(-1) for p in mf.parameters()]), gt), it
+        assert torch.equal(mf.flat_parameters, mt.flat_parameters), it
+    assert torch.equal(mf.state_dict()["lin1.weight"], mt.state_dict()["lin1.weight"])

@@ -223,11 +223,20 @@ def test_graph_flags_symmetric(pkg, lib):
         assert lib.gatres_graph_flags_host(ei.data_ptr(), ei.shape[1], 60, C.byref(f)) == 0
         return f.value
 
-    SYM, LE32 = 1, 2          # GATRES_GRAPH_SYMMETRIC, GATRES_GRAPH_DEG_LE32 (every water network has low degrees)
-    assert flags(t) == SYM | LE32
-    assert flags(torch.cat([t, t[:, :5], torch.tensor([[3, 7], [3, 7]])], dim=1)) == SYM | LE32       # duplicates + self loops
-    assert flags(t[:, 1:]) == LE32                                                         # one direction missing
-    assert flags(t[:, t[0] < t[1]]) == LE32
+    SYM, LE32, LE6 = 1, 2, 4  # GATRES_GRAPH_SYMMETRIC, GATRES_GRAPH_DEG_LE32 (every water network has low degrees), _DEG_LE6
+    both = SYM | LE32
+    assert flags(t) & both == both
+    assert flags(torch.cat([t, t[:, :5], torch.tensor([[3, 7], [3, 7]])], dim=1)) & both == both      # duplicates + self loops
+    assert flags(t[:, 1:]) & both == LE32                                                  # one direction missing
+    assert flags(t[:, t[0] < t[1]]) & both == LE32
+    # GATRES_GRAPH_DEG_LE6: no node with more than 5 edges into or out of it -- every row of every CSR of the plan has at most 6
+    # entries (GATConv's self loop included), the slot width of the per-snapshot kernels (k_window.hip: the instantiation without
+    # edge-at-a-time paths).  Counted on edge_index as it is (self loops and duplicates count: never optimistic).
+    deg = max(int(torch.bincount(t[0], minlength=60).max()), int(torch.bincount(t[1], minlength=60).max()))
+    assert deg <= 5 and flags(t) & LE6 == LE6
+    star = lambda k: torch.stack([torch.arange(1, k + 1), torch.zeros(k, dtype=torch.long)])   # k edges INTO node 0
+    assert flags(star(5)) & LE6 == LE6 and flags(star(6)) & LE6 == 0 and flags(star(6).flip(0)) & LE6 == 0
+    assert flags(torch.cat([star(5), torch.tensor([[0], [0]])], dim=1)) & LE6 == 0            # (a self loop counts)
     # GATRES_GRAPH_DEG_LE32: no node with more than 31 edges into or out of it (a row of 32 with GATConv's self loop)
     hub = torch.stack([torch.arange(1, 33), torch.zeros(32, dtype=torch.long)])                # 32 edges INTO node 0
     assert flags(torch.cat([t, hub], dim=1)) & LE32 == 0
