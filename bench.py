@@ -230,12 +230,12 @@ def survey_bytes_per_snapshot(nb, nc, n_g, e_g, s):
 SURVEY_STATED_BYTES = {("gatres_small", 388, 860, "fp32"): 50.6e6, ("gatres_large", 388, 860, "bf16"): 163e6}
 
 
-PMC_FILE = "r05_fused_pmc_raw.json"      # written by tests/micro/profile_r05.sh from the round's own counter passes
+PMC_FILE = "r06_fused_pmc_raw.json"      # written by tests/micro/profile_r06.sh from the round's own counter passes
 
 
 def pmc_traffic(args, us_main, us_second):
     """HBM-side bytes per step of the two heavy launches from the committed rocprofv3 --pmc passes of THIS round
-    (profiles/r05_fused_pmc_raw.json: FETCH_SIZE and WRITE_SIZE collected in separate runs of this script, KB per launch;
+    (profiles/r06_fused_pmc_raw.json: FETCH_SIZE and WRITE_SIZE collected in separate runs of this script, KB per launch;
     FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for wide coalesced reads on gfx950), plus the wait counters of the
     dominant kernel.  Only for the workload they were taken on, and only while the kernels still are the kernels that were
     counted: the file records each kernel's average duration in the profiled run, and a file whose figures differ from
@@ -260,7 +260,7 @@ def pmc_traffic(args, us_main, us_second):
         if abs(live - was) > tol * was:
             return None, (f"profiles/{PMC_FILE} REFUSED: its {what} averaged {was:.1f} us in the profiled run, this run "
                           f"measures {live:.1f} us (> {int(tol * 100)} % apart): the counters describe other kernels; rerun "
-                          f"tests/micro/profile_r05.sh"), None, None
+                          f"tests/micro/profile_r06.sh"), None, None
     val = int((2.0 * raw["FETCH_SIZE"]["mean_counter_value_KB"] + raw["WRITE_SIZE"]["mean_counter_value_KB"]) * 1024)
     sk = raw.get("second_kernel")
     val_second = None
@@ -334,12 +334,12 @@ def time_kernels(rows, device, reps=200):
     return out
 
 
-PEROP_PMC_FILES = {("gatres_large", 128, 388, "bf16"): "r05_large_ctown_bs128_bf16_pmc.json"}
+PEROP_PMC_FILES = {("gatres_large", 128, 388, "bf16"): "r06_large_ctown_bs128_bf16_pmc.json"}
 
 
 def hbm_side_rates(args):
     """Counter-based HBM-side traffic of the per-op kernels ((2 x FETCH_SIZE + WRITE_SIZE) x 1024 bytes per launch, separate
-    rocprofv3 --pmc passes of this command, tests/micro/profile_r05.sh) over their rocprof average durations: what HBM (or
+    rocprofv3 --pmc passes of this command, tests/micro/profile_r06.sh) over their rocprof average durations: what HBM (or
     the Infinity Cache in front of it) physically moved, per kernel symbol -- beside the L2-side `gbs` of the kernel table."""
     name = PEROP_PMC_FILES.get((args.model, args.batch_size, args.nodes, args.dtype))
     if name is None:

@@ -107,8 +107,18 @@ __device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<floa
 __device__ __forceinline__ float4 f4zero() { return make_float4(0.f, 0.f, 0.f, 0.f); }
 // acc += a * v with ONE rounding per element (fma); used by every neighbour accumulation, fused and per-op alike,
 // so both paths produce bit-identical sums.
+// Written on two-element vectors so that hipcc emits v_pk_fma_f32 (two IEEE fmas per instruction at the issue rate of one: the
+// sparse stages are VALU-issue-bound); element for element the same fmaf as before -- the same bits.
+typedef float gatres_f2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void gatres_axpy4(float4& acc, float a, const float4 v) {
+#ifdef GATRES_NO_PK_FMA
   acc.x = fmaf(a, v.x, acc.x); acc.y = fmaf(a, v.y, acc.y); acc.z = fmaf(a, v.z, acc.z); acc.w = fmaf(a, v.w, acc.w);
+#else
+  const gatres_f2 aa = {a, a};
+  const gatres_f2 lo = __builtin_elementwise_fma(aa, (gatres_f2){v.x, v.y}, (gatres_f2){acc.x, acc.y});
+  const gatres_f2 hi = __builtin_elementwise_fma(aa, (gatres_f2){v.z, v.w}, (gatres_f2){acc.z, acc.w});
+  acc.x = lo.x; acc.y = lo.y; acc.z = hi.x; acc.w = hi.y;
+#endif
 }
 
 // Sum of `d` over the LH adjacent lanes that own one attention head of a row (LH = C/4, a power of two).

@@ -546,15 +546,25 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
     if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(drop_count, 1u);
     return;
   }
+  // No tickets where the step count was snapshotted for this launch (mask_next != null: the data-parallel step's Adam phase
+  // behind a parameter-gradient launch that left mask_snap, exactly the condition under which the sampling blocks above use
+  // it): every block reads the SNAPSHOT and block 0 alone stores the new count -- up to 258 read-modify-writes on one address
+  // serialise in the L2 at ~20 ns each, 4 of this launch's 7.5 us (reduce_adam_kernel lost its tickets the same way).
+  const bool snap = mask_next != nullptr;
   if (threadIdx.x == 0) {
-    const unsigned long long t = __hip_atomic_load(step_counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1ULL;
+    const unsigned long long t = (snap ? mask_snap[0]
+                                       : __hip_atomic_load(step_counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) + 1ULL;
     const double bc1 = 1.0 - gatres_powi(b1, t), bc2 = 1.0 - gatres_powi(b2, t);
     s_step_size = (float)(lr / bc1);
     s_bc2_sqrt = (float)sqrt(bc2);
-    // the step is counted once every block has READ the counter: the ticket follows this block's read (no fence: nothing
-    // orders the count behind the parameter stores but the next launch -- see reduce_adam_kernel, k_fused.hip)
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    done = atomicAdd(&step_counter[1], 1ULL);           // (its result is only looked at after this block's elements)
+    if (snap) {
+      if (blockIdx.x == 0) step_counter[0] = t;         // (nobody reads the counter in this launch: the blocks read the snapshot)
+    } else {
+      // the step is counted once every block has READ the counter: the ticket follows this block's read (no fence: nothing
+      // orders the count behind the parameter stores but the next launch -- see reduce_adam_kernel, k_fused.hip)
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      done = atomicAdd(&step_counter[1], 1ULL);         // (its result is only looked at after this block's elements)
+    }
   }
   __syncthreads();
   // Grid-stride: the launch has at most ADAM_MAX_BLOCKS blocks.  One block per 256 parameters meant 6.6 k tickets on ONE
@@ -587,7 +597,7 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
     }
   }
   }
-  if (threadIdx.x == 0 && done == (unsigned long long)update_blocks - 1ULL) {
+  if (!snap && threadIdx.x == 0 && done == (unsigned long long)update_blocks - 1ULL) {
     step_counter[1] = 0ULL;
     atomicAdd(&step_counter[0], 1ULL);
   }

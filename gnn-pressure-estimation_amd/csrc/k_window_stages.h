@@ -1084,8 +1084,7 @@ __device__ __forceinline__ void win_bwd_dst(Rows rw, const u16* nb, const u16* r
         for (int k = 0; k < MAXD; ++k) {
           const float w1 = k < od.deg ? 1.f : 0.f;                      // x + 0 * q == x exactly
           if constexpr (PRE) {                                          // g_pre holds g / max(indeg, 1): win_proj's cnt_rp
-            acc.x = fmaf(w1, v[k][0], acc.x); acc.y = fmaf(w1, v[k][1], acc.y);
-            acc.z = fmaf(w1, v[k][2], acc.z); acc.w = fmaf(w1, v[k][3], acc.w);
+            gatres_axpy4(acc, w1, as_f4(v[k]));
           } else {
             const float cnt = (float)od.x[k];
             acc.x = fmaf(w1, v[k][0] / cnt, acc.x); acc.y = fmaf(w1, v[k][1] / cnt, acc.y);
