@@ -1191,6 +1191,7 @@ extern "C" __attribute__((visibility("hidden"))) int gatres_fused_launch_window(
       if (!gatres_knobs()->window_runtime_phases) {
         switch (key) {
           case 0x1f16: hipLaunchKernelGGL((gatres_window_kernel<32, 1024, 0x1f16>), dim3(grid), dim3(1024), 0, st, a); return gatres_launch_status();
+          case 0x1b16: hipLaunchKernelGGL((gatres_window_kernel<32, 1024, 0x1b16>), dim3(grid), dim3(1024), 0, st, a); return gatres_launch_status();      // (a plan with hub rows)
           case 0x0f16: hipLaunchKernelGGL((gatres_window_kernel<32, 1024, 0x0f16>), dim3(grid), dim3(1024), 0, st, a); return gatres_launch_status();
           case 0x0716: hipLaunchKernelGGL((gatres_window_kernel<32, 1024, 0x0716>), dim3(grid), dim3(1024), 0, st, a); return gatres_launch_status();
           case 0x0316: hipLaunchKernelGGL((gatres_window_kernel<32, 1024, 0x0316>), dim3(grid), dim3(1024), 0, st, a); return gatres_launch_status();

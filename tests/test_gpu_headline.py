@@ -458,7 +458,12 @@ def test_window_kernel_instantiations_are_bit_identical(pkg, oracle, lib, monkey
 
     ref = run({"GATRES_WINDOW_RUNTIME_PHASES": "1"})
     assert plan_flags & 1 and plan_flags & 4, "the synthetic WDN is symmetric with rows of at most six entries"
-    for m in ("65535", "4095", "2047", "1023", "511"):
+    for m in ("65535", "7167", "4095", "2047", "1023", "511"):       # (7167 = 0x1bff: everything but "rows of at most six entries")
         got = run({"GATRES_WINDOW_PH_MASK": m})
         for k, v in ref.items():
             assert torch.equal(v, got[k]), (m, k)
+    # the training launch without keep-in-LDS (GATRES_FUSED_NO_KEEP: ReLU sign masks and own-row g_pre come back from HBM in the
+    # backward phase, dX through the operand-in-memory form): the same arithmetic, the same bits
+    got = run({"GATRES_FUSED_NO_KEEP": "1"})
+    for k, v in ref.items():
+        assert torch.equal(v, got[k]), ("no-keep", k)
