@@ -23,13 +23,30 @@ from .graph_plan import GraphPlan, PlanCache
 # ----------------------------------------------------------------------------------------------
 # parameter containers with PyG's names / shapes / initialisers
 # ----------------------------------------------------------------------------------------------
+# Every (re-)registration of a parameter on one of this file's modules bumps this counter (``module.weight = nn.Parameter(..)``,
+# ``load_state_dict(assign=True)``): ``GATResMeanConv._flat_is_current`` then compares one integer instead of walking 124
+# ``_parameters`` dicts per forward call (the reference's evaluation times every call: utils/timer.py:22-41).
+_PARAM_EPOCH = [0]
+
+
+class _TrackedModule(nn.Module):
+    def register_parameter(self, name, param) -> None:
+        _PARAM_EPOCH[0] += 1
+        super().register_parameter(name, param)
+
+    def __delattr__(self, name) -> None:
+        if name in self.__dict__.get("_parameters", ()):
+            _PARAM_EPOCH[0] += 1
+        super().__delattr__(name)
+
+
 def _glorot_(t: Tensor) -> None:
     stdv = math.sqrt(6.0 / (t.size(-2) + t.size(-1)))
     with torch.no_grad():
         t.uniform_(-stdv, stdv)
 
 
-class Linear(nn.Module):
+class Linear(_TrackedModule):
     """Parameter holder for ``torch_geometric.nn.dense.linear.Linear`` (GraphModels.py:11,477,484)."""
 
     def __init__(self, in_channels: int, out_channels: int, bias: bool = True, weight_initializer: Optional[str] = None):
@@ -56,7 +73,7 @@ class Linear(nn.Module):
         return f"{self.in_channels}, {self.out_channels}, bias={self.bias is not None}"
 
 
-class GATConv(nn.Module):
+class GATConv(_TrackedModule):
     """Parameter holder for ``torch_geometric.nn.GATConv(in, out, heads, concat)`` as the reference builds it
     (GraphModels.py:458-459: edge_dim=None, add_self_loops=True, negative_slope=0.2, dropout=0, bias=True).
     ``lin_dst`` aliases ``lin_src`` exactly as PyG 2.3 does, so both keys appear in the state_dict."""
@@ -165,7 +182,7 @@ class _GATResFunction(torch.autograd.Function):
 # ----------------------------------------------------------------------------------------------
 # the model
 # ----------------------------------------------------------------------------------------------
-class GATResMeanConv(nn.Module):
+class GATResMeanConv(_TrackedModule):
     """GraphModels.py:471-494.  ``gatres_small`` = (num_blocks=15, nc=32), ``gatres_large`` = (25, 128)
     (ConfigModels.py:22-42)."""
 
@@ -247,6 +264,8 @@ class GATResMeanConv(nn.Module):
             raise RuntimeError("parameter traversal order changed")
         self._param_table = table
         self._param_list = params
+        self._param_ptrs = [4 * 0 + flat.data_ptr() + t[3] for t in table]       # (where every parameter must point)
+        self._param_epoch = _PARAM_EPOCH[0]
         self._grad_bufs = None          # (two flat gradient buffers and the parameters' views of them: _grad_target)
         self._grad_views = None
         self._grad_cur = None
@@ -380,12 +399,15 @@ class GATResMeanConv(nn.Module):
         table = getattr(self, "_param_table", None)
         if flat is None or table is None:
             return False
-        base = flat.data_ptr()
-        for owner, name, q, off in table:
-            # the registered object is still the one we flattened, and it still points into the flat buffer
-            if owner.get(name) is not q or q.data_ptr() != base + off:
-                return False
-        return True
+        if self._param_epoch != _PARAM_EPOCH[0]:
+            # some parameter of some module of this file was (re-)registered since: walk the tables once; if these modules'
+            # registrations are untouched, adopt the new epoch
+            for owner, name, q, off in table:
+                if owner.get(name) is not q:
+                    return False
+            self._param_epoch = _PARAM_EPOCH[0]
+        # every parameter still points into the flat buffer (``p.data = ...`` cannot be intercepted: compare the addresses)
+        return [q.data_ptr() for q in self._param_list] == self._param_ptrs
 
     def _apply(self, fn, *args, **kwargs):
         out = super()._apply(fn, *args, **kwargs)
