@@ -2210,12 +2210,12 @@ __device__ __forceinline__ void w_prefetch(float* wl, const float* __restrict__ 
 // (hl: gatres_graph_t.halo -- the forward phase keeps two u16 lists of up to hl entries, the backward phase four)
 __host__ __device__ inline long long win_fwd_bytes(int nc, int wr, int ow, int ge, int gm, int hl) {
   const long long wlf = 2LL * nc * (2 * nc + 4) + 4 * nc;
-  return 4LL * (wr * (3LL * nc + 2) + ow * (3LL * nc + 2)) + 2 * (4 * wlf + 16) + 2LL * (2 * even(ow + 2) + even(ge) + even(gm)) +
+  return 4LL * (wr * (3LL * nc + 2) + ow * (3LL * nc + 2 + 8)) + 2 * (4 * wlf + 16) + 2LL * (2 * even(ow + 2) + even(ge) + even(gm)) +
          64 + 4LL * (hl + 4) + 32LL * ow + 16 + ow + 16;      // (+ the padded edge descriptors of k_window_stages.h: 2 x 16 B per own row, + export flags)
 }
 __host__ __device__ inline long long win_bwd_bytes(int nc, int threads, int wr, int ow, int ge, int gm, int hl) {
   const long long wlf = 2LL * nc * (2 * nc + 4) + 4 * nc;
-  return 12LL * threads + 4LL * (wr * (4LL * nc + 2) + ow * (2LL * nc + 4) + 4LL * even(ge)) + 2 * (4 * wlf + 16) +
+  return 12LL * threads + 4LL * (wr * (4LL * nc + 2) + ow * (2LL * nc + 4 + 4) + 4LL * even(ge)) + 2 * (4 * wlf + 16) +
          2LL * (3 * even(ow + 2) + 3 * even(ge) + even(wr + 2) + even(gm)) + 64 + 8LL * (hl + 4) + 80LL * ow + 16 + ow + 16;   // (16 + 32 + 32 B of descriptors per own row, + export flags)
 }
 

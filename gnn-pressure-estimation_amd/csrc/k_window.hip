@@ -125,6 +125,16 @@ __global__ __launch_bounds__(THREADS) void gatres_window_kernel(const FusedArgs 
   constexpr bool NOHUB = PH >= 0 && (PH & 0x400) != 0;
   constexpr bool PTAB = PH >= 0 && (PH & 0x800) != 0;
   constexpr bool OW64 = PH >= 0 && (PH & 0x1000) != 0;
+  // Row padding of the MFMA stages' x operand tables (xA / xB forward, xG backward): 16 rows K floats apart share their banks,
+  // K + 4 apart they do not (the x fragment reads of win_proj were 8- / 16-way conflicted).  Only where every writer and reader
+  // of the table is a win_* stage of this instantiation: forward with the fallbacks compiled out (NOHUB), backward with
+  // keep-in-LDS as a compile-time fact (its other form runs dX through seg_proj).
+#ifdef GATRES_NO_XPAD          // (A/B builds: tests/micro/mk_probe.sh)
+  constexpr int XPF = 0, XPB = 0;
+#else
+  constexpr int XPF = (NC == 32 && NOHUB) ? 4 : 0;
+  constexpr int XPB = (NC == 32 && PH >= 0 && (PH & 0x100) != 0) ? 4 : 0;
+#endif
   __shared__ __attribute__((aligned(16))) unsigned char lds_raw[LDS_BYTES];
   float* ldsf = reinterpret_cast<float*>(lds_raw);
   const Layout& L = a.L;
@@ -270,8 +280,8 @@ __global__ __launch_bounds__(THREADS) void gatres_window_kernel(const FusedArgs 
     float* saw = hBw + (size_t)wr * NC;
     float* sdo = saw + (size_t)((wr * 2 + 3) & ~3);      // (every table starts 16-byte aligned: ds_read_b128)
     float* xAo = sdo + (size_t)((ow * 2 + 3) & ~3);
-    float* xBo = xAo + (size_t)ow * NC;
-    float* wlA = reinterpret_cast<float*>(lds_raw + ((reinterpret_cast<unsigned char*>(xBo + (size_t)ow * 2 * NC) - lds_raw + 15) & ~15));
+    float* xBo = xAo + (size_t)ow * (NC + XPF);
+    float* wlA = reinterpret_cast<float*>(lds_raw + ((reinterpret_cast<unsigned char*>(xBo + (size_t)ow * (2 * NC + XPF)) - lds_raw + 15) & ~15));
     float* wlB = wlA + WLB;
     u16* tp = reinterpret_cast<u16*>(wlB + WLB);
     u16* rpo = tp;             tp += even(ow + 1);
@@ -296,8 +306,8 @@ __global__ __launch_bounds__(THREADS) void gatres_window_kernel(const FusedArgs 
     float* hB = hBw - wlo * NC;
     float* sa2 = saw - wlo * 2;  float* sa1 = saw - wlo;                 // a_src tables (H = 2 / H = 1)
     float* sd2 = sdo - lo * 2;   float* sd1 = sdo - lo;
-    float* xA = xAo - lo * NC;
-    float* xB = xBo - lo * 2 * NC;
+    float* xA = xAo - lo * (NC + XPF);
+    float* xB = xBo - lo * (2 * NC + XPF);
     const u16* rp = rpo - lo;  const u16* mrp = mrpo - lo;
     int hcnt = 0, ecnt = 0;
     if (PTAB || pt) {
@@ -336,7 +346,7 @@ __global__ __launch_bounds__(THREADS) void gatres_window_kernel(const FusedArgs 
         float4 o;
         o.x = xv * wv.x + bv.x; o.y = xv * wv.y + bv.y; o.z = xv * wv.z + bv.z; o.w = xv * wv.w + bv.w;
         st4(xcur + (unsigned)(r * NC + c0), o);
-        st4(xA + (unsigned)(r * NC + c0), o);
+        st4(xA + (unsigned)(r * (NC + XPF) + c0), o);
       }
     }
     dma_land(0);
@@ -402,7 +412,7 @@ __global__ __launch_bounds__(THREADS) void gatres_window_kernel(const FusedArgs 
         }
         if constexpr (NC == 32) {
           if (wave_u < PW) {                         // the tile waves
-            win_proj<NC, 2 * NC, 2, EPI_ATT, 2, PW, THREADS>(rw, xA, wlA, base + SL.h1, 0, hA, base + SL.as1, base + SL.ad1, sa2,
+            win_proj<NC, 2 * NC, 2, EPI_ATT, 2, PW, THREADS, NC + XPF>(rw, xA, wlA, base + SL.h1, 0, hA, base + SL.as1, base + SL.ad1, sa2,
                                                          sd2, nullptr, nullptr, nullptr, nullptr, xout(xreg, fflag, XL.f1h, XL.f1a));
           }
         } else
@@ -440,7 +450,7 @@ __global__ __launch_bounds__(THREADS) void gatres_window_kernel(const FusedArgs 
         // K2 conv1: alpha -> HBM, the gather's o1 -> HBM + the x buffer of proj2
         if (NOHUB || __builtin_expect(2 * oeg <= wr * NC, 1)) {
           if constexpr (NC == 32) {
-            win_fwd_agg<true, 2, NC, THREADS, NOHUB>(rw, nbin, rp, colo, hA, sa2, sd2, base + SL.al1, elo, hBw, wlA + B1OFF,
+            win_fwd_agg<true, 2, NC, THREADS, NOHUB, 2 * NC + XPF>(rw, nbin, rp, colo, hA, sa2, sd2, base + SL.al1, elo, hBw, wlA + B1OFF,
                                               base + SL.o1, 0, xB, mo1 ? mo1 + b * ow : nullptr, xout(false, fflag, 0, 0));
           } else {
             win_softmax<2, THREADS>(rw, nbin, rp, colo, sa2, sd2, base + SL.al1, elo, hBw);
@@ -474,7 +484,7 @@ __global__ __launch_bounds__(THREADS) void gatres_window_kernel(const FusedArgs 
         }
         if constexpr (NC == 32) {
           if (wave_u < PW) {
-            win_proj<2 * NC, NC, 1, EPI_ATT, 2, PW, THREADS>(rw, xB, wlB, base + SL.h2, 0, hB, base + SL.as2, base + SL.ad2, sa1,
+            win_proj<2 * NC, NC, 1, EPI_ATT, 2, PW, THREADS, 2 * NC + XPF>(rw, xB, wlB, base + SL.h2, 0, hB, base + SL.as2, base + SL.ad2, sa1,
                                                          sd1, nullptr, nullptr, nullptr, nullptr, xout(xreg, fflag, XL.f2h, XL.f2a));
           }
         } else
@@ -550,7 +560,7 @@ __global__ __launch_bounds__(THREADS) void gatres_window_kernel(const FusedArgs 
 #undef LIST_
         // K3: residual from the x buffer, result back into it (and to HBM: saved xin of the next block)
         float* xnext = segbase + (int64_t)(launder_s(b) + 1) * SL.bstride + SL.xin;
-        win_mean_fwd<NC, THREADS, NOHUB>(rw, mbin, mrp, mcolo, y2T, xA, xnext, xA,
+        win_mean_fwd<NC, THREADS, NOHUB, NC + XPF>(rw, mbin, mrp, mcolo, y2T, xA, xnext, xA,
                                        (mxin && b + 1 < nb) ? mxin + (b + 1) * ow : nullptr);
         lds_barrier();
         STAMP();
@@ -588,7 +598,7 @@ __global__ __launch_bounds__(THREADS) void gatres_window_kernel(const FusedArgs 
         float yv = 0.f;
         bool mk = false;
         if (fuse_loss && valid && (tid % G) == 0) { yv = a.y[node]; mk = a.mask[node] != 0; }
-        const float4 xv = ld4(xA + (unsigned)(r * NC + (tid % G) * 4));
+        const float4 xv = ld4(xA + (unsigned)(r * (NC + XPF) + (tid % G) * 4));
         float d = xv.x * wv.x;
         d = fmaf(xv.y, wv.y, d); d = fmaf(xv.z, wv.z, d); d = fmaf(xv.w, wv.w, d);
         for (int off = G >> 1; off > 0; off >>= 1) d += __shfl_xor(d, off);
@@ -604,7 +614,7 @@ __global__ __launch_bounds__(THREADS) void gatres_window_kernel(const FusedArgs 
 #pragma unroll
           for (int k = 0; k < 2; ++k) {
             const int r = rw.lo + rg + k * LB_R;
-            if (r < rw.hi) xk[k] = xA[(unsigned)(r * NC + c)];
+            if (r < rw.hi) xk[k] = xA[(unsigned)(r * (NC + XPF) + c)];
           }
         }
         const float Mn = block_sum<THREADS>(cnt, ldsf);            // (its barriers also publish dml)
@@ -674,7 +684,7 @@ __global__ __launch_bounds__(THREADS) void gatres_window_kernel(const FusedArgs 
     float* adTo = asTw + (size_t)((wr * 2 + 3) & ~3);
     float* alTw = adTo + (size_t)((ow * 2 + 3) & ~3);
     float* xGo = alTw + 2 * (size_t)even(weg);
-    float* gko = xGo + (size_t)ow * 2 * NC;                              // keep_: g_pre of the own rows (dX1's residual term)
+    float* gko = xGo + (size_t)ow * (2 * NC + XPB);                              // keep_: g_pre of the own rows (dX1's residual term)
     float* wlA = reinterpret_cast<float*>(lds_raw + ((reinterpret_cast<unsigned char*>(gko + (keep_ ? (size_t)ow * NC : 0)) - lds_raw + 15) & ~15));
     float* wlB = wlA + WLB;
     u16* tp = reinterpret_cast<u16*>(wlB + WLB);
@@ -735,7 +745,7 @@ __global__ __launch_bounds__(THREADS) void gatres_window_kernel(const FusedArgs 
     float* asT2 = asTw - wlo;     float* asT1 = asTw - wlo * 2;
     float* adT2 = adTo - lo;      float* adT1 = adTo - lo * 2;
     float* alT2 = alTw - ewlo;    float* alT1 = alTw - ewlo * 2;
-    float* xG2 = xGo - lo * NC;   float* xG1 = xGo - lo * 2 * NC;
+    float* xG2 = xGo - lo * (NC + XPB);   float* xG1 = xGo - lo * (2 * NC + XPB);
     float* gkeep = keep_ ? gko - lo * NC : nullptr;
 
     const float* xfinal = segbase + (int64_t)L.nb * SL.bstride + SL.xin;
@@ -990,7 +1000,7 @@ __global__ __launch_bounds__(THREADS) void gatres_window_kernel(const FusedArgs 
         if (!lean) seg_bias_finish<NC, THREADS>(red, sb + L.c2_b);
         if (lean && wave_u >= 8) seg_bias_part_by<NC, THREADS, 512, THREADS - 512>(rw, gy2T, 0, red);
         else
-        win_agg_bwd_src<1, NC, THREADS, NOHUB>(rw, tout, trp, teido, tdsto, 0, gy2T, alT2, ge2, gad2, wlA + A2OFF, wlA + A2OFF + NC,
+        win_agg_bwd_src<1, NC, THREADS, NOHUB, NC + XPB>(rw, tout, trp, teido, tdsto, 0, gy2T, alT2, ge2, gad2, wlA + A2OFF, wlA + A2OFF + NC,
                                              keep + L.k_gh2, n0, keep + L.k_gas2, keep + L.k_gad2, xG2);
         lds_barrier();                   // g_y2 (RA) and the conv2 tables are dead
         if (lean) seg_bias_finish_by<NC, THREADS, THREADS - 64>(red, sb + L.c2_b);      // (the last wave: `red` rests until dst1)
@@ -1009,7 +1019,7 @@ __global__ __launch_bounds__(THREADS) void gatres_window_kernel(const FusedArgs 
             REC_PINS(LIST_);
             REC_DEFS(LIST_);
 #undef LIST_
-            win_proj<NC, 2 * NC, 1, EPI_RESID_MASK, 1, PW, THREADS>(rw, xG2, wlA, RA, 0, nullptr, nullptr, nullptr, nullptr,
+            win_proj<NC, 2 * NC, 1, EPI_RESID_MASK, 1, PW, THREADS, NC + XPB>(rw, xG2, wlA, RA, 0, nullptr, nullptr, nullptr, nullptr,
                                                                 nullptr, nullptr, nullptr, mo1 + launder_s(b) * ow, nullptr,
                                                                 xout(xrows, bflag, (unsigned)XL.b3o, 0u));
           }
@@ -1078,7 +1088,7 @@ __global__ __launch_bounds__(THREADS) void gatres_window_kernel(const FusedArgs 
         REC_DEFS(LIST_);
 #undef LIST_
         seg_bias_finish<2 * NC, THREADS>(red, sb + L.c1_b);
-        win_agg_bwd_src<2, NC, THREADS, NOHUB>(rw, tout, trp, teido, tdsto, 0, RA, alT1, ge1, gad1, wlB + A1OFF, wlB + A1OFF + 2 * NC,
+        win_agg_bwd_src<2, NC, THREADS, NOHUB, 2 * NC + XPB>(rw, tout, trp, teido, tdsto, 0, RA, alT1, ge1, gad1, wlB + A1OFF, wlB + A1OFF + 2 * NC,
                                              keep + L.k_gh1, n0, keep + L.k_gas1, keep + L.k_gad1, xG1);
         lds_barrier();
         XSTAMP();
@@ -1097,7 +1107,7 @@ __global__ __launch_bounds__(THREADS) void gatres_window_kernel(const FusedArgs 
             REC_DEFS(LIST_);
 #undef LIST_
             const int bl = launder_s(b);
-            win_proj<2 * NC, NC, 1, EPI_RESID_MASK, 1, PW, THREADS>(rw, xG1, wlB, gp_nxt, n0, gpT, nullptr, nullptr, nullptr,
+            win_proj<2 * NC, NC, 1, EPI_RESID_MASK, 1, PW, THREADS, 2 * NC + XPB>(rw, xG1, wlB, gp_nxt, n0, gpT, nullptr, nullptr, nullptr,
                                                                 nullptr, gkeep, gkeep, nullptr, bl > 0 ? mxin + bl * ow : nullptr,
                                                                 xout(xrows && bl > 0, bflag, (unsigned)XL.b1, 0u), mrp);
           }

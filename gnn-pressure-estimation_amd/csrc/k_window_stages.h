@@ -383,10 +383,12 @@ __device__ __forceinline__ void xout_store1(const XOut& x, unsigned granule, con
 //   X: [row][K] own rows (LDS, shifted view); wl: W slot [M][K + 4] (+ att_src[M] | att_dst[M] for EPI_ATT);
 //   OUT (global, row ob + r) / OUT2 (LDS, shifted view) / OUT3 (LDS [row][M], shifted view); resid_l: LDS [row][M];
 //   m64 / m32: relu_bits words per row (fields 16 / 8 bits apart).
+//   XS: row stride of X in floats (K + 4 where the table is padded: 16 rows K floats apart share their banks -- the x fragment
+//   reads were 8- / 16-way conflicted, profiles/r05_lds_conflicts.txt).
 //   MW: the units go round the first MW waves only -- the waves behind them issue the stage's LDS-DMA, and a wave that
 //   streams from HBM sits in its issue loop for up to a microsecond (every CU streams at the same moment; a work unit on
 //   such a wave would start that much later: measured, 4.0 -> 4.9 us for dX1 + the hand-off behind it).
-template <int K, int M, int H, int EPI, int NTG, int MW, int THREADS>
+template <int K, int M, int H, int EPI, int NTG, int MW, int THREADS, int XS = K>
 __device__ __forceinline__ void win_proj(Rows rw, const float* X, const float* wl, float* OUT, int ob, float* OUT2,
                                          float* as_g, float* ad_g, float* as_l, float* ad_l, const float* resid_l,
                                          float* OUT3, const unsigned long long* m64, const unsigned* m32, const XOut& xo,
@@ -420,7 +422,7 @@ __device__ __forceinline__ void win_proj(Rows rw, const float* X, const float* w
 #ifdef GATRES_PROBE_XPAD      // (timing probe, WRONG results: the x operand read as if its rows were K + 4 floats apart -- no bank conflicts)
     for (int s = 0; s < XR; ++s) ad[s] = a_x + (unsigned)((min(r, rw.hi - 1) - rw.lo) * (K + 4) + rw.lo * K + 4 * s) * 4u;
 #else
-    for (int s = 0; s < XR; ++s) ad[s] = a_x + (unsigned)(min(r, rw.hi - 1) * K + 4 * s) * 4u;
+    for (int s = 0; s < XR; ++s) ad[s] = a_x + (unsigned)(min(r, rw.hi - 1) * XS + 4 * s) * 4u;      // (XS: the x table's row stride)
 #endif
 #pragma unroll
     for (int tt = 0; tt < NTG; ++tt)
@@ -717,7 +719,7 @@ __device__ __forceinline__ void win_gather(Rows rw, const u16* nb, const u16* rp
 template <int K> __device__ __forceinline__ float group8_bcast(float v) {
   return __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(v), 0x18 | (K << 5)));      // lane (l & 0x18) | K
 }
-template <bool RELU, int H, int C, int THREADS, bool NH = false>
+template <bool RELU, int H, int C, int THREADS, bool NH = false, int OPS = H * C>
 __device__ __forceinline__ void win_fwd_agg(Rows rw, const u16* nb, const u16* rp, const u16* col, const float* hsrc,
                                             const float* asrc, const float* adst_t, float* __restrict__ alpha_g, int eb,
                                             float* alpha_l, const float* bias, float* out, int ob, float* out_pub,
@@ -815,7 +817,7 @@ __device__ __forceinline__ void win_fwd_agg(Rows rw, const u16* nb, const u16* r
     }
     if (valid) {
       st4(out + (unsigned)((ob + r) * HC + c0), acc);
-      if (out_pub) st4(out_pub + (unsigned)(r * HC + c0), acc);
+      if (out_pub) st4(out_pub + (unsigned)(r * OPS + c0), acc);      // (OPS: row stride of the x operand table it fills)
       if (xo.on && xo.flag[r] != 0) xout_store4(xo, xo.t_rows + (unsigned)(r * HC + c0), acc);
     }
     if constexpr (RELU && G <= 16) {
@@ -828,7 +830,7 @@ __device__ __forceinline__ void win_fwd_agg(Rows rw, const u16* nb, const u16* r
 }
 
 // K3 forward (seg_mean_fwd): out = relu(mean_{j->r} y[j] + x0[r]).
-template <int C, int THREADS, bool NH = false>
+template <int C, int THREADS, bool NH = false, int XS = C>
 __device__ __forceinline__ void win_mean_fwd(Rows rw, const u16* mb, const u16* mrp, const u16* mcol, const float* y,
                                              const float* x0, float* out, float* out2, unsigned* mask32) {
   const int tid = stage_tid();
@@ -841,7 +843,7 @@ __device__ __forceinline__ void win_mean_fwd(Rows rw, const u16* mb, const u16* 
     const bool valid = r < rw.hi;
     if (!valid) r = rw.hi - 1;
     uint4 w, xr;
-    lds_rd128x2(a_mb + (unsigned)(r - rw.lo) * 16u, a_x + (unsigned)(r * C) * 4u, w, xr);
+    lds_rd128x2(a_mb + (unsigned)(r - rw.lo) * 16u, a_x + (unsigned)(r * XS) * 4u, w, xr);      // (x0 / out2: the x table, row stride XS)
     const NbrIn d = unpack_in(w);
     const float4 rr = as_f4(xr);
     float4 acc = f4zero();
@@ -863,7 +865,7 @@ __device__ __forceinline__ void win_mean_fwd(Rows rw, const u16* mb, const u16* 
     o.z = fmaxf(acc.z / cnt + rr.z, 0.f); o.w = fmaxf(acc.w / cnt + rr.w, 0.f);
     if (valid) {
       st4(out + (unsigned)(r * C + c0), o);
-      st4(out2 + (unsigned)(r * C + c0), o);
+      st4(out2 + (unsigned)(r * XS + c0), o);
     }
     if constexpr (G <= 8) {
       if (mask32) {                                             // (workgroup-uniform)
@@ -1209,7 +1211,7 @@ __device__ __forceinline__ void win_bwd_dst(Rows rw, const u16* nb, const u16* r
 //   to: out-edge descriptors (x_k = window-relative edge id); g_out: [row][HC] over the window; alpha / g_e: LDS [e][H]
 //   over the WINDOW's edges; g_a_dst: [row][H] own rows; g_h: global (kept for the deferred parameter gradients, row
 //   hb + r); g_h2: LDS x operand of the dX stage.
-template <int H, int C, int THREADS, bool NH = false>
+template <int H, int C, int THREADS, bool NH = false, int G2S = H * C>
 __device__ __forceinline__ void win_agg_bwd_src(Rows rw, const u16* to, const u16* trp, const u16* teid, const u16* tdst,
                                                 int eid_sub, const float* g_out, const float* alpha, const float* g_e,
                                                 const float* g_a_dst, const float* att_src, const float* att_dst,
@@ -1298,7 +1300,7 @@ __device__ __forceinline__ void win_agg_bwd_src(Rows rw, const u16* to, const u1
     gatres_axpy4(acc, gad, ad);
     if (valid) {
       st4(g_h + (unsigned)((hb + r) * HC + c0), acc);
-      st4(g_h2 + (unsigned)(r * HC + c0), acc);
+      st4(g_h2 + (unsigned)(r * G2S + c0), acc);      // (g_h2: the dX stage's x table, row stride G2S)
     }
   }
 }
