@@ -112,5 +112,31 @@ def large_pmc(d):
     print(json.dumps({k: {n: v[n] for n in ("avg_us_kernel_trace", "hbm_side_gbs", "mfma_pipe_utilisation", "wait_any_ratio") if n in v} for k, v in out.items()}))
 
 
+def publish(d):
+    """HERE (after the gpurun call merged its files back): gpurun_out/r06_final/* -> profiles/r06_* under the names the documents
+    cite."""
+    import shutil
+    same = ["batch_scaling.txt", "bench_driver_protocol.json", "bench_n1.json", "collective_path_1rank.json",
+            "collective_path_1rank_eager.json", "collective_path_1rank_eager_2buckets.json", "collective_path_kernel_stats.csv",
+            "eager_kernel_stats.csv", "eager.json", "from_store.json", "fused_kernel_stats.csv", "fused_pmc.json",
+            "fused_pmc_raw.json", "host_batches.json", "large_50k_bs2_bf16.json", "launcher_2ranks_one_gpu.json",
+            "one_step_per_graph.json", "param_grads_pmc.json", "per_op.json", "shuffle_nodes.json", "small_50k_bs16.json",
+            "drop_in_breakdown.txt", "eval_large_bs128_bf16.json", "eval_small_bs32.json", "copy_batches.json"]
+    renamed = {"large_bf16.json": "large_ctown_bs128_bf16.json", "large_bf16_kernel_stats.csv": "large_ctown_bs128_bf16_kernel_stats.csv",
+               "large_bf16_pmc.json": "large_ctown_bs128_bf16_pmc.json", "large_fp32.json": "large_ctown_bs128_fp32.json",
+               "stage_times.txt": "window_stage_times.txt", "drop_in.json": "drop_in_torch_adam.json",
+               "drop_in--flat-adam.json": "drop_in_flat_adam.json", "drop_in--fused-adam.json": "drop_in_fused_adam.json",
+               "phase_ab.txt": "window_instantiations_ab.txt"}
+    for src, dst in [(f, f) for f in same] + list(renamed.items()):
+        a = os.path.join(d, src)
+        if os.path.exists(a) and os.path.getsize(a) > 0:
+            shutil.copyfile(a, os.path.join(ROOT, "profiles", "r06_" + dst))
+        else:
+            print("missing:", a)
+    pr = os.path.join(ROOT, "gpurun_out", "parity_report.json")
+    if os.path.exists(pr):
+        shutil.copyfile(pr, os.path.join(ROOT, "profiles", "r06_parity_report.json"))
+
+
 if __name__ == "__main__":
-    {"pmc_raw": pmc_raw, "large_pmc": large_pmc}[sys.argv[1]](sys.argv[2])
+    {"pmc_raw": pmc_raw, "large_pmc": large_pmc, "publish": publish}[sys.argv[1]](sys.argv[2])
