@@ -13,6 +13,8 @@ replayed from a hipGraph.  Inputs (several batches, rotated) are resident in HBM
 Protocol: W untimed warm-up steps, then `--repeats` (default 5) timed blocks of EXACTLY K steps,
 each bracketed by a barrier + torch.cuda.synchronize() on both sides and reduced with MAX over ranks; `value` and
 `ms_per_step` come from the MEDIAN block, min / max are reported beside it.  Rank 0 prints ONE JSON line.
+`roofline.traffic` is measured in the run: before touching the GPU the script runs itself twice as a child under
+`rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` (a few seconds each; `--no-live-pmc` skips them).
 Data: synthetic (seeded WDN topology with C-Town's size, N(0,1) pressures, PyG-style random-init weights); the
 reference's C-Town files are not shipped.
 """
@@ -85,6 +87,10 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-live-pmc", action="store_true",
+                    help="do not run the two rocprofv3 --pmc child passes (FETCH_SIZE, WRITE_SIZE) that measure roofline.traffic "
+                         "in this run; the committed counter file of the round is used instead (accepted only inside its "
+                         "duration band)")
     ap.add_argument("--repeats", type=int, default=5, help="timed blocks of --steps steps; the median block is reported")
     ap.add_argument("--shuffle-nodes", action="store_true",
                     help="randomly relabel the nodes of the synthetic topology (a junction order with no locality, as an "
@@ -233,6 +239,62 @@ SURVEY_STATED_BYTES = {("gatres_small", 388, 860, "fp32"): 50.6e6, ("gatres_larg
 PMC_FILE = "r06_fused_pmc_raw.json"      # written by tests/micro/profile_r06.sh from the round's own counter passes
 
 
+LIVE_PMC = {}          # filled by live_pmc() before this process touches the GPU
+
+
+def live_pmc(args):
+    """roofline.traffic MEASURED IN THIS RUN: two child passes of this very command under ``rocprofv3 --pmc FETCH_SIZE`` and
+    ``--pmc WRITE_SIZE`` (separate passes, the program directly behind ``--``, as MI355X_MICROARCH.md prescribes), started
+    BEFORE this process initialises the GPU (a process that has must not start GPU children on this pool), each bounded by a
+    timeout.  Returns {kernel substring: {counter: mean KB per launch}} or a reason string."""
+    import csv
+    import glob
+    import shutil
+    import tempfile
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return "rocprofv3 not found"
+    kernels = ("gatres_window_kernel", "param_grads_reg_kernel")
+    out = {k: {} for k in kernels}
+    base = ["--steps", "20", "--warmup", "5", "--repeats", "1", "--no-cpu-baseline", "--no-roofline", "--model", args.model,
+            "--batch-size", str(args.batch_size), "--nodes", str(args.nodes), "--pipes", str(args.pipes),
+            "--graph-steps", str(args.graph_steps)]
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = tempfile.mkdtemp(prefix="gatres_pmc_", dir="/tmp")
+        try:
+            cmd = [exe, "--pmc", counter, "--output-format", "csv", "-d", d, "-o", "p", "--", sys.executable,
+                   os.path.abspath(__file__)] + base
+            r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp", GATRES_BENCH_CHILD="1"),
+                               stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=240)
+            if r.returncode != 0:
+                return f"the rocprofv3 --pmc {counter} child pass exited with {r.returncode}"
+            files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+            if not files:
+                return f"the rocprofv3 --pmc {counter} child pass left no counter file"
+            acc = {}
+            for path in files:
+                for row in csv.DictReader(open(path)):
+                    if row.get("Counter_Name") != counter:
+                        continue
+                    for k in kernels:
+                        if k in row.get("Kernel_Name", ""):
+                            key = (k, path, row.get("Dispatch_Id"))
+                            acc[key] = acc.get(key, 0.0) + float(row["Counter_Value"])      # (one row per XCD: summed)
+            for k in kernels:
+                vals = [v for (kk, _, _), v in acc.items() if kk == k]
+                if not vals:
+                    return f"no {k} launch in the {counter} pass"
+                out[k][counter] = sum(vals) / len(vals)
+                out[k]["launches"] = len(vals)
+        except subprocess.TimeoutExpired:
+            return f"the rocprofv3 --pmc {counter} child pass timed out"
+        except Exception as e:      # noqa: BLE001
+            return f"live counter pass failed ({type(e).__name__}: {e})"
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    return out
+
+
 def pmc_traffic(args, us_main, us_second):
     """HBM-side bytes per step of the two heavy launches from the committed rocprofv3 --pmc passes of THIS round
     (profiles/r06_fused_pmc_raw.json: FETCH_SIZE and WRITE_SIZE collected in separate runs of this script, KB per launch;
@@ -241,8 +303,23 @@ def pmc_traffic(args, us_main, us_second):
     counted: the file records each kernel's average duration in the profiled run, and a file whose figures differ from
     this run's live HIP-event durations by more than 5 % (dominant kernel; 10 % for the second launch, see below) is REFUSED
     (traffic = null, the reason in traffic_source) -- no falling back to another round's file."""
+    live_data = LIVE_PMC.get("data")
+    if isinstance(live_data, dict):
+        live = live_data
+        b = lambda c: int((2.0 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024)
+        main_b, pg_b = b(live["gatres_window_kernel"]), b(live["param_grads_reg_kernel"])
+        wait = None
+        try:      # (the wait / issue ratios still come from the round's SQ counter pass: they are evidence, not a roofline input)
+            with open(os.path.join(ROOT, "profiles", PMC_FILE)) as f:
+                wait = json.load(f).get("wait")
+        except Exception:      # noqa: BLE001
+            pass
+        src = (f"MEASURED IN THIS RUN: two child passes of this command under rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE before "
+               f"the timed run (mean over {live['gatres_window_kernel']['launches']} launches of the window kernel), 2 x FETCH + WRITE "
+               f"per launch, window kernel + parameter-gradient launch")
+        return main_b + (pg_b if us_second is not None else 0), src, wait, (pg_b if us_second is not None else None)
     if args.model != "gatres_small" or args.batch_size != 32 or args.nodes != 388 or args.per_op or args.shuffle_nodes:
-        return None, "no counter passes were taken for this workload", None, None
+        return None, "no counter passes were taken for this workload" + (f" ({live_data})" if isinstance(live_data, str) else ""), None, None
     path = os.path.join(ROOT, "profiles", PMC_FILE)
     try:
         with open(path) as f:
@@ -267,7 +344,8 @@ def pmc_traffic(args, us_main, us_second):
     if sk:           # the parameter gradients (+ update) run as a launch of their own: both launches, like counted_us
         val_second = int((2.0 * sk["FETCH_SIZE"]["mean_counter_value_KB"] + sk["WRITE_SIZE"]["mean_counter_value_KB"]) * 1024)
         val += val_second
-    src = (f"profiles/{PMC_FILE}: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, 2 x FETCH + WRITE "
+    src = ((f"live counter passes unavailable ({live_data}); " if isinstance(live_data, str) else "") +
+           f"profiles/{PMC_FILE}: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, 2 x FETCH + WRITE "
            f"per launch{' (window kernel + parameter-gradient launch)' if sk else ''}; a committed constant, NOT measured in "
            f"this run; accepted because the recorded kernel durations ({rec[0]:.1f}"
            f"{'' if rec[1] is None else ' + %.1f' % rec[1]} us) agree with this run's within 5 % (dominant kernel) / 10 % (second launch)")
@@ -562,6 +640,14 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if (world == 1 and rank == 0 and not (args.no_roofline or args.no_live_pmc or args.per_op or args.drop_in or args.eval
+                                          or args.force_collective_path or args.dtype == "bf16" or args.model != "gatres_small")
+            and not os.environ.get("GATRES_BENCH_CHILD") and torch.cuda.device_count() > 0):
+        # (device_count() does not initialise the GPU on this image; the child passes must come before anything that does)
+        log("two rocprofv3 --pmc child passes (FETCH_SIZE, WRITE_SIZE) for roofline.traffic ...")
+        t0 = time.perf_counter()
+        LIVE_PMC["data"] = live_pmc(args)
+        log(f"... {time.perf_counter() - t0:.0f} s: " + (LIVE_PMC["data"] if isinstance(LIVE_PMC["data"], str) else "ok"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP engine has no CPU path")
     # host-side tensor ops here are tiny (collation, masks): a 256-wide OpenMP team makes each of them ~20 ms
