@@ -265,7 +265,7 @@ def live_pmc(args):
             cmd = [exe, "--pmc", counter, "--output-format", "csv", "-d", d, "-o", "p", "--", sys.executable,
                    os.path.abspath(__file__)] + base
             r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp", GATRES_BENCH_CHILD="1"),
-                               stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=240)
+                               stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=120)
             if r.returncode != 0:
                 return f"the rocprofv3 --pmc {counter} child pass exited with {r.returncode}"
             files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
