@@ -60,6 +60,16 @@ class FusedAdam(torch.optim.Optimizer):
         cat = torch.cat([p.grad.reshape(-1).to(torch.float32) for p in params])
         return cat.data_ptr(), cat
 
+    def zero_grad(self, set_to_none: bool = True) -> None:
+        super().zero_grad(set_to_none)
+        fp = self.model.flat_parameter          # (a model in flat mode -- optimizer_parameters() was called -- keeps THE gradient there)
+        if fp is not None and fp.grad is not None:
+            if set_to_none:
+                fp.grad = None
+                self.model._grad_cur = None
+            else:
+                fp.grad.zero_()
+
     @torch.no_grad()
     def step(self, closure=None):
         loss = None
