@@ -36,9 +36,12 @@ class GatresGraph(C.Structure):
                 ("part_tables", C.c_void_p), ("part_tables_m", C.c_int32), ("part_tables_stride", C.c_int32)]
 
 
+MODEL_INFERENCE = 1            # GATRES_MODEL_INFERENCE (gatres_model_t.flags)
+
+
 class GatresModel(C.Structure):
     """gatres_model_t"""
-    _fields_ = [("num_blocks", C.c_int32), ("nc", C.c_int32), ("act_dtype", C.c_int32), ("reserved", C.c_int32)]
+    _fields_ = [("num_blocks", C.c_int32), ("nc", C.c_int32), ("act_dtype", C.c_int32), ("flags", C.c_int32)]
 
 
 _P = C.c_void_p

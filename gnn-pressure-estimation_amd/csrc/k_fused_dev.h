@@ -68,7 +68,8 @@ struct FusedArgs {
   int C;                    // consumer workgroups per segment (deferred parameter gradients on spare CUs), 0 = none
   int sym;                  // the plan's GATRES_GRAPH_SYMMETRIC: partners owe each other halo rows in both directions
   int facts;                // window kernel, host side only: what the launch may take as compile-time facts (k_window.hip: 0x400
-                            // no row with more than MAXD entries, 0x1000 no part with more than 64 rows)
+                            // no row with more than MAXD entries, 0x1000 no part with more than 64 rows, 0x2000 a forward-only launch whose saved
+                            // activations nobody reads)
   const int* ptab;          // the plan's part tables (gatres_graph_t.part_tables) and what they were built for; may be null
   int ptab_m, ptab_stride;
   unsigned* ready;          // [segment][4] lines: items published by the segment's part 0 for each consumer

@@ -582,7 +582,8 @@ extern "C" int gatres_fused_run(const gatres_model_t* m, const gatres_graph_t* g
   a.ptab = g->part_tables; a.ptab_m = g->part_tables_m; a.ptab_stride = g->part_tables_stride;
   {
     const int tiles = (g->max_segment_nodes + 15) / 16, part_rows = a.M > 0 ? 16 * ((tiles + a.M - 1) / a.M) : INT32_MAX;
-    a.facts = ((g->flags & GATRES_GRAPH_DEG_LE6) ? 0x400 : 0) | (part_rows <= 64 ? 0x1000 : 0);
+    a.facts = ((g->flags & GATRES_GRAPH_DEG_LE6) ? 0x400 : 0) | (part_rows <= 64 ? 0x1000 : 0) |
+              (((m->flags & GATRES_MODEL_INFERENCE) && phases == GATRES_PHASE_FORWARD) ? 0x2000 : 0);
   }
   a.keep_lds = (phases & GATRES_PHASE_FORWARD) && (phases & GATRES_PHASE_BACKWARD) && !gatres_knobs()->fused_no_keep &&
            window_kernel_fits(a.L, g, a.M, true) ? 1 : 0;

@@ -125,6 +125,9 @@ __global__ __launch_bounds__(THREADS) void gatres_window_kernel(const FusedArgs 
   constexpr bool NOHUB = PH >= 0 && (PH & 0x400) != 0;
   constexpr bool PTAB = PH >= 0 && (PH & 0x800) != 0;
   constexpr bool OW64 = PH >= 0 && (PH & 0x1000) != 0;
+  // PH & 0x2000 (forward-only launches): nobody reads the saved activations (GATRES_MODEL_INFERENCE) -- their stores, a
+  // tenth of the forward's VMEM and VALU work, are not compiled
+  constexpr bool NOSAVE = PH >= 0 && (PH & 0x2000) != 0 && (PH & 0xff) == GATRES_PHASE_FORWARD;
   // Row padding of the MFMA stages' x operand tables (xA / xB forward, xG backward): 16 rows K floats apart share their banks,
   // K + 4 apart they do not (the x fragment reads of win_proj were 8- / 16-way conflicted).  Only where every writer and reader
   // of the table is a win_* stage of this instantiation: forward with the fallbacks compiled out (NOHUB), backward with
@@ -345,7 +348,7 @@ __global__ __launch_bounds__(THREADS) void gatres_window_kernel(const FusedArgs 
         const float4 wv = ld4(w + c0), bv = ld4(b + c0);
         float4 o;
         o.x = xv * wv.x + bv.x; o.y = xv * wv.y + bv.y; o.z = xv * wv.z + bv.z; o.w = xv * wv.w + bv.w;
-        st4(xcur + (unsigned)(r * NC + c0), o);
+        if (!NOSAVE) st4(xcur + (unsigned)(r * NC + c0), o);
         st4(xA + (unsigned)(r * (NC + XPF) + c0), o);
       }
     }
@@ -412,7 +415,8 @@ __global__ __launch_bounds__(THREADS) void gatres_window_kernel(const FusedArgs 
         }
         if constexpr (NC == 32) {
           if (wave_u < PW) {                         // the tile waves
-            win_proj<NC, 2 * NC, 2, EPI_ATT, 2, PW, THREADS, NC + XPF>(rw, xA, wlA, base + SL.h1, 0, hA, base + SL.as1, base + SL.ad1, sa2,
+            win_proj<NC, 2 * NC, 2, EPI_ATT, 2, PW, THREADS, NC + XPF>(rw, xA, wlA, NOSAVE ? nullptr : base + SL.h1, 0, hA,
+                                                         NOSAVE ? nullptr : base + SL.as1, NOSAVE ? nullptr : base + SL.ad1, sa2,
                                                          sd2, nullptr, nullptr, nullptr, nullptr, xout(xreg, fflag, XL.f1h, XL.f1a));
           }
         } else
@@ -450,8 +454,8 @@ __global__ __launch_bounds__(THREADS) void gatres_window_kernel(const FusedArgs 
         // K2 conv1: alpha -> HBM, the gather's o1 -> HBM + the x buffer of proj2
         if (NOHUB || __builtin_expect(2 * oeg <= wr * NC, 1)) {
           if constexpr (NC == 32) {
-            win_fwd_agg<true, 2, NC, THREADS, NOHUB, 2 * NC + XPF>(rw, nbin, rp, colo, hA, sa2, sd2, base + SL.al1, elo, hBw, wlA + B1OFF,
-                                              base + SL.o1, 0, xB, mo1 ? mo1 + b * ow : nullptr, xout(false, fflag, 0, 0));
+            win_fwd_agg<true, 2, NC, THREADS, NOHUB, 2 * NC + XPF>(rw, nbin, rp, colo, hA, sa2, sd2, NOSAVE ? nullptr : base + SL.al1, elo, hBw, wlA + B1OFF,
+                                              NOSAVE ? nullptr : base + SL.o1, 0, xB, mo1 ? mo1 + b * ow : nullptr, xout(false, fflag, 0, 0));
           } else {
             win_softmax<2, THREADS>(rw, nbin, rp, colo, sa2, sd2, base + SL.al1, elo, hBw);
             lds_barrier();
@@ -484,7 +488,8 @@ __global__ __launch_bounds__(THREADS) void gatres_window_kernel(const FusedArgs 
         }
         if constexpr (NC == 32) {
           if (wave_u < PW) {
-            win_proj<2 * NC, NC, 1, EPI_ATT, 2, PW, THREADS, 2 * NC + XPF>(rw, xB, wlB, base + SL.h2, 0, hB, base + SL.as2, base + SL.ad2, sa1,
+            win_proj<2 * NC, NC, 1, EPI_ATT, 2, PW, THREADS, 2 * NC + XPF>(rw, xB, wlB, NOSAVE ? nullptr : base + SL.h2, 0, hB,
+                                                         NOSAVE ? nullptr : base + SL.as2, NOSAVE ? nullptr : base + SL.ad2, sa1,
                                                          sd1, nullptr, nullptr, nullptr, nullptr, xout(xreg, fflag, XL.f2h, XL.f2a));
           }
         } else
@@ -522,7 +527,7 @@ __global__ __launch_bounds__(THREADS) void gatres_window_kernel(const FusedArgs 
 #undef LIST_
         if (NOHUB || __builtin_expect(oeg <= wr * NC, 1)) {
           if constexpr (NC == 32) {
-            win_fwd_agg<false, 1, NC, THREADS, NOHUB>(rw, nbin, rp, colo, hB, sa1, sd1, base + SL.al2, elo, al2L, wlB + B2OFF, y2T,
+            win_fwd_agg<false, 1, NC, THREADS, NOHUB>(rw, nbin, rp, colo, hB, sa1, sd1, NOSAVE ? nullptr : base + SL.al2, elo, al2L, wlB + B2OFF, y2T,
                                                0, nullptr, nullptr, xout(xreg, fflag, XL.f3, 0));
           } else {
             win_softmax<1, THREADS>(rw, nbin, rp, colo, sa1, sd1, base + SL.al2, elo, al2L);
@@ -560,7 +565,7 @@ __global__ __launch_bounds__(THREADS) void gatres_window_kernel(const FusedArgs 
 #undef LIST_
         // K3: residual from the x buffer, result back into it (and to HBM: saved xin of the next block)
         float* xnext = segbase + (int64_t)(launder_s(b) + 1) * SL.bstride + SL.xin;
-        win_mean_fwd<NC, THREADS, NOHUB, NC + XPF>(rw, mbin, mrp, mcolo, y2T, xA, xnext, xA,
+        win_mean_fwd<NC, THREADS, NOHUB, NC + XPF>(rw, mbin, mrp, mcolo, y2T, xA, NOSAVE ? nullptr : xnext, xA,
                                        (mxin && b + 1 < nb) ? mxin + (b + 1) * ow : nullptr);
         lds_barrier();
         STAMP();
@@ -1196,7 +1201,8 @@ extern "C" __attribute__((visibility("hidden"))) int gatres_fused_launch_window(
     case 32: {
       // the launch's compile-time facts (gatres_window_kernel): phases | 0x100 keep-in-LDS | 0x200 symmetric plan, no consumer
       // workgroups | 0x400 rows of at most MAXD entries | 0x800 part tables | 0x1000 parts of at most 64 rows
-      const int facts = ((a.sym && a.C == 0) ? 0x200 : 0) | (a.facts & 0x1400) | ((a.ptab && a.ptab_m == a.M) ? 0x800 : 0);
+      int facts = ((a.sym && a.C == 0) ? 0x200 : 0) | (a.facts & 0x1400) | ((a.ptab && a.ptab_m == a.M) ? 0x800 : 0);
+      if ((a.facts & 0x2000) && facts == 0x1e00) facts |= 0x2000;      // (inference: only with every other fact -- one instantiation)
       const int key = a.phases | (a.keep_lds ? 0x100 : 0) | (facts & gatres_knobs()->window_ph_mask);
       if (!gatres_knobs()->window_runtime_phases) {
         switch (key) {
@@ -1205,6 +1211,7 @@ extern "C" __attribute__((visibility("hidden"))) int gatres_fused_launch_window(
           case 0x0f16: hipLaunchKernelGGL((gatres_window_kernel<32, 1024, 0x0f16>), dim3(grid), dim3(1024), 0, st, a); return gatres_launch_status();
           case 0x0716: hipLaunchKernelGGL((gatres_window_kernel<32, 1024, 0x0716>), dim3(grid), dim3(1024), 0, st, a); return gatres_launch_status();
           case 0x0316: hipLaunchKernelGGL((gatres_window_kernel<32, 1024, 0x0316>), dim3(grid), dim3(1024), 0, st, a); return gatres_launch_status();
+          case 0x3e02: hipLaunchKernelGGL((gatres_window_kernel<32, 1024, 0x3e02>), dim3(grid), dim3(1024), 0, st, a); return gatres_launch_status();
           case 0x1e02: hipLaunchKernelGGL((gatres_window_kernel<32, 1024, 0x1e02>), dim3(grid), dim3(1024), 0, st, a); return gatres_launch_status();
           case 0x1e04: hipLaunchKernelGGL((gatres_window_kernel<32, 1024, 0x1e04>), dim3(grid), dim3(1024), 0, st, a); return gatres_launch_status();
           case 0x116: hipLaunchKernelGGL((gatres_window_kernel<32, 1024, 0x116>), dim3(grid), dim3(1024), 0, st, a); return gatres_launch_status();

@@ -467,8 +467,10 @@ __device__ __forceinline__ void win_proj(Rows rw, const float* X, const float* w
 #pragma unroll
         for (int hh = 0; hh < HG; ++hh) {
           const int hd = (g * NTG) / TPH + hh;
-          as_g[(unsigned)(r * H + hd)] = ps[hh];
-          ad_g[(unsigned)(r * H + hd)] = pd[hh];
+          if (as_g) {
+            as_g[(unsigned)(r * H + hd)] = ps[hh];
+            ad_g[(unsigned)(r * H + hd)] = pd[hh];
+          }
           as_l[r * H + hd] = ps[hh]; ad_l[r * H + hd] = pd[hh];
           if (xrow) xout_store1(xo, xo.t_small + (unsigned)(r * H + hd), ps[hh]);       // a_src goes to the partners
         }
@@ -493,7 +495,7 @@ __device__ __forceinline__ void win_proj(Rows rw, const float* X, const float* w
             o.z = ((b >> (2 * fs)) & 1) ? o.z : 0.f;   o.w = ((b >> (3 * fs)) & 1) ? o.w : 0.f;
           }
         }
-        st4(OUT + (unsigned)((ob + r) * M + mb), o);
+        if (OUT) st4(OUT + (unsigned)((ob + r) * M + mb), o);      // (null: an inference launch keeps no saved activations)
         float4 os = o;
         if (cnt_rp) { os.x = o.x / rcnt; os.y = o.y / rcnt; os.z = o.z / rcnt; os.w = o.w / rcnt; }
         if (OUT2) st4(OUT2 + (unsigned)(r * M + mb), os);
@@ -765,7 +767,7 @@ __device__ __forceinline__ void win_fwd_agg(Rows rw, const u16* nb, const u16* r
         Z = Z + GATRES_SOFTMAX_EPS;
         for (int e = beg; e < end; ++e) {
           const float al = expf(gatres_leaky(at(e) + adst) - m) / Z;
-          if (valid) alpha_g[(unsigned)((eb + e) * H + hd)] = al;
+          if (alpha_g && valid) alpha_g[(unsigned)((eb + e) * H + hd)] = al;
           alpha_l[e * H + hd] = al;
         }
       }
@@ -803,7 +805,7 @@ __device__ __forceinline__ void win_fwd_agg(Rows rw, const u16* nb, const u16* r
       for (int k = 0; k < MAXD; ++k) Z = Z + e[k];
       Z = Z + GATRES_SOFTMAX_EPS;
       const float alj = ex / Z;
-      if (valid && j < d.deg) alpha_g[(unsigned)((eb + d.beg + j) * H + hd)] = alj;
+      if (alpha_g && valid && j < d.deg) alpha_g[(unsigned)((eb + d.beg + j) * H + hd)] = alj;
       float al[MAXD];
       al[0] = group8_bcast<0>(alj); al[1] = group8_bcast<1>(alj); al[2] = group8_bcast<2>(alj);
       al[3] = group8_bcast<3>(alj); al[4] = group8_bcast<4>(alj); al[5] = group8_bcast<5>(alj);
@@ -816,7 +818,7 @@ __device__ __forceinline__ void win_fwd_agg(Rows rw, const u16* nb, const u16* r
       acc.z = fmaxf(acc.z, 0.f); acc.w = fmaxf(acc.w, 0.f);
     }
     if (valid) {
-      st4(out + (unsigned)((ob + r) * HC + c0), acc);
+      if (out) st4(out + (unsigned)((ob + r) * HC + c0), acc);
       if (out_pub) st4(out_pub + (unsigned)(r * OPS + c0), acc);      // (OPS: row stride of the x operand table it fills)
       if (xo.on && xo.flag[r] != 0) xout_store4(xo, xo.t_rows + (unsigned)(r * HC + c0), acc);
     }
@@ -864,7 +866,7 @@ __device__ __forceinline__ void win_mean_fwd(Rows rw, const u16* mb, const u16* 
     o.x = fmaxf(acc.x / cnt + rr.x, 0.f); o.y = fmaxf(acc.y / cnt + rr.y, 0.f);
     o.z = fmaxf(acc.z / cnt + rr.z, 0.f); o.w = fmaxf(acc.w / cnt + rr.w, 0.f);
     if (valid) {
-      st4(out + (unsigned)(r * C + c0), o);
+      if (out) st4(out + (unsigned)(r * C + c0), o);
       st4(out2 + (unsigned)(r * XS + c0), o);
     }
     if constexpr (G <= 8) {

@@ -368,8 +368,13 @@ typedef struct gatres_model {
    * (the fused per-snapshot path is fp32).  Buffers keep their fp32 SIZES (gatres_saved_floats / gatres_scratch_floats):
    * a bf16 tensor occupies the first half of its fp32 slot.  x, y, out, g_out, g_x, params, grads are always fp32. */
   int32_t act_dtype;
-  int32_t reserved;
+  int32_t flags;            /* GATRES_MODEL_* bits (0 = none) */
 } gatres_model_t;
+
+/* gatres_model_t.flags */
+#define GATRES_MODEL_INFERENCE 1   /* forward-only calls whose `saved` buffer nobody will read (evaluation): the per-snapshot
+                                    * kernel still needs the buffer (pass gatres_saved_floats floats) but may leave it unwritten --
+                                    * the window kernel then runs an instantiation without the saved-activation stores */
 
 /* --------------------------------------------------------------------------------------------------------
  * Blocked kernels (round 5; k_blocked.hip): a SPARSE stage and the dense projection that consumes its output

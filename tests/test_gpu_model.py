@@ -782,3 +782,26 @@ def test_flat_parameter_mode_equals_per_tensor_adam(pkg, oracle):
         assert torch.equal(torch.cat([p.grad.reshape(-1) for p in mf.parameters()]), gt), it
         assert torch.equal(mf.flat_parameters, mt.flat_parameters), it
     assert torch.equal(mf.state_dict()["lin1.weight"], mt.state_dict()["lin1.weight"])
+
+
+def test_inference_notices_parameters_repointed_behind_its_back(pkg, oracle):
+    """Under ``torch.no_grad()`` the forward launch goes out BEFORE the module checks that its 124 parameters still are views
+    of the flat vector the kernels read (the reference times every inference call, utils/timer.py).  A parameter re-pointed
+    (``p.data = ...``) or replaced (``module.weight = nn.Parameter(...)``) since the last call must still be honoured: the flat
+    vector is rebuilt and the forward runs again."""
+    nb, nc, bs = 2, 32, 2
+    x, _, ei, _ = ctown_batch(pkg, bs)
+    model, p = build(pkg, oracle, nb, nc, seed=9)
+    x, ei = x.cuda(), ei.cuda()
+    with torch.no_grad():
+        a = model(x, ei).clone()
+        model.lin1.bias.data = model.lin1.bias.data + 1.0                    # re-pointed: a new storage
+        b = model(x, ei).clone()
+        assert float((b - a - 1.0).abs().max()) < 1e-5
+        model.lin1.weight = torch.nn.Parameter(torch.zeros_like(model.lin1.weight))      # replaced
+        c = model(x, ei)
+        assert float((c - float(model.lin1.bias)).abs().max()) < 1e-6
+    p2 = dict(p)
+    p2["lin1.bias"] = p["lin1.bias"] + 1.0
+    p2["lin1.weight"] = torch.zeros_like(p["lin1.weight"])
+    assert relerr(c, oracle.gatres_forward(p2, x.cpu(), ei.cpu(), num_blocks=nb)) < 1e-5
