@@ -121,7 +121,8 @@ def publish(d):
             "eager_kernel_stats.csv", "eager.json", "from_store.json", "fused_kernel_stats.csv", "fused_pmc.json",
             "fused_pmc_raw.json", "host_batches.json", "large_50k_bs2_bf16.json", "launcher_2ranks_one_gpu.json",
             "one_step_per_graph.json", "param_grads_pmc.json", "per_op.json", "shuffle_nodes.json", "small_50k_bs16.json",
-            "drop_in_breakdown.txt", "eval_large_bs128_bf16.json", "eval_small_bs32.json", "copy_batches.json"]
+            "drop_in_breakdown.txt", "eval_large_bs128_bf16.json", "eval_small_bs32.json", "copy_batches.json",
+            "eval_kernel_stats.csv"]
     renamed = {"large_bf16.json": "large_ctown_bs128_bf16.json", "large_bf16_kernel_stats.csv": "large_ctown_bs128_bf16_kernel_stats.csv",
                "large_bf16_pmc.json": "large_ctown_bs128_bf16_pmc.json", "large_fp32.json": "large_ctown_bs128_fp32.json",
                "stage_times.txt": "window_stage_times.txt", "drop_in.json": "drop_in_torch_adam.json",

@@ -39,6 +39,9 @@ for f in "" "--flat-adam" "--fused-adam"; do timeout 300 $B --drop-in $f --steps
 timeout 300 python3 tests/micro/drop_in_breakdown.py > $O/drop_in_breakdown.txt 2>&1; tail -12 $O/drop_in_breakdown.txt
 timeout 300 $B --eval --steps 100 2>/dev/null | tail -1 > $O/eval_small_bs32.json; cut -c1-300 $O/eval_small_bs32.json
 timeout 600 $B --eval --steps 30 --model gatres_large --batch-size 128 --dtype bf16 2>/dev/null | tail -1 > $O/eval_large_bs128_bf16.json; cut -c1-300 $O/eval_large_bs128_bf16.json
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_eval -o kt -- $B --eval --steps 200 > $O/kt_eval.log 2>&1
+python3 tests/micro/summarize_prof.py stats $O/kt_eval $O/eval_kernel_stats.csv; rm -rf $O/kt_eval
+timeout 300 $B --no-cpu-baseline --copy-batches 2>/dev/null | tail -1 > $O/copy_batches.json
 bash tests/micro/r06_phase_ab.sh > /dev/null 2>&1; cp gpurun_out/r06_phase_ab.txt $O/phase_ab.txt; tail -7 $O/phase_ab.txt
 timeout 300 $B --no-cpu-baseline --no-roofline --graph-steps 1 2>/dev/null | tail -1 > $O/one_step_per_graph.json; python3 -c "$short" < $O/one_step_per_graph.json
 # ---- the launcher path: 2 ranks on this one GPU (test overrides: gloo, shared device)
