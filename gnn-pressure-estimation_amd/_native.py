@@ -62,6 +62,7 @@ SIGNATURES = {
     "gatres_permute_f32": (C.c_int, [_P, _P, _P, _I32, _I32, _P]),
     "gatres_gather_u8": (C.c_int, [_P, _P, _P, _I32, _P]),
     "gatres_fused_serialize": (C.c_int, [_P]),
+    "gatres_probe_xcd_dispatch": (C.c_int, [_P]),
     "gatres_knobs_reload": (C.c_int, []),
     "gatres_fused_status_offset": (_I64, [_MP, _GP]),
     "gatres_lin0_fwd": (C.c_int, [_P, _P, _P, _P, _P, _I32, _I32, _P]),
@@ -132,7 +133,7 @@ SIGNATURES = {
 }
 
 
-ABI_VERSION = 5                # GATRES_ABI_VERSION of include/gatres.h
+ABI_VERSION = 6                # GATRES_ABI_VERSION of include/gatres.h
 
 
 def diag_build() -> bool:

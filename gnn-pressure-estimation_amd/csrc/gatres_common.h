@@ -40,6 +40,7 @@ struct gatres_knobs_t {
                               // to the per-op pairs, measured 5 - 20 % slower than them (profiles/r05_blocked_probe.txt)
   int window_runtime_phases;  // GATRES_WINDOW_RUNTIME_PHASES: the window kernel reads its phases at run time (one register allocation
                               // for forward and backward) instead of taking the per-phase instantiations
+  int window_sync_start;      // GATRES_WINDOW_SYNC_START: a split launch starts with its cross-CU barrier even where the dispatch was probed
   int window_ph_mask;         // GATRES_WINDOW_PH_MASK (default all ones): which compile-time facts a launch may use (k_window.hip)
   // DIAGNOSTIC build only (fixed at the defaults in the product build): measured-and-lost alternatives, tuning sweeps and the
   // switches that give WRONG results

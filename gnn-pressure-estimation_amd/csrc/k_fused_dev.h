@@ -69,7 +69,8 @@ struct FusedArgs {
   int sym;                  // the plan's GATRES_GRAPH_SYMMETRIC: partners owe each other halo rows in both directions
   int facts;                // window kernel, host side only: what the launch may take as compile-time facts (k_window.hip: 0x400
                             // no row with more than MAXD entries, 0x1000 no part with more than 64 rows, 0x2000 a forward-only launch whose saved
-                            // activations nobody reads)
+                            // activations nobody reads) and, read by the kernel itself, 0x4000: parts 8 ids apart share an XCD
+                            // (gatres_probe_xcd_dispatch: the launch starts without its first cross-CU barrier)
   const int* ptab;          // the plan's part tables (gatres_graph_t.part_tables) and what they were built for; may be null
   int ptab_m, ptab_stride;
   unsigned* ready;          // [segment][4] lines: items published by the segment's part 0 for each consumer
@@ -1862,19 +1863,36 @@ __device__ __forceinline__ void group_sync(Group& g) {
 }
 
 // First barrier of a launch: publishes the XCD ids (always with the safe agent-scope form) and decides `local`.
+// assume_local (the host probed the device's dispatch: gatres_probe_xcd_dispatch): the parts take their shared XCD for granted
+// and do NOT meet here -- the barrier made every part wait until the last one of its segment had been dispatched and had
+// crossed an agent-scope flag round trip: 7 us per launch.  The ids are still recorded; group_verify_local compares them at
+// the end of the launch.  (Wrong placement cannot go unnoticed earlier either: a granule that never arrives in this part's L2
+// ends its sweep with the fault word set.)
 template <int THREADS>
-__device__ __forceinline__ void group_init(Group& g) {
+__device__ __forceinline__ void group_init(Group& g, bool assume_local = false) {
   g.dead = false; g.local = false;
   if (g.M == 1) { g.epoch = 0u; return; }
   g.epoch = __hip_atomic_load(g.flags + g.part * FLAG_STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   if (threadIdx.x == 0)
     __hip_atomic_store(g.flags + g.part * FLAG_STRIDE + 1, xcc_id(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (assume_local) { g.local = true; return; }
   group_sync<THREADS>(g);
   bool same = true;
   const unsigned mine = xcc_id();
   for (int p = 0; p < g.M; ++p)
     same = same && (__hip_atomic_load(g.flags + p * FLAG_STRIDE + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == mine);
   g.local = same;
+}
+
+// End of a launch that started with assume_local: every partner this part exchanged rows with has recorded its XCD id long ago.
+// (lanes 0 .. M-1 of wave 0, one partner each: ONE L2 round trip, not M dependent ones)
+__device__ __forceinline__ void group_verify_local(const Group& g) {
+  if (g.M <= 1 || threadIdx.x >= 64) return;
+  const unsigned mine = xcc_id();
+  unsigned v = mine;
+  if ((int)threadIdx.x < g.M)
+    v = __hip_atomic_load(g.flags + threadIdx.x * FLAG_STRIDE + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (__any(v != mine) && threadIdx.x == 0) *g.err = 1;
 }
 
 // dst[k] = src[k] for k in [0, a) and [b, total): the partners' part of a table whose own part is [a, b).

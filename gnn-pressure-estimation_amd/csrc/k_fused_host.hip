@@ -1,5 +1,7 @@
 // Host side of the fused per-snapshot path: launch geometry, the deferred parameter-gradient launch, the slab reduction +
 // Adam launch, and the C-ABI entry points (include/gatres.h: gatres_fused_*).
+#include <atomic>
+#include <vector>
 #include "k_fused_dev.h"
 #include "k_mask.h"
 
@@ -332,6 +334,15 @@ __global__ __launch_bounds__(PGR_THREADS) void param_grads_finish_kernel(const P
   }
 }
 
+// gatres_probe_xcd_dispatch: one workgroup per CU (the whole LDS, 1024 threads: the shape of the split launches), each records
+// the XCD it runs on.
+__global__ __launch_bounds__(1024) void xcd_probe_kernel(unsigned* __restrict__ out) {
+  __shared__ unsigned char lds[LDS_BYTES];
+  lds[threadIdx.x] = (unsigned char)threadIdx.x;
+  __syncthreads();
+  if (threadIdx.x == 0) out[blockIdx.x] = xcc_id() | ((unsigned)(lds[1] & 0u) << 8);
+}
+
 // The same bookkeeping after a split launch that no gatres_fused_finish follows (forward / inference launches)
 __global__ __launch_bounds__(64) void fused_status_kernel(unsigned* __restrict__ status) {
   if (threadIdx.x == 0 && __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
@@ -552,6 +563,12 @@ extern "C" int gatres_fused_prepare_backward(const gatres_model_t* m, const gatr
   return gatres_transpose_conv_weights(params, scratch + L.sc_wt, L.nb, L.nc, stream);
 }
 
+static std::atomic<int> g_xcd_rr[64];          // per device: 0 = not probed, 1 = no, 2 = workgroups 8 ids apart share an XCD
+static int xcd_rr_cached() {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 0;
+  return g_xcd_rr[dev].load(std::memory_order_acquire) == 2 ? 1 : 0;
+}
 extern "C" int gatres_fused_run(const gatres_model_t* m, const gatres_graph_t* g, const float* params,
                                 const float* x, const uint8_t* mask, const float* y, float* out, float* g_out,
                                 float* loss_part, float* g_x, float* saved, float* scratch, int32_t phases,
@@ -583,7 +600,8 @@ extern "C" int gatres_fused_run(const gatres_model_t* m, const gatres_graph_t* g
   {
     const int tiles = (g->max_segment_nodes + 15) / 16, part_rows = a.M > 0 ? 16 * ((tiles + a.M - 1) / a.M) : INT32_MAX;
     a.facts = ((g->flags & GATRES_GRAPH_DEG_LE6) ? 0x400 : 0) | (part_rows <= 64 ? 0x1000 : 0) |
-              (((m->flags & GATRES_MODEL_INFERENCE) && phases == GATRES_PHASE_FORWARD) ? 0x2000 : 0);
+              (((m->flags & GATRES_MODEL_INFERENCE) && phases == GATRES_PHASE_FORWARD) ? 0x2000 : 0) |
+              ((xcd_rr_cached() && !gatres_knobs()->window_sync_start) ? 0x4000 : 0);
   }
   a.keep_lds = (phases & GATRES_PHASE_FORWARD) && (phases & GATRES_PHASE_BACKWARD) && !gatres_knobs()->fused_no_keep &&
            window_kernel_fits(a.L, g, a.M, true) ? 1 : 0;
@@ -608,6 +626,33 @@ extern "C" int gatres_fused_run(const gatres_model_t* m, const gatres_graph_t* g
 }
 
 extern "C" int gatres_fused_serialize(void* stream) { return serialize_split_launch(gatres_stream(stream)); }
+
+extern "C" int gatres_probe_xcd_dispatch(void* stream) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 0;
+  const int have = g_xcd_rr[dev].load(std::memory_order_acquire);
+  if (have != 0) return have == 2 ? 1 : 0;
+  hipStream_t st = gatres_stream(stream);
+  hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) return 0;      // (not now)
+  const int cus = device_cus();
+  if (cus < 16 || cus > 4096) { g_xcd_rr[dev].store(1, std::memory_order_release); return 0; }
+  unsigned* d = nullptr;
+  if (hipMalloc(&d, sizeof(unsigned) * cus) != hipSuccess) return 0;
+  std::vector<unsigned> h((size_t)cus, 0xffu);
+  bool ok = hipMemsetAsync(d, 0xff, sizeof(unsigned) * cus, st) == hipSuccess;
+  if (ok) {
+    hipLaunchKernelGGL(xcd_probe_kernel, dim3((unsigned)cus), dim3(1024), 0, st, d);
+    ok = hipGetLastError() == hipSuccess && hipStreamSynchronize(st) == hipSuccess &&
+         hipMemcpy(h.data(), d, sizeof(unsigned) * cus, hipMemcpyDeviceToHost) == hipSuccess;
+  }
+  (void)hipFree(d);
+  if (!ok) return 0;
+  bool rr = true;
+  for (int b = 0; b < cus && rr; ++b) rr = (h[b] & 0xfu) == (h[b & 7] & 0xfu) && h[b] != 0xffffffffu;
+  g_xcd_rr[dev].store(rr ? 2 : 1, std::memory_order_release);
+  return rr ? 1 : 0;
+}
 
 extern "C" int64_t gatres_fused_status_offset(const gatres_model_t* m, const gatres_graph_t* g) {
   Layout L;

@@ -38,6 +38,7 @@ void read_knobs(gatres_knobs_t* k) {
   k->blocked = env_flag("GATRES_BLOCKED");
   k->window_runtime_phases = env_flag("GATRES_WINDOW_RUNTIME_PHASES");
   k->window_ph_mask = env_int("GATRES_WINDOW_PH_MASK", 0xffff);
+  k->window_sync_start = env_flag("GATRES_WINDOW_SYNC_START");
   k->fused_no_keep = env_flag("GATRES_FUSED_NO_KEEP");
   // diagnostic build only
   k->agg_wide_offsets = 0; k->fused_threads = 1024; k->fused_no_window = 0; k->fused_prefer_consumers = 0;

@@ -128,6 +128,10 @@ __global__ __launch_bounds__(THREADS) void gatres_window_kernel(const FusedArgs 
   // PH & 0x2000 (forward-only launches): nobody reads the saved activations (GATRES_MODEL_INFERENCE) -- their stores, a
   // tenth of the forward's VMEM and VALU work, are not compiled
   constexpr bool NOSAVE = PH >= 0 && (PH & 0x2000) != 0 && (PH & 0xff) == GATRES_PHASE_FORWARD;
+  // PH & 0x4000: the host probed the device's dispatch (gatres_probe_xcd_dispatch): parts 8 ids apart share an XCD.  The launch
+  // starts without its first cross-CU barrier and `local` is a compile-time truth -- the agent-scope forms of every granule
+  // store and sweep are not compiled.  Every part still records its XCD id; the end of the launch compares (group_verify_local).
+  constexpr bool XLOCAL = PH >= 0 && (PH & 0x4000) != 0;
   // Row padding of the MFMA stages' x operand tables (xA / xB forward, xG backward): 16 rows K floats apart share their banks,
   // K + 4 apart they do not (the x fragment reads of win_proj were 8- / 16-way conflicted).  Only where every writer and reader
   // of the table is a win_* stage of this instantiation: forward with the fallbacks compiled out (NOHUB), backward with
@@ -185,8 +189,10 @@ __global__ __launch_bounds__(THREADS) void gatres_window_kernel(const FusedArgs 
   const bool ow64 = OW64 || ow <= 64;
   Group grp;
   grp.flags = a.flags + (size_t)seg * 8 * FLAG_STRIDE; grp.M = M; grp.part = part; grp.err = a.err;
-  group_init<THREADS>(grp);
-  if (a.safe_sync) grp.local = false;
+  constexpr bool assume_local = XLOCAL;
+  group_init<THREADS>(grp, XLOCAL);
+  if constexpr (XLOCAL) grp.local = true;
+  else if (a.safe_sync) grp.local = false;
   // granule exchange state of this part (epochs persist in word 2 of the part's flag line)
   const XchLayout& XL = a.XL;
   Xch xc;
@@ -571,6 +577,9 @@ __global__ __launch_bounds__(THREADS) void gatres_window_kernel(const FusedArgs 
         STAMP();
       }
     }
+    // (assume_local: every partner has exchanged rows with this part by now -- its XCD id is on record; checked here, off the
+    //  launch's tail, in a launch without a backward phase)
+    if (assume_local && !(ph_ & GATRES_PHASE_BACKWARD)) group_verify_local(grp);
     FRESH_FWD();
 #define LIST_(T_, N_, I_) I_(lo) I_(hi) T_(float, xA)
     REC_LOADS(LIST_);
@@ -1151,6 +1160,7 @@ __global__ __launch_bounds__(THREADS) void gatres_window_kernel(const FusedArgs 
     // The parts only meet here for the consumers' sake (the last items are published behind this barrier); without consumer
     // workgroups nothing of a partner is needed any more: a workgroup barrier that also drains this part's own stores (g_x below
     // reads gp_cur back) replaces the flag barrier.  a.C is the same for every part: the barrier count per launch stays equal.
+    if (assume_local) group_verify_local(grp);      // (one L2 round trip on wave 0, under the barrier below)
     if (nC_ > 0) group_sync<THREADS>(grp);
     else         __syncthreads();
     if constexpr (!LEAN) publish_items<THREADS>(a, seg, part, 2 * L.nb, grp.local || !pub, !pub);
@@ -1203,9 +1213,14 @@ extern "C" __attribute__((visibility("hidden"))) int gatres_fused_launch_window(
       // workgroups | 0x400 rows of at most MAXD entries | 0x800 part tables | 0x1000 parts of at most 64 rows
       int facts = ((a.sym && a.C == 0) ? 0x200 : 0) | (a.facts & 0x1400) | ((a.ptab && a.ptab_m == a.M) ? 0x800 : 0);
       if ((a.facts & 0x2000) && facts == 0x1e00) facts |= 0x2000;      // (inference: only with every other fact -- one instantiation)
+      if ((a.facts & 0x4000) && (facts & 0x1e00) == 0x1e00 && !a.safe_sync) facts |= 0x4000;      // (probed dispatch: likewise)
       const int key = a.phases | (a.keep_lds ? 0x100 : 0) | (facts & gatres_knobs()->window_ph_mask);
       if (!gatres_knobs()->window_runtime_phases) {
         switch (key) {
+          case 0x5f16: hipLaunchKernelGGL((gatres_window_kernel<32, 1024, 0x5f16>), dim3(grid), dim3(1024), 0, st, a); return gatres_launch_status();
+          case 0x7e02: hipLaunchKernelGGL((gatres_window_kernel<32, 1024, 0x7e02>), dim3(grid), dim3(1024), 0, st, a); return gatres_launch_status();
+          case 0x5e02: hipLaunchKernelGGL((gatres_window_kernel<32, 1024, 0x5e02>), dim3(grid), dim3(1024), 0, st, a); return gatres_launch_status();
+          case 0x5e04: hipLaunchKernelGGL((gatres_window_kernel<32, 1024, 0x5e04>), dim3(grid), dim3(1024), 0, st, a); return gatres_launch_status();
           case 0x1f16: hipLaunchKernelGGL((gatres_window_kernel<32, 1024, 0x1f16>), dim3(grid), dim3(1024), 0, st, a); return gatres_launch_status();
           case 0x1b16: hipLaunchKernelGGL((gatres_window_kernel<32, 1024, 0x1b16>), dim3(grid), dim3(1024), 0, st, a); return gatres_launch_status();      // (a plan with hub rows)
           case 0x0f16: hipLaunchKernelGGL((gatres_window_kernel<32, 1024, 0x0f16>), dim3(grid), dim3(1024), 0, st, a); return gatres_launch_status();
@@ -1215,8 +1230,6 @@ extern "C" __attribute__((visibility("hidden"))) int gatres_fused_launch_window(
           case 0x1e02: hipLaunchKernelGGL((gatres_window_kernel<32, 1024, 0x1e02>), dim3(grid), dim3(1024), 0, st, a); return gatres_launch_status();
           case 0x1e04: hipLaunchKernelGGL((gatres_window_kernel<32, 1024, 0x1e04>), dim3(grid), dim3(1024), 0, st, a); return gatres_launch_status();
           case 0x116: hipLaunchKernelGGL((gatres_window_kernel<32, 1024, 0x116>), dim3(grid), dim3(1024), 0, st, a); return gatres_launch_status();
-          case 0x002: hipLaunchKernelGGL((gatres_window_kernel<32, 1024, 0x002>), dim3(grid), dim3(1024), 0, st, a); return gatres_launch_status();
-          case 0x004: hipLaunchKernelGGL((gatres_window_kernel<32, 1024, 0x004>), dim3(grid), dim3(1024), 0, st, a); return gatres_launch_status();
           default: break;
         }
       }

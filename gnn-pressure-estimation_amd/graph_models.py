@@ -468,6 +468,11 @@ class GATResMeanConv(_TrackedModule):
                 _native.check(int(n), "gatres_scratch_floats")
             # zeroed once: the split-segment barrier epochs of the fused kernel live in here (include/gatres.h)
             buf = torch.zeros(int(n), dtype=torch.float32, device=plan.device)
+            if buf.is_cuda:
+                # once per device (cached in the library): does the dispatch put workgroups 8 ids apart on one XCD?  Then the
+                # split launches start without their first cross-CU barrier (gatres_probe_xcd_dispatch)
+                with torch.cuda.device(buf.device):
+                    lib.gatres_probe_xcd_dispatch(_native.current_stream(buf.device))
             self._remember(key, buf)
         return buf
 

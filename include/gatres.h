@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define GATRES_ABI_VERSION 5
+#define GATRES_ABI_VERSION 6
 
 #define GATRES_E_BADARG      (-1)  /* null pointer, negative size, misaligned pointer            */
 #define GATRES_E_UNSUPPORTED (-2)  /* width not supported by the gfx950 kernels                  */
@@ -477,6 +477,13 @@ int gatres_fused_reset_sync(const gatres_model_t* m, const gatres_graph_t* g, fl
  * orders itself behind the previous split launch when the stream changes; a captured launch cannot do that, so call
  * this on `stream` before REPLAYING a hipGraph that contains fused launches. */
 int gatres_fused_serialize(void* stream);
+/* How does the current device place the workgroups of a launch?  Runs ONCE per device (a 1-KB allocation, one launch of one
+ * workgroup per CU, a synchronisation of `stream`: NOT inside a stream capture -- it then returns what is cached, 0 if nothing)
+ * and caches: 1 = workgroups whose ids are 8 apart run on the same XCD (round-robin dispatch: every full MI355X), 0 = not.
+ * With 1 the parts of a split segment take their shared L2 for granted and the launch starts WITHOUT its first cross-CU
+ * barrier (round 6: 7 us per launch; every part still records its XCD id and compares at the end of the launch -- a mismatch
+ * faults the launch, which is then dropped and counted like any other fault).  A caller that never asks gets the barrier. */
+int gatres_probe_xcd_dispatch(void* stream);
 /* Float index inside `scratch` of the split-launch status words {uint32 fault (set by a launch whose partner never
  * arrived; cleared by gatres_fused_finish / the next forward launch's epilogue), uint32 faults seen so far, uint32
  * internal}; -1 if the fused path does not apply.  A faulted training step is dropped: loss = NaN, gradients = NaN,
