@@ -127,7 +127,7 @@ def publish(d):
                "large_bf16_pmc.json": "large_ctown_bs128_bf16_pmc.json", "large_fp32.json": "large_ctown_bs128_fp32.json",
                "stage_times.txt": "window_stage_times.txt", "drop_in.json": "drop_in_torch_adam.json",
                "drop_in--flat-adam.json": "drop_in_flat_adam.json", "drop_in--fused-adam.json": "drop_in_fused_adam.json",
-               "phase_ab.txt": "window_instantiations_ab.txt"}
+               "phase_ab.txt": "window_instantiations_ab.txt", "sync_start_ab.txt": "window_sync_start_ab.txt"}
     for src, dst in [(f, f) for f in same] + list(renamed.items()):
         a = os.path.join(d, src)
         if os.path.exists(a) and os.path.getsize(a) > 0:
