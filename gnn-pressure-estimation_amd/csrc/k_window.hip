@@ -166,6 +166,20 @@ __global__ __launch_bounds__(THREADS) void gatres_window_kernel(const FusedArgs 
   int hv = 0;
   if (PTAB || pt) hv = pt[min((int)(threadIdx.x & 63), GATRES_PT_HEADER - 1)];
   auto H = [&](int field) { return __builtin_amdgcn_readlane(hv, field); };
+#ifndef GATRES_NO_L2_TOUCH
+  if constexpr (PTAB && NC == 32) {
+    // While the header is on its way (an HBM-cold line: the previous launches of the step streamed 300 MB through the L2s): ask
+    // for the lines the prologue's LDS-DMA will want NEXT -- the part's image, which follows the header in its record, and the
+    // first block's W1 -- so that the second of two dependent cold reads is a hit.  Values unused (see the touch before lin1).
+    if (ph_ & GATRES_PHASE_FORWARD) {
+      if (tid < 64) { if (tid * 32 < a.ptab_stride) (void)*reinterpret_cast<const volatile int*>(pt + tid * 32); }
+      else if (tid < 64 + 2 * NC * NC / 32 && L.nb > 0)
+        (void)*reinterpret_cast<const volatile float*>(a.params + L.p_block0 + L.c1_W + (tid - 64) * 32);
+    } else {
+      for (int k = tid * 32; k < a.ptab_stride; k += THREADS * 32) (void)*reinterpret_cast<const volatile int*>(pt + k);
+    }
+  }
+#endif
   int n0, n, e0, em0, t0, mt0;
   Rows rw;
   if (PTAB || pt) {
@@ -580,6 +594,26 @@ __global__ __launch_bounds__(THREADS) void gatres_window_kernel(const FusedArgs 
     // (assume_local: every partner has exchanged rows with this part by now -- its XCD id is on record; checked here, off the
     //  launch's tail, in a launch without a backward phase)
     if (assume_local && !(ph_ & GATRES_PHASE_BACKWARD)) group_verify_local(grp);
+#ifndef GATRES_NO_L2_TOUCH
+    if constexpr (PTAB && NC == 32) {
+      // Training launches: the backward prologue opens with LDS-DMA of tables nobody has touched for a whole forward phase -- the
+      // part's backward image and hand-off lists (the tail of its record) and the last block's W2^T | att: HBM-cold, and every CU
+      // asks at the same moment.  One load per 128 bytes here, under lin1 and the loss, brings the lines into this XCD's L2; the
+      // values are not used (volatile loads: the compiler counts them, nothing waits for them before the prologue's own waits).
+      if (ph_ & GATRES_PHASE_BACKWARD) {
+        const int b0 = H(GATRES_PT_B_IMG);
+        for (int k = b0 + tid * 32; k < a.ptab_stride; k += THREADS * 32) (void)*reinterpret_cast<const volatile int*>(pt + k);
+        if (L.nb > 0 && tid >= THREADS / 2) {
+          const int t2 = tid - THREADS / 2;
+          constexpr int WT_LINES = 2 * NC * NC / 32;                     // W2^T: 2NC x NC floats
+          const float* wt2 = a.wt + (int64_t)(L.nb - 1) * 4 * NC * NC + 2 * NC * NC;
+          if (t2 < WT_LINES) (void)*reinterpret_cast<const volatile float*>(wt2 + t2 * 32);
+          else if (t2 < WT_LINES + 2)
+            (void)*reinterpret_cast<const volatile float*>(P + L.p_block0 + (int64_t)(L.nb - 1) * L.p_block_stride + L.c2_as + (t2 - WT_LINES) * 32);
+        }
+      }
+    }
+#endif
     FRESH_FWD();
 #define LIST_(T_, N_, I_) I_(lo) I_(hi) T_(float, xA)
     REC_LOADS(LIST_);
