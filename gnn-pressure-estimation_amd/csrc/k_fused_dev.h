@@ -1183,15 +1183,21 @@ __device__ __forceinline__ void seg_lin1_bwd(Rows rw, int n0, const int* __restr
 template <int NC, int THREADS>
 __device__ __forceinline__ void seg_lin0_bwd(Rows rw, int n0, const int* __restrict__ perm, const float* __restrict__ g, const float* __restrict__ x,
                                              const uint8_t* __restrict__ mask, float* __restrict__ slab_w,
-                                             float* __restrict__ slab_b, float* red, const float* g_local = nullptr) {
+                                             float* __restrict__ slab_b, float* red, const float* g_local = nullptr,
+                                             const unsigned* x_local = nullptr) {
   // g_local: the same gradient rows in LDS, indexed by LOCAL row (window kernel: the last dX stage left them there)
+  // x_local: the masked input of the rows as lin0 saw it, float bits in LDS indexed by local row (window kernel, keep-in-LDS)
   constexpr int R = THREADS / NC;
   const int c = threadIdx.x % NC, rg = threadIdx.x / NC;
   float aw = 0.f, ab = 0.f;
   for (int r = rw.lo + rg; r < rw.hi; r += R) {
     const size_t node = (size_t)n0 + r;
-    const int en = ext_id(perm, n0 + r);
-    const float xv = (mask && mask[en]) ? 0.f : x[en];
+    float xv;
+    if (x_local) xv = __uint_as_float(x_local[r]);
+    else {
+      const int en = ext_id(perm, n0 + r);
+      xv = (mask && mask[en]) ? 0.f : x[en];
+    }
     const float gv = g_local ? g_local[(size_t)r * NC + c] : g[node * NC + c];
     aw = fmaf(gv, xv, aw);
     ab += gv;

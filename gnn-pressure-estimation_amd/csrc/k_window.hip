@@ -365,6 +365,11 @@ __global__ __launch_bounds__(THREADS) void gatres_window_kernel(const FusedArgs 
         const int r = idx / (NC / 4), c0 = (idx % (NC / 4)) * 4;
         const int node = ext_id(a.perm, n0 + r);
         const float xv = (a.mask && a.mask[node]) ? 0.f : a.x[node];
+        // (keep-in-LDS launches: the masked input of the own rows rides in block 0's slot of the ReLU-mask table, which no block
+        //  uses -- lin0 backward, the launch's last step, then needs no perm -> mask -> x chain of cold global reads)
+#ifndef GATRES_NO_XKEEP
+        if (mxin && L.nb > 0 && c0 == 0) mxin[r] = __float_as_uint(xv);
+#endif
         const float4 wv = ld4(w + c0), bv = ld4(b + c0);
         float4 o;
         o.x = xv * wv.x + bv.x; o.y = xv * wv.y + bv.y; o.z = xv * wv.z + bv.z; o.w = xv * wv.w + bv.w;
@@ -1201,7 +1206,13 @@ __global__ __launch_bounds__(THREADS) void gatres_window_kernel(const FusedArgs 
     // lin0's partial sums: g_pre of the own rows from LDS when the launch keeps them there (gkeep; gpT holds them divided by
     // the in-degrees for NC == 32), else from gp_cur
     seg_lin0_bwd<NC, THREADS>(rw, n0, a.perm, gp_cur, a.x, a.mask, slab + L.p_lin0_w, slab + L.p_lin0_b, red,
-                              NC == 32 ? gkeep : gpT);
+                              NC == 32 ? gkeep : gpT,
+#ifndef GATRES_NO_XKEEP
+                              (NC == 32 && keep_ && L.nb > 0 && (ph_ & GATRES_PHASE_FORWARD)) ? mxin : nullptr
+#else
+                              nullptr
+#endif
+                              );
     if (pub && nC_ > 0) {
       group_sync<THREADS>(grp);
       publish_items<THREADS>(a, seg, part, 2 * L.nb + 1, grp.local, true);
