@@ -1,6 +1,6 @@
 # Round-6 evidence run (MI355X): everything lands under gpurun_out/r06_final/; the summaries are copied into profiles/ by
 # tests/micro/collect_r06.py (run here, after the call).
-#   /usr/local/graft/bin/gpurun --timeout 2400 -- 'bash tests/micro/profile_r06.sh'
+#   /usr/local/graft/bin/gpurun --timeout 2400 -- 'bash tests/micro/profile_r06.sh'; then HERE: python tests/micro/collect_r06.py publish gpurun_out/r06_final
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 O=gpurun_out/r06_final; mkdir -p $O
 B="python3 bench.py"
@@ -43,6 +43,7 @@ timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_eval -
 python3 tests/micro/summarize_prof.py stats $O/kt_eval $O/eval_kernel_stats.csv; rm -rf $O/kt_eval
 timeout 300 $B --no-cpu-baseline --copy-batches 2>/dev/null | tail -1 > $O/copy_batches.json
 bash tests/micro/r06_phase_ab.sh > /dev/null 2>&1; cp gpurun_out/r06_phase_ab.txt $O/phase_ab.txt; tail -7 $O/phase_ab.txt
+bash tests/micro/r06_sync_start_ab.sh > /dev/null 2>&1; cp gpurun_out/r06_sync_start_ab.txt $O/sync_start_ab.txt; tail -4 $O/sync_start_ab.txt
 timeout 300 $B --no-cpu-baseline --no-roofline --graph-steps 1 2>/dev/null | tail -1 > $O/one_step_per_graph.json; python3 -c "$short" < $O/one_step_per_graph.json
 # ---- the launcher path: 2 ranks on this one GPU (test overrides: gloo, shared device)
 GATRES_DIST_BACKEND=gloo GATRES_BENCH_SHARE_GPU=1 timeout 600 $B --gpus 2 --batch-size 8 --steps 50 --warmup 5 --no-cpu-baseline --no-roofline 2>/dev/null | tail -1 > $O/launcher_2ranks_one_gpu.json; python3 -c "$short" < $O/launcher_2ranks_one_gpu.json
